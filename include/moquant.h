@@ -1,0 +1,205 @@
+/*
+ * moquant.h -- C-ABI of libmoquant.so: the MI355X (gfx950) PTQ calibration / quantize-dequantize hot path.
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface
+ * it replaces (paths relative to the reference checkout of NVIDIA/Model-Optimizer).  Conventions, shared
+ * by all functions:
+ *
+ *   - plain pointers + sizes, no torch types.  Pointers named x / y / w / out / amax ... are DEVICE
+ *     pointers (HBM) unless the comment says "host".  The caller owns and allocates every buffer
+ *     (the reference's pybind layer allocates with empty_like -- tensor_quant.cpp:50,59; here the Python
+ *     adapter does that and hands over data_ptr()).
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  Kernels are enqueued on it and the
+ *     call returns without synchronising (reference: c10::cuda::getCurrentCUDAStream(),
+ *     tensor_quant_gpu.cu:78,90,131).
+ *   - return value: MOQ_OK (0) or a negative moq_status; moq_last_error() gives a thread-local message.
+ *     Unsupported layouts return MOQ_ERR_UNSUPPORTED so that the adapter can raise ValueError, which the
+ *     reference's callers treat as "fall back to eager" (tensor_quant.py:386-389).
+ *   - dtype codes follow moq_dtype.  All arithmetic is fp32 as in the reference kernels; results are
+ *     rounded to the storage dtype with round-to-nearest-even.
+ */
+#ifndef MOQUANT_H_
+#define MOQUANT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOQ_ABI_VERSION 1
+
+typedef enum moq_status {
+  MOQ_OK = 0,
+  MOQ_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unknown enum) */
+  MOQ_ERR_UNSUPPORTED = -2, /* valid request that this build has no kernel for          */
+  MOQ_ERR_LAUNCH = -3       /* HIP reported an error at launch                          */
+} moq_status;
+
+typedef enum moq_dtype { MOQ_F32 = 0, MOQ_F16 = 1, MOQ_BF16 = 2 } moq_dtype;
+
+/* Element/scale formats of the MX path; numbering mirrors `enum class Types`
+ * (modelopt/torch/kernels/quantization/gemm/tensor_quant_mx.h:39). */
+typedef enum moq_mx_type {
+  MOQ_E4M3 = 0, MOQ_E5M2 = 1, MOQ_INT8 = 2, MOQ_E0M3 = 3, MOQ_E1M2 = 4,
+  MOQ_E3M0 = 5, MOQ_E2M1 = 6, MOQ_E3M2 = 7, MOQ_E2M3 = 8, MOQ_E8M0 = 9
+} moq_mx_type;
+
+/* How an amax array maps onto the elements of a contiguous tensor. */
+typedef enum moq_amax_mode {
+  MOQ_AMAX_SCALAR = 0, /* amax[0] for every element                                     */
+  MOQ_AMAX_AXIS = 1    /* amax[(i / inner) % axis_size]; per-group: inner=g, axis_size=n/g */
+} moq_amax_mode;
+
+/* Rounding used by the real INT4 packer (the reference has two twins, see moq_int4_pack). */
+typedef enum moq_round { MOQ_ROUND_HALF_EVEN = 0, MOQ_ROUND_HALF_AWAY = 1 } moq_round;
+
+int moq_abi_version(void);
+const char* moq_last_error(void);
+/* Device facts used by the host for grid sizing / reporting: CU count of the current device. */
+int moq_device_cu_count(void);
+
+/* ------------------------------------------------------------------ amax (a1, a2, a3) */
+
+/* Per-tensor abs-max: out[0] = max|x| as fp32 (NaN if any element is NaN -- torch.max propagates NaN,
+ * quantization/utils/core_utils.py:172-174).  accumulate != 0 fuses MaxCalibrator's running max
+ * (calib/max.py:79-83): out[0] = max(out[0], max|x|); out must then hold a non-negative float or NaN.
+ * Replaces reduce_amax(x, axis=None) -- core_utils.py:146-183. */
+int moq_amax(const void* x, int64_t n, int dt, float* out, int accumulate, void* stream);
+
+/* Abs-max over every dimension except one.  x is viewed as contiguous [outer, axis_size, inner];
+ * out[a] = max over (o, i) of |x[o, a, i]|.  Covers per-channel weights (outer=1, axis_size=Cout,
+ * inner=Cin), per-channel activations axis=-1 (outer=tokens, axis_size=Cin, inner=1) and static
+ * per-group amax of a (-1, g) view (outer=1, axis_size=n/g, inner=g).
+ * Replaces reduce_amax(x, axis=reduce_axes) -- core_utils.py:175-182 -- and, with accumulate,
+ * MaxCalibrator.collect (calib/max.py:52-86). */
+int moq_amax_axis(const void* x, int64_t outer, int64_t axis_size, int64_t inner, int dt, float* out,
+                  int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ INT-k fake quant (a6) */
+
+/* y = clamp(rint(x * s), lo, hi) / s with s = bound / amax, bound = 2^(bits-1+unsigned) - 1,
+ * hi = bound, lo = unsigned ? 0 : -(bound + !narrow); amax <= 2^-24 gives 0.  fp32 math, IEEE division.
+ * Replaces cuda_ext.fake_tensor_quant / fake_tensor_quant_with_axis (tensor_quant.cpp:40-61,
+ * tensor_quant_gpu.cu:43-140) and eager _tensor_quant (quantization/tensor_quant.py:607-645).
+ * x == y (in place) is allowed (fake_tensor_quant_). */
+int moq_fake_quant_int(const void* x, void* y, int64_t n, int dt, const float* amax, int amax_mode,
+                       int64_t axis_size, int64_t inner, int num_bits, int is_unsigned,
+                       int narrow_range, void* stream);
+
+/* Fused dynamic per-group abs-max + INT-k QDQ over a contiguous (n_groups, g) view -- ONE read, ONE
+ * write of the tensor.  amax_out[n_groups] receives the fp32 group amax (may be NULL).
+ * This is what TensorQuantizer._get_amax + fake_tensor_quant do back to back for a static-block
+ * quantizer without an _amax buffer (nn/modules/tensor_quantizer.py:736-751, :937), i.e. the inner
+ * loop of the AWQ search, and max_calibrate + one forward for INT4 g=128 weights. */
+int moq_amax_qdq_int_group(const void* x, void* y, float* amax_out, int64_t n_groups, int g, int dt,
+                           int num_bits, int is_unsigned, int narrow_range, void* stream);
+
+/* ------------------------------------------------------------------ FP8-E4M3 fake quant (a7) */
+
+/* amax != NULL: s = 448 / (amax <= 2^-24 ? 1 : amax); y = e4m3fn_rne(clamp(x*s, +-448)) * (1/s).
+ * amax == NULL: y = e4m3fn_rne(x) (torch's non-saturating cast: |x| > 464 -> NaN).
+ * Replaces cuda_ext_fp8.fake_e4m3fy / fake_e4m3fy_with_axis (tensor_quant_gpu_fp8.cu:35-107) and
+ * eager _fp8_eager (quantization/tensor_quant.py:46-59). */
+int moq_fake_quant_e4m3(const void* x, void* y, int64_t n, int dt, const float* amax, int amax_mode,
+                        int64_t axis_size, int64_t inner, void* stream);
+
+/* ------------------------------------------------------------------ multi-tensor weight passes */
+
+/* One segment = one weight tensor living anywhere in HBM.  A table of segments (device memory) lets a
+ * single launch calibrate / QDQ a whole layer or model (launch gaps otherwise dominate 8-100 MB
+ * tensors at HBM speed).  `blk_start` (device, n_seg+1 entries) is the exclusive prefix sum of
+ * ceil(n / MOQ_MT_CHUNK) per segment, built by moq_mt_plan on the host. */
+#define MOQ_MT_CHUNK 8192 /* elements per workgroup-chunk */
+typedef struct moq_seg {
+  const void* x; /* input tensor                                    */
+  void* y;       /* QDQ output (may equal x)                        */
+  float* amax;   /* per-tensor: [1]; per-group: [n/g]               */
+  int64_t n;     /* elements                                        */
+} moq_seg;
+
+/* host helper: fills blk_start_host[n_seg+1]; returns total chunk count or negative status. */
+int64_t moq_mt_plan(const int64_t* n_host, int n_seg, int64_t* blk_start_host);
+
+/* Per-tensor abs-max of every segment: segs[s].amax[0] = max|x_s| (a1 over a tensor list;
+ * model_calib.py:187-199 weight_only_quantize loop).  Zeroes the amax slots first. */
+int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                void* stream);
+/* Per-tensor FP8-E4M3 QDQ of every segment with its own amax (a7 over a tensor list). */
+int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
+                           int dt, void* stream);
+/* Per-tensor INT-k QDQ of every segment with its own amax (a6 over a tensor list). */
+int moq_mt_fake_quant_int(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
+                          int dt, int num_bits, int is_unsigned, int narrow_range, void* stream);
+/* Fused per-group amax + INT-k QDQ of every segment (n % g == 0 per segment). */
+int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk_start, int n_seg,
+                              int64_t n_chunks, int g, int dt, int num_bits, int is_unsigned,
+                              int narrow_range, void* stream);
+
+/* ------------------------------------------------------------------ MX dynamic block QDQ (a8) */
+
+/* Per `block` consecutive elements of the last dim (cols virtually right-padded with zeros to a block
+ * multiple): block amax -> E8M0 scale 2^ceil(log2(amax/fmt_max)) -> y = sign * round_fmt(|x|*2^-e) * 2^e.
+ * Replaces cuda_ext_mx.fused_amax_convert (tensor_quant_mx.cu:239-387, tensor_quant_mx.h:39-245).
+ * Only scale_fmt == MOQ_E8M0 without global_amax is implemented; others -> MOQ_ERR_UNSUPPORTED. */
+int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols, int block, int dt,
+                              int fmt, int scale_fmt, const float* global_amax, void* stream);
+
+/* ------------------------------------------------------------------ histogram (a4) */
+
+/* counts[b] += #{ i : bin(|x_i|) == b }, bin = (int)(|x| * bins / max_edge) computed in fp32 with the
+ * last bin closed (|x| == max_edge -> bins-1); |x| > max_edge and NaN are dropped; skip_zeros drops
+ * exact zeros.  This is torch.histc(|x|.float(), bins, min=0, max=max_edge) as used by
+ * HistogramCalibrator.collect (calib/histogram.py:77-130), with exact 64-bit integer counts. */
+int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
+                 float max_edge, int skip_zeros, void* stream);
+
+/* ------------------------------------------------------------------ 2:4 mask (a14) */
+
+/* mask[r, c] in {0,1}: for every 4 consecutive elements of a row keep the 2-of-4 pattern with the
+ * largest |w| sum, first-max tie break in the reference's pattern order.  cols % 4 == 0.
+ * Replaces create_asp_mask / mn_1d_best (sparsity/weight_sparsity/magnitude.py:68-128). */
+int moq_mask_2to4(const void* w, int64_t rows, int64_t cols, int dt, uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------ real INT4 (a15) + export pack */
+
+/* q = round(x * scale[i/g]) clamped to [-8,7], byte = ((q_even+8) << 4) | (q_odd+8); arithmetic in the
+ * storage dtype like the reference (scales have dtype dt).  rounding = MOQ_ROUND_HALF_EVEN restates the
+ * eager twin (qtensor/int4_tensor.py:69-84), MOQ_ROUND_HALF_AWAY the CUDA kernel
+ * (tensor_quant_gpu.cu:310-340: clamp first, then roundf(v + 8)).  n % g == 0, g even. */
+int moq_int4_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int g, int dt,
+                  int rounding, void* stream);
+/* out[2b] = ((q[b] >> 4) - 8) / scale, out[2b+1] = ((q[b] & 15) - 8) / scale, in dtype dt.
+ * Replaces cuda_ext.INT4_dequantize (tensor_quant_gpu.cu:261-308). */
+int moq_int4_unpack(const uint8_t* q, const void* scales, void* out, int64_t n_bytes, int g, int dt,
+                    void* stream);
+/* Checkpoint packer: q = clamp(rint(w[r,c] / wsf[r, c/g]), -8, 7) (fp32 division),
+ * out[r/2, c] = (q[2*(r/2), c] & 15) | (q[2*(r/2)+1, c] << 4).  wsf is fp32 [rows, cols/g].
+ * Replaces export/quant_utils.py:792-833 pack_int4_in_uint8 (2-D case). */
+int moq_int4_pack_export(const void* w, const float* wsf, uint8_t* out, int64_t rows, int64_t cols,
+                         int g, int dt, void* stream);
+
+/* ------------------------------------------------------------------ AWQ / SmoothQuant helpers (a11, a12) */
+
+/* y[r,c] = dtype(w[r,c] * s[c]) with an fp32 multiply (s fp32) -- _apply_weight_pre_quant_scale
+ * (quantization/model_calib.py:1208-1216).  x == y allowed. */
+int moq_scale_cols(const void* w, const float* s, void* y, int64_t rows, int64_t cols, int dt,
+                   void* stream);
+/* Fused AWQ search inner op: t = dtype(w[r,c] * s[c]) (s already in dtype dt, product rounded to dt as
+ * TensorQuantizer.forward does, tensor_quantizer.py:1143-1144), then per-group (g along cols) dynamic
+ * amax + INT-k QDQ of t.  cols % g == 0.  Replaces model_calib.py:1552-1554 weight side. */
+int moq_awq_scale_qdq(const void* w, const void* s, void* y, int64_t rows, int64_t cols, int g, int dt,
+                      int num_bits, void* stream);
+/* Column abs statistics of an activation batch x[tokens, cols]: sum_out[c] (+)= sum_t |x[t,c]| (fp32,
+ * deterministic two-stage; `partial` is caller-provided fp32 workspace of moq_col_stats_workspace()
+ * floats) and, if amax_out != NULL, amax_out[c] = max(amax_out[c], max_t |x[t,c]|).
+ * Feeds get_act_scale (model_calib.py:1471-1472) and per-channel input amax (smoothquant :1309). */
+int64_t moq_col_stats_workspace(int64_t tokens, int64_t cols);
+int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, int dt, float* sum_out,
+                      float* amax_out, float* partial, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOQUANT_H_ */

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Build libmoquant.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU present.
+#   -ffp-contract=off : the reference results depend on separately rounded mul / rint / div
+#   -fhip-fp32-correctly-rounded-divide-sqrt : IEEE fp32 division (default, stated explicitly)
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=${1:-libmoquant.so}
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
+objs=()
+for src in moq_*.hip; do
+  obj="build/${src%.hip}.o"
+  mkdir -p build
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
+    echo "[moquant] hipcc $src"
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+  fi
+  objs+=("$obj")
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
+echo "[moquant] built $(pwd)/$OUT"

@@ -1,0 +1,313 @@
+// moq_common.h -- shared device/host helpers for libmoquant (gfx950 / CDNA4 only).
+//
+// Layout conventions used by every kernel in this directory:
+//   * tensors are contiguous; a lane moves 16 bytes per memory instruction (8 x bf16/f16 or 4 x f32),
+//     a wave64 therefore moves 1 KiB per instruction, fully coalesced;
+//   * all arithmetic is fp32 (as in the reference kernels), storage dtype conversion is RNE through
+//     the gfx950 hardware converters (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32);
+//   * the library is built with -ffp-contract=off: the reference's results depend on separately rounded
+//     multiply / round / divide, so no FMA contraction may happen behind our back.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/moquant.h"
+
+namespace moq {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // threads per workgroup for the streaming kernels
+constexpr float kAmaxEps = 1.0f / (1 << 24);  // "amax <= 2^-24" rule (tensor_quant.py:629, :50)
+
+// ---------------------------------------------------------------- error plumbing (host)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// grid for grid-stride streaming kernels: enough workgroups to fill 256 CUs x 8 blocks, never more than
+// the work available (cdna_hip_programming.md guideline 11).
+inline int stream_grid(int64_t work_items_per_block_iter, int64_t total_items) {
+  int64_t need = (total_items + work_items_per_block_iter - 1) / work_items_per_block_iter;
+  if (need < 1) need = 1;
+  const int64_t cap = 256 * 8;
+  return (int)(need < cap ? need : cap);
+}
+
+// ---------------------------------------------------------------- element traits
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int DT>
+struct Elem;
+template <>
+struct Elem<MOQ_F32> {
+  using storage = float;
+  static constexpr int kVec = 4;  // elements per 16-byte lane access
+};
+template <>
+struct Elem<MOQ_F16> {
+  using storage = uint16_t;
+  static constexpr int kVec = 8;
+};
+template <>
+struct Elem<MOQ_BF16> {
+  using storage = uint16_t;
+  static constexpr int kVec = 8;
+};
+
+// A 16-byte register packet.
+struct alignas(16) Pack16 {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ Pack16 load16(const void* p) {
+  return *reinterpret_cast<const Pack16*>(p);
+}
+__device__ __forceinline__ void store16(void* p, const Pack16& v) {
+  *reinterpret_cast<Pack16*>(p) = v;
+}
+// streaming (read-once / write-once) variants: non-temporal hint keeps L2/MALL for data that is reused
+__device__ __forceinline__ Pack16 load16_nt(const void* p) {
+  Pack16 r;
+  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
+  r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+  return r;
+}
+__device__ __forceinline__ void store16_nt(void* p, const Pack16& r) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v = {r.w[0], r.w[1], r.w[2], r.w[3]};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+}
+
+// unpack a 16-byte packet into kVec floats
+template <int DT>
+__device__ __forceinline__ void unpack(const Pack16& p, float* f);
+template <>
+__device__ __forceinline__ void unpack<MOQ_F32>(const Pack16& p, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(p.w[i]);
+}
+template <>
+__device__ __forceinline__ void unpack<MOQ_BF16>(const Pack16& p, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(p.w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(p.w[i] & 0xFFFF0000u);
+  }
+}
+template <>
+__device__ __forceinline__ void unpack<MOQ_F16>(const Pack16& p, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f16x2 h = *reinterpret_cast<const f16x2*>(&p.w[i]);
+    f[2 * i] = (float)h.x;
+    f[2 * i + 1] = (float)h.y;
+  }
+}
+
+// pack kVec floats (RNE) into a 16-byte packet
+template <int DT>
+__device__ __forceinline__ Pack16 pack(const float* f);
+template <>
+__device__ __forceinline__ Pack16 pack<MOQ_F32>(const float* f) {
+  Pack16 p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) p.w[i] = __float_as_uint(f[i]);
+  return p;
+}
+template <>
+__device__ __forceinline__ Pack16 pack<MOQ_BF16>(const float* f) {
+  Pack16 p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 v = {f[2 * i], f[2 * i + 1]};
+    bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    p.w[i] = *reinterpret_cast<uint32_t*>(&b);
+  }
+  return p;
+}
+template <>
+__device__ __forceinline__ Pack16 pack<MOQ_F16>(const float* f) {
+  Pack16 p;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 v = {f[2 * i], f[2 * i + 1]};
+    f16x2 h = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE)
+    p.w[i] = *reinterpret_cast<uint32_t*>(&h);
+  }
+  return p;
+}
+
+// scalar element access (tails, strided kernels)
+template <int DT>
+__device__ __forceinline__ float load1(const void* base, int64_t i);
+template <>
+__device__ __forceinline__ float load1<MOQ_F32>(const void* b, int64_t i) {
+  return reinterpret_cast<const float*>(b)[i];
+}
+template <>
+__device__ __forceinline__ float load1<MOQ_BF16>(const void* b, int64_t i) {
+  return __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(b)[i] << 16);
+}
+template <>
+__device__ __forceinline__ float load1<MOQ_F16>(const void* b, int64_t i) {
+  return (float) reinterpret_cast<const _Float16*>(b)[i];
+}
+template <int DT>
+__device__ __forceinline__ void store1(void* base, int64_t i, float v);
+template <>
+__device__ __forceinline__ void store1<MOQ_F32>(void* b, int64_t i, float v) {
+  reinterpret_cast<float*>(b)[i] = v;
+}
+template <>
+__device__ __forceinline__ void store1<MOQ_BF16>(void* b, int64_t i, float v) {
+  reinterpret_cast<__bf16*>(b)[i] = (__bf16)v;
+}
+template <>
+__device__ __forceinline__ void store1<MOQ_F16>(void* b, int64_t i, float v) {
+  reinterpret_cast<_Float16*>(b)[i] = (_Float16)v;
+}
+// round an fp32 value to the storage dtype and back (the value a store+load would produce)
+template <int DT>
+__device__ __forceinline__ float round_to_dtype(float v);
+template <>
+__device__ __forceinline__ float round_to_dtype<MOQ_F32>(float v) { return v; }
+template <>
+__device__ __forceinline__ float round_to_dtype<MOQ_BF16>(float v) { return (float)(__bf16)v; }
+template <>
+__device__ __forceinline__ float round_to_dtype<MOQ_F16>(float v) { return (float)(_Float16)v; }
+
+// ---------------------------------------------------------------- abs-max on bit patterns
+// |x| as an unsigned pattern orders exactly like the float for non-NaN values and puts every NaN above
+// +inf, so an unsigned max both reduces and propagates NaN (torch.max semantics) with integer ops only.
+__device__ __forceinline__ uint32_t absbits(float v) { return __float_as_uint(v) & 0x7FFFFFFFu; }
+
+// max of the two 16-bit abs patterns packed in a dword against a running packed max (v_pk_max_u16)
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_absmax_u16(uint32_t acc, uint32_t w) {
+  u16x2 a = *reinterpret_cast<u16x2*>(&acc);
+  uint32_t m = w & 0x7FFF7FFFu;
+  u16x2 b = *reinterpret_cast<u16x2*>(&m);
+  u16x2 r = __builtin_elementwise_max(a, b);
+  return *reinterpret_cast<uint32_t*>(&r);
+}
+// 16-bit storage abs pattern -> fp32 abs pattern (order preserving; NaN stays NaN)
+template <int DT>
+__device__ __forceinline__ uint32_t widen_abs16(uint32_t h);
+template <>
+__device__ __forceinline__ uint32_t widen_abs16<MOQ_BF16>(uint32_t h) { return h << 16; }
+template <>
+__device__ __forceinline__ uint32_t widen_abs16<MOQ_F16>(uint32_t h) {
+  uint16_t hs = (uint16_t)h;
+  return __float_as_uint((float)*reinterpret_cast<_Float16*>(&hs));
+}
+
+// abs-max pattern (fp32 pattern) of one 16-byte packet
+template <int DT>
+__device__ __forceinline__ uint32_t pack_absmax(const Pack16& p) {
+  if constexpr (DT == MOQ_F32) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t a = p.w[i] & 0x7FFFFFFFu;
+      m = a > m ? a : m;
+    }
+    return m;
+  } else {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = pk_absmax_u16(acc, p.w[i]);
+    uint32_t lo = acc & 0xFFFFu, hi = acc >> 16;
+    return widen_abs16<DT>(lo > hi ? lo : hi);
+  }
+}
+
+// ---------------------------------------------------------------- cross-lane reductions (wave64)
+// butterfly max over aligned sub-groups of `WIDTH` lanes (WIDTH power of two <= 64): every lane of the
+// group ends with the group's max.  xor-shuffles of 1/2 lower to DPP quad_perm, 4/8 to DPP row ops,
+// 16 to row_bcast/permlane, 32 to v_permlane32_swap / readlane on gfx950.
+template <int WIDTH>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 1; off < WIDTH; off <<= 1) {
+    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// workgroup max (kBlock threads): returns the result in every lane of wave 0 (valid for threadIdx.x == 0)
+__device__ __forceinline__ uint32_t block_max_u32(uint32_t v, uint32_t* smem /* kBlock/64 words */) {
+  v = group_max_u32<64>(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t t = lane < (int)(blockDim.x >> 6) ? smem[lane] : 0u;
+    v = group_max_u32<4>(t);  // kBlock = 256 -> 4 waves
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------- quantize-dequantize cores
+struct IntQ {
+  float lo, hi;  // clamp bounds as floats (integers)
+};
+__host__ __device__ __forceinline__ IntQ make_intq(int num_bits, int is_unsigned, int narrow) {
+  // bound = 2^(bits-1+unsigned) - 1 (tensor_quant_gpu.cu:38-41)
+  float bound = (float)((1 << (num_bits - 1 + (is_unsigned ? 1 : 0))) - 1);
+  IntQ q;
+  q.hi = bound;
+  // eager: unsigned -> 0, narrow -> -bound, else -bound-1 (tensor_quant.py:622-628)
+  q.lo = is_unsigned ? 0.0f : (narrow ? -bound : -bound - 1.0f);
+  return q;
+}
+// scale for INT-k: bound / amax, 0 flags "amax <= eps" (outputs are then 0, tensor_quant.py:629-642)
+__device__ __forceinline__ float int_scale(float amax, float bound) {
+  return amax <= kAmaxEps ? 0.0f : bound / amax;
+}
+__device__ __forceinline__ float qdq_int(float x, float scale, const IntQ& q) {
+  // rint(x*scale), clamp, then IEEE divide by the same scale; scale == 0 encodes the tiny-amax case where
+  // the reference multiplies by 0 and divides by 1.  torch.clamp propagates NaN while fmaxf/fminf drop
+  // it, so a NaN product (NaN input, or inf * 0) is re-injected.
+  float p = x * scale;
+  float t = __builtin_rintf(p);
+  t = __builtin_fminf(__builtin_fmaxf(t, q.lo), q.hi);
+  t = (p != p) ? p : t;
+  return scale == 0.0f ? t : t / scale;
+}
+
+// FP8-E4M3 (OCP e4m3fn) round trip through the gfx950 converters.  The input is already clamped to
+// +-448 on the amax path, so saturation behaviour of the converter is irrelevant there.
+__device__ __forceinline__ void e4m3_roundtrip2(float a, float b, float& ra, float& rb) {
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  ra = __builtin_amdgcn_cvt_f32_fp8(p, 0);
+  rb = __builtin_amdgcn_cvt_f32_fp8(p, 1);
+}
+struct Fp8Scale {
+  float s, inv;
+};
+__device__ __forceinline__ Fp8Scale fp8_scale(float amax) {
+  // scale = 448 / where(amax <= eps, 1, amax); inv = 1 / scale (tensor_quant.py:49-54).
+  // NB: in the eager reference `448.0 / tensor` is Tensor.__rtruediv__ = tensor.reciprocal() * 448.0,
+  // two roundings -- the normative arithmetic (the oracle is pinned on it), so it is restated as such.
+  float safe = amax <= kAmaxEps ? 1.0f : amax;
+  Fp8Scale r;
+  r.s = (1.0f / safe) * 448.0f;
+  r.inv = 1.0f / r.s;
+  return r;
+}
+
+}  // namespace moq
+
+// dtype dispatch for host entry points
+#define MOQ_DISPATCH_DTYPE(dt, ...)                                   \
+  switch (dt) {                                                       \
+    case MOQ_F32: { constexpr int DT = MOQ_F32; __VA_ARGS__; } break; \
+    case MOQ_F16: { constexpr int DT = MOQ_F16; __VA_ARGS__; } break; \
+    case MOQ_BF16: { constexpr int DT = MOQ_BF16; __VA_ARGS__; } break; \
+    default: moq::set_error("unknown dtype code %d", (int)(dt)); return MOQ_ERR_INVALID; \
+  }

@@ -1,0 +1,738 @@
+// moq_stream.hip -- the HBM-streaming kernels of the PTQ hot path:
+//   per-tensor abs-max, INT-k / FP8-E4M3 quantize-dequantize with scalar amax, fused per-group
+//   abs-max + INT-k QDQ, and their multi-tensor (segment table) forms.
+//
+// One skeleton serves all of them.  A *chunk* is MOQ_MT_CHUNK = 8192 consecutive elements of one tensor;
+// a 256-thread workgroup owns a chunk at a time and moves it with 16-byte lane accesses: packet u of
+// thread t covers elements (u*256 + t)*kVec ... so each wave instruction touches one contiguous KiB.
+// All loads of a chunk are issued before the first use (4 x 16 B per lane in flight for bf16, 8 for f32),
+// which with 8 resident workgroups per CU keeps ~128 KiB per CU outstanding -- well past the ~25 KiB/CU
+// that 6.3 TB/s x ~1 us of loaded HBM latency needs (MI355X_MICROARCH.md, HBM / per-instruction table).
+//
+// Roofline: every kernel here is HBM-bound.  Algorithmic bytes per element (bf16): amax 2; QDQ 4;
+// fused group amax+QDQ 4 + 4/g.  VALU cost per element (~30 lane-ops incl. the IEEE divide) stays under
+// the ~50 lane-ops/element a CU can issue at the HBM rate, so the divide is kept exact, not approximated.
+#include "moq_common.h"
+
+namespace moq {
+
+template <int DT>
+struct Chunk {
+  static constexpr int kVec = Elem<DT>::kVec;
+  static constexpr int kPackets = MOQ_MT_CHUNK / (kBlock * kVec);  // 4 (16-bit) or 8 (f32)
+  static_assert(kPackets * kBlock * kVec == MOQ_MT_CHUNK, "chunk must tile exactly");
+};
+
+// element offset (inside the chunk) of packet u of this thread
+template <int DT>
+__device__ __forceinline__ int packet_off(int u) {
+  return (u * kBlock + (int)threadIdx.x) * Elem<DT>::kVec;
+}
+
+// Guarded / unaligned packet access.  FAST = chunk fully inside the tensor and base 16-byte aligned.
+template <int DT, bool FAST>
+__device__ __forceinline__ Pack16 ld_packet(const void* base, int64_t e, int64_t n) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int ES = 16 / V;
+  if constexpr (FAST) {
+    return load16(reinterpret_cast<const char*>(base) + e * ES);
+  } else {
+    float f[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) f[i] = (e + i < n) ? load1<DT>(base, e + i) : 0.0f;
+    if constexpr (DT == MOQ_F32) {
+      return pack<DT>(f);
+    } else {
+      // keep the exact 16-bit patterns (no re-rounding): rebuild from raw storage
+      Pack16 p;
+      const uint16_t* b = reinterpret_cast<const uint16_t*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t lo = (e + 2 * i < n) ? b[e + 2 * i] : 0u;
+        uint32_t hi = (e + 2 * i + 1 < n) ? b[e + 2 * i + 1] : 0u;
+        p.w[i] = lo | (hi << 16);
+      }
+      return p;
+    }
+  }
+}
+template <int DT, bool FAST>
+__device__ __forceinline__ void st_packet(void* base, int64_t e, int64_t n, const Pack16& p) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int ES = 16 / V;
+  if constexpr (FAST) {
+    store16(reinterpret_cast<char*>(base) + e * ES, p);
+  } else {
+    if constexpr (DT == MOQ_F32) {
+      float* b = reinterpret_cast<float*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e + i < n) b[e + i] = __uint_as_float(p.w[i]);
+    } else {
+      uint16_t* b = reinterpret_cast<uint16_t*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (e + 2 * i < n) b[e + 2 * i] = (uint16_t)(p.w[i] & 0xFFFFu);
+        if (e + 2 * i + 1 < n) b[e + 2 * i + 1] = (uint16_t)(p.w[i] >> 16);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-element operators applied by the chunk loop
+// ------------------------------------------------------------------------------------------------
+struct OpIntQdq {  // a6 with one scalar amax
+  float scale;
+  IntQ q;
+  __device__ __forceinline__ void operator()(float* f, int n) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < n) f[i] = qdq_int(f[i], scale, q);
+  }
+};
+struct OpFp8Qdq {  // a7 with one scalar amax
+  Fp8Scale sc;
+  __device__ __forceinline__ void operator()(float* f, int n) const {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      if (i < n) {
+        float a = f[i] * sc.s, b = f[i + 1] * sc.s;
+        // clamp(+-448) then RNE cast; NaN survives fmin/fmax-free med3 style clamp by re-injection
+        float ca = __builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f);
+        float cb = __builtin_fminf(__builtin_fmaxf(b, -448.0f), 448.0f);
+        ca = (a != a) ? a : ca;
+        cb = (b != b) ? b : cb;
+        float ra, rb;
+        e4m3_roundtrip2(ca, cb, ra, rb);
+        f[i] = ra * sc.inv;
+        f[i + 1] = rb * sc.inv;
+      }
+    }
+  }
+};
+struct OpFp8Cast {  // a7 with amax=None: plain (non-saturating) e4m3fn cast, |x| > 464 -> NaN like torch
+  __device__ __forceinline__ void operator()(float* f, int n) const {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      if (i < n) {
+        float a = f[i], b = f[i + 1];
+        float ra, rb;
+        // 464 = midpoint between 448 and the (non-existent) next value 480: RNE ties-to-even keeps 448
+        e4m3_roundtrip2(__builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f),
+                        __builtin_fminf(__builtin_fmaxf(b, -448.0f), 448.0f), ra, rb);
+        const float nanv = __uint_as_float(0x7FC00000u);
+        f[i] = (__builtin_fabsf(a) > 464.0f || a != a) ? nanv : ra;
+        f[i + 1] = (__builtin_fabsf(b) > 464.0f || b != b) ? nanv : rb;
+      }
+    }
+  }
+};
+
+// apply an elementwise operator to one chunk of one tensor
+template <int DT, bool FAST, class Op>
+__device__ __forceinline__ void chunk_apply(const void* x, void* y, int64_t e0, int64_t n, const Op& op) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + packet_off<DT>(u), n);
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    float f[8];
+    unpack<DT>(in[u], f);
+    op(f, V);
+    st_packet<DT, FAST>(y, e0 + packet_off<DT>(u), n, pack<DT>(f));
+  }
+}
+
+// abs-max pattern of one chunk (per thread partial)
+template <int DT, bool FAST>
+__device__ __forceinline__ uint32_t chunk_absmax(const void* x, int64_t e0, int64_t n, uint32_t acc) {
+  constexpr int P = Chunk<DT>::kPackets;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + packet_off<DT>(u), n);
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    uint32_t m = pack_absmax<DT>(in[u]);
+    acc = m > acc ? m : acc;
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-tensor kernels
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(kBlock) void amax_kernel(const void* __restrict__ x, int64_t n,
+                                                      uint32_t* __restrict__ out_bits) {
+  __shared__ uint32_t smem[kBlock / 64];
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  const bool al = aligned16(x);
+  uint32_t acc = 0;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if (al && e0 + MOQ_MT_CHUNK <= n)
+      acc = chunk_absmax<DT, true>(x, e0, n, acc);
+    else
+      acc = chunk_absmax<DT, false>(x, e0, n, acc);
+  }
+  acc = block_max_u32(acc, smem);
+  if (threadIdx.x == 0) atomicMax(out_bits, acc);  // non-negative float patterns order like uints
+}
+
+template <int DT, class Op>
+__global__ __launch_bounds__(kBlock) void map_scalar_amax_kernel(const void* __restrict__ x,
+                                                                 void* __restrict__ y, int64_t n,
+                                                                 const float* __restrict__ amax,
+                                                                 int num_bits, int is_unsigned,
+                                                                 int narrow) {
+  Op op;
+  if constexpr (__is_same(Op, OpIntQdq)) {
+    op.q = make_intq(num_bits, is_unsigned, narrow);
+    op.scale = int_scale(amax[0], op.q.hi);
+  } else if constexpr (__is_same(Op, OpFp8Qdq)) {
+    op.sc = fp8_scale(amax[0]);
+  }
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  const bool al = aligned16(x) && aligned16(y);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if (al && e0 + MOQ_MT_CHUNK <= n)
+      chunk_apply<DT, true>(x, y, e0, n, op);
+    else
+      chunk_apply<DT, false>(x, y, e0, n, op);
+  }
+}
+
+// QDQ with a per-axis amax: amax index = (i / inner) % axis_size.  Generic (any inner); the per-group
+// case (inner = g) has the dedicated fused kernel below, per-channel rows (inner = Cin) take the
+// "uniform per packet" fast path when inner % kVec == 0.
+template <int DT, bool FP8>
+__global__ __launch_bounds__(kBlock) void map_axis_amax_kernel(const void* __restrict__ x,
+                                                               void* __restrict__ y, int64_t n,
+                                                               const float* __restrict__ amax,
+                                                               int64_t axis_size, int64_t inner,
+                                                               int num_bits, int is_unsigned,
+                                                               int narrow) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const IntQ q = make_intq(num_bits, is_unsigned, narrow);
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  const bool al = aligned16(x) && aligned16(y);
+  const bool uniform = (inner % V) == 0;  // a 16-byte packet never straddles two amax entries
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    const bool fast = al && e0 + MOQ_MT_CHUNK <= n;
+    Pack16 in[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      in[u] = fast ? ld_packet<DT, true>(x, e, n) : ld_packet<DT, false>(x, e, n);
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      float f[8];
+      unpack<DT>(in[u], f);
+      if (uniform) {
+        const float a = e < n ? amax[(e / inner) % axis_size] : 1.0f;
+        if constexpr (FP8) {
+          OpFp8Qdq op;
+          op.sc = fp8_scale(a);
+          op(f, V);
+        } else {
+          OpIntQdq op;
+          op.q = q;
+          op.scale = int_scale(a, q.hi);
+          op(f, V);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int64_t ei = e + i;
+          const float a = ei < n ? amax[(ei / inner) % axis_size] : 1.0f;
+          if constexpr (FP8) {
+            const Fp8Scale sc = fp8_scale(a);
+            float t = f[i] * sc.s;
+            float ct = __builtin_fminf(__builtin_fmaxf(t, -448.0f), 448.0f);
+            ct = (t != t) ? t : ct;
+            float r0, r1;
+            e4m3_roundtrip2(ct, 0.0f, r0, r1);
+            f[i] = r0 * sc.inv;
+          } else {
+            f[i] = qdq_int(f[i], int_scale(a, q.hi), q);
+          }
+        }
+      }
+      const Pack16 o = pack<DT>(f);
+      if (fast)
+        st_packet<DT, true>(y, e, n, o);
+      else
+        st_packet<DT, false>(y, e, n, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused per-group abs-max + INT-k QDQ (the headline kernel)
+// ------------------------------------------------------------------------------------------------
+// LPG = lanes per group = g / kVec (power of two, 1..64).  A group's lanes are consecutive lanes of one
+// wave for one packet index, so the group max is an LPG-wide butterfly in registers (DPP for <= 16
+// lanes); the QDQ then runs from the registers the load filled: one HBM read, one HBM write.
+// When QDQ is false only the group amax is produced (static per-group calibration).
+// pre-scale: if s != nullptr the element is first multiplied by s[col] and rounded to the storage dtype
+// (AWQ search: W * awq_scale in bf16, tensor_quantizer.py:1143-1144).
+template <int DT, int LPG, bool QDQ, bool PRESCALE>
+__device__ __forceinline__ void group_chunk(const void* __restrict__ x, void* __restrict__ y,
+                                            float* __restrict__ amax_out, int64_t e0, const IntQ q,
+                                            const void* __restrict__ s, int64_t cols) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  constexpr int G = LPG * V;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, true>(x, e0 + packet_off<DT>(u), 0);
+  Pack16 sc[P];
+  if constexpr (PRESCALE) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      sc[u] = ld_packet<DT, true>(s, e % cols, 0);  // cols % V == 0 so a packet stays inside one row
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float f[8];
+    uint32_t m;
+    if constexpr (PRESCALE) {
+      float sf[8];
+      unpack<DT>(in[u], f);
+      unpack<DT>(sc[u], sf);
+      m = 0;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        f[i] = round_to_dtype<DT>(f[i] * sf[i]);
+        const uint32_t a = absbits(f[i]);
+        m = a > m ? a : m;
+      }
+    } else {
+      m = pack_absmax<DT>(in[u]);
+      if constexpr (QDQ) unpack<DT>(in[u], f);
+    }
+    m = group_max_u32<LPG>(m);
+    const float amax = __uint_as_float(m);
+    if (amax_out != nullptr && (threadIdx.x & (LPG - 1)) == 0) amax_out[e / G] = amax;
+    if constexpr (QDQ) {
+      const float scale = int_scale(amax, q.hi);
+#pragma unroll
+      for (int i = 0; i < V; ++i) f[i] = qdq_int(f[i], scale, q);
+      st_packet<DT, true>(y, e, 0, pack<DT>(f));
+    }
+  }
+}
+
+// tail / unaligned groups: one thread per group, scalar (rare: only when n is not a chunk multiple or
+// the base pointer is not 16-byte aligned)
+template <int DT, bool QDQ, bool PRESCALE>
+__device__ __forceinline__ void group_scalar(const void* x, void* y, float* amax_out, int64_t grp,
+                                             int g, const IntQ q, const void* s, int64_t cols) {
+  const int64_t e0 = grp * (int64_t)g;
+  uint32_t m = 0;
+  for (int i = 0; i < g; ++i) {
+    float v = load1<DT>(x, e0 + i);
+    if constexpr (PRESCALE) v = round_to_dtype<DT>(v * load1<DT>(s, (e0 + i) % cols));
+    const uint32_t a = absbits(v);
+    m = a > m ? a : m;
+  }
+  const float amax = __uint_as_float(m);
+  if (amax_out != nullptr) amax_out[grp] = amax;
+  if constexpr (QDQ) {
+    const float scale = int_scale(amax, q.hi);
+    for (int i = 0; i < g; ++i) {
+      float v = load1<DT>(x, e0 + i);
+      if constexpr (PRESCALE) v = round_to_dtype<DT>(v * load1<DT>(s, (e0 + i) % cols));
+      store1<DT>(y, e0 + i, qdq_int(v, scale, q));
+    }
+  }
+}
+
+template <int DT, int LPG, bool QDQ, bool PRESCALE>
+__global__ __launch_bounds__(kBlock) void group_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                       float* __restrict__ amax_out, int64_t n_groups,
+                                                       int num_bits, int is_unsigned, int narrow,
+                                                       const void* __restrict__ s, int64_t cols) {
+  constexpr int G = LPG * Elem<DT>::kVec;
+  const IntQ q = make_intq(num_bits, is_unsigned, narrow);
+  const int64_t n = n_groups * G;
+  const bool al = aligned16(x) && (!QDQ || aligned16(y)) && (!PRESCALE || aligned16(s));
+  const int64_t full_chunks = al ? n / MOQ_MT_CHUNK : 0;
+  for (int64_t c = blockIdx.x; c < full_chunks; c += gridDim.x)
+    group_chunk<DT, LPG, QDQ, PRESCALE>(x, y, amax_out, c * MOQ_MT_CHUNK, q, s, cols);
+  // remainder groups (fewer than one chunk unless unaligned)
+  const int64_t g0 = full_chunks * (MOQ_MT_CHUNK / G);
+  for (int64_t grp = g0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; grp < n_groups;
+       grp += (int64_t)gridDim.x * kBlock)
+    group_scalar<DT, QDQ, PRESCALE>(x, y, amax_out, grp, G, q, s, cols);
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor kernels: a block owns a contiguous run of chunks of the segment table, so per-tensor
+// reductions cost ~one atomic per (block, tensor) instead of one per chunk (same-address L2 atomics
+// retire at only ~80 M/s on this chip -- MI355X_MICROARCH.md "fanin"/"dequeue" rows).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_segment(const int64_t* __restrict__ blk_start, int n_seg,
+                                            int64_t chunk) {
+  int lo = 0, hi = n_seg;  // invariant: blk_start[lo] <= chunk < blk_start[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_start[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+struct ChunkRange {
+  int64_t begin, end;
+};
+__device__ __forceinline__ ChunkRange block_range(int64_t n_chunks) {
+  const int64_t per = (n_chunks + gridDim.x - 1) / gridDim.x;
+  ChunkRange r;
+  r.begin = (int64_t)blockIdx.x * per;
+  r.end = r.begin + per < n_chunks ? r.begin + per : n_chunks;
+  return r;
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restrict__ segs,
+                                                         const int64_t* __restrict__ blk_start,
+                                                         int n_seg, int64_t n_chunks) {
+  __shared__ uint32_t smem[kBlock / 64];
+  const ChunkRange r = block_range(n_chunks);
+  if (r.begin >= r.end) return;
+  int s = find_segment(blk_start, n_seg, r.begin);
+  uint32_t acc = 0;
+  for (int64_t c = r.begin; c < r.end; ++c) {
+    if (c >= blk_start[s + 1]) {  // crossed into the next tensor: flush
+      acc = block_max_u32(acc, smem);
+      if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(segs[s].amax), acc);
+      __syncthreads();
+      acc = 0;
+      while (c >= blk_start[s + 1]) ++s;
+    }
+    const moq_seg sg = segs[s];
+    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
+    if (aligned16(sg.x) && e0 + MOQ_MT_CHUNK <= sg.n)
+      acc = chunk_absmax<DT, true>(sg.x, e0, sg.n, acc);
+    else
+      acc = chunk_absmax<DT, false>(sg.x, e0, sg.n, acc);
+  }
+  acc = block_max_u32(acc, smem);
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(segs[s].amax), acc);
+}
+
+__global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_seg) segs[i].amax[0] = 0.0f;
+}
+
+template <int DT, class Op>
+__global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restrict__ segs,
+                                                        const int64_t* __restrict__ blk_start,
+                                                        int n_seg, int64_t n_chunks, int num_bits,
+                                                        int is_unsigned, int narrow) {
+  const ChunkRange r = block_range(n_chunks);
+  if (r.begin >= r.end) return;
+  int s = find_segment(blk_start, n_seg, r.begin);
+  int cur = -1;
+  Op op;
+  for (int64_t c = r.begin; c < r.end; ++c) {
+    while (c >= blk_start[s + 1]) ++s;
+    const moq_seg sg = segs[s];
+    if (cur != s) {
+      cur = s;
+      if constexpr (__is_same(Op, OpIntQdq)) {
+        op.q = make_intq(num_bits, is_unsigned, narrow);
+        op.scale = int_scale(sg.amax[0], op.q.hi);
+      } else {
+        op.sc = fp8_scale(sg.amax[0]);
+      }
+    }
+    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
+    if (aligned16(sg.x) && aligned16(sg.y) && e0 + MOQ_MT_CHUNK <= sg.n)
+      chunk_apply<DT, true>(sg.x, sg.y, e0, sg.n, op);
+    else
+      chunk_apply<DT, false>(sg.x, sg.y, e0, sg.n, op);
+  }
+}
+
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void mt_group_kernel(const moq_seg* __restrict__ segs,
+                                                          const int64_t* __restrict__ blk_start,
+                                                          int n_seg, int64_t n_chunks, int num_bits,
+                                                          int is_unsigned, int narrow) {
+  constexpr int G = LPG * Elem<DT>::kVec;
+  const IntQ q = make_intq(num_bits, is_unsigned, narrow);
+  const ChunkRange r = block_range(n_chunks);
+  if (r.begin >= r.end) return;
+  int s = find_segment(blk_start, n_seg, r.begin);
+  for (int64_t c = r.begin; c < r.end; ++c) {
+    while (c >= blk_start[s + 1]) ++s;
+    const moq_seg sg = segs[s];
+    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
+    if (aligned16(sg.x) && aligned16(sg.y) && e0 + MOQ_MT_CHUNK <= sg.n) {
+      group_chunk<DT, LPG, true, false>(sg.x, sg.y, sg.amax, e0, q, nullptr, 0);
+    } else {
+      const int64_t g0 = e0 / G;
+      const int64_t g1 = (e0 + MOQ_MT_CHUNK < sg.n ? e0 + MOQ_MT_CHUNK : sg.n) / G;
+      for (int64_t grp = g0 + threadIdx.x; grp < g1; grp += kBlock)
+        group_scalar<DT, true, false>(sg.x, sg.y, sg.amax, grp, G, q, nullptr, 0);
+    }
+  }
+}
+
+}  // namespace moq
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+using namespace moq;
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int moq_amax(const void* x, int64_t n, int dt, float* out, int accumulate, void* stream) {
+  if (out == nullptr || n < 0 || (n > 0 && x == nullptr)) {
+    set_error("moq_amax: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float), S(stream)) != hipSuccess) return check_launch("moq_amax memset");
+  }
+  if (n == 0) return MOQ_OK;
+  const int64_t chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  // <= 512 workgroups: one same-address atomic per workgroup at the end (see mt_amax_kernel note)
+  const int grid = (int)(chunks < 512 ? chunks : 512);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                            x, n, reinterpret_cast<uint32_t*>(out)));
+  return check_launch("moq_amax");
+}
+
+template <bool FP8>
+static int launch_map(const void* x, void* y, int64_t n, int dt, const float* amax, int amax_mode,
+                      int64_t axis_size, int64_t inner, int num_bits, int is_unsigned, int narrow,
+                      void* stream, const char* who) {
+  if (n < 0 || (n > 0 && (x == nullptr || y == nullptr))) {
+    set_error("%s: null pointer or negative size", who);
+    return MOQ_ERR_INVALID;
+  }
+  if (!FP8 && (num_bits < 2 || num_bits > 16)) {
+    set_error("%s: num_bits=%d out of range [2,16]", who, num_bits);
+    return MOQ_ERR_INVALID;
+  }
+  if (n == 0) return MOQ_OK;
+  const int grid = stream_grid(MOQ_MT_CHUNK, n);
+  if (amax_mode == MOQ_AMAX_SCALAR) {
+    if (amax == nullptr) {
+      if (!FP8) {
+        set_error("%s: amax must not be NULL", who);
+        return MOQ_ERR_INVALID;
+      }
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpFp8Cast>), dim3(grid),
+                                                dim3(kBlock), 0, S(stream), x, y, n, amax, 0, 0, 0));
+    } else if (FP8) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpFp8Qdq>), dim3(grid),
+                                                dim3(kBlock), 0, S(stream), x, y, n, amax, 0, 0, 0));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpIntQdq>), dim3(grid),
+                                                dim3(kBlock), 0, S(stream), x, y, n, amax, num_bits,
+                                                is_unsigned, narrow));
+    }
+  } else if (amax_mode == MOQ_AMAX_AXIS) {
+    if (amax == nullptr || axis_size <= 0 || inner <= 0) {
+      set_error("%s: axis mode needs amax, axis_size > 0, inner > 0", who);
+      return MOQ_ERR_INVALID;
+    }
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_axis_amax_kernel<DT, FP8>), dim3(grid), dim3(kBlock),
+                                              0, S(stream), x, y, n, amax, axis_size, inner, num_bits,
+                                              is_unsigned, narrow));
+  } else {
+    set_error("%s: unknown amax_mode %d", who, amax_mode);
+    return MOQ_ERR_INVALID;
+  }
+  return check_launch(who);
+}
+
+extern "C" int moq_fake_quant_int(const void* x, void* y, int64_t n, int dt, const float* amax,
+                                  int amax_mode, int64_t axis_size, int64_t inner, int num_bits,
+                                  int is_unsigned, int narrow_range, void* stream) {
+  return launch_map<false>(x, y, n, dt, amax, amax_mode, axis_size, inner, num_bits, is_unsigned,
+                           narrow_range, stream, "moq_fake_quant_int");
+}
+
+extern "C" int moq_fake_quant_e4m3(const void* x, void* y, int64_t n, int dt, const float* amax,
+                                   int amax_mode, int64_t axis_size, int64_t inner, void* stream) {
+  return launch_map<true>(x, y, n, dt, amax, amax_mode, axis_size, inner, 8, 0, 0, stream,
+                          "moq_fake_quant_e4m3");
+}
+
+// LPG dispatch for the group kernels
+#define MOQ_DISPATCH_LPG(lpg, ...)                                   \
+  switch (lpg) {                                                     \
+    case 1: { constexpr int LPG = 1; __VA_ARGS__; } break;           \
+    case 2: { constexpr int LPG = 2; __VA_ARGS__; } break;           \
+    case 4: { constexpr int LPG = 4; __VA_ARGS__; } break;           \
+    case 8: { constexpr int LPG = 8; __VA_ARGS__; } break;           \
+    case 16: { constexpr int LPG = 16; __VA_ARGS__; } break;         \
+    case 32: { constexpr int LPG = 32; __VA_ARGS__; } break;         \
+    case 64: { constexpr int LPG = 64; __VA_ARGS__; } break;         \
+    default: set_error("group size %d not supported (g / elements-per-16B must be a power of two <= 64)", g); \
+             return MOQ_ERR_UNSUPPORTED;                             \
+  }
+
+namespace moq {
+int launch_group(const void* x, void* y, float* amax_out, int64_t n_groups, int g, int dt, int num_bits,
+                 int is_unsigned, int narrow, bool qdq, const void* s, int64_t cols, void* stream,
+                 const char* who) {
+  if (n_groups < 0 || g <= 0 || (n_groups > 0 && (x == nullptr || (qdq && y == nullptr)))) {
+    set_error("%s: null pointer or bad sizes", who);
+    return MOQ_ERR_INVALID;
+  }
+  if (qdq && (num_bits < 2 || num_bits > 16)) {
+    set_error("%s: num_bits=%d out of range [2,16]", who, num_bits);
+    return MOQ_ERR_INVALID;
+  }
+  if (n_groups == 0) return MOQ_OK;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if (g % vec != 0) {
+    set_error("%s: group size %d is not a multiple of %d", who, g, vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (s != nullptr && (cols <= 0 || cols % g != 0)) {
+    set_error("%s: cols must be a positive multiple of g", who);
+    return MOQ_ERR_INVALID;
+  }
+  const int lpg = g / vec;
+  const int grid = stream_grid(MOQ_MT_CHUNK, n_groups * (int64_t)g);
+#define MOQ_LAUNCH_GROUP(QDQ, PRE)                                                                   \
+  MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((group_kernel<DT, LPG, QDQ, PRE>),  \
+                                                                  dim3(grid), dim3(kBlock), 0,        \
+                                                                  S(stream), x, y, amax_out, n_groups, \
+                                                                  num_bits, is_unsigned, narrow, s,   \
+                                                                  cols)))
+  if (qdq && s != nullptr) { MOQ_LAUNCH_GROUP(true, true); }
+  else if (qdq) { MOQ_LAUNCH_GROUP(true, false); }
+  else { MOQ_LAUNCH_GROUP(false, false); }
+#undef MOQ_LAUNCH_GROUP
+  return check_launch(who);
+}
+}  // namespace moq
+
+extern "C" int moq_amax_qdq_int_group(const void* x, void* y, float* amax_out, int64_t n_groups, int g,
+                                      int dt, int num_bits, int is_unsigned, int narrow_range,
+                                      void* stream) {
+  return launch_group(x, y, amax_out, n_groups, g, dt, num_bits, is_unsigned, narrow_range, true,
+                      nullptr, 0, stream, "moq_amax_qdq_int_group");
+}
+
+extern "C" int moq_awq_scale_qdq(const void* w, const void* s, void* y, int64_t rows, int64_t cols,
+                                 int g, int dt, int num_bits, void* stream) {
+  if (s == nullptr) {
+    set_error("moq_awq_scale_qdq: scale vector is NULL");
+    return MOQ_ERR_INVALID;
+  }
+  if (rows < 0 || cols <= 0 || g <= 0 || cols % g != 0) {
+    set_error("moq_awq_scale_qdq: cols must be a positive multiple of g");
+    return MOQ_ERR_INVALID;
+  }
+  return launch_group(w, y, nullptr, rows * (cols / g), g, dt, num_bits, 0, 0, true, s, cols, stream,
+                      "moq_awq_scale_qdq");
+}
+
+// ---------------------------------------------------------------- multi-tensor
+extern "C" int64_t moq_mt_plan(const int64_t* n_host, int n_seg, int64_t* blk_start_host) {
+  if (n_host == nullptr || blk_start_host == nullptr || n_seg < 0) {
+    set_error("moq_mt_plan: null pointer");
+    return MOQ_ERR_INVALID;
+  }
+  int64_t acc = 0;
+  for (int i = 0; i < n_seg; ++i) {
+    if (n_host[i] < 0) {
+      set_error("moq_mt_plan: negative element count in segment %d", i);
+      return MOQ_ERR_INVALID;
+    }
+    blk_start_host[i] = acc;
+    acc += (n_host[i] + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  }
+  blk_start_host[n_seg] = acc;
+  return acc;
+}
+
+static int mt_check(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
+                    const char* who) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr))) {
+    set_error("%s: null pointer or negative size", who);
+    return MOQ_ERR_INVALID;
+  }
+  return MOQ_OK;
+}
+static int mt_grid(int64_t n_chunks) { return (int)(n_chunks < 2048 ? n_chunks : 2048); }
+
+extern "C" int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
+                           int dt, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_amax");
+  if (rc != MOQ_OK || n_seg == 0) return rc;
+  hipLaunchKernelGGL(mt_zero_amax_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, S(stream), segs, n_seg);
+  if (n_chunks > 0) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_kernel<DT>), dim3(mt_grid(n_chunks)), dim3(kBlock),
+                                              0, S(stream), segs, blk_start, n_seg, n_chunks));
+  }
+  return check_launch("moq_mt_amax");
+}
+
+extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_start, int n_seg,
+                                      int64_t n_chunks, int dt, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_e4m3");
+  if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpFp8Qdq>), dim3(mt_grid(n_chunks)),
+                                            dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
+                                            0, 0, 0));
+  return check_launch("moq_mt_fake_quant_e4m3");
+}
+
+extern "C" int moq_mt_fake_quant_int(const moq_seg* segs, const int64_t* blk_start, int n_seg,
+                                     int64_t n_chunks, int dt, int num_bits, int is_unsigned,
+                                     int narrow_range, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_int");
+  if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
+  if (num_bits < 2 || num_bits > 16) {
+    set_error("moq_mt_fake_quant_int: num_bits=%d out of range", num_bits);
+    return MOQ_ERR_INVALID;
+  }
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpIntQdq>), dim3(mt_grid(n_chunks)),
+                                            dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
+                                            num_bits, is_unsigned, narrow_range));
+  return check_launch("moq_mt_fake_quant_int");
+}
+
+extern "C" int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk_start, int n_seg,
+                                         int64_t n_chunks, int g, int dt, int num_bits, int is_unsigned,
+                                         int narrow_range, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_amax_qdq_int_group");
+  if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if (g <= 0 || g % vec != 0 || MOQ_MT_CHUNK % g != 0) {
+    set_error("moq_mt_amax_qdq_int_group: unsupported group size %d", g);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int lpg = g / vec;
+  MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((mt_group_kernel<DT, LPG>),
+                                                                  dim3(mt_grid(n_chunks)), dim3(kBlock),
+                                                                  0, S(stream), segs, blk_start, n_seg,
+                                                                  n_chunks, num_bits, is_unsigned,
+                                                                  narrow_range)));
+  return check_launch("moq_mt_amax_qdq_int_group");
+}

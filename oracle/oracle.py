@@ -1,0 +1,204 @@
+"""Python face of the CPU oracle (oracle/moq_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package.  Each function takes/returns torch CPU tensors and forwards to the C
+restatement of the reference algorithm (see the C file for reference file:line citations).
+Parity status: PINNED against reference-generated fixtures and the reference tests' golden vectors
+(tests/test_oracle_golden.py).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmoq_oracle.so")
+_lib = None
+
+DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+MX_TYPES = {"E4M3": 0, "E5M2": 1, "INT8": 2, "E0M3": 3, "E1M2": 4, "E3M0": 5, "E2M1": 6, "E3M2": 7,
+            "E2M3": 8, "E8M0": 9}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "moq_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.orc_reduce_amax.restype = ctypes.c_float
+        _lib.orc_e4m3fn_round.restype = ctypes.c_float
+        _lib.orc_e4m3fn_round.argtypes = [ctypes.c_float]
+    return _lib
+
+
+def _np(t: torch.Tensor) -> np.ndarray:
+    """Contiguous numpy view of a CPU tensor (16-bit floats as uint16 patterns)."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16)
+    return t.numpy()
+
+
+def _from_np(a: np.ndarray, dtype: torch.dtype, shape) -> torch.Tensor:
+    if dtype in (torch.bfloat16, torch.float16):
+        return torch.from_numpy(a.view(np.int16)).view(dtype).reshape(shape)
+    return torch.from_numpy(a).reshape(shape)
+
+
+def _p(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _empty_like_np(t: torch.Tensor) -> np.ndarray:
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return np.empty(t.numel(), dtype=np.uint16)
+    return np.empty(t.numel(), dtype=np.float32)
+
+
+I64 = ctypes.c_int64
+
+
+def reduce_amax(x: torch.Tensor) -> torch.Tensor:
+    a = _np(x)
+    v = lib().orc_reduce_amax(_p(a), I64(x.numel()), DT[x.dtype])
+    return torch.tensor(v, dtype=torch.float32)
+
+
+def reduce_amax_axis(x: torch.Tensor, outer: int, axis_size: int, inner: int) -> torch.Tensor:
+    a = _np(x)
+    out = np.empty(axis_size, dtype=np.float32)
+    lib().orc_reduce_amax_axis(_p(a), I64(outer), I64(axis_size), I64(inner), DT[x.dtype], _p(out))
+    return torch.from_numpy(out)
+
+
+def _amax_args(amax, mode_axis):
+    if amax is None:
+        return None, 0
+    am = np.ascontiguousarray(amax.detach().cpu().float().reshape(-1).numpy())
+    return am, (1 if mode_axis else 0)
+
+
+def fake_quant_int(x, amax, num_bits=8, unsigned=False, narrow_range=True, axis_size=1, inner=1,
+                   per_axis=False):
+    a = _np(x)
+    y = _empty_like_np(x)
+    am, mode = _amax_args(amax, per_axis)
+    lib().orc_fake_quant_int(_p(a), _p(y), I64(x.numel()), DT[x.dtype], _p(am), mode, I64(axis_size),
+                             I64(inner), int(num_bits), int(unsigned), int(narrow_range))
+    return _from_np(y, x.dtype, x.shape)
+
+
+def fake_quant_e4m3(x, amax=None, axis_size=1, inner=1, per_axis=False):
+    a = _np(x)
+    y = _empty_like_np(x)
+    am, mode = _amax_args(amax, per_axis)
+    lib().orc_fake_quant_e4m3(_p(a), _p(y), I64(x.numel()), DT[x.dtype], _p(am), mode, I64(axis_size),
+                              I64(inner))
+    return _from_np(y, x.dtype, x.shape)
+
+
+def amax_qdq_int_group(x, g, num_bits=4, unsigned=False, narrow_range=False, qdq=True):
+    assert x.numel() % g == 0
+    a = _np(x)
+    ng = x.numel() // g
+    y = _empty_like_np(x) if qdq else None
+    am = np.empty(ng, dtype=np.float32)
+    lib().orc_amax_qdq_int_group(_p(a), _p(y), _p(am), I64(ng), int(g), DT[x.dtype], int(num_bits),
+                                 int(unsigned), int(narrow_range))
+    return (_from_np(y, x.dtype, x.shape) if qdq else None), torch.from_numpy(am)
+
+
+def mx_fused_amax_convert(x, block, fmt="E2M1"):
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    a = _np(x)
+    y = _empty_like_np(x)
+    lib().orc_mx_fused_amax_convert(_p(a), _p(y), I64(rows), I64(cols), int(block), DT[x.dtype],
+                                    MX_TYPES[fmt])
+    return _from_np(y, x.dtype, x.shape)
+
+
+def hist_abs(x, bins, max_edge, skip_zeros=False, counts=None):
+    a = _np(x)
+    c = np.zeros(bins, dtype=np.uint64) if counts is None else counts
+    lib().orc_hist_abs(_p(a), I64(x.numel()), DT[x.dtype], _p(c), int(bins),
+                       ctypes.c_float(float(max_edge)), int(skip_zeros))
+    return c
+
+
+def mask_2to4(w):
+    cols = w.shape[-1]
+    rows = w.numel() // cols
+    a = _np(w)
+    m = np.empty(w.numel(), dtype=np.uint8)
+    lib().orc_mask_2to4(_p(a), I64(rows), I64(cols), DT[w.dtype], _p(m))
+    return torch.from_numpy(m).reshape(w.shape).bool()
+
+
+def int4_pack(x, scales, g, rounding=0):
+    a, s = _np(x), _np(scales)
+    out = np.empty(x.numel() // 2, dtype=np.uint8)
+    lib().orc_int4_pack(_p(a), _p(s), _p(out), I64(x.numel()), int(g), DT[x.dtype], int(rounding))
+    return torch.from_numpy(out)
+
+
+def int4_unpack(q, scales, g):
+    qa = np.ascontiguousarray(q.detach().cpu().reshape(-1).numpy())
+    s = _np(scales)
+    out = _empty_like_np(torch.empty(qa.size * 2, dtype=scales.dtype))
+    lib().orc_int4_unpack(_p(qa), _p(s), _p(out), I64(qa.size), int(g), DT[scales.dtype])
+    return _from_np(out, scales.dtype, (qa.size * 2,))
+
+
+def int4_pack_export(w, wsf):
+    rows, cols = w.shape
+    g = cols // wsf.shape[-1]
+    a = _np(w)
+    s = np.ascontiguousarray(wsf.detach().cpu().float().numpy())
+    out = np.empty(rows // 2 * cols, dtype=np.uint8)
+    lib().orc_int4_pack_export(_p(a), _p(s), _p(out), I64(rows), I64(cols), int(g), DT[w.dtype])
+    return torch.from_numpy(out).reshape(rows // 2, cols)
+
+
+def scale_cols(w, s):
+    rows, cols = w.shape
+    a = _np(w)
+    sv = np.ascontiguousarray(s.detach().cpu().float().reshape(-1).numpy())
+    y = _empty_like_np(w)
+    lib().orc_scale_cols(_p(a), _p(sv), _p(y), I64(rows), I64(cols), DT[w.dtype])
+    return _from_np(y, w.dtype, w.shape)
+
+
+def awq_scale_qdq(w, s, g, num_bits=4):
+    rows, cols = w.shape
+    a, sv = _np(w), _np(s.to(w.dtype))
+    y = _empty_like_np(w)
+    lib().orc_awq_scale_qdq(_p(a), _p(sv), _p(y), I64(rows), I64(cols), int(g), DT[w.dtype],
+                            int(num_bits))
+    return _from_np(y, w.dtype, w.shape)
+
+
+def col_abs_stats(x):
+    tokens, cols = x.shape
+    a = _np(x)
+    s = np.empty(cols, dtype=np.float64)
+    m = np.empty(cols, dtype=np.float32)
+    lib().orc_col_abs_stats(_p(a), I64(tokens), I64(cols), DT[x.dtype], _p(s), _p(m))
+    return torch.from_numpy(s), torch.from_numpy(m)
+
+
+def e4m3fn_round(v: float) -> float:
+    return float(lib().orc_e4m3fn_round(ctypes.c_float(v)))

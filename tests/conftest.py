@@ -1,0 +1,73 @@
+"""pytest configuration: the `gpu` marker, repo-root imports and golden-fixture helpers."""
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def from_bits(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+    """Inverse of gen_golden.bits(): uint16 patterns -> bf16/f16 tensors."""
+    if dtype in (torch.bfloat16, torch.float16):
+        return torch.from_numpy(a.view(np.int16).copy()).view(dtype)
+    return torch.from_numpy(a.copy())
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+        self.cases = json.loads(str(self.z["cases"]))
+
+    def t(self, key, dtype=torch.float32):
+        return from_bits(self.z[key], dtype)
+
+    def raw(self, key):
+        return self.z[key]
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+
+    return get
+
+
+def bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Bit-exact equality that treats NaN == NaN and +0 == -0 like torch.equal does not."""
+    a, b = a.detach().cpu(), b.detach().cpu()
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    both_nan = torch.isnan(a.float()) & torch.isnan(b.float())
+    return bool(((a == b) | both_nan).all())
+
+
+def assert_bits_equal(a, b, what=""):
+    a, b = a.detach().cpu(), b.detach().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert a.dtype == b.dtype, f"{what}: dtype {a.dtype} vs {b.dtype}"
+    both_nan = torch.isnan(a.float()) & torch.isnan(b.float())
+    bad = ~((a == b) | both_nan)
+    if bad.any():
+        i = bad.reshape(-1).nonzero()[0].item()
+        raise AssertionError(
+            f"{what}: {int(bad.sum())} of {a.numel()} elements differ; first at flat index {i}: "
+            f"{a.reshape(-1)[i].item()!r} vs {b.reshape(-1)[i].item()!r}")

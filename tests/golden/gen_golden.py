@@ -1,0 +1,368 @@
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE on CPU.
+
+Run in the build container only (needs /root/reference):  python tests/golden/gen_golden.py
+The GPU box has no reference checkout; tests there read the committed .npz files.
+
+What is produced (every array is the reference's own output on seeded inputs that are stored next to it):
+  int_fq.npz    -- _tensor_quant / fake_tensor_quant (quantization/tensor_quant.py:607-645)
+  fp8_fq.npz    -- _fp8_eager (quantization/tensor_quant.py:46-59)
+  amax.npz      -- reduce_amax (quantization/utils/core_utils.py:146-183)
+  tq_block.npz  -- TensorQuantizer static-block INT4 forward incl. padding
+                   (nn/modules/tensor_quantizer.py:975-1061, :1119-1221) and MaxCalibrator
+  hist.npz      -- HistogramCalibrator.collect with bin growth (calib/histogram.py:77-130)
+  mask24.npz    -- create_asp_mask (sparsity/weight_sparsity/magnitude.py:91-128) + pattern order
+  int4.npz      -- INT4QTensor.quantize/dequantize eager twin (qtensor/int4_tensor.py:39-130) and
+                   pack_int4_in_uint8 (export/quant_utils.py:792-833)
+  awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
+  mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
+                   test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
+                   the MX kernels have no CPU implementation in the reference)
+"""
+
+import ast
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+
+from modelopt.torch.quantization import tensor_quant as tq  # noqa: E402
+from modelopt.torch.quantization import utils as quant_utils  # noqa: E402
+from modelopt.torch.quantization.calib import HistogramCalibrator, MaxCalibrator  # noqa: E402
+from modelopt.torch.quantization.config import QuantizerAttributeConfig  # noqa: E402
+from modelopt.torch.quantization.nn import TensorQuantizer  # noqa: E402
+from modelopt.torch.quantization.qtensor import INT4QTensor  # noqa: E402
+from modelopt.torch.sparsity.weight_sparsity import magnitude  # noqa: E402
+from modelopt.torch.export.quant_utils import pack_int4_in_uint8  # noqa: E402
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """Store tensors losslessly: 16-bit floats as uint16 patterns, the rest as-is."""
+    t = t.detach().cpu().contiguous()
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.view(torch.int16).numpy().view(np.uint16).copy()
+    return t.numpy().copy()
+
+
+def weight_like(shape, dtype, seed, outliers=True):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(*shape, generator=g) * 0.02
+    if outliers:
+        m = torch.rand(*shape, generator=g) < 0.001
+        w = torch.where(m, w * 8, w)
+    return w.to(dtype)
+
+
+def gen_int_fq(out):
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        for bits_, unsigned, narrow in [(8, False, True), (8, False, False), (4, False, False),
+                                        (3, False, True), (8, True, False), (5, False, False)]:
+            x = weight_like((24, 128), dt, 100 + idx)
+            if unsigned:
+                x = x.abs()
+            # scalar amax
+            amax = x.abs().amax().float()
+            y = tq._tensor_quant(x, amax, bits_, unsigned, narrow)
+            cases[f"c{idx}"] = dict(dtype=dn, bits=bits_, unsigned=unsigned, narrow=narrow, mode="scalar")
+            out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(x), bits(amax.reshape(1)), bits(y)
+            idx += 1
+            # per-channel amax (axis 0)
+            amax = x.abs().amax(dim=1, keepdim=True).float()
+            y = tq._tensor_quant(x, amax, bits_, unsigned, narrow)
+            cases[f"c{idx}"] = dict(dtype=dn, bits=bits_, unsigned=unsigned, narrow=narrow, mode="axis0")
+            out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(x), bits(amax), bits(y)
+            idx += 1
+            # per-group (g=32) amax via the (-1, g) view
+            xg = x.reshape(-1, 32)
+            amax = xg.abs().amax(dim=1, keepdim=True).float()
+            y = tq._tensor_quant(xg, amax, bits_, unsigned, narrow).reshape(x.shape)
+            cases[f"c{idx}"] = dict(dtype=dn, bits=bits_, unsigned=unsigned, narrow=narrow, mode="group32")
+            out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(x), bits(amax), bits(y)
+            idx += 1
+    # tiny / zero amax rows (tests/gpu/torch/quantization/test_tensor_quant_cuda.py:115-119)
+    x = weight_like((4, 64), torch.float32, 7)
+    amax = torch.tensor([[0.0], [2.0 ** -24], [2.0 ** -23], [1.0]])
+    y = tq._tensor_quant(x, amax, 8, False, True)
+    cases[f"c{idx}"] = dict(dtype="f32", bits=8, unsigned=False, narrow=True, mode="axis0")
+    out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(x), bits(amax), bits(y)
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_fp8(out):
+    cases = {}
+    idx = 0
+    special = torch.tensor([0.0, -0.0, 1e-4, 0.0019, 0.00195, 2.0 ** -9, 2.0 ** -10, 3 * 2.0 ** -10, 0.0156,
+                            1.0, 1.0625, 1.125, 1.1875, 240.0, 447.0, 448.0, 449.0, 463.9, 464.0, 464.1,
+                            479.0, 480.0, 1e6, -1e6, float("inf"), float("-inf"), float("nan"), -449.0,
+                            -464.0, -465.0, 17.0, 18.0, 19.0, 20.0, 21.0, 22.0, 23.0, 25.0, 27.0, 0.3])
+    for dn, dt in DT.items():
+        x = torch.cat([special.to(dt).float(), (weight_like((32, 128), dt, 200 + idx).float() * 40).reshape(-1)])
+        x = x[: x.numel() // 8 * 8].reshape(-1, 8).to(dt)
+        # amax=None: plain cast
+        y = tq._fp8_eager(x, None)
+        cases[f"c{idx}"] = dict(dtype=dn, mode="none")
+        out[f"c{idx}_x"], out[f"c{idx}_y"] = bits(x), bits(y)
+        idx += 1
+        for amax_v in [x[torch.isfinite(x)].abs().max().float(), torch.tensor(3.0), torch.tensor(0.0),
+                       torch.tensor(2.0 ** -24), torch.tensor(1e-3)]:
+            y = tq._fp8_eager(x, amax_v)
+            cases[f"c{idx}"] = dict(dtype=dn, mode="scalar")
+            out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(x), bits(amax_v.reshape(1)), bits(y)
+            idx += 1
+        xw = weight_like((48, 128), dt, 300 + idx)
+        amax = xw.abs().amax(dim=1, keepdim=True).float()
+        y = tq._fp8_eager(xw, amax)
+        cases[f"c{idx}"] = dict(dtype=dn, mode="axis0")
+        out[f"c{idx}_x"], out[f"c{idx}_amax"], out[f"c{idx}_y"] = bits(xw), bits(amax), bits(y)
+        idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_amax(out):
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        x = weight_like((6, 40, 24), dt, 400 + idx)
+        for axis in [None, 0, 1, 2, -1, (0, 2)]:
+            red = quant_utils.convert_quantization_axis_to_reduce_axis(x, axis)
+            a = quant_utils.reduce_amax(x, axis=red)
+            cases[f"c{idx}"] = dict(dtype=dn, axis=axis if not isinstance(axis, tuple) else list(axis),
+                                    out_dtype=str(a.dtype), out_shape=list(a.shape))
+            out[f"c{idx}_x"], out[f"c{idx}_a"] = bits(x), bits(a.float())
+            idx += 1
+    # NaN / inf propagation
+    x = torch.tensor([[1.0, float("nan"), -3.0], [2.0, float("-inf"), 0.5]])
+    for axis in [None, 0]:
+        red = quant_utils.convert_quantization_axis_to_reduce_axis(x, axis)
+        a = quant_utils.reduce_amax(x, axis=red)
+        cases[f"c{idx}"] = dict(dtype="f32", axis=axis, out_dtype=str(a.dtype), out_shape=list(a.shape))
+        out[f"c{idx}_x"], out[f"c{idx}_a"] = bits(x), bits(a.float())
+        idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_tq_block(out):
+    """TensorQuantizer(INT4, block {-1: g}) standalone: dynamic amax + QDQ, with and without padding,
+    then MaxCalibrator static path."""
+    cases = {}
+    idx = 0
+    for dn, dt in [("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)]:
+        for shape, g in [((32, 256), 128), ((16, 200), 128), ((8, 96), 32), ((4, 3, 64), 16)]:
+            w = weight_like(shape, dt, 500 + idx)
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: g}))
+            y = q(w)  # no _amax buffer -> dynamic per-block amax
+            cases[f"c{idx}"] = dict(dtype=dn, g=g, kind="dynamic")
+            out[f"c{idx}_x"], out[f"c{idx}_y"] = bits(w), bits(y)
+            idx += 1
+            # static: calibrate then quantize
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: g}))
+            q.disable_quant(); q.enable_calib()
+            q(w)
+            q.load_calib_amax(); q.enable_quant(); q.disable_calib()
+            y = q(w)
+            cases[f"c{idx}"] = dict(dtype=dn, g=g, kind="static", amax_dtype=str(q._amax.dtype),
+                                    amax_shape=list(q._amax.shape))
+            out[f"c{idx}_x"], out[f"c{idx}_y"], out[f"c{idx}_amax"] = bits(w), bits(y), bits(q._amax.float())
+            idx += 1
+    # MaxCalibrator running max over batches, per-tensor and per-channel(axis=-1 -> reduce others)
+    g_ = torch.Generator().manual_seed(9)
+    batches = [torch.randn(4, 16, 64, generator=g_).to(torch.bfloat16) * (i + 1) for i in range(3)]
+    for axis in [None, -1]:
+        cal = MaxCalibrator(8, axis, False)
+        for b in batches:
+            cal.collect(b)
+        a = cal.compute_amax()
+        cases[f"c{idx}"] = dict(kind="maxcal", axis=axis, out_dtype=str(a.dtype), out_shape=list(a.shape))
+        for k, b in enumerate(batches):
+            out[f"c{idx}_b{k}"] = bits(b)
+        out[f"c{idx}_a"] = bits(a.float())
+        idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_hist(out):
+    cases = {}
+    idx = 0
+    for dn, dt in [("bf16", torch.bfloat16), ("f32", torch.float32), ("f16", torch.float16)]:
+        for skip_zeros in [False, True]:
+            g_ = torch.Generator().manual_seed(600 + idx)
+            b0 = (torch.randn(64, 257, generator=g_)).to(dt)
+            b1 = (torch.randn(64, 257, generator=g_) * 1.7).to(dt)   # larger max -> bins grow
+            b2 = (torch.randn(64, 257, generator=g_) * 0.5).to(dt)   # smaller max -> same edges
+            b0.view(-1)[::37] = 0
+            cal = HistogramCalibrator(8, None, False, num_bins=256, skip_zeros=skip_zeros)
+            snaps = []
+            for b in (b0, b1, b2):
+                cal.collect(b)
+                snaps.append((cal._calib_hist.clone(), cal._calib_bin_edges.clone()))
+            cases[f"c{idx}"] = dict(dtype=dn, skip_zeros=skip_zeros, num_bins=256)
+            for k, b in enumerate((b0, b1, b2)):
+                out[f"c{idx}_b{k}"] = bits(b)
+                out[f"c{idx}_h{k}"] = bits(snaps[k][0])
+                out[f"c{idx}_e{k}"] = bits(snaps[k][1])
+            idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_mask(out):
+    cases = {}
+    idx = 0
+    pats = magnitude.compute_valid_1d_patterns(4, 2)
+    out["patterns"] = bits(pats)
+    for dn, dt in DT.items():
+        w = weight_like((64, 128), dt, 700 + idx)
+        # force ties: coarse values, zeros, equal groups
+        w2 = (torch.randint(-3, 4, (32, 64), generator=torch.Generator().manual_seed(701 + idx)).float()).to(dt)
+        w2[0, :8] = 0
+        w2[1, :8] = 1.5
+        for name, t in (("rand", w), ("ties", w2)):
+            m = magnitude.create_asp_mask(t, "2:4 sparsity")
+            cases[f"c{idx}"] = dict(dtype=dn, kind=name)
+            out[f"c{idx}_w"], out[f"c{idx}_m"] = bits(t), m.numpy().astype(np.uint8)
+            idx += 1
+    # special values
+    t = torch.tensor([[3.0, -3.0, 1.0, 3.0], [float("inf"), 1.0, 2.0, 3.0], [float("nan"), 5.0, 1.0, 2.0],
+                      [0.0, 0.0, 0.0, 0.0]] * 2).reshape(8, 4).repeat(1, 4)
+    m = magnitude.create_asp_mask(t, "2:4 sparsity")
+    cases[f"c{idx}"] = dict(dtype="f32", kind="special")
+    out[f"c{idx}_w"], out[f"c{idx}_m"] = bits(t), m.numpy().astype(np.uint8)
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_int4(out):
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        for shape, g in [((16, 256), 128), ((8, 64), 32)]:
+            w = weight_like(shape, dt, 800 + idx)
+            qt, scales = INT4QTensor.quantize(w, g)
+            deq = qt.dequantize(scale=scales, block_sizes={-1: g})
+            cases[f"c{idx}"] = dict(dtype=dn, g=g, kind="qtensor")
+            out[f"c{idx}_w"], out[f"c{idx}_q"] = bits(w), qt._quantized_data.numpy()
+            out[f"c{idx}_s"], out[f"c{idx}_d"] = bits(scales), bits(deq)
+            idx += 1
+            # export packer: weights_scaling_factor = amax/7 fp32 [rows, cols/g]
+            wsf = (w.reshape(shape[0], -1, g).abs().amax(-1).float() / 7.0)
+            packed = pack_int4_in_uint8(w, wsf)
+            cases[f"c{idx}"] = dict(dtype=dn, g=g, kind="export")
+            out[f"c{idx}_w"], out[f"c{idx}_wsf"], out[f"c{idx}_p"] = bits(w), bits(wsf), packed.numpy()
+            idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_awq(out):
+    """AWQ-lite building blocks, restated inline from model_calib.py:1453-1495 by CALLING the same torch
+    ops the reference calls (the helpers are closures inside awq_lite and cannot be imported)."""
+    import torch.nn.functional as F  # noqa: F401
+
+    cases = {}
+    idx = 0
+    for dn, dt in [("bf16", torch.bfloat16), ("f16", torch.float16)]:
+        w = weight_like((64, 256), dt, 900 + idx)
+        g_ = torch.Generator().manual_seed(901 + idx)
+        x = (torch.randn(96, 256, generator=g_) * torch.exp(torch.randn(256, generator=g_))).to(dt)
+        g = 128
+        # get_weight_scale (model_calib.py:1453-1469)
+        wv = w.contiguous().view(-1, g)
+        wa = wv.abs()
+        scale = wa / (wa.amax(dim=1, keepdim=True) + torch.finfo(w.dtype).tiny)
+        w_scale = scale.view(w.shape).mean(0).to(torch.float32)
+        # get_act_scale (model_calib.py:1471-1472)
+        x_scale = x.abs().contiguous().view(-1, x.shape[-1]).mean(0).to(torch.float32)
+        out[f"c{idx}_w"], out[f"c{idx}_x"] = bits(w), bits(x)
+        out[f"c{idx}_wscale"], out[f"c{idx}_xscale"] = bits(w_scale), bits(x_scale)
+        alphas = [0.0, 0.3, 0.5, 1.0]
+        for k, alpha in enumerate(alphas):
+            # get_scale (model_calib.py:1474-1487)
+            s = (x_scale.pow(alpha) / (w_scale.pow(1 - alpha) + torch.finfo(torch.float32).tiny)).clamp(
+                min=1e-4, max=1e4).view(-1)
+            s = (s / (s.max() * s.min()).sqrt()).view(-1)
+            # search forward weight side (model_calib.py:1552-1554): weight_quantizer with pre_quant_scale
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: g}))
+            q.pre_quant_scale = s.to(w.dtype)
+            wq = q(w)
+            out[f"c{idx}_s{k}"], out[f"c{idx}_wq{k}"] = bits(s), bits(wq)
+            # postprocess weight fold (model_calib.py:1208-1216): fp32 multiply then cast
+            folded = (w * s.squeeze()[None, :]).to(w.dtype)
+            out[f"c{idx}_fold{k}"] = bits(folded)
+        cases[f"c{idx}"] = dict(dtype=dn, g=g, alphas=alphas)
+        idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def extract_mx_vectors():
+    """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
+    path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
+    tree = ast.parse(open(path).read())
+    fmt_names = {"8": "INT8", "(2, 1)": "E2M1", "(3, 2)": "E3M2", "(2, 3)": "E2M3", "(4, 3)": "E4M3",
+                 "(5, 2)": "E5M2"}
+    cases = []
+    for fn in tree.body:
+        if not isinstance(fn, ast.FunctionDef) or fn.name not in ("test_mxfp4", "test_mxfp6", "test_mxfp8",
+                                                                 "test_mxint8"):
+            continue
+        state = {"block_size": None, "in_size": None, "test_in": None, "test_out": None, "dtype": None}
+        pending = None
+        for node in fn.body:
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name):
+                name = node.targets[0].id
+                if name in ("test_in", "test_out"):
+                    state[name] = ast.literal_eval(node.value.args[0])
+                elif name == "block_size":
+                    state["block_size"] = ast.literal_eval(node.value)
+                elif name == "dtype":
+                    state["dtype"] = ast.unparse(node.value)
+                elif name == "outputs":
+                    key = None
+                    for sub in ast.walk(node.value):
+                        if isinstance(sub, ast.Subscript) and getattr(sub.value, "id", "") == "mx_format_map":
+                            key = ast.unparse(sub.slice)
+                            break
+                    pending = dict(fn=fn.name, fmt=fmt_names[key], block_size=state["block_size"],
+                                   in_size=state["in_size"], test_in=state["test_in"],
+                                   test_out=state["test_out"], dtype=state["dtype"])
+                elif isinstance(node.targets[0], ast.Name) and name == "sign":
+                    pass
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Tuple):
+                # inputs, expected_outputs = _get_test_inputs_outputs(..., block_size, IN_SIZE)
+                state["in_size"] = ast.literal_eval(node.value.args[3])
+            if isinstance(node, ast.Assert) and pending is not None:
+                atol = 1e-8
+                for kw in node.test.keywords:
+                    if kw.arg == "atol":
+                        atol = ast.literal_eval(kw.value)
+                pending["atol"] = atol
+                cases.append(pending)
+                pending = None
+    return cases
+
+
+def main():
+    torch.manual_seed(1234)
+    for name, fn in [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
+                     ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
+                     ("int4", gen_int4), ("awq", gen_awq)]:
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+    mx = extract_mx_vectors()
+    with open(os.path.join(HERE, "mx_vectors.json"), "w") as f:
+        json.dump(mx, f)
+    print(f"mx_vectors: {len(mx)} cases")
+
+
+if __name__ == "__main__":
+    main()

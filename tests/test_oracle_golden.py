@@ -1,0 +1,210 @@
+"""Pin the CPU oracle (oracle/moq_oracle.c) to the reference.
+
+Every case compares the C restatement with outputs the reference itself produced on CPU in the build
+container (tests/golden/*.npz, generator: tests/golden/gen_golden.py) or with the literal golden vectors of
+the reference's own MX tests (tests/golden/mx_vectors.json).  Integer / index results must be bit-exact.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import DT, GOLDEN, assert_bits_equal, from_bits
+from oracle import oracle
+
+
+def test_int_fake_quant_matches_reference(golden):
+    g = golden("int_fq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        amax = g.t(f"{k}_amax")
+        if c["mode"] == "scalar":
+            got = oracle.fake_quant_int(x, amax, c["bits"], c["unsigned"], c["narrow"])
+        elif c["mode"] == "axis0":
+            got = oracle.fake_quant_int(x, amax, c["bits"], c["unsigned"], c["narrow"],
+                                        axis_size=x.shape[0], inner=x.shape[1], per_axis=True)
+        else:
+            got = oracle.fake_quant_int(x, amax, c["bits"], c["unsigned"], c["narrow"],
+                                        axis_size=x.numel() // 32, inner=32, per_axis=True)
+        assert_bits_equal(got, y, f"int_fq {k} {c}")
+
+
+def test_fp8_fake_quant_matches_reference(golden):
+    g = golden("fp8_fq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        if c["mode"] == "none":
+            got = oracle.fake_quant_e4m3(x, None)
+        elif c["mode"] == "scalar":
+            got = oracle.fake_quant_e4m3(x, g.t(f"{k}_amax"))
+        else:
+            got = oracle.fake_quant_e4m3(x, g.t(f"{k}_amax"), axis_size=x.shape[0], inner=x.shape[1],
+                                         per_axis=True)
+        assert_bits_equal(got, y, f"fp8_fq {k} {c}")
+
+
+def _view3(shape, axis):
+    """[outer, axis, inner] factorisation of keeping one axis of a contiguous tensor."""
+    axis = axis % len(shape)
+    outer = int(np.prod(shape[:axis])) if axis > 0 else 1
+    inner = int(np.prod(shape[axis + 1:])) if axis + 1 < len(shape) else 1
+    return outer, shape[axis], inner
+
+
+def test_reduce_amax_matches_reference(golden):
+    g = golden("amax")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, want = g.t(f"{k}_x", dt), g.t(f"{k}_a")
+        axis = c["axis"]
+        if axis is None:
+            got = oracle.reduce_amax(x).reshape(want.shape)
+        elif isinstance(axis, int):
+            o, a, i = _view3(list(x.shape), axis)
+            got = oracle.reduce_amax_axis(x, o, a, i).reshape(want.shape)
+        else:
+            continue  # multi-axis keep: composed by the adapter, covered in the adapter tests
+        assert_bits_equal(got, want, f"amax {k} {c}")
+        # the reference returns the input dtype; fp32 -> dtype must be lossless
+        assert torch.equal(got.to(dt).float()[~torch.isnan(got)], got[~torch.isnan(got)])
+
+
+def test_block_quantizer_matches_reference(golden):
+    """TensorQuantizer INT4 block {-1: g}: right-pad last dim, (-1, g) view, amax, QDQ, slice back."""
+    g = golden("tq_block")
+    for k, c in g.cases.items():
+        if c.get("kind") not in ("dynamic", "static"):
+            continue
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        gs = c["g"]
+        cols = x.shape[-1]
+        pad = (-cols) % gs
+        xp = torch.nn.functional.pad(x, (0, pad)) if pad else x
+        yq, am = oracle.amax_qdq_int_group(xp, gs, num_bits=4, narrow_range=False)
+        got = yq[..., :cols]
+        assert_bits_equal(got.contiguous(), y, f"tq_block {k} {c}")
+        if c["kind"] == "static":
+            assert_bits_equal(am.reshape(-1), g.t(f"{k}_amax").reshape(-1), f"tq_block amax {k}")
+
+
+def test_max_calibrator_running_max(golden):
+    g = golden("tq_block")
+    for k, c in g.cases.items():
+        if c.get("kind") != "maxcal":
+            continue
+        want = g.t(f"{k}_a")
+        acc = None
+        for b in range(3):
+            x = g.t(f"{k}_b{b}", torch.bfloat16)
+            if c["axis"] is None:
+                a = oracle.reduce_amax(x)
+            else:
+                a = oracle.reduce_amax_axis(x, x.numel() // x.shape[-1], x.shape[-1], 1)
+            acc = a if acc is None else torch.maximum(acc, a)
+        assert_bits_equal(acc.reshape(want.shape), want, f"maxcal {k}")
+
+
+def test_histogram_collect_matches_reference(golden):
+    g = golden("hist")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        hist = None
+        width = None
+        nbins = c["num_bins"]
+        for b in range(3):
+            x = g.t(f"{k}_b{b}", dt)
+            want_h, want_e = g.t(f"{k}_h{b}"), g.t(f"{k}_e{b}")
+            xf = x.float().abs()
+            if c["skip_zeros"]:
+                xf = xf[xf != 0]
+            x_max = xf.max()
+            if hist is None:
+                edge = float(x_max)
+                counts = oracle.hist_abs(x, nbins, edge, c["skip_zeros"])
+                hist = counts.astype(np.float32)
+                edges = torch.linspace(0, x_max, nbins + 1)
+            else:
+                # growth rule of calib/histogram.py:121-127, host side (tiny tensors)
+                if x_max > edges[-1]:
+                    width = edges[1] - edges[0]
+                    nbins = int((x_max / width).ceil().item())
+                    edges = torch.arange(0, x_max + width, width)
+                counts = oracle.hist_abs(x, nbins, float(edges[-1]), c["skip_zeros"])
+                new = counts.astype(np.float32)
+                new[: hist.size] += hist
+                hist = new
+            assert torch.equal(torch.from_numpy(hist), want_h), f"hist {k} batch {b}"
+            assert torch.equal(edges, want_e), f"edges {k} batch {b}"
+
+
+def test_mask_2to4_matches_reference(golden):
+    g = golden("mask24")
+    pats = g.t("patterns")
+    assert pats.tolist() == [[0, 1, 0, 1], [1, 1, 0, 0], [0, 1, 1, 0], [1, 0, 1, 0], [1, 0, 0, 1],
+                             [0, 0, 1, 1]], "reference pattern order changed"
+    for k, c in g.cases.items():
+        w = g.t(f"{k}_w", DT[c["dtype"]])
+        want = torch.from_numpy(g.raw(f"{k}_m")).bool()
+        got = oracle.mask_2to4(w)
+        assert torch.equal(got, want), f"mask {k} {c}: {(got != want).sum().item()} differ"
+
+
+def test_int4_qtensor_and_export_pack(golden):
+    g = golden("int4")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        w = g.t(f"{k}_w", dt)
+        if c["kind"] == "qtensor":
+            s = g.t(f"{k}_s", dt)
+            q = torch.from_numpy(g.raw(f"{k}_q"))
+            got = oracle.int4_pack(w.reshape(-1), s.reshape(-1), c["g"], rounding=0)
+            assert torch.equal(got, q.reshape(-1)), f"int4 pack {k}"
+            deq = oracle.int4_unpack(q.reshape(-1), s.reshape(-1), c["g"])
+            assert_bits_equal(deq.reshape(w.shape), g.t(f"{k}_d", dt), f"int4 unpack {k}")
+        else:
+            wsf = g.t(f"{k}_wsf")
+            got = oracle.int4_pack_export(w, wsf)
+            assert torch.equal(got, torch.from_numpy(g.raw(f"{k}_p"))), f"export pack {k}"
+
+
+def test_awq_building_blocks(golden):
+    g = golden("awq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        w, x = g.t(f"{k}_w", dt), g.t(f"{k}_x", dt)
+        # act scale: the reference averages |x| in the storage dtype (fp32 accumulate, one rounding)
+        s64, _ = oracle.col_abs_stats(x)
+        mean = (s64 / x.shape[0]).to(torch.float32).to(dt).float()
+        want = g.t(f"{k}_xscale")
+        ulp = (want.abs() * 2.0 ** -7).clamp_min(1e-30)
+        assert ((mean - want).abs() <= ulp).all(), f"act scale {k}"
+        for j, _ in enumerate(c["alphas"]):
+            s = g.t(f"{k}_s{j}")
+            got = oracle.awq_scale_qdq(w, s.to(dt), c["g"], 4)
+            assert_bits_equal(got, g.t(f"{k}_wq{j}", dt), f"awq scale+qdq {k} alpha#{j}")
+            fold = oracle.scale_cols(w, s)
+            assert_bits_equal(fold, g.t(f"{k}_fold{j}", dt), f"weight fold {k} alpha#{j}")
+
+
+def test_mx_golden_vectors():
+    """Literal vectors of the reference's tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py."""
+    cases = json.load(open(os.path.join(GOLDEN, "mx_vectors.json")))
+    assert len(cases) == 6
+    for c in cases:
+        blocks = [c["block_size"]] if c["block_size"] else [8, 16, 32]
+        dtypes = [torch.float32] if c["dtype"] else [torch.float32, torch.float16, torch.bfloat16]
+        for bs in blocks:
+            for dt in dtypes:
+                rep = max(bs // c["in_size"], 1)
+                tin = torch.tensor(c["test_in"], dtype=dt).repeat(1, rep)
+                tout = torch.tensor(c["test_out"], dtype=dt).repeat(1, rep)
+                for sign in (1.0, -1.0):
+                    got = oracle.mx_fused_amax_convert(tin * sign, bs, c["fmt"])
+                    assert torch.allclose(got.float(), (tout * sign).float(), rtol=1e-5, atol=c["atol"]), \
+                        f"{c['fn']} {c['fmt']} bs={bs} {dt}"
