@@ -1,0 +1,277 @@
+"""bench.py -- GB/s of weights calibrated + quantize-dequantized on MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path over ALL linear weights of a synthetic Llama-3-8B (224 tensors,
+6.98 G elements, 13.96 GB bf16), already resident in HBM:
+    fp8      (default, BASELINE configs[1]): per-tensor abs-max of every weight (one multi-tensor launch),
+             [N>1: ONE bucketed RCCL all-reduce(MAX) of the 224 amax values -- the reference's
+             sync_amax_across_distributed_group, model_calib.py:390-407], per-tensor FP8-E4M3 QDQ of every
+             weight (one multi-tensor launch).      algorithmic HBM bytes: 2 + 4 = 6 B/element
+    int4g128 (BASELINE configs[2] weight side / north-star kernel): fused per-group(128) abs-max + INT4 QDQ,
+             one launch, 4 + 4/128 B/element.
+    mxfp4, mask24, int8 : the other formats of the path, for the record.
+`value` = weight bytes (2 B/element, all ranks) / wall time per step.  Multi-GPU is weak scaling: every rank
+owns one full set of per-layer weight tensors (per-layer tensors shard across GPUs; nothing but the tiny
+amax bucket crosses xGMI).
+
+Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import _moa_import  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+MODELS = {
+    # (hidden, intermediate, layers, kv_dim)
+    "llama3-8b": (4096, 14336, 32, 1024),
+    "llama3-70b": (8192, 28672, 80, 1024),
+}
+
+
+def layer_shapes(model):
+    h, i, _, kv = MODELS[model]
+    return [(h, h), (kv, h), (kv, h), (h, h), (i, h), (i, h), (h, i)]  # q k v o gate up down
+
+
+def make_weights(model, n_layers, device, seed=1234):
+    """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ws = []
+    for _ in range(n_layers):
+        for shape in layer_shapes(model):
+            w = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
+            m = torch.rand(shape, generator=g, device=device) < 0.001
+            ws.append(torch.where(m, w * 8, w).to(torch.bfloat16))
+            del w, m
+    return ws
+
+
+def cpu_baseline(workload, budget_s=12.0):
+    """Time the CPU oracle (a C restatement of the reference's eager path, OpenMP on all host cores) on a
+    bounded sample: repeated 4096x4096 bf16 weights until ~budget_s of CPU work."""
+    from oracle import oracle
+
+    threads = os.cpu_count() or 1
+    w = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(1234)) * 0.02).to(torch.bfloat16)
+    n_bytes = w.numel() * 2
+
+    def one():
+        if workload == "fp8":
+            a = oracle.reduce_amax(w)
+            oracle.fake_quant_e4m3(w, a.reshape(1))
+        elif workload == "int4g128":
+            oracle.amax_qdq_int_group(w, 128, num_bits=4, narrow_range=False)
+        elif workload == "int8":
+            a = oracle.reduce_amax(w)
+            oracle.fake_quant_int(w, a.reshape(1), 8, False, True)
+        elif workload == "mxfp4":
+            oracle.mx_fused_amax_convert(w, 32, "E2M1")
+        else:
+            oracle.mask_2to4(w)
+
+    one()  # warm (builds the .so, faults pages)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s:
+        one()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * n_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x (4096x4096 bf16 weight, {workload} calibrate+QDQ), C oracle with OpenMP, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mask24"])
+    ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
+    ap.add_argument("--layers", type=int, default=0, help="0 = all layers of the model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernel measurements")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    moa = _moa_import.load()
+    from model_optimizer_amd.multi_tensor import SegmentTable
+
+    n_layers = args.layers or MODELS[args.model][2]
+    weights = make_weights(args.model, n_layers, dev)
+    n_elem = sum(w.numel() for w in weights)
+    wl = args.workload
+
+    tab = SegmentTable(weights, group_size=128 if wl == "int4g128" else None)
+    masks = None
+    if wl == "mask24":
+        masks = [None] * len(weights)
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    dom_events = []
+
+    def step(record):
+        if wl == "fp8" or wl == "int8":
+            tab.calibrate_amax()
+            if world > 1:
+                dist.all_reduce(tab.amax_flat, op=dist.ReduceOp.MAX)  # one bucket for all 224 amax
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            tab.fake_quant_e4m3() if wl == "fp8" else tab.fake_quant_int(8, False, True)
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+        elif wl == "int4g128":
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            tab.amax_qdq_int_group(4, False, False)
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+        elif wl == "mxfp4":
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            for i, w in enumerate(weights):
+                tab.outputs[i] = moa.ops.fused_amax_convert(w, 32, "E2M1")
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+        else:
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            for i, w in enumerate(weights):
+                masks[i] = moa.ops.mask_2to4(w)
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_elem * 2 / (elapsed / args.steps) / 1e9
+
+    # dominant kernel: average launch duration from the HIP events recorded inside the timed region
+    dom_ms = sum(a.elapsed_time(b) for a, b in dom_events) / len(dom_events)
+    alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mask24": 3.0}[wl]
+    dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
+                "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mx_kernel<bf16, 4> (224 launches)",
+                "mask24": "mask24_kernel<bf16> (224 launches)"}[wl]
+    achieved = n_elem * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4)}
+
+    out = {
+        "metric": "GB/s weights calibrated+QDQ (Llama-3-8B)",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16 storage, f32 arithmetic",
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} all {len(weights)} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16 per GPU), "
+                               f"{wl} calibrate + quantize-dequantize, inputs resident in HBM",
+                   "format": wl, "model": args.model, "layers": n_layers,
+                   "parallelism": f"per-layer weight tensors sharded over {world} GPU(s); one amax bucket all-reduce(MAX)"
+                                  if world > 1 else "single GPU"},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and not args.no_extra and world == 1:
+        # secondary measurements on the same resident weights (not part of `value`)
+        extra = {}
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            a, b = ev(), ev()
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+
+        if wl != "int4g128":
+            tabg = SegmentTable(weights, outputs=tab.outputs, group_size=128)
+            ms = timed(lambda: tabg.amax_qdq_int_group(4, False, False))
+            b = n_elem * (4.0 + 4.0 / 128)
+            extra["int4g128_fused_amax_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
+                                                "hbm_GBs": round(b / ms / 1e6, 1),
+                                                "frac_of_8TBs": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del tabg
+        if wl in ("fp8", "int8"):
+            ms = timed(lambda: tab.calibrate_amax())
+            extra["per_tensor_amax"] = {"ms": round(ms, 4), "hbm_GBs": round(n_elem * 2 / ms / 1e6, 1),
+                                        "frac_of_8TBs": round(n_elem * 2 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        out["extra"] = extra
+
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
+            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

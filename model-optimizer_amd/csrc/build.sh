@@ -8,15 +8,19 @@ OUT=${1:-libmoquant.so}
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
 objs=()
+pids=()
 for src in moq_*.hip; do
   obj="build/${src%.hip}.o"
   mkdir -p build
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
     echo "[moquant] hipcc $src"
     $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
   fi
   objs+=("$obj")
 done
-wait
+for pid in "${pids[@]:-}"; do
+  if [ -n "$pid" ]; then wait "$pid" || { echo "[moquant] compile failed"; exit 1; }; fi
+done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "${objs[@]}"
 echo "[moquant] built $(pwd)/$OUT"

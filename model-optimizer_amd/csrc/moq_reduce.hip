@@ -1,0 +1,256 @@
+// moq_reduce.hip -- abs-max over all dimensions but one (per-channel / per-group / per-column amax) and
+// the fused column statistics of an activation batch (AWQ act-scale numerator + SmoothQuant channel amax).
+//
+// Three layouts of the contiguous [outer, axis_size, inner] view, each with its own access pattern:
+//   rows    (inner >= one 16-byte packet): every (o, a) pair is a contiguous run of `inner` elements.
+//           A wave streams a row segment with 1-KiB instructions and finishes with a 64-lane butterfly.
+//   columns (inner == 1): out[a] reduces a strided column of the [outer, axis_size] matrix.  A lane owns
+//           8 (bf16) adjacent columns, walks down the rows with 16-byte loads and keeps 4 packed
+//           v_pk_max_u16 accumulators; one atomicMax per column per row-block.
+//   generic (anything else / unaligned): one element per lane, correctness path.
+// All of them are HBM-read bound: 2 B/element (bf16) in, ~0 out.
+#include "moq_common.h"
+
+namespace moq {
+
+constexpr int kColRows = 16;  // rows per workgroup in the column kernels
+
+__device__ __forceinline__ bool al16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// ---------------------------------------------------------------- rows
+// grid: blockIdx.x enumerates (row, segment) work items four per block (one per wave)
+template <int DT>
+__global__ __launch_bounds__(kBlock) void amax_rows_kernel(const void* __restrict__ x, int64_t n_rows,
+                                                           int64_t axis_size, int64_t inner,
+                                                           int64_t seg_packets, int64_t segs_per_row,
+                                                           uint32_t* __restrict__ out) {
+  constexpr int V = Elem<DT>::kVec;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t n_items = n_rows * segs_per_row;
+  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+  const int64_t row_packets = inner / V;
+  const char* base = reinterpret_cast<const char*>(x);
+  for (int64_t item = wave_id; item < n_items; item += n_waves) {
+    const int64_t row = item / segs_per_row, seg = item % segs_per_row;
+    const int64_t p0 = seg * seg_packets;
+    const int64_t p1 = p0 + seg_packets < row_packets ? p0 + seg_packets : row_packets;
+    const char* rp = base + row * inner * (16 / V);
+    uint32_t acc = 0;
+    int64_t p = p0 + lane;
+    // 4 independent 16-byte loads in flight per lane
+    for (; p + 3 * 64 < p1; p += 4 * 64) {
+      Pack16 a = load16(rp + p * 16), b = load16(rp + (p + 64) * 16), c = load16(rp + (p + 128) * 16),
+             d = load16(rp + (p + 192) * 16);
+      uint32_t m0 = pack_absmax<DT>(a), m1 = pack_absmax<DT>(b), m2 = pack_absmax<DT>(c),
+               m3 = pack_absmax<DT>(d);
+      m0 = m0 > m1 ? m0 : m1;
+      m2 = m2 > m3 ? m2 : m3;
+      m0 = m0 > m2 ? m0 : m2;
+      acc = acc > m0 ? acc : m0;
+    }
+    for (; p < p1; p += 64) {
+      uint32_t m = pack_absmax<DT>(load16(rp + p * 16));
+      acc = acc > m ? acc : m;
+    }
+    acc = group_max_u32<64>(acc);
+    if (lane == 0) atomicMax(&out[row % axis_size], acc);
+  }
+}
+
+// ---------------------------------------------------------------- columns
+// grid.x = column tiles of kBlock*V columns, grid.y = row blocks of kColRows rows.
+// SUM: also produce per-row-block partial column sums of |x| (fp32) into partial[rowblk][col].
+template <int DT, bool SUM, bool AMAX>
+__global__ __launch_bounds__(kBlock) void col_stats_kernel(const void* __restrict__ x, int64_t rows,
+                                                           int64_t cols, uint32_t* __restrict__ amax_out,
+                                                           float* __restrict__ partial) {
+  constexpr int V = Elem<DT>::kVec;
+  const int64_t c0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+  if (c0 >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * kColRows;
+  const int64_t r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
+  const char* base = reinterpret_cast<const char*>(x);
+  const int64_t row_bytes = cols * (16 / V);
+  uint32_t am[V];
+  float sm[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { am[i] = 0; sm[i] = 0.0f; }
+  Pack16 pk[kColRows];
+#pragma unroll
+  for (int r = 0; r < kColRows; ++r)
+    if (r0 + r < r1) pk[r] = load16(base + (r0 + r) * row_bytes + c0 * (16 / V));
+#pragma unroll
+  for (int r = 0; r < kColRows; ++r) {
+    if (r0 + r < r1) {
+      float f[8];
+      unpack<DT>(pk[r], f);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const uint32_t a = absbits(f[i]);
+        if (AMAX) am[i] = a > am[i] ? a : am[i];
+        if (SUM) sm[i] += __uint_as_float(a);  // rows are added in row order: deterministic
+      }
+    }
+  }
+  if (AMAX) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) atomicMax(&amax_out[c0 + i], am[i]);
+  }
+  if (SUM) {
+    float* dst = partial + (int64_t)blockIdx.y * cols + c0;
+#pragma unroll
+    for (int i = 0; i < V; ++i) dst[i] = sm[i];
+  }
+}
+
+// sum_out[c] (+)= sum over row blocks, in row-block order (deterministic)
+__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64_t n_blk, int64_t cols,
+                                        float* __restrict__ sum_out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int64_t b = 0; b < n_blk; ++b) s += partial[b * cols + c];
+  sum_out[c] = accumulate ? sum_out[c] + s : s;
+}
+
+// ---------------------------------------------------------------- generic
+template <int DT>
+__global__ void amax_generic_kernel(const void* __restrict__ x, int64_t n, int64_t axis_size,
+                                    int64_t inner, uint32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    atomicMax(&out[(i / inner) % axis_size], absbits(load1<DT>(x, i)));
+}
+template <int DT>
+__global__ void col_sum_generic_kernel(const void* __restrict__ x, int64_t rows, int64_t cols,
+                                       float* __restrict__ sum_out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int64_t r = 0; r < rows; ++r) s += __builtin_fabsf(load1<DT>(x, r * cols + c));
+  sum_out[c] = accumulate ? sum_out[c] + s : s;
+}
+
+int launch_group(const void* x, void* y, float* amax_out, int64_t n_groups, int g, int dt, int num_bits,
+                 int is_unsigned, int narrow, bool qdq, const void* s, int64_t cols, void* stream,
+                 const char* who);
+
+}  // namespace moq
+
+using namespace moq;
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int moq_amax_axis(const void* x, int64_t outer, int64_t axis_size, int64_t inner, int dt,
+                             float* out, int accumulate, void* stream) {
+  if (outer < 0 || axis_size < 0 || inner < 0 || out == nullptr) {
+    set_error("moq_amax_axis: bad sizes or NULL out");
+    return MOQ_ERR_INVALID;
+  }
+  const int64_t n = outer * axis_size * inner;
+  if (n > 0 && x == nullptr) {
+    set_error("moq_amax_axis: NULL input");
+    return MOQ_ERR_INVALID;
+  }
+  if (axis_size == 0) return MOQ_OK;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  // per-group fast path: short power-of-two rows -> sub-wave butterfly kernel (plain stores, no atomics)
+  if (!accumulate && outer == 1 && aligned && inner % vec == 0) {
+    const int64_t lpg = inner / vec;
+    if (lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0 && n > 0)
+      return launch_group(x, nullptr, out, axis_size, (int)inner, dt, 8, 0, 0, false, nullptr, 0, stream,
+                          "moq_amax_axis(group)");
+  }
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * axis_size, S(stream)) != hipSuccess)
+      return check_launch("moq_amax_axis memset");
+  }
+  if (n == 0) return MOQ_OK;
+  uint32_t* ob = reinterpret_cast<uint32_t*>(out);
+  if (aligned && inner >= vec && inner % vec == 0) {
+    const int64_t n_rows = outer * axis_size;
+    const int64_t row_packets = inner / vec;
+    // split long rows so that at least ~8192 wave work items exist
+    int64_t segs = 1;
+    if (n_rows < 8192) segs = (8192 + n_rows - 1) / n_rows;
+    int64_t seg_packets = (row_packets + segs - 1) / segs;
+    if (seg_packets < 256) seg_packets = 256 < row_packets ? 256 : row_packets;  // >= 4 KiB per item
+    segs = (row_packets + seg_packets - 1) / seg_packets;
+    const int64_t items = n_rows * segs;
+    int64_t blocks = (items + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_rows_kernel<DT>), dim3((int)blocks), dim3(kBlock), 0,
+                                              S(stream), x, n_rows, axis_size, inner, seg_packets, segs,
+                                              ob));
+  } else if (aligned && inner == 1 && axis_size % vec == 0) {
+    dim3 grid((unsigned)((axis_size / vec + kBlock - 1) / kBlock),
+              (unsigned)((outer + kColRows - 1) / kColRows));
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, false, true>), grid, dim3(kBlock), 0,
+                                              S(stream), x, outer, axis_size, ob, (float*)nullptr));
+  } else {
+    const int grid = stream_grid(kBlock, n);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_generic_kernel<DT>), dim3(grid), dim3(kBlock), 0,
+                                              S(stream), x, n, axis_size, inner, ob));
+  }
+  return check_launch("moq_amax_axis");
+}
+
+extern "C" int64_t moq_col_stats_workspace(int64_t tokens, int64_t cols) {
+  if (tokens < 0 || cols < 0) return MOQ_ERR_INVALID;
+  return ((tokens + kColRows - 1) / kColRows) * cols;
+}
+
+extern "C" int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, int dt, float* sum_out,
+                                 float* amax_out, float* partial, int accumulate, void* stream) {
+  if (tokens < 0 || cols <= 0 || (tokens > 0 && x == nullptr) || (sum_out == nullptr && amax_out == nullptr)) {
+    set_error("moq_col_abs_stats: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (!accumulate && amax_out != nullptr) {
+    if (hipMemsetAsync(amax_out, 0, sizeof(float) * cols, S(stream)) != hipSuccess)
+      return check_launch("moq_col_abs_stats memset");
+  }
+  if (tokens == 0) {
+    if (!accumulate && sum_out != nullptr) (void)hipMemsetAsync(sum_out, 0, sizeof(float) * cols, S(stream));
+    return check_launch("moq_col_abs_stats");
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const bool fast = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && cols % vec == 0;
+  uint32_t* ab = reinterpret_cast<uint32_t*>(amax_out);
+  if (fast && (sum_out == nullptr || partial != nullptr)) {
+    const int64_t n_blk = (tokens + kColRows - 1) / kColRows;
+    dim3 grid((unsigned)((cols / vec + kBlock - 1) / kBlock), (unsigned)n_blk);
+    if (sum_out != nullptr && amax_out != nullptr) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, true, true>), grid, dim3(kBlock), 0,
+                                                S(stream), x, tokens, cols, ab, partial));
+    } else if (sum_out != nullptr) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, true, false>), grid, dim3(kBlock), 0,
+                                                S(stream), x, tokens, cols, ab, partial));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, false, true>), grid, dim3(kBlock), 0,
+                                                S(stream), x, tokens, cols, ab, partial));
+    }
+    if (sum_out != nullptr)
+      hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                         S(stream), partial, n_blk, cols, sum_out, accumulate);
+  } else {
+    if (sum_out != nullptr && partial == nullptr && fast) {
+      set_error("moq_col_abs_stats: workspace `partial` is required for the column sum");
+      return MOQ_ERR_INVALID;
+    }
+    if (amax_out != nullptr) {
+      const int grid = stream_grid(kBlock, tokens * cols);
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_generic_kernel<DT>), dim3(grid), dim3(kBlock), 0,
+                                                S(stream), x, tokens * cols, cols, (int64_t)1, ab));
+    }
+    if (sum_out != nullptr) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_sum_generic_kernel<DT>),
+                                                dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                                                S(stream), x, tokens, cols, sum_out, accumulate));
+    }
+  }
+  return check_launch("moq_col_abs_stats");
+}

@@ -1,0 +1,106 @@
+"""Whole-layer / whole-model weight passes in ONE launch (the multi-tensor forms of the C-ABI).
+
+The reference walks the model and calls one kernel per weight (weight_only_quantize,
+quantization/model_calib.py:187-199).  At HBM speed an 8-100 MB tensor takes 2-20 us, the same order as a
+launch gap, so here the tensors of a layer / model are described by a device-resident segment table and
+calibrated / quantize-dequantized by a single grid.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import MoquantError, check
+from .ops import _dt, _on, _p, _require_gpu
+
+
+class SegmentTable:
+    """Device-side table of (x, y, amax, n) segments + chunk prefix sums.
+
+    inputs      : list of contiguous GPU tensors of one dtype
+    outputs     : list of same-shaped tensors (default: new tensors; pass inputs for in place)
+    group_size  : None -> one fp32 amax per tensor; g -> n/g fp32 amax per tensor (per-group formats)
+    """
+
+    def __init__(self, inputs, outputs=None, group_size: int | None = None):
+        if not inputs:
+            raise MoquantError("SegmentTable needs at least one tensor")
+        for t in inputs:
+            _require_gpu(t, "SegmentTable")
+            if not t.is_contiguous():
+                raise MoquantError("SegmentTable tensors must be contiguous")
+            if t.dtype != inputs[0].dtype or t.device != inputs[0].device:
+                raise MoquantError("SegmentTable tensors must share dtype and device")
+        self.inputs = list(inputs)
+        self.outputs = [torch.empty_like(t) for t in inputs] if outputs is None else list(outputs)
+        self.group_size = group_size
+        self.device = inputs[0].device
+        self.dtype_code = _dt(inputs[0])
+        n_seg = len(inputs)
+        sizes = [t.numel() for t in inputs]
+        if group_size is None:
+            self.amax_flat = torch.zeros(n_seg, dtype=torch.float32, device=self.device)
+            offs = list(range(n_seg))
+            self.amax = [self.amax_flat[i:i + 1] for i in range(n_seg)]
+        else:
+            if any(s % group_size for s in sizes):
+                raise MoquantError("every tensor's numel must be a multiple of group_size")
+            counts = [s // group_size for s in sizes]
+            self.amax_flat = torch.zeros(sum(counts), dtype=torch.float32, device=self.device)
+            offs, acc = [], 0
+            for c in counts:
+                offs.append(acc)
+                acc += c
+            self.amax = [self.amax_flat[o:o + c] for o, c in zip(offs, counts)]
+        # host plan -> device table
+        n_arr = (ctypes.c_int64 * n_seg)(*sizes)
+        blk = (ctypes.c_int64 * (n_seg + 1))()
+        total = _lib.lib().moq_mt_plan(n_arr, n_seg, blk)
+        if total < 0:
+            check(int(total))
+        self.n_chunks = int(total)
+        self.n_seg = n_seg
+        rows = []
+        base = self.amax_flat.data_ptr()
+        for i, (x, y) in enumerate(zip(self.inputs, self.outputs)):
+            rows.append([x.data_ptr(), y.data_ptr(), base + 4 * offs[i], sizes[i]])
+        # pointers are < 2^63 so int64 storage is lossless; layout == struct moq_seg (4 x 8 bytes)
+        self._segs = torch.tensor(rows, dtype=torch.int64).to(self.device)
+        self._blk = torch.tensor(list(blk), dtype=torch.int64).to(self.device)
+        self.bytes_in = sum(s * inputs[0].element_size() for s in sizes)
+
+    # -- a1 over the table
+    def calibrate_amax(self):
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_amax(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                         self.dtype_code, stream))
+        return self.amax_flat
+
+    # -- a7 over the table (uses the per-tensor amax slots)
+    def fake_quant_e4m3(self):
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_fake_quant_e4m3(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                                    self.dtype_code, stream))
+        return self.outputs
+
+    # -- a6 over the table (per-tensor amax)
+    def fake_quant_int(self, num_bits=8, unsigned=False, narrow_range=True):
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_fake_quant_int(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                                   self.dtype_code, int(num_bits), int(unsigned),
+                                                   int(narrow_range), stream))
+        return self.outputs
+
+    # -- fused per-group amax + QDQ over the table
+    def amax_qdq_int_group(self, num_bits=4, unsigned=False, narrow_range=False):
+        if self.group_size is None:
+            raise MoquantError("table was built without group_size")
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_amax_qdq_int_group(_p(self._segs), _p(self._blk), self.n_seg,
+                                                       self.n_chunks, int(self.group_size), self.dtype_code,
+                                                       int(num_bits), int(unsigned), int(narrow_range),
+                                                       stream))
+        return self.outputs

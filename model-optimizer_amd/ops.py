@@ -1,0 +1,377 @@
+"""Functional layer over the C-ABI: torch tensors in, torch tensors out, HIP kernels in between.
+
+Names, argument meaning and error behaviour mirror the reference's L1 functional ops
+(modelopt/torch/quantization/tensor_quant.py, utils/core_utils.py, sparsity/weight_sparsity/magnitude.py)
+so that parity tests read like the reference's own tests.  torch is used for device memory, streams and
+tiny host-side bookkeeping only; every pass over tensor data is one of our kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from contextlib import contextmanager
+
+import torch
+
+from . import _lib
+from ._lib import MoquantError, MoquantUnsupported, check
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise MoquantUnsupported(f"dtype {t.dtype} is not supported by libmoquant (f32/f16/bf16)") from None
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    # reference: TORCH_CHECK(inputs.is_cuda()) (tensor_quant.cpp:46,56) -> RuntimeError
+    if not t.is_cuda:
+        raise MoquantError(f"{what}: tensor must live on the GPU (got {t.device}); "
+                           "there is no CPU path in model_optimizer_amd")
+
+
+@contextmanager
+def _on(t: torch.Tensor):
+    """Device guard + current stream handle (reference: same_device_as, tensor_quantizer.py:1205)."""
+    with torch.cuda.device(t.device):
+        yield ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _p(t: torch.Tensor | None):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------- amax
+def _reduce_layout(shape, reduce_axes):
+    """Factor `shape` as [outer, kept, inner] when exactly one block of adjacent dims is kept."""
+    nd = len(shape)
+    red = sorted({a % nd for a in reduce_axes})
+    keep = [d for d in range(nd) if d not in red]
+    if not keep:
+        return None
+    if keep != list(range(keep[0], keep[-1] + 1)):
+        raise MoquantUnsupported(f"reduce_amax: kept dims {keep} are not adjacent")
+    outer = 1
+    for d in range(keep[0]):
+        outer *= shape[d]
+    kept = 1
+    for d in keep:
+        kept *= shape[d]
+    inner = 1
+    for d in range(keep[-1] + 1, nd):
+        inner *= shape[d]
+    return outer, kept, inner, keep
+
+
+@torch.no_grad()
+def reduce_amax(input: torch.Tensor, axis=None, keepdims=True, squeeze_scalar=True,
+                out: torch.Tensor | None = None, accumulate: bool = False) -> torch.Tensor:
+    """Abs-max over `axis` (the dims to REDUCE; None = all) -- core_utils.py:146-183.
+
+    Returns the input dtype like the reference (exact: a max of representable values).  `out`/`accumulate`
+    expose the fused running max used by MaxCalibrator (fp32 buffer, updated in place).
+    """
+    _require_gpu(input, "reduce_amax")
+    x = input.detach()
+    if x.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+        x = x.to(torch.get_default_dtype())  # core_utils.py:169-170
+    x = x.contiguous()
+    nd = x.dim()
+    if isinstance(axis, int):
+        axis = (axis,)
+    per_tensor = axis is None or len({a % nd for a in axis}) == nd or nd == 0
+    with _on(x) as stream:
+        if per_tensor:
+            buf = out if out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+            check(_lib.lib().moq_amax(_p(x), x.numel(), _dt(x), _p(buf), int(accumulate), stream))
+            if out is not None:
+                return out
+            if axis is None:
+                return buf.reshape(()).to(x.dtype)  # torch.max(input) is 0-dim
+            res = buf.to(x.dtype).reshape([1] * nd if keepdims else [])
+            if squeeze_scalar:
+                res = res.reshape(())
+            return res
+        if len(axis) == 0:
+            raise MoquantUnsupported("reduce_amax: empty reduce axis list")
+        outer, kept, inner, keep = _reduce_layout(list(x.shape), axis)
+        buf = out if out is not None else torch.empty(kept, dtype=torch.float32, device=x.device)
+        check(_lib.lib().moq_amax_axis(_p(x), outer, kept, inner, _dt(x), _p(buf), int(accumulate), stream))
+        if out is not None:
+            return out
+        shape = [x.shape[d] if d in keep else 1 for d in range(nd)] if keepdims else [x.shape[d] for d in keep]
+        res = buf.to(x.dtype).reshape(shape)
+        if squeeze_scalar and res.numel() == 1:
+            res = res.reshape(())
+        return res
+
+
+# ----------------------------------------------------------------------------------------------- QDQ
+def _amax_mode(inputs: torch.Tensor, amax: torch.Tensor):
+    """(mode, axis_size, inner) from an amax tensor, following fake_quant_impl / scaled_e4m3_impl
+    (tensor_quant.py:83-91, :103-111): numel 1 -> per tensor; else one non-singleton dim = the axis."""
+    if amax.numel() == 1:
+        return _lib.AMAX_SCALAR, 1, 1
+    if amax.dim() != inputs.dim() and amax.squeeze().dim() != 1:
+        raise MoquantUnsupported("amax must be a scalar or have exactly one non-singleton dim")
+    if amax.dim() == inputs.dim():
+        if amax.squeeze().dim() > 1:
+            # reference: ValueError -> caller falls back to eager (tensor_quant.py:386-389)
+            raise MoquantUnsupported("multi-dimensional amax is not supported by the kernel")
+        axis = list(amax.shape).index(amax.numel())
+    elif amax.dim() == 1 and inputs.dim() >= 1:
+        axis = None
+        for d in range(inputs.dim()):
+            if inputs.shape[d] == amax.numel():
+                axis = d
+                break
+        if axis is None:
+            raise MoquantError("amax length does not match any input dim")
+    else:
+        raise MoquantUnsupported("unsupported amax shape")
+    if inputs.shape[axis] != amax.numel():
+        raise MoquantError(f"amax.numel()={amax.numel()} != inputs.size({axis})={inputs.shape[axis]}")
+    inner = 1
+    for d in range(axis + 1, inputs.dim()):
+        inner *= inputs.shape[d]
+    return _lib.AMAX_AXIS, inputs.shape[axis], inner
+
+
+@torch.no_grad()
+def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 8, unsigned: bool = False,
+                      narrow_range: bool = True, inplace: bool = False,
+                      check_inputs: bool = False) -> torch.Tensor:
+    """INT-k quantize-dequantize -- tensor_quant.py:607-645 / tensor_quant_gpu.cu:43-140."""
+    _require_gpu(inputs, "fake_tensor_quant")
+    x = inputs if inplace else inputs.contiguous()
+    if inplace and not x.is_contiguous():
+        raise MoquantError("in-place fake quant needs a contiguous tensor")  # tensor_quant.cpp:41-42
+    am = _f32(amax, x.device)
+    if check_inputs:
+        # the eager reference raises here (tensor_quant.py:611, :619-620); the CUDA extension only has
+        # device asserts.  Both checks cost a device->host sync, so they are opt-in.
+        if unsigned and x.numel() and bool((x.min() < 0).item()):
+            raise TypeError("Negative values encountered in unsigned quantization.")
+        if bool((am.min() < 0).item()):
+            raise ValueError("Negative values in amax")
+    mode, axis_size, inner = _amax_mode(x, am)
+    y = x if inplace else torch.empty_like(x)
+    with _on(x) as stream:
+        check(_lib.lib().moq_fake_quant_int(_p(x), _p(y), x.numel(), _dt(x), _p(am), mode, axis_size, inner,
+                                            int(num_bits), int(unsigned), int(narrow_range), stream))
+    return y
+
+
+@torch.no_grad()
+def scaled_e4m3(inputs: torch.Tensor, amax: torch.Tensor | None) -> torch.Tensor:
+    """FP8-E4M3 quantize-dequantize -- tensor_quant.py:46-92 / tensor_quant_gpu_fp8.cu:35-107."""
+    _require_gpu(inputs, "scaled_e4m3")
+    x = inputs.contiguous()
+    y = torch.empty_like(x)
+    with _on(x) as stream:
+        if amax is None:
+            check(_lib.lib().moq_fake_quant_e4m3(_p(x), _p(y), x.numel(), _dt(x), None, _lib.AMAX_SCALAR, 1,
+                                                 1, stream))
+        else:
+            am = _f32(amax, x.device)
+            mode, axis_size, inner = _amax_mode(x, am)
+            check(_lib.lib().moq_fake_quant_e4m3(_p(x), _p(y), x.numel(), _dt(x), _p(am), mode, axis_size,
+                                                 inner, stream))
+    return y
+
+
+@torch.no_grad()
+def amax_qdq_int_group(inputs: torch.Tensor, group_size: int, num_bits: int = 4, unsigned: bool = False,
+                       narrow_range: bool = False, return_amax: bool = True):
+    """Fused dynamic per-group amax + INT-k QDQ over the (-1, g) view of a contiguous tensor whose
+    element count is a multiple of g (the caller pads the last dim like _process_for_blockquant,
+    tensor_quantizer.py:1045-1055).  Returns (y, amax[n/g] fp32 or None)."""
+    _require_gpu(inputs, "amax_qdq_int_group")
+    x = inputs.contiguous()
+    if x.numel() % group_size:
+        raise MoquantError("numel must be a multiple of group_size (pad the last dim first)")
+    ng = x.numel() // group_size
+    y = torch.empty_like(x)
+    am = torch.empty(ng, dtype=torch.float32, device=x.device) if return_amax else None
+    with _on(x) as stream:
+        check(_lib.lib().moq_amax_qdq_int_group(_p(x), _p(y), _p(am), ng, int(group_size), _dt(x),
+                                                int(num_bits), int(unsigned), int(narrow_range), stream))
+    return y, am
+
+
+_MX_FORMAT_MAP = {(4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3", 8: "INT8", (8, 0): "E8M0",
+                  (2, 1): "E2M1", (1, 2): "E1M2", (0, 3): "E0M3", (3, 0): "E3M0"}  # tensor_quant.py:30-41
+
+
+@torch.no_grad()
+def fused_amax_convert(inputs: torch.Tensor, block_size: int, fmt: str | int, scale_fmt: str | int = "E8M0",
+                       global_amax: torch.Tensor | None = None) -> torch.Tensor:
+    """MX dynamic block QDQ along the last dim -- cuda_ext_mx.fused_amax_convert
+    (tensor_quant_mx.cu:355-387)."""
+    _require_gpu(inputs, "fused_amax_convert")
+    x = inputs.contiguous()
+    f = _lib.MX_TYPES[fmt] if isinstance(fmt, str) else int(fmt)
+    sf = _lib.MX_TYPES[scale_fmt] if isinstance(scale_fmt, str) else int(scale_fmt)
+    cols = x.shape[-1] if x.dim() else 1
+    rows = x.numel() // max(cols, 1)
+    y = torch.empty_like(x)
+    ga = None if global_amax is None else _f32(global_amax, x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_mx_fused_amax_convert(_p(x), _p(y), rows, cols, int(block_size), _dt(x), f, sf,
+                                                   _p(ga), stream))
+    return y
+
+
+@torch.no_grad()
+def dynamic_block_quant(inputs, block_size, amax, num_bits, scale_bits):
+    """tensor_quant.dynamic_block_quant front door (tensor_quant.py:157-195): num_bits / scale_bits are
+    (E, M) tuples or 8."""
+    if num_bits not in _MX_FORMAT_MAP or scale_bits not in _MX_FORMAT_MAP:
+        raise NotImplementedError(f"Unsupported num_bits: {num_bits}, scale_bits: {scale_bits}")
+    return fused_amax_convert(inputs, block_size, _MX_FORMAT_MAP[num_bits], _MX_FORMAT_MAP[scale_bits],
+                              None if scale_bits == (8, 0) else amax)
+
+
+# ----------------------------------------------------------------------------------------------- histogram
+@torch.no_grad()
+def hist_abs(x: torch.Tensor, bins: int, max_edge: float, skip_zeros: bool = False,
+             counts: torch.Tensor | None = None) -> torch.Tensor:
+    """counts[b] += #|x| in bin b of torch.histc(|x|, bins, 0, max_edge); int64 counts on device."""
+    _require_gpu(x, "hist_abs")
+    x = x.detach().contiguous()
+    if counts is None:
+        counts = torch.zeros(bins, dtype=torch.int64, device=x.device)
+    elif counts.dtype != torch.int64 or counts.numel() != bins or not counts.is_contiguous():
+        raise MoquantError("counts must be a contiguous int64 tensor with `bins` entries")
+    with _on(x) as stream:
+        check(_lib.lib().moq_hist_abs(_p(x), x.numel(), _dt(x), _p(counts), int(bins), float(max_edge),
+                                      int(skip_zeros), stream))
+    return counts
+
+
+# ----------------------------------------------------------------------------------------------- sparsity
+@torch.no_grad()
+def mask_2to4(w: torch.Tensor) -> torch.Tensor:
+    """2:4 magnitude mask over groups of 4 along the last dim of a contiguous 2-D view."""
+    _require_gpu(w, "mask_2to4")
+    x = w.detach().contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_mask_2to4(_p(x), rows, cols, _dt(x), _p(mask), stream))
+    return mask.view(torch.bool)
+
+
+# ----------------------------------------------------------------------------------------------- INT4
+@torch.no_grad()
+def int4_quantize(flat_input: torch.Tensor, scales: torch.Tensor, block_size: int,
+                  rounding: int = _lib.ROUND_HALF_EVEN) -> torch.Tensor:
+    """cuda_ext.INT4_quantize(input, scales, block_size) -> uint8[n/2] (tensor_quant_gpu.cu:342-366)."""
+    _require_gpu(flat_input, "INT4_quantize")
+    x = flat_input.contiguous()
+    s = scales.to(x.dtype).contiguous()
+    out = torch.empty(x.numel() // 2, dtype=torch.uint8, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_int4_pack(_p(x), _p(s), _p(out), x.numel(), int(block_size), _dt(x),
+                                       int(rounding), stream))
+    return out
+
+
+@torch.no_grad()
+def int4_dequantize(quantized: torch.Tensor, scales: torch.Tensor, block_size: int) -> torch.Tensor:
+    """cuda_ext.INT4_dequantize(uint8, scales, block_size) -> scales.dtype[2n] (tensor_quant_gpu.cu:283-308)."""
+    _require_gpu(quantized, "INT4_dequantize")
+    q = quantized.contiguous().view(-1)
+    if q.dtype != torch.uint8:
+        raise MoquantError("quantized data must be uint8")
+    s = scales.contiguous()
+    out = torch.empty(2 * q.numel(), dtype=s.dtype, device=q.device)
+    with _on(q) as stream:
+        check(_lib.lib().moq_int4_unpack(_p(q), _p(s), _p(out), q.numel(), int(block_size), _dt(s), stream))
+    return out
+
+
+@torch.no_grad()
+def pack_int4_in_uint8(weight: torch.Tensor, weights_scaling_factor: torch.Tensor) -> torch.Tensor:
+    """Checkpoint packer (export/quant_utils.py:792-833): uint8 [..., out/2, in]."""
+    _require_gpu(weight, "pack_int4_in_uint8")
+    out_dim, in_dim = weight.shape[-2], weight.shape[-1]
+    if out_dim % 2:
+        raise AssertionError(f"Cannot pack weight. Out dimension {out_dim} is not an even number.")
+    g = in_dim // weights_scaling_factor.shape[-1]
+    w = weight.contiguous()
+    wsf = _f32(weights_scaling_factor, w.device)
+    lead = w.shape[:-2]
+    batch = 1
+    for d in lead:
+        batch *= d
+    out = torch.empty(*lead, out_dim // 2, in_dim, dtype=torch.uint8, device=w.device)
+    w3, s3, o3 = w.reshape(batch, out_dim, in_dim), wsf.reshape(batch, out_dim, -1), out.view(batch, out_dim // 2, in_dim)
+    with _on(w) as stream:
+        for b in range(batch):  # experts: one launch each
+            check(_lib.lib().moq_int4_pack_export(_p(w3[b]), _p(s3[b]), _p(o3[b]), out_dim, in_dim, int(g),
+                                                  _dt(w), stream))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- AWQ / smooth
+@torch.no_grad()
+def scale_cols(weight: torch.Tensor, scale: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """(W * s_fp32[None, :]).to(W.dtype) -- _apply_weight_pre_quant_scale (model_calib.py:1208-1216)."""
+    _require_gpu(weight, "scale_cols")
+    w = weight.contiguous()
+    s = _f32(scale, w.device).reshape(-1)
+    cols = w.shape[-1]
+    if s.numel() != cols:
+        raise MoquantError("scale length must equal the last weight dim")
+    y = torch.empty_like(w) if out is None else out
+    with _on(w) as stream:
+        check(_lib.lib().moq_scale_cols(_p(w), _p(s), _p(y), w.numel() // cols, cols, _dt(w), stream))
+    return y
+
+
+@torch.no_grad()
+def awq_scale_qdq(weight: torch.Tensor, awq_scale: torch.Tensor, group_size: int, num_bits: int = 4,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """QDQ_int_g((W * s).to(W.dtype)) with dynamic per-group amax: the weight side of one AWQ-lite search
+    step (model_calib.py:1552-1554), one read + one write of W."""
+    _require_gpu(weight, "awq_scale_qdq")
+    w = weight.contiguous()
+    s = awq_scale.detach().to(device=w.device, dtype=w.dtype).contiguous().reshape(-1)
+    cols = w.shape[-1]
+    y = torch.empty_like(w) if out is None else out
+    with _on(w) as stream:
+        check(_lib.lib().moq_awq_scale_qdq(_p(w), _p(s), _p(y), w.numel() // cols, cols, int(group_size),
+                                           _dt(w), int(num_bits), stream))
+    return y
+
+
+@torch.no_grad()
+def col_abs_stats(x: torch.Tensor, sum_out: torch.Tensor | None = None, amax_out: torch.Tensor | None = None,
+                  accumulate: bool = False, want_sum: bool = True, want_amax: bool = True):
+    """Column sum of |x| (fp32) and column abs-max of x[tokens, cols] in one read."""
+    _require_gpu(x, "col_abs_stats")
+    x2 = x.detach().contiguous().view(-1, x.shape[-1])
+    tokens, cols = x2.shape
+    dev = x2.device
+    if want_sum and sum_out is None:
+        sum_out = torch.zeros(cols, dtype=torch.float32, device=dev)
+    if want_amax and amax_out is None:
+        amax_out = torch.zeros(cols, dtype=torch.float32, device=dev)
+    ws = None
+    if want_sum:
+        ws = torch.empty(max(int(_lib.lib().moq_col_stats_workspace(tokens, cols)), 1), dtype=torch.float32,
+                         device=dev)
+    with _on(x2) as stream:
+        check(_lib.lib().moq_col_abs_stats(_p(x2), tokens, cols, _dt(x2), _p(sum_out if want_sum else None),
+                                           _p(amax_out if want_amax else None), _p(ws), int(accumulate),
+                                           stream))
+    return sum_out, amax_out

@@ -1,0 +1,432 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the reference-generated golden
+fixtures.  Integer / index / byte results must be bit-exact; floating-point QDQ outputs are compared
+bit-exactly too (same fp32 arithmetic), with the few stated exceptions (column sums: fp32 summation order).
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _moa_import
+from conftest import DT, GOLDEN, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+
+moa = _moa_import.load()
+ops = moa.ops
+from oracle import oracle  # noqa: E402  (the checker)
+
+DEV = "cuda:0"
+DTYPES = [torch.bfloat16, torch.float16, torch.float32]
+
+
+def weight_like(shape, dtype, seed, outliers=True):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(*shape, generator=g) * 0.02
+    if outliers:
+        m = torch.rand(*shape, generator=g) < 0.001
+        w = torch.where(m, w * 8, w)
+    return w.to(dtype)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _needs_gpu():
+    assert torch.cuda.is_available(), "these tests need a GPU (run with -m 'not gpu' elsewhere)"
+
+
+# ------------------------------------------------------------------------------------------ golden fixtures
+def test_golden_int_fake_quant(golden):
+    g = golden("int_fq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        amax = g.t(f"{k}_amax")
+        xd = x.to(DEV)
+        if c["mode"] == "group32":
+            xv = xd.reshape(-1, 32)
+            got = ops.fake_tensor_quant(xv, amax.to(DEV), c["bits"], c["unsigned"], c["narrow"]).reshape(x.shape)
+        else:
+            got = ops.fake_tensor_quant(xd, amax.to(DEV), c["bits"], c["unsigned"], c["narrow"])
+        assert_bits_equal(got, y, f"int_fq {k} {c}")
+
+
+def test_golden_fp8_fake_quant(golden):
+    g = golden("fp8_fq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        amax = None if c["mode"] == "none" else g.t(f"{k}_amax").to(DEV)
+        got = ops.scaled_e4m3(x.to(DEV), amax)
+        assert_bits_equal(got, y, f"fp8_fq {k} {c}")
+
+
+def test_golden_reduce_amax(golden):
+    g = golden("amax")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, want = g.t(f"{k}_x", dt), g.t(f"{k}_a")
+        axis = c["axis"]
+        nd = x.dim()
+        if axis is None:
+            red = None
+        else:
+            keep = [a % nd for a in (axis if isinstance(axis, list) else [axis])]
+            red = [d for d in range(nd) if d not in keep]
+        if isinstance(axis, list):
+            with pytest.raises(ValueError):
+                ops.reduce_amax(x.to(DEV), axis=red)  # non-adjacent kept dims: loud, not wrong
+            continue
+        got = ops.reduce_amax(x.to(DEV), axis=red)
+        assert str(got.dtype) == c["out_dtype"], f"{k}: dtype {got.dtype} vs {c['out_dtype']}"
+        assert list(got.shape) == c["out_shape"], f"{k}: shape {list(got.shape)} vs {c['out_shape']}"
+        assert_bits_equal(got.float(), want, f"amax {k} {c}")
+
+
+def test_golden_block_quantizer(golden):
+    g = golden("tq_block")
+    for k, c in g.cases.items():
+        if c.get("kind") not in ("dynamic", "static"):
+            continue
+        dt = DT[c["dtype"]]
+        x, y = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        gs = c["g"]
+        cols = x.shape[-1]
+        pad = (-cols) % gs
+        xd = x.to(DEV)
+        xp = torch.nn.functional.pad(xd, (0, pad)) if pad else xd
+        yq, am = ops.amax_qdq_int_group(xp, gs, num_bits=4, narrow_range=False)
+        assert_bits_equal(yq[..., :cols].contiguous(), y, f"tq_block {k} {c}")
+        if c["kind"] == "static":
+            assert_bits_equal(am.reshape(-1), g.t(f"{k}_amax").reshape(-1), f"tq_block amax {k}")
+            # static path: amax from the axis kernel, then QDQ with that amax
+            am2 = ops.reduce_amax(xp.reshape(-1, gs), axis=(1,))
+            assert_bits_equal(am2.float().reshape(-1), g.t(f"{k}_amax").reshape(-1), f"static amax {k}")
+            y2 = ops.fake_tensor_quant(xp.reshape(-1, gs), am2.float(), 4, False, False).reshape(xp.shape)
+            assert_bits_equal(y2[..., :cols].contiguous(), y, f"tq_block static {k}")
+
+
+def test_golden_max_calibrator_running(golden):
+    g = golden("tq_block")
+    for k, c in g.cases.items():
+        if c.get("kind") != "maxcal":
+            continue
+        want = g.t(f"{k}_a")
+        n = 1 if c["axis"] is None else want.numel()
+        buf = torch.zeros(n, dtype=torch.float32, device=DEV)
+        for b in range(3):
+            x = g.t(f"{k}_b{b}", torch.bfloat16).to(DEV)
+            red = None if c["axis"] is None else list(range(x.dim() - 1))
+            ops.reduce_amax(x, axis=red, out=buf, accumulate=True)
+        assert_bits_equal(buf.cpu().reshape(want.shape), want, f"maxcal {k}")
+
+
+def test_golden_histogram(golden):
+    g = golden("hist")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        hist, edges, nbins = None, None, c["num_bins"]
+        for b in range(3):
+            x = g.t(f"{k}_b{b}", dt).to(DEV)
+            want_h = g.t(f"{k}_h{b}")
+            xa = x.float().abs()
+            if c["skip_zeros"]:
+                xa = xa[xa != 0]
+            x_max = xa.max().cpu()
+            if hist is None:
+                counts = ops.hist_abs(x, nbins, float(x_max), c["skip_zeros"])
+                hist = counts.cpu().float()
+                edges = torch.linspace(0, x_max, nbins + 1)
+            else:
+                if x_max > edges[-1]:
+                    width = edges[1] - edges[0]
+                    nbins = int((x_max / width).ceil().item())
+                    edges = torch.arange(0, x_max + width, width)
+                counts = ops.hist_abs(x, nbins, float(edges[-1]), c["skip_zeros"])
+                new = counts.cpu().float()
+                new[: hist.numel()] += hist
+                hist = new
+            assert torch.equal(hist, want_h), f"hist {k} batch {b}: {(hist != want_h).sum().item()} bins differ"
+
+
+def test_golden_mask_2to4(golden):
+    g = golden("mask24")
+    for k, c in g.cases.items():
+        w = g.t(f"{k}_w", DT[c["dtype"]])
+        want = torch.from_numpy(g.raw(f"{k}_m")).bool()
+        got = ops.mask_2to4(w.to(DEV)).cpu()
+        assert torch.equal(got, want), f"mask {k} {c}: {(got != want).sum().item()} differ"
+
+
+def test_golden_int4(golden):
+    g = golden("int4")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        w = g.t(f"{k}_w", dt)
+        if c["kind"] == "qtensor":
+            s, q = g.t(f"{k}_s", dt), torch.from_numpy(g.raw(f"{k}_q"))
+            got = ops.int4_quantize(w.reshape(-1).to(DEV), s.reshape(-1).to(DEV), c["g"]).cpu()
+            assert torch.equal(got, q.reshape(-1)), f"int4 pack {k}"
+            deq = ops.int4_dequantize(q.reshape(-1).to(DEV), s.reshape(-1).to(DEV), c["g"]).cpu()
+            assert_bits_equal(deq.reshape(w.shape), g.t(f"{k}_d", dt), f"int4 unpack {k}")
+        else:
+            got = ops.pack_int4_in_uint8(w.to(DEV), g.t(f"{k}_wsf").to(DEV)).cpu()
+            assert torch.equal(got, torch.from_numpy(g.raw(f"{k}_p"))), f"export pack {k}"
+
+
+def test_golden_awq_blocks(golden):
+    g = golden("awq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        w, x = g.t(f"{k}_w", dt).to(DEV), g.t(f"{k}_x", dt).to(DEV)
+        ssum, amax = ops.col_abs_stats(x)
+        want = g.t(f"{k}_xscale")
+        mean = (ssum / x.shape[0]).to(dt).float().cpu()
+        # tolerance: one storage-dtype ulp (the reference's own mean differs CPU vs GPU by summation order)
+        ulp = (want.abs() * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)).clamp_min(1e-30)
+        assert ((mean - want).abs() <= ulp).all(), f"act scale {k}"
+        _, am_ref = oracle.col_abs_stats(x.cpu())
+        assert_bits_equal(amax.cpu(), am_ref, f"col amax {k}")
+        for j, _ in enumerate(c["alphas"]):
+            s = g.t(f"{k}_s{j}")
+            got = ops.awq_scale_qdq(w, s.to(DEV), c["g"], 4)
+            assert_bits_equal(got, g.t(f"{k}_wq{j}", dt), f"awq scale+qdq {k} alpha#{j}")
+            assert_bits_equal(ops.scale_cols(w, s.to(DEV)), g.t(f"{k}_fold{j}", dt), f"fold {k} alpha#{j}")
+
+
+def test_mx_golden_vectors():
+    cases = json.load(open(os.path.join(GOLDEN, "mx_vectors.json")))
+    for c in cases:
+        blocks = [c["block_size"]] if c["block_size"] else [8, 16, 32]
+        dtypes = [torch.float32] if c["dtype"] else DTYPES
+        for bs in blocks:
+            for dt in dtypes:
+                rep = max(bs // c["in_size"], 1)
+                tin = torch.tensor(c["test_in"], dtype=dt).repeat(1, rep)
+                tout = torch.tensor(c["test_out"], dtype=dt).repeat(1, rep)
+                for sign in (1.0, -1.0):
+                    got = ops.fused_amax_convert((tin * sign).to(DEV), bs, c["fmt"]).cpu()
+                    assert torch.allclose(got.float(), (tout * sign).float(), rtol=1e-5, atol=c["atol"]), \
+                        f"{c['fn']} {c['fmt']} bs={bs} {dt}"
+
+
+# ------------------------------------------------------------------------------------------ oracle, seeded
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 1000, 8192, 8193, 3 * 8192 + 5, 1 << 20])
+def test_amax_per_tensor_vs_oracle(dtype, n):
+    x = weight_like((n,), dtype, 11 + n) if n else torch.empty(0, dtype=dtype)
+    got = ops.reduce_amax(x.to(DEV))
+    want = oracle.reduce_amax(x) if n else torch.tensor(0.0)
+    assert_bits_equal(got.float().cpu(), want, f"amax n={n}")
+    if n > 16:
+        # unaligned base pointer (slice of a bigger buffer)
+        big = torch.zeros(n + 3, dtype=dtype, device=DEV)
+        big[3:] = x.to(DEV)
+        assert_bits_equal(ops.reduce_amax(big[3:]).float().cpu(), want, "unaligned amax")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_amax_nan_inf_propagation(dtype):
+    x = weight_like((4, 4096), dtype, 5)
+    x[2, 17] = float("nan")
+    assert torch.isnan(ops.reduce_amax(x.to(DEV))).item()
+    a = ops.reduce_amax(x.to(DEV), axis=(1,))
+    assert torch.isnan(a[2]).item() and not torch.isnan(a[0]).item()
+    x[2, 17] = float("-inf")
+    assert torch.isinf(ops.reduce_amax(x.to(DEV))).item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 8, 64), (1, 300, 4096), (5, 64, 24), (1, 4, 1 << 18), (257, 4096, 1),
+                                   (33, 520, 1), (7, 13, 5), (3, 100, 3)])
+def test_amax_axis_vs_oracle(dtype, shape):
+    outer, axis, inner = shape
+    x = weight_like(shape, dtype, 21 + axis)
+    got = ops.reduce_amax(x.to(DEV), axis=(0, 2))
+    want = oracle.reduce_amax_axis(x, outer, axis, inner)
+    assert_bits_equal(got.float().cpu().reshape(-1), want, f"amax_axis {shape}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("bits,unsigned,narrow", [(8, False, True), (4, False, False), (3, False, True),
+                                                  (8, True, False), (11, False, False)])
+def test_fake_quant_int_vs_oracle(dtype, bits, unsigned, narrow):
+    x = weight_like((129, 520), dtype, 31 + bits)
+    x[0, :6] = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), float("nan"), 1e-30]).to(dtype)
+    if unsigned:
+        x = x.abs()
+    # scalar
+    amax = x[torch.isfinite(x)].abs().max().float().reshape(1)
+    got = ops.fake_tensor_quant(x.to(DEV), amax.to(DEV), bits, unsigned, narrow)
+    assert_bits_equal(got, oracle.fake_quant_int(x, amax, bits, unsigned, narrow), "scalar")
+    # per row (axis 0) and per column (axis 1)
+    xf = torch.nan_to_num(x.float(), nan=0.0, posinf=0.0, neginf=0.0)
+    am0 = xf.abs().amax(dim=1, keepdim=True)
+    got = ops.fake_tensor_quant(x.to(DEV), am0.to(DEV), bits, unsigned, narrow)
+    want = oracle.fake_quant_int(x, am0, bits, unsigned, narrow, axis_size=x.shape[0], inner=x.shape[1], per_axis=True)
+    assert_bits_equal(got, want, "axis0")
+    am1 = xf.abs().amax(dim=0, keepdim=True)
+    got = ops.fake_tensor_quant(x.to(DEV), am1.to(DEV), bits, unsigned, narrow)
+    want = oracle.fake_quant_int(x, am1, bits, unsigned, narrow, axis_size=x.shape[1], inner=1, per_axis=True)
+    assert_bits_equal(got, want, "axis1")
+    # zero / tiny amax
+    for a in (0.0, 2.0 ** -24, 2.0 ** -23):
+        am = torch.tensor([a])
+        assert_bits_equal(ops.fake_tensor_quant(x.to(DEV), am.to(DEV), bits, unsigned, narrow),
+                          oracle.fake_quant_int(x, am, bits, unsigned, narrow), f"tiny amax {a}")
+    # in place
+    xd = x.to(DEV).clone()
+    ops.fake_tensor_quant(xd, amax.to(DEV), bits, unsigned, narrow, inplace=True)
+    assert_bits_equal(xd, oracle.fake_quant_int(x, amax, bits, unsigned, narrow), "inplace")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fp8_vs_oracle_dense_sweep(dtype):
+    """Every bf16 / f16 bit pattern (and 1M random f32) through the E4M3 QDQ, several amax values."""
+    if dtype == torch.float32:
+        x = torch.randn(1 << 20, generator=torch.Generator().manual_seed(3)) * torch.logspace(-6, 4, 1 << 20)
+    else:
+        x = torch.arange(0, 1 << 16, dtype=torch.int32).to(torch.int16).view(dtype)
+    for a in (None, 1.0, 3.0, 448.0, 0.017, 1e-8, 57344.0):
+        amax = None if a is None else torch.tensor([a])
+        got = ops.scaled_e4m3(x.to(DEV), None if amax is None else amax.to(DEV))
+        want = oracle.fake_quant_e4m3(x, amax)
+        assert_bits_equal(got, want, f"fp8 {dtype} amax={a}")
+    xw = weight_like((64, 264), dtype, 77)
+    am = xw.float().abs().amax(dim=1, keepdim=True)
+    got = ops.scaled_e4m3(xw.to(DEV), am.to(DEV))
+    assert_bits_equal(got, oracle.fake_quant_e4m3(xw, am, axis_size=64, inner=264, per_axis=True), "fp8 axis0")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("g", [16, 32, 128, 256])
+@pytest.mark.parametrize("bits", [4, 8])
+def test_fused_group_vs_oracle(dtype, g, bits):
+    for rows, cols in [(3, g), (64, 4 * g), (96, 8192 // g * g + g)]:
+        x = weight_like((rows, cols), dtype, 41 + g + rows)
+        x[0, :2] = torch.tensor([float("nan"), float("inf")]).to(dtype)
+        if rows > 3:
+            x[1, :g] = 0  # an all-zero group
+        y, am = ops.amax_qdq_int_group(x.to(DEV), g, num_bits=bits, narrow_range=False)
+        wy, wam = oracle.amax_qdq_int_group(x, g, num_bits=bits, narrow_range=False)
+        assert_bits_equal(am.cpu(), wam, f"group amax g={g} {rows}x{cols}")
+        assert_bits_equal(y, wy, f"group qdq g={g} {rows}x{cols}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("fmt", ["E2M1", "E3M2", "E2M3", "E4M3", "E5M2", "INT8", "E1M2", "E0M3", "E3M0"])
+def test_mx_vs_oracle(dtype, fmt):
+    for shape, bs in [((16, 64), 32), ((8, 32), 8), ((5, 40), 16), ((3, 7, 50), 32), ((130, 4096), 32)]:
+        g_ = torch.Generator().manual_seed(hash((fmt, bs)) % 1000)
+        x = (torch.randn(*shape, generator=g_) * torch.exp(2 * torch.randn(*shape, generator=g_))).to(dtype)
+        x.view(-1)[:5] = torch.tensor([0.0, -0.0, float("inf"), float("nan"), 6.0]).to(dtype)
+        got = ops.fused_amax_convert(x.to(DEV), bs, fmt)
+        want = oracle.mx_fused_amax_convert(x, bs, fmt)
+        assert_bits_equal(got, want, f"mx {fmt} {shape} bs={bs}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mask_vs_oracle(dtype):
+    for shape in [(8, 16), (64, 4096), (33, 20), (1, 4)]:
+        w = weight_like(shape, dtype, 51 + shape[1])
+        w2 = torch.randint(-2, 3, shape, generator=torch.Generator().manual_seed(1)).to(dtype)
+        for t in (w, w2):
+            got = ops.mask_2to4(t.to(DEV)).cpu()
+            assert torch.equal(got, oracle.mask_2to4(t)), f"mask {shape}"
+            assert (got.view(-1, 4).sum(1) == 2).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_int4_pack_vs_oracle(dtype):
+    for shape, g in [((64, 256), 128), ((7, 64), 32), ((16, 4096), 128)]:
+        w = weight_like(shape, dtype, 61 + g)
+        scales = (7 / w.reshape(-1, g).abs().amax(dim=1, keepdim=True)).to(dtype)
+        for rounding in (0, 1):
+            got = ops.int4_quantize(w.reshape(-1).to(DEV), scales.reshape(-1).to(DEV), g, rounding).cpu()
+            assert torch.equal(got, oracle.int4_pack(w.reshape(-1), scales.reshape(-1), g, rounding)), \
+                f"int4 pack {shape} rounding={rounding}"
+        q = oracle.int4_pack(w.reshape(-1), scales.reshape(-1), g, 0)
+        deq = ops.int4_dequantize(q.to(DEV), scales.reshape(-1).to(DEV), g).cpu()
+        assert_bits_equal(deq, oracle.int4_unpack(q, scales.reshape(-1), g), f"int4 unpack {shape}")
+        if shape[0] % 2 == 0:
+            wsf = w.reshape(shape[0], -1, g).abs().amax(-1).float() / 7.0
+            got = ops.pack_int4_in_uint8(w.to(DEV), wsf.to(DEV)).cpu()
+            assert torch.equal(got, oracle.int4_pack_export(w, wsf)), f"export pack {shape}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_col_stats_and_scale_vs_oracle(dtype):
+    g_ = torch.Generator().manual_seed(71)
+    x = (torch.randn(300, 4096, generator=g_) * torch.exp(torch.randn(4096, generator=g_))).to(dtype)
+    ssum, amax = ops.col_abs_stats(x.to(DEV))
+    s64, am = oracle.col_abs_stats(x)
+    assert_bits_equal(amax.cpu(), am, "col amax")
+    rel = ((ssum.cpu().double() - s64).abs() / s64.clamp_min(1e-30)).max().item()
+    assert rel < 1e-5, f"col sum rel err {rel}"  # fp32 two-stage sum vs fp64: tolerance 1e-5 relative
+    # accumulate over two batches == one pass over the concatenation
+    s2, a2 = ops.col_abs_stats(x[:100].to(DEV))
+    ops.col_abs_stats(x[100:].to(DEV), sum_out=s2, amax_out=a2, accumulate=True)
+    assert_bits_equal(a2.cpu(), am, "col amax accumulate")
+    assert ((s2.cpu().double() - s64).abs() / s64.clamp_min(1e-30)).max().item() < 1e-5
+    w = weight_like((64, 4096), dtype, 72)
+    s = torch.exp(torch.randn(4096, generator=g_) * 0.5)
+    assert_bits_equal(ops.scale_cols(w.to(DEV), s.to(DEV)), oracle.scale_cols(w, s), "scale_cols")
+    assert_bits_equal(ops.awq_scale_qdq(w.to(DEV), s.to(DEV), 128, 4), oracle.awq_scale_qdq(w, s.to(dtype), 128, 4),
+                      "awq_scale_qdq")
+
+
+# ------------------------------------------------------------------------------------------ multi-tensor
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_multi_tensor_matches_single(dtype):
+    shapes = [(64, 256), (3, 8192), (17, 128), (1, 128), (100, 4096), (1024, 1024)]
+    ws = [weight_like(s, dtype, 81 + i).to(DEV) for i, s in enumerate(shapes)]
+    tab = moa.multi_tensor.SegmentTable(ws)
+    am = tab.calibrate_amax().cpu()
+    for i, w in enumerate(ws):
+        assert_bits_equal(am[i].reshape(()), oracle.reduce_amax(w.cpu()).reshape(()), f"mt amax {i}")
+    outs = tab.fake_quant_e4m3()
+    for i, w in enumerate(ws):
+        assert_bits_equal(outs[i], oracle.fake_quant_e4m3(w.cpu(), am[i:i + 1]), f"mt fp8 {i}")
+    outs = tab.fake_quant_int(8, False, True)
+    for i, w in enumerate(ws):
+        assert_bits_equal(outs[i], oracle.fake_quant_int(w.cpu(), am[i:i + 1], 8, False, True), f"mt int8 {i}")
+    tabg = moa.multi_tensor.SegmentTable(ws, group_size=128)
+    outs = tabg.amax_qdq_int_group(4, False, False)
+    for i, w in enumerate(ws):
+        wy, wam = oracle.amax_qdq_int_group(w.cpu(), 128, num_bits=4, narrow_range=False)
+        assert_bits_equal(outs[i], wy, f"mt group qdq {i}")
+        assert_bits_equal(tabg.amax[i].cpu(), wam, f"mt group amax {i}")
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_llama70b_tensor():
+    """BASELINE-size tensor (28672 x 8192 bf16, Llama-3-70B gate/up): size-independent properties."""
+    torch.manual_seed(1234)
+    w = (torch.randn(28672, 8192, device=DEV) * 0.02).to(torch.bfloat16)
+    y, am = ops.amax_qdq_int_group(w, 128, num_bits=4, narrow_range=False)
+    # (1) group amax == torch's own reduction
+    assert torch.equal(am, w.view(-1, 128).abs().amax(dim=1).float())
+    # (2) idempotence: QDQ of the QDQ output with the same amax is a fixed point
+    y2 = ops.fake_tensor_quant(y.view(-1, 128), am.view(-1, 1), 4, False, False).view_as(y)
+    assert torch.equal(y2, y)
+    # (3) at most 16 distinct values per group, error bounded by half a step
+    step = (am / 7).view(-1, 1)
+    err = (y.view(-1, 128).float() - w.view(-1, 128).float()).abs()
+    assert (err <= step * 0.5 + step * 2.0 ** -7).all()
+    # (4) spot-check a slice bit-exactly against the oracle
+    sl = w[1000:1016].cpu()
+    wy, _ = oracle.amax_qdq_int_group(sl, 128, num_bits=4, narrow_range=False)
+    assert_bits_equal(y[1000:1016], wy, "slice vs oracle")
+    # (5) per-tensor amax == max of group amax; FP8 QDQ idempotent
+    a = ops.reduce_amax(w)
+    assert a.float().item() == am.max().item()
+    f1 = ops.scaled_e4m3(w, a.float())
+    assert torch.equal(ops.scaled_e4m3(f1, a.float()), f1)
+    # (6) 2:4 mask keeps exactly 2 of 4 and never drops the largest magnitude of a group
+    m = ops.mask_2to4(w)
+    assert (m.view(-1, 4).sum(1) == 2).all()
+    wa = w.view(-1, 4).abs().float()
+    assert (m.view(-1, 4).gather(1, wa.argmax(1, keepdim=True))).all()
