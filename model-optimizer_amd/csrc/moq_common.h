@@ -229,11 +229,23 @@ __device__ __forceinline__ uint32_t pack_absmax(const Pack16& p) {
 // butterfly max over aligned sub-groups of `WIDTH` lanes (WIDTH power of two <= 64): every lane of the
 // group ends with the group's max.  xor-shuffles of 1/2 lower to DPP quad_perm, 4/8 to DPP row ops,
 // 16 to row_bcast/permlane, 32 to v_permlane32_swap / readlane on gfx950.
+// DPP controls: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror.  Once both lanes of a pair
+// (then all 4 of a quad, all 8 of a half row) hold the same value, the mirrors act as xor-4 / xor-8, so a
+// 16-lane max costs four full-rate VALU ops and never touches the LDS crossbar (ds_bpermute).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
 template <int WIDTH>
 __device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+  uint32_t o;
+  if constexpr (WIDTH >= 2) { o = dpp_u32<0xB1>(v); v = o > v ? o : v; }
+  if constexpr (WIDTH >= 4) { o = dpp_u32<0x4E>(v); v = o > v ? o : v; }
+  if constexpr (WIDTH >= 8) { o = dpp_u32<0x141>(v); v = o > v ? o : v; }
+  if constexpr (WIDTH >= 16) { o = dpp_u32<0x140>(v); v = o > v ? o : v; }
 #pragma unroll
-  for (int off = 1; off < WIDTH; off <<= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+  for (int off = 16; off < WIDTH; off <<= 1) {  // across 16-lane rows: LDS-crossbar shuffle
+    o = (uint32_t)__shfl_xor((int)v, off, 64);
     v = o > v ? o : v;
   }
   return v;
@@ -268,6 +280,44 @@ __host__ __device__ __forceinline__ IntQ make_intq(int num_bits, int is_unsigned
 // scale for INT-k: bound / amax, 0 flags "amax <= eps" (outputs are then 0, tensor_quant.py:629-642)
 __device__ __forceinline__ float int_scale(float amax, float bound) {
   return amax <= kAmaxEps ? 0.0f : bound / amax;
+}
+// Division of many numerators by ONE denominator (all elements of a quantization group share `scale`).
+// The refined reciprocal y = rcp(d) + one Newton step is computed once; each quotient then costs five
+// full-rate FMAs: q0 = n*y, two residual corrections -- the same Markstein sequence the compiler emits
+// for `/` (v_div_scale / v_rcp / v_fma x4 / v_div_fmas / v_div_fixup) minus the per-element rcp (quarter
+// rate) and scaling ops.  The final fma(r1, y, q1) is correctly rounded when no intermediate over- or
+// underflows, which holds for d in [2^-60, 2^60] and |n| <= 2^16 (results are never subnormal there);
+// outside that window the plain IEEE division is used.  Bit-equality with `/` is checked on the GPU by
+// tests/test_gpu_parity.py::test_shared_division_exact.
+struct SharedDiv {
+  float d, y;
+  bool fast;
+};
+__device__ __forceinline__ SharedDiv make_shared_div(float d) {
+  SharedDiv r;
+  r.d = d;
+  const float a = __builtin_fabsf(d);
+  r.fast = (a >= 0x1p-60f) && (a <= 0x1p60f);
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, y0, 1.0f);
+  r.y = __builtin_fmaf(y0, e, y0);
+  return r;
+}
+__device__ __forceinline__ float shared_div(float n, const SharedDiv& s) {
+  if (!s.fast) return n / s.d;
+  const float q0 = n * s.y;
+  const float r0 = __builtin_fmaf(-s.d, q0, n);
+  const float q1 = __builtin_fmaf(r0, s.y, q0);
+  const float r1 = __builtin_fmaf(-s.d, q1, n);
+  return __builtin_fmaf(r1, s.y, q1);
+}
+// INT-k QDQ with a group-shared scale: same arithmetic as qdq_int, division through SharedDiv
+__device__ __forceinline__ float qdq_int_shared(float x, float scale, const SharedDiv& sd, const IntQ& q) {
+  float p = x * scale;
+  float t = __builtin_rintf(p);
+  t = __builtin_fminf(__builtin_fmaxf(t, q.lo), q.hi);
+  t = (p != p) ? p : t;
+  return scale == 0.0f ? t : shared_div(t, sd);
 }
 __device__ __forceinline__ float qdq_int(float x, float scale, const IntQ& q) {
   // rint(x*scale), clamp, then IEEE divide by the same scale; scale == 0 encodes the tiny-amax case where

@@ -89,10 +89,15 @@ __device__ __forceinline__ bool aligned16(const void* p) {
 struct OpIntQdq {  // a6 with one scalar amax
   float scale;
   IntQ q;
+  SharedDiv sd;
+  __device__ __forceinline__ void set(float amax) {
+    scale = int_scale(amax, q.hi);
+    sd = make_shared_div(scale);
+  }
   __device__ __forceinline__ void operator()(float* f, int n) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < n) f[i] = qdq_int(f[i], scale, q);
+      if (i < n) f[i] = qdq_int_shared(f[i], scale, sd, q);
   }
 };
 struct OpFp8Qdq {  // a7 with one scalar amax
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void map_scalar_amax_kernel(const void* __r
   Op op;
   if constexpr (__is_same(Op, OpIntQdq)) {
     op.q = make_intq(num_bits, is_unsigned, narrow);
-    op.scale = int_scale(amax[0], op.q.hi);
+    op.set(amax[0]);
   } else if constexpr (__is_same(Op, OpFp8Qdq)) {
     op.sc = fp8_scale(amax[0]);
   }
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void map_axis_amax_kernel(const void* __res
         } else {
           OpIntQdq op;
           op.q = q;
-          op.scale = int_scale(a, q.hi);
+          op.set(a);
           op(f, V);
         }
       } else {
@@ -331,8 +336,9 @@ __device__ __forceinline__ void group_chunk(const void* __restrict__ x, void* __
     if (amax_out != nullptr && (threadIdx.x & (LPG - 1)) == 0) amax_out[e / G] = amax;
     if constexpr (QDQ) {
       const float scale = int_scale(amax, q.hi);
+      const SharedDiv sd = make_shared_div(scale);
 #pragma unroll
-      for (int i = 0; i < V; ++i) f[i] = qdq_int(f[i], scale, q);
+      for (int i = 0; i < V; ++i) f[i] = qdq_int_shared(f[i], scale, sd, q);
       st_packet<DT, true>(y, e, 0, pack<DT>(f));
     }
   }
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restric
       cur = s;
       if constexpr (__is_same(Op, OpIntQdq)) {
         op.q = make_intq(num_bits, is_unsigned, narrow);
-        op.scale = int_scale(sg.amax[0], op.q.hi);
+        op.set(sg.amax[0]);
       } else {
         op.sc = fp8_scale(sg.amax[0]);
       }
