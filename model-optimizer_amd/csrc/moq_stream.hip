@@ -12,6 +12,8 @@
 // Roofline: every kernel here is HBM-bound.  Algorithmic bytes per element (bf16): amax 2; QDQ 4;
 // fused group amax+QDQ 4 + 4/g.  VALU cost per element (~30 lane-ops incl. the IEEE divide) stays under
 // the ~50 lane-ops/element a CU can issue at the HBM rate, so the divide is kept exact, not approximated.
+#include <stdlib.h>
+
 #include "moq_common.h"
 
 namespace moq {
@@ -35,7 +37,9 @@ __device__ __forceinline__ Pack16 ld_packet(const void* base, int64_t e, int64_t
   constexpr int V = Elem<DT>::kVec;
   constexpr int ES = 16 / V;
   if constexpr (FAST) {
-    return load16(reinterpret_cast<const char*>(base) + e * ES);
+    // streaming data is read exactly once: non-temporal hint (measured on MI355X, 14 GiB streams:
+    // read-only 6.2 -> 7.0 TB/s, copy 5.9 -> 6.5 TB/s; tools/exp/stream_probe.hip)
+    return load16_nt(reinterpret_cast<const char*>(base) + e * ES);
   } else {
     float f[V];
 #pragma unroll
@@ -61,7 +65,7 @@ __device__ __forceinline__ void st_packet(void* base, int64_t e, int64_t n, cons
   constexpr int V = Elem<DT>::kVec;
   constexpr int ES = 16 / V;
   if constexpr (FAST) {
-    store16(reinterpret_cast<char*>(base) + e * ES, p);
+    store16_nt(reinterpret_cast<char*>(base) + e * ES, p);
   } else {
     if constexpr (DT == MOQ_F32) {
       float* b = reinterpret_cast<float*>(base);
@@ -412,6 +416,36 @@ __device__ __forceinline__ ChunkRange block_range(int64_t n_chunks) {
   r.end = r.begin + per < n_chunks ? r.begin + per : n_chunks;
   return r;
 }
+// Cursor over the segment table: the current tensor's fields stay in (scalar) registers and are reloaded
+// only when a workgroup's chunk index crosses into another tensor, so the vector loads of a chunk never
+// wait on a table lookup.
+struct SegCursor {
+  const moq_seg* segs;
+  const int64_t* blk_start;
+  int s;
+  int64_t c_begin, c_end;  // chunk range of the current segment
+  moq_seg sg;
+  bool aligned;
+  __device__ __forceinline__ void init(const moq_seg* sgs, const int64_t* bs, int n_seg, int64_t chunk) {
+    segs = sgs;
+    blk_start = bs;
+    s = find_segment(bs, n_seg, chunk);
+    load();
+  }
+  __device__ __forceinline__ void load() {
+    c_begin = blk_start[s];
+    c_end = blk_start[s + 1];
+    sg = segs[s];
+    aligned = aligned16(sg.x) && aligned16(sg.y);
+  }
+  // returns true when the segment changed (chunk indices only ever grow)
+  __device__ __forceinline__ bool seek(int64_t chunk) {
+    if (chunk < c_end) return false;
+    do { ++s; } while (chunk >= blk_start[s + 1]);
+    load();
+    return true;
+  }
+};
 
 template <int DT>
 __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restrict__ segs,
@@ -420,25 +454,25 @@ __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restri
   __shared__ uint32_t smem[kBlock / 64];
   const ChunkRange r = block_range(n_chunks);
   if (r.begin >= r.end) return;
-  int s = find_segment(blk_start, n_seg, r.begin);
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, r.begin);
   uint32_t acc = 0;
   for (int64_t c = r.begin; c < r.end; ++c) {
-    if (c >= blk_start[s + 1]) {  // crossed into the next tensor: flush
+    if (c >= cur.c_end) {  // crossed into the next tensor: flush the finished one
       acc = block_max_u32(acc, smem);
-      if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(segs[s].amax), acc);
+      if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(cur.sg.amax), acc);
       __syncthreads();
       acc = 0;
-      while (c >= blk_start[s + 1]) ++s;
+      cur.seek(c);
     }
-    const moq_seg sg = segs[s];
-    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
-    if (aligned16(sg.x) && e0 + MOQ_MT_CHUNK <= sg.n)
-      acc = chunk_absmax<DT, true>(sg.x, e0, sg.n, acc);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    if (cur.aligned && e0 + MOQ_MT_CHUNK <= cur.sg.n)
+      acc = chunk_absmax<DT, true>(cur.sg.x, e0, cur.sg.n, acc);
     else
-      acc = chunk_absmax<DT, false>(sg.x, e0, sg.n, acc);
+      acc = chunk_absmax<DT, false>(cur.sg.x, e0, cur.sg.n, acc);
   }
   acc = block_max_u32(acc, smem);
-  if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(segs[s].amax), acc);
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(cur.sg.amax), acc);
 }
 
 __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg) {
@@ -446,33 +480,36 @@ __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg)
   if (i < n_seg) segs[i].amax[0] = 0.0f;
 }
 
+// Copy-shaped passes (read + write) run fastest when the workgroups sweep memory as one dense window:
+// chunk = blockIdx + k * gridDim with a large grid (few chunks per workgroup), 6.6 vs 5.4 TB/s for the
+// contiguous-run order on this chip (tools/exp/stream_probe.hip).  Chunks visited by a workgroup grow
+// monotonically, so the segment cursor only ever advances.
 template <int DT, class Op>
 __global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restrict__ segs,
                                                         const int64_t* __restrict__ blk_start,
                                                         int n_seg, int64_t n_chunks, int num_bits,
                                                         int is_unsigned, int narrow) {
-  const ChunkRange r = block_range(n_chunks);
-  if (r.begin >= r.end) return;
-  int s = find_segment(blk_start, n_seg, r.begin);
-  int cur = -1;
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
   Op op;
-  for (int64_t c = r.begin; c < r.end; ++c) {
-    while (c >= blk_start[s + 1]) ++s;
-    const moq_seg sg = segs[s];
-    if (cur != s) {
-      cur = s;
+  bool fresh = true;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    fresh |= cur.seek(c);
+    if (fresh) {
+      fresh = false;
       if constexpr (__is_same(Op, OpIntQdq)) {
         op.q = make_intq(num_bits, is_unsigned, narrow);
-        op.set(sg.amax[0]);
+        op.set(cur.sg.amax[0]);
       } else {
-        op.sc = fp8_scale(sg.amax[0]);
+        op.sc = fp8_scale(cur.sg.amax[0]);
       }
     }
-    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
-    if (aligned16(sg.x) && aligned16(sg.y) && e0 + MOQ_MT_CHUNK <= sg.n)
-      chunk_apply<DT, true>(sg.x, sg.y, e0, sg.n, op);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    if (cur.aligned && e0 + MOQ_MT_CHUNK <= cur.sg.n)
+      chunk_apply<DT, true>(cur.sg.x, cur.sg.y, e0, cur.sg.n, op);
     else
-      chunk_apply<DT, false>(sg.x, sg.y, e0, sg.n, op);
+      chunk_apply<DT, false>(cur.sg.x, cur.sg.y, e0, cur.sg.n, op);
   }
 }
 
@@ -483,20 +520,19 @@ __global__ __launch_bounds__(kBlock) void mt_group_kernel(const moq_seg* __restr
                                                           int is_unsigned, int narrow) {
   constexpr int G = LPG * Elem<DT>::kVec;
   const IntQ q = make_intq(num_bits, is_unsigned, narrow);
-  const ChunkRange r = block_range(n_chunks);
-  if (r.begin >= r.end) return;
-  int s = find_segment(blk_start, n_seg, r.begin);
-  for (int64_t c = r.begin; c < r.end; ++c) {
-    while (c >= blk_start[s + 1]) ++s;
-    const moq_seg sg = segs[s];
-    const int64_t e0 = (c - blk_start[s]) * MOQ_MT_CHUNK;
-    if (aligned16(sg.x) && aligned16(sg.y) && e0 + MOQ_MT_CHUNK <= sg.n) {
-      group_chunk<DT, LPG, true, false>(sg.x, sg.y, sg.amax, e0, q, nullptr, 0);
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    cur.seek(c);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    if (cur.aligned && e0 + MOQ_MT_CHUNK <= cur.sg.n) {
+      group_chunk<DT, LPG, true, false>(cur.sg.x, cur.sg.y, cur.sg.amax, e0, q, nullptr, 0);
     } else {
       const int64_t g0 = e0 / G;
-      const int64_t g1 = (e0 + MOQ_MT_CHUNK < sg.n ? e0 + MOQ_MT_CHUNK : sg.n) / G;
+      const int64_t g1 = (e0 + MOQ_MT_CHUNK < cur.sg.n ? e0 + MOQ_MT_CHUNK : cur.sg.n) / G;
       for (int64_t grp = g0 + threadIdx.x; grp < g1; grp += kBlock)
-        group_scalar<DT, true, false>(sg.x, sg.y, sg.amax, grp, G, q, nullptr, 0);
+        group_scalar<DT, true, false>(cur.sg.x, cur.sg.y, cur.sg.amax, grp, G, q, nullptr, 0);
     }
   }
 }
@@ -509,6 +545,18 @@ __global__ __launch_bounds__(kBlock) void mt_group_kernel(const moq_seg* __restr
 using namespace moq;
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int mt_grid(int64_t n_chunks) { return (int)(n_chunks < 2048 ? n_chunks : 2048); }  // reductions
+// copy-shaped passes: ~8 chunks per workgroup, at least a full machine (2048), at most 128 Ki workgroups
+static int copy_grid(int64_t n_chunks) {
+  static const int64_t div = [] { const char* e = getenv("MOQ_TUNE_CHUNKS_PER_WG"); return e ? atoll(e) : 8LL; }();
+  int64_t g = n_chunks / (div > 0 ? div : 8);
+  if (g < 2048) g = 2048;
+  if (g > 131072) g = 131072;
+  if (g > n_chunks) g = n_chunks;
+  return (int)(g < 1 ? 1 : g);
+}
+
 
 extern "C" int moq_amax(const void* x, int64_t n, int dt, float* out, int accumulate, void* stream) {
   if (out == nullptr || n < 0 || (n > 0 && x == nullptr)) {
@@ -540,7 +588,7 @@ static int launch_map(const void* x, void* y, int64_t n, int dt, const float* am
     return MOQ_ERR_INVALID;
   }
   if (n == 0) return MOQ_OK;
-  const int grid = stream_grid(MOQ_MT_CHUNK, n);
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
   if (amax_mode == MOQ_AMAX_SCALAR) {
     if (amax == nullptr) {
       if (!FP8) {
@@ -622,7 +670,7 @@ int launch_group(const void* x, void* y, float* amax_out, int64_t n_groups, int 
     return MOQ_ERR_INVALID;
   }
   const int lpg = g / vec;
-  const int grid = stream_grid(MOQ_MT_CHUNK, n_groups * (int64_t)g);
+  const int grid = copy_grid((n_groups * (int64_t)g + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
 #define MOQ_LAUNCH_GROUP(QDQ, PRE)                                                                   \
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((group_kernel<DT, LPG, QDQ, PRE>),  \
                                                                   dim3(grid), dim3(kBlock), 0,        \
@@ -685,8 +733,6 @@ static int mt_check(const moq_seg* segs, const int64_t* blk_start, int n_seg, in
   }
   return MOQ_OK;
 }
-static int mt_grid(int64_t n_chunks) { return (int)(n_chunks < 2048 ? n_chunks : 2048); }
-
 extern "C" int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
                            int dt, void* stream) {
   int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_amax");
@@ -703,7 +749,7 @@ extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_st
                                       int64_t n_chunks, int dt, void* stream) {
   int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_e4m3");
   if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpFp8Qdq>), dim3(mt_grid(n_chunks)),
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpFp8Qdq>), dim3(copy_grid(n_chunks)),
                                             dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
                                             0, 0, 0));
   return check_launch("moq_mt_fake_quant_e4m3");
@@ -718,7 +764,7 @@ extern "C" int moq_mt_fake_quant_int(const moq_seg* segs, const int64_t* blk_sta
     set_error("moq_mt_fake_quant_int: num_bits=%d out of range", num_bits);
     return MOQ_ERR_INVALID;
   }
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpIntQdq>), dim3(mt_grid(n_chunks)),
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpIntQdq>), dim3(copy_grid(n_chunks)),
                                             dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
                                             num_bits, is_unsigned, narrow_range));
   return check_launch("moq_mt_fake_quant_int");
@@ -736,7 +782,7 @@ extern "C" int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk
   }
   const int lpg = g / vec;
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((mt_group_kernel<DT, LPG>),
-                                                                  dim3(mt_grid(n_chunks)), dim3(kBlock),
+                                                                  dim3(copy_grid(n_chunks)), dim3(kBlock),
                                                                   0, S(stream), segs, blk_start, n_seg,
                                                                   n_chunks, num_bits, is_unsigned,
                                                                   narrow_range)));

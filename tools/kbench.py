@@ -1,0 +1,78 @@
+"""Per-kernel throughput table on one MI355X: every C-ABI kernel on Llama-3-70B-sized tensors.
+Algorithmic bytes (SURVEY.md 8d / DESIGN.md) divided by the HIP-event time of the launch.
+Usage (GPU box): python tools/kbench.py [> profiles/rNN_kernel_table.md]"""
+
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _moa_import  # noqa: E402
+
+moa = _moa_import.load()
+ops = moa.ops
+DEV = "cuda:0"
+PEAK = 8000.0
+
+
+def timed(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    torch.manual_seed(1234)
+    rows, cols = 28672, 8192  # Llama-3-70B gate/up projection
+    w = (torch.randn(rows, cols, device=DEV) * 0.02).to(torch.bfloat16)
+    n = w.numel()
+    x = torch.randn(8 * 512, 8192, device=DEV).to(torch.bfloat16)  # activation batch [B*S, H]
+    nx = x.numel()
+    amax1 = ops.reduce_amax(w).float().reshape(1)
+    am_g = ops.reduce_amax(w.view(-1, 128), axis=(1,)).float()
+    am_c = ops.reduce_amax(w, axis=(1,)).float()
+    s_col = torch.rand(cols, device=DEV) + 0.5
+    scales = (7 / am_g).to(torch.bfloat16).reshape(-1)
+    wsf = (am_g / 7).reshape(rows, cols // 128)
+    q4 = ops.int4_quantize(w.view(-1), scales, 128)
+    counts = torch.zeros(2048, dtype=torch.int64, device=DEV)
+    xmax = float(x.float().abs().max())
+    cases = [
+        ("moq_amax (per-tensor)", lambda: ops.reduce_amax(w), 2 * n),
+        ("moq_amax_axis rows (per-channel, axis 0)", lambda: ops.reduce_amax(w, axis=(1,)), 2 * n),
+        ("moq_amax_axis groups g=128 (static per-group)", lambda: ops.reduce_amax(w.view(-1, 128), axis=(1,)), 2 * n + 4 * n / 128),
+        ("moq_amax_axis columns (activation per-channel)", lambda: ops.reduce_amax(x, axis=(0,)), 2 * nx),
+        ("moq_col_abs_stats (act sum + amax)", lambda: ops.col_abs_stats(x), 2 * nx),
+        ("moq_fake_quant_int INT8 per-tensor", lambda: ops.fake_tensor_quant(w, amax1, 8, False, True), 4 * n),
+        ("moq_fake_quant_int INT8 per-channel", lambda: ops.fake_tensor_quant(w, am_c.view(-1, 1), 8, False, True), 4 * n),
+        ("moq_fake_quant_int INT4 static g=128", lambda: ops.fake_tensor_quant(w.view(-1, 128), am_g.view(-1, 1), 4, False, False), 4 * n + 4 * n / 128),
+        ("moq_amax_qdq_int_group INT4 g=128 (fused)", lambda: ops.amax_qdq_int_group(w, 128, 4), 4 * n + 4 * n / 128),
+        ("moq_fake_quant_e4m3 per-tensor", lambda: ops.scaled_e4m3(w, amax1), 4 * n),
+        ("moq_fake_quant_e4m3 per-channel", lambda: ops.scaled_e4m3(w, am_c.view(-1, 1)), 4 * n),
+        ("moq_mx_fused_amax_convert MXFP4 g=32", lambda: ops.fused_amax_convert(w, 32, "E2M1"), 4 * n),
+        ("moq_mx_fused_amax_convert MXFP8 e4m3 g=32", lambda: ops.fused_amax_convert(w, 32, "E4M3"), 4 * n),
+        ("moq_awq_scale_qdq INT4 g=128", lambda: ops.awq_scale_qdq(w, s_col, 128, 4), 4 * n),
+        ("moq_scale_cols", lambda: ops.scale_cols(w, s_col), 4 * n),
+        ("moq_mask_2to4", lambda: ops.mask_2to4(w), 3 * n),
+        ("moq_int4_pack (qtensor)", lambda: ops.int4_quantize(w.view(-1), scales, 128), 2.5 * n + 2 * n / 128),
+        ("moq_int4_unpack (qtensor)", lambda: ops.int4_dequantize(q4, scales, 128), 2.5 * n + 2 * n / 128),
+        ("moq_int4_pack_export", lambda: ops.pack_int4_in_uint8(w, wsf), 2.5 * n + 4 * n / 128),
+        ("moq_hist_abs 2048 bins", lambda: ops.hist_abs(x, 2048, xmax, False, counts), 2 * nx),
+    ]
+    print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
+    print("|---|---|---|---|")
+    for name, fn, nbytes in cases:
+        ms = timed(fn)
+        gbs = nbytes / ms / 1e6
+        print(f"| {name} | {ms:.3f} | {gbs:.0f} | {gbs / PEAK:.3f} |")
+
+
+if __name__ == "__main__":
+    main()
