@@ -191,6 +191,11 @@ int moq_scale_cols(const void* w, const float* s, void* y, int64_t rows, int64_t
  * amax + INT-k QDQ of t.  cols % g == 0.  Replaces model_calib.py:1552-1554 weight side. */
 int moq_awq_scale_qdq(const void* w, const void* s, void* y, int64_t rows, int64_t cols, int g, int dt,
                       int num_bits, void* stream);
+/* AWQ weight scale: out[c] = dtype(mean_r dtype(|w[r,c]| / dtype(gamax[r, c/g] + tiny_dtype))) as fp32,
+ * gamax = abs-max of the g-column group (get_weight_scale, quantization/model_calib.py:1453-1469).
+ * `partial`: caller-provided fp32 workspace of moq_col_stats_workspace(rows, cols) floats. */
+int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, int g, int dt, float* out,
+                         float* partial, void* stream);
 /* Column abs statistics of an activation batch x[tokens, cols]: sum_out[c] (+)= sum_t |x[t,c]| (fp32,
  * deterministic two-stage; `partial` is caller-provided fp32 workspace of moq_col_stats_workspace()
  * floats) and, if amax_out != NULL, amax_out[c] = max(amax_out[c], max_t |x[t,c]|).

@@ -2,14 +2,32 @@
 
 Python host (torch for memory/streams/distributed) over hand-written gfx950 HIP kernels behind the C-ABI of
 libmoquant.so (include/moquant.h).  Mirrors the reference's plugin surface for this path:
-  ops            -- functional ops (reduce_amax, fake_tensor_quant, scaled_e4m3, dynamic_block_quant, ...)
-  multi_tensor   -- whole-model weight passes through a segment table
-No CPU fallback exists: every op raises if the HIP library is missing or the tensor is not on the GPU.
+  ops              functional ops (reduce_amax, fake_tensor_quant, scaled_e4m3, dynamic_block_quant, ...)
+  multi_tensor     whole-model weight passes through a segment table (one launch per pass)
+  calib            Max / Histogram / Mse calibrators with device-resident state
+  tensor_quantizer TensorQuantizer (same attributes and life cycle as the reference's)
+  nn, model_quant, model_calib   QuantLinear, quantize(), max_calibrate / smoothquant / awq_lite
+  sparsity         create_asp_mask (2:4 magnitude)
+  distributed      bucketed all-reduce of amax / histograms / AWQ statistics (RCCL via torch.distributed)
+  modelopt_plugin  install() -- the seams into an unmodified modelopt checkout
+No CPU fallback exists: every op raises if the HIP library is missing or a tensor is not on the GPU.
 """
 
 from . import _lib  # noqa: F401
 from ._lib import MoquantError, MoquantUnsupported  # noqa: F401
 from . import ops  # noqa: F401
 from . import multi_tensor  # noqa: F401
+from . import calib  # noqa: F401
+from . import tensor_quantizer  # noqa: F401
+from . import nn  # noqa: F401
+from . import distributed  # noqa: F401
+from . import model_calib  # noqa: F401
+from . import model_quant  # noqa: F401
+from . import sparsity  # noqa: F401
+from . import modelopt_plugin  # noqa: F401
+from .model_quant import quantize  # noqa: F401
+from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
-__all__ = ["ops", "multi_tensor", "MoquantError", "MoquantUnsupported"]
+__all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "distributed", "model_calib", "model_quant",
+           "sparsity", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
+           "MoquantError", "MoquantUnsupported"]

@@ -59,6 +59,7 @@ SIGNATURES = {
     "moq_scale_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "moq_awq_scale_qdq": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                                   c_void_p]),
+    "moq_awq_weight_scale": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "moq_col_stats_workspace": (c_int64, [c_int64, c_int64]),
     "moq_col_abs_stats": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p]),

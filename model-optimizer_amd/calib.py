@@ -1,0 +1,285 @@
+"""Calibrators -- same API as modelopt.torch.quantization.calib (collect / reset / compute_amax), with
+the statistics kept ON THE DEVICE and every pass over the data done by one HIP kernel.
+
+Differences from the reference that do not change results:
+  * MaxCalibrator keeps one fp32 running-max buffer that the kernel updates in place (fused
+    `torch.max(prev, new)`), and the three per-collect asserts of calib/max.py:69-77 (NaN / negative / inf,
+    each a device->host sync) are evaluated ONCE in compute_amax from the accumulated amax itself:
+    abs-max is NaN iff some element was NaN, inf iff some element was inf, never negative.
+  * HistogramCalibrator counts in exact 64-bit integers (torch.histc counts in fp32).
+"""
+
+from __future__ import annotations
+
+import math
+from collections import Counter
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import _reduce_layout
+
+
+class _Calibrator:
+    """calib/calibrator.py:25-69."""
+
+    def __init__(self, num_bits=8, axis=None, unsigned=False):
+        self._num_bits = num_bits
+        self._axis = axis
+        self._unsigned = unsigned
+
+    def collect(self, x):
+        raise NotImplementedError
+
+    def reset(self):
+        raise NotImplementedError
+
+    def compute_amax(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def __repr__(self):
+        return f"num_bits={self._num_bits} axis={self._axis} unsigned={self._unsigned}"
+
+
+def convert_quantization_axis_to_reduce_axis(input, axis):
+    """core_utils.py:128-143."""
+    if axis is None:
+        return None
+    axis = axis if isinstance(axis, (list, tuple)) else [axis]
+    return [i for i in range(input.dim()) if i not in axis and (i - input.dim()) not in axis]
+
+
+class MaxCalibrator(_Calibrator):
+    """Running abs-max, per tensor or per kept axis -- calib/max.py:26-110."""
+
+    def __init__(self, num_bits=8, axis=None, unsigned=False, track_amax=False):
+        super().__init__(num_bits, axis, unsigned)
+        self._track_amax = track_amax
+        self._amaxs = [] if track_amax else None
+        self._buf = None       # fp32 running max on the device (flat)
+        self._shape = None     # shape the reference's amax would have (keepdims=True)
+        self._dtype = None
+
+    @property
+    def amaxs(self):
+        return self._amaxs
+
+    @torch.no_grad()
+    def collect(self, x):
+        reduce_axis = convert_quantization_axis_to_reduce_axis(x, self._axis)
+        nd = x.dim()
+        if reduce_axis is None or len(reduce_axis) == nd:
+            shape = () if reduce_axis is None else ()  # reduce_amax squeezes scalars
+            n = 1
+        else:
+            _, kept, _, keep = _reduce_layout(list(x.shape), reduce_axis)
+            shape = tuple(x.shape[d] if d in keep else 1 for d in range(nd))
+            n = kept
+            if n == 1:
+                shape = ()
+        if self._buf is None:
+            self._buf = torch.zeros(n, dtype=torch.float32, device=x.device)
+            self._shape, self._dtype = shape, x.dtype
+        elif shape != self._shape:
+            raise RuntimeError("amax shape changed!")  # calib/max.py:81-82
+        ops.reduce_amax(x, axis=reduce_axis, out=self._buf, accumulate=True)
+        if self._track_amax:
+            self._amaxs.append(ops.reduce_amax(x, axis=reduce_axis).float().cpu().numpy())
+
+    def reset(self):
+        self._buf = None
+        self._shape = None
+
+    def compute_amax(self):
+        if self._buf is None:
+            return None
+        amax = self._buf.to(self._dtype).reshape(self._shape)
+        # deferred form of the asserts in calib/max.py:69-77 (one sync per quantizer per calibration)
+        bad = torch.stack([torch.isnan(self._buf).any(), torch.isinf(self._buf).any()]).tolist()
+        assert not bad[0], "detected nan values in amax"
+        assert not bad[1], "detected inf values in amax"
+        return amax
+
+    def __str__(self):
+        return f"MaxCalibrator(track_amax={self._track_amax})"
+
+
+class HistogramCalibrator(_Calibrator):
+    """|x| histogram with the reference's growth rule -- calib/histogram.py:36-205."""
+
+    def __init__(self, num_bits=8, axis=None, unsigned=False, num_bins=2048, grow_method=None,
+                 skip_zeros=False, torch_hist=True):
+        super().__init__(num_bits, axis, unsigned)
+        if axis is not None:
+            raise NotImplementedError("Calibrator histogram collection only supports per tensor scaling")
+        self._num_bins = num_bins
+        self._skip_zeros = skip_zeros
+        self._calib_bin_edges = None  # torch fp32, like the reference's torch_hist=True branch
+        self._calib_hist = None       # int64 counts on the device
+
+    @torch.no_grad()
+    def collect(self, x):
+        x = x.detach()
+        # x_max of what is histogrammed (|x| in fp32; zeros never raise the max)
+        x_max = ops.reduce_amax(x).float().cpu()
+        if self._calib_bin_edges is None and self._calib_hist is None:
+            self._calib_hist = ops.hist_abs(x, self._num_bins, float(x_max), self._skip_zeros)
+            self._calib_bin_edges = torch.linspace(0, x_max, self._num_bins + 1)
+        else:
+            if x_max > self._calib_bin_edges[-1]:
+                # keep the bin width, extend the range (calib/histogram.py:121-127)
+                width = self._calib_bin_edges[1] - self._calib_bin_edges[0]
+                self._num_bins = int((x_max / width).ceil().item())
+                self._calib_bin_edges = torch.arange(0, x_max + width, width)
+                grown = torch.zeros(self._num_bins, dtype=torch.int64, device=self._calib_hist.device)
+                grown[: self._calib_hist.numel()] = self._calib_hist
+                self._calib_hist = grown
+            ops.hist_abs(x, self._num_bins, float(self._calib_bin_edges[-1]), self._skip_zeros,
+                         counts=self._calib_hist)
+
+    def reset(self):
+        self._calib_bin_edges = None
+        self._calib_hist = None
+
+    def merge(self, other_hist: torch.Tensor):
+        """Add counts collected elsewhere (used by the cross-rank SUM all-reduce, distributed.py)."""
+        self._calib_hist += other_hist.to(self._calib_hist.device)
+
+    def compute_amax(self, method: str, *, stride: int = 1, start_bin: int = 128, percentile: float = 99.99):
+        if self._calib_hist is None:
+            return None
+        hist = self._calib_hist.cpu().numpy()
+        edges = self._calib_bin_edges.cpu().numpy()
+        if method == "entropy":
+            return _compute_amax_entropy(hist, edges, self._num_bits, self._unsigned, stride, start_bin)
+        if method == "mse":
+            return _compute_amax_mse(self._calib_hist, self._calib_bin_edges, self._num_bits, self._unsigned,
+                                     stride, start_bin)
+        if method == "percentile":
+            return _compute_amax_percentile(hist, edges, percentile)
+        raise TypeError(f"Unknown calibration method {method}")
+
+
+def _compute_amax_percentile(calib_hist, calib_bin_edges, percentile):
+    """calib/histogram.py:326-343."""
+    if percentile < 0 or percentile > 100:
+        raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
+    total = calib_hist.sum()
+    cdf = np.cumsum(calib_hist / total)
+    idx = np.searchsorted(cdf, percentile / 100)
+    return torch.tensor(calib_bin_edges[idx].item())
+
+
+def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, stride=1, start_bin=128):
+    """KL-divergence threshold search -- calib/histogram.py:210-283 (host numpy, O(bins^2 / stride))."""
+    from scipy.stats import entropy
+
+    bins = calib_hist.astype(np.int64).copy()
+    bins[0] = bins[1]
+    total_data = np.sum(bins)
+    nbins = 1 << (num_bits - 1 + int(unsigned))
+    divergences = []
+    for i in range(start_bin, len(bins) + 1, stride):
+        space = np.linspace(0, i, num=nbins + 1)
+        digitized_space = np.digitize(range(i), space) - 1
+        digitized_space[bins[:i] == 0] = -1
+        valid = digitized_space != -1
+        new_density_counts = np.zeros(nbins, dtype=np.float64)
+        np.add.at(new_density_counts, digitized_space[valid], bins[:i][valid])
+        for key, val in Counter(digitized_space.tolist()).items():
+            if key != -1:
+                new_density_counts[key] = new_density_counts[key] / val
+        new_density = np.zeros(i, dtype=np.float64)
+        new_density[valid] = new_density_counts[digitized_space[valid]]
+        total_counts_new = np.sum(new_density) + np.sum(bins[i:])
+        reference_density = np.array(bins[:i], dtype=np.float64)
+        reference_density[-1] += np.sum(bins[i:])
+        total_counts_old = np.sum(reference_density)
+        if round(total_counts_new) != total_data or round(total_counts_old) != total_data:
+            raise RuntimeError(f"Count mismatch! total_counts_new={total_counts_new}, "
+                               f"total_counts_old={total_counts_old}, total_data={total_data}")
+        # NB: the reference's _normalize_distr rebinds a local and normalises nothing (histogram.py:217-220);
+        # scipy.stats.entropy normalises both arguments itself, so the result is the same either way.
+        divergences.append(entropy(reference_density, new_density))
+    divergences = np.array(divergences)
+    last_argmin = len(divergences) - 1 - np.argmin(divergences[::-1])
+    return torch.tensor(calib_bin_edges[last_argmin * stride + start_bin].item())
+
+
+def _compute_amax_mse(counts, edges, num_bits, unsigned, stride=1, start_bin=128):
+    """MSE threshold search over bin centres.  The reference's version (calib/histogram.py:286-323) passes
+    `num_bits` in the `bias` slot of fake_tensor_quant and therefore returns a constant; this implements
+    the documented intent (QDQ of the centres at each candidate amax) and is NOT parity-pinned."""
+    dev = counts.device
+    c = counts.float()
+    e = edges.float().to(dev)
+    centers = ((e[1:] + e[:-1]) / 2).contiguous()
+    best, best_i = None, None
+    for i in range(start_bin, centers.numel(), stride):
+        amax = centers[i:i + 1]
+        if isinstance(num_bits, int):
+            q = ops.fake_tensor_quant(centers, amax, num_bits, unsigned)
+        elif tuple(num_bits) == (4, 3):
+            q = ops.scaled_e4m3(centers, amax)
+        else:
+            raise TypeError("Invalid num_bits. num_bits must be a positive integer or tuple (4,3).")
+        mse = (((q - centers) ** 2) * c).mean().item()
+        if best is None or mse < best:
+            best, best_i = mse, i
+    return centers[best_i].clone()
+
+
+class MseCalibrator(_Calibrator):
+    """amax multiplier sweep minimising the QDQ error -- calib/mse.py:31-172.  quant_func(x, amax) is
+    supplied by the quantizer (model_calib.py:639-662) and runs our QDQ kernels; the candidate loop and the
+    argmin stay as in the reference."""
+
+    def __init__(self, amax, axis=None, step_size=0.1, start_multiplier=0.25, stop_multiplier=4.0,
+                 quant_func=None, error_func=None):
+        super().__init__(num_bits=None, axis=axis, unsigned=None)
+        self._initial_amax = amax
+        self._num_steps = math.ceil((stop_multiplier - start_multiplier) / step_size) + 1
+        self._start_multiplier, self._stop_multiplier = start_multiplier, stop_multiplier
+        self._quant_func, self._error_func = quant_func, error_func
+        self._losses_sum = None
+        self._candidates = None
+        self._amax = None
+
+    def _generate_candidates(self, device):
+        return torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps, device=device)
+
+    def _compute_candidate_amax(self, candidates):
+        if candidates.ndim != 0:
+            candidates = candidates.view_as(self._initial_amax)
+        return self._initial_amax * candidates
+
+    @torch.no_grad()
+    def collect(self, x):
+        if self._quant_func is None:
+            raise RuntimeError("Quantization function not set.")
+        x = x.detach().to(dtype=torch.float32)
+        candidates = self._generate_candidates(x.device)
+        if self._candidates is None:
+            self._candidates = candidates
+            self._losses_sum = [None] * len(candidates)
+        reduce_axis = convert_quantization_axis_to_reduce_axis(x, self._axis)
+        for step, candidate in enumerate(candidates):
+            xq = self._quant_func(x, self._compute_candidate_amax(candidate))
+            error = self._error_func(x, xq) if self._error_func is not None else (x - xq) ** 2
+            loss = error.sum() if reduce_axis is None else error.sum(dim=reduce_axis)
+            self._losses_sum[step] = loss.clone() if self._losses_sum[step] is None else self._losses_sum[step] + loss
+
+    def reset(self):
+        self._losses_sum = None
+        self._candidates = None
+        self._amax = None
+
+    @torch.no_grad()
+    def compute_amax(self, verbose=False):
+        if self._losses_sum is None or not any(v is not None for v in self._losses_sum):
+            return None
+        losses = torch.stack([v for v in self._losses_sum])
+        best = torch.argmin(losses, dim=0)
+        self._amax = self._compute_candidate_amax(self._candidates[best])
+        return self._amax

@@ -116,6 +116,54 @@ __global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64
   sum_out[c] = accumulate ? sum_out[c] + s : s;
 }
 
+// ---------------------------------------------------------------- AWQ weight scale (a12)
+// get_weight_scale (model_calib.py:1453-1469): scale[r,c] = dt(|w[r,c]| / dt(gamax[r, c/g] + tiny_dt)),
+// w_scale[c] = dt(mean_r scale[r,c]) widened to fp32.  Same grid shape as the column statistics: a lane owns
+// V adjacent columns of kColRows rows; the g columns of a group are LPG adjacent lanes, so the group amax is
+// a DPP butterfly and the weight is read exactly once.
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void awq_wscale_kernel(const void* __restrict__ w, int64_t rows,
+                                                            int64_t cols, float tiny,
+                                                            float* __restrict__ partial) {
+  constexpr int V = Elem<DT>::kVec;
+  const int64_t c0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+  if (c0 >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * kColRows;
+  const int64_t r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
+  const char* base = reinterpret_cast<const char*>(w);
+  const int64_t row_bytes = cols * (16 / V);
+  float sm[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) sm[i] = 0.0f;
+  Pack16 pk[kColRows];
+#pragma unroll
+  for (int r = 0; r < kColRows; ++r)
+    if (r0 + r < r1) pk[r] = load16(base + (r0 + r) * row_bytes + c0 * (16 / V));
+#pragma unroll
+  for (int r = 0; r < kColRows; ++r) {
+    if (r0 + r < r1) {
+      const float gmax = __uint_as_float(group_max_u32<LPG>(pack_absmax<DT>(pk[r])));
+      const float den = round_to_dtype<DT>(gmax + tiny);
+      float f[8];
+      unpack<DT>(pk[r], f);
+#pragma unroll
+      for (int i = 0; i < V; ++i) sm[i] += round_to_dtype<DT>(__builtin_fabsf(f[i]) / den);
+    }
+  }
+  float* dst = partial + (int64_t)blockIdx.y * cols + c0;
+#pragma unroll
+  for (int i = 0; i < V; ++i) dst[i] = sm[i];
+}
+template <int DT>
+__global__ void awq_wscale_finalize_kernel(const float* __restrict__ partial, int64_t n_blk, int64_t rows,
+                                           int64_t cols, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int64_t b = 0; b < n_blk; ++b) s += partial[b * cols + c];
+  out[c] = round_to_dtype<DT>(s / (float)rows);  // torch.mean: fp32 accumulate, one rounding to dtype
+}
+
 // ---------------------------------------------------------------- generic
 template <int DT>
 __global__ void amax_generic_kernel(const void* __restrict__ x, int64_t n, int64_t axis_size,
@@ -253,4 +301,33 @@ extern "C" int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, in
     }
   }
   return check_launch("moq_col_abs_stats");
+}
+
+extern "C" int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, int g, int dt, float* out,
+                                    float* partial, void* stream) {
+  if (rows <= 0 || cols <= 0 || g <= 0 || w == nullptr || out == nullptr || partial == nullptr) {
+    set_error("moq_awq_weight_scale: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = g / vec;
+  if (cols % g != 0 || g % vec != 0 || lpg > 64 || (lpg & (lpg - 1)) != 0 ||
+      (reinterpret_cast<uintptr_t>(w) & 15u) != 0) {
+    set_error("moq_awq_weight_scale: needs cols %% g == 0, g/%d a power of two <= 64, 16-byte aligned weight", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  // torch.finfo(dtype).tiny: smallest positive normal of the storage dtype (model_calib.py:1465)
+  const float tiny = dt == MOQ_F16 ? 6.103515625e-05f : 1.17549435e-38f;
+  const int64_t n_blk = (rows + kColRows - 1) / kColRows;
+  dim3 grid((unsigned)((cols / vec + kBlock - 1) / kBlock), (unsigned)n_blk);
+#define MOQ_WS_CASE(L) \
+  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((awq_wscale_kernel<DT, L>), grid, dim3(kBlock), 0, S(stream), w, rows, cols, tiny, partial)); break;
+  switch (lpg) {
+    MOQ_WS_CASE(1) MOQ_WS_CASE(2) MOQ_WS_CASE(4) MOQ_WS_CASE(8) MOQ_WS_CASE(16) MOQ_WS_CASE(32) MOQ_WS_CASE(64)
+    default: set_error("unreachable"); return MOQ_ERR_INVALID;
+  }
+#undef MOQ_WS_CASE
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((awq_wscale_finalize_kernel<DT>), dim3((unsigned)((cols + 255) / 256)),
+                                            dim3(256), 0, S(stream), partial, n_blk, rows, cols, out));
+  return check_launch("moq_awq_weight_scale");
 }

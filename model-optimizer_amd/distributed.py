@@ -1,0 +1,100 @@
+"""Cross-rank synchronisation of calibration statistics -- ONE bucketed collective per reduce-op type.
+
+The reference issues one small all-reduce per quantizer (model_calib.py:390-407 -> tensor_quantizer.py:
+1373-1385; ~450 for Llama-3-8B) and does not synchronise histograms at all (calib/histogram.py:158-163).
+On MI355X these payloads (KB..MB) are latency-bound over xGMI, so all amax values travel in one flat fp32
+bucket (MAX), all histograms in one int64 bucket (SUM), all AWQ act-scales / losses in one fp32 bucket
+(SUM, then / world).  torch.distributed's "nccl" backend is RCCL on ROCm; the same code runs on gloo/CPU,
+which is how the N > 1 path is tested without GPUs (tests/test_distributed_cpu.py).
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def _initialized(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def all_reduce_bucket(tensors, op, group=None, average: bool = False):
+    """All-reduce a list of tensors as one flat buffer (per dtype), results written back in place."""
+    if not tensors or not _initialized(group):
+        return
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    world = dist.get_world_size(group)
+    for (_, _), ts in by_dtype.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        dist.all_reduce(flat, op=op, group=group)
+        if average:
+            flat = flat / world
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def sync_amax_bucketed(quantizers, group=None):
+    """MAX-reduce every calibrated `_amax` buffer of `quantizers` in one collective
+    (semantics of sync_amax_across_distributed_group, tensor_quantizer.py:1373-1385)."""
+    bufs = [q._amax for q in quantizers if getattr(q, "_amax", None) is not None]
+    # NaN must survive the reduction like it does locally: MAX drops NaN on some backends, so carry a flag
+    if not bufs or not _initialized(group):
+        return
+    nan_flags = torch.stack([torch.isnan(b).any().to(torch.float32) for b in bufs])
+    f32 = [b.float() for b in bufs]
+    all_reduce_bucket(f32 + [nan_flags], dist.ReduceOp.MAX, group)
+    for b, r, flag in zip(bufs, f32, nan_flags.tolist()):
+        b.copy_(torch.full_like(r, float("nan")) if flag else r)
+
+
+def sync_calibrators_bucketed(calibrators, group=None):
+    """Synchronise raw calibrator state before compute_amax: running maxima (MAX) and histograms (SUM).
+    Histograms are first brought to a common range: ranks agree on the largest last edge (MAX), re-bin is
+    not needed because every rank grows its histogram with the SAME bin width only if the first batch's
+    range agreed -- so the width is agreed up front by `agree_histogram_range`."""
+    from .calib import HistogramCalibrator, MaxCalibrator
+
+    if not _initialized(group):
+        return
+    maxes = [c._buf for c in calibrators if isinstance(c, MaxCalibrator) and c._buf is not None]
+    all_reduce_bucket(maxes, dist.ReduceOp.MAX, group)
+    hists = [c for c in calibrators if isinstance(c, HistogramCalibrator) and c._calib_hist is not None]
+    if hists:
+        # common number of bins: pad every histogram to the longest one across ranks (same width by contract)
+        lens = torch.tensor([c._calib_hist.numel() for c in hists], dtype=torch.int64,
+                            device=hists[0]._calib_hist.device)
+        dist.all_reduce(lens, op=dist.ReduceOp.MAX, group=group)
+        padded = []
+        for c, n in zip(hists, lens.tolist()):
+            if c._calib_hist.numel() < n:
+                width = c._calib_bin_edges[1] - c._calib_bin_edges[0]
+                grown = torch.zeros(n, dtype=torch.int64, device=c._calib_hist.device)
+                grown[: c._calib_hist.numel()] = c._calib_hist
+                c._calib_hist = grown
+                c._num_bins = n
+                c._calib_bin_edges = torch.arange(0, n + 1, dtype=torch.float32) * width
+            padded.append(c._calib_hist)
+        all_reduce_bucket(padded, dist.ReduceOp.SUM, group)
+
+
+def agree_histogram_range(x_max_local: torch.Tensor, group=None) -> torch.Tensor:
+    """First-batch range agreement: every rank uses max over ranks of its first batch's |x| max, so that
+    all ranks bin with the same width and their counts can be SUM-reduced exactly."""
+    if _initialized(group):
+        dist.all_reduce(x_max_local, op=dist.ReduceOp.MAX, group=group)
+    return x_max_local
+
+
+def shard_list(items, rank: int | None = None, world: int | None = None):
+    """Round-robin shard of per-layer weight tensors (or calibration batches) over the ranks: independent
+    units, no data-path collective."""
+    if rank is None:
+        rank = dist.get_rank() if _initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if _initialized() else 1
+    return [it for i, it in enumerate(items) if i % world == rank]

@@ -1,0 +1,246 @@
+"""Calibration algorithms of the path -- mirrors of quantization/model_calib.py on our kernels:
+max_calibrate (:310-498), smoothquant (:1273-1359), awq_lite (:1394-1721) and their helpers.
+
+Host-side orchestration is the reference's; the passes over tensor data are HIP kernels:
+  weights            -> ONE multi-tensor launch per pass for all linears that share a format
+  activations        -> fused column statistics (sum |x| + abs-max in one read)
+  AWQ search weights -> fused (W * s) -> group amax -> INT-k QDQ
+  cross-rank sync    -> one bucketed collective per reduce op (distributed.py)
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import distributed as mdist
+from . import ops
+from .multi_tensor import SegmentTable
+from .nn import QuantLinear, is_quantized_linear
+from .tensor_quantizer import TensorQuantizer
+
+
+def _quantizers(model):
+    return [m for m in model.modules() if isinstance(m, TensorQuantizer)]
+
+
+def enable_stats_collection(model: nn.Module):
+    """model_calib.py:1128-1141."""
+    for q in _quantizers(model):
+        if q.is_enabled and not q._dynamic:
+            q.disable_quant()
+            q.enable_calib()
+
+
+def finish_stats_collection(model: nn.Module, method: str | None = None, **kwargs):
+    """model_calib.py:1144-1167: load_calib_amax on every calibrated quantizer, back to quant mode."""
+    for q in _quantizers(model):
+        if not q.is_enabled or q._dynamic:
+            continue
+        amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
+        if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
+            if hasattr(q, "_amax") and q._amax.shape != amax.shape:
+                delattr(q, "_amax")
+            q.amax = amax
+        q.enable_quant()
+        q.disable_calib()
+
+
+def weight_only_quantize(model: nn.Module):
+    """model_calib.py:187-199: pass every weight through its quantizer (collects weight statistics).
+
+    Fast path: all enabled per-tensor 'max' weight quantizers of one dtype are calibrated by ONE
+    multi-tensor abs-max launch instead of one reduction per layer."""
+    mods = [m for m in model.modules() if is_quantized_linear(m) and m.weight_quantizer.is_enabled]
+    batched = []
+    for m in mods:
+        wq = m.weight_quantizer
+        per_tensor_max = (wq._if_calib and wq.axis is None and wq.block_sizes is None
+                          and type(wq._calibrator).__name__ == "MaxCalibrator" and m.weight.is_cuda
+                          and m.weight.is_contiguous() and wq.pre_quant_scale is None)
+        if per_tensor_max:
+            batched.append(m)
+        else:
+            wq(m.weight)
+    by_key = {}
+    for m in batched:
+        by_key.setdefault((m.weight.dtype, m.weight.device), []).append(m)
+    for group in by_key.values():
+        tab = SegmentTable([m.weight.detach() for m in group], outputs=[m.weight.detach() for m in group])
+        amax = tab.calibrate_amax()
+        for i, m in enumerate(group):
+            cal = m.weight_quantizer._calibrator
+            if cal._buf is None:
+                cal._buf = amax[i:i + 1].clone()
+                cal._shape, cal._dtype = (), m.weight.dtype
+            else:
+                torch.maximum(cal._buf, amax[i:i + 1], out=cal._buf)
+
+
+@torch.no_grad()
+def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True):
+    """model_calib.py:310-498 (DP part): collect abs-max statistics for weights and activations, load them,
+    then MAX-reduce every amax across the data-parallel group in ONE bucket."""
+    enable_stats_collection(model)
+    weight_only_quantize(model)
+    if forward_loop is not None:
+        forward_loop(model)
+    finish_stats_collection(model)
+    if distributed_sync and dist.is_available() and dist.is_initialized():
+        mdist.sync_amax_bucketed(_quantizers(model))
+
+
+# ------------------------------------------------------------------------------------------------ smoothquant
+@torch.no_grad()
+def apply_pre_quant_scale_and_smooth(linear: QuantLinear, pre_quant_scale: torch.Tensor):
+    """model_calib.py:1226-1270: input quantizer gets s (in W.dtype), W <- (W * (1/s)_fp32).to(dtype),
+    weight amax recalibrated, input amax <- max(amax_for_smoothing * s)."""
+    assert linear.input_quantizer.pre_quant_scale is None, "pre_quant_scale should be None first!"
+    assert torch.all(pre_quant_scale > 0), "pre_quant_scale should be positive"
+    pre_quant_scale = pre_quant_scale.to(torch.float32)
+    linear.input_quantizer._enable_pre_quant_scale = True
+    linear.input_quantizer.pre_quant_scale = pre_quant_scale.to(linear.weight.dtype)
+    inv_scale = 1.0 / pre_quant_scale
+    ops.scale_cols(linear.weight.data, inv_scale, out=linear.weight.data)  # fp32 multiply, one rounding
+    linear.weight_quantizer.reset_amax()
+    max_calibrate(linear, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
+    if linear.input_quantizer.amax is not None:
+        dev, dt = linear.weight.device, linear.weight.dtype
+        a = linear.input_quantizer._amax_for_smoothing.to(device=dev, dtype=dt)
+        linear.input_quantizer.amax = (a * pre_quant_scale.to(dev)).amax().to(dt)
+
+
+@torch.no_grad()
+def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
+    """model_calib.py:1273-1359."""
+    assert forward_loop is not None, "forward_loop must be provided for smoothquant"
+    for m in model.modules():
+        if is_quantized_linear(m) and m.input_quantizer.is_enabled and m.input_quantizer.axis is None:
+            m.input_quantizer.axis = -1
+    max_calibrate(model, forward_loop)
+    smoothed = 0
+    for name, m in model.named_modules():
+        if not is_quantized_linear(m):
+            continue
+        iq, wq = m.input_quantizer, m.weight_quantizer
+        if not hasattr(iq, "_amax"):
+            warnings.warn(f"{name} is not calibrated, skip smoothing")
+            continue
+        if iq.num_bits != 8 or wq.num_bits != 8:
+            warnings.warn(f"Only int8 smoothing is supported, skip {name}")
+            continue
+        if iq.axis != -1:
+            warnings.warn(f"Only per-channel smoothing is supported, skip {name}")
+            continue
+        act_amax = iq.amax.float().reshape(-1)
+        weight_scale = ops.reduce_amax(m.weight, axis=(0,)).float().reshape(-1)  # |W|.amax(dim=0)
+        scale_a = weight_scale.pow(1 - alpha) / act_amax.pow(alpha)
+        iq._amax_for_smoothing = act_amax.cpu()
+        iq.reset_amax()
+        iq.axis = None
+        iq.amax = act_amax.amax().to(dtype=m.weight.dtype, device=m.weight.device)
+        epsilon = 1.0 / (1 << 31)
+        if scale_a.min() <= epsilon:
+            scale_a[act_amax <= epsilon] = 1
+        scale_a = scale_a.clamp(min=1e-4, max=1e4)
+        apply_pre_quant_scale_and_smooth(m, scale_a)
+        smoothed += 1
+    return smoothed
+
+
+# ------------------------------------------------------------------------------------------------ AWQ lite
+def get_scale(x_max, w_max, alpha):
+    """model_calib.py:1474-1487 (no tensor parallel group here)."""
+    scales = (x_max.pow(alpha) / (w_max.to(x_max.device).pow(1 - alpha) + torch.finfo(torch.float32).tiny)).clamp(
+        min=1e-4, max=1e4).view(-1)
+    return (scales / (scales.max() * scales.min()).sqrt()).view(-1)
+
+
+class AWQLiteHelper:
+    """Per-linear state of awq_lite (model_calib.py:1416-1451)."""
+
+    def __init__(self, module: QuantLinear, alpha_step: float):
+        wq = module.weight_quantizer
+        self.block_size = wq.block_sizes.get(-1, None) or wq.block_sizes.get(module.weight.dim() - 1)
+        self.weight_scale = ops.awq_weight_scale(module.weight, self.block_size)
+        self.act_sum = torch.zeros(module.weight.shape[1], dtype=torch.float32, device=module.weight.device)
+        self.act_scale = None
+        self.num_cache_steps = 0
+        self.num_tokens = 0
+        self.alphas = [k.item() for k in torch.arange(0, 1.0 + alpha_step, alpha_step)]  # same float32 keys as :1431
+        self.loss = {a: torch.zeros((), dtype=torch.float32, device=module.weight.device) for a in self.alphas}
+        self.best_alpha = None
+        self.best_scale = None
+
+
+@torch.no_grad()
+def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
+    """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
+    (the INT4_AWQ_CFG preset).  Two passes of forward_loop: cache (act scales), search (alpha grid)."""
+    mods = [(n, m) for n, m in model.named_modules()
+            if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
+    state = {"mode": "cache"}
+
+    def patched_forward(self, input):
+        h = helpers[self]
+        out_actual = F.linear(input, self.weight, self.bias)
+        if input.numel() == 0:
+            return out_actual
+        x2 = input.reshape(-1, input.shape[-1])
+        if state["mode"] == "cache":
+            # act_scale += mean_tokens |x| in the activation dtype (get_act_scale, :1471-1472)
+            ssum, _ = ops.col_abs_stats(x2, want_amax=False)
+            h.act_sum += (ssum / x2.shape[0]).to(input.dtype).float()
+            h.num_cache_steps += 1
+            h.num_tokens += x2.shape[0]
+            return out_actual
+        for alpha in h.alphas:
+            s = get_scale(h.act_scale, h.weight_scale, alpha)
+            xs = ops.scale_cols(x2, (1 / s).to(self.weight.dtype).float()).view_as(input)  # x * (1/s).to(dtype)
+            wq = ops.awq_scale_qdq(self.weight, s.to(self.weight.dtype), h.block_size, self.weight_quantizer.num_bits)
+            out = F.linear(xs, wq, self.bias)
+            h.loss[alpha] += (out - out_actual).float().pow(2).mean()
+        return out_actual
+
+    originals = {}
+    for _, m in mods:
+        originals[m] = m.forward
+        m.forward = patched_forward.__get__(m, type(m))
+    try:
+        forward_loop(model)  # cache pass
+        for h in helpers.values():
+            if h.num_cache_steps:
+                h.act_scale = h.act_sum / h.num_cache_steps
+        if dist.is_available() and dist.is_initialized():
+            # DP: act_scale AVG in ONE bucket (reference: one all_reduce per linear, :1588-1593)
+            mdist.all_reduce_bucket([h.act_scale for h in helpers.values() if h.act_scale is not None],
+                                    dist.ReduceOp.SUM, average=True)
+        state["mode"] = "search"
+        forward_loop(model)  # search pass
+        if dist.is_available() and dist.is_initialized():
+            # every rank must pick the same alpha: SUM the per-alpha losses in one bucket
+            mdist.all_reduce_bucket([v for h in helpers.values() for v in h.loss.values()], dist.ReduceOp.SUM)
+    finally:
+        for m, f in originals.items():
+            m.forward = f
+    for _, m in mods:
+        h = helpers[m]
+        if h.act_scale is None:
+            warnings.warn("awq_lite: a linear saw no tokens; falling back to max calibration for it")
+            continue
+        losses = {a: float(v) for a, v in h.loss.items()}
+        h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)
+        h.best_scale = get_scale(h.act_scale, h.weight_scale, h.best_alpha)
+        m.awq_lite = h
+        # postprocess (:1636-1659): fold s into W (fp32 multiply), recalibrate, input gets 1/s
+        ops.scale_cols(m.weight.data, h.best_scale, out=m.weight.data)
+        m.weight_quantizer.reset_amax()
+        max_calibrate(m, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
+        m.input_quantizer._enable_pre_quant_scale = True
+        m.input_quantizer.pre_quant_scale = (1.0 / h.best_scale).to(m.weight.dtype)
+    return helpers

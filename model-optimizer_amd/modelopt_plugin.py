@@ -1,0 +1,151 @@
+"""Drop-in seams into modelopt.torch.quantization / modelopt.torch.sparsity.
+
+`install()` makes an unmodified Model-Optimizer checkout run this path on our HIP kernels:
+
+  S1  extension modules : modelopt caches its JIT-built CUDA extensions on function attributes
+      (quantization/extensions.py:30,42,58).  We pre-seed `get_cuda_ext.extension`,
+      `get_cuda_ext_fp8.extension`, `get_cuda_ext_mx.extension` with adapter objects exposing the pybind
+      surface (tensor_quant.cpp:63-77, tensor_quant_gpu_fp8.cu:109-114, tensor_quant_mx.cu:393-411).  On ROCm
+      the loader otherwise returns None (utils/cpp_extension.py:57-58) and modelopt runs eager ops.
+  S3  quant backend     : register_quant_backend("mi355x", entrypoint) -- a fused per-quantizer path.
+  S5  sparsity          : magnitude.create_asp_mask is re-pointed at our mask kernel.
+  S6  utilities         : core_utils.reduce_amax (and its re-export) is re-pointed at our reductions.
+
+Nothing here imports modelopt at module import time; `install()` raises ImportError if it is absent.
+"""
+
+from __future__ import annotations
+
+import types
+
+import torch
+
+from . import _lib, ops, sparsity
+
+
+class IntExtension:
+    """Stands in for the `modelopt_cuda_ext` pybind module."""
+
+    @staticmethod
+    def fake_tensor_quant(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        return ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range)
+
+    @staticmethod
+    def fake_tensor_quant_(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range, inplace=True)
+
+    @staticmethod
+    def fake_tensor_quant_with_axis(inputs, amax, axis, num_bits=8, unsigned=False, narrow_range=True):
+        return ops.fake_tensor_quant_with_axis(inputs, amax, axis, num_bits, unsigned, narrow_range)
+
+    @staticmethod
+    def INT4_quantize(input, scales, block_size):  # noqa: N802
+        # the CUDA kernel's rounding (clamp, then roundf(v + 8)) -- tensor_quant_gpu.cu:322-333
+        return ops.int4_quantize(input.reshape(-1), scales.reshape(-1), block_size, _lib.ROUND_HALF_AWAY)
+
+    @staticmethod
+    def INT4_dequantize(quantized_data, scales, block_size):  # noqa: N802
+        return ops.int4_dequantize(quantized_data, scales.reshape(-1), block_size)
+
+    @staticmethod
+    def NF4_quantize(*a, **k):  # noqa: N802
+        raise NotImplementedError("NF4 is outside the MI355X PTQ path (SURVEY.md 2.3)")
+
+    NF4_dequantize = NF4_quantize
+
+
+class Fp8Extension:
+    """Stands in for `modelopt_cuda_ext_fp8`."""
+
+    @staticmethod
+    def fake_e4m3fy(inputs, amax):
+        return ops.scaled_e4m3(inputs, amax.reshape(-1)[:1])
+
+    @staticmethod
+    def fake_e4m3fy_with_axis(inputs, amax, axis):
+        return ops.fake_e4m3fy_with_axis(inputs, amax, axis)
+
+
+class MxExtension:
+    """Stands in for `modelopt_cuda_ext_mx` (Types numbering: tensor_quant_mx.h:39)."""
+
+    Types = types.SimpleNamespace(**_lib.MX_TYPES)
+
+    @staticmethod
+    def fused_amax_convert(inputs, block_size, format, scale_format, global_amax=None):
+        return ops.fused_amax_convert(inputs, block_size, int(format), int(scale_format), global_amax)
+
+
+def mi355x_backend(inputs: torch.Tensor, tq) -> torch.Tensor:
+    """S3 entrypoint(inputs, tensor_quantizer): fused dynamic-amax QDQ for static-block INT quantizers,
+    plain kernels otherwise.  `tq` is a *modelopt* TensorQuantizer (duck-typed)."""
+    nb = tq._num_bits
+    amax = getattr(tq, "_amax", None)
+    if isinstance(nb, int) and tq.block_sizes and amax is None and inputs.dim() == 2:
+        y, _ = ops.amax_qdq_int_group(inputs, inputs.shape[-1], nb, tq._unsigned, tq._narrow_range,
+                                      return_amax=False)
+        return y
+    if amax is None:
+        from .calib import convert_quantization_axis_to_reduce_axis
+
+        amax = ops.reduce_amax(inputs, axis=convert_quantization_axis_to_reduce_axis(inputs, tq._axis))
+    if isinstance(nb, tuple):
+        return ops.scaled_e4m3(inputs, amax)
+    return ops.fake_tensor_quant(inputs, amax, nb, tq._unsigned, tq._narrow_range)
+
+
+def _reduce_amax_seam(original):
+    def reduce_amax(input, axis=None, keepdims=True, squeeze_scalar=True):
+        if not input.is_cuda:
+            return original(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
+        try:
+            return ops.reduce_amax(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
+        except _lib.MoquantUnsupported:
+            return original(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
+
+    return reduce_amax
+
+
+def _asp_mask_seam(original):
+    def create_asp_mask(tensor, pattern):
+        if not tensor.is_cuda:
+            return original(tensor, pattern)
+        return sparsity.create_asp_mask(tensor, pattern)
+
+    return create_asp_mask
+
+
+def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True):
+    """Wire the seams into an importable modelopt.  Returns the list of seams installed."""
+    import modelopt.torch.quantization.extensions as ext  # ImportError if modelopt is absent
+
+    installed = []
+    if extensions:
+        ext.get_cuda_ext.extension = IntExtension()
+        ext.get_cuda_ext_fp8.extension = Fp8Extension()
+        ext.get_cuda_ext_mx.extension = MxExtension()
+        installed.append("S1:extensions")
+    if backend:
+        from modelopt.torch.quantization.nn.modules import tensor_quantizer as mtq_tq
+
+        mtq_tq.register_quant_backend("mi355x", mi355x_backend)
+        installed.append("S3:backend=mi355x")
+    if utilities:
+        import modelopt.torch.quantization.utils as qutils
+        from modelopt.torch.quantization.utils import core_utils
+
+        if not getattr(core_utils.reduce_amax, "_moq_seam", False):
+            seam = _reduce_amax_seam(core_utils.reduce_amax)
+            seam._moq_seam = True
+            core_utils.reduce_amax = seam
+            qutils.reduce_amax = seam
+        installed.append("S6:reduce_amax")
+    if sparsity_seam:
+        from modelopt.torch.sparsity.weight_sparsity import magnitude
+
+        if not getattr(magnitude.create_asp_mask, "_moq_seam", False):
+            seam = _asp_mask_seam(magnitude.create_asp_mask)
+            seam._moq_seam = True
+            magnitude.create_asp_mask = seam
+        installed.append("S5:create_asp_mask")
+    return installed

@@ -1,0 +1,45 @@
+"""QuantLinear -- mirror of the reference's _QuantLinear (nn/modules/quant_linear.py:38-53,
+quant_module.py:227-278): an nn.Linear with input / weight / output TensorQuantizers."""
+
+from __future__ import annotations
+
+import torch.nn.functional as F
+from torch import nn
+
+from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer
+
+
+class QuantLinear(nn.Linear):
+    """forward = output_quantizer(F.linear(input_quantizer(x), weight_quantizer(W), b))."""
+
+    default_quant_desc_input = QuantizerAttributeConfig(num_bits=8, axis=None)
+    default_quant_desc_weight = QuantizerAttributeConfig(num_bits=8, axis=0)
+
+    def _setup(self):
+        self.input_quantizer = TensorQuantizer(self.default_quant_desc_input)
+        self.weight_quantizer = TensorQuantizer(self.default_quant_desc_weight)
+        self.output_quantizer = TensorQuantizer(QuantizerAttributeConfig(enable=False))
+
+    @classmethod
+    def convert(cls, linear: nn.Linear) -> "QuantLinear":
+        """In-place class swap (the reference's DynamicModule conversion keeps parameters in place)."""
+        linear.__class__ = cls
+        linear._setup()
+        return linear
+
+    def forward(self, input):
+        x = self.input_quantizer(input)
+        w = self.weight_quantizer(self.weight)
+        return self.output_quantizer(F.linear(x, w, self.bias))
+
+
+def is_quantized_linear(m) -> bool:
+    return isinstance(m, QuantLinear)
+
+
+def replace_quant_module(model: nn.Module) -> nn.Module:
+    """nn.Linear -> QuantLinear everywhere (conversion.py:214 replace_quant_module for the Linear entry)."""
+    for mod in list(model.modules()):
+        if type(mod) is nn.Linear:
+            QuantLinear.convert(mod)
+    return model

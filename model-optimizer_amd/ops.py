@@ -375,3 +375,57 @@ def col_abs_stats(x: torch.Tensor, sum_out: torch.Tensor | None = None, amax_out
                                            _p(amax_out if want_amax else None), _p(ws), int(accumulate),
                                            stream))
     return sum_out, amax_out
+
+
+@torch.no_grad()
+def awq_weight_scale(weight: torch.Tensor, group_size: int) -> torch.Tensor:
+    """get_weight_scale (model_calib.py:1453-1469): fp32 [Cin] = mean over Cout of |W| / (group amax + tiny),
+    computed in W.dtype like the reference.  One read of W."""
+    _require_gpu(weight, "awq_weight_scale")
+    w = weight.detach().contiguous()
+    rows, cols = w.shape
+    out = torch.empty(cols, dtype=torch.float32, device=w.device)
+    ws = torch.empty(max(int(_lib.lib().moq_col_stats_workspace(rows, cols)), 1), dtype=torch.float32,
+                     device=w.device)
+    with _on(w) as stream:
+        check(_lib.lib().moq_awq_weight_scale(_p(w), rows, cols, int(group_size), _dt(w), _p(out), _p(ws),
+                                              stream))
+    return out
+
+
+def _axis_layout(inputs: torch.Tensor, amax: torch.Tensor, axis: int):
+    axis = axis % inputs.dim()
+    if amax.numel() != inputs.shape[axis]:
+        raise MoquantError(f"amax.numel()={amax.numel()} != inputs.size({axis})={inputs.shape[axis]}")  # TORCH_CHECK
+    inner = 1
+    for d in range(axis + 1, inputs.dim()):
+        inner *= inputs.shape[d]
+    return inputs.shape[axis], inner
+
+
+@torch.no_grad()
+def fake_tensor_quant_with_axis(inputs, amax, axis, num_bits=8, unsigned=False, narrow_range=True):
+    """cuda_ext.fake_tensor_quant_with_axis (tensor_quant.cpp:54-61): amax is 1-D of length inputs.size(axis)."""
+    _require_gpu(inputs, "fake_tensor_quant_with_axis")
+    x = inputs.contiguous()
+    am = _f32(amax, x.device).reshape(-1)
+    axis_size, inner = _axis_layout(x, am, axis)
+    y = torch.empty_like(x)
+    with _on(x) as stream:
+        check(_lib.lib().moq_fake_quant_int(_p(x), _p(y), x.numel(), _dt(x), _p(am), _lib.AMAX_AXIS, axis_size,
+                                            inner, int(num_bits), int(unsigned), int(narrow_range), stream))
+    return y
+
+
+@torch.no_grad()
+def fake_e4m3fy_with_axis(inputs, amax, axis):
+    """cuda_ext_fp8.fake_e4m3fy_with_axis (tensor_quant_gpu_fp8.cu:66-86)."""
+    _require_gpu(inputs, "fake_e4m3fy_with_axis")
+    x = inputs.contiguous()
+    am = _f32(amax, x.device).reshape(-1)
+    axis_size, inner = _axis_layout(x, am, axis)
+    y = torch.empty_like(x)
+    with _on(x) as stream:
+        check(_lib.lib().moq_fake_quant_e4m3(_p(x), _p(y), x.numel(), _dt(x), _p(am), _lib.AMAX_AXIS, axis_size,
+                                             inner, stream))
+    return y

@@ -1,0 +1,336 @@
+"""TensorQuantizer -- host-side mirror of modelopt.torch.quantization.nn.TensorQuantizer for the PTQ hot
+path (nn/modules/tensor_quantizer.py:136-1413), running on our HIP kernels.
+
+Same attribute names, same calibrate -> load_calib_amax -> quantize life cycle, same block-quant padding
+rules, same error behaviour; what differs is underneath: where the reference chains several eager ops
+(pre_quant_scale multiply, F.pad, reduce_amax, QDQ) this module issues ONE fused kernel when the layout
+allows it (static-block INT with dynamic amax, optionally with a per-column pre_quant_scale -- the AWQ
+search inner loop), and otherwise one kernel per stage.  GPU tensors only: there is no CPU path.
+
+Scope: fake quantization for INT-k (per-tensor / per-channel / static last-axis blocks), FP8-E4M3
+(per-tensor / per-channel) and dynamic MX blocks.  N-D (non-last-axis) block layouts, rotation, bias
+calibration and real-quant QTensors are outside this path and raise.
+"""
+
+from __future__ import annotations
+
+import math
+import warnings
+from dataclasses import dataclass, field
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from ._lib import MoquantUnsupported
+from .calib import HistogramCalibrator, MaxCalibrator, _Calibrator, convert_quantization_axis_to_reduce_axis
+
+
+@dataclass
+class QuantizerAttributeConfig:
+    """The fields of quantization/config.py:322-711 that matter on this path."""
+
+    num_bits: int | tuple = 8
+    axis: int | tuple | None = None
+    block_sizes: dict | None = None
+    unsigned: bool = False
+    narrow_range: bool = False  # config default (config.py:459-463)
+    calibrator: str | tuple = "max"
+    fake_quant: bool = True
+    enable: bool = True
+    learn_amax: bool = False
+    extra: dict = field(default_factory=dict)
+
+
+class TensorQuantizer(nn.Module):
+    def __init__(self, quant_attribute_cfg: QuantizerAttributeConfig | None = None, if_quant=True,
+                 if_calib=False, amax=None):
+        super().__init__()
+        cfg = quant_attribute_cfg or QuantizerAttributeConfig()
+        self._num_bits = cfg.num_bits
+        self._axis = cfg.axis
+        self._block_sizes = dict(cfg.block_sizes) if cfg.block_sizes else None
+        self._unsigned = cfg.unsigned
+        self._narrow_range = cfg.narrow_range
+        self._fake_quant = cfg.fake_quant
+        self._disabled = not cfg.enable
+        self._if_quant = if_quant
+        self._if_calib = if_calib
+        self._enable_pre_quant_scale = True
+        self._calibrator = self._make_calibrator(cfg.calibrator)
+        if not cfg.fake_quant:
+            raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
+        if amax is not None:
+            self.amax = amax
+
+    # ------------------------------------------------------------------ configuration
+    def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
+        """tensor_quantizer.py:228-290: (re)configure in place; calibration state is dropped."""
+        for name in ("_amax", "_pre_quant_scale"):
+            if hasattr(self, name):
+                delattr(self, name)
+        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export"):
+            self.__dict__.pop(name, None)
+        if not cfg.fake_quant:
+            raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
+        self._num_bits = cfg.num_bits
+        self._axis = cfg.axis
+        self._block_sizes = dict(cfg.block_sizes) if cfg.block_sizes else None
+        self._unsigned = cfg.unsigned
+        self._narrow_range = cfg.narrow_range
+        self._fake_quant = cfg.fake_quant
+        self._disabled = not cfg.enable
+        self._calibrator = self._make_calibrator(cfg.calibrator)
+
+    def _make_calibrator(self, spec) -> _Calibrator:
+        # config.py:599-613 / tensor_quantizer.py:235-241: "max", "histogram" or (cls, args, kwargs)
+        nb = self._num_bits if isinstance(self._num_bits, int) else 8
+        if spec == "max":
+            return MaxCalibrator(nb, self._axis, self._unsigned)
+        if spec == "histogram":
+            return HistogramCalibrator(nb, self._axis, self._unsigned)
+        cls, args, kwargs = (list(spec) + [(), {}])[:3] if isinstance(spec, (tuple, list)) else (spec, (), {})
+        return cls(*args, **kwargs)
+
+    num_bits = property(lambda self: self._num_bits)
+    unsigned = property(lambda self: self._unsigned)
+    narrow_range = property(lambda self: self._narrow_range)
+    block_sizes = property(lambda self: self._block_sizes)
+    fake_quant = property(lambda self: self._fake_quant)
+    is_enabled = property(lambda self: not self._disabled)
+
+    @property
+    def axis(self):
+        return self._axis
+
+    @axis.setter
+    def axis(self, value):
+        self._axis = value
+        self._calibrator._axis = value  # tensor_quantizer.py:309-316
+
+    @property
+    def _dynamic(self):
+        return self._block_sizes is not None and self._block_sizes.get("type", "static") == "dynamic"
+
+    @property
+    def is_mx_format(self):
+        # block scales in E8M0 (tensor_quantizer.py: is_mx_format)
+        return self._dynamic and self._block_sizes.get("scale_bits", None) == (8, 0)
+
+    @property
+    def is_static_block_quant(self):
+        return (self._block_sizes is not None and self._block_sizes.get("type", "static") == "static"
+                and self._fake_quant)
+
+    @property
+    def maxbound(self):
+        if self._num_bits == (4, 3):
+            return 448.0
+        if self._num_bits == (2, 1):
+            return 6.0
+        if isinstance(self._num_bits, int):
+            return float((1 << (self._num_bits - 1 + int(self._unsigned))) - 1)
+        raise MoquantUnsupported(f"maxbound of {self._num_bits}")
+
+    # ------------------------------------------------------------------ state
+    @property
+    def amax(self):
+        return getattr(self, "_amax", None)
+
+    @amax.setter
+    def amax(self, value):
+        assert value is not None, "amax cannot be set to None."
+        if not isinstance(value, torch.Tensor):
+            value = torch.tensor(value)
+        if not hasattr(self, "_amax"):
+            self.register_buffer("_amax", value.clone().detach())
+        else:
+            if self._amax.shape != value.shape:
+                raise RuntimeError("Changing shape when setting amax is not allowed.")
+            self._amax.data.copy_(value.clone().detach().to(self._amax.device))
+
+    def reset_amax(self):
+        if hasattr(self, "_amax"):
+            delattr(self, "_amax")
+        self._calibrator.reset()
+
+    @property
+    def pre_quant_scale(self):
+        if not hasattr(self, "_pre_quant_scale") or not self._enable_pre_quant_scale:
+            return None
+        return self._pre_quant_scale
+
+    @pre_quant_scale.setter
+    def pre_quant_scale(self, value):
+        assert value is not None, "pre_quant_scale cannot be set to None."
+        if not isinstance(value, torch.Tensor):
+            value = torch.tensor(value)
+        if not hasattr(self, "_pre_quant_scale"):
+            self.register_buffer("_pre_quant_scale", value.clone().detach())
+        else:
+            self._pre_quant_scale = value.clone().detach().to(self._pre_quant_scale.device)
+
+    def disable(self):
+        self._disabled = True
+
+    def enable(self):
+        self._disabled = False
+
+    def enable_calib(self):
+        self._if_calib = True
+
+    def disable_calib(self):
+        self._if_calib = False
+
+    def enable_quant(self):
+        self._if_quant = True
+
+    def disable_quant(self):
+        self._if_quant = False
+
+    def load_calib_amax(self, *args, **kwargs):
+        """tensor_quantizer.py:693-720."""
+        assert not self._dynamic, "Dynamic quantization does not need calibration."
+        strict = kwargs.pop("strict", True)
+        calib_amax = self._calibrator.compute_amax(*args, **kwargs)
+        if calib_amax is None:
+            msg = "Calibrator returned None. This usually happens when calibrator hasn't seen any tensor."
+            if strict:
+                raise RuntimeError(msg + " Passing 'strict=False' to `load_calib_amax()` will ignore the error.")
+            warnings.warn(msg)
+            warnings.warn("Set amax to NaN!")
+            calib_amax = torch.tensor(math.nan)
+        self.amax = calib_amax
+
+    def export_amax(self):
+        """tensor_quantizer.py:1087-1117: 0 / NaN entries are replaced by maxbound; static last-axis block
+        amax is reshaped to (*shape[:-1], -1)."""
+        if self.amax is None:
+            return None
+        amax = self.amax.detach().clone()
+        amax[(amax == 0) | torch.isnan(amax)] = self.maxbound
+        if hasattr(self, "_amax_shape_for_export"):
+            amax = amax.reshape(self._amax_shape_for_export)
+        return amax
+
+    def sync_amax_across_distributed_group(self, group=None):
+        """tensor_quantizer.py:1373-1385 (one all-reduce; use distributed.sync_amax_bucketed for many)."""
+        if dist.is_available() and dist.is_initialized() and getattr(self, "_amax", None) is not None:
+            dist.all_reduce(self._amax, op=dist.ReduceOp.MAX, group=group)
+
+    # ------------------------------------------------------------------ block layout (last axis only)
+    def _block_size_last(self, inputs):
+        bs = self._block_sizes
+        g = bs.get(-1, None) or bs.get(inputs.dim() - 1, None)
+        other = [k for k in bs if isinstance(k, int) and k not in (-1, inputs.dim() - 1)]
+        if g is None or other:
+            raise MoquantUnsupported("only last-axis block quantization is implemented on this path "
+                                     "(reference general N-D path: tensor_quantizer.py:1018-1043)")
+        return g
+
+    def _setup_for_blockquant(self, inputs):
+        """Last-axis fast path of tensor_quantizer.py:975-1016: right-pad the last dim with zeros to a block
+        multiple, view as (-1, g), quantization axis (0,)."""
+        if hasattr(self, "_block_reshape_size"):
+            return
+        g = self._block_size_last(inputs)
+        self._original_shape = inputs.shape
+        pad = (-inputs.shape[-1]) % g
+        if pad:
+            self._padding = (0, pad)
+            self._slices = (*(slice(None),) * (inputs.dim() - 1), slice(inputs.shape[-1]))
+            self._original_shape = torch.Size((*inputs.shape[:-1], inputs.shape[-1] + pad))
+        self._block_reshape_size = torch.Size((-1, g))
+        self._amax_shape_for_export = (*inputs.shape[:-1], -1)
+        self.axis = (0,)
+
+    def _process_for_blockquant(self, inputs):
+        if hasattr(self, "_padding"):
+            inputs = F.pad(inputs, self._padding, "constant", 0)
+        if inputs.shape != self._original_shape:
+            raise ValueError(f"Input shape has changed from {self._original_shape} to {inputs.shape}."
+                             " Block-quantization requires a fixed input shape.")
+        return inputs.reshape(self._block_reshape_size)
+
+    def _reset_to_original_shape(self, outputs):
+        outputs = outputs.reshape(self._original_shape)
+        if hasattr(self, "_slices"):
+            outputs = outputs[self._slices]
+        return outputs
+
+    # ------------------------------------------------------------------ forward
+    def _get_amax(self, inputs):
+        if hasattr(self, "_amax"):
+            return self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
+        reduce_axis = convert_quantization_axis_to_reduce_axis(inputs, self._axis)
+        return ops.reduce_amax(inputs, axis=reduce_axis, keepdims=True)
+
+    def collect(self, inputs):
+        if not self._if_calib or self._dynamic:
+            return
+        self._calibrator.collect(inputs)
+
+    def _fake_quantize(self, inputs):
+        if self._dynamic:
+            g = self._block_sizes.get(-1, None) or self._block_sizes.get(inputs.dim() - 1, None)
+            if g is None:
+                raise ValueError("block size for dynamic quantization not found.")
+            amax = None if self.is_mx_format else self._get_amax(inputs)
+            nb = self._num_bits if not isinstance(self._num_bits, list) else tuple(self._num_bits)
+            return ops.dynamic_block_quant(inputs, g, amax, nb, tuple(self._block_sizes.get("scale_bits", (8, 0))))
+        if isinstance(self._num_bits, tuple):
+            if tuple(self._num_bits) != (4, 3):
+                raise MoquantUnsupported(f"float format {self._num_bits} without dynamic blocks")
+            return ops.scaled_e4m3(inputs, self._get_amax(inputs))
+        if self.is_static_block_quant and not hasattr(self, "_amax"):
+            # dynamic per-block amax + QDQ in one pass (what _get_amax + fake_tensor_quant do in two)
+            y, _ = ops.amax_qdq_int_group(inputs, inputs.shape[-1], self._num_bits, self._unsigned,
+                                          self._narrow_range, return_amax=False)
+            return y
+        return ops.fake_tensor_quant(inputs, self._get_amax(inputs), self._num_bits, self._unsigned,
+                                     self._narrow_range)
+
+    def forward(self, inputs):
+        if inputs.numel() == 0:
+            return inputs
+        pqs = self.pre_quant_scale
+        fused_pqs = False
+        if pqs is not None:
+            can_fuse = (not self._disabled and self._if_quant and not self._if_calib and self.is_static_block_quant
+                        and not hasattr(self, "_amax") and isinstance(self._num_bits, int) and not self._unsigned
+                        and not self._narrow_range and inputs.dim() == 2 and pqs.numel() == inputs.shape[-1])
+            if can_fuse:
+                g = self._block_size_last(inputs)
+                can_fuse = inputs.shape[-1] % g == 0
+            if can_fuse:
+                fused_pqs = True
+            elif pqs.numel() == inputs.shape[-1] and pqs.numel() > 1:
+                inputs = ops.scale_cols(inputs, pqs)  # x * s rounded once to x.dtype == inputs * pre_quant_scale
+            else:
+                inputs = inputs * pqs
+        if self._disabled:
+            return inputs
+        if fused_pqs:
+            # AWQ search inner op: QDQ_g((W * s).to(dtype)) with dynamic group amax, one read + one write
+            return ops.awq_scale_qdq(inputs, pqs, self._block_size_last(inputs), self._num_bits)
+        if self.is_static_block_quant:
+            self._setup_for_blockquant(inputs)
+            inputs = self._process_for_blockquant(inputs)
+        outputs = inputs
+        if self._if_calib and not self._dynamic:
+            self.collect(inputs)
+        if self._if_quant:
+            if not inputs.is_contiguous():
+                inputs = inputs.contiguous()
+            outputs = self._fake_quantize(inputs)
+        if self.is_static_block_quant:
+            outputs = self._reset_to_original_shape(outputs)
+        return outputs
+
+    def extra_repr(self):
+        return (f"{self._num_bits} bit fake axis={self._axis} block_sizes={self._block_sizes} "
+                f"amax={'dynamic' if self.amax is None else tuple(self.amax.shape)} "
+                f"calibrator={type(self._calibrator).__name__} quant={'on' if self._if_quant else 'off'}"
+                f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")

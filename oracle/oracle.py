@@ -202,3 +202,11 @@ def col_abs_stats(x):
 
 def e4m3fn_round(v: float) -> float:
     return float(lib().orc_e4m3fn_round(ctypes.c_float(v)))
+
+
+def awq_weight_scale(w, g):
+    rows, cols = w.shape
+    a = _np(w)
+    out = np.empty(cols, dtype=np.float32)
+    lib().orc_awq_weight_scale(_p(a), I64(rows), I64(cols), int(g), DT[w.dtype], _p(out))
+    return torch.from_numpy(out)

@@ -14,6 +14,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   int4.npz      -- INT4QTensor.quantize/dequantize eager twin (qtensor/int4_tensor.py:39-130) and
                    pack_int4_in_uint8 (export/quant_utils.py:792-833)
   awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
+  model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
                    the MX kernels have no CPU implementation in the reference)
@@ -207,6 +208,8 @@ def gen_hist(out):
                 cal.collect(b)
                 snaps.append((cal._calib_hist.clone(), cal._calib_bin_edges.clone()))
             cases[f"c{idx}"] = dict(dtype=dn, skip_zeros=skip_zeros, num_bins=256)
+            out[f"c{idx}_pct"] = bits(cal.compute_amax("percentile", percentile=99.9).float().reshape(1))
+            out[f"c{idx}_ent"] = bits(cal.compute_amax("entropy", start_bin=64).float().reshape(1))
             for k, b in enumerate((b0, b1, b2)):
                 out[f"c{idx}_b{k}"] = bits(b)
                 out[f"c{idx}_h{k}"] = bits(snaps[k][0])
@@ -301,6 +304,80 @@ def gen_awq(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+class _TinyMLP(torch.nn.Module):
+    def __init__(self, d=128, h=128, dtype=torch.float32, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.fc1 = torch.nn.Linear(d, h, bias=False)
+        self.fc2 = torch.nn.Linear(h, d, bias=True)
+        with torch.no_grad():
+            self.fc1.weight.copy_(torch.randn(h, d, generator=g) * 0.05)
+            self.fc2.weight.copy_(torch.randn(d, h, generator=g) * 0.05)
+            self.fc2.bias.copy_(torch.randn(d, generator=g) * 0.01)
+        self.to(dtype)
+
+    def forward(self, x):
+        return self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+
+def _calib_batches(d, dtype, seed, n=4):
+    g = torch.Generator().manual_seed(seed)
+    ch = torch.exp(torch.randn(d, generator=g))
+    ch[:4] *= 30  # a few massive channels so that the AWQ / SmoothQuant search is not degenerate
+    return [(torch.randn(24, d, generator=g) * ch).to(dtype) for _ in range(n)]
+
+
+def gen_model_flows(out):
+    """mtq.quantize() on a tiny MLP: max (INT8 / FP8), smoothquant (INT8) and awq_lite (INT4 g128).
+    Stores inputs, the reference's resulting buffers and one forward output."""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+
+    cases = {}
+    flows = [("int8_max", mtq.INT8_DEFAULT_CFG, torch.float32), ("fp8_max", mtq.FP8_DEFAULT_CFG, torch.bfloat16),
+             ("int8_sq", mtq.INT8_SMOOTHQUANT_CFG, torch.float32), ("int4_awq", mtq.INT4_AWQ_CFG, torch.float32),
+             ("int4_awq_bf16", mtq.INT4_AWQ_CFG, torch.bfloat16)]
+    for name, cfg, dt in flows:
+        dn = {torch.float32: "f32", torch.bfloat16: "bf16"}[dt]
+        model = _TinyMLP(dtype=dt, seed=3)
+        batches = _calib_batches(128, dt, 5)
+        # inputs are identical for every flow of one dtype: stored once under the dtype name
+        out[f"{dn}_w1"], out[f"{dn}_w2"], out[f"{dn}_b2"] = bits(model.fc1.weight), bits(model.fc2.weight), bits(model.fc2.bias)
+        for i, b in enumerate(batches):
+            out[f"{dn}_x{i}"] = bits(b)
+
+        def loop(m):
+            for b in batches:
+                m(b)
+
+        cfg = copy.deepcopy(cfg)
+        if isinstance(cfg.get("algorithm"), dict) and cfg["algorithm"].get("method") == "awq_lite":
+            cfg["algorithm"]["debug"] = True  # keeps module.awq_lite (best_alpha, losses) after calibration
+        q = mtq.quantize(copy.deepcopy(model), cfg, loop)
+        info = dict(dtype=dn, n_batches=len(batches), tensors=[])
+        for lname in ("fc1", "fc2"):
+            lin = getattr(q, lname)
+            out[f"{name}_{lname}_wfinal"] = bits(lin.weight)
+            for qn in ("input_quantizer", "weight_quantizer"):
+                tq_ = getattr(lin, qn)
+                for attr in ("_amax", "_pre_quant_scale"):
+                    if hasattr(tq_, attr):
+                        t = getattr(tq_, attr)
+                        out[f"{name}_{lname}_{qn}{attr}"] = bits(t.float())
+                        info["tensors"].append([f"{lname}_{qn}{attr}", str(t.dtype), list(t.shape)])
+            if hasattr(lin, "awq_lite"):
+                h = lin.awq_lite
+                info[f"{lname}_best_alpha"] = float(h.best_alpha)
+                info[f"{lname}_loss"] = {str(k): float(v) for k, v in h.loss.items()}
+                out[f"{name}_{lname}_act_scale"] = bits(h.act_scale.float())
+                out[f"{name}_{lname}_weight_scale"] = bits(h.weight_scale.float())
+                out[f"{name}_{lname}_best_scale"] = bits(h.best_scale.float())
+        out[f"{name}_y"] = bits(q(batches[0]))
+        cases[name] = info
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def extract_mx_vectors():
     """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
     path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
@@ -352,7 +429,7 @@ def main():
     torch.manual_seed(1234)
     for name, fn in [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
-                     ("int4", gen_int4), ("awq", gen_awq)]:
+                     ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

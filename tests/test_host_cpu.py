@@ -1,0 +1,114 @@
+"""CPU tests of host-side logic that needs no kernel: histogram threshold searches against the reference's
+own results, block-quant bookkeeping, config plumbing, and (build container only) the modelopt seams."""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import _moa_import
+from conftest import DT, GOLDEN
+
+moa = _moa_import.load()
+from model_optimizer_amd import QuantizerAttributeConfig, TensorQuantizer, calib, model_quant  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def test_histogram_threshold_searches_match_reference(golden):
+    """percentile / entropy reductions (calib/histogram.py:210-343) on the reference's own histograms."""
+    g = golden("hist")
+    for k, c in g.cases.items():
+        hist = g.t(f"{k}_h2").numpy().astype(np.int64)
+        edges = g.t(f"{k}_e2").numpy()
+        pct = calib._compute_amax_percentile(hist, edges, 99.9)
+        ent = calib._compute_amax_entropy(hist, edges, 8, False, 1, 64)
+        assert torch.equal(pct.reshape(1), g.t(f"{k}_pct")), f"percentile {k}"
+        assert torch.equal(ent.reshape(1), g.t(f"{k}_ent")), f"entropy {k}"
+    with pytest.raises(ValueError):
+        calib._compute_amax_percentile(hist, edges, 101)
+
+
+def test_oracle_awq_weight_scale_matches_reference(golden):
+    g = golden("awq")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        got = oracle.awq_weight_scale(g.t(f"{k}_w", dt), c["g"])
+        want = g.t(f"{k}_wscale")
+        ulp = want.abs() * (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10)
+        assert ((got - want).abs() <= ulp).all(), f"oracle awq_weight_scale {k}"
+
+
+def test_tensor_quantizer_config_and_state_without_gpu():
+    q = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: 128}))
+    assert q.is_static_block_quant and not q._dynamic and q.maxbound == 7.0 and q.amax is None
+    q.amax = torch.tensor([[1.0], [2.0]])
+    with pytest.raises(RuntimeError, match="Changing shape"):
+        q.amax = torch.tensor(1.0)
+    q.reset_amax()
+    assert q.amax is None
+    with pytest.raises(RuntimeError, match="Calibrator returned None"):
+        q.load_calib_amax()
+    mx = TensorQuantizer(QuantizerAttributeConfig(num_bits=(2, 1), block_sizes={-1: 32, "type": "dynamic", "scale_bits": (8, 0)}))
+    assert mx.is_mx_format and mx._dynamic and not mx.is_static_block_quant
+    q.pre_quant_scale = torch.ones(4)
+    assert q.pre_quant_scale is not None
+    q._enable_pre_quant_scale = False
+    assert q.pre_quant_scale is None
+    # block bookkeeping: padding / slices exactly like tensor_quantizer.py:975-1016 (no kernel involved)
+    x = torch.zeros(3, 200)
+    q2 = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: 128}))
+    q2._setup_for_blockquant(x)
+    v = q2._process_for_blockquant(x)
+    assert v.shape == (6, 128) and q2.axis == (0,) and q2._amax_shape_for_export == (3, -1)
+    assert q2._reset_to_original_shape(v).shape == (3, 200)
+    with pytest.raises(ValueError, match="shape has changed"):
+        q2._process_for_blockquant(torch.zeros(3, 100))
+    with pytest.raises(ValueError):  # MoquantUnsupported is a ValueError: N-D block layouts are outside the path
+        TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: 16, -2: 16}))._setup_for_blockquant(x)
+
+
+def test_quantize_config_plumbing_without_gpu():
+    model = torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.GELU(), torch.nn.Linear(128, 128))
+    model_quant.replace_quant_module(model)
+    model_quant.set_quantizer_by_cfg(model, model_quant.INT4_AWQ_CFG["quant_cfg"])
+    lin = model[0]
+    assert lin.weight_quantizer.block_sizes == {-1: 128, "type": "static"} and lin.weight_quantizer.num_bits == 4
+    assert not lin.input_quantizer.is_enabled and lin.weight_quantizer.is_enabled
+    # the product path has no CPU fallback: running it on CPU tensors must fail loudly
+    with pytest.raises(moa.MoquantError, match="must live on the GPU"):
+        model(torch.randn(2, 128))
+    with pytest.raises(ValueError, match="outside this path"):
+        moa.quantize(torch.nn.Linear(4, 4), {"quant_cfg": {}, "algorithm": "gptq"})
+
+
+def test_modelopt_seams_install():
+    sys.path.insert(0, GOLDEN)
+    import ref_shim
+
+    if not ref_shim.reference_available():
+        pytest.skip("reference checkout not present (GPU box)")
+    ref_shim.install()
+    installed = moa.modelopt_plugin.install()
+    assert installed == ["S1:extensions", "S3:backend=mi355x", "S6:reduce_amax", "S5:create_asp_mask"]
+    import modelopt.torch.quantization.extensions as ext
+    from modelopt.torch.quantization.nn.modules import tensor_quantizer as ref_tq
+    from modelopt.torch.quantization.utils import core_utils
+
+    for fn, names in [(ext.get_cuda_ext, ["fake_tensor_quant", "fake_tensor_quant_", "fake_tensor_quant_with_axis",
+                                          "INT4_quantize", "INT4_dequantize", "NF4_quantize", "NF4_dequantize"]),
+                      (ext.get_cuda_ext_fp8, ["fake_e4m3fy", "fake_e4m3fy_with_axis"]),
+                      (ext.get_cuda_ext_mx, ["fused_amax_convert", "Types"])]:
+        for n in names:
+            assert hasattr(fn(), n), f"adapter lacks {n}"
+    assert ext.get_cuda_ext_mx().Types.E2M1 == 6 and ext.get_cuda_ext_mx().Types.E8M0 == 9  # tensor_quant_mx.h:39
+    assert ref_tq.is_registered_quant_backend("mi355x")
+    # CPU tensors keep flowing through the reference's own eager code (the seams only take GPU tensors)
+    x = torch.randn(4, 8)
+    assert torch.equal(core_utils.reduce_amax(x), x.abs().max())
+    import modelopt.torch.quantization as mtq
+
+    m = torch.nn.Sequential(torch.nn.Linear(16, 16))
+    mtq.quantize(m, mtq.INT8_DEFAULT_CFG, lambda mod: mod(torch.randn(2, 16)))
+    assert m[0].weight_quantizer.amax is not None
