@@ -204,6 +204,28 @@ int64_t moq_col_stats_workspace(int64_t tokens, int64_t cols);
 int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, int dt, float* sum_out,
                       float* amax_out, float* partial, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ AWQ-lite search error GEMM (a12) */
+
+/* One alpha step of the AWQ-lite search for one linear and one calibration batch, contraction and loss fused
+ * on the matrix cores (MFMA, fp32 accumulate):
+ *   out[t, n]  = dtype( sum_k x[t, k] * w[n, k]  (+ bias[n]) )            (F.linear of the patched forward)
+ *   loss_acc[0] += (float) mean_{t,n} ( float(dtype(out[t, n] - out_actual[t, n])) ^ 2 )
+ * which is update_loss() of the reference (quantization/model_calib.py:1489-1495) applied to the output of
+ * the patched forward (:1552-1556); `out` itself is never written.  x = input * (1/awq_scale) [tokens, cin]
+ * and w = QDQ(weight * awq_scale) [cout, cin] are row-major and 16-byte aligned; dt is MOQ_BF16 or MOQ_F16
+ * (fp32 models: MOQ_ERR_UNSUPPORTED, the host uses the library GEMM).  cin % 8 == 0, cout % 4 == 0.
+ * `partial`: fp32 workspace of moq_awq_err_gemm_workspace(tokens, cout) floats (per-tile sums, reduced in a
+ * fixed order: the result is deterministic).  Not bit-identical to the reference's BLAS accumulation order;
+ * tolerance stated in tests/test_gpu_parity.py. */
+int64_t moq_awq_err_gemm_workspace(int64_t tokens, int64_t cout);
+int moq_awq_err_gemm(const void* x, const void* w, const void* out_actual, const void* bias,
+                     int64_t tokens, int64_t cout, int64_t cin, int dt, float* partial, float* loss_acc,
+                     void* stream);
+/* The same MFMA main loop with a store epilogue: out[t, n] = dtype(sum_k x[t,k] * w[n,k] (+ bias[n])) --
+ * torch.nn.functional.linear for the model dtype (used to check the contraction on its own). */
+int moq_gemm_nt(const void* x, const void* w, const void* bias, void* out, int64_t tokens, int64_t cout,
+                int64_t cin, int dt, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

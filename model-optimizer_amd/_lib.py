@@ -63,6 +63,10 @@ SIGNATURES = {
     "moq_col_stats_workspace": (c_int64, [c_int64, c_int64]),
     "moq_col_abs_stats": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p]),
+    "moq_awq_err_gemm_workspace": (c_int64, [c_int64, c_int64]),
+    "moq_awq_err_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

@@ -429,3 +429,47 @@ def fake_e4m3fy_with_axis(inputs, amax, axis):
         check(_lib.lib().moq_fake_quant_e4m3(_p(x), _p(y), x.numel(), _dt(x), _p(am), _lib.AMAX_AXIS, axis_size,
                                              inner, stream))
     return y
+
+
+# ----------------------------------------------------------------------------------------------- AWQ error GEMM
+def mfma_gemm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Shapes / dtypes the MFMA kernel takes (fp32 models go through the library GEMM instead)."""
+    return (x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and w.shape[-1] % 8 == 0
+            and w.shape[0] % 4 == 0)
+
+
+@torch.no_grad()
+def awq_err_gemm(xs: torch.Tensor, w_hat: torch.Tensor, out_actual: torch.Tensor, bias: torch.Tensor | None,
+                 loss_acc: torch.Tensor) -> torch.Tensor:
+    """loss_acc += mean((linear(xs, w_hat, bias) - out_actual).float() ** 2) without materialising the output:
+    update_loss of awq_lite (model_calib.py:1489-1495) fused into the MFMA contraction.  loss_acc: fp32 [1]."""
+    _require_gpu(xs, "awq_err_gemm")
+    x2 = xs.detach().contiguous().view(-1, xs.shape[-1])
+    w = w_hat.detach().contiguous()
+    ref = out_actual.detach().contiguous().view(-1, w.shape[0])
+    if ref.shape[0] != x2.shape[0] or w.shape[1] != x2.shape[1] or ref.dtype != x2.dtype or w.dtype != x2.dtype:
+        raise MoquantError("awq_err_gemm: shape / dtype mismatch between xs, w_hat and out_actual")
+    if loss_acc.dtype != torch.float32 or loss_acc.numel() != 1 or not loss_acc.is_cuda:
+        raise MoquantError("awq_err_gemm: loss_acc must be a 1-element fp32 GPU tensor")
+    b = None if bias is None else bias.detach().to(x2.dtype).contiguous()
+    tokens, cin = x2.shape
+    cout = w.shape[0]
+    ws = torch.empty(int(_lib.lib().moq_awq_err_gemm_workspace(tokens, cout)), dtype=torch.float32, device=x2.device)
+    with _on(x2) as stream:
+        check(_lib.lib().moq_awq_err_gemm(_p(x2), _p(w), _p(ref), _p(b), tokens, cout, cin, _dt(x2), _p(ws),
+                                          _p(loss_acc), stream))
+    return loss_acc
+
+
+@torch.no_grad()
+def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
+    """F.linear(x, w, bias) for bf16 / f16 on the same MFMA main loop (store epilogue)."""
+    _require_gpu(x, "gemm_nt")
+    x2 = x.detach().contiguous().view(-1, x.shape[-1])
+    wc = w.detach().contiguous()
+    b = None if bias is None else bias.detach().to(x2.dtype).contiguous()
+    out = torch.empty(x2.shape[0], wc.shape[0], dtype=x2.dtype, device=x2.device)
+    with _on(x2) as stream:
+        check(_lib.lib().moq_gemm_nt(_p(x2), _p(wc), _p(b), _p(out), x2.shape[0], wc.shape[0], x2.shape[1],
+                                     _dt(x2), stream))
+    return out.view(*x.shape[:-1], wc.shape[0])

@@ -210,3 +210,17 @@ def awq_weight_scale(w, g):
     out = np.empty(cols, dtype=np.float32)
     lib().orc_awq_weight_scale(_p(a), I64(rows), I64(cols), int(g), DT[w.dtype], _p(out))
     return torch.from_numpy(out)
+
+
+def awq_err_gemm(x, w, out_actual=None, bias=None, return_out=False):
+    """(mean squared error vs out_actual, out) of out = linear(x, w, bias) in x.dtype (bf16 / f16 / f32)."""
+    tokens, cin = x.shape
+    cout = w.shape[0]
+    a, b = _np(x), _np(w)
+    r = None if out_actual is None else _np(out_actual)
+    bi = None if bias is None else _np(bias)
+    o = _empty_like_np(torch.empty(tokens * cout, dtype=x.dtype)) if return_out else None
+    f = lib().orc_awq_err_gemm
+    f.restype = ctypes.c_double
+    loss = f(_p(a), _p(b), _p(r), _p(bi), _p(o), I64(tokens), I64(cout), I64(cin), DT[x.dtype])
+    return (float(loss), _from_np(o, x.dtype, (tokens, cout))) if return_out else float(loss)

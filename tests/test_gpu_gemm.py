@@ -1,0 +1,127 @@
+"""GPU parity of the AWQ-lite search error GEMM (moq_awq_err_gemm / moq_gemm_nt, MFMA) against the CPU oracle.
+
+The contraction is floating point with a hardware-defined accumulation order, so this is the one kernel of the
+path that is compared with a stated tolerance instead of bit-exactly:
+  * exact-arithmetic inputs (small integers: every partial sum is representable) must match bit for bit --
+    this pins the MFMA fragment / C-layout mapping, the LDS swizzle and the ragged-edge handling;
+  * random inputs: fp32 accumulation-order noise is <= ~K * 2^-24 relative to sum|x*w|, which can flip the
+    final rounding to the model dtype of a few outputs by one ulp.  Stated tolerances: stored outputs within
+    one model-dtype ulp of the oracle and >= 99% bit-identical; loss within rtol 2e-3.
+"""
+
+import pytest
+import torch
+
+import _moa_import
+
+pytestmark = pytest.mark.gpu
+
+moa = _moa_import.load()
+ops = moa.ops
+from oracle import oracle  # noqa: E402  (the checker)
+
+DEV = "cuda:0"
+SHAPES = [  # (tokens, cout, cin): ragged tokens / cout, K tail (cin % 64 != 0), multi-tile, single tiny tile
+    (1, 4, 8), (5, 12, 24), (128, 128, 64), (130, 132, 72), (257, 384, 200), (64, 256, 1024), (300, 260, 136)]
+
+
+def _ints(shape, dtype, seed, lo=-3, hi=4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_nt_exact_on_integer_inputs(dtype, shape):
+    t, n, k = shape
+    x, w, b = _ints((t, k), dtype, 1), _ints((n, k), dtype, 2), _ints((n,), dtype, 3)
+    for bias in (None, b):
+        _, want = oracle.awq_err_gemm(x, w, None, bias, return_out=True)
+        got = ops.gemm_nt(x.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV)).cpu()
+        assert got.shape == want.shape and got.dtype == dtype
+        bad = (got.view(torch.int16) != want.view(torch.int16)) & ~((got == 0) & (want == 0))
+        assert not bad.any(), f"{shape} {dtype} bias={bias is not None}: {int(bad.sum())} of {got.numel()} outputs differ; " \
+                              f"first at {bad.nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_err_gemm_exact_on_integer_inputs(dtype, shape):
+    """Integer data: out and the differences are exact, so the fused loss must equal the oracle's up to the
+    final fp32 rounding of the mean."""
+    t, n, k = shape
+    x, w = _ints((t, k), dtype, 4), _ints((n, k), dtype, 5)
+    ref = _ints((t, n), dtype, 6, -8, 9)
+    want = oracle.awq_err_gemm(x, w, ref)
+    acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(x.to(DEV), w.to(DEV), ref.to(DEV), None, acc)
+    ops.awq_err_gemm(x.to(DEV), w.to(DEV), ref.to(DEV), None, acc)  # accumulates: loss[alpha] += ...
+    got = acc.item()
+    assert abs(got - 2 * want) <= 2e-6 * abs(2 * want) + 1e-30, f"{shape} {dtype}: {got} vs {2 * want}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_random_within_one_ulp(dtype):
+    torch.manual_seed(7)
+    t, n, k = 192, 320, 4096
+    x = torch.randn(t, k).to(dtype)
+    w = (torch.randn(n, k) * 0.02).to(dtype)
+    _, want = oracle.awq_err_gemm(x, w, None, None, return_out=True)
+    got = ops.gemm_nt(x.to(DEV), w.to(DEV)).cpu()
+    same = (got.view(torch.int16) == want.view(torch.int16)).float().mean().item()
+    assert same >= 0.99, f"only {same:.4f} of outputs bit-identical"
+    # one ulp of the model dtype at the output's magnitude, plus the fp32 accumulation-order noise that
+    # dominates where the sum cancels to ~0 (bound K * 2^-24 * sum|x*w|; 2e-6 * sum|x*w| stated here --
+    # the library GEMM shows the same few near-zero outliers against the fp64 oracle)
+    ulp = torch.finfo(dtype).eps * want.float().abs()
+    noise = 2e-6 * (x.float().abs() @ w.float().abs().T)
+    assert ((got.float() - want.float()).abs() <= ulp * 1.001 + noise).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_err_gemm_awq_like_loss(dtype):
+    """The search's actual use: w_hat = QDQ(W * s), xs = x / s, out_actual = x @ W^T; loss vs the oracle."""
+    torch.manual_seed(11)
+    t, n, k, g = 256, 256, 512, 128
+    x = (torch.randn(t, k) * torch.exp(torch.randn(k))).to(dtype)
+    w = (torch.randn(n, k) * 0.02).to(dtype)
+    s = torch.exp(torch.randn(k) * 0.3).to(dtype)
+    _, out_actual = oracle.awq_err_gemm(x, w, None, None, return_out=True)
+    w_hat = oracle.awq_scale_qdq(w, s, g, 4)
+    xs = oracle.scale_cols(x, (1 / s.float()).to(dtype).float())
+    want = oracle.awq_err_gemm(xs, w_hat, out_actual)
+    acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(xs.to(DEV), w_hat.to(DEV), out_actual.to(DEV), None, acc)
+    got = acc.item()
+    assert want > 0 and abs(got - want) <= 2e-3 * want, f"{dtype}: loss {got} vs oracle {want}"
+
+
+def test_err_gemm_rejects_unsupported():
+    x = torch.randn(8, 16, device=DEV)
+    w = torch.randn(8, 16, device=DEV)
+    acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+    with pytest.raises(ValueError):  # fp32 operands: MOQ_ERR_UNSUPPORTED -> ValueError, loud
+        ops.awq_err_gemm(x, w, torch.randn(8, 8, device=DEV), None, acc)
+    xb = x.to(torch.bfloat16)
+    with pytest.raises(ValueError):  # cin % 8 != 0
+        ops.gemm_nt(xb[:, :12].contiguous(), w.to(torch.bfloat16)[:, :12].contiguous())
+
+
+def test_err_gemm_full_size_linearity_property():
+    """Llama-3-8B gate_proj shape at one calibration batch (4096 tokens): scaling out_actual and w_hat by 2
+    scales every difference by exactly 2 (power-of-two scaling commutes with every rounding), so the loss
+    must be exactly 4x -- a size-independent check at full size where the oracle is too slow."""
+    torch.manual_seed(3)
+    t, n, k = 4096, 14336, 4096
+    x = torch.randn(t, k, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=DEV) * 0.02).to(torch.bfloat16)
+    ref = ops.gemm_nt(x, (w.float() * 1.03).to(torch.bfloat16))
+    a1 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    a2 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(x, w, ref, None, a1)
+    ops.awq_err_gemm(x, w * 2, ref * 2, None, a2)
+    assert a1.item() > 0 and abs(a2.item() - 4 * a1.item()) <= 1e-6 * a2.item()
+    # and the deterministic reduction: same inputs, same bits
+    a3 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(x, w, ref, None, a3)
+    assert a3.item() == a1.item()

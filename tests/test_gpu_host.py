@@ -179,7 +179,7 @@ def test_quantize_awq_lite_matches_reference(golden, name):
             _close(lin.input_quantizer._pre_quant_scale, g.t(f"{name}_{lname}_input_quantizer_pre_quant_scale"), tol,
                    f"{lname} pre_quant_scale")
             _close(lin.weight_quantizer._amax, g.t(f"{name}_{lname}_weight_quantizer_amax"), tol, f"{lname} weight amax")
-            _close(lin.weight, g.t(f"{name}_{lname}_wfinal"), tol * 10, f"{lname} folded weight")
+            _close(lin.weight, g.t(f"{name}_{lname}_wfinal", dt), tol * 10, f"{lname} folded weight")
 
 
 def test_create_asp_mask_shapes_vs_oracle():
