@@ -57,6 +57,30 @@ def make_weights(model, n_layers, device, seed=1234):
     return ws
 
 
+PMC_KERNEL = {"fp8": "mt_map_kernel<2, moq::OpFp8Qdq>", "int8": "mt_map_kernel<2, moq::OpIntQdq>",
+              "int4g128": "mt_group_kernel<2, 16>"}
+
+
+def pmc_traffic(workload, model, n_layers):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC profile of this same
+    command (tools/profile_bench.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE x 1024 B verified against a kernel with known write bytes).
+    Counters cannot be read from inside the timed process, so the bench line quotes the profile; null when no
+    profile of this workload / model size is committed."""
+    if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
+        return None, None
+    path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        for name, v in prof.items():
+            if PMC_KERNEL[workload] in name and v.get("hbm_read_bytes") is not None:
+                return int(v["hbm_read_bytes"] + (v.get("hbm_write_bytes_raw") or 0)), os.path.relpath(path, ROOT)
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def cpu_baseline(workload, budget_s=12.0):
     """Time the CPU oracle (a C restatement of the reference's eager path, OpenMP on all host cores) on a
     bounded sample: repeated 4096x4096 bf16 weights until ~budget_s of CPU work."""
@@ -204,8 +228,10 @@ def main():
                 "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mx_kernel<bf16, 4> (224 launches)",
                 "mask24": "mask24_kernel<bf16> (224 launches)"}[wl]
     achieved = n_elem * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(wl, args.model, n_layers)
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4)}
 
     out = {

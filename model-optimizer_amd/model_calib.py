@@ -160,6 +160,24 @@ def get_scale(x_max, w_max, alpha):
     return (scales / (scales.max() * scales.min()).sqrt()).view(-1)
 
 
+class _WeightCacheBudget:
+    """HBM budget for keeping the 11 search weights QDQ(W * s_alpha) of every linear resident between
+    calibration batches (the reference re-quantizes them on every forward, model_calib.py:1552-1554).  288 GB of
+    HBM3E hold all of Llama-3-8B's candidates (11 x 14 GB); larger models cache what fits and recompute the rest."""
+
+    def __init__(self, device):
+        self.left = 0
+        if device.type == "cuda":
+            free, _ = torch.cuda.mem_get_info(device)
+            self.left = int(free * 0.6)
+
+    def reserve(self, nbytes: int) -> bool:
+        if nbytes <= self.left:
+            self.left -= nbytes
+            return True
+        return False
+
+
 class AWQLiteHelper:
     """Per-linear state of awq_lite (model_calib.py:1416-1451)."""
 
@@ -170,11 +188,35 @@ class AWQLiteHelper:
         self.act_sum = torch.zeros(module.weight.shape[1], dtype=torch.float32, device=module.weight.device)
         self.act_scale = None
         self.num_cache_steps = 0
+        self.num_search_steps = 0
         self.num_tokens = 0
         self.alphas = [k.item() for k in torch.arange(0, 1.0 + alpha_step, alpha_step)]  # same float32 keys as :1431
-        self.loss = {a: torch.zeros((), dtype=torch.float32, device=module.weight.device) for a in self.alphas}
+        # one device buffer for all per-alpha losses; loss[alpha] is a 1-element view the kernels accumulate into
+        self.loss_buf = torch.zeros(len(self.alphas), dtype=torch.float32, device=module.weight.device)
+        self.loss = {a: self.loss_buf[i:i + 1] for i, a in enumerate(self.alphas)}
         self.best_alpha = None
         self.best_scale = None
+        # search-pass caches (alpha -> tensors); scales depend on alpha only once act_scale is final
+        self._inv_scale = {}
+        self._w_hat = {}
+        self._cache_w = False
+
+    def search_operands(self, module, alpha):
+        """(1/s in the weight dtype widened to fp32, QDQ(W * s)) for one alpha."""
+        if alpha not in self._inv_scale:
+            s = get_scale(self.act_scale, self.weight_scale, alpha)
+            self._inv_scale[alpha] = ((1 / s).to(module.weight.dtype).float(), s.to(module.weight.dtype))
+        inv_s, s_dt = self._inv_scale[alpha]
+        w_hat = self._w_hat.get(alpha)
+        if w_hat is None:
+            w_hat = ops.awq_scale_qdq(module.weight, s_dt, self.block_size, module.weight_quantizer.num_bits)
+            if self._cache_w:
+                self._w_hat[alpha] = w_hat
+        return inv_s, w_hat
+
+    def release(self):
+        self._inv_scale.clear()
+        self._w_hat.clear()
 
 
 @torch.no_grad()
@@ -185,6 +227,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
     state = {"mode": "cache"}
+    if mods:
+        budget = _WeightCacheBudget(mods[0][1].weight.device)
+        for _, m in mods:
+            h = helpers[m]
+            h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
 
     def patched_forward(self, input):
         h = helpers[self]
@@ -199,12 +246,18 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
             return out_actual
+        out2 = out_actual.reshape(-1, out_actual.shape[-1])
+        fused = ops.mfma_gemm_supported(x2, self.weight)
         for alpha in h.alphas:
-            s = get_scale(h.act_scale, h.weight_scale, alpha)
-            xs = ops.scale_cols(x2, (1 / s).to(self.weight.dtype).float()).view_as(input)  # x * (1/s).to(dtype)
-            wq = ops.awq_scale_qdq(self.weight, s.to(self.weight.dtype), h.block_size, self.weight_quantizer.num_bits)
-            out = F.linear(xs, wq, self.bias)
-            h.loss[alpha] += (out - out_actual).float().pow(2).mean()
+            inv_s, w_hat = h.search_operands(self, alpha)
+            xs = ops.scale_cols(x2, inv_s)  # x * (1/s).to(dtype): the input quantizer's pre_quant_scale
+            if fused:
+                # contraction + (out - out_actual)^2 mean on the matrix cores; `out` never reaches HBM
+                ops.awq_err_gemm(xs, w_hat, out2, self.bias, h.loss[alpha])
+            else:  # fp32 models: library GEMM, the reference's own arithmetic
+                out = F.linear(xs, w_hat, self.bias)
+                h.loss[alpha] += (out - out2).float().pow(2).mean()
+        h.num_search_steps += 1
         return out_actual
 
     originals = {}
@@ -224,10 +277,12 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
         forward_loop(model)  # search pass
         if dist.is_available() and dist.is_initialized():
             # every rank must pick the same alpha: SUM the per-alpha losses in one bucket
-            mdist.all_reduce_bucket([v for h in helpers.values() for v in h.loss.values()], dist.ReduceOp.SUM)
+            mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()], dist.ReduceOp.SUM)
     finally:
         for m, f in originals.items():
             m.forward = f
+        for h in helpers.values():
+            h.release()
     for _, m in mods:
         h = helpers[m]
         if h.act_scale is None:

@@ -1,0 +1,126 @@
+"""INT4-AWQ (awq_lite, g=128, alpha_step 0.1) PTQ wall-clock on synthetic Llama-shaped linears -- the second
+half of BASELINE.json's metric ("INT4-AWQ PTQ wall-clock 1/2/4/8 GPU").
+
+The model is a stack of `layers` x 7 QuantLinear modules with the Llama-3-8B / 70B projection shapes; every
+linear gets its own synthetic activation batches [tokens, Cin] (per-channel log-normal scale + a few massive
+channels), i.e. the attention / norm glue of a real forward is left out: what is timed is exactly
+the awq_lite work of the path -- weight scale, act-scale pass, 11 x (x/s, QDQ(W*s), MFMA error GEMM + loss),
+best-alpha fold, final per-group max calibration -- plus the library GEMM for `out_actual`.
+N > 1 (torchrun): calibration batches shard across ranks (data parallel); act scales and per-alpha losses are
+reduced in one bucket each (distributed.py), so every rank picks the same alpha.
+
+Usage: python tools/awq_bench.py [--model llama3-8b] [--layers 4] [--batches 4] [--tokens 4096]
+       python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/awq_bench.py ...
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _moa_import  # noqa: E402
+
+MODELS = {"llama3-8b": (4096, 14336, 32, 1024), "llama3-70b": (8192, 28672, 80, 1024)}
+
+
+def layer_shapes(model):
+    h, i, _, kv = MODELS[model]
+    return [(h, h), (kv, h), (kv, h), (h, h), (i, h), (i, h), (h, i)]  # (Cout, Cin): q k v o gate up down
+
+
+class LinearStack(torch.nn.Module):
+    def __init__(self, model, layers, device, dtype):
+        super().__init__()
+        g = torch.Generator(device=device).manual_seed(1234)
+        self.linears = torch.nn.ModuleList()
+        for _ in range(layers):
+            for cout, cin in layer_shapes(model):
+                lin = torch.nn.Linear(cin, cout, bias=False, device=device, dtype=dtype)
+                with torch.no_grad():
+                    w = torch.randn(cout, cin, generator=g, device=device) * 0.02
+                    m = torch.rand(cout, cin, generator=g, device=device) < 0.001
+                    lin.weight.copy_(torch.where(m, w * 8, w).to(dtype))
+                self.linears.append(lin)
+
+    def forward(self, acts):
+        """acts: dict Cin -> activation batch [tokens, Cin]; every linear consumes the batch of its width."""
+        for lin in self.linears:
+            lin(acts[lin.in_features])
+
+
+def make_batch(cins, tokens, device, dtype, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for cin in cins:
+        chan = torch.exp(torch.randn(cin, generator=g, device=device))
+        chan[torch.randint(0, cin, (4,), generator=g, device=device)] *= 50.0
+        out[cin] = (torch.randn(tokens, cin, generator=g, device=device) * chan).to(dtype)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--batches", type=int, default=4, help="calibration batches in total (sharded over ranks)")
+    ap.add_argument("--tokens", type=int, default=4096, help="tokens per batch (8 x 512)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    moa = _moa_import.load()
+    dtype = torch.bfloat16
+
+    model = LinearStack(args.model, args.layers, dev, dtype)
+    cins = sorted({cin for _, cin in layer_shapes(args.model)})
+    my_batches = [make_batch(cins, args.tokens, dev, dtype, 100 + b) for b in range(args.batches) if b % world == rank]
+
+    def loop(m):
+        for b in my_batches:
+            m(b)
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    moa.quantize(model, moa.model_quant.INT4_AWQ_CFG, loop)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    n_w = sum(lin.weight.numel() for lin in model.linears)
+    flops = 12.0 * 2.0 * args.tokens * args.batches * n_w  # 11 alpha GEMMs + out_actual, all ranks
+    alphas = [float(lin.awq_lite.best_alpha) for lin in model.linears]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "INT4-AWQ PTQ wall-clock", "value": round(dt, 4), "unit": "s", "n_gpus": world,
+            "higher_is_better": False,
+            "config": {"workload": f"{args.model} x {args.layers} layers ({len(model.linears)} linears, {n_w * 2 / 1e9:.2f} GB bf16), "
+                                   f"awq_lite g128 alpha_step 0.1, {args.batches} batches x {args.tokens} tokens, synthetic",
+                       "parallelism": f"calibration batches sharded over {world} GPU(s)"},
+            "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
+            "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
