@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mask24"])
     ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
     ap.add_argument("--layers", type=int, default=0, help="0 = all layers of the model")
+    ap.add_argument("--group-mb", type=int, default=0,
+                    help="fp8/int8: calibrate+QDQ in groups of <= this many MB of weights (second read from the "
+                         "Infinity Cache) instead of two whole-model passes; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernel measurements")
     args = ap.parse_args()
@@ -153,6 +156,18 @@ def main():
     wl = args.workload
 
     tab = SegmentTable(weights, group_size=128 if wl == "int4g128" else None)
+    groups = None
+    if args.group_mb and wl in ("fp8", "int8"):
+        groups, cur, cur_b = [], [], 0
+        for i, w in enumerate(weights):
+            b = w.numel() * w.element_size()
+            if cur and cur_b + b > args.group_mb * 1e6:
+                groups.append(cur)
+                cur, cur_b = [], 0
+            cur.append(i)
+            cur_b += b
+        groups.append(cur)
+        groups = [SegmentTable([weights[i] for i in g], outputs=[tab.outputs[i] for i in g]) for g in groups]
     masks = None
     if wl == "mask24":
         masks = [None] * len(weights)
@@ -161,7 +176,19 @@ def main():
     dom_events = []
 
     def step(record):
-        if wl == "fp8" or wl == "int8":
+        if groups is not None:
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            for gt in groups:
+                gt.calibrate_amax()
+                gt.fake_quant_e4m3() if wl == "fp8" else gt.fake_quant_int(8, False, True)
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+            if world > 1:
+                dist.all_reduce(torch.cat([gt.amax_flat for gt in groups]), op=dist.ReduceOp.MAX)
+        elif wl == "fp8" or wl == "int8":
             tab.calibrate_amax()
             if world > 1:
                 dist.all_reduce(tab.amax_flat, op=dist.ReduceOp.MAX)  # one bucket for all 224 amax

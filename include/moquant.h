@@ -186,6 +186,11 @@ int moq_int4_pack_export(const void* w, const float* wsf, uint8_t* out, int64_t 
  * (quantization/model_calib.py:1208-1216).  x == y allowed. */
 int moq_scale_cols(const void* w, const float* s, void* y, int64_t rows, int64_t cols, int dt,
                    void* stream);
+/* y[a, r, c] = dtype(w[r,c] * s[a, c]) for a < n_scales (s fp32 [n_scales, cols]): one read, n_scales writes
+ * -- the pre-scaled inputs x * (1/s_alpha) of all AWQ candidates (input_quantizer.pre_quant_scale,
+ * nn/modules/tensor_quantizer.py:1143-1144 applied by model_calib.py:1552).  cols % (16 / elem size) == 0. */
+int moq_scale_cols_multi(const void* w, const float* s, void* y, int64_t rows, int64_t cols, int n_scales,
+                         int dt, void* stream);
 /* Fused AWQ search inner op: t = dtype(w[r,c] * s[c]) (s already in dtype dt, product rounded to dt as
  * TensorQuantizer.forward does, tensor_quantizer.py:1143-1144), then per-group (g along cols) dynamic
  * amax + INT-k QDQ of t.  cols % g == 0.  Replaces model_calib.py:1552-1554 weight side. */
@@ -221,6 +226,13 @@ int64_t moq_awq_err_gemm_workspace(int64_t tokens, int64_t cout);
 int moq_awq_err_gemm(const void* x, const void* w, const void* out_actual, const void* bias,
                      int64_t tokens, int64_t cout, int64_t cin, int dt, float* partial, float* loss_acc,
                      void* stream);
+/* All candidates of one linear in ONE grid (blockIdx.y = candidate): x[a] = x + a * x_stride elements,
+ * w[a] = w + a * w_stride elements (strides multiples of 8; 0 shares the operand), loss_acc[a] += loss_a.
+ * `partial`: n_cand * moq_awq_err_gemm_workspace(tokens, cout) floats.  Replaces the alpha loop of the
+ * patched forward (quantization/model_calib.py:1535-1556) -- 11 launches and 11 host round trips become one. */
+int moq_awq_err_gemm_multi(const void* x, const void* w, const void* out_actual, const void* bias,
+                           int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
+                           int64_t w_stride, float* partial, float* loss_acc, void* stream);
 /* The same MFMA main loop with a store epilogue: out[t, n] = dtype(sum_k x[t,k] * w[n,k] (+ bias[n])) --
  * torch.nn.functional.linear for the model dtype (used to check the contraction on its own). */
 int moq_gemm_nt(const void* x, const void* w, const void* bias, void* out, int64_t tokens, int64_t cout,

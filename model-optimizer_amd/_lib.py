@@ -66,6 +66,9 @@ SIGNATURES = {
     "moq_awq_err_gemm_workspace": (c_int64, [c_int64, c_int64]),
     "moq_awq_err_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                  c_void_p, c_void_p, c_void_p]),
+    "moq_awq_err_gemm_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
+                                       c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "moq_scale_cols_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -418,6 +418,35 @@ __global__ __launch_bounds__(kBlock) void scale_cols_kernel(const void* __restri
   }
 }
 
+// y[a, r, c] = dtype(w[r, c] * s[a, c]) for a < n_scales: ONE read of w, n_scales writes (the 11 pre-scaled
+// activation copies of an AWQ search step).  Requires the fast layout (checked by the host entry).
+template <int DT>
+__global__ __launch_bounds__(kBlock) void scale_cols_multi_kernel(const void* __restrict__ w,
+                                                                  const float* __restrict__ s,
+                                                                  void* __restrict__ y, int64_t rows,
+                                                                  int64_t cols, int n_scales) {
+  constexpr int V = Elem<DT>::kVec;
+  const int64_t n = rows * cols;
+  const int64_t n_packets = n / V;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
+       p += (int64_t)gridDim.x * kBlock) {
+    float v[8];
+    unpack<DT>(load16_nt(reinterpret_cast<const char*>(w) + p * 16), v);
+    const int64_t c = (p * V) % cols;
+    for (int a = 0; a < n_scales; ++a) {
+      const float* sa = s + (int64_t)a * cols + c;
+      float o[8];
+      const float4 s0 = *reinterpret_cast<const float4*>(sa);
+      o[0] = v[0] * s0.x; o[1] = v[1] * s0.y; o[2] = v[2] * s0.z; o[3] = v[3] * s0.w;
+      if constexpr (V == 8) {
+        const float4 s1 = *reinterpret_cast<const float4*>(sa + 4);
+        o[4] = v[4] * s1.x; o[5] = v[5] * s1.y; o[6] = v[6] * s1.z; o[7] = v[7] * s1.w;
+      }
+      store16(reinterpret_cast<char*>(y) + ((int64_t)a * n_packets + p) * 16, pack<DT>(o));
+    }
+  }
+}
+
 }  // namespace moq
 
 // ================================================================================================
@@ -573,4 +602,24 @@ extern "C" int moq_scale_cols(const void* w, const float* s, void* y, int64_t ro
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
                                             s, y, rows, cols));
   return check_launch("moq_scale_cols");
+}
+
+extern "C" int moq_scale_cols_multi(const void* w, const float* s, void* y, int64_t rows, int64_t cols,
+                                    int n_scales, int dt, void* stream) {
+  if (rows < 0 || cols <= 0 || n_scales < 1 || w == nullptr || s == nullptr || y == nullptr) {
+    set_error("moq_scale_cols_multi: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if (cols % vec != 0 || ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) |
+                            reinterpret_cast<uintptr_t>(s)) & 15u) != 0) {
+    set_error("moq_scale_cols_multi: needs cols %% %d == 0 and 16-byte aligned pointers", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int64_t n = rows * cols;
+  if (n == 0) return MOQ_OK;
+  const int grid = stream_grid(kBlock, n / vec);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_multi_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                            w, s, y, rows, cols, n_scales));
+  return check_launch("moq_scale_cols_multi");
 }

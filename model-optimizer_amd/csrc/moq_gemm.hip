@@ -31,12 +31,23 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-constexpr int kTile = 128;                          // rows per operand tile
-constexpr int kBK = 64;                             // k per stage
-constexpr int kRowBytes = kBK * 2;                  // 128 B
-constexpr int kTileBytes = kTile * kRowBytes;       // 16 KiB per operand per stage
-constexpr int kStageBytes = 2 * kTileBytes;         // A + B
-constexpr int kGemmLds = 2 * kStageBytes;           // double buffered: 64 KiB
+constexpr int kBK = 64;            // k per stage
+constexpr int kRowBytes = kBK * 2;  // 128 B LDS rows
+
+// Tile geometries.  Waves form a WN x WT grid; each wave owns NI x NJ MFMA tiles of 32 x 32.
+//   GEO 0: 128 x 128, 4 waves, ONE 32 KiB LDS stage, ~4 workgroups per CU hide each other's DMA waits
+//   GEO 1: 128 x 128, 4 waves, two stages; all fragments of a K-step are read before the next DMA is issued
+//          (hipcc orders an LDS-DMA before every later ds_read with vmcnt(0), so reads must come first)
+//   GEO 2: 256 x 256, 8 waves, two 64 KiB stages, ONE workgroup per CU; the DMA is issued from inline asm right
+//          after the barrier (the compiler then neither sees a pending LDS write nor drains it early) and lands
+//          under the K-step's 32 MFMAs per wave; half the L2->LDS bytes per flop of the 128 x 128 tile
+template <int GEO> struct Geo;
+template <> struct Geo<0> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 1; };
+template <> struct Geo<1> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 2; };
+template <> struct Geo<2> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * kRowBytes; }
+template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
+template <int GEO> constexpr int lds_bytes() { return Geo<GEO>::STAGES * stage_bytes<GEO>(); }
 
 template <int DT>
 __device__ __forceinline__ f32x16_t mfma32(const Pack16& a, const Pack16& b, f32x16_t c) {
@@ -49,21 +60,52 @@ __device__ __forceinline__ f32x16_t mfma32(const Pack16& a, const Pack16& b, f32
   }
 }
 
-// One operand tile (128 rows x 64 k) HBM -> LDS.  `rsrc` covers the tile's valid rows only (base = first
-// row of the tile, num_records = valid_rows * ld * 2), so out-of-range rows read as zero.  Each wave issues
-// 4 instructions of 8 rows x 128 B.
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, uint8_t* lds_tile, int64_t ld_bytes,
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
+
+// One operand tile (TILE rows x 64 k) HBM -> LDS.  `rsrc` covers the tile's valid rows only (base = first row
+// of the tile, num_records = valid_rows * ld * 2), so out-of-range rows read as zero.  Each wave-instruction
+// moves 8 rows x 128 B; lane l fills LDS slot (row l >> 3, chunk position l & 7) with the source chunk
+// (l & 7) ^ ((row >> 1) & 7).
+// The descriptor travels as 4 dwords (V# layout: base[47:0], stride = 0, num_records, flags 0x00020000 = raw dword
+// format) so that the inline-asm form can name it as an SGPR quad.
+struct TileDesc {
+  i32x4_t words;  // wave-uniform
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ TileDesc make_tile_desc(const void* base, int num_bytes) {
+  TileDesc d;
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  d.words.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  d.words.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)((a >> 32) & 0xFFFFu));
+  d.words.z = __builtin_amdgcn_readfirstlane(num_bytes);
+  d.words.w = 0x00020000;
+  d.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_bytes, 0x00020000);
+  return d;
+}
+
+template <int GEO, bool ASM>
+__device__ __forceinline__ void stage_tile(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes,
                                            int k0, int K, int wave, int lane) {
+  constexpr int PER_WAVE = Geo<GEO>::TILE / 8 / Geo<GEO>::WAVES;
   const int r_local = lane >> 3, pos = lane & 7;
+  const i32x4_t rs = desc.words;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rbase = (wave * 4 + j) * 8;
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int rbase = (wave * PER_WAVE + j) * 8;
     const int r = rbase + r_local;
     const int c = pos ^ ((r >> 1) & 7);
     const int k = k0 + c * 8;
     // K tail (K % 8 == 0 guaranteed): chunks at or past K must read as zero -> force an out-of-range offset
     const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds_tile + rbase * kRowBytes), 16, voff, 0, 0, 0);
+    uint8_t* dst = lds_tile + rbase * kRowBytes;
+    if constexpr (ASM) {
+      const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(desc.rsrc, (lds_ptr_t)dst, 16, voff, 0, 0, 0);
+    }
   }
 }
 
@@ -72,15 +114,55 @@ __device__ __forceinline__ Pack16 read_frag(const uint8_t* lds_tile, int r, int 
   return *reinterpret_cast<const Pack16*>(lds_tile + r * kRowBytes + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
+// one K-step (64 k) of a wave's NI x NJ tiles from the stage at `stage`.  Fragments are double-buffered in
+// registers: the reads of sub-step ks+1 are in flight while the MFMAs of sub-step ks issue.  `after_first`
+// runs once the first sub-step's reads have been issued (GEO 2 issues the next tile's DMA there, so its address
+// arithmetic hides under the LDS latency instead of delaying the first MFMA after the barrier).
+template <int DT, int GEO, class F>
+__device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int fr, int fh,
+                                       f32x16_t (&acc)[Geo<GEO>::NI][Geo<GEO>::NJ], F&& after_first) {
+  constexpr int NI = Geo<GEO>::NI, NJ = Geo<GEO>::NJ;
+  const uint8_t* la = stage + (wn * NI * 32) * kRowBytes;
+  const uint8_t* lb = stage + tile_bytes<GEO>() + (wt * NJ * 32) * kRowBytes;
+  Pack16 a[2][NI], b[2][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a[0][i] = read_frag(la, i * 32 + fr, fh);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b[0][j] = read_frag(lb, j * 32 + fr, fh);
+  after_first();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int cur = ks & 1, nxt = cur ^ 1;
+    if (ks < 3) {
+      const int c = (ks + 1) * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[nxt][i] = read_frag(la, i * 32 + fr, c);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[nxt][j] = read_frag(lb, j * 32 + fr, c);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[cur][i], b[cur][j], acc[i][j]);
+    // pin the issue order hipcc would otherwise collapse: the next sub-step's reads go out first, then this
+    // sub-step's MFMAs run while they are in flight (mask 0x100 = DS read, 0x008 = MFMA)
+    if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+  }
+}
+
 // MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n].
-template <int DT, int MODE, bool DBUF>
-__global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void* __restrict__ x,    // [T, K]
-                                                          const void* __restrict__ w,    // [N, K]
-                                                          const void* __restrict__ ref,  // [T, N] (MODE 0)
-                                                          const void* __restrict__ bias, // [N] or null
-                                                          void* __restrict__ out,        // [T, N] (MODE 1)
-                                                          float* __restrict__ partial, int T, int N, int K,
-                                                          int tiles_t, int tiles_n) {
+template <int DT, int MODE, int GEO>
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : 2)
+void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
+                     const void* __restrict__ w,     // [N, K]
+                     const void* __restrict__ ref,   // [T, N] (MODE 0)
+                     const void* __restrict__ bias,  // [N] or null
+                     void* __restrict__ out,         // [T, N] (MODE 1)
+                     float* __restrict__ partial, int T, int N, int K, int tiles_t, int tiles_n,
+                     int64_t x_stride, int64_t w_stride) {
+  constexpr int TILE = Geo<GEO>::TILE, NI = Geo<GEO>::NI, NJ = Geo<GEO>::NJ;
+  constexpr int WTC = Geo<GEO>::WAVES / Geo<GEO>::WN;  // waves along t
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
@@ -92,41 +174,56 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int tn = bid / tiles_t, tt = bid % tiles_t;  // consecutive workgroups share the W tile
-  const int n0 = tn * kTile, t0 = tt * kTile;
-  const int rows_w = N - n0 < kTile ? N - n0 : kTile;
-  const int rows_x = T - t0 < kTile ? T - t0 : kTile;
+  const int n0 = tn * TILE, t0 = tt * TILE;
+  // blockIdx.y = candidate index of a batched launch (all alphas of one linear in one grid): every candidate has
+  // its own operands x[a] / w[a] and its own partial-sum plane; `ref` / `bias` are shared
+  x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
+  w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
+  if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
+  const int rows_w = N - n0 < TILE ? N - n0 : TILE;
+  const int rows_x = T - t0 < TILE ? T - t0 : TILE;
   const int64_t ld_bytes = (int64_t)K * 2;
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(w)) + (int64_t)n0 * ld_bytes, 0,
-      (int)(rows_w * ld_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(x)) + (int64_t)t0 * ld_bytes, 0,
-      (int)(rows_x * ld_bytes), 0x00020000);
+  const TileDesc rs_w = make_tile_desc(reinterpret_cast<const uint8_t*>(w) + (int64_t)n0 * ld_bytes,
+                                       (int)(rows_w * ld_bytes));
+  const TileDesc rs_x = make_tile_desc(reinterpret_cast<const uint8_t*>(x) + (int64_t)t0 * ld_bytes,
+                                       (int)(rows_x * ld_bytes));
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int wn = wave >> 1, wt = wave & 1;  // wave's 64 x 64 quadrant: n rows wn*64.., t cols wt*64..
+  const int wn = wave / WTC, wt = wave % WTC;  // wave's sub-tile: n rows wn*NI*32.., t cols wt*NJ*32..
   const int fr = lane & 31, fh = lane >> 5;
   const int nk = (K + kBK - 1) / kBK;
+  constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (DBUF) {
-    // two LDS stages: all 16 fragments of tile kt go to registers first, then the DMA of tile kt+1 is issued
-    // and runs under the 16 MFMAs (the compiler orders an LDS-DMA before any later ds_read of the same
-    // array with vmcnt(0), so reads must precede the issue for the overlap to exist)
-    stage_tile(rs_w, smem, ld_bytes, 0, K, wave, lane);
-    stage_tile(rs_x, smem + kTileBytes, ld_bytes, 0, K, wave, lane);
+  if constexpr (GEO == 2) {
+    stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
+    stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile kt has landed
+      __syncthreads();  // ... everyone's has, and everyone is done reading the other stage (K-step kt-1)
+      k_step<DT, GEO>(smem + (kt & 1) * SB, wn, wt, fr, fh, acc, [&]() {
+        if (kt + 1 < nk) {
+          uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+          stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+          stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        }
+      });
+    }
+  } else if constexpr (GEO == 1) {
+    stage_tile<GEO, false>(rs_w, smem, ld_bytes, 0, K, wave, lane);
+    stage_tile<GEO, false>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();  // tile kt landed for everyone; everyone finished reading the other stage
-      const uint8_t* cur = smem + (kt & 1) * kStageBytes;
+      const uint8_t* cur = smem + (kt & 1) * SB;
       const uint8_t* la = cur + (wn * 64) * kRowBytes;
-      const uint8_t* lb = cur + kTileBytes + (wt * 64) * kRowBytes;
+      const uint8_t* lb = cur + TB + (wt * 64) * kRowBytes;
       Pack16 a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -135,9 +232,9 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
         b0[ks] = read_frag(lb, fr, c); b1[ks] = read_frag(lb, 32 + fr, c);
       }
       if (kt + 1 < nk) {
-        uint8_t* nxt = smem + ((kt + 1) & 1) * kStageBytes;
-        stage_tile(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        stage_tile(rs_x, nxt + kTileBytes, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        stage_tile<GEO, false>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        stage_tile<GEO, false>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
       }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -148,24 +245,12 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
       }
     }
   } else {
-    // one LDS stage (32 KiB): up to 4 workgroups per CU overlap each other's DMA waits
     for (int kt = 0; kt < nk; ++kt) {
-      stage_tile(rs_w, smem, ld_bytes, kt * kBK, K, wave, lane);
-      stage_tile(rs_x, smem + kTileBytes, ld_bytes, kt * kBK, K, wave, lane);
+      stage_tile<GEO, false>(rs_w, smem, ld_bytes, kt * kBK, K, wave, lane);
+      stage_tile<GEO, false>(rs_x, smem + TB, ld_bytes, kt * kBK, K, wave, lane);
       __builtin_amdgcn_s_waitcnt(0);
       __syncthreads();
-      const uint8_t* la = smem + (wn * 64) * kRowBytes;
-      const uint8_t* lb = smem + kTileBytes + (wt * 64) * kRowBytes;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks * 2 + fh;
-        const Pack16 a0 = read_frag(la, fr, c), a1 = read_frag(la, 32 + fr, c);
-        const Pack16 b0 = read_frag(lb, fr, c), b1 = read_frag(lb, 32 + fr, c);
-        acc[0][0] = mfma32<DT>(a0, b0, acc[0][0]);
-        acc[0][1] = mfma32<DT>(a0, b1, acc[0][1]);
-        acc[1][0] = mfma32<DT>(a1, b0, acc[1][0]);
-        acc[1][1] = mfma32<DT>(a1, b1, acc[1][1]);
-      }
+      k_step<DT, GEO>(smem, wn, wt, fr, fh, acc, []() {});
       __syncthreads();  // all fragment reads done before the next tile overwrites the stage
     }
   }
@@ -175,10 +260,10 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
   float sq = 0.0f;
   const bool has_bias = bias != nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NI; ++i) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * fh;
+      const int n = n0 + (wn * NI + i) * 32 + 8 * q + 4 * fh;
       if (n >= N) continue;  // N % 4 == 0 is required by the host, so a run of 4 is all-in or all-out
       float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (has_bias) {
@@ -186,8 +271,8 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
         for (int e = 0; e < 4; ++e) bv[e] = load1<DT>(bias, n + e);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int t = t0 + wt * 64 + j * 32 + fr;
+      for (int j = 0; j < NJ; ++j) {
+        const int t = t0 + (wt * NJ + j) * 32 + fr;
         if (t >= T) continue;
         float o[4];
 #pragma unroll
@@ -219,14 +304,18 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
     }
   }
   if constexpr (MODE == 0) {
-    // deterministic workgroup sum: butterfly inside the wave, fixed order across the 4 waves
+    // deterministic workgroup sum: butterfly inside the wave, fixed order across the waves
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
     __syncthreads();  // all LDS tile reads are done; reuse the first words
     float* red = reinterpret_cast<float*>(smem);
     if (lane == 0) red[wave] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+      float s = red[0];
+      for (int v = 1; v < Geo<GEO>::WAVES; ++v) s += red[v];
+      partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
   }
 }
 
@@ -234,6 +323,8 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void err_gemm_kernel(const void*
 __global__ void err_finalize_kernel(const float* __restrict__ partial, int n, double inv_count,
                                     float* __restrict__ loss_acc) {
   __shared__ double sm[256];
+  partial += (int64_t)blockIdx.x * n;  // one workgroup per candidate
+  loss_acc += blockIdx.x;
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
   sm[threadIdx.x] = s;
@@ -276,67 +367,109 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
   return MOQ_OK;
 }
 
-static int64_t n_tiles(int64_t tokens, int64_t cout) {
-  return ((tokens + kTile - 1) / kTile) * ((cout + kTile - 1) / kTile);
+static int gemm_geo() {
+  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 selects the tile geometry (A/B knob, read once)
+  static const int geo = [] {
+    const char* e = getenv("MOQ_TUNE_GEMM_GEO");
+    const int g = e ? atoi(e) : 2;
+    return g < 0 || g > 2 ? 2 : g;
+  }();
+  return geo;
+}
+static int64_t n_tiles_for(int64_t tokens, int64_t cout, int tile) {
+  return ((tokens + tile - 1) / tile) * ((cout + tile - 1) / tile);
 }
 
+template <int MODE, int GEO>
+static void launch_geo(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
+                       int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
+                       int64_t w_stride, void* stream) {
+  constexpr int TILE = Geo<GEO>::TILE;
+  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  const unsigned nblk = (unsigned)(tiles_t * tiles_n);
+  static bool attr_set = false;
+  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_BF16, MODE, GEO>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
+    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_F16, MODE, GEO>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
+    attr_set = true;
+  }
+  const dim3 grid(nblk, (unsigned)n_cand), block(Geo<GEO>::WAVES * 64);
+  if (dt == MOQ_BF16) {
+    hipLaunchKernelGGL((err_gemm_kernel<MOQ_BF16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
+                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride);
+  } else {
+    hipLaunchKernelGGL((err_gemm_kernel<MOQ_F16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
+                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride);
+  }
+}
+
+// returns the number of per-tile partial sums each candidate produced (MODE 0), or a negative status
 template <int MODE>
-static int launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
-                       float* partial, int64_t tokens, int64_t cout, int64_t cin, int dt, void* stream) {
-  const int tiles_t = (int)((tokens + kTile - 1) / kTile), tiles_n = (int)((cout + kTile - 1) / kTile);
-  const int64_t nblk = (int64_t)tiles_t * tiles_n;
+static int64_t launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
+                           float* partial, int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand,
+                           int64_t x_stride, int64_t w_stride, void* stream) {
+  const int geo = gemm_geo();
+  const int tile = geo == 2 ? 256 : 128;
+  const int64_t nblk = n_tiles_for(tokens, cout, tile);
   if (nblk > 0x7FFFFFFF) {
     set_error("gemm: too many tiles");
     return MOQ_ERR_UNSUPPORTED;
   }
-  // MOQ_TUNE_GEMM_DBUF=1 selects the two-stage variant (A/B knob; default is the single-stage kernel)
-  static const bool dbuf = [] { const char* e = getenv("MOQ_TUNE_GEMM_DBUF"); return e && atoi(e) != 0; }();
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_BF16, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_BF16, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_F16, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-    (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_F16, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-    attr_set = true;
+  switch (geo) {
+    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
+    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
+    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
   }
-#define MOQ_LAUNCH_GEMM(DTV, DB)                                                                              \
-  hipLaunchKernelGGL((err_gemm_kernel<DTV, MODE, DB>), dim3((unsigned)nblk), dim3(256),                       \
-                     DB ? kGemmLds : kStageBytes, S(stream), x, w, ref, bias, out, partial, (int)tokens,      \
-                     (int)cout, (int)cin, tiles_t, tiles_n)
-  if (dt == MOQ_BF16) {
-    if (dbuf) MOQ_LAUNCH_GEMM(MOQ_BF16, true); else MOQ_LAUNCH_GEMM(MOQ_BF16, false);
-  } else {
-    if (dbuf) MOQ_LAUNCH_GEMM(MOQ_F16, true); else MOQ_LAUNCH_GEMM(MOQ_F16, false);
-  }
-#undef MOQ_LAUNCH_GEMM
-  return MOQ_OK;
+  return nblk;
 }
 
 extern "C" int64_t moq_awq_err_gemm_workspace(int64_t tokens, int64_t cout) {
   if (tokens < 0 || cout < 0) return MOQ_ERR_INVALID;
-  const int64_t n = n_tiles(tokens, cout);
+  const int64_t n = n_tiles_for(tokens, cout, 128);  // upper bound over all tile geometries
   return n < 1 ? 1 : n;
+}
+
+static int err_gemm_common(const void* x, const void* w, const void* out_actual, const void* bias,
+                           int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
+                           int64_t w_stride, float* partial, float* loss_acc, void* stream, const char* who) {
+  int rc = gemm_check(x, w, tokens, cout, cin, dt, who);
+  if (rc != MOQ_OK) return rc;
+  if (out_actual == nullptr || partial == nullptr || loss_acc == nullptr) {
+    set_error("%s: out_actual / partial / loss_acc must not be NULL", who);
+    return MOQ_ERR_INVALID;
+  }
+  if ((reinterpret_cast<uintptr_t>(out_actual) & 7u) != 0) {
+    set_error("%s: out_actual must be 8-byte aligned", who);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (n_cand < 1 || n_cand > 65535 || x_stride < 0 || w_stride < 0 || ((x_stride | w_stride) & 7) != 0) {
+    set_error("%s: n_cand must be in [1, 65535] and candidate strides multiples of 8 elements", who);
+    return MOQ_ERR_INVALID;
+  }
+  if (tokens == 0) return MOQ_OK;
+  const int64_t nblk = launch_gemm<0>(x, w, out_actual, bias, nullptr, partial, tokens, cout, cin, dt, n_cand,
+                                      x_stride, w_stride, stream);
+  if (nblk < 0) return (int)nblk;
+  hipLaunchKernelGGL(err_finalize_kernel, dim3((unsigned)n_cand), dim3(256), 0, S(stream), partial, (int)nblk,
+                     1.0 / ((double)tokens * (double)cout), loss_acc);
+  return check_launch(who);
 }
 
 extern "C" int moq_awq_err_gemm(const void* x, const void* w, const void* out_actual, const void* bias,
                                 int64_t tokens, int64_t cout, int64_t cin, int dt, float* partial,
                                 float* loss_acc, void* stream) {
-  int rc = gemm_check(x, w, tokens, cout, cin, dt, "moq_awq_err_gemm");
-  if (rc != MOQ_OK) return rc;
-  if (out_actual == nullptr || partial == nullptr || loss_acc == nullptr) {
-    set_error("moq_awq_err_gemm: out_actual / partial / loss_acc must not be NULL");
-    return MOQ_ERR_INVALID;
-  }
-  if ((reinterpret_cast<uintptr_t>(out_actual) & 7u) != 0) {
-    set_error("moq_awq_err_gemm: out_actual must be 8-byte aligned");
-    return MOQ_ERR_UNSUPPORTED;
-  }
-  if (tokens == 0) return MOQ_OK;
-  rc = launch_gemm<0>(x, w, out_actual, bias, nullptr, partial, tokens, cout, cin, dt, stream);
-  if (rc != MOQ_OK) return rc;
-  hipLaunchKernelGGL(err_finalize_kernel, dim3(1), dim3(256), 0, S(stream), partial, (int)n_tiles(tokens, cout),
-                     1.0 / ((double)tokens * (double)cout), loss_acc);
-  return check_launch("moq_awq_err_gemm");
+  return err_gemm_common(x, w, out_actual, bias, tokens, cout, cin, dt, 1, 0, 0, partial, loss_acc, stream,
+                         "moq_awq_err_gemm");
+}
+
+extern "C" int moq_awq_err_gemm_multi(const void* x, const void* w, const void* out_actual, const void* bias,
+                                      int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand,
+                                      int64_t x_stride, int64_t w_stride, float* partial, float* loss_acc,
+                                      void* stream) {
+  return err_gemm_common(x, w, out_actual, bias, tokens, cout, cin, dt, n_cand, x_stride, w_stride, partial,
+                         loss_acc, stream, "moq_awq_err_gemm_multi");
 }
 
 extern "C" int moq_gemm_nt(const void* x, const void* w, const void* bias, void* out, int64_t tokens,
@@ -348,7 +481,7 @@ extern "C" int moq_gemm_nt(const void* x, const void* w, const void* bias, void*
     return MOQ_ERR_INVALID;
   }
   if (tokens == 0) return MOQ_OK;
-  rc = launch_gemm<1>(x, w, nullptr, bias, out, nullptr, tokens, cout, cin, dt, stream);
-  if (rc != MOQ_OK) return rc;
+  const int64_t nblk = launch_gemm<1>(x, w, nullptr, bias, out, nullptr, tokens, cout, cin, dt, 1, 0, 0, stream);
+  if (nblk < 0) return (int)nblk;
   return check_launch("moq_gemm_nt");
 }

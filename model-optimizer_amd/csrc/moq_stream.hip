@@ -32,14 +32,16 @@ __device__ __forceinline__ int packet_off(int u) {
 }
 
 // Guarded / unaligned packet access.  FAST = chunk fully inside the tensor and base 16-byte aligned.
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool NT = true>
 __device__ __forceinline__ Pack16 ld_packet(const void* base, int64_t e, int64_t n) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int ES = 16 / V;
   if constexpr (FAST) {
     // streaming data is read exactly once: non-temporal hint (measured on MI355X, 14 GiB streams:
-    // read-only 6.2 -> 7.0 TB/s, copy 5.9 -> 6.5 TB/s; tools/exp/stream_probe.hip)
-    return load16_nt(reinterpret_cast<const char*>(base) + e * ES);
+    // read-only 6.2 -> 7.0 TB/s, copy 5.9 -> 6.5 TB/s; tools/exp/stream_probe.hip).  NT = false keeps the
+    // lines in L2 / Infinity Cache for a second pass over the same tensor (grouped calibrate -> QDQ).
+    if constexpr (NT) return load16_nt(reinterpret_cast<const char*>(base) + e * ES);
+    else return load16(reinterpret_cast<const char*>(base) + e * ES);
   } else {
     float f[V];
 #pragma unroll
@@ -160,12 +162,12 @@ __device__ __forceinline__ void chunk_apply(const void* x, void* y, int64_t e0, 
 }
 
 // abs-max pattern of one chunk (per thread partial)
-template <int DT, bool FAST>
+template <int DT, bool FAST, bool NT = true>
 __device__ __forceinline__ uint32_t chunk_absmax(const void* x, int64_t e0, int64_t n, uint32_t acc) {
   constexpr int P = Chunk<DT>::kPackets;
   Pack16 in[P];
 #pragma unroll
-  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + packet_off<DT>(u), n);
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST, NT>(x, e0 + packet_off<DT>(u), n);
 #pragma unroll
   for (int u = 0; u < P; ++u) {
     uint32_t m = pack_absmax<DT>(in[u]);
@@ -447,7 +449,7 @@ struct SegCursor {
   }
 };
 
-template <int DT>
+template <int DT, bool NT>
 __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restrict__ segs,
                                                          const int64_t* __restrict__ blk_start,
                                                          int n_seg, int64_t n_chunks) {
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restri
     }
     const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
     if (cur.aligned && e0 + MOQ_MT_CHUNK <= cur.sg.n)
-      acc = chunk_absmax<DT, true>(cur.sg.x, e0, cur.sg.n, acc);
+      acc = chunk_absmax<DT, true, NT>(cur.sg.x, e0, cur.sg.n, acc);
     else
       acc = chunk_absmax<DT, false>(cur.sg.x, e0, cur.sg.n, acc);
   }
@@ -739,8 +741,16 @@ extern "C" int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_
   if (rc != MOQ_OK || n_seg == 0) return rc;
   hipLaunchKernelGGL(mt_zero_amax_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, S(stream), segs, n_seg);
   if (n_chunks > 0) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_kernel<DT>), dim3(mt_grid(n_chunks)), dim3(kBlock),
-                                              0, S(stream), segs, blk_start, n_seg, n_chunks));
+    // MOQ_TUNE_AMAX_KEEP=1: plain (cache-allocating) loads, for a QDQ pass that follows while the tensors are
+    // still in the 256 MB Infinity Cache
+    static const bool keep = [] { const char* e = getenv("MOQ_TUNE_AMAX_KEEP"); return e && atoi(e) != 0; }();
+    if (keep) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_kernel<DT, false>), dim3(mt_grid(n_chunks)), dim3(kBlock),
+                                                0, S(stream), segs, blk_start, n_seg, n_chunks));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_kernel<DT, true>), dim3(mt_grid(n_chunks)), dim3(kBlock),
+                                                0, S(stream), segs, blk_start, n_seg, n_chunks));
+    }
   }
   return check_launch("moq_mt_amax");
 }

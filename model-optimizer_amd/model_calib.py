@@ -197,26 +197,31 @@ class AWQLiteHelper:
         self.best_alpha = None
         self.best_scale = None
         # search-pass caches (alpha -> tensors); scales depend on alpha only once act_scale is final
-        self._inv_scale = {}
-        self._w_hat = {}
+        self._inv_scale = None
+        self._scale_dt = None
+        self._w_hat = None
         self._cache_w = False
 
-    def search_operands(self, module, alpha):
-        """(1/s in the weight dtype widened to fp32, QDQ(W * s)) for one alpha."""
-        if alpha not in self._inv_scale:
-            s = get_scale(self.act_scale, self.weight_scale, alpha)
-            self._inv_scale[alpha] = ((1 / s).to(module.weight.dtype).float(), s.to(module.weight.dtype))
-        inv_s, s_dt = self._inv_scale[alpha]
-        w_hat = self._w_hat.get(alpha)
+    def search_operands(self, module):
+        """(inv_s [A, Cin] fp32 = (1/s_alpha) rounded to the weight dtype, w_hat [A, Cout, Cin] = QDQ(W * s_alpha))
+        for all candidates.  Scales depend on alpha only (act_scale is final in the search pass) and are computed
+        once; w_hat stays resident when the budget allows, otherwise it is rebuilt per batch."""
+        dt = module.weight.dtype
+        if self._inv_scale is None:
+            scales = [get_scale(self.act_scale, self.weight_scale, a) for a in self.alphas]
+            self._inv_scale = torch.stack([(1 / s).to(dt).float() for s in scales]).contiguous()
+            self._scale_dt = [s.to(dt) for s in scales]
+        w_hat = self._w_hat
         if w_hat is None:
-            w_hat = ops.awq_scale_qdq(module.weight, s_dt, self.block_size, module.weight_quantizer.num_bits)
+            w_hat = torch.empty(len(self.alphas), *module.weight.shape, dtype=dt, device=module.weight.device)
+            for i, s in enumerate(self._scale_dt):
+                ops.awq_scale_qdq(module.weight, s, self.block_size, module.weight_quantizer.num_bits, out=w_hat[i])
             if self._cache_w:
-                self._w_hat[alpha] = w_hat
-        return inv_s, w_hat
+                self._w_hat = w_hat
+        return self._inv_scale, w_hat
 
     def release(self):
-        self._inv_scale.clear()
-        self._w_hat.clear()
+        self._inv_scale = self._scale_dt = self._w_hat = None
 
 
 @torch.no_grad()
@@ -247,15 +252,15 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             h.num_tokens += x2.shape[0]
             return out_actual
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
-        fused = ops.mfma_gemm_supported(x2, self.weight)
-        for alpha in h.alphas:
-            inv_s, w_hat = h.search_operands(self, alpha)
-            xs = ops.scale_cols(x2, inv_s)  # x * (1/s).to(dtype): the input quantizer's pre_quant_scale
-            if fused:
-                # contraction + (out - out_actual)^2 mean on the matrix cores; `out` never reaches HBM
-                ops.awq_err_gemm(xs, w_hat, out2, self.bias, h.loss[alpha])
-            else:  # fp32 models: library GEMM, the reference's own arithmetic
-                out = F.linear(xs, w_hat, self.bias)
+        inv_s, w_hat = h.search_operands(self)
+        if ops.mfma_gemm_supported(x2, self.weight):
+            # all 11 candidates in two launches: xs[a] = x * (1/s_a) (one read of x), then the batched MFMA
+            # contraction with the (out - out_actual)^2 mean fused -- `out` never reaches HBM
+            xs = ops.scale_cols_multi(x2, inv_s)
+            ops.awq_err_gemm_multi(xs, w_hat, out2, self.bias, h.loss_buf)
+        else:  # fp32 models: library GEMM, the reference's own arithmetic
+            for i, alpha in enumerate(h.alphas):
+                out = F.linear(ops.scale_cols(x2, inv_s[i]), w_hat[i], self.bias)
                 h.loss[alpha] += (out - out2).float().pow(2).mean()
         h.num_search_steps += 1
         return out_actual

@@ -473,3 +473,48 @@ def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) 
         check(_lib.lib().moq_gemm_nt(_p(x2), _p(wc), _p(b), _p(out), x2.shape[0], wc.shape[0], x2.shape[1],
                                      _dt(x2), stream))
     return out.view(*x.shape[:-1], wc.shape[0])
+
+
+@torch.no_grad()
+def scale_cols_multi(x: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """y[a] = (x * scales[a]).to(x.dtype) for every row a of the fp32 matrix `scales` [A, cols]: one read of x,
+    A writes -- the pre-scaled inputs of all AWQ candidates at once."""
+    _require_gpu(x, "scale_cols_multi")
+    x2 = x.detach().contiguous().view(-1, x.shape[-1])
+    s = _f32(scales, x2.device)
+    if s.dim() != 2 or s.shape[1] != x2.shape[1]:
+        raise MoquantError("scale_cols_multi: scales must be [A, cols]")
+    y = torch.empty(s.shape[0], x2.shape[0], x2.shape[1], dtype=x2.dtype, device=x2.device)
+    with _on(x2) as stream:
+        check(_lib.lib().moq_scale_cols_multi(_p(x2), _p(s), _p(y), x2.shape[0], x2.shape[1], s.shape[0], _dt(x2),
+                                              stream))
+    return y
+
+
+@torch.no_grad()
+def awq_err_gemm_multi(xs: torch.Tensor, w_hat: torch.Tensor, out_actual: torch.Tensor,
+                       bias: torch.Tensor | None, loss_acc: torch.Tensor) -> torch.Tensor:
+    """All candidates of one linear in one launch: xs [A, T, K] (or [T, K] shared), w_hat [A, N, K] (or [N, K]
+    shared); loss_acc[a] += mean((linear(xs[a], w_hat[a], bias) - out_actual).float() ** 2).  fp32 [A]."""
+    _require_gpu(xs, "awq_err_gemm_multi")
+    n_cand = loss_acc.numel()
+    x3 = xs.detach().contiguous()
+    w3 = w_hat.detach().contiguous()
+    tokens, cin = x3.shape[-2], x3.shape[-1]
+    cout = w3.shape[-2]
+    x_stride = tokens * cin if x3.dim() == 3 else 0
+    w_stride = cout * cin if w3.dim() == 3 else 0
+    if (x3.dim() == 3 and x3.shape[0] != n_cand) or (w3.dim() == 3 and w3.shape[0] != n_cand):
+        raise MoquantError("awq_err_gemm_multi: leading dim of xs / w_hat must equal loss_acc.numel()")
+    ref = out_actual.detach().contiguous().view(-1, cout)
+    if ref.shape[0] != tokens or w3.shape[-1] != cin or ref.dtype != x3.dtype or w3.dtype != x3.dtype:
+        raise MoquantError("awq_err_gemm_multi: shape / dtype mismatch between xs, w_hat and out_actual")
+    if loss_acc.dtype != torch.float32 or not loss_acc.is_cuda or not loss_acc.is_contiguous():
+        raise MoquantError("awq_err_gemm_multi: loss_acc must be a contiguous fp32 GPU tensor")
+    b = None if bias is None else bias.detach().to(x3.dtype).contiguous()
+    ws = torch.empty(n_cand * int(_lib.lib().moq_awq_err_gemm_workspace(tokens, cout)), dtype=torch.float32,
+                     device=x3.device)
+    with _on(x3) as stream:
+        check(_lib.lib().moq_awq_err_gemm_multi(_p(x3), _p(w3), _p(ref), _p(b), tokens, cout, cin, _dt(x3), n_cand,
+                                                x_stride, w_stride, _p(ws), _p(loss_acc), stream))
+    return loss_acc

@@ -125,3 +125,30 @@ def test_err_gemm_full_size_linearity_property():
     a3 = torch.zeros(1, dtype=torch.float32, device=DEV)
     ops.awq_err_gemm(x, w, ref, None, a3)
     assert a3.item() == a1.item()
+
+
+def test_err_gemm_multi_equals_single_launches():
+    """The batched launch (all AWQ candidates of a linear in one grid) must give exactly the per-candidate
+    results of single launches -- same tiles, same reduction order -- for strided and shared operands."""
+    torch.manual_seed(5)
+    a, t, n, k = 5, 200, 136, 328
+    x = torch.randn(t, k, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(n, k, device=DEV) * 0.05).to(torch.bfloat16)
+    ref = ops.gemm_nt(x, w)
+    inv_s = torch.exp(torch.randn(a, k, device=DEV) * 0.2)
+    xs = ops.scale_cols_multi(x, inv_s)
+    for i in range(a):  # one read / A writes == A single-scale passes
+        assert torch.equal(xs[i], ops.scale_cols(x, inv_s[i]))
+    w_hat = torch.stack([ops.awq_scale_qdq(w, (1 / inv_s[i]).to(torch.bfloat16), 8, 4) for i in range(a)])
+    multi = torch.zeros(a, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm_multi(xs, w_hat, ref, None, multi)
+    single = torch.zeros(a, dtype=torch.float32, device=DEV)
+    for i in range(a):
+        ops.awq_err_gemm(xs[i], w_hat[i], ref, None, single[i:i + 1])
+    assert torch.equal(multi, single) and (multi > 0).all()
+    shared = torch.zeros(a, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm_multi(x, w_hat, ref, None, shared)  # x shared by all candidates (stride 0)
+    for i in range(a):
+        one = torch.zeros(1, dtype=torch.float32, device=DEV)
+        ops.awq_err_gemm(x, w_hat[i], ref, None, one)
+        assert shared[i].item() == one.item()

@@ -35,15 +35,21 @@ def main():
     shapes = [("8b q/o", 4096, 4096, 4096), ("8b k/v", 4096, 1024, 4096), ("8b gate/up", 4096, 14336, 4096),
               ("8b down", 4096, 4096, 14336), ("70b gate/up", 4096, 28672, 8192), ("70b down", 4096, 8192, 28672),
               ("square 8192", 8192, 8192, 8192)]
-    print(f"variant: {'two-stage (DBUF)' if os.environ.get('MOQ_TUNE_GEMM_DBUF') == '1' else 'single-stage'}\n")
-    print("| shape (T x Cout x Cin) | fused err-GEMM ms | TFLOP/s | frac of 2.5 PF | F.linear ms | F.linear TFLOP/s | F.linear + unfused loss ms |")
-    print("|---|---|---|---|---|---|---|")
+    print(f"variant: MOQ_TUNE_GEMM_GEO={os.environ.get('MOQ_TUNE_GEMM_GEO', '2 (default)')}\n")
+    print("| shape (T x Cout x Cin) | fused err-GEMM ms | TFLOP/s | frac of 2.5 PF | batched (11 cand.) ms/cand | TFLOP/s | frac | F.linear ms | F.linear TFLOP/s | F.linear + unfused loss ms |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
     for name, t, n, k in shapes:
         x = torch.randn(t, k, device=DEV).to(torch.bfloat16)
         w = (torch.randn(n, k, device=DEV) * 0.02).to(torch.bfloat16)
         ref = torch.nn.functional.linear(x, w)
         acc = torch.zeros(1, dtype=torch.float32, device=DEV)
         ms = timed(lambda: ops.awq_err_gemm(x, w, ref, None, acc))
+        ncand = 11 if t * k * 11 * 2 + n * k * 11 * 2 < 60e9 else 4
+        xs = x.unsqueeze(0).repeat(ncand, 1, 1)
+        wh = w.unsqueeze(0).repeat(ncand, 1, 1)
+        accm = torch.zeros(ncand, dtype=torch.float32, device=DEV)
+        ms_multi = timed(lambda: ops.awq_err_gemm_multi(xs, wh, ref, None, accm), reps=3) / ncand
+        del xs, wh
         ms_lin = timed(lambda: torch.nn.functional.linear(x, w))
 
         def unfused():
@@ -52,7 +58,8 @@ def main():
 
         ms_unf = timed(unfused)
         fl = 2.0 * t * n * k
-        print(f"| {name} {t}x{n}x{k} | {ms:.3f} | {fl / ms / 1e9:.0f} | {fl / ms / 1e9 / PEAK:.3f} | {ms_lin:.3f} | "
+        print(f"| {name} {t}x{n}x{k} | {ms:.3f} | {fl / ms / 1e9:.0f} | {fl / ms / 1e9 / PEAK:.3f} | {ms_multi:.3f} | "
+              f"{fl / ms_multi / 1e9:.0f} | {fl / ms_multi / 1e9 / PEAK:.3f} | {ms_lin:.3f} | "
               f"{fl / ms_lin / 1e9:.0f} | {ms_unf:.3f} |")
         del x, w, ref
 
