@@ -155,6 +155,20 @@ int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols
 int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
                  float max_edge, int skip_zeros, void* stream);
 
+/* ------------------------------------------------------------------ MSE amax sweep (a5) */
+
+/* loss[k, a] (+)= sum over the elements governed by amax entry a of (x - QDQ(x, cand_amax[k, a]))^2 for all
+ * n_cand (<= 64) candidates in ONE read of x.  x is viewed as contiguous [outer, axis_size, inner] exactly like
+ * moq_amax_axis (per-tensor: axis_size = 1; per-channel: inner = Cin; static blocks: outer = 1, inner = g).
+ * Arithmetic as MseCalibrator.collect with the quantizer's fake quant as quant_func (calib/mse.py:83-121,
+ * model_calib.py:639-662): x upcast to fp32, QDQ in fp32 (fp8 != 0: E4M3, else INT-k with num_bits /
+ * is_unsigned / narrow_range), squared error summed in fp32.  cand_amax, loss: fp32 [n_cand, axis_size].
+ * `partial`: workspace of moq_mse_sweep_workspace() floats (may be NULL for the static-block layout). */
+int64_t moq_mse_sweep_workspace(int64_t outer, int64_t axis_size, int64_t inner, int n_cand);
+int moq_mse_sweep(const void* x, int64_t outer, int64_t axis_size, int64_t inner, int dt,
+                  const float* cand_amax, int n_cand, float* loss, float* partial, int accumulate, int fp8,
+                  int num_bits, int is_unsigned, int narrow_range, void* stream);
+
 /* ------------------------------------------------------------------ 2:4 mask (a14) */
 
 /* mask[r, c] in {0,1}: for every 4 consecutive elements of a row keep the 2-of-4 pattern with the

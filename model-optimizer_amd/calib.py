@@ -236,9 +236,14 @@ class MseCalibrator(_Calibrator):
     argmin stay as in the reference."""
 
     def __init__(self, amax, axis=None, step_size=0.1, start_multiplier=0.25, stop_multiplier=4.0,
-                 quant_func=None, error_func=None):
+                 quant_func=None, error_func=None, fused_format=None):
+        """fused_format = (num_bits, unsigned, narrow_range) of the quantizer behind `quant_func` (INT-k, or
+        num_bits == (4, 3) for FP8): with the default squared error all candidates are then evaluated by ONE
+        kernel (ops.mse_sweep) instead of the reference's per-candidate QDQ / error / reduce passes."""
         super().__init__(num_bits=None, axis=axis, unsigned=None)
+        self._fused_format = fused_format
         self._initial_amax = amax
+        self._initial_amax_host = None
         self._num_steps = math.ceil((stop_multiplier - start_multiplier) / step_size) + 1
         self._start_multiplier, self._stop_multiplier = start_multiplier, stop_multiplier
         self._quant_func, self._error_func = quant_func, error_func
@@ -247,23 +252,44 @@ class MseCalibrator(_Calibrator):
         self._amax = None
 
     def _generate_candidates(self, device):
-        return torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps, device=device)
+        # calib/mse.py:69-73.  The multipliers are generated on the host and copied: torch's CPU and GPU linspace
+        # differ in the last ulp for some steps, which moves bf16 / f16 candidate amax values by one ulp; the host
+        # values are the ones the (CPU-run) reference fixtures are pinned to, and they are device independent.
+        return torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps).to(device)
 
     def _compute_candidate_amax(self, candidates):
-        if candidates.ndim != 0:
+        if candidates.ndim != 0:  # final compute_amax: dimensioned x dimensioned promotes to fp32, unambiguous
             candidates = candidates.view_as(self._initial_amax)
-        return self._initial_amax * candidates
+            return self._initial_amax * candidates
+        # 0-dim multiplier x amax tensor keeps the amax dtype (bf16 / f16 for 16-bit weights), and torch's CPU and
+        # GPU kernels round that product differently (the GPU casts the 0-dim operand to the 16-bit dtype first).
+        # One ulp of amax moves a clipping-dominated loss by >10 %, so the product is formed with the host
+        # arithmetic the CPU-run reference fixtures are pinned to -- identical on every device.
+        if self._initial_amax_host is None:
+            self._initial_amax_host = self._initial_amax.detach().cpu()
+        return (self._initial_amax_host * candidates.detach().cpu()).to(self._initial_amax.device)
 
     @torch.no_grad()
     def collect(self, x):
-        if self._quant_func is None:
+        if self._quant_func is None and self._fused_format is None:
             raise RuntimeError("Quantization function not set.")
-        x = x.detach().to(dtype=torch.float32)
         candidates = self._generate_candidates(x.device)
         if self._candidates is None:
             self._candidates = candidates
             self._losses_sum = [None] * len(candidates)
         reduce_axis = convert_quantization_axis_to_reduce_axis(x, self._axis)
+        if self._fused_format is not None and self._error_func is None and x.is_cuda and len(candidates) <= 64:
+            # candidate amax values with the reference's dtype promotion (0-dim multiplier x amax tensor), then
+            # one pass over x for all of them; the fp32 upcast of x (mse.py:92) happens in registers
+            cand = torch.stack([self._compute_candidate_amax(c).float().reshape(-1) for c in candidates])
+            nb, uns, narrow = self._fused_format
+            losses = ops.mse_sweep(x.detach(), cand, reduce_axis, nb, uns, narrow)
+            shape = () if reduce_axis is None else None
+            for step in range(len(candidates)):
+                loss = losses[step].reshape(shape) if shape is not None else losses[step]
+                self._losses_sum[step] = loss.clone() if self._losses_sum[step] is None else self._losses_sum[step] + loss
+            return
+        x = x.detach().to(dtype=torch.float32)
         for step, candidate in enumerate(candidates):
             xq = self._quant_func(x, self._compute_candidate_amax(candidate))
             error = self._error_func(x, xq) if self._error_func is not None else (x - xq) ** 2

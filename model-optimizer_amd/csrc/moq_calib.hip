@@ -1,0 +1,237 @@
+// moq_calib.hip -- fused MSE amax-multiplier sweep (a5): MseCalibrator.collect (quantization/calib/mse.py:83-121)
+// with the quantizer's fake-quant as quant_func (_mse_quant_func, quantization/model_calib.py:639-662).
+//
+// The reference loops over the K = ceil((stop - start) / step) + 1 (39 by default) candidate amax values and, per
+// candidate, runs a QDQ pass, an elementwise squared error and a reduction -- K x ~5 passes over the tensor.
+// Here the tensor is read ONCE: a lane keeps its 16-byte packets in registers and evaluates all K candidates on
+// them.  ~12 lane-ops per element per candidate make this the one VALU-bound kernel of the path
+// (K * 12 ~ 470 lane-ops per element against ~50 per element at the HBM rate), so the design goal is op count:
+// one exact shared-denominator division per (row, candidate), no per-element reciprocal, errors accumulated in
+// registers, one DPP / shuffle reduction per candidate at the end of a row segment.
+//
+// Layout: the tensor is [rows, inner] with one amax per row group: cand[k, row % axis_size].  Rows are what the
+// quantizer's calibrator reduces over -- per-channel weights (inner = Cin), static blocks (inner = g, the
+// (-1, g) view) or the whole tensor (rows = 1).  x is upcast to fp32 like the reference (mse.py:92), the
+// QDQ result is NOT rounded to the storage dtype, the error sum is fp32.
+#include "moq_common.h"
+
+namespace moq {
+
+constexpr int kMaxCand = 64;
+
+template <bool FP8>
+struct CandQ {
+  float scale, inv;  // INT: scale = bound / amax (0 = tiny amax), FP8: s and 1/s
+  SharedDiv sd;
+};
+
+template <bool FP8>
+__device__ __forceinline__ CandQ<FP8> make_cand(float amax, const IntQ& q) {
+  CandQ<FP8> c;
+  if constexpr (FP8) {
+    const Fp8Scale s = fp8_scale(amax);
+    c.scale = s.s;
+    c.inv = s.inv;
+  } else {
+    c.scale = int_scale(amax, q.hi);
+    c.inv = 0.0f;
+    c.sd = make_shared_div(c.scale);
+  }
+  return c;
+}
+
+// squared error of one element under one candidate
+template <bool FP8>
+__device__ __forceinline__ float sq_err(float x, const CandQ<FP8>& c, const IntQ& q) {
+  float y;
+  if constexpr (FP8) {
+    const float a = x * c.scale;
+    float ca = __builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f);
+    ca = (a != a) ? a : ca;
+    float r0, r1;
+    e4m3_roundtrip2(ca, 0.0f, r0, r1);
+    y = r0 * c.inv;
+  } else {
+    y = qdq_int_shared(x, c.scale, c.sd, q);
+  }
+  const float d = x - y;
+  return d * d;
+}
+
+// One wave per (row, segment) work item; a segment is kSeg = 4096 consecutive elements of a row, held as 64
+// fp32 values per lane across all candidates (zero padding past the row end: QDQ(0) = 0 adds no error).
+// cand: [n_cand, axis_size] fp32.  partial: [n_items, n_cand] fp32.
+constexpr int kSeg = 4096;
+template <int DT, bool FP8>
+__global__ __launch_bounds__(kBlock) void mse_rows_kernel(const void* __restrict__ x, int64_t n_rows,
+                                                          int64_t axis_size, int64_t inner,
+                                                          int64_t segs_per_row,
+                                                          const float* __restrict__ cand, int n_cand,
+                                                          float* __restrict__ partial, int num_bits,
+                                                          int is_unsigned, int narrow) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = kSeg / (64 * V);  // packets per lane: 8 (16-bit) or 16 (f32)
+  const IntQ q = make_intq(num_bits, is_unsigned, narrow);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t n_items = n_rows * segs_per_row;
+  const int64_t n_waves = (int64_t)gridDim.x * (kBlock / 64);
+  const bool vec_ok = (inner % V) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  for (int64_t item = wave_id; item < n_items; item += n_waves) {
+    const int64_t row = item / segs_per_row, seg = item % segs_per_row;
+    const int64_t e0 = seg * kSeg;
+    float f[P * V];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + ((int64_t)u * 64 + lane) * V;
+      if (vec_ok && e + V <= inner) {
+        unpack<DT>(load16_nt(reinterpret_cast<const char*>(x) + (row * inner + e) * (16 / V)), &f[u * V]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) f[u * V + i] = e + i < inner ? load1<DT>(x, row * inner + e + i) : 0.0f;
+      }
+    }
+    const float* crow = cand + (row % axis_size);
+    for (int k = 0; k < n_cand; ++k) {
+      const CandQ<FP8> c = make_cand<FP8>(crow[(int64_t)k * axis_size], q);
+      float a0 = 0.0f, a1 = 0.0f;  // two chains halve the dependent-add latency
+#pragma unroll
+      for (int i = 0; i < P * V; i += 2) {
+        a0 += sq_err<FP8>(f[i], c, q);
+        a1 += sq_err<FP8>(f[i + 1], c, q);
+      }
+      float acc = a0 + a1;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (lane == 0) partial[item * n_cand + k] = acc;
+    }
+  }
+}
+
+// Short power-of-two rows (static blocks, inner = LPG * V <= 64 * V): LPG adjacent lanes own a row, its packet
+// stays in registers across all candidates, the per-candidate sum is an LPG-wide butterfly.
+template <int DT, int LPG, bool FP8>
+__global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restrict__ x, int64_t n_rows,
+                                                           int64_t axis_size,
+                                                           const float* __restrict__ cand, int n_cand,
+                                                           float* __restrict__ loss, int accumulate,
+                                                           int num_bits, int is_unsigned, int narrow) {
+  constexpr int V = Elem<DT>::kVec;
+  const IntQ q = make_intq(num_bits, is_unsigned, narrow);
+  const int64_t n_packets = n_rows * LPG;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < ((n_packets + 63) & ~(int64_t)63);
+       p += (int64_t)gridDim.x * kBlock) {
+    const bool live = p < n_packets;
+    const int64_t row = (live ? p : n_packets - 1) / LPG;
+    float f[8];
+    if (live) {
+      unpack<DT>(load16_nt(reinterpret_cast<const char*>(x) + p * 16), f);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = 0.0f;
+    }
+    const int64_t a = row % axis_size;
+    for (int k = 0; k < n_cand; ++k) {
+      const CandQ<FP8> c = make_cand<FP8>(cand[(int64_t)k * axis_size + a], q);
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) acc += sq_err<FP8>(f[i], c, q);
+#pragma unroll
+      for (int off = LPG / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (live && (threadIdx.x & (LPG - 1)) == 0) {
+        float* dst = loss + (int64_t)k * axis_size + a;
+        // outer == 1 for block layouts, so every (k, a) has exactly one writer: plain read-modify-write
+        *dst = accumulate ? *dst + acc : acc;
+      }
+    }
+  }
+}
+
+// loss[k, a] (+)= sum over the work items of rows with row % axis_size == a, in item order (deterministic)
+__global__ void mse_finalize_kernel(const float* __restrict__ partial, int64_t n_rows, int64_t axis_size,
+                                    int64_t segs_per_row, int n_cand, float* __restrict__ loss,
+                                    int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_cand * axis_size) return;
+  const int k = (int)(idx / axis_size);
+  const int64_t a = idx % axis_size;
+  float s = 0.0f;
+  for (int64_t row = a; row < n_rows; row += axis_size)
+    for (int64_t seg = 0; seg < segs_per_row; ++seg) s += partial[(row * segs_per_row + seg) * n_cand + k];
+  loss[idx] = accumulate ? loss[idx] + s : s;
+}
+
+}  // namespace moq
+
+using namespace moq;
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static void mse_plan(int64_t n_rows, int64_t inner, int64_t* seg_elems, int64_t* segs) {
+  (void)n_rows;
+  *seg_elems = kSeg;
+  *segs = (inner + kSeg - 1) / kSeg;
+}
+
+extern "C" int64_t moq_mse_sweep_workspace(int64_t outer, int64_t axis_size, int64_t inner, int n_cand) {
+  if (outer < 0 || axis_size <= 0 || inner <= 0 || n_cand <= 0) return MOQ_ERR_INVALID;
+  int64_t se, segs;
+  mse_plan(outer * axis_size, inner, &se, &segs);
+  return outer * axis_size * segs * n_cand;
+}
+
+extern "C" int moq_mse_sweep(const void* x, int64_t outer, int64_t axis_size, int64_t inner, int dt,
+                             const float* cand_amax, int n_cand, float* loss, float* partial, int accumulate,
+                             int fp8, int num_bits, int is_unsigned, int narrow_range, void* stream) {
+  if (x == nullptr || cand_amax == nullptr || loss == nullptr || outer <= 0 || axis_size <= 0 || inner <= 0) {
+    set_error("moq_mse_sweep: null pointer or bad sizes");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_cand < 1 || n_cand > kMaxCand) {
+    set_error("moq_mse_sweep: n_cand must be in [1, %d]", kMaxCand);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (!fp8 && (num_bits < 2 || num_bits > 16)) {
+    set_error("moq_mse_sweep: num_bits=%d out of range [2,16]", num_bits);
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int64_t n_rows = outer * axis_size;
+  const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+  const int64_t lpg = inner % vec == 0 ? inner / vec : 0;
+  if (outer == 1 && aligned && lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
+    const int grid = stream_grid(kBlock, n_rows * lpg);
+#define MOQ_MSE_G(L)                                                                                            \
+  case L:                                                                                                       \
+    if (fp8) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mse_group_kernel<DT, L, true>), dim3(grid), dim3(kBlock), 0, S(stream), x, n_rows, axis_size, cand_amax, n_cand, loss, accumulate, num_bits, is_unsigned, narrow_range)); } \
+    else { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mse_group_kernel<DT, L, false>), dim3(grid), dim3(kBlock), 0, S(stream), x, n_rows, axis_size, cand_amax, n_cand, loss, accumulate, num_bits, is_unsigned, narrow_range)); } \
+    break;
+    switch ((int)lpg) {
+      MOQ_MSE_G(1) MOQ_MSE_G(2) MOQ_MSE_G(4) MOQ_MSE_G(8) MOQ_MSE_G(16) MOQ_MSE_G(32) MOQ_MSE_G(64)
+      default: set_error("unreachable"); return MOQ_ERR_INVALID;
+    }
+#undef MOQ_MSE_G
+    return check_launch("moq_mse_sweep(group)");
+  }
+  if (partial == nullptr) {
+    set_error("moq_mse_sweep: workspace `partial` is required for this layout");
+    return MOQ_ERR_INVALID;
+  }
+  int64_t seg_elems, segs;
+  mse_plan(n_rows, inner, &seg_elems, &segs);
+  const int64_t items = n_rows * segs;
+  int64_t blocks = (items + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  if (fp8) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mse_rows_kernel<DT, true>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                                              S(stream), x, n_rows, axis_size, inner, segs, cand_amax,
+                                              n_cand, partial, num_bits, is_unsigned, narrow_range));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mse_rows_kernel<DT, false>), dim3((unsigned)blocks), dim3(kBlock), 0,
+                                              S(stream), x, n_rows, axis_size, inner, segs, cand_amax,
+                                              n_cand, partial, num_bits, is_unsigned, narrow_range));
+  }
+  const int64_t n_out = (int64_t)n_cand * axis_size;
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S(stream), partial,
+                     n_rows, axis_size, segs, n_cand, loss, accumulate);
+  return check_launch("moq_mse_sweep");
+}

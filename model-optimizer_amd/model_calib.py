@@ -92,6 +92,79 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
     finish_stats_collection(model)
     if distributed_sync and dist.is_available() and dist.is_initialized():
         mdist.sync_amax_bucketed(_quantizers(model))
+    promote_static_block_weight_quantizers(model)
+
+
+def promote_static_block_weight_quantizers(model: nn.Module) -> int:
+    """utils/core_utils.py:1077-1150, INT branch: once their amax is final, enabled static-block INT weight
+    quantizers of quantized linears keep `_amax` in fp32 (the reference swaps their class to
+    StaticBlockScaleQuantizer).  Later amax writes (MSE refinement, AWQ re-calibration) are then not rounded to
+    the weight dtype."""
+    n = 0
+    for m in model.modules():
+        if not is_quantized_linear(m):
+            continue
+        wq = m.weight_quantizer
+        if (wq.is_enabled and wq.is_static_block_quant and wq.amax is not None and isinstance(wq._num_bits, int)
+                and not getattr(wq, "_is_static_block_scale_quantizer", False)):
+            wq.promote_static_block()
+            n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ mse
+def _mse_quant_func(x, amax, quantizer):
+    """model_calib.py:639-662: QDQ `x` with a trial amax through the quantizer itself."""
+    had = hasattr(quantizer, "_amax")
+    original = quantizer._amax.clone() if had else None
+    quantizer._amax = amax
+    state = (quantizer._if_quant, quantizer._if_calib)
+    quantizer._if_quant, quantizer._if_calib = True, False
+    try:
+        if hasattr(quantizer, "_original_shape"):
+            x = quantizer._reset_to_original_shape(x)
+        xq = quantizer(x)
+        if hasattr(quantizer, "_block_reshape_size"):
+            xq = quantizer._process_for_blockquant(xq)
+    finally:
+        quantizer._if_quant, quantizer._if_calib = state
+        if had:
+            quantizer._amax = original
+        else:
+            delattr(quantizer, "_amax")
+    return xq
+
+
+@torch.no_grad()
+def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, step_size: float = 0.1,
+                  start_multiplier: float = 0.25, stop_multiplier: float = 4.0):
+    """model_calib.py:732-826 (multiplier search, fp8_scale_sweep=False): max calibration first, then every
+    eligible weight quantizer's amax is refined by the MSE sweep -- here one fused kernel per weight."""
+    from functools import partial
+
+    from .calib import MseCalibrator
+
+    max_calibrate(model, forward_loop, distributed_sync)
+    for m in model.modules():
+        if not is_quantized_linear(m):
+            continue
+        wq = m.weight_quantizer
+        if (not wq.is_enabled or wq._dynamic or wq.is_mx_format or wq._calibrator is None
+                or getattr(wq, "_amax", None) is None):
+            continue  # _make_weight_mse_calibrator's eligibility test (model_calib.py:681-689)
+        nb = wq._num_bits
+        fused = (nb, wq._unsigned, wq._narrow_range) if isinstance(nb, int) or tuple(nb) == (4, 3) else None
+        cal = MseCalibrator(amax=wq._amax.clone().detach(), axis=wq._calibrator._axis, step_size=step_size,
+                            start_multiplier=start_multiplier, stop_multiplier=stop_multiplier,
+                            quant_func=partial(_mse_quant_func, quantizer=wq), fused_format=fused)
+        wq._calibrator = cal
+        wq.disable_quant()
+        wq.enable_calib()
+        wq(m.weight)
+        wq.load_calib_amax(strict=False)
+        wq.enable_quant()
+        wq.disable_calib()
+        cal.reset()
 
 
 # ------------------------------------------------------------------------------------------------ smoothquant

@@ -22,6 +22,10 @@ INT4_AWQ_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes"
                               "*input_quantizer": {"enable": False},
                               "*lm_head*": {"enable": False}},
                 "algorithm": {"method": "awq_lite", "alpha_step": 0.1}}
+# presets/model/int4_blockwise_weight_only.yaml (numerics/int4_per_block.yaml: num_bits 4, block_sizes {-1: 128})
+INT4_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                                                "*input_quantizer": {"enable": False},
+                                                "*lm_head*": {"enable": False}}, "algorithm": "max"}
 MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*lm_head*": {"enable": False}}, "algorithm": None}
@@ -59,6 +63,8 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
         return model
     if method == "max":
         model_calib.max_calibrate(model, forward_loop)
+    elif method == "mse":
+        model_calib.mse_calibrate(model, forward_loop, **kwargs)
     elif method == "smoothquant":
         model_calib.smoothquant(model, forward_loop, **kwargs)
     elif method == "awq_lite":

@@ -518,3 +518,43 @@ def awq_err_gemm_multi(xs: torch.Tensor, w_hat: torch.Tensor, out_actual: torch.
         check(_lib.lib().moq_awq_err_gemm_multi(_p(x3), _p(w3), _p(ref), _p(b), tokens, cout, cin, _dt(x3), n_cand,
                                                 x_stride, w_stride, _p(ws), _p(loss_acc), stream))
     return loss_acc
+
+
+# ----------------------------------------------------------------------------------------------- MSE sweep
+@torch.no_grad()
+def mse_sweep(x: torch.Tensor, cand_amax: torch.Tensor, reduce_axis, num_bits=8, unsigned: bool = False,
+              narrow_range: bool = False, loss: torch.Tensor | None = None) -> torch.Tensor:
+    """loss[k, ...] (+)= sum over `reduce_axis` of (x - QDQ(x, cand_amax[k]))^2 for all K candidates in one read
+    of x -- the body of MseCalibrator.collect (calib/mse.py:99-113).  cand_amax: [K, C] (C = kept elements, 1 for
+    per-tensor); num_bits int -> INT-k, (4, 3) -> FP8-E4M3.  Returns fp32 [K, C]."""
+    _require_gpu(x, "mse_sweep")
+    xc = x.detach().contiguous()
+    nd = xc.dim()
+    if reduce_axis is None:
+        outer, kept, inner = 1, 1, xc.numel()
+    else:
+        if isinstance(reduce_axis, int):
+            reduce_axis = (reduce_axis,)
+        if len({a % nd for a in reduce_axis}) == nd:
+            outer, kept, inner = 1, 1, xc.numel()
+        else:
+            outer, kept, inner, _ = _reduce_layout(list(xc.shape), reduce_axis)
+    cand = _f32(cand_amax, xc.device).reshape(cand_amax.shape[0], -1)
+    if cand.shape[1] != kept:
+        raise MoquantError(f"mse_sweep: cand_amax has {cand.shape[1]} entries per candidate, layout keeps {kept}")
+    k = cand.shape[0]
+    if isinstance(num_bits, int):
+        fp8, bits = 0, num_bits
+    elif tuple(num_bits) == (4, 3):
+        fp8, bits = 1, 8
+    else:
+        raise MoquantUnsupported(f"mse_sweep: num_bits {num_bits} not supported")
+    accumulate = loss is not None
+    if loss is None:
+        loss = torch.empty(k, kept, dtype=torch.float32, device=xc.device)
+    n_ws = int(_lib.lib().moq_mse_sweep_workspace(outer, kept, inner, k))
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=xc.device)
+    with _on(xc) as stream:
+        check(_lib.lib().moq_mse_sweep(_p(xc), outer, kept, inner, _dt(xc), _p(cand), k, _p(loss), _p(ws),
+                                       int(accumulate), fp8, int(bits), int(unsigned), int(narrow_range), stream))
+    return loss

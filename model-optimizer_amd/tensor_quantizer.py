@@ -150,6 +150,20 @@ class TensorQuantizer(nn.Module):
             if self._amax.shape != value.shape:
                 raise RuntimeError("Changing shape when setting amax is not allowed.")
             self._amax.data.copy_(value.clone().detach().to(self._amax.device))
+        if getattr(self, "_is_static_block_scale_quantizer", False):
+            self._preserve_amax_in_fp32()
+
+    def _preserve_amax_in_fp32(self):
+        """StaticBlockScaleQuantizer._preserve_amax_in_fp32 (tensor_quantizer.py:1501-1518)."""
+        amax = getattr(self, "_amax", None)
+        if amax is not None and amax.dtype != torch.float32:
+            self._amax = amax.to(dtype=torch.float32)
+
+    def promote_static_block(self):
+        """StaticBlockScaleQuantizer.from_tensor_quantizer (tensor_quantizer.py:1521-1546) for INT static-block
+        weight quantizers: from now on the per-block amax is kept in fp32."""
+        self._is_static_block_scale_quantizer = True
+        self._preserve_amax_in_fp32()
 
     def reset_amax(self):
         if hasattr(self, "_amax"):

@@ -224,3 +224,14 @@ def awq_err_gemm(x, w, out_actual=None, bias=None, return_out=False):
     f.restype = ctypes.c_double
     loss = f(_p(a), _p(b), _p(r), _p(bi), _p(o), I64(tokens), I64(cout), I64(cin), DT[x.dtype])
     return (float(loss), _from_np(o, x.dtype, (tokens, cout))) if return_out else float(loss)
+
+
+def mse_sweep(x, cand_amax, outer, axis_size, inner, fp8=False, num_bits=8, unsigned=False, narrow_range=False):
+    """loss[k, a] = sum (x - QDQ(x, cand_amax[k, a]))^2 over the elements of amax entry a; fp64 [K, axis_size]."""
+    a = _np(x)
+    c = np.ascontiguousarray(cand_amax.detach().cpu().float().numpy())
+    k = c.shape[0]
+    loss = np.empty((k, axis_size), dtype=np.float64)
+    lib().orc_mse_sweep(_p(a), I64(outer), I64(axis_size), I64(inner), DT[x.dtype], _p(c), int(k), _p(loss),
+                        int(fp8), int(num_bits), int(unsigned), int(narrow_range))
+    return torch.from_numpy(loss)

@@ -15,6 +15,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
                    pack_int4_in_uint8 (export/quant_utils.py:792-833)
   awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
+  mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
                    the MX kernels have no CPU implementation in the reference)
@@ -425,16 +426,78 @@ def extract_mx_vectors():
     return cases
 
 
+def gen_mse(out):
+    """MseCalibrator (calib/mse.py) driven the way mse_calibrate drives it (model_calib.py:639-826):
+    per-candidate losses and the chosen amax for INT8 per-tensor / per-channel, INT4 static blocks (with
+    padding) and FP8 per-tensor quantizers, plus mtq.quantize(..., algorithm='mse') on the tiny MLP."""
+    import copy
+    from functools import partial
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.calib import MseCalibrator
+    from modelopt.torch.quantization.model_calib import _mse_quant_func, max_calibrate
+
+    cases = {}
+    specs = [
+        ("int8_tensor_f32", dict(num_bits=8, axis=None), (48, 200), "f32"),
+        ("int8_chan_bf16", dict(num_bits=8, axis=0), (40, 264), "bf16"),
+        ("int4_chan_f16", dict(num_bits=4, axis=0), (16, 4100), "f16"),
+        ("int4_block128_bf16", dict(num_bits=4, block_sizes={-1: 128, "type": "static"}), (24, 512), "bf16"),
+        ("int4_block32_pad_f32", dict(num_bits=4, block_sizes={-1: 32, "type": "static"}), (10, 72), "f32"),
+        ("fp8_tensor_bf16", dict(num_bits=(4, 3), axis=None), (64, 320), "bf16"),
+        ("int8_tensor_big_bf16", dict(num_bits=8, axis=None), (96, 1100), "bf16"),
+    ]
+    for i, (name, cfg, shape, dn) in enumerate(specs):
+        w = weight_like(shape, DT[dn], 500 + i)
+        q = TensorQuantizer(QuantizerAttributeConfig(**cfg))
+        max_calibrate(q, lambda qq: qq(w), distributed_sync=False)
+        init = q._amax.clone().detach()
+        cal = MseCalibrator(amax=init, axis=q._calibrator._axis, step_size=0.1, start_multiplier=0.25,
+                            stop_multiplier=4.0, quant_func=partial(_mse_quant_func, quantizer=q))
+        q._calibrator = cal
+        q.disable_quant(); q.enable_calib()
+        q(w)
+        losses = torch.stack([l.reshape(-1) for l in cal._losses_sum]).float()
+        amax = cal.compute_amax()
+        out[f"{name}_w"] = bits(w)
+        out[f"{name}_init_amax"] = bits(init.float())
+        out[f"{name}_losses"] = bits(losses)
+        out[f"{name}_amax"] = bits(amax.float())
+        cases[name] = dict(cfg={k: (list(v) if isinstance(v, tuple) else ({str(a): b for a, b in v.items()} if isinstance(v, dict) else v))
+                                for k, v in cfg.items()}, dtype=dn, shape=list(shape),
+                           init_dtype=str(init.dtype), init_shape=list(init.shape), amax_dtype=str(amax.dtype),
+                           amax_shape=list(amax.shape))
+    # model flow
+    for name, base, dt in [("flow_int8_mse", mtq.INT8_DEFAULT_CFG, torch.float32),
+                           ("flow_int4blk_mse_bf16", mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, torch.bfloat16)]:
+        dn = {torch.float32: "f32", torch.bfloat16: "bf16"}[dt]
+        model = _TinyMLP(dtype=dt, seed=3)
+        batches = _calib_batches(128, dt, 5)
+        cfg = copy.deepcopy(base)
+        cfg["algorithm"] = {"method": "mse"}
+        q = mtq.quantize(copy.deepcopy(model), cfg, lambda m: [m(b) for b in batches])
+        info = dict(dtype=dn, n_batches=len(batches))
+        for lname in ("fc1", "fc2"):
+            a = getattr(q, lname).weight_quantizer._amax
+            out[f"{name}_{lname}_weight_amax"] = bits(a.float())
+            info[f"{lname}_amax_shape"] = list(a.shape)
+        cases[name] = info
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def main():
     torch.manual_seed(1234)
-    for name, fn in [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
+    only = sys.argv[1:] or None
+    for name, fn in [("mse", gen_mse)] if only == ["mse"] else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
-                     ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows)]:
+                     ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+    if only == ["mse"]:
+        return
     mx = extract_mx_vectors()
     with open(os.path.join(HERE, "mx_vectors.json"), "w") as f:
         json.dump(mx, f)

@@ -208,3 +208,42 @@ def test_mx_golden_vectors():
                     got = oracle.mx_fused_amax_convert(tin * sign, bs, c["fmt"])
                     assert torch.allclose(got.float(), (tout * sign).float(), rtol=1e-5, atol=c["atol"]), \
                         f"{c['fn']} {c['fmt']} bs={bs} {dt}"
+
+
+def _mse_candidates(g, name, c):
+    """Candidate amax values exactly as MseCalibrator builds them (calib/mse.py:75-81, :99-101): a 0-dim fp32
+    multiplier times the initial amax tensor in ITS dtype (torch type promotion keeps the dimensioned dtype)."""
+    dt = {"torch.float32": torch.float32, "torch.bfloat16": torch.bfloat16, "torch.float16": torch.float16}[c["init_dtype"]]
+    init = g.t(f"{name}_init_amax").to(dt).reshape(c["init_shape"])
+    mult = torch.linspace(0.25, 4.0, steps=39)
+    return torch.stack([(init * m).float().reshape(-1) for m in mult]), init, mult
+
+
+def test_oracle_mse_sweep_matches_reference_losses(golden):
+    g = golden("mse")
+    for name, c in g.cases.items():
+        if name.startswith("flow_"):
+            continue
+        w = g.t(f"{name}_w", DT[c["dtype"]])
+        cand, init, mult = _mse_candidates(g, name, c)
+        cfg = c["cfg"]
+        nb = cfg["num_bits"]
+        fp8 = isinstance(nb, list)
+        if "block_sizes" in cfg:
+            gsz = cfg["block_sizes"]["-1"]
+            pad = (-w.shape[-1]) % gsz
+            wv = torch.nn.functional.pad(w, (0, pad)).reshape(-1, gsz)
+            outer, axis_size, inner = 1, wv.shape[0], gsz
+        elif cfg.get("axis", None) == 0:
+            wv, outer, axis_size, inner = w, 1, w.shape[0], w.shape[1]
+        else:
+            wv, outer, axis_size, inner = w, 1, 1, w.numel()
+        got = oracle.mse_sweep(wv.contiguous(), cand, outer, axis_size, inner, fp8=fp8, num_bits=8 if fp8 else nb,
+                               unsigned=False, narrow_range=False)
+        want = g.t(f"{name}_losses").double()
+        assert got.shape == want.shape, name
+        rel = ((got - want).abs() / want.abs().clamp_min(1e-20)).max().item()
+        assert rel < 2e-5, f"{name}: max rel loss diff {rel:.2e}"  # reference sums in fp32, the oracle in fp64
+        best = got.argmin(0)
+        amax = (init.reshape(-1) * mult[best]).float() if init.dim() else (init * mult[best]).float().reshape(-1)
+        assert torch.equal(amax.reshape(-1), g.t(f"{name}_amax").reshape(-1)), f"{name}: chosen amax differs"
