@@ -200,6 +200,11 @@ int moq_int4_pack_export(const void* w, const float* wsf, uint8_t* out, int64_t 
  * (quantization/model_calib.py:1208-1216).  x == y allowed. */
 int moq_scale_cols(const void* w, const float* s, void* y, int64_t rows, int64_t cols, int dt,
                    void* stream);
+/* y[r,c] = dtype((w[r,c] * mul[c]) / div[c]) in fp32 (mul, div fp32 [cols]) -- _update_pre_quant_scale of the
+ * checkpoint export's resmooth step: W * old_pre_quant_scale / new_pre_quant_scale
+ * (export/quant_utils.py:1285-1296).  x == y allowed. */
+int moq_rescale_cols(const void* w, const float* mul, const float* div, void* y, int64_t rows, int64_t cols,
+                     int dt, void* stream);
 /* y[a, r, c] = dtype(w[r,c] * s[a, c]) for a < n_scales (s fp32 [n_scales, cols]): one read, n_scales writes
  * -- the pre-scaled inputs x * (1/s_alpha) of all AWQ candidates (input_quantizer.pre_quant_scale,
  * nn/modules/tensor_quantizer.py:1143-1144 applied by model_calib.py:1552).  cols % (16 / elem size) == 0. */

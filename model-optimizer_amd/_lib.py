@@ -68,6 +68,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "moq_awq_err_gemm_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int,
                                        c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "moq_rescale_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "moq_scale_cols_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "moq_mse_sweep_workspace": (c_int64, [c_int64, c_int64, c_int64, c_int]),
     "moq_mse_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p,

@@ -418,6 +418,35 @@ __global__ __launch_bounds__(kBlock) void scale_cols_kernel(const void* __restri
   }
 }
 
+// y[r, c] = dtype((w[r, c] * mul[c]) / div[c]): _update_pre_quant_scale of the export resmooth step
+// (export/quant_utils.py:1285-1296) -- fp32 multiply, fp32 IEEE divide, one rounding to the storage dtype.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void rescale_cols_kernel(const void* __restrict__ w,
+                                                              const float* __restrict__ mul,
+                                                              const float* __restrict__ div,
+                                                              void* __restrict__ y, int64_t rows,
+                                                              int64_t cols) {
+  constexpr int V = Elem<DT>::kVec;
+  const int64_t n = rows * cols;
+  const bool fast = al16(w) && al16(y) && (cols % V) == 0 && al16(mul) && al16(div);
+  const int64_t n_packets = (n + V - 1) / V;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
+       p += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = p * V;
+    if (fast) {
+      float v[8];
+      unpack<DT>(load16(reinterpret_cast<const char*>(w) + p * 16), v);
+      const int64_t c = e % cols;
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = (v[i] * mul[c + i]) / div[c + i];
+      store16(reinterpret_cast<char*>(y) + p * 16, pack<DT>(v));
+    } else {
+      for (int i = 0; i < V; ++i)
+        if (e + i < n) store1<DT>(y, e + i, (load1<DT>(w, e + i) * mul[(e + i) % cols]) / div[(e + i) % cols]);
+    }
+  }
+}
+
 // y[a, r, c] = dtype(w[r, c] * s[a, c]) for a < n_scales: ONE read of w, n_scales writes (the 11 pre-scaled
 // activation copies of an AWQ search step).  Requires the fast layout (checked by the host entry).
 template <int DT>
@@ -622,4 +651,19 @@ extern "C" int moq_scale_cols_multi(const void* w, const float* s, void* y, int6
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_multi_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
                                             w, s, y, rows, cols, n_scales));
   return check_launch("moq_scale_cols_multi");
+}
+
+extern "C" int moq_rescale_cols(const void* w, const float* mul, const float* div, void* y, int64_t rows,
+                                int64_t cols, int dt, void* stream) {
+  if (rows < 0 || cols < 0 || (rows * cols > 0 && (w == nullptr || mul == nullptr || div == nullptr || y == nullptr))) {
+    set_error("moq_rescale_cols: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  const int64_t n = rows * cols;
+  if (n == 0) return MOQ_OK;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int grid = stream_grid(kBlock, (n + vec - 1) / vec);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((rescale_cols_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
+                                            mul, div, y, rows, cols));
+  return check_launch("moq_rescale_cols");
 }

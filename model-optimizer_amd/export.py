@@ -1,0 +1,269 @@
+"""Checkpoint export for the formats of this path -- mirror of the INT4-AWQ / FP8 / INT8 branch of
+modelopt.torch.export (unified_export_hf.py:280-810, export/quant_utils.py:225-345, :792-938, :1285-1302, :1442-1547).
+
+What runs where:
+  * every pass over a weight tensor is a HIP kernel: the resmooth rescale W * old / new (moq_rescale_cols), the
+    per-block amax recalibration (fused group amax), the nibble packer (moq_int4_pack_export), FP8 / INT8 casts;
+  * the per-channel / per-block vectors (pre_quant_scale averages, weight scales = amax / maxbound) are tiny and are
+    computed on the HOST in the reference's exact torch expressions, so the exported bytes do not depend on a GPU
+    reduction order (the reference is pinned on its CPU run).
+Byte-identity with the reference's exported tensors, given the same calibrated state, is tested against a
+reference-generated tiny-Llama checkpoint (tests/golden/export_llama.npz).
+"""
+
+from __future__ import annotations
+
+import json
+import os
+from collections import defaultdict
+
+import torch
+from torch import nn
+
+from . import ops
+from .nn import is_quantized_linear
+
+QUANTIZATION_NONE = None
+QUANTIZATION_FP8 = "fp8"
+QUANTIZATION_INT8_SQ = "int8_sq"
+QUANTIZATION_INT8_WO = "int8_wo"
+QUANTIZATION_INT4_AWQ = "int4_awq"
+
+
+def get_quantization_format(module) -> str | None:
+    """export/quant_utils.py:506-700 for the quantizer settings of this path."""
+    if not is_quantized_linear(module):
+        return QUANTIZATION_NONE
+    wq, iq = module.weight_quantizer, module.input_quantizer
+    if not wq.is_enabled:
+        return QUANTIZATION_NONE
+    nb = wq._num_bits
+    if nb == 4 and wq.is_static_block_quant:
+        return QUANTIZATION_INT4_AWQ
+    if nb == 8:
+        return QUANTIZATION_INT8_SQ if iq.is_enabled else QUANTIZATION_INT8_WO
+    if isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is None:
+        return QUANTIZATION_FP8
+    raise NotImplementedError(f"export of weight format num_bits={nb} block_sizes={wq.block_sizes} is outside this path")
+
+
+def get_scaling_factor(quantizer) -> torch.Tensor | None:
+    """export/quant_utils.py:225-243: export_amax().float() / maxbound."""
+    if not quantizer.is_enabled:
+        return None
+    amax = quantizer.export_amax()
+    if amax is None:
+        return None
+    # IEEE fp32 division on the host: torch's GPU kernel turns `tensor / python_scalar` into a multiplication by
+    # the reciprocal (last-bit differences), the CPU kernel the reference fixtures come from divides
+    scaling_factor = (amax.float().cpu() / quantizer.maxbound).to(amax.device)
+    assert torch.all(scaling_factor > 0), f"scaling factor {scaling_factor} not positive."
+    return scaling_factor
+
+
+def get_weight_scaling_factor(module) -> torch.Tensor | None:
+    return get_scaling_factor(module.weight_quantizer)
+
+
+@torch.no_grad()
+def _update_pre_quant_scale(module, new_pre_quant_scale: torch.Tensor):
+    """export/quant_utils.py:1285-1302: W <- (W.f32 * old.f32 / new.f32).to(dtype); input quantizer gets the new
+    scale; the weight amax is re-collected."""
+    old = module.input_quantizer._pre_quant_scale
+    ops.rescale_cols(module.weight.data, old, new_pre_quant_scale, out=module.weight.data)
+    module.input_quantizer.pre_quant_scale = new_pre_quant_scale
+    # "Redo weights collection" (:1297-1301) on the weight quantizer alone
+    wq = module.weight_quantizer
+    wq.reset_amax()
+    was_quant = wq._if_quant
+    wq.disable_quant()
+    wq.enable_calib()
+    wq(module.weight)
+    wq.load_calib_amax()
+    wq.disable_calib()
+    if was_quant:
+        wq.enable_quant()
+
+
+@torch.no_grad()
+def preprocess_linear_fusion(modules, resmooth_only: bool = False):
+    """export/quant_utils.py:1476-1547: linears that share an input get one pre_quant_scale (the mean), one input
+    amax (the max) and, for per-tensor weight formats, one weight amax (the max)."""
+    fmts = [get_quantization_format(m) for m in modules]
+    assert all(f == fmts[0] for f in fmts), "Modules have different quantization formats"
+    iq0 = modules[0].input_quantizer
+    if iq0.pre_quant_scale is not None:
+        dev = modules[0].weight.device
+        # tiny [Cin] vectors: the reference's expression on the host, then back to the device
+        stacked = torch.stack([m.input_quantizer.pre_quant_scale.detach().cpu() for m in modules])
+        avg = torch.mean(stacked, dim=0)
+        for m in modules:
+            if not torch.equal(m.input_quantizer.pre_quant_scale.detach().cpu(), avg):
+                _update_pre_quant_scale(m, avg.to(dev))
+    if resmooth_only:
+        return
+    if iq0.is_enabled and iq0.amax is not None:
+        assert iq0.amax.numel() == 1, "Only support scalar input quant amax"
+        input_amax = torch.max(torch.stack([m.input_quantizer.amax for m in modules]))
+        for m in modules:
+            m.input_quantizer.amax = input_amax
+    wq0 = modules[0].weight_quantizer
+    if wq0.is_enabled and wq0.amax is not None and wq0.amax.numel() == 1:
+        weight_amax = torch.max(torch.stack([m.weight_quantizer.amax for m in modules]))
+        for m in modules:
+            m.weight_quantizer.amax = weight_amax
+
+
+@torch.no_grad()
+def fuse_prequant_layernorm(layernorm_module, modules):
+    """export/quant_utils.py:1442-1473: fold the (shared) pre_quant_scale into the preceding norm's weight."""
+    if not hasattr(modules[0].input_quantizer, "_pre_quant_scale"):
+        return
+    pqs = modules[0].input_quantizer._pre_quant_scale.to(layernorm_module.weight.device)
+    fused = layernorm_module.weight * pqs
+    layernorm_module.weight = nn.Parameter(fused.to(layernorm_module.weight.dtype))
+    if getattr(layernorm_module, "bias", None) is not None:
+        layernorm_module.bias = nn.Parameter(layernorm_module.bias * pqs)
+    for m in modules:
+        delattr(m.input_quantizer, "_pre_quant_scale")
+        m.fused_with_prequant = True
+
+
+def is_layernorm(module) -> bool:
+    """export/layer_utils.py is_layernorm: LayerNorm / *RMSNorm by class name."""
+    n = type(module).__name__
+    return any(k in n for k in ("LayerNorm", "RMSNorm", "RmsNorm"))
+
+
+@torch.no_grad()
+def collect_shared_input_modules(model, dummy_forward_fn):
+    """unified_export_hf.py:280-348: run one probe forward with all quantizers off and record, by tensor identity,
+    which quantized linears consume the same input and which norm produced it."""
+    from .tensor_quantizer import TensorQuantizer
+
+    input_to_linear, output_to_layernorm = defaultdict(list), {}
+    handles = []
+    for name, m in model.named_modules():
+        if is_layernorm(m):
+            m.name = name
+            handles.append(m.register_forward_hook(lambda mod, i, o: output_to_layernorm.__setitem__(o, mod)
+                                                   if isinstance(o, torch.Tensor) else None))
+        elif is_quantized_linear(m) and (m.input_quantizer.is_enabled or m.weight_quantizer.is_enabled):
+            m.name = name
+            handles.append(m.register_forward_hook(lambda mod, i, o: input_to_linear[i[0]].append(mod)
+                                                   if len(i) and isinstance(i[0], torch.Tensor) else None))
+    quantizers = [q for q in model.modules() if isinstance(q, TensorQuantizer)]
+    saved = [q._disabled for q in quantizers]
+    try:
+        for q in quantizers:
+            q._disabled = True
+        dummy_forward_fn()
+    finally:
+        for q, d in zip(quantizers, saved):
+            q._disabled = d
+        for h in handles:
+            h.remove()
+    return input_to_linear, output_to_layernorm
+
+
+@torch.no_grad()
+def requantize_resmooth_fused_llm_layers(model, dummy_forward_fn):
+    """unified_export_hf.py:433-543 (dense LLM part): resmooth + unify every group of linears that share an input
+    and, for AWQ formats, fold the shared pre_quant_scale into the norm that feeds them."""
+    input_to_linear, output_to_layernorm = collect_shared_input_modules(model, dummy_forward_fn)
+    fused = {}
+    for tensor, modules in input_to_linear.items():
+        fmt = get_quantization_format(modules[0])
+        if len(modules) > 1 and fmt not in (QUANTIZATION_FP8, QUANTIZATION_NONE):
+            preprocess_linear_fusion(modules)
+            fused[modules[0].name] = [m.name for m in modules]
+            if fmt is not None and "awq" in fmt and tensor in output_to_layernorm:
+                fuse_prequant_layernorm(output_to_layernorm[tensor], modules)
+    return fused
+
+
+@torch.no_grad()
+def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
+    """export/quant_utils.py:836-938 for the formats of this path."""
+    if quantization == QUANTIZATION_INT4_AWQ:
+        return ops.pack_int4_in_uint8(weight, weights_scaling_factor)
+    wsf = weights_scaling_factor.to(weight.device)
+    if quantization == QUANTIZATION_FP8:
+        return (weight / wsf).to(torch.float8_e4m3fn)
+    if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
+        return (weight / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)
+    raise NotImplementedError(f"quantization format {quantization} not supported")
+
+
+@torch.no_grad()
+def export_quantized_weight(module, dtype: torch.dtype):
+    """unified_export_hf.py:569-810 for one quantized linear: returns the tensors the checkpoint stores for it
+    ({'weight', 'weight_scale'[, 'input_scale'][, 'pre_quant_scale']})."""
+    fmt = get_quantization_format(module)
+    if fmt is QUANTIZATION_NONE:
+        return {"weight": module.weight.detach()}
+    wq, iq = module.weight_quantizer, module.input_quantizer
+    out = {}
+    if fmt == QUANTIZATION_FP8:
+        amax = wq._amax.to(torch.float32)
+        # per-tensor: python float division of amax.item() (unified_export_hf.py:643-647)
+        weight_scale = (torch.tensor(amax.item() / wq.maxbound) if amax.numel() == 1
+                        else (amax.cpu() / wq.maxbound).to(amax.device))
+    else:
+        weight_scale = get_weight_scaling_factor(module)
+    if iq.is_enabled and iq.amax is not None:
+        out["input_scale"] = get_scaling_factor(iq).squeeze()
+    out["weight"] = to_quantized_weight(module.weight.detach().to(dtype), weight_scale, fmt)
+    out["weight_scale"] = weight_scale
+    pqs = getattr(iq, "_pre_quant_scale", None)
+    if pqs is not None:  # unified_export_hf.py:1121-1138: promoted to <module>.pre_quant_scale
+        out["pre_quant_scale"] = pqs.detach().clone()
+    return out
+
+
+@torch.no_grad()
+def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
+    """Checkpoint tensors of a quantized model: resmooth / fuse (when a probe forward is given), then pack every
+    quantized linear; everything else is copied through."""
+    if dummy_forward_fn is not None:
+        requantize_resmooth_fused_llm_layers(model, dummy_forward_fn)
+    state = {}
+    handled = set()
+    for name, m in model.named_modules():
+        if is_quantized_linear(m):
+            prefix = name + "." if name else ""
+            for k, v in export_quantized_weight(m, dtype).items():
+                state[prefix + k] = v
+            if m.bias is not None:
+                state[prefix + "bias"] = m.bias.detach()
+            handled.add(name)
+    for k, v in model.state_dict().items():
+        owner = k.rsplit(".", 1)[0] if "." in k else ""
+        if any(owner == h or owner.startswith(h + ".") for h in handled):
+            continue  # quantizer buffers (_amax, _pre_quant_scale) and raw weights of exported linears
+        state[k] = v.detach()
+    return state
+
+
+def hf_quant_config(model, group_size: int | None = None) -> dict:
+    """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
+    fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
+    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
+            QUANTIZATION_INT8_WO: "W8A16"}
+    fmt = next(iter(fmts)) if len(fmts) == 1 else None
+    q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": None}
+    if fmt == QUANTIZATION_INT4_AWQ:
+        q.update(group_size=group_size or 128, has_zero_point=False, pre_quant_scale=True)
+    return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}
+
+
+def save_checkpoint(state: dict, export_dir: str, quant_config: dict | None = None):
+    """model.safetensors (+ hf_quant_config.json); tensors are written sorted by key like safetensors does."""
+    from safetensors.torch import save_file
+
+    os.makedirs(export_dir, exist_ok=True)
+    save_file({k: v.detach().cpu().contiguous() for k, v in state.items()},
+              os.path.join(export_dir, "model.safetensors"), metadata={"format": "pt"})
+    if quant_config is not None:
+        with open(os.path.join(export_dir, "hf_quant_config.json"), "w") as f:
+            json.dump(quant_config, f, indent=4)

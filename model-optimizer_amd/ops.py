@@ -558,3 +558,19 @@ def mse_sweep(x: torch.Tensor, cand_amax: torch.Tensor, reduce_axis, num_bits=8,
         check(_lib.lib().moq_mse_sweep(_p(xc), outer, kept, inner, _dt(xc), _p(cand), k, _p(loss), _p(ws),
                                        int(accumulate), fp8, int(bits), int(unsigned), int(narrow_range), stream))
     return loss
+
+
+@torch.no_grad()
+def rescale_cols(weight: torch.Tensor, mul: torch.Tensor, div: torch.Tensor, out: torch.Tensor | None = None):
+    """(W.float() * mul.float() / div.float()).to(W.dtype) per column -- _update_pre_quant_scale of the export
+    resmooth step (export/quant_utils.py:1285-1296)."""
+    _require_gpu(weight, "rescale_cols")
+    w = weight.contiguous()
+    cols = w.shape[-1]
+    m, d = _f32(mul, w.device).reshape(-1), _f32(div, w.device).reshape(-1)
+    if m.numel() != cols or d.numel() != cols:
+        raise MoquantError("rescale_cols: mul / div length must equal the last weight dim")
+    y = torch.empty_like(w) if out is None else out
+    with _on(w) as stream:
+        check(_lib.lib().moq_rescale_cols(_p(w), _p(m), _p(d), _p(y), w.numel() // cols, cols, _dt(w), stream))
+    return y

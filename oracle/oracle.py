@@ -235,3 +235,13 @@ def mse_sweep(x, cand_amax, outer, axis_size, inner, fp8=False, num_bits=8, unsi
     lib().orc_mse_sweep(_p(a), I64(outer), I64(axis_size), I64(inner), DT[x.dtype], _p(c), int(k), _p(loss),
                         int(fp8), int(num_bits), int(unsigned), int(narrow_range))
     return torch.from_numpy(loss)
+
+
+def rescale_cols(w, mul, div):
+    rows, cols = w.shape
+    a = _np(w)
+    m = np.ascontiguousarray(mul.detach().cpu().float().reshape(-1).numpy())
+    d = np.ascontiguousarray(div.detach().cpu().float().reshape(-1).numpy())
+    y = _empty_like_np(w)
+    lib().orc_rescale_cols(_p(a), _p(m), _p(d), _p(y), I64(rows), I64(cols), DT[w.dtype])
+    return _from_np(y, w.dtype, w.shape)

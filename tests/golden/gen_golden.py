@@ -15,6 +15,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
                    pack_int4_in_uint8 (export/quant_utils.py:792-833)
   awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
+  export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -485,18 +486,69 @@ def gen_mse(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_export(out):
+    """INT4-AWQ checkpoint export of a tiny bf16 Llama by the reference (mtq.quantize(INT4_AWQ_CFG) +
+    export_hf_checkpoint, export/unified_export_hf.py:1491): the original weights + calibration tokens (for the
+    end-to-end test), the calibrated state right before export (folded weights, pre_quant_scales, per-block amax,
+    norm weights) and every tensor of the exported model.safetensors."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16)
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    for i, b in enumerate(batches):
+        out[f"tokens{i}"] = b.numpy()
+    import copy as _copy
+    awq_cfg = _copy.deepcopy(mtq.INT4_AWQ_CFG)
+    awq_cfg["algorithm"]["debug"] = True  # keeps module.awq_lite (best_alpha) after calibration
+    q = mtq.quantize(model, awq_cfg, lambda m: [m(b) for b in batches])
+    linears = []
+    for n, m in q.named_modules():
+        if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
+            linears.append(n)
+            out[f"pre/{n}.weight"] = bits(m.weight)
+            out[f"pre/{n}.amax"] = bits(m.weight_quantizer._amax)
+            out[f"pre/{n}.pre_quant_scale"] = bits(m.input_quantizer._pre_quant_scale)
+            out[f"pre/{n}.best_alpha"] = np.array(float(m.awq_lite.best_alpha) if hasattr(m, "awq_lite") else -1.0)
+        elif type(m).__name__.endswith("RMSNorm"):
+            out[f"pre/{n}.weight"] = bits(m.weight)
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), linears=linears, dtypes=dtypes,
+                                             hf_quant_config=quant_cfg)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    for name, fn in [("mse", gen_mse)] if only == ["mse"] else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
+    single = {"mse": gen_mse, "export_llama": gen_export}
+    for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
-                     ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse)]:
+                     ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
+                     ("export_llama", gen_export)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
-    if only == ["mse"]:
+    if only:
         return
     mx = extract_mx_vectors()
     with open(os.path.join(HERE, "mx_vectors.json"), "w") as f:
