@@ -257,6 +257,24 @@ int moq_awq_err_gemm_multi(const void* x, const void* w, const void* out_actual,
 int moq_gemm_nt(const void* x, const void* w, const void* bias, void* out, int64_t tokens, int64_t cout,
                 int64_t cin, int dt, void* stream);
 
+/* ------------------------------------------------------------------ AWQ-clip block search (a13) */
+
+/* Per-(output channel, block) loss of every clip ratio, one pass over W (MFMA block dots):
+ *   org[t]    = dt( sum_j x[t, b*g+j] * w[r, b*g+j] )
+ *   cur_k[t]  = dt( sum_j x[t, b*g+j] * QDQ_int(w[r, b*g+j]; amax_k) ),  amax_k = amax_dt(amax[r, b] * shrinks[k])
+ *   loss[k, b, r] += mean_t float( dt(cur_k[t] - org[t]) )^2
+ * which is _clip_search's block branch of awq_clip (quantization/model_calib.py:1817-1868): the reference
+ * loops over output-channel batches and shrinks, materialising [co, tokens, n_block, g] products each time.
+ * x: [n_tok, cin] rows x_row_stride elements apart (the reference's token sub-sampling inputs[0::step],
+ * :1820, is a stride here); w: [cout, cin]; amax: fp32 [cout, nblk] holding values of dtype amax_dt (the
+ * dtype of the reference's w_amax: the weight dtype, or MOQ_F32 once the quantizer keeps fp32 amax);
+ * nblk = ceil(cin / g), a ragged last block is zero padded like F.pad (:1825-1828); shrinks: device fp32
+ * [n_shrink <= 32]; loss: fp32 [n_shrink, nblk, cout] (note: block-major, cout contiguous).
+ * signed INT-num_bits, narrow_range False.  cin % (16 / elem size) == 0; g / (32 / elem size) in {2,4,8,16}. */
+int moq_awq_clip_loss(const void* x, int64_t n_tok, int64_t x_row_stride, const void* w, int64_t cout,
+                      int64_t cin, int g, int dt, const float* amax, int amax_dt, const float* shrinks,
+                      int n_shrink, int num_bits, float* loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

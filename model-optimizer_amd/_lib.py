@@ -73,6 +73,8 @@ SIGNATURES = {
     "moq_mse_sweep_workspace": (c_int64, [c_int64, c_int64, c_int64, c_int]),
     "moq_mse_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "moq_awq_clip_loss": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int,
+                                  c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

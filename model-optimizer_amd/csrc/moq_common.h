@@ -129,12 +129,20 @@ __device__ __forceinline__ Pack16 pack<MOQ_BF16>(const float* f) {
   }
   return p;
 }
+// fp32 -> f16 conversions take their operand through `fp32_value`: an empty asm that forces the value to exist as a
+// ROUNDED fp32 number.  Without it the compiler folds a preceding fp32 multiply / add into v_fma_mixlo_f16 /
+// v_fma_mixhi_f16, which rounds the exact product ONCE to f16, while the reference rounds twice (fp32 result,
+// then .to(float16)) -- a rare one-ulp difference that -ffp-contract=off does not cover.
+__device__ __forceinline__ float fp32_value(float v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 template <>
 __device__ __forceinline__ Pack16 pack<MOQ_F16>(const float* f) {
   Pack16 p;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    f32x2 v = {f[2 * i], f[2 * i + 1]};
+    f32x2 v = {fp32_value(f[2 * i]), fp32_value(f[2 * i + 1])};
     f16x2 h = __builtin_convertvector(v, f16x2);  // v_cvt_pk_f16_f32 (RNE)
     p.w[i] = *reinterpret_cast<uint32_t*>(&h);
   }
@@ -168,7 +176,7 @@ __device__ __forceinline__ void store1<MOQ_BF16>(void* b, int64_t i, float v) {
 }
 template <>
 __device__ __forceinline__ void store1<MOQ_F16>(void* b, int64_t i, float v) {
-  reinterpret_cast<_Float16*>(b)[i] = (_Float16)v;
+  reinterpret_cast<_Float16*>(b)[i] = (_Float16)fp32_value(v);
 }
 // round an fp32 value to the storage dtype and back (the value a store+load would produce)
 template <int DT>
@@ -178,7 +186,7 @@ __device__ __forceinline__ float round_to_dtype<MOQ_F32>(float v) { return v; }
 template <>
 __device__ __forceinline__ float round_to_dtype<MOQ_BF16>(float v) { return (float)(__bf16)v; }
 template <>
-__device__ __forceinline__ float round_to_dtype<MOQ_F16>(float v) { return (float)(_Float16)v; }
+__device__ __forceinline__ float round_to_dtype<MOQ_F16>(float v) { return (float)(_Float16)fp32_value(v); }
 
 // ---------------------------------------------------------------- abs-max on bit patterns
 // |x| as an unsigned pattern orders exactly like the float for non-NaN values and puts every NaN above

@@ -10,6 +10,7 @@ Host-side orchestration is the reference's; the passes over tensor data are HIP 
 
 from __future__ import annotations
 
+import math
 import warnings
 
 import torch
@@ -377,3 +378,122 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
         m.input_quantizer._enable_pre_quant_scale = True
         m.input_quantizer.pre_quant_scale = (1.0 / h.best_scale).to(m.weight.dtype)
     return helpers
+
+
+# ------------------------------------------------------------------------------------------------ AWQ clip
+class AWQClipHelper:
+    """Per-linear state of awq_clip (model_calib.py:1746-1785): the max-calibrated block amax, one block-loss
+    table for all clip ratios (device fp32 [K, nblk, Cout], the layout the kernel writes) and the result."""
+
+    def __init__(self, module: QuantLinear, min_clip_ratio: float, shrink_step: float):
+        wq = module.weight_quantizer
+        self.num_tokens = 0
+        self.block_size = wq.block_sizes.get(-1, None) or wq.block_sizes.get(module.weight.dim() - 1)
+        wq.reset_amax()  # cache the original amax (:1751-1756)
+        enable_stats_collection(wq)
+        wq(module.weight)
+        finish_stats_collection(wq)
+        self.w_amax = wq.amax.clone()
+        co, ci = module.weight.shape
+        # same float keys as :1759-1761
+        self.clip_ratios = [round(float(k), 2) for k in torch.arange(min_clip_ratio, 1.0, shrink_step)] + [1.0]
+        self.nblk = math.ceil(ci / self.block_size)
+        self.shrinks = torch.tensor(self.clip_ratios, dtype=torch.float32, device=module.weight.device)
+        self.loss_buf = torch.zeros(len(self.clip_ratios), self.nblk, co, dtype=torch.float32,
+                                    device=module.weight.device)
+        self.best_clip_val = None
+        self.best_loss = None
+        self.is_input_quantized = module.input_quantizer.is_enabled
+        wq.disable()
+
+    @property
+    def loss(self):
+        """{clip ratio: fp32 [Cout, nblk]} -- the reference's per-shrink dict view of the loss table."""
+        return {k: self.loss_buf[i].t() for i, k in enumerate(self.clip_ratios)}
+
+    def update_best_params(self):
+        """model_calib.py:1788-1798: first strictly smaller loss wins; clip value = w_amax * shrink in
+        w_amax's dtype."""
+        self.best_loss = torch.ones_like(self.w_amax) * float("inf")
+        self.best_clip_val = torch.zeros_like(self.w_amax)
+        for shrink, loss in self.loss.items():
+            loss = loss.reshape(self.w_amax.shape)
+            indices = loss < self.best_loss
+            self.best_loss = torch.where(indices, loss.to(self.best_loss.dtype), self.best_loss)
+            self.best_clip_val = torch.where(indices, self.w_amax * shrink, self.best_clip_val)
+
+
+@torch.no_grad()
+def awq_clip(model: nn.Module, forward_loop, max_co_batch_size: int = 1024, max_tokens_per_batch: int = 64,
+             min_clip_ratio: float = 0.5, shrink_step: float = 0.05, debug: bool = False, **kwargs):
+    """AWQ-clip (model_calib.py:1724-1940) for static-block INT weight quantizers: per weight block, the clip
+    ratio of the block amax that minimises the block's output error on (sub-sampled) calibration tokens.
+    `max_co_batch_size` bounds the reference's broadcast temporaries and has no effect here: the search is one
+    kernel pass over the weight per forward call (ops.awq_clip_loss)."""
+    assert forward_loop is not None, "forward_loop must be provided for awq_clip"
+    mods = [(n, m) for n, m in model.named_modules()
+            if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.block_sizes is not None]
+    for name, m in mods:
+        wq = m.weight_quantizer
+        if not wq.is_static_block_quant or not isinstance(wq._num_bits, int) or wq._unsigned or wq._narrow_range:
+            raise ValueError(f"awq_clip: {name}: only signed static-block INT weight quantizers are on this path "
+                             "(the per-tensor NVFP4 branch, model_calib.py:1804-1813, is outside it)")
+    helpers = {m: AWQClipHelper(m, min_clip_ratio, shrink_step) for _, m in mods}
+
+    def patched_forward(self, input):
+        h = helpers[self]
+        iq = self.input_quantizer
+        if h.is_input_quantized:  # :1873-1876: calibrate the input quantizer on this batch, then bypass it
+            iq.enable()
+            max_calibrate(iq, lambda q: q(input), distributed_sync=False)
+            iq.disable()
+        x = iq(input)  # applies pre_quant_scale (awq_full: the AWQ-lite scale) even though disabled
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[0] > 0:
+            step = max(1, x2.shape[0] // max_tokens_per_batch)  # inputs[0::step] (:1820)
+            h.num_tokens += -(-x2.shape[0] // step)
+            ops.awq_clip_loss(x2, self.weight, h.w_amax, h.shrinks, h.block_size, self.weight_quantizer.num_bits,
+                              h.loss_buf, token_step=step)
+        return F.linear(x, self.weight, self.bias)  # _forward_no_awq with the weight quantizer disabled (:1893)
+
+    originals = {}
+    for _, m in mods:
+        originals[m] = m.forward
+        m.forward = patched_forward.__get__(m, type(m))
+    try:
+        enable_stats_collection(model)  # input / KV quantizers collect during the same pass (:1910-1913)
+        forward_loop(model)
+        finish_stats_collection(model)
+        if dist.is_available() and dist.is_initialized():
+            # DP: the reference all-reduces every block-loss tensor inside the search loop (:1861-1863); linear
+            # in the loss, so ONE bucketed SUM + divide at the end is the same value
+            mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()], dist.ReduceOp.SUM, average=True)
+            mdist.sync_amax_bucketed([q for q in _quantizers(model) if q.is_enabled])
+    finally:
+        for m, f in originals.items():
+            m.forward = f
+    for _, m in mods:
+        h = helpers[m]
+        if h.num_tokens > 0:  # postprocess (:1921-1929)
+            h.update_best_params()
+            m.weight_quantizer.amax = h.best_clip_val
+            m.weight_quantizer.enable()
+            if h.is_input_quantized:
+                m.input_quantizer.enable()
+        if debug:
+            m.awq_clip = h
+    return helpers
+
+
+@torch.no_grad()
+def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwargs):
+    """model_calib.py:1362-1391: awq_lite, awq_clip or both (awq_full)."""
+    out = {}
+    if algorithm in ("awq_full", "awq_lite"):
+        lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step",)}
+        out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
+    if algorithm in ("awq_full", "awq_clip"):
+        clip_kw = {k: v for k, v in kwargs.items()
+                   if k in ("max_co_batch_size", "max_tokens_per_batch", "min_clip_ratio", "shrink_step", "debug")}
+        out["awq_clip"] = awq_clip(model, forward_loop, **clip_kw)
+    return out

@@ -67,8 +67,8 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
         model_calib.mse_calibrate(model, forward_loop, **kwargs)
     elif method == "smoothquant":
         model_calib.smoothquant(model, forward_loop, **kwargs)
-    elif method == "awq_lite":
-        model_calib.awq_lite(model, forward_loop, **kwargs)
+    elif method in ("awq_lite", "awq_clip", "awq_full"):
+        model_calib.awq(model, forward_loop, algorithm=method, **kwargs)
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
     return model

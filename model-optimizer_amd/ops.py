@@ -574,3 +574,36 @@ def rescale_cols(weight: torch.Tensor, mul: torch.Tensor, div: torch.Tensor, out
     with _on(w) as stream:
         check(_lib.lib().moq_rescale_cols(_p(w), _p(m), _p(d), _p(y), w.numel() // cols, cols, _dt(w), stream))
     return y
+
+
+# ----------------------------------------------------------------------------------------------- AWQ clip
+@torch.no_grad()
+def awq_clip_loss(inputs: torch.Tensor, weight: torch.Tensor, w_amax: torch.Tensor, shrinks: torch.Tensor,
+                  block_size: int, num_bits: int, loss: torch.Tensor, token_step: int = 1) -> torch.Tensor:
+    """loss[k, b, r] += mean_t (cur_k - org)^2 for every clip ratio k -- _clip_search's block branch
+    (model_calib.py:1817-1868) in one pass over the weight.  inputs [T, Cin] (rows inputs[0::token_step] are
+    used, :1820), weight [Cout, Cin], w_amax [Cout * nblk] in the dtype the reference's w_amax has, shrinks fp32
+    [K] on device, loss fp32 [K, nblk, Cout] (block-major; use .transpose(1, 2) for the reference's layout)."""
+    _require_gpu(weight, "awq_clip_loss")
+    x2 = inputs.detach().reshape(-1, inputs.shape[-1])
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    w = weight.detach().contiguous()
+    cout, cin = w.shape
+    nblk = -(-cin // block_size)
+    n_tok = -(-x2.shape[0] // token_step)
+    if x2.dtype != w.dtype or x2.shape[1] != cin:
+        raise MoquantError("awq_clip_loss: inputs / weight mismatch")
+    adt = _lib.F32 if w_amax.dtype == torch.float32 else _dt(w_amax)
+    am = _f32(w_amax, w.device).reshape(-1)
+    if am.numel() != cout * nblk:
+        raise MoquantError(f"awq_clip_loss: w_amax has {am.numel()} entries, expected {cout * nblk}")
+    if (loss.dtype != torch.float32 or not loss.is_contiguous()
+            or tuple(loss.shape) != (shrinks.numel(), nblk, cout)):
+        raise MoquantError("awq_clip_loss: loss must be contiguous fp32 [n_shrink, nblk, cout]")
+    sh = shrinks.to(device=w.device, dtype=torch.float32).contiguous()
+    with _on(w) as stream:
+        check(_lib.lib().moq_awq_clip_loss(_p(x2), n_tok, token_step * cin, _p(w), cout, cin, int(block_size),
+                                           _dt(w), _p(am), adt, _p(sh), sh.numel(), int(num_bits), _p(loss),
+                                           stream))
+    return loss

@@ -245,3 +245,23 @@ def rescale_cols(w, mul, div):
     y = _empty_like_np(w)
     lib().orc_rescale_cols(_p(a), _p(m), _p(d), _p(y), I64(rows), I64(cols), DT[w.dtype])
     return _from_np(y, w.dtype, w.shape)
+
+
+def awq_clip_loss(x, w, amax, shrinks, g, num_bits=4, loss=None):
+    """loss[k, r, b] (+)= mean_t (cur_k - org)^2 of awq_clip's block search (model_calib.py:1800-1868).
+    x [n_tok <= 256, cin], w [cout, cin] (same dtype); amax [cout, nblk] in the dtype w_amax has in the reference
+    (weight dtype or fp32); shrinks: python floats.  fp32 [n_shrink, cout, nblk]."""
+    n_tok, cin = x.shape
+    cout = w.shape[0]
+    nblk = (cin + g - 1) // g
+    assert n_tok <= 256 and g <= 1024 and tuple(amax.shape) == (cout, nblk)
+    a, b = _np(x), _np(w)
+    am = np.ascontiguousarray(amax.detach().cpu().float().numpy())
+    sh = np.asarray([float(s) for s in shrinks], dtype=np.float32)
+    if loss is None:
+        loss = np.zeros((len(sh), cout, nblk), dtype=np.float32)
+    else:
+        loss = np.ascontiguousarray(loss.detach().cpu().float().numpy())
+    lib().orc_awq_clip_loss(_p(a), I64(n_tok), _p(b), I64(cout), I64(cin), int(g), DT[w.dtype], _p(am),
+                            DT[amax.dtype], _p(sh), int(len(sh)), int(num_bits), _p(loss))
+    return torch.from_numpy(loss)

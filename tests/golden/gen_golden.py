@@ -16,6 +16,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
+  awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -380,6 +381,58 @@ def gen_model_flows(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_awq_clip(out):
+    """mtq.quantize() with algorithm awq_clip / awq_full (model_calib.py:1724-1940) on the tiny MLP, debug=True so
+    that module.awq_clip (w_amax, per-shrink block losses, best_clip_val) survives.  fc1's inputs are the stored
+    batches themselves, so its losses pin the block-search kernel directly."""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+
+    cases = {}
+    for name, method, dt, d, ntok in [("clip_f32", "awq_clip", torch.float32, 128, 24),
+                                      ("clip_bf16", "awq_clip", torch.bfloat16, 128, 24),
+                                      ("clip_f16_200", "awq_clip", torch.float16, 256, 200),
+                                      ("full_f32", "awq_full", torch.float32, 128, 24),
+                                      ("full_bf16", "awq_full", torch.bfloat16, 128, 24)]:
+        model = _TinyMLP(d=d, h=128, dtype=dt, seed=11)
+        g = torch.Generator().manual_seed(17)
+        ch = torch.exp(torch.randn(d, generator=g))
+        ch[:4] *= 30
+        batches = [(torch.randn(ntok, d, generator=g) * ch).to(dt) for _ in range(3)]
+        out[f"{name}_w1"], out[f"{name}_w2"], out[f"{name}_b2"] = bits(model.fc1.weight), bits(model.fc2.weight), bits(model.fc2.bias)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+
+        def loop(m):
+            for b in batches:
+                m(b)
+
+        cfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+        cfg["algorithm"] = {"method": method, "debug": True}
+        q = mtq.quantize(copy.deepcopy(model), cfg, loop)
+        info = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches), d=d, method=method)
+        for lname in ("fc1", "fc2"):
+            lin = getattr(q, lname)
+            h = lin.awq_clip
+            info[f"{lname}_shrinks"] = [float(k) for k in h.loss]
+            info[f"{lname}_w_amax_dtype"] = str(h.w_amax.dtype).split(".")[-1]
+            info[f"{lname}_num_tokens"] = int(h.num_tokens)
+            out[f"{name}_{lname}_w_amax"] = bits(h.w_amax.float())
+            out[f"{name}_{lname}_loss"] = bits(torch.stack([v.float() for v in h.loss.values()]))
+            out[f"{name}_{lname}_best_clip_val"] = bits(h.best_clip_val.float())
+            out[f"{name}_{lname}_wfinal"] = bits(lin.weight)
+            wq = lin.weight_quantizer
+            out[f"{name}_{lname}_amax_final"] = bits(wq._amax.float())
+            info[f"{lname}_amax_final_dtype"] = str(wq._amax.dtype).split(".")[-1]
+            info[f"{lname}_amax_final_shape"] = list(wq._amax.shape)
+            if hasattr(lin.input_quantizer, "_pre_quant_scale"):
+                out[f"{name}_{lname}_pre_quant_scale"] = bits(lin.input_quantizer._pre_quant_scale.float())
+        out[f"{name}_y"] = bits(q(batches[0]))
+        cases[name] = info
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def extract_mx_vectors():
     """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
     path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
@@ -538,11 +591,11 @@ def gen_export(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

@@ -247,3 +247,24 @@ def test_oracle_mse_sweep_matches_reference_losses(golden):
         best = got.argmin(0)
         amax = (init.reshape(-1) * mult[best]).float() if init.dim() else (init * mult[best]).float().reshape(-1)
         assert torch.equal(amax.reshape(-1), g.t(f"{name}_amax").reshape(-1)), f"{name}: chosen amax differs"
+
+
+@pytest.mark.parametrize("name", ["clip_f32", "clip_bf16", "clip_f16_200"])
+def test_awq_clip_loss_matches_reference_run(golden, name):
+    """orc_awq_clip_loss vs the block losses the reference's awq_clip accumulated over three calibration batches
+    (fc1 of the tiny MLP: its inputs are the stored batches).  Differences: fp32 summation order of torch's sum
+    only (fp32 <= 1e-4; 16-bit: an occasional flipped final rounding, <= 2e-3); chosen clip ratio identical."""
+    g = golden("awq_clip")
+    c = g.cases[name]
+    dt = getattr(torch, c["dtype"])
+    w = g.t(f"{name}_w1", dt)
+    amax = g.t(f"{name}_fc1_w_amax").to(getattr(torch, c["fc1_w_amax_dtype"])).reshape(w.shape[0], -1)
+    loss = None
+    for i in range(c["n_batches"]):
+        x = g.t(f"{name}_x{i}", dt)
+        xs = x[0::max(1, x.shape[0] // 64)].contiguous()
+        loss = oracle.awq_clip_loss(xs, w, amax, c["fc1_shrinks"], 128, 4, loss)
+    want = g.t(f"{name}_fc1_loss").reshape(loss.shape)
+    rel = ((loss - want).abs() / want.abs().clamp_min(1e-30)).max().item()
+    assert rel <= (1e-4 if dt == torch.float32 else 2e-3), f"{name}: max rel err {rel:.3e}"
+    assert torch.equal(loss.argmin(0), want.argmin(0))
