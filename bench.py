@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--group-mb", type=int, default=0,
                     help="fp8/int8: calibrate+QDQ in groups of <= this many MB of weights (second read from the "
                          "Infinity Cache) instead of two whole-model passes; 0 = off")
+    ap.add_argument("--inplace", action="store_true",
+                    help="QDQ output overwrites the weights (y == x is part of the C-ABI contract); needed for "
+                         "llama3-70b on one GPU: 137 GB of weights + 137 GB of outputs do not fit in 288 GB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernel measurements")
     args = ap.parse_args()
@@ -155,7 +158,7 @@ def main():
     n_elem = sum(w.numel() for w in weights)
     wl = args.workload
 
-    tab = SegmentTable(weights, group_size=128 if wl == "int4g128" else None)
+    tab = SegmentTable(weights, outputs=weights if args.inplace else None, group_size=128 if wl == "int4g128" else None)
     groups = None
     if args.group_mb and wl in ("fp8", "int8"):
         groups, cur, cur_b = [], [], 0
@@ -262,7 +265,7 @@ def main():
                 "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4)}
 
     out = {
-        "metric": "GB/s weights calibrated+QDQ (Llama-3-8B)",
+        "metric": f"GB/s weights calibrated+QDQ ({'Llama-3-8B' if args.model == 'llama3-8b' else 'Llama-3-70B'})",
         "value": round(value, 2),
         "unit": "GB/s",
         "n_gpus": world,
@@ -275,7 +278,7 @@ def main():
         "dtype": "bf16 storage, f32 arithmetic",
         "data": "synthetic",
         "config": {"workload": f"{args.model} all {len(weights)} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16 per GPU), "
-                               f"{wl} calibrate + quantize-dequantize, inputs resident in HBM",
+                               f"{wl} calibrate + quantize-dequantize{' in place' if args.inplace else ''}, inputs resident in HBM",
                    "format": wl, "model": args.model, "layers": n_layers,
                    "parallelism": f"per-layer weight tensors sharded over {world} GPU(s); one amax bucket all-reduce(MAX)"
                                   if world > 1 else "single GPU"},

@@ -275,6 +275,30 @@ int moq_awq_clip_loss(const void* x, int64_t n_tok, int64_t x_row_stride, const 
                       int64_t cin, int g, int dt, const float* amax, int amax_dt, const float* shrinks,
                       int n_shrink, int num_bits, float* loss, void* stream);
 
+/* ------------------------------------------------------------------ real FP8 / MXFP4 (a15) */
+
+/* out[i] = e4m3fn( dt( x[i] / scale ) ): the quotient is rounded to the storage dtype first (both operands of the
+ * reference's division have the model dtype), then cast with torch's NON-saturating RNE cast (|v| > 464 or NaN ->
+ * 0x7F | sign).  scales: dtype dt; amax_mode MOQ_AMAX_SCALAR: scales[0]; MOQ_AMAX_AXIS: scales[(i / inner) %
+ * axis_size] (per-channel rows: inner = Cin; 1-D blocks: inner = block, axis_size = n / block).
+ * Replaces FP8QTensor.quantize's cast (quantization/qtensor/fp8_tensor.py:103-107) and the FP8 branch of
+ * to_quantized_weight (export/quant_utils.py).  n % (16 / elem size) == 0, inner likewise. */
+int moq_fp8_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int dt, int amax_mode,
+                 int64_t axis_size, int64_t inner, void* stream);
+/* out[i] = dt( dt(float(q[i])) * scale ) -- FP8QTensor.dequantize (fp8_tensor.py:151). */
+int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, int64_t n, int dt, int amax_mode,
+                   int64_t axis_size, int64_t inner, void* stream);
+/* MXFP4QTensor.quantize (quantization/qtensor/mxfp4_tensor.py:37-81) over n_blocks consecutive blocks of `block`
+ * elements: e = ceil(max(log2(amax / 6), -127)); e8m0[b] = e + 127; v = x / 2^e; nibble = (sign_bit << 3) +
+ * #{bound < |v|} over {0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5} (strict: ties round down; an exact zero gets sign_bit
+ * 1); packed[i / 2] = (nibble_odd << 4) + nibble_even.  block even. */
+int moq_mxfp4_pack(const void* x, uint8_t* packed, uint8_t* e8m0, int64_t n_blocks, int block, int dt,
+                   void* stream);
+/* out = dt( sign * {0, .5, 1, 1.5, 2, 3, 4, 6}[nibble & 7] * 2^(e8m0 - 127) ) -- MXFP4QTensor.dequantize
+ * (mxfp4_tensor.py:83-144). */
+int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void* out, int64_t n_blocks, int block, int dt,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@ pids=()
 for src in moq_*.hip; do
   obj="build/${src%.hip}.o"
   mkdir -p build
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ moq_chunk.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
     echo "[moquant] hipcc $src"
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)

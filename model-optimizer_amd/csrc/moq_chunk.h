@@ -1,0 +1,120 @@
+// moq_chunk.h -- the chunk skeleton shared by the HBM-streaming kernels (moq_stream.hip, moq_formats.hip).
+//
+// A *chunk* is MOQ_MT_CHUNK = 8192 consecutive elements; a 256-thread workgroup owns a chunk at a time and moves
+// it with 16-byte lane accesses: packet u of thread t covers elements (u*256 + t)*kVec ..., so every wave
+// instruction touches one contiguous KiB.  All loads of a chunk are issued before the first use; read-once /
+// write-once streams carry the non-temporal hint; copy-shaped passes use a large strided grid (copy_grid).
+#pragma once
+
+#include <stdlib.h>
+
+#include "moq_common.h"
+
+namespace moq {
+
+template <int DT>
+struct Chunk {
+  static constexpr int kVec = Elem<DT>::kVec;
+  static constexpr int kPackets = MOQ_MT_CHUNK / (kBlock * kVec);  // 4 (16-bit) or 8 (f32)
+  static_assert(kPackets * kBlock * kVec == MOQ_MT_CHUNK, "chunk must tile exactly");
+};
+
+// element offset (inside the chunk) of packet u of this thread
+template <int DT>
+__device__ __forceinline__ int packet_off(int u) {
+  return (u * kBlock + (int)threadIdx.x) * Elem<DT>::kVec;
+}
+
+// Guarded / unaligned packet access.  FAST = chunk fully inside the tensor and base 16-byte aligned.
+template <int DT, bool FAST, bool NT = true>
+__device__ __forceinline__ Pack16 ld_packet(const void* base, int64_t e, int64_t n) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int ES = 16 / V;
+  if constexpr (FAST) {
+    // streaming data is read exactly once: non-temporal hint (measured on MI355X, 14 GiB streams:
+    // read-only 6.2 -> 7.0 TB/s, copy 5.9 -> 6.5 TB/s; tools/exp/stream_probe.hip).  NT = false keeps the
+    // lines in L2 / Infinity Cache for a second pass over the same tensor (grouped calibrate -> QDQ).
+    if constexpr (NT) return load16_nt(reinterpret_cast<const char*>(base) + e * ES);
+    else return load16(reinterpret_cast<const char*>(base) + e * ES);
+  } else {
+    float f[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) f[i] = (e + i < n) ? load1<DT>(base, e + i) : 0.0f;
+    if constexpr (DT == MOQ_F32) {
+      return pack<DT>(f);
+    } else {
+      // keep the exact 16-bit patterns (no re-rounding): rebuild from raw storage
+      Pack16 p;
+      const uint16_t* b = reinterpret_cast<const uint16_t*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t lo = (e + 2 * i < n) ? b[e + 2 * i] : 0u;
+        uint32_t hi = (e + 2 * i + 1 < n) ? b[e + 2 * i + 1] : 0u;
+        p.w[i] = lo | (hi << 16);
+      }
+      return p;
+    }
+  }
+}
+template <int DT, bool FAST>
+__device__ __forceinline__ void st_packet(void* base, int64_t e, int64_t n, const Pack16& p) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int ES = 16 / V;
+  if constexpr (FAST) {
+    store16_nt(reinterpret_cast<char*>(base) + e * ES, p);
+  } else {
+    if constexpr (DT == MOQ_F32) {
+      float* b = reinterpret_cast<float*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (e + i < n) b[e + i] = __uint_as_float(p.w[i]);
+    } else {
+      uint16_t* b = reinterpret_cast<uint16_t*>(base);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (e + 2 * i < n) b[e + 2 * i] = (uint16_t)(p.w[i] & 0xFFFFu);
+        if (e + 2 * i + 1 < n) b[e + 2 * i + 1] = (uint16_t)(p.w[i] >> 16);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+// Index of the group (quantization block / scale entry) an element belongs to, for kernels that walk chunks:
+// one 64-bit division per chunk (uniform), 32-bit shift / division per packet.
+struct GroupIndex {
+  int64_t q0;
+  uint32_t r0, g;
+  int shift;  // log2(g) when g is a power of two, else -1
+  __device__ __forceinline__ void seek(int64_t e0) {
+    q0 = e0 / (int64_t)g;
+    r0 = (uint32_t)(e0 - q0 * (int64_t)g);
+  }
+  __device__ __forceinline__ int64_t at(uint32_t off) const {
+    const uint32_t t = r0 + off;
+    return q0 + (int64_t)(shift >= 0 ? (t >> shift) : (t / g));
+  }
+};
+}  // namespace moq
+
+static inline int log2_or_neg(int64_t g) {
+  if (g <= 0 || (g & (g - 1)) != 0) return -1;
+  int s = 0;
+  while ((1LL << s) < g) ++s;
+  return s;
+}
+
+// copy-shaped passes: ~8 chunks per workgroup, at least a full machine (2048), at most 128 Ki workgroups
+static inline int copy_grid(int64_t n_chunks) {
+  static const int64_t div = [] { const char* e = getenv("MOQ_TUNE_CHUNKS_PER_WG"); return e ? atoll(e) : 8LL; }();
+  int64_t g = n_chunks / (div > 0 ? div : 8);
+  if (g < 2048) g = 2048;
+  if (g > 131072) g = 131072;
+  if (g > n_chunks) g = n_chunks;
+  return (int)(g < 1 ? 1 : g);
+}
+
+

@@ -61,7 +61,7 @@ __device__ __forceinline__ Pack16 zero_pack() {
 // NP = 16-byte packets per lane per block row = g / (2 * kVec): lane half h owns packets 2p + h.
 // TT = token tiles (32 tokens each) held in registers per pass.
 template <int DT, int NP, int TT, int ADT>
-__global__ __launch_bounds__(kBlock) void awq_clip_kernel(const void* __restrict__ x, int64_t n_tok,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((TT <= 2 && NP <= 8 && DT != MOQ_F32) ? 2 : 1, (TT <= 2 && NP <= 8 && DT != MOQ_F32) ? 2 : 1))) void awq_clip_kernel(const void* __restrict__ x, int64_t n_tok,
                                                           int64_t x_row_stride, const void* __restrict__ w,
                                                           int64_t cout, int64_t cin,
                                                           const float* __restrict__ amax,

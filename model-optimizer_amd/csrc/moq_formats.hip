@@ -1,6 +1,7 @@
 // moq_formats.hip -- MX dynamic-block QDQ, histogram, 2:4 mask, real INT4 pack/unpack, export packer and
 // the column-scale fold.  All HBM-bound streaming kernels with 16-byte lane accesses.
 #include "moq_common.h"
+#include "moq_chunk.h"
 
 namespace moq {
 
@@ -88,33 +89,46 @@ __device__ __forceinline__ float mx_abs_clamped(float x) {
   return a > 3.402823466e+38f ? 3.402823466e+38f : a;
 }
 
-// fast path: cols % block == 0, block % kVec == 0 -> an MX block is LPG adjacent lanes of one packet
-template <int DT, int LPG>
+// fast path: cols % block == 0, block % kVec == 0 -> an MX block is LPG adjacent lanes of one packet.
+// Chunk skeleton: all packets of a chunk in flight before the first use, non-temporal loads and stores, dense
+// strided grid.  FMT >= 0 fixes the element format at compile time (E2M1 / E4M3: the MXFP4 / MXFP8 presets) so
+// that the rounding constants fold; FMT < 0 reads it from `fmt`.
+template <int DT, int LPG, int FMT>
 __global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                    int64_t n_packets, int fmt) {
+                                                    int64_t n, int fmt) {
   constexpr int V = Elem<DT>::kVec;
-  const MxFmt f = mx_fmt(fmt);
+  constexpr int P = Chunk<DT>::kPackets;
+  constexpr int ES = 16 / V;
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
   const char* xb = reinterpret_cast<const char*>(x);
   char* yb = reinterpret_cast<char*>(y);
-  // whole waves iterate together so that the LPG-lane butterfly always has all its lanes
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const int64_t n_round = (n_packets + 63) / 64 * 64;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_round; p += stride) {
-    const bool live = p < n_packets;
-    float v[8];
-    if (live) unpack<DT>(load16(xb + p * 16), v);
-    else
-      for (int i = 0; i < V; ++i) v[i] = 0.0f;
-    float am = 0.0f;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    Pack16 in[P];
+    // n is a multiple of the block (= LPG * V elements), so a group is entirely live or entirely past the end
 #pragma unroll
-    for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
-    // non-negative floats order like their bit patterns
-    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
-    float sc, un;
-    mx_scale_e8m0(am, f.maxv, sc, un);
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      if (e < n) in[u] = load16_nt(xb + e * ES);
+      else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+    }
 #pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
-    if (live) store16(yb + p * 16, pack<DT>(v));
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      float v[8];
+      unpack<DT>(in[u], v);
+      float am = 0.0f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+      // non-negative floats order like their bit patterns
+      am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
+      float sc, un;
+      mx_scale_e8m0(am, f.maxv, sc, un);
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+      if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
+    }
   }
 }
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding) and any alignment
@@ -144,50 +158,89 @@ __global__ void mx_generic_kernel(const void* __restrict__ x, void* __restrict__
 // atomics.
 constexpr int kHistMaxLdsBins = 16384;  // 64 KiB of the CU's 160 KiB LDS
 
-__device__ __forceinline__ int hist_bin(float a, int bins, float max_edge, int skip_zeros) {
+// Branch-free binning: one LDS atomic per element, invalid elements (outside [0, max_edge], NaN, skipped zeros,
+// past the end) go to a trash slot instead of around a branch -- the exec-mask juggling of a guarded atomic costs
+// more issue slots than the atomic itself.  SHARED selects the shared-denominator division (bit-identical to `/`
+// while |a * bins| <= 2^16, checked by the caller): five full-rate FMAs instead of the IEEE sequence per element.
+// LDS layout: R = 2^rshift interleaved copies of the histogram (copy = lane & (R - 1), slot = bin * R + copy) plus R
+// trash slots at bin index `bins`: activations pile up in a few low bins and same-address LDS atomics of one wave
+// serialise -- R copies cut that R-fold and spread a hot bin over R banks.
+template <bool SHARED>
+__device__ __forceinline__ int hist_bin(float a, int bins, float max_edge, const SharedDiv& sd, int skip_zeros) {
   // torch.histc: pos = (int)((v - min) * bins / (max - min)) in fp32, v == max -> last bin, outside -> skip
-  if (!(a <= max_edge)) return -1;  // also drops NaN
-  if (skip_zeros && a == 0.0f) return -1;
-  int pos = (int)(a * (float)bins / max_edge);
-  if (pos >= bins) pos = bins - 1;
-  return pos;
-}
-template <int DT, bool LDS>
-__global__ __launch_bounds__(kBlock) void hist_kernel(const void* __restrict__ x, int64_t n,
-                                                      unsigned long long* __restrict__ counts, int bins,
-                                                      float max_edge, int skip_zeros) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
-  constexpr int V = Elem<DT>::kVec;
-  if (LDS) {
-    for (int b = threadIdx.x; b < bins; b += kBlock) lds_hist[b] = 0;
-    __syncthreads();
+  const float num = a * (float)bins;
+  float qf;
+  if constexpr (SHARED) {  // shared_div without its range check (the host selected this instantiation)
+    const float q0 = num * sd.y;
+    const float r0 = __builtin_fmaf(-sd.d, q0, num);
+    const float q1 = __builtin_fmaf(r0, sd.y, q0);
+    const float r1 = __builtin_fmaf(-sd.d, q1, num);
+    qf = __builtin_fmaf(r1, sd.y, q1);
+  } else {
+    qf = num / max_edge;
   }
-  const bool fast = al16(x);
-  const int64_t n_packets = (n + V - 1) / V;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
+  int pos = (int)qf;
+  pos = pos < bins - 1 ? pos : bins - 1;
+  // bitwise, not short-circuit: no exec-mask branches.  a <= max_edge also drops NaN.
+  const bool ok = (a <= max_edge) & !((skip_zeros != 0) & (a == 0.0f));
+  return ok ? pos : bins;
+}
+template <int DT, bool FAST, bool SHARED>
+__device__ __forceinline__ void hist_chunk(const void* x, int64_t e0, int64_t n, uint32_t* lds_hist, int bins,
+                                           float max_edge, const SharedDiv& sd, int skip_zeros, int rshift, int copy) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + packet_off<DT>(u), n);
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
     float v[8];
-    const int64_t e = p * V;
-    if (fast && e + V <= n) {
-      unpack<DT>(load16(reinterpret_cast<const char*>(x) + p * 16), v);
-    } else {
-      for (int i = 0; i < V; ++i) v[i] = e + i < n ? load1<DT>(x, e + i) : __uint_as_float(0x7FC00000u);
-    }
+    unpack<DT>(in[u], v);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int b = hist_bin(__builtin_fabsf(v[i]), bins, max_edge, skip_zeros);
-      if (b >= 0) {
-        if (LDS) atomicAdd(&lds_hist[b], 1u);
-        else atomicAdd(&counts[b], 1ull);
-      }
+      int b = hist_bin<SHARED>(__builtin_fabsf(v[i]), bins, max_edge, sd, skip_zeros);
+      if constexpr (!FAST) b = e + i < n ? b : bins;
+      atomicAdd(&lds_hist[(b << rshift) + copy], 1u);
     }
   }
-  if (LDS) {
-    __syncthreads();
-    for (int b = threadIdx.x; b < bins; b += kBlock) {
-      const uint32_t c = lds_hist[b];
-      if (c) atomicAdd(&counts[b], (unsigned long long)c);
-    }
+}
+template <int DT, bool SHARED>
+__global__ __launch_bounds__(kBlock) void hist_kernel(const void* __restrict__ x, int64_t n,
+                                                      unsigned long long* __restrict__ counts, int bins,
+                                                      float max_edge, int skip_zeros, int rshift) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
+  const int slots = (bins + 1) << rshift;
+  const int copy = (int)(threadIdx.x & ((1u << rshift) - 1u));
+  for (int b = threadIdx.x; b < slots; b += kBlock) lds_hist[b] = 0;
+  __syncthreads();
+  const bool al = al16(x);
+  const SharedDiv sd = make_shared_div(max_edge);
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if (al && e0 + MOQ_MT_CHUNK <= n)
+      hist_chunk<DT, true, SHARED>(x, e0, n, lds_hist, bins, max_edge, sd, skip_zeros, rshift, copy);
+    else
+      hist_chunk<DT, false, SHARED>(x, e0, n, lds_hist, bins, max_edge, sd, skip_zeros, rshift, copy);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kBlock) {
+    uint32_t cnt = 0;
+    for (int r = 0; r < (1 << rshift); ++r) cnt += lds_hist[(b << rshift) + r];
+    if (cnt) atomicAdd(&counts[b], (unsigned long long)cnt);
+  }
+}
+// bin counts beyond the LDS budget (after many growth steps of the calibrator): straight to L2 atomics
+template <int DT>
+__global__ __launch_bounds__(kBlock) void hist_global_kernel(const void* __restrict__ x, int64_t n,
+                                                             unsigned long long* __restrict__ counts, int bins,
+                                                             float max_edge, int skip_zeros) {
+  const SharedDiv sd = make_shared_div(max_edge);
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int b = hist_bin<false>(__builtin_fabsf(load1<DT>(x, e)), bins, max_edge, sd, skip_zeros);
+    if (b < bins) atomicAdd(&counts[b], 1ull);
   }
 }
 
@@ -218,169 +271,265 @@ __device__ __forceinline__ uint32_t mask4(float a0, float a1, float a2, float a3
   const uint32_t tbl[6] = {0x01000100u, 0x00000101u, 0x00010100u, 0x00010001u, 0x01000001u, 0x01010000u};
   return tbl[best];
 }
-template <int DT>
+__device__ __forceinline__ void store8_nt(void* p, uint32_t a, uint32_t b) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+}
+__device__ __forceinline__ void store4_nt(void* p, uint32_t a) {
+  __builtin_nontemporal_store(a, reinterpret_cast<uint32_t*>(p));
+}
+template <int DT, bool NTS>
 __global__ __launch_bounds__(kBlock) void mask24_kernel(const void* __restrict__ w,
                                                         uint8_t* __restrict__ mask, int64_t n) {
   constexpr int V = Elem<DT>::kVec;  // 8 (two groups of 4) or 4 (one group)
-  const bool fast = al16(w) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
-  const int64_t n_packets = n / V;  // n % 4 == 0; a trailing half packet (bf16) is handled below
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
-    float v[8];
-    if (fast) unpack<DT>(load16(reinterpret_cast<const char*>(w) + p * 16), v);
-    else
-      for (int i = 0; i < V; ++i) v[i] = load1<DT>(w, p * V + i);
+  constexpr int P = Chunk<DT>::kPackets;
+  const bool al = al16(w) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    const bool fast = al && e0 + MOQ_MT_CHUNK <= n;
+    Pack16 in[P];
 #pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = __builtin_fabsf(v[i]);
-    uint32_t m0 = mask4(v[0], v[1], v[2], v[3]);
-    if constexpr (V == 8) {
-      uint32_t m1 = mask4(v[4], v[5], v[6], v[7]);
-      if (fast) {
-        *reinterpret_cast<uint2*>(mask + p * 8) = make_uint2(m0, m1);
-      } else {
-        for (int i = 0; i < 4; ++i) { mask[p * 8 + i] = (m0 >> (8 * i)) & 1; mask[p * 8 + 4 + i] = (m1 >> (8 * i)) & 1; }
-      }
-    } else {
-      if (fast) *reinterpret_cast<uint32_t*>(mask + p * 4) = m0;
-      else
-        for (int i = 0; i < 4; ++i) mask[p * 4 + i] = (m0 >> (8 * i)) & 1;
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      in[u] = fast ? ld_packet<DT, true>(w, e, n) : ld_packet<DT, false>(w, e, n);
     }
-  }
-  // tail: n % V == 4 for 16-bit types
-  if (blockIdx.x == 0 && threadIdx.x == 0 && (n % V) != 0) {
-    const int64_t e = n_packets * V;
-    const uint32_t m0 = mask4(__builtin_fabsf(load1<DT>(w, e)), __builtin_fabsf(load1<DT>(w, e + 1)),
-                              __builtin_fabsf(load1<DT>(w, e + 2)), __builtin_fabsf(load1<DT>(w, e + 3)));
-    for (int i = 0; i < 4; ++i) mask[e + i] = (m0 >> (8 * i)) & 1;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      float v[8];
+      unpack<DT>(in[u], v);
+#pragma unroll
+      for (int i = 0; i < V; ++i) v[i] = __builtin_fabsf(v[i]);
+      const uint32_t m0 = mask4(v[0], v[1], v[2], v[3]);
+      uint32_t m1 = 0;
+      if constexpr (V == 8) m1 = mask4(v[4], v[5], v[6], v[7]);
+      if (fast) {
+        if constexpr (NTS) {
+          if constexpr (V == 8) store8_nt(mask + e, m0, m1);
+          else store4_nt(mask + e, m0);
+        } else {
+          if constexpr (V == 8) *reinterpret_cast<uint2*>(mask + e) = make_uint2(m0, m1);
+          else *reinterpret_cast<uint32_t*>(mask + e) = m0;
+        }
+      } else {  // n % 4 == 0: groups of four are all-in or all-out
+        if (e + 4 <= n)
+          for (int i = 0; i < 4; ++i) mask[e + i] = (m0 >> (8 * i)) & 1;
+        if (V == 8 && e + 8 <= n)
+          for (int i = 0; i < 4; ++i) mask[e + 4 + i] = (m1 >> (8 * i)) & 1;
+      }
+    }
   }
 }
 
 // ================================================================================================
 // real INT4 (a15) and the export packer
 // ================================================================================================
+// quantise one element to its biased nibble (q + 8); arithmetic in the storage dtype like the reference
 template <int DT>
+__device__ __forceinline__ uint32_t int4_nibble(float v, float s, int rounding) {
+  float t = round_to_dtype<DT>(v * s);
+  if (rounding == MOQ_ROUND_HALF_EVEN) {
+    // qtensor/int4_tensor.py:72-76: round() (half-even), clamp [-8, 7], + 8
+    float r = __builtin_rintf(t);
+    r = __builtin_fminf(__builtin_fmaxf(r, -8.0f), 7.0f);
+    return (uint32_t)(int)(r + 8.0f) & 0xFu;
+  }
+  // tensor_quant_gpu.cu:322-333: clamp first, roundf(v + 8) (half away), in the storage dtype
+  t = __builtin_fminf(__builtin_fmaxf(t, -8.0f), 7.0f);
+  t = round_to_dtype<DT>(t + 8.0f);
+  return (uint32_t)(int)__builtin_roundf(t) & 0xFu;
+}
+// FAST layout (host-checked): x 16-byte aligned, g % kVec == 0, n % kVec == 0, out 4-byte aligned: a packet has ONE
+// scale and becomes one 4-byte (2-byte for f32) store; chunk skeleton with all loads in flight.
+template <int DT, bool FASTL>
 __global__ __launch_bounds__(kBlock) void int4_pack_kernel(const void* __restrict__ x,
                                                            const void* __restrict__ scales,
                                                            uint8_t* __restrict__ out, int64_t n, int g,
-                                                           int rounding) {
+                                                           int g_shift, int rounding) {
   constexpr int V = Elem<DT>::kVec;
-  const bool fast = al16(x) && (g % V) == 0 && (reinterpret_cast<uintptr_t>(out) & 3u) == 0 && (n % V) == 0;
-  const int64_t n_packets = (n + V - 1) / V;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    float v[8];
-    if (fast) unpack<DT>(load16(reinterpret_cast<const char*>(x) + p * 16), v);
-    else
-      for (int i = 0; i < V; ++i) v[i] = e + i < n ? load1<DT>(x, e + i) : 0.0f;
-    uint32_t q[8];
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  GroupIndex gi;
+  gi.g = (uint32_t)g;
+  gi.shift = g_shift;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if constexpr (FASTL) {
+      gi.seek(e0);
+      Pack16 in[P];
+      float sc[P];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const float s = load1<DT>(scales, (e + i < n ? e + i : e) / g);
-      float t = round_to_dtype<DT>(v[i] * s);  // arithmetic in the storage dtype, like the reference
-      if (rounding == MOQ_ROUND_HALF_EVEN) {
-        // qtensor/int4_tensor.py:72-76: round() (half-even), clamp [-8, 7], + 8
-        float r = __builtin_rintf(t);
-        r = __builtin_fminf(__builtin_fmaxf(r, -8.0f), 7.0f);
-        q[i] = (uint32_t)(int)(r + 8.0f) & 0xFu;
-      } else {
-        // tensor_quant_gpu.cu:322-333: clamp first, roundf(v + 8) (half away), in the storage dtype
-        t = __builtin_fminf(__builtin_fmaxf(t, -8.0f), 7.0f);
-        t = round_to_dtype<DT>(t + 8.0f);
-        q[i] = (uint32_t)(int)__builtin_roundf(t) & 0xFu;
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e < n) {
+          in[u] = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
+          sc[u] = load1<DT>(scales, gi.at((uint32_t)packet_off<DT>(u)));
+        }
       }
-    }
-    if (fast) {
-      if constexpr (V == 8) {
-        const uint32_t wv = ((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8) |
-                            (((q[4] << 4) | q[5]) << 16) | (((q[6] << 4) | q[7]) << 24);
-        *reinterpret_cast<uint32_t*>(out + p * 4) = wv;
-      } else {
-        const uint16_t hv = (uint16_t)(((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8));
-        *reinterpret_cast<uint16_t*>(out + p * 2) = hv;
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e >= n) continue;
+        float v[8];
+        unpack<DT>(in[u], v);
+        uint32_t q[8];
+#pragma unroll
+        for (int i = 0; i < V; ++i) q[i] = int4_nibble<DT>(v[i], sc[u], rounding);
+        if constexpr (V == 8) {
+          const uint32_t wv = ((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8) |
+                              (((q[4] << 4) | q[5]) << 16) | (((q[6] << 4) | q[7]) << 24);
+          store4_nt(out + e / 2, wv);
+        } else {
+          *reinterpret_cast<uint16_t*>(out + e / 2) = (uint16_t)(((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8));
+        }
       }
     } else {
-      for (int i = 0; i + 1 < V; i += 2)
-        if (e + i + 1 < n) out[(e + i) / 2] = (uint8_t)((q[i] << 4) | q[i + 1]);
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        uint32_t q[8];
+        for (int i = 0; i < V; ++i)
+          q[i] = e + i < n ? int4_nibble<DT>(load1<DT>(x, e + i), load1<DT>(scales, (e + i) / g), rounding) : 8u;
+        for (int i = 0; i + 1 < V; i += 2)
+          if (e + i + 1 < n) out[(e + i) / 2] = (uint8_t)((q[i] << 4) | q[i + 1]);
+      }
     }
   }
 }
-template <int DT>
+// 4 bytes -> 8 elements per lane.  FAST layout (host-checked): q 4-byte aligned, n_bytes % 4 == 0, g % 8 == 0,
+// out 16-byte aligned, 16-bit dtype: one scale and one shared exact division per packet.
+template <int DT, bool FASTL>
 __global__ __launch_bounds__(kBlock) void int4_unpack_kernel(const uint8_t* __restrict__ q,
                                                              const void* __restrict__ scales,
                                                              void* __restrict__ out, int64_t n_bytes,
-                                                             int g) {
-  // 4 bytes -> 8 elements per lane
-  const int64_t n_words = (n_bytes + 3) / 4;
-  const bool fast = (reinterpret_cast<uintptr_t>(q) & 3u) == 0 && (g % 8) == 0 && (n_bytes % 4) == 0 &&
-                    al16(out) && DT != MOQ_F32;
-  for (int64_t wi = (int64_t)blockIdx.x * kBlock + threadIdx.x; wi < n_words;
-       wi += (int64_t)gridDim.x * kBlock) {
-    float v[8];
+                                                             int g, int g_shift) {
+  if constexpr (FASTL && DT != MOQ_F32) {
+    constexpr int P = 4;
+    const int64_t n = 2 * n_bytes;  // elements
+    const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+    GroupIndex gi;
+    gi.g = (uint32_t)g;
+    gi.shift = g_shift;
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+      const int64_t e0 = c * MOQ_MT_CHUNK;
+      gi.seek(e0);
+      uint32_t wv[P];
+      float sc[P];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t bi = wi * 4 + b;
-      const uint32_t byte = bi < n_bytes ? q[bi] : 0x88u;
-      const float s = load1<DT>(scales, (bi < n_bytes ? 2 * bi : 0) / g);
-      // tensor_quant_gpu.cu:275-281: (nibble - 8) / scale in the scale dtype
-      v[2 * b] = (float)((int)(byte >> 4) - 8) / s;
-      v[2 * b + 1] = (float)((int)(byte & 0xFu) - 8) / s;
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e < n) {
+          wv[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q + e / 2));
+          sc[u] = load1<DT>(scales, gi.at((uint32_t)packet_off<DT>(u)));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e >= n) continue;
+        float v[8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const uint32_t byte = (wv[u] >> (8 * b)) & 0xFFu;
+          // tensor_quant_gpu.cu:275-281: (nibble - 8) / scale in the scale dtype
+          v[2 * b] = (float)((int)(byte >> 4) - 8) / sc[u];
+          v[2 * b + 1] = (float)((int)(byte & 0xFu) - 8) / sc[u];
+        }
+        store16_nt(reinterpret_cast<char*>(out) + e * 2, pack<DT>(v));
+      }
     }
-    if (fast) {
-      if constexpr (DT != MOQ_F32) store16(reinterpret_cast<char*>(out) + wi * 16, pack<DT>(v));
-    } else {
-      for (int i = 0; i < 8; ++i)
-        if (wi * 8 + i < 2 * n_bytes) store1<DT>(out, wi * 8 + i, v[i]);
+  } else {
+    const int64_t n_words = (n_bytes + 3) / 4;
+    for (int64_t wi = (int64_t)blockIdx.x * kBlock + threadIdx.x; wi < n_words;
+         wi += (int64_t)gridDim.x * kBlock) {
+      for (int b = 0; b < 4; ++b) {
+        const int64_t bi = wi * 4 + b;
+        if (bi >= n_bytes) break;
+        const uint32_t byte = q[bi];
+        const float s = load1<DT>(scales, (2 * bi) / g);
+        store1<DT>(out, 2 * bi, (float)((int)(byte >> 4) - 8) / s);
+        store1<DT>(out, 2 * bi + 1, (float)((int)(byte & 0xFu) - 8) / s);
+      }
     }
   }
 }
 // export packer: a lane owns 8 (4 for f32) adjacent columns of a row PAIR (2i, 2i+1): two 16-byte loads,
 // one 8-byte (4-byte) store; rows of the pair are cols*elem bytes apart so both loads are fully coalesced.
-template <int DT>
+// grid.x = row-pair groups (kExportPairs pairs per workgroup: 2 * kExportPairs loads in flight per lane),
+// grid.y = column tiles of kBlock packets.  FAST layout (host-checked): 16-byte aligned rows, g % kVec == 0.
+constexpr int kExportPairs = 2;
+template <int DT, bool FASTL>
 __global__ __launch_bounds__(kBlock) void int4_export_kernel(const void* __restrict__ w,
                                                              const float* __restrict__ wsf,
                                                              uint8_t* __restrict__ out, int64_t rows,
-                                                             int64_t cols, int g) {
+                                                             int64_t cols, int g, int g_shift) {
   constexpr int V = Elem<DT>::kVec;
   const int64_t spr = cols / g;
-  const int64_t ppr = (cols + V - 1) / V;  // packets per row
-  const int64_t n_items = (rows / 2) * ppr;
-  const bool fast = al16(w) && (cols % V) == 0 && (g % V) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
-  for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items;
-       it += (int64_t)gridDim.x * kBlock) {
-    const int64_t r2 = it / ppr, c0 = (it % ppr) * V;
-    float a[8], b[8];
-    if (fast) {
-      unpack<DT>(load16(reinterpret_cast<const char*>(w) + ((2 * r2) * cols + c0) * (16 / V)), a);
-      unpack<DT>(load16(reinterpret_cast<const char*>(w) + ((2 * r2 + 1) * cols + c0) * (16 / V)), b);
-    } else {
-      for (int i = 0; i < V; ++i) {
-        a[i] = c0 + i < cols ? load1<DT>(w, (2 * r2) * cols + c0 + i) : 0.0f;
-        b[i] = c0 + i < cols ? load1<DT>(w, (2 * r2 + 1) * cols + c0 + i) : 0.0f;
+  if constexpr (FASTL) {
+    const int64_t c0 = ((int64_t)blockIdx.y * kBlock + threadIdx.x) * V;
+    if (c0 >= cols) return;
+    const int64_t sidx = g_shift >= 0 ? (c0 >> g_shift) : (c0 / g);
+    Pack16 pa[kExportPairs], pb[kExportPairs];
+    float sa[kExportPairs], sb[kExportPairs];
+#pragma unroll
+    for (int k = 0; k < kExportPairs; ++k) {
+      const int64_t r2 = (int64_t)blockIdx.x * kExportPairs + k;
+      if (2 * r2 + 1 < rows) {
+        pa[k] = load16_nt(reinterpret_cast<const char*>(w) + ((2 * r2) * cols + c0) * (16 / V));
+        pb[k] = load16_nt(reinterpret_cast<const char*>(w) + ((2 * r2 + 1) * cols + c0) * (16 / V));
+        sa[k] = wsf[(2 * r2) * spr + sidx];
+        sb[k] = wsf[(2 * r2 + 1) * spr + sidx];
       }
     }
-    uint32_t byte[8];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int64_t c = c0 + i < cols ? c0 + i : cols - 1;
+    for (int k = 0; k < kExportPairs; ++k) {
+      const int64_t r2 = (int64_t)blockIdx.x * kExportPairs + k;
+      if (2 * r2 + 1 >= rows) continue;
+      float a[8], b[8];
+      unpack<DT>(pa[k], a);
+      unpack<DT>(pb[k], b);
+      // quant_utils.py:800-805: (w / wsf).round().clamp(-8, 7) with fp32 division; the 8 quotients of a row share
+      // their denominator (exact shared division, moq_common.h)
+      const SharedDiv da = make_shared_div(sa[k]), db = make_shared_div(sb[k]);
+      // the shared division is exact for |numerator| <= 2^16; anything larger (or inf / NaN) takes the IEEE divide
+      bool big = false;
+#pragma unroll
+      for (int i = 0; i < V; ++i)
+        big |= !(__builtin_fabsf(a[i]) <= 65536.0f) || !(__builtin_fabsf(b[i]) <= 65536.0f);
+      uint32_t byte[8];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float qa, qb;
+        if (big) {
+          qa = __builtin_rintf(a[i] / sa[k]);
+          qb = __builtin_rintf(b[i] / sb[k]);
+        } else {
+          qa = __builtin_rintf(shared_div(a[i], da));
+          qb = __builtin_rintf(shared_div(b[i], db));
+        }
+        qa = __builtin_fminf(__builtin_fmaxf(qa, -8.0f), 7.0f);
+        qb = __builtin_fminf(__builtin_fmaxf(qb, -8.0f), 7.0f);
+        byte[i] = ((uint32_t)(int)qa & 0xFu) | (((uint32_t)(int)qb & 0xFu) << 4);
+      }
+      uint8_t* dst = out + r2 * cols + c0;
+      if constexpr (V == 8) {
+        store8_nt(dst, byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24),
+                  byte[4] | (byte[5] << 8) | (byte[6] << 16) | (byte[7] << 24));
+      } else {
+        store4_nt(dst, byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24));
+      }
+    }
+  } else {
+    const int64_t n_items = (rows / 2) * cols;
+    for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < n_items; it += (int64_t)gridDim.x * kBlock) {
+      const int64_t r2 = it / cols, c = it % cols;
+      const float a = load1<DT>(w, (2 * r2) * cols + c), b = load1<DT>(w, (2 * r2 + 1) * cols + c);
       const float sa = wsf[(2 * r2) * spr + c / g], sb = wsf[(2 * r2 + 1) * spr + c / g];
-      // quant_utils.py:800-805: (w / wsf).round().clamp(-8, 7) with fp32 division
-      float qa = __builtin_rintf(a[i] / sa), qb = __builtin_rintf(b[i] / sb);
+      float qa = __builtin_rintf(a / sa), qb = __builtin_rintf(b / sb);
       qa = __builtin_fminf(__builtin_fmaxf(qa, -8.0f), 7.0f);
       qb = __builtin_fminf(__builtin_fmaxf(qb, -8.0f), 7.0f);
-      byte[i] = ((uint32_t)(int)qa & 0xFu) | (((uint32_t)(int)qb & 0xFu) << 4);
-    }
-    uint8_t* dst = out + r2 * cols + c0;
-    if (fast) {
-      if constexpr (V == 8) {
-        *reinterpret_cast<uint2*>(dst) = make_uint2(byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24),
-                                                    byte[4] | (byte[5] << 8) | (byte[6] << 16) | (byte[7] << 24));
-      } else {
-        *reinterpret_cast<uint32_t*>(dst) = byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24);
-      }
-    } else {
-      for (int i = 0; i < V; ++i)
-        if (c0 + i < cols) dst[i] = (uint8_t)byte[i];
+      out[r2 * cols + c] = (uint8_t)(((uint32_t)(int)qa & 0xFu) | (((uint32_t)(int)qb & 0xFu) << 4));
     }
   }
 }
@@ -388,61 +537,55 @@ __global__ __launch_bounds__(kBlock) void int4_export_kernel(const void* __restr
 // ================================================================================================
 // column scale fold (a11/a12 postprocess)
 // ================================================================================================
-template <int DT>
+// MODE 0: y = dtype(w * mul[c]);  MODE 1: y = dtype((w * mul[c]) / div[c])  (fp32 multiply, fp32 IEEE divide, one
+// rounding to the storage dtype: _apply_weight_pre_quant_scale, model_calib.py:1208-1216, and _update_pre_quant_scale
+// of the export resmooth step, export/quant_utils.py:1285-1296).  Chunk skeleton; the column of a packet comes from
+// one 64-bit division per chunk.  FAST layout (host-checked): 16-byte aligned w / y / mul / div, cols % kVec == 0.
+template <int DT, int MODE, bool FASTL>
 __global__ __launch_bounds__(kBlock) void scale_cols_kernel(const void* __restrict__ w,
-                                                            const float* __restrict__ s,
+                                                            const float* __restrict__ mul,
+                                                            const float* __restrict__ div,
                                                             void* __restrict__ y, int64_t rows,
                                                             int64_t cols) {
   constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
   const int64_t n = rows * cols;
-  const bool fast = al16(w) && al16(y) && (cols % V) == 0 && (reinterpret_cast<uintptr_t>(s) & 15u) == 0;
-  const int64_t n_packets = (n + V - 1) / V;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    float v[8];
-    if (fast) {
-      unpack<DT>(load16(reinterpret_cast<const char*>(w) + p * 16), v);
-      const int64_t c = e % cols;
-      const float4 s0 = *reinterpret_cast<const float4*>(s + c);
-      v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
-      if constexpr (V == 8) {
-        const float4 s1 = *reinterpret_cast<const float4*>(s + c + 4);
-        v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
-      }
-      store16(reinterpret_cast<char*>(y) + p * 16, pack<DT>(v));
-    } else {
-      for (int i = 0; i < V; ++i)
-        if (e + i < n) store1<DT>(y, e + i, load1<DT>(w, e + i) * s[(e + i) % cols]);
-    }
-  }
-}
-
-// y[r, c] = dtype((w[r, c] * mul[c]) / div[c]): _update_pre_quant_scale of the export resmooth step
-// (export/quant_utils.py:1285-1296) -- fp32 multiply, fp32 IEEE divide, one rounding to the storage dtype.
-template <int DT>
-__global__ __launch_bounds__(kBlock) void rescale_cols_kernel(const void* __restrict__ w,
-                                                              const float* __restrict__ mul,
-                                                              const float* __restrict__ div,
-                                                              void* __restrict__ y, int64_t rows,
-                                                              int64_t cols) {
-  constexpr int V = Elem<DT>::kVec;
-  const int64_t n = rows * cols;
-  const bool fast = al16(w) && al16(y) && (cols % V) == 0 && al16(mul) && al16(div);
-  const int64_t n_packets = (n + V - 1) / V;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    if (fast) {
-      float v[8];
-      unpack<DT>(load16(reinterpret_cast<const char*>(w) + p * 16), v);
-      const int64_t c = e % cols;
+  if constexpr (FASTL) {
+    const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+      const int64_t e0 = c * MOQ_MT_CHUNK;
+      const int64_t col0 = e0 % cols;  // uniform
+      Pack16 in[P];
 #pragma unroll
-      for (int i = 0; i < V; ++i) v[i] = (v[i] * mul[c + i]) / div[c + i];
-      store16(reinterpret_cast<char*>(y) + p * 16, pack<DT>(v));
-    } else {
-      for (int i = 0; i < V; ++i)
-        if (e + i < n) store1<DT>(y, e + i, (load1<DT>(w, e + i) * mul[(e + i) % cols]) / div[(e + i) % cols]);
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e < n) in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e >= n) continue;
+        int64_t col = col0 + packet_off<DT>(u);
+        if (col >= cols) col %= cols;
+        float v[8];
+        unpack<DT>(in[u], v);
+#pragma unroll
+        for (int i = 0; i < V; i += 4) {
+          const float4 m = *reinterpret_cast<const float4*>(mul + col + i);
+          v[i] *= m.x; v[i + 1] *= m.y; v[i + 2] *= m.z; v[i + 3] *= m.w;
+          if constexpr (MODE == 1) {
+            const float4 d = *reinterpret_cast<const float4*>(div + col + i);
+            v[i] /= d.x; v[i + 1] /= d.y; v[i + 2] /= d.z; v[i + 3] /= d.w;
+          }
+        }
+        store16_nt(reinterpret_cast<char*>(y) + e * (16 / V), pack<DT>(v));
+      }
+    }
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+      float v = load1<DT>(w, e) * mul[e % cols];
+      if constexpr (MODE == 1) v = v / div[e % cols];
+      store1<DT>(y, e, v);
     }
   }
 }
@@ -505,15 +648,21 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;
   const int lpg = block / vec;
   if (aligned && cols % block == 0 && block % vec == 0 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
-    const int64_t n_packets = n / vec;
-    const int grid = stream_grid(kBlock, n_packets);
-#define MOQ_MX_CASE(L) \
-  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_kernel<DT, L>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, n_packets, fmt)); break;
+    const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+#define MOQ_MX_LAUNCH(L, F) \
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, n, fmt))
+#define MOQ_MX_CASE(L)                                                  \
+  case L:                                                               \
+    if (L <= 8 && fmt == MOQ_E2M1) { MOQ_MX_LAUNCH(L, (L <= 8 ? MOQ_E2M1 : -1)); }       \
+    else if (L <= 8 && fmt == MOQ_E4M3) { MOQ_MX_LAUNCH(L, (L <= 8 ? MOQ_E4M3 : -1)); }  \
+    else { MOQ_MX_LAUNCH(L, -1); }                                      \
+    break;
     switch (lpg) {
       MOQ_MX_CASE(1) MOQ_MX_CASE(2) MOQ_MX_CASE(4) MOQ_MX_CASE(8) MOQ_MX_CASE(16) MOQ_MX_CASE(32) MOQ_MX_CASE(64)
       default: set_error("unreachable"); return MOQ_ERR_INVALID;
     }
 #undef MOQ_MX_CASE
+#undef MOQ_MX_LAUNCH
   } else {
     const int64_t nb = rows * ((cols + block - 1) / block);
     const int grid = stream_grid(kBlock, nb);
@@ -530,17 +679,24 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
     return MOQ_ERR_INVALID;
   }
   if (n == 0) return MOQ_OK;
-  const int vec = dt == MOQ_F32 ? 4 : 8;
-  // one workgroup per ~64 KiB of input keeps the LDS flush (bins atomics per workgroup) amortised
-  int64_t blocks = (n / vec + kBlock * 16 - 1) / (kBlock * 16);
-  if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
-  if (bins <= kHistMaxLdsBins) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, true>), dim3((int)blocks), dim3(kBlock),
-                                              (size_t)bins * 4, S(stream), x, n, counts, bins, max_edge,
-                                              skip_zeros));
+  // <= 512 workgroups: the flush costs `bins` 64-bit global atomics per workgroup
+  int64_t blocks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  if (blocks > 512) blocks = 512;
+  if (bins < kHistMaxLdsBins) {
+    int rshift = 0;
+    while (rshift < 3 && ((int64_t)(bins + 1) << (rshift + 1)) <= kHistMaxLdsBins + 8) ++rshift;
+    const size_t lds = ((size_t)(bins + 1) << rshift) * 4;
+    // the shared-denominator division is exact for numerators up to 2^16 and denominators in [2^-60, 2^60]
+    const bool shared = max_edge >= 0x1p-60f && max_edge <= 0x1p60f && max_edge * (float)bins <= 65536.0f;
+    if (shared) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, true>), dim3((int)blocks), dim3(kBlock), lds, S(stream),
+                                                x, n, counts, bins, max_edge, skip_zeros, rshift));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, false>), dim3((int)blocks), dim3(kBlock), lds, S(stream),
+                                                x, n, counts, bins, max_edge, skip_zeros, rshift));
+    }
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, false>), dim3((int)blocks), dim3(kBlock), 0,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_global_kernel<DT>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
                                               S(stream), x, n, counts, bins, max_edge, skip_zeros));
   }
   return check_launch("moq_hist_abs");
@@ -558,9 +714,8 @@ extern "C" int moq_mask_2to4(const void* w, int64_t rows, int64_t cols, int dt, 
   }
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
-  const int vec = dt == MOQ_F32 ? 4 : 8;
-  const int grid = stream_grid(kBlock, (n + vec - 1) / vec);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), w,
                                             mask, n));
   return check_launch("moq_mask_2to4");
 }
@@ -581,9 +736,17 @@ extern "C" int moq_int4_pack(const void* x, const void* scales, uint8_t* out, in
   }
   if (n == 0) return MOQ_OK;
   const int vec = dt == MOQ_F32 ? 4 : 8;
-  const int grid = stream_grid(kBlock, (n + vec - 1) / vec);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), x,
-                                            scales, out, n, g, rounding));
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  const bool fastl = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (g % vec) == 0 && (n % vec) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
+  const int gs = log2_or_neg(g);
+  if (fastl) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              x, scales, out, n, g, gs, rounding));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              x, scales, out, n, g, gs, rounding));
+  }
   return check_launch("moq_int4_pack");
 }
 
@@ -594,9 +757,18 @@ extern "C" int moq_int4_unpack(const uint8_t* q, const void* scales, void* out, 
     return MOQ_ERR_INVALID;
   }
   if (n_bytes == 0) return MOQ_OK;
-  const int grid = stream_grid(kBlock, (n_bytes + 3) / 4);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_unpack_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
-                                            q, scales, out, n_bytes, g));
+  const bool fastl = dt != MOQ_F32 && (reinterpret_cast<uintptr_t>(q) & 3u) == 0 && (g % 8) == 0 &&
+                     (n_bytes % 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const int gs = log2_or_neg(g);
+  if (fastl) {
+    const int grid = copy_grid((2 * n_bytes + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              q, scales, out, n_bytes, g, gs));
+  } else {
+    const int grid = stream_grid(kBlock, (n_bytes + 3) / 4);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_unpack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              q, scales, out, n_bytes, g, gs));
+  }
   return check_launch("moq_int4_unpack");
 }
 
@@ -612,9 +784,19 @@ extern "C" int moq_int4_pack_export(const void* w, const float* wsf, uint8_t* ou
   }
   if (rows * cols == 0) return MOQ_OK;
   const int vec = dt == MOQ_F32 ? 4 : 8;
-  const int grid = stream_grid(kBlock, (rows / 2) * ((cols + vec - 1) / vec));
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_export_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
-                                            w, wsf, out, rows, cols, g));
+  const bool fastl = (reinterpret_cast<uintptr_t>(w) & 15u) == 0 && (cols % vec) == 0 && (g % vec) == 0 &&
+                     (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+  const int gs = log2_or_neg(g);
+  const int64_t col_tiles = (cols / vec + kBlock - 1) / kBlock;
+  if (fastl && col_tiles <= 65535) {
+    dim3 grid((unsigned)((rows / 2 + kExportPairs - 1) / kExportPairs), (unsigned)col_tiles);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_export_kernel<DT, true>), grid, dim3(kBlock), 0, S(stream),
+                                              w, wsf, out, rows, cols, g, gs));
+  } else {
+    const int grid = stream_grid(kBlock, (rows / 2) * cols);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_export_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              w, wsf, out, rows, cols, g, gs));
+  }
   return check_launch("moq_int4_pack_export");
 }
 
@@ -627,9 +809,15 @@ extern "C" int moq_scale_cols(const void* w, const float* s, void* y, int64_t ro
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
   const int vec = dt == MOQ_F32 ? 4 : 8;
-  const int grid = stream_grid(kBlock, (n + vec - 1) / vec);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
-                                            s, y, rows, cols));
+  const bool fastl = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(s)) & 15u) == 0 &&
+                     (cols % vec) == 0;
+  if (fastl) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 0, true>), dim3(copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK)),
+                                              dim3(kBlock), 0, S(stream), w, s, (const float*)nullptr, y, rows, cols));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 0, false>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
+                                              S(stream), w, s, (const float*)nullptr, y, rows, cols));
+  }
   return check_launch("moq_scale_cols");
 }
 
@@ -662,8 +850,14 @@ extern "C" int moq_rescale_cols(const void* w, const float* mul, const float* di
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
   const int vec = dt == MOQ_F32 ? 4 : 8;
-  const int grid = stream_grid(kBlock, (n + vec - 1) / vec);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((rescale_cols_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
-                                            mul, div, y, rows, cols));
+  const bool fastl = ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(mul) |
+                       reinterpret_cast<uintptr_t>(div)) & 15u) == 0 && (cols % vec) == 0;
+  if (fastl) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 1, true>), dim3(copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK)),
+                                              dim3(kBlock), 0, S(stream), w, mul, div, y, rows, cols));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 1, false>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
+                                              S(stream), w, mul, div, y, rows, cols));
+  }
   return check_launch("moq_rescale_cols");
 }

@@ -1,0 +1,393 @@
+// moq_qtensor.hip -- real (storage) quantisation of the path's formats other than INT4 (a15):
+//   FP8QTensor.quantize / dequantize   (quantization/qtensor/fp8_tensor.py:40-151; also export's to_quantized_weight)
+//   MXFP4QTensor.quantize / dequantize (quantization/qtensor/mxfp4_tensor.py:37-144)
+// HBM-bound streaming kernels on the chunk skeleton (moq_chunk.h): 16-byte lane loads, all packets of a chunk in
+// flight, non-temporal loads / stores.  Algorithmic bytes per element (bf16): FP8 pack 2 + 1, unpack 1 + 2;
+// MXFP4 pack 2 + 0.5 + 1/32, unpack 0.5 + 1/32 + 2.
+#include "moq_common.h"
+#include "moq_chunk.h"
+
+namespace moq {
+
+__device__ __forceinline__ void q_store8_nt(void* p, uint32_t a, uint32_t b) {
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 v = {a, b};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+}
+
+// torch's float -> float8_e4m3fn cast: RNE, NOT saturating: |v| > 464 (the midpoint above 448) and NaN give NaN
+// (byte 0x7F | sign).  The hardware converter is fed values clamped to +-448, overflow is patched afterwards.
+__device__ __forceinline__ uint32_t e4m3fn_bytes2(float a, float b) {
+  const float ca = __builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f);
+  const float cb = __builtin_fminf(__builtin_fmaxf(b, -448.0f), 448.0f);
+  uint32_t p = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(ca, cb, 0, false) & 0xFFFFu;
+  const uint32_t na = ((__float_as_uint(a) >> 31) << 7) | 0x7Fu, nb = ((__float_as_uint(b) >> 31) << 7) | 0x7Fu;
+  if (!(__builtin_fabsf(a) <= 464.0f)) p = (p & 0xFF00u) | na;
+  if (!(__builtin_fabsf(b) <= 464.0f)) p = (p & 0x00FFu) | (nb << 8);
+  return p;
+}
+
+// ---------------------------------------------------------------- FP8 pack / unpack
+// scales have the storage dtype DT (the reference divides two tensors of the model dtype).  AXIS: one scale per
+// `inner` consecutive elements, index = (e / inner) % axis_size (per-channel rows, 1-D blocks); else one scale.
+template <int DT, bool AXIS>
+__global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict__ x,
+                                                          const void* __restrict__ scales,
+                                                          uint8_t* __restrict__ out, int64_t n, int64_t axis_size,
+                                                          int64_t inner, int inner_shift, int wrap) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  GroupIndex gi;
+  gi.g = (uint32_t)inner;
+  gi.shift = inner_shift;
+  const float s0 = AXIS ? 1.0f : load1<DT>(scales, 0);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if (AXIS) gi.seek(e0);
+    Pack16 in[P];
+    float sc[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      sc[u] = s0;
+      if (e < n) {
+        in[u] = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
+        if (AXIS) {
+          int64_t row = gi.at((uint32_t)packet_off<DT>(u));
+          if (wrap) row %= axis_size;
+          sc[u] = load1<DT>(scales, row);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      if (e >= n) continue;
+      float v[8];
+      unpack<DT>(in[u], v);
+      uint32_t b[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < V; i += 2) {
+        const float qa = round_to_dtype<DT>(v[i] / sc[u]), qb = round_to_dtype<DT>(v[i + 1] / sc[u]);
+        b[i / 2] = e4m3fn_bytes2(qa, qb);
+      }
+      if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+      else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
+    }
+  }
+}
+template <int DT, bool AXIS>
+__global__ __launch_bounds__(kBlock) void fp8_unpack_kernel(const uint8_t* __restrict__ q,
+                                                            const void* __restrict__ scales,
+                                                            void* __restrict__ out, int64_t n, int64_t axis_size,
+                                                            int64_t inner, int inner_shift, int wrap) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  GroupIndex gi;
+  gi.g = (uint32_t)inner;
+  gi.shift = inner_shift;
+  const float s0 = AXIS ? 1.0f : load1<DT>(scales, 0);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    if (AXIS) gi.seek(e0);
+    uint32_t in[P][2];
+    float sc[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      sc[u] = s0;
+      if (e < n) {
+        if constexpr (V == 8) {
+          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(q + e));
+          in[u][0] = t.x;
+          in[u][1] = t.y;
+        } else {
+          in[u][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q + e));
+          in[u][1] = 0;
+        }
+        if (AXIS) {
+          int64_t row = gi.at((uint32_t)packet_off<DT>(u));
+          if (wrap) row %= axis_size;
+          sc[u] = load1<DT>(scales, row);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      if (e >= n) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int word = (int)in[u][i / 4];
+        float f;
+        switch (i & 3) {  // byte select must be an immediate
+          case 0: f = __builtin_amdgcn_cvt_f32_fp8(word, 0); break;
+          case 1: f = __builtin_amdgcn_cvt_f32_fp8(word, 1); break;
+          case 2: f = __builtin_amdgcn_cvt_f32_fp8(word, 2); break;
+          default: f = __builtin_amdgcn_cvt_f32_fp8(word, 3); break;
+        }
+        v[i] = f * sc[u];  // q.to(dtype) is exact (3 mantissa bits), product rounded once to dtype by pack()
+      }
+      store16_nt(reinterpret_cast<char*>(out) + e * (16 / V), pack<DT>(v));
+    }
+  }
+}
+
+// ---------------------------------------------------------------- MXFP4 pack / unpack
+// e = ceil(max(log2(descale), -127)) with torch's fp32 log2: the exact exponent / mantissa split, then the fp32
+// addition k + log2(1 + f) decides whether a mantissa a few ulps above a power of two still rounds to the integer k.
+__device__ __forceinline__ int mxfp4_exponent(float amax) {
+  const float descale = amax / 6.0f;
+  if (!(descale > 0.0f)) return -127;  // log2(0) = -inf -> max(-inf, -127)
+  const uint32_t u = __float_as_uint(descale), ef = (u >> 23) & 0xFFu, mf = u & 0x7FFFFFu;
+  if (ef == 0) return mf > 0x400000u ? -126 : -127;  // subnormal descale: 2^-127 is mf == 0x400000
+  const int k = (int)ef - 127;
+  if (mf == 0) return k;
+  const float t = (float)k + (float)mf * 0x1p-23f * 1.44269504f;
+  const int e = t > (float)k ? k + 1 : k;
+  return e < -127 ? -127 : e;
+}
+__device__ __forceinline__ float pow2i(int e) {  // 2^e for e in [-127, 127]
+  return e >= -126 ? __uint_as_float((uint32_t)(e + 127) << 23) : __uint_as_float(0x00400000u);
+}
+__device__ __forceinline__ uint32_t mxfp4_nibble(float v) {
+  const float a = __builtin_fabsf(v);
+  // strict > against the 7 bounds (ties round down); sign_bit = (2 - sign(v)) // 2: zero gets 1
+  const uint32_t ord = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f);
+  return ((v > 0.0f) ? 0u : 8u) + ord;
+}
+// FAST layout (host-checked): n % block == 0, block % kVec == 0, LPG = block / kVec a power of two <= 64.
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void mxfp4_pack_kernel(const void* __restrict__ x,
+                                                            uint8_t* __restrict__ packed,
+                                                            uint8_t* __restrict__ e8m0, int64_t n,
+                                                            int block_shift) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  const int lane = threadIdx.x & 63;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    Pack16 in[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      if (e < n) in[u] = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
+      else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      const float amax = __uint_as_float(group_max_u32<LPG>(pack_absmax<DT>(in[u])));  // amax in fp32 (:70)
+      const int ex = mxfp4_exponent(amax);
+      const float inv = pow2i(-ex);  // x / 2^e == x * 2^-e exactly (power of two; same rounding when it underflows)
+      float v[8];
+      unpack<DT>(in[u], v);
+      uint32_t word = 0;
+#pragma unroll
+      for (int i = 0; i < V; i += 2) {
+        const uint32_t lo = mxfp4_nibble(v[i] * inv), hi = mxfp4_nibble(v[i + 1] * inv);
+        word |= ((hi << 4) + lo) << (8 * (i / 2));
+      }
+      if (e < n) {
+        if constexpr (V == 8) __builtin_nontemporal_store(word, reinterpret_cast<uint32_t*>(packed + e / 2));
+        else *reinterpret_cast<uint16_t*>(packed + e / 2) = (uint16_t)word;
+        if ((lane & (LPG - 1)) == 0) e8m0[e >> block_shift] = (uint8_t)(ex + 127);
+      }
+    }
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mxfp4_generic_pack_kernel(const void* __restrict__ x,
+                                                                    uint8_t* __restrict__ packed,
+                                                                    uint8_t* __restrict__ e8m0,
+                                                                    int64_t n_blocks, int block) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n_blocks;
+       b += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t am = 0;
+    for (int j = 0; j < block; ++j) {
+      const uint32_t a = absbits(load1<DT>(x, b * block + j));
+      am = a > am ? a : am;
+    }
+    const int ex = mxfp4_exponent(__uint_as_float(am));
+    const float inv = pow2i(-ex);
+    e8m0[b] = (uint8_t)(ex + 127);
+    for (int j = 0; j < block; j += 2) {
+      const uint32_t lo = mxfp4_nibble(load1<DT>(x, b * block + j) * inv);
+      const uint32_t hi = mxfp4_nibble(load1<DT>(x, b * block + j + 1) * inv);
+      packed[(b * block + j) / 2] = (uint8_t)((hi << 4) + lo);
+    }
+  }
+}
+// 4 bytes -> 8 elements per lane (16-bit dtypes); generic per-element path otherwise
+template <int DT, bool FASTL>
+__global__ __launch_bounds__(kBlock) void mxfp4_unpack_kernel(const uint8_t* __restrict__ packed,
+                                                              const uint8_t* __restrict__ e8m0,
+                                                              void* __restrict__ out, int64_t n, int block,
+                                                              int block_shift) {
+  const float tbl[8] = {0.0f, 0.5f, 1.0f, 1.5f, 2.0f, 3.0f, 4.0f, 6.0f};
+  if constexpr (FASTL && DT != MOQ_F32) {
+    constexpr int P = 4;
+    const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+      const int64_t e0 = c * MOQ_MT_CHUNK;
+      uint32_t wv[P];
+      uint32_t sb[P];
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e < n) {
+          wv[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(packed + e / 2));
+          sb[u] = e8m0[e >> block_shift];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (e >= n) continue;
+        const float sc = pow2i((int)sb[u] - 127);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t nib = (wv[u] >> (4 * i)) & 0xFu;  // byte j: low nibble = even element, high = odd
+          // E2M1 magnitude {0, .5, 1, 1.5, 2, 3, 4, 6} = exponent field (m >> 1), mantissa bit (m & 1)
+          const uint32_t m = nib & 7u;
+          const float mag = m < 2 ? 0.5f * (float)m : __uint_as_float(((m >> 1) + 126u) << 23 | (m & 1u) << 22);
+          v[i] = ((nib & 8u) ? -mag : mag) * sc;
+        }
+        store16_nt(reinterpret_cast<char*>(out) + e * 2, pack<DT>(v));
+      }
+    }
+  } else {
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+      const uint8_t byte = packed[e / 2];
+      const uint32_t nib = (e & 1) ? (byte >> 4) : (byte & 0xFu);
+      const float sc = pow2i((int)e8m0[e / block] - 127);
+      const float mag = tbl[nib & 7u];
+      store1<DT>(out, e, ((nib & 8u) ? -mag : mag) * sc);
+    }
+  }
+}
+
+}  // namespace moq
+
+using namespace moq;
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static int fp8_args_ok(const char* who, const void* a, const void* b, const void* c, int64_t n, int amax_mode,
+                       int64_t axis_size, int64_t inner) {
+  if (n < 0 || (n > 0 && (a == nullptr || b == nullptr || c == nullptr))) {
+    set_error("%s: null pointer or negative size", who);
+    return MOQ_ERR_INVALID;
+  }
+  if (amax_mode != MOQ_AMAX_SCALAR && amax_mode != MOQ_AMAX_AXIS) {
+    set_error("%s: unknown amax_mode %d", who, amax_mode);
+    return MOQ_ERR_INVALID;
+  }
+  if (amax_mode == MOQ_AMAX_AXIS && (axis_size <= 0 || inner <= 0)) {
+    set_error("%s: axis mode needs axis_size > 0 and inner > 0", who);
+    return MOQ_ERR_INVALID;
+  }
+  return MOQ_OK;
+}
+
+extern "C" int moq_fp8_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int dt, int amax_mode,
+                            int64_t axis_size, int64_t inner, void* stream) {
+  const int rc = fp8_args_ok("moq_fp8_pack", x, scales, out, n, amax_mode, axis_size, inner);
+  if (rc != MOQ_OK || n == 0) return rc;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) != 0 || n % vec != 0 ||
+      (amax_mode == MOQ_AMAX_AXIS && (inner % vec != 0 || inner >= (1LL << 31)))) {
+    set_error("moq_fp8_pack: needs 16-byte aligned x, 8-byte aligned out, n and inner multiples of %d", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  if (amax_mode == MOQ_AMAX_AXIS) {
+    const int wrap = n > axis_size * inner ? 1 : 0;
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+                                              scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+                                              scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
+  }
+  return check_launch("moq_fp8_pack");
+}
+
+extern "C" int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, int64_t n, int dt, int amax_mode,
+                              int64_t axis_size, int64_t inner, void* stream) {
+  const int rc = fp8_args_ok("moq_fp8_unpack", q, scales, out, n, amax_mode, axis_size, inner);
+  if (rc != MOQ_OK || n == 0) return rc;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(q) & 7u) != 0 || n % vec != 0 ||
+      (amax_mode == MOQ_AMAX_AXIS && (inner % vec != 0 || inner >= (1LL << 31)))) {
+    set_error("moq_fp8_unpack: needs 16-byte aligned out, 8-byte aligned q, n and inner multiples of %d", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  if (amax_mode == MOQ_AMAX_AXIS) {
+    const int wrap = n > axis_size * inner ? 1 : 0;
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), q,
+                                              scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), q,
+                                              scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
+  }
+  return check_launch("moq_fp8_unpack");
+}
+
+extern "C" int moq_mxfp4_pack(const void* x, uint8_t* packed, uint8_t* e8m0, int64_t n_blocks, int block, int dt,
+                              void* stream) {
+  if (n_blocks < 0 || block <= 0 || block % 2 != 0 ||
+      (n_blocks > 0 && (x == nullptr || packed == nullptr || e8m0 == nullptr))) {
+    set_error("moq_mxfp4_pack: bad arguments (block must be even)");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_blocks == 0) return MOQ_OK;
+  const int64_t n = n_blocks * block;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = block / vec;
+  const bool fast = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 &&
+                    block % vec == 0 && lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0;
+  if (fast) {
+    const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+    const int bs = log2_or_neg(block);
+#define MOQ_MXP_CASE(L) \
+  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_pack_kernel<DT, L>), dim3(grid), dim3(kBlock), 0, S(stream), x, packed, e8m0, n, bs)); break;
+    switch (lpg) {
+      MOQ_MXP_CASE(1) MOQ_MXP_CASE(2) MOQ_MXP_CASE(4) MOQ_MXP_CASE(8) MOQ_MXP_CASE(16) MOQ_MXP_CASE(32) MOQ_MXP_CASE(64)
+      default: set_error("unreachable"); return MOQ_ERR_INVALID;
+    }
+#undef MOQ_MXP_CASE
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_generic_pack_kernel<DT>), dim3(stream_grid(kBlock, n_blocks)),
+                                              dim3(kBlock), 0, S(stream), x, packed, e8m0, n_blocks, block));
+  }
+  return check_launch("moq_mxfp4_pack");
+}
+
+extern "C" int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void* out, int64_t n_blocks, int block,
+                                int dt, void* stream) {
+  if (n_blocks < 0 || block <= 0 || block % 2 != 0 ||
+      (n_blocks > 0 && (packed == nullptr || e8m0 == nullptr || out == nullptr))) {
+    set_error("moq_mxfp4_unpack: bad arguments (block must be even)");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_blocks == 0) return MOQ_OK;
+  const int64_t n = n_blocks * block;
+  const int bs = log2_or_neg(block);
+  const bool fast = dt != MOQ_F32 && bs >= 3 && (reinterpret_cast<uintptr_t>(packed) & 3u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  if (fast) {
+    const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                              packed, e8m0, out, n, block, bs));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_unpack_kernel<DT, false>), dim3(stream_grid(kBlock, n)),
+                                              dim3(kBlock), 0, S(stream), packed, e8m0, out, n, block, bs));
+  }
+  return check_launch("moq_mxfp4_unpack");
+}

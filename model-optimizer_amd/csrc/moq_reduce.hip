@@ -40,19 +40,19 @@ __global__ __launch_bounds__(kBlock) void amax_rows_kernel(const void* __restric
     const char* rp = base + row * inner * (16 / V);
     uint32_t acc = 0;
     int64_t p = p0 + lane;
-    // 4 independent 16-byte loads in flight per lane
-    for (; p + 3 * 64 < p1; p += 4 * 64) {
-      Pack16 a = load16(rp + p * 16), b = load16(rp + (p + 64) * 16), c = load16(rp + (p + 128) * 16),
-             d = load16(rp + (p + 192) * 16);
-      uint32_t m0 = pack_absmax<DT>(a), m1 = pack_absmax<DT>(b), m2 = pack_absmax<DT>(c),
-               m3 = pack_absmax<DT>(d);
-      m0 = m0 > m1 ? m0 : m1;
-      m2 = m2 > m3 ? m2 : m3;
-      m0 = m0 > m2 ? m0 : m2;
-      acc = acc > m0 ? acc : m0;
+    // 8 independent 16-byte loads in flight per lane, read-once stream (non-temporal)
+    for (; p + 7 * 64 < p1; p += 8 * 64) {
+      Pack16 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = load16_nt(rp + (p + u * 64) * 16);
+      uint32_t m[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m[u] = pack_absmax<DT>(q[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = acc > m[u] ? acc : m[u];
     }
     for (; p < p1; p += 64) {
-      uint32_t m = pack_absmax<DT>(load16(rp + p * 16));
+      uint32_t m = pack_absmax<DT>(load16_nt(rp + p * 16));
       acc = acc > m ? acc : m;
     }
     acc = group_max_u32<64>(acc);
@@ -61,48 +61,64 @@ __global__ __launch_bounds__(kBlock) void amax_rows_kernel(const void* __restric
 }
 
 // ---------------------------------------------------------------- columns
-// grid.x = column tiles of kBlock*V columns, grid.y = row blocks of kColRows rows.
-// SUM: also produce per-row-block partial column sums of |x| (fp32) into partial[rowblk][col].
+// A workgroup owns a tile of kColTile = 64 lanes x kVec adjacent columns and kColRowsWG = 64 rows: wave w walks rows
+// r0 + 16 w .. +16 with sixteen 16-byte loads per lane in flight (a wave instruction = 1 KiB of one row), the four
+// waves are combined through LDS in wave order, and ONE result per column leaves the workgroup: a plain store of
+// the partial |x| sum (deterministic two-stage sum) and one atomicMax of the abs-max pattern.
+// grid.x = column tiles, grid.y = row blocks.  partial: [n_rowblk, cols] fp32.
+constexpr int kColRowsWG = 64;
 template <int DT, bool SUM, bool AMAX>
 __global__ __launch_bounds__(kBlock) void col_stats_kernel(const void* __restrict__ x, int64_t rows,
                                                            int64_t cols, uint32_t* __restrict__ amax_out,
                                                            float* __restrict__ partial) {
   constexpr int V = Elem<DT>::kVec;
-  const int64_t c0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * V;
-  if (c0 >= cols) return;
-  const int64_t r0 = (int64_t)blockIdx.y * kColRows;
-  const int64_t r1 = r0 + kColRows < rows ? r0 + kColRows : rows;
+  constexpr int kTileCols = 64 * V;
+  __shared__ float s_sum[SUM ? 4 : 1][SUM ? kTileCols : 1];
+  __shared__ uint32_t s_max[AMAX ? 4 : 1][AMAX ? kTileCols : 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * V;
+  const int64_t r0 = (int64_t)blockIdx.y * kColRowsWG + wave * kColRows;
   const char* base = reinterpret_cast<const char*>(x);
   const int64_t row_bytes = cols * (16 / V);
   uint32_t am[V];
   float sm[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) { am[i] = 0; sm[i] = 0.0f; }
-  Pack16 pk[kColRows];
+  if (c0 < cols) {
+    Pack16 pk[kColRows];
 #pragma unroll
-  for (int r = 0; r < kColRows; ++r)
-    if (r0 + r < r1) pk[r] = load16(base + (r0 + r) * row_bytes + c0 * (16 / V));
+    for (int r = 0; r < kColRows; ++r)
+      if (r0 + r < rows) pk[r] = load16_nt(base + (r0 + r) * row_bytes + c0 * (16 / V));
 #pragma unroll
-  for (int r = 0; r < kColRows; ++r) {
-    if (r0 + r < r1) {
-      float f[8];
-      unpack<DT>(pk[r], f);
+    for (int r = 0; r < kColRows; ++r) {
+      if (r0 + r < rows) {
+        float f[8];
+        unpack<DT>(pk[r], f);
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        const uint32_t a = absbits(f[i]);
-        if (AMAX) am[i] = a > am[i] ? a : am[i];
-        if (SUM) sm[i] += __uint_as_float(a);  // rows are added in row order: deterministic
+        for (int i = 0; i < V; ++i) {
+          const uint32_t a = absbits(f[i]);
+          if (AMAX) am[i] = a > am[i] ? a : am[i];
+          if (SUM) sm[i] += __uint_as_float(a);  // rows are added in row order: deterministic
+        }
       }
     }
   }
-  if (AMAX) {
 #pragma unroll
-    for (int i = 0; i < V; ++i) atomicMax(&amax_out[c0 + i], am[i]);
+  for (int i = 0; i < V; ++i) {
+    if (SUM) s_sum[wave][lane * V + i] = sm[i];
+    if (AMAX) s_max[wave][lane * V + i] = am[i];
   }
-  if (SUM) {
-    float* dst = partial + (int64_t)blockIdx.y * cols + c0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < kTileCols; j += kBlock) {
+    const int64_t c = (int64_t)blockIdx.x * kTileCols + j;
+    if (c >= cols) continue;
+    if (SUM) partial[(int64_t)blockIdx.y * cols + c] = ((s_sum[0][j] + s_sum[1][j]) + s_sum[2][j]) + s_sum[3][j];
+    if (AMAX) {
+      uint32_t m = s_max[0][j];
 #pragma unroll
-    for (int i = 0; i < V; ++i) dst[i] = sm[i];
+      for (int w = 1; w < 4; ++w) m = s_max[w][j] > m ? s_max[w][j] : m;
+      atomicMax(&amax_out[c], m);
+    }
   }
 }
 
@@ -112,7 +128,15 @@ __global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.0f;
-  for (int64_t b = 0; b < n_blk; ++b) s += partial[b * cols + c];
+  int64_t b = 0;
+  for (; b + 8 <= n_blk; b += 8) {  // 8 independent loads in flight, added in row-block order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < n_blk; ++b) s += partial[b * cols + c];
   sum_out[c] = accumulate ? sum_out[c] + s : s;
 }
 
@@ -160,7 +184,15 @@ __global__ void awq_wscale_finalize_kernel(const float* __restrict__ partial, in
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   float s = 0.0f;
-  for (int64_t b = 0; b < n_blk; ++b) s += partial[b * cols + c];
+  int64_t b = 0;
+  for (; b + 8 <= n_blk; b += 8) {  // 8 independent loads in flight, added in row-block order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < n_blk; ++b) s += partial[b * cols + c];
   out[c] = round_to_dtype<DT>(s / (float)rows);  // torch.mean: fp32 accumulate, one rounding to dtype
 }
 
@@ -229,13 +261,12 @@ extern "C" int moq_amax_axis(const void* x, int64_t outer, int64_t axis_size, in
     segs = (row_packets + seg_packets - 1) / seg_packets;
     const int64_t items = n_rows * segs;
     int64_t blocks = (items + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 4096) blocks = 4096;
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_rows_kernel<DT>), dim3((int)blocks), dim3(kBlock), 0,
                                               S(stream), x, n_rows, axis_size, inner, seg_packets, segs,
                                               ob));
   } else if (aligned && inner == 1 && axis_size % vec == 0) {
-    dim3 grid((unsigned)((axis_size / vec + kBlock - 1) / kBlock),
-              (unsigned)((outer + kColRows - 1) / kColRows));
+    dim3 grid((unsigned)((axis_size / vec + 63) / 64), (unsigned)((outer + kColRowsWG - 1) / kColRowsWG));
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, false, true>), grid, dim3(kBlock), 0,
                                               S(stream), x, outer, axis_size, ob, (float*)nullptr));
   } else {
@@ -269,8 +300,8 @@ extern "C" int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, in
   const bool fast = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && cols % vec == 0;
   uint32_t* ab = reinterpret_cast<uint32_t*>(amax_out);
   if (fast && (sum_out == nullptr || partial != nullptr)) {
-    const int64_t n_blk = (tokens + kColRows - 1) / kColRows;
-    dim3 grid((unsigned)((cols / vec + kBlock - 1) / kBlock), (unsigned)n_blk);
+    const int64_t n_blk = (tokens + kColRowsWG - 1) / kColRowsWG;
+    dim3 grid((unsigned)((cols / vec + 63) / 64), (unsigned)n_blk);
     if (sum_out != nullptr && amax_out != nullptr) {
       MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, true, true>), grid, dim3(kBlock), 0,
                                                 S(stream), x, tokens, cols, ab, partial));

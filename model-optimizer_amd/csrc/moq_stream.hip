@@ -15,79 +15,9 @@
 #include <stdlib.h>
 
 #include "moq_common.h"
+#include "moq_chunk.h"
 
 namespace moq {
-
-template <int DT>
-struct Chunk {
-  static constexpr int kVec = Elem<DT>::kVec;
-  static constexpr int kPackets = MOQ_MT_CHUNK / (kBlock * kVec);  // 4 (16-bit) or 8 (f32)
-  static_assert(kPackets * kBlock * kVec == MOQ_MT_CHUNK, "chunk must tile exactly");
-};
-
-// element offset (inside the chunk) of packet u of this thread
-template <int DT>
-__device__ __forceinline__ int packet_off(int u) {
-  return (u * kBlock + (int)threadIdx.x) * Elem<DT>::kVec;
-}
-
-// Guarded / unaligned packet access.  FAST = chunk fully inside the tensor and base 16-byte aligned.
-template <int DT, bool FAST, bool NT = true>
-__device__ __forceinline__ Pack16 ld_packet(const void* base, int64_t e, int64_t n) {
-  constexpr int V = Elem<DT>::kVec;
-  constexpr int ES = 16 / V;
-  if constexpr (FAST) {
-    // streaming data is read exactly once: non-temporal hint (measured on MI355X, 14 GiB streams:
-    // read-only 6.2 -> 7.0 TB/s, copy 5.9 -> 6.5 TB/s; tools/exp/stream_probe.hip).  NT = false keeps the
-    // lines in L2 / Infinity Cache for a second pass over the same tensor (grouped calibrate -> QDQ).
-    if constexpr (NT) return load16_nt(reinterpret_cast<const char*>(base) + e * ES);
-    else return load16(reinterpret_cast<const char*>(base) + e * ES);
-  } else {
-    float f[V];
-#pragma unroll
-    for (int i = 0; i < V; ++i) f[i] = (e + i < n) ? load1<DT>(base, e + i) : 0.0f;
-    if constexpr (DT == MOQ_F32) {
-      return pack<DT>(f);
-    } else {
-      // keep the exact 16-bit patterns (no re-rounding): rebuild from raw storage
-      Pack16 p;
-      const uint16_t* b = reinterpret_cast<const uint16_t*>(base);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint32_t lo = (e + 2 * i < n) ? b[e + 2 * i] : 0u;
-        uint32_t hi = (e + 2 * i + 1 < n) ? b[e + 2 * i + 1] : 0u;
-        p.w[i] = lo | (hi << 16);
-      }
-      return p;
-    }
-  }
-}
-template <int DT, bool FAST>
-__device__ __forceinline__ void st_packet(void* base, int64_t e, int64_t n, const Pack16& p) {
-  constexpr int V = Elem<DT>::kVec;
-  constexpr int ES = 16 / V;
-  if constexpr (FAST) {
-    store16_nt(reinterpret_cast<char*>(base) + e * ES, p);
-  } else {
-    if constexpr (DT == MOQ_F32) {
-      float* b = reinterpret_cast<float*>(base);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (e + i < n) b[e + i] = __uint_as_float(p.w[i]);
-    } else {
-      uint16_t* b = reinterpret_cast<uint16_t*>(base);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (e + 2 * i < n) b[e + 2 * i] = (uint16_t)(p.w[i] & 0xFFFFu);
-        if (e + 2 * i + 1 < n) b[e + 2 * i + 1] = (uint16_t)(p.w[i] >> 16);
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ bool aligned16(const void* p) {
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Per-element operators applied by the chunk loop
@@ -229,22 +159,34 @@ __global__ __launch_bounds__(kBlock) void map_axis_amax_kernel(const void* __res
                                                                void* __restrict__ y, int64_t n,
                                                                const float* __restrict__ amax,
                                                                int64_t axis_size, int64_t inner,
-                                                               int num_bits, int is_unsigned,
-                                                               int narrow) {
+                                                               int inner_shift, int wrap, int num_bits,
+                                                               int is_unsigned, int narrow) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
   const IntQ q = make_intq(num_bits, is_unsigned, narrow);
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   const bool al = aligned16(x) && aligned16(y);
-  const bool uniform = (inner % V) == 0;  // a 16-byte packet never straddles two amax entries
+  // a 16-byte packet never straddles two amax entries; the row index then costs one 64-bit division per chunk
+  // (uniform) and a 32-bit shift / division per packet instead of a 64-bit div + mod per packet
+  const bool uniform = (inner % V) == 0 && inner < (1LL << 31);
+  GroupIndex gi;
+  gi.g = (uint32_t)inner;
+  gi.shift = inner_shift;
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     const bool fast = al && e0 + MOQ_MT_CHUNK <= n;
+    if (uniform) gi.seek(e0);
     Pack16 in[P];
+    float am[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
       in[u] = fast ? ld_packet<DT, true>(x, e, n) : ld_packet<DT, false>(x, e, n);
+      if (uniform) {
+        int64_t row = gi.at((uint32_t)packet_off<DT>(u));
+        if (wrap) row %= axis_size;
+        am[u] = e < n ? amax[row] : 1.0f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < P; ++u) {
@@ -252,15 +194,14 @@ __global__ __launch_bounds__(kBlock) void map_axis_amax_kernel(const void* __res
       float f[8];
       unpack<DT>(in[u], f);
       if (uniform) {
-        const float a = e < n ? amax[(e / inner) % axis_size] : 1.0f;
         if constexpr (FP8) {
           OpFp8Qdq op;
-          op.sc = fp8_scale(a);
+          op.sc = fp8_scale(am[u]);
           op(f, V);
         } else {
           OpIntQdq op;
           op.q = q;
-          op.set(a);
+          op.set(am[u]);
           op(f, V);
         }
       } else {
@@ -549,16 +490,6 @@ using namespace moq;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static int mt_grid(int64_t n_chunks) { return (int)(n_chunks < 2048 ? n_chunks : 2048); }  // reductions
-// copy-shaped passes: ~8 chunks per workgroup, at least a full machine (2048), at most 128 Ki workgroups
-static int copy_grid(int64_t n_chunks) {
-  static const int64_t div = [] { const char* e = getenv("MOQ_TUNE_CHUNKS_PER_WG"); return e ? atoll(e) : 8LL; }();
-  int64_t g = n_chunks / (div > 0 ? div : 8);
-  if (g < 2048) g = 2048;
-  if (g > 131072) g = 131072;
-  if (g > n_chunks) g = n_chunks;
-  return (int)(g < 1 ? 1 : g);
-}
-
 
 extern "C" int moq_amax(const void* x, int64_t n, int dt, float* out, int accumulate, void* stream) {
   if (out == nullptr || n < 0 || (n > 0 && x == nullptr)) {
@@ -612,9 +543,10 @@ static int launch_map(const void* x, void* y, int64_t n, int dt, const float* am
       set_error("%s: axis mode needs amax, axis_size > 0, inner > 0", who);
       return MOQ_ERR_INVALID;
     }
+    const int wrap = n > axis_size * inner ? 1 : 0;  // outer > 1: the amax index wraps around
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_axis_amax_kernel<DT, FP8>), dim3(grid), dim3(kBlock),
-                                              0, S(stream), x, y, n, amax, axis_size, inner, num_bits,
-                                              is_unsigned, narrow));
+                                              0, S(stream), x, y, n, amax, axis_size, inner,
+                                              log2_or_neg(inner), wrap, num_bits, is_unsigned, narrow));
   } else {
     set_error("%s: unknown amax_mode %d", who, amax_mode);
     return MOQ_ERR_INVALID;

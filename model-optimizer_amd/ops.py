@@ -607,3 +607,74 @@ def awq_clip_loss(inputs: torch.Tensor, weight: torch.Tensor, w_amax: torch.Tens
                                            _dt(w), _p(am), adt, _p(sh), sh.numel(), int(num_bits), _p(loss),
                                            stream))
     return loss
+
+
+# ----------------------------------------------------------------------------------------------- real FP8 / MXFP4
+def _scale_layout(x: torch.Tensor, scales: torch.Tensor):
+    """(mode, axis_size, inner) of a scale tensor over contiguous x: one scale, or one scale per run of `inner`
+    consecutive elements (per-channel rows of a 2-D weight, 1-D blocks along the last dim)."""
+    ns = scales.numel()
+    if ns == 1:
+        return _lib.AMAX_SCALAR, 1, 1
+    if x.numel() % ns:
+        raise MoquantUnsupported("scale count does not divide the element count")
+    inner = x.numel() // ns
+    if x.shape[-1] % inner and inner % x.shape[-1]:
+        raise MoquantUnsupported("scales must run along the flattened last dims (per-row or last-dim blocks)")
+    return _lib.AMAX_AXIS, ns, inner
+
+
+@torch.no_grad()
+def fp8_quantize(inputs: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+    """(inputs / scales).to(torch.float8_e4m3fn) -- FP8QTensor.quantize's cast (fp8_tensor.py:103-107) / the FP8
+    branch of to_quantized_weight.  scales: 1 element, per row, or per last-dim block (row-major order)."""
+    _require_gpu(inputs, "fp8_quantize")
+    x = inputs.detach().contiguous()
+    s = scales.detach().to(device=x.device, dtype=x.dtype).contiguous().reshape(-1)
+    mode, axis_size, inner = _scale_layout(x, s)
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_fp8_pack(_p(x), _p(s), _p(out), x.numel(), _dt(x), mode, axis_size, inner, stream))
+    return out.view(torch.float8_e4m3fn)
+
+
+@torch.no_grad()
+def fp8_dequantize(quantized: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """quantized.to(dtype) * scales.to(dtype) -- FP8QTensor.dequantize (fp8_tensor.py:151)."""
+    _require_gpu(quantized, "fp8_dequantize")
+    q = quantized.detach().contiguous().view(torch.uint8)
+    s = scales.detach().to(device=q.device, dtype=dtype).contiguous().reshape(-1)
+    mode, axis_size, inner = _scale_layout(q, s)
+    out = torch.empty(q.shape, dtype=dtype, device=q.device)
+    with _on(q) as stream:
+        check(_lib.lib().moq_fp8_unpack(_p(q), _p(s), _p(out), q.numel(), _dt(out), mode, axis_size, inner, stream))
+    return out
+
+
+@torch.no_grad()
+def mxfp4_quantize(inputs: torch.Tensor, block_size: int = 32):
+    """MXFP4QTensor.quantize (mxfp4_tensor.py:37-81): (uint8 [..., K/2], e8m0 uint8 [n/block, 1])."""
+    _require_gpu(inputs, "mxfp4_quantize")
+    x = inputs.detach().contiguous()
+    if x.numel() % block_size or x.shape[-1] % 2:
+        raise MoquantError("mxfp4_quantize: numel must be a multiple of block_size and the last dim even")
+    nb = x.numel() // block_size
+    packed = torch.empty(*x.shape[:-1], x.shape[-1] // 2, dtype=torch.uint8, device=x.device)
+    e8 = torch.empty(nb, 1, dtype=torch.uint8, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_mxfp4_pack(_p(x), _p(packed), _p(e8), nb, int(block_size), _dt(x), stream))
+    return packed, e8
+
+
+@torch.no_grad()
+def mxfp4_dequantize(packed: torch.Tensor, e8m0: torch.Tensor, dtype: torch.dtype, block_size: int = 32):
+    """MXFP4QTensor.dequantize (mxfp4_tensor.py:83-144)."""
+    _require_gpu(packed, "mxfp4_dequantize")
+    p = packed.detach().contiguous()
+    e = e8m0.detach().to(p.device).contiguous().reshape(-1)
+    if p.dtype != torch.uint8 or e.dtype != torch.uint8 or (2 * p.numel()) != e.numel() * block_size:
+        raise MoquantError("mxfp4_dequantize: packed / scale size mismatch")
+    out = torch.empty(*p.shape[:-1], p.shape[-1] * 2, dtype=dtype, device=p.device)
+    with _on(p) as stream:
+        check(_lib.lib().moq_mxfp4_unpack(_p(p), _p(e), _p(out), e.numel(), int(block_size), _dt(out), stream))
+    return out

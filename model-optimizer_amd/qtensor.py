@@ -1,0 +1,116 @@
+"""Real-quantised tensors of the path -- mirrors of modelopt.torch.quantization.qtensor.{INT4QTensor, FP8QTensor,
+MXFP4QTensor} (qtensor/int4_tensor.py:39-130, fp8_tensor.py:40-151, mxfp4_tensor.py:37-144): same classmethod
+`quantize(...) -> (qtensor, scales)` and `dequantize(dtype, scale=..., block_sizes=...)` surface, every pass over
+tensor data is one HIP kernel (block amax, pack, unpack).  GPU tensors only."""
+
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, ops
+from ._lib import MoquantUnsupported
+
+
+class BaseQuantizedTensor:
+    """qtensor/base_qtensor.py: original shape / dtype + the packed data."""
+
+    def __init__(self, original_shape, original_dtype, quantized_data):
+        self.metadata = {"shape": torch.Size(original_shape), "dtype": original_dtype}
+        self._quantized_data = quantized_data
+
+
+def _div448(amax: torch.Tensor) -> torch.Tensor:
+    """amax / 448.0 as a TRUE division.  torch's GPU `tensor / python_float` multiplies by the reciprocal, which is one
+    ulp off the CPU result for some inputs; tensor / tensor divides on both devices."""
+    return amax / torch.full((), 448.0, dtype=amax.dtype, device=amax.device)
+
+
+def _pad_last(x: torch.Tensor, block: int) -> torch.Tensor:
+    pad = (-x.shape[-1]) % block
+    return F.pad(x, (0, pad), "constant", 0) if pad else x
+
+
+class INT4QTensor(BaseQuantizedTensor):
+    @classmethod
+    def quantize(cls, input: torch.Tensor, block_size: int):
+        """int4_tensor.py:39-87: flat view padded to a block multiple, scales = 7 / block amax (input dtype),
+        byte = ((q_even + 8) << 4) | (q_odd + 8).  Rounding follows the reference's CUDA kernel (the path taken
+        for GPU tensors there): clamp, then round-half-away of v + 8 (tensor_quant_gpu.cu:322-333)."""
+        assert input.shape[-1] % 2 == 0, "Input tensor must have even number on last dimension."
+        flat = _pad_last(input.reshape(-1), block_size).contiguous()
+        amax = ops.reduce_amax(flat.view(-1, block_size), axis=(1,))  # input dtype, [n/g, 1]
+        scales = (7.0 / amax).view(-1, 1)
+        packed = ops.int4_quantize(flat, scales.reshape(-1), block_size, rounding=_lib.ROUND_HALF_AWAY)
+        packed = packed.reshape(*input.shape[:-1], -1)
+        return cls(input.shape, input.dtype, packed), scales
+
+    def dequantize(self, dtype: torch.dtype = None, **kwarg):
+        """int4_tensor.py:89-130 (CUDA branch): (nibble - 8) / scale in the scale dtype."""
+        dtype = dtype or self.metadata["dtype"]
+        scales, block = kwarg["scale"], kwarg["block_sizes"][-1]
+        out = ops.int4_dequantize(self._quantized_data.reshape(-1), scales.to(self._quantized_data.device).reshape(-1),
+                                  block)
+        n = math.prod(self.metadata["shape"])
+        return out.view(-1)[:n].view(self.metadata["shape"]).to(dtype)
+
+
+class FP8QTensor(BaseQuantizedTensor):
+    @classmethod
+    def quantize(cls, input: torch.Tensor, scales: torch.Tensor = None, axis=None, block_sizes: dict | None = None):
+        """fp8_tensor.py:40-112.  Supported layouts: per-tensor, one kept axis whose scales run along the flattened
+        leading dims (per-channel rows), and 1-D blocks along the last dim; N-D block grids raise."""
+        x = input
+        if block_sizes:
+            dims = {(d if d >= 0 else input.dim() + d): b for d, b in block_sizes.items() if isinstance(d, int)}
+            if list(dims) != [input.dim() - 1]:
+                raise MoquantUnsupported("FP8QTensor: only last-dim blocks are on this path "
+                                         "(reference N-D blocks: fp8_tensor.py:77-100)")
+            block = dims[input.dim() - 1]
+            x = _pad_last(input, block).contiguous()
+            if scales is None:
+                amax = ops.reduce_amax(x.view(-1, block), axis=(1,))
+                scales = _div448(amax).reshape(*x.shape[:-1], x.shape[-1] // block)
+            else:
+                scales = scales.reshape(*x.shape[:-1], x.shape[-1] // block)
+        elif scales is None:
+            if axis is None:
+                scales = _div448(ops.reduce_amax(x))
+            else:
+                ax = [axis] if isinstance(axis, int) else list(axis)
+                reduce_axis = [i for i in range(x.dim()) if i not in ax and (i - x.dim()) not in ax]
+                scales = _div448(ops.reduce_amax(x, axis=reduce_axis))
+        q = ops.fp8_quantize(x, scales)
+        if q.shape != input.shape:
+            q = q[tuple(slice(0, d) for d in input.shape)]
+        return cls(input.shape, input.dtype, q), scales
+
+    def dequantize(self, dtype: torch.dtype = None, **kwarg):
+        """fp8_tensor.py:114-151."""
+        dtype = dtype or self.metadata["dtype"]
+        assert "scale" in kwarg, "Require scale for FP8 dequantization."
+        scales, block_sizes = kwarg["scale"], kwarg.get("block_sizes")
+        q = self._quantized_data
+        if block_sizes:
+            block = block_sizes.get(-1) or block_sizes.get(q.dim() - 1)
+            q = _pad_last(q.view(torch.uint8), block).contiguous()
+        out = ops.fp8_dequantize(q, scales, dtype)
+        return out[tuple(slice(0, d) for d in self.metadata["shape"])]
+
+
+class MXFP4QTensor(BaseQuantizedTensor):
+    E2M1_max = 6.0
+
+    @classmethod
+    def quantize(cls, input: torch.Tensor, block_size: int | None):
+        """mxfp4_tensor.py:37-81."""
+        block_size = block_size or 32
+        packed, e8m0 = ops.mxfp4_quantize(input, block_size)
+        return cls(input.shape, input.dtype, packed), e8m0
+
+    def dequantize(self, dtype: torch.dtype = None, **kwarg):
+        """mxfp4_tensor.py:83-144."""
+        dtype = dtype or self.metadata["dtype"]
+        return ops.mxfp4_dequantize(self._quantized_data, kwarg["scale"], dtype, kwarg["block_sizes"][-1])

@@ -265,3 +265,43 @@ def awq_clip_loss(x, w, amax, shrinks, g, num_bits=4, loss=None):
     lib().orc_awq_clip_loss(_p(a), I64(n_tok), _p(b), I64(cout), I64(cin), int(g), DT[w.dtype], _p(am),
                             DT[amax.dtype], _p(sh), int(len(sh)), int(num_bits), _p(loss))
     return torch.from_numpy(loss)
+
+
+def _mode(x, scales, axis_size, inner):
+    return (0, 1, 1) if scales.numel() == 1 else (1, axis_size, inner)
+
+
+def fp8_pack(x, scales, axis_size=1, inner=1):
+    """(x / scales).to(float8_e4m3fn) bytes, scales in x.dtype (FP8QTensor.quantize, fp8_tensor.py:103-107)."""
+    a, s = _np(x), _np(scales.to(x.dtype))
+    out = np.empty(x.numel(), dtype=np.uint8)
+    m, ax, inn = _mode(x, scales, axis_size, inner)
+    lib().orc_fp8_pack(_p(a), _p(s), _p(out), I64(x.numel()), DT[x.dtype], m, I64(ax), I64(inn))
+    return torch.from_numpy(out).reshape(x.shape)
+
+
+def fp8_unpack(q, scales, dtype, axis_size=1, inner=1):
+    qa = np.ascontiguousarray(q.detach().cpu().contiguous().view(torch.uint8).numpy()).reshape(-1)
+    s = _np(scales.to(dtype))
+    out = _empty_like_np(torch.empty(qa.size, dtype=dtype))
+    m, ax, inn = _mode(q, scales, axis_size, inner)
+    lib().orc_fp8_unpack(_p(qa), _p(s), _p(out), I64(qa.size), DT[dtype], m, I64(ax), I64(inn))
+    return _from_np(out, dtype, q.shape)
+
+
+def mxfp4_pack(x, block=32):
+    """MXFP4QTensor.quantize (mxfp4_tensor.py:37-81): (packed uint8 [..., K/2], e8m0 uint8 [n/block, 1])."""
+    a = _np(x)
+    nb = x.numel() // block
+    packed = np.empty(x.numel() // 2, dtype=np.uint8)
+    e8 = np.empty(nb, dtype=np.uint8)
+    lib().orc_mxfp4_pack(_p(a), _p(packed), _p(e8), I64(nb), int(block), DT[x.dtype])
+    return torch.from_numpy(packed).reshape(*x.shape[:-1], x.shape[-1] // 2), torch.from_numpy(e8).reshape(-1, 1)
+
+
+def mxfp4_unpack(packed, e8m0, dtype, block=32):
+    p = np.ascontiguousarray(packed.detach().cpu().numpy()).reshape(-1)
+    e = np.ascontiguousarray(e8m0.detach().cpu().numpy()).reshape(-1)
+    out = _empty_like_np(torch.empty(p.size * 2, dtype=dtype))
+    lib().orc_mxfp4_unpack(_p(p), _p(e), _p(out), I64(e.size), int(block), DT[dtype])
+    return _from_np(out, dtype, (*packed.shape[:-1], packed.shape[-1] * 2))

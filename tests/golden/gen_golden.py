@@ -17,6 +17,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
+  qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -433,6 +434,35 @@ def gen_awq_clip(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_qtensor(out):
+    """FP8QTensor / MXFP4QTensor real quantisation (qtensor/fp8_tensor.py:40-151, qtensor/mxfp4_tensor.py:37-144):
+    quantized bytes, scales and the dequantised tensors the reference produces on CPU."""
+    from modelopt.torch.quantization.qtensor import FP8QTensor, MXFP4QTensor
+
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        w = weight_like((48, 256), dt, 1300 + idx)
+        w[0, :8] = torch.tensor([0.0, -0.0, 1e-6, -1e-6, 0.5, -0.5, 3.0, -3.0], dtype=dt)
+        # FP8: per-tensor, per-channel (axis 0), 1-D blocks of 128 along the last dim
+        for mode, kw in [("tensor", {}), ("axis0", {"axis": 0}), ("block128", {"block_sizes": {-1: 128}})]:
+            qt, scales = FP8QTensor.quantize(w, **kw)
+            deq = qt.dequantize(scale=scales, **({"block_sizes": {-1: 128}} if mode == "block128" else {}))
+            k = f"fp8_{dn}_{mode}"
+            out[f"{k}_x"], out[f"{k}_q"] = bits(w), qt._quantized_data.view(torch.uint8).numpy().copy()
+            out[f"{k}_scales"], out[f"{k}_deq"] = bits(scales), bits(deq)
+            cases[k] = dict(kind="fp8", dtype=dn, mode=mode, scale_shape=list(scales.shape))
+        for block in (32, 16):
+            qt, e8 = MXFP4QTensor.quantize(w, block)
+            deq = qt.dequantize(scale=e8, block_sizes={-1: block})
+            k = f"mxfp4_{dn}_b{block}"
+            out[f"{k}_x"], out[f"{k}_q"], out[f"{k}_e8m0"] = bits(w), qt._quantized_data.numpy().copy(), e8.numpy().copy()
+            out[f"{k}_deq"] = bits(deq)
+            cases[k] = dict(kind="mxfp4", dtype=dn, block=block)
+        idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def extract_mx_vectors():
     """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
     path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
@@ -591,11 +621,11 @@ def gen_export(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

@@ -1,0 +1,127 @@
+"""Real quantisation (a15) on the GPU: FP8 / MXFP4 pack + unpack kernels and the QTensor mirrors, byte-exact against
+the oracle and against FP8QTensor / MXFP4QTensor / INT4QTensor run by the reference on CPU
+(tests/golden/qtensor.npz, tests/golden/int4.npz)."""
+
+import pytest
+import torch
+
+import _moa_import
+from conftest import DT, assert_bits_equal
+
+pytestmark = pytest.mark.gpu
+moa = _moa_import.load()
+from model_optimizer_amd import ops, qtensor  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _layout(c, x):
+    if c["mode"] == "tensor":
+        return 1, 1
+    if c["mode"] == "axis0":
+        return x.shape[0], x.shape[1]
+    return x.numel() // 128, 128
+
+
+def test_fp8_and_mxfp4_kernels_match_reference_run(golden):
+    g = golden("qtensor")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x = g.t(f"{k}_x", dt)
+        want_q = torch.from_numpy(g.raw(f"{k}_q").copy())
+        want_deq = g.t(f"{k}_deq", dt)
+        if c["kind"] == "fp8":
+            scales = g.t(f"{k}_scales", dt)
+            got_q = ops.fp8_quantize(x.to(DEV), scales.to(DEV)).view(torch.uint8).cpu()
+            assert torch.equal(got_q.reshape(-1), want_q.reshape(-1)), f"{k}: fp8 bytes differ from the reference"
+            got = ops.fp8_dequantize(want_q.reshape(x.shape).to(DEV), scales.to(DEV), dt).cpu()
+            assert_bits_equal(got, want_deq, f"{k}: fp8 dequant")
+            # the QTensor mirror computes its own scales: same bytes, same scales
+            kw = {"axis": 0} if c["mode"] == "axis0" else ({"block_sizes": {-1: 128}} if c["mode"] == "block128" else {})
+            qt, sc = qtensor.FP8QTensor.quantize(x.to(DEV), **kw)
+            assert list(sc.shape) == c["scale_shape"], f"{k}: scale shape {tuple(sc.shape)}"
+            assert_bits_equal(sc.cpu(), scales, f"{k}: scales")
+            assert torch.equal(qt._quantized_data.view(torch.uint8).cpu().reshape(-1), want_q.reshape(-1))
+            deq = qt.dequantize(scale=sc, **({"block_sizes": {-1: 128}} if c["mode"] == "block128" else {}))
+            assert_bits_equal(deq.cpu(), want_deq, f"{k}: FP8QTensor round trip")
+        else:
+            want_e = torch.from_numpy(g.raw(f"{k}_e8m0").copy())
+            qt, e8 = qtensor.MXFP4QTensor.quantize(x.to(DEV), c["block"])
+            assert torch.equal(e8.cpu(), want_e), f"{k}: e8m0 scales differ"
+            assert torch.equal(qt._quantized_data.cpu(), want_q), f"{k}: mxfp4 bytes differ from the reference"
+            deq = qt.dequantize(scale=e8, block_sizes={-1: c["block"]})
+            assert_bits_equal(deq.cpu(), want_deq, f"{k}: MXFP4QTensor round trip")
+
+
+@pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
+def test_fp8_pack_unpack_vs_oracle(dn):
+    dt = DT[dn]
+    gen = torch.Generator().manual_seed(5)
+    for shape, inner in [((64, 1024), None), ((96, 512), 512), ((40, 384), 128), ((17, 4096 + 64), 64)]:
+        x = (torch.randn(*shape, generator=gen) * torch.exp(torch.randn(shape[0], 1, generator=gen))).to(dt)
+        x.view(-1)[:6] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e-9], dtype=dt)
+        if inner is None:
+            scales, ax, inn = (x.float().abs().max() / 448.0).to(dt).reshape(1), 1, 1
+            scales = torch.tensor([0.0123], dtype=dt)  # inf / nan in x: use a fixed finite scale
+        else:
+            ax, inn = x.numel() // inner, inner
+            scales = (torch.rand(ax, generator=gen) * 0.01 + 1e-4).to(dt)
+        want = oracle.fp8_pack(x, scales, ax, inn)
+        got = ops.fp8_quantize(x.to(DEV), scales.to(DEV)).view(torch.uint8).cpu()
+        assert torch.equal(got, want), f"fp8 pack {dn} {shape} inner={inner}"
+        q = torch.randint(0, 256, shape, generator=gen, dtype=torch.uint8)
+        want_d = oracle.fp8_unpack(q, scales, dt, ax, inn)
+        got_d = ops.fp8_dequantize(q.to(DEV), scales.to(DEV), dt).cpu()
+        assert_bits_equal(got_d, want_d, f"fp8 unpack {dn} {shape}")
+
+
+@pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("block", [32, 16, 64, 8])
+def test_mxfp4_pack_unpack_vs_oracle(dn, block):
+    dt = DT[dn]
+    gen = torch.Generator().manual_seed(block)
+    for shape in [(64, 1024), (33, 320), (8200, 64)]:
+        x = (torch.randn(*shape, generator=gen) * torch.exp(torch.randn(shape[0], 1, generator=gen) * 2)).to(dt)
+        x[0, :block] = 0  # all-zero block: scale byte 0, every nibble 8
+        x[1, :8] = torch.tensor([6.0, 3.0, 1.5, 0.75, 0.25, -0.25, 5.0, -2.5], dtype=dt)  # exact bounds: ties go down
+        x[2, :block] = x[2, :block] * 1e-30  # tiny amax
+        want_q, want_e = oracle.mxfp4_pack(x, block)
+        got_q, got_e = ops.mxfp4_quantize(x.to(DEV), block)
+        assert torch.equal(got_e.cpu(), want_e), f"mxfp4 e8m0 {dn} {shape} b={block}"
+        assert torch.equal(got_q.cpu(), want_q), f"mxfp4 bytes {dn} {shape} b={block}"
+        q = torch.randint(0, 256, want_q.shape, generator=gen, dtype=torch.uint8)
+        e = torch.randint(0, 255, want_e.shape, generator=gen, dtype=torch.uint8)
+        if dt == torch.float16:
+            e = e.clamp(100, 140)  # keep 6 * 2^(e-127) inside the f16 range
+        want_d = oracle.mxfp4_unpack(q, e, dt, block)
+        got_d = ops.mxfp4_dequantize(q.to(DEV), e.to(DEV), dt, block).cpu()
+        assert_bits_equal(got_d, want_d, f"mxfp4 unpack {dn} {shape} b={block}")
+
+
+def test_mxfp4_power_of_two_edges():
+    """amax / 6 exactly a power of two, and one / two fp32 ulps above it (where torch.log2 in fp32 still returns the
+    integer): kernel and oracle agree on the exponent."""
+    vals = []
+    for k in (-20, -6, -1, 0, 3, 10):
+        base = torch.tensor(6.0 * 2.0 ** k, dtype=torch.float32)
+        bits = base.view(torch.int32)
+        vals += [base, (bits + 1).view(torch.float32), (bits + 2).view(torch.float32), (bits + 40).view(torch.float32),
+                 (bits - 1).view(torch.float32)]
+    x = torch.zeros(len(vals), 32)
+    x[:, 0] = torch.stack(vals)
+    want_q, want_e = oracle.mxfp4_pack(x, 32)
+    got_q, got_e = ops.mxfp4_quantize(x.to(DEV), 32)
+    assert torch.equal(got_e.cpu(), want_e) and torch.equal(got_q.cpu(), want_q)
+
+
+def test_int4_qtensor_round_trip_matches_kernels():
+    gen = torch.Generator().manual_seed(3)
+    w = (torch.randn(64, 256, generator=gen) * 0.02).to(torch.bfloat16)
+    qt, scales = qtensor.INT4QTensor.quantize(w.to(DEV), 128)
+    assert qt._quantized_data.shape == (64, 128) and scales.shape == (128, 1)
+    want = oracle.int4_pack(w.reshape(-1), scales.cpu().reshape(-1), 128, rounding=1)
+    assert torch.equal(qt._quantized_data.cpu().reshape(-1), want)
+    deq = qt.dequantize(scale=scales, block_sizes={-1: 128})
+    assert deq.shape == w.shape and deq.dtype == w.dtype
+    assert (deq.cpu().float() - w.float()).abs().max() <= (w.float().abs().max() / 7) * 0.51

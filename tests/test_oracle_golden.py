@@ -268,3 +268,31 @@ def test_awq_clip_loss_matches_reference_run(golden, name):
     rel = ((loss - want).abs() / want.abs().clamp_min(1e-30)).max().item()
     assert rel <= (1e-4 if dt == torch.float32 else 2e-3), f"{name}: max rel err {rel:.3e}"
     assert torch.equal(loss.argmin(0), want.argmin(0))
+
+
+def test_real_quant_fp8_mxfp4_match_reference(golden):
+    """orc_fp8_pack/unpack and orc_mxfp4_pack/unpack vs FP8QTensor / MXFP4QTensor run on CPU: bytes identical."""
+    g = golden("qtensor")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x = g.t(f"{k}_x", dt)
+        want_q = torch.from_numpy(g.raw(f"{k}_q").copy())
+        want_deq = g.t(f"{k}_deq", dt)
+        if c["kind"] == "fp8":
+            scales = g.t(f"{k}_scales", dt)
+            if c["mode"] == "tensor":
+                ax, inner = 1, 1
+            elif c["mode"] == "axis0":
+                ax, inner = x.shape[0], x.shape[1]
+            else:
+                ax, inner = x.numel() // 128, 128
+            got_q = oracle.fp8_pack(x, scales.reshape(-1), ax, inner)
+            assert torch.equal(got_q.reshape(-1), want_q.reshape(-1)), f"{k}: fp8 bytes differ"
+            got = oracle.fp8_unpack(want_q.reshape(x.shape), scales.reshape(-1), dt, ax, inner)
+            assert_bits_equal(got, want_deq, f"{k}: fp8 dequant")
+        else:
+            got_q, got_e = oracle.mxfp4_pack(x, c["block"])
+            assert torch.equal(got_e.reshape(-1), torch.from_numpy(g.raw(f"{k}_e8m0").copy()).reshape(-1)), f"{k}: e8m0"
+            assert torch.equal(got_q.reshape(-1), want_q.reshape(-1)), f"{k}: mxfp4 bytes differ"
+            got = oracle.mxfp4_unpack(want_q, torch.from_numpy(g.raw(f"{k}_e8m0").copy()), dt, c["block"])
+            assert_bits_equal(got, want_deq, f"{k}: mxfp4 dequant")

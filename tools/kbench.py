@@ -65,10 +65,14 @@ def main():
         ("moq_int4_unpack (qtensor)", lambda: ops.int4_dequantize(q4, scales, 128), 2.5 * n + 2 * n / 128),
         ("moq_int4_pack_export", lambda: ops.pack_int4_in_uint8(w, wsf), 2.5 * n + 4 * n / 128),
         ("moq_hist_abs 2048 bins", lambda: ops.hist_abs(x, 2048, xmax, False, counts), 2 * nx),
+        ("moq_rescale_cols", lambda: ops.rescale_cols(w, s_col, s_col), 4 * n),
     ]
     print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|")
+    only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, fn, nbytes in cases:
+        if only and only not in name:
+            continue
         ms = timed(fn)
         gbs = nbytes / ms / 1e6
         print(f"| {name} | {ms:.3f} | {gbs:.0f} | {gbs / PEAK:.3f} |")
