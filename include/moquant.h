@@ -299,6 +299,28 @@ int moq_mxfp4_pack(const void* x, uint8_t* packed, uint8_t* e8m0, int64_t n_bloc
 int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void* out, int64_t n_blocks, int block, int dt,
                      void* stream);
 
+/* ------------------------------------------------------------------ SparseGPT */
+
+/* y[c, r] = x[r, c] for 2-byte elements (bf16 / f16): turns an activation batch [tokens, cin] into the
+ * K-contiguous operand [cin, tokens] of moq_hessian_accum. */
+int moq_transpose16(const void* x, void* y, int64_t rows, int64_t cols, void* stream);
+/* hessian[i, j] = hessian[i, j] * decay + scale * sum_t xt[i, t] * xt[j, t]   (fp32 [cin, cin], updated in place)
+ * on the matrix cores: bf16 / f16 products are exact in fp32, accumulation is fp32 -- the arithmetic of the
+ * reference's fp32 `inp.matmul(inp.t())` up to summation order.  One calibration batch of
+ * SparseGPTSearcher._hook_compute_hessian (sparsity/weight_sparsity/sparsegpt.py:238-276): decay =
+ * samples / (samples + new), scale = 2 / (samples + new).  xt: [cin, tokens] (dt = MOQ_BF16 | MOQ_F16, 16-byte
+ * aligned, tokens % 8 == 0, cin % 4 == 0). */
+int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, int dt, float* hessian, float decay,
+                      float scale, void* stream);
+/* Column sweep of create_sgpt_mask over one column block [i1, i1 + bs) (sparsegpt.py:96-127), all rows at once:
+ * w: fp32 [rows, ld] working weights (block overwritten with the pruned weights q), hinv: fp32 [ld, ld] upper
+ * Cholesky factor of the damped inverse Hessian, delta: fp32 [rows, bs] receives err_j = (w_j - q_j) / hinv_jj.
+ * Every prune_m consecutive columns lose their prune_n smallest w^2 / (hinv_kk^2 + 1e-9).  bs <= 128,
+ * prune_m in {2, 4, 8}, bs % prune_m == 0.  The trailing update w[:, i2:] -= delta @ hinv[i1:i2, i2:] is the
+ * caller's (library fp32 GEMM). */
+int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
+                         int prune_n, int prune_m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

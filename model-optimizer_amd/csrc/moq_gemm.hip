@@ -151,7 +151,8 @@ __device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int
   }
 }
 
-// MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n].
+// MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n];
+// MODE 2: out is fp32 [T, N], out[t, n] = out[t, n] * decay + scale * acc (running Hessian X^T X of SparseGPT).
 template <int DT, int MODE, int GEO>
 __global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : 2)
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
@@ -160,7 +161,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ bias,  // [N] or null
                      void* __restrict__ out,         // [T, N] (MODE 1)
                      float* __restrict__ partial, int T, int N, int K, int tiles_t, int tiles_n,
-                     int64_t x_stride, int64_t w_stride) {
+                     int64_t x_stride, int64_t w_stride, float decay, float scale) {
   constexpr int TILE = Geo<GEO>::TILE, NI = Geo<GEO>::NI, NJ = Geo<GEO>::NJ;
   constexpr int WTC = Geo<GEO>::WAVES / Geo<GEO>::WN;  // waves along t
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -278,7 +279,15 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = round_to_dtype<DT>(acc[i][j][q * 4 + e] + bv[e]);
         const int64_t off = (int64_t)t * N + n;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 2) {
+          float4* hp = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off);
+          float4 h = *hp;
+          h.x = h.x * decay + scale * acc[i][j][q * 4 + 0];
+          h.y = h.y * decay + scale * acc[i][j][q * 4 + 1];
+          h.z = h.z * decay + scale * acc[i][j][q * 4 + 2];
+          h.w = h.w * decay + scale * acc[i][j][q * 4 + 3];
+          *hp = h;
+        } else if constexpr (MODE == 0) {
           const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
           float rf[4];
           if constexpr (DT == MOQ_BF16) {
@@ -383,7 +392,7 @@ static int64_t n_tiles_for(int64_t tokens, int64_t cout, int tile) {
 template <int MODE, int GEO>
 static void launch_geo(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
-                       int64_t w_stride, void* stream) {
+                       int64_t w_stride, void* stream, float decay = 0.0f, float scale = 0.0f) {
   constexpr int TILE = Geo<GEO>::TILE;
   const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
   const unsigned nblk = (unsigned)(tiles_t * tiles_n);
@@ -398,10 +407,12 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   const dim3 grid(nblk, (unsigned)n_cand), block(Geo<GEO>::WAVES * 64);
   if (dt == MOQ_BF16) {
     hipLaunchKernelGGL((err_gemm_kernel<MOQ_BF16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
-                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride);
+                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
+                       decay, scale);
   } else {
     hipLaunchKernelGGL((err_gemm_kernel<MOQ_F16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
-                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride);
+                       bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
+                       decay, scale);
   }
 }
 
@@ -409,7 +420,8 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
 template <int MODE>
 static int64_t launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
                            float* partial, int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand,
-                           int64_t x_stride, int64_t w_stride, void* stream) {
+                           int64_t x_stride, int64_t w_stride, void* stream, float decay = 0.0f,
+                           float scale = 0.0f) {
   const int geo = gemm_geo();
   const int tile = geo == 2 ? 256 : 128;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
@@ -418,9 +430,9 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     return MOQ_ERR_UNSUPPORTED;
   }
   switch (geo) {
-    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
-    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
-    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream); break;
+    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
+    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
+    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
   }
   return nblk;
 }
@@ -484,4 +496,18 @@ extern "C" int moq_gemm_nt(const void* x, const void* w, const void* bias, void*
   const int64_t nblk = launch_gemm<1>(x, w, nullptr, bias, out, nullptr, tokens, cout, cin, dt, 1, 0, 0, stream);
   if (nblk < 0) return (int)nblk;
   return check_launch("moq_gemm_nt");
+}
+
+extern "C" int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, int dt, float* hessian, float decay,
+                                 float scale, void* stream) {
+  int rc = gemm_check(xt, xt, cin, cin, tokens, dt, "moq_hessian_accum");
+  if (rc != MOQ_OK) return rc;
+  if (hessian == nullptr || (reinterpret_cast<uintptr_t>(hessian) & 15u) != 0) {
+    set_error("moq_hessian_accum: hessian must be a non-NULL 16-byte aligned pointer");
+    return MOQ_ERR_INVALID;
+  }
+  const int64_t nblk = launch_gemm<2>(xt, xt, nullptr, nullptr, hessian, nullptr, cin, cin, tokens, dt, 1, 0, 0, stream,
+                                      decay, scale);
+  if (nblk < 0) return (int)nblk;
+  return check_launch("moq_hessian_accum");
 }

@@ -22,7 +22,7 @@ from . import distributed as mdist
 from . import ops
 from .multi_tensor import SegmentTable
 from .nn import QuantLinear, is_quantized_linear
-from .tensor_quantizer import TensorQuantizer
+from .tensor_quantizer import SequentialQuantizer, TensorQuantizer
 
 
 def _quantizers(model):
@@ -60,7 +60,7 @@ def weight_only_quantize(model: nn.Module):
     batched = []
     for m in mods:
         wq = m.weight_quantizer
-        per_tensor_max = (wq._if_calib and wq.axis is None and wq.block_sizes is None
+        per_tensor_max = (isinstance(wq, TensorQuantizer) and wq._if_calib and wq.axis is None and wq.block_sizes is None
                           and type(wq._calibrator).__name__ == "MaxCalibrator" and m.weight.is_cuda
                           and m.weight.is_contiguous() and wq.pre_quant_scale is None)
         if per_tensor_max:
@@ -106,6 +106,8 @@ def promote_static_block_weight_quantizers(model: nn.Module) -> int:
         if not is_quantized_linear(m):
             continue
         wq = m.weight_quantizer
+        if isinstance(wq, SequentialQuantizer):
+            continue
         if (wq.is_enabled and wq.is_static_block_quant and wq.amax is not None and isinstance(wq._num_bits, int)
                 and not getattr(wq, "_is_static_block_scale_quantizer", False)):
             wq.promote_static_block()
@@ -489,11 +491,15 @@ def awq_clip(model: nn.Module, forward_loop, max_co_batch_size: int = 1024, max_
 def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwargs):
     """model_calib.py:1362-1391: awq_lite, awq_clip or both (awq_full)."""
     out = {}
-    if algorithm in ("awq_full", "awq_lite"):
-        lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step",)}
-        out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
-    if algorithm in ("awq_full", "awq_clip"):
-        clip_kw = {k: v for k, v in kwargs.items()
-                   if k in ("max_co_batch_size", "max_tokens_per_batch", "min_clip_ratio", "shrink_step", "debug")}
-        out["awq_clip"] = awq_clip(model, forward_loop, **clip_kw)
+    with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
+        if algorithm in ("awq_full", "awq_lite"):
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step",)}
+            out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
+        if algorithm in ("awq_full", "awq_clip"):
+            clip_kw = {k: v for k, v in kwargs.items()
+                       if k in ("max_co_batch_size", "max_tokens_per_batch", "min_clip_ratio", "shrink_step", "debug")}
+            out["awq_clip"] = awq_clip(model, forward_loop, **clip_kw)
+    for m in model.modules():  # every stage of a sequential weight quantizer is re-calibrated on the final weight (:1385-1391)
+        if is_quantized_linear(m) and isinstance(m.weight_quantizer, SequentialQuantizer):
+            max_calibrate(m, lambda linear: linear.weight_quantizer(linear.weight), distributed_sync=False)
     return out

@@ -9,7 +9,7 @@ from torch import nn
 
 from . import model_calib
 from .nn import replace_quant_module
-from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer
+from .tensor_quantizer import QuantizerAttributeConfig, SequentialQuantizer, TensorQuantizer
 
 # presets mirroring modelopt_recipes/configs/ptq/presets/model/{int8,fp8,int4_awq,mxfp4,int8_smoothquant}.yaml
 INT8_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
@@ -29,29 +29,58 @@ INT4_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits"
 MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*lm_head*": {"enable": False}}, "algorithm": None}
+# presets/model/w4a8_awq_beta.yaml quantizer layout (INT4 blocks then FP8 on the weights, FP8 inputs); calibrated with
+# "max" here -- the AWQ search with quantized inputs is outside this path
+W4A8_MAX_CFG = {"quant_cfg": {"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                                                    {"num_bits": (4, 3), "axis": None}],
+                              "*input_quantizer": {"num_bits": (4, 3), "axis": None},
+                              "*lm_head*": {"enable": False}}, "algorithm": "max"}
 INT8_SMOOTHQUANT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
                                       "*input_quantizer": {"num_bits": 8, "axis": None},
                                       "*lm_head*": {"enable": False}},
                         "algorithm": {"method": "smoothquant", "alpha": 1.0}}
 
 
+def _apply_attrs(mod: TensorQuantizer, attrs: dict):
+    attrs = dict(attrs)
+    enable = attrs.pop("enable", True)
+    if attrs:
+        mod.set_from_attribute_config(QuantizerAttributeConfig(**{"narrow_range": False, **attrs, "enable": enable}))
+    if enable:
+        mod.enable()
+    else:
+        mod.disable()
+
+
 def set_quantizer_by_cfg(model: nn.Module, quant_cfg: dict):
-    """conversion.py:245 set_quantizer_by_cfg: later wildcard entries override earlier ones."""
-    for name, mod in model.named_modules():
-        if not isinstance(mod, TensorQuantizer):
+    """conversion.py:245 set_quantizer_by_cfg: later wildcard entries override earlier ones.  A LIST of attribute
+    dicts turns the quantizer into a SequentialQuantizer with one member per entry (conversion.py:296-321)."""
+    for name, mod in list(model.named_modules()):
+        if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
             continue
+        if "." in name and isinstance(model.get_submodule(name.rpartition(".")[0]), SequentialQuantizer):
+            continue  # members are configured through their container
         for pattern, attrs in quant_cfg.items():
             if not fnmatch.fnmatch(name, pattern):
                 continue
-            attrs = dict(attrs)
-            enable = attrs.pop("enable", True)
-            if attrs:
-                mod.set_from_attribute_config(QuantizerAttributeConfig(**{"narrow_range": False, **attrs,
-                                                                          "enable": enable}))
-            if enable:
-                mod.enable()
+            parent = model.get_submodule(name.rpartition(".")[0]) if "." in name else model
+            attr = name.rpartition(".")[-1]
+            cur = getattr(parent, attr)
+            if isinstance(attrs, (list, tuple)):
+                if not isinstance(cur, SequentialQuantizer) or len(cur) != len(attrs):
+                    cur = SequentialQuantizer(*[TensorQuantizer() for _ in attrs])
+                    setattr(parent, attr, cur)
+                for q, a in zip(cur, attrs):
+                    _apply_attrs(q, a)
             else:
-                mod.disable()
+                if isinstance(cur, SequentialQuantizer):
+                    if set(attrs) <= {"enable"}:  # enable / disable broadcasts to the members
+                        for q in cur:
+                            _apply_attrs(q, attrs)
+                        continue
+                    cur = TensorQuantizer()
+                    setattr(parent, attr, cur)
+                _apply_attrs(cur, attrs)
 
 
 def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:

@@ -678,3 +678,53 @@ def mxfp4_dequantize(packed: torch.Tensor, e8m0: torch.Tensor, dtype: torch.dtyp
     with _on(p) as stream:
         check(_lib.lib().moq_mxfp4_unpack(_p(p), _p(e), _p(out), e.numel(), int(block_size), _dt(out), stream))
     return out
+
+
+# ----------------------------------------------------------------------------------------------- SparseGPT
+@torch.no_grad()
+def transpose16(x: torch.Tensor) -> torch.Tensor:
+    """x.t().contiguous() for a 2-D bf16 / f16 tensor (LDS-tiled)."""
+    _require_gpu(x, "transpose16")
+    if x.dim() != 2 or x.element_size() != 2:
+        raise MoquantUnsupported("transpose16: 2-D tensor of a 2-byte dtype expected")
+    xc = x.detach().contiguous()
+    y = torch.empty(xc.shape[1], xc.shape[0], dtype=xc.dtype, device=xc.device)
+    with _on(xc) as stream:
+        check(_lib.lib().moq_transpose16(_p(xc), _p(y), xc.shape[0], xc.shape[1], stream))
+    return y
+
+
+@torch.no_grad()
+def hessian_accum(hessian: torch.Tensor, inputs: torch.Tensor, decay: float, scale: float) -> torch.Tensor:
+    """hessian <- hessian * decay + scale * inputs^T @ inputs (fp32 [Cin, Cin], in place) for inputs [tokens, Cin]
+    in bf16 / f16: transpose + MFMA contraction (exact products, fp32 accumulation)."""
+    _require_gpu(inputs, "hessian_accum")
+    x2 = inputs.detach().reshape(-1, inputs.shape[-1])
+    cin = x2.shape[1]
+    if hessian.dtype != torch.float32 or tuple(hessian.shape) != (cin, cin) or not hessian.is_contiguous():
+        raise MoquantError("hessian_accum: hessian must be a contiguous fp32 [Cin, Cin] tensor")
+    if x2.dtype not in (torch.bfloat16, torch.float16) or cin % 4:
+        raise MoquantUnsupported("hessian_accum: bf16 / f16 inputs with Cin % 4 == 0 run on the MFMA path")
+    pad = (-x2.shape[0]) % 8  # zero tokens add nothing to X^T X
+    if pad:
+        x2 = torch.nn.functional.pad(x2, (0, 0, 0, pad))
+    xt = transpose16(x2)
+    with _on(xt) as stream:
+        check(_lib.lib().moq_hessian_accum(_p(xt), cin, xt.shape[1], _dt(xt), _p(hessian), float(decay), float(scale),
+                                           stream))
+    return hessian
+
+
+@torch.no_grad()
+def sgpt_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, prune_n: int = 2,
+                     prune_m: int = 4) -> torch.Tensor:
+    """In-place column sweep of create_sgpt_mask over block [i1, i1 + bs) (sparsegpt.py:96-127); returns delta."""
+    _require_gpu(w, "sgpt_block_sweep")
+    if w.dtype != torch.float32 or hinv.dtype != torch.float32 or not w.is_contiguous() or not hinv.is_contiguous():
+        raise MoquantError("sgpt_block_sweep: contiguous fp32 tensors expected")
+    rows, ld = w.shape
+    delta = torch.empty(rows, bs, dtype=torch.float32, device=w.device)
+    with _on(w) as stream:
+        check(_lib.lib().moq_sgpt_block_sweep(_p(w), rows, ld, int(i1), int(bs), _p(hinv), _p(delta), int(prune_n),
+                                              int(prune_m), stream))
+    return delta

@@ -57,3 +57,128 @@ def create_asp_mask(tensor: torch.Tensor, pattern: str = _PATTERN_2_4) -> torch.
     if back is not None:
         mask = back(mask)
     return mask.view(shape).to(dtype=torch.bool)
+
+
+# ------------------------------------------------------------------------------------------------ SparseGPT
+class HessianState:
+    """Running Hessian of one linear's inputs -- mod.hessian / mod.samples of SparseGPTSearcher
+    (sparsegpt.py:206-236): fp32 [Cin, Cin] on the weight's device."""
+
+    def __init__(self, cols: int, device):
+        self.hessian = torch.zeros(cols, cols, dtype=torch.float32, device=device)
+        self.samples = 0
+
+    @torch.no_grad()
+    def update(self, inp: torch.Tensor):
+        """_hook_compute_hessian (sparsegpt.py:238-276) for a linear: H <- H * s/(s+b) + (2/(s+b)) X^T X with b the
+        batch dimension of the input.  16-bit inputs: transpose + MFMA contraction (ops.hessian_accum); fp32 inputs:
+        the library's fp32 GEMM, like the reference."""
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        b = inp.shape[0]
+        x2 = inp.reshape(-1, inp.shape[-1])
+        decay = self.samples / (self.samples + b)
+        self.samples += b
+        scale = 2.0 / self.samples
+        if x2.dtype in (torch.bfloat16, torch.float16) and x2.shape[1] % 4 == 0:
+            ops.hessian_accum(self.hessian, x2, decay, scale)
+        else:
+            xf = x2.float()
+            self.hessian.mul_(decay).addmm_(xf.t(), xf, alpha=scale)
+
+
+def invert(hessian: torch.Tensor) -> torch.Tensor:
+    """sparsegpt.py:30-42: upper Cholesky factor of H^-1."""
+    try:
+        h = torch.linalg.cholesky(hessian)
+        h = torch.cholesky_inverse(h)
+        h = torch.linalg.cholesky(h, upper=True)
+    except RuntimeError:
+        eps = 1e-6 * torch.eye(hessian.size(0), device=hessian.device)
+        h = torch.cholesky_inverse(torch.linalg.cholesky(hessian + eps))
+    return h
+
+
+def prepare(tensor: torch.Tensor, hessian: torch.Tensor, hessian_damp: float):
+    """sparsegpt.py:45-69: dead columns, damping, inverse factor.  Returns (fp32 working weight, hinv)."""
+    weight = tensor.detach().clone()
+    hessian = hessian.to(weight.device).clone()
+    if weight.dim() == 4:
+        weight = weight.flatten(1)
+    zero = torch.diag(hessian) == 0
+    hessian[zero, zero] = 1
+    weight[:, zero] = 0
+    damp = hessian_damp * torch.mean(torch.diag(hessian))
+    diag = torch.arange(weight.size(1), device=hessian.device)
+    hessian[diag, diag] += damp
+    return weight, invert(hessian).contiguous()
+
+
+@torch.no_grad()
+def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, hessian_inv: torch.Tensor | None = None):
+    """sparsegpt.py:72-133.  The per-column Python loop of the reference is one kernel per column block
+    (ops.sgpt_block_sweep); the trailing-block update is an fp32 library GEMM as in the reference.
+    `hessian_inv` short-cuts prepare() with an already prepared factor (tests)."""
+    shape = tensor.size()
+    is_nm, n, m = get_nmprune_info(config.get("pattern", _PATTERN_2_4))
+    if not is_nm:
+        raise NotImplementedError("SparseGPT: only n:m patterns produce a mask (sparsegpt.py:111-115)")
+    if hessian_inv is None:
+        weight, hessian_inv = prepare(tensor, hessian, config.get("hessian_damp", 0.1))
+    else:
+        weight = tensor.detach().clone().flatten(1) if tensor.dim() == 4 else tensor.detach().clone()
+    rows, cols = weight.size()
+    col_bs = config.get("col_block_size", 128)
+    row_bs = config.get("row_block_size", -1)
+    if row_bs == -1:
+        row_bs = rows
+    for r1 in range(0, rows, row_bs):
+        r2 = min(r1 + row_bs, rows)
+        w_rows = weight[r1:r2].float().contiguous()
+        for i1 in range(0, cols, col_bs):
+            i2 = min(i1 + col_bs, cols)
+            delta = ops.sgpt_block_sweep(w_rows, i1, i2 - i1, hessian_inv, n, m)
+            if i2 < cols:
+                w_rows[:, i2:] -= delta.matmul(hessian_inv[i1:i2, i2:])
+        weight[r1:r2] = w_rows.to(weight.dtype)
+    return (weight != 0).view(shape)
+
+
+def check_weight_size_sgpt(weight: torch.Tensor, pattern: str = _PATTERN_2_4, mod_name: str = "") -> bool:
+    """SparseGPTSearcher._check_weight_size (sparsegpt.py:152-165)."""
+    _, _, m = get_nmprune_info(pattern)
+    if weight.size(0) % m != 0 or weight.size(1) % m != 0:
+        warnings.warn(f"Skipping pruning {mod_name} of size={weight.size()!s} and type={weight.dtype!s} for SparseGPT")
+        return False
+    return True
+
+
+@torch.no_grad()
+def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loop=None, config: dict | None = None):
+    """mts.sparsify for the two modes of the path (sparsification.py:32-97): every eligible nn.Linear gets a bool
+    `_weight_mask` buffer and its weight is masked in place (the reference's SparseModule multiplies on access).
+    "sparsegpt": forward hooks accumulate the input Hessians during forward_loop, then create_sgpt_mask."""
+    cfg = {"pattern": _PATTERN_2_4, "col_block_size": 128, "row_block_size": -1, "hessian_damp": 0.1, **(config or {})}
+    linears = [(n, m) for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)]
+    if mode == "sparse_magnitude":
+        targets = [(n, m) for n, m in linears if check_weight_size(m.weight, n)]
+        masks = {m: create_asp_mask(m.weight, cfg["pattern"]) for _, m in targets}
+    elif mode == "sparsegpt":
+        assert forward_loop is not None, "Please provide `data_loader` or `forward_loop`!"
+        targets = [(n, m) for n, m in linears if check_weight_size_sgpt(m.weight, cfg["pattern"], n)]
+        states = {m: HessianState(m.weight.size(1), m.weight.device) for _, m in targets}
+        handles = [m.register_forward_hook(lambda mod, inp, out: states[mod].update(inp[0] if isinstance(inp, tuple) else inp))
+                   for _, m in targets]
+        try:
+            forward_loop(model)
+        finally:
+            for h in handles:
+                h.remove()
+        masks = {m: create_sgpt_mask(m.weight, states[m].hessian, cfg) for _, m in targets}
+    else:
+        raise ValueError(f"sparsity mode {mode!r} is outside this path")
+    for _, m in targets:
+        mask = masks[m]
+        m.register_buffer("_weight_mask", mask)
+        m.weight.data.mul_(mask.to(m.weight.dtype))
+    return model

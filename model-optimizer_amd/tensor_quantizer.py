@@ -348,3 +348,55 @@ class TensorQuantizer(nn.Module):
                 f"amax={'dynamic' if self.amax is None else tuple(self.amax.shape)} "
                 f"calibrator={type(self._calibrator).__name__} quant={'on' if self._if_quant else 'off'}"
                 f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")
+
+
+class SequentialQuantizer(nn.Sequential):
+    """A chain of TensorQuantizers applied one after the other to the same tensor (W4A8: INT4 blocks, then FP8) --
+    nn/modules/tensor_quantizer.py:1797-1862.  Methods are broadcast to every member, properties come from the
+    first one, like the reference's _QuantizerContainerBase delegation."""
+
+    _BROADCAST = ("disable", "enable", "enable_calib", "disable_calib", "enable_quant", "disable_quant",
+                  "reset_amax", "load_calib_amax")
+
+    def __init__(self, *quantizers: TensorQuantizer):
+        super().__init__(*quantizers)
+        assert all(isinstance(q, TensorQuantizer) for q in self), "All quantizers must be a TensorQuantizer."
+
+    def __getattr__(self, name):
+        if name in SequentialQuantizer._BROADCAST:
+            def call(*args, **kwargs):
+                out = None
+                for q in self:
+                    out = getattr(q, name)(*args, **kwargs)
+                return out  # the last member's result (_format_delegated_method_outputs, :1825)
+            return call
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if len(self) and not name.startswith("__"):
+                return getattr(self[0], name)  # first member wins
+            raise
+
+    @staticmethod
+    def convert_to_single_quantizer(model, indx: int = 0):
+        """Context manager: every SequentialQuantizer in `model` is replaced by its member `indx` (used to calibrate
+        the members individually, e.g. the AWQ search on the INT4 stage) -- :1836-1862."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            saved = []
+            for name, module in list(model.named_modules()):
+                if isinstance(module, SequentialQuantizer):
+                    assert len(module) > indx
+                    parent = model.get_submodule(name.rpartition(".")[0])
+                    attr = name.rpartition(".")[-1]
+                    saved.append((parent, attr, module))
+                    setattr(parent, attr, module[indx])
+            try:
+                yield
+            finally:
+                for parent, attr, module in saved:
+                    setattr(parent, attr, module)
+
+        return ctx()

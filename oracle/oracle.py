@@ -305,3 +305,27 @@ def mxfp4_unpack(packed, e8m0, dtype, block=32):
     out = _empty_like_np(torch.empty(p.size * 2, dtype=dtype))
     lib().orc_mxfp4_unpack(_p(p), _p(e), _p(out), I64(e.size), int(block), DT[dtype])
     return _from_np(out, dtype, (*packed.shape[:-1], packed.shape[-1] * 2))
+
+
+def sgpt_block_sweep(w, i1, bs, hinv, prune_n=2, prune_m=4):
+    """In-place column sweep of create_sgpt_mask over block [i1, i1 + bs) (sparsegpt.py:96-127); returns delta."""
+    assert w.dtype == torch.float32 and w.is_contiguous() and hinv.dtype == torch.float32 and bs <= 1024
+    rows, ld = w.shape
+    wa = w.numpy()
+    ha = np.ascontiguousarray(hinv.numpy())
+    delta = np.zeros((rows, bs), dtype=np.float32)
+    lib().orc_sgpt_block_sweep(_p(wa), I64(rows), I64(ld), I64(i1), int(bs), _p(ha), _p(delta), int(prune_n),
+                               int(prune_m))
+    return torch.from_numpy(delta)
+
+
+def create_sgpt_mask(weight, hinv, prune_n=2, prune_m=4, col_bs=128):
+    """create_sgpt_mask (sparsegpt.py:72-133) given the prepared inverse-Hessian factor: mask = pruned weight != 0."""
+    w = weight.detach().float().clone().contiguous()
+    cols = w.shape[1]
+    for i1 in range(0, cols, col_bs):
+        i2 = min(i1 + col_bs, cols)
+        delta = sgpt_block_sweep(w, i1, i2 - i1, hinv, prune_n, prune_m)
+        if i2 < cols:
+            w[:, i2:] -= delta.matmul(hinv[i1:i2, i2:])
+    return w.to(weight.dtype) != 0

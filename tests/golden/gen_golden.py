@@ -17,6 +17,8 @@ What is produced (every array is the reference's own output on seeded inputs tha
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
+  sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
+  w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
@@ -463,6 +465,67 @@ def gen_qtensor(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_w4a8(out):
+    """SequentialQuantizer flow: the W4A8 quantizer layout (INT4 g128 blocks then FP8 per tensor on the weights, FP8
+    inputs; presets/model/w4a8_awq_beta.yaml) calibrated with algorithm "max" on the tiny MLP."""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+
+    cases = {}
+    for name, dt in [("w4a8_f32", torch.float32), ("w4a8_bf16", torch.bfloat16)]:
+        model = _TinyMLP(dtype=dt, seed=21)
+        batches = _calib_batches(128, dt, 23)
+        out[f"{name}_w1"], out[f"{name}_w2"], out[f"{name}_b2"] = bits(model.fc1.weight), bits(model.fc2.weight), bits(model.fc2.bias)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+        cfg = copy.deepcopy(mtq.W4A8_AWQ_BETA_CFG)
+        cfg["algorithm"] = "max"
+        q = mtq.quantize(copy.deepcopy(model), cfg, lambda m: [m(b) for b in batches])
+        info = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches))
+        for lname in ("fc1", "fc2"):
+            lin = getattr(q, lname)
+            wq = lin.weight_quantizer
+            info[f"{lname}_n_stages"] = len(wq)
+            for i, st in enumerate(wq):
+                out[f"{name}_{lname}_w{i}_amax"] = bits(st._amax.float())
+                info[f"{lname}_w{i}_amax_shape"] = list(st._amax.shape)
+            out[f"{name}_{lname}_in_amax"] = bits(lin.input_quantizer._amax.float())
+            out[f"{name}_{lname}_wq"] = bits(wq(lin.weight))
+        out[f"{name}_y"] = bits(q(batches[0]))
+        cases[name] = info
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_sgpt(out):
+    """SparseGPT (sparsity/weight_sparsity/sparsegpt.py): Hessian accumulated by the reference's forward hook over
+    seeded activation batches, prepare() (damping + Cholesky inverse) and create_sgpt_mask, all run on CPU."""
+    from modelopt.torch.sparsity.weight_sparsity import sparsegpt
+
+    cases = {}
+    for name, dt, co, ci, ntok in [("sgpt_f32", torch.float32, 64, 256, 96), ("sgpt_bf16", torch.bfloat16, 96, 384, 128)]:
+        w = weight_like((co, ci), dt, 1700 + co)
+        g = torch.Generator().manual_seed(1701 + ci)
+        ch = torch.exp(torch.randn(ci, generator=g) * 0.7)
+        batches = [(torch.randn(ntok, ci, generator=g) * ch).to(dt) for _ in range(3)]
+        mod = type("Linear", (), {})()  # the hook looks at type(mod).__name__
+        mod.hessian, mod.samples = torch.zeros(ci, ci, dtype=torch.float32), 0
+        for b in batches:
+            sparsegpt.SparseGPTSearcher._hook_compute_hessian(mod, (b.clone().unsqueeze(0),), None)
+        cfg = {"pattern": "2:4 sparsity", "col_block_size": 128, "row_block_size": -1, "hessian_damp": 0.1}
+        hessian = mod.hessian.clone()
+        _, hinv = sparsegpt.prepare(w, hessian.clone(), cfg["hessian_damp"])
+        mask = sparsegpt.create_sgpt_mask(w, hessian.clone(), cfg)
+        out[f"{name}_w"] = bits(w)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+        out[f"{name}_hessian"], out[f"{name}_hinv"] = bits(hessian), bits(hinv)
+        out[f"{name}_mask"] = mask.numpy().astype(np.uint8)
+        cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches), samples=int(mod.samples),
+                           kept=float(mask.float().mean()))
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def extract_mx_vectors():
     """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
     path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
@@ -621,11 +684,11 @@ def gen_export(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

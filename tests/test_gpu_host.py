@@ -203,3 +203,27 @@ def test_multi_tensor_weight_calibration_in_quantize():
     q = moa.quantize(model, model_quant.FP8_DEFAULT_CFG, lambda m: m(torch.randn(8, 256, device=DEV).to(torch.bfloat16)))
     for lin in q:
         assert lin.weight_quantizer._amax.item() == lin.weight.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["w4a8_f32", "w4a8_bf16"])
+def test_sequential_quantizer_w4a8_matches_reference(golden, name):
+    """SequentialQuantizer (INT4 g128 blocks, then FP8 per tensor) on the weights + FP8 inputs, max calibration:
+    per-stage amax and the chained fake-quantized weight equal the reference's (weights: bit-exact)."""
+    g = golden("w4a8")
+    c = g.cases[name]
+    dt = getattr(torch, c["dtype"])
+    model = TinyMLP(g.t(f"{name}_w1", dt), g.t(f"{name}_w2", dt), g.t(f"{name}_b2", dt)).to(DEV)
+    batches = [g.t(f"{name}_x{i}", dt).to(DEV) for i in range(c["n_batches"])]
+    q = moa.quantize(model, copy.deepcopy(model_quant.W4A8_MAX_CFG), lambda m: [m(b) for b in batches])
+    for lname in ("fc1", "fc2"):
+        lin = getattr(q, lname)
+        wq = lin.weight_quantizer
+        assert isinstance(wq, moa.tensor_quantizer.SequentialQuantizer) and len(wq) == c[f"{lname}_n_stages"]
+        for i, st in enumerate(wq):
+            want = g.t(f"{name}_{lname}_w{i}_amax")
+            assert list(st._amax.shape) == c[f"{lname}_w{i}_amax_shape"]
+            assert_bits_equal(st._amax.float().cpu().reshape(want.shape), want, f"{name} {lname} stage {i} amax")
+        assert_bits_equal(wq(lin.weight).cpu(), g.t(f"{name}_{lname}_wq", dt), f"{name} {lname} chained QDQ")
+        tol = 1e-6 if lname == "fc1" else (1e-4 if dt == torch.float32 else 2e-2)
+        _close(lin.input_quantizer._amax, g.t(f"{name}_{lname}_in_amax"), tol, f"{name} {lname} input amax")
+    _close(q(batches[0]), g.t(f"{name}_y", dt), 0.3 if dt == torch.bfloat16 else 2e-2, f"{name} forward")
