@@ -9,6 +9,7 @@ libmoquant.so (include/moquant.h).  Mirrors the reference's plugin surface for t
   nn, model_quant, model_calib   QuantLinear, quantize(), max_calibrate / smoothquant / awq_lite
   sparsity         create_asp_mask (2:4 magnitude)
   qtensor          INT4QTensor / FP8QTensor / MXFP4QTensor real quantisation (pack / unpack kernels)
+  layerwise        layer-by-layer calibration with checkpoint / resume
   export           resmooth / layernorm fusion / INT4 nibble packing of the checkpoint export (byte-identical)
   distributed      bucketed all-reduce of amax / histograms / AWQ statistics (RCCL via torch.distributed)
   modelopt_plugin  install() -- the seams into an unmodified modelopt checkout
@@ -28,10 +29,11 @@ from . import model_quant  # noqa: F401
 from . import sparsity  # noqa: F401
 from . import export  # noqa: F401
 from . import qtensor  # noqa: F401
+from . import layerwise  # noqa: F401
 from . import modelopt_plugin  # noqa: F401
 from .model_quant import quantize  # noqa: F401
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
 __all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "distributed", "model_calib", "model_quant",
-           "sparsity", "export", "qtensor", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
+           "sparsity", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
            "MoquantError", "MoquantUnsupported"]

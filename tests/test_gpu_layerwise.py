@@ -1,0 +1,94 @@
+"""Layer-by-layer calibration: same statistics as a whole-model pass, checkpoint / resume."""
+
+import copy
+
+import pytest
+import torch
+
+import _moa_import
+
+pytestmark = pytest.mark.gpu
+moa = _moa_import.load()
+from model_optimizer_amd import layerwise, model_calib, model_quant  # noqa: E402
+
+DEV = "cuda:0"
+
+
+class Block(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(d, 2 * d, bias=False)
+        self.fc2 = torch.nn.Linear(2 * d, d, bias=False)
+
+    def forward(self, h, scale=1.0):
+        return h + scale * self.fc2(torch.nn.functional.gelu(self.fc1(h)))
+
+
+class Stack(torch.nn.Module):
+    def __init__(self, d=128, n=4):
+        super().__init__()
+        self.embed = torch.nn.Linear(d, d, bias=False)
+        self.layers = torch.nn.ModuleList([Block(d) for _ in range(n)])
+
+    def forward(self, x):
+        h = self.embed(x)
+        for layer in self.layers:
+            h = layer(h, scale=0.5)
+        return h
+
+
+def _setup(cfg):
+    torch.manual_seed(0)
+    model = Stack().to(DEV).to(torch.bfloat16)
+    batches = [torch.randn(16, 128, device=DEV).to(torch.bfloat16) for _ in range(3)]
+    moa.nn.replace_quant_module(model)
+    q_cfg = {k: v for k, v in cfg["quant_cfg"].items()}
+    q_cfg["*embed*"] = {"enable": False}
+    model_quant.set_quantizer_by_cfg(model, q_cfg)
+    return model, batches
+
+
+def _amax(model):
+    return {n: q._amax.detach().float().cpu().clone() for n, q in model.named_modules()
+            if isinstance(q, moa.TensorQuantizer) and hasattr(q, "_amax")}
+
+
+@pytest.mark.parametrize("cfg", [model_quant.FP8_DEFAULT_CFG, model_quant.INT4_BLOCKWISE_WEIGHT_ONLY_CFG])
+def test_layerwise_max_equals_whole_model_max(cfg):
+    model, batches = _setup(cfg)
+    whole = copy.deepcopy(model)
+    model_calib.max_calibrate(whole, lambda m: [m(b) for b in batches])
+    n = layerwise.layerwise_calibrate(model, lambda m: [m(b) for b in batches], model_calib.max_calibrate)
+    assert n == 4
+    a, b = _amax(whole), _amax(model)
+    assert set(a) == set(b) and len(a) >= 8
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: layerwise amax differs from the whole-model pass"
+
+
+def test_layerwise_resume(tmp_path):
+    cfg = model_quant.FP8_DEFAULT_CFG
+    model, batches = _setup(cfg)
+    ref = copy.deepcopy(model)
+    layerwise.layerwise_calibrate(ref, lambda m: [m(b) for b in batches], model_calib.max_calibrate)
+    calls = {"n": 0}
+
+    def flaky(layer, loop, **kw):
+        if calls["n"] == 2:
+            raise KeyboardInterrupt
+        calls["n"] += 1
+        model_calib.max_calibrate(layer, loop, **kw)
+
+    m1 = copy.deepcopy(model)
+    with pytest.raises(KeyboardInterrupt):
+        layerwise.layerwise_calibrate(m1, lambda m: [m(b) for b in batches], flaky, checkpoint_dir=str(tmp_path))
+    m2 = copy.deepcopy(model)  # a fresh process: nothing calibrated yet
+    n = layerwise.layerwise_calibrate(m2, lambda m: [m(b) for b in batches], model_calib.max_calibrate,
+                                      checkpoint_dir=str(tmp_path))
+    assert n == 2, "resume must start at the first unfinished layer"
+    a, b = _amax(ref), _amax(m2)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: resumed run differs"
+    assert layerwise.layerwise_calibrate(m2, lambda m: [m(b) for b in batches], model_calib.max_calibrate,
+                                         checkpoint_dir=str(tmp_path)) == 0
