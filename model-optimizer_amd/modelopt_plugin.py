@@ -8,7 +8,8 @@
       surface (tensor_quant.cpp:63-77, tensor_quant_gpu_fp8.cu:109-114, tensor_quant_mx.cu:393-411).  On ROCm
       the loader otherwise returns None (utils/cpp_extension.py:57-58) and modelopt runs eager ops.
   S3  quant backend     : register_quant_backend("mi355x", entrypoint) -- a fused per-quantizer path.
-  S5  sparsity          : magnitude.create_asp_mask is re-pointed at our mask kernel.
+  S5  sparsity          : magnitude.create_asp_mask, sparsegpt.create_sgpt_mask and the SparseGPT Hessian hook are
+                          re-pointed at our kernels.
   S6  utilities         : core_utils.reduce_amax (and its re-export) is re-pointed at our reductions.
 
 Nothing here imports modelopt at module import time; `install()` raises ImportError if it is absent.
@@ -115,6 +116,32 @@ def _asp_mask_seam(original):
     return create_asp_mask
 
 
+def _sgpt_mask_seam(original):
+    def create_sgpt_mask(tensor, hessian, config):
+        if not tensor.is_cuda:
+            return original(tensor, hessian, config)
+        return sparsity.create_sgpt_mask(tensor, hessian, dict(config))
+
+    return create_sgpt_mask
+
+
+def _sgpt_hessian_seam(original):
+    """SparseGPTSearcher._hook_compute_hessian (sparsegpt.py:238-276): 16-bit GPU activations of a linear take the
+    MFMA accumulation; everything else (CPU Hessians, conv layers, fp32 inputs) stays on the reference's code."""
+
+    def hook(cls, mod, inp, out):
+        x = inp[0] if isinstance(inp, tuple) else inp
+        if not ("Linear" in type(mod).__name__ and x.is_cuda and mod.hessian.is_cuda
+                and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 4 == 0):
+            return original.__func__(cls, mod, inp, out)
+        b = 1 if x.dim() == 2 else x.shape[0]
+        decay = mod.samples / (mod.samples + b)
+        mod.samples += b
+        ops.hessian_accum(mod.hessian, x.reshape(-1, x.shape[-1]), decay, 2.0 / mod.samples)
+
+    return classmethod(hook)
+
+
 def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True):
     """Wire the seams into an importable modelopt.  Returns the list of seams installed."""
     import modelopt.torch.quantization.extensions as ext  # ImportError if modelopt is absent
@@ -148,4 +175,13 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
             seam._moq_seam = True
             magnitude.create_asp_mask = seam
         installed.append("S5:create_asp_mask")
+        from modelopt.torch.sparsity.weight_sparsity import sparsegpt
+
+        if not getattr(sparsegpt.create_sgpt_mask, "_moq_seam", False):
+            seam = _sgpt_mask_seam(sparsegpt.create_sgpt_mask)
+            seam._moq_seam = True
+            sparsegpt.create_sgpt_mask = seam
+            sparsegpt.SparseGPTSearcher._hook_compute_hessian = _sgpt_hessian_seam(
+                sparsegpt.SparseGPTSearcher.__dict__["_hook_compute_hessian"])
+        installed.append("S5:create_sgpt_mask")
     return installed

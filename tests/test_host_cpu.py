@@ -91,7 +91,8 @@ def test_modelopt_seams_install():
         pytest.skip("reference checkout not present (GPU box)")
     ref_shim.install()
     installed = moa.modelopt_plugin.install()
-    assert installed == ["S1:extensions", "S3:backend=mi355x", "S6:reduce_amax", "S5:create_asp_mask"]
+    assert installed == ["S1:extensions", "S3:backend=mi355x", "S6:reduce_amax", "S5:create_asp_mask",
+                         "S5:create_sgpt_mask"]
     import modelopt.torch.quantization.extensions as ext
     from modelopt.torch.quantization.nn.modules import tensor_quantizer as ref_tq
     from modelopt.torch.quantization.utils import core_utils
@@ -112,3 +113,14 @@ def test_modelopt_seams_install():
     m = torch.nn.Sequential(torch.nn.Linear(16, 16))
     mtq.quantize(m, mtq.INT8_DEFAULT_CFG, lambda mod: mod(torch.randn(2, 16)))
     assert m[0].weight_quantizer.amax is not None
+    # SparseGPT seams: CPU tensors keep running the reference's own code through the re-pointed functions
+    from modelopt.torch.sparsity.weight_sparsity import sparsegpt
+
+    lin = type("Linear", (), {})()
+    lin.hessian, lin.samples = torch.zeros(16, 16), 0
+    sparsegpt.SparseGPTSearcher._hook_compute_hessian(lin, (torch.randn(1, 8, 16),), None)
+    assert lin.samples == 1 and lin.hessian.abs().sum() > 0
+    mask = sparsegpt.create_sgpt_mask(torch.randn(8, 16), lin.hessian + torch.eye(16),
+                                      {"pattern": "2:4 sparsity", "col_block_size": 128, "row_block_size": -1,
+                                       "hessian_damp": 0.1})
+    assert mask.dtype == torch.bool and (mask.view(8, -1, 4).sum(-1) <= 2).all()
