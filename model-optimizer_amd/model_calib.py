@@ -277,6 +277,9 @@ class AWQLiteHelper:
         self._scale_dt = None
         self._w_hat = None
         self._cache_w = False
+        # Gram-matrix search: G = sum_b X_b^T X_b / T_b (fp32 [Cin, Cin]), accumulated in the cache pass
+        self.gram = None
+        self.use_gram = False
 
     def search_operands(self, module):
         """(inv_s [A, Cin] fp32 = (1/s_alpha) rounded to the weight dtype, w_hat [A, Cout, Cin] = QDQ(W * s_alpha))
@@ -300,10 +303,43 @@ class AWQLiteHelper:
         self._inv_scale = self._scale_dt = self._w_hat = None
 
 
+def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
+    """All per-alpha losses of one linear from its Gram matrix, without touching the activations again.
+
+    The reference's loss (model_calib.py:1489-1495, :1552-1556) is sum_b mean_{t,n} (out_alpha - out_actual)^2 with
+    out_alpha = (x * 1/s) @ QDQ(W * s)^T and out_actual = x @ W^T, i.e. out_alpha - out_actual = x @ E^T with the
+    fp32 error weight E = QDQ(W * s) * (1/s) - W.  Hence  sum_b ||X_b E^T||_F^2 / (T_b N) = trace(E G E^T) / N  with
+    G = sum_b X_b^T X_b / T_b: the 11 GEMMs over every calibration token become 11 Cout x Cin x Cin contractions that
+    do not depend on the number of tokens (Llama-3-8B, 512 x 512 tokens: 4.4e16 -> 0.6e16 FLOP including the Gram
+    accumulation).  What it leaves out is the reference's rounding of x/s, out_alpha and out_actual to the model
+    dtype -- a noise floor ~1e-3 below the INT4 error energy (fp32 models agree to 4e-7, bf16 within 1e-2 on the
+    reference fixtures, same best alpha; tests/test_gpu_host.py, tests/test_gpu_awq_search.py)."""
+    w = module.weight
+    dt = w.dtype
+    wf = w.float()
+    n_out = w.shape[0]
+    bits = module.weight_quantizer.num_bits
+    for i, alpha in enumerate(h.alphas):
+        s = get_scale(h.act_scale, h.weight_scale, alpha)
+        r = (1 / s).to(dt).float()  # input_quantizer.pre_quant_scale as the forward uses it (:1551)
+        w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
+        err = w_hat.float().mul_(r).sub_(wf)
+        h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
+    h.num_search_steps = h.num_cache_steps
+
+
 @torch.no_grad()
-def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
+def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto"):
     """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
-    (the INT4_AWQ_CFG preset).  Two passes of forward_loop: cache (act scales), search (alpha grid)."""
+    (the INT4_AWQ_CFG preset).
+
+    search = "gemm": the reference's structure -- two passes of forward_loop (cache: act scales; search: for every
+             alpha the patched forward's GEMM, here one batched MFMA error-GEMM launch per linear and batch);
+    search = "gram": ONE pass of forward_loop that also accumulates every linear's Gram matrix on the matrix cores
+             (ops.hessian_accum); all alpha losses then come from trace(E G E^T) (see _gram_losses);
+    search = "auto" (default): "gram" for the linears whose Gram matrix fits the HBM budget, "gemm" for the rest."""
+    if search not in ("auto", "gram", "gemm"):
+        raise ValueError(f"awq_lite: unknown search mode {search!r}")
     mods = [(n, m) for n, m in model.named_modules()
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
@@ -312,7 +348,12 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
             h = helpers[m]
-            h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
+            cin = m.weight.shape[1]
+            if search != "gemm" and cin % 4 == 0 and (search == "gram" or budget.reserve(4 * cin * cin)):
+                h.gram = torch.zeros(cin, cin, dtype=torch.float32, device=m.weight.device)
+                h.use_gram = True
+            else:
+                h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
 
     def patched_forward(self, input):
         h = helpers[self]
@@ -326,7 +367,15 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             h.act_sum += (ssum / x2.shape[0]).to(input.dtype).float()
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
+            if h.gram is not None:
+                if x2.dtype in (torch.bfloat16, torch.float16):
+                    ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0])  # G += X^T X / T_b on the matrix cores
+                else:
+                    xf = x2.float()
+                    h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
             return out_actual
+        if h.use_gram:
+            return out_actual  # this linear's losses came from its Gram matrix
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
         inv_s, w_hat = h.search_operands(self)
         if ops.mfma_gemm_supported(x2, self.weight):
@@ -354,8 +403,14 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             # DP: act_scale AVG in ONE bucket (reference: one all_reduce per linear, :1588-1593)
             mdist.all_reduce_bucket([h.act_scale for h in helpers.values() if h.act_scale is not None],
                                     dist.ReduceOp.SUM, average=True)
-        state["mode"] = "search"
-        forward_loop(model)  # search pass
+        for _, m in mods:  # Gram-matrix linears: losses now (local Gram; the loss is linear in it, summed below)
+            h = helpers[m]
+            if h.gram is not None and h.act_scale is not None:
+                _gram_losses(h, m)
+                h.gram = None  # release Cin^2 floats as soon as the linear is done
+        if any(not h.use_gram and h.act_scale is not None for h in helpers.values()):
+            state["mode"] = "search"
+            forward_loop(model)  # search pass for the linears on the error-GEMM path
         if dist.is_available() and dist.is_initialized():
             # every rank must pick the same alpha: SUM the per-alpha losses in one bucket
             mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()], dist.ReduceOp.SUM)
@@ -364,6 +419,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1):
             m.forward = f
         for h in helpers.values():
             h.release()
+            h.gram = None
     for _, m in mods:
         h = helpers[m]
         if h.act_scale is None:
@@ -493,7 +549,7 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
     out = {}
     with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
         if algorithm in ("awq_full", "awq_lite"):
-            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step",)}
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search")}
             out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
         if algorithm in ("awq_full", "awq_clip"):
             clip_kw = {k: v for k, v in kwargs.items()

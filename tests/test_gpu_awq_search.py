@@ -1,0 +1,66 @@
+"""AWQ-lite search modes on the GPU: the Gram-matrix search (one forward pass, trace(E G E^T)) against the error-GEMM
+search (the reference's structure: one fused MFMA GEMM per alpha and batch) on Llama-shaped random linears -- same
+best alpha, losses within the reference's own bf16 rounding floor."""
+
+import copy
+
+import pytest
+import torch
+
+import _moa_import
+
+pytestmark = pytest.mark.gpu
+moa = _moa_import.load()
+from model_optimizer_amd import model_quant  # noqa: E402
+
+DEV = "cuda:0"
+
+
+class Stack(torch.nn.Module):
+    def __init__(self, dims, dtype):
+        super().__init__()
+        g = torch.Generator().manual_seed(7)
+        self.linears = torch.nn.ModuleList()
+        for co, ci in dims:
+            lin = torch.nn.Linear(ci, co, bias=False)
+            with torch.no_grad():
+                w = torch.randn(co, ci, generator=g) * 0.02
+                lin.weight.copy_(torch.where(torch.rand(co, ci, generator=g) < 0.001, w * 8, w))
+            self.linears.append(lin)
+        self.to(dtype)
+
+    def forward(self, xs):
+        return [lin(x) for lin, x in zip(self.linears, xs)]
+
+
+def _batches(dims, dtype, n, tokens):
+    g = torch.Generator().manual_seed(11)
+    out = []
+    for _ in range(n):
+        xs = []
+        for _, ci in dims:
+            ch = torch.exp(torch.randn(ci, generator=g))
+            ch[:4] *= 50
+            xs.append((torch.randn(tokens, ci, generator=g) * ch).to(dtype).to(DEV))
+        out.append(xs)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_gram_search_equals_gemm_search(dtype):
+    dims = [(512, 1024), (1024, 512), (256, 1536)]
+    batches = _batches(dims, dtype, 3, 200)  # 200 tokens: exercises the pad-to-8 of the transpose + MFMA path
+    results = {}
+    for mode in ("gemm", "gram"):
+        model = Stack(dims, dtype).to(DEV)
+        cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+        cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": mode}
+        q = moa.quantize(model, cfg, lambda m: [m(b) for b in batches])
+        results[mode] = [(lin.awq_lite.best_alpha, lin.awq_lite.loss_buf.cpu().clone(), lin.weight.detach().cpu().clone(),
+                          lin.awq_lite.num_search_steps) for lin in q.linears]
+    for (a_gemm, l_gemm, w_gemm, _), (a_gram, l_gram, w_gram, steps) in zip(results["gemm"], results["gram"]):
+        rel = ((l_gram - l_gemm).abs() / l_gemm).max().item()
+        assert rel <= (1e-4 if dtype == torch.float32 else 2e-2), f"{dtype}: Gram vs GEMM loss differs by {rel:.3e}"
+        assert a_gram == a_gemm, f"{dtype}: best alpha {a_gram} (gram) vs {a_gemm} (gemm)"
+        assert torch.equal(w_gram, w_gemm)  # same alpha -> identical folded weights
+        assert steps == 3
