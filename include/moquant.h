@@ -306,12 +306,17 @@ int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void* out, int6
 int moq_transpose16(const void* x, void* y, int64_t rows, int64_t cols, void* stream);
 /* hessian[i, j] = hessian[i, j] * decay + scale * sum_t xt[i, t] * xt[j, t]   (fp32 [cin, cin], updated in place)
  * on the matrix cores: bf16 / f16 products are exact in fp32, accumulation is fp32 -- the arithmetic of the
- * reference's fp32 `inp.matmul(inp.t())` up to summation order.  One calibration batch of
+ * reference's fp32 `inp.matmul(inp.t())` up to summation order (only the tiles on or above the diagonal are
+ * contracted, the mirror images are written from the transposed accumulators).  One calibration batch of
  * SparseGPTSearcher._hook_compute_hessian (sparsity/weight_sparsity/sparsegpt.py:238-276): decay =
  * samples / (samples + new), scale = 2 / (samples + new).  xt: [cin, tokens] (dt = MOQ_BF16 | MOQ_F16, 16-byte
- * aligned, tokens % 8 == 0, cin % 4 == 0). */
+ * aligned, tokens % 8 == 0, cin % 4 == 0).
+ * upper_only != 0: only the tiles on / above the diagonal are updated (half the contraction, no mirrored writes);
+ * call moq_symmetrize once after the last batch.  upper_only == 0: the matrix is complete after every call. */
 int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, int dt, float* hessian, float decay,
-                      float scale, void* stream);
+                      float scale, int upper_only, void* stream);
+/* h[r, c] = h[c, r] for r > c: completes an fp32 [n, n] matrix accumulated with upper_only. */
+int moq_symmetrize(float* h, int64_t n, void* stream);
 /* Column sweep of create_sgpt_mask over one column block [i1, i1 + bs) (sparsegpt.py:96-127), all rows at once:
  * w: fp32 [rows, ld] working weights (block overwritten with the pruned weights q), hinv: fp32 [ld, ld] upper
  * Cholesky factor of the damped inverse Hessian, delta: fp32 [rows, bs] receives err_j = (w_j - q_j) / hinv_jj.
@@ -320,6 +325,17 @@ int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, int dt, float
  * caller's (library fp32 GEMM). */
 int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
                          int prune_n, int prune_m, void* stream);
+
+/* ------------------------------------------------------------------ AWQ-lite Gram-matrix search (a12) */
+
+/* loss_acc[0] += inv_count * sum_{r,c} ( sum_k a[r, k] * b[c, k] ) * ref[r, c]   -- the dot product <a b^T, ref>
+ * with the contraction on the matrix cores and the product with `ref` (fp32 [rows, cols]) fused into the epilogue.
+ * Used for trace(E G E^T) = <E G, E> of the AWQ Gram search: a = [E_hi | E_hi | E_lo] (bf16 [Cout, 3 Cin]),
+ * b = [G_hi | G_lo | G_hi] (bf16 [Cin, 3 Cin]; G symmetric), ref = E -- the K-concatenation sums the three
+ * split-precision products in the fp32 accumulators.  a, b: dt = MOQ_BF16 | MOQ_F16, 16-byte aligned, k % 8 == 0,
+ * cols % 4 == 0.  partial: moq_awq_err_gemm_workspace(rows, cols) floats. */
+int moq_awq_quadform(const void* a, const void* b, const float* ref, int64_t rows, int64_t cols, int64_t k, int dt,
+                     float* partial, float* loss_acc, double inv_count, void* stream);
 
 #ifdef __cplusplus
 }

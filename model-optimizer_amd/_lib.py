@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_uint8, c_ulonglong, c_void_p  # noqa: F401
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint8, c_ulonglong, c_void_p  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmoquant.so")
@@ -80,9 +80,12 @@ SIGNATURES = {
     "moq_mxfp4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "moq_mxfp4_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "moq_transpose16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
-    "moq_hessian_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_float, c_float, c_void_p]),
+    "moq_hessian_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_float, c_float, c_int, c_void_p]),
+    "moq_symmetrize": (c_int, [c_void_p, c_int64, c_void_p]),
     "moq_sgpt_block_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p]),
+    "moq_awq_quadform": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
+                                 c_double, c_void_p]),
     "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -152,7 +152,12 @@ __device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int
 }
 
 // MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n];
-// MODE 2: out is fp32 [T, N], out[t, n] = out[t, n] * decay + scale * acc (running Hessian X^T X of SparseGPT).
+// MODE 2: out is fp32 [T, N], T == N, x == w: out = out * decay + scale * acc (running Gram / Hessian X^T X of
+//         SparseGPT and of the AWQ Gram search); only tiles with n-tile >= t-tile are contracted.  upper_only = 0:
+//         the mirror images are written from the transposed accumulators (4-byte read-modify-writes: slow, but the
+//         matrix is complete after every call); upper_only = 1: they are left alone and the caller mirrors the matrix
+//         ONCE when the accumulation is over (moq_symmetrize);
+// MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
 __global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : 2)
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
@@ -161,7 +166,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ bias,  // [N] or null
                      void* __restrict__ out,         // [T, N] (MODE 1)
                      float* __restrict__ partial, int T, int N, int K, int tiles_t, int tiles_n,
-                     int64_t x_stride, int64_t w_stride, float decay, float scale) {
+                     int64_t x_stride, int64_t w_stride, float decay, float scale, int upper_only) {
   constexpr int TILE = Geo<GEO>::TILE, NI = Geo<GEO>::NI, NJ = Geo<GEO>::NJ;
   constexpr int WTC = Geo<GEO>::WAVES / Geo<GEO>::WN;  // waves along t
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -176,6 +181,9 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   }
   const int tn = bid / tiles_t, tt = bid % tiles_t;  // consecutive workgroups share the W tile
   const int n0 = tn * TILE, t0 = tt * TILE;
+  if constexpr (MODE == 2) {
+    if (tn < tt) return;  // mirror image of tile (tn, tt)
+  }
   // blockIdx.y = candidate index of a batched launch (all alphas of one linear in one grid): every candidate has
   // its own operands x[a] / w[a] and its own partial-sum plane; `ref` / `bias` are shared
   x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
@@ -287,6 +295,17 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
           h.z = h.z * decay + scale * acc[i][j][q * 4 + 2];
           h.w = h.w * decay + scale * acc[i][j][q * 4 + 3];
           *hp = h;
+          if (tn != tt && !upper_only) {  // mirrored block: out[n + e, t]; lanes run along t -> 128-byte runs
+            float* hm = reinterpret_cast<float*>(out) + (int64_t)n * N + t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hm[(int64_t)e * N] = hm[(int64_t)e * N] * decay + scale * acc[i][j][q * 4 + e];
+          }
+        } else if constexpr (MODE == 3) {
+          const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ref) + off);
+          sq += acc[i][j][q * 4 + 0] * rv.x;
+          sq += acc[i][j][q * 4 + 1] * rv.y;
+          sq += acc[i][j][q * 4 + 2] * rv.z;
+          sq += acc[i][j][q * 4 + 3] * rv.w;
         } else if constexpr (MODE == 0) {
           const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
           float rf[4];
@@ -312,7 +331,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       }
     }
   }
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE == 3) {
     // deterministic workgroup sum: butterfly inside the wave, fixed order across the waves
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
@@ -392,7 +411,7 @@ static int64_t n_tiles_for(int64_t tokens, int64_t cout, int tile) {
 template <int MODE, int GEO>
 static void launch_geo(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
-                       int64_t w_stride, void* stream, float decay = 0.0f, float scale = 0.0f) {
+                       int64_t w_stride, void* stream, float decay = 0.0f, float scale = 0.0f, int upper_only = 0) {
   constexpr int TILE = Geo<GEO>::TILE;
   const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
   const unsigned nblk = (unsigned)(tiles_t * tiles_n);
@@ -408,11 +427,11 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   if (dt == MOQ_BF16) {
     hipLaunchKernelGGL((err_gemm_kernel<MOQ_BF16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
                        bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
-                       decay, scale);
+                       decay, scale, upper_only);
   } else {
     hipLaunchKernelGGL((err_gemm_kernel<MOQ_F16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
                        bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
-                       decay, scale);
+                       decay, scale, upper_only);
   }
 }
 
@@ -421,7 +440,7 @@ template <int MODE>
 static int64_t launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
                            float* partial, int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand,
                            int64_t x_stride, int64_t w_stride, void* stream, float decay = 0.0f,
-                           float scale = 0.0f) {
+                           float scale = 0.0f, int upper_only = 0) {
   const int geo = gemm_geo();
   const int tile = geo == 2 ? 256 : 128;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
@@ -430,9 +449,9 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     return MOQ_ERR_UNSUPPORTED;
   }
   switch (geo) {
-    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
-    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
-    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale); break;
+    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
   return nblk;
 }
@@ -498,8 +517,42 @@ extern "C" int moq_gemm_nt(const void* x, const void* w, const void* bias, void*
   return check_launch("moq_gemm_nt");
 }
 
+// out[i, j] = out[j, i] for i > j... the lower triangle of an fp32 [n, n] matrix becomes the mirror of the upper one
+// (in the kernel's tile orientation `upper` = column-tile >= row-tile of the [t, n] = [row, col] view)
+__global__ __launch_bounds__(256) void symmetrize_kernel(float* __restrict__ h, int64_t n) {
+  __shared__ float tile[64][65];
+  const int64_t bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = bi * 64, c0 = bj * 64;
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < n && c < n) ? h[r * n + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = c0 + i, c = r0 + tx;  // mirrored position of tile element [tx][i]
+    if (r < n && c < n && r > c) h[r * n + c] = tile[tx][i];
+  }
+}
+
+extern "C" int moq_symmetrize(float* h, int64_t n, void* stream) {
+  if (h == nullptr || n < 0) {
+    set_error("moq_symmetrize: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (n == 0) return MOQ_OK;
+  const unsigned nb = (unsigned)((n + 63) / 64);
+  if (nb > 65535) {
+    set_error("moq_symmetrize: matrix too large");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nb, nb), dim3(256), 0, S(stream), h, n);
+  return check_launch("moq_symmetrize");
+}
+
 extern "C" int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, int dt, float* hessian, float decay,
-                                 float scale, void* stream) {
+                                 float scale, int upper_only, void* stream) {
   int rc = gemm_check(xt, xt, cin, cin, tokens, dt, "moq_hessian_accum");
   if (rc != MOQ_OK) return rc;
   if (hessian == nullptr || (reinterpret_cast<uintptr_t>(hessian) & 15u) != 0) {
@@ -507,7 +560,22 @@ extern "C" int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, in
     return MOQ_ERR_INVALID;
   }
   const int64_t nblk = launch_gemm<2>(xt, xt, nullptr, nullptr, hessian, nullptr, cin, cin, tokens, dt, 1, 0, 0, stream,
-                                      decay, scale);
+                                      decay, scale, upper_only ? 1 : 0);
   if (nblk < 0) return (int)nblk;
   return check_launch("moq_hessian_accum");
+}
+
+extern "C" int moq_awq_quadform(const void* a, const void* b, const float* ref, int64_t rows, int64_t cols, int64_t k,
+                                int dt, float* partial, float* loss_acc, double inv_count, void* stream) {
+  int rc = gemm_check(a, b, rows, cols, k, dt, "moq_awq_quadform");
+  if (rc != MOQ_OK) return rc;
+  if (ref == nullptr || partial == nullptr || loss_acc == nullptr || (reinterpret_cast<uintptr_t>(ref) & 15u) != 0) {
+    set_error("moq_awq_quadform: ref (16-byte aligned) / partial / loss_acc must not be NULL");
+    return MOQ_ERR_INVALID;
+  }
+  if (rows == 0) return MOQ_OK;
+  const int64_t nblk = launch_gemm<3>(a, b, ref, nullptr, nullptr, partial, rows, cols, k, dt, 1, 0, 0, stream);
+  if (nblk < 0) return (int)nblk;
+  hipLaunchKernelGGL(err_finalize_kernel, dim3(1), dim3(256), 0, S(stream), partial, (int)nblk, inv_count, loss_acc);
+  return check_launch("moq_awq_quadform");
 }

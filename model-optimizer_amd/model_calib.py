@@ -319,12 +319,20 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     wf = w.float()
     n_out = w.shape[0]
     bits = module.weight_quantizer.num_bits
+    # 16-bit models: the Cout x Cin x Cin contraction runs on the matrix cores in split precision (three bf16
+    # products summed in the fp32 accumulators, ~1e-5 relative) with the <., E> product fused; fp32 models keep the
+    # library's fp32 GEMM (agreement with the reference to ~1e-6 is asserted for them)
+    mfma = dt in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0
+    gram_op = ops.gram_operand(h.gram) if mfma else None
     for i, alpha in enumerate(h.alphas):
         s = get_scale(h.act_scale, h.weight_scale, alpha)
         r = (1 / s).to(dt).float()  # input_quantizer.pre_quant_scale as the forward uses it (:1551)
         w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
         err = w_hat.float().mul_(r).sub_(wf)
-        h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
+        if mfma:
+            ops.awq_quadform(err, gram_op, h.loss_buf[i:i + 1], 1.0 / n_out)
+        else:
+            h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
     h.num_search_steps = h.num_cache_steps
 
 
@@ -369,7 +377,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.num_tokens += x2.shape[0]
             if h.gram is not None:
                 if x2.dtype in (torch.bfloat16, torch.float16):
-                    ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0])  # G += X^T X / T_b on the matrix cores
+                    ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)  # G += X^T X / T_b (MFMA)
                 else:
                     xf = x2.float()
                     h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
@@ -406,6 +414,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for _, m in mods:  # Gram-matrix linears: losses now (local Gram; the loss is linear in it, summed below)
             h = helpers[m]
             if h.gram is not None and h.act_scale is not None:
+                if m.weight.dtype != torch.float32:
+                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only
                 _gram_losses(h, m)
                 h.gram = None  # release Cin^2 floats as soon as the linear is done
         if any(not h.use_gram and h.act_scale is not None for h in helpers.values()):

@@ -695,9 +695,11 @@ def transpose16(x: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def hessian_accum(hessian: torch.Tensor, inputs: torch.Tensor, decay: float, scale: float) -> torch.Tensor:
+def hessian_accum(hessian: torch.Tensor, inputs: torch.Tensor, decay: float, scale: float,
+                  upper_only: bool = False) -> torch.Tensor:
     """hessian <- hessian * decay + scale * inputs^T @ inputs (fp32 [Cin, Cin], in place) for inputs [tokens, Cin]
-    in bf16 / f16: transpose + MFMA contraction (exact products, fp32 accumulation)."""
+    in bf16 / f16: transpose + MFMA contraction (exact products, fp32 accumulation).  upper_only: update the tiles on
+    and above the diagonal only (half the work); call symmetrize() once after the last batch."""
     _require_gpu(inputs, "hessian_accum")
     x2 = inputs.detach().reshape(-1, inputs.shape[-1])
     cin = x2.shape[1]
@@ -711,8 +713,19 @@ def hessian_accum(hessian: torch.Tensor, inputs: torch.Tensor, decay: float, sca
     xt = transpose16(x2)
     with _on(xt) as stream:
         check(_lib.lib().moq_hessian_accum(_p(xt), cin, xt.shape[1], _dt(xt), _p(hessian), float(decay), float(scale),
-                                           stream))
+                                           int(upper_only), stream))
     return hessian
+
+
+@torch.no_grad()
+def symmetrize(h: torch.Tensor) -> torch.Tensor:
+    """h[r, c] = h[c, r] for r > c (in place): completes a matrix accumulated with hessian_accum(upper_only=True)."""
+    _require_gpu(h, "symmetrize")
+    if h.dtype != torch.float32 or h.dim() != 2 or h.shape[0] != h.shape[1] or not h.is_contiguous():
+        raise MoquantError("symmetrize: contiguous square fp32 matrix expected")
+    with _on(h) as stream:
+        check(_lib.lib().moq_symmetrize(_p(h), h.shape[0], stream))
+    return h
 
 
 @torch.no_grad()
@@ -728,3 +741,38 @@ def sgpt_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, prun
         check(_lib.lib().moq_sgpt_block_sweep(_p(w), rows, ld, int(i1), int(bs), _p(hinv), _p(delta), int(prune_n),
                                               int(prune_m), stream))
     return delta
+
+
+# ----------------------------------------------------------------------------------------------- AWQ Gram search
+def split_bf16(x: torch.Tensor):
+    """fp32 -> (hi, lo) bf16 with hi + lo == x to ~2^-17 relative."""
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    return hi, lo
+
+
+@torch.no_grad()
+def gram_operand(gram: torch.Tensor) -> torch.Tensor:
+    """[G_hi | G_lo | G_hi] (bf16 [Cin, 3 Cin]) of a symmetric fp32 Gram matrix -- the `b` operand of awq_quadform."""
+    hi, lo = split_bf16(gram)
+    return torch.cat([hi, lo, hi], dim=1).contiguous()
+
+
+@torch.no_grad()
+def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tensor, inv_count: float) -> torch.Tensor:
+    """loss_acc[0] += inv_count * trace(E G E^T) = inv_count * <E G, E> for the fp32 error weight E [Cout, Cin] and
+    gram_op = gram_operand(G): one MFMA contraction over K = 3 Cin (split-precision: E_hi G_hi + E_hi G_lo + E_lo G_hi)
+    with the product against E fused into the epilogue."""
+    _require_gpu(err, "awq_quadform")
+    if err.dtype != torch.float32 or not err.is_contiguous() or gram_op.dtype != torch.bfloat16:
+        raise MoquantError("awq_quadform: err must be contiguous fp32, gram_op bf16")
+    rows, cols = err.shape
+    if tuple(gram_op.shape) != (cols, 3 * cols) or loss_acc.dtype != torch.float32 or loss_acc.numel() != 1:
+        raise MoquantError("awq_quadform: operand shapes do not match")
+    hi, lo = split_bf16(err)
+    a = torch.cat([hi, hi, lo], dim=1).contiguous()
+    ws = torch.empty(int(_lib.lib().moq_awq_err_gemm_workspace(rows, cols)), dtype=torch.float32, device=err.device)
+    with _on(err) as stream:
+        check(_lib.lib().moq_awq_quadform(_p(a), _p(gram_op), _p(err), rows, cols, 3 * cols, _lib.BF16, _p(ws),
+                                          _p(loss_acc), float(inv_count), stream))
+    return loss_acc

@@ -65,8 +65,16 @@ class HessianState:
     (sparsegpt.py:206-236): fp32 [Cin, Cin] on the weight's device."""
 
     def __init__(self, cols: int, device):
-        self.hessian = torch.zeros(cols, cols, dtype=torch.float32, device=device)
+        self._h = torch.zeros(cols, cols, dtype=torch.float32, device=device)
+        self._upper = False  # lower triangle stale (MFMA path updates the upper tiles only)
         self.samples = 0
+
+    @property
+    def hessian(self) -> torch.Tensor:
+        if self._upper:
+            ops.symmetrize(self._h)
+            self._upper = False
+        return self._h
 
     @torch.no_grad()
     def update(self, inp: torch.Tensor):
@@ -81,7 +89,8 @@ class HessianState:
         self.samples += b
         scale = 2.0 / self.samples
         if x2.dtype in (torch.bfloat16, torch.float16) and x2.shape[1] % 4 == 0:
-            ops.hessian_accum(self.hessian, x2, decay, scale)
+            ops.hessian_accum(self._h, x2, decay, scale, upper_only=True)
+            self._upper = True
         else:
             xf = x2.float()
             self.hessian.mul_(decay).addmm_(xf.t(), xf, alpha=scale)

@@ -64,3 +64,23 @@ def test_gram_search_equals_gemm_search(dtype):
         assert a_gram == a_gemm, f"{dtype}: best alpha {a_gram} (gram) vs {a_gemm} (gemm)"
         assert torch.equal(w_gram, w_gemm)  # same alpha -> identical folded weights
         assert steps == 3
+
+
+def test_quadform_split_precision_vs_fp64():
+    """<E G, E> on the matrix cores in split bf16 precision against fp64, on shapes with ragged tiles."""
+    from model_optimizer_amd import ops
+
+    gen = torch.Generator().manual_seed(3)
+    for cout, cin, tokens in [(512, 1024, 700), (300, 520, 2000), (64, 128, 50)]:
+        ch = torch.exp(torch.randn(cin, generator=gen))
+        ch[:4] *= 50
+        x = torch.randn(tokens, cin, generator=gen) * ch
+        g = (x.t() @ x / tokens).float()
+        e = (torch.randn(cout, cin, generator=gen) * 1e-3).float()
+        want = ((e.double() @ g.double()) * e.double()).sum().item() / cout
+        acc = torch.zeros(1, device=DEV)
+        ops.awq_quadform(e.to(DEV), ops.gram_operand(g.to(DEV)), acc, 1.0 / cout)
+        got = acc.item()
+        assert abs(got - want) <= 5e-5 * abs(want), f"{cout}x{cin}: {got} vs {want}"
+        ops.awq_quadform(e.to(DEV), ops.gram_operand(g.to(DEV)), acc, 1.0 / cout)  # accumulates
+        assert abs(acc.item() - 2 * want) <= 1e-4 * abs(want)

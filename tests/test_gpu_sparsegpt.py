@@ -48,6 +48,14 @@ def test_hessian_mfma_exact_on_integer_inputs():
     assert torch.equal(h.cpu(), x.float().t() @ x.float())
     ops.hessian_accum(h, x.to(DEV), 0.5, 2.0)
     assert torch.equal(h.cpu(), 2.5 * (x.float().t() @ x.float()))
+    # upper-tile accumulation + one mirror pass at the end gives the same matrix
+    for n in (320, 700, 64):
+        xs = [torch.randint(-3, 4, (96, n), generator=gen).to(torch.bfloat16) for _ in range(2)]
+        hu = torch.zeros(n, n, device=DEV)
+        for xb in xs:
+            ops.hessian_accum(hu, xb.to(DEV), 1.0, 1.0, upper_only=True)
+        ops.symmetrize(hu)
+        assert torch.equal(hu.cpu(), sum(xb.float().t() @ xb.float() for xb in xs)), n
 
 
 @pytest.mark.parametrize("m,n", [(4, 2), (2, 1), (8, 4)])

@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--batches", type=int, default=4, help="calibration batches in total (sharded over ranks)")
     ap.add_argument("--tokens", type=int, default=4096, help="tokens per batch (8 x 512)")
+    ap.add_argument("--search", default="auto", choices=["auto", "gram", "gemm"],
+                    help="awq_lite search: Gram matrix (one pass, token-count independent) or per-alpha error GEMMs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,7 +98,11 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    moa.quantize(model, moa.model_quant.INT4_AWQ_CFG, loop)
+    import copy
+
+    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": args.search}
+    moa.quantize(model, cfg, loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -116,6 +122,7 @@ def main():
             "config": {"workload": f"{args.model} x {args.layers} layers ({len(model.linears)} linears, {n_w * 2 / 1e9:.2f} GB bf16), "
                                    f"awq_lite g128 alpha_step 0.1, {args.batches} batches x {args.tokens} tokens, synthetic",
                        "parallelism": f"calibration batches sharded over {world} GPU(s)"},
+            "search": args.search,
             "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
             "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}), flush=True)
     if world > 1:
