@@ -146,11 +146,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # MOQ_BENCH_DEBUG_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo -- lets the N > 1 control
+    # flow (collective counts, barriers, rank-0 reporting) be exercised on a single-GPU box; never a measurement.
+    one_gpu_debug = os.environ.get("MOQ_BENCH_DEBUG_ONE_GPU") == "1"
+    if one_gpu_debug:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu_debug:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     moa = _moa_import.load()
     from model_optimizer_amd.multi_tensor import SegmentTable
@@ -235,10 +243,13 @@ def main():
     # bandwidth-bound kernel ~15 % slower than one that has been busy for a second (measured: the same launch takes
     # 5.1 ms as the first work after process start and 4.4 ms later in the same session), so the device is kept busy
     # for ~1.5 s before the contractual warm-up + timed region.
+    # The ramp is time-based, so ranks may run different numbers of iterations: it must not contain a collective.
+    dist_world, world = world, 1  # step() reads `world` from this scope: no all-reduce inside the ramp
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 1.5:
         step(False)
         torch.cuda.synchronize()
+    world = dist_world
     for _ in range(args.warmup):
         step(False)
 

@@ -78,11 +78,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
 
+    one_gpu_debug = os.environ.get("MOQ_BENCH_DEBUG_ONE_GPU") == "1"  # all ranks on cuda:0, gloo collectives
+    if one_gpu_debug:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu_debug:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     moa = _moa_import.load()
     dtype = torch.bfloat16
 
