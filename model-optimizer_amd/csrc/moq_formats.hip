@@ -185,17 +185,22 @@ __device__ __forceinline__ int hist_bin(float a, int bins, float max_edge, const
   const bool ok = (a <= max_edge) & !((skip_zeros != 0) & (a == 0.0f));
   return ok ? pos : bins;
 }
+// The workgroup is kHistBlock = 1024 threads (16 waves) around ONE LDS histogram: the histogram (64 KiB with 8 copies
+// of 2048 bins) limits a CU to two workgroups, and with 256-thread workgroups that meant two waves per SIMD -- too few
+// to hide the load -> bin -> ds_add dependency chain.  Each 256-thread quarter walks its own chunks.
+constexpr int kHistBlock = 1024;
 template <int DT, bool FAST, bool SHARED>
 __device__ __forceinline__ void hist_chunk(const void* x, int64_t e0, int64_t n, uint32_t* lds_hist, int bins,
                                            float max_edge, const SharedDiv& sd, int skip_zeros, int rshift, int copy) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
+  const int tid = threadIdx.x & (kBlock - 1);
   Pack16 in[P];
 #pragma unroll
-  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + packet_off<DT>(u), n);
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, FAST>(x, e0 + (u * kBlock + tid) * V, n);
 #pragma unroll
   for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
+    const int64_t e = e0 + (u * kBlock + tid) * V;
     float v[8];
     unpack<DT>(in[u], v);
 #pragma unroll
@@ -207,18 +212,19 @@ __device__ __forceinline__ void hist_chunk(const void* x, int64_t e0, int64_t n,
   }
 }
 template <int DT, bool SHARED>
-__global__ __launch_bounds__(kBlock) void hist_kernel(const void* __restrict__ x, int64_t n,
-                                                      unsigned long long* __restrict__ counts, int bins,
-                                                      float max_edge, int skip_zeros, int rshift) {
+__global__ __launch_bounds__(kHistBlock) void hist_kernel(const void* __restrict__ x, int64_t n,
+                                                          unsigned long long* __restrict__ counts, int bins,
+                                                          float max_edge, int skip_zeros, int rshift) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_hist[];
   const int slots = (bins + 1) << rshift;
   const int copy = (int)(threadIdx.x & ((1u << rshift) - 1u));
-  for (int b = threadIdx.x; b < slots; b += kBlock) lds_hist[b] = 0;
+  for (int b = threadIdx.x; b < slots; b += kHistBlock) lds_hist[b] = 0;
   __syncthreads();
   const bool al = al16(x);
   const SharedDiv sd = make_shared_div(max_edge);
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
-  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+  constexpr int Q = kHistBlock / kBlock;
+  for (int64_t c = (int64_t)blockIdx.x * Q + (threadIdx.x / kBlock); c < n_chunks; c += (int64_t)gridDim.x * Q) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     if (al && e0 + MOQ_MT_CHUNK <= n)
       hist_chunk<DT, true, SHARED>(x, e0, n, lds_hist, bins, max_edge, sd, skip_zeros, rshift, copy);
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const void* __restrict__ x
       hist_chunk<DT, false, SHARED>(x, e0, n, lds_hist, bins, max_edge, sd, skip_zeros, rshift, copy);
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kBlock) {
+  for (int b = threadIdx.x; b < bins; b += kHistBlock) {
     uint32_t cnt = 0;
     for (int r = 0; r < (1 << rshift); ++r) cnt += lds_hist[(b << rshift) + r];
     if (cnt) atomicAdd(&counts[b], (unsigned long long)cnt);
@@ -679,8 +685,8 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
     return MOQ_ERR_INVALID;
   }
   if (n == 0) return MOQ_OK;
-  // <= 512 workgroups: the flush costs `bins` 64-bit global atomics per workgroup
-  int64_t blocks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  // <= 512 workgroups of 1024 threads: the flush costs `bins` 64-bit global atomics per workgroup
+  int64_t blocks = ((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK + 3) / 4;
   if (blocks > 512) blocks = 512;
   if (bins < kHistMaxLdsBins) {
     int rshift = 0;
@@ -689,10 +695,10 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
     // the shared-denominator division is exact for numerators up to 2^16 and denominators in [2^-60, 2^60]
     const bool shared = max_edge >= 0x1p-60f && max_edge <= 0x1p60f && max_edge * (float)bins <= 65536.0f;
     if (shared) {
-      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, true>), dim3((int)blocks), dim3(kBlock), lds, S(stream),
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, true>), dim3((int)blocks), dim3(kHistBlock), lds, S(stream),
                                                 x, n, counts, bins, max_edge, skip_zeros, rshift));
     } else {
-      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, false>), dim3((int)blocks), dim3(kBlock), lds, S(stream),
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((hist_kernel<DT, false>), dim3((int)blocks), dim3(kHistBlock), lds, S(stream),
                                                 x, n, counts, bins, max_edge, skip_zeros, rshift));
     }
   } else {

@@ -45,7 +45,12 @@ template <int GEO> struct Geo;
 template <> struct Geo<0> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 1; };
 template <> struct Geo<1> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 2; };
 template <> struct Geo<2> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * kRowBytes; }
+//   GEO 3: 256 x 256, 8 waves, K-step 32 with FOUR 32 KiB stages: three tiles (96 KiB) stay in flight and the wait
+//          before a step is a counted vmcnt(8) (never 0 in steady state) -- the GEO 2 loop keeps one 64 KiB tile in
+//          flight and drains the queue every step, which parks its waves ~35 % of the time (SQ_WAIT_ANY)
+template <> struct Geo<3> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 4; };
+template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
+template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
 template <int GEO> constexpr int lds_bytes() { return Geo<GEO>::STAGES * stage_bytes<GEO>(); }
 
@@ -151,6 +156,56 @@ __device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int
   }
 }
 
+// ---- GEO 3: 64-byte LDS rows (32 k).  Chunk c (0..3) of row r sits at position c ^ ((r >> 2) & 3): the 16 rows of a
+// ds_read_b128 service group then cover 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
+// One wave-instruction of the DMA moves 16 rows x 64 B: lane l fills (row l >> 2, position l & 3).
+__device__ __forceinline__ void stage_tile3(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
+                                            int wave, int lane) {
+  constexpr int PER_WAVE = 256 / 16 / 8;  // 2
+  const int r_local = lane >> 2, pos = lane & 3;
+  const i32x4_t rs = desc.words;
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int rbase = (wave * PER_WAVE + j) * 16;
+    const int r = rbase + r_local;
+    const int c = pos ^ ((r >> 2) & 3);
+    const int k = k0 + c * 8;
+    const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
+    uint8_t* dst = lds_tile + rbase * 64;
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+  }
+}
+__device__ __forceinline__ Pack16 read_frag3(const uint8_t* lds_tile, int r, int c) {
+  return *reinterpret_cast<const Pack16*>(lds_tile + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
+}
+// one K-step of 32 k (two MFMA sub-steps) from the stage at `stage`
+template <int DT, class F>
+__device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, int fr, int fh,
+                                        f32x16_t (&acc)[4][2], F&& after_first) {
+  constexpr int NI = 4, NJ = 2;
+  const uint8_t* la = stage + (wn * NI * 32) * 64;
+  const uint8_t* lb = stage + tile_bytes<3>() + (wt * NJ * 32) * 64;
+  Pack16 a[2][NI], b[2][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a[0][i] = read_frag3(la, i * 32 + fr, fh);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b[0][j] = read_frag3(lb, j * 32 + fr, fh);
+  after_first();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) a[1][i] = read_frag3(la, i * 32 + fr, 2 + fh);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) b[1][j] = read_frag3(lb, j * 32 + fr, 2 + fh);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[ks][i], b[ks][j], acc[i][j]);
+  }
+}
+
 // MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n];
 // MODE 2: out is fp32 [T, N], T == N, x == w: out = out * decay + scale * acc (running Gram / Hessian X^T X of
 //         SparseGPT and of the AWQ Gram search); only tiles with n-tile >= t-tile are contracted.  upper_only = 0:
@@ -210,7 +265,33 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 2) {
+  if constexpr (GEO == 3) {
+    constexpr int BK3 = 32;
+    const int nk3 = (K + BK3 - 1) / BK3;
+    // prologue: three tiles in flight
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      if (p < nk3) {
+        stage_tile3(rs_w, smem + p * SB, ld_bytes, p * BK3, K, wave, lane);
+        stage_tile3(rs_x, smem + p * SB + TB, ld_bytes, p * BK3, K, wave, lane);
+      }
+    }
+    for (int kt = 0; kt < nk3; ++kt) {
+      // tile kt has landed once at most the DMA pieces of the (up to two) younger tiles are outstanding:
+      // 4 pieces per tile per wave
+      if (kt + 2 < nk3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (kt + 1 < nk3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // everyone's part of tile kt landed; everyone finished reading stage (kt - 1) % 4
+      k_step3<DT>(smem + (kt & 3) * SB, wn, wt, fr, fh, acc, [&]() {
+        if (kt + 3 < nk3) {
+          uint8_t* nxt = smem + ((kt + 3) & 3) * SB;
+          stage_tile3(rs_w, nxt, ld_bytes, (kt + 3) * BK3, K, wave, lane);
+          stage_tile3(rs_x, nxt + TB, ld_bytes, (kt + 3) * BK3, K, wave, lane);
+        }
+      });
+    }
+  } else if constexpr (GEO == 2) {
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
@@ -396,11 +477,11 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
 }
 
 static int gemm_geo() {
-  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 selects the tile geometry (A/B knob, read once)
+  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 | 3 selects the tile geometry (A/B knob, read once)
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 2;
-    return g < 0 || g > 2 ? 2 : g;
+    return g < 0 || g > 3 ? 2 : g;
   }();
   return geo;
 }
@@ -442,7 +523,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
                            int64_t x_stride, int64_t w_stride, void* stream, float decay = 0.0f,
                            float scale = 0.0f, int upper_only = 0) {
   const int geo = gemm_geo();
-  const int tile = geo == 2 ? 256 : 128;
+  const int tile = geo >= 2 ? 256 : 128;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
   if (nblk > 0x7FFFFFFF) {
     set_error("gemm: too many tiles");
@@ -451,6 +532,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
   switch (geo) {
     case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
   return nblk;
