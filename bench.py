@@ -33,15 +33,18 @@ import _moa_import  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 MODELS = {
-    # (hidden, intermediate, layers, kv_dim)
+    # (hidden, intermediate, layers, kv_dim[, experts])
     "llama3-8b": (4096, 14336, 32, 1024),
     "llama3-70b": (8192, 28672, 80, 1024),
+    "mixtral-8x7b": (4096, 14336, 32, 1024, 8),  # BASELINE configs[3]: 8 experts per layer (w1, w3, w2 each)
 }
+MODEL_NAMES = {"llama3-8b": "Llama-3-8B", "llama3-70b": "Llama-3-70B", "mixtral-8x7b": "Mixtral-8x7B"}
 
 
 def layer_shapes(model):
-    h, i, _, kv = MODELS[model]
-    return [(h, h), (kv, h), (kv, h), (h, h), (i, h), (i, h), (h, i)]  # q k v o gate up down
+    h, i, _, kv = MODELS[model][:4]
+    experts = MODELS[model][4] if len(MODELS[model]) > 4 else 1
+    return [(h, h), (kv, h), (kv, h), (h, h)] + [(i, h), (i, h), (h, i)] * experts  # q k v o, (gate up down) x experts
 
 
 def make_weights(model, n_layers, device, seed=1234):
@@ -183,7 +186,8 @@ def main():
         groups = [SegmentTable([weights[i] for i in g], outputs=[tab.outputs[i] for i in g]) for g in groups]
     masks = None
     if wl == "mask24":
-        masks = [None] * len(weights)
+        masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in weights]
+        mask_tab = SegmentTable(weights, outputs=masks)
 
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
     dom_events = []
@@ -224,8 +228,7 @@ def main():
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
-            for i, w in enumerate(weights):
-                tab.outputs[i] = moa.ops.fused_amax_convert(w, 32, "E2M1")
+            tab.mx_fused_amax_convert(32, "E2M1")  # every weight of the model in one launch
             if record:
                 e1.record()
                 dom_events.append((e0, e1))
@@ -233,8 +236,7 @@ def main():
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
-            for i, w in enumerate(weights):
-                masks[i] = moa.ops.mask_2to4(w)
+            mask_tab.mask_2to4()  # every weight of the model in one launch
             if record:
                 e1.record()
                 dom_events.append((e0, e1))
@@ -276,8 +278,8 @@ def main():
     dom_ms = sum(a.elapsed_time(b) for a, b in dom_events) / len(dom_events)
     alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mask24": 3.0}[wl]
     dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
-                "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mx_kernel<bf16, 4> (224 launches)",
-                "mask24": "mask24_kernel<bf16> (224 launches)"}[wl]
+                "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
+                "mask24": "mt_mask24_kernel<bf16>"}[wl]
     achieved = n_elem * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic(wl, args.model, n_layers)
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -286,7 +288,7 @@ def main():
                 "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4)}
 
     out = {
-        "metric": f"GB/s weights calibrated+QDQ ({'Llama-3-8B' if args.model == 'llama3-8b' else 'Llama-3-70B'})",
+        "metric": f"GB/s weights calibrated+QDQ ({MODEL_NAMES[args.model]})",
         "value": round(value, 2),
         "unit": "GB/s",
         "n_gpus": world,

@@ -137,6 +137,16 @@ int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk_start, int
                               int64_t n_chunks, int g, int dt, int num_bits, int is_unsigned,
                               int narrow_range, void* stream);
 
+/* 2:4 magnitude mask (see moq_mask_2to4) of every segment in one launch: segs[s].y is the uint8 mask [n] of the
+ * weight segs[s].x (groups of 4 run along the flattened tensor: every row length % 4 == 0). */
+int moq_mt_mask_2to4(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                     void* stream);
+/* MX dynamic-block QDQ (see moq_mx_fused_amax_convert) of every segment in one launch; block in
+ * {kVec, 2 kVec, 4 kVec, 8 kVec} elements (8..64 for 16-bit types), every segment 16-byte aligned with
+ * n % block == 0; E8M0 scales.  segs[s].amax is not used. */
+int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
+                                 int block, int dt, int fmt, void* stream);
+
 /* ------------------------------------------------------------------ MX dynamic block QDQ (a8) */
 
 /* Per `block` consecutive elements of the last dim (cols virtually right-padded with zeros to a block
@@ -336,6 +346,19 @@ int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs,
  * cols % 4 == 0.  partial: moq_awq_err_gemm_workspace(rows, cols) floats. */
 int moq_awq_quadform(const void* a, const void* b, const float* ref, int64_t rows, int64_t cols, int64_t k, int dt,
                      float* partial, float* loss_acc, double inv_count, void* stream);
+
+/* ------------------------------------------------------------------ 2-D block amax / QDQ (a2) */
+
+/* br x bc tiles of a contiguous [rows, cols] tensor; amax: fp32 [rows/br, cols/bc].
+ *   mode 0: amax[i, j] = max |tile| (accumulate != 0: running max with the stored value)
+ *   mode 1: y = QDQ(x) with the given tile amax      mode 2: amax (stored if amax != NULL) + QDQ, one read of x
+ * fp8 != 0: FP8-E4M3 QDQ (as moq_fake_quant_e4m3), else INT-num_bits (as moq_fake_quant_int).  x == y allowed.
+ * Replaces reduce_block_amax (quantization/utils/core_utils.py:43-90) and the eager fake-quant TensorQuantizer falls
+ * back to for a two-axis block amax (nn/modules/tensor_quantizer.py:1018-1043, tensor_quant.py:80) -- the FP8 2-D
+ * blockwise weight preset.  rows % br == 0, cols % bc == 0 (pad on the host), br * bc <= 32768 elements (16384 for
+ * fp32), bc % (16 / elem size) == 0. */
+int moq_block2d(const void* x, void* y, float* amax, int64_t rows, int64_t cols, int br, int bc, int dt, int mode,
+                int accumulate, int fp8, int num_bits, int is_unsigned, int narrow_range, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ SIGNATURES = {
                                       c_void_p]),
     "moq_mt_amax_qdq_int_group": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p]),
+    "moq_mt_mask_2to4": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "moq_mt_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "moq_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p]),
     "moq_hist_abs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
@@ -86,6 +88,8 @@ SIGNATURES = {
                                      c_void_p]),
     "moq_awq_quadform": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                  c_double, c_void_p]),
+    "moq_block2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_void_p]),
     "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

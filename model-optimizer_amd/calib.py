@@ -72,6 +72,10 @@ class MaxCalibrator(_Calibrator):
         if reduce_axis is None or len(reduce_axis) == nd:
             shape = () if reduce_axis is None else ()  # reduce_amax squeezes scalars
             n = 1
+        elif nd == 4 and sorted(a % nd for a in reduce_axis) == [1, 3]:
+            # 2-D blocks: the (R/br, br, C/bc, bc) view reduced over the block dims (ops.block2d)
+            shape = (x.shape[0], 1, x.shape[2], 1)
+            n = x.shape[0] * x.shape[2]
         else:
             _, kept, _, keep = _reduce_layout(list(x.shape), reduce_axis)
             shape = tuple(x.shape[d] if d in keep else 1 for d in range(nd))

@@ -93,42 +93,58 @@ __device__ __forceinline__ float mx_abs_clamped(float x) {
 // Chunk skeleton: all packets of a chunk in flight before the first use, non-temporal loads and stores, dense
 // strided grid.  FMT >= 0 fixes the element format at compile time (E2M1 / E4M3: the MXFP4 / MXFP8 presets) so
 // that the rounding constants fold; FMT < 0 reads it from `fmt`.
-template <int DT, int LPG, int FMT>
-__global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                    int64_t n, int fmt) {
+template <int DT, int LPG>
+__device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
   constexpr int ES = 16 / V;
+  Pack16 in[P];
+  // n is a multiple of the block (= LPG * V elements), so a group is entirely live or entirely past the end
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    if (e < n) in[u] = load16_nt(xb + e * ES);
+    else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float v[8];
+    unpack<DT>(in[u], v);
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+    // non-negative floats order like their bit patterns
+    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
+    float sc, un;
+    mx_scale_e8m0(am, f.maxv, sc, un);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+    if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
+  }
+}
+template <int DT, int LPG, int FMT>
+__global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                    int64_t n, int fmt) {
   const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
-  const char* xb = reinterpret_cast<const char*>(x);
-  char* yb = reinterpret_cast<char*>(y);
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
+    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f);
+}
+// the same over a segment table: all weights of a layer / model in ONE launch (every segment 16-byte aligned with
+// n % block == 0, checked when the table is built)
+template <int DT, int LPG, int FMT>
+__global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict__ segs,
+                                                       const int64_t* __restrict__ blk_start, int n_seg,
+                                                       int64_t n_chunks, int fmt) {
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const int64_t e0 = c * MOQ_MT_CHUNK;
-    Pack16 in[P];
-    // n is a multiple of the block (= LPG * V elements), so a group is entirely live or entirely past the end
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
-      if (e < n) in[u] = load16_nt(xb + e * ES);
-      else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
-      float v[8];
-      unpack<DT>(in[u], v);
-      float am = 0.0f;
-#pragma unroll
-      for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
-      // non-negative floats order like their bit patterns
-      am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
-      float sc, un;
-      mx_scale_e8m0(am, f.maxv, sc, un);
-#pragma unroll
-      for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
-      if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
-    }
+    cur.seek(c);
+    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y),
+                      (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f);
   }
 }
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding) and any alignment
@@ -285,47 +301,60 @@ __device__ __forceinline__ void store8_nt(void* p, uint32_t a, uint32_t b) {
 __device__ __forceinline__ void store4_nt(void* p, uint32_t a) {
   __builtin_nontemporal_store(a, reinterpret_cast<uint32_t*>(p));
 }
-template <int DT, bool NTS>
-__global__ __launch_bounds__(kBlock) void mask24_kernel(const void* __restrict__ w,
-                                                        uint8_t* __restrict__ mask, int64_t n) {
+template <int DT>
+__device__ __forceinline__ void mask_chunk(const void* w, uint8_t* mask, int64_t e0, int64_t n, bool fast) {
   constexpr int V = Elem<DT>::kVec;  // 8 (two groups of 4) or 4 (one group)
   constexpr int P = Chunk<DT>::kPackets;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    in[u] = fast ? ld_packet<DT, true>(w, e, n) : ld_packet<DT, false>(w, e, n);
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float v[8];
+    unpack<DT>(in[u], v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = __builtin_fabsf(v[i]);
+    const uint32_t m0 = mask4(v[0], v[1], v[2], v[3]);
+    uint32_t m1 = 0;
+    if constexpr (V == 8) m1 = mask4(v[4], v[5], v[6], v[7]);
+    if (fast) {
+      if constexpr (V == 8) store8_nt(mask + e, m0, m1);
+      else store4_nt(mask + e, m0);
+    } else {  // n % 4 == 0: groups of four are all-in or all-out
+      if (e + 4 <= n)
+        for (int i = 0; i < 4; ++i) mask[e + i] = (m0 >> (8 * i)) & 1;
+      if (V == 8 && e + 8 <= n)
+        for (int i = 0; i < 4; ++i) mask[e + 4 + i] = (m1 >> (8 * i)) & 1;
+    }
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mask24_kernel(const void* __restrict__ w,
+                                                        uint8_t* __restrict__ mask, int64_t n) {
   const bool al = al16(w) && (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
-    const bool fast = al && e0 + MOQ_MT_CHUNK <= n;
-    Pack16 in[P];
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
-      in[u] = fast ? ld_packet<DT, true>(w, e, n) : ld_packet<DT, false>(w, e, n);
-    }
-#pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
-      float v[8];
-      unpack<DT>(in[u], v);
-#pragma unroll
-      for (int i = 0; i < V; ++i) v[i] = __builtin_fabsf(v[i]);
-      const uint32_t m0 = mask4(v[0], v[1], v[2], v[3]);
-      uint32_t m1 = 0;
-      if constexpr (V == 8) m1 = mask4(v[4], v[5], v[6], v[7]);
-      if (fast) {
-        if constexpr (NTS) {
-          if constexpr (V == 8) store8_nt(mask + e, m0, m1);
-          else store4_nt(mask + e, m0);
-        } else {
-          if constexpr (V == 8) *reinterpret_cast<uint2*>(mask + e) = make_uint2(m0, m1);
-          else *reinterpret_cast<uint32_t*>(mask + e) = m0;
-        }
-      } else {  // n % 4 == 0: groups of four are all-in or all-out
-        if (e + 4 <= n)
-          for (int i = 0; i < 4; ++i) mask[e + i] = (m0 >> (8 * i)) & 1;
-        if (V == 8 && e + 8 <= n)
-          for (int i = 0; i < 4; ++i) mask[e + 4 + i] = (m1 >> (8 * i)) & 1;
-      }
-    }
+    mask_chunk<DT>(w, mask, e0, n, al && e0 + MOQ_MT_CHUNK <= n);
+  }
+}
+// the same over a segment table (segs[s].y = the uint8 / bool mask of segs[s].x): one launch per layer / model
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mt_mask24_kernel(const moq_seg* __restrict__ segs,
+                                                           const int64_t* __restrict__ blk_start, int n_seg,
+                                                           int64_t n_chunks) {
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    cur.seek(c);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    const bool al = al16(cur.sg.x) && (reinterpret_cast<uintptr_t>(cur.sg.y) & 7u) == 0;
+    mask_chunk<DT>(cur.sg.x, reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n, al && e0 + MOQ_MT_CHUNK <= cur.sg.n);
   }
 }
 
@@ -678,6 +707,41 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
   return check_launch("moq_mx_fused_amax_convert");
 }
 
+extern "C" int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* blk_start, int n_seg,
+                                            int64_t n_chunks, int block, int dt, int fmt, void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr))) {
+    set_error("moq_mt_mx_fused_amax_convert: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (mx_fmt(fmt).kind < 0) {
+    set_error("moq_mt_mx_fused_amax_convert: unknown element format %d", fmt);
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = block / vec;
+  if (block <= 0 || block % vec != 0 || lpg > 8 || (lpg & (lpg - 1)) != 0) {
+    set_error("moq_mt_mx_fused_amax_convert: block sizes %d..%d (powers of two) are supported, got %d", vec, 8 * vec, block);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
+  const int grid = copy_grid(n_chunks);
+#define MOQ_MTMX_LAUNCH(L, F) \
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, fmt))
+#define MOQ_MTMX_CASE(L)                                     \
+  case L:                                                    \
+    if (fmt == MOQ_E2M1) { MOQ_MTMX_LAUNCH(L, MOQ_E2M1); }   \
+    else if (fmt == MOQ_E4M3) { MOQ_MTMX_LAUNCH(L, MOQ_E4M3); } \
+    else { MOQ_MTMX_LAUNCH(L, -1); }                         \
+    break;
+  switch (lpg) {
+    MOQ_MTMX_CASE(1) MOQ_MTMX_CASE(2) MOQ_MTMX_CASE(4) MOQ_MTMX_CASE(8)
+    default: set_error("unreachable"); return MOQ_ERR_INVALID;
+  }
+#undef MOQ_MTMX_CASE
+#undef MOQ_MTMX_LAUNCH
+  return check_launch("moq_mt_mx_fused_amax_convert");
+}
+
 extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
                             float max_edge, int skip_zeros, void* stream) {
   if (n < 0 || bins <= 0 || counts == nullptr || (n > 0 && x == nullptr)) {
@@ -721,9 +785,21 @@ extern "C" int moq_mask_2to4(const void* w, int64_t rows, int64_t cols, int dt, 
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
   const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), w,
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
                                             mask, n));
   return check_launch("moq_mask_2to4");
+}
+
+extern "C" int moq_mt_mask_2to4(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                                void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr))) {
+    set_error("moq_mt_mask_2to4: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mask24_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), 0,
+                                            S(stream), segs, blk_start, n_seg, n_chunks));
+  return check_launch("moq_mt_mask_2to4");
 }
 
 extern "C" int moq_int4_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int g, int dt,

@@ -26,6 +26,10 @@ INT4_AWQ_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes"
 INT4_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
                                                 "*input_quantizer": {"enable": False},
                                                 "*lm_head*": {"enable": False}}, "algorithm": "max"}
+# presets/model/fp8_2d_blockwise_weight_only.yaml: FP8 weights with one scale per 128 x 128 tile
+FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "block_sizes": {-1: 128, -2: 128}},
+                                                  "*input_quantizer": {"enable": False},
+                                                  "*lm_head*": {"enable": False}}, "algorithm": "max"}
 MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*lm_head*": {"enable": False}}, "algorithm": None}

@@ -104,3 +104,24 @@ class SegmentTable:
                                                        int(num_bits), int(unsigned), int(narrow_range),
                                                        stream))
         return self.outputs
+
+    # -- a8 over the table (dynamic MX blocks along the flattened tensors; every numel % block == 0)
+    def mx_fused_amax_convert(self, block_size: int = 32, fmt: str = "E2M1"):
+        if any(t.numel() % block_size or t.shape[-1] % block_size for t in self.inputs):
+            raise MoquantError("every tensor's last dim must be a multiple of the MX block size")
+        if any(t.data_ptr() % 16 for t in self.inputs) or any(t.data_ptr() % 16 for t in self.outputs):
+            raise MoquantError("multi-tensor MX needs 16-byte aligned tensors")
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_mx_fused_amax_convert(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                                          int(block_size), self.dtype_code, _lib.MX_TYPES[fmt], stream))
+        return self.outputs
+
+    # -- a14 over the table: outputs must be uint8 / bool tensors of the inputs' shapes
+    def mask_2to4(self):
+        for x, m in zip(self.inputs, self.outputs):
+            if m.element_size() != 1 or m.numel() != x.numel() or x.shape[-1] % 4:
+                raise MoquantError("mask_2to4: outputs must be 1-byte masks of the inputs' shapes (last dim % 4 == 0)")
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_mask_2to4(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                              self.dtype_code, stream))
+        return self.outputs

@@ -101,6 +101,13 @@ def reduce_amax(input: torch.Tensor, axis=None, keepdims=True, squeeze_scalar=Tr
             return res
         if len(axis) == 0:
             raise MoquantUnsupported("reduce_amax: empty reduce axis list")
+        if _is_block2d_view(x, reduce_axes=axis):
+            # [A, br, B, bc] reduced over (1, 3): 2-D block amax (reduce_block_amax, core_utils.py:43-90)
+            buf = block2d(x, 0, amax=out, accumulate=accumulate)
+            if out is not None:
+                return out
+            res = buf.to(x.dtype)
+            return res if keepdims else res.reshape(x.shape[0], x.shape[2])
         outer, kept, inner, keep = _reduce_layout(list(x.shape), axis)
         buf = out if out is not None else torch.empty(kept, dtype=torch.float32, device=x.device)
         check(_lib.lib().moq_amax_axis(_p(x), outer, kept, inner, _dt(x), _p(buf), int(accumulate), stream))
@@ -154,6 +161,9 @@ def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 
     if inplace and not x.is_contiguous():
         raise MoquantError("in-place fake quant needs a contiguous tensor")  # tensor_quant.cpp:41-42
     am = _f32(amax, x.device)
+    if _is_block2d_view(x, amax_shape=am.shape):
+        return block2d(x, 1, amax=am, fp8=False, num_bits=num_bits, unsigned=unsigned, narrow_range=narrow_range,
+                       out=x if inplace else None)
     if check_inputs:
         # the eager reference raises here (tensor_quant.py:611, :619-620); the CUDA extension only has
         # device asserts.  Both checks cost a device->host sync, so they are opt-in.
@@ -181,6 +191,8 @@ def scaled_e4m3(inputs: torch.Tensor, amax: torch.Tensor | None) -> torch.Tensor
                                                  1, stream))
         else:
             am = _f32(amax, x.device)
+            if _is_block2d_view(x, amax_shape=am.shape):
+                return block2d(x, 1, amax=am, fp8=True, out=y)
             mode, axis_size, inner = _amax_mode(x, am)
             check(_lib.lib().moq_fake_quant_e4m3(_p(x), _p(y), x.numel(), _dt(x), _p(am), mode, axis_size,
                                                  inner, stream))
@@ -212,7 +224,7 @@ _MX_FORMAT_MAP = {(4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3"
 
 @torch.no_grad()
 def fused_amax_convert(inputs: torch.Tensor, block_size: int, fmt: str | int, scale_fmt: str | int = "E8M0",
-                       global_amax: torch.Tensor | None = None) -> torch.Tensor:
+                       global_amax: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
     """MX dynamic block QDQ along the last dim -- cuda_ext_mx.fused_amax_convert
     (tensor_quant_mx.cu:355-387)."""
     _require_gpu(inputs, "fused_amax_convert")
@@ -221,7 +233,7 @@ def fused_amax_convert(inputs: torch.Tensor, block_size: int, fmt: str | int, sc
     sf = _lib.MX_TYPES[scale_fmt] if isinstance(scale_fmt, str) else int(scale_fmt)
     cols = x.shape[-1] if x.dim() else 1
     rows = x.numel() // max(cols, 1)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out  # out may be x itself (in place)
     ga = None if global_amax is None else _f32(global_amax, x.device)
     with _on(x) as stream:
         check(_lib.lib().moq_mx_fused_amax_convert(_p(x), _p(y), rows, cols, int(block_size), _dt(x), f, sf,
@@ -258,13 +270,13 @@ def hist_abs(x: torch.Tensor, bins: int, max_edge: float, skip_zeros: bool = Fal
 
 # ----------------------------------------------------------------------------------------------- sparsity
 @torch.no_grad()
-def mask_2to4(w: torch.Tensor) -> torch.Tensor:
+def mask_2to4(w: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """2:4 magnitude mask over groups of 4 along the last dim of a contiguous 2-D view."""
     _require_gpu(w, "mask_2to4")
     x = w.detach().contiguous()
     cols = x.shape[-1]
     rows = x.numel() // cols
-    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if out is None else out.view(torch.uint8)
     with _on(x) as stream:
         check(_lib.lib().moq_mask_2to4(_p(x), rows, cols, _dt(x), _p(mask), stream))
     return mask.view(torch.bool)
@@ -776,3 +788,43 @@ def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tenso
         check(_lib.lib().moq_awq_quadform(_p(a), _p(gram_op), _p(err), rows, cols, 3 * cols, _lib.BF16, _p(ws),
                                           _p(loss_acc), float(inv_count), stream))
     return loss_acc
+
+
+# ----------------------------------------------------------------------------------------------- 2-D blocks
+def _is_block2d_view(x: torch.Tensor, amax_shape=None, reduce_axes=None) -> bool:
+    """x is the contiguous [A, br, B, bc] view of a 2-D tensor and the amax / kept axes are (0, 2)."""
+    if x.dim() != 4 or not x.is_contiguous():
+        return False
+    if amax_shape is not None:
+        return tuple(amax_shape) == (x.shape[0], 1, x.shape[2], 1) and x.shape[0] * x.shape[2] > 1
+    nd = 4
+    return sorted({a % nd for a in reduce_axes}) == [1, 3]
+
+
+@torch.no_grad()
+def block2d(x4: torch.Tensor, mode: int, amax: torch.Tensor | None = None, accumulate: bool = False,
+            fp8: bool = True, num_bits: int = 8, unsigned: bool = False, narrow_range: bool = False,
+            out: torch.Tensor | None = None):
+    """2-D block abs-max / QDQ on the [A, br, B, bc] view of a [A * br, B * bc] tensor (moq_block2d).
+    mode 0: returns amax fp32 [A, 1, B, 1]; mode 1: QDQ with `amax`; mode 2: (y, amax)."""
+    _require_gpu(x4, "block2d")
+    a_, br, b_, bc = x4.shape
+    rows, cols = a_ * br, b_ * bc
+    x2 = x4.reshape(rows, cols)
+    if not x2.is_contiguous() or x2.data_ptr() != x4.data_ptr():
+        raise MoquantUnsupported("block2d: the 4-D tensor must be a view of a contiguous 2-D tensor")
+    am = amax
+    if mode != 1:
+        if am is None:
+            am = torch.zeros(a_, 1, b_, 1, dtype=torch.float32, device=x4.device)
+    else:
+        am = _f32(amax, x4.device)
+    y = None
+    if mode != 0:
+        y = torch.empty_like(x4) if out is None else out
+    with _on(x4) as stream:
+        check(_lib.lib().moq_block2d(_p(x2), _p(y), _p(am), rows, cols, int(br), int(bc), _dt(x4), int(mode),
+                                     int(accumulate), int(fp8), int(num_bits), int(unsigned), int(narrow_range), stream))
+    if mode == 0:
+        return am
+    return (y, am) if mode == 2 else y

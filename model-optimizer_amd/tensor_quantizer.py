@@ -245,9 +245,21 @@ class TensorQuantizer(nn.Module):
         return g
 
     def _setup_for_blockquant(self, inputs):
-        """Last-axis fast path of tensor_quantizer.py:975-1016: right-pad the last dim with zeros to a block
-        multiple, view as (-1, g), quantization axis (0,)."""
+        """tensor_quantizer.py:975-1043.  Last-axis blocks: right-pad the last dim with zeros to a block multiple,
+        view as (-1, g), quantization axis (0,).  Blocks on BOTH axes of a 2-D tensor (the FP8 2-D blockwise
+        preset): view as (R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D block kernel; shapes
+        that would need padding, and other N-D layouts, raise."""
         if hasattr(self, "_block_reshape_size"):
+            return
+        bs = self._block_sizes
+        axes = {(k if k >= 0 else inputs.dim() + k): v for k, v in bs.items() if isinstance(k, int)}
+        if len(axes) == 2 and inputs.dim() == 2 and set(axes) == {0, 1}:
+            br, bc = axes[0], axes[1]
+            if inputs.shape[0] % br or inputs.shape[1] % bc:
+                raise MoquantUnsupported("2-D block quantization of a shape that needs padding is not on this path")
+            self._original_shape = inputs.shape
+            self._block_reshape_size = torch.Size((inputs.shape[0] // br, br, inputs.shape[1] // bc, bc))
+            self.axis = (0, 2)
             return
         g = self._block_size_last(inputs)
         self._original_shape = inputs.shape
@@ -298,7 +310,7 @@ class TensorQuantizer(nn.Module):
             if tuple(self._num_bits) != (4, 3):
                 raise MoquantUnsupported(f"float format {self._num_bits} without dynamic blocks")
             return ops.scaled_e4m3(inputs, self._get_amax(inputs))
-        if self.is_static_block_quant and not hasattr(self, "_amax"):
+        if self.is_static_block_quant and not hasattr(self, "_amax") and inputs.dim() == 2:
             # dynamic per-block amax + QDQ in one pass (what _get_amax + fake_tensor_quant do in two)
             y, _ = ops.amax_qdq_int_group(inputs, inputs.shape[-1], self._num_bits, self._unsigned,
                                           self._narrow_range, return_amax=False)

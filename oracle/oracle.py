@@ -329,3 +329,15 @@ def create_sgpt_mask(weight, hinv, prune_n=2, prune_m=4, col_bs=128):
         if i2 < cols:
             w[:, i2:] -= delta.matmul(hinv[i1:i2, i2:])
     return w.to(weight.dtype) != 0
+
+
+def block2d(x, br, bc, mode=2, amax=None, fp8=True, num_bits=8, unsigned=False, narrow_range=False):
+    """2-D block amax / QDQ over br x bc tiles of x [rows, cols]: returns (y or None, amax fp32 [rows/br, cols/bc])."""
+    rows, cols = x.shape
+    a = _np(x)
+    y = _empty_like_np(x) if mode != 0 else None
+    am = np.zeros((rows // br, cols // bc), dtype=np.float32) if amax is None else \
+        np.ascontiguousarray(amax.detach().cpu().float().numpy()).reshape(rows // br, cols // bc).copy()
+    lib().orc_block2d(_p(a), _p(y), _p(am), I64(rows), I64(cols), int(br), int(bc), DT[x.dtype], int(mode), int(fp8),
+                      int(num_bits), int(unsigned), int(narrow_range))
+    return (None if y is None else _from_np(y, x.dtype, x.shape)), torch.from_numpy(am)

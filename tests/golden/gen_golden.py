@@ -17,6 +17,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
+  block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
@@ -526,6 +527,28 @@ def gen_sgpt(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_block2d(out):
+    """TensorQuantizer with block_sizes on BOTH axes (FP8 128 x 128 tiles, INT8 64 x 32 tiles): calibrated amax
+    (reduce over the (R/br, br, C/bc, bc) view, tensor_quantizer.py:1018-1043) and the eager fake-quant output."""
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        for nb, br, bc, shape in [((4, 3), 128, 128, (256, 384)), (8, 64, 32, (128, 96))]:
+            w = weight_like(shape, dt, 1900 + idx)
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes={-1: bc, -2: br}))
+            q.disable_quant(); q.enable_calib()
+            q(w)
+            q.load_calib_amax()
+            q.enable_quant(); q.disable_calib()
+            y = q(w)
+            k = f"c{idx}"
+            out[f"{k}_x"], out[f"{k}_y"], out[f"{k}_amax"] = bits(w), bits(y), bits(q._amax.float())
+            cases[k] = dict(dtype=dn, num_bits=list(nb) if isinstance(nb, tuple) else nb, br=br, bc=bc,
+                            amax_shape=list(q._amax.shape), amax_dtype=str(q._amax.dtype).split(".")[-1])
+            idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def extract_mx_vectors():
     """Pull the literal test_in / test_out tables out of the reference's MX test (no execution)."""
     path = os.path.join(ref_shim.REFERENCE_ROOT, "tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py")
@@ -684,11 +707,11 @@ def gen_export(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

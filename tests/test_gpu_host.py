@@ -227,3 +227,32 @@ def test_sequential_quantizer_w4a8_matches_reference(golden, name):
         tol = 1e-6 if lname == "fc1" else (1e-4 if dt == torch.float32 else 2e-2)
         _close(lin.input_quantizer._amax, g.t(f"{name}_{lname}_in_amax"), tol, f"{name} {lname} input amax")
     _close(q(batches[0]), g.t(f"{name}_y", dt), 0.3 if dt == torch.bfloat16 else 2e-2, f"{name} forward")
+
+
+def test_tensor_quantizer_2d_blocks_match_reference(golden):
+    """block_sizes on both axes (FP8 128 x 128 tiles / INT8 64 x 32 tiles): calibrated amax (shape, dtype, values) and
+    the fake-quant output equal the reference's run; kernel modes agree with the oracle."""
+    g = golden("block2d")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x = g.t(f"{k}_x", dt).to(DEV)
+        nb = tuple(c["num_bits"]) if isinstance(c["num_bits"], list) else c["num_bits"]
+        q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes={-1: c["bc"], -2: c["br"]}))
+        q.disable_quant(); q.enable_calib()
+        q(x)
+        q.load_calib_amax()
+        q.enable_quant(); q.disable_calib()
+        y = q(x)
+        assert list(q._amax.shape) == c["amax_shape"] and str(q._amax.dtype).split(".")[-1] == c["amax_dtype"]
+        assert_bits_equal(q._amax.float().cpu(), g.t(f"{k}_amax").reshape(q._amax.shape), f"{k} amax")
+        assert_bits_equal(y.cpu(), g.t(f"{k}_y", dt), f"{k} 2-D block fake quant")
+        # fused mode (amax + QDQ in one read) and running-max accumulation against the oracle
+        fp8 = isinstance(nb, tuple)
+        x4 = x.reshape(x.shape[0] // c["br"], c["br"], x.shape[1] // c["bc"], c["bc"])
+        y2, am2 = ops.block2d(x4, 2, fp8=fp8, num_bits=8 if fp8 else nb)
+        wy, wam = oracle.block2d(x.cpu(), c["br"], c["bc"], 2, fp8=fp8, num_bits=8 if fp8 else nb)
+        assert torch.equal(am2.cpu().reshape(-1), wam.reshape(-1))
+        assert_bits_equal(y2.reshape(x.shape).cpu(), wy, f"{k} fused block2d")
+        am3 = ops.block2d((x4 * 0.5).contiguous(), 0)
+        ops.block2d(x4, 0, amax=am3, accumulate=True)
+        assert torch.equal(am3.cpu().reshape(-1), wam.reshape(-1))

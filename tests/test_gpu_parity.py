@@ -453,3 +453,35 @@ def test_full_size_properties_llama70b_tensor():
     wa = w.view(-1, 4).abs().float()
     kept = (wa * m.view(-1, 4)).sum(1)
     assert torch.equal(kept, wa.topk(2, dim=1).values.sum(1))
+
+
+@pytest.mark.parametrize("dn", ["bf16", "f16", "f32"])
+def test_multi_tensor_mx_equals_per_tensor(dn):
+    """moq_mt_mx_fused_amax_convert over a segment table == moq_mx_fused_amax_convert tensor by tensor == oracle."""
+    dt = DT[dn]
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(64, 256), (8192 + 32, 32), (3, 96), (128, 1024)]
+    ws = [(torch.randn(*s, generator=gen) * torch.exp(torch.randn(s[0], 1, generator=gen))).to(dt).to(DEV) for s in shapes]
+    for fmt, block in [("E2M1", 32), ("E4M3", 32), ("E2M1", 16), ("E3M2", 32)]:
+        tab = moa.multi_tensor.SegmentTable(ws)
+        outs = tab.mx_fused_amax_convert(block, fmt)
+        for w, y in zip(ws, outs):
+            assert_bits_equal(y.cpu(), oracle.mx_fused_amax_convert(w.cpu(), block, fmt), f"mt mx {dn} {fmt} b{block} {tuple(w.shape)}")
+            assert_bits_equal(y, ops.fused_amax_convert(w, block, fmt), f"mt vs single {dn} {fmt}")
+    # in place (outputs = inputs) and the `out=` form of the single-tensor op
+    w0 = ws[0].clone()
+    want = ops.fused_amax_convert(w0, 32, "E2M1")
+    moa.multi_tensor.SegmentTable([w0], outputs=[w0]).mx_fused_amax_convert(32, "E2M1")
+    assert_bits_equal(w0, want, "in-place mt mx")
+    w1 = ws[3].clone()
+    ops.fused_amax_convert(w1, 32, "E2M1", out=w1)
+    assert_bits_equal(w1, ops.fused_amax_convert(ws[3], 32, "E2M1"), "in-place single mx")
+
+
+def test_multi_tensor_mask_equals_per_tensor():
+    gen = torch.Generator().manual_seed(2)
+    ws = [torch.randn(*s, generator=gen).to(torch.bfloat16).to(DEV) for s in [(64, 256), (8192 + 8, 16), (3, 96), (100, 1024)]]
+    masks = [torch.empty(w.shape, dtype=torch.bool, device=DEV) for w in ws]
+    moa.multi_tensor.SegmentTable(ws, outputs=masks).mask_2to4()
+    for w, m in zip(ws, masks):
+        assert torch.equal(m.cpu(), oracle.mask_2to4(w.cpu()))

@@ -296,3 +296,15 @@ def test_real_quant_fp8_mxfp4_match_reference(golden):
             assert torch.equal(got_q.reshape(-1), want_q.reshape(-1)), f"{k}: mxfp4 bytes differ"
             got = oracle.mxfp4_unpack(want_q, torch.from_numpy(g.raw(f"{k}_e8m0").copy()), dt, c["block"])
             assert_bits_equal(got, want_deq, f"{k}: mxfp4 dequant")
+
+
+def test_block2d_matches_reference(golden):
+    """orc_block2d vs TensorQuantizer with blocks on both axes run by the reference on CPU: amax and QDQ bit-exact."""
+    g = golden("block2d")
+    for k, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        x, want = g.t(f"{k}_x", dt), g.t(f"{k}_y", dt)
+        fp8 = isinstance(c["num_bits"], list)
+        y, am = oracle.block2d(x, c["br"], c["bc"], 2, fp8=fp8, num_bits=8 if fp8 else c["num_bits"])
+        assert torch.equal(am.reshape(-1), g.t(f"{k}_amax").reshape(-1)), f"{k}: block amax"
+        assert_bits_equal(y, want, f"block2d {k} {c}")
