@@ -275,7 +275,8 @@ def main():
     value = world * n_elem * 2 / (elapsed / args.steps) / 1e9
 
     # dominant kernel: average launch duration from the HIP events recorded inside the timed region
-    dom_ms = sum(a.elapsed_time(b) for a, b in dom_events) / len(dom_events)
+    dom_all = [a.elapsed_time(b) for a, b in dom_events]
+    dom_ms = sum(dom_all) / len(dom_all)
     alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mask24": 3.0}[wl]
     dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
                 "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
@@ -285,7 +286,8 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
-                "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4)}
+                "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4),
+                "min_launch_ms": round(min(dom_all), 4), "max_launch_ms": round(max(dom_all), 4)}
 
     out = {
         "metric": f"GB/s weights calibrated+QDQ ({MODEL_NAMES[args.model]})",
