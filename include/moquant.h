@@ -289,11 +289,12 @@ int moq_awq_clip_loss(const void* x, int64_t n_tok, int64_t x_row_stride, const 
 
 /* out[i] = e4m3fn( dt( x[i] / scale ) ): the quotient is rounded to the storage dtype first (both operands of the
  * reference's division have the model dtype), then cast with torch's NON-saturating RNE cast (|v| > 464 or NaN ->
- * 0x7F | sign).  scales: dtype dt; amax_mode MOQ_AMAX_SCALAR: scales[0]; MOQ_AMAX_AXIS: scales[(i / inner) %
+ * 0x7F | sign).  scales: dtype scale_dt = dt (FP8QTensor: amax / 448 in the model dtype) or MOQ_F32 (checkpoint export:
+ * fp32 weights_scaling_factor; the quotient is still rounded to dt); amax_mode MOQ_AMAX_SCALAR: scales[0]; MOQ_AMAX_AXIS: scales[(i / inner) %
  * axis_size] (per-channel rows: inner = Cin; 1-D blocks: inner = block, axis_size = n / block).
  * Replaces FP8QTensor.quantize's cast (quantization/qtensor/fp8_tensor.py:103-107) and the FP8 branch of
  * to_quantized_weight (export/quant_utils.py).  n % (16 / elem size) == 0, inner likewise. */
-int moq_fp8_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int dt, int amax_mode,
+int moq_fp8_pack(const void* x, const void* scales, int scale_dt, uint8_t* out, int64_t n, int dt, int amax_mode,
                  int64_t axis_size, int64_t inner, void* stream);
 /* out[i] = dt( dt(float(q[i])) * scale ) -- FP8QTensor.dequantize (fp8_tensor.py:151). */
 int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, int64_t n, int dt, int amax_mode,

@@ -78,7 +78,7 @@ SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "moq_awq_clip_loss": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int,
                                   c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "moq_fp8_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "moq_fp8_pack": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
     "moq_fp8_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_void_p]),
     "moq_mxfp4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "moq_mxfp4_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

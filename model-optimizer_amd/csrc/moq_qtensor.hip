@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t e4m3fn_bytes2(float a, float b) {
 // ---------------------------------------------------------------- FP8 pack / unpack
 // scales have the storage dtype DT (the reference divides two tensors of the model dtype).  AXIS: one scale per
 // `inner` consecutive elements, index = (e / inner) % axis_size (per-channel rows, 1-D blocks); else one scale.
-template <int DT, bool AXIS>
+template <int DT, bool AXIS, bool SF32>
 __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict__ x,
                                                           const void* __restrict__ scales,
                                                           uint8_t* __restrict__ out, int64_t n, int64_t axis_size,
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
   GroupIndex gi;
   gi.g = (uint32_t)inner;
   gi.shift = inner_shift;
-  const float s0 = AXIS ? 1.0f : load1<DT>(scales, 0);
+  auto ld_scale = [&](int64_t i) { return SF32 ? reinterpret_cast<const float*>(scales)[i] : load1<DT>(scales, i); };
+  const float s0 = AXIS ? 1.0f : ld_scale(0);
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     if (AXIS) gi.seek(e0);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
         if (AXIS) {
           int64_t row = gi.at((uint32_t)packet_off<DT>(u));
           if (wrap) row %= axis_size;
-          sc[u] = load1<DT>(scales, row);
+          sc[u] = ld_scale(row);
         }
       }
     }
@@ -295,8 +296,13 @@ static int fp8_args_ok(const char* who, const void* a, const void* b, const void
   return MOQ_OK;
 }
 
-extern "C" int moq_fp8_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int dt, int amax_mode,
-                            int64_t axis_size, int64_t inner, void* stream) {
+extern "C" int moq_fp8_pack(const void* x, const void* scales, int scale_dt, uint8_t* out, int64_t n, int dt,
+                            int amax_mode, int64_t axis_size, int64_t inner, void* stream) {
+  if (scale_dt != MOQ_F32 && scale_dt != dt) {
+    set_error("moq_fp8_pack: scale_dt must be MOQ_F32 or the tensor dtype");
+    return MOQ_ERR_INVALID;
+  }
+  const bool sf32 = scale_dt == MOQ_F32 && dt != MOQ_F32;
   const int rc = fp8_args_ok("moq_fp8_pack", x, scales, out, n, amax_mode, axis_size, inner);
   if (rc != MOQ_OK || n == 0) return rc;
   const int vec = dt == MOQ_F32 ? 4 : 8;
@@ -308,10 +314,18 @@ extern "C" int moq_fp8_pack(const void* x, const void* scales, uint8_t* out, int
   const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
   if (amax_mode == MOQ_AMAX_AXIS) {
     const int wrap = n > axis_size * inner ? 1 : 0;
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
-                                              scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
+    if (sf32) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                                x, scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+                                                x, scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
+    }
+  } else if (sf32) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+                                              scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   }
   return check_launch("moq_fp8_pack");

@@ -189,6 +189,8 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         return ops.pack_int4_in_uint8(weight, weights_scaling_factor)
     wsf = weights_scaling_factor.to(weight.device)
     if quantization == QUANTIZATION_FP8:
+        if weight.is_cuda and weight.dtype in (torch.bfloat16, torch.float16) and weight.numel() % 8 == 0:
+            return ops.fp8_quantize(weight, wsf, fp32_scales=True)  # one kernel: divide, round to dtype, cast
         return (weight / wsf).to(torch.float8_e4m3fn)
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
         return (weight / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)

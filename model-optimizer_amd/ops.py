@@ -637,16 +637,19 @@ def _scale_layout(x: torch.Tensor, scales: torch.Tensor):
 
 
 @torch.no_grad()
-def fp8_quantize(inputs: torch.Tensor, scales: torch.Tensor) -> torch.Tensor:
+def fp8_quantize(inputs: torch.Tensor, scales: torch.Tensor, fp32_scales: bool = False) -> torch.Tensor:
     """(inputs / scales).to(torch.float8_e4m3fn) -- FP8QTensor.quantize's cast (fp8_tensor.py:103-107) / the FP8
-    branch of to_quantized_weight.  scales: 1 element, per row, or per last-dim block (row-major order)."""
+    branch of to_quantized_weight.  scales: 1 element, per row, or per last-dim block (row-major order); they are
+    used in the tensor dtype (FP8QTensor) or, with fp32_scales, in fp32 (export: the quotient of a 16-bit weight and
+    an fp32 scaling factor is still rounded to the weight dtype before the cast)."""
     _require_gpu(inputs, "fp8_quantize")
     x = inputs.detach().contiguous()
-    s = scales.detach().to(device=x.device, dtype=x.dtype).contiguous().reshape(-1)
+    sdt = torch.float32 if fp32_scales else x.dtype
+    s = scales.detach().to(device=x.device, dtype=sdt).contiguous().reshape(-1)
     mode, axis_size, inner = _scale_layout(x, s)
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     with _on(x) as stream:
-        check(_lib.lib().moq_fp8_pack(_p(x), _p(s), _p(out), x.numel(), _dt(x), mode, axis_size, inner, stream))
+        check(_lib.lib().moq_fp8_pack(_p(x), _p(s), _DT[sdt], _p(out), x.numel(), _dt(x), mode, axis_size, inner, stream))
     return out.view(torch.float8_e4m3fn)
 
 

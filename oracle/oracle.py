@@ -271,12 +271,14 @@ def _mode(x, scales, axis_size, inner):
     return (0, 1, 1) if scales.numel() == 1 else (1, axis_size, inner)
 
 
-def fp8_pack(x, scales, axis_size=1, inner=1):
-    """(x / scales).to(float8_e4m3fn) bytes, scales in x.dtype (FP8QTensor.quantize, fp8_tensor.py:103-107)."""
-    a, s = _np(x), _np(scales.to(x.dtype))
+def fp8_pack(x, scales, axis_size=1, inner=1, fp32_scales=False):
+    """(x / scales).to(float8_e4m3fn) bytes; scales in x.dtype (FP8QTensor.quantize, fp8_tensor.py:103-107) or fp32
+    (to_quantized_weight of the checkpoint export)."""
+    sdt = torch.float32 if fp32_scales else x.dtype
+    a, s = _np(x), _np(scales.to(sdt))
     out = np.empty(x.numel(), dtype=np.uint8)
     m, ax, inn = _mode(x, scales, axis_size, inner)
-    lib().orc_fp8_pack(_p(a), _p(s), _p(out), I64(x.numel()), DT[x.dtype], m, I64(ax), I64(inn))
+    lib().orc_fp8_pack(_p(a), _p(s), DT[sdt], _p(out), I64(x.numel()), DT[x.dtype], m, I64(ax), I64(inn))
     return torch.from_numpy(out).reshape(x.shape)
 
 
