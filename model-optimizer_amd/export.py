@@ -28,6 +28,7 @@ QUANTIZATION_FP8 = "fp8"
 QUANTIZATION_INT8_SQ = "int8_sq"
 QUANTIZATION_INT8_WO = "int8_wo"
 QUANTIZATION_INT4_AWQ = "int4_awq"
+QUANTIZATION_MXFP4 = "mxfp4"
 
 
 def get_quantization_format(module) -> str | None:
@@ -44,6 +45,9 @@ def get_quantization_format(module) -> str | None:
         return QUANTIZATION_INT8_SQ if iq.is_enabled else QUANTIZATION_INT8_WO
     if isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is None:
         return QUANTIZATION_FP8
+    if (isinstance(nb, (tuple, list)) and tuple(nb) == (2, 1) and wq.block_sizes is not None
+            and tuple(wq.block_sizes.get("scale_bits", ())) == (8, 0)):
+        return QUANTIZATION_MXFP4  # export/quant_utils.py:585-586
     raise NotImplementedError(f"export of weight format num_bits={nb} block_sizes={wq.block_sizes} is outside this path")
 
 
@@ -192,6 +196,8 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         if weight.is_cuda and weight.dtype in (torch.bfloat16, torch.float16) and weight.numel() % 8 == 0:
             return ops.fp8_quantize(weight, wsf, fp32_scales=True)  # one kernel: divide, round to dtype, cast
         return (weight / wsf).to(torch.float8_e4m3fn)
+    if quantization == QUANTIZATION_MXFP4:
+        raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
         return (weight / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)
     raise NotImplementedError(f"quantization format {quantization} not supported")
@@ -206,6 +212,13 @@ def export_quantized_weight(module, dtype: torch.dtype):
         return {"weight": module.weight.detach()}
     wq, iq = module.weight_quantizer, module.input_quantizer
     out = {}
+    if fmt == QUANTIZATION_MXFP4:
+        # export/quant_utils.py:304-307, :935-936: MXFP4QTensor.quantize gives the packed nibbles and the E8M0 scale
+        # bytes in one pass (moq_mxfp4_pack); the scales are stored as [..., Cin / block]
+        block = wq.block_sizes.get(-1) or wq.block_sizes.get(module.weight.dim() - 1)
+        w = module.weight.detach().to(dtype)
+        packed, e8m0 = ops.mxfp4_quantize(w, block)
+        return {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
     if fmt == QUANTIZATION_FP8:
         amax = wq._amax.to(torch.float32)
         # per-tensor: python float division of amax.item() (unified_export_hf.py:643-647)
@@ -250,7 +263,7 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
 def hf_quant_config(model, group_size: int | None = None) -> dict:
     """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
     fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
-    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
+    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
             QUANTIZATION_INT8_WO: "W8A16"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
     q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": None}

@@ -21,6 +21,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
+  export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
@@ -746,14 +747,43 @@ def gen_export_fp8(out):
                                              hf_quant_config=quant_cfg)))
 
 
+def gen_export_mxfp4(out):
+    """MXFP4 (dynamic blocks of 32, E8M0 scales; MXFP4_DEFAULT_CFG, no calibration) export of the tiny bf16 Llama by
+    the reference: original weights and every exported tensor (packed nibbles, E8M0 scale bytes)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    model = LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)).to(torch.bfloat16)
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    q = mtq.quantize(model, mtq.MXFP4_DEFAULT_CFG, None)
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")
