@@ -87,6 +87,8 @@ SIGNATURES = {
     "moq_symmetrize": (c_int, [c_void_p, c_int64, c_void_p]),
     "moq_sgpt_block_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p]),
+    "moq_awq_err_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
+                                   c_void_p]),
     "moq_awq_quadform": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                  c_double, c_void_p]),
     "moq_block2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,

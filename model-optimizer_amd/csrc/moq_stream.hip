@@ -291,6 +291,94 @@ __device__ __forceinline__ void group_chunk(const void* __restrict__ x, void* __
   }
 }
 
+// AWQ Gram search: the fp32 error weight of one candidate scale, E = dt(QDQ(dt(W * s))) * r - W (r = fp32 value of the
+// dtype-rounded 1/s the input side uses), straight from one read of W -- plus its split-precision MFMA operand
+// A = [E_hi | E_hi | E_lo] (bf16 [rows, 3 cols], E_hi = bf16(E), E_lo = bf16(E - E_hi)) for moq_awq_quadform.
+// Replaces awq_scale_qdq + float() + mul + sub + two casts + a concatenation (ten elementwise passes, ~50 B/element)
+// by one kernel: 2 B read, 4 + 6 B written per element.
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void awq_err_weight_kernel(const void* __restrict__ w,
+                                                                const void* __restrict__ s,
+                                                                const float* __restrict__ r,
+                                                                float* __restrict__ e_out,
+                                                                uint16_t* __restrict__ a_out, int64_t n,
+                                                                int64_t cols, int cols_shift, int num_bits) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const IntQ q = make_intq(num_bits, 0, 0);
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  GroupIndex gi;
+  gi.g = (uint32_t)cols;
+  gi.shift = cols_shift;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    gi.seek(e0);
+    Pack16 in[P], sc[P];
+    int64_t row[P];
+    uint32_t col[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      row[u] = gi.at((uint32_t)packet_off<DT>(u));
+      col[u] = (uint32_t)(e - row[u] * cols);
+      if (e < n) {
+        in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
+        sc[u] = load16(reinterpret_cast<const char*>(s) + (int64_t)col[u] * (16 / V));
+      } else {
+        in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+        sc[u] = in[u];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      float w0[8], f[8], sf[8];
+      unpack<DT>(in[u], w0);
+      unpack<DT>(sc[u], sf);
+      uint32_t m = 0;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        f[i] = round_to_dtype<DT>(w0[i] * sf[i]);  // (W * s).to(dtype)
+        const uint32_t a = absbits(f[i]);
+        m = a > m ? a : m;
+      }
+      m = group_max_u32<LPG>(m);
+      const float scale = int_scale(__uint_as_float(m), q.hi);
+      const SharedDiv sd = make_shared_div(scale);
+      if (e >= n) continue;
+      float err[8], lo[8];
+      uint32_t hi_bits[8];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float what = round_to_dtype<DT>(qdq_int_shared(f[i], scale, sd, q));
+        const float t = what * r[col[u] + i];
+        err[i] = t - w0[i];
+        const float hi = round_to_dtype<MOQ_BF16>(err[i]);
+        hi_bits[i] = __float_as_uint(hi) >> 16;
+        lo[i] = err[i] - hi;
+      }
+      float* ep = e_out + e;
+      *reinterpret_cast<float4*>(ep) = make_float4(err[0], err[1], err[2], err[3]);
+      if constexpr (V == 8) *reinterpret_cast<float4*>(ep + 4) = make_float4(err[4], err[5], err[6], err[7]);
+      uint16_t* ap = a_out + row[u] * 3 * cols + col[u];
+      const Pack16 plo = pack<MOQ_BF16>(lo);
+      if constexpr (V == 8) {
+        Pack16 phi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) phi.w[i] = hi_bits[2 * i] | (hi_bits[2 * i + 1] << 16);
+        store16(ap, phi);
+        store16(ap + cols, phi);
+        store16(ap + 2 * cols, plo);
+      } else {
+        const uint2 phi = make_uint2(hi_bits[0] | (hi_bits[1] << 16), hi_bits[2] | (hi_bits[3] << 16));
+        *reinterpret_cast<uint2*>(ap) = phi;
+        *reinterpret_cast<uint2*>(ap + cols) = phi;
+        *reinterpret_cast<uint2*>(ap + 2 * cols) = make_uint2(plo.w[0], plo.w[1]);
+      }
+    }
+  }
+}
+
 // tail / unaligned groups: one thread per group, scalar (rare: only when n is not a chunk multiple or
 // the base pointer is not 16-byte aligned)
 template <int DT, bool QDQ, bool PRESCALE>
@@ -674,4 +762,30 @@ extern "C" int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk
                                                                   n_chunks, num_bits, is_unsigned,
                                                                   narrow_range)));
   return check_launch("moq_mt_amax_qdq_int_group");
+}
+
+extern "C" int moq_awq_err_weight(const void* w, const void* s, const float* r, float* e_out, void* a_out, int64_t rows,
+                                  int64_t cols, int g, int dt, int num_bits, void* stream) {
+  if (w == nullptr || s == nullptr || r == nullptr || e_out == nullptr || a_out == nullptr || rows <= 0 || cols <= 0 ||
+      g <= 0 || num_bits < 2 || num_bits > 8) {
+    set_error("moq_awq_err_weight: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = g / vec;
+  if (cols % g != 0 || g % vec != 0 || lpg > 64 || (lpg & (lpg - 1)) != 0 || MOQ_MT_CHUNK % g != 0 ||
+      cols >= (1LL << 31) ||
+      ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(r) |
+        reinterpret_cast<uintptr_t>(e_out) | reinterpret_cast<uintptr_t>(a_out)) & 15u) != 0) {
+    set_error("moq_awq_err_weight: needs cols %% g == 0, g / %d a power of two <= 64, 16-byte aligned pointers", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int64_t n = rows * cols;
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  const int cs = log2_or_neg(cols);
+  MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((awq_err_weight_kernel<DT, LPG>), dim3(grid),
+                                                                  dim3(kBlock), 0, S(stream), w, s, r, e_out,
+                                                                  reinterpret_cast<uint16_t*>(a_out), n, cols, cs,
+                                                                  num_bits)));
+  return check_launch("moq_awq_err_weight");
 }

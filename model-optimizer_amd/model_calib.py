@@ -316,22 +316,24 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     reference fixtures, same best alpha; tests/test_gpu_host.py, tests/test_gpu_awq_search.py)."""
     w = module.weight
     dt = w.dtype
-    wf = w.float()
     n_out = w.shape[0]
     bits = module.weight_quantizer.num_bits
     # 16-bit models: the Cout x Cin x Cin contraction runs on the matrix cores in split precision (three bf16
     # products summed in the fp32 accumulators, ~1e-5 relative) with the <., E> product fused; fp32 models keep the
     # library's fp32 GEMM (agreement with the reference to ~1e-6 is asserted for them)
-    mfma = dt in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0
+    mfma = dt in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0 and w.shape[1] % h.block_size == 0
+    wf = None if mfma else w.float()
     gram_op = ops.gram_operand(h.gram) if mfma else None
     for i, alpha in enumerate(h.alphas):
         s = get_scale(h.act_scale, h.weight_scale, alpha)
         r = (1 / s).to(dt).float()  # input_quantizer.pre_quant_scale as the forward uses it (:1551)
-        w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
-        err = w_hat.float().mul_(r).sub_(wf)
         if mfma:
-            ops.awq_quadform(err, gram_op, h.loss_buf[i:i + 1], 1.0 / n_out)
+            # E and its split-precision MFMA operand from ONE read of W, then <E G, E> on the matrix cores
+            err, a_op = ops.awq_err_weight(w, s.to(dt), r, h.block_size, bits)
+            ops.awq_quadform(err, gram_op, h.loss_buf[i:i + 1], 1.0 / n_out, a_operand=a_op)
         else:
+            w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
+            err = w_hat.float().mul_(r).sub_(wf)
             h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
     h.num_search_steps = h.num_cache_steps
 

@@ -774,7 +774,26 @@ def gram_operand(gram: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tensor, inv_count: float) -> torch.Tensor:
+def awq_err_weight(weight: torch.Tensor, awq_scale_dt: torch.Tensor, inv_scale_f32: torch.Tensor, group_size: int,
+                   num_bits: int = 4):
+    """(E fp32 [Cout, Cin], A bf16 [Cout, 3 Cin]) of one candidate: E = QDQ((W * s).to(dtype)) * r - W and its
+    split-precision MFMA operand, from one read of W."""
+    _require_gpu(weight, "awq_err_weight")
+    w = weight.detach().contiguous()
+    rows, cols = w.shape
+    s = awq_scale_dt.detach().to(device=w.device, dtype=w.dtype).contiguous().reshape(-1)
+    r = _f32(inv_scale_f32, w.device).reshape(-1)
+    err = torch.empty(rows, cols, dtype=torch.float32, device=w.device)
+    a = torch.empty(rows, 3 * cols, dtype=torch.bfloat16, device=w.device)
+    with _on(w) as stream:
+        check(_lib.lib().moq_awq_err_weight(_p(w), _p(s), _p(r), _p(err), _p(a), rows, cols, int(group_size), _dt(w),
+                                            int(num_bits), stream))
+    return err, a
+
+
+@torch.no_grad()
+def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tensor, inv_count: float,
+                 a_operand: torch.Tensor | None = None) -> torch.Tensor:
     """loss_acc[0] += inv_count * trace(E G E^T) = inv_count * <E G, E> for the fp32 error weight E [Cout, Cin] and
     gram_op = gram_operand(G): one MFMA contraction over K = 3 Cin (split-precision: E_hi G_hi + E_hi G_lo + E_lo G_hi)
     with the product against E fused into the epilogue."""
@@ -784,8 +803,11 @@ def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tenso
     rows, cols = err.shape
     if tuple(gram_op.shape) != (cols, 3 * cols) or loss_acc.dtype != torch.float32 or loss_acc.numel() != 1:
         raise MoquantError("awq_quadform: operand shapes do not match")
-    hi, lo = split_bf16(err)
-    a = torch.cat([hi, hi, lo], dim=1).contiguous()
+    if a_operand is None:
+        hi, lo = split_bf16(err)
+        a = torch.cat([hi, hi, lo], dim=1).contiguous()
+    else:
+        a = a_operand
     ws = torch.empty(int(_lib.lib().moq_awq_err_gemm_workspace(rows, cols)), dtype=torch.float32, device=err.device)
     with _on(err) as stream:
         check(_lib.lib().moq_awq_quadform(_p(a), _p(gram_op), _p(err), rows, cols, 3 * cols, _lib.BF16, _p(ws),

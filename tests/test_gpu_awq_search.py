@@ -84,3 +84,20 @@ def test_quadform_split_precision_vs_fp64():
         assert abs(got - want) <= 5e-5 * abs(want), f"{cout}x{cin}: {got} vs {want}"
         ops.awq_quadform(e.to(DEV), ops.gram_operand(g.to(DEV)), acc, 1.0 / cout)  # accumulates
         assert abs(acc.item() - 2 * want) <= 1e-4 * abs(want)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_err_weight_kernel_equals_composed_ops(dtype):
+    """moq_awq_err_weight (one read of W) == awq_scale_qdq -> float -> * r -> - W and the bf16 split, bit for bit."""
+    from model_optimizer_amd import ops
+
+    gen = torch.Generator().manual_seed(5)
+    for cout, cin, g in [(96, 512, 128), (33, 256, 64), (260, 8192 + 128, 128)]:
+        w = (torch.randn(cout, cin, generator=gen) * 0.02).to(dtype).to(DEV)
+        s = torch.exp(torch.randn(cin, generator=gen) * 0.5).to(dtype).to(DEV)
+        r = (1 / s.float()).to(dtype).float()
+        err, a = ops.awq_err_weight(w, s, r, g, 4)
+        want = ops.awq_scale_qdq(w, s, g, 4).float().mul_(r).sub_(w.float())
+        assert torch.equal(err, want), f"E differs ({cout}x{cin} g={g})"
+        hi, lo = ops.split_bf16(want)
+        assert torch.equal(a, torch.cat([hi, hi, lo], dim=1)), "split-precision operand differs"
