@@ -49,6 +49,10 @@ template <> struct Geo<2> { static constexpr int TILE = 256, WAVES = 8, WN = 2, 
 //          before a step is a counted vmcnt(8) (never 0 in steady state) -- the GEO 2 loop keeps one 64 KiB tile in
 //          flight and drains the queue every step, which parks its waves ~35 % of the time (SQ_WAIT_ANY)
 template <> struct Geo<3> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 4; };
+//   GEO 4: GEO 2 with the K-loop rotated by one sub-step: the MFMAs of the LAST sub-step of tile k run after the barrier
+//          that opens tile k + 1, underneath that tile's first fragment reads -- the matrix cores no longer idle
+//          through "wait for the DMA, barrier, first ds_reads" at every K-step boundary
+template <> struct Geo<4> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -145,14 +149,22 @@ __device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int
 #pragma unroll
       for (int j = 0; j < NJ; ++j) b[nxt][j] = read_frag(lb, j * 32 + fr, c);
     }
+#ifdef MOQ_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[cur][i], b[cur][j], acc[i][j]);
+#ifdef MOQ_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#ifndef MOQ_GEMM_NOPIN
     // pin the issue order hipcc would otherwise collapse: the next sub-step's reads go out first, then this
     // sub-step's MFMAs run while they are in flight (mask 0x100 = DS read, 0x008 = MFMA)
     if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+#endif
   }
 }
 
@@ -265,7 +277,57 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 3) {
+  if constexpr (GEO == 4) {
+    const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
+    const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
+    Pack16 a[2][NI], b[2][NJ];
+    auto read_sub = [&](int buf, int stage_off, int ks) {
+      const int c = ks * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[buf][i] = read_frag(la0 + stage_off, i * 32 + fr, c);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[buf][j] = read_frag(lb0 + stage_off, j * 32 + fr, c);
+    };
+    auto mma_sub = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[buf][i], b[buf][j], acc[i][j]);
+    };
+    stage_tile<2, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
+    stage_tile<2, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int so = (kt & 1) * SB;
+      // tile kt landed (own part; the barrier makes it everyone's) and every fragment read of tile kt - 1 has
+      // completed -- its last sub-step sits in a[1] / b[1], not yet multiplied
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      read_sub(0, so, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      if (kt > 0) {
+        mma_sub(1);  // last sub-step of tile kt - 1, under the reads above
+        __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+      }
+      if (kt + 1 < nk) {  // next tile's DMA: its address arithmetic issues in the gaps of the MFMAs above
+        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        stage_tile<2, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        stage_tile<2, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+      }
+      read_sub(1, so, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      mma_sub(0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+      read_sub(0, so, 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      mma_sub(1);
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+      read_sub(1, so, 3);
+      __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      mma_sub(0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+    }
+    mma_sub(1);  // last sub-step of the last tile
+  } else if constexpr (GEO == 3) {
     constexpr int BK3 = 32;
     const int nk3 = (K + BK3 - 1) / BK3;
     // prologue: three tiles in flight
@@ -477,11 +539,11 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
 }
 
 static int gemm_geo() {
-  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 | 3 selects the tile geometry (A/B knob, read once)
+  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 | 3 | 4 selects the tile geometry / loop structure (A/B knob, read once)
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
-    const int g = e ? atoi(e) : 2;
-    return g < 0 || g > 3 ? 2 : g;
+    const int g = e ? atoi(e) : 4;
+    return g < 0 || g > 4 ? 4 : g;
   }();
   return geo;
 }
@@ -533,7 +595,8 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    default: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
   return nblk;
 }
