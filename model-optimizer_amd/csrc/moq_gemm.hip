@@ -53,6 +53,9 @@ template <> struct Geo<3> { static constexpr int TILE = 256, WAVES = 8, WN = 2, 
 //          that opens tile k + 1, underneath that tile's first fragment reads -- the matrix cores no longer idle
 //          through "wait for the DMA, barrier, first ds_reads" at every K-step boundary
 template <> struct Geo<4> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+//   GEO 5 (experiment): the GEO 4 loop with FOUR waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator registers, one
+//          wave per SIMD): 8 fragment reads per 16 MFMAs instead of 6 per 8 -- a third less LDS read traffic
+template <> struct Geo<5> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -226,7 +229,7 @@ __device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, in
 //         ONCE when the accumulation is over (moq_symmetrize);
 // MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
-__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : 2)
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 ? 1 : 2))
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ w,     // [N, K]
                      const void* __restrict__ ref,   // [T, N] (MODE 0)
@@ -277,7 +280,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 4) {
+  if constexpr (GEO == 4 || GEO == 5) {
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
     Pack16 a[2][NI], b[2][NJ];
@@ -294,8 +297,8 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[buf][i], b[buf][j], acc[i][j]);
     };
-    stage_tile<2, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
-    stage_tile<2, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
+    stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
+    stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
       const int so = (kt & 1) * SB;
       // tile kt landed (own part; the barrier makes it everyone's) and every fragment read of tile kt - 1 has
@@ -310,8 +313,8 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       }
       if (kt + 1 < nk) {  // next tile's DMA: its address arithmetic issues in the gaps of the MFMAs above
         uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
-        stage_tile<2, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        stage_tile<2, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
       }
       read_sub(1, so, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
@@ -543,7 +546,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 4;
-    return g < 0 || g > 4 ? 4 : g;
+    return g < 0 || g > 5 ? 4 : g;
   }();
   return geo;
 }
@@ -595,6 +598,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 5: launch_geo<MODE, 5>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
