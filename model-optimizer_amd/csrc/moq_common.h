@@ -317,7 +317,10 @@ __device__ __forceinline__ float shared_div(float n, const SharedDiv& s) {
   const float r0 = __builtin_fmaf(-s.d, q0, n);
   const float q1 = __builtin_fmaf(r0, s.y, q0);
   const float r1 = __builtin_fmaf(-s.d, q1, n);
-  return __builtin_fmaf(r1, s.y, q1);
+  const float q = __builtin_fmaf(r1, s.y, q1);
+  // a zero numerator: the residual steps turn -0 into +0 ((+0) + (-0) = +0 in round-to-nearest), IEEE division
+  // keeps the sign (-0 / d = -0 for d > 0) -- and so does the first product
+  return q0 == 0.0f ? q0 : q;
 }
 // INT-k QDQ with a group-shared scale: same arithmetic as qdq_int, division through SharedDiv
 __device__ __forceinline__ float qdq_int_shared(float x, float scale, const SharedDiv& sd, const IntQ& q) {

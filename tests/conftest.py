@@ -51,21 +51,30 @@ def golden():
     return get
 
 
+_INT_VIEW = {torch.float32: torch.int32, torch.float16: torch.int16, torch.bfloat16: torch.int16, torch.float64: torch.int64}
+
+
+def _same_bits(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Elementwise: identical bit patterns (so -0.0 != +0.0), except that any NaN equals any NaN."""
+    if a.dtype in _INT_VIEW:
+        ai, bi = a.contiguous().view(_INT_VIEW[a.dtype]), b.contiguous().view(_INT_VIEW[b.dtype])
+        return (ai == bi) | (torch.isnan(a) & torch.isnan(b))
+    return a == b
+
+
 def bits_equal(a: torch.Tensor, b: torch.Tensor) -> bool:
-    """Bit-exact equality that treats NaN == NaN and +0 == -0 like torch.equal does not."""
+    """Bit-exact equality (the sign of zero counts); NaN == NaN."""
     a, b = a.detach().cpu(), b.detach().cpu()
     if a.shape != b.shape or a.dtype != b.dtype:
         return False
-    both_nan = torch.isnan(a.float()) & torch.isnan(b.float())
-    return bool(((a == b) | both_nan).all())
+    return bool(_same_bits(a, b).all())
 
 
 def assert_bits_equal(a, b, what=""):
     a, b = a.detach().cpu(), b.detach().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     assert a.dtype == b.dtype, f"{what}: dtype {a.dtype} vs {b.dtype}"
-    both_nan = torch.isnan(a.float()) & torch.isnan(b.float())
-    bad = ~((a == b) | both_nan)
+    bad = ~_same_bits(a, b)
     if bad.any():
         i = bad.reshape(-1).nonzero()[0].item()
         raise AssertionError(
