@@ -330,6 +330,23 @@ __device__ __forceinline__ float qdq_int_shared(float x, float scale, const Shar
   t = (p != p) ? p : t;
   return scale == 0.0f ? t : shared_div(t, sd);
 }
+// The same result with five VALU ops less per element, for groups where it is provably safe: every element of the
+// group is finite (the group abs-max is finite), the scale is an ordinary positive number (amax > 2^-24) inside
+// SharedDiv's exact window.  Then x * scale is finite, so no NaN can appear (no re-injection), the clamp can be the
+// single v_med3_f32, the divide needs no fallback, and the only thing the residual steps of the shared division
+// lose -- the sign of a zero quotient -- is put back by copying the sign of the (integer) numerator (v_bfi_b32).
+__device__ __forceinline__ bool qdq_fast_ok(uint32_t amax_bits, float scale, const SharedDiv& sd) {
+  return sd.fast && scale != 0.0f && amax_bits < 0x7F800000u;
+}
+__device__ __forceinline__ float qdq_int_fast(float x, float scale, const SharedDiv& sd, const IntQ& q) {
+  float t = __builtin_rintf(x * scale);
+  t = __builtin_amdgcn_fmed3f(t, q.lo, q.hi);
+  const float q0 = t * sd.y;
+  const float r0 = __builtin_fmaf(-sd.d, q0, t);
+  const float q1 = __builtin_fmaf(r0, sd.y, q0);
+  const float r1 = __builtin_fmaf(-sd.d, q1, t);
+  return __builtin_copysignf(__builtin_fmaf(r1, sd.y, q1), t);
+}
 __device__ __forceinline__ float qdq_int(float x, float scale, const IntQ& q) {
   // rint(x*scale), clamp, then IEEE divide by the same scale; scale == 0 encodes the tiny-amax case where
   // the reference multiplies by 0 and divides by 1.  torch.clamp propagates NaN while fmaxf/fminf drop

@@ -284,8 +284,13 @@ __device__ __forceinline__ void group_chunk(const void* __restrict__ x, void* __
     if constexpr (QDQ) {
       const float scale = int_scale(amax, q.hi);
       const SharedDiv sd = make_shared_div(scale);
+      if (qdq_fast_ok(m, scale, sd)) {  // all but NaN / inf / tiny-amax groups: 5 VALU ops per element less
 #pragma unroll
-      for (int i = 0; i < V; ++i) f[i] = qdq_int_shared(f[i], scale, sd, q);
+        for (int i = 0; i < V; ++i) f[i] = qdq_int_fast(f[i], scale, sd, q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) f[i] = qdq_int_shared(f[i], scale, sd, q);
+      }
       st_packet<DT, true>(y, e, 0, pack<DT>(f));
     }
   }
