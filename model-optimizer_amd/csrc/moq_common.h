@@ -67,19 +67,21 @@ __device__ __forceinline__ Pack16 load16(const void* p) {
 __device__ __forceinline__ void store16(void* p, const Pack16& v) {
   *reinterpret_cast<Pack16*>(p) = v;
 }
-// streaming (read-once / write-once) variants: non-temporal hint keeps L2/MALL for data that is reused
+// streaming (read-once / write-once) variants: non-temporal hint keeps L2/MALL for data that is reused.  The pointer
+// is cast to the global address space: tensors always live in HBM, and pointers that reach a kernel through a
+// segment table (multi-tensor launches) would otherwise compile to FLAT instructions (aperture check, both counters).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const u32x4_t* gptr_c16;
+typedef __attribute__((address_space(1))) u32x4_t* gptr_16;
 __device__ __forceinline__ Pack16 load16_nt(const void* p) {
   Pack16 r;
-  const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
+  const u32x4_t v = __builtin_nontemporal_load((gptr_c16)(uintptr_t)p);
   r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
   return r;
 }
 __device__ __forceinline__ void store16_nt(void* p, const Pack16& r) {
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 v = {r.w[0], r.w[1], r.w[2], r.w[3]};
-  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  u32x4_t v = {r.w[0], r.w[1], r.w[2], r.w[3]};
+  __builtin_nontemporal_store(v, (gptr_16)(uintptr_t)p);
 }
 
 // unpack a 16-byte packet into kVec floats
