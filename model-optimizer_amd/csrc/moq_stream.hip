@@ -456,6 +456,46 @@ __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restri
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(cur.sg.amax), acc);
 }
 
+// Two-stage form of the per-tensor abs-max: stage 1 sweeps memory as one dense window (chunk = blockIdx + k * gridDim,
+// large grid -- the order in which a read-only stream reaches 7.0-7.2 TB/s instead of 6.3, tools/exp/stream_probe.hip)
+// and stores ONE value per chunk with a plain store; stage 2 folds the per-chunk values of every tensor (one workgroup
+// per tensor, 3.4 MB in total for Llama-3-8B).  No same-address atomics at all.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mt_amax_chunks_kernel(const moq_seg* __restrict__ segs,
+                                                                const int64_t* __restrict__ blk_start,
+                                                                int n_seg, int64_t n_chunks,
+                                                                uint32_t* __restrict__ chunk_max) {
+  __shared__ uint32_t smem[kBlock / 64];
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    cur.seek(c);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    uint32_t acc;
+    if (cur.aligned && e0 + MOQ_MT_CHUNK <= cur.sg.n)
+      acc = chunk_absmax<DT, true, true>(cur.sg.x, e0, cur.sg.n, 0u);
+    else
+      acc = chunk_absmax<DT, false>(cur.sg.x, e0, cur.sg.n, 0u);
+    acc = block_max_u32(acc, smem);
+    if (threadIdx.x == 0) chunk_max[c] = acc;
+    __syncthreads();  // smem is reused by the next chunk
+  }
+}
+__global__ __launch_bounds__(kBlock) void mt_amax_fold_kernel(const moq_seg* __restrict__ segs,
+                                                              const int64_t* __restrict__ blk_start,
+                                                              const uint32_t* __restrict__ chunk_max) {
+  __shared__ uint32_t smem[kBlock / 64];
+  const int s = blockIdx.x;
+  uint32_t acc = 0;
+  for (int64_t c = blk_start[s] + threadIdx.x; c < blk_start[s + 1]; c += kBlock) {
+    const uint32_t v = chunk_max[c];
+    acc = v > acc ? v : acc;
+  }
+  acc = block_max_u32(acc, smem);
+  if (threadIdx.x == 0) segs[s].amax[0] = __uint_as_float(acc);
+}
+
 __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_seg) segs[i].amax[0] = 0.0f;
@@ -723,6 +763,24 @@ extern "C" int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_
     }
   }
   return check_launch("moq_mt_amax");
+}
+
+extern "C" int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                             float* chunk_scratch, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_amax_ws");
+  if (rc != MOQ_OK || n_seg == 0) return rc;
+  if (chunk_scratch == nullptr) {
+    set_error("moq_mt_amax_ws: chunk_scratch (n_chunks floats) must not be NULL");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_chunks > 0) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_chunks_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), 0,
+                                              S(stream), segs, blk_start, n_seg, n_chunks,
+                                              reinterpret_cast<uint32_t*>(chunk_scratch)));
+  }
+  hipLaunchKernelGGL(mt_amax_fold_kernel, dim3((unsigned)n_seg), dim3(kBlock), 0, S(stream), segs, blk_start,
+                     reinterpret_cast<const uint32_t*>(chunk_scratch));
+  return check_launch("moq_mt_amax_ws");
 }
 
 extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_start, int n_seg,

@@ -73,10 +73,20 @@ class SegmentTable:
         self.bytes_in = sum(s * inputs[0].element_size() for s in sizes)
 
     # -- a1 over the table
-    def calibrate_amax(self):
+    def calibrate_amax(self, atomic: bool = False):
+        """Per-tensor abs-max of every tensor of the table.  Default: two-stage (per-chunk values in a scratch buffer,
+        then one fold per tensor; the faster sweep order); atomic=True: the single-launch atomicMax form."""
+        if self.group_size is not None:
+            raise MoquantError("calibrate_amax is the per-tensor pass (table built with group_size)")
         with _on(self._segs) as stream:
-            check(_lib.lib().moq_mt_amax(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
-                                         self.dtype_code, stream))
+            if atomic:
+                check(_lib.lib().moq_mt_amax(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                             self.dtype_code, stream))
+            else:
+                if getattr(self, "_scratch", None) is None:
+                    self._scratch = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=self.device)
+                check(_lib.lib().moq_mt_amax_ws(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                                self.dtype_code, _p(self._scratch), stream))
         return self.amax_flat
 
     # -- a7 over the table (uses the per-tensor amax slots)

@@ -409,6 +409,13 @@ def test_multi_tensor_matches_single(dtype):
     am = tab.calibrate_amax().cpu()
     for i, w in enumerate(ws):
         assert_bits_equal(am[i].reshape(()), oracle.reduce_amax(w.cpu()).reshape(()), f"mt amax {i}")
+    tab.amax_flat.fill_(7.0)  # the atomic single-launch form gives the same answer (and resets the table itself)
+    assert_bits_equal(tab.calibrate_amax(atomic=True).cpu(), am, "mt amax atomic form")
+    ws[2].view(-1)[5] = float("nan")  # NaN poisons that tensor's amax in both forms (torch.max semantics)
+    a_ws, a_at = tab.calibrate_amax().cpu().clone(), tab.calibrate_amax(atomic=True).cpu().clone()
+    assert torch.isnan(a_ws[2]) and torch.isnan(a_at[2]) and not torch.isnan(a_ws[[0, 1, 3, 4, 5]]).any()
+    ws[2].view(-1)[5] = 0.0
+    am = tab.calibrate_amax().cpu()
     outs = tab.fake_quant_e4m3()
     for i, w in enumerate(ws):
         assert_bits_equal(outs[i], oracle.fake_quant_e4m3(w.cpu(), am[i:i + 1]), f"mt fp8 {i}")
