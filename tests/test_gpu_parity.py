@@ -462,6 +462,56 @@ def test_full_size_properties_llama70b_tensor():
     assert torch.equal(kept, wa.topk(2, dim=1).values.sum(1))
 
 
+def test_tensor_beyond_int32_elements():
+    """A single tensor of 2^31 + 2^19 elements (4.3 GB bf16): every index the kernels form must be 64-bit.  Slices at
+    the start, around element 2^31 and at the very end are compared bit-exactly with the oracle."""
+    rows, cols = 32768 + 8, 65536
+    assert rows * cols > 2 ** 31
+    torch.manual_seed(77)
+    w = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    for r0 in range(0, rows, 4096):  # generate in slabs: randn of 2^31 elements at once needs 8.6 GB of fp32
+        r1 = min(rows, r0 + 4096)
+        w[r0:r1] = (torch.randn(r1 - r0, cols, device=DEV) * 0.02).to(torch.bfloat16)
+    w[rows - 1, cols - 3] = 3.0  # the per-tensor abs-max sits in the last packet of the tensor
+    w[5, 7] = -2.5
+    probes = [(0, 2), (32766, 32770), (rows - 2, rows)]  # row 32768 starts at element 2^31
+
+    a = ops.reduce_amax(w)
+    assert a.float().item() == 3.0
+    am_rows = ops.reduce_amax(w, axis=[1])  # per-channel (axis=0 kept)
+    assert am_rows.shape == (rows, 1) and am_rows[rows - 1].float().item() == 3.0 and am_rows[5].float().item() == 2.5
+
+    y = ops.scaled_e4m3(w, a.float())
+    yi = ops.fake_tensor_quant(w, a.float(), 8, False, True)
+    yg, amg = ops.amax_qdq_int_group(w, 128, num_bits=4, narrow_range=False)
+    yc = ops.fake_tensor_quant_with_axis(w, am_rows.reshape(-1).float(), 0, 8, False, True)
+    ymx = ops.fused_amax_convert(w, 32, "E2M1")
+    m = ops.mask_2to4(w)
+    assert amg.numel() == rows * cols // 128
+    for r0, r1 in probes:
+        sl = w[r0:r1].cpu()
+        assert_bits_equal(y[r0:r1], oracle.fake_quant_e4m3(sl, a.float().cpu().reshape(1)), f"fp8 rows {r0}")
+        assert_bits_equal(yi[r0:r1], oracle.fake_quant_int(sl, a.float().cpu().reshape(1), 8, False, True), f"int8 rows {r0}")
+        gy, gam = oracle.amax_qdq_int_group(sl, 128, num_bits=4, narrow_range=False)
+        assert_bits_equal(yg[r0:r1], gy, f"int4 g128 rows {r0}")
+        assert_bits_equal(amg.view(rows, -1)[r0:r1].reshape(-1).cpu(), gam.reshape(-1), f"group amax rows {r0}")
+        cy = oracle.fake_quant_int(sl, am_rows[r0:r1].reshape(-1).float().cpu(), 8, False, True, axis_size=r1 - r0,
+                                   inner=cols, per_axis=True)
+        assert_bits_equal(yc[r0:r1], cy, f"per-channel rows {r0}")
+        assert_bits_equal(ymx[r0:r1], oracle.mx_fused_amax_convert(sl, 32, "E2M1"), f"mxfp4 rows {r0}")
+        assert torch.equal(m[r0:r1].cpu().bool(), oracle.mask_2to4(sl).bool()), f"mask rows {r0}"
+    del y, yi, yg, yc, ymx, m
+    # multi-tensor table holding the big tensor behind a small one: chunk prefix sums past 2^31 elements
+    small = (torch.randn(3, 1000, device=DEV) * 0.02).to(torch.bfloat16)
+    tab = moa.multi_tensor.SegmentTable([small, w])
+    am = tab.calibrate_amax().cpu()
+    assert am[1].item() == 3.0 and am[0].item() == small.abs().max().float().item()
+    assert torch.equal(tab.calibrate_amax(atomic=True).cpu(), am)
+    outs = tab.fake_quant_e4m3()
+    for r0, r1 in probes:
+        assert_bits_equal(outs[1][r0:r1], oracle.fake_quant_e4m3(w[r0:r1].cpu(), am[1:2]), f"mt fp8 rows {r0}")
+
+
 @pytest.mark.parametrize("dn", ["bf16", "f16", "f32"])
 def test_multi_tensor_mx_equals_per_tensor(dn):
     """moq_mt_mx_fused_amax_convert over a segment table == moq_mx_fused_amax_convert tensor by tensor == oracle."""
