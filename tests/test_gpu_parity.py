@@ -512,6 +512,60 @@ def test_tensor_beyond_int32_elements():
         assert_bits_equal(outs[1][r0:r1], oracle.fake_quant_e4m3(w[r0:r1].cpu(), am[1:2]), f"mt fp8 rows {r0}")
 
 
+def test_packers_beyond_int32_elements():
+    """The real-quant / export / statistics entries on the same 2^31 + 2^19 element tensor."""
+    rows, cols, g = 32768 + 8, 65536, 128
+    torch.manual_seed(78)
+    w = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    for r0 in range(0, rows, 4096):
+        r1 = min(rows, r0 + 4096)
+        w[r0:r1] = (torch.randn(r1 - r0, cols, device=DEV) * 0.02).to(torch.bfloat16)
+    w[rows - 1, cols - 3] = 1.5
+    probes = [(0, 2), (32766, 32770), (rows - 2, rows)]
+    am = ops.reduce_amax(w.view(-1, g), axis=[1]).float()          # [n/g, 1] block amax
+    scales = (am / 7.0).to(torch.bfloat16)                          # INT4QTensor: scales = amax / 7
+    q4 = ops.int4_quantize(w.view(-1), scales, g)
+    d4 = ops.int4_dequantize(q4, scales, g)
+    wsf = (am / 7.0).view(rows, cols // g)
+    qe = ops.pack_int4_in_uint8(w, wsf)
+    a_t = ops.reduce_amax(w).float()
+    q8 = ops.fp8_quantize(w, (a_t / 448.0).reshape(1))
+    d8 = ops.fp8_dequantize(q8, (a_t / 448.0).reshape(1), torch.bfloat16)
+    qm, em = ops.mxfp4_quantize(w, 32)
+    dm = ops.mxfp4_dequantize(qm, em, torch.bfloat16, 32)
+    s_col = torch.exp(torch.randn(cols, device=DEV) * 0.3)
+    ws = ops.scale_cols(w, s_col)
+    for r0, r1 in probes:
+        sl, n_sl = w[r0:r1].cpu(), (r1 - r0) * cols
+        e0 = r0 * cols
+        sc = scales.view(-1)[e0 // g:(e0 + n_sl) // g].cpu()
+        assert torch.equal(q4[e0 // 2:(e0 + n_sl) // 2].cpu(), oracle.int4_pack(sl.reshape(-1), sc, g)), f"int4 pack {r0}"
+        assert_bits_equal(d4[e0:e0 + n_sl], oracle.int4_unpack(q4[e0 // 2:(e0 + n_sl) // 2].cpu(), sc, g), f"int4 unpack {r0}")
+        if r0 % 2 == 0:  # export packer pairs rows (2i, 2i + 1)
+            assert torch.equal(qe[r0 // 2:r1 // 2].cpu(), oracle.int4_pack_export(sl, wsf[r0:r1].cpu())), f"export {r0}"
+        s8 = (a_t / 448.0).reshape(1).cpu()
+        assert torch.equal(q8[r0:r1].cpu().view(torch.uint8), oracle.fp8_pack(sl, s8)), f"fp8 pack {r0}"
+        assert_bits_equal(d8[r0:r1], oracle.fp8_unpack(q8[r0:r1].cpu(), s8, torch.bfloat16), f"fp8 unpack {r0}")
+        op, oe = oracle.mxfp4_pack(sl, 32)
+        assert torch.equal(qm[r0:r1].cpu(), op) and torch.equal(em.view(rows, -1)[r0:r1].reshape(-1, 1).cpu(), oe), f"mxfp4 {r0}"
+        assert_bits_equal(dm[r0:r1], oracle.mxfp4_unpack(op, oe, torch.bfloat16, 32), f"mxfp4 unpack {r0}")
+        assert_bits_equal(ws[r0:r1], oracle.scale_cols(sl, s_col.cpu()), f"scale_cols {r0}")
+    del q4, d4, qe, q8, d8, qm, em, dm, ws
+    # histogram and column statistics: additive over a split at a row boundary (each half < 2^31 elements)
+    half = 20000
+    mx = float(ops.reduce_amax(w).float())
+    h_all = ops.hist_abs(w, 2048, mx)
+    h_sum = ops.hist_abs(w[:half], 2048, mx)
+    ops.hist_abs(w[half:], 2048, mx, counts=h_sum)
+    assert int(h_all.sum()) == rows * cols and torch.equal(h_all, h_sum)
+    csum, camax = ops.col_abs_stats(w)
+    c2, a2 = ops.col_abs_stats(w[:half])
+    ops.col_abs_stats(w[half:], sum_out=c2, amax_out=a2, accumulate=True)
+    assert torch.equal(camax, a2) and torch.equal(camax, w.abs().amax(0).float())
+    assert ((csum - c2).abs() / c2.clamp_min(1e-30)).max().item() < 1e-5
+    assert torch.equal(ops.mask_2to4(w[rows - 4:]).cpu(), oracle.mask_2to4(w[rows - 4:].cpu()))
+
+
 @pytest.mark.parametrize("dn", ["bf16", "f16", "f32"])
 def test_multi_tensor_mx_equals_per_tensor(dn):
     """moq_mt_mx_fused_amax_convert over a segment table == moq_mx_fused_amax_convert tensor by tensor == oracle."""
