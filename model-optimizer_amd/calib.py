@@ -12,7 +12,6 @@ Differences from the reference that do not change results:
 from __future__ import annotations
 
 import math
-from collections import Counter
 
 import numpy as np
 import torch
@@ -175,38 +174,59 @@ def _compute_amax_percentile(calib_hist, calib_bin_edges, percentile):
     return torch.tensor(calib_bin_edges[idx].item())
 
 
-def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, stride=1, start_bin=128):
-    """KL-divergence threshold search -- calib/histogram.py:210-283 (host numpy, O(bins^2 / stride))."""
-    from scipy.stats import entropy
+def _kl_divergence(pk, qk):
+    """scipy.stats.entropy(pk, qk) without its argument-policy wrapper (0.3 ms per call, most of the search): the
+    same three statements on the same arrays -- normalise both, special.rel_entr, sum."""
+    from scipy.special import rel_entr
+    with np.errstate(invalid="ignore"):
+        pk = 1.0 * pk / np.sum(pk, axis=0, keepdims=True)
+    qk = 1.0 * qk / np.sum(qk, axis=0, keepdims=True)
+    return np.sum(rel_entr(pk, qk), axis=0)
 
+
+def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, stride=1, start_bin=128,
+                          divergences_out=None):
+    """KL-divergence threshold search -- calib/histogram.py:210-283.
+
+    Same arithmetic as the reference's loop, candidate by candidate, with its slow steps replaced by exact
+    equivalents (about 4x faster on the host, identical divergences bit for bit -- tests/test_host_cpu.py):
+      * `np.digitize(range(i), np.linspace(0, i, nbins + 1)) - 1`: nbins is a power of two, so every edge k*i/nbins
+        is exact in fp64 and the bucket of source bin j is floor(j * nbins / i);
+      * `np.add.at` of the counts: integer-valued fp64 sums below 2^53 are exact in any order (np.bincount);
+      * `Counter(digitized.tolist())`: the number of non-empty source bins per bucket (np.bincount).
+    The floating-point part (division, the two totals, the entropy formula) is the reference's, on identical arrays."""
     bins = calib_hist.astype(np.int64).copy()
     bins[0] = bins[1]
     total_data = np.sum(bins)
     nbins = 1 << (num_bits - 1 + int(unsigned))
+    nonzero = bins != 0
+    bins_f = bins.astype(np.float64)
+    tail = np.concatenate([np.cumsum(bins[::-1])[::-1], [0]])  # tail[i] = sum(bins[i:]), exact
+    j_scaled = np.arange(len(bins), dtype=np.int64) * nbins
     divergences = []
     for i in range(start_bin, len(bins) + 1, stride):
-        space = np.linspace(0, i, num=nbins + 1)
-        digitized_space = np.digitize(range(i), space) - 1
-        digitized_space[bins[:i] == 0] = -1
-        valid = digitized_space != -1
+        valid = nonzero[:i]
+        bucket = (j_scaled[:i] // i)[valid]
+        sums = np.bincount(bucket, weights=bins_f[:i][valid], minlength=nbins)
+        members = np.bincount(bucket, minlength=nbins)
         new_density_counts = np.zeros(nbins, dtype=np.float64)
-        np.add.at(new_density_counts, digitized_space[valid], bins[:i][valid])
-        for key, val in Counter(digitized_space.tolist()).items():
-            if key != -1:
-                new_density_counts[key] = new_density_counts[key] / val
+        hit = members > 0
+        new_density_counts[hit] = sums[hit] / members[hit]
         new_density = np.zeros(i, dtype=np.float64)
-        new_density[valid] = new_density_counts[digitized_space[valid]]
-        total_counts_new = np.sum(new_density) + np.sum(bins[i:])
-        reference_density = np.array(bins[:i], dtype=np.float64)
-        reference_density[-1] += np.sum(bins[i:])
+        new_density[valid] = new_density_counts[bucket]
+        total_counts_new = np.sum(new_density) + tail[i]
+        reference_density = bins_f[:i].copy()
+        reference_density[-1] += tail[i]
         total_counts_old = np.sum(reference_density)
         if round(total_counts_new) != total_data or round(total_counts_old) != total_data:
             raise RuntimeError(f"Count mismatch! total_counts_new={total_counts_new}, "
                                f"total_counts_old={total_counts_old}, total_data={total_data}")
         # NB: the reference's _normalize_distr rebinds a local and normalises nothing (histogram.py:217-220);
         # scipy.stats.entropy normalises both arguments itself, so the result is the same either way.
-        divergences.append(entropy(reference_density, new_density))
+        divergences.append(_kl_divergence(reference_density, new_density))
     divergences = np.array(divergences)
+    if divergences_out is not None:
+        divergences_out.extend(divergences.tolist())
     last_argmin = len(divergences) - 1 - np.argmin(divergences[::-1])
     return torch.tensor(calib_bin_edges[last_argmin * stride + start_bin].item())
 

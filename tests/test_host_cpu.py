@@ -30,6 +30,52 @@ def test_histogram_threshold_searches_match_reference(golden):
         calib._compute_amax_percentile(hist, edges, 101)
 
 
+def _entropy_divergences_textbook(hist, num_bits, unsigned, stride, start_bin):
+    """The reference's loop as written (digitize / add.at / Counter), returning every divergence."""
+    from collections import Counter
+
+    from scipy.stats import entropy
+    bins = hist.astype(np.int64).copy()
+    bins[0] = bins[1]
+    nbins = 1 << (num_bits - 1 + int(unsigned))
+    out = []
+    for i in range(start_bin, len(bins) + 1, stride):
+        space = np.linspace(0, i, num=nbins + 1)
+        dig = np.digitize(range(i), space) - 1
+        dig[bins[:i] == 0] = -1
+        valid = dig != -1
+        ndc = np.zeros(nbins, dtype=np.float64)
+        np.add.at(ndc, dig[valid], bins[:i][valid])
+        for key, val in Counter(dig.tolist()).items():
+            if key != -1:
+                ndc[key] = ndc[key] / val
+        new_density = np.zeros(i, dtype=np.float64)
+        new_density[valid] = ndc[dig[valid]]
+        ref = np.array(bins[:i], dtype=np.float64)
+        ref[-1] += np.sum(bins[i:])
+        out.append(entropy(ref, new_density))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("num_bits,unsigned,nb,stride,start", [(8, False, 2048, 1, 128), (8, True, 2048, 3, 128),
+                                                                 (4, False, 777, 1, 16), (6, False, 1500, 7, 100)])
+def test_entropy_search_is_the_reference_loop_bit_for_bit(num_bits, unsigned, nb, stride, start):
+    """calib._compute_amax_entropy replaces digitize / add.at / Counter by exact integer equivalents: every
+    divergence must equal the textbook loop's bit for bit (zeros, gaps and a heavy tail included)."""
+    rng = np.random.default_rng(nb + num_bits)
+    hist = (rng.exponential(1.0, nb) * 1e6 * np.exp(-np.arange(nb) / (nb / 6))).astype(np.int64)
+    hist[rng.integers(0, nb, nb // 10)] = 0          # empty bins
+    hist[nb // 2: nb // 2 + 40] = 0                   # a gap wider than a bucket
+    hist[-1] = 12345
+    got = []
+    edges = np.linspace(0, 1.0, nb + 1, dtype=np.float32)
+    amax = calib._compute_amax_entropy(hist, edges, num_bits, unsigned, stride, start, divergences_out=got)
+    want = _entropy_divergences_textbook(hist, num_bits, unsigned, stride, start)
+    assert np.array_equal(np.array(got).view(np.uint64), want.view(np.uint64))
+    last_argmin = len(want) - 1 - np.argmin(want[::-1])
+    assert amax.item() == edges[last_argmin * stride + start].item()
+
+
 def test_oracle_awq_weight_scale_matches_reference(golden):
     g = golden("awq")
     for k, c in g.cases.items():
