@@ -252,12 +252,54 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
             if m.bias is not None:
                 state[prefix + "bias"] = m.bias.detach()
             handled.add(name)
+    kv_format = get_kv_cache_format(model)
     for k, v in model.state_dict().items():
         owner = k.rsplit(".", 1)[0] if "." in k else ""
         if any(owner == h or owner.startswith(h + ".") for h in handled):
             continue  # quantizer buffers (_amax, _pre_quant_scale) and raw weights of exported linears
-        state[k] = v.detach()
+        new_key, value = _postprocess_kv_key(k, v, kv_format)
+        if new_key is not None:
+            state[new_key] = value
     return state
+
+
+KV_CACHE_FP8 = "FP8"
+# export/quant_utils.py:964-970: where the KV-cache quantizer buffers land in the checkpoint
+_KV_CACHE_REPLACEMENTS = {"k_bmm_quantizer._amax": "k_proj.k_scale", "v_bmm_quantizer._amax": "v_proj.v_scale",
+                          "k_bmm_quantizer._bias_value": "k_proj.k_bias", "v_bmm_quantizer._bias_value": "v_proj.v_bias"}
+
+
+def get_kv_cache_format(model) -> str | None:
+    """export/quant_utils.py:408-470 for this path: "FP8" when the enabled k / v bmm quantizers are E4M3, None when
+    there are none; every attention must agree (unified_export_hf.py:1679-1690)."""
+    fmt = None
+    for m in model.modules():
+        kq, vq = getattr(m, "k_bmm_quantizer", None), getattr(m, "v_bmm_quantizer", None)
+        if kq is None or vq is None or not (kq.is_enabled or vq.is_enabled):
+            continue
+        bits = {tuple(q._num_bits) if isinstance(q._num_bits, (tuple, list)) else q._num_bits
+                for q in (kq, vq) if q.is_enabled}
+        if bits != {(4, 3)}:
+            raise NotImplementedError(f"KV-cache format num_bits={bits} is outside this path (FP8 E4M3 only)")
+        this = KV_CACHE_FP8
+        assert fmt in (None, this), "Do not support mixed precision kv cache quantization"
+        fmt = this
+    return fmt
+
+
+def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
+    """The KV-cache part of postprocess_state_dict (export/quant_utils.py:1000-1060): `<attn>.k_bmm_quantizer._amax`
+    becomes `<attn>.k_proj.k_scale = amax.float() / maxbound`; every other quantizer buffer is dropped; the rest is
+    copied through."""
+    if not any(s in key for s in ("_bmm_quantizer", "output_quantizer", "_amax", "_bias_value")):
+        return key, value.detach()
+    for old, new in _KV_CACHE_REPLACEMENTS.items():
+        if key.endswith(old):
+            if "_amax" in key:
+                assert kv_format == KV_CACHE_FP8, "Invalid KV cache quantization format."
+                value = (value.detach().float().cpu() / 448.0).to(value.device)  # IEEE division (see get_scaling_factor)
+            return key[: -len(old)] + new, value
+    return None, None
 
 
 def hf_quant_config(model, group_size: int | None = None) -> dict:
@@ -266,7 +308,7 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
             QUANTIZATION_INT8_WO: "W8A16"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
-    q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": None}
+    q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}
     if fmt == QUANTIZATION_INT4_AWQ:
         q.update(group_size=group_size or 128, has_zero_point=False, pre_quant_scale=True)
     return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}

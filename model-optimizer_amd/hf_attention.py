@@ -1,0 +1,129 @@
+"""KV-cache quantizers on Hugging Face attention modules -- the mirror of `_QuantAttention` and
+`register_hf_attentions_on_the_fly` (quantization/plugins/huggingface.py:78-360, :416-470) for this path.
+
+An attention module that goes through transformers' attention interface (`ALL_ATTENTION_FUNCTIONS` /
+`eager_attention_forward`, transformers >= 4.48) gets `q_bmm_quantizer`, `k_bmm_quantizer`, `v_bmm_quantizer`
+(`TensorQuantizer`s, disabled until a config entry such as `*[kv]_bmm_quantizer` enables them).  During the module's
+forward the interface function is replaced by one that passes the query / key / value states through those quantizers
+first, and restored afterwards -- also when the forward raises.  The statistics and the QDQ are the same kernels as
+for every other activation (per-tensor abs-max `moq_amax`, FP8 QDQ `moq_fake_quant_e4m3`); key / value states are
+permuted dense views (`[B, heads, S, D]` of a `[B, S, heads, D]` buffer), which the per-tensor entries walk in place
+(ops._flat_alias) instead of copying.
+
+Not mirrored: the softmax (`p_bmm_quantizer`) path, which the reference runs on its own Triton / "kitchen" flash
+attention kernels (huggingface.py:92-197) -- enabling it raises; T5's matmul patching (:315-352).
+"""
+
+from __future__ import annotations
+
+import inspect
+from functools import partial
+
+from torch import nn
+
+from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer
+
+_BMM_QUANTIZERS = ("q_bmm_quantizer", "k_bmm_quantizer", "v_bmm_quantizer", "p_bmm_quantizer")
+_quant_classes: dict[type, type] = {}
+
+
+def _attention_module_of(cls: type):
+    return inspect.getmodule(cls)
+
+
+class _QuantAttentionMixin:
+    """forward = original forward with the attention interface wrapped by `_quantized_attention`."""
+
+    def _setup_bmm_quantizers(self):
+        for name in _BMM_QUANTIZERS:
+            if not hasattr(self, name):
+                setattr(self, name, TensorQuantizer(QuantizerAttributeConfig(enable=False)))
+
+    @staticmethod
+    def _quantized_attention(original_attention_interface, self, query_states, key_states, value_states, *args,
+                             **kwargs):
+        # huggingface.py:222-236
+        query_states = self.q_bmm_quantizer(query_states)
+        key_states = self.k_bmm_quantizer(key_states)
+        value_states = self.v_bmm_quantizer(value_states)
+        if self.p_bmm_quantizer.is_enabled:
+            raise NotImplementedError("p_bmm_quantizer (softmax QDQ inside flash attention) is outside this path")
+        return original_attention_interface(self, query_states, key_states, value_states, *args, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        # huggingface.py:283-334: pick the function this forward is going to call, patch, run, restore
+        config = getattr(self, "config", None)
+        if config is None:
+            config = next((getattr(m, "config", None) for m in self.children() if hasattr(m, "config")), None)
+        impl = getattr(config, "_attn_implementation", None) if config is not None else None
+        eager = impl is None or impl == "eager" or (impl == "sdpa" and kwargs.get("output_attentions", False))
+        module = _attention_module_of(self._moq_original_cls)
+        if eager:
+            if not hasattr(module, "eager_attention_forward"):
+                raise AssertionError(f"Module {module} does not have `eager_attention_forward` to enable KV Cache "
+                                     "quantization. Please use a different attention implementation such as `sdpa`.")
+            original = module.eager_attention_forward
+            module.eager_attention_forward = partial(self._quantized_attention, original)
+        else:
+            original = module.ALL_ATTENTION_FUNCTIONS[impl]
+            module.ALL_ATTENTION_FUNCTIONS[impl] = partial(self._quantized_attention, original)
+        try:
+            return super().forward(*args, **kwargs)
+        finally:
+            if eager:
+                module.eager_attention_forward = original
+            else:
+                module.ALL_ATTENTION_FUNCTIONS[impl] = original
+
+
+def is_compatible_attention(cls: type) -> bool:
+    """huggingface.py:336-343: the class's module uses the attention interface."""
+    return getattr(_attention_module_of(cls), "ALL_ATTENTION_FUNCTIONS", None) is not None
+
+
+def _wraps_nested_attention(module: nn.Module) -> bool:
+    """huggingface.py:355-368: a wrapper (e.g. ViTAttention around ViTSelfAttention) is not patched itself."""
+    return any(child is not module and type(child).__name__.endswith("Attention") for _, child in module.named_modules())
+
+
+def is_quantized_attention(m) -> bool:
+    return isinstance(m, _QuantAttentionMixin)
+
+
+def convert_attention(module: nn.Module) -> nn.Module:
+    """In-place class swap to a `Quant<cls>` subclass (one per attention class) + the bmm quantizers."""
+    cls = type(module)
+    if issubclass(cls, _QuantAttentionMixin):
+        return module
+    qcls = _quant_classes.get(cls)
+    if qcls is None:
+        qcls = type(f"Quant{cls.__name__}", (_QuantAttentionMixin, cls), {"_moq_original_cls": cls})
+        _quant_classes[cls] = qcls
+    module.__class__ = qcls
+    module._setup_bmm_quantizers()
+    return module
+
+
+def _is_supported_hf_model(model) -> bool:
+    try:
+        import transformers
+    except ImportError:
+        return False
+    return isinstance(model, transformers.PreTrainedModel)
+
+
+def register_hf_attentions_on_the_fly(model: nn.Module) -> int:
+    """Convert every `*Attention` module of a Hugging Face model that calls the attention interface
+    (huggingface.py:371-415).  Returns how many modules were converted."""
+    if not _is_supported_hf_model(model):
+        return 0
+    n = 0
+    for _, m in list(model.named_modules()):
+        cls = type(m)
+        if is_quantized_attention(m) or not cls.__name__.endswith("Attention"):
+            continue
+        if _wraps_nested_attention(m) or not is_compatible_attention(cls):
+            continue
+        convert_attention(m)
+        n += 1
+    return n

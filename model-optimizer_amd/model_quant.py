@@ -45,6 +45,23 @@ INT8_SMOOTHQUANT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis
                         "algorithm": {"method": "smoothquant", "alpha": 1.0}}
 
 
+# presets/kv/fp8.yaml (units/kv_fp8.yaml): FP8 E4M3 per-tensor key / value quantizers, merged into a model preset
+FP8_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "axis": None, "enable": True}},
+              "algorithm": "max"}
+
+
+def update_quant_cfg_with_kv_cache_quant(quant_cfg: dict, kv_cache_quant_cfg: dict) -> dict:
+    """utils/core_utils.py:1049-1075: a copy of `quant_cfg` with the KV-cache entries appended (later entries win);
+    a config without an algorithm gets "max" so that the KV quantizers are calibrated."""
+    import copy
+
+    out = copy.deepcopy(quant_cfg)
+    out["quant_cfg"] = {**out.get("quant_cfg", {}), **copy.deepcopy(kv_cache_quant_cfg)}
+    if out.get("algorithm") is None:
+        out["algorithm"] = "max"
+    return out
+
+
 def _apply_attrs(mod: TensorQuantizer, attrs: dict):
     attrs = dict(attrs)
     enable = attrs.pop("enable", True)

@@ -38,7 +38,12 @@ def is_quantized_linear(m) -> bool:
 
 
 def replace_quant_module(model: nn.Module) -> nn.Module:
-    """nn.Linear -> QuantLinear everywhere (conversion.py:214 replace_quant_module for the Linear entry)."""
+    """nn.Linear -> QuantLinear everywhere (conversion.py:214 replace_quant_module for the Linear entry); attention
+    modules of a Hugging Face model get their KV-cache quantizers (plugins/huggingface.py:371-415, run by the
+    reference from the same place through its on-the-fly plugin registry)."""
+    from .hf_attention import register_hf_attentions_on_the_fly
+
+    register_hf_attentions_on_the_fly(model)
     for mod in list(model.modules()):
         if type(mod) is nn.Linear:
             QuantLinear.convert(mod)

@@ -49,6 +49,25 @@ def _f32(t: torch.Tensor, device) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------------- amax
+def _is_dense(x: torch.Tensor) -> bool:
+    """Non-overlapping and dense: some permutation of the dims is contiguous (transposed views of a contiguous
+    buffer -- HF key / value states [B, heads, S, D] are `.view(B, S, heads, D).transpose(1, 2)`)."""
+    if x.is_contiguous():
+        return True
+    expect = 1
+    for st, sz in sorted((st, sz) for sz, st in zip(x.shape, x.stride()) if sz != 1):
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+def _flat_alias(x: torch.Tensor) -> torch.Tensor:
+    """The memory of a dense tensor as one 1-D run (what a per-tensor statistic or an elementwise per-tensor QDQ may
+    walk in any order): no `.contiguous()` copy -- one of the extra passes listed for TensorQuantizer.forward."""
+    return x if x.is_contiguous() else x.as_strided((x.numel(),), (1,))
+
+
 def _reduce_layout(shape, reduce_axes):
     """Factor `shape` as [outer, kept, inner] when exactly one block of adjacent dims is kept."""
     nd = len(shape)
@@ -82,11 +101,11 @@ def reduce_amax(input: torch.Tensor, axis=None, keepdims=True, squeeze_scalar=Tr
     x = input.detach()
     if x.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
         x = x.to(torch.get_default_dtype())  # core_utils.py:169-170
-    x = x.contiguous()
     nd = x.dim()
     if isinstance(axis, int):
         axis = (axis,)
     per_tensor = axis is None or len({a % nd for a in axis}) == nd or nd == 0
+    x = _flat_alias(x) if per_tensor and _is_dense(x) else x.contiguous()
     with _on(x) as stream:
         if per_tensor:
             buf = out if out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
@@ -157,10 +176,18 @@ def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 
                       check_inputs: bool = False) -> torch.Tensor:
     """INT-k quantize-dequantize -- tensor_quant.py:607-645 / tensor_quant_gpu.cu:43-140."""
     _require_gpu(inputs, "fake_tensor_quant")
+    am = _f32(amax, inputs.device)
+    if not inplace and am.numel() == 1 and not inputs.is_contiguous() and _is_dense(inputs) and not check_inputs:
+        # per-tensor amax on a permuted dense tensor: elementwise over its memory, output keeps the strides
+        y = torch.empty_like(inputs)
+        xa, ya = _flat_alias(inputs.detach()), _flat_alias(y)
+        with _on(xa) as stream:
+            check(_lib.lib().moq_fake_quant_int(_p(xa), _p(ya), xa.numel(), _dt(xa), _p(am), _lib.AMAX_SCALAR, 1, 1,
+                                                int(num_bits), int(unsigned), int(narrow_range), stream))
+        return y
     x = inputs if inplace else inputs.contiguous()
     if inplace and not x.is_contiguous():
         raise MoquantError("in-place fake quant needs a contiguous tensor")  # tensor_quant.cpp:41-42
-    am = _f32(amax, x.device)
     if _is_block2d_view(x, amax_shape=am.shape):
         return block2d(x, 1, amax=am, fp8=False, num_bits=num_bits, unsigned=unsigned, narrow_range=narrow_range,
                        out=x if inplace else None)
@@ -183,6 +210,14 @@ def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 
 def scaled_e4m3(inputs: torch.Tensor, amax: torch.Tensor | None) -> torch.Tensor:
     """FP8-E4M3 quantize-dequantize -- tensor_quant.py:46-92 / tensor_quant_gpu_fp8.cu:35-107."""
     _require_gpu(inputs, "scaled_e4m3")
+    if (amax is None or amax.numel() == 1) and not inputs.is_contiguous() and _is_dense(inputs):
+        y = torch.empty_like(inputs)  # keeps the (permuted) strides of a dense input
+        xa, ya = _flat_alias(inputs.detach()), _flat_alias(y)
+        am = None if amax is None else _f32(amax, inputs.device)
+        with _on(xa) as stream:
+            check(_lib.lib().moq_fake_quant_e4m3(_p(xa), _p(ya), xa.numel(), _dt(xa), _p(am), _lib.AMAX_SCALAR, 1, 1,
+                                                 stream))
+        return y
     x = inputs.contiguous()
     y = torch.empty_like(x)
     with _on(x) as stream:

@@ -348,8 +348,8 @@ class TensorQuantizer(nn.Module):
         if self._if_calib and not self._dynamic:
             self.collect(inputs)
         if self._if_quant:
-            if not inputs.is_contiguous():
-                inputs = inputs.contiguous()
+            # no `.contiguous()` here: every op takes what it needs (per-tensor formats walk a permuted dense
+            # tensor in place, the others copy)
             outputs = self._fake_quantize(inputs)
         if self.is_static_block_quant:
             outputs = self._reset_to_original_shape(outputs)

@@ -23,6 +23,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
+  export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -776,14 +777,70 @@ def gen_export_mxfp4(out):
     out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg)))
 
 
+def gen_export_fp8_kv(out):
+    """FP8 W + A with the FP8 KV-cache quantizers (FP8_DEFAULT_CFG + FP8_KV_CFG merged as hf_ptq does with
+    update_quant_cfg_with_kv_cache_quant, examples/hf_ptq/hf_ptq.py:552-556) on the tiny fp32 Llama: the k / v
+    bmm-quantizer amax of every attention after calibration, the logits of one batch with KV fake-quant active, and
+    the exported k_scale / v_scale + hf_quant_config."""
+    import copy
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    for impl in ("sdpa", "eager"):
+        cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)
+        cfg._attn_implementation = impl
+        torch.manual_seed(0)
+        model = LlamaForCausalLM(cfg).to(torch.float32)
+        batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+        if impl == "sdpa":
+            for k, v in model.state_dict().items():
+                out[f"orig/{k}"] = bits(v)
+            for i, b in enumerate(batches):
+                out[f"tokens{i}"] = b.numpy()
+        qcfg = mtq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(mtq.FP8_DEFAULT_CFG),
+                                                        copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
+        q = mtq.quantize(model, qcfg, lambda m: [m(b) for b in batches])
+        attns = []
+        for n, m in q.named_modules():
+            if hasattr(m, "k_bmm_quantizer"):
+                attns.append(n)
+                for which in "qkv":
+                    tqz = getattr(m, f"{which}_bmm_quantizer")
+                    out[f"{impl}/{n}.{which}_enabled"] = np.array(bool(tqz.is_enabled))
+                    if tqz.is_enabled:
+                        out[f"{impl}/{n}.{which}_amax"] = bits(tqz._amax.float())
+        with torch.no_grad():
+            out[f"{impl}/logits"] = bits(q(batches[0]).logits)
+        if impl == "sdpa":
+            with tempfile.TemporaryDirectory() as d:
+                export_hf_checkpoint(q, export_dir=d)
+                dtypes = {}
+                with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+                    for k in f.keys():
+                        if "k_scale" in k or "v_scale" in k or "k_bias" in k or "v_bias" in k:
+                            out[f"exp/{k}"] = bits(f.get_tensor(k))
+                            dtypes[k] = str(f.get_tensor(k).dtype)
+                    all_keys = sorted(f.keys())
+                quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=3, attentions=attns, dtypes=dtypes,
+                                             exported_keys=all_keys, hf_quant_config=quant_cfg)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

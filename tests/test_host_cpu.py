@@ -170,3 +170,53 @@ def test_modelopt_seams_install():
                                       {"pattern": "2:4 sparsity", "col_block_size": 128, "row_block_size": -1,
                                        "hessian_damp": 0.1})
     assert mask.dtype == torch.bool and (mask.view(8, -1, 4).sum(-1) <= 2).all()
+
+
+def test_hf_attention_registration_patches_and_restores_the_interface():
+    """hf_attention (plugins/huggingface.py:283-334 mirror) without any kernel: with all bmm quantizers disabled the
+    converted model computes exactly what the original did, the attention interface is restored after every forward
+    -- also when the forward raises -- and only modules that call the interface are converted."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers.models.llama import modeling_llama
+
+    from model_optimizer_amd import hf_attention, nn as mnn
+    cfgd = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=64, max_position_embeddings=32)
+    tokens = torch.randint(0, 64, (2, 16), generator=torch.Generator().manual_seed(0))
+    for impl in ("sdpa", "eager"):
+        cfg = LlamaConfig(**cfgd)
+        cfg._attn_implementation = impl
+        torch.manual_seed(0)
+        model = LlamaForCausalLM(cfg).eval()
+        with torch.no_grad():
+            want = model(tokens).logits
+        eager_fn, sdpa_fn = modeling_llama.eager_attention_forward, modeling_llama.ALL_ATTENTION_FUNCTIONS["sdpa"]
+        assert hf_attention.register_hf_attentions_on_the_fly(model) == 2
+        assert hf_attention.register_hf_attentions_on_the_fly(model) == 0  # idempotent
+        attn = model.model.layers[0].self_attn
+        assert type(attn).__name__ == "QuantLlamaAttention" and isinstance(attn, modeling_llama.LlamaAttention)
+        for name in ("q_bmm_quantizer", "k_bmm_quantizer", "v_bmm_quantizer"):
+            assert not getattr(attn, name).is_enabled
+        seen = []
+        attn.k_bmm_quantizer.register_forward_hook(lambda m, i, o: seen.append(tuple(i[0].shape)))
+        with torch.no_grad():
+            got = model(tokens).logits
+        assert torch.equal(got, want)
+        assert seen == [(2, 2, 16, 16)]  # [B, kv_heads, S, head_dim]: the key states reach the quantizer
+        assert modeling_llama.eager_attention_forward is eager_fn
+        assert modeling_llama.ALL_ATTENTION_FUNCTIONS["sdpa"] is sdpa_fn
+        with pytest.raises(Exception):
+            model(torch.full((1, 4), 10 ** 6))  # out-of-range token: the forward raises inside the model
+        assert modeling_llama.eager_attention_forward is eager_fn
+        assert modeling_llama.ALL_ATTENTION_FUNCTIONS["sdpa"] is sdpa_fn
+        # set_quantizer_by_cfg reaches the new quantizers by wildcard; the KV preset enables k and v only
+        mq = moa.model_quant
+        mnn.replace_quant_module(model)
+        cfg2 = mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"])
+        assert cfg2 is not mq.FP8_DEFAULT_CFG and "*[kv]_bmm_quantizer" not in mq.FP8_DEFAULT_CFG["quant_cfg"]
+        mq.set_quantizer_by_cfg(model, cfg2["quant_cfg"])
+        assert attn.k_bmm_quantizer.is_enabled and attn.v_bmm_quantizer.is_enabled
+        assert not attn.q_bmm_quantizer.is_enabled and not attn.p_bmm_quantizer.is_enabled
+        assert tuple(attn.k_bmm_quantizer._num_bits) == (4, 3)
+        assert moa.export.get_kv_cache_format(model) == "FP8"
+    assert hf_attention.register_hf_attentions_on_the_fly(torch.nn.Linear(2, 2)) == 0
