@@ -38,18 +38,84 @@ def all_reduce_bucket(tensors, op, group=None, average: bool = False):
             off += n
 
 
-def sync_amax_bucketed(quantizers, group=None):
+def _agree_amax_membership(quantizers, group, on_missing: str, device=None):
+    """Every rank must put the SAME tensors into the bucket.  A quantizer that saw no data on this rank (a routed
+    expert that received no tokens from this rank's calibration shard) has no `_amax` here but may have one
+    elsewhere: per-quantizer all-reduces as the reference issues them would then dead-lock (its MoE check,
+    model_calib.py:226-245, turns that into an error when expert parallelism is on).  One object all-gather of
+    (shape, dtype) per quantizer -- control plane, once per calibration -- settles membership:
+      on_missing="adopt": ranks without the amax join with zeros (abs-max identity) and end up with the group's
+                          value -- the calibration set as a whole did exercise the quantizer;
+      on_missing="raise": the reference's "MoE calibration incomplete" RuntimeError."""
+    local = [None if getattr(q, "_amax", None) is None else (tuple(q._amax.shape), str(q._amax.dtype).split(".")[-1])
+             for q in quantizers]
+    gathered = [None] * dist.get_world_size(group)
+    dist.all_gather_object(gathered, local, group=group)
+    if device is None:
+        device = next((q._amax.device for q in quantizers if getattr(q, "_amax", None) is not None), None)
+    for i, q in enumerate(quantizers):
+        present = [g[i] for g in gathered if g[i] is not None]
+        if not present or len(present) == len(gathered):
+            if present and len(set(present)) != 1:
+                raise RuntimeError(f"amax of quantizer #{i} differs in shape / dtype across ranks: {set(present)}")
+            continue
+        if on_missing == "raise":
+            raise RuntimeError("MoE calibration incomplete: some experts received no tokens during calibration. "
+                               "Increase --calib-size to ensure all experts see calibration data.")
+        if local[i] is None:
+            shape, dt = present[0]
+            dev = device
+            if dev is None and isinstance(q, torch.nn.Module):
+                dev = next((b.device for b in q.buffers()), None)
+            zeros = torch.zeros(shape, dtype=getattr(torch, dt), device=dev if dev is not None else "cpu")
+            if isinstance(q, torch.nn.Module) and isinstance(getattr(type(q), "amax", None), property):
+                q.amax = zeros
+            else:
+                q._amax = zeros
+
+
+def sync_amax_bucketed(quantizers, group=None, on_missing: str = "adopt", device=None):
     """MAX-reduce every calibrated `_amax` buffer of `quantizers` in one collective
     (semantics of sync_amax_across_distributed_group, tensor_quantizer.py:1373-1385)."""
+    if not _initialized(group):
+        return
+    quantizers = list(quantizers)
+    _agree_amax_membership(quantizers, group, on_missing, device)
     bufs = [q._amax for q in quantizers if getattr(q, "_amax", None) is not None]
     # NaN must survive the reduction like it does locally: MAX drops NaN on some backends, so carry a flag
-    if not bufs or not _initialized(group):
+    if not bufs:
         return
     nan_flags = torch.stack([torch.isnan(b).any().to(torch.float32) for b in bufs])
     f32 = [b.float() for b in bufs]
     all_reduce_bucket(f32 + [nan_flags], dist.ReduceOp.MAX, group)
     for b, r, flag in zip(bufs, f32, nan_flags.tolist()):
         b.copy_(torch.full_like(r, float("nan")) if flag else r)
+
+
+def sync_awq_act_scales(act_scales, weight_scales, widths, device, group=None):
+    """Data-parallel step of awq_lite after the cache pass (model_calib.py:1588-1619) for ALL linears in one
+    collective.  act_scales[i] is this rank's mean-|x| vector of linear i or None (no tokens here); widths[i] = Cin.
+    Returns (synced, enabled): synced[i] = average over the ranks that HAVE a scale (None when no rank has one);
+    enabled[i] = False when any rank saw NaN in its act or weight scale (the reference's any-NaN vote) or when no
+    rank has data.  The reference averages with ReduceOp.AVG assuming every rank has every linear -- the same
+    answer whenever that holds."""
+    n = len(act_scales)
+    flags = torch.zeros(2 * n, dtype=torch.float32, device=device)  # [has..., nan...]
+    vecs = []
+    for i, (a, w) in enumerate(zip(act_scales, weight_scales)):
+        if a is not None:
+            flags[i] = 1.0
+            bad = torch.isnan(a).any() | torch.isnan(w).any()
+            flags[n + i] = bad.to(torch.float32)
+            vecs.append(torch.where(torch.isnan(a), torch.zeros_like(a), a).float().clone())
+        else:
+            vecs.append(torch.zeros(widths[i], dtype=torch.float32, device=device))
+    if _initialized(group):
+        all_reduce_bucket(vecs + [flags], dist.ReduceOp.SUM, group)
+    has, nan = flags[:n].tolist(), flags[n:].tolist()
+    synced = [v / h if h > 0 else None for v, h in zip(vecs, has)]
+    enabled = [h > 0 and b == 0 for h, b in zip(has, nan)]
+    return synced, enabled
 
 
 def sync_calibrators_bucketed(calibrators, group=None):

@@ -92,7 +92,8 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
         forward_loop(model)
     finish_stats_collection(model)
     if distributed_sync and dist.is_available() and dist.is_initialized():
-        mdist.sync_amax_bucketed(_quantizers(model))
+        dev = next((p.device for p in model.parameters()), None)
+        mdist.sync_amax_bucketed(_quantizers(model), device=dev)
     promote_static_block_weight_quantizers(model)
 
 
@@ -272,6 +273,7 @@ class AWQLiteHelper:
         self.loss = {a: self.loss_buf[i:i + 1] for i, a in enumerate(self.alphas)}
         self.best_alpha = None
         self.best_scale = None
+        self.is_enabled = True  # False: NaN in a scale on some rank, or no tokens anywhere (:1605-1629)
         # search-pass caches (alpha -> tensors); scales depend on alpha only once act_scale is final
         self._inv_scale = None
         self._scale_dt = None
@@ -384,8 +386,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                     xf = x2.float()
                     h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
             return out_actual
-        if h.use_gram:
-            return out_actual  # this linear's losses came from its Gram matrix
+        if h.use_gram or not h.is_enabled:
+            return out_actual  # losses came from the Gram matrix / the linear is out of the search
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
         inv_s, w_hat = h.search_operands(self)
         if ops.mfma_gemm_supported(x2, self.weight):
@@ -409,10 +411,18 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for h in helpers.values():
             if h.num_cache_steps:
                 h.act_scale = h.act_sum / h.num_cache_steps
-        if dist.is_available() and dist.is_initialized():
-            # DP: act_scale AVG in ONE bucket (reference: one all_reduce per linear, :1588-1593)
-            mdist.all_reduce_bucket([h.act_scale for h in helpers.values() if h.act_scale is not None],
-                                    dist.ReduceOp.SUM, average=True)
+        if mods:
+            # DP: act_scale average + the any-NaN vote for ALL linears in ONE bucket (reference: one all_reduce and
+            # one object gather per linear, :1588-1619); ranks whose shard never reached a linear join with zeros
+            hs = [helpers[m] for _, m in mods]
+            synced, enabled = mdist.sync_awq_act_scales([h.act_scale for h in hs], [h.weight_scale for h in hs],
+                                                        [m.weight.shape[1] for _, m in mods], mods[0][1].weight.device)
+            for h, a, ok in zip(hs, synced, enabled):
+                h.is_enabled = ok
+                h.act_scale = a if ok else None
+                if not ok:
+                    h.gram = None
+                    h.use_gram = False
         for _, m in mods:  # Gram-matrix linears: losses now (local Gram; the loss is linear in it, summed below)
             h = helpers[m]
             if h.gram is not None and h.act_scale is not None:
@@ -423,19 +433,40 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         if any(not h.use_gram and h.act_scale is not None for h in helpers.values()):
             state["mode"] = "search"
             forward_loop(model)  # search pass for the linears on the error-GEMM path
-        if dist.is_available() and dist.is_initialized():
-            # every rank must pick the same alpha: SUM the per-alpha losses in one bucket
-            mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()], dist.ReduceOp.SUM)
+        for h in helpers.values():
+            h.search_steps_all_ranks = h.num_search_steps
+        if dist.is_available() and dist.is_initialized() and mods:
+            # every rank must pick the same alpha -- and take the same "was it searched at all" decision: SUM the
+            # per-alpha losses and the search-step counters in one bucket
+            steps = torch.tensor([float(h.num_search_steps) for h in helpers.values()], device=mods[0][1].weight.device)
+            mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()] + [steps], dist.ReduceOp.SUM)
+            for h, n in zip(helpers.values(), steps.tolist()):
+                h.search_steps_all_ranks = int(n)
     finally:
         for m, f in originals.items():
             m.forward = f
         for h in helpers.values():
             h.release()
             h.gram = None
-    for _, m in mods:
+    for name, m in mods:
         h = helpers[m]
-        if h.act_scale is None:
-            warnings.warn("awq_lite: a linear saw no tokens; falling back to max calibration for it")
+        if h.is_enabled and h.search_steps_all_ranks == 0 and not h.use_gram:
+            h.is_enabled = False  # :1665-1672
+            warnings.warn("awq_lite: Calling `forward_loop(model)` the second time did not forward data through the "
+                          f"{name}. Please provide a valid `forward_loop` function that can be used to forward data "
+                          "through the model many times.")
+        if not h.is_enabled:
+            # :1674-1700: uncalibrated / NaN / never searched -> max-calibrated weights and a neutral pre_quant_scale,
+            # so that every linear of the model exports in the same format
+            warnings.warn(f"awq_lite: Forcing pre_quant_scale=1 for {name} because the expert was not properly "
+                          "exercised during calibration. This may degrade accuracy; consider increasing calibration "
+                          "size or using a more diverse dataset.")
+            m.awq_lite = h
+            m.weight_quantizer.reset_amax()
+            max_calibrate(m, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
+            m.input_quantizer._enable_pre_quant_scale = True
+            m.input_quantizer.pre_quant_scale = torch.ones(m.weight.shape[1], dtype=m.weight.dtype,
+                                                           device=m.weight.device)
             continue
         losses = {a: float(v) for a, v in h.loss.items()}
         h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)

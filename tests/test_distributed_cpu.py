@@ -93,6 +93,56 @@ def _job_bucket_and_shard(rank, world, moa):
     assert sorted(sum(gathered, [])) == items  # a partition: nothing lost, nothing duplicated
 
 
+def _job_missing_amax(rank, world, moa):
+    """A quantizer that saw no data on one rank (routed expert without tokens from that rank's shard): the bucket
+    membership is agreed first, the rank without the amax adopts the group's value; strict mode raises the
+    reference's error on every rank instead of dead-locking."""
+    def make():
+        return [_FakeQuantizer(torch.tensor([1.0 + rank])),
+                _FakeQuantizer(torch.tensor([[2.0], [7.0]]).bfloat16() if rank == 0 else None),   # missing on rank 1
+                _FakeQuantizer(None),                                                               # missing everywhere
+                _FakeQuantizer(torch.tensor(4.0) if rank == 1 else None)]                           # missing on rank 0
+    qs = make()
+    moa.distributed.sync_amax_bucketed(qs)
+    assert qs[0]._amax.item() == 2.0
+    assert qs[1]._amax.dtype == torch.bfloat16 and torch.equal(qs[1]._amax.float(), torch.tensor([[2.0], [7.0]]))
+    assert qs[2]._amax is None
+    assert qs[3]._amax.shape == () and qs[3]._amax.item() == 4.0
+    with pytest.raises(RuntimeError, match="MoE calibration incomplete"):
+        moa.distributed.sync_amax_bucketed(make(), on_missing="raise")
+    # a real TensorQuantizer gets a registered buffer through its amax setter
+    tq = moa.TensorQuantizer(moa.QuantizerAttributeConfig(num_bits=8, axis=None))
+    if rank == 0:
+        tq.amax = torch.tensor(3.0)
+    moa.distributed.sync_amax_bucketed([tq])
+    assert tq.amax.item() == 3.0 and "_amax" in dict(tq.named_buffers())
+
+
+def _job_awq_scales(rank, world, moa):
+    cin = [4, 3, 2, 5]
+    act = [torch.full((4,), 1.0 + rank),                       # both ranks: average
+           torch.full((3,), 5.0) if rank == 0 else None,       # rank 1 saw no tokens: rank 0's value
+           None,                                               # nobody: disabled
+           torch.tensor([1.0, float("nan") if rank == 1 else 2.0, 3.0, 4.0, 5.0])]   # NaN on one rank: disabled
+    wsc = [torch.ones(c) for c in cin]
+    synced, enabled = moa.distributed.sync_awq_act_scales(act, wsc, cin, torch.device("cpu"))
+    assert enabled == [True, True, False, False]
+    assert torch.equal(synced[0], torch.full((4,), 1.5)) and torch.equal(synced[1], torch.full((3,), 5.0))
+    assert synced[2] is None
+    # NaN in the weight scale votes too
+    wsc[0][1] = float("nan") if rank == 0 else 1.0
+    _, enabled = moa.distributed.sync_awq_act_scales(act, wsc, cin, torch.device("cpu"))
+    assert enabled == [False, True, False, False]
+
+
+def test_sync_amax_with_missing_members_gloo():
+    _spawn("_job_missing_amax")
+
+
+def test_sync_awq_act_scales_gloo():
+    _spawn("_job_awq_scales")
+
+
 def test_sync_amax_bucketed_gloo():
     _spawn("_job_amax")
 

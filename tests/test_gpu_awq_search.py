@@ -101,3 +101,47 @@ def test_err_weight_kernel_equals_composed_ops(dtype):
         assert torch.equal(err, want), f"E differs ({cout}x{cin} g={g})"
         hi, lo = ops.split_bf16(want)
         assert torch.equal(a, torch.cat([hi, hi, lo], dim=1)), "split-precision operand differs"
+
+
+class Experts(torch.nn.Module):
+    """Three "experts"; the router sends tokens to experts 0 and 1 only, expert 1's input carries a NaN."""
+
+    def __init__(self, dtype):
+        super().__init__()
+        self.stack = Stack([(256, 512), (256, 512), (256, 512)], dtype)
+
+    def forward(self, xs):
+        return [self.stack.linears[0](xs[0]), self.stack.linears[1](xs[1])]  # expert 2 never runs
+
+
+@pytest.mark.parametrize("mode", ["gram", "gemm"])
+def test_unexercised_and_nan_linears_fall_back_to_max_calibration(mode):
+    """awq_lite's guard rails (model_calib.py:1605-1700): a linear that saw no tokens, or whose act scale holds a
+    NaN, leaves the search, gets max-calibrated weights and a neutral pre_quant_scale; the others are searched as
+    usual."""
+    dtype = torch.bfloat16
+    dims = [(256, 512)] * 3
+    batches = _batches(dims, dtype, 2, 96)
+    for b in batches:
+        b[1][5, 7] = float("nan")
+    model = Experts(dtype).to(DEV)
+    w_before = [lin.weight.detach().clone() for lin in model.stack.linears]
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": mode}
+    with pytest.warns(UserWarning, match="Forcing pre_quant_scale=1"):
+        q = moa.quantize(model, cfg, lambda m: [m(b) for b in batches])
+    l0, l1, l2 = q.stack.linears
+    assert l0.awq_lite.is_enabled and l0.awq_lite.best_alpha is not None
+    assert not torch.equal(l0.weight, w_before[0])  # scale folded into the weight
+    for lin, w0 in ((l1, w_before[1]), (l2, w_before[2])):
+        assert not lin.awq_lite.is_enabled and lin.awq_lite.best_scale is None
+        assert torch.equal(lin.weight, w0)  # untouched
+        pqs = lin.input_quantizer.pre_quant_scale
+        assert pqs.dtype == dtype and torch.equal(pqs, torch.ones_like(pqs))
+        want = w0.view(-1, 128).abs().amax(dim=1).float()
+        assert torch.equal(lin.weight_quantizer.amax.float().reshape(-1), want)  # plain max calibration
+    # the searched linear is what a run without the broken experts gives
+    ref = Stack(dims[:1], dtype).to(DEV)
+    qr = moa.quantize(ref, cfg, lambda m: [m(b[:1]) for b in batches])
+    assert qr.linears[0].awq_lite.best_alpha == l0.awq_lite.best_alpha
+    assert torch.equal(qr.linears[0].weight, l0.weight)
