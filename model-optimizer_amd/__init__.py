@@ -8,6 +8,7 @@ libmoquant.so (include/moquant.h).  Mirrors the reference's plugin surface for t
   tensor_quantizer TensorQuantizer (same attributes and life cycle as the reference's)
   nn, model_quant, model_calib   QuantLinear, quantize(), max_calibrate / smoothquant / awq_lite
   hf_attention     q / k / v bmm quantizers (FP8 KV cache) on Hugging Face attention modules
+  hf_experts       per-expert weight quantizers on fused 3-D MoE expert containers (Mixtral, Qwen-MoE, ...)
   sparsity         create_asp_mask (2:4 magnitude)
   qtensor          INT4QTensor / FP8QTensor / MXFP4QTensor real quantisation (pack / unpack kernels)
   layerwise        layer-by-layer calibration with checkpoint / resume
@@ -25,6 +26,7 @@ from . import calib  # noqa: F401
 from . import tensor_quantizer  # noqa: F401
 from . import nn  # noqa: F401
 from . import hf_attention  # noqa: F401
+from . import hf_experts  # noqa: F401
 from . import distributed  # noqa: F401
 from . import model_calib  # noqa: F401
 from . import model_quant  # noqa: F401
@@ -36,6 +38,6 @@ from . import modelopt_plugin  # noqa: F401
 from .model_quant import quantize  # noqa: F401
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
-__all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "hf_attention", "distributed", "model_calib", "model_quant",
+__all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "hf_attention", "hf_experts", "distributed", "model_calib", "model_quant",
            "sparsity", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
            "MoquantError", "MoquantUnsupported"]

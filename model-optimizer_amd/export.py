@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .hf_experts import is_quant_fused_experts
 from .nn import is_quantized_linear
 
 QUANTIZATION_NONE = None
@@ -33,7 +34,7 @@ QUANTIZATION_MXFP4 = "mxfp4"
 
 def get_quantization_format(module) -> str | None:
     """export/quant_utils.py:506-700 for the quantizer settings of this path."""
-    if not is_quantized_linear(module):
+    if not (is_quantized_linear(module) or isinstance(module, _ExpertProjection)):
         return QUANTIZATION_NONE
     wq, iq = module.weight_quantizer, module.input_quantizer
     if not wq.is_enabled:
@@ -203,6 +204,101 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
     raise NotImplementedError(f"quantization format {quantization} not supported")
 
 
+class _ExpertProjection:
+    """One expert's 2-D projection cut out of a fused 3-D expert weight, dressed like a quantized linear for
+    export_quantized_weight (the reference builds an nn.Module wrapper for the same purpose, moe_utils.py:196-201)."""
+
+    def __init__(self, weight, weight_quantizer, input_quantizer):
+        self.weight, self.weight_quantizer, self.input_quantizer, self.bias = weight, weight_quantizer, input_quantizer, None
+
+
+def _needs_amax_fallback(q) -> bool:
+    return q.is_enabled and (getattr(q, "_amax", None) is None or bool(torch.all(q._amax == 0)))
+
+
+@torch.no_grad()
+def export_fused_experts(module, dtype: torch.dtype) -> dict:
+    """moe_utils.py:48-215: split the fused 3-D expert weights into per-expert 2-D projections (gated: gate_proj,
+    up_proj, down_proj; non-gated: up_proj, down_proj) and export each like a quantized linear.  Keys:
+    `<E>.<proj>.weight`, `.weight_scale`, `.input_scale`.  gate and up share the fused tensor's weight quantizer:
+    a per-tensor amax is shared (runtimes re-fuse W1 / W3 under ONE scale), a per-row / per-block amax is sliced along
+    dim 0 with the weight; quantizers that never got an amax fall back to the weight's own abs-max with a warning."""
+    import copy
+    import warnings
+
+    first_attr = module._first_proj_attr
+    first, down = getattr(module, first_attr).data, module.down_proj.data
+    first_wqs = getattr(module, module._first_proj_weight_quantizers_attr)
+    first_iq, down_iq = getattr(module, module._first_proj_input_quantizer_attr), module.down_proj_input_quantizer
+    fused_rows = first.shape[1]
+    inter = fused_rows // 2 if module._is_gated else None
+    out = {}
+    for idx in range(module.num_experts):
+        fq = first_wqs[idx]
+        if module._is_gated and _needs_amax_fallback(fq):
+            if hasattr(fq, "_amax"):
+                delattr(fq, "_amax")
+            fq.amax = ops.reduce_amax(first[idx]).to(torch.float32)
+            warnings.warn(f"Expert {idx} gate_up_proj weight quantizer was not calibrated (amax missing or zero). "
+                          "Using fused-tensor amax as fallback (shared by gate and up).", stacklevel=2)
+        if module._is_gated:
+            projections = [("gate_proj", first[idx, :inter], 0, True), ("up_proj", first[idx, inter:], inter, True),
+                           ("down_proj", down[idx], 0, False)]
+        else:
+            projections = [("up_proj", first[idx], 0, True), ("down_proj", down[idx], 0, False)]
+        for proj, w, row0, uses_first in projections:
+            src = fq if uses_first else module.down_proj_weight_quantizers[idx]
+            wq = copy.deepcopy(src) if uses_first else src
+            total = fused_rows if uses_first else down.shape[1]
+            amax = getattr(wq, "_amax", None)
+            if amax is not None and amax.dim() >= 1 and amax.numel() > 1:
+                if amax.numel() != total and amax.numel() % total == 0:
+                    amax = amax.contiguous().view(total, amax.numel() // total)
+                rows = amax.shape[0]
+                if total % rows == 0:
+                    sliced = amax[row0 * rows // total:(row0 + w.shape[0]) * rows // total].contiguous()
+                    delattr(wq, "_amax")
+                    wq.amax = sliced.reshape(-1, 1) if src._amax.dim() == 2 and src._amax.shape[-1] == 1 else sliced
+                else:
+                    warnings.warn(f"Expert {idx} {proj}: fused amax dim0 ({rows}) does not evenly divide the fused "
+                                  f"rows ({total}). Skipping amax slicing.", stacklevel=2)
+            if _needs_amax_fallback(wq):
+                if hasattr(wq, "_amax"):
+                    delattr(wq, "_amax")
+                wq.amax = ops.reduce_amax(w.contiguous()).to(torch.float32)
+                warnings.warn(f"Expert {idx} {proj} weight quantizer was not calibrated (amax missing or zero). "
+                              "Using weight-derived amax as fallback.", stacklevel=2)
+            wrapper = _ExpertProjection(w.contiguous(), wq, first_iq if uses_first else down_iq)
+            for k, v in export_quantized_weight(wrapper, dtype).items():
+                out[f"{idx}.{proj}.{k}"] = v
+    return out
+
+
+# checkpoint names that differ from the module tree: transformers >= 5 loads / saves some architectures through a
+# key conversion (its save_pretrained applies the reverse mapping to whatever state dict it is given -- which is how
+# the reference's exported tensors get these names); (regex on our key, replacement)
+_CHECKPOINT_KEY_RENAMES = {
+    "mixtral": [(r"\.mlp\.experts\.(\d+)\.gate_proj\.", r".block_sparse_moe.experts.\1.w1."),
+                (r"\.mlp\.experts\.(\d+)\.down_proj\.", r".block_sparse_moe.experts.\1.w2."),
+                (r"\.mlp\.experts\.(\d+)\.up_proj\.", r".block_sparse_moe.experts.\1.w3."),
+                (r"\.mlp\.gate\.", r".block_sparse_moe.gate.")],
+}
+
+
+def rename_to_checkpoint_keys(state: dict, model) -> dict:
+    import re
+
+    rules = _CHECKPOINT_KEY_RENAMES.get(getattr(getattr(model, "config", None), "model_type", None))
+    if not rules:
+        return state
+    out = {}
+    for k, v in state.items():
+        for pat, rep in rules:
+            k = re.sub(pat, rep, k)
+        out[k] = v
+    return out
+
+
 @torch.no_grad()
 def export_quantized_weight(module, dtype: torch.dtype):
     """unified_export_hf.py:569-810 for one quantized linear: returns the tensors the checkpoint stores for it
@@ -245,12 +341,16 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
     state = {}
     handled = set()
     for name, m in model.named_modules():
+        prefix = name + "." if name else ""
         if is_quantized_linear(m):
-            prefix = name + "." if name else ""
             for k, v in export_quantized_weight(m, dtype).items():
                 state[prefix + k] = v
             if m.bias is not None:
                 state[prefix + "bias"] = m.bias.detach()
+            handled.add(name)
+        elif is_quant_fused_experts(m):
+            for k, v in export_fused_experts(m, dtype).items():
+                state[prefix + k] = v
             handled.add(name)
     kv_format = get_kv_cache_format(model)
     for k, v in model.state_dict().items():
@@ -260,7 +360,7 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
         new_key, value = _postprocess_kv_key(k, v, kv_format)
         if new_key is not None:
             state[new_key] = value
-    return state
+    return rename_to_checkpoint_keys(state, model)
 
 
 KV_CACHE_FP8 = "FP8"

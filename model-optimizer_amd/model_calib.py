@@ -21,6 +21,7 @@ from torch import nn
 from . import distributed as mdist
 from . import ops
 from .multi_tensor import SegmentTable
+from .hf_experts import is_quant_fused_experts
 from .nn import QuantLinear, is_quantized_linear
 from .tensor_quantizer import SequentialQuantizer, TensorQuantizer
 
@@ -56,28 +57,31 @@ def weight_only_quantize(model: nn.Module):
 
     Fast path: all enabled per-tensor 'max' weight quantizers of one dtype are calibrated by ONE
     multi-tensor abs-max launch instead of one reduction per layer."""
-    mods = [m for m in model.modules() if is_quantized_linear(m) and m.weight_quantizer.is_enabled]
+    pairs = [(m.weight, m.weight_quantizer) for m in model.modules()
+             if is_quantized_linear(m) and m.weight_quantizer.is_enabled]
+    for m in model.modules():  # fused MoE expert containers: one (slice, quantizer) pair per expert and projection
+        if is_quant_fused_experts(m):
+            pairs += [(w, q) for w, q in m.iter_weights_for_calibration() if q.is_enabled]
     batched = []
-    for m in mods:
-        wq = m.weight_quantizer
+    for w, wq in pairs:
         per_tensor_max = (isinstance(wq, TensorQuantizer) and wq._if_calib and wq.axis is None and wq.block_sizes is None
-                          and type(wq._calibrator).__name__ == "MaxCalibrator" and m.weight.is_cuda
-                          and m.weight.is_contiguous() and wq.pre_quant_scale is None)
+                          and type(wq._calibrator).__name__ == "MaxCalibrator" and w.is_cuda
+                          and w.is_contiguous() and wq.pre_quant_scale is None)
         if per_tensor_max:
-            batched.append(m)
+            batched.append((w, wq))
         else:
-            wq(m.weight)
+            wq(w)
     by_key = {}
-    for m in batched:
-        by_key.setdefault((m.weight.dtype, m.weight.device), []).append(m)
+    for w, wq in batched:
+        by_key.setdefault((w.dtype, w.device), []).append((w, wq))
     for group in by_key.values():
-        tab = SegmentTable([m.weight.detach() for m in group], outputs=[m.weight.detach() for m in group])
+        tab = SegmentTable([w.detach() for w, _ in group], outputs=[w.detach() for w, _ in group])
         amax = tab.calibrate_amax()
-        for i, m in enumerate(group):
-            cal = m.weight_quantizer._calibrator
+        for i, (w, wq) in enumerate(group):
+            cal = wq._calibrator
             if cal._buf is None:
                 cal._buf = amax[i:i + 1].clone()
-                cal._shape, cal._dtype = (), m.weight.dtype
+                cal._shape, cal._dtype = (), w.dtype
             else:
                 torch.maximum(cal._buf, amax[i:i + 1], out=cal._buf)
 

@@ -4,6 +4,7 @@
 from __future__ import annotations
 
 import fnmatch
+import re
 
 from torch import nn
 
@@ -73,6 +74,14 @@ def _apply_attrs(mod: TensorQuantizer, attrs: dict):
         mod.disable()
 
 
+_FUSED_EXPERTS_QUANTIZER_LIST_RE = re.compile(r"(weight_quantizers?|input_quantizers?)\.\d+(?=$|\.)")
+
+
+def _normalize_fused_experts_quantizer_name(name: str) -> str:
+    """conversion.py:317-341: `...gate_up_proj_weight_quantizers.3` also answers to `*weight_quantizer`."""
+    return _FUSED_EXPERTS_QUANTIZER_LIST_RE.sub(lambda m: m.group(1).removesuffix("s"), name)
+
+
 def set_quantizer_by_cfg(model: nn.Module, quant_cfg: dict):
     """conversion.py:245 set_quantizer_by_cfg: later wildcard entries override earlier ones.  A LIST of attribute
     dicts turns the quantizer into a SequentialQuantizer with one member per entry (conversion.py:296-321)."""
@@ -81,8 +90,9 @@ def set_quantizer_by_cfg(model: nn.Module, quant_cfg: dict):
             continue
         if "." in name and isinstance(model.get_submodule(name.rpartition(".")[0]), SequentialQuantizer):
             continue  # members are configured through their container
+        normalized = _normalize_fused_experts_quantizer_name(name)
         for pattern, attrs in quant_cfg.items():
-            if not fnmatch.fnmatch(name, pattern):
+            if not (fnmatch.fnmatch(name, pattern) or (normalized != name and fnmatch.fnmatch(normalized, pattern))):
                 continue
             parent = model.get_submodule(name.rpartition(".")[0]) if "." in name else model
             attr = name.rpartition(".")[-1]

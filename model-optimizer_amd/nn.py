@@ -40,10 +40,13 @@ def is_quantized_linear(m) -> bool:
 def replace_quant_module(model: nn.Module) -> nn.Module:
     """nn.Linear -> QuantLinear everywhere (conversion.py:214 replace_quant_module for the Linear entry); attention
     modules of a Hugging Face model get their KV-cache quantizers (plugins/huggingface.py:371-415, run by the
-    reference from the same place through its on-the-fly plugin registry)."""
+    reference from the same place through its on-the-fly plugin registry); fused 3-D expert containers get per-expert
+    weight quantizers (:1697-1730)."""
     from .hf_attention import register_hf_attentions_on_the_fly
+    from .hf_experts import register_fused_experts_on_the_fly
 
     register_hf_attentions_on_the_fly(model)
+    register_fused_experts_on_the_fly(model)
     for mod in list(model.modules()):
         if type(mod) is nn.Linear:
             QuantLinear.convert(mod)

@@ -24,6 +24,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
   export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
+  moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -833,14 +834,62 @@ def gen_export_fp8_kv(out):
                                              exported_keys=all_keys, hf_quant_config=quant_cfg)))
 
 
+def gen_moe_fp8(out):
+    """FP8_DEFAULT_CFG on a tiny fp32 Mixtral (transformers >= 5: fused 3-D expert weights, quantized by the
+    reference's _QuantFusedExperts, plugins/huggingface.py:976-1115): every enabled quantizer's amax (per-expert
+    weight quantizers, shared input quantizers), logits with fake-quant active, and the exported checkpoint
+    (per-expert gate / up / down projections split out of the fused tensors, moe_utils.py:48-215)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64, num_local_experts=4,
+                num_experts_per_tok=2)
+    model = MixtralForCausalLM(MixtralConfig(architectures=["MixtralForCausalLM"], **cfgd)).to(torch.float32)
+    with torch.no_grad():  # expert 3 of layer 1 never wins the routing: exercises the uncalibrated-expert fallbacks
+        model.model.layers[1].mlp.gate.weight[3] = 0
+        model.model.layers[1].mlp.gate.weight[3, 0] = -1e4
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    for i, b in enumerate(batches):
+        out[f"tokens{i}"] = b.numpy()
+    q = mtq.quantize(model, mtq.FP8_DEFAULT_CFG, lambda m: [m(b) for b in batches])
+    quantizers = {}
+    for n, m in q.named_modules():
+        if type(m).__name__ == "TensorQuantizer":
+            quantizers[n] = bool(m.is_enabled)
+            if m.is_enabled and getattr(m, "_amax", None) is not None:
+                out[f"amax/{n}"] = bits(m._amax.float())
+    with torch.no_grad():
+        out["logits"] = bits(q(batches[0]).logits)
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                dtypes[k] = str(t.dtype)
+                if ".mlp." in k or "block_sparse_moe" in k:
+                    out[f"exp/{k}"] = t.view(torch.uint8).numpy().copy() if t.dtype == torch.float8_e4m3fn else bits(t)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), quantizers=quantizers, dtypes=dtypes,
+                                             hf_quant_config=quant_cfg)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

@@ -220,3 +220,54 @@ def test_hf_attention_registration_patches_and_restores_the_interface():
         assert tuple(attn.k_bmm_quantizer._num_bits) == (4, 3)
         assert moa.export.get_kv_cache_format(model) == "FP8"
     assert hf_attention.register_hf_attentions_on_the_fly(torch.nn.Linear(2, 2)) == 0
+
+
+def test_fused_experts_registration_and_name_matching():
+    """hf_experts (plugins/huggingface.py:976-1142, conversion.py:317-341 mirror) without any kernel: per-expert
+    quantizer layout, wildcard matching through the ModuleList index, F.linear restored after the forward, outputs
+    unchanged while every quantizer is disabled."""
+    import torch.nn.functional as F
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    from model_optimizer_amd import hf_experts, nn as mnn
+    cfg = MixtralConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=4,
+                        num_key_value_heads=2, vocab_size=64, max_position_embeddings=32, num_local_experts=4,
+                        num_experts_per_tok=2)
+    torch.manual_seed(0)
+    model = MixtralForCausalLM(cfg).eval()
+    tokens = torch.randint(0, 64, (2, 16), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = model(tokens).logits
+    linear_fn = F.linear
+    mnn.replace_quant_module(model)
+    ex = model.model.layers[0].mlp.experts
+    assert hf_experts.is_quant_fused_experts(ex) and type(ex).__name__ == "QuantMixtralExperts"
+    assert len(ex.gate_up_proj_weight_quantizers) == 4 and len(ex.down_proj_weight_quantizers) == 4
+    mq = moa.model_quant
+    assert mq._normalize_fused_experts_quantizer_name("a.experts.gate_up_proj_weight_quantizers.3") == \
+        "a.experts.gate_up_proj_weight_quantizer"
+    assert mq._normalize_fused_experts_quantizer_name("a.weight_quantizer.0") == "a.weight_quantizer"
+    assert mq._normalize_fused_experts_quantizer_name("a.input_quantizer") == "a.input_quantizer"
+    mq.set_quantizer_by_cfg(model, {"*weight_quantizer": {"num_bits": (4, 3), "axis": None},
+                                    "*input_quantizer": {"num_bits": (4, 3), "axis": None},
+                                    "*experts.down_proj_weight_quantizers.2": {"enable": False}})
+    assert tuple(ex.gate_up_proj_weight_quantizers[3]._num_bits) == (4, 3)
+    assert tuple(ex.gate_up_proj_input_quantizer._num_bits) == (4, 3)
+    assert ex.down_proj_weight_quantizers[1].is_enabled and not ex.down_proj_weight_quantizers[2].is_enabled
+    for q in [m for m in model.modules() if isinstance(m, TensorQuantizer)]:
+        q.disable()
+    seen = []
+    for i, q in enumerate(ex.gate_up_proj_weight_quantizers):
+        q.register_forward_hook(lambda m, inp, out, i=i: seen.append((i, inp[0].data_ptr() == ex.gate_up_proj[i].data_ptr())))
+    with torch.no_grad():
+        got = model(tokens).logits
+    assert torch.equal(got, want) and F.linear is linear_fn
+    assert seen and all(ok for _, ok in seen)  # expert i's slice reached expert i's quantizer
+    pairs = list(ex.iter_weights_for_calibration())
+    assert len(pairs) == 8 and pairs[5][0].data_ptr() == ex.down_proj[1].data_ptr() and pairs[5][1] is ex.down_proj_weight_quantizers[1]
+    # checkpoint key names of the exported per-expert tensors
+    ren = moa.export.rename_to_checkpoint_keys({"model.layers.0.mlp.experts.2.up_proj.weight": 1,
+                                                "model.layers.0.mlp.gate.weight": 2,
+                                                "model.layers.0.self_attn.q_proj.weight": 3}, model)
+    assert set(ren) == {"model.layers.0.block_sparse_moe.experts.2.w3.weight", "model.layers.0.block_sparse_moe.gate.weight",
+                        "model.layers.0.self_attn.q_proj.weight"}
