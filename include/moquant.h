@@ -130,6 +130,11 @@ int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_
  * as one dense window (read-only stream at ~7 TB/s instead of ~6.3), then one fold per tensor. */
 int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
                    float* chunk_scratch, void* stream);
+/* a4 `calibrate_weights` (calib/histogram.py:346-433): counts[r, b] += number of |x[r, :]| in bin b of
+ * np.histogram(|x[r]|, bins, range=(first[r], last[r])) -- numpy's float32 edges and closed last bin, bit for bit.
+ * counts is int32 [rows, bins] and is accumulated into (zero it first). */
+int moq_row_hist_np(const void* x, int64_t rows, int64_t cols, int dt, int bins, const float* first,
+                    const float* last, int* counts, void* stream);
 /* Per-tensor FP8-E4M3 QDQ of every segment with its own amax (a7 over a tensor list). */
 int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
                            int dt, void* stream);

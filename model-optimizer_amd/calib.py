@@ -254,6 +254,50 @@ def _compute_amax_mse(counts, edges, num_bits, unsigned, stride=1, start_bin=128
     return centers[best_i].clone()
 
 
+@torch.no_grad()
+def calibrate_weights(model, method="percentile", perchannel=True, percentile=99.99, num_bins=2048):
+    """calib/histogram.py:346-433: set the amax of every `weight_quantizer` from a histogram of its weight -- one
+    histogram per output channel (axis 0; transposed convolutions are outside this path) or one per tensor.
+
+    The reference moves every channel to the host and calls np.histogram on it (Cout numpy calls per weight); here
+    all channel histograms of a weight come from ONE kernel with numpy's float32 edges (ops.row_hist_np), and the
+    per-channel reductions stay numpy on the host, on [Cout, bins] arrays: `percentile` = cumsum / searchsorted in
+    the reference's float64 arithmetic, row by row."""
+    for _, module in model.named_modules():
+        if not (hasattr(module, "weight") and hasattr(module, "weight_quantizer")):
+            continue
+        wq = module.weight_quantizer
+        w = module.weight.detach()
+        axis = 0 if perchannel else None
+        if method == "max":
+            reduce_axis = convert_quantization_axis_to_reduce_axis(w, axis)
+            amax = ops.reduce_amax(w, axis=reduce_axis)
+        elif method in ("percentile", "mse"):
+            if method == "percentile" and (percentile < 0 or percentile > 100):
+                raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
+            counts, edges = ops.row_hist_np(w if perchannel else w.reshape(1, -1), num_bins)
+            if method == "percentile":
+                hist, e = counts.cpu().numpy().astype(np.int64), edges.cpu().numpy()
+                total = hist.sum(axis=1, keepdims=True)
+                cdf = np.cumsum(hist / total, axis=1)  # float64, sequential along the row like the 1-D call
+                idx = [int(np.searchsorted(cdf[r], percentile / 100)) for r in range(hist.shape[0])]
+                vals = torch.tensor([e[r, i].item() for r, i in enumerate(idx)])
+            else:
+                vals = torch.stack([_compute_amax_mse(counts[r].to(torch.int64), edges[r], wq._num_bits, wq._unsigned).cpu()
+                                    for r in range(counts.shape[0])])
+            if perchannel:
+                amax = vals.reshape([w.shape[0]] + [1] * (w.dim() - 1))
+            else:
+                amax = vals.reshape(())
+        else:
+            raise TypeError(f"Unsupported calibration method {method}")
+        if amax.numel() == 1:
+            amax = amax.reshape(())
+        if hasattr(wq, "_amax"):
+            wq.reset_amax()
+        wq.amax = amax.to(w.device)
+
+
 class MseCalibrator(_Calibrator):
     """amax multiplier sweep minimising the QDQ error -- calib/mse.py:31-172.  quant_func(x, amax) is
     supplied by the quantizer (model_calib.py:639-662) and runs our QDQ kernels; the candidate loop and the

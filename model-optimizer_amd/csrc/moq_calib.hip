@@ -161,6 +161,48 @@ __global__ void mse_finalize_kernel(const float* __restrict__ partial, int64_t n
   loss[idx] = accumulate ? loss[idx] + s : s;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// calibrate_weights (quantization/calib/histogram.py:346-433): one |w| histogram PER OUTPUT CHANNEL with numpy's
+// np.histogram(a, bins, range=(0, a.max())) semantics.  numpy builds float32 edges e_k = fp32(fp32(k * step) + first),
+// step = (last - first) / bins, e_bins = last, estimates the bin as trunc(((v - first) / (last - first)) * bins) and
+// then corrects the estimate against the edges (decrement if v < e_idx, then increment if v >= e_{idx+1}); the last
+// bin is closed.  The same steps in the same fp32 arithmetic here; grid = (column splits, rows), LDS histogram per
+// workgroup, int32 global atomics on flush.  first / last per row come from the host (row abs-max, or -0.5 / +0.5
+// for an all-zero row exactly like numpy's _get_outer_edges).
+template <int DT>
+__global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restrict__ x, int64_t cols, int bins,
+                                                             const float* __restrict__ first,
+                                                             const float* __restrict__ last,
+                                                             int* __restrict__ counts) {
+  extern __shared__ int lds_hist[];
+  const int64_t row = blockIdx.y;
+  for (int b = threadIdx.x; b < bins; b += kBlock) lds_hist[b] = 0;
+  __syncthreads();
+  const float lo = first[row], hi = last[row];
+  const float width = hi - lo;
+  const float fbins = (float)bins;
+  const float step = width / fbins;
+  const int64_t per = (cols + gridDim.x - 1) / gridDim.x;
+  const int64_t c0 = blockIdx.x * per, c1 = c0 + per < cols ? c0 + per : cols;
+  const int64_t base = row * cols;
+  auto edge = [&](int k) { return k == bins ? hi : (float)k * step + lo; };
+  for (int64_t c = c0 + threadIdx.x; c < c1; c += kBlock) {
+    const float v = __builtin_fabsf(load1<DT>(x, base + c));
+    if (!(v >= lo && v <= hi)) continue;  // NaN (numpy raises on non-finite ranges; nothing is counted here)
+    int idx = (int)(((v - lo) / width) * fbins);
+    if (idx == bins) idx = bins - 1;
+    if (v < edge(idx)) --idx;
+    if (idx != bins - 1 && v >= edge(idx + 1)) ++idx;
+    atomicAdd(&lds_hist[idx], 1);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < bins; b += kBlock) {
+    const int n = lds_hist[b];
+    if (n) atomicAdd(&counts[row * bins + b], n);
+  }
+}
+
 }  // namespace moq
 
 using namespace moq;
@@ -234,4 +276,27 @@ extern "C" int moq_mse_sweep(const void* x, int64_t outer, int64_t axis_size, in
   hipLaunchKernelGGL(mse_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S(stream), partial,
                      n_rows, axis_size, segs, n_cand, loss, accumulate);
   return check_launch("moq_mse_sweep");
+}
+
+extern "C" int moq_row_hist_np(const void* x, int64_t rows, int64_t cols, int dt, int bins, const float* first,
+                               const float* last, int* counts, void* stream) {
+  if (rows < 0 || cols < 0 || bins <= 0 || (rows * cols > 0 && (x == nullptr || first == nullptr || last == nullptr ||
+                                                               counts == nullptr))) {
+    set_error("moq_row_hist_np: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (bins > 16384 || rows > 65535 || cols >= ((int64_t)1 << 31)) {
+    set_error("moq_row_hist_np: needs bins <= 16384, rows <= 65535, cols < 2^31");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (rows * cols == 0) return MOQ_OK;
+  // enough workgroups to fill the chip, but at least ~8 elements per thread per workgroup
+  int64_t splits = (2048 + rows - 1) / rows;
+  const int64_t max_splits = (cols + 8 * kBlock - 1) / (8 * kBlock);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((row_hist_np_kernel<DT>), dim3((unsigned)splits, (unsigned)rows), dim3(kBlock),
+                                            (size_t)bins * 4, reinterpret_cast<hipStream_t>(stream), x, cols, bins,
+                                            first, last, counts));
+  return check_launch("moq_row_hist_np");
 }

@@ -303,6 +303,31 @@ def hist_abs(x: torch.Tensor, bins: int, max_edge: float, skip_zeros: bool = Fal
     return counts
 
 
+@torch.no_grad()
+def row_hist_np(w: torch.Tensor, bins: int):
+    """Per-row histograms of |w| with np.histogram(a, bins, range=(0, a.max())) semantics (calibrate_weights,
+    calib/histogram.py:346-433): returns (counts int32 [rows, bins], edges fp32 [rows, bins + 1]).  A 1-D / flattened
+    call (rows = 1) is the per-tensor histogram.  16-bit inputs are binned as fp32 values (numpy itself has no bf16
+    and would bin fp16 against fp16 edges)."""
+    _require_gpu(w, "row_hist_np")
+    x = w.detach().contiguous()
+    x = x.reshape(1, -1) if x.dim() < 2 else x.reshape(x.shape[0], -1)
+    rows, cols = x.shape
+    mx = reduce_amax(x, axis=[1]).float().reshape(-1) if cols else torch.zeros(rows, device=x.device)
+    zero = mx == 0
+    first = torch.where(zero, torch.full_like(mx, -0.5), torch.zeros_like(mx)).contiguous()  # _get_outer_edges
+    last = torch.where(zero, torch.full_like(mx, 0.5), mx).contiguous()
+    counts = torch.zeros(rows, bins, dtype=torch.int32, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_row_hist_np(_p(x), rows, cols, _dt(x), int(bins), _p(first), _p(last), _p(counts), stream))
+    # np.linspace in float32: fp32(fp32(k * step) + first), last edge = stop
+    k = torch.arange(bins + 1, dtype=torch.float32, device=x.device)
+    step = (last - first) / float(bins)
+    edges = k[None, :] * step[:, None] + first[:, None]
+    edges[:, -1] = last
+    return counts, edges
+
+
 # ----------------------------------------------------------------------------------------------- sparsity
 @torch.no_grad()
 def mask_2to4(w: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

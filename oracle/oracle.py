@@ -139,6 +139,17 @@ def hist_abs(x, bins, max_edge, skip_zeros=False, counts=None):
     return c
 
 
+def row_hist_np(w, bins, first, last):
+    """Per-row |w| histograms with np.histogram's float32 edges (calibrate_weights, calib/histogram.py:346-433)."""
+    rows, cols = w.shape
+    a = _np(w)
+    counts = np.zeros((rows, bins), dtype=np.int32)
+    f = np.ascontiguousarray(first.detach().cpu().float().numpy())
+    la = np.ascontiguousarray(last.detach().cpu().float().numpy())
+    lib().orc_row_hist_np(_p(a), I64(rows), I64(cols), DT[w.dtype], int(bins), _p(f), _p(la), _p(counts))
+    return torch.from_numpy(counts)
+
+
 def mask_2to4(w):
     cols = w.shape[-1]
     rows = w.numel() // cols

@@ -25,6 +25,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
   export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
   moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
+  calibrate_weights.npz -- calib.calibrate_weights per-channel / per-tensor percentile amax + numpy's channel histograms
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -882,14 +883,51 @@ def gen_moe_fp8(out):
                                              hf_quant_config=quant_cfg)))
 
 
+def gen_calibrate_weights(out):
+    """calib.calibrate_weights (calib/histogram.py:346-433) on fp32 linears: per-channel and per-tensor percentile
+    amax, "max", and the per-channel histograms numpy produced on the way (re-derived with the same np.histogram call)."""
+    from modelopt.torch.quantization import calib as ref_calib
+    from modelopt.torch.quantization import nn as qnn
+
+    cases = {}
+    gen = torch.Generator().manual_seed(21)
+    for idx, (co, ci, kind) in enumerate([(16, 300, "normal"), (8, 4096, "heavy"), (5, 64, "grid"), (4, 33, "zero_row")]):
+        lin = qnn.QuantLinear(ci, co, bias=False)
+        with torch.no_grad():
+            w = torch.randn(co, ci, generator=gen) * 0.05
+            if kind == "heavy":
+                w = torch.where(torch.rand(co, ci, generator=gen) < 0.002, w * 20, w)
+            if kind == "grid":
+                w = torch.randint(-8, 9, (co, ci), generator=gen).float() * 0.125  # values ON bin edges
+            if kind == "zero_row":
+                w[2] = 0
+            lin.weight.copy_(w)
+        k = f"c{idx}"
+        cases[k] = dict(cout=co, cin=ci, kind=kind)
+        out[f"{k}_w"] = bits(lin.weight.detach())
+        for tag, kw in [("pc9999", dict(method="percentile", perchannel=True)),
+                        ("pc99", dict(method="percentile", perchannel=True, percentile=99.0)),
+                        ("pt999", dict(method="percentile", perchannel=False, percentile=99.9)),
+                        ("pcmax", dict(method="max", perchannel=True)),
+                        ("pc512", dict(method="percentile", perchannel=True, percentile=99.5, num_bins=512))]:
+            if kind == "zero_row" and "max" not in tag and "pt" not in tag:
+                pass  # all-zero channel: numpy widens the range to (-0.5, 0.5); still a defined result
+            lin.weight_quantizer.reset_amax()
+            ref_calib.calibrate_weights(lin, **kw)
+            out[f"{k}_{tag}"] = bits(lin.weight_quantizer.amax.float())
+        hists = [np.histogram(r.abs().numpy(), bins=2048, range=(0, r.abs().numpy().max()))[0] for r in lin.weight.detach()]
+        out[f"{k}_hist"] = np.stack(hists).astype(np.int32)
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

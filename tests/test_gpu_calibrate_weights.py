@@ -1,0 +1,78 @@
+"""calibrate_weights (calib/histogram.py:346-433) on the GPU: the per-channel histogram kernel against
+the oracle (numpy's float32-edge binning, bit-exact counts) and the amax values against the reference run
+(tests/golden/calibrate_weights.npz: per-channel / per-tensor percentile, max, 512 bins)."""
+
+import numpy as np
+import pytest
+import torch
+
+import _moa_import
+from conftest import DT
+
+pytestmark = pytest.mark.gpu
+moa = _moa_import.load()
+from model_optimizer_amd import calib, ops  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _range(w):
+    mx = w.float().abs().amax(1)
+    zero = mx == 0
+    return torch.where(zero, torch.full_like(mx, -0.5), torch.zeros_like(mx)), torch.where(zero, torch.full_like(mx, 0.5), mx)
+
+
+@pytest.mark.parametrize("dn", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("shape,bins", [((16, 300), 2048), ((3, 70000), 2048), ((1, 1), 8), ((64, 4096), 512),
+                                        ((5, 33), 16384), ((300, 17), 100)])
+def test_row_hist_kernel_equals_oracle(dn, shape, bins):
+    gen = torch.Generator().manual_seed(hash((dn, shape, bins)) & 0xffff)
+    w = (torch.randn(*shape, generator=gen) * torch.exp(torch.randn(shape[0], 1, generator=gen))).to(DT[dn])
+    if shape[0] > 2:
+        w[1] = 0                                  # all-zero channel: numpy's (-0.5, 0.5) range
+        w[2] = (torch.randint(-8, 9, (shape[1],), generator=gen).float() * 0.125).to(DT[dn])  # values on bin edges
+    counts, edges = ops.row_hist_np(w.to(DEV), bins)
+    first, last = _range(w)
+    want = oracle.row_hist_np(w, bins, first, last)
+    assert torch.equal(counts.cpu(), want), f"{(counts.cpu() != want).sum().item()} bins differ"
+    assert torch.equal(counts.sum(1).cpu(), torch.full((shape[0],), shape[1], dtype=torch.int64))
+    # the edges are np.linspace(first, last, bins + 1) in float32
+    for r in range(min(shape[0], 3)):
+        e = np.linspace(np.float32(first[r].item()), np.float32(last[r].item()), bins + 1, dtype=np.float32)
+        assert np.array_equal(edges[r].cpu().numpy(), e)
+
+
+def test_row_hist_equals_numpy_on_reference_weights(golden):
+    g = golden("calibrate_weights")
+    for k in g.cases:
+        w = g.t(f"{k}_w", torch.float32)
+        counts, _ = ops.row_hist_np(w.to(DEV), 2048)
+        assert torch.equal(counts.cpu(), torch.from_numpy(g.raw(f"{k}_hist").copy())), k
+
+
+class _Lin(torch.nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.weight = torch.nn.Parameter(w)
+        self.weight_quantizer = moa.TensorQuantizer(moa.QuantizerAttributeConfig(num_bits=8, axis=0))
+
+
+def test_calibrate_weights_matches_reference_run(golden):
+    g = golden("calibrate_weights")
+    for k, c in g.cases.items():
+        lin = _Lin(g.t(f"{k}_w", torch.float32).to(DEV))
+        for tag, kw in [("pc9999", dict(method="percentile", perchannel=True)),
+                        ("pc99", dict(method="percentile", perchannel=True, percentile=99.0)),
+                        ("pt999", dict(method="percentile", perchannel=False, percentile=99.9)),
+                        ("pcmax", dict(method="max", perchannel=True)),
+                        ("pc512", dict(method="percentile", perchannel=True, percentile=99.5, num_bins=512))]:
+            calib.calibrate_weights(lin, **kw)
+            want = g.t(f"{k}_{tag}", torch.float32)
+            got = lin.weight_quantizer.amax.float().cpu()
+            assert got.shape == want.shape, f"{k} {tag}: {got.shape} vs {want.shape}"
+            assert torch.equal(got, want), f"{k} {tag} ({c['kind']}): {(got != want).sum().item()} channels differ"
+    with pytest.raises(ValueError):
+        calib.calibrate_weights(lin, percentile=101)
+    with pytest.raises(TypeError):
+        calib.calibrate_weights(lin, method="entropy")

@@ -308,3 +308,22 @@ def test_block2d_matches_reference(golden):
         y, am = oracle.block2d(x, c["br"], c["bc"], 2, fp8=fp8, num_bits=8 if fp8 else c["num_bits"])
         assert torch.equal(am.reshape(-1), g.t(f"{k}_amax").reshape(-1)), f"{k}: block amax"
         assert_bits_equal(y, want, f"block2d {k} {c}")
+
+
+def _np_range(w):
+    mx = w.abs().amax(1)
+    zero = mx == 0
+    return torch.where(zero, torch.full_like(mx, -0.5), torch.zeros_like(mx)), torch.where(zero, torch.full_like(mx, 0.5), mx)
+
+
+def test_row_histograms_match_numpy_run_by_the_reference(golden):
+    """calibrate_weights' per-channel np.histogram(|w_row|, 2048, range=(0, max)) counts, as produced next to the
+    reference run (values on bin edges, an all-zero channel and heavy tails included)."""
+    g = golden("calibrate_weights")
+    for k, c in g.cases.items():
+        w = g.t(f"{k}_w", torch.float32)
+        first, last = _np_range(w)
+        got = oracle.row_hist_np(w, 2048, first, last)
+        want = torch.from_numpy(g.raw(f"{k}_hist").copy())
+        assert torch.equal(got, want), f"{k} ({c['kind']}): {(got != want).sum().item()} bins differ"
+        assert int(got.sum()) == w.numel()
