@@ -130,6 +130,18 @@ int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_
  * as one dense window (read-only stream at ~7 TB/s instead of ~6.3), then one fold per tensor. */
 int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
                    float* chunk_scratch, void* stream);
+/* FP8QTensor.quantize / dequantize with block_sizes on BOTH axes of a 2-D tensor (qtensor/fp8_tensor.py:60-112, :114-151;
+ * the FP8 2-D blockwise weight-only export, export/quant_utils.py:874-877): scales is [rows/br, cols/bc] row-major.
+ * pack: byte = e4m3fn(x / scale); scale_dt == dt: the quotient is rounded to dt first (same-dtype division);
+ * scale_dt == MOQ_F32 with a 16-bit x: fp32 quotient (torch promotes a dimensioned fp32 operand).
+ * unpack: out = dt(q) * scale, scales in dt. */
+int moq_fp8_pack_tile(const void* x, const void* scales, int scale_dt, uint8_t* out, int64_t rows, int64_t cols,
+                      int br, int bc, int dt, void* stream);
+int moq_fp8_unpack_tile(const uint8_t* q, const void* scales, void* out, int64_t rows, int64_t cols, int br, int bc,
+                        int dt, void* stream);
+/* out[o, i] = max_b |x[o, b, i]| for x viewed as [outer, mid, inner] (one step of reduce_block_amax,
+ * quantization/utils/core_utils.py:43-90, on a dim that is not the last one). */
+int moq_amax_mid(const void* x, int64_t outer, int64_t mid, int64_t inner, int dt, float* out, void* stream);
 /* a4 `calibrate_weights` (calib/histogram.py:346-433): counts[r, b] += number of |x[r, :]| in bin b of
  * np.histogram(|x[r]|, bins, range=(first[r], last[r])) -- numpy's float32 edges and closed last bin, bit for bit.
  * counts is int32 [rows, bins] and is accumulated into (zero it first). */

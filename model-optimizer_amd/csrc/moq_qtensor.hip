@@ -274,6 +274,80 @@ __global__ __launch_bounds__(kBlock) void mxfp4_unpack_kernel(const uint8_t* __r
   }
 }
 
+
+// ---------------------------------------------------------------- FP8 pack / unpack with one scale per br x bc tile
+// FP8QTensor.quantize with block_sizes on both axes (fp8_tensor.py:60-112; the FP8 2-D blockwise weight-only export,
+// export/quant_utils.py:874-877): the reference expands the [R/br, C/bc] scales with repeat_interleave and divides
+// elementwise.  Here a packet (V elements of one row, inside one tile because bc % V == 0) looks its tile's scale up.
+// PROMOTE: scales are fp32 while the tensor is 16-bit -> torch promotes the quotient to fp32 (dimensioned operand),
+// so it is NOT rounded to the tensor dtype before the e4m3 cast; with scales of the tensor dtype it is.
+template <int DT, bool PROMOTE>
+__global__ __launch_bounds__(kBlock) void fp8_pack_tile_kernel(const void* __restrict__ x,
+                                                               const void* __restrict__ scales,
+                                                               uint8_t* __restrict__ out, int64_t n_packets,
+                                                               int64_t cols, int br, int bc, int64_t tiles_per_row) {
+  constexpr int V = Elem<DT>::kVec;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = p * V;
+    const int64_t row = e / cols;
+    const int64_t col = e - row * cols;
+    const int64_t t = (row / br) * tiles_per_row + col / bc;
+    const float sc = PROMOTE ? reinterpret_cast<const float*>(scales)[t] : load1<DT>(scales, t);
+    const Pack16 in = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
+    float v[8];
+    unpack<DT>(in, v);
+    uint32_t b[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < V; i += 2) {
+      float qa = v[i] / sc, qb = v[i + 1] / sc;
+      if constexpr (!PROMOTE) {
+        qa = round_to_dtype<DT>(qa);
+        qb = round_to_dtype<DT>(qb);
+      }
+      b[i / 2] = e4m3fn_bytes2(qa, qb);
+    }
+    if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+    else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
+  }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kBlock) void fp8_unpack_tile_kernel(const uint8_t* __restrict__ q,
+                                                                 const void* __restrict__ scales,
+                                                                 void* __restrict__ out, int64_t n_packets,
+                                                                 int64_t cols, int br, int bc, int64_t tiles_per_row) {
+  constexpr int V = Elem<DT>::kVec;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = p * V;
+    const int64_t row = e / cols;
+    const int64_t col = e - row * cols;
+    const float sc = load1<DT>(scales, (row / br) * tiles_per_row + col / bc);
+    uint32_t in[2] = {0, 0};
+    if constexpr (V == 8) {
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(q + e));
+      in[0] = t.x;
+      in[1] = t.y;
+    } else {
+      in[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q + e));
+    }
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int word = (int)in[i / 4];
+      float f;
+      switch (i & 3) {
+        case 0: f = __builtin_amdgcn_cvt_f32_fp8(word, 0); break;
+        case 1: f = __builtin_amdgcn_cvt_f32_fp8(word, 1); break;
+        case 2: f = __builtin_amdgcn_cvt_f32_fp8(word, 2); break;
+        default: f = __builtin_amdgcn_cvt_f32_fp8(word, 3); break;
+      }
+      v[i] = f * sc;
+    }
+    store16_nt(reinterpret_cast<char*>(out) + e * (16 / V), pack<DT>(v));
+  }
+}
+
 }  // namespace moq
 
 using namespace moq;
@@ -404,4 +478,59 @@ extern "C" int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void
                                               dim3(kBlock), 0, S(stream), packed, e8m0, out, n, block, bs));
   }
   return check_launch("moq_mxfp4_unpack");
+}
+
+static int fp8_tile_args_ok(const char* who, const void* a, const void* b, const void* c, int64_t rows, int64_t cols,
+                            int br, int bc, int dt) {
+  if (rows < 0 || cols < 0 || br <= 0 || bc <= 0 || (rows * cols > 0 && (a == nullptr || b == nullptr || c == nullptr))) {
+    set_error("%s: bad arguments", who);
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if (rows % br != 0 || cols % bc != 0 || bc % vec != 0) {
+    set_error("%s: needs rows %% br == 0, cols %% bc == 0 and bc %% %d == 0 (pad on the host like "
+              "reduce_block_padding)", who, vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  return MOQ_OK;
+}
+
+extern "C" int moq_fp8_pack_tile(const void* x, const void* scales, int scale_dt, uint8_t* out, int64_t rows,
+                                 int64_t cols, int br, int bc, int dt, void* stream) {
+  if (scale_dt != MOQ_F32 && scale_dt != dt) {
+    set_error("moq_fp8_pack_tile: scale_dt must be MOQ_F32 or the tensor dtype");
+    return MOQ_ERR_INVALID;
+  }
+  const int rc = fp8_tile_args_ok("moq_fp8_pack_tile", x, scales, out, rows, cols, br, bc, dt);
+  if (rc != MOQ_OK || rows * cols == 0) return rc;
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) != 0) {
+    set_error("moq_fp8_pack_tile: needs 16-byte aligned x and 8-byte aligned out");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int64_t n_packets = rows * cols / vec;
+  const int grid = stream_grid(kBlock, n_packets);
+  if (scale_dt == MOQ_F32 && dt != MOQ_F32) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+                                              scales, out, n_packets, cols, br, bc, cols / bc));
+  } else {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+                                              scales, out, n_packets, cols, br, bc, cols / bc));
+  }
+  return check_launch("moq_fp8_pack_tile");
+}
+
+extern "C" int moq_fp8_unpack_tile(const uint8_t* q, const void* scales, void* out, int64_t rows, int64_t cols, int br,
+                                   int bc, int dt, void* stream) {
+  const int rc = fp8_tile_args_ok("moq_fp8_unpack_tile", q, scales, out, rows, cols, br, bc, dt);
+  if (rc != MOQ_OK || rows * cols == 0) return rc;
+  if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(q) & 7u) != 0) {
+    set_error("moq_fp8_unpack_tile: needs 16-byte aligned out and 8-byte aligned q");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int64_t n_packets = rows * cols / vec;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_tile_kernel<DT>), dim3(stream_grid(kBlock, n_packets)), dim3(kBlock), 0,
+                                            S(stream), q, scales, out, n_packets, cols, br, bc, cols / bc));
+  return check_launch("moq_fp8_unpack_tile");
 }

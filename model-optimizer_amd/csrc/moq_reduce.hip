@@ -214,6 +214,25 @@ __global__ void col_sum_generic_kernel(const void* __restrict__ x, int64_t rows,
   sum_out[c] = accumulate ? sum_out[c] + s : s;
 }
 
+// out[o, i] = max_b |x[o, b, i]|: lanes run along `inner` (coalesced), each walks the `mid` entries of its column.
+// One step of reduce_block_amax (core_utils.py:43-90) for a blocked dim that is not the last: the first such step
+// reads the tensor once, the later ones work on data already reduced by a block size.
+template <int DT>
+__global__ __launch_bounds__(kBlock) void amax_mid_kernel(const void* __restrict__ x, int64_t outer, int64_t mid,
+                                                          int64_t inner, float* __restrict__ out) {
+  const int64_t n_out = outer * inner;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < n_out; t += (int64_t)gridDim.x * kBlock) {
+    const int64_t o = t / inner, i = t - o * inner;
+    const int64_t base = o * mid * inner + i;
+    uint32_t acc = 0;
+    for (int64_t b = 0; b < mid; ++b) {
+      const uint32_t v = absbits(load1<DT>(x, base + b * inner));
+      acc = v > acc ? v : acc;
+    }
+    out[t] = __uint_as_float(acc);
+  }
+}
+
 int launch_group(const void* x, void* y, float* amax_out, int64_t n_groups, int g, int dt, int num_bits,
                  int is_unsigned, int narrow, bool qdq, const void* s, int64_t cols, void* stream,
                  const char* who);
@@ -361,4 +380,16 @@ extern "C" int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, i
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((awq_wscale_finalize_kernel<DT>), dim3((unsigned)((cols + 255) / 256)),
                                             dim3(256), 0, S(stream), partial, n_blk, rows, cols, out));
   return check_launch("moq_awq_weight_scale");
+}
+
+extern "C" int moq_amax_mid(const void* x, int64_t outer, int64_t mid, int64_t inner, int dt, float* out,
+                            void* stream) {
+  if (outer < 0 || mid <= 0 || inner < 0 || (outer * inner > 0 && (x == nullptr || out == nullptr))) {
+    set_error("moq_amax_mid: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (outer * inner == 0) return MOQ_OK;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_mid_kernel<DT>), dim3(stream_grid(kBlock, outer * inner)), dim3(kBlock), 0,
+                                            S(stream), x, outer, mid, inner, out));
+  return check_launch("moq_amax_mid");
 }

@@ -30,6 +30,7 @@ QUANTIZATION_INT8_SQ = "int8_sq"
 QUANTIZATION_INT8_WO = "int8_wo"
 QUANTIZATION_INT4_AWQ = "int4_awq"
 QUANTIZATION_MXFP4 = "mxfp4"
+QUANTIZATION_FP8_PB_WO = "fp8_pb_wo"
 
 
 def get_quantization_format(module) -> str | None:
@@ -46,6 +47,9 @@ def get_quantization_format(module) -> str | None:
         return QUANTIZATION_INT8_SQ if iq.is_enabled else QUANTIZATION_INT8_WO
     if isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is None:
         return QUANTIZATION_FP8
+    if (isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is not None
+            and wq.block_sizes.get("type", "static") != "dynamic"):
+        return QUANTIZATION_FP8_PB_WO  # export/quant_utils.py:531-544 (fake-quant static blocks)
     if (isinstance(nb, (tuple, list)) and tuple(nb) == (2, 1) and wq.block_sizes is not None
             and tuple(wq.block_sizes.get("scale_bits", ())) == (8, 0)):
         return QUANTIZATION_MXFP4  # export/quant_utils.py:585-586
@@ -315,6 +319,16 @@ def export_quantized_weight(module, dtype: torch.dtype):
         w = module.weight.detach().to(dtype)
         packed, e8m0 = ops.mxfp4_quantize(w, block)
         return {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
+    if fmt == QUANTIZATION_FP8_PB_WO:
+        # export/quant_utils.py:874-877: FP8QTensor.quantize(weight, scale.squeeze(), block_sizes on both axes); the
+        # scale keeps the quantizer's amax shape [R/br, 1, C/bc, 1]
+        from .qtensor import FP8QTensor
+
+        blocks = {d: b for d, b in wq.block_sizes.items() if isinstance(d, int)}
+        weight_scale = get_weight_scaling_factor(module)
+        w = module.weight.detach().to(dtype)
+        qt, _ = FP8QTensor.quantize(w, weight_scale.squeeze(), block_sizes=blocks)
+        return {"weight": qt._quantized_data, "weight_scale": weight_scale}
     if fmt == QUANTIZATION_FP8:
         amax = wq._amax.to(torch.float32)
         # per-tensor: python float division of amax.item() (unified_export_hf.py:643-647)
@@ -405,7 +419,7 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
 def hf_quant_config(model, group_size: int | None = None) -> dict:
     """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
     fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
-    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
+    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
             QUANTIZATION_INT8_WO: "W8A16"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
     q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}

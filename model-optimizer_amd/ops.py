@@ -12,6 +12,7 @@ import ctypes
 from contextlib import contextmanager
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import MoquantError, MoquantUnsupported, check
@@ -137,6 +138,62 @@ def reduce_amax(input: torch.Tensor, axis=None, keepdims=True, squeeze_scalar=Tr
         if squeeze_scalar and res.numel() == 1:
             res = res.reshape(())
         return res
+
+
+def reduce_block_padding(input: torch.Tensor, block_sizes: dict, pad_value: float = 0) -> torch.Tensor:
+    """core_utils.py:93-125: right-pad every blocked dim to a multiple of its block size."""
+    nd = input.dim()
+    pad = [0] * (2 * nd)
+    for dim, block in block_sizes.items():
+        if not isinstance(dim, int):
+            continue
+        d = dim if dim >= 0 else nd + dim
+        rem = input.size(d) % block
+        if rem:
+            pad[(nd - 1 - d) * 2 + 1] = block - rem
+    return F.pad(input, pad, value=pad_value) if any(pad) else input
+
+
+@torch.no_grad()
+def reduce_block_amax(input_tensor: torch.Tensor, block_sizes: dict) -> torch.Tensor:
+    """core_utils.py:43-90: abs-max over blocks along every dim named in block_sizes; the result has the input's
+    rank with each blocked dim divided by its block size, in the input dtype.
+
+    A 2-D tensor blocked on both axes is ONE kernel with the tile in registers (moq_block2d); otherwise one reduction
+    per blocked dim, like the reference, but without its clone: rows of a (-1, g) view for the last dim, lanes along
+    the trailing dims for any other (moq_amax_mid).  Max is exact, so the order of the steps does not matter."""
+    _require_gpu(input_tensor, "reduce_block_amax")
+    x = input_tensor.detach().contiguous()
+    nd = x.dim()
+    dims = {(d if d >= 0 else nd + d): b for d, b in block_sizes.items() if isinstance(d, int)}
+    for d, b in dims.items():
+        assert x.shape[d] % b == 0, f"Tensor dimension {d}, {x.shape[d]} is not divisible by {b}"
+    vec = 4 if x.dtype == torch.float32 else 8
+    if nd == 2 and set(dims) == {0, 1} and dims[1] % vec == 0 and dims[0] * dims[1] <= 16 * 256 * vec \
+            and x.data_ptr() % 16 == 0:
+        x4 = x.view(x.shape[0] // dims[0], dims[0], x.shape[1] // dims[1], dims[1])
+        return block2d(x4, 0).to(x.dtype).reshape(x.shape[0] // dims[0], x.shape[1] // dims[1])
+    cur = x
+    for d in sorted(dims, reverse=True):  # last dim first: the big pass uses the row kernel
+        b = dims[d]
+        shape = list(cur.shape)
+        outer = 1
+        for k in range(d):
+            outer *= shape[k]
+        inner = 1
+        for k in range(d + 1, nd):
+            inner *= shape[k]
+        nblk = shape[d] // b
+        if inner == 1:
+            red = reduce_amax(cur.reshape(-1, b), axis=[1], keepdims=False).reshape(-1)
+        else:
+            buf = torch.empty(outer * nblk * inner, dtype=torch.float32, device=cur.device)
+            with _on(cur) as stream:
+                check(_lib.lib().moq_amax_mid(_p(cur), outer * nblk, b, inner, _dt(cur), _p(buf), stream))
+            red = buf.to(cur.dtype)
+        shape[d] = nblk
+        cur = red.reshape(shape)
+    return cur
 
 
 # ----------------------------------------------------------------------------------------------- QDQ
@@ -723,6 +780,37 @@ def fp8_dequantize(quantized: torch.Tensor, scales: torch.Tensor, dtype: torch.d
     out = torch.empty(q.shape, dtype=dtype, device=q.device)
     with _on(q) as stream:
         check(_lib.lib().moq_fp8_unpack(_p(q), _p(s), _p(out), q.numel(), _dt(out), mode, axis_size, inner, stream))
+    return out
+
+
+@torch.no_grad()
+def fp8_quantize_tile(inputs: torch.Tensor, scales: torch.Tensor, br: int, bc: int) -> torch.Tensor:
+    """(inputs / scales expanded over br x bc tiles).to(float8_e4m3fn) for a 2-D tensor -- FP8QTensor.quantize with
+    blocks on both axes (fp8_tensor.py:60-112).  scales: [R/br, C/bc] in the tensor dtype (quotient rounded to it) or
+    fp32 (fp32 quotient, as torch promotes)."""
+    _require_gpu(inputs, "fp8_quantize_tile")
+    x = inputs.detach().contiguous()
+    sdt = torch.float32 if scales.dtype == torch.float32 else x.dtype
+    s = scales.detach().to(device=x.device, dtype=sdt).contiguous().reshape(-1)
+    rows, cols = x.shape
+    if s.numel() != (rows // br) * (cols // bc):
+        raise MoquantError(f"fp8_quantize_tile: {s.numel()} scales for a {rows}x{cols} tensor in {br}x{bc} tiles")
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with _on(x) as stream:
+        check(_lib.lib().moq_fp8_pack_tile(_p(x), _p(s), _DT[sdt], _p(out), rows, cols, int(br), int(bc), _dt(x), stream))
+    return out.view(torch.float8_e4m3fn)
+
+
+@torch.no_grad()
+def fp8_dequantize_tile(quantized: torch.Tensor, scales: torch.Tensor, dtype: torch.dtype, br: int, bc: int):
+    """quantized.to(dtype) * scales expanded over br x bc tiles (fp8_tensor.py:114-151)."""
+    _require_gpu(quantized, "fp8_dequantize_tile")
+    q = quantized.detach().contiguous().view(torch.uint8)
+    s = scales.detach().to(device=q.device, dtype=dtype).contiguous().reshape(-1)
+    rows, cols = q.shape
+    out = torch.empty(q.shape, dtype=dtype, device=q.device)
+    with _on(q) as stream:
+        check(_lib.lib().moq_fp8_unpack_tile(_p(q), _p(s), _p(out), rows, cols, int(br), int(bc), _dt(out), stream))
     return out
 
 

@@ -61,12 +61,25 @@ class FP8QTensor(BaseQuantizedTensor):
     @classmethod
     def quantize(cls, input: torch.Tensor, scales: torch.Tensor = None, axis=None, block_sizes: dict | None = None):
         """fp8_tensor.py:40-112.  Supported layouts: per-tensor, one kept axis whose scales run along the flattened
-        leading dims (per-channel rows), and 1-D blocks along the last dim; N-D block grids raise."""
+        leading dims (per-channel rows), 1-D blocks along the last dim, and blocks on both axes of a 2-D tensor
+        (the FP8 2-D blockwise weight format); other N-D block grids raise."""
         x = input
         if block_sizes:
             dims = {(d if d >= 0 else input.dim() + d): b for d, b in block_sizes.items() if isinstance(d, int)}
+            if input.dim() == 2 and set(dims) == {0, 1}:
+                # blocks on both axes (fp8_tensor.py:62-100): pad, tile amax, one scale per br x bc tile
+                x = ops.reduce_block_padding(input, dims).contiguous()
+                br, bc = dims[0], dims[1]
+                if scales is None:
+                    scales = _div448(ops.reduce_block_amax(x, dims))
+                else:
+                    scales = scales.reshape(x.shape[0] // br, x.shape[1] // bc)
+                q = ops.fp8_quantize_tile(x, scales, br, bc)
+                if q.shape != input.shape:
+                    q = q[tuple(slice(0, d) for d in input.shape)]
+                return cls(input.shape, input.dtype, q), scales
             if list(dims) != [input.dim() - 1]:
-                raise MoquantUnsupported("FP8QTensor: only last-dim blocks are on this path "
+                raise MoquantUnsupported("FP8QTensor: blocks along the last dim, or on both axes of a 2-D tensor "
                                          "(reference N-D blocks: fp8_tensor.py:77-100)")
             block = dims[input.dim() - 1]
             x = _pad_last(input, block).contiguous()
@@ -93,6 +106,11 @@ class FP8QTensor(BaseQuantizedTensor):
         assert "scale" in kwarg, "Require scale for FP8 dequantization."
         scales, block_sizes = kwarg["scale"], kwarg.get("block_sizes")
         q = self._quantized_data
+        dims = {(d if d >= 0 else q.dim() + d): b for d, b in (block_sizes or {}).items() if isinstance(d, int)}
+        if q.dim() == 2 and set(dims) == {0, 1}:
+            qp = ops.reduce_block_padding(q.view(torch.uint8), dims).contiguous()
+            out = ops.fp8_dequantize_tile(qp, scales, dtype, dims[0], dims[1])
+            return out[tuple(slice(0, d) for d in self.metadata["shape"])]
         if block_sizes:
             block = block_sizes.get(-1) or block_sizes.get(q.dim() - 1)
             q = _pad_last(q.view(torch.uint8), block).contiguous()

@@ -302,6 +302,34 @@ def fp8_unpack(q, scales, dtype, axis_size=1, inner=1):
     return _from_np(out, dtype, q.shape)
 
 
+def fp8_pack_tile(x, scales, br, bc):
+    """FP8QTensor.quantize with blocks on both axes (fp8_tensor.py:60-112) as a composition of the pinned per-tensor
+    restatement: every br x bc tile is packed with its own scalar scale.  A 0-dim fp32 scale with a 16-bit tensor
+    would NOT promote in torch, a dimensioned one does -- so for fp32 scales the tile is upcast first."""
+    rows, cols = x.shape
+    out = torch.empty(rows, cols, dtype=torch.uint8)
+    promote = scales.dtype == torch.float32 and x.dtype != torch.float32
+    s2 = scales.reshape(rows // br, cols // bc)
+    for i in range(rows // br):
+        for j in range(cols // bc):
+            tile = x[i * br:(i + 1) * br, j * bc:(j + 1) * bc].contiguous()
+            if promote:
+                tile = tile.float()
+            out[i * br:(i + 1) * br, j * bc:(j + 1) * bc] = fp8_pack(tile, s2[i, j].reshape(1).to(tile.dtype))
+    return out
+
+
+def fp8_unpack_tile(q, scales, dtype, br, bc):
+    rows, cols = q.shape
+    out = torch.empty(rows, cols, dtype=dtype)
+    s2 = scales.reshape(rows // br, cols // bc)
+    for i in range(rows // br):
+        for j in range(cols // bc):
+            out[i * br:(i + 1) * br, j * bc:(j + 1) * bc] = fp8_unpack(
+                q[i * br:(i + 1) * br, j * bc:(j + 1) * bc].contiguous(), s2[i, j].reshape(1), dtype)
+    return out
+
+
 def mxfp4_pack(x, block=32):
     """MXFP4QTensor.quantize (mxfp4_tensor.py:37-81): (packed uint8 [..., K/2], e8m0 uint8 [n/block, 1])."""
     a = _np(x)

@@ -26,6 +26,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
   moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
   calibrate_weights.npz -- calib.calibrate_weights per-channel / per-tensor percentile amax + numpy's channel histograms
+  export_llama_fp8_2d.npz -- FP8 2-D blockwise weight-only export of a tiny Llama + FP8QTensor with blocks on both axes
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -920,14 +921,67 @@ def gen_calibrate_weights(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
+def gen_export_fp8_2d(out):
+    """FP8 2-D blockwise weight-only (FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG, 128 x 128 tiles) export of a tiny bf16 Llama
+    whose intermediate size (640) and head layout exercise several tile grids: per-tile amax of every linear, the
+    exported e4m3 bytes and [R/128, 1, C/128, 1] scales; plus FP8QTensor.quantize / dequantize with blocks on both
+    axes incl. padding (fp8_tensor.py:60-151)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from modelopt.torch.quantization.qtensor import FP8QTensor
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    model = LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)).to(torch.bfloat16)
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    q = mtq.quantize(model, mtq.FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG, None)
+    for n, m in q.named_modules():
+        if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
+            out[f"pre/{n}.w_amax"] = bits(m.weight_quantizer._amax.float())
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = t.view(torch.uint8).numpy().copy() if t.dtype == torch.float8_e4m3fn else bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    # the QTensor class on its own: computed scales (tensor dtype) and given fp32 scales, with padding on both axes
+    qt_cases = {}
+    gen = torch.Generator().manual_seed(5)
+    for idx, (shape, blocks, dn, given) in enumerate([((256, 384), {-1: 128, -2: 128}, "bf16", False),
+                                                      ((200, 300), {-1: 128, -2: 64}, "f16", False),
+                                                      ((64, 96), {-1: 32, -2: 16}, "f32", False),
+                                                      ((256, 256), {-1: 128, -2: 128}, "bf16", True)]):
+        x = (torch.randn(*shape, generator=gen) * torch.exp(torch.randn(shape[0], 1, generator=gen))).to(DT[dn])
+        scales = None
+        if given:
+            scales = (torch.rand(2, 2, generator=gen) * 0.01 + 1e-3).float()
+        qt, sc = FP8QTensor.quantize(x, scales, block_sizes=blocks)
+        deq = qt.dequantize(DT[dn], scale=sc, block_sizes=blocks)
+        k = f"qt{idx}"
+        qt_cases[k] = dict(shape=shape, blocks={str(a): b for a, b in blocks.items()}, dtype=dn, given=given,
+                           scale_dtype=str(sc.dtype))
+        out[f"{k}_x"], out[f"{k}_q"] = bits(x), qt._quantized_data.view(torch.uint8).numpy().copy()
+        out[f"{k}_scales"], out[f"{k}_deq"] = bits(sc), bits(deq)
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg, qt=qt_cases)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

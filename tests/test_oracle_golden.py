@@ -327,3 +327,24 @@ def test_row_histograms_match_numpy_run_by_the_reference(golden):
         want = torch.from_numpy(g.raw(f"{k}_hist").copy())
         assert torch.equal(got, want), f"{k} ({c['kind']}): {(got != want).sum().item()} bins differ"
         assert int(got.sum()) == w.numel()
+
+
+def test_fp8_tile_pack_matches_reference(golden):
+    """FP8QTensor.quantize / dequantize with blocks on both axes (fp8_tensor.py:60-151) run by the reference: the
+    oracle's tile composition of the pinned per-tensor pack gives the same bytes and dequantised values."""
+    import torch.nn.functional as F
+
+    g = golden("export_llama_fp8_2d")
+    for k, c in g.cases["qt"].items():
+        dt = DT[c["dtype"]]
+        x = g.t(f"{k}_x", dt)
+        br, bc = c["blocks"]["-2"], c["blocks"]["-1"]
+        sdt = torch.float32 if c["scale_dtype"] == "torch.float32" else dt
+        scales = g.t(f"{k}_scales", sdt)
+        xp = F.pad(x, (0, (-x.shape[1]) % bc, 0, (-x.shape[0]) % br))
+        got = oracle.fp8_pack_tile(xp, scales, br, bc)[: x.shape[0], : x.shape[1]]
+        want = torch.from_numpy(g.raw(f"{k}_q").copy())
+        assert torch.equal(got, want), f"{k}: {(got != want).sum().item()} bytes differ"
+        qp = F.pad(want, (0, (-x.shape[1]) % bc, 0, (-x.shape[0]) % br))
+        deq = oracle.fp8_unpack_tile(qp, scales.to(dt), dt, br, bc)[: x.shape[0], : x.shape[1]]
+        assert_bits_equal(deq, g.t(f"{k}_deq", dt), f"{k} dequant")
