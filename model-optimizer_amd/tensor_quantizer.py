@@ -412,3 +412,29 @@ class SequentialQuantizer(nn.Sequential):
                     setattr(parent, attr, module)
 
         return ctx()
+
+
+class GroupedQuantizer(nn.ModuleList):
+    """Per-group quantizers for one module that holds several independently quantized weights
+    (nn/modules/tensor_quantizer.py:1865-1893: the fused experts of a grouped linear).  Unlike SequentialQuantizer the
+    members act on DIFFERENT tensors: index in with `grouped[i](weight_i)`; `forward` applies the first member (the
+    single-weight compatibility path), property reads come from the first member, life-cycle methods are broadcast
+    and return the list of the members' results."""
+
+    def __init__(self, *quantizers):
+        super().__init__(quantizers)
+        assert all(isinstance(q, (TensorQuantizer, SequentialQuantizer)) for q in self), \
+            "All quantizers must be a TensorQuantizer or SequentialQuantizer."
+
+    def forward(self, inputs):
+        return self[0](inputs)
+
+    def __getattr__(self, name):
+        if name in SequentialQuantizer._BROADCAST:
+            return lambda *args, **kwargs: [getattr(q, name)(*args, **kwargs) for q in self]
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            if len(self) and not name.startswith("__"):
+                return getattr(self[0], name)
+            raise

@@ -271,3 +271,25 @@ def test_fused_experts_registration_and_name_matching():
                                                 "model.layers.0.self_attn.q_proj.weight": 3}, model)
     assert set(ren) == {"model.layers.0.block_sparse_moe.experts.2.w3.weight", "model.layers.0.block_sparse_moe.gate.weight",
                         "model.layers.0.self_attn.q_proj.weight"}
+
+
+def test_grouped_quantizer_container():
+    """GroupedQuantizer (tensor_quantizer.py:1865-1893): members act on different tensors, broadcasts return lists,
+    property reads come from the first member; set_quantizer_by_cfg reaches the members through the index."""
+    from model_optimizer_amd.tensor_quantizer import GroupedQuantizer, SequentialQuantizer
+    qs = [TensorQuantizer(QuantizerAttributeConfig(num_bits=8, axis=None)) for _ in range(3)]
+    g = GroupedQuantizer(*qs)
+    assert len(g) == 3 and g[1] is qs[1] and g.is_enabled and g.amax is None
+    assert g.disable() == [None, None, None] and not any(q.is_enabled for q in qs)
+    g.enable()
+    qs[0].amax = torch.tensor(2.0)
+    assert g.amax.item() == 2.0 and qs[1].amax is None
+    g.reset_amax()
+    assert g.amax is None
+    with pytest.raises(AssertionError):
+        GroupedQuantizer(torch.nn.Identity())
+    m = torch.nn.Module()
+    m.weight_quantizer = g
+    model_quant.set_quantizer_by_cfg(m, {"*weight_quantizer": {"num_bits": (4, 3), "axis": None}})
+    assert all(tuple(q._num_bits) == (4, 3) for q in g) and isinstance(m.weight_quantizer, GroupedQuantizer)
+    assert isinstance(GroupedQuantizer(SequentialQuantizer(TensorQuantizer(), TensorQuantizer()))[0], SequentialQuantizer)
