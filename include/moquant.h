@@ -130,6 +130,9 @@ int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_
  * as one dense window (read-only stream at ~7 TB/s instead of ~6.3), then one fold per tensor. */
 int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
                    float* chunk_scratch, void* stream);
+/* cuda_ext_mx.convert_to_exmy (tensor_quant_mx.cu:398 -> convert_to_types, tensor_quant_mx.h:163-186): y[i] = the value
+ * of element format `fmt` nearest to x[i] (format's own tie rule, saturating), no scaling.  fp32 in / out. */
+int moq_mx_convert(const float* x, float* y, int64_t n, int fmt, void* stream);
 /* FP8QTensor.quantize / dequantize with block_sizes on BOTH axes of a 2-D tensor (qtensor/fp8_tensor.py:60-112, :114-151;
  * the FP8 2-D blockwise weight-only export, export/quant_utils.py:874-877): scales is [rows/br, cols/bc] row-major.
  * pack: byte = e4m3fn(x / scale); scale_dt == dt: the quotient is rounded to dt first (same-dtype division);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "moq_fp8_pack_tile": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "moq_fp8_unpack_tile": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "moq_amax_mid": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "moq_mx_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "moq_row_hist_np": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "moq_mt_amax_ws": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "moq_mt_fake_quant_e4m3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),

@@ -654,6 +654,19 @@ __global__ __launch_bounds__(kBlock) void scale_cols_multi_kernel(const void* __
   }
 }
 
+
+// convert_to_exmy (tensor_quant_mx.cu:398, tensor_quant_mx.h:163-186): one fp32 value -> the nearest value of the
+// element format, no scale.  The pybind surface exposes it for scalars; here it is elementwise over an array.
+__global__ __launch_bounds__(kBlock) void mx_convert_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                            int fmt) {
+  const MxFmt f = mx_fmt(fmt);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float v = x[i];
+    const float r = mx_round_abs(__builtin_fabsf(v), f);
+    y[i] = (__float_as_uint(v) >> 31) ? -r : r;
+  }
+}
+
 }  // namespace moq
 
 // ================================================================================================
@@ -942,4 +955,18 @@ extern "C" int moq_rescale_cols(const void* w, const float* mul, const float* di
                                               S(stream), w, mul, div, y, rows, cols));
   }
   return check_launch("moq_rescale_cols");
+}
+
+extern "C" int moq_mx_convert(const float* x, float* y, int64_t n, int fmt, void* stream) {
+  if (n < 0 || (n > 0 && (x == nullptr || y == nullptr))) {
+    set_error("moq_mx_convert: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (mx_fmt(fmt).kind < 0) {
+    set_error("moq_mx_convert: unknown element format %d", fmt);
+    return MOQ_ERR_INVALID;
+  }
+  if (n == 0) return MOQ_OK;
+  hipLaunchKernelGGL(mx_convert_kernel, dim3(stream_grid(kBlock, n)), dim3(kBlock), 0, S(stream), x, y, n, fmt);
+  return check_launch("moq_mx_convert");
 }

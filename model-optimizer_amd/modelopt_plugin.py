@@ -76,6 +76,10 @@ class MxExtension:
     def fused_amax_convert(inputs, block_size, format, scale_format, global_amax=None):
         return ops.fused_amax_convert(inputs, block_size, int(format), int(scale_format), global_amax)
 
+    @staticmethod
+    def convert_to_exmy(x, format):
+        return ops.convert_to_exmy(x, int(format))
+
 
 def mi355x_backend(inputs: torch.Tensor, tq) -> torch.Tensor:
     """S3 entrypoint(inputs, tensor_quantizer): fused dynamic-amax QDQ for static-block INT quantizers,

@@ -334,6 +334,20 @@ def fused_amax_convert(inputs: torch.Tensor, block_size: int, fmt: str | int, sc
 
 
 @torch.no_grad()
+def convert_to_exmy(x, fmt: str | int):
+    """cuda_ext_mx.convert_to_exmy(x, format): round to the element format's grid, no scale.  A Python float gives a
+    Python float (the pybind surface); a GPU tensor is converted elementwise (fp32 in / out)."""
+    f = _lib.MX_TYPES[fmt] if isinstance(fmt, str) else int(fmt)
+    scalar = not isinstance(x, torch.Tensor)
+    t = torch.tensor([float(x)], dtype=torch.float32, device="cuda") if scalar else x.detach().float().contiguous()
+    _require_gpu(t, "convert_to_exmy")
+    y = torch.empty_like(t)
+    with _on(t) as stream:
+        check(_lib.lib().moq_mx_convert(_p(t), _p(y), t.numel(), f, stream))
+    return float(y.item()) if scalar else y
+
+
+@torch.no_grad()
 def dynamic_block_quant(inputs, block_size, amax, num_bits, scale_bits):
     """tensor_quant.dynamic_block_quant front door (tensor_quant.py:157-195): num_bits / scale_bits are
     (E, M) tuples or 8."""

@@ -131,6 +131,13 @@ def mx_fused_amax_convert(x, block, fmt="E2M1"):
     return _from_np(y, x.dtype, x.shape)
 
 
+def mx_convert(x, fmt):
+    a = np.ascontiguousarray(x.detach().cpu().float().numpy())
+    y = np.empty_like(a)
+    lib().orc_mx_convert(_p(a), _p(y), I64(a.size), MX_TYPES[fmt] if isinstance(fmt, str) else int(fmt))
+    return torch.from_numpy(y)
+
+
 def hist_abs(x, bins, max_edge, skip_zeros=False, counts=None):
     a = _np(x)
     c = np.zeros(bins, dtype=np.uint64) if counts is None else counts

@@ -596,3 +596,20 @@ def test_multi_tensor_mask_equals_per_tensor():
     moa.multi_tensor.SegmentTable(ws, outputs=masks).mask_2to4()
     for w, m in zip(ws, masks):
         assert torch.equal(m.cpu(), oracle.mask_2to4(w.cpu()))
+
+
+@pytest.mark.parametrize("fmt", ["E2M1", "E1M2", "E0M3", "E3M0", "E3M2", "E2M3", "E4M3", "E5M2", "INT8"])
+def test_convert_to_exmy_vs_oracle(fmt):
+    """cuda_ext_mx.convert_to_exmy: a dense sweep (every tie of the small formats included), negatives, zeros,
+    infinities, NaN, values beyond the format maximum."""
+    grid = torch.arange(-40000, 40001, dtype=torch.float32) / 64.0            # multiples of 1/64: all ties of the tables
+    gen = torch.Generator().manual_seed(4)
+    rnd = torch.randn(20000, generator=gen) * torch.exp(torch.randn(20000, generator=gen) * 4)
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e30, -1e30, 1e-30, 448.0, 464.0, 465.0,
+                            57344.0, 61440.0, 127.5, -127.5, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -16])
+    x = torch.cat([grid, rnd, special])
+    got = ops.convert_to_exmy(x.to(DEV), fmt).cpu()
+    want = oracle.mx_convert(x, fmt)
+    assert_bits_equal(got, want, f"convert_to_exmy {fmt}")
+    assert ops.convert_to_exmy(2.4, "E2M1") == 2.0 and ops.convert_to_exmy(-2.5, "E2M1") == -2.0  # tie -> even code
+    assert isinstance(ops.convert_to_exmy(0.3, fmt), float)
