@@ -663,7 +663,10 @@ __global__ __launch_bounds__(kBlock) void mx_convert_kernel(const float* __restr
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
     const float v = x[i];
     const float r = mx_round_abs(__builtin_fabsf(v), f);
-    y[i] = (__float_as_uint(v) >> 31) ? -r : r;
+    // table formats take the sign from `x < 0` (h:104-160: -0 and NaN count as positive), the fp8 / int8
+    // conversions keep the sign bit
+    const bool neg = f.kind == 0 ? v < 0.0f : (__float_as_uint(v) >> 31) != 0;
+    y[i] = neg ? -r : r;
   }
 }
 
