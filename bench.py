@@ -87,11 +87,12 @@ def pmc_traffic(workload, model, n_layers):
 
 
 def cpu_baseline(workload, budget_s=12.0):
-    """Time the CPU oracle (a C restatement of the reference's eager path, OpenMP on all host cores) on a
-    bounded sample: repeated 4096x4096 bf16 weights until ~budget_s of CPU work."""
+    """Time the CPU oracle (a C restatement of the reference's eager path, OpenMP on every host CPU this process
+    may use) on a bounded sample: repeated 4096x4096 bf16 weights until ~budget_s of CPU work."""
     from oracle import oracle
 
-    threads = os.cpu_count() or 1
+    threads = oracle.usable_cpus()  # visible CPUs capped by affinity and the cgroup quota (16 of 256 on the GPU boxes)
+    oracle.set_threads(threads)
     w = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(1234)) * 0.02).to(torch.bfloat16)
     n_bytes = w.numel() * 2
 
