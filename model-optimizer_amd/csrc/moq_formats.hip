@@ -147,11 +147,41 @@ __global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict
                       (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f);
   }
 }
-// generic path: one thread per MX block, handles ragged last blocks (virtual zero padding) and any alignment
+// compute_scale / compute_scale_with_global (tensor_quant_mx.cu:139-183) for block-scale formats other than E8M0
+// (NVFP4-style: E2M1 elements, E4M3 block scales, optional tensor-wide amax).  The reference mixes float and double
+// steps; they are kept one by one: float divisions, the product and the reciprocal in double, results narrowed to
+// float when the tuple<float, float> is formed.
+__device__ __forceinline__ bool mx_bad_amax(float v) { return v == 0.0f || v != v || __float_as_uint(v) == 0x7F800000u; }
+__device__ __forceinline__ void mx_scale_general(float amax, float emax, const MxFmt sf, const float* global,
+                                                 float& scale, float& unscale) {
+  scale = 1.0f;
+  unscale = 1.0f;
+  if (global != nullptr) {
+    const float g = *global;
+    if (mx_bad_amax(amax) || mx_bad_amax(g)) return;
+    const float local_unscale = amax / emax;
+    const double two_level = (double)sf.maxv * (double)(emax / g);
+    const float arg = (float)((double)local_unscale * two_level);
+    const double q = (double)mx_round_abs(arg, sf) / two_level;
+    scale = (float)(1.0 / q);
+    unscale = (float)q;
+  } else {
+    if (mx_bad_amax(amax)) return;
+    const double s = (double)(emax / amax);
+    const double inv = (double)mx_round_abs((float)(1.0 / s), sf);
+    scale = (float)(1.0 / inv);
+    unscale = (float)inv;
+  }
+}
+
+// generic path: one thread per MX block, handles ragged last blocks (virtual zero padding), any alignment and
+// every block-scale format (scale_fmt == MOQ_E8M0: the exponent/mantissa test; else the general path above)
 template <int DT>
 __global__ void mx_generic_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t rows,
-                                  int64_t cols, int block, int fmt) {
+                                  int64_t cols, int block, int fmt, int scale_fmt,
+                                  const float* __restrict__ global_amax) {
   const MxFmt f = mx_fmt(fmt);
+  const MxFmt sf = mx_fmt(scale_fmt);
   const int64_t bpr = (cols + block - 1) / block;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < rows * bpr;
        b += (int64_t)gridDim.x * blockDim.x) {
@@ -160,7 +190,8 @@ __global__ void mx_generic_kernel(const void* __restrict__ x, void* __restrict__
     float am = 0.0f;
     for (int64_t c = c0; c < c1; ++c) am = __builtin_fmaxf(am, mx_abs_clamped(load1<DT>(x, r * cols + c)));
     float sc, un;
-    mx_scale_e8m0(am, f.maxv, sc, un);
+    if (scale_fmt == MOQ_E8M0) mx_scale_e8m0(am, f.maxv, sc, un);
+    else mx_scale_general(am, f.maxv, sf, global_amax, sc, un);
     for (int64_t c = c0; c < c1; ++c)
       store1<DT>(y, r * cols + c, mx_qdq(load1<DT>(x, r * cols + c), sc, un, f));
   }
@@ -685,8 +716,9 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
     set_error("moq_mx_fused_amax_convert: bad arguments");
     return MOQ_ERR_INVALID;
   }
-  if (scale_fmt != MOQ_E8M0 || global_amax != nullptr) {
-    set_error("moq_mx_fused_amax_convert: only E8M0 block scales without a global amax are implemented");
+  if (scale_fmt == MOQ_E8M0 ? global_amax != nullptr : mx_fmt(scale_fmt).kind < 0) {
+    set_error("moq_mx_fused_amax_convert: block scales are E8M0 (no global amax) or an element format "
+              "(E4M3, ...; optional global amax)");
     return MOQ_ERR_UNSUPPORTED;
   }
   if (mx_fmt(fmt).kind < 0) {
@@ -698,7 +730,7 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
   const int vec = dt == MOQ_F32 ? 4 : 8;
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;
   const int lpg = block / vec;
-  if (aligned && cols % block == 0 && block % vec == 0 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
+  if (scale_fmt == MOQ_E8M0 && aligned && cols % block == 0 && block % vec == 0 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
 #define MOQ_MX_LAUNCH(L, F) \
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, n, fmt))
@@ -718,7 +750,7 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
     const int64_t nb = rows * ((cols + block - 1) / block);
     const int grid = stream_grid(kBlock, nb);
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_generic_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
-                                              x, y, rows, cols, block, fmt));
+                                              x, y, rows, cols, block, fmt, scale_fmt, global_amax));
   }
   return check_launch("moq_mx_fused_amax_convert");
 }

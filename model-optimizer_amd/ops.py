@@ -327,6 +327,11 @@ def fused_amax_convert(inputs: torch.Tensor, block_size: int, fmt: str | int, sc
     rows = x.numel() // max(cols, 1)
     y = torch.empty_like(x) if out is None else out  # out may be x itself (in place)
     ga = None if global_amax is None else _f32(global_amax, x.device)
+    if ga is not None and ga.numel() != 1:
+        # the reference's per-channel variant (global_amax.numel() == rows) indexes the amax with the PADDED flat
+        # index divided by the unpadded width (tensor_quant_mx.cu:277) and reads past the end for the last rows;
+        # its Python front door always reduces to one value first (tensor_quant.py:171-172)
+        raise MoquantUnsupported("fused_amax_convert: global_amax must have one element")
     with _on(x) as stream:
         check(_lib.lib().moq_mx_fused_amax_convert(_p(x), _p(y), rows, cols, int(block_size), _dt(x), f, sf,
                                                    _p(ga), stream))

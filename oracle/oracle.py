@@ -148,13 +148,14 @@ def amax_qdq_int_group(x, g, num_bits=4, unsigned=False, narrow_range=False, qdq
     return (_from_np(y, x.dtype, x.shape) if qdq else None), torch.from_numpy(am)
 
 
-def mx_fused_amax_convert(x, block, fmt="E2M1"):
+def mx_fused_amax_convert(x, block, fmt="E2M1", scale_fmt="E8M0", global_amax=None):
     cols = x.shape[-1]
     rows = x.numel() // cols
     a = _np(x)
     y = _empty_like_np(x)
-    lib().orc_mx_fused_amax_convert(_p(a), _p(y), I64(rows), I64(cols), int(block), DT[x.dtype],
-                                    MX_TYPES[fmt])
+    g = None if global_amax is None else np.ascontiguousarray(global_amax.detach().cpu().float().reshape(-1).numpy()[:1])
+    lib().orc_mx_fused_amax_convert2(_p(a), _p(y), I64(rows), I64(cols), int(block), DT[x.dtype],
+                                     MX_TYPES[fmt], MX_TYPES[scale_fmt], _p(g))
     return _from_np(y, x.dtype, x.shape)
 
 

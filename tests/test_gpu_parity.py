@@ -613,3 +613,40 @@ def test_convert_to_exmy_vs_oracle(fmt):
     assert_bits_equal(got, want, f"convert_to_exmy {fmt}")
     assert ops.convert_to_exmy(2.4, "E2M1") == 2.0 and ops.convert_to_exmy(-2.5, "E2M1") == -2.0  # tie -> even code
     assert isinstance(ops.convert_to_exmy(0.3, fmt), float)
+
+
+_FP4_LITERALS = [([0, 0.5, 1, 1.5, 2, 3, 4, 6], [0, 0.5, 1, 1.5, 2, 3, 4, 6]),
+                 ([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5, 6], [0.0, 1, 1, 2, 2, 4, 4, 6]),
+                 ([0.15, 0.65, 1.15, 1.65, 2.4, 3.4, 4.9, 6], [0.0, 0.5, 1, 1.5, 2, 3, 4, 6]),
+                 ([0.35, 0.85, 1.35, 1.85, 2.6, 3.6, 5.1, 6], [0.5, 1, 1.5, 2, 3, 4, 6, 6])]
+
+
+@pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
+def test_block_scale_formats_other_than_e8m0(dn):
+    """fused_amax_convert with element-format block scales (NVFP4-style E2M1 + E4M3 scales, with and without the
+    tensor-wide amax; E5M2 scales; MXFP8-style E4M3 elements with E4M3 scales): the reference test's literal rows
+    (test_tensor_quant_cuda.py:205-261) and random tensors against the oracle, ragged widths included."""
+    dt = DT[dn]
+    for block_size in (8, 16, 32):
+        for test_in, test_out in _FP4_LITERALS:
+            for sign in (1.0, -1.0):
+                x = torch.cat([torch.tensor([test_in]) * sign] * (block_size // 8), dim=-1).to(dt).to(DEV)
+                want = torch.cat([torch.tensor([test_out]) * sign] * (block_size // 8), dim=-1).to(dt)
+                got = ops.fused_amax_convert(x, 16, "E2M1", "E4M3", x.abs().amax())
+                assert torch.allclose(got.cpu().float(), want.float())
+    gen = torch.Generator().manual_seed(17)
+    for shape, block in [((64, 256), 16), ((7, 100), 16), ((33, 48), 32), ((5, 8), 8)]:
+        x = (torch.randn(*shape, generator=gen) * torch.exp(torch.randn(shape[0], 1, generator=gen) * 2)).to(dt)
+        x[0, :block] = 0
+        g = x.abs().amax().float()
+        for fmt, sfmt, glob in [("E2M1", "E4M3", g), ("E2M1", "E4M3", None), ("E2M1", "E5M2", g), ("E4M3", "E4M3", g),
+                                ("E2M3", "E4M3", None), ("E2M1", "E4M3", torch.tensor(0.0))]:
+            got = ops.fused_amax_convert(x.to(DEV), block, fmt, sfmt, None if glob is None else glob.to(DEV))
+            want = oracle.mx_fused_amax_convert(x, block, fmt, sfmt, glob)
+            assert_bits_equal(got, want, f"{fmt}/{sfmt} global={glob is not None} {shape} block {block}")
+    # the front door: dynamic_block_quant with scale_bits (4, 3) takes the quantizer's amax as the tensor-wide amax
+    x = (torch.randn(16, 64, generator=gen) * 3).to(dt)
+    got = ops.dynamic_block_quant(x.to(DEV), 16, x.abs().amax().to(DEV), (2, 1), (4, 3))
+    assert_bits_equal(got, oracle.mx_fused_amax_convert(x, 16, "E2M1", "E4M3", x.abs().amax().float()), "nvfp4 front door")
+    with pytest.raises(moa.MoquantUnsupported):
+        ops.fused_amax_convert(x.to(DEV), 16, "E2M1", "E4M3", torch.ones(16, device=DEV))

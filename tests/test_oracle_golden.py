@@ -348,3 +348,25 @@ def test_fp8_tile_pack_matches_reference(golden):
         qp = F.pad(want, (0, (-x.shape[1]) % bc, 0, (-x.shape[0]) % br))
         deq = oracle.fp8_unpack_tile(qp, scales.to(dt), dt, br, bc)[: x.shape[0], : x.shape[1]]
         assert_bits_equal(deq, g.t(f"{k}_deq", dt), f"{k} dequant")
+
+
+_FP4_LITERALS = [  # tests/gpu/torch/quantization/test_tensor_quant_cuda.py:236-258 (test_cuda_ext_fp4)
+    ([0, 0.5, 1, 1.5, 2, 3, 4, 6], [0, 0.5, 1, 1.5, 2, 3, 4, 6]),                      # table values
+    ([0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5, 6], [0.0, 1, 1, 2, 2, 4, 4, 6]),            # exact ties: even code
+    ([0.15, 0.65, 1.15, 1.65, 2.4, 3.4, 4.9, 6], [0.0, 0.5, 1, 1.5, 2, 3, 4, 6]),      # just below the ties
+    ([0.35, 0.85, 1.35, 1.85, 2.6, 3.6, 5.1, 6], [0.5, 1, 1.5, 2, 3, 4, 6, 6]),        # just above
+]
+
+
+@pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+def test_two_level_fp4_scaling_literal_vectors(dn, block_size):
+    """fused_amax_convert(inputs, 16, E2M1, E4M3 block scales, global amax) on the reference test's literal rows:
+    pins compute_scale_with_global (tensor_quant_mx.cu:154-183) in the oracle."""
+    dt = DT[dn]
+    for test_in, test_out in _FP4_LITERALS:
+        for sign in (1.0, -1.0):
+            x = torch.cat([torch.tensor([test_in]) * sign] * (block_size // 8), dim=-1).to(dt)
+            want = torch.cat([torch.tensor([test_out]) * sign] * (block_size // 8), dim=-1).to(dt)
+            got = oracle.mx_fused_amax_convert(x, 16, "E2M1", "E4M3", x.abs().amax())
+            assert torch.allclose(got.float(), want.float()), f"{dn} bs={block_size}: {got} vs {want}"
