@@ -157,7 +157,7 @@ def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
         if not is_quantized_linear(m):
             continue
         wq = m.weight_quantizer
-        if (not wq.is_enabled or wq._dynamic or wq.is_mx_format or wq._calibrator is None
+        if (not wq.is_enabled or wq._dynamic or wq._block_dynamic or wq._calibrator is None
                 or getattr(wq, "_amax", None) is None):
             continue  # _make_weight_mse_calibrator's eligibility test (model_calib.py:681-689)
         nb = wq._num_bits

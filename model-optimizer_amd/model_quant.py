@@ -34,6 +34,14 @@ FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bit
 MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*lm_head*": {"enable": False}}, "algorithm": None}
+# presets/model/nvfp4.yaml quantizer layout (numerics/nvfp4.yaml): E2M1 elements in blocks of 16 with E4M3 block scales
+# relative to a max-calibrated tensor-wide amax (two-level scaling, tensor_quant_mx.cu:154-183).  The format is NVIDIA's;
+# what runs here is its fake quantization and calibration (no packed export)
+NVFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "axis": None,
+                                                         "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}},
+                                   "*input_quantizer": {"num_bits": (2, 1), "axis": None,
+                                                        "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}},
+                                   "*lm_head*": {"enable": False}}, "algorithm": "max"}
 # presets/model/w4a8_awq_beta.yaml quantizer layout (INT4 blocks then FP8 on the weights, FP8 inputs); calibrated with
 # "max" here -- the AWQ search with quantized inputs is outside this path
 W4A8_MAX_CFG = {"quant_cfg": {"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},

@@ -40,6 +40,7 @@ class QuantizerAttributeConfig:
     calibrator: str | tuple = "max"
     fake_quant: bool = True
     enable: bool = True
+    type: str = "static"  # "dynamic": amax recomputed from every input, never calibrated (config.py:478-489)
     learn_amax: bool = False
     extra: dict = field(default_factory=dict)
 
@@ -56,6 +57,7 @@ class TensorQuantizer(nn.Module):
         self._narrow_range = cfg.narrow_range
         self._fake_quant = cfg.fake_quant
         self._disabled = not cfg.enable
+        self._dynamic = cfg.type == "dynamic"
         self._if_quant = if_quant
         self._if_calib = if_calib
         self._enable_pre_quant_scale = True
@@ -82,6 +84,7 @@ class TensorQuantizer(nn.Module):
         self._narrow_range = cfg.narrow_range
         self._fake_quant = cfg.fake_quant
         self._disabled = not cfg.enable
+        self._dynamic = cfg.type == "dynamic"
         self._calibrator = self._make_calibrator(cfg.calibrator)
 
     def _make_calibrator(self, spec) -> _Calibrator:
@@ -111,13 +114,17 @@ class TensorQuantizer(nn.Module):
         self._calibrator._axis = value  # tensor_quantizer.py:309-316
 
     @property
-    def _dynamic(self):
+    def _block_dynamic(self):
+        """Dynamic BLOCK quantization (block_sizes["type"] == "dynamic": MX formats, NVFP4-style two-level scaling):
+        block scales come from every input.  Not the same as the top-level `type: dynamic` (`_dynamic`): a
+        block-dynamic quantizer with E4M3 block scales still calibrates a per-tensor amax, which becomes the
+        tensor-wide amax of the two-level scale (tensor_quantizer.py:890-920, tensor_quant.py:157-195)."""
         return self._block_sizes is not None and self._block_sizes.get("type", "static") == "dynamic"
 
     @property
     def is_mx_format(self):
         # block scales in E8M0 (tensor_quantizer.py: is_mx_format)
-        return self._dynamic and self._block_sizes.get("scale_bits", None) == (8, 0)
+        return self._block_dynamic and self._block_sizes.get("scale_bits", None) == (8, 0)
 
     @property
     def is_static_block_quant(self):
@@ -193,6 +200,8 @@ class TensorQuantizer(nn.Module):
         self._disabled = False
 
     def enable_calib(self):
+        if self._dynamic:  # dynamic quantization does not need calibration (tensor_quantizer.py:676-684)
+            return
         self._if_calib = True
 
     def disable_calib(self):
@@ -299,7 +308,7 @@ class TensorQuantizer(nn.Module):
         self._calibrator.collect(inputs)
 
     def _fake_quantize(self, inputs):
-        if self._dynamic:
+        if self._block_dynamic:
             g = self._block_sizes.get(-1, None) or self._block_sizes.get(inputs.dim() - 1, None)
             if g is None:
                 raise ValueError("block size for dynamic quantization not found.")

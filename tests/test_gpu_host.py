@@ -256,3 +256,32 @@ def test_tensor_quantizer_2d_blocks_match_reference(golden):
         am3 = ops.block2d((x4 * 0.5).contiguous(), 0)
         ops.block2d(x4, 0, amax=am3, accumulate=True)
         assert torch.equal(am3.cpu().reshape(-1), wam.reshape(-1))
+
+
+def test_two_level_block_format_flow_and_dynamic_type():
+    """NVFP4-style quantizers (E2M1 blocks of 16, E4M3 block scales): the block scales are dynamic but the tensor-wide
+    amax is max-calibrated and becomes the global amax of the two-level scale (tensor_quantizer.py:890-920).
+    A top-level `type: dynamic` quantizer is never calibrated and takes the amax of each input."""
+    torch.manual_seed(2)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 96, bias=False), torch.nn.Linear(96, 32, bias=False)).to(torch.bfloat16).to(DEV)
+    batches = [torch.randn(40, 64, device=DEV, dtype=torch.bfloat16) * (1 + i) for i in range(3)]
+    ref_w = [m.weight.detach().clone() for m in model]
+    moa.quantize(model, moa.model_quant.NVFP4_DEFAULT_CFG, lambda m: [m(b) for b in batches])
+    lin0 = model[0]
+    assert lin0.weight_quantizer._block_dynamic and not lin0.weight_quantizer._dynamic and not lin0.weight_quantizer.is_mx_format
+    assert lin0.weight_quantizer.amax.float().item() == ref_w[0].abs().max().float().item()
+    assert lin0.input_quantizer.amax.float().item() == max(b.abs().max().float().item() for b in batches)
+    x = batches[0]
+    got = lin0.input_quantizer(x)
+    want = oracle.mx_fused_amax_convert(x.cpu(), 16, "E2M1", "E4M3", lin0.input_quantizer.amax.float().cpu())
+    assert_bits_equal(got, want, "input fake-quant with the calibrated global amax")
+    gw = lin0.weight_quantizer(lin0.weight)
+    assert_bits_equal(gw, oracle.mx_fused_amax_convert(ref_w[0].cpu(), 16, "E2M1", "E4M3", ref_w[0].abs().max().float().cpu()),
+                      "weight fake-quant")
+    # top-level dynamic: no calibration state, amax from the input at hand
+    q = moa.TensorQuantizer(moa.QuantizerAttributeConfig(num_bits=(4, 3), axis=None, type="dynamic"))
+    q.enable_calib()
+    assert not q._if_calib
+    for b in batches:
+        assert_bits_equal(q(b), ops.scaled_e4m3(b, ops.reduce_amax(b)), "dynamic per-tensor FP8")
+    assert q.amax is None
