@@ -398,7 +398,7 @@ def row_hist_np(w: torch.Tensor, bins: int):
         check(_lib.lib().moq_row_hist_np(_p(x), rows, cols, _dt(x), int(bins), _p(first), _p(last), _p(counts), stream))
     # np.linspace in float32: fp32(fp32(k * step) + first), last edge = stop
     k = torch.arange(bins + 1, dtype=torch.float32, device=x.device)
-    step = (last - first) / float(bins)
+    step = (last - first) / torch.full_like(last, float(bins))  # tensor / tensor: a true division on the GPU too
     edges = k[None, :] * step[:, None] + first[:, None]
     edges[:, -1] = last
     return counts, edges

@@ -40,8 +40,9 @@ def test_argument_validation_without_gpu():
     assert lib.moq_mask_2to4(ctypes.c_void_p(16), 2, 6, _lib.BF16, ctypes.c_void_p(16), None) == _lib.MOQ_ERR_UNSUPPORTED
     assert lib.moq_int4_pack(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), 130, 128, 2, 0, None) \
         == _lib.MOQ_ERR_INVALID
-    assert lib.moq_mx_fused_amax_convert(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 32, 32, 2, 6, 0, None, None) \
-        == _lib.MOQ_ERR_UNSUPPORTED  # E4M3 block scales: not implemented -> loud
+    assert lib.moq_mx_fused_amax_convert(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 32, 32, 2, 6, _lib.MX_TYPES["E8M0"],
+                                         ctypes.c_void_p(16), None) \
+        == _lib.MOQ_ERR_UNSUPPORTED  # E8M0 block scales take no global amax -> loud
     with pytest.raises(ValueError):
         _lib.check(_lib.MOQ_ERR_UNSUPPORTED)
     with pytest.raises(RuntimeError):
