@@ -124,5 +124,5 @@ def test_reduce_block_amax_and_padding(dn, shape, blocks):
     for d, b in blocks.items():
         assert padded.shape[d] % b == 0 and padded.shape[d] - ragged.shape[d] < b
     assert torch.equal(padded[tuple(slice(0, s) for s in ragged.shape)], ragged)
-    assert (padded.float().abs().sum() == ragged.float().abs().sum()).item()  # the padding is zeros
+    assert int((padded != 0).sum()) == int((ragged != 0).sum())  # the padding is zeros
     assert ops.reduce_block_padding(x, {k: 1 for k in blocks}) is x

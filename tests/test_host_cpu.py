@@ -97,7 +97,7 @@ def test_tensor_quantizer_config_and_state_without_gpu():
     with pytest.raises(RuntimeError, match="Calibrator returned None"):
         q.load_calib_amax()
     mx = TensorQuantizer(QuantizerAttributeConfig(num_bits=(2, 1), block_sizes={-1: 32, "type": "dynamic", "scale_bits": (8, 0)}))
-    assert mx.is_mx_format and mx._dynamic and not mx.is_static_block_quant
+    assert mx.is_mx_format and mx._block_dynamic and not mx._dynamic and not mx.is_static_block_quant
     q.pre_quant_scale = torch.ones(4)
     assert q.pre_quant_scale is not None
     q._enable_pre_quant_scale = False
