@@ -176,7 +176,9 @@ int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* blk_start, 
 /* Per `block` consecutive elements of the last dim (cols virtually right-padded with zeros to a block
  * multiple): block amax -> E8M0 scale 2^ceil(log2(amax/fmt_max)) -> y = sign * round_fmt(|x|*2^-e) * 2^e.
  * Replaces cuda_ext_mx.fused_amax_convert (tensor_quant_mx.cu:239-387, tensor_quant_mx.h:39-245).
- * Only scale_fmt == MOQ_E8M0 without global_amax is implemented; others -> MOQ_ERR_UNSUPPORTED. */
+ * scale_fmt == MOQ_E8M0 (MX formats): no global_amax.  scale_fmt = an element format (MOQ_E4M3 for NVFP4-style
+ * configs): compute_scale (tensor_quant_mx.cu:139-152) or, with global_amax (one fp32 value, the tensor-wide amax),
+ * compute_scale_with_global (:154-183).  E8M0 with a global amax -> MOQ_ERR_UNSUPPORTED. */
 int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols, int block, int dt,
                               int fmt, int scale_fmt, const float* global_amax, void* stream);
 
