@@ -72,7 +72,9 @@ def pmc_traffic(workload, model, n_layers):
     profile of this workload / model size is committed."""
     if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
-    path = os.path.join(ROOT, "profiles", f"r01b_{workload}_pmc.json")
+    path = os.path.join(ROOT, "profiles", f"r01c_{workload}_pmc.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", f"r01b_{workload}_pmc.json")
     if not os.path.exists(path):
         path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc.json")
     try:
