@@ -348,6 +348,33 @@ __global__ __launch_bounds__(kBlock) void fp8_unpack_tile_kernel(const uint8_t* 
   }
 }
 
+
+// element-wise forms of the two tile kernels for tiles narrower than a packet or unaligned tensors (the reference's
+// own literal test vectors use 2 x 2 tiles, test_qtensor_cuda.py:190-236)
+template <int DT, bool PROMOTE>
+__global__ __launch_bounds__(kBlock) void fp8_pack_tile_elem_kernel(const void* __restrict__ x, const void* __restrict__ scales,
+                                                                    uint8_t* __restrict__ out, int64_t n, int64_t cols,
+                                                                    int br, int bc, int64_t tiles_per_row) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = e / cols, col = e - row * cols;
+    const int64_t t = (row / br) * tiles_per_row + col / bc;
+    const float sc = PROMOTE ? reinterpret_cast<const float*>(scales)[t] : load1<DT>(scales, t);
+    float q = load1<DT>(x, e) / sc;
+    if constexpr (!PROMOTE) q = round_to_dtype<DT>(q);
+    out[e] = (uint8_t)(e4m3fn_bytes2(q, 0.0f) & 0xFFu);
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void fp8_unpack_tile_elem_kernel(const uint8_t* __restrict__ q, const void* __restrict__ scales,
+                                                                      void* __restrict__ out, int64_t n, int64_t cols,
+                                                                      int br, int bc, int64_t tiles_per_row) {
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t row = e / cols, col = e - row * cols;
+    const float sc = load1<DT>(scales, (row / br) * tiles_per_row + col / bc);
+    store1<DT>(out, e, __builtin_amdgcn_cvt_f32_fp8((int)q[e], 0) * sc);
+  }
+}
+
 }  // namespace moq
 
 using namespace moq;
@@ -486,10 +513,9 @@ static int fp8_tile_args_ok(const char* who, const void* a, const void* b, const
     set_error("%s: bad arguments", who);
     return MOQ_ERR_INVALID;
   }
-  const int vec = dt == MOQ_F32 ? 4 : 8;
-  if (rows % br != 0 || cols % bc != 0 || bc % vec != 0) {
-    set_error("%s: needs rows %% br == 0, cols %% bc == 0 and bc %% %d == 0 (pad on the host like "
-              "reduce_block_padding)", who, vec);
+  (void)dt;
+  if (rows % br != 0 || cols % bc != 0) {
+    set_error("%s: needs rows %% br == 0 and cols %% bc == 0 (pad on the host like reduce_block_padding)", who);
     return MOQ_ERR_UNSUPPORTED;
   }
   return MOQ_OK;
@@ -503,14 +529,22 @@ extern "C" int moq_fp8_pack_tile(const void* x, const void* scales, int scale_dt
   }
   const int rc = fp8_tile_args_ok("moq_fp8_pack_tile", x, scales, out, rows, cols, br, bc, dt);
   if (rc != MOQ_OK || rows * cols == 0) return rc;
-  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) != 0) {
-    set_error("moq_fp8_pack_tile: needs 16-byte aligned x and 8-byte aligned out");
-    return MOQ_ERR_UNSUPPORTED;
-  }
   const int vec = dt == MOQ_F32 ? 4 : 8;
+  const bool promote = scale_dt == MOQ_F32 && dt != MOQ_F32;
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) != 0 || bc % vec != 0) {
+    const int64_t n = rows * cols;
+    if (promote) {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_elem_kernel<DT, true>), dim3(stream_grid(kBlock, n)), dim3(kBlock),
+                                                0, S(stream), x, scales, out, n, cols, br, bc, cols / bc));
+    } else {
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_elem_kernel<DT, false>), dim3(stream_grid(kBlock, n)), dim3(kBlock),
+                                                0, S(stream), x, scales, out, n, cols, br, bc, cols / bc));
+    }
+    return check_launch("moq_fp8_pack_tile");
+  }
   const int64_t n_packets = rows * cols / vec;
   const int grid = stream_grid(kBlock, n_packets);
-  if (scale_dt == MOQ_F32 && dt != MOQ_F32) {
+  if (promote) {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
                                               scales, out, n_packets, cols, br, bc, cols / bc));
   } else {
@@ -524,11 +558,13 @@ extern "C" int moq_fp8_unpack_tile(const uint8_t* q, const void* scales, void* o
                                    int bc, int dt, void* stream) {
   const int rc = fp8_tile_args_ok("moq_fp8_unpack_tile", q, scales, out, rows, cols, br, bc, dt);
   if (rc != MOQ_OK || rows * cols == 0) return rc;
-  if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(q) & 7u) != 0) {
-    set_error("moq_fp8_unpack_tile: needs 16-byte aligned out and 8-byte aligned q");
-    return MOQ_ERR_UNSUPPORTED;
-  }
   const int vec = dt == MOQ_F32 ? 4 : 8;
+  if ((reinterpret_cast<uintptr_t>(out) & 15u) != 0 || (reinterpret_cast<uintptr_t>(q) & 7u) != 0 || bc % vec != 0) {
+    const int64_t n = rows * cols;
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_tile_elem_kernel<DT>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
+                                              S(stream), q, scales, out, n, cols, br, bc, cols / bc));
+    return check_launch("moq_fp8_unpack_tile");
+  }
   const int64_t n_packets = rows * cols / vec;
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_tile_kernel<DT>), dim3(stream_grid(kBlock, n_packets)), dim3(kBlock), 0,
                                             S(stream), q, scales, out, n_packets, cols, br, bc, cols / bc));

@@ -125,3 +125,31 @@ def test_int4_qtensor_round_trip_matches_kernels():
     deq = qt.dequantize(scale=scales, block_sizes={-1: 128})
     assert deq.shape == w.shape and deq.dtype == w.dtype
     assert (deq.cpu().float() - w.float()).abs().max() <= (w.float().abs().max() / 7) * 0.51
+
+
+# the reference's own literal vectors for real quantization: tests/gpu/torch/quantization/test_qtensor_cuda.py:110-250
+# (test_qtensor_accuracy: quantize, dequantize, torch.allclose with the listed values; bf16 tensors)
+_QT_LITERALS = [
+    ("int4", {-1: 4}, None, [[0, 1, 2, 3, 4, 5, 6, 7]], [[0.0000, 0.8516, 2.1406, 2.9844, 4.0000, 5.0000, 6.0000, 7.0000]]),
+    ("int4", {-1: 4}, None, [[0, 1, 2, 3, 4, 5, 6, 7, 3, 3]],
+     [[0.0000, 0.8516, 2.1406, 2.9844, 4.0000, 5.0000, 6.0000, 7.0000, 2.9844, 2.9844]]),
+    ("fp8", {-1: 2, -2: 2}, None, [[0, 1, 2, 3], [4, 5, 6, 7]], [[0.0000, 0.9844, 2.0000, 3.0000], [3.9375, 5.0000, 6.0000, 7.0000]]),
+    ("fp8", {-1: 2, -2: 2}, None, [[0, 1, 3], [4, 5, 7]], [[0.0000, 0.9844, 3.0000], [3.9375, 5.0000, 7.0000]]),
+    ("fp8", {-1: 2}, None, [[0, 1, 2, 3], [4, 5, 6, 7]], [[0.0000, 1.0000, 1.9219, 3.0000], [3.9375, 5.0000, 6.0000, 7.0000]]),
+    ("fp8", None, 0, [[0, 1, 2, 3], [4, 5, 6, 7]], [[0.0000, 0.9609, 1.9219, 3.0000], [4.0000, 5.0000, 6.0000, 7.0000]]),
+    ("fp8", None, None, [[0, 1, 2, 3], [4, 5, 6, 7]], [[0, 1, 2, 3], [4, 5, 6, 7]]),
+]
+
+
+@pytest.mark.parametrize("kind,block_sizes,axis,test_input,test_output", _QT_LITERALS)
+def test_reference_literal_vectors_for_real_quantization(kind, block_sizes, axis, test_input, test_output):
+    x = torch.tensor(test_input, dtype=torch.bfloat16, device=DEV)
+    want = torch.tensor(test_output, dtype=torch.bfloat16)
+    if kind == "int4":
+        qt, scales = qtensor.INT4QTensor.quantize(x, block_sizes[-1])
+        deq = qt.dequantize(torch.bfloat16, scale=scales, block_sizes=block_sizes)
+    else:
+        qt, scales = qtensor.FP8QTensor.quantize(x, None, axis=axis, block_sizes=block_sizes)
+        deq = qt.dequantize(torch.bfloat16, scale=scales, block_sizes=block_sizes)
+    assert deq.shape == want.shape
+    assert torch.allclose(deq.cpu(), want), f"{deq.cpu()} vs {want}"
