@@ -124,6 +124,8 @@ class HistogramCalibrator(_Calibrator):
     @torch.no_grad()
     def collect(self, x):
         x = x.detach()
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            x = x.float()  # the reference histograms x.abs().float() whatever the dtype (calib/histogram.py:95-96)
         # x_max of what is histogrammed (|x| in fp32; zeros never raise the max)
         x_max = ops.reduce_amax(x).float().cpu()
         if self._calib_bin_edges is None and self._calib_hist is None:

@@ -131,3 +131,141 @@ class TestScaledE4M3:
         x = torch.randn(2, 3, 4, device=DEV, dtype=torch.float32)
         amax = torch.tensor([1.0, 0.0, 1.0], device=DEV).view(1, 3, 1)
         assert torch.isfinite(ops.scaled_e4m3(x, amax)).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# tests/unit/torch/quantization/test_calibrator.py restated (the tensors live on the GPU; same values, same bounds)
+from model_optimizer_amd import calib  # noqa: E402
+
+
+class TestMaxCalibrator:
+    def test_simple_run(self):
+        c = calib.MaxCalibrator(8, None, False)
+        x_1, x_2 = torch.rand(16).to(DEV), torch.rand(16).to(DEV)
+        c.collect(x_1)
+        c.collect(x_2)
+        assert torch.allclose(c.compute_amax(), torch.max(x_1.max(), x_2.max()), atol=0, rtol=0)
+        calib.MaxCalibrator(8, None, True)
+
+    @pytest.mark.parametrize("axis", [0, -4])
+    def test_fine_grain(self, axis):
+        c = calib.MaxCalibrator(8, axis, False)
+        x_1, x_2 = torch.rand(3, 4, 2, 2).to(DEV), torch.rand(3, 4, 2, 2).to(DEV)
+        c.collect(x_1)
+        c.collect(x_2)
+        assert c.compute_amax().shape[0] == 3
+        assert torch.allclose(c.compute_amax(), ops.reduce_amax(torch.max(x_1, x_2), axis=(1, 2, 3)), atol=0, rtol=0)
+        c.reset()
+        assert c.compute_amax() is None
+
+    def test_track_amax(self):
+        import numpy as np
+        c = calib.MaxCalibrator(8, None, False, track_amax=True)
+        x_1, x_2 = torch.rand(16).to(DEV), torch.rand(16).to(DEV)
+        c.collect(x_1)
+        c.collect(x_2)
+        assert torch.allclose(c.compute_amax(), torch.max(x_1.max(), x_2.max()), atol=0, rtol=0)
+        np.testing.assert_array_equal(c.amaxs[0], x_1.max().cpu().numpy())
+        np.testing.assert_array_equal(c.amaxs[1], x_2.max().cpu().numpy())
+
+    def test_shape_change_raises(self):
+        c = calib.MaxCalibrator(8, 0, False)
+        c.collect(torch.rand(3, 4, 2, 2).to(DEV))
+        with pytest.raises(RuntimeError, match="shape changed"):
+            c.collect(torch.rand(4, 4, 2, 2).to(DEV))
+
+
+class TestHistogramCalibrators:
+    def test_skip_zeros(self):
+        c = calib.HistogramCalibrator(8, None, False, num_bins=2048, skip_zeros=True)
+        c.collect(torch.tensor([0, 0, 0, 0, 0, 1, 2, 3, 4, 5]).to(DEV))
+        c.collect(torch.tensor([0, 0, 0, 0, 0, 6, 7, 8, 9, 10]).to(DEV))
+        amax = c.compute_amax("percentile", percentile=50, start_bin=128)
+        assert (amax - 5.0).abs() < 10 / 2048
+
+    def test_grown_histogram_equals_numpy(self):
+        """test_torch_hist: counts after growth equal numpy's histogram over the grown range."""
+        import numpy as np
+        torch.manual_seed(0)
+        x_1 = torch.rand(15)
+        x_1[0] = 0
+        x_2 = torch.rand(15) + 1
+        x_2[1] = 0
+        c = calib.HistogramCalibrator(8, None, False, num_bins=19, torch_hist=True)
+        c.collect(x_1.to(DEV))
+        assert c._calib_hist.numel() == c._calib_bin_edges.numel() - 1
+        want, edges = np.histogram(x_1.numpy(), bins=19, range=(0, x_1.max().item()))
+        np.testing.assert_array_equal(want, c._calib_hist.cpu().numpy())
+        np.testing.assert_array_almost_equal(edges, c._calib_bin_edges.cpu().numpy())
+        for _ in range(3):
+            c.collect(x_2.to(DEV))
+            c.collect(x_1.to(DEV))
+            c.compute_amax("percentile", percentile=99.99)
+            assert c._calib_hist.numel() == c._calib_bin_edges.numel() - 1
+        assert int(c._calib_hist.sum()) == 15 * 7
+
+    @pytest.mark.parametrize("unsigned", [False, True])
+    def test_entropy_one_tensor(self, unsigned):
+        c = calib.HistogramCalibrator(8, None, unsigned, num_bins=512, grow_method="stretch")
+        x_2 = torch.rand(11, 7, 3, 3)
+        x_2[1, 1, 1, 1] = 10.0  # the outlier must be discarded by the KL search
+        c.collect(x_2.to(DEV))
+        assert c.compute_amax("entropy", start_bin=32) < 1.1
+
+    def test_entropy_two_tensor(self):
+        c = calib.HistogramCalibrator(8, None, False, num_bins=512)
+        x_2 = torch.rand(11, 7, 3, 3)
+        x_2[1, 1, 1, 1] = 10.0
+        c.collect(x_2.to(DEV))
+        c.collect(torch.rand(11, 7, 3, 3).to(DEV))
+        assert c.compute_amax("entropy", start_bin=32) < 1.1
+
+    def test_mse_one_tensor(self):
+        c = calib.HistogramCalibrator(8, None, False, num_bins=32)
+        x_1 = torch.ones(4, 4, 4) * 255.0
+        x_1[1, 1, 1] = 256.0
+        c.collect(x_1.to(DEV))
+        amax = c.compute_amax("mse", start_bin=16).cpu()
+        assert (amax - 255.0).abs() < (amax - 256.0).abs()
+
+    def test_mse_unsigned_one_tensor(self):
+        c = calib.HistogramCalibrator(8, None, True, num_bins=32)
+        x_1 = torch.ones(11, 7, 3, 3) * 512.0
+        x_1[1, 1, 1, 1] = 513.0
+        c.collect(x_1.to(DEV))
+        amax = c.compute_amax("mse", start_bin=8).cpu()
+        assert (amax - 512.0).abs() < (amax - 513.0).abs()
+
+    def test_mse_two_tensor(self):
+        c = calib.HistogramCalibrator(8, None, False)
+        x_1 = torch.ones(11, 7, 3, 3) * 255.0
+        x_1[1, 1, 1, 1] = 256.0
+        c.collect(x_1.to(DEV))
+        c.collect((torch.ones(11, 7, 3, 3) * 255.0).to(DEV))
+        amax = c.compute_amax("mse").cpu()
+        assert (amax - 255.0).abs() < (amax - 256.0).abs()
+
+    def test_percentile_one_tensor(self):
+        c = calib.HistogramCalibrator(8, None, False)
+        c.collect(torch.arange(100).to(DEV))
+        assert (c.compute_amax("percentile", percentile=90) - 89.0).abs() < 100 / 1024
+
+    def test_percentile_unsigned_one_tensor(self):
+        c = calib.HistogramCalibrator(8, None, True)
+        c.collect(torch.arange(100).to(DEV))
+        assert (c.compute_amax("percentile", percentile=80) - 79.0).abs() < 100 / 2048
+
+    def test_percentile_two_tensor(self):
+        c = calib.HistogramCalibrator(8, None, False)
+        c.collect(torch.arange(100).to(DEV))
+        c.collect(torch.arange(0, 50, 0.5).to(DEV))
+        assert (c.compute_amax("percentile", percentile=99) - 97.0).abs() < 100 / 1024
+
+    def test_percentile_range_and_repr(self):
+        c = calib.HistogramCalibrator(8, None, False)
+        c.collect(torch.arange(100).to(DEV))
+        with pytest.raises(ValueError, match="range"):
+            c.compute_amax("percentile", percentile=-10)
+        with pytest.raises(ValueError, match="range"):
+            c.compute_amax("percentile", percentile=200)
+        repr(c)
