@@ -286,6 +286,8 @@ class AWQLiteHelper:
         # Gram-matrix search: G = sum_b X_b^T X_b / T_b (fp32 [Cin, Cin]), accumulated in the cache pass
         self.gram = None
         self.use_gram = False
+        self.gram_owner = None  # the helper whose Gram matrix this one aliases (same input tensor)
+        self.gram_symmetrized = False
 
     def search_operands(self, module):
         """(inv_s [A, Cin] fp32 = (1/s_alpha) rounded to the weight dtype, w_hat [A, Cout, Cin] = QDQ(W * s_alpha))
@@ -384,11 +386,25 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
             if h.gram is not None:
+                # Linears fed by the SAME tensor (q / k / v of an attention block, gate / up of an MLP) have the same
+                # Gram matrix: the first one accumulates it, the others alias it.  Identity of the tensor object is the
+                # test (a reference to the last input is kept, so its address cannot be reused in between).
+                owner = state.get("gram_owner") if state.get("gram_input") is input else None
+                if owner is not None and owner.gram is not None and owner.gram.shape == h.gram.shape \
+                        and h.gram_owner in (None, owner):
+                    if h.gram_owner is None:
+                        h.gram_owner = owner
+                        h.gram = owner.gram  # the own buffer is released
+                    return out_actual
+                if h.gram_owner is not None:
+                    raise RuntimeError("awq_lite (Gram search): a linear that shared its input with another one in an "
+                                       "earlier batch got a different tensor now; use search='gemm' for this model")
                 if x2.dtype in (torch.bfloat16, torch.float16):
                     ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)  # G += X^T X / T_b (MFMA)
                 else:
                     xf = x2.float()
                     h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
+                state["gram_input"], state["gram_owner"] = input, h
             return out_actual
         if h.use_gram or not h.is_enabled:
             return out_actual  # losses came from the Gram matrix / the linear is out of the search
@@ -412,6 +428,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         m.forward = patched_forward.__get__(m, type(m))
     try:
         forward_loop(model)  # cache pass
+        state.pop("gram_input", None)
+        state.pop("gram_owner", None)
         for h in helpers.values():
             if h.num_cache_steps:
                 h.act_scale = h.act_sum / h.num_cache_steps
@@ -430,10 +448,12 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for _, m in mods:  # Gram-matrix linears: losses now (local Gram; the loss is linear in it, summed below)
             h = helpers[m]
             if h.gram is not None and h.act_scale is not None:
-                if m.weight.dtype != torch.float32:
-                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only
+                own = h.gram_owner or h
+                if m.weight.dtype != torch.float32 and not own.gram_symmetrized:
+                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
+                    own.gram_symmetrized = True
                 _gram_losses(h, m)
-                h.gram = None  # release Cin^2 floats as soon as the linear is done
+                h.gram = None  # release Cin^2 floats as soon as the last linear using them is done
         if any(not h.use_gram and h.act_scale is not None for h in helpers.values()):
             state["mode"] = "search"
             forward_loop(model)  # search pass for the linears on the error-GEMM path

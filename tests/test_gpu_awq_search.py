@@ -145,3 +145,48 @@ def test_unexercised_and_nan_linears_fall_back_to_max_calibration(mode):
     qr = moa.quantize(ref, cfg, lambda m: [m(b[:1]) for b in batches])
     assert qr.linears[0].awq_lite.best_alpha == l0.awq_lite.best_alpha
     assert torch.equal(qr.linears[0].weight, l0.weight)
+
+
+class SharedInputs(torch.nn.Module):
+    """q / k / v read ONE tensor object (as in an attention block), o reads another of the same width."""
+
+    def __init__(self, dtype):
+        super().__init__()
+        self.stack = Stack([(256, 512), (128, 512), (128, 512), (512, 512)], dtype)
+
+    def forward(self, xs):
+        q, k, v, o = self.stack.linears
+        return [q(xs[0]), k(xs[0]), v(xs[0]), o(xs[1])]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gram_matrix_is_shared_between_linears_with_the_same_input(dtype):
+    """The Gram search accumulates X^T X once per distinct input tensor: k and v alias q's matrix, o (a different
+    tensor of the same width) owns its own; the result equals a run where every linear gets its own copy."""
+    dims = [(256, 512)] * 2
+    batches = _batches(dims, dtype, 3, 96)
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": "gram"}
+    shared = SharedInputs(dtype).to(DEV)
+    calls = []
+    from model_optimizer_amd import ops
+    orig_h, orig_a = ops.hessian_accum, torch.Tensor.addmm_
+    ops.hessian_accum = lambda *a, **k: (calls.append(1), orig_h(*a, **k))[1]
+    try:
+        qs = moa.quantize(shared, cfg, lambda m: [m(b) for b in batches])
+    finally:
+        ops.hessian_accum = orig_h
+    lin = qs.stack.linears
+    assert lin[1].awq_lite.gram_owner is lin[0].awq_lite and lin[2].awq_lite.gram_owner is lin[0].awq_lite
+    assert lin[0].awq_lite.gram_owner is None and lin[3].awq_lite.gram_owner is None
+    if dtype != torch.float32:
+        assert len(calls) == 2 * len(batches)  # q and o only
+    # reference: the same linears, every one with a private clone of its input
+    private = SharedInputs(dtype).to(DEV)
+    private.forward = lambda xs: [l(x.clone()) for l, x in zip(private.stack.linears, (xs[0], xs[0], xs[0], xs[1]))]
+    qp = moa.quantize(private, cfg, lambda m: [m(b) for b in batches])
+    for a, b in zip(qs.stack.linears, qp.stack.linears):
+        assert b.awq_lite.gram_owner is None
+        assert a.awq_lite.best_alpha == b.awq_lite.best_alpha
+        assert torch.equal(a.awq_lite.loss_buf, b.awq_lite.loss_buf)
+        assert torch.equal(a.weight, b.weight)

@@ -48,18 +48,25 @@ class LinearStack(torch.nn.Module):
                 self.linears.append(lin)
 
     def forward(self, acts):
-        """acts: dict Cin -> activation batch [tokens, Cin]; every linear consumes the batch of its width."""
-        for lin in self.linears:
-            lin(acts[lin.in_features])
+        """acts: dict role -> activation batch [tokens, Cin].  As in a decoder layer, q / k / v read one tensor, the
+        output projection another, gate / up a third and the down projection a fourth."""
+        for i, lin in enumerate(self.linears):
+            lin(acts[ROLES[i % 7]])
 
 
-def make_batch(cins, tokens, device, dtype, seed):
+ROLES = ("qkv", "qkv", "qkv", "o", "gate_up", "gate_up", "down")
+
+
+def make_batch(model, tokens, device, dtype, seed):
     g = torch.Generator(device=device).manual_seed(seed)
+    shapes = layer_shapes(model)
     out = {}
-    for cin in cins:
+    for role, (_, cin) in zip(ROLES, shapes):
+        if role in out:
+            continue
         chan = torch.exp(torch.randn(cin, generator=g, device=device))
         chan[torch.randint(0, cin, (4,), generator=g, device=device)] *= 50.0
-        out[cin] = (torch.randn(tokens, cin, generator=g, device=device) * chan).to(dtype)
+        out[role] = (torch.randn(tokens, cin, generator=g, device=device) * chan).to(dtype)
     return out
 
 
@@ -93,8 +100,7 @@ def main():
     dtype = torch.bfloat16
 
     model = LinearStack(args.model, args.layers, dev, dtype)
-    cins = sorted({cin for _, cin in layer_shapes(args.model)})
-    my_batches = [make_batch(cins, args.tokens, dev, dtype, 100 + b) for b in range(args.batches) if b % world == rank]
+    my_batches = [make_batch(args.model, args.tokens, dev, dtype, 100 + b) for b in range(args.batches) if b % world == rank]
 
     def loop(m):
         for b in my_batches:
