@@ -108,26 +108,35 @@ def invert(hessian: torch.Tensor) -> torch.Tensor:
     return h
 
 
+def prepare_hessian(hessian: torch.Tensor, hessian_damp: float):
+    """The weight-independent half of sparsegpt.py:45-69: dead columns (zero diagonal), damping, inverse factor.
+    Returns (dead-column mask, hinv).  Linears that read the same tensor have the same Hessian and share this."""
+    hessian = hessian.clone()
+    zero = torch.diag(hessian) == 0
+    hessian[zero, zero] = 1
+    damp = hessian_damp * torch.mean(torch.diag(hessian))
+    diag = torch.arange(hessian.size(0), device=hessian.device)
+    hessian[diag, diag] += damp
+    return zero, invert(hessian).contiguous()
+
+
 def prepare(tensor: torch.Tensor, hessian: torch.Tensor, hessian_damp: float):
     """sparsegpt.py:45-69: dead columns, damping, inverse factor.  Returns (fp32 working weight, hinv)."""
     weight = tensor.detach().clone()
-    hessian = hessian.to(weight.device).clone()
     if weight.dim() == 4:
         weight = weight.flatten(1)
-    zero = torch.diag(hessian) == 0
-    hessian[zero, zero] = 1
+    zero, hinv = prepare_hessian(hessian.to(weight.device), hessian_damp)
     weight[:, zero] = 0
-    damp = hessian_damp * torch.mean(torch.diag(hessian))
-    diag = torch.arange(weight.size(1), device=hessian.device)
-    hessian[diag, diag] += damp
-    return weight, invert(hessian).contiguous()
+    return weight, hinv
 
 
 @torch.no_grad()
-def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, hessian_inv: torch.Tensor | None = None):
+def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, hessian_inv: torch.Tensor | None = None,
+                     dead_columns: torch.Tensor | None = None):
     """sparsegpt.py:72-133.  The per-column Python loop of the reference is one kernel per column block
     (ops.sgpt_block_sweep); the trailing-block update is an fp32 library GEMM as in the reference.
-    `hessian_inv` short-cuts prepare() with an already prepared factor (tests)."""
+    `hessian_inv` (+ `dead_columns`) short-cuts prepare() with an already prepared factor: tests, and linears that
+    share a Hessian."""
     shape = tensor.size()
     is_nm, n, m = get_nmprune_info(config.get("pattern", _PATTERN_2_4))
     if not is_nm:
@@ -136,6 +145,8 @@ def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, 
         weight, hessian_inv = prepare(tensor, hessian, config.get("hessian_damp", 0.1))
     else:
         weight = tensor.detach().clone().flatten(1) if tensor.dim() == 4 else tensor.detach().clone()
+        if dead_columns is not None:
+            weight[:, dead_columns] = 0
     rows, cols = weight.size()
     col_bs = config.get("col_block_size", 128)
     row_bs = config.get("row_block_size", -1)
@@ -176,14 +187,48 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
         assert forward_loop is not None, "Please provide `data_loader` or `forward_loop`!"
         targets = [(n, m) for n, m in linears if check_weight_size_sgpt(m.weight, cfg["pattern"], n)]
         states = {m: HessianState(m.weight.size(1), m.weight.device) for _, m in targets}
-        handles = [m.register_forward_hook(lambda mod, inp, out: states[mod].update(inp[0] if isinstance(inp, tuple) else inp))
-                   for _, m in targets]
+        # Linears fed by the SAME tensor object (q / k / v, gate / up) have the same Hessian: the first one accumulates
+        # it, the others point at it -- one X^T X, one Cholesky inverse per distinct input instead of one per linear.
+        owner_of: dict = {}
+        last = {"input": None, "owner": None}
+
+        def hook(mod, inp, out):
+            x = inp[0] if isinstance(inp, tuple) else inp
+            owner = last["owner"] if last["input"] is x else None
+            if owner is not None and states[owner]._h.shape == states[mod]._h.shape and owner_of.get(mod, owner) is owner:
+                owner_of[mod] = owner
+                return
+            if mod in owner_of:
+                raise RuntimeError("sparsegpt: a linear that shared its input with another one in an earlier batch got "
+                                   "a different tensor now")
+            states[mod].update(x)
+            last["input"], last["owner"] = x, mod
+
+        handles = [m.register_forward_hook(hook) for _, m in targets]
         try:
             forward_loop(model)
         finally:
             for h in handles:
                 h.remove()
-        masks = {m: create_sgpt_mask(m.weight, states[m].hessian, cfg) for _, m in targets}
+            last["input"] = None
+        for mod in owner_of:
+            states[mod]._h = None  # never written: release
+        prepared: dict = {}
+        users: dict = {}
+        for _, m in targets:
+            own = owner_of.get(m, m)
+            users[own] = users.get(own, 0) + 1
+        masks = {}
+        for _, m in targets:
+            own = owner_of.get(m, m)
+            if own not in prepared:
+                prepared[own] = prepare_hessian(states[own].hessian, cfg["hessian_damp"])
+                states[own]._h = None  # Cin^2 floats: only the inverse factor is needed from here on
+            zero, hinv = prepared[own]
+            masks[m] = create_sgpt_mask(m.weight, None, cfg, hessian_inv=hinv, dead_columns=zero)
+            users[own] -= 1
+            if users[own] == 0:
+                del prepared[own]
     else:
         raise ValueError(f"sparsity mode {mode!r} is outside this path")
     for _, m in targets:

@@ -112,3 +112,42 @@ def test_sparsify_sparsegpt_flow():
     w_before = model2[0].weight.detach().clone()
     sparsity.sparsify(model2, "sparse_magnitude")
     assert torch.equal(model2[0]._weight_mask.cpu(), oracle.mask_2to4(w_before.cpu()))
+
+
+class _Attn(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.q, self.k, self.v = (torch.nn.Linear(256, 128, bias=False) for _ in range(3))
+        self.o = torch.nn.Linear(256, 64, bias=False)
+        self.private = False
+
+    def forward(self, x, y):
+        if self.private:
+            return self.q(x.clone()) + self.k(x.clone()) + self.v(x.clone()), self.o(y)
+        return self.q(x) + self.k(x) + self.v(x), self.o(y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_sparsegpt_hessian_shared_between_linears_with_the_same_input(dtype):
+    """q / k / v read one tensor object: one Hessian accumulation and one inverse factor for the three; the masks equal
+    those of a run where every linear gets a private copy of its input."""
+    torch.manual_seed(3)
+    batches = [(torch.randn(2, 48, 256, device=DEV).to(dtype), torch.randn(2, 48, 256, device=DEV).to(dtype)) for _ in range(3)]
+    results = []
+    for private in (False, True):
+        torch.manual_seed(11)
+        model = _Attn().to(DEV).to(dtype)
+        model.private = private
+        updates, inverts = [], []
+        orig_u, orig_i = sparsity.HessianState.update, sparsity.invert
+        sparsity.HessianState.update = lambda self, x: (updates.append(1), orig_u(self, x))[1]
+        sparsity.invert = lambda h: (inverts.append(1), orig_i(h))[1]
+        try:
+            sparsity.sparsify(model, "sparsegpt", lambda m: [m(*b) for b in batches])
+        finally:
+            sparsity.HessianState.update, sparsity.invert = orig_u, orig_i
+        assert (len(updates), len(inverts)) == ((4 * 3, 4) if private else (2 * 3, 2))
+        results.append({n: m._weight_mask.clone() for n, m in model.named_modules() if hasattr(m, "_weight_mask")})
+    assert set(results[0]) == {"q", "k", "v", "o"}
+    for n in results[0]:
+        assert torch.equal(results[0][n], results[1][n]), n
