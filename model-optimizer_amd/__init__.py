@@ -14,6 +14,7 @@ libmoquant.so (include/moquant.h).  Mirrors the reference's plugin surface for t
   layerwise        layer-by-layer calibration with checkpoint / resume
   export           resmooth / layernorm fusion / INT4 nibble packing of the checkpoint export (byte-identical)
   distributed      bucketed all-reduce of amax / histograms / AWQ statistics (RCCL via torch.distributed)
+  library_ops      torch.library operators (moquant::quantize_op, moquant::dynamic_block_quantize_op) with fake impls
   modelopt_plugin  install() -- the seams into an unmodified modelopt checkout
 No CPU fallback exists: every op raises if the HIP library is missing or a tensor is not on the GPU.
 """
@@ -34,6 +35,7 @@ from . import sparsity  # noqa: F401
 from . import export  # noqa: F401
 from . import qtensor  # noqa: F401
 from . import layerwise  # noqa: F401
+from . import library_ops  # noqa: F401
 from . import modelopt_plugin  # noqa: F401
 from .model_quant import quantize  # noqa: F401
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401

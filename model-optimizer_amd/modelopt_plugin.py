@@ -146,8 +146,20 @@ def _sgpt_hessian_seam(original):
     return classmethod(hook)
 
 
-def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True):
-    """Wire the seams into an importable modelopt.  Returns the list of seams installed."""
+def _library_op_seam(original, ours):
+    def op(inputs, *args, **kwargs):
+        return ours(inputs, *args, **kwargs) if inputs.is_cuda else original(inputs, *args, **kwargs)
+
+    op._moq_seam = True
+    return op
+
+
+def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True,
+            library_ops: bool = False):
+    """Wire the seams into an importable modelopt.  Returns the list of seams installed.  `library_ops` additionally
+    re-points the S2 module globals `tensor_quant.quantize_op / dynamic_block_quantize_op` at the `moquant::`
+    torch.library operators for GPU tensors (redundant with S1 for results; it removes the reference's Python
+    dispatch layers from the call and keeps graphs traceable through our fake implementations)."""
     import modelopt.torch.quantization.extensions as ext  # ImportError if modelopt is absent
 
     installed = []
@@ -188,4 +200,15 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
             sparsegpt.SparseGPTSearcher._hook_compute_hessian = _sgpt_hessian_seam(
                 sparsegpt.SparseGPTSearcher.__dict__["_hook_compute_hessian"])
         installed.append("S5:create_sgpt_mask")
+    if library_ops:
+        from modelopt.torch.quantization import tensor_quant as ref_tq
+
+        from . import library_ops as lo
+
+        if lo.define():
+            if not getattr(ref_tq.quantize_op, "_moq_seam", False):
+                ref_tq.quantize_op = _library_op_seam(ref_tq.quantize_op, lo.quantize_op)
+                ref_tq.dynamic_block_quantize_op = _library_op_seam(ref_tq.dynamic_block_quantize_op,
+                                                                    lo.dynamic_block_quantize_op)
+            installed.append("S2:library_ops")
     return installed

@@ -285,3 +285,19 @@ def test_two_level_block_format_flow_and_dynamic_type():
     for b in batches:
         assert_bits_equal(q(b), ops.scaled_e4m3(b, ops.reduce_amax(b)), "dynamic per-tensor FP8")
     assert q.amax is None
+
+
+def test_library_ops_on_gpu_and_under_fake_tensor_tracing():
+    from model_optimizer_amd import library_ops as lo
+    x = (torch.randn(8, 128, device=DEV) * 3).to(torch.bfloat16)
+    amax = x.abs().amax().float()
+    assert_bits_equal(lo.quantize_op(x, amax, 8, 4, False, False), ops.scaled_e4m3(x, amax), "fp8 through the library op")
+    assert_bits_equal(lo.quantize_op(x, amax, 4, 0, False, False), ops.fake_tensor_quant(x, amax, 4, False, False), "int4")
+    assert_bits_equal(lo.dynamic_block_quantize_op(x, 32, None, 4, 2, 9, 8), ops.fused_amax_convert(x, 32, "E2M1"), "mxfp4")
+    assert_bits_equal(lo.dynamic_block_quantize_op(x, 16, amax, 4, 2, 8, 4),
+                      ops.fused_amax_convert(x, 16, "E2M1", "E4M3", amax), "two-level fp4")
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode(allow_non_fake_inputs=True) as mode:
+        fx = mode.from_tensor(x)
+        fy = torch.ops.moquant.quantize_op(fx, mode.from_tensor(amax), 8, 4, False, False)
+        assert fy.shape == x.shape and fy.dtype == x.dtype

@@ -146,7 +146,7 @@ def test_modelopt_seams_install():
     for fn, names in [(ext.get_cuda_ext, ["fake_tensor_quant", "fake_tensor_quant_", "fake_tensor_quant_with_axis",
                                           "INT4_quantize", "INT4_dequantize", "NF4_quantize", "NF4_dequantize"]),
                       (ext.get_cuda_ext_fp8, ["fake_e4m3fy", "fake_e4m3fy_with_axis"]),
-                      (ext.get_cuda_ext_mx, ["fused_amax_convert", "Types"])]:
+                      (ext.get_cuda_ext_mx, ["fused_amax_convert", "convert_to_exmy", "Types"])]:
         for n in names:
             assert hasattr(fn(), n), f"adapter lacks {n}"
     assert ext.get_cuda_ext_mx().Types.E2M1 == 6 and ext.get_cuda_ext_mx().Types.E8M0 == 9  # tensor_quant_mx.h:39
@@ -159,6 +159,17 @@ def test_modelopt_seams_install():
     m = torch.nn.Sequential(torch.nn.Linear(16, 16))
     mtq.quantize(m, mtq.INT8_DEFAULT_CFG, lambda mod: mod(torch.randn(2, 16)))
     assert m[0].weight_quantizer.amax is not None
+    # S2 (opt-in): the module-level operators are re-pointed; CPU tensors still reach the reference's implementation
+    from modelopt.torch.quantization import tensor_quant as ref_tensor_quant
+    assert "S2:library_ops" in moa.modelopt_plugin.install(library_ops=True)
+    assert getattr(ref_tensor_quant.quantize_op, "_moq_seam", False)
+    # a CPU tensor still takes the reference's own operator -- which, with an extension module present (S1), hands it
+    # to the extension and gets the extension's "must be a GPU tensor" RuntimeError, exactly as with the CUDA build
+    with pytest.raises(RuntimeError, match="GPU"):
+        ref_tensor_quant.quantize_op(x, x.abs().max(), 8, 0, False, True)
+    m2 = torch.nn.Sequential(torch.nn.Linear(16, 16))
+    mtq.quantize(m2, mtq.INT8_DEFAULT_CFG, lambda mod: mod(torch.randn(2, 16)))
+    assert torch.isfinite(m2(torch.randn(2, 16))).all()
     # SparseGPT seams: CPU tensors keep running the reference's own code through the re-pointed functions
     from modelopt.torch.sparsity.weight_sparsity import sparsegpt
 
@@ -293,3 +304,23 @@ def test_grouped_quantizer_container():
     model_quant.set_quantizer_by_cfg(m, {"*weight_quantizer": {"num_bits": (4, 3), "axis": None}})
     assert all(tuple(q._num_bits) == (4, 3) for q in g) and isinstance(m.weight_quantizer, GroupedQuantizer)
     assert isinstance(GroupedQuantizer(SequentialQuantizer(TensorQuantizer(), TensorQuantizer()))[0], SequentialQuantizer)
+
+
+def test_library_ops_schema_and_fake_implementations():
+    """moquant::quantize_op / moquant::dynamic_block_quantize_op (S2 mirror): defined once, schemas as the reference's
+    tensorrt:: operators, fake implementations give shape / dtype without touching a kernel (meta tensors)."""
+    from model_optimizer_amd import library_ops as lo
+    assert lo.define() and lo.define()
+    s1 = torch.ops.moquant.quantize_op.default._schema
+    assert [a.name for a in s1.arguments] == ["input", "amax", "num_bits", "exponent_bits", "unsigned", "narrow_range"]
+    s2 = torch.ops.moquant.dynamic_block_quantize_op.default._schema
+    assert [a.name for a in s2.arguments] == ["input", "block_size", "amax", "num_bits", "exponent_bits", "scale_num_bits",
+                                              "scale_exponent_bits"]
+    x = torch.empty(4, 64, dtype=torch.bfloat16, device="meta")
+    y = torch.ops.moquant.quantize_op(x, torch.empty((), device="meta"), 8, 4, False, False)
+    assert y.shape == x.shape and y.dtype == x.dtype and y.device.type == "meta"
+    y = torch.ops.moquant.dynamic_block_quantize_op(x, 32, None, 4, 2, 9, 8)
+    assert y.shape == x.shape and y.dtype == x.dtype
+    assert lo._formats(4, 2, 9, 8) == ((2, 1), (8, 0)) and lo._formats(4, 2, 8, 4) == ((2, 1), (4, 3))  # E + M + 1 bits
+    with pytest.raises(NotImplementedError):
+        torch.ops.moquant.quantize_op(torch.zeros(4), torch.ones(()), 8, 0, False, True)  # no CPU implementation
