@@ -92,3 +92,21 @@ def test_layerwise_resume(tmp_path):
         assert torch.equal(a[k], b[k]), f"{k}: resumed run differs"
     assert layerwise.layerwise_calibrate(m2, lambda m: [m(b) for b in batches], model_calib.max_calibrate,
                                          checkpoint_dir=str(tmp_path)) == 0
+
+
+@pytest.mark.parametrize("search", ["gram", "gemm"])
+def test_layerwise_awq_lite_equals_whole_model(search):
+    """awq_lite as the per-layer calibration function (how a model whose Gram matrices do not all fit at once --
+    Llama-3-70B: 263 GB -- still takes the Gram search: one layer's matrices are alive at a time).  The layer inputs
+    come from the un-quantized previous layers, as in the whole-model pass, so alphas and folded weights agree."""
+    model, batches = _setup(model_quant.INT4_AWQ_CFG)
+    whole = copy.deepcopy(model)
+    hw = model_calib.awq_lite(whole, lambda m: [m(b) for b in batches], search=search)
+    n = layerwise.layerwise_calibrate(model, lambda m: [m(b) for b in batches], model_calib.awq_lite, search=search)
+    assert n == 4 and len(hw) == 8
+    for (name, a), (_, b) in zip(whole.layers.named_modules(), model.layers.named_modules()):
+        if hasattr(a, "awq_lite"):
+            assert a.awq_lite.best_alpha == b.awq_lite.best_alpha, name
+            assert torch.equal(a.weight, b.weight), name
+            assert torch.equal(a.input_quantizer.pre_quant_scale, b.input_quantizer.pre_quant_scale), name
+            assert torch.equal(a.weight_quantizer.amax, b.weight_quantizer.amax), name
