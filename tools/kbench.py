@@ -44,6 +44,9 @@ def main():
     q4 = ops.int4_quantize(w.view(-1), scales, 128)
     counts = torch.zeros(2048, dtype=torch.int64, device=DEV)
     xmax = float(x.float().abs().max())
+    s448 = (amax1 / 448.0).to(torch.bfloat16)
+    s_tile = (ops.reduce_block_amax(w, {-1: 128, -2: 128}).float() / 448.0).to(torch.bfloat16)
+    q8t = ops.fp8_quantize_tile(w, s_tile, 128, 128).view(torch.uint8)
     cases = [
         ("moq_amax (per-tensor)", lambda: ops.reduce_amax(w), 2 * n),
         ("moq_amax_axis rows (per-channel, axis 0)", lambda: ops.reduce_amax(w, axis=(1,)), 2 * n),
@@ -66,6 +69,15 @@ def main():
         ("moq_int4_pack_export", lambda: ops.pack_int4_in_uint8(w, wsf), 2.5 * n + 4 * n / 128),
         ("moq_hist_abs 2048 bins", lambda: ops.hist_abs(x, 2048, xmax, False, counts), 2 * nx),
         ("moq_rescale_cols", lambda: ops.rescale_cols(w, s_col, s_col), 4 * n),
+        ("moq_block2d amax 128x128 tiles (reduce_block_amax)", lambda: ops.reduce_block_amax(w, {-1: 128, -2: 128}), 2 * n),
+        ("moq_block2d FP8 amax + QDQ 128x128 tiles", lambda: ops.block2d(w.view(rows // 128, 128, cols // 128, 128), 2), 4 * n),
+        ("moq_fp8_pack per-tensor (qtensor / export)", lambda: ops.fp8_quantize(w, s448), 3 * n),
+        ("moq_fp8_pack_tile 128x128 (fp8_pb_wo export)", lambda: ops.fp8_quantize_tile(w, s_tile, 128, 128), 3 * n),
+        ("moq_fp8_unpack_tile 128x128", lambda: ops.fp8_dequantize_tile(q8t, s_tile, torch.bfloat16, 128, 128), 3 * n),
+        ("moq_mxfp4_pack g=32", lambda: ops.mxfp4_quantize(w, 32), 2.5 * n + n / 32),
+        ("moq_row_hist_np 2048 bins per channel (calibrate_weights)", lambda: ops.row_hist_np(w, 2048), 4 * n),
+        ("moq_amax_mid (block amax over a middle dim)", lambda: ops.reduce_block_amax(w.view(rows // 64, 64, cols), {1: 64}), 2 * n),
+        ("moq_mx_fused_amax_convert E2M1 / E4M3 scales g=16 (two-level)", lambda: ops.fused_amax_convert(w, 16, "E2M1", "E4M3", amax1), 4 * n),
     ]
     print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|")
