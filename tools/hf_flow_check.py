@@ -1,0 +1,74 @@
+"""End-to-end flow on a Hugging Face Llama with Llama-3-8B layer shapes (random init, `--layers` decoder layers):
+quantize (FP8 W + A, FP8 KV cache, max calibration; or INT4-AWQ) on synthetic token batches, then build the checkpoint
+tensors.  A timing / integration check at real shapes, not a parity test (those use the reference-run fixtures)."""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import _moa_import  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--batches", type=int, default=4)
+    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "mxfp4"])
+    args = ap.parse_args()
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    moa = _moa_import.load()
+    mq = moa.model_quant
+    dev = torch.device("cuda:0")
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
+                      num_key_value_heads=8, vocab_size=128256, max_position_embeddings=8192, architectures=["LlamaForCausalLM"])
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    batches = [torch.randint(0, cfg.vocab_size, (8, 512), device=dev, generator=torch.Generator(device=dev).manual_seed(i))
+               for i in range(args.batches)]
+
+    def loop(m):
+        with torch.no_grad():
+            for b in batches:
+                m(b)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(model)
+    torch.cuda.synchronize()
+    t_plain = time.perf_counter() - t0
+    qcfg = {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
+            "int4_awq": mq.INT4_AWQ_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG}[args.qformat]
+    t0 = time.perf_counter()
+    moa.quantize(model, qcfg, loop)
+    torch.cuda.synchronize()
+    t_quant = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        logits = model(batches[0]).logits
+    torch.cuda.synchronize()
+    t_fq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    state = moa.export.export_state_dict(model, torch.bfloat16,
+                                         (lambda: model(torch.ones([1, 2], dtype=torch.long, device=dev)))
+                                         if args.qformat == "int4_awq" else None)
+    torch.cuda.synchronize()
+    t_export = time.perf_counter() - t0
+    n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
+    print(json.dumps({"qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
+                      "plain_forward_loop_s": round(t_plain, 3), "quantize_s": round(t_quant, 3),
+                      "fake_quant_forward_s": round(t_fq, 3), "export_state_dict_s": round(t_export, 3),
+                      "enabled_quantizers": n_q, "exported_tensors": len(state),
+                      "logits_finite": bool(torch.isfinite(logits).all()),
+                      "kv_cache_quant_algo": moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"]}))
+
+
+if __name__ == "__main__":
+    main()
