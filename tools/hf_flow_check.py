@@ -20,8 +20,10 @@ def main():
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "mxfp4"])
+    ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
+                    help="mixtral: 8 experts per layer with fused 3-D expert weights (Mixtral-8x7B layer shapes)")
     args = ap.parse_args()
-    from transformers import LlamaConfig, LlamaForCausalLM
+    from transformers import LlamaConfig, LlamaForCausalLM, MixtralConfig, MixtralForCausalLM
 
     moa = _moa_import.load()
     mq = moa.model_quant
@@ -29,8 +31,12 @@ def main():
     cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
                       num_key_value_heads=8, vocab_size=128256, max_position_embeddings=8192, architectures=["LlamaForCausalLM"])
     torch.manual_seed(1234)
+    if args.arch == "mixtral":
+        cfg = MixtralConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
+                            num_key_value_heads=8, vocab_size=32000, max_position_embeddings=8192, num_local_experts=8,
+                            num_experts_per_tok=2, architectures=["MixtralForCausalLM"])
     with torch.device(dev):
-        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+        model = (MixtralForCausalLM if args.arch == "mixtral" else LlamaForCausalLM)(cfg).to(torch.bfloat16).eval()
     batches = [torch.randint(0, cfg.vocab_size, (8, 512), device=dev, generator=torch.Generator(device=dev).manual_seed(i))
                for i in range(args.batches)]
 
@@ -62,7 +68,7 @@ def main():
     torch.cuda.synchronize()
     t_export = time.perf_counter() - t0
     n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
-    print(json.dumps({"qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
+    print(json.dumps({"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
                       "plain_forward_loop_s": round(t_plain, 3), "quantize_s": round(t_quant, 3),
                       "fake_quant_forward_s": round(t_fq, 3), "export_state_dict_s": round(t_export, 3),
                       "enabled_quantizers": n_q, "exported_tensors": len(state),
