@@ -324,3 +324,61 @@ def test_library_ops_schema_and_fake_implementations():
     assert lo._formats(4, 2, 9, 8) == ((2, 1), (8, 0)) and lo._formats(4, 2, 8, 4) == ((2, 1), (4, 3))  # E + M + 1 bits
     with pytest.raises(NotImplementedError):
         torch.ops.moquant.quantize_op(torch.zeros(4), torch.ones(()), 8, 0, False, True)  # no CPU implementation
+
+
+def test_host_helpers_agree_with_the_reference_functions():
+    """Pure-host helpers (no kernel) against the reference's own functions, called directly on CPU (build container only):
+    quantizer-name normalisation, block padding, reduce-axis conversion, percentile / entropy threshold searches, the
+    KV-cache key post-processing of the checkpoint export."""
+    sys.path.insert(0, GOLDEN)
+    import ref_shim
+
+    if not ref_shim.reference_available():
+        pytest.skip("reference checkout not present (GPU box)")
+    ref_shim.install()
+    from modelopt.torch.export import quant_utils as ref_export
+    from modelopt.torch.quantization import conversion as ref_conv
+    from modelopt.torch.quantization.calib import histogram as ref_hist
+    from modelopt.torch.quantization.utils import core_utils as ref_core
+
+    from model_optimizer_amd import export as our_export
+    from model_optimizer_amd import ops as our_ops
+
+    names = ["model.layers.0.mlp.experts.gate_up_proj_weight_quantizers.3", "a.b.down_proj_input_quantizer",
+             "x.weight_quantizer.0", "x.weight_quantizer.12.inner", "y.input_quantizers.7", "z.weight_quantizers",
+             "w.k_bmm_quantizer", "experts.10.w1.weight_quantizer", "q.weight_quantizers.0.1"]
+    for n in names:
+        assert model_quant._normalize_fused_experts_quantizer_name(n) == ref_conv._normalize_fused_experts_quantizer_name(n), n
+    gen = torch.Generator().manual_seed(0)
+    for shape, blocks in [((5, 7), {-1: 4, -2: 2}), ((3, 10, 33), {-1: 16}), ((8, 8), {-1: 4, -2: 4}), ((2, 3, 5, 9), {1: 2, -1: 4})]:
+        x = torch.randn(*shape, generator=gen)
+        assert torch.equal(our_ops.reduce_block_padding(x, blocks), ref_core.reduce_block_padding(x, blocks))
+        assert torch.equal(our_ops.reduce_block_padding(x, blocks, 1.5), ref_core.reduce_block_padding(x, blocks, 1.5))
+    for nd in (1, 2, 4):
+        x = torch.zeros(*([2] * nd))
+        for axis in [None, 0, -1, (0,), tuple(range(nd))]:
+            got = calib.convert_quantization_axis_to_reduce_axis(x, axis)
+            assert got == ref_core.convert_quantization_axis_to_reduce_axis(x, axis), (nd, axis)
+    rng = np.random.default_rng(5)
+    for nb in (512, 2048):
+        hist = (rng.exponential(1.0, nb) * 1e5 * np.exp(-np.arange(nb) / (nb / 5))).astype(np.int64)
+        hist[rng.integers(0, nb, nb // 20)] = 0
+        edges = np.linspace(0, 3.0, nb + 1, dtype=np.float32)
+        for pct in (99.0, 99.99, 50.0):
+            assert torch.equal(calib._compute_amax_percentile(hist, edges, pct), ref_hist._compute_amax_percentile(hist, edges, pct))
+        assert torch.equal(calib._compute_amax_entropy(hist, edges, 8, False, 4, 128),
+                           ref_hist._compute_amax_entropy(hist, edges, 8, False, 4, 128))
+        assert torch.equal(calib._compute_amax_entropy(hist, edges, 8, True, 16, 64),
+                           ref_hist._compute_amax_entropy(hist, edges, 8, True, 16, 64))
+    keys = {"model.layers.0.self_attn.k_bmm_quantizer._amax": torch.tensor(3.5),
+            "model.layers.0.self_attn.v_bmm_quantizer._amax": torch.tensor(100.0),
+            "model.layers.0.self_attn.q_bmm_quantizer._amax": torch.tensor(1.0),
+            "model.layers.0.self_attn.o_proj.output_quantizer._amax": torch.tensor(1.0),
+            "model.layers.0.input_layernorm.weight": torch.ones(4),
+            "model.layers.0.mlp.gate.weight": torch.ones(2, 2)}
+    for k, v in keys.items():
+        ours = our_export._postprocess_kv_key(k, v, "FP8")
+        ref = ref_export._postprocess_single_tensor(k, v, 448.0, "FP8")
+        assert ours[0] == ref[0], k
+        if ref[0] is not None:
+            assert torch.equal(ours[1], ref[1]), k
