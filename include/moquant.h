@@ -341,6 +341,9 @@ int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void* out, int6
 /* y[c, r] = x[r, c] for 2-byte elements (bf16 / f16): turns an activation batch [tokens, cin] into the
  * K-contiguous operand [cin, tokens] of moq_hessian_accum. */
 int moq_transpose16(const void* x, void* y, int64_t rows, int64_t cols, void* stream);
+/* The same with a leading dimension for y (y[c * y_ld + r] = x[r, c], y_ld >= rows): transposes a calibration batch
+ * straight into a column block of a wider [cols, y_ld] staging buffer (several batches per moq_hessian_accum launch). */
+int moq_transpose16_ld(const void* x, void* y, int64_t rows, int64_t cols, int64_t y_ld, void* stream);
 /* hessian[i, j] = hessian[i, j] * decay + scale * sum_t xt[i, t] * xt[j, t]   (fp32 [cin, cin], updated in place)
  * on the matrix cores: bf16 / f16 products are exact in fp32, accumulation is fp32 -- the arithmetic of the
  * reference's fp32 `inp.matmul(inp.t())` up to summation order (only the tiles on or above the diagonal are

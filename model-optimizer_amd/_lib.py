@@ -89,6 +89,7 @@ SIGNATURES = {
     "moq_mxfp4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "moq_mxfp4_unpack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "moq_transpose16": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "moq_transpose16_ld": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "moq_hessian_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_float, c_float, c_int, c_void_p]),
     "moq_symmetrize": (c_int, [c_void_p, c_int64, c_void_p]),
     "moq_sgpt_block_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,

@@ -80,9 +80,10 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
 }
 
 // y[c, r] = x[r, c] for 16-bit elements through a 64 x 64 LDS tile (+1 column of padding: conflict-free columns)
+// y_ld: leading dimension of y (>= rows): y may be a column block of a wider [cols, y_ld] staging buffer
 __global__ __launch_bounds__(kBlock) void transpose16_kernel(const uint16_t* __restrict__ x,
                                                              uint16_t* __restrict__ y, int64_t rows,
-                                                             int64_t cols) {
+                                                             int64_t cols, int64_t y_ld) {
   __shared__ uint16_t tile[64][66];
   const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBlock) void transpose16_kernel(const uint16_t* __r
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int64_t c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) y[c * rows + r] = tile[tx][i];
+    if (c < cols && r < rows) y[c * y_ld + r] = tile[tx][i];
   }
 }
 
@@ -124,8 +125,12 @@ extern "C" int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t 
   return check_launch("moq_sgpt_block_sweep");
 }
 
+extern "C" int moq_transpose16_ld(const void* x, void* y, int64_t rows, int64_t cols, int64_t y_ld, void* stream);
 extern "C" int moq_transpose16(const void* x, void* y, int64_t rows, int64_t cols, void* stream) {
-  if (rows < 0 || cols < 0 || (rows * cols > 0 && (x == nullptr || y == nullptr))) {
+  return moq_transpose16_ld(x, y, rows, cols, rows, stream);
+}
+extern "C" int moq_transpose16_ld(const void* x, void* y, int64_t rows, int64_t cols, int64_t y_ld, void* stream) {
+  if (rows < 0 || cols < 0 || y_ld < rows || (rows * cols > 0 && (x == nullptr || y == nullptr))) {
     set_error("moq_transpose16: bad arguments");
     return MOQ_ERR_INVALID;
   }
@@ -136,6 +141,6 @@ extern "C" int moq_transpose16(const void* x, void* y, int64_t rows, int64_t col
     return MOQ_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, S(stream),
-                     reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), rows, cols);
+                     reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), rows, cols, y_ld);
   return check_launch("moq_transpose16");
 }

@@ -287,6 +287,8 @@ class AWQLiteHelper:
         self.gram = None
         self.use_gram = False
         self.gram_owner = None  # the helper whose Gram matrix this one aliases (same input tensor)
+        self.gram_stage = None  # ops.GramStage: several calibration batches per Gram launch
+        self.gram_stage_denied = False
         self.gram_symmetrized = False
 
     def search_operands(self, module):
@@ -400,7 +402,16 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                     raise RuntimeError("awq_lite (Gram search): a linear that shared its input with another one in an "
                                        "earlier batch got a different tensor now; use search='gemm' for this model")
                 if x2.dtype in (torch.bfloat16, torch.float16):
-                    ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)  # G += X^T X / T_b (MFMA)
+                    # G += X^T X / T_b on the matrix cores; several batches per launch when the staging buffer fits
+                    if h.gram_stage is None and not h.gram_stage_denied:
+                        if budget.reserve(ops.GramStage.nbytes(x2.shape[1], x2.shape[0])):
+                            h.gram_stage = ops.GramStage(h.gram, x2.shape[0], x2.dtype)
+                        else:
+                            h.gram_stage_denied = True
+                    if h.gram_stage is not None:
+                        h.gram_stage.add(x2)
+                    else:
+                        ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)
                 else:
                     xf = x2.float()
                     h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
@@ -430,6 +441,10 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         forward_loop(model)  # cache pass
         state.pop("gram_input", None)
         state.pop("gram_owner", None)
+        for h in helpers.values():
+            if h.gram_stage is not None:
+                h.gram_stage.flush()
+                h.gram_stage = None
         for h in helpers.values():
             if h.num_cache_steps:
                 h.act_scale = h.act_sum / h.num_cache_steps
