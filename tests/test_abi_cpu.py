@@ -43,6 +43,21 @@ def test_argument_validation_without_gpu():
     assert lib.moq_mx_fused_amax_convert(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 32, 32, 2, 6, _lib.MX_TYPES["E8M0"],
                                          ctypes.c_void_p(16), None) \
         == _lib.MOQ_ERR_UNSUPPORTED  # E8M0 block scales take no global amax -> loud
+    # the entries added later in the round: argument checks happen before any HIP call
+    P = ctypes.c_void_p(16)
+    assert lib.moq_row_hist_np(P, 4, 64, _lib.BF16, 0, P, P, P, None) == _lib.MOQ_ERR_INVALID           # bins <= 0
+    assert lib.moq_row_hist_np(P, 70000, 64, _lib.BF16, 2048, P, P, P, None) == _lib.MOQ_ERR_UNSUPPORTED  # rows > 65535
+    assert lib.moq_row_hist_np(None, 0, 64, _lib.BF16, 2048, None, None, None, None) == _lib.MOQ_OK      # empty: nothing to do
+    assert lib.moq_fp8_pack_tile(P, P, _lib.F16, P, 256, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_INVALID  # scale dtype
+    assert lib.moq_fp8_pack_tile(P, P, _lib.BF16, P, 200, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_UNSUPPORTED  # ragged tiles
+    assert lib.moq_fp8_unpack_tile(None, P, P, 256, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_INVALID
+    assert lib.moq_amax_mid(P, 4, 0, 8, _lib.BF16, P, None) == _lib.MOQ_ERR_INVALID                      # empty reduced dim
+    assert lib.moq_amax_mid(None, 0, 4, 8, _lib.BF16, None, None) == _lib.MOQ_OK
+    assert lib.moq_mx_convert(P, P, 8, 99, None) == _lib.MOQ_ERR_INVALID                                  # unknown format
+    assert lib.moq_mx_convert(None, None, 0, _lib.MX_TYPES["E2M1"], None) == _lib.MOQ_OK
+    assert lib.moq_transpose16_ld(P, P, 64, 32, 63, None) == _lib.MOQ_ERR_INVALID                         # y_ld < rows
+    assert lib.moq_mt_amax_ws(P, P, 3, 10, _lib.BF16, None, None) == _lib.MOQ_ERR_INVALID                 # no scratch
+    assert b"chunk_scratch" in lib.moq_last_error()
     with pytest.raises(ValueError):
         _lib.check(_lib.MOQ_ERR_UNSUPPORTED)
     with pytest.raises(RuntimeError):
