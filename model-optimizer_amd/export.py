@@ -336,6 +336,10 @@ def export_quantized_weight(module, dtype: torch.dtype):
                         else (amax.cpu() / wq.maxbound).to(amax.device))
     else:
         weight_scale = get_weight_scaling_factor(module)
+        if fmt in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO) and weight_scale.dim() > 1:
+            # per-channel amax is kept as [Cout, 1]; the checkpoint stores [Cout] (export_amax squeezes the kept-dims
+            # shape, tensor_quantizer.py:1087-1117) and to_quantized_weight divides by wsf[:, None]
+            weight_scale = weight_scale.reshape(-1)
     if iq.is_enabled and iq.amax is not None:
         out["input_scale"] = get_scaling_factor(iq).squeeze()
     out["weight"] = to_quantized_weight(module.weight.detach().to(dtype), weight_scale, fmt)

@@ -228,14 +228,25 @@ class TensorQuantizer(nn.Module):
         self.amax = calib_amax
 
     def export_amax(self):
-        """tensor_quantizer.py:1087-1117: 0 / NaN entries are replaced by maxbound; static last-axis block
-        amax is reshaped to (*shape[:-1], -1)."""
+        """tensor_quantizer.py:1087-1117: 0 / NaN entries are replaced by maxbound, values clamped to the dtype's
+        finite positive range; static last-axis block amax is reshaped to (*shape[:-1], -1); without blocks a per-tensor
+        amax gets a leading dim (runtimes expect dim >= 1) and a single-axis amax is squeezed to 1-D."""
+        if self._block_dynamic:
+            return self.amax
         if self.amax is None:
             return None
         amax = self.amax.detach().clone()
-        amax[(amax == 0) | torch.isnan(amax)] = self.maxbound
         if hasattr(self, "_amax_shape_for_export"):
             amax = amax.reshape(self._amax_shape_for_export)
+        amax[(amax == 0) | torch.isnan(amax)] = self.maxbound
+        fi = torch.finfo(amax.dtype)
+        amax = amax.clamp(min=fi.tiny, max=fi.max)
+        if self._block_sizes is None:
+            if self._axis is None:
+                if amax.dim() == 0:
+                    amax = amax.unsqueeze(0)
+            elif isinstance(self._axis, int) or (isinstance(self._axis, (list, tuple)) and len(self._axis) == 1):
+                amax = amax.squeeze()
         return amax
 
     def sync_amax_across_distributed_group(self, group=None):

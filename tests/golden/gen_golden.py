@@ -27,6 +27,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
   calibrate_weights.npz -- calib.calibrate_weights per-channel / per-tensor percentile amax + numpy's channel histograms
   export_llama_fp8_2d.npz -- FP8 2-D blockwise weight-only export of a tiny Llama + FP8QTensor with blocks on both axes
+  export_llama_int8_sq.npz -- INT8 SmoothQuant export of the tiny Llama (pre-export state + exported tensors)
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
@@ -974,14 +975,58 @@ def gen_export_fp8_2d(out):
     out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg, qt=qt_cases)))
 
 
+def gen_export_int8_sq(out):
+    """INT8 SmoothQuant (INT8_SMOOTHQUANT_CFG: per-channel INT8 weights, per-tensor INT8 inputs, alpha = 1.0) checkpoint
+    export of the tiny bf16 Llama by the reference: the calibrated state right before export (smoothed weights,
+    per-channel weight amax, input amax, pre_quant_scale, norm weights) and every exported tensor (W8A8_SQ_PER_CHANNEL)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    model = LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)).to(torch.bfloat16)
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    for i, b in enumerate(batches):
+        out[f"tokens{i}"] = b.numpy()
+    q = mtq.quantize(model, mtq.INT8_SMOOTHQUANT_CFG, lambda m: [m(b) for b in batches])
+    linears = []
+    for n, m in q.named_modules():
+        if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
+            linears.append(n)
+            out[f"pre/{n}.weight"] = bits(m.weight)
+            out[f"pre/{n}.w_amax"] = bits(m.weight_quantizer._amax.float())
+            out[f"pre/{n}.in_amax"] = bits(m.input_quantizer._amax.float())
+            out[f"pre/{n}.pre_quant_scale"] = bits(m.input_quantizer._pre_quant_scale)
+        elif type(m).__name__.endswith("RMSNorm"):
+            out[f"pre/{n}.weight"] = bits(m.weight)
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = t.view(torch.uint8).numpy().copy() if t.dtype == torch.int8 else bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), linears=linears, dtypes=dtypes,
+                                             hf_quant_config=quant_cfg)))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")
