@@ -23,6 +23,7 @@ from torch import nn
 from . import ops
 from .hf_experts import is_quant_fused_experts
 from .nn import is_quantized_linear
+from .tensor_quantizer import SequentialQuantizer
 
 QUANTIZATION_NONE = None
 QUANTIZATION_FP8 = "fp8"
@@ -40,6 +41,10 @@ def get_quantization_format(module) -> str | None:
     wq, iq = module.weight_quantizer, module.input_quantizer
     if not wq.is_enabled:
         return QUANTIZATION_NONE
+    if isinstance(wq, SequentialQuantizer):
+        # W4A8 (INT4 blocks -> FP8) needs its own packing and a second scale (QUANTIZATION_W4A8_AWQ,
+        # export/quant_utils.py:519-526); exporting the first stage alone would silently drop the FP8 stage
+        raise NotImplementedError("export of a SequentialQuantizer weight format (W4A8) is outside this path")
     nb = wq._num_bits
     if nb == 4 and wq.is_static_block_quant:
         return QUANTIZATION_INT4_AWQ

@@ -382,3 +382,28 @@ def test_host_helpers_agree_with_the_reference_functions():
         assert ours[0] == ref[0], k
         if ref[0] is not None:
             assert torch.equal(ours[1], ref[1]), k
+
+
+def test_export_refuses_formats_it_does_not_pack():
+    """get_quantization_format: a W4A8 SequentialQuantizer weight format raises instead of exporting its first stage
+    only; disabled weight quantizers export the plain weight; NVFP4-layout blocks are refused too."""
+    from model_optimizer_amd import export, nn as mnn
+    m = torch.nn.Sequential(torch.nn.Linear(128, 64, bias=False))
+    mnn.replace_quant_module(m)
+    model_quant.set_quantizer_by_cfg(m, model_quant.W4A8_MAX_CFG["quant_cfg"])
+    with pytest.raises(NotImplementedError, match="W4A8"):
+        export.get_quantization_format(m[0])
+    model_quant.set_quantizer_by_cfg(m, {"*weight_quantizer": {"enable": False}})
+    assert export.get_quantization_format(m[0]) is export.QUANTIZATION_NONE
+    m2 = torch.nn.Sequential(torch.nn.Linear(128, 64, bias=False))
+    mnn.replace_quant_module(m2)
+    model_quant.set_quantizer_by_cfg(m2, model_quant.NVFP4_DEFAULT_CFG["quant_cfg"])
+    with pytest.raises(NotImplementedError):
+        export.get_quantization_format(m2[0])
+    for cfg, want in [(model_quant.INT8_DEFAULT_CFG, "int8_sq"), (model_quant.FP8_DEFAULT_CFG, "fp8"),
+                      (model_quant.INT4_AWQ_CFG, "int4_awq"), (model_quant.MXFP4_DEFAULT_CFG, "mxfp4"),
+                      (model_quant.FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG, "fp8_pb_wo")]:
+        m3 = torch.nn.Sequential(torch.nn.Linear(128, 64, bias=False))
+        mnn.replace_quant_module(m3)
+        model_quant.set_quantizer_by_cfg(m3, cfg["quant_cfg"])
+        assert export.get_quantization_format(m3[0]) == want, want
