@@ -1,0 +1,142 @@
+"""The whole Python host on CPU, through a host-memory stand-in for the C-ABI (tests/hostmem_backend.py: every
+`moq_*` call is served by the oracle's C restatement on host pointers): calibration flows and checkpoint exports on
+the tiny Llama / Mixtral of the fixtures, compared with what the reference produced -- on this same kind of CPU, so
+activations agree bit for bit and the comparisons are exact where the GPU tests need a tolerance.
+
+What this tier adds: host-side bugs (shapes, scale layouts, key names, promotion rules) are caught without a GPU.
+What it does not claim: anything about the HIP kernels -- those are the `-m gpu` tests."""
+
+import numpy as np
+import pytest
+import torch
+
+import _moa_import
+import hostmem_backend
+from conftest import from_bits
+
+moa = _moa_import.load()
+
+_TD = {"torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32, "torch.uint8": torch.uint8,
+       "torch.float16": torch.float16}
+
+
+@pytest.fixture
+def hostmem(monkeypatch):
+    return hostmem_backend.install(monkeypatch, moa)
+
+
+def _llama(g, cases, dtype, impl=None):
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **cases["config"])
+    if impl:
+        cfg._attn_implementation = impl
+    model = LlamaForCausalLM(cfg).to(dtype)
+    sd = {k[len("orig/"):]: from_bits(g.raw(k), dtype) for k in g.z.files if k.startswith("orig/")}
+    assert not model.load_state_dict(sd, strict=False).unexpected_keys
+    return model.eval()
+
+
+def _compare_state(state, g, cases, exact=True):
+    assert sorted(state) == sorted(cases["dtypes"]), set(state) ^ set(cases["dtypes"])
+    for key, dts in cases["dtypes"].items():
+        if f"exp/{key}" not in g.z.files:
+            continue
+        got = state[key].detach().cpu().contiguous()
+        raw = g.raw(f"exp/{key}")
+        if dts in ("torch.float8_e4m3fn", "torch.int8", "torch.uint8"):
+            assert np.array_equal(got.view(torch.uint8).numpy().reshape(raw.shape), raw), f"{key}: bytes differ"
+        else:
+            want = from_bits(raw, _TD[dts])
+            assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{key}: {got.dtype} {tuple(got.shape)}"
+            assert torch.equal(got.reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), key
+
+
+def test_fp8_calibration_and_export_equal_reference(golden, hostmem):
+    """FP8 W + A max calibration of the tiny bf16 Llama from the ORIGINAL weights and tokens, then the checkpoint:
+    every amax and every exported tensor equals the reference run."""
+    g = golden("export_llama_fp8")
+    cases = g.cases
+    model = _llama(g, cases, torch.bfloat16)
+    batches = [torch.from_numpy(g.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    with torch.no_grad():
+        moa.quantize(model, moa.model_quant.FP8_DEFAULT_CFG, lambda m: [m(b) for b in batches])
+    for name in cases["linears"]:
+        lin = model.get_submodule(name)
+        assert torch.equal(lin.weight_quantizer._amax.float().reshape(-1), from_bits(g.raw(f"pre/{name}.w_amax"), torch.float32).reshape(-1)), name
+        assert torch.equal(lin.input_quantizer._amax.float().reshape(-1), from_bits(g.raw(f"pre/{name}.in_amax"), torch.float32).reshape(-1)), name
+    state = moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    _compare_state(state, g, cases)
+
+
+def test_int8_smoothquant_flow_and_export_equal_reference(golden, hostmem):
+    g = golden("export_llama_int8_sq")
+    cases = g.cases
+    model = _llama(g, cases, torch.bfloat16)
+    batches = [torch.from_numpy(g.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    with torch.no_grad():
+        moa.quantize(model, moa.model_quant.INT8_SMOOTHQUANT_CFG, lambda m: [m(b) for b in batches])
+    for name in cases["linears"]:
+        lin = model.get_submodule(name)
+        assert torch.equal(lin.input_quantizer._pre_quant_scale, from_bits(g.raw(f"pre/{name}.pre_quant_scale"), torch.bfloat16)), name
+        assert torch.equal(lin.weight, from_bits(g.raw(f"pre/{name}.weight"), torch.bfloat16)), name
+        assert torch.equal(lin.weight_quantizer._amax.float().reshape(-1), from_bits(g.raw(f"pre/{name}.w_amax"), torch.float32).reshape(-1)), name
+        assert torch.equal(lin.input_quantizer._amax.float().reshape(-1), from_bits(g.raw(f"pre/{name}.in_amax"), torch.float32).reshape(-1)), name
+    state = moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    _compare_state(state, g, cases)
+
+
+def test_fp8_2d_blockwise_and_mxfp4_exports_equal_reference(golden, hostmem):
+    for fixture, cfg in (("export_llama_fp8_2d", moa.model_quant.FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG),
+                         ("export_llama_mxfp4", moa.model_quant.MXFP4_DEFAULT_CFG)):
+        g = golden(fixture)
+        cases = g.cases
+        model = _llama(g, cases, torch.bfloat16)
+        moa.quantize(model, cfg, None)
+        _compare_state(moa.export.export_state_dict(model, torch.bfloat16), g, cases)
+
+
+@pytest.mark.parametrize("impl", ["sdpa", "eager"])
+def test_fp8_kv_cache_flow_equals_reference(golden, hostmem, impl):
+    g = golden("export_llama_fp8_kv")
+    cases = g.cases
+    mq = moa.model_quant
+    model = _llama(g, cases, torch.float32, impl)
+    batches = [torch.from_numpy(g.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    cfg = mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"])
+    with torch.no_grad():
+        mq.quantize(model, cfg, lambda m: [m(b) for b in batches])
+        logits = model(batches[0]).logits
+    for n in cases["attentions"]:
+        m = model.get_submodule(n)
+        for which in "kv":
+            want = from_bits(g.raw(f"{impl}/{n}.{which}_amax"), torch.float32)
+            assert torch.equal(getattr(m, f"{which}_bmm_quantizer")._amax.float().reshape(()), want.reshape(())), (n, which)
+    assert torch.equal(logits, from_bits(g.raw(f"{impl}/logits"), torch.float32))
+    if impl == "sdpa":
+        state = moa.export.export_state_dict(model, torch.float32)
+        for key in cases["dtypes"]:
+            assert torch.equal(state[key].cpu(), from_bits(g.raw(f"exp/{key}"), torch.float32)), key
+        assert sorted(state) == cases["exported_keys"]
+
+
+def test_mixtral_fused_experts_flow_and_export_equal_reference(golden, hostmem):
+    from transformers import MixtralConfig, MixtralForCausalLM
+
+    g = golden("moe_fp8")
+    cases = g.cases
+    model = MixtralForCausalLM(MixtralConfig(architectures=["MixtralForCausalLM"], **cases["config"])).to(torch.float32)
+    sd = {k[len("orig/"):]: from_bits(g.raw(k), torch.float32) for k in g.z.files if k.startswith("orig/")}
+    assert not model.load_state_dict(sd, strict=False).unexpected_keys
+    model.eval()
+    batches = [torch.from_numpy(g.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    with torch.no_grad():
+        moa.quantize(model, moa.model_quant.FP8_DEFAULT_CFG, lambda m: [m(b) for b in batches])
+        logits = model(batches[0]).logits
+    ours = {n: m for n, m in model.named_modules() if isinstance(m, moa.TensorQuantizer)}
+    for key in g.z.files:
+        if key.startswith("amax/"):
+            n = key[len("amax/"):]
+            assert torch.equal(ours[n]._amax.float().reshape(-1), from_bits(g.raw(key), torch.float32).reshape(-1)), n
+    assert torch.equal(logits, from_bits(g.raw("logits"), torch.float32))
+    _compare_state(moa.export.export_state_dict(model, torch.float32), g, cases)
