@@ -51,6 +51,8 @@ def get_quantization_format(module) -> str | None:
     if nb == 8:
         return QUANTIZATION_INT8_SQ if iq.is_enabled else QUANTIZATION_INT8_WO
     if isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is None:
+        if wq._axis is not None:  # QUANTIZATION_FP8_PC_PT (export/quant_utils.py:545-546): per-channel weight scales
+            raise NotImplementedError("export of per-channel FP8 weights (fp8_pc_pt) is outside this path")
         return QUANTIZATION_FP8
     if (isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is not None
             and wq.block_sizes.get("type", "static") != "dynamic"):
@@ -203,9 +205,12 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         return ops.pack_int4_in_uint8(weight, weights_scaling_factor)
     wsf = weights_scaling_factor.to(weight.device)
     if quantization == QUANTIZATION_FP8:
-        if weight.is_cuda and weight.dtype in (torch.bfloat16, torch.float16) and weight.numel() % 8 == 0:
-            return ops.fp8_quantize(weight, wsf, fp32_scales=True)  # one kernel: divide, round to dtype, cast
-        return (weight / wsf).to(torch.float8_e4m3fn)
+        # (weight / wsf).to(float8_e4m3fn) with a 0-dim fp32 scaling factor: torch keeps the WEIGHT dtype for the
+        # quotient (a 0-dim operand does not promote), so a 16-bit quotient is rounded to 16 bits before the cast --
+        # one kernel: divide, round to dtype, cast
+        if wsf.numel() != 1:
+            raise NotImplementedError("FP8 export with a dimensioned weight scale (per-channel FP8) is outside this path")
+        return ops.fp8_quantize(weight, wsf, fp32_scales=weight.dtype != torch.float32)
     if quantization == QUANTIZATION_MXFP4:
         raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):

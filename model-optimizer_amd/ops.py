@@ -657,8 +657,8 @@ def awq_err_gemm_multi(xs: torch.Tensor, w_hat: torch.Tensor, out_actual: torch.
     ref = out_actual.detach().contiguous().view(-1, cout)
     if ref.shape[0] != tokens or w3.shape[-1] != cin or ref.dtype != x3.dtype or w3.dtype != x3.dtype:
         raise MoquantError("awq_err_gemm_multi: shape / dtype mismatch between xs, w_hat and out_actual")
-    if loss_acc.dtype != torch.float32 or not loss_acc.is_cuda or not loss_acc.is_contiguous():
-        raise MoquantError("awq_err_gemm_multi: loss_acc must be a contiguous fp32 GPU tensor")
+    if loss_acc.dtype != torch.float32 or loss_acc.device != x3.device or not loss_acc.is_contiguous():
+        raise MoquantError("awq_err_gemm_multi: loss_acc must be a contiguous fp32 tensor on the inputs' device")
     b = None if bias is None else bias.detach().to(x3.dtype).contiguous()
     ws = torch.empty(n_cand * int(_lib.lib().moq_awq_err_gemm_workspace(tokens, cout)), dtype=torch.float32,
                      device=x3.device)

@@ -197,6 +197,28 @@ class HostMemLib:
         self.o.orc_awq_weight_scale(_vp(w), I64(rows), I64(cols), int(g), int(dt), _vp(out))
         return OK
 
+    def moq_scale_cols_multi(self, w, s, y, rows, cols, n_scales, dt, stream):
+        elem = 4 if dt == 0 else 2
+        for a in range(int(n_scales)):
+            self.o.orc_scale_cols(_vp(w), ctypes.c_void_p(_addr(s) + a * cols * 4),
+                                  ctypes.c_void_p(_addr(y) + a * rows * cols * elem), I64(rows), I64(cols), int(dt))
+        return OK
+
+    def moq_awq_err_gemm_workspace(self, tokens, cout):
+        return 0
+
+    def moq_awq_err_gemm_multi(self, x, w, out_actual, bias, tokens, cout, cin, dt, n_cand, x_stride, w_stride, partial,
+                               loss_acc, stream):
+        elem = 4 if dt == 0 else 2
+        self.o.orc_awq_err_gemm.restype = ctypes.c_double
+        acc = _f32_view(loss_acc, n_cand)
+        for a in range(int(n_cand)):
+            v = self.o.orc_awq_err_gemm(ctypes.c_void_p(_addr(x) + a * x_stride * elem),
+                                        ctypes.c_void_p(_addr(w) + a * w_stride * elem), _vp(out_actual), _vp(bias), None,
+                                        I64(tokens), I64(cout), I64(cin), int(dt))
+            acc[a] += np.float32(v)
+        return OK
+
     def moq_mask_2to4(self, w, rows, cols, dt, mask, stream):
         self.o.orc_mask_2to4(_vp(w), I64(rows), I64(cols), int(dt), _vp(mask))
         return OK
