@@ -140,3 +140,97 @@ def test_mixtral_fused_experts_flow_and_export_equal_reference(golden, hostmem):
             assert torch.equal(ours[n]._amax.float().reshape(-1), from_bits(g.raw(key), torch.float32).reshape(-1)), n
     assert torch.equal(logits, from_bits(g.raw("logits"), torch.float32))
     _compare_state(moa.export.export_state_dict(model, torch.float32), g, cases)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mtq.quantize() flows of the reference on the tiny MLP (tests/golden/model_flows.npz), here exact where the GPU tests
+# (tests/test_gpu_host.py) need tolerances for the GEMM summation order
+import copy
+
+from conftest import DT, assert_bits_equal
+
+
+class _TinyMLP(torch.nn.Module):
+    def __init__(self, w1, w2, b2):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(w1.shape[1], w1.shape[0], bias=False)
+        self.fc2 = torch.nn.Linear(w2.shape[1], w2.shape[0], bias=True)
+        self.to(w1.dtype)
+        with torch.no_grad():
+            self.fc1.weight.copy_(w1); self.fc2.weight.copy_(w2); self.fc2.bias.copy_(b2)
+
+    def forward(self, x):
+        return self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+
+def _mlp_flow(golden, name, cfg):
+    g = golden("model_flows")
+    c = g.cases[name]
+    dn = c["dtype"]
+    dt = DT[dn]
+    model = _TinyMLP(g.t(f"{dn}_w1", dt), g.t(f"{dn}_w2", dt), g.t(f"{dn}_b2", dt))
+    batches = [g.t(f"{dn}_x{i}", dt) for i in range(c["n_batches"])]
+    q = moa.quantize(model, copy.deepcopy(cfg), lambda m: [m(b) for b in batches])
+    return g, c, q, batches, dt
+
+
+@pytest.mark.parametrize("name", ["int8_max", "fp8_max"])
+def test_mlp_max_calibration_equals_reference(golden, hostmem, name):
+    cfg = moa.model_quant.INT8_DEFAULT_CFG if name == "int8_max" else moa.model_quant.FP8_DEFAULT_CFG
+    g, c, q, batches, dt = _mlp_flow(golden, name, cfg)
+    for tname, tdtype, tshape in c["tensors"]:
+        lname, rest = tname.split("_", 1)
+        qn, attr = rest.rsplit("_", 1)
+        t = getattr(getattr(getattr(q, lname), qn), "_" + attr)
+        assert list(t.shape) == tshape and str(t.dtype) == tdtype, f"{name} {tname}: {t.dtype} {tuple(t.shape)}"
+        want = g.t(f"{name}_{tname}")
+        assert_bits_equal(t.float().reshape(want.shape), want, f"{name} {tname}")
+    assert_bits_equal(q(batches[0]), g.t(f"{name}_y", dt), f"{name} forward with fake quant")
+
+
+def test_mlp_smoothquant_equals_reference(golden, hostmem):
+    g, c, q, batches, dt = _mlp_flow(golden, "int8_sq", moa.model_quant.INT8_SMOOTHQUANT_CFG)
+    for lname in ("fc1", "fc2"):
+        lin = getattr(q, lname)
+        for attr, key in (("input_quantizer._pre_quant_scale", "input_quantizer_pre_quant_scale"),
+                          ("weight_quantizer._amax", "weight_quantizer_amax"), ("input_quantizer._amax", "input_quantizer_amax")):
+            obj = lin
+            for part in attr.split("."):
+                obj = getattr(obj, part)
+            want = g.t(f"int8_sq_{lname}_{key}")
+            assert_bits_equal(obj.float().reshape(want.shape), want, f"{lname} {key}")
+        assert_bits_equal(lin.weight.float(), g.t(f"int8_sq_{lname}_wfinal").float().reshape(lin.weight.shape), f"{lname} smoothed weight")
+    assert_bits_equal(q(batches[0]), g.t("int8_sq_y", dt), "smoothquant forward")
+
+
+@pytest.mark.parametrize("name,search", [("int4_awq", "gram"), ("int4_awq", "gemm"), ("int4_awq_bf16", "gemm")])
+def test_mlp_awq_lite_equals_reference(golden, hostmem, name, search):
+    """awq_lite on CPU with both engines (bf16: the error-GEMM engine through the oracle's contraction): same alpha as the
+    reference on every linear, statistics / losses / folded weights within the summation-order tolerances of the GPU
+    test (tests/test_gpu_host.py)."""
+    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"]["search"] = search
+    g, c, q, batches, dt = _mlp_flow(golden, name, cfg)
+    def close(x, want, rtol, what):
+        x, want = x.float().reshape(-1), want.float().reshape(-1)
+        assert x.shape == want.shape, what
+        err = ((x - want).abs() / want.abs().clamp_min(1e-12)).max().item()
+        assert err <= rtol, f"{what}: max rel err {err:.3e} > {rtol}"
+
+    f32 = dt == torch.float32
+    for lname in ("fc1", "fc2"):
+        lin = getattr(q, lname)
+        h = lin.awq_lite
+        # mean |x| / mean |w| ratios: the reference reduces with torch's fp32 order, the oracle with a wide sum
+        close(h.act_scale, g.t(f"{name}_{lname}_act_scale"), 1e-6 if f32 else 2 ** -7, f"{lname} act_scale")
+        close(h.weight_scale, g.t(f"{name}_{lname}_weight_scale"), 1e-6 if f32 else 2 ** -7, f"{lname} weight_scale")
+        ref_loss = c[f"{lname}_loss"]
+        for a, v in h.loss.items():
+            rv = ref_loss[str(a)]
+            assert abs(float(v) - rv) <= (1e-4 if f32 else 3e-2) * max(rv, 1e-9), f"{name} {lname} loss[alpha={a}] {float(v)} vs {rv}"
+        assert h.best_alpha == c[f"{lname}_best_alpha"], f"{name} {lname}: alpha {h.best_alpha}"
+        tol = 1e-5 if f32 else 2e-2
+        close(h.best_scale, g.t(f"{name}_{lname}_best_scale"), tol, f"{lname} best_scale")
+        close(lin.input_quantizer._pre_quant_scale, g.t(f"{name}_{lname}_input_quantizer_pre_quant_scale"), tol, f"{lname} pqs")
+        close(lin.weight_quantizer._amax, g.t(f"{name}_{lname}_weight_quantizer_amax"), tol, f"{lname} weight amax")
+        close(lin.weight, g.t(f"{name}_{lname}_wfinal", dt), tol * 10, f"{lname} folded weight")
