@@ -219,6 +219,76 @@ class HostMemLib:
             acc[a] += np.float32(v)
         return OK
 
+    def moq_awq_clip_loss(self, x, n_tok, x_row_stride, w, cout, cin, g, dt, amax, amax_dt, shrinks, n_shrink, num_bits,
+                          loss, stream):
+        """The oracle takes contiguous token rows and writes [K, cout, nblk]; the C-ABI strides over tokens and
+        accumulates into [K, nblk, cout]."""
+        xa = self._as_2d(x, 1, (n_tok - 1) * x_row_stride + cin, dt)[0]
+        rows = np.ascontiguousarray(np.stack([xa[t * x_row_stride:t * x_row_stride + cin] for t in range(int(n_tok))]))
+        nblk = (cin + g - 1) // g
+        tmp = np.zeros((int(n_shrink), int(cout), int(nblk)), dtype=np.float32)
+        self.o.orc_awq_clip_loss(oracle._p(rows), I64(n_tok), _vp(w), I64(cout), I64(cin), int(g), int(dt), _vp(amax),
+                                 int(amax_dt), _vp(shrinks), int(n_shrink), int(num_bits), oracle._p(tmp))
+        out = _f32_view(loss, n_shrink * nblk * cout).reshape(int(n_shrink), int(nblk), int(cout))
+        out += tmp.transpose(0, 2, 1)
+        return OK
+
+    def moq_sgpt_block_sweep(self, w, rows, ld, i1, bs, hinv, delta, prune_n, prune_m, stream):
+        self.o.orc_sgpt_block_sweep(_vp(w), I64(rows), I64(ld), I64(i1), int(bs), _vp(hinv), _vp(delta), int(prune_n),
+                                    int(prune_m))
+        return OK
+
+    # -- Gram-matrix AWQ search / SparseGPT Hessian: numpy restatements (fp64 accumulation) of the MFMA entries
+    @staticmethod
+    def _bf16_round(f32):
+        u = np.ascontiguousarray(f32, dtype=np.float32).view(np.uint32)
+        r = ((u >> 16) & 1) + np.uint32(0x7FFF)
+        return ((u + r) >> 16).astype(np.uint16)
+
+    def moq_transpose16_ld(self, x, y, rows, cols, y_ld, stream):
+        xa = np.ctypeslib.as_array(ctypes.cast(_addr(x), ctypes.POINTER(ctypes.c_uint16)), shape=(int(rows), int(cols)))
+        ya = np.ctypeslib.as_array(ctypes.cast(_addr(y), ctypes.POINTER(ctypes.c_uint16)),
+                                   shape=((int(cols) - 1) * int(y_ld) + int(rows),))
+        for c in range(int(cols)):
+            ya[c * y_ld:c * y_ld + rows] = xa[:, c]
+        return OK
+
+    def moq_transpose16(self, x, y, rows, cols, stream):
+        return self.moq_transpose16_ld(x, y, rows, cols, rows, stream)
+
+    def moq_hessian_accum(self, xt, cin, tokens, dt, hessian, decay, scale, upper_only, stream):
+        x = self._to_f32(self._as_2d(xt, cin, tokens, dt), dt).astype(np.float64)
+        h = _f32_view(hessian, cin * cin).reshape(int(cin), int(cin))
+        h[:] = (h.astype(np.float64) * float(decay) + float(scale) * (x @ x.T)).astype(np.float32)
+        return OK
+
+    def moq_symmetrize(self, h, n, stream):
+        a = _f32_view(h, n * n).reshape(int(n), int(n))
+        iu = np.triu_indices(int(n), 1)
+        a[(iu[1], iu[0])] = a[iu]
+        return OK
+
+    def moq_awq_err_weight(self, w, s, r, e_out, a_out, rows, cols, g, dt, num_bits, stream):
+        y = np.empty((int(rows), int(cols)), dtype=np.float32 if dt == 0 else np.uint16)
+        self.o.orc_awq_scale_qdq(_vp(w), _vp(s), oracle._p(y), I64(rows), I64(cols), int(g), int(dt), int(num_bits))
+        wa = self._as_2d(w, rows, cols, dt)
+        wf = wa.astype(np.float32) if dt == 0 else self._to_f32(wa, dt)
+        yf = y if dt == 0 else self._to_f32(y, dt)
+        e = (yf * _f32_view(r, cols)[None, :] - wf).astype(np.float32)
+        _f32_view(e_out, rows * cols).reshape(int(rows), int(cols))[:] = e
+        hi = self._bf16_round(e)
+        lo = self._bf16_round(e - self._to_f32(hi, 2))
+        ao = np.ctypeslib.as_array(ctypes.cast(_addr(a_out), ctypes.POINTER(ctypes.c_uint16)), shape=(int(rows), 3 * int(cols)))
+        ao[:, :cols], ao[:, cols:2 * cols], ao[:, 2 * cols:] = hi, hi, lo
+        return OK
+
+    def moq_awq_quadform(self, a, b, ref, rows, cols, k, dt, partial, loss_acc, inv_count, stream):
+        af = self._to_f32(self._as_2d(a, rows, k, dt), dt).astype(np.float64)
+        bf = self._to_f32(self._as_2d(b, cols, k, dt), dt).astype(np.float64)
+        rf = _f32_view(ref, rows * cols).reshape(int(rows), int(cols)).astype(np.float64)
+        _f32_view(loss_acc, 1)[0] += np.float32(float(inv_count) * float(((af @ bf.T) * rf).sum()))
+        return OK
+
     def moq_mask_2to4(self, w, rows, cols, dt, mask, stream):
         self.o.orc_mask_2to4(_vp(w), I64(rows), I64(cols), int(dt), _vp(mask))
         return OK
