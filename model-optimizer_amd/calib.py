@@ -75,6 +75,8 @@ class MaxCalibrator(_Calibrator):
             # 2-D blocks: the (R/br, br, C/bc, bc) view reduced over the block dims (ops.block2d)
             shape = (x.shape[0], 1, x.shape[2], 1)
             n = x.shape[0] * x.shape[2]
+            if n == 1:
+                shape = ()  # a single tile: reduce_amax squeezes scalars (core_utils.py:181-182)
         else:
             _, kept, _, keep = _reduce_layout(list(x.shape), reduce_axis)
             shape = tuple(x.shape[d] if d in keep else 1 for d in range(nd))

@@ -267,18 +267,22 @@ class TensorQuantizer(nn.Module):
     def _setup_for_blockquant(self, inputs):
         """tensor_quantizer.py:975-1043.  Last-axis blocks: right-pad the last dim with zeros to a block multiple,
         view as (-1, g), quantization axis (0,).  Blocks on BOTH axes of a 2-D tensor (the FP8 2-D blockwise
-        preset): view as (R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D block kernel; shapes
-        that would need padding, and other N-D layouts, raise."""
+        preset): zero-pad to whole tiles, view as (R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D
+        block kernel; other N-D layouts raise."""
         if hasattr(self, "_block_reshape_size"):
             return
         bs = self._block_sizes
         axes = {(k if k >= 0 else inputs.dim() + k): v for k, v in bs.items() if isinstance(k, int)}
         if len(axes) == 2 and inputs.dim() == 2 and set(axes) == {0, 1}:
             br, bc = axes[0], axes[1]
-            if inputs.shape[0] % br or inputs.shape[1] % bc:
-                raise MoquantUnsupported("2-D block quantization of a shape that needs padding is not on this path")
+            rows, cols = inputs.shape
+            pad_r, pad_c = (-rows) % br, (-cols) % bc
             self._original_shape = inputs.shape
-            self._block_reshape_size = torch.Size((inputs.shape[0] // br, br, inputs.shape[1] // bc, bc))
+            if pad_r or pad_c:  # right / bottom zero padding to whole tiles, cut off again after the QDQ (:1018-1043)
+                self._padding = (0, pad_c, 0, pad_r)
+                self._slices = (slice(rows), slice(cols))
+                self._original_shape = torch.Size((rows + pad_r, cols + pad_c))
+            self._block_reshape_size = torch.Size(((rows + pad_r) // br, br, (cols + pad_c) // bc, bc))
             self.axis = (0, 2)
             return
         g = self._block_size_last(inputs)
