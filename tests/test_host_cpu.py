@@ -111,8 +111,11 @@ def test_tensor_quantizer_config_and_state_without_gpu():
     assert q2._reset_to_original_shape(v).shape == (3, 200)
     with pytest.raises(ValueError, match="shape has changed"):
         q2._process_for_blockquant(torch.zeros(3, 100))
-    with pytest.raises(ValueError):  # MoquantUnsupported is a ValueError: N-D block layouts are outside the path
-        TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: 16, -2: 16}))._setup_for_blockquant(x)
+    # blocks on both axes: ragged shapes are zero-padded to whole tiles and cut back (tensor_quantizer.py:1018-1043)
+    q3 = TensorQuantizer(QuantizerAttributeConfig(num_bits=4, block_sizes={-1: 16, -2: 16}))
+    q3._setup_for_blockquant(x)
+    v3 = q3._process_for_blockquant(x)
+    assert v3.shape == (1, 16, 13, 16) and q3.axis == (0, 2) and q3._reset_to_original_shape(v3).shape == (3, 200)
 
 
 def test_quantize_config_plumbing_without_gpu():
