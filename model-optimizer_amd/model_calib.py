@@ -218,7 +218,9 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
             warnings.warn(f"Only per-channel smoothing is supported, skip {name}")
             continue
         act_amax = iq.amax.float().reshape(-1)
-        weight_scale = ops.reduce_amax(m.weight, axis=(0,)).float().reshape(-1)  # |W|.amax(dim=0)
+        # |W|.amax(dim=0) stays in the WEIGHT dtype and so does its power (model_calib.py:1311, :1319): for a 16-bit
+        # model weight_scale^(1 - alpha) is rounded to 16 bits before the fp32 division
+        weight_scale = ops.reduce_amax(m.weight, axis=(0,)).reshape(-1)
         scale_a = weight_scale.pow(1 - alpha) / act_amax.pow(alpha)
         iq._amax_for_smoothing = act_amax.cpu()
         iq.reset_amax()

@@ -2,6 +2,7 @@
 
 from __future__ import annotations
 
+import fnmatch
 import re
 import warnings
 
@@ -179,7 +180,8 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
     `_weight_mask` buffer and its weight is masked in place (the reference's SparseModule multiplies on access).
     "sparsegpt": forward hooks accumulate the input Hessians during forward_loop, then create_sgpt_mask."""
     cfg = {"pattern": _PATTERN_2_4, "col_block_size": 128, "row_block_size": -1, "hessian_damp": 0.1, **(config or {})}
-    linears = [(n, m) for n, m in model.named_modules() if isinstance(m, torch.nn.Linear)]
+    # weight_sparsity/config.py:27-45: {"nn.Linear": {"*": {}, "*lm_head*": None}} -- the output head stays dense
+    linears = [(n, m) for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and not fnmatch.fnmatch(n, "*lm_head*")]
     if mode == "sparse_magnitude":
         targets = [(n, m) for n, m in linears if check_weight_size(m.weight, n)]
         masks = {m: create_asp_mask(m.weight, cfg["pattern"]) for _, m in targets}

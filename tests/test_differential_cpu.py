@@ -26,10 +26,13 @@ CFG = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_atte
            vocab_size=96, max_position_embeddings=64)
 
 
-def _model(dtype):
-    from transformers import LlamaConfig, LlamaForCausalLM
+def _model(dtype, arch="llama"):
+    from transformers import LlamaConfig, LlamaForCausalLM, MixtralConfig, MixtralForCausalLM
 
     torch.manual_seed(7)
+    if arch == "mixtral":
+        cfg = MixtralConfig(architectures=["MixtralForCausalLM"], num_local_experts=4, num_experts_per_tok=2, **CFG)
+        return MixtralForCausalLM(cfg).to(dtype).eval()
     return LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **CFG)).to(dtype).eval()
 
 
@@ -37,14 +40,16 @@ def _batches():
     return [torch.randint(0, CFG["vocab_size"], (3, 24), generator=torch.Generator().manual_seed(40 + i)) for i in range(3)]
 
 
-def _reference_run(preset, dtype, with_kv):
+def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     ref_shim.install()
     import modelopt.torch.quantization as mtq
     from modelopt.torch.export import export_hf_checkpoint
     from safetensors import safe_open
 
-    model = _model(dtype)
+    model = _model(dtype, arch)
     cfg = copy.deepcopy(getattr(mtq, preset))
+    if algorithm is not None:
+        cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
         cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
     batches = _batches()
@@ -61,10 +66,12 @@ def _reference_run(preset, dtype, with_kv):
     return amax, out
 
 
-def _our_run(preset, dtype, with_kv):
+def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     mq = moa.model_quant
-    model = _model(dtype)
+    model = _model(dtype, arch)
     cfg = copy.deepcopy(getattr(mq, preset))
+    if algorithm is not None:
+        cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
         cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, mq.FP8_KV_CFG["quant_cfg"])
     batches = _batches()
@@ -76,17 +83,24 @@ def _our_run(preset, dtype, with_kv):
     return amax, state
 
 
-@pytest.mark.parametrize("preset,dtype,with_kv", [
-    ("FP8_DEFAULT_CFG", torch.bfloat16, False), ("FP8_DEFAULT_CFG", torch.float32, True), ("FP8_DEFAULT_CFG", torch.float16, True),
-    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False), ("INT8_SMOOTHQUANT_CFG", torch.float32, False),
-    ("INT8_DEFAULT_CFG", torch.bfloat16, False),
-    ("FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False), ("MXFP4_DEFAULT_CFG", torch.bfloat16, False),
-    ("MXFP4_DEFAULT_CFG", torch.float16, False), ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False),
+SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
+
+
+@pytest.mark.parametrize("preset,dtype,with_kv,arch,algorithm", [
+    ("FP8_DEFAULT_CFG", torch.bfloat16, False, "llama", None), ("FP8_DEFAULT_CFG", torch.float32, True, "llama", None),
+    ("FP8_DEFAULT_CFG", torch.float16, True, "llama", None),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", None), ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "llama", None),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", SQ_HALF),
+    ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", None),
+    ("FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None), ("MXFP4_DEFAULT_CFG", torch.bfloat16, False, "llama", None),
+    ("MXFP4_DEFAULT_CFG", torch.float16, False, "llama", None), ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None), ("FP8_DEFAULT_CFG", torch.float32, False, "mixtral", None),
+    ("MXFP4_DEFAULT_CFG", torch.bfloat16, False, "mixtral", None),
 ])
-def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv):
-    ref_amax, ref_state = _reference_run(preset, dtype, with_kv)
+def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
+    ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
     hostmem_backend.install(monkeypatch, moa)
-    our_amax, our_state = _our_run(preset, dtype, with_kv)
+    our_amax, our_state = _our_run(preset, dtype, with_kv, arch, algorithm)
     # every enabled quantizer the reference calibrated exists here under the same name with the same amax
     for n, a in ref_amax.items():
         assert n in our_amax, f"{preset}: quantizer {n} has no amax here"
@@ -96,3 +110,18 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
         got = our_state[k].detach().cpu()
         assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{preset} {k}: {got.dtype} {tuple(got.shape)} vs {want.dtype} {tuple(want.shape)}"
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
+
+
+def test_magnitude_sparsity_equals_the_reference_live(monkeypatch):
+    """mts.sparsify(model, "sparse_magnitude") of the reference against sparsity.sparsify on the same model: masks equal."""
+    ref_shim.install()
+    import modelopt.torch.sparsity as mts
+
+    ref = mts.sparsify(_model(torch.bfloat16), "sparse_magnitude")
+    ref_masks = {n[: -len("._weight_mask")]: b.clone() for n, b in ref.named_buffers() if n.endswith("_weight_mask")}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = moa.sparsity.sparsify(_model(torch.bfloat16), "sparse_magnitude")
+    our_masks = {n[: -len("._weight_mask")]: b for n, b in ours.named_buffers() if n.endswith("_weight_mask")}
+    assert set(our_masks) == set(ref_masks) and len(ref_masks) >= 14
+    for n, m in ref_masks.items():
+        assert torch.equal(our_masks[n].bool(), m.bool()), n
