@@ -271,8 +271,9 @@ def export_fused_experts(module, dtype: torch.dtype) -> dict:
                 rows = amax.shape[0]
                 if total % rows == 0:
                     sliced = amax[row0 * rows // total:(row0 + w.shape[0]) * rows // total].contiguous()
+                    keep_col = wq._amax.dim() == 2 and wq._amax.shape[-1] == 1  # [rows, 1] per-channel layout
                     delattr(wq, "_amax")
-                    wq.amax = sliced.reshape(-1, 1) if src._amax.dim() == 2 and src._amax.shape[-1] == 1 else sliced
+                    wq.amax = sliced.reshape(-1, 1) if keep_col else sliced
                 else:
                     warnings.warn(f"Expert {idx} {proj}: fused amax dim0 ({rows}) does not evenly divide the fused "
                                   f"rows ({total}). Skipping amax slicing.", stacklevel=2)

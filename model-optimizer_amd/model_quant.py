@@ -16,6 +16,10 @@ from .tensor_quantizer import QuantizerAttributeConfig, SequentialQuantizer, Ten
 INT8_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
                                   "*input_quantizer": {"num_bits": 8, "axis": None},
                                   "*lm_head*": {"enable": False}}, "algorithm": "max"}
+# presets/model/int8_weight_only.yaml: per-channel INT8 weights, inputs untouched
+INT8_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
+                                      "*input_quantizer": {"enable": False},
+                                      "*lm_head*": {"enable": False}}, "algorithm": "max"}
 FP8_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "axis": None},
                                  "*input_quantizer": {"num_bits": (4, 3), "axis": None},
                                  "*lm_head*": {"enable": False}}, "algorithm": "max"}

@@ -57,7 +57,11 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     q = mtq.quantize(model, cfg, loop)
     amax = {n: m._amax.detach().float().clone() for n, m in q.named_modules()
             if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
-    out = {}
+    logits = None
+    if "MXFP4" not in preset:  # the reference's MX fake quant has no CPU implementation
+        with torch.no_grad():
+            logits = q(batches[0]).logits.clone()
+    out = {"__logits__": logits}
     with tempfile.TemporaryDirectory() as d:
         export_hf_checkpoint(q, export_dir=d)
         with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
@@ -79,7 +83,10 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
         moa.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
     amax = {n: m._amax.detach().float().clone() for n, m in model.named_modules()
             if isinstance(m, moa.TensorQuantizer) and m.is_enabled and getattr(m, "_amax", None) is not None}
+    with torch.no_grad():
+        logits = model(batches[0]).logits.clone()
     state = moa.export.export_state_dict(model, dtype, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    state["__logits__"] = logits
     return amax, state
 
 
@@ -91,7 +98,8 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("FP8_DEFAULT_CFG", torch.float16, True, "llama", None),
     ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", None), ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "llama", None),
     ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", SQ_HALF),
-    ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", None),
+    ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", None), ("INT8_WEIGHT_ONLY_CFG", torch.float16, False, "llama", None),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "mixtral", None),
     ("FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None), ("MXFP4_DEFAULT_CFG", torch.bfloat16, False, "llama", None),
     ("MXFP4_DEFAULT_CFG", torch.float16, False, "llama", None), ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None), ("FP8_DEFAULT_CFG", torch.float32, False, "mixtral", None),
@@ -105,6 +113,9 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
     for n, a in ref_amax.items():
         assert n in our_amax, f"{preset}: quantizer {n} has no amax here"
         assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"{preset}: amax of {n} differs"
+    ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
+    if ref_logits is not None:  # the forward with fake quantization active, after calibration
+        assert torch.equal(our_logits, ref_logits), f"{preset}: logits of the fake-quantized model differ"
     assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
     for k, want in ref_state.items():
         got = our_state[k].detach().cpu()
@@ -125,3 +136,30 @@ def test_magnitude_sparsity_equals_the_reference_live(monkeypatch):
     assert set(our_masks) == set(ref_masks) and len(ref_masks) >= 14
     for n, m in ref_masks.items():
         assert torch.equal(our_masks[n].bool(), m.bool()), n
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_awq_lite_picks_the_reference_alphas_live(monkeypatch, dtype):
+    """INT4_AWQ_CFG on the tiny Llama: the reference (debug=True keeps its per-linear state) and this package pick the
+    same alpha for every linear; exported tensors agree within 2 ulp of the model dtype (the activation statistics are
+    reduced in different orders, which can move a scale by one ulp)."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    cfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+    cfg["algorithm"]["debug"] = True
+    ref = mtq.quantize(_model(dtype), cfg, lambda m: [m(b) for b in batches])
+    ref_alpha = {n: float(m.awq_lite.best_alpha) for n, m in ref.named_modules() if hasattr(m, "awq_lite")}
+    ref_w = {n: m.weight.detach().float().clone() for n, m in ref.named_modules() if hasattr(m, "awq_lite")}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(dtype)
+    with torch.no_grad():
+        moa.quantize(ours, moa.model_quant.INT4_AWQ_CFG, lambda m: [m(b) for b in batches])
+    our_alpha = {n: float(m.awq_lite.best_alpha) for n, m in ours.named_modules() if hasattr(m, "awq_lite")}
+    assert set(our_alpha) == set(ref_alpha) and len(ref_alpha) == 14
+    assert our_alpha == ref_alpha, {n: (our_alpha[n], ref_alpha[n]) for n in ref_alpha if our_alpha[n] != ref_alpha[n]}
+    ulp = torch.finfo(dtype).eps
+    for n, w in ref_w.items():
+        got = ours.get_submodule(n).weight.detach().float()
+        assert ((got - w).abs() <= max(2 * ulp, 1e-5) * w.abs() + 1e-30).all(), f"{n}: folded weight off by more than 2 ulp / 1e-5"
