@@ -163,3 +163,82 @@ def test_awq_lite_picks_the_reference_alphas_live(monkeypatch, dtype):
     for n, w in ref_w.items():
         got = ours.get_submodule(n).weight.detach().float()
         assert ((got - w).abs() <= max(2 * ulp, 1e-5) * w.abs() + 1e-30).all(), f"{n}: folded weight off by more than 2 ulp / 1e-5"
+
+
+@pytest.mark.parametrize("preset,dtype", [("INT8_DEFAULT_CFG", torch.float32), ("FP8_DEFAULT_CFG", torch.bfloat16),
+                                          ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16)])
+def test_mse_calibration_equals_the_reference_live(monkeypatch, preset, dtype):
+    """algorithm "mse" (max calibration, then the 39-candidate amax sweep per weight quantizer): same refined amax
+    everywhere, up to candidates whose losses tie within the summation order (at most 1 % of the entries may sit on a
+    neighbouring candidate)."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    cfg = copy.deepcopy(getattr(mtq, preset))
+    cfg["algorithm"] = "mse"
+    ref = mtq.quantize(_model(dtype), cfg, lambda m: [m(b) for b in batches])
+    ref_amax = {n: m._amax.detach().float().reshape(-1).clone() for n, m in ref.named_modules()
+                if type(m).__name__.endswith("Quantizer") and getattr(m, "_amax", None) is not None and m.is_enabled}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(dtype)
+    cfg2 = copy.deepcopy(getattr(moa.model_quant, preset))
+    cfg2["algorithm"] = "mse"
+    with torch.no_grad():
+        moa.quantize(ours, cfg2, lambda m: [m(b) for b in batches])
+    our_amax = {n: m._amax.detach().float().reshape(-1) for n, m in ours.named_modules()
+                if isinstance(m, moa.TensorQuantizer) and getattr(m, "_amax", None) is not None and m.is_enabled}
+    assert set(our_amax) == set(ref_amax)
+    total = differing = 0
+    for n, a in ref_amax.items():
+        assert our_amax[n].shape == a.shape, n
+        total += a.numel()
+        differing += int((our_amax[n] != a).sum())
+    assert differing <= 0.01 * total, f"{preset}: {differing} of {total} amax entries differ"
+
+
+def test_awq_clip_equals_the_reference_live(monkeypatch):
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    cfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_clip"}
+    ref = mtq.quantize(_model(torch.float32), cfg, lambda m: [m(b) for b in batches])
+    ref_amax = {n: m.weight_quantizer._amax.detach().float().reshape(-1).clone() for n, m in ref.named_modules()
+                if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(torch.float32)
+    cfg2 = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg2["algorithm"] = {"method": "awq_clip"}
+    with torch.no_grad():
+        moa.quantize(ours, cfg2, lambda m: [m(b) for b in batches])
+    total = differing = 0
+    for n, a in ref_amax.items():
+        got = ours.get_submodule(n).weight_quantizer._amax.detach().float().reshape(-1)
+        assert got.shape == a.shape, n
+        total += a.numel()
+        differing += int(((got - a).abs() > 1e-6 * a.abs()).sum())
+    assert total > 0 and differing <= 0.01 * total, f"awq_clip: {differing} of {total} clipped block amax values differ"
+
+
+def test_sparsegpt_equals_the_reference_live(monkeypatch):
+    """mts.sparsify(model, "sparsegpt") against sparsity.sparsify on the same model and batches (fp32 model: both sides
+    accumulate the Hessian with an fp32 library GEMM): masks agree on at least 99 % of the weights of every linear
+    (Cholesky / trailing-update summation order), every mask is 2:4."""
+    ref_shim.install()
+    import modelopt.torch.sparsity as mts
+
+    batches = _batches()
+    ref = mts.sparsify(_model(torch.float32), "sparsegpt",
+                       config={"data_loader": batches, "collect_func": lambda b: b})
+    ref_masks = {n[: -len("._weight_mask")]: b.clone() for n, b in ref.named_buffers() if n.endswith("_weight_mask")}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = moa.sparsity.sparsify(_model(torch.float32), "sparsegpt", lambda m: [m(b) for b in batches])
+    our_masks = {n[: -len("._weight_mask")]: b for n, b in ours.named_buffers() if n.endswith("_weight_mask")}
+    assert set(our_masks) == set(ref_masks) and len(ref_masks) == 14
+    for n, m in ref_masks.items():
+        got = our_masks[n].bool()
+        assert (got.view(got.shape[0], -1, 4).sum(-1) <= 2).all(), n
+        same = (got == m.bool()).float().mean().item()
+        assert same >= 0.99, f"{n}: only {same:.4f} of the mask equals the reference's"
