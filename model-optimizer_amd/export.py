@@ -389,7 +389,31 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
         new_key, value = _postprocess_kv_key(k, v, kv_format)
         if new_key is not None:
             state[new_key] = value
+    for alias in _tied_alias_keys(model, state):
+        del state[alias]
     return rename_to_checkpoint_keys(state, model)
+
+
+def _tied_alias_keys(model, state: dict) -> list:
+    """Tied weights are stored once (postprocess_state_dict's tied-weight dedup, export/quant_utils.py:1062-1110): a key
+    the model DECLARES as an alias (`_tied_weights_keys`: alias -> canonical, transformers >= 5; a list of aliases
+    before) is dropped when its canonical counterpart is in the state and the two really share memory."""
+    tied = getattr(model, "_tied_weights_keys", None)
+    if not tied:
+        return []
+    pairs = tied.items() if isinstance(tied, dict) else [(a, None) for a in tied]
+    out = []
+    for alias, canonical in pairs:
+        if alias not in state:
+            continue
+        ptr = state[alias].data_ptr()
+        if canonical is not None:
+            same = canonical in state and state[canonical].data_ptr() == ptr
+        else:
+            same = any(k != alias and v.data_ptr() == ptr for k, v in state.items())
+        if same:
+            out.append(alias)
+    return out
 
 
 KV_CACHE_FP8 = "FP8"

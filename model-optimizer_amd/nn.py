@@ -33,6 +33,26 @@ class QuantLinear(nn.Linear):
         return self.output_quantizer(F.linear(x, w, self.bias))
 
 
+class QuantLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm with an input (and output) quantizer -- the reference registers nn.LayerNorm with QuantInputBase
+    (nn/modules/quant_layernorm.py:28, quant_module.py:192-240), so the `*input_quantizer` entries of the presets also
+    fake-quantize what goes INTO every LayerNorm of OPT / GPT-style models.  RMSNorm classes of the Llama family are
+    model code, not nn.LayerNorm, and stay untouched on both sides."""
+
+    def _setup(self):
+        self.input_quantizer = TensorQuantizer(QuantLinear.default_quant_desc_input)
+        self.output_quantizer = TensorQuantizer(QuantizerAttributeConfig(enable=False))
+
+    @classmethod
+    def convert(cls, norm: nn.LayerNorm) -> "QuantLayerNorm":
+        norm.__class__ = cls
+        norm._setup()
+        return norm
+
+    def forward(self, input):
+        return self.output_quantizer(super().forward(self.input_quantizer(input)))
+
+
 def is_quantized_linear(m) -> bool:
     return isinstance(m, QuantLinear)
 
@@ -50,4 +70,6 @@ def replace_quant_module(model: nn.Module) -> nn.Module:
     for mod in list(model.modules()):
         if type(mod) is nn.Linear:
             QuantLinear.convert(mod)
+        elif type(mod) is nn.LayerNorm:
+            QuantLayerNorm.convert(mod)
     return model

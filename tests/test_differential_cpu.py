@@ -30,6 +30,12 @@ def _model(dtype, arch="llama"):
     from transformers import LlamaConfig, LlamaForCausalLM, MixtralConfig, MixtralForCausalLM
 
     torch.manual_seed(7)
+    if arch == "opt":  # BASELINE configs[0] family: biased linears, LayerNorm, learned positions
+        from transformers import OPTConfig, OPTForCausalLM
+
+        cfg = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4, vocab_size=96,
+                        max_position_embeddings=64, word_embed_proj_dim=128, architectures=["OPTForCausalLM"])
+        return OPTForCausalLM(cfg).to(dtype).eval()
     if arch == "mixtral":
         cfg = MixtralConfig(architectures=["MixtralForCausalLM"], num_local_experts=4, num_experts_per_tok=2, **CFG)
         return MixtralForCausalLM(cfg).to(dtype).eval()
@@ -104,6 +110,8 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("MXFP4_DEFAULT_CFG", torch.float16, False, "llama", None), ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None), ("FP8_DEFAULT_CFG", torch.float32, False, "mixtral", None),
     ("MXFP4_DEFAULT_CFG", torch.bfloat16, False, "mixtral", None),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "opt", None), ("INT8_SMOOTHQUANT_CFG", torch.float16, False, "opt", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "opt", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
