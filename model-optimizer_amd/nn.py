@@ -3,6 +3,7 @@ quant_module.py:227-278): an nn.Linear with input / weight / output TensorQuanti
 
 from __future__ import annotations
 
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -72,4 +73,11 @@ def replace_quant_module(model: nn.Module) -> nn.Module:
             QuantLinear.convert(mod)
         elif type(mod) is nn.LayerNorm:
             QuantLayerNorm.convert(mod)
+        elif type(mod).__name__ == "Conv1D" and type(mod).__module__.startswith("transformers."):
+            # transformers' Conv1D (GPT-2) is a linear layer with a transposed [in, out] weight and addmm: the weight
+            # is transposed once and the module becomes a quantized nn.Linear (plugins/huggingface.py:559-571)
+            with torch.no_grad():
+                mod.weight = nn.Parameter(mod.weight.T.contiguous())
+            mod.out_features, mod.in_features = mod.weight.shape
+            QuantLinear.convert(mod)
     return model

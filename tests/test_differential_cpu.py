@@ -36,6 +36,15 @@ def _model(dtype, arch="llama"):
         cfg = OPTConfig(hidden_size=128, ffn_dim=256, num_hidden_layers=2, num_attention_heads=4, vocab_size=96,
                         max_position_embeddings=64, word_embed_proj_dim=128, architectures=["OPTForCausalLM"])
         return OPTForCausalLM(cfg).to(dtype).eval()
+    if arch == "qwen2":  # biased q / k / v projections, tied embeddings by default
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+
+        return Qwen2ForCausalLM(Qwen2Config(architectures=["Qwen2ForCausalLM"], tie_word_embeddings=True, **CFG)).to(dtype).eval()
+    if arch == "gpt2":  # Conv1D projections ([in, out] weights), LayerNorm, tied embeddings
+        from transformers import GPT2Config, GPT2LMHeadModel
+
+        return GPT2LMHeadModel(GPT2Config(n_embd=128, n_layer=2, n_head=4, vocab_size=96, n_positions=64,
+                                          architectures=["GPT2LMHeadModel"])).to(dtype).eval()
     if arch == "mixtral":
         cfg = MixtralConfig(architectures=["MixtralForCausalLM"], num_local_experts=4, num_experts_per_tok=2, **CFG)
         return MixtralForCausalLM(cfg).to(dtype).eval()
@@ -112,6 +121,8 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("MXFP4_DEFAULT_CFG", torch.bfloat16, False, "mixtral", None),
     ("INT8_DEFAULT_CFG", torch.float32, False, "opt", None), ("INT8_SMOOTHQUANT_CFG", torch.float16, False, "opt", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "opt", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen2", None), ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "qwen2", None),
+    ("FP8_DEFAULT_CFG", torch.float32, False, "gpt2", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
