@@ -289,27 +289,50 @@ def export_fused_experts(module, dtype: torch.dtype) -> dict:
     return out
 
 
-# checkpoint names that differ from the module tree: transformers >= 5 loads / saves some architectures through a
-# key conversion (its save_pretrained applies the reverse mapping to whatever state dict it is given -- which is how
-# the reference's exported tensors get these names); (regex on our key, replacement)
-_CHECKPOINT_KEY_RENAMES = {
-    "mixtral": [(r"\.mlp\.experts\.(\d+)\.gate_proj\.", r".block_sparse_moe.experts.\1.w1."),
-                (r"\.mlp\.experts\.(\d+)\.down_proj\.", r".block_sparse_moe.experts.\1.w2."),
-                (r"\.mlp\.experts\.(\d+)\.up_proj\.", r".block_sparse_moe.experts.\1.w3."),
-                (r"\.mlp\.gate\.", r".block_sparse_moe.gate.")],
-}
+# Checkpoint names that differ from the module tree: transformers >= 5 loads / saves some architectures through a key
+# conversion (`transformers.conversion_mapping`), and its save_pretrained applies the REVERSE mapping to whatever state
+# dict it is given -- which is how the reference's exported tensors get the checkpoint's names.  The same reverse
+# mapping is derived here from transformers' own table: plain renamings (Mixtral: `.mlp.` -> `.block_sparse_moe.`) and
+# the per-expert projections a fused-experts converter was built from (`experts.*.w1 / w3` -> `experts.gate_up_proj`
+# tells that our `experts.N.gate_proj / up_proj` are `w1 / w3`).
+def _checkpoint_rename_rules(model_type):
+    import re
+
+    try:
+        from transformers import conversion_mapping as cm
+
+        mapping = cm.get_checkpoint_conversion_mapping(model_type)
+    except Exception:  # noqa: BLE001 -- older transformers: module trees and checkpoints share their names
+        mapping = None
+    rules = []
+    for item in mapping or []:
+        src = list(getattr(item, "source_patterns", []) or [])
+        tgt = list(getattr(item, "target_patterns", []) or [])
+        if type(item).__name__ == "WeightRenaming" and len(src) == 1 and len(tgt) == 1:
+            rules.append(("rename", tgt[0], src[0]))
+        elif type(item).__name__ == "WeightConverter" and len(tgt) == 1 and tgt[0].endswith(("experts.gate_up_proj", "experts.down_proj")):
+            ours = ["gate_proj", "up_proj"] if tgt[0].endswith("gate_up_proj") else ["down_proj"]
+            for our_name, pat in zip(ours, src):
+                m = re.search(r"experts\.\*\.([A-Za-z0-9_]+)\.weight$", pat)
+                if m and m.group(1) != our_name:
+                    rules.append(("expert", our_name, m.group(1)))
+    return rules
 
 
 def rename_to_checkpoint_keys(state: dict, model) -> dict:
     import re
 
-    rules = _CHECKPOINT_KEY_RENAMES.get(getattr(getattr(model, "config", None), "model_type", None))
+    rules = _checkpoint_rename_rules(getattr(getattr(model, "config", None), "model_type", None))
     if not rules:
         return state
     out = {}
     for k, v in state.items():
-        for pat, rep in rules:
-            k = re.sub(pat, rep, k)
+        for kind, a, b in rules:
+            if kind == "expert":
+                k = re.sub(rf"(\.experts\.\d+\.){re.escape(a)}\.", rf"\g<1>{b}.", k)
+        for kind, a, b in rules:
+            if kind == "rename":
+                k = k.replace(a, b)
         out[k] = v
     return out
 

@@ -69,7 +69,9 @@ def replace_quant_module(model: nn.Module) -> nn.Module:
     register_hf_attentions_on_the_fly(model)
     register_fused_experts_on_the_fly(model)
     for mod in list(model.modules()):
-        if type(mod) is nn.Linear:
+        # nn.Linear itself, and FalconLinear (an nn.Linear subclass computing input @ W.T + b), which the reference
+        # registers explicitly (plugins/huggingface.py:1417-1420, :1574-1590); other subclasses are left alone
+        if type(mod) is nn.Linear or (type(mod).__name__ == "FalconLinear" and isinstance(mod, nn.Linear)):
             QuantLinear.convert(mod)
         elif type(mod) is nn.LayerNorm:
             QuantLayerNorm.convert(mod)

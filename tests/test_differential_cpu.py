@@ -45,6 +45,20 @@ def _model(dtype, arch="llama"):
 
         return GPT2LMHeadModel(GPT2Config(n_embd=128, n_layer=2, n_head=4, vocab_size=96, n_positions=64,
                                           architectures=["GPT2LMHeadModel"])).to(dtype).eval()
+    if arch in ("mistral", "phi3", "gemma2", "qwen3_moe", "falcon"):
+        import transformers as tf
+
+        if arch == "mistral":
+            return tf.MistralForCausalLM(tf.MistralConfig(architectures=["MistralForCausalLM"], **CFG)).to(dtype).eval()
+        if arch == "phi3":  # fused qkv_proj / gate_up_proj linears
+            return tf.Phi3ForCausalLM(tf.Phi3Config(architectures=["Phi3ForCausalLM"], pad_token_id=0, **CFG)).to(dtype).eval()
+        if arch == "gemma2":  # soft-capped attention, tied embeddings
+            return tf.Gemma2ForCausalLM(tf.Gemma2Config(architectures=["Gemma2ForCausalLM"], head_dim=32, **CFG)).to(dtype).eval()
+        if arch == "falcon":  # FalconLinear (nn.Linear subclass), fused query_key_value
+            return tf.FalconForCausalLM(tf.FalconConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=4, vocab_size=96,
+                                                         architectures=["FalconForCausalLM"])).to(dtype).eval()
+        return tf.Qwen3MoeForCausalLM(tf.Qwen3MoeConfig(architectures=["Qwen3MoeForCausalLM"], moe_intermediate_size=64,
+                                                        num_experts=4, num_experts_per_tok=2, head_dim=32, **CFG)).to(dtype).eval()
     if arch == "mixtral":
         cfg = MixtralConfig(architectures=["MixtralForCausalLM"], num_local_experts=4, num_experts_per_tok=2, **CFG)
         return MixtralForCausalLM(cfg).to(dtype).eval()
@@ -123,6 +137,9 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "opt", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen2", None), ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "qwen2", None),
     ("FP8_DEFAULT_CFG", torch.float32, False, "gpt2", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mistral", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "phi3", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gemma2", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen3_moe", None),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "qwen3_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "falcon", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -135,6 +152,8 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
     ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
     if ref_logits is not None:  # the forward with fake quantization active, after calibration
         assert torch.equal(our_logits, ref_logits), f"{preset}: logits of the fake-quantized model differ"
+    if arch == "falcon":
+        return  # the reference's exporter leaves FalconLinear weights unpacked; calibration and fake quant are compared
     assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
     for k, want in ref_state.items():
         got = our_state[k].detach().cpu()
