@@ -30,6 +30,10 @@ def _model(dtype, arch="llama"):
     from transformers import LlamaConfig, LlamaForCausalLM, MixtralConfig, MixtralForCausalLM
 
     torch.manual_seed(7)
+    if arch == "llama-eager":  # eager attention: the KV quantizers are reached through eager_attention_forward
+        cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **CFG)
+        cfg._attn_implementation = "eager"
+        return LlamaForCausalLM(cfg).to(dtype).eval()
     if arch == "opt":  # BASELINE configs[0] family: biased linears, LayerNorm, learned positions
         from transformers import OPTConfig, OPTForCausalLM
 
@@ -140,6 +144,7 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mistral", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "phi3", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gemma2", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen3_moe", None),
     ("INT8_DEFAULT_CFG", torch.float32, False, "qwen3_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "falcon", None),
+    ("FP8_DEFAULT_CFG", torch.float32, True, "llama-eager", None), ("FP8_DEFAULT_CFG", torch.float16, True, "mixtral", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -176,7 +181,7 @@ def test_magnitude_sparsity_equals_the_reference_live(monkeypatch):
         assert torch.equal(our_masks[n].bool(), m.bool()), n
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_awq_lite_picks_the_reference_alphas_live(monkeypatch, dtype):
     """INT4_AWQ_CFG on the tiny Llama: the reference (debug=True keeps its per-linear state) and this package pick the
     same alpha for every linear; exported tensors agree within 2 ulp of the model dtype (the activation statistics are
@@ -280,3 +285,34 @@ def test_sparsegpt_equals_the_reference_live(monkeypatch):
         assert (got.view(got.shape[0], -1, 4).sum(-1) <= 2).all(), n
         same = (got == m.bool()).float().mean().item()
         assert same >= 0.99, f"{n}: only {same:.4f} of the mask equals the reference's"
+
+
+def test_awq_full_equals_the_reference_live(monkeypatch):
+    """algorithm awq_full = awq_lite, then awq_clip on the scaled weights: same alphas, clipped block amax equal up to
+    ties, pre_quant_scale within the statistics' summation order."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    cfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_full", "debug": True}
+    ref = mtq.quantize(_model(torch.float32), cfg, lambda m: [m(b) for b in batches])
+    ref_state = {n: (float(m.awq_lite.best_alpha), m.weight_quantizer._amax.detach().float().reshape(-1).clone(),
+                     m.input_quantizer._pre_quant_scale.detach().float().clone())
+                 for n, m in ref.named_modules() if hasattr(m, "awq_lite")}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(torch.float32)
+    cfg2 = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg2["algorithm"] = {"method": "awq_full"}
+    with torch.no_grad():
+        moa.quantize(ours, cfg2, lambda m: [m(b) for b in batches])
+    assert len(ref_state) == 14
+    total = differing = 0
+    for n, (alpha, amax, pqs) in ref_state.items():
+        lin = ours.get_submodule(n)
+        assert float(lin.awq_lite.best_alpha) == alpha, n
+        got = lin.weight_quantizer._amax.detach().float().reshape(-1)
+        total += amax.numel()
+        differing += int(((got - amax).abs() > 1e-5 * amax.abs()).sum())
+        assert ((lin.input_quantizer._pre_quant_scale.float() - pqs).abs() <= 1e-5 * pqs.abs()).all(), n
+    assert differing <= 0.01 * total, f"awq_full: {differing} of {total} block amax values differ"
