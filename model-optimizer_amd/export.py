@@ -130,13 +130,24 @@ def preprocess_linear_fusion(modules, resmooth_only: bool = False):
             m.weight_quantizer.amax = weight_amax
 
 
+def _layernorm_uses_weight_plus_one(module) -> bool:
+    """export/quant_utils.py:1432-1439: Gemma-style norms and zero-centred gammas scale by (1 + weight)."""
+    n = type(module).__name__
+    if any(k in n for k in ("LayerNorm1P", "GemmaRMSNorm", "Gemma2RMSNorm", "Gemma3RMSNorm")):
+        return True
+    return bool(getattr(module, "zero_centered_gamma", False))
+
+
 @torch.no_grad()
 def fuse_prequant_layernorm(layernorm_module, modules):
     """export/quant_utils.py:1442-1473: fold the (shared) pre_quant_scale into the preceding norm's weight."""
     if not hasattr(modules[0].input_quantizer, "_pre_quant_scale"):
         return
     pqs = modules[0].input_quantizer._pre_quant_scale.to(layernorm_module.weight.device)
-    fused = layernorm_module.weight * pqs
+    if _layernorm_uses_weight_plus_one(layernorm_module):
+        fused = (layernorm_module.weight + 1.0) * pqs - 1.0  # the norm multiplies by (1 + weight)
+    else:
+        fused = layernorm_module.weight * pqs
     layernorm_module.weight = nn.Parameter(fused.to(layernorm_module.weight.dtype))
     if getattr(layernorm_module, "bias", None) is not None:
         layernorm_module.bias = nn.Parameter(layernorm_module.bias * pqs)

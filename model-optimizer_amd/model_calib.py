@@ -291,6 +291,7 @@ class AWQLiteHelper:
         self.gram_owner = None  # the helper whose Gram matrix this one aliases (same input tensor)
         self.gram_stage = None  # ops.GramStage: several calibration batches per Gram launch
         self.gram_stage_denied = False
+        self.num_gram_steps = 0  # batches that reached the Gram accumulation (own or aliased)
         self.gram_symmetrized = False
 
     def search_operands(self, module):
@@ -347,7 +348,7 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
             w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
             err = w_hat.float().mul_(r).sub_(wf)
             h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
-    h.num_search_steps = h.num_cache_steps
+    h.num_search_steps = h.num_gram_steps
 
 
 @torch.no_grad()
@@ -377,6 +378,44 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             else:
                 h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
 
+    searched = {id(q) for _, m in mods for q in (m.weight_quantizer, m.input_quantizer)}
+    others = [q for q in _quantizers(model) if id(q) not in searched and q.is_enabled and not q._dynamic]
+    others_holder = nn.ModuleList(others)
+    # With other quantizers active (FP8 KV cache, ...) the reference's search pass sees THEIR quantization noise in
+    # the activations; the Gram matrices are then accumulated in a second pass instead of the cache pass.
+    state["gram_pass"] = "search" if others else "cache"
+
+    def accumulate_gram(h, input, x2):
+        h.num_gram_steps += 1
+        # Linears fed by the SAME tensor (q / k / v of an attention block, gate / up of an MLP) have the same
+        # Gram matrix: the first one accumulates it, the others alias it.  Identity of the tensor object is the
+        # test (a reference to the last input is kept, so its address cannot be reused in between).
+        owner = state.get("gram_owner") if state.get("gram_input") is input else None
+        if owner is not None and owner.gram is not None and owner.gram.shape == h.gram.shape \
+                and h.gram_owner in (None, owner):
+            if h.gram_owner is None:
+                h.gram_owner = owner
+                h.gram = owner.gram  # the own buffer is released
+            return
+        if h.gram_owner is not None:
+            raise RuntimeError("awq_lite (Gram search): a linear that shared its input with another one in an "
+                               "earlier batch got a different tensor now; use search='gemm' for this model")
+        if x2.dtype in (torch.bfloat16, torch.float16):
+            # G += X^T X / T_b on the matrix cores; several batches per launch when the staging buffer fits
+            if h.gram_stage is None and not h.gram_stage_denied:
+                if budget.reserve(ops.GramStage.nbytes(x2.shape[1], x2.shape[0])):
+                    h.gram_stage = ops.GramStage(h.gram, x2.shape[0], x2.dtype)
+                else:
+                    h.gram_stage_denied = True
+            if h.gram_stage is not None:
+                h.gram_stage.add(x2)
+            else:
+                ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)
+        else:
+            xf = x2.float()
+            h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
+        state["gram_input"], state["gram_owner"] = input, h
+
     def patched_forward(self, input):
         h = helpers[self]
         out_actual = F.linear(input, self.weight, self.bias)
@@ -389,35 +428,9 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.act_sum += (ssum / x2.shape[0]).to(input.dtype).float()
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
-            if h.gram is not None:
-                # Linears fed by the SAME tensor (q / k / v of an attention block, gate / up of an MLP) have the same
-                # Gram matrix: the first one accumulates it, the others alias it.  Identity of the tensor object is the
-                # test (a reference to the last input is kept, so its address cannot be reused in between).
-                owner = state.get("gram_owner") if state.get("gram_input") is input else None
-                if owner is not None and owner.gram is not None and owner.gram.shape == h.gram.shape \
-                        and h.gram_owner in (None, owner):
-                    if h.gram_owner is None:
-                        h.gram_owner = owner
-                        h.gram = owner.gram  # the own buffer is released
-                    return out_actual
-                if h.gram_owner is not None:
-                    raise RuntimeError("awq_lite (Gram search): a linear that shared its input with another one in an "
-                                       "earlier batch got a different tensor now; use search='gemm' for this model")
-                if x2.dtype in (torch.bfloat16, torch.float16):
-                    # G += X^T X / T_b on the matrix cores; several batches per launch when the staging buffer fits
-                    if h.gram_stage is None and not h.gram_stage_denied:
-                        if budget.reserve(ops.GramStage.nbytes(x2.shape[1], x2.shape[0])):
-                            h.gram_stage = ops.GramStage(h.gram, x2.shape[0], x2.dtype)
-                        else:
-                            h.gram_stage_denied = True
-                    if h.gram_stage is not None:
-                        h.gram_stage.add(x2)
-                    else:
-                        ops.hessian_accum(h.gram, x2, 1.0, 1.0 / x2.shape[0], upper_only=True)
-                else:
-                    xf = x2.float()
-                    h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
-                state["gram_input"], state["gram_owner"] = input, h
+        if state["mode"] == state["gram_pass"] and h.gram is not None and h.is_enabled:
+            accumulate_gram(h, input, x2)
+        if state["mode"] == "cache":
             return out_actual
         if h.use_gram or not h.is_enabled:
             return out_actual  # losses came from the Gram matrix / the linear is out of the search
@@ -439,14 +452,38 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
     for _, m in mods:
         originals[m] = m.forward
         m.forward = patched_forward.__get__(m, type(m))
-    try:
-        forward_loop(model)  # cache pass
+
+    def finish_gram_pass():
         state.pop("gram_input", None)
         state.pop("gram_owner", None)
         for h in helpers.values():
             if h.gram_stage is not None:
                 h.gram_stage.flush()
                 h.gram_stage = None
+
+    def gram_losses():  # Gram-matrix linears: all alpha losses from the (local) Gram; the loss is linear in it
+        for _, m in mods:
+            h = helpers[m]
+            if h.gram is not None and h.act_scale is not None:
+                own = h.gram_owner or h
+                if m.weight.dtype != torch.float32 and not own.gram_symmetrized:
+                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
+                    own.gram_symmetrized = True
+                _gram_losses(h, m)
+                h.gram = None  # release Cin^2 floats as soon as the last linear using them is done
+
+    try:
+        # every OTHER enabled quantizer (KV-cache bmm quantizers, linears outside the search, ...) collects its amax
+        # during the cache pass and quantizes during the search pass, as in the reference (:1574-1586)
+        for q in others:
+            q.disable_quant()
+            q.enable_calib()
+        forward_loop(model)  # cache pass
+        finish_stats_collection(others_holder)
+        if others and dist.is_available() and dist.is_initialized():
+            mdist.sync_amax_bucketed(others, device=mods[0][1].weight.device if mods else None)
+        if state["gram_pass"] == "cache":
+            finish_gram_pass()
         for h in helpers.values():
             if h.num_cache_steps:
                 h.act_scale = h.act_sum / h.num_cache_steps
@@ -462,18 +499,16 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 if not ok:
                     h.gram = None
                     h.use_gram = False
-        for _, m in mods:  # Gram-matrix linears: losses now (local Gram; the loss is linear in it, summed below)
-            h = helpers[m]
-            if h.gram is not None and h.act_scale is not None:
-                own = h.gram_owner or h
-                if m.weight.dtype != torch.float32 and not own.gram_symmetrized:
-                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
-                    own.gram_symmetrized = True
-                _gram_losses(h, m)
-                h.gram = None  # release Cin^2 floats as soon as the last linear using them is done
-        if any(not h.use_gram and h.act_scale is not None for h in helpers.values()):
+        if state["gram_pass"] == "cache":
+            gram_losses()
+        need_gemm = any(not h.use_gram and h.act_scale is not None for h in helpers.values())
+        need_gram = state["gram_pass"] == "search" and any(h.gram is not None for h in helpers.values())
+        if need_gemm or need_gram:
             state["mode"] = "search"
-            forward_loop(model)  # search pass for the linears on the error-GEMM path
+            forward_loop(model)  # search pass: error GEMMs, and the Gram matrices when they wait for quantized inputs
+            if need_gram:
+                finish_gram_pass()
+                gram_losses()
         for h in helpers.values():
             h.search_steps_all_ranks = h.num_search_steps
         if dist.is_available() and dist.is_initialized() and mods:
@@ -491,7 +526,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.gram = None
     for name, m in mods:
         h = helpers[m]
-        if h.is_enabled and h.search_steps_all_ranks == 0 and not h.use_gram:
+        if h.is_enabled and h.search_steps_all_ranks == 0:
             h.is_enabled = False  # :1665-1672
             warnings.warn("awq_lite: Calling `forward_loop(model)` the second time did not forward data through the "
                           f"{name}. Please provide a valid `forward_loop` function that can be used to forward data "

@@ -145,6 +145,11 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gemma2", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen3_moe", None),
     ("INT8_DEFAULT_CFG", torch.float32, False, "qwen3_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "falcon", None),
     ("FP8_DEFAULT_CFG", torch.float32, True, "llama-eager", None), ("FP8_DEFAULT_CFG", torch.float16, True, "mixtral", None),
+    # AWQ-lite search + resmooth + norm fusion + INT4 packing, end to end
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "opt", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "phi3", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "gpt2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "gemma2", None),
+    ("INT4_AWQ_CFG", torch.float16, True, "mistral", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -316,3 +321,22 @@ def test_awq_full_equals_the_reference_live(monkeypatch):
         differing += int(((got - amax).abs() > 1e-5 * amax.abs()).sum())
         assert ((lin.input_quantizer._pre_quant_scale.float() - pqs).abs() <= 1e-5 * pqs.abs()).all(), n
     assert differing <= 0.01 * total, f"awq_full: {differing} of {total} block amax values differ"
+
+
+@pytest.mark.parametrize("search", ["gram", "gemm"])
+def test_awq_lite_with_kv_cache_quantizers_both_search_modes_live(monkeypatch, search):
+    """INT4_AWQ + FP8 KV cache: the KV quantizers calibrate during the cache pass and quantize during the search pass
+    (model_calib.py:1574-1586), so the Gram search accumulates in the second pass; both search modes give the reference's
+    KV amax, alphas and checkpoint."""
+    ref_amax, ref_state = _reference_run("INT4_AWQ_CFG", torch.bfloat16, True)
+    hostmem_backend.install(monkeypatch, moa)
+    algo = {"method": "awq_lite", "alpha_step": 0.1, "search": search}
+    our_amax, our_state = _our_run("INT4_AWQ_CFG", torch.bfloat16, True, algorithm=algo)
+    assert any("k_bmm_quantizer" in n for n in ref_amax)
+    for n, a in ref_amax.items():
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
+    ref_state.pop("__logits__"), our_state.pop("__logits__")
+    assert sorted(our_state) == sorted(ref_state)
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), k
