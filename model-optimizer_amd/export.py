@@ -32,6 +32,7 @@ QUANTIZATION_INT8_WO = "int8_wo"
 QUANTIZATION_INT4_AWQ = "int4_awq"
 QUANTIZATION_MXFP4 = "mxfp4"
 QUANTIZATION_FP8_PB_WO = "fp8_pb_wo"
+QUANTIZATION_MXFP8 = "mxfp8"
 
 
 def get_quantization_format(module) -> str | None:
@@ -54,6 +55,10 @@ def get_quantization_format(module) -> str | None:
         if wq._axis is not None:  # QUANTIZATION_FP8_PC_PT (export/quant_utils.py:545-546): per-channel weight scales
             raise NotImplementedError("export of per-channel FP8 weights (fp8_pc_pt) is outside this path")
         return QUANTIZATION_FP8
+    if (isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is not None
+            and wq.block_sizes.get("type", "static") == "dynamic"
+            and tuple(wq.block_sizes.get("scale_bits") or ()) == (8, 0)):
+        return QUANTIZATION_MXFP8  # export/quant_utils.py:534-541
     if (isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is not None
             and wq.block_sizes.get("type", "static") != "dynamic"):
         return QUANTIZATION_FP8_PB_WO  # export/quant_utils.py:531-544 (fake-quant static blocks)
@@ -364,6 +369,14 @@ def export_quantized_weight(module, dtype: torch.dtype):
         w = module.weight.detach().to(dtype)
         packed, e8m0 = ops.mxfp4_quantize(w, block)
         return {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
+    if fmt == QUANTIZATION_MXFP8:
+        # unified_export_hf.py:671-679, export/quant_utils.py:871-872: E8M0 scale bytes [Cout, Cin / 32] from the block
+        # abs-max, E4M3 elements from the tile pack kernel
+        from .qtensor import MXFP8QTensor
+
+        w = module.weight.detach().to(dtype)
+        e8m0 = MXFP8QTensor.get_weights_scaling_factor_from_quantizer(w, wq)
+        return {"weight": MXFP8QTensor.quantize_with_scale(w, e8m0), "weight_scale": e8m0}
     if fmt == QUANTIZATION_FP8_PB_WO:
         # export/quant_utils.py:874-877: FP8QTensor.quantize(weight, scale.squeeze(), block_sizes on both axes); the
         # scale keeps the quantizer's amax shape [R/br, 1, C/bc, 1]
@@ -492,7 +505,7 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
 def hf_quant_config(model, group_size: int | None = None) -> dict:
     """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
     fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
-    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
+    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_MXFP8: "MXFP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
             QUANTIZATION_INT8_WO: "W8A16"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
     q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}

@@ -38,6 +38,17 @@ FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bit
 MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
                                    "*lm_head*": {"enable": False}}, "algorithm": None}
+
+
+def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8M0 block scales, weights and inputs
+    q = {"num_bits": num_bits, "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}}
+    return {"quant_cfg": {"*weight_quantizer": dict(q), "*input_quantizer": dict(q), "*lm_head*": {"enable": False}},
+            "algorithm": None}
+
+
+MXFP8_DEFAULT_CFG = _mx_cfg((4, 3))  # presets/model/mxfp8.yaml
+MXFP6_DEFAULT_CFG = _mx_cfg((3, 2))  # presets/model/mxfp6.yaml
+MXINT8_DEFAULT_CFG = _mx_cfg(8)      # presets/model/mxint8.yaml
 # presets/model/nvfp4.yaml quantizer layout (numerics/nvfp4.yaml): E2M1 elements in blocks of 16 with E4M3 block scales
 # relative to a max-calibrated tensor-wide amax (two-level scaling, tensor_quant_mx.cu:154-183).  The format is NVIDIA's;
 # what runs here is its fake quantization and calibration (no packed export)

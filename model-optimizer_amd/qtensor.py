@@ -132,3 +132,83 @@ class MXFP4QTensor(BaseQuantizedTensor):
         """mxfp4_tensor.py:83-144."""
         dtype = dtype or self.metadata["dtype"]
         return ops.mxfp4_dequantize(self._quantized_data, kwarg["scale"], dtype, kwarg["block_sizes"][-1])
+
+
+class MXFP8QTensor(BaseQuantizedTensor):
+    """E4M3 elements with one E8M0 scale byte per 32 elements of the last dim (qtensor/mxfp8_tensor.py:26-268).
+
+    Two passes over the tensor, both existing kernels: the per-block abs-max (row reduction of the (-1, 32) view,
+    `moq_amax_axis`) and the tile pack with a 1 x 32 tile (`moq_fp8_pack_tile`, fp32 scales: the quotient is not
+    rounded to the tensor dtype, as torch promotes `weight * scale_factor` to fp32).  The scale bytes in between are the
+    reference's own formula on the [..., K / 32] amax tensor.  Dividing by 2^(e-127) here is the reference's
+    multiplication by 2^(127-e): both are exact up to the same final rounding (fp32 denormals are preserved on gfx950).
+    """
+
+    E4M3_MAX = 448.0
+    BLOCK_SIZE = 32
+    SCALE_DTYPE = torch.uint8
+
+    @classmethod
+    def _compute_e8m0_exponent(cls, amax: torch.Tensor) -> torch.Tensor:
+        """mxfp8_tensor.py:43-68: ceil(log2(amax / 448)) in fp32, -127 for blocks without a positive amax."""
+        descale = amax.float() / cls.E4M3_MAX
+        log2_descale = torch.where(descale > 0, torch.log2(descale), torch.tensor(-127.0, device=descale.device))
+        return torch.clamp(torch.ceil(log2_descale), min=-127, max=127)
+
+    @classmethod
+    def get_weights_scaling_factor(cls, weight: torch.Tensor) -> torch.Tensor:
+        """mxfp8_tensor.py:70-97: uint8 biased exponents [..., K / 32]."""
+        assert weight.dim() >= 2, f"Weight must be at least 2D, got {weight.dim()}D"
+        assert weight.shape[-1] % cls.BLOCK_SIZE == 0, (
+            f"Weight inner dimension ({weight.shape[-1]}) must be divisible by MXFP8 block size ({cls.BLOCK_SIZE})")
+        amax = ops.reduce_block_amax(weight, {-1: cls.BLOCK_SIZE})
+        return (cls._compute_e8m0_exponent(amax) + 127).to(cls.SCALE_DTYPE)
+
+    @classmethod
+    def get_weights_scaling_factor_from_quantizer(cls, weight: torch.Tensor, weight_quantizer) -> torch.Tensor:
+        """mxfp8_tensor.py:99-147."""
+        assert weight_quantizer.block_sizes[-1] == cls.BLOCK_SIZE, (
+            f"MXFP8 requires block size {cls.BLOCK_SIZE}, got {weight_quantizer.block_sizes[-1]}")
+        expected = (*weight.shape[:-1], weight.shape[-1] // cls.BLOCK_SIZE)
+        scale = getattr(weight_quantizer, "_scale", None)
+        if scale is not None:
+            assert scale.dtype == cls.SCALE_DTYPE, f"MXFP8 scale must be {cls.SCALE_DTYPE} (E8M0 format), got {scale.dtype}"
+            assert tuple(scale.shape) == expected, f"Scale shape {scale.shape} does not match expected shape {expected}"
+            return scale
+        return cls.get_weights_scaling_factor(weight)
+
+    @classmethod
+    def quantize_with_scale(cls, weight: torch.Tensor, weights_scaling_factor: torch.Tensor) -> torch.Tensor:
+        """mxfp8_tensor.py:149-197: float8_e4m3fn tensor of the weight's shape."""
+        assert weights_scaling_factor.dtype == cls.SCALE_DTYPE, (
+            f"weights_scaling_factor must be {cls.SCALE_DTYPE} (E8M0 format), got {weights_scaling_factor.dtype}")
+        k = weight.shape[-1]
+        assert k % cls.BLOCK_SIZE == 0, f"Weight inner dimension ({k}) must be divisible by MXFP8 block size ({cls.BLOCK_SIZE})"
+        descale = torch.exp2(weights_scaling_factor.float() - 127)
+        q = ops.fp8_quantize_tile(weight.detach().reshape(-1, k), descale.reshape(-1, k // cls.BLOCK_SIZE), 1, cls.BLOCK_SIZE)
+        return q.view(weight.shape)
+
+    @classmethod
+    def quantize(cls, input: torch.Tensor, weights_scaling_factor: torch.Tensor | None = None):
+        """mxfp8_tensor.py:199-233: ragged last dims are zero-padded to a whole block and cropped afterwards."""
+        shape, dtype = input.shape, input.dtype
+        x = ops.reduce_block_padding(input, {-1: cls.BLOCK_SIZE})
+        if weights_scaling_factor is None:
+            amax = ops.reduce_block_amax(x, {-1: cls.BLOCK_SIZE})
+            weights_scaling_factor = (cls._compute_e8m0_exponent(amax) + 127).to(cls.SCALE_DTYPE)
+        q = cls.quantize_with_scale(x, weights_scaling_factor)[..., : shape[-1]]
+        return cls(shape, dtype, q), weights_scaling_factor
+
+    def dequantize(self, dtype: torch.dtype = None, **kwarg):
+        """mxfp8_tensor.py:235-268: e4m3 value * 2^(e - 127), computed in fp32, cast to `dtype`."""
+        assert "scale" in kwarg, "dequantize requires 'scale' in kwargs"
+        dtype = dtype or self.metadata["dtype"]
+        shape = self.metadata["shape"]
+        q = ops.reduce_block_padding(self._quantized_data.view(torch.uint8), {-1: self.BLOCK_SIZE})
+        k = q.shape[-1]
+        descale = torch.exp2(kwarg["scale"].float() - 127)
+        # the product of an e4m3 value and a power of two is exact in fp32, so rounding it once to `dtype` is the
+        # reference's fp32 product followed by .to(dtype)
+        out = ops.fp8_dequantize_tile(q.reshape(-1, k).view(torch.float8_e4m3fn), descale.reshape(-1, k // self.BLOCK_SIZE),
+                                      torch.float32, 1, self.BLOCK_SIZE)
+        return out.view(*q.shape)[..., : shape[-1]].to(dtype)

@@ -1019,14 +1019,47 @@ def gen_export_int8_sq(out):
                                              hf_quant_config=quant_cfg)))
 
 
+def gen_mxfp8(out):
+    """MXFP8QTensor (qtensor/mxfp8_tensor.py:26-268) on CPU: E8M0 scale bytes, E4M3 bytes and the dequantised tensor
+    for 2-D / 3-D weights, a ragged last dim, all-zero blocks, block maxima ON the 448 * 2^k boundary and tiny /
+    huge magnitudes (exponent clamps)."""
+    from modelopt.torch.quantization.qtensor import MXFP8QTensor
+
+    cases = {}
+    idx = 0
+    for dn, dt in DT.items():
+        for shape, kind in [((48, 256), "normal"), ((3, 16, 64), "moe3d"), ((5, 70), "ragged"), ((8, 128), "edges")]:
+            w = weight_like(shape, dt, 1700 + idx)
+            if kind == "normal":
+                w[1, :32] = 0
+                w[2, 32:64] = w[2, 32:64] * 1e4
+            if kind == "edges":
+                w[0, :32] = 0
+                w[1, 0] = 448.0          # descale == 1 exactly
+                w[2, 0] = 1.75           # 448 * 2^-8
+                w[3, 0] = 3.5 * 2.0 ** -20
+                w[4, :32] = w[4, :32] * 1e-30 if dt != torch.float16 else w[4, :32] * 1e-4
+                w[5, 0] = 6e4 if dt == torch.float16 else 3e38
+                w[6, 0] = 449.0 if dt == torch.float32 else 450.0
+                w[7, 5] = -448.0
+            qt, e8 = MXFP8QTensor.quantize(w)
+            deq = qt.dequantize(scale=e8)
+            k = f"{dn}_{kind}"
+            out[f"{k}_x"], out[f"{k}_q"] = bits(w), qt._quantized_data.view(torch.uint8).numpy().copy()
+            out[f"{k}_e8m0"], out[f"{k}_deq"] = e8.numpy().copy(), bits(deq)
+            cases[k] = dict(dtype=dn, shape=list(shape), kind=kind)
+            idx += 1
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

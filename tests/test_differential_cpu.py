@@ -91,7 +91,7 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     amax = {n: m._amax.detach().float().clone() for n, m in q.named_modules()
             if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
     logits = None
-    if "MXFP4" not in preset:  # the reference's MX fake quant has no CPU implementation
+    if "MXFP" not in preset:  # the reference's MX fake quant has no CPU implementation
         with torch.no_grad():
             logits = q(batches[0]).logits.clone()
     out = {"__logits__": logits}
@@ -150,6 +150,8 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "phi3", None),
     ("INT4_AWQ_CFG", torch.bfloat16, False, "gpt2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "gemma2", None),
     ("INT4_AWQ_CFG", torch.float16, True, "mistral", None),
+    ("MXFP8_DEFAULT_CFG", torch.bfloat16, False, "llama", None), ("MXFP8_DEFAULT_CFG", torch.float16, True, "qwen2", None),
+    ("MXFP8_DEFAULT_CFG", torch.float32, False, "opt", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)

@@ -33,6 +33,8 @@ SELECTED = {
     "test_gpu_calibrate_weights": ["test_row_hist_equals_numpy_on_reference_weights", "test_calibrate_weights_matches_reference_run"],
     "test_gpu_fp8_2d": ["test_fp8_qtensor_2d_blocks_match_reference_run", "test_fp8_2d_blockwise_export_is_byte_identical",
                         "test_reduce_block_amax_and_padding"],
+    "test_gpu_mxfp8": ["test_mxfp8_qtensor_matches_reference_run", "test_mxfp8_rejects_wrong_scale_dtype_and_block",
+                       "test_mxfp8_preset_exports_e4m3_weights_with_e8m0_scales"],
     "test_gpu_reference_style": None,  # None: every test of the module
     "test_gpu_clip": ["test_clip_loss_matches_reference_run", "test_quantize_awq_clip_matches_reference"],
     "test_gpu_sparsegpt": ["test_create_sgpt_mask_matches_reference", "test_hessian_matches_reference_hook",

@@ -234,3 +234,21 @@ def test_mlp_awq_lite_equals_reference(golden, hostmem, name, search):
         close(lin.input_quantizer._pre_quant_scale, g.t(f"{name}_{lname}_input_quantizer_pre_quant_scale"), tol, f"{lname} pqs")
         close(lin.weight_quantizer._amax, g.t(f"{name}_{lname}_weight_quantizer_amax"), tol, f"{lname} weight amax")
         close(lin.weight, g.t(f"{name}_{lname}_wfinal", dt), tol * 10, f"{lname} folded weight")
+
+
+@pytest.mark.parametrize("preset,fmt", [("MXFP8_DEFAULT_CFG", "E4M3"), ("MXFP6_DEFAULT_CFG", "E3M2"),
+                                        ("MXINT8_DEFAULT_CFG", "INT8"), ("MXFP4_DEFAULT_CFG", "E2M1")])
+def test_mx_presets_configure_dynamic_e8m0_block_quantizers(hostmem, preset, fmt):
+    """presets/model/mx{fp8,fp6,int8,fp4}.yaml: weights and inputs in blocks of 32 with E8M0 scales, no calibration;
+    the weight QDQ is the fused block kernel's result for that element format."""
+    from oracle import oracle
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 32)).to(torch.bfloat16)
+    moa.quantize(model, getattr(moa.model_quant, preset), None)
+    lin = model[0]
+    for q in (lin.weight_quantizer, lin.input_quantizer):
+        assert q.is_enabled and q._block_dynamic and q.block_sizes[-1] == 32 and not hasattr(q, "_amax")
+    w = lin.weight.detach()
+    assert_bits_equal(lin.weight_quantizer(w), oracle.mx_fused_amax_convert(w, 32, fmt, "E8M0", None), preset)
+    assert model(torch.randn(3, 64).to(torch.bfloat16)).shape == (3, 32)
