@@ -46,6 +46,13 @@ def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8
             "algorithm": None}
 
 
+# presets/model/fp8_per_channel_per_token.yaml: per-output-channel FP8 weights, FP8 inputs with a dynamic abs-max per
+# token ({-1: None}: the last dim is reduced; becomes `axis` on the first input).  Calibration and fake quantization;
+# the fp8_pc_pt checkpoint format is not exported on this path
+FP8_PER_CHANNEL_PER_TOKEN_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "axis": 0},
+                                               "*input_quantizer": {"num_bits": (4, 3), "axis": None, "type": "dynamic",
+                                                                    "block_sizes": {-1: None}},
+                                               "*lm_head*": {"enable": False}}, "algorithm": "max"}
 MXFP8_DEFAULT_CFG = _mx_cfg((4, 3))  # presets/model/mxfp8.yaml
 MXFP6_DEFAULT_CFG = _mx_cfg((3, 2))  # presets/model/mxfp6.yaml
 MXINT8_DEFAULT_CFG = _mx_cfg(8)      # presets/model/mxint8.yaml

@@ -206,6 +206,14 @@ def _amax_mode(inputs: torch.Tensor, amax: torch.Tensor):
         raise MoquantUnsupported("amax must be a scalar or have exactly one non-singleton dim")
     if amax.dim() == inputs.dim():
         if amax.squeeze().dim() > 1:
+            # amax over a leading prefix of dims (per-token activations: [B, T, 1] for [B, T, H]) is axis 0 of the
+            # [B * T, H] view of a contiguous input
+            k = max(d for d in range(amax.dim()) if amax.shape[d] != 1) + 1
+            if tuple(amax.shape[:k]) == tuple(inputs.shape[:k]) and inputs.is_contiguous():
+                inner = 1
+                for d in range(k, inputs.dim()):
+                    inner *= inputs.shape[d]
+                return _lib.AMAX_AXIS, amax.numel(), inner
             # reference: ValueError -> caller falls back to eager (tensor_quant.py:386-389)
             raise MoquantUnsupported("multi-dimensional amax is not supported by the kernel")
         axis = list(amax.shape).index(amax.numel())

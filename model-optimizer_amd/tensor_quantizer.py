@@ -311,6 +311,19 @@ class TensorQuantizer(nn.Module):
         return outputs
 
     # ------------------------------------------------------------------ forward
+    def _block_sizes_to_axis(self, x):
+        """tensor_quantizer.py:1056-1085: block_sizes whose sizes are all None name the REDUCED dims (per-token
+        activations: {-1: None}); they become the complementary `axis` on the first input and block_sizes is dropped."""
+        bs = self._block_sizes
+        if bs is None or not all(v is None for k, v in bs.items() if isinstance(k, int)):
+            return
+        assert self._axis is None, "Axis and block_sizes are both set."
+        reduced = tuple(k if k >= 0 else k + x.dim() for k in bs if isinstance(k, int))
+        self._axis = tuple(i for i in range(x.dim()) if i not in reduced) or None
+        if getattr(self, "_calibrator", None) is not None:
+            self._calibrator._axis = self._axis
+        self._block_sizes = None
+
     def _get_amax(self, inputs):
         if hasattr(self, "_amax"):
             return self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
@@ -362,6 +375,8 @@ class TensorQuantizer(nn.Module):
                 inputs = inputs * pqs
         if self._disabled:
             return inputs
+        if self._block_sizes is not None and self._fake_quant:
+            self._block_sizes_to_axis(inputs)
         if fused_pqs:
             # AWQ search inner op: QDQ_g((W * s).to(dtype)) with dynamic group amax, one read + one write
             return ops.awq_scale_qdq(inputs, pqs, self._block_size_last(inputs), self._num_bits)
