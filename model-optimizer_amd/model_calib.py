@@ -23,6 +23,7 @@ from . import ops
 from .multi_tensor import SegmentTable
 from .hf_experts import is_quant_fused_experts
 from .nn import QuantLinear, is_quantized_linear
+from ._lib import MoquantUnsupported
 from .tensor_quantizer import SequentialQuantizer, TensorQuantizer
 
 
@@ -31,24 +32,31 @@ def _quantizers(model):
 
 
 def enable_stats_collection(model: nn.Module):
-    """model_calib.py:1128-1141."""
+    """model_calib.py:1128-1141.  Every enabled quantizer stops quantizing while statistics are collected -- the
+    dynamic ones too (their `enable_calib` is a no-op), so that the static quantizers downstream of them calibrate on
+    clean activations; a quantizer without a calibrator is switched off altogether (:1140-1141)."""
     for q in _quantizers(model):
-        if q.is_enabled and not q._dynamic:
+        if not q.is_enabled:
+            continue
+        if q._calibrator is not None:
             q.disable_quant()
             q.enable_calib()
+        else:
+            q.disable()
 
 
 def finish_stats_collection(model: nn.Module, method: str | None = None, **kwargs):
     """model_calib.py:1144-1167: load_calib_amax on every calibrated quantizer, back to quant mode."""
     for q in _quantizers(model):
-        if not q.is_enabled or q._dynamic:
+        if not q.is_enabled:
             continue
-        amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
-        if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
-            if hasattr(q, "_amax") and q._amax.shape != amax.shape:
-                delattr(q, "_amax")
-            q.amax = amax
-        q.enable_quant()
+        if q._calibrator is not None and not q._dynamic:
+            amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
+            if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
+                if hasattr(q, "_amax") and q._amax.shape != amax.shape:
+                    delattr(q, "_amax")
+                q.amax = amax
+        q.enable_quant()  # dynamic quantizers come back on here (:1166)
         q.disable_calib()
 
 
@@ -248,8 +256,10 @@ class _WeightCacheBudget:
     calibration batches (the reference re-quantizes them on every forward, model_calib.py:1552-1554).  288 GB of
     HBM3E hold all of Llama-3-8B's candidates (11 x 14 GB); larger models cache what fits and recompute the rest."""
 
+    host_bytes = 0  # budget on a non-GPU device (the CPU test tier's stand-in backend sets it)
+
     def __init__(self, device):
-        self.left = 0
+        self.left = int(self.host_bytes)
         if device.type == "cuda":
             free, _ = torch.cuda.mem_get_info(device)
             self.left = int(free * 0.6)
@@ -259,6 +269,9 @@ class _WeightCacheBudget:
             self.left -= nbytes
             return True
         return False
+
+    def release(self, nbytes: int):
+        self.left += nbytes
 
 
 class AWQLiteHelper:
@@ -293,19 +306,28 @@ class AWQLiteHelper:
         self.gram_stage_denied = False
         self.num_gram_steps = 0  # batches that reached the Gram accumulation (own or aliased)
         self.gram_symmetrized = False
+        self.gram_bytes = 0  # what this helper holds of the HBM budget for its Gram matrix
+        # tie-aware re-evaluation (search="auto"): candidates whose Gram loss lies within the margin of the best one
+        # are re-scored by the exact-rounding error-GEMM engine; `gram_loss` keeps the Gram scores for inspection
+        self.gram_loss = None
+        self.contenders = None  # indices into `alphas`, ascending; None: the Gram scores decide
+        self.exact_buf = None  # fp32 [len(contenders)] accumulated by the error GEMM
+        self.num_exact_steps = 0
 
-    def search_operands(self, module):
+    def search_operands(self, module, subset=None):
         """(inv_s [A, Cin] fp32 = (1/s_alpha) rounded to the weight dtype, w_hat [A, Cout, Cin] = QDQ(W * s_alpha))
-        for all candidates.  Scales depend on alpha only (act_scale is final in the search pass) and are computed
-        once; w_hat stays resident when the budget allows, otherwise it is rebuilt per batch."""
+        for all candidates (or the `subset` of candidate indices -- fixed for the life of the caches).  Scales depend
+        on alpha only (act_scale is final in the search pass) and are computed once; w_hat stays resident when the
+        budget allows, otherwise it is rebuilt per batch."""
         dt = module.weight.dtype
         if self._inv_scale is None:
-            scales = [get_scale(self.act_scale, self.weight_scale, a) for a in self.alphas]
+            alphas = self.alphas if subset is None else [self.alphas[i] for i in subset]
+            scales = [get_scale(self.act_scale, self.weight_scale, a) for a in alphas]
             self._inv_scale = torch.stack([(1 / s).to(dt).float() for s in scales]).contiguous()
             self._scale_dt = [s.to(dt) for s in scales]
         w_hat = self._w_hat
         if w_hat is None:
-            w_hat = torch.empty(len(self.alphas), *module.weight.shape, dtype=dt, device=module.weight.device)
+            w_hat = torch.empty(len(self._scale_dt), *module.weight.shape, dtype=dt, device=module.weight.device)
             for i, s in enumerate(self._scale_dt):
                 ops.awq_scale_qdq(module.weight, s, self.block_size, module.weight_quantizer.num_bits, out=w_hat[i])
             if self._cache_w:
@@ -351,8 +373,18 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     h.num_search_steps = h.num_gram_steps
 
 
+# Relative margin inside which two candidates' Gram scores do not decide the search (search="auto").  The Gram loss
+# differs from the reference-structured loss by the roundings of x/s, `out` and `out_actual` to the model dtype: a term
+# that is almost the same for every alpha of a linear plus a small alpha-dependent part.  The bounds are the
+# measured worst case of (loss_gemm - loss_gram)(alpha) - (loss_gemm - loss_gram)(alpha') over every pair of candidates,
+# relative to the best loss, on the full-size synthetic Llama-3-8B run (profiles/r02_awq_tie_margin.md), times a
+# safety factor; fp32 models agree with the reference to 4e-7 (tests/test_gpu_host.py).
+GRAM_TIE_MARGIN = {torch.bfloat16: 3e-2, torch.float16: 6e-3, torch.float32: 2e-5}
+
+
 @torch.no_grad()
-def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto"):
+def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto",
+             tie_margin: float | None = None):
     """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
     (the INT4_AWQ_CFG preset).
 
@@ -360,26 +392,40 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              alpha the patched forward's GEMM, here one batched MFMA error-GEMM launch per linear and batch);
     search = "gram": ONE pass of forward_loop that also accumulates every linear's Gram matrix on the matrix cores
              (ops.hessian_accum); all alpha losses then come from trace(E G E^T) (see _gram_losses);
-    search = "auto" (default): "gram" for the linears whose Gram matrix fits the HBM budget, "gemm" for the rest."""
+    search = "auto" (default): the Gram scores screen the candidates of every linear whose Gram matrix fits the HBM
+             budget ("gemm" for the rest); candidates whose score lies within `tie_margin` (relative; default
+             GRAM_TIE_MARGIN of the weight dtype) of the linear's best one are re-scored in a further pass by the
+             error-GEMM engine -- the reference's arithmetic with all its roundings -- and the best alpha is the
+             first minimum of THOSE scores, so that the selection equals search="gemm" (model_calib.py:1489-1495,
+             :1548-1556, :1637).  Linears with a clear winner cost nothing extra; when no linear has a near-tie the
+             extra pass is skipped."""
     if search not in ("auto", "gram", "gemm"):
         raise ValueError(f"awq_lite: unknown search mode {search!r}")
     mods = [(n, m) for n, m in model.named_modules()
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    for n, m in mods:
+        if m.input_quantizer.is_enabled:
+            # the reference max-calibrates such inputs in the cache pass and searches on the quantized activations
+            # (is_input_quantized, :1427, :1527-1531); that branch (W4A8 AWQ) is outside this path
+            raise MoquantUnsupported(f"awq_lite: {n}: the AWQ search with an enabled input quantizer is outside this "
+                                     "path; disable the input quantizers of the searched linears")
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
-    state = {"mode": "cache"}
+    state = {"mode": "cache", "do_gemm": True, "do_exact": False}
     if mods:
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
             h = helpers[m]
             cin = m.weight.shape[1]
-            if search != "gemm" and cin % 4 == 0 and (search == "gram" or budget.reserve(4 * cin * cin)):
+            fits = search != "gemm" and cin % 4 == 0 and budget.reserve(4 * cin * cin)
+            if fits or (search == "gram" and cin % 4 == 0):
                 h.gram = torch.zeros(cin, cin, dtype=torch.float32, device=m.weight.device)
+                h.gram_bytes = 4 * cin * cin if fits else 0
                 h.use_gram = True
             else:
                 h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
 
     searched = {id(q) for _, m in mods for q in (m.weight_quantizer, m.input_quantizer)}
-    others = [q for q in _quantizers(model) if id(q) not in searched and q.is_enabled and not q._dynamic]
+    others = [q for q in _quantizers(model) if id(q) not in searched and q.is_enabled]
     others_holder = nn.ModuleList(others)
     # With other quantizers active (FP8 KV cache, ...) the reference's search pass sees THEIR quantization noise in
     # the activations; the Gram matrices are then accumulated in a second pass instead of the cache pass.
@@ -396,6 +442,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             if h.gram_owner is None:
                 h.gram_owner = owner
                 h.gram = owner.gram  # the own buffer is released
+                budget.release(h.gram_bytes)
+                h.gram_bytes = 0
             return
         if h.gram_owner is not None:
             raise RuntimeError("awq_lite (Gram search): a linear that shared its input with another one in an "
@@ -416,6 +464,20 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.gram.addmm_(xf.t(), xf, alpha=1.0 / x2.shape[0])
         state["gram_input"], state["gram_owner"] = input, h
 
+    def error_gemms(self, h, x2, out2, subset, loss_buf):
+        """loss_buf[j] += mean((linear(x / s_a, QDQ(W s_a)) - out_actual)^2) for the candidates `subset` (None: all)
+        with the reference's roundings (x/s, the output and out_actual in the model dtype)."""
+        inv_s, w_hat = h.search_operands(self, subset)
+        if ops.mfma_gemm_supported(x2, self.weight):
+            # all candidates in two launches: xs[a] = x * (1/s_a) (one read of x), then the batched MFMA
+            # contraction with the (out - out_actual)^2 mean fused -- `out` never reaches HBM
+            xs = ops.scale_cols_multi(x2, inv_s)
+            ops.awq_err_gemm_multi(xs, w_hat, out2, self.bias, loss_buf)
+        else:  # fp32 models: library GEMM, the reference's own arithmetic
+            for j in range(inv_s.shape[0]):
+                out = F.linear(ops.scale_cols(x2, inv_s[j]), w_hat[j], self.bias)
+                loss_buf[j] += (out - out2).float().pow(2).mean()
+
     def patched_forward(self, input):
         h = helpers[self]
         out_actual = F.linear(input, self.weight, self.bias)
@@ -430,22 +492,17 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.num_tokens += x2.shape[0]
         if state["mode"] == state["gram_pass"] and h.gram is not None and h.is_enabled:
             accumulate_gram(h, input, x2)
-        if state["mode"] == "cache":
+        if state["mode"] == "cache" or not h.is_enabled:
             return out_actual
-        if h.use_gram or not h.is_enabled:
-            return out_actual  # losses came from the Gram matrix / the linear is out of the search
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
-        inv_s, w_hat = h.search_operands(self)
-        if ops.mfma_gemm_supported(x2, self.weight):
-            # all 11 candidates in two launches: xs[a] = x * (1/s_a) (one read of x), then the batched MFMA
-            # contraction with the (out - out_actual)^2 mean fused -- `out` never reaches HBM
-            xs = ops.scale_cols_multi(x2, inv_s)
-            ops.awq_err_gemm_multi(xs, w_hat, out2, self.bias, h.loss_buf)
-        else:  # fp32 models: library GEMM, the reference's own arithmetic
-            for i, alpha in enumerate(h.alphas):
-                out = F.linear(ops.scale_cols(x2, inv_s[i]), w_hat[i], self.bias)
-                h.loss[alpha] += (out - out2).float().pow(2).mean()
-        h.num_search_steps += 1
+        if h.use_gram:
+            # scores came from the Gram matrix; only near-ties are re-scored with the reference's arithmetic
+            if state["do_exact"] and h.contenders is not None:
+                error_gemms(self, h, x2, out2, h.contenders, h.exact_buf)
+                h.num_exact_steps += 1
+        elif state["do_gemm"]:
+            error_gemms(self, h, x2, out2, None, h.loss_buf)
+            h.num_search_steps += 1
         return out_actual
 
     originals = {}
@@ -470,18 +527,53 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                     ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
                     own.gram_symmetrized = True
                 _gram_losses(h, m)
+                budget.release(h.gram_bytes)  # an owner's matrix really goes when its last alias has been scored
+                h.gram_bytes = 0
                 h.gram = None  # release Cin^2 floats as soon as the last linear using them is done
+
+    def pick_contenders() -> bool:
+        """After the Gram scores are known: which candidates of which linears need the exact engine.  The decision is
+        taken on the scores summed over the data-parallel group, so every rank re-scores the same candidates."""
+        scored = [(m, helpers[m]) for _, m in mods if helpers[m].use_gram and helpers[m].is_enabled
+                  and helpers[m].act_scale is not None]
+        if not scored:
+            return False
+        distributed = dist.is_available() and dist.is_initialized()
+        if distributed:
+            steps = torch.tensor([float(h.num_search_steps) for _, h in scored], device=scored[0][0].weight.device)
+            mdist.all_reduce_bucket([h.loss_buf for _, h in scored] + [steps], dist.ReduceOp.SUM)
+            for (_, h), n in zip(scored, steps.tolist()):
+                h.search_steps_all_ranks = int(n)
+                h.loss_synced = True
+        if search != "auto":
+            return False
+        table = torch.stack([h.loss_buf for _, h in scored]).cpu()  # one host sync for all linears
+        any_tie = False
+        for (m, h), row in zip(scored, table.tolist()):
+            h.gram_loss = list(row)
+            margin = GRAM_TIE_MARGIN.get(m.weight.dtype, 3e-2) if tie_margin is None else tie_margin
+            best = min(row)  # a NaN score never compares smaller: such a linear keeps the plain first-minimum rule
+            if not math.isfinite(best):
+                continue
+            close = [i for i, v in enumerate(row) if v <= best * (1.0 + margin)]
+            if len(close) > 1:
+                h.contenders = close
+                h.exact_buf = torch.zeros(len(close), dtype=torch.float32, device=m.weight.device)
+                h._inv_scale = h._scale_dt = h._w_hat = None
+                h._cache_w = budget.reserve(len(close) * m.weight.numel() * m.weight.element_size())
+                any_tie = True
+        return any_tie
 
     try:
         # every OTHER enabled quantizer (KV-cache bmm quantizers, linears outside the search, ...) collects its amax
-        # during the cache pass and quantizes during the search pass, as in the reference (:1574-1586)
-        for q in others:
-            q.disable_quant()
-            q.enable_calib()
+        # during the cache pass and quantizes during the search pass, as in the reference (:1574-1586); dynamic ones
+        # are switched to pass-through for the cache pass
+        enable_stats_collection(others_holder)
         forward_loop(model)  # cache pass
         finish_stats_collection(others_holder)
         if others and dist.is_available() and dist.is_initialized():
-            mdist.sync_amax_bucketed(others, device=mods[0][1].weight.device if mods else None)
+            mdist.sync_amax_bucketed([q for q in others if not q._dynamic],
+                                     device=mods[0][1].weight.device if mods else None)
         if state["gram_pass"] == "cache":
             finish_gram_pass()
         for h in helpers.values():
@@ -501,23 +593,42 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                     h.use_gram = False
         if state["gram_pass"] == "cache":
             gram_losses()
+            state["do_exact"] = pick_contenders()
         need_gemm = any(not h.use_gram and h.act_scale is not None for h in helpers.values())
         need_gram = state["gram_pass"] == "search" and any(h.gram is not None for h in helpers.values())
-        if need_gemm or need_gram:
+        if need_gemm or need_gram or state["do_exact"]:
             state["mode"] = "search"
-            forward_loop(model)  # search pass: error GEMMs, and the Gram matrices when they wait for quantized inputs
+            # search pass: error GEMMs (all candidates of the linears without a Gram matrix, the near-ties of the
+            # others), and the Gram matrices when they had to wait for quantized inputs
+            forward_loop(model)
+            state["do_gemm"] = False
             if need_gram:
                 finish_gram_pass()
                 gram_losses()
+                state["gram_pass"] = None
+                state["do_exact"] = pick_contenders()
+                if state["do_exact"]:
+                    forward_loop(model)  # the near-ties of linears whose Gram matrix came from this pass
         for h in helpers.values():
-            h.search_steps_all_ranks = h.num_search_steps
+            if not getattr(h, "loss_synced", False):
+                h.search_steps_all_ranks = h.num_search_steps
+            h.exact_steps_all_ranks = h.num_exact_steps
         if dist.is_available() and dist.is_initialized() and mods:
             # every rank must pick the same alpha -- and take the same "was it searched at all" decision: SUM the
-            # per-alpha losses and the search-step counters in one bucket
-            steps = torch.tensor([float(h.num_search_steps) for h in helpers.values()], device=mods[0][1].weight.device)
-            mdist.all_reduce_bucket([h.loss_buf for h in helpers.values()] + [steps], dist.ReduceOp.SUM)
-            for h, n in zip(helpers.values(), steps.tolist()):
+            # per-alpha losses and the search-step counters in one bucket (Gram-scored linears were summed when the
+            # near-ties were picked; their exact scores travel here)
+            dev = mods[0][1].weight.device
+            late = [h for h in helpers.values() if not getattr(h, "loss_synced", False)]
+            exact = [h for h in helpers.values() if h.contenders is not None]
+            steps = torch.tensor([float(h.num_search_steps) for h in late] + [float(h.num_exact_steps) for h in exact],
+                                 device=dev)
+            mdist.all_reduce_bucket([h.loss_buf for h in late] + [h.exact_buf for h in exact] + [steps],
+                                    dist.ReduceOp.SUM)
+            counts = steps.tolist()
+            for h, n in zip(late, counts[:len(late)]):
                 h.search_steps_all_ranks = int(n)
+            for h, n in zip(exact, counts[len(late):]):
+                h.exact_steps_all_ranks = int(n)
     finally:
         for m, f in originals.items():
             m.forward = f
@@ -544,8 +655,16 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             m.input_quantizer.pre_quant_scale = torch.ones(m.weight.shape[1], dtype=m.weight.dtype,
                                                            device=m.weight.device)
             continue
-        losses = {a: float(v) for a, v in h.loss.items()}
-        h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)
+        if h.contenders is not None and h.exact_steps_all_ranks > 0:
+            # near-ties: the exact scores replace the Gram scores of the re-scored candidates and decide among them
+            # (ascending alpha, first minimum: the reference's dict order, :1637)
+            h.loss_buf[torch.tensor(h.contenders, device=h.loss_buf.device)] = h.exact_buf
+            exact = h.exact_buf.tolist()
+            losses = {a: float(v) for a, v in h.loss.items()}
+            h.best_alpha = h.alphas[h.contenders[min(range(len(exact)), key=exact.__getitem__)]]
+        else:
+            losses = {a: float(v) for a, v in h.loss.items()}
+            h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)
         h.best_scale = get_scale(h.act_scale, h.weight_scale, h.best_alpha)
         m.awq_lite = h
         # postprocess (:1636-1659): fold s into W (fp32 multiply), recalibrate, input gets 1/s
@@ -668,7 +787,7 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
     out = {}
     with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
         if algorithm in ("awq_full", "awq_lite"):
-            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search")}
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin")}
             out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
         if algorithm in ("awq_full", "awq_clip"):
             clip_kw = {k: v for k, v in kwargs.items()

@@ -16,6 +16,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   awq.npz       -- AWQ-lite building blocks on one linear (quantization/model_calib.py:1453-1495)
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
+  export_llama_replay.npz -- the same run: every linear's input per calibration batch + the search's statistics
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
   block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
@@ -662,11 +663,12 @@ def gen_mse(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
-def gen_export(out):
+def gen_export(out, capture=None):
     """INT4-AWQ checkpoint export of a tiny bf16 Llama by the reference (mtq.quantize(INT4_AWQ_CFG) +
     export_hf_checkpoint, export/unified_export_hf.py:1491): the original weights + calibration tokens (for the
     end-to-end test), the calibrated state right before export (folded weights, pre_quant_scales, per-block amax,
-    norm weights) and every tensor of the exported model.safetensors."""
+    norm weights) and every tensor of the exported model.safetensors.  `capture` (a dict) additionally receives what
+    gen_export_replay stores: every linear's input per forward call and the search's intermediate statistics."""
     import tempfile
 
     import modelopt.torch.quantization as mtq
@@ -684,6 +686,11 @@ def gen_export(out):
         out[f"orig/{k}"] = bits(v)
     for i, b in enumerate(batches):
         out[f"tokens{i}"] = b.numpy()
+    calls = {}
+    if capture is not None:
+        for n, m in model.named_modules():
+            if isinstance(m, torch.nn.Linear):
+                m.register_forward_pre_hook(lambda mod, args, n=n: calls.setdefault(n, []).append(args[0].detach().clone()))
     import copy as _copy
     awq_cfg = _copy.deepcopy(mtq.INT4_AWQ_CFG)
     awq_cfg["algorithm"]["debug"] = True  # keeps module.awq_lite (best_alpha) after calibration
@@ -696,6 +703,18 @@ def gen_export(out):
             out[f"pre/{n}.amax"] = bits(m.weight_quantizer._amax)
             out[f"pre/{n}.pre_quant_scale"] = bits(m.input_quantizer._pre_quant_scale)
             out[f"pre/{n}.best_alpha"] = np.array(float(m.awq_lite.best_alpha) if hasattr(m, "awq_lite") else -1.0)
+            if capture is not None:
+                h = m.awq_lite
+                capture[f"ref/{n}.act_scale"] = bits(h.act_scale)
+                capture[f"ref/{n}.weight_scale"] = bits(h.weight_scale)
+                capture[f"ref/{n}.best_scale"] = bits(h.best_scale)
+                capture[f"ref/{n}.loss"] = np.array([float(v) for v in h.loss.values()], dtype=np.float64)
+                seen = calls[n]
+                # cache pass and search pass feed every linear the same tensors (nothing quantizes in between)
+                assert len(seen) == 2 * len(batches), (n, len(seen))
+                for b in range(len(batches)):
+                    assert torch.equal(seen[b], seen[b + len(batches)]), (n, b)
+                    capture[f"in/{n}/{b}"] = seen[b]
         elif type(m).__name__.endswith("RMSNorm"):
             out[f"pre/{n}.weight"] = bits(m.weight)
     with tempfile.TemporaryDirectory() as d:
@@ -709,6 +728,36 @@ def gen_export(out):
         quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
     out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), linears=linears, dtypes=dtypes,
                                              hf_quant_config=quant_cfg)))
+
+
+def gen_export_replay(out):
+    """Replay data for the end-to-end INT4-AWQ checkpoint test: the SAME reference run as export_llama.npz (checked
+    array by array against that file), plus what every quantized linear received in each calibration batch and the
+    search's intermediate statistics (act_scale, weight_scale, per-alpha losses, best_scale).  Feeding these inputs to
+    the patched linears takes the model's own GEMMs (attention, MLP: library kernels whose summation order differs
+    between machines) out of the comparison: everything the path computes from them must then equal the reference
+    byte for byte.  Linears that read one tensor (q / k / v, gate / up) store it once (`alias`)."""
+    full, cap = {}, {}
+    gen_export(full, capture=cap)
+    have = np.load(os.path.join(HERE, "export_llama.npz"))
+    assert set(have.files) == set(full), "export_llama.npz is not from this run"
+    for k in have.files:
+        assert np.array_equal(have[k], full[k]), f"export_llama.npz[{k}] differs from this run"
+    cases = json.loads(str(full["cases"]))
+    alias, stored = {}, {}
+    for n in cases["linears"]:
+        for b in range(cases["n_batches"]):
+            x = cap.pop(f"in/{n}/{b}")
+            owner = next((o for o, t in stored.items() if o[1] == b and t.shape == x.shape and torch.equal(t, x)), None)
+            if owner is None:
+                stored[(n, b)] = x
+                out[f"in/{n}/{b}"] = bits(x)
+                out[f"in_shape/{n}/{b}"] = np.array(x.shape)
+            else:
+                assert alias.setdefault(n, owner[0]) == owner[0]
+    for k, v in cap.items():
+        out[k] = v
+    out["cases"] = np.array(json.dumps(dict(alias=alias, linears=cases["linears"], n_batches=cases["n_batches"])))
 
 
 def gen_export_fp8(out):
@@ -1055,11 +1104,11 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

@@ -190,3 +190,81 @@ def test_gram_matrix_is_shared_between_linears_with_the_same_input(dtype):
         assert a.awq_lite.best_alpha == b.awq_lite.best_alpha
         assert torch.equal(a.awq_lite.loss_buf, b.awq_lite.loss_buf)
         assert torch.equal(a.weight, b.weight)
+
+
+class FlatStack(torch.nn.Module):
+    """Plain Gaussian weights; with nearly uniform activation channels the 11 candidates score almost alike, so the
+    roundings the Gram formulation leaves out decide the order: the near-tie case."""
+
+    def __init__(self, dims, dtype, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.linears = torch.nn.ModuleList()
+        for co, ci in dims:
+            lin = torch.nn.Linear(ci, co, bias=False)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(co, ci, generator=g) * 0.02)
+            self.linears.append(lin)
+        self.to(dtype)
+
+    def forward(self, xs):
+        return [lin(x) for lin, x in zip(self.linears, xs)]
+
+
+def _flat_batches(dims, dtype, n, tokens, seed, spread):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        xs = []
+        for _, ci in dims:
+            ch = torch.exp(spread * torch.randn(ci, generator=g))
+            xs.append((torch.randn(tokens, ci, generator=g) * ch).to(dtype).to(DEV))
+        out.append(xs)
+    return out
+
+
+def _run_flat(dims, dtype, seed, spread, search, **kw):
+    model = FlatStack(dims, dtype, seed).to(DEV)
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": search, **kw}
+    b = _flat_batches(dims, dtype, 2, 200, seed + 100, spread)
+    q = moa.quantize(model, cfg, lambda m: [m(x) for x in b])
+    return [lin.awq_lite for lin in q.linears], [lin.weight.detach().clone() for lin in q.linears]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_auto_search_rescoring_near_ties_equals_gemm_search(dtype):
+    """search="auto" (the default): near-ties of the Gram scores are re-scored by the exact-rounding error-GEMM engine
+    and the selection equals search="gemm" on every linear (model_calib.py:1489-1495, :1548-1556, :1637) -- over seeds
+    whose loss curves are flat enough that the plain Gram search flips some of them."""
+    dims = [(256, 512), (512, 256), (128, 1024)]
+    flipped = rescored = 0
+    for seed in range(6):
+        for spread in (0.02, 0.1):
+            gemm, w_gemm = _run_flat(dims, dtype, seed, spread, "gemm")
+            gram, _ = _run_flat(dims, dtype, seed, spread, "gram")
+            auto, w_auto = _run_flat(dims, dtype, seed, spread, "auto")
+            for hg, hm, ha, wg, wa in zip(gemm, gram, auto, w_gemm, w_auto):
+                flipped += hm.best_alpha != hg.best_alpha
+                assert ha.best_alpha == hg.best_alpha, f"seed {seed} spread {spread}: auto {ha.best_alpha} vs gemm {hg.best_alpha}"
+                assert torch.equal(wa, wg)
+                if ha.contenders is not None:
+                    rescored += 1
+                    for j, i in enumerate(ha.contenders):  # same kernel, same operands -> same number
+                        assert float(ha.exact_buf[j]) == float(hg.loss_buf[i]) == float(ha.loss_buf[i])
+    assert rescored > 0
+    if dtype == torch.bfloat16:
+        assert flipped > 0, "no seed where the plain Gram search disagrees: the test lost its teeth"
+
+
+def test_auto_search_margins():
+    dims, dt = [(256, 512), (128, 1024)], torch.bfloat16
+    gemm, _ = _run_flat(dims, dt, 1, 0.02, "gemm")
+    gram, _ = _run_flat(dims, dt, 1, 0.02, "gram")
+    zero, _ = _run_flat(dims, dt, 1, 0.02, "auto", tie_margin=0.0)
+    assert all(h.contenders is None for h in zero)
+    assert [h.best_alpha for h in zero] == [h.best_alpha for h in gram]
+    inf, _ = _run_flat(dims, dt, 1, 0.02, "auto", tie_margin=float("inf"))
+    for hg, hi, hm in zip(gemm, inf, gram):
+        assert hi.contenders == list(range(11)) and torch.equal(hi.loss_buf, hg.loss_buf)
+        assert hi.gram_loss == [float(v) for v in hm.loss_buf.tolist()]

@@ -252,3 +252,86 @@ def test_mx_presets_configure_dynamic_e8m0_block_quantizers(hostmem, preset, fmt
     w = lin.weight.detach()
     assert_bits_equal(lin.weight_quantizer(w), oracle.mx_fused_amax_convert(w, 32, fmt, "E8M0", None), preset)
     assert model(torch.randn(3, 64).to(torch.bfloat16)).shape == (3, 32)
+
+
+class _FlatStack(torch.nn.Module):
+    """Linears with plain Gaussian weights: with nearly uniform activation channels the 11 AWQ candidates score almost
+    alike, so the roundings the Gram formulation leaves out decide the order -- the near-tie case."""
+
+    def __init__(self, dims, dtype, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.linears = torch.nn.ModuleList()
+        for co, ci in dims:
+            lin = torch.nn.Linear(ci, co, bias=False)
+            with torch.no_grad():
+                lin.weight.copy_(torch.randn(co, ci, generator=g) * 0.02)
+            self.linears.append(lin)
+        self.to(dtype)
+
+    def forward(self, xs):
+        return [lin(x) for lin, x in zip(self.linears, xs)]
+
+
+def _flat_batches(dims, dtype, n, tokens, seed, spread):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        xs = []
+        for _, ci in dims:
+            ch = torch.exp(spread * torch.randn(ci, generator=g))
+            xs.append((torch.randn(tokens, ci, generator=g) * ch).to(dtype))
+        out.append(xs)
+    return out
+
+
+def test_awq_lite_near_tie_is_rescored_like_the_reference_structure(hostmem, monkeypatch):
+    """search="auto": candidates whose Gram scores lie within the margin are re-scored by the error-GEMM engine (the
+    reference's arithmetic, model_calib.py:1489-1495, :1548-1556) and the first minimum of THOSE scores wins -- the
+    selection of search="gemm".  Seed 4 is a case where the plain Gram search picks another alpha."""
+    from model_optimizer_amd import model_calib
+
+    monkeypatch.setattr(model_calib._WeightCacheBudget, "host_bytes", 1 << 30)
+    dims, dt = [(64, 256), (128, 128)], torch.bfloat16
+
+    def run(search, **kw):
+        model = _FlatStack(dims, dt, 4)
+        cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+        cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": search, **kw}
+        b = _flat_batches(dims, dt, 2, 48, 104, 0.02)
+        q = moa.quantize(model, cfg, lambda m: [m(x) for x in b])
+        return [lin.awq_lite for lin in q.linears], [lin.weight.detach().clone() for lin in q.linears]
+
+    gemm, w_gemm = run("gemm")
+    gram, _ = run("gram")
+    auto, w_auto = run("auto")
+    assert [h.best_alpha for h in gram] != [h.best_alpha for h in gemm], "fixture no longer holds a flipped near-tie"
+    for hg, ha, wg, wa in zip(gemm, auto, w_gemm, w_auto):
+        assert ha.use_gram and ha.contenders is not None and len(ha.contenders) > 1
+        assert ha.best_alpha == hg.best_alpha
+        assert_bits_equal(wa, wg, "folded weight after the re-scored search")
+        # the re-scored candidates carry the error-GEMM engine's loss, bit for bit; the others keep the Gram score
+        for j, i in enumerate(ha.contenders):
+            assert float(ha.exact_buf[j]) == float(hg.loss_buf[i]) == float(ha.loss_buf[i])
+        assert ha.num_exact_steps == 2 and ha.num_search_steps == 2
+    # margin 0: nothing is re-scored (a single best candidate), the Gram scores decide
+    zero, _ = run("auto", tie_margin=0.0)
+    assert [h.best_alpha for h in zero] == [h.best_alpha for h in gram] and all(h.contenders is None for h in zero)
+    # infinite margin: every candidate is re-scored -> the full table of the error-GEMM engine
+    inf, _ = run("auto", tie_margin=float("inf"))
+    for hg, hi in zip(gemm, inf):
+        assert hi.contenders == list(range(11)) and torch.equal(hi.loss_buf, hg.loss_buf)
+        assert hi.gram_loss is not None and len(hi.gram_loss) == 11
+
+
+def test_awq_lite_refuses_enabled_input_quantizers(hostmem):
+    """The W4A8 AWQ branch (inputs calibrated in the cache pass, search on quantized activations) is outside this path
+    and must say so instead of leaving the input quantizers uncalibrated."""
+    from model_optimizer_amd._lib import MoquantUnsupported
+
+    model = _FlatStack([(64, 128)], torch.float32, 0)
+    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg["quant_cfg"]["*input_quantizer"] = {"num_bits": 8, "axis": None, "enable": True}
+    b = _flat_batches([(64, 128)], torch.float32, 1, 16, 1, 0.1)
+    with pytest.raises(MoquantUnsupported):
+        moa.quantize(model, cfg, lambda m: [m(x) for x in b])

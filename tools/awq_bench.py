@@ -78,6 +78,11 @@ def main():
     ap.add_argument("--tokens", type=int, default=4096, help="tokens per batch (8 x 512)")
     ap.add_argument("--search", default="auto", choices=["auto", "gram", "gemm"],
                     help="awq_lite search: Gram matrix (one pass, token-count independent) or per-alpha error GEMMs")
+    ap.add_argument("--tie-margin", type=float, default=None,
+                    help="search=auto: relative margin inside which candidates are re-scored by the error-GEMM engine "
+                         "(default: model_calib.GRAM_TIE_MARGIN of the dtype; inf = every candidate)")
+    ap.add_argument("--dump", default=None, help="write every linear's loss tables / chosen alpha to this JSON file")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -97,7 +102,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     moa = _moa_import.load()
-    dtype = torch.bfloat16
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
 
     model = LinearStack(args.model, args.layers, dev, dtype)
     my_batches = [make_batch(args.model, args.tokens, dev, dtype, 100 + b) for b in range(args.batches) if b % world == rank]
@@ -114,6 +119,8 @@ def main():
 
     cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
     cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": args.search}
+    if args.tie_margin is not None:
+        cfg["algorithm"]["tie_margin"] = args.tie_margin
     moa.quantize(model, cfg, loop)
     torch.cuda.synchronize()
     if world > 1:
@@ -127,6 +134,15 @@ def main():
     n_w = sum(lin.weight.numel() for lin in model.linears)
     flops = 12.0 * 2.0 * args.tokens * args.batches * n_w  # 11 alpha GEMMs + out_actual, all ranks
     alphas = [float(lin.awq_lite.best_alpha) for lin in model.linears]
+    helpers = [lin.awq_lite for lin in model.linears]
+    rescored = [h for h in helpers if h.contenders is not None]
+    if rank == 0 and args.dump:
+        os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
+        with open(args.dump, "w") as f:
+            json.dump({"search": args.search, "tie_margin": args.tie_margin, "alphas": helpers[0].alphas,
+                       "linears": [{"shape": list(lin.weight.shape), "best_alpha": float(h.best_alpha),
+                                    "loss": [float(v) for v in h.loss_buf.tolist()], "gram_loss": h.gram_loss,
+                                    "contenders": h.contenders} for lin, h in zip(model.linears, helpers)]}, f)
     if rank == 0:
         print(json.dumps({
             "metric": "INT4-AWQ PTQ wall-clock", "value": round(dt, 4), "unit": "s", "n_gpus": world,
@@ -134,7 +150,8 @@ def main():
             "config": {"workload": f"{args.model} x {args.layers} layers ({len(model.linears)} linears, {n_w * 2 / 1e9:.2f} GB bf16), "
                                    f"awq_lite g128 alpha_step 0.1, {args.batches} batches x {args.tokens} tokens, synthetic",
                        "parallelism": f"calibration batches sharded over {world} GPU(s)"},
-            "search": args.search,
+            "search": args.search, "dtype": args.dtype,
+            "rescored_linears": len(rescored), "rescored_candidates": sum(len(h.contenders) for h in rescored),
             "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
             "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}), flush=True)
     if world > 1:
