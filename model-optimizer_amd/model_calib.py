@@ -374,12 +374,17 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
 
 
 # Relative margin inside which two candidates' Gram scores do not decide the search (search="auto").  The Gram loss
-# differs from the reference-structured loss by the roundings of x/s, `out` and `out_actual` to the model dtype: a term
-# that is almost the same for every alpha of a linear plus a small alpha-dependent part.  The bounds are the
-# measured worst case of (loss_gemm - loss_gram)(alpha) - (loss_gemm - loss_gram)(alpha') over every pair of candidates,
-# relative to the best loss, on the full-size synthetic Llama-3-8B run (profiles/r02_awq_tie_margin.md), times a
-# safety factor; fp32 models agree with the reference to 4e-7 (tests/test_gpu_host.py).
-GRAM_TIE_MARGIN = {torch.bfloat16: 3e-2, torch.float16: 6e-3, torch.float32: 2e-5}
+# differs from the reference-structured loss d(alpha) = loss_gemm - loss_gram by the roundings of x/s, `out` and
+# `out_actual` to the model dtype.  The true minimum can only fall outside the re-scored set if d differs between two
+# candidates by more than the margin (relative to the best loss).  Measured on the full-size synthetic Llama-3-8B run
+# (224 linears x 11 candidates, 64 x 4096 tokens; profiles/r02_awq_tie_margin.md): the worst spread of d over ALL
+# candidate pairs of a linear is 2.5e-3 (bf16) / 2.6e-4 (f16) of the best loss -- a smooth function of the loss itself
+# -- and 9.3e-5 / 3.9e-6 between candidates that score within 2 % of each other.  The margins are 2x / 4x the
+# all-pairs worst case; fp32 models agree with the reference to 4e-7 (tests/test_gpu_host.py).  On top comes the
+# zero-mean part of d (cross term error x rounding), which shrinks with the number of outputs in the loss:
+# GRAM_TIE_NOISE / sqrt(tokens * Cout), ~8 sigma.
+GRAM_TIE_MARGIN = {torch.bfloat16: 5e-3, torch.float16: 1e-3, torch.float32: 2e-5}
+GRAM_TIE_NOISE = 0.5
 
 
 @torch.no_grad()
@@ -540,10 +545,13 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             return False
         distributed = dist.is_available() and dist.is_initialized()
         if distributed:
-            steps = torch.tensor([float(h.num_search_steps) for _, h in scored], device=scored[0][0].weight.device)
+            steps = torch.tensor([float(h.num_search_steps) for _, h in scored] + [float(h.num_tokens) for _, h in scored],
+                                 device=scored[0][0].weight.device)
             mdist.all_reduce_bucket([h.loss_buf for _, h in scored] + [steps], dist.ReduceOp.SUM)
-            for (_, h), n in zip(scored, steps.tolist()):
+            counts = steps.tolist()
+            for (_, h), n, t in zip(scored, counts[:len(scored)], counts[len(scored):]):
                 h.search_steps_all_ranks = int(n)
+                h.tokens_all_ranks = int(t)
                 h.loss_synced = True
         if search != "auto":
             return False
@@ -551,7 +559,10 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         any_tie = False
         for (m, h), row in zip(scored, table.tolist()):
             h.gram_loss = list(row)
-            margin = GRAM_TIE_MARGIN.get(m.weight.dtype, 3e-2) if tie_margin is None else tie_margin
+            margin = tie_margin
+            if margin is None:
+                outputs = max(1, getattr(h, "tokens_all_ranks", h.num_tokens) * m.weight.shape[0])
+                margin = GRAM_TIE_MARGIN.get(m.weight.dtype, 5e-3) + GRAM_TIE_NOISE / math.sqrt(outputs)
             best = min(row)  # a NaN score never compares smaller: such a linear keeps the plain first-minimum rule
             if not math.isfinite(best):
                 continue
@@ -667,12 +678,15 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)
         h.best_scale = get_scale(h.act_scale, h.weight_scale, h.best_alpha)
         m.awq_lite = h
-        # postprocess (:1636-1659): fold s into W (fp32 multiply), recalibrate, input gets 1/s
-        ops.scale_cols(m.weight.data, h.best_scale, out=m.weight.data)
+        # postprocess (:1636-1659) -> apply_pre_quant_scale_and_smooth(module, 1 / best_scale) (:1226-1252): the input
+        # gets 1/s in the weight dtype; the weight is multiplied (fp32, one rounding) by 1 / (1/s) -- the fp32 double
+        # reciprocal, which is not always s itself -- and recalibrated
+        pre_quant_scale = (1.0 / h.best_scale).to(torch.float32)
+        ops.scale_cols(m.weight.data, 1.0 / pre_quant_scale, out=m.weight.data)
         m.weight_quantizer.reset_amax()
         max_calibrate(m, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
         m.input_quantizer._enable_pre_quant_scale = True
-        m.input_quantizer.pre_quant_scale = (1.0 / h.best_scale).to(m.weight.dtype)
+        m.input_quantizer.pre_quant_scale = pre_quant_scale.to(m.weight.dtype)
     return helpers
 
 

@@ -1,0 +1,62 @@
+"""Shared by the CPU (host-memory stand-in) and GPU tiers: the end-to-end INT4-AWQ checkpoint of the tiny Llama with the
+reference run's per-linear inputs REPLAYED (tests/golden/export_llama_replay.npz, gen_golden.gen_export_replay).
+
+The model's own GEMMs (attention / MLP glue: library kernels whose summation order differs between machines) are taken
+out of the comparison: the calibration loop hands every quantized linear exactly the tensor the reference's linear
+received in that batch.  Everything the path computes from there -- activation / weight statistics, the alpha search,
+the fold, the per-group amax, the resmooth + norm fusion + nibble packing of the export -- must then reproduce the
+reference's model.safetensors byte for byte (export/unified_export_hf.py:1491, export/quant_utils.py:792-833)."""
+
+import torch
+
+from conftest import from_bits
+
+
+def replay_loop(replay, device):
+    """forward_loop(model): feeds every quantized linear the reference's input of each batch.  Linears that read one
+    tensor in the model (q / k / v, gate / up) get the SAME tensor object, as in a real forward."""
+    rc = replay.cases
+    cache = {}
+
+    def x_of(name, b):
+        owner = rc["alias"].get(name, name)
+        if (owner, b) not in cache:
+            shape = [int(v) for v in replay.raw(f"in_shape/{owner}/{b}")]
+            cache[(owner, b)] = from_bits(replay.raw(f"in/{owner}/{b}"), torch.bfloat16).reshape(shape).to(device)
+        return cache[(owner, b)]
+
+    def loop(model):
+        for b in range(rc["n_batches"]):
+            for name in rc["linears"]:
+                model.get_submodule(name)(x_of(name, b))
+
+    return loop
+
+
+def stage_report(q, g, replay):
+    """Per linear: which stage first differs from the reference run (None = all equal).  Diagnostics for a failing
+    byte comparison; the stages are in the order the flow computes them."""
+    out = {}
+    for name in replay.cases["linears"]:
+        lin = q.get_submodule(name)
+        h = lin.awq_lite
+        stages = [
+            ("act_scale", h.act_scale.float().cpu(), from_bits(replay.raw(f"ref/{name}.act_scale"), torch.float32)),
+            ("weight_scale", h.weight_scale.float().cpu(), from_bits(replay.raw(f"ref/{name}.weight_scale"), torch.float32)),
+            ("best_alpha", torch.tensor(float(h.best_alpha)), torch.tensor(float(g.raw(f"pre/{name}.best_alpha")))),
+            ("best_scale", h.best_scale.float().cpu(), from_bits(replay.raw(f"ref/{name}.best_scale"), torch.float32)),
+            ("pre_quant_scale", lin.input_quantizer._pre_quant_scale.cpu(),
+             from_bits(g.raw(f"pre/{name}.pre_quant_scale"), torch.bfloat16)),
+            ("weight", lin.weight.detach().cpu(), from_bits(g.raw(f"pre/{name}.weight"), torch.bfloat16)),
+            ("amax", lin.weight_quantizer._amax.float().cpu().reshape(-1),
+             from_bits(g.raw(f"pre/{name}.amax"), torch.float32).reshape(-1)),
+        ]
+        first = None
+        for what, got, want in stages:
+            got, want = got.reshape(-1), want.reshape(-1)
+            if got.shape != want.shape or not torch.equal(got, want):
+                n = int((got != want).sum()) if got.shape == want.shape else -1
+                first = f"{what} ({n} of {want.numel()} values)"
+                break
+        out[name] = first
+    return out

@@ -335,3 +335,19 @@ def test_awq_lite_refuses_enabled_input_quantizers(hostmem):
     b = _flat_batches([(64, 128)], torch.float32, 1, 16, 1, 0.1)
     with pytest.raises(MoquantUnsupported):
         moa.quantize(model, cfg, lambda m: [m(x) for x in b])
+
+
+def test_int4_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, hostmem):
+    """The whole INT4-AWQ flow (awq_lite search -> fold -> per-group amax -> export) from the ORIGINAL weights, with the
+    reference run's per-linear inputs replayed: every statistic of the search and every exported byte equal the
+    reference's (tests/replay_common.py)."""
+    import replay_common
+
+    g, r = golden("export_llama"), golden("export_llama_replay")
+    model = _llama(g, g.cases, torch.bfloat16)
+    with torch.no_grad():
+        q = moa.quantize(model, moa.model_quant.INT4_AWQ_CFG, replay_common.replay_loop(r, "cpu"))
+    report = replay_common.stage_report(q, g, r)
+    assert not any(report.values()), {k: v for k, v in report.items() if v}
+    state = moa.export.export_state_dict(q, torch.bfloat16, lambda: q(torch.ones([1, 2], dtype=torch.long)))
+    _compare_state(state, g, g.cases)
