@@ -122,6 +122,15 @@ class HistogramCalibrator(_Calibrator):
         self._skip_zeros = skip_zeros
         self._calib_bin_edges = None  # torch fp32, like the reference's torch_hist=True branch
         self._calib_hist = None       # int64 counts on the device
+        self._share_range = False     # data parallel: bin with rank 0's first-batch range (distributed.py)
+        self._grown_to = None         # the abs-max the range was last extended for
+
+    def share_range_across_ranks(self, on: bool = True):
+        """Data-parallel calibration: the first collect broadcasts rank 0's first-batch abs-max, every rank bins with
+        that width (growing its range by the reference's rule when a batch exceeds it), and the int64 counts of all
+        ranks add up exactly (distributed.sync_calibrators_bucketed) to the histogram a single rank would have built
+        from all batches starting with rank 0's first one."""
+        self._share_range = bool(on)
 
     @torch.no_grad()
     def collect(self, x):
@@ -131,23 +140,31 @@ class HistogramCalibrator(_Calibrator):
         # x_max of what is histogrammed (|x| in fp32; zeros never raise the max)
         x_max = ops.reduce_amax(x).float().cpu()
         if self._calib_bin_edges is None and self._calib_hist is None:
-            self._calib_hist = ops.hist_abs(x, self._num_bins, float(x_max), self._skip_zeros)
-            self._calib_bin_edges = torch.linspace(0, x_max, self._num_bins + 1)
-        else:
-            if x_max > self._calib_bin_edges[-1]:
-                # keep the bin width, extend the range (calib/histogram.py:121-127)
-                width = self._calib_bin_edges[1] - self._calib_bin_edges[0]
-                self._num_bins = int((x_max / width).ceil().item())
-                self._calib_bin_edges = torch.arange(0, x_max + width, width)
-                grown = torch.zeros(self._num_bins, dtype=torch.int64, device=self._calib_hist.device)
-                grown[: self._calib_hist.numel()] = self._calib_hist
-                self._calib_hist = grown
-            ops.hist_abs(x, self._num_bins, float(self._calib_bin_edges[-1]), self._skip_zeros,
-                         counts=self._calib_hist)
+            first_max = x_max
+            if self._share_range:
+                from . import distributed as mdist
+
+                first_max = mdist.agree_histogram_range(x_max.clone().to(x.device)).cpu()
+            self._calib_bin_edges = torch.linspace(0, first_max, self._num_bins + 1)
+            self._calib_hist = torch.zeros(self._num_bins, dtype=torch.int64, device=x.device)
+        if x_max > self._calib_bin_edges[-1]:
+            self._grow_to(x_max)
+        ops.hist_abs(x, self._num_bins, float(self._calib_bin_edges[-1]), self._skip_zeros, counts=self._calib_hist)
+
+    def _grow_to(self, x_max: torch.Tensor):
+        """Keep the bin width, extend the range to hold `x_max` (a 0-dim fp32 host tensor) -- calib/histogram.py:121-127."""
+        width = self._calib_bin_edges[1] - self._calib_bin_edges[0]
+        self._num_bins = int((x_max / width).ceil().item())
+        self._calib_bin_edges = torch.arange(0, x_max + width, width)
+        grown = torch.zeros(self._num_bins, dtype=torch.int64, device=self._calib_hist.device)
+        grown[: self._calib_hist.numel()] = self._calib_hist
+        self._calib_hist = grown
+        self._grown_to = x_max.clone()
 
     def reset(self):
         self._calib_bin_edges = None
         self._calib_hist = None
+        self._grown_to = None
 
     def merge(self, other_hist: torch.Tensor):
         """Add counts collected elsewhere (used by the cross-rank SUM all-reduce, distributed.py)."""

@@ -120,9 +120,11 @@ def sync_awq_act_scales(act_scales, weight_scales, widths, device, group=None):
 
 def sync_calibrators_bucketed(calibrators, group=None):
     """Synchronise raw calibrator state before compute_amax: running maxima (MAX) and histograms (SUM).
-    Histograms are first brought to a common range: ranks agree on the largest last edge (MAX), re-bin is
-    not needed because every rank grows its histogram with the SAME bin width only if the first batch's
-    range agreed -- so the width is agreed up front by `agree_histogram_range`."""
+
+    Histograms: every rank binned with the SAME width (rank 0's first-batch range, `agree_histogram_range` at the
+    first collect) and grew its range independently, so the histograms differ only in length: the ranks agree on the
+    largest abs-max any of them extended its range for (MAX, one small collective), grow to it by the reference's own
+    rule, and SUM the int64 counts in one bucket.  Contract: a histogram-calibrated quantizer is reached by every rank or by none (dense models)."""
     from .calib import HistogramCalibrator, MaxCalibrator
 
     if not _initialized(group):
@@ -131,28 +133,23 @@ def sync_calibrators_bucketed(calibrators, group=None):
     all_reduce_bucket(maxes, dist.ReduceOp.MAX, group)
     hists = [c for c in calibrators if isinstance(c, HistogramCalibrator) and c._calib_hist is not None]
     if hists:
-        # common number of bins: pad every histogram to the longest one across ranks (same width by contract)
-        lens = torch.tensor([c._calib_hist.numel() for c in hists], dtype=torch.int64,
-                            device=hists[0]._calib_hist.device)
-        dist.all_reduce(lens, op=dist.ReduceOp.MAX, group=group)
-        padded = []
-        for c, n in zip(hists, lens.tolist()):
-            if c._calib_hist.numel() < n:
-                width = c._calib_bin_edges[1] - c._calib_bin_edges[0]
-                grown = torch.zeros(n, dtype=torch.int64, device=c._calib_hist.device)
-                grown[: c._calib_hist.numel()] = c._calib_hist
-                c._calib_hist = grown
-                c._num_bins = n
-                c._calib_bin_edges = torch.arange(0, n + 1, dtype=torch.float32) * width
-            padded.append(c._calib_hist)
-        all_reduce_bucket(padded, dist.ReduceOp.SUM, group)
+        # common range: the largest abs-max any rank extended its range for; ranks below it grow by the same rule
+        # (HistogramCalibrator._grow_to), which leaves every rank with the bins and edges a single rank would have
+        dev = hists[0]._calib_hist.device
+        tops = torch.stack([(c._grown_to if c._grown_to is not None else torch.zeros(())).float().reshape(()) for c in hists]).to(dev)
+        dist.all_reduce(tops, op=dist.ReduceOp.MAX, group=group)
+        for c, top in zip(hists, tops.cpu()):
+            if top > c._calib_bin_edges[-1]:
+                c._grow_to(top)
+        all_reduce_bucket([c._calib_hist for c in hists], dist.ReduceOp.SUM, group)
 
 
-def agree_histogram_range(x_max_local: torch.Tensor, group=None) -> torch.Tensor:
-    """First-batch range agreement: every rank uses max over ranks of its first batch's |x| max, so that
-    all ranks bin with the same width and their counts can be SUM-reduced exactly."""
+def agree_histogram_range(x_max_local: torch.Tensor, group=None, src: int = 0) -> torch.Tensor:
+    """First-batch range agreement: every rank bins with the width of rank `src`'s first batch (a broadcast), so that
+    all counts can be SUM-reduced exactly AND the merged histogram is the one a single rank builds when it starts
+    with that batch (the growth rule keeps the first width, calib/histogram.py:121-127)."""
     if _initialized(group):
-        dist.all_reduce(x_max_local, op=dist.ReduceOp.MAX, group=group)
+        dist.broadcast(x_max_local, src=src, group=group)
     return x_max_local
 
 

@@ -31,25 +31,40 @@ def _quantizers(model):
     return [m for m in model.modules() if isinstance(m, TensorQuantizer)]
 
 
-def enable_stats_collection(model: nn.Module):
+def _dist_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def enable_stats_collection(model: nn.Module, distributed_sync: bool = False):
     """model_calib.py:1128-1141.  Every enabled quantizer stops quantizing while statistics are collected -- the
     dynamic ones too (their `enable_calib` is a no-op), so that the static quantizers downstream of them calibrate on
-    clean activations; a quantizer without a calibrator is switched off altogether (:1140-1141)."""
+    clean activations; a quantizer without a calibrator is switched off altogether (:1140-1141).
+
+    distributed_sync (data-parallel calibration): histogram calibrators take the bin width of rank 0's first batch
+    (one broadcast at their first collect), so that the ranks' counts can be summed exactly at the end."""
     for q in _quantizers(model):
         if not q.is_enabled:
             continue
         if q._calibrator is not None:
             q.disable_quant()
             q.enable_calib()
+            if hasattr(q._calibrator, "share_range_across_ranks"):
+                q._calibrator.share_range_across_ranks(distributed_sync and _dist_on())
         else:
             q.disable()
 
 
-def finish_stats_collection(model: nn.Module, method: str | None = None, **kwargs):
-    """model_calib.py:1144-1167: load_calib_amax on every calibrated quantizer, back to quant mode."""
-    for q in _quantizers(model):
-        if not q.is_enabled:
-            continue
+def finish_stats_collection(model: nn.Module, method: str | None = None, distributed_sync: bool = False, **kwargs):
+    """model_calib.py:1144-1167: load_calib_amax on every calibrated quantizer, back to quant mode.
+
+    distributed_sync: the raw histograms of all histogram calibrators are SUM-reduced in one bucket before their
+    amax is computed (the reference leaves every rank with its own histogram, calib/histogram.py:158-163); running
+    maxima need nothing here -- their amax is MAX-reduced afterwards (sync_amax_bucketed)."""
+    qs = [q for q in _quantizers(model) if q.is_enabled]
+    if distributed_sync and _dist_on():
+        mdist.sync_calibrators_bucketed([q._calibrator for q in qs if q._calibrator is not None and not q._dynamic
+                                         and hasattr(q._calibrator, "share_range_across_ranks")])
+    for q in qs:
         if q._calibrator is not None and not q._dynamic:
             amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
             if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
@@ -60,16 +75,23 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, **kwarg
         q.disable_calib()
 
 
-def weight_only_quantize(model: nn.Module):
+def weight_only_quantize(model: nn.Module, shard: bool = False):
     """model_calib.py:187-199: pass every weight through its quantizer (collects weight statistics).
 
     Fast path: all enabled per-tensor 'max' weight quantizers of one dtype are calibrated by ONE
-    multi-tensor abs-max launch instead of one reduction per layer."""
+    multi-tensor abs-max launch instead of one reduction per layer.
+
+    shard (data-parallel replicas): the (weight, quantizer) list is dealt round-robin over the ranks
+    (distributed.shard_list) and every rank calibrates only its share -- independent units, no data-path collective;
+    the values reach the other ranks with the amax MAX-reduction that follows (a rank without a value joins with the
+    identity, distributed.sync_amax_bucketed).  Only valid when that reduction runs (max_calibrate does both)."""
     pairs = [(m.weight, m.weight_quantizer) for m in model.modules()
              if is_quantized_linear(m) and m.weight_quantizer.is_enabled]
     for m in model.modules():  # fused MoE expert containers: one (slice, quantizer) pair per expert and projection
         if is_quant_fused_experts(m):
             pairs += [(w, q) for w, q in m.iter_weights_for_calibration() if q.is_enabled]
+    if shard and _dist_on():
+        pairs = mdist.shard_list(pairs)
     batched = []
     for w, wq in pairs:
         per_tensor_max = (isinstance(wq, TensorQuantizer) and wq._if_calib and wq.axis is None and wq.block_sizes is None
@@ -97,15 +119,44 @@ def weight_only_quantize(model: nn.Module):
 @torch.no_grad()
 def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True):
     """model_calib.py:310-498 (DP part): collect abs-max statistics for weights and activations, load them,
-    then MAX-reduce every amax across the data-parallel group in ONE bucket."""
-    enable_stats_collection(model)
-    weight_only_quantize(model)
+    then MAX-reduce every amax across the data-parallel group in ONE bucket.  With a process group up, the weight
+    statistics are sharded over the ranks (weight_only_quantize) and each rank's forward_loop sees its own share of
+    the calibration batches."""
+    sync = distributed_sync and _dist_on()
+    enable_stats_collection(model, distributed_sync=sync)
+    weight_only_quantize(model, shard=sync)
     if forward_loop is not None:
         forward_loop(model)
     finish_stats_collection(model)
-    if distributed_sync and dist.is_available() and dist.is_initialized():
+    if sync:
         dev = next((p.device for p in model.parameters()), None)
         mdist.sync_amax_bucketed(_quantizers(model), device=dev)
+    promote_static_block_weight_quantizers(model)
+
+
+@torch.no_grad()
+def histogram_calibrate(model: nn.Module, forward_loop, method: str = "percentile", distributed_sync: bool = True,
+                        **kwargs):
+    """The classic histogram flow -- enable_stats_collection, forward, finish_stats_collection(method=...) as users of
+    the reference write it by hand (model_calib.py:1128-1167 with calib/histogram.py) -- for models whose quantizers
+    were configured with `calibrator: "histogram"`; max calibrators in the same model are loaded as usual.
+
+    Data parallel: every rank feeds its share of the batches; histogram calibrators bin with rank 0's first-batch
+    width and their int64 counts are SUM-reduced in one bucket before the threshold search, so every rank computes the
+    amax of the WHOLE calibration set -- equal to a single-rank run over all batches when rank 0 holds the first
+    batch.  Contract: every rank reaches every histogram-calibrated quantizer (dense models)."""
+    sync = distributed_sync and _dist_on()
+    enable_stats_collection(model, distributed_sync=sync)
+    weight_only_quantize(model, shard=False)
+    forward_loop(model)
+    hist, rest = nn.ModuleList(), nn.ModuleList()
+    for q in _quantizers(model):
+        (hist if hasattr(q._calibrator, "share_range_across_ranks") else rest).append(q)
+    finish_stats_collection(hist, method, distributed_sync=sync, **kwargs)
+    finish_stats_collection(rest)
+    if sync:
+        dev = next((p.device for p in model.parameters()), None)
+        mdist.sync_amax_bucketed(list(rest), device=dev)
     promote_static_block_weight_quantizers(model)
 
 

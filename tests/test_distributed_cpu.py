@@ -70,6 +70,7 @@ def _job_calibrators(rank, world, moa):
     h._calib_hist = torch.arange(n, dtype=torch.int64) + rank
     h._num_bins = n
     h._calib_bin_edges = torch.arange(0, n + 1, dtype=torch.float32) * width
+    h._grown_to = torch.tensor(3.0) if rank == 1 else None  # the abs-max rank 1 extended its range for
     moa.distributed.sync_calibrators_bucketed([m, h])
     assert m._buf.item() == 2.0
     want = torch.zeros(6, dtype=torch.int64)
@@ -78,7 +79,7 @@ def _job_calibrators(rank, world, moa):
     assert torch.equal(h._calib_hist, want), h._calib_hist
     assert h._calib_bin_edges.numel() == 7 and h._calib_bin_edges[-1].item() == 3.0
     r = moa.distributed.agree_histogram_range(torch.tensor(1.0 + rank))
-    assert r.item() == 2.0
+    assert r.item() == 1.0  # rank 0's first-batch range: the width a single rank starting with that batch would use
 
 
 def _job_bucket_and_shard(rank, world, moa):

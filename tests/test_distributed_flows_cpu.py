@@ -1,0 +1,175 @@
+"""world_size-2 gloo END-TO-END tests of the data-parallel calibration flows on the host-memory stand-in
+backend: every rank holds a replica of the model and calibrates on its share of the batches (rank r: batches r, r+2, ...),
+the weight-side statistics are dealt round-robin over the ranks, and the result must equal a SINGLE-rank run over all
+batches -- the reference's property (tests/unit/torch/quantization/test_dist.py:27-47: after quantize every amax equals
+its all_reduce(MAX)), extended to histograms (SUM of int64 counts), AWQ activation scales (average,
+model_calib.py:1588-1594) and the chosen alpha (per-alpha losses SUMmed so every rank takes the same decision).
+
+Each worker first computes the single-rank result on its own (before the process group exists), then joins the group and
+runs the sharded flow.  On the GPU node the same code runs over RCCL (backend "nccl")."""
+
+import copy
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import _moa_import
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class MLP(torch.nn.Module):
+    def __init__(self, d=128, h=256, dtype=torch.float32, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.fc1 = torch.nn.Linear(d, h, bias=False)
+        self.fc2 = torch.nn.Linear(h, d, bias=True)
+        self.fc3 = torch.nn.Linear(d, d, bias=False)
+        with torch.no_grad():
+            for lin in (self.fc1, self.fc2, self.fc3):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.05)
+            self.fc2.bias.copy_(torch.randn(d, generator=g) * 0.01)
+        self.to(dtype)
+
+    def forward(self, x):
+        return self.fc3(self.fc2(torch.relu(self.fc1(x))))
+
+
+def _batches(d, dtype, n=4):
+    g = torch.Generator().manual_seed(5)
+    ch = torch.exp(torch.randn(d, generator=g))
+    ch[:3] *= 20
+    out = [(torch.randn(24, d, generator=g) * ch).to(dtype) for _ in range(n)]
+    out[2][0, 5] = 400.0  # the largest activation sits in a LATER batch of rank 0's share: histograms must grow
+    out[1][3, 7] = 250.0  # and rank 1's first batch exceeds rank 0's first-batch range
+    return out
+
+
+def _install_backend(moa):
+    sys.path.insert(0, HERE)
+    import hostmem_backend
+
+    mpatch = pytest.MonkeyPatch()
+    hostmem_backend.install(mpatch, moa)
+    from model_optimizer_amd import model_calib
+
+    model_calib._WeightCacheBudget.host_bytes = 1 << 30  # Gram search on the host stand-in
+    return mpatch
+
+
+def _amaxes(model):
+    return {n: m._amax.clone() for n, m in model.named_modules() if hasattr(m, "_amax")}
+
+
+def _job_max_and_smoothquant(rank, world, moa, single):
+    """FP8 per-tensor + INT8 per-channel max calibration and SmoothQuant: amax of weights (sharded over the ranks) and
+    activations (batches sharded) bit-equal to the single-rank run."""
+    mq = moa.model_quant
+    for cfg in (mq.FP8_DEFAULT_CFG, mq.INT8_DEFAULT_CFG, mq.INT8_SMOOTHQUANT_CFG):
+        batches = _batches(128, torch.float32)
+        if single:
+            model = moa.quantize(MLP(), copy.deepcopy(cfg), lambda m: [m(b) for b in batches])
+        else:
+            model = moa.quantize(MLP(), copy.deepcopy(cfg), lambda m: [m(b) for b in batches[rank::world]])
+        yield {"amax": _amaxes(model), "w": {n: p.detach().clone() for n, p in model.named_parameters()},
+               "pqs": {n: m._pre_quant_scale.clone() for n, m in model.named_modules() if hasattr(m, "_pre_quant_scale")}}
+
+
+def _job_histogram(rank, world, moa, single):
+    """Histogram calibrators on the activations (percentile and entropy): int64 counts, bin edges and the amax equal
+    the single-rank run over all batches."""
+    from model_optimizer_amd import model_calib
+
+    mq = moa.model_quant
+    for method, kw in (("percentile", {"percentile": 99.9}), ("entropy", {})):
+        cfg = copy.deepcopy(mq.INT8_DEFAULT_CFG)
+        cfg["quant_cfg"]["*input_quantizer"] = {"num_bits": 8, "axis": None, "calibrator": "histogram"}
+        cfg["algorithm"] = None
+        model = moa.quantize(MLP(), cfg, None)
+        batches = _batches(128, torch.float32)
+        mine = batches if single else batches[rank::world]
+        model_calib.histogram_calibrate(model, lambda m: [m(b) for b in mine], method=method, **kw)
+        cals = {n: m._calibrator for n, m in model.named_modules() if n.endswith("input_quantizer")}
+        yield {"amax": _amaxes(model), "hist": {n: c._calib_hist.clone() for n, c in cals.items()},
+               "edges": {n: c._calib_bin_edges.clone() for n, c in cals.items()}}
+
+
+def _job_awq(rank, world, moa, single):
+    """awq_lite (default search: Gram scores + re-scored near-ties; and the error-GEMM engine): act_scale is the average
+    of the ranks' means, the per-alpha losses are summed, every rank picks the single-rank run's alpha and folds the
+    same weights."""
+    mq = moa.model_quant
+    for search, dtype in (("auto", torch.bfloat16), ("gemm", torch.bfloat16), ("gram", torch.float32)):
+        cfg = copy.deepcopy(mq.INT4_AWQ_CFG)
+        cfg["algorithm"]["search"] = search
+        batches = _batches(128, dtype)
+        mine = batches if single else batches[rank::world]
+        model = moa.quantize(MLP(dtype=dtype), cfg, lambda m: [m(b) for b in mine])
+        hs = {n: m.awq_lite for n, m in model.named_modules() if hasattr(m, "awq_lite")}
+        yield {"alpha": {n: h.best_alpha for n, h in hs.items()}, "act_scale": {n: h.act_scale.clone() for n, h in hs.items()},
+               "loss": {n: h.loss_buf.clone() for n, h in hs.items()}, "amax": _amaxes(model),
+               "w": {n: p.detach().clone() for n, p in model.named_parameters()},
+               "contenders": {n: h.contenders for n, h in hs.items()}}
+
+
+def _compare(kind, want, got):
+    for i, (a, b) in enumerate(zip(want, got)):
+        for key in a:
+            for name in a[key]:
+                x, y = a[key][name], b[key][name]
+                if key in ("alpha", "contenders"):
+                    assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
+                elif key in ("act_scale", "loss") or (kind == "awq" and key in ("amax", "w")):
+                    # averages / sums over ranks associate differently from the single-rank order (fp32)
+                    tol = 1e-6 if key == "act_scale" else 2e-2
+                    assert torch.allclose(x.float(), y.float(), rtol=tol, atol=0), f"{kind}[{i}] {key} {name}"
+                else:
+                    assert x.shape == y.shape and torch.equal(x, y), f"{kind}[{i}] {key} {name}: not bit-equal"
+
+
+def _worker(rank, world, port, kind, ret):
+    try:
+        moa = _moa_import.load()
+        _install_backend(moa)
+        job = globals()[f"_job_{kind}"]
+        with torch.no_grad():
+            want = list(job(rank, world, moa, single=True))  # no process group yet: plain single-rank flow
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            got = list(job(rank, world, moa, single=False))
+        _compare(kind, want, got)
+        # and every rank holds the same state (the reference's property)
+        for g in got:
+            for key in ("amax", "hist"):
+                for name, t in g.get(key, {}).items():
+                    ref = t.clone().float()
+                    dist.all_reduce(ref, op=dist.ReduceOp.MAX)
+                    assert torch.equal(ref, t.float()), f"{kind} {key} {name} differs between ranks"
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = f"{type(e).__name__}: {e}\n{traceback.format_exc()}"
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq"])
+def test_data_parallel_flow_equals_single_rank(kind):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {v}" for r, v in dict(ret).items())
