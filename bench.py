@@ -9,9 +9,14 @@ One step = one pass of the hot path over ALL linear weights of a synthetic Llama
     int4g128 (BASELINE configs[2] weight side / north-star kernel): fused per-group(128) abs-max + INT4 QDQ,
              one launch, 4 + 4/128 B/element.
     mxfp4, mask24, int8 : the other formats of the path, for the record.
-`value` = weight bytes (2 B/element, all ranks) / wall time per step.  Multi-GPU is weak scaling: every rank
-owns one full set of per-layer weight tensors (per-layer tensors shard across GPUs; nothing but the tiny
-amax bucket crosses xGMI).
+`value` = weight bytes of the WHOLE model (2 B/element) / wall time per step.  Multi-GPU is STRONG scaling: the 224
+per-layer weight tensors are dealt round-robin over the ranks (distributed.shard_list: independent units, no
+data-path collective); the only exchange is one bucketed all-reduce(MAX) that leaves every rank with all 224 amax
+values (a rank contributes zeros -- the abs-max identity -- for the tensors it does not own).
+
+`extra` (rank 0, outside the timed region) carries the other half of BASELINE.json's metric and the north-star
+target: the INT4-AWQ PTQ wall-clock of the full synthetic Llama-3-8B (tools/awq_bench.py, calibration batches sharded
+over the ranks) and, at N = 1, the fused per-group amax + INT4 QDQ kernel over all Llama-3-70B weights in place.
 
 Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
 """
@@ -47,17 +52,23 @@ def layer_shapes(model):
     return [(h, h), (kv, h), (kv, h), (h, h)] + [(i, h), (i, h), (h, i)] * experts  # q k v o, (gate up down) x experts
 
 
-def make_weights(model, n_layers, device, seed=1234):
-    """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    ws = []
-    for _ in range(n_layers):
-        for shape in layer_shapes(model):
-            w = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
-            m = torch.rand(shape, generator=g, device=device) < 0.001
-            ws.append(torch.where(m, w * 8, w).to(torch.bfloat16))
-            del w, m
-    return ws
+def make_weights(model, n_layers, device, seed=1234, rank=0, world=1):
+    """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU; tensor i of the model's list is
+    seeded by its index and lives on rank i % world (round-robin shard of the per-layer tensors).
+    Returns (tensors of this rank, their indices in the model's list, number of tensors of the whole model)."""
+    shapes = [shape for _ in range(n_layers) for shape in layer_shapes(model)]
+    g = torch.Generator(device=device)
+    ws, idx = [], []
+    for i, shape in enumerate(shapes):
+        if i % world != rank:
+            continue
+        g.manual_seed(seed + i)
+        w = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
+        m = torch.rand(shape, generator=g, device=device) < 0.001
+        ws.append(torch.where(m, w * 8, w).to(torch.bfloat16))
+        idx.append(i)
+        del w, m
+    return ws, idx, len(shapes)
 
 
 PMC_KERNEL = {"fp8": "mt_map_kernel<2, moq::OpFp8Qdq>", "int8": "mt_map_kernel<2, moq::OpIntQdq>",
@@ -119,9 +130,20 @@ def cpu_baseline(workload, budget_s=12.0):
         one()
         reps += 1
     dt = time.perf_counter() - t0
-    return {"value": round(reps * n_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x (4096x4096 bf16 weight, {workload} calibrate+QDQ), C oracle with OpenMP, "
-                      f"{dt:.1f} s"}
+    out = {"value": round(reps * n_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x (4096x4096 bf16 weight, {workload} calibrate+QDQ), C oracle with OpenMP, "
+                     f"{dt:.1f} s"}
+    # the reference's own eager CPU path on the same sample, timed in the build container (the GPU box has no
+    # reference checkout): tools/ref_cpu_baseline.py -> profiles/r02_ref_cpu_baseline.json
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")) as f:
+            ref = json.load(f)
+        if workload in ref["workloads"]:
+            out["reference_eager"] = {"value": ref["workloads"][workload]["GBs"], "unit": "GB/s", "cores": ref["cores"],
+                                      "host": ref["host"], "sample": ref["sample"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def main():
@@ -139,7 +161,10 @@ def main():
                     help="QDQ output overwrites the weights (y == x is part of the C-ABI contract); needed for "
                          "llama3-70b on one GPU: 137 GB of weights + 137 GB of outputs do not fit in 288 GB")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernel measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other kernels, the "
+                                                            "Llama-3-70B in-place pass, the INT4-AWQ wall-clock)")
+    ap.add_argument("--awq-layers", type=int, default=32, help="extra: layers of the INT4-AWQ wall-clock run (0 = skip)")
+    ap.add_argument("--awq-batches", type=int, default=64, help="extra: calibration batches of 4096 tokens in total")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,9 +195,12 @@ def main():
     from model_optimizer_amd.multi_tensor import SegmentTable
 
     n_layers = args.layers or MODELS[args.model][2]
-    weights = make_weights(args.model, n_layers, dev)
-    n_elem = sum(w.numel() for w in weights)
+    weights, owned, n_tensors = make_weights(args.model, n_layers, dev, rank=rank, world=world)
+    n_local = sum(w.numel() for w in weights)
+    n_elem = sum(r * c for _ in range(n_layers) for r, c in layer_shapes(args.model))  # the whole model
     wl = args.workload
+    owned_idx = torch.tensor(owned, dtype=torch.int64, device=dev)
+    amax_all = torch.zeros(n_tensors, dtype=torch.float32, device=dev)  # every rank ends with every tensor's amax
 
     tab = SegmentTable(weights, outputs=weights if args.inplace else None, group_size=128 if wl == "int4g128" else None)
     groups = None
@@ -207,11 +235,16 @@ def main():
                 e1.record()
                 dom_events.append((e0, e1))
             if world > 1:
-                dist.all_reduce(torch.cat([gt.amax_flat for gt in groups]), op=dist.ReduceOp.MAX)
+                amax_all.zero_()
+                amax_all[owned_idx] = torch.cat([gt.amax_flat for gt in groups])
+                dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
         elif wl == "fp8" or wl == "int8":
             tab.calibrate_amax()
             if world > 1:
-                dist.all_reduce(tab.amax_flat, op=dist.ReduceOp.MAX)  # one bucket for all 224 amax
+                # one bucket: the owners' values reach every rank (zeros are the identity of abs-max)
+                amax_all.zero_()
+                amax_all[owned_idx] = tab.amax_flat
+                dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
@@ -275,7 +308,7 @@ def main():
         elapsed = t.item()
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * n_elem * 2 / (elapsed / args.steps) / 1e9
+    value = n_elem * 2 / (elapsed / args.steps) / 1e9  # the whole model's weights, whatever the number of ranks
 
     # dominant kernel: average launch duration from the HIP events recorded inside the timed region
     dom_all = [a.elapsed_time(b) for a, b in dom_events]
@@ -284,12 +317,12 @@ def main():
     dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
                 "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
                 "mask24": "mt_mask24_kernel<bf16>"}[wl]
-    achieved = n_elem * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(wl, args.model, n_layers)
+    achieved = n_local * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9  # this rank's launch over this rank's tensors
+    traffic, traffic_src = pmc_traffic(wl, args.model, n_layers) if world == 1 else (None, None)
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
-                "alg_bytes_per_launch": int(n_elem * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4),
+                "alg_bytes_per_launch": int(n_local * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4),
                 "min_launch_ms": round(min(dom_all), 4), "max_launch_ms": round(max(dom_all), 4)}
 
     out = {
@@ -301,33 +334,34 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "bf16 storage, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} all {len(weights)} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16 per GPU), "
+        "config": {"workload": f"{args.model} all {n_tensors} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16), "
                                f"{wl} calibrate + quantize-dequantize{' in place' if args.inplace else ''}, inputs resident in HBM",
                    "format": wl, "model": args.model, "layers": n_layers,
-                   "parallelism": f"per-layer weight tensors sharded over {world} GPU(s); one amax bucket all-reduce(MAX)"
+                   "parallelism": f"the {n_tensors} per-layer weight tensors dealt round-robin over {world} GPUs "
+                                  f"({len(weights)} on rank 0); one amax bucket all-reduce(MAX)"
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
     }
 
-    if rank == 0 and not args.no_extra and world == 1:
-        # secondary measurements on the same resident weights (not part of `value`)
-        extra = {}
+    extra = {}
 
-        def timed(fn, reps=5):
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(reps):
             fn()
-            torch.cuda.synchronize()
-            a, b = ev(), ev()
-            a.record()
-            for _ in range(reps):
-                fn()
-            b.record()
-            torch.cuda.synchronize()
-            return a.elapsed_time(b) / reps
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
 
+    if not args.no_extra and world == 1:
+        # secondary measurements on the same resident weights (not part of `value`)
         if wl != "int4g128":
             tabg = SegmentTable(weights, outputs=tab.outputs, group_size=128)
             ms = timed(lambda: tabg.amax_qdq_int_group(4, False, False))
@@ -340,6 +374,47 @@ def main():
             ms = timed(lambda: tab.calibrate_amax())
             extra["per_tensor_amax"] = {"ms": round(ms, 4), "hbm_GBs": round(n_elem * 2 / ms / 1e6, 1),
                                         "frac_of_8TBs": round(n_elem * 2 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    if not args.no_extra:
+        # release the main workload's tensors: the extras below bring their own
+        del tab, weights, groups, masks
+        if wl == "mask24":
+            del mask_tab
+        torch.cuda.empty_cache()
+    if not args.no_extra and world == 1 and args.model == "llama3-8b":
+        # north-star target (BASELINE.json): per-group amax + QDQ over ALL Llama-3-70B weight tensors on one GPU, in
+        # place (136.9 GB of weights; out of place would need 274 GB)
+        try:
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free > 150e9:
+                w70, _, _ = make_weights("llama3-70b", MODELS["llama3-70b"][2], dev)
+                n70 = sum(w.numel() for w in w70)
+                t70 = SegmentTable(w70, outputs=w70, group_size=128)
+                ms = timed(lambda: t70.amax_qdq_int_group(4, False, False), reps=3)
+                b = n70 * (4.0 + 4.0 / 128)
+                extra["llama3_70b_int4g128_inplace"] = {
+                    "ms": round(ms, 3), "weights_GB": round(n70 * 2 / 1e9, 2), "weights_GBs": round(n70 * 2 / ms / 1e6, 1),
+                    "hbm_GBs": round(b / ms / 1e6, 1), "frac_of_8TBs": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                del t70, w70
+                torch.cuda.empty_cache()
+        except Exception as e:  # a reported extra, never a reason to lose the main result
+            extra["llama3_70b_int4g128_inplace"] = {"failed": f"{type(e).__name__}: {e}"}
+    if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b":
+        # the second half of BASELINE.json's metric: INT4-AWQ PTQ wall-clock (awq_lite g128, alpha_step 0.1, default
+        # search) of the synthetic Llama-3-8B linear stack; every rank holds the linears, the calibration batches
+        # (4096 tokens each) are dealt over the ranks, statistics travel in bucketed all-reduces
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import awq_bench
+
+            line = awq_bench.run(moa, "llama3-8b", args.awq_layers, args.awq_batches, 4096, "auto", dev, rank, world)
+            line.pop("best_alphas", None)
+            extra["awq_wallclock_s"] = line["value"]
+            extra["awq"] = {k: line[k] for k in ("config", "search", "rescored_linears", "rescored_candidates",
+                                                 "search_gemm_TFLOPs_equiv", "best_alpha_hist")}
+        except Exception as e:
+            extra["awq_wallclock_s"] = None
+            extra["awq"] = {"failed": f"{type(e).__name__}: {e}"}
+    if extra:
         out["extra"] = extra
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:

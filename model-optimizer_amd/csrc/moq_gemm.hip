@@ -20,6 +20,7 @@
 // matrix cores; one barrier per K-step.
 //
 // Roofline: MFMA-bound.  2 * T * Cout * Cin flop per launch against ~2.5 PFLOP/s dense bf16.
+#include <atomic>
 #include <stdlib.h>
 
 #include "moq_common.h"
@@ -561,13 +562,18 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   constexpr int TILE = Geo<GEO>::TILE;
   const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
   const unsigned nblk = (unsigned)(tiles_t * tiles_n);
-  static bool attr_set = false;
-  if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+  // > 64 KiB of dynamic LDS needs the opt-in attribute -- per DEVICE (a process may drive several GPUs), set by
+  // whichever thread gets there first (setting it twice is harmless, so a relaxed bit mask is enough)
+  static std::atomic<uint64_t> attr_set{0};
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const uint64_t bit = 1ull << (device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_BF16, MODE, GEO>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
     (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_F16, MODE, GEO>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   const dim3 grid(nblk, (unsigned)n_cand), block(Geo<GEO>::WAVES * 64);
   if (dt == MOQ_BF16) {

@@ -70,6 +70,64 @@ def make_batch(model, tokens, device, dtype, seed):
     return out
 
 
+def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, tie_margin=None,
+        dtype=torch.bfloat16, dump=None):
+    """One timed INT4-AWQ quantize() of the synthetic stack; every rank holds the linears, the calibration batches are
+    dealt round-robin over the ranks (data parallel).  Returns the result line (a dict) on every rank."""
+    import copy
+
+    import torch.distributed as dist
+
+    model = LinearStack(model_name, layers, dev, dtype)
+    my_batches = [make_batch(model_name, tokens, dev, dtype, 100 + b) for b in range(batches) if b % world == rank]
+
+    def loop(m):
+        for b in my_batches:
+            m(b)
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": search}
+    if tie_margin is not None:
+        cfg["algorithm"]["tie_margin"] = tie_margin
+    moa.quantize(model, cfg, loop)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    n_w = sum(lin.weight.numel() for lin in model.linears)
+    flops = 12.0 * 2.0 * tokens * batches * n_w  # 11 alpha GEMMs + out_actual, all ranks
+    alphas = [float(lin.awq_lite.best_alpha) for lin in model.linears]
+    helpers = [lin.awq_lite for lin in model.linears]
+    rescored = [h for h in helpers if h.contenders is not None]
+    if rank == 0 and dump:
+        os.makedirs(os.path.dirname(os.path.abspath(dump)), exist_ok=True)
+        with open(dump, "w") as f:
+            json.dump({"search": search, "tie_margin": tie_margin, "alphas": helpers[0].alphas,
+                       "linears": [{"shape": list(lin.weight.shape), "best_alpha": float(h.best_alpha),
+                                    "loss": [float(v) for v in h.loss_buf.tolist()], "gram_loss": h.gram_loss,
+                                    "contenders": h.contenders} for lin, h in zip(model.linears, helpers)]}, f)
+    return {
+        "metric": "INT4-AWQ PTQ wall-clock", "value": round(dt, 4), "unit": "s", "n_gpus": world,
+        "higher_is_better": False,
+        "config": {"workload": f"{model_name} x {layers} layers ({len(model.linears)} linears, {n_w * 2 / 1e9:.2f} GB bf16), "
+                               f"awq_lite g128 alpha_step 0.1, {batches} batches x {tokens} tokens, synthetic",
+                   "parallelism": f"calibration batches sharded over {world} GPU(s)"},
+        "search": search, "dtype": str(dtype).split(".")[-1],
+        "rescored_linears": len(rescored), "rescored_candidates": sum(len(h.contenders) for h in rescored),
+        "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
+        "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))},
+        "best_alphas": alphas}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
@@ -77,12 +135,15 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="calibration batches in total (sharded over ranks)")
     ap.add_argument("--tokens", type=int, default=4096, help="tokens per batch (8 x 512)")
     ap.add_argument("--search", default="auto", choices=["auto", "gram", "gemm"],
-                    help="awq_lite search: Gram matrix (one pass, token-count independent) or per-alpha error GEMMs")
+                    help="awq_lite search: Gram matrix (one pass, token-count independent), per-alpha error GEMMs, or "
+                         "auto = Gram scores with near-ties re-scored by the error-GEMM engine")
     ap.add_argument("--tie-margin", type=float, default=None,
                     help="search=auto: relative margin inside which candidates are re-scored by the error-GEMM engine "
                          "(default: model_calib.GRAM_TIE_MARGIN of the dtype; inf = every candidate)")
     ap.add_argument("--dump", default=None, help="write every linear's loss tables / chosen alpha to this JSON file")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--compare", default=None, help="second search mode to run on the same data; reports how many "
+                                                    "linears pick the same alpha")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,57 +164,17 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     moa = _moa_import.load()
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
-
-    model = LinearStack(args.model, args.layers, dev, dtype)
-    my_batches = [make_batch(args.model, args.tokens, dev, dtype, 100 + b) for b in range(args.batches) if b % world == rank]
-
-    def loop(m):
-        for b in my_batches:
-            m(b)
-
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    import copy
-
-    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
-    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": args.search}
-    if args.tie_margin is not None:
-        cfg["algorithm"]["tie_margin"] = args.tie_margin
-    moa.quantize(model, cfg, loop)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-
-    n_w = sum(lin.weight.numel() for lin in model.linears)
-    flops = 12.0 * 2.0 * args.tokens * args.batches * n_w  # 11 alpha GEMMs + out_actual, all ranks
-    alphas = [float(lin.awq_lite.best_alpha) for lin in model.linears]
-    helpers = [lin.awq_lite for lin in model.linears]
-    rescored = [h for h in helpers if h.contenders is not None]
-    if rank == 0 and args.dump:
-        os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
-        with open(args.dump, "w") as f:
-            json.dump({"search": args.search, "tie_margin": args.tie_margin, "alphas": helpers[0].alphas,
-                       "linears": [{"shape": list(lin.weight.shape), "best_alpha": float(h.best_alpha),
-                                    "loss": [float(v) for v in h.loss_buf.tolist()], "gram_loss": h.gram_loss,
-                                    "contenders": h.contenders} for lin, h in zip(model.linears, helpers)]}, f)
+    line = run(moa, args.model, args.layers, args.batches, args.tokens, args.search, dev, rank, world,
+               args.tie_margin, dtype, args.dump)
+    alphas = line.pop("best_alphas")
+    if args.compare:
+        other = run(moa, args.model, args.layers, args.batches, args.tokens, args.compare, dev, rank, world, None, dtype)
+        oa = other.pop("best_alphas")
+        line["compare"] = {"search": args.compare, "value": other["value"],
+                           "same_alpha": sum(int(a == b) for a, b in zip(alphas, oa)), "of": len(alphas),
+                           "best_alpha_hist": other["best_alpha_hist"]}
     if rank == 0:
-        print(json.dumps({
-            "metric": "INT4-AWQ PTQ wall-clock", "value": round(dt, 4), "unit": "s", "n_gpus": world,
-            "higher_is_better": False,
-            "config": {"workload": f"{args.model} x {args.layers} layers ({len(model.linears)} linears, {n_w * 2 / 1e9:.2f} GB bf16), "
-                                   f"awq_lite g128 alpha_step 0.1, {args.batches} batches x {args.tokens} tokens, synthetic",
-                       "parallelism": f"calibration batches sharded over {world} GPU(s)"},
-            "search": args.search, "dtype": args.dtype,
-            "rescored_linears": len(rescored), "rescored_candidates": sum(len(h.contenders) for h in rescored),
-            "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
-            "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
