@@ -263,6 +263,12 @@ int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, int g, int d
 int64_t moq_col_stats_workspace(int64_t tokens, int64_t cols);
 int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, int dt, float* sum_out,
                       float* amax_out, float* partial, int accumulate, void* stream);
+/* acc[c] += (float) dtype( mean_t |x[t,c]| ): one step of awq_lite's running activation scale --
+ * get_act_scale (model_calib.py:1471-1472: x.abs().mean(0) in the activation dtype, then .to(float32)) added to the
+ * sum over calibration batches (:1527).  fp32 accumulation, IEEE division by `tokens`, one rounding to `dt`.
+ * `partial` as for moq_col_abs_stats.  Needs a 16-byte aligned batch with cols % (16 / sizeof(elem)) == 0. */
+int moq_col_abs_mean_accum(const void* x, int64_t tokens, int64_t cols, int dt, float* acc, float* partial,
+                           void* stream);
 
 /* ------------------------------------------------------------------ AWQ-lite search error GEMM (a12) */
 

@@ -140,6 +140,27 @@ __global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64
   sum_out[c] = accumulate ? sum_out[c] + s : s;
 }
 
+// acc[c] += float(dtype(sum over row blocks / rows)): get_act_scale of awq_lite (model_calib.py:1471-1472,
+// x.abs().mean(0) in the activation dtype -- fp32 accumulation, IEEE division, ONE rounding to the dtype -- then
+// .to(float32)), added to the running sum of the per-batch means
+template <int DT>
+__global__ void col_mean_accum_kernel(const float* __restrict__ partial, int64_t n_blk, int64_t rows, int64_t cols,
+                                      float* __restrict__ acc) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  int64_t b = 0;
+  for (; b + 8 <= n_blk; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < n_blk; ++b) s += partial[b * cols + c];
+  acc[c] = acc[c] + round_to_dtype<DT>(s / (float)rows);
+}
+
 // ---------------------------------------------------------------- AWQ weight scale (a12)
 // get_weight_scale (model_calib.py:1453-1469): scale[r,c] = dt(|w[r,c]| / dt(gamax[r, c/g] + tiny_dt)),
 // w_scale[c] = dt(mean_r scale[r,c]) widened to fp32.  Same grid shape as the column statistics: a lane owns
@@ -351,6 +372,26 @@ extern "C" int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, in
     }
   }
   return check_launch("moq_col_abs_stats");
+}
+
+extern "C" int moq_col_abs_mean_accum(const void* x, int64_t tokens, int64_t cols, int dt, float* acc,
+                                      float* partial, void* stream) {
+  if (tokens <= 0 || cols <= 0 || x == nullptr || acc == nullptr || partial == nullptr) {
+    set_error("moq_col_abs_mean_accum: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0 || cols % vec != 0) {
+    set_error("moq_col_abs_mean_accum: needs a 16-byte aligned batch and cols %% %d == 0", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int64_t n_blk = (tokens + kColRowsWG - 1) / kColRowsWG;
+  dim3 grid((unsigned)((cols / vec + 63) / 64), (unsigned)n_blk);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, true, false>), grid, dim3(kBlock), 0, S(stream), x,
+                                            tokens, cols, (uint32_t*)nullptr, partial));
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_mean_accum_kernel<DT>), dim3((unsigned)((cols + 255) / 256)),
+                                            dim3(256), 0, S(stream), partial, n_blk, tokens, cols, acc));
+  return check_launch("moq_col_abs_mean_accum");
 }
 
 extern "C" int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, int g, int dt, float* out,

@@ -296,10 +296,26 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
 
 # ------------------------------------------------------------------------------------------------ AWQ lite
 def get_scale(x_max, w_max, alpha):
-    """model_calib.py:1474-1487 (no tensor parallel group here)."""
-    scales = (x_max.pow(alpha) / (w_max.to(x_max.device).pow(1 - alpha) + torch.finfo(torch.float32).tiny)).clamp(
-        min=1e-4, max=1e4).view(-1)
-    return (scales / (scales.max() * scales.min()).sqrt()).view(-1)
+    """model_calib.py:1474-1487 (no tensor parallel group here).
+
+    The [Cin] vector math (pow, divide, clamp, normalise) runs on the HOST in IEEE fp32, whatever device the
+    statistics live on: it is a few microseconds of work per candidate, and the GPU math library's pow / torch's
+    reciprocal-multiply for `tensor / scalar` differ from the host's in the last bit, which would make the folded
+    weights -- and with them every byte of the exported checkpoint -- depend on the device the search ran on.  The
+    result goes back to x_max's device."""
+    dev = x_max.device
+    x, w = x_max.detach().float().cpu(), w_max.detach().float().cpu()
+    scales = (x.pow(alpha) / (w.pow(1 - alpha) + torch.finfo(torch.float32).tiny)).clamp(min=1e-4, max=1e4).view(-1)
+    return (scales / (scales.max() * scales.min()).sqrt()).view(-1).to(dev)
+
+
+def _host_div(t: torch.Tensor, divisor: float) -> torch.Tensor:
+    """t / divisor as IEEE fp32 division on the host (see get_scale), back on t's device."""
+    return (t.detach().float().cpu() / divisor).to(t.device)
+
+
+def _host_reciprocal(t: torch.Tensor) -> torch.Tensor:
+    return (1.0 / t.detach().float().cpu()).to(t.device)
 
 
 class _WeightCacheBudget:
@@ -349,6 +365,7 @@ class AWQLiteHelper:
         self._scale_dt = None
         self._w_hat = None
         self._cache_w = False
+        self._stats_host = None
         # Gram-matrix search: G = sum_b X_b^T X_b / T_b (fp32 [Cin, Cin]), accumulated in the cache pass
         self.gram = None
         self.use_gram = False
@@ -365,6 +382,13 @@ class AWQLiteHelper:
         self.exact_buf = None  # fp32 [len(contenders)] accumulated by the error GEMM
         self.num_exact_steps = 0
 
+    def scale(self, alpha):
+        """get_scale(act_scale, weight_scale, alpha) on host copies of the two statistics (fetched once, after the
+        data-parallel average), on the statistics' device."""
+        if self._stats_host is None:
+            self._stats_host = (self.act_scale.detach().float().cpu(), self.weight_scale.detach().float().cpu())
+        return get_scale(self._stats_host[0], self._stats_host[1], alpha).to(self.act_scale.device)
+
     def search_operands(self, module, subset=None):
         """(inv_s [A, Cin] fp32 = (1/s_alpha) rounded to the weight dtype, w_hat [A, Cout, Cin] = QDQ(W * s_alpha))
         for all candidates (or the `subset` of candidate indices -- fixed for the life of the caches).  Scales depend
@@ -373,8 +397,8 @@ class AWQLiteHelper:
         dt = module.weight.dtype
         if self._inv_scale is None:
             alphas = self.alphas if subset is None else [self.alphas[i] for i in subset]
-            scales = [get_scale(self.act_scale, self.weight_scale, a) for a in alphas]
-            self._inv_scale = torch.stack([(1 / s).to(dt).float() for s in scales]).contiguous()
+            scales = [self.scale(a) for a in alphas]
+            self._inv_scale = torch.stack([_host_reciprocal(s).to(dt).float() for s in scales]).contiguous()
             self._scale_dt = [s.to(dt) for s in scales]
         w_hat = self._w_hat
         if w_hat is None:
@@ -411,8 +435,8 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     wf = None if mfma else w.float()
     gram_op = ops.gram_operand(h.gram) if mfma else None
     for i, alpha in enumerate(h.alphas):
-        s = get_scale(h.act_scale, h.weight_scale, alpha)
-        r = (1 / s).to(dt).float()  # input_quantizer.pre_quant_scale as the forward uses it (:1551)
+        s = h.scale(alpha)
+        r = _host_reciprocal(s).to(dt).float()  # input_quantizer.pre_quant_scale as the forward uses it (:1551)
         if mfma:
             # E and its split-precision MFMA operand from ONE read of W, then <E G, E> on the matrix cores
             err, a_op = ops.awq_err_weight(w, s.to(dt), r, h.block_size, bits)
@@ -541,9 +565,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             return out_actual
         x2 = input.reshape(-1, input.shape[-1])
         if state["mode"] == "cache":
-            # act_scale += mean_tokens |x| in the activation dtype (get_act_scale, :1471-1472)
-            ssum, _ = ops.col_abs_stats(x2, want_amax=False)
-            h.act_sum += (ssum / x2.shape[0]).to(input.dtype).float()
+            # act_scale += mean_tokens |x| in the activation dtype (get_act_scale, :1471-1472), one kernel pass
+            ops.col_abs_mean_accum(x2, h.act_sum)
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
         if state["mode"] == state["gram_pass"] and h.gram is not None and h.is_enabled:
@@ -640,7 +663,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             finish_gram_pass()
         for h in helpers.values():
             if h.num_cache_steps:
-                h.act_scale = h.act_sum / h.num_cache_steps
+                h.act_scale = _host_div(h.act_sum, h.num_cache_steps)  # :1601, IEEE division (see get_scale)
         if mods:
             # DP: act_scale average + the any-NaN vote for ALL linears in ONE bucket (reference: one all_reduce and
             # one object gather per linear, :1588-1619); ranks whose shard never reached a linear join with zeros
@@ -727,13 +750,13 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         else:
             losses = {a: float(v) for a, v in h.loss.items()}
             h.best_alpha = min(losses, key=losses.get)  # first minimal alpha (:1637)
-        h.best_scale = get_scale(h.act_scale, h.weight_scale, h.best_alpha)
+        h.best_scale = h.scale(h.best_alpha)
         m.awq_lite = h
         # postprocess (:1636-1659) -> apply_pre_quant_scale_and_smooth(module, 1 / best_scale) (:1226-1252): the input
         # gets 1/s in the weight dtype; the weight is multiplied (fp32, one rounding) by 1 / (1/s) -- the fp32 double
         # reciprocal, which is not always s itself -- and recalibrated
-        pre_quant_scale = (1.0 / h.best_scale).to(torch.float32)
-        ops.scale_cols(m.weight.data, 1.0 / pre_quant_scale, out=m.weight.data)
+        pre_quant_scale = _host_reciprocal(h.best_scale)
+        ops.scale_cols(m.weight.data, _host_reciprocal(pre_quant_scale), out=m.weight.data)
         m.weight_quantizer.reset_amax()
         max_calibrate(m, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
         m.input_quantizer._enable_pre_quant_scale = True

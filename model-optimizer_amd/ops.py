@@ -534,6 +534,28 @@ def col_abs_stats(x: torch.Tensor, sum_out: torch.Tensor | None = None, amax_out
 
 
 @torch.no_grad()
+def col_abs_mean_accum(x: torch.Tensor, acc: torch.Tensor) -> torch.Tensor:
+    """acc += x.abs().mean(0).to(float32) with the mean rounded to x.dtype like the reference's get_act_scale
+    (model_calib.py:1471-1472) -- one read of the batch, the division and the rounding inside the kernel (IEEE
+    division: torch's GPU `tensor / python_scalar` multiplies by the reciprocal, which is not the CPU result)."""
+    _require_gpu(x, "col_abs_mean_accum")
+    x2 = x.detach().contiguous().view(-1, x.shape[-1])
+    tokens, cols = x2.shape
+    if acc.dtype != torch.float32 or acc.numel() != cols or not acc.is_contiguous() or acc.device != x2.device:
+        raise MoquantError("col_abs_mean_accum: acc must be a contiguous fp32 [cols] tensor on the batch's device")
+    vec = 4 if x2.dtype == torch.float32 else 8
+    if cols % vec or x2.data_ptr() % 16:
+        ssum, _ = col_abs_stats(x2, want_amax=False)
+        acc += torch.div(ssum, torch.full((), float(tokens), device=x2.device)).to(x2.dtype).float()
+        return acc
+    ws = torch.empty(max(int(_lib.lib().moq_col_stats_workspace(tokens, cols)), 1), dtype=torch.float32,
+                     device=x2.device)
+    with _on(x2) as stream:
+        check(_lib.lib().moq_col_abs_mean_accum(_p(x2), tokens, cols, _dt(x2), _p(acc), _p(ws), stream))
+    return acc
+
+
+@torch.no_grad()
 def awq_weight_scale(weight: torch.Tensor, group_size: int) -> torch.Tensor:
     """get_weight_scale (model_calib.py:1453-1469): fp32 [Cin] = mean over Cout of |W| / (group amax + tiny),
     computed in W.dtype like the reference.  One read of W."""

@@ -168,6 +168,17 @@ class HostMemLib:
             ao[:] = np.where(np.isnan(am) | (am > ao), am, ao) if accumulate else am
         return OK
 
+    def moq_col_abs_mean_accum(self, x, tokens, cols, dt, acc, workspace, stream):
+        s64 = np.zeros(int(cols), dtype=np.float64)
+        self.o.orc_col_abs_stats(_vp(x), I64(tokens), I64(cols), int(dt), oracle._p(s64), None)
+        import torch
+
+        tdt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(dt)]
+        mean = (torch.from_numpy(s64.astype(np.float32)) / float(tokens)).to(tdt).float().numpy()
+        a = _f32_view(acc, cols)
+        a[:] = a + mean
+        return OK
+
     def moq_mse_sweep_workspace(self, outer, axis_size, inner, n_cand):
         return 0
 

@@ -268,3 +268,28 @@ def test_auto_search_margins():
     for hg, hi, hm in zip(gemm, inf, gram):
         assert hi.contenders == list(range(11)) and torch.equal(hi.loss_buf, hg.loss_buf)
         assert hi.gram_loss == [float(v) for v in hm.loss_buf.tolist()]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_col_abs_mean_accum_equals_host_get_act_scale(dtype):
+    """acc += x.abs().mean(0).to(float32) exactly as the reference computes it on the host (model_calib.py:1471-1472,
+    :1527): token counts that are not powers of two (torch's GPU tensor / scalar is a reciprocal multiply and differs),
+    several batches accumulated."""
+    from model_optimizer_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    cols = 1024
+    acc = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    want = torch.zeros(cols, dtype=torch.float32)
+    for tokens in (200, 77, 4099, 1):
+        x = (torch.randn(tokens, cols, generator=g) * torch.exp(torch.randn(cols, generator=g))).to(dtype)
+        ops.col_abs_mean_accum(x.to(DEV), acc)
+        want += x.abs().contiguous().view(-1, cols).mean(0).to(torch.float32)
+    got = acc.cpu()
+    # the mean is an fp32 sum of <= 4099 values rounded ONCE to the dtype: a different summation order can only matter
+    # when the sum sits within ~1e-6 of a rounding boundary -- none of these columns does (seeded); fp32 needs no luck
+    # only up to the summation order itself
+    if dtype == torch.float32:
+        assert torch.allclose(got, want, rtol=2e-6, atol=0)
+    else:
+        assert torch.equal(got, want), f"{int((got != want).sum())} of {cols} columns differ"
