@@ -191,6 +191,25 @@ int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols
 int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
                  float max_edge, int skip_zeros, void* stream);
 
+/* ------------------------------------------------------------------ fused input-quantizer pass (8f-3) */
+
+/* TensorQuantizer.forward for a per-tensor input quantizer in ONE read of the activation x[rows, cols]
+ * (nn/modules/tensor_quantizer.py:1119-1221); every stage is optional:
+ *   pre_quant_scale != NULL : v = dtype(x * pre_quant_scale[col])  (:1143-1144; fp32 [cols] holding model-dtype values)
+ *   amax_running   != NULL  : amax_running[0] = max(amax_running[0], max |v|)   (collect -> MaxCalibrator, calib/max.py:63-85;
+ *                             NaN propagates like torch.max)
+ *   hist_counts    != NULL  : hist_counts[bin(|v|)] += 1 with moq_hist_abs' binning over [0, hist_max_edge]
+ *                             (HistogramCalibrator.collect with a known range, calib/histogram.py:95-130); 8 <= bins < 16384
+ *   fmt 1 / 2               : y = INT-k / FP8-E4M3 quantize-dequantize of v with the per-tensor qdq_amax[0]
+ *                             (moq_fake_quant_int / moq_fake_quant_e4m3 arithmetic, tensor_quant.py:607-645, :46-59)
+ *   fmt 0                   : y = v when y != NULL and a pre_quant_scale is given (the calibration pass hands the scaled
+ *                             activation on to the linear), otherwise nothing is written.
+ * y may alias x.  pre_quant_scale needs cols % (16 / sizeof(elem)) == 0. */
+int moq_input_quant(const void* x, const float* pre_quant_scale, void* y, int64_t rows, int64_t cols, int dt,
+                    float* amax_running, const float* qdq_amax, int fmt, int num_bits, int is_unsigned,
+                    int narrow_range, unsigned long long* hist_counts, int hist_bins, float hist_max_edge,
+                    int hist_skip_zeros, void* stream);
+
 /* ------------------------------------------------------------------ MSE amax sweep (a5) */
 
 /* loss[k, a] (+)= sum over the elements governed by amax entry a of (x - QDQ(x, cand_amax[k, a]))^2 for all

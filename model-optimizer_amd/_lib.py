@@ -60,6 +60,8 @@ SIGNATURES = {
     "moq_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p]),
     "moq_col_abs_mean_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "moq_input_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
+                                c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
     "moq_hist_abs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
     "moq_mask_2to4": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "moq_int4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

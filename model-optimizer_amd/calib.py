@@ -137,8 +137,23 @@ class HistogramCalibrator(_Calibrator):
         x = x.detach()
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             x = x.float()  # the reference histograms x.abs().float() whatever the dtype (calib/histogram.py:95-96)
-        # x_max of what is histogrammed (|x| in fp32; zeros never raise the max)
-        x_max = ops.reduce_amax(x).float().cpu()
+        lo, hi = ops.INPUT_QUANT_HIST_BINS
+        if (self._calib_hist is not None and x.is_contiguous() and lo <= self._num_bins < hi
+                and x.dim() >= 1 and x.numel() > 0):
+            # later batches: abs-max AND the histogram over the current range from ONE read of the batch
+            # (ops.input_quant); only if the batch exceeds the range -- the growth step of calib/histogram.py:121-127 --
+            # are the optimistic counts dropped and the batch binned again over the extended range
+            amax = torch.zeros(1, dtype=torch.float32, device=x.device)
+            counts = torch.zeros(self._num_bins, dtype=torch.int64, device=x.device)
+            ops.input_quant(x.reshape(1, -1), amax_running=amax, hist_counts=counts,
+                            hist_max_edge=float(self._calib_bin_edges[-1]), hist_skip_zeros=self._skip_zeros)
+            x_max = amax.reshape(()).cpu()
+            if not x_max > self._calib_bin_edges[-1]:
+                self._calib_hist += counts
+                return
+        else:
+            # x_max of what is histogrammed (|x| in fp32; zeros never raise the max)
+            x_max = ops.reduce_amax(x).float().cpu()
         if self._calib_bin_edges is None and self._calib_hist is None:
             first_max = x_max
             if self._share_range:

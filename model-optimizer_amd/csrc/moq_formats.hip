@@ -2,6 +2,7 @@
 // the column-scale fold.  All HBM-bound streaming kernels with 16-byte lane accesses.
 #include "moq_common.h"
 #include "moq_chunk.h"
+#include "moq_hist.h"
 
 namespace moq {
 
@@ -205,33 +206,6 @@ __global__ void mx_generic_kernel(const void* __restrict__ x, void* __restrict__
 // atomics.
 constexpr int kHistMaxLdsBins = 16384;  // 64 KiB of the CU's 160 KiB LDS
 
-// Branch-free binning: one LDS atomic per element, invalid elements (outside [0, max_edge], NaN, skipped zeros,
-// past the end) go to a trash slot instead of around a branch -- the exec-mask juggling of a guarded atomic costs
-// more issue slots than the atomic itself.  SHARED selects the shared-denominator division (bit-identical to `/`
-// while |a * bins| <= 2^16, checked by the caller): five full-rate FMAs instead of the IEEE sequence per element.
-// LDS layout: R = 2^rshift interleaved copies of the histogram (copy = lane & (R - 1), slot = bin * R + copy) plus R
-// trash slots at bin index `bins`: activations pile up in a few low bins and same-address LDS atomics of one wave
-// serialise -- R copies cut that R-fold and spread a hot bin over R banks.
-template <bool SHARED>
-__device__ __forceinline__ int hist_bin(float a, int bins, float max_edge, const SharedDiv& sd, int skip_zeros) {
-  // torch.histc: pos = (int)((v - min) * bins / (max - min)) in fp32, v == max -> last bin, outside -> skip
-  const float num = a * (float)bins;
-  float qf;
-  if constexpr (SHARED) {  // shared_div without its range check (the host selected this instantiation)
-    const float q0 = num * sd.y;
-    const float r0 = __builtin_fmaf(-sd.d, q0, num);
-    const float q1 = __builtin_fmaf(r0, sd.y, q0);
-    const float r1 = __builtin_fmaf(-sd.d, q1, num);
-    qf = __builtin_fmaf(r1, sd.y, q1);
-  } else {
-    qf = num / max_edge;
-  }
-  int pos = (int)qf;
-  pos = pos < bins - 1 ? pos : bins - 1;
-  // bitwise, not short-circuit: no exec-mask branches.  a <= max_edge also drops NaN.
-  const bool ok = (a <= max_edge) & !((skip_zeros != 0) & (a == 0.0f));
-  return ok ? pos : bins;
-}
 // The workgroup is kHistBlock = 1024 threads (16 waves) around ONE LDS histogram: the histogram (64 KiB with 8 copies
 // of 2048 bins) limits a CU to two workgroups, and with 256-thread workgroups that meant two waves per SIMD -- too few
 // to hide the load -> bin -> ds_add dependency chain.  Each 256-thread quarter walks its own chunks.
@@ -797,6 +771,13 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
     return MOQ_ERR_INVALID;
   }
   if (n == 0) return MOQ_OK;
+  // default: the histogram stage of the fused input-quantizer kernel (moq_inputq.hip): the lowest bins -- where
+  // activations pile up -- are counted with wave ballots instead of LDS atomics.  MOQ_TUNE_HIST=0 selects the
+  // round-1 kernel below (one LDS atomic per element) for A/B measurements.
+  static const bool ballot_hist = [] { const char* e = getenv("MOQ_TUNE_HIST"); return !(e && e[0] == '0'); }();
+  if (ballot_hist && bins >= 8 && bins < kHistMaxLdsBins)
+    return moq_input_quant(x, nullptr, nullptr, 1, n, dt, nullptr, nullptr, 0, 0, 0, 0, counts, bins, max_edge,
+                           skip_zeros, stream);
   // <= 512 workgroups of 1024 threads: the flush costs `bins` 64-bit global atomics per workgroup
   int64_t blocks = ((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK + 3) / 4;
   if (blocks > 512) blocks = 512;

@@ -387,6 +387,65 @@ def hist_abs(x: torch.Tensor, bins: int, max_edge: float, skip_zeros: bool = Fal
     return counts
 
 
+INPUT_QUANT_HIST_BINS = (8, 16384)  # bin counts the histogram stage of moq_input_quant takes
+
+
+@torch.no_grad()
+def input_quant(x: torch.Tensor, pre_quant_scale: torch.Tensor | None = None, amax_running: torch.Tensor | None = None,
+                qdq_amax: torch.Tensor | None = None, num_bits=None, unsigned: bool = False, narrow_range: bool = False,
+                hist_counts: torch.Tensor | None = None, hist_max_edge: float = 0.0, hist_skip_zeros: bool = False,
+                out: torch.Tensor | None = None) -> torch.Tensor | None:
+    """The per-tensor input-quantizer pass of TensorQuantizer.forward in one read of x (nn/modules/tensor_quantizer.py:
+    1119-1221): optional `x * pre_quant_scale` in x.dtype, running abs-max into `amax_running` (fp32 [1]), |.| histogram
+    into `hist_counts` (int64 [bins], range [0, hist_max_edge]) and INT-k (num_bits int) / FP8-E4M3 (num_bits (4, 3))
+    quantize-dequantize with `qdq_amax`.  Returns the output tensor (the scaled and / or fake-quantized activation) or
+    None when only statistics were asked for."""
+    _require_gpu(x, "input_quant")
+    xc = x.detach()
+    if not xc.is_contiguous():
+        xc = xc.contiguous()
+    cols = xc.shape[-1]
+    rows = xc.numel() // max(cols, 1)
+    dev = xc.device
+    fmt = 0
+    if qdq_amax is not None:
+        if isinstance(num_bits, int):
+            fmt = 1
+        elif num_bits is not None and tuple(num_bits) == (4, 3):
+            fmt = 2
+        else:
+            raise MoquantUnsupported(f"input_quant: format {num_bits}")
+        qa = _f32(qdq_amax, dev).reshape(-1)
+        if qa.numel() != 1:
+            raise MoquantUnsupported("input_quant: per-tensor amax only")
+    else:
+        qa = None
+    pqs = None
+    if pre_quant_scale is not None:
+        if pre_quant_scale.numel() != cols:
+            raise MoquantError("input_quant: pre_quant_scale must have one entry per column")
+        pqs = _f32(pre_quant_scale.to(xc.dtype), dev).reshape(-1).contiguous()
+    if amax_running is not None and (amax_running.dtype != torch.float32 or amax_running.numel() != 1
+                                     or amax_running.device != dev):
+        raise MoquantError("input_quant: amax_running must be a 1-element fp32 tensor on x's device")
+    bins = 0
+    if hist_counts is not None:
+        bins = hist_counts.numel()
+        if hist_counts.dtype != torch.int64 or not hist_counts.is_contiguous() or hist_counts.device != dev:
+            raise MoquantError("input_quant: hist_counts must be a contiguous int64 tensor on x's device")
+    y = None
+    if fmt or pqs is not None:
+        y = out if out is not None else torch.empty_like(xc)
+        if y.shape != xc.shape or y.dtype != xc.dtype or not y.is_contiguous():
+            raise MoquantError("input_quant: `out` must be contiguous with x's shape and dtype")
+    nb = int(num_bits) if fmt == 1 else 0
+    with _on(xc) as stream:
+        check(_lib.lib().moq_input_quant(_p(xc), _p(pqs), _p(y), rows, cols, _dt(xc), _p(amax_running), _p(qa), fmt, nb,
+                                         int(bool(unsigned)), int(bool(narrow_range)), _p(hist_counts), int(bins),
+                                         float(hist_max_edge), int(bool(hist_skip_zeros)), stream))
+    return y
+
+
 @torch.no_grad()
 def row_hist_np(w: torch.Tensor, bins: int):
     """Per-row histograms of |w| with np.histogram(a, bins, range=(0, a.max())) semantics (calibrate_weights,

@@ -355,12 +355,46 @@ class TensorQuantizer(nn.Module):
         return ops.fake_tensor_quant(inputs, self._get_amax(inputs), self._num_bits, self._unsigned,
                                      self._narrow_range)
 
+    def _fused_input_pass(self, inputs, pqs):
+        """pre_quant_scale * x -> collect -> fake-quantize of a PER-TENSOR quantizer as ONE kernel pass over the
+        activation (ops.input_quant; the reference runs a multiply, an amax + amin pair and ~8 elementwise kernels,
+        tensor_quantizer.py:1143-1212).  Returns the output, or None when this call is not of that shape."""
+        if (self._disabled or inputs.dtype not in (torch.float32, torch.float16, torch.bfloat16)
+                or self._axis is not None or self._block_sizes is not None or self._dynamic
+                or not (self._if_quant or self._if_calib) or pqs.numel() != inputs.shape[-1] or pqs.numel() < 2
+                or inputs.shape[-1] % (4 if inputs.dtype == torch.float32 else 8)):
+            return None
+        nb = self._num_bits
+        if not (isinstance(nb, int) or tuple(nb) == (4, 3)):
+            return None
+        amax_q = None
+        if self._if_quant:
+            amax_q = getattr(self, "_amax", None)
+            if amax_q is None or amax_q.numel() != 1:
+                return None  # dynamic amax of this very input: the reduction has to finish before the QDQ can start
+        running = None
+        if self._if_calib:
+            cal = self._calibrator
+            if type(cal) is not MaxCalibrator or cal._track_amax:
+                return None
+            if cal._buf is None:
+                cal._buf = torch.zeros(1, dtype=torch.float32, device=inputs.device)
+                cal._shape, cal._dtype = (), inputs.dtype
+            elif cal._shape != ():
+                raise RuntimeError("amax shape changed!")
+            running = cal._buf
+        return ops.input_quant(inputs, pqs, amax_running=running, qdq_amax=amax_q, num_bits=nb if amax_q is not None else None,
+                               unsigned=self._unsigned, narrow_range=self._narrow_range)
+
     def forward(self, inputs):
         if inputs.numel() == 0:
             return inputs
         pqs = self.pre_quant_scale
         fused_pqs = False
         if pqs is not None:
+            out = self._fused_input_pass(inputs, pqs)
+            if out is not None:
+                return out
             can_fuse = (not self._disabled and self._if_quant and not self._if_calib and self.is_static_block_quant
                         and not hasattr(self, "_amax") and isinstance(self._num_bits, int) and not self._unsigned
                         and not self._narrow_range and inputs.dim() == 2 and pqs.numel() == inputs.shape[-1])

@@ -179,6 +179,37 @@ class HostMemLib:
         a[:] = a + mean
         return OK
 
+    def moq_input_quant(self, x, pqs, y, rows, cols, dt, amax_running, qdq_amax, fmt, num_bits, unsigned, narrow,
+                        hist_counts, hist_bins, hist_max_edge, hist_skip_zeros, stream):
+        """The fused pass as the chain of the oracle's single stages (scale -> amax -> histogram -> QDQ)."""
+        import torch
+
+        tdt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(dt)]
+        n = int(rows) * int(cols)
+        es = 4 if int(dt) == 0 else 2
+        src = (ctypes.c_char * (n * es)).from_address(_addr(x))
+        v = torch.frombuffer(bytearray(src), dtype=tdt).reshape(int(rows), int(cols))
+        if _addr(pqs):
+            sv = torch.from_numpy(_f32_view(pqs, cols).copy())
+            v = oracle.scale_cols(v, sv)
+        if _addr(amax_running):
+            a = _f32_view(amax_running, 1)
+            m = float(oracle.reduce_amax(v).float())
+            a[0] = m if (m != m or m > a[0]) else a[0]
+        if _addr(hist_counts):
+            cnt = np.ctypeslib.as_array(ctypes.cast(_addr(hist_counts), ctypes.POINTER(ctypes.c_int64)), shape=(int(hist_bins),))
+            cnt += oracle.hist_abs(v.reshape(-1), int(hist_bins), float(hist_max_edge), bool(hist_skip_zeros)).astype(np.int64)
+        if int(fmt) == 1:
+            am = torch.from_numpy(_f32_view(qdq_amax, 1).copy())
+            v = oracle.fake_quant_int(v, am, int(num_bits), bool(unsigned), bool(narrow))
+        elif int(fmt) == 2:
+            am = torch.from_numpy(_f32_view(qdq_amax, 1).copy())
+            v = oracle.fake_quant_e4m3(v, am)
+        if _addr(y) and (int(fmt) or _addr(pqs)):
+            raw = v.contiguous().view(torch.uint8).numpy().tobytes()
+            ctypes.memmove(_addr(y), raw, len(raw))
+        return OK
+
     def moq_mse_sweep_workspace(self, outer, axis_size, inner, n_cand):
         return 0
 

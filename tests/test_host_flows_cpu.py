@@ -351,3 +351,35 @@ def test_int4_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, host
     assert not any(report.values()), {k: v for k, v in report.items() if v}
     state = moa.export.export_state_dict(q, torch.bfloat16, lambda: q(torch.ones([1, 2], dtype=torch.long)))
     _compare_state(state, g, g.cases)
+
+
+def test_tensor_quantizer_fused_input_pass_equals_unfused_chain(hostmem):
+    """Per-tensor input quantizer with a pre_quant_scale: one moq_input_quant call per forward (calibrating, quantizing, or
+    both); outputs, running amax and the calibrated amax equal the stage-by-stage path."""
+    TQ, Cfg = moa.TensorQuantizer, moa.QuantizerAttributeConfig
+    g = torch.Generator().manual_seed(0)
+    x1 = (torch.randn(24, 64, generator=g) * torch.exp(torch.randn(64, generator=g))).to(torch.bfloat16)
+    x2 = (torch.randn(10, 64, generator=g) * 3).to(torch.bfloat16)
+    pqs = torch.exp(torch.randn(64, generator=g) * 0.3).to(torch.bfloat16)
+    calls = []
+    real = hostmem.moq_input_quant
+    hostmem.moq_input_quant = lambda *a: (calls.append(1), real(*a))[1]
+    for nb in (8, (4, 3)):
+        q = TQ(Cfg(num_bits=nb, axis=None))
+        q.pre_quant_scale = pqs
+        q.disable_quant()
+        q.enable_calib()
+        n0 = len(calls)
+        assert_bits_equal(q(x1), x1 * pqs, "calibration hands x * s on")
+        q(x2)
+        q._if_quant = True  # calibrating and quantizing at once needs an amax first
+        q.amax = torch.tensor(2.5, dtype=torch.bfloat16)
+        y_both = q(x1)
+        assert len(calls) - n0 == 3
+        q.disable_calib()
+        amax = q._calibrator.compute_amax()
+        assert amax.item() == max((x1 * pqs).abs().max().item(), (x2 * pqs).abs().max().item())
+        v = moa.ops.scale_cols(x1, pqs)
+        want = moa.ops.scaled_e4m3(v, q.amax) if nb == (4, 3) else moa.ops.fake_tensor_quant(v, q.amax, 8, False, False)
+        assert_bits_equal(y_both, want, f"num_bits={nb}")
+        assert_bits_equal(q(x1), want, f"quant only, num_bits={nb}")

@@ -47,7 +47,27 @@ def main():
     s448 = (amax1 / 448.0).to(torch.bfloat16)
     s_tile = (ops.reduce_block_amax(w, {-1: 128, -2: 128}).float() / 448.0).to(torch.bfloat16)
     q8t = ops.fp8_quantize_tile(w, s_tile, 128, 128).view(torch.uint8)
+    # activations with per-channel spread and a few massive channels: the abs-max is set by outliers, the
+    # bulk of |x| sits in the lowest histogram bins
+    chan = torch.exp(torch.randn(8192, device=DEV))
+    chan[:4] *= 50.0
+    xo = (torch.randn(8 * 512, 8192, device=DEV) * chan).to(torch.bfloat16)
+    xo_max = float(xo.float().abs().max())
+    xbig = (torch.randn(32 * 4096, 8192, device=DEV) * chan).to(torch.bfloat16)  # 2.1 GB: past the Infinity Cache
+    xbig_max = float(xbig.float().abs().max())
+    counts_big = torch.zeros(2048, dtype=torch.int64, device=DEV)
+    run_amax = torch.zeros(1, dtype=torch.float32, device=DEV)
+    pqs = (torch.rand(8192, device=DEV) + 0.5).to(torch.bfloat16)
+    amax_x = torch.tensor(xo_max * 0.5, device=DEV)
+    ybig = torch.empty_like(xbig)
     cases = [
+        ("moq_hist_abs 2048 bins, activations with outlier channels (67 MB)", lambda: ops.hist_abs(xo, 2048, xo_max, False, counts), 2 * nx),
+        ("moq_hist_abs 2048 bins, activations with outlier channels (2.1 GB)", lambda: ops.hist_abs(xbig, 2048, xbig_max, False, counts_big), 2 * xbig.numel()),
+        ("moq_input_quant: amax + histogram, one read (2.1 GB)", lambda: ops.input_quant(xbig, amax_running=run_amax, hist_counts=counts_big, hist_max_edge=xbig_max), 2 * xbig.numel()),
+        ("moq_input_quant: x * pqs -> amax -> FP8 QDQ (2.1 GB)", lambda: ops.input_quant(xbig, pqs, amax_running=run_amax, qdq_amax=amax_x, num_bits=(4, 3), out=ybig), 4 * xbig.numel()),
+        ("moq_input_quant: x * pqs -> amax -> INT8 QDQ (2.1 GB)", lambda: ops.input_quant(xbig, pqs, amax_running=run_amax, qdq_amax=amax_x, num_bits=8, out=ybig), 4 * xbig.numel()),
+        ("unfused: scale_cols + amax + FP8 QDQ (2.1 GB, 3 kernels)", lambda: (lambda v: (ops.reduce_amax(v), ops.scaled_e4m3(v, amax_x)))(ops.scale_cols(xbig, pqs)), 4 * xbig.numel()),
+        ("moq_col_abs_mean_accum (awq act scale, 67 MB)", lambda: ops.col_abs_mean_accum(x, torch.zeros(8192, device=DEV)), 2 * nx),
         ("moq_amax (per-tensor)", lambda: ops.reduce_amax(w), 2 * n),
         ("moq_amax_axis rows (per-channel, axis 0)", lambda: ops.reduce_amax(w, axis=(1,)), 2 * n),
         ("moq_amax_axis groups g=128 (static per-group)", lambda: ops.reduce_amax(w.view(-1, 128), axis=(1,)), 2 * n + 4 * n / 128),
