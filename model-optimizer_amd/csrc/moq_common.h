@@ -328,7 +328,8 @@ __device__ __forceinline__ float shared_div(float n, const SharedDiv& s) {
 __device__ __forceinline__ float qdq_int_shared(float x, float scale, const SharedDiv& sd, const IntQ& q) {
   float p = x * scale;
   float t = __builtin_rintf(p);
-  t = __builtin_fminf(__builtin_fmaxf(t, q.lo), q.hi);
+  t = t < q.lo ? q.lo : t;  // torch.clamp's max(t, lo): keeps t when equal, so a -0 survives an unsigned lower bound of +0
+  t = __builtin_fminf(t, q.hi);
   t = (p != p) ? p : t;
   return scale == 0.0f ? t : shared_div(t, sd);
 }
@@ -355,7 +356,8 @@ __device__ __forceinline__ float qdq_int(float x, float scale, const IntQ& q) {
   // it, so a NaN product (NaN input, or inf * 0) is re-injected.
   float p = x * scale;
   float t = __builtin_rintf(p);
-  t = __builtin_fminf(__builtin_fmaxf(t, q.lo), q.hi);
+  t = t < q.lo ? q.lo : t;  // as in qdq_int_shared
+  t = __builtin_fminf(t, q.hi);
   t = (p != p) ? p : t;
   return scale == 0.0f ? t : t / scale;
 }

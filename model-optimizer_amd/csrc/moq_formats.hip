@@ -771,11 +771,11 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
     return MOQ_ERR_INVALID;
   }
   if (n == 0) return MOQ_OK;
-  // default: the histogram stage of the fused input-quantizer kernel (moq_inputq.hip): the lowest bins -- where
-  // activations pile up -- are counted with wave ballots instead of LDS atomics.  MOQ_TUNE_HIST=0 selects the
-  // round-1 kernel below (one LDS atomic per element) for A/B measurements.
-  static const bool ballot_hist = [] { const char* e = getenv("MOQ_TUNE_HIST"); return !(e && e[0] == '0'); }();
-  if (ballot_hist && bins >= 8 && bins < kHistMaxLdsBins)
+  // 16-bit inputs: the histogram stage of the fused input-quantizer kernel (moq_inputq.hip), which tabulates the
+  // binning rule per |x| pattern once per workgroup instead of evaluating it per element.  MOQ_TUNE_HIST=0 selects the
+  // arithmetic kernel below (the fp32 path) for A/B measurements.
+  static const bool lut_hist = [] { const char* e = getenv("MOQ_TUNE_HIST"); return !(e && e[0] == '0'); }();
+  if (lut_hist && dt != MOQ_F32 && bins < kHistMaxLdsBins)
     return moq_input_quant(x, nullptr, nullptr, 1, n, dt, nullptr, nullptr, 0, 0, 0, 0, counts, bins, max_edge,
                            skip_zeros, stream);
   // <= 512 workgroups of 1024 threads: the flush costs `bins` 64-bit global atomics per workgroup

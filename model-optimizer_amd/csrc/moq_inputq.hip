@@ -12,16 +12,17 @@
 // enabled stage works on the registers of the same 16-byte packets: 2 B/elem read, 2 B/elem written when there is
 // an output -- the stage list is a template, so a disabled stage costs nothing.
 //
-// Histogram stage: LDS atomics retire about two lanes per clock per CU when the lanes of a wave pile onto a few bins
-// (round 1: 2.3 TB/s), and activations do exactly that -- the range is set by a handful of outliers, the bulk sits in
-// the lowest bins.  The lowest kHotBins bins are therefore counted WITHOUT atomics, in packed per-lane registers
-// (hot_add below) that reach the LDS histogram once per wave at the end.  Only elements beyond the hot bins take the
-// (guarded) LDS atomic; with a
-// flat distribution that is every element, but then the lanes of a wave spread over the whole histogram and the
-// atomics do not serialise.  Counts are exact integers either way (torch.histc semantics, moq_hist.h).
+// Histogram stage.  LDS atomics are not what bounds a histogram on this chip -- a probe (tools/exp/lds_atomic_probe.hip,
+// profiles/r02_lds_atomic_probe.txt) retires 10 random / 6.5 hot-binned ds_add_u32 lanes per clock per CU, four times
+// what round 1's kernel used -- the ~15 VALU instructions per element of torch.histc's binning rule are (multiply, exact
+// division, convert, clamp, range tests).  A 16-bit input has only 2^15 distinct |x| patterns, so each workgroup first
+// tabulates the rule once -- lut[pattern] = histogram slot, built with the very same hist_bin() (64 KiB of LDS) -- and
+// an element then costs a field extract, one ds_read_u16 and the ds_add_u32: 3 VALU + 2 LDS instructions.  Results are
+// identical by construction.  fp32 inputs keep the arithmetic rule.  Counts are exact integers either way.
 //
 // Layout: 1024-thread workgroups (four 256-thread quarters walking their own 8192-element chunks, moq_chunk.h) so
-// that the one LDS histogram of a workgroup (<= 64 KiB) is shared by 16 waves; <= 512 workgroups.
+// that the one LDS histogram (+ table) of a workgroup is shared by 16 waves; <= 512 workgroups (one per CU with the
+// table: 64 KiB table + <= 64 KiB of interleaved histogram copies).
 // Roofline: HBM.  Algorithmic bytes per element (bf16): 2 (statistics only) or 4 (with an output).
 #include <stdlib.h>
 
@@ -33,31 +34,7 @@
 namespace moq {
 
 constexpr int kIqBlock = 1024;
-constexpr int kHotBins = 8;
-
-// Hot bins without atomics: every lane keeps the counts of the kHotBins lowest bins for ITS elements in two packed
-// registers (8-bit fields: bins 0-3 in `lo`, 4-7 in `hi`) -- nine full-rate VALU ops per element (shift, shift, and
-// twice compare / select / add), no scalar-unit work (the CU's one scalar ALU would cap a ballot + s_bcnt1 scheme at
-// ~3 TB/s) and no cross-lane traffic.  A lane sees 32 elements per chunk, so the fields are emptied into 32-bit
-// per-lane counters every kHotFlush = 7 chunks (224 <= 255); the counters are summed over the wave once, at the end.
-static_assert(kHotBins == 8, "two packed accumulators of four 8-bit fields");
-constexpr int kHotFlush = 7;
-struct HotAcc {
-  uint32_t lo, hi;
-};
-__device__ __forceinline__ void hot_add(HotAcc& a, int b) {
-  const uint32_t m = 1u << (((uint32_t)b << 3) & 31u);  // field of bin (b & 3); the hardware masks the shift anyway
-  a.lo += (uint32_t)b < 4u ? m : 0u;
-  a.hi += (uint32_t)(b - 4) < 4u ? m : 0u;
-}
-__device__ __forceinline__ void hot_flush(HotAcc& a, uint32_t (&cnt)[kHotBins]) {
-#pragma unroll
-  for (int h = 0; h < 4; ++h) {
-    cnt[h] += (a.lo >> (8 * h)) & 0xFFu;
-    cnt[4 + h] += (a.hi >> (8 * h)) & 0xFFu;
-  }
-  a.lo = a.hi = 0;
-}
+constexpr int kLutEntries = 32768;  // |x| patterns of a 16-bit float
 
 struct IqParams {
   const void* x;
@@ -83,9 +60,22 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   const int tid = threadIdx.x & (kBlock - 1);
   const int lane = threadIdx.x & 63;
   const int copy = (int)(threadIdx.x & ((1u << p.rshift) - 1u));
+  const SharedDiv sd = make_shared_div(p.max_edge);
+  constexpr bool LUT = HIST && DT != MOQ_F32;
+  const int slots = (p.bins + 1) << p.rshift;
+  // LDS: [histogram: slots x u32][table: 32768 x u16 (16-bit inputs)]
+  uint16_t* lut = reinterpret_cast<uint16_t*>(lds_hist + slots);
   if constexpr (HIST) {
-    const int slots = (p.bins + 1) << p.rshift;
     for (int b = threadIdx.x; b < slots; b += kIqBlock) lds_hist[b] = 0;
+    if constexpr (LUT) {
+      // lut[|x| pattern] = first slot of the pattern's bin ((bin << rshift); invalid -> the trash bin `bins`)
+      for (int v = threadIdx.x; v < kLutEntries; v += kIqBlock) {
+        float a;
+        if constexpr (DT == MOQ_BF16) a = __uint_as_float((uint32_t)v << 16);
+        else { uint16_t h = (uint16_t)v; a = (float)*reinterpret_cast<_Float16*>(&h); }
+        lut[v] = (uint16_t)(hist_bin<SHARED>(a, p.bins, p.max_edge, sd, p.skip_zeros) << p.rshift);
+      }
+    }
     __syncthreads();
   }
   OpIntQdq opi;
@@ -96,12 +86,6 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   } else if constexpr (FMT == 2) {
     opf.sc = fp8_scale(p.qdq_amax[0]);
   }
-  const SharedDiv sd = make_shared_div(p.max_edge);
-  HotAcc hot_acc = {0u, 0u};
-  uint32_t hot[kHotBins];
-#pragma unroll
-  for (int h = 0; h < kHotBins; ++h) hot[h] = 0;
-  int hot_age = 0;
   uint32_t amax_acc = 0;
   const bool al = aligned16(p.x) && (p.y == nullptr || aligned16(p.y));
   const int64_t n_chunks = (p.n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
@@ -110,12 +94,6 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   for (int64_t c = (int64_t)blockIdx.x * Q + quarter; c < n_chunks; c += (int64_t)gridDim.x * Q) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     const bool fast = al && e0 + MOQ_MT_CHUNK <= p.n;
-    if constexpr (HIST) {
-      if (++hot_age > kHotFlush) {
-        hot_flush(hot_acc, hot);
-        hot_age = 1;
-      }
-    }
     int64_t col0 = 0;
     if constexpr (PQS) col0 = e0 % p.cols;  // wave-uniform; cols % V == 0 (host-checked): a packet stays in one row
     Pack16 in[P];
@@ -152,12 +130,28 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
         }
       }
       if constexpr (HIST) {
+        if constexpr (LUT) {
+          // the 16-bit patterns of v: straight from the packet, or re-packed when a pre_quant_scale changed them
+          const Pack16 pv = PQS ? pack<DT>(f) : in[u];
+          uint32_t slot[8];  // all table reads of the packet first, then its atomics: one LDS round trip per packet
 #pragma unroll
-        for (int i = 0; i < V; ++i) {
-          int b = hist_bin<SHARED>(__builtin_fabsf(f[i]), p.bins, p.max_edge, sd, p.skip_zeros);
-          if (!fast) b = e + i < p.n ? b : p.bins;
-          hot_add(hot_acc, b);
-          if (b >= kHotBins && b < p.bins) atomicAdd(&lds_hist[(b << p.rshift) + copy], 1u);
+          for (int i = 0; i < 4; ++i) {
+            slot[2 * i] = lut[pv.w[i] & 0x7FFFu];
+            slot[2 * i + 1] = lut[(pv.w[i] >> 16) & 0x7FFFu];
+          }
+          if (!fast) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) slot[i] = e + i < p.n ? slot[i] : (uint32_t)(p.bins << p.rshift);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) atomicAdd(&lds_hist[slot[i] + copy], 1u);
+        } else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            int b = hist_bin<SHARED>(__builtin_fabsf(f[i]), p.bins, p.max_edge, sd, p.skip_zeros);
+            if (!fast) b = e + i < p.n ? b : p.bins;
+            atomicAdd(&lds_hist[(b << p.rshift) + copy], 1u);
+          }
         }
       }
       if constexpr (FMT == 1) opi(f, V);
@@ -173,19 +167,6 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   if constexpr (AMAX) {
     amax_acc = group_max_u32<64>(amax_acc);
     if (lane == 0) s_max[threadIdx.x >> 6] = amax_acc;
-  }
-  if constexpr (HIST) {
-    // the lanes' hot-bin counters are summed over the wave (butterfly), lane h adds bin h to the workgroup histogram
-    hot_flush(hot_acc, hot);
-    uint32_t mine = 0;
-#pragma unroll
-    for (int h = 0; h < kHotBins; ++h) {
-      uint32_t v = hot[h];
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
-      mine = lane == h ? v : mine;
-    }
-    if (lane < kHotBins && mine != 0) atomicAdd(&lds_hist[(lane << p.rshift) + copy], mine);
   }
   __syncthreads();
   if constexpr (AMAX) {
@@ -209,12 +190,20 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
 using namespace moq;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-constexpr int kIqMaxLdsBins = 16384;  // 64 KiB of LDS, as moq_hist_abs
+constexpr int kIqMaxLdsBins = 16384;   // bin counts beyond this go to moq_hist_abs' global-atomic kernel
+constexpr size_t kIqLdsBudget = 156 * 1024;  // of the CU's 160 KiB (a few words of static LDS come on top)
 
 template <int DT, int FMT, bool PQS>
 static void launch_iq(const IqParams& p, bool amax, bool hist, bool shared, int blocks, size_t lds, void* stream) {
-#define MOQ_IQ_GO(A, H, SH) \
-  hipLaunchKernelGGL((input_quant_kernel<DT, FMT, PQS, A, H, SH>), dim3(blocks), dim3(kIqBlock), lds, S(stream), p)
+#define MOQ_IQ_GO(A, H, SH)                                                                                         \
+  do {                                                                                                              \
+    if (lds > 64 * 1024) {                                                                                          \
+      /* > 64 KiB of dynamic LDS needs the opt-in attribute, per device; setting it again is harmless */           \
+      (void)hipFuncSetAttribute((const void*)input_quant_kernel<DT, FMT, PQS, A, H, SH>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIqLdsBudget);                     \
+    }                                                                                                               \
+    hipLaunchKernelGGL((input_quant_kernel<DT, FMT, PQS, A, H, SH>), dim3(blocks), dim3(kIqBlock), lds, S(stream), p); \
+  } while (0)
   if (amax && hist) { if (shared) MOQ_IQ_GO(true, true, true); else MOQ_IQ_GO(true, true, false); }
   else if (hist) { if (shared) MOQ_IQ_GO(false, true, true); else MOQ_IQ_GO(false, true, false); }
   else if (amax) MOQ_IQ_GO(true, false, false);
@@ -238,8 +227,8 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
     set_error("moq_input_quant: num_bits=%d out of range", num_bits);
     return MOQ_ERR_INVALID;
   }
-  if (hist_counts != nullptr && (hist_bins < kHotBins || hist_bins >= kIqMaxLdsBins)) {
-    set_error("moq_input_quant: histogram stage needs %d <= bins < %d (use moq_hist_abs beyond)", kHotBins, kIqMaxLdsBins);
+  if (hist_counts != nullptr && (hist_bins < 1 || hist_bins >= kIqMaxLdsBins)) {
+    set_error("moq_input_quant: histogram stage needs 1 <= bins < %d (use moq_hist_abs beyond)", kIqMaxLdsBins);
     return MOQ_ERR_UNSUPPORTED;
   }
   const int vec = dt == MOQ_F32 ? 4 : 8;
@@ -247,7 +236,7 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
     set_error("moq_input_quant: pre_quant_scale needs cols %% %d == 0 and a 16-byte aligned scale vector", vec);
     return MOQ_ERR_UNSUPPORTED;
   }
-  if (pre_quant_scale != nullptr && fmt == 0 && y == nullptr && amax_running == nullptr && hist_counts == nullptr) {
+  if (fmt == 0 && amax_running == nullptr && hist_counts == nullptr && (pre_quant_scale == nullptr || y == nullptr)) {
     set_error("moq_input_quant: nothing to do");
     return MOQ_ERR_INVALID;
   }
@@ -261,13 +250,22 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
   p.skip_zeros = hist_skip_zeros; p.rshift = 0;
   size_t lds = 0;
   bool shared = false;
-  if (hist_counts != nullptr) {
-    while (p.rshift < 3 && ((int64_t)(hist_bins + 1) << (p.rshift + 1)) <= kIqMaxLdsBins + 8) ++p.rshift;
-    lds = ((size_t)(hist_bins + 1) << p.rshift) * 4;
-    shared = hist_max_edge >= 0x1p-60f && hist_max_edge <= 0x1p60f && hist_max_edge * (float)hist_bins <= 65536.0f;
-  }
   int64_t blocks = ((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK + 3) / 4;
   if (blocks > 512) blocks = 512;
+  if (hist_counts != nullptr) {
+    // interleaved copies of the histogram (hot bins spread over banks) as far as LDS allows; the table of a 16-bit
+    // input takes 64 KiB, which leaves room for one workgroup per CU
+    const size_t table = dt == MOQ_F32 ? 0 : (size_t)kLutEntries * 2;
+    const size_t room = (table ? kIqLdsBudget : (size_t)64 * 1024 + 32) - table;
+    while (p.rshift < 3 && ((size_t)(hist_bins + 1) << (p.rshift + 1)) * 4 <= room) ++p.rshift;
+    lds = ((size_t)(hist_bins + 1) << p.rshift) * 4 + table;
+    if (lds > kIqLdsBudget) {
+      set_error("moq_input_quant: %d bins do not fit the LDS histogram", hist_bins);
+      return MOQ_ERR_UNSUPPORTED;
+    }
+    if (table && blocks > 256) blocks = 256;
+    shared = hist_max_edge >= 0x1p-60f && hist_max_edge <= 0x1p60f && hist_max_edge * (float)hist_bins <= 65536.0f;
+  }
   const bool amax = amax_running != nullptr, hist = hist_counts != nullptr;
 #define MOQ_IQ_FMT(F)                                                                                         \
   if (pre_quant_scale != nullptr) {                                                                           \

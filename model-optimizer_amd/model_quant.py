@@ -12,38 +12,44 @@ from . import model_calib
 from .nn import replace_quant_module
 from .tensor_quantizer import QuantizerAttributeConfig, SequentialQuantizer, TensorQuantizer
 
+# modelopt_recipes/configs/ptq/units/default_disabled_quantizers.yaml: module patterns every preset keeps in high
+# precision (routers / MoE gates, lm_head and other output layers, conv1d mixers, the vision branch of multimodal
+# models).  The reference's presets are [disable all, enable the format's quantizers, THIS list]; so are ours.  Its
+# parent_class entries (BatchNorm*, LeakyReLU, Embedding) name modules this path never wraps.
+DEFAULT_DISABLED_QUANTIZERS = (
+    "*block_sparse_moe.gate*", "*linear_attn.conv1d*", "*linear_attn.in_proj_a*", "*linear_attn.in_proj_b*", "*lm_head*",
+    "*mixer.conv1d*", "*mlp.gate.*", "*mlp.shared_expert_gate.*", "*output_layer*", "*proj_out.*", "*router*", "mtp.*",
+    "output.*", "*embed_vision*", "*vision_tower*", "*visual*", "*vision_model*", "*multi_modal_projector*")
+
+
+def _preset(quantizers: dict, algorithm) -> dict:
+    return {"quant_cfg": {**quantizers, **{pat: {"enable": False} for pat in DEFAULT_DISABLED_QUANTIZERS}},
+            "algorithm": algorithm}
+
+
 # presets mirroring modelopt_recipes/configs/ptq/presets/model/{int8,fp8,int4_awq,mxfp4,int8_smoothquant}.yaml
-INT8_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
-                                  "*input_quantizer": {"num_bits": 8, "axis": None},
-                                  "*lm_head*": {"enable": False}}, "algorithm": "max"}
+INT8_DEFAULT_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
+                            "*input_quantizer": {"num_bits": 8, "axis": None}}, "max")
 # presets/model/int8_weight_only.yaml: per-channel INT8 weights, inputs untouched
-INT8_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
-                                      "*input_quantizer": {"enable": False},
-                                      "*lm_head*": {"enable": False}}, "algorithm": "max"}
-FP8_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "axis": None},
-                                 "*input_quantizer": {"num_bits": (4, 3), "axis": None},
-                                 "*lm_head*": {"enable": False}}, "algorithm": "max"}
-INT4_AWQ_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
-                              "*input_quantizer": {"enable": False},
-                              "*lm_head*": {"enable": False}},
-                "algorithm": {"method": "awq_lite", "alpha_step": 0.1}}
+INT8_WEIGHT_ONLY_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
+                                "*input_quantizer": {"enable": False}}, "max")
+FP8_DEFAULT_CFG = _preset({"*weight_quantizer": {"num_bits": (4, 3), "axis": None},
+                           "*input_quantizer": {"num_bits": (4, 3), "axis": None}}, "max")
+INT4_AWQ_CFG = _preset({"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                        "*input_quantizer": {"enable": False}}, {"method": "awq_lite", "alpha_step": 0.1})
 # presets/model/int4_blockwise_weight_only.yaml (numerics/int4_per_block.yaml: num_bits 4, block_sizes {-1: 128})
-INT4_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
-                                                "*input_quantizer": {"enable": False},
-                                                "*lm_head*": {"enable": False}}, "algorithm": "max"}
+INT4_BLOCKWISE_WEIGHT_ONLY_CFG = _preset({"*weight_quantizer": {"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                                          "*input_quantizer": {"enable": False}}, "max")
 # presets/model/fp8_2d_blockwise_weight_only.yaml: FP8 weights with one scale per 128 x 128 tile
-FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "block_sizes": {-1: 128, -2: 128}},
-                                                  "*input_quantizer": {"enable": False},
-                                                  "*lm_head*": {"enable": False}}, "algorithm": "max"}
-MXFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
-                                   "*input_quantizer": {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}},
-                                   "*lm_head*": {"enable": False}}, "algorithm": None}
+FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG = _preset({"*weight_quantizer": {"num_bits": (4, 3), "block_sizes": {-1: 128, -2: 128}},
+                                            "*input_quantizer": {"enable": False}}, "max")
+_MXFP4_Q = {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}}
+MXFP4_DEFAULT_CFG = _preset({"*weight_quantizer": dict(_MXFP4_Q), "*input_quantizer": dict(_MXFP4_Q)}, None)
 
 
 def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8M0 block scales, weights and inputs
     q = {"num_bits": num_bits, "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}}
-    return {"quant_cfg": {"*weight_quantizer": dict(q), "*input_quantizer": dict(q), "*lm_head*": {"enable": False}},
-            "algorithm": None}
+    return _preset({"*weight_quantizer": dict(q), "*input_quantizer": dict(q)}, None)
 
 
 # presets/model/fp8_per_channel_per_token.yaml: per-output-channel FP8 weights, FP8 inputs with a dynamic abs-max per

@@ -387,7 +387,7 @@ def hist_abs(x: torch.Tensor, bins: int, max_edge: float, skip_zeros: bool = Fal
     return counts
 
 
-INPUT_QUANT_HIST_BINS = (8, 16384)  # bin counts the histogram stage of moq_input_quant takes
+INPUT_QUANT_HIST_BINS = (1, 16384)  # bin counts the histogram stage of moq_input_quant takes
 
 
 @torch.no_grad()
