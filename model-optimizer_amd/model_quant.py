@@ -55,31 +55,25 @@ def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8
 # presets/model/fp8_per_channel_per_token.yaml: per-output-channel FP8 weights, FP8 inputs with a dynamic abs-max per
 # token ({-1: None}: the last dim is reduced; becomes `axis` on the first input).  Calibration and fake quantization;
 # the fp8_pc_pt checkpoint format is not exported on this path
-FP8_PER_CHANNEL_PER_TOKEN_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (4, 3), "axis": 0},
-                                               "*input_quantizer": {"num_bits": (4, 3), "axis": None, "type": "dynamic",
-                                                                    "block_sizes": {-1: None}},
-                                               "*lm_head*": {"enable": False}}, "algorithm": "max"}
+FP8_PER_CHANNEL_PER_TOKEN_CFG = _preset({"*weight_quantizer": {"num_bits": (4, 3), "axis": 0},
+                                         "*input_quantizer": {"num_bits": (4, 3), "axis": None, "type": "dynamic",
+                                                              "block_sizes": {-1: None}}}, "max")
 MXFP8_DEFAULT_CFG = _mx_cfg((4, 3))  # presets/model/mxfp8.yaml
 MXFP6_DEFAULT_CFG = _mx_cfg((3, 2))  # presets/model/mxfp6.yaml
 MXINT8_DEFAULT_CFG = _mx_cfg(8)      # presets/model/mxint8.yaml
 # presets/model/nvfp4.yaml quantizer layout (numerics/nvfp4.yaml): E2M1 elements in blocks of 16 with E4M3 block scales
 # relative to a max-calibrated tensor-wide amax (two-level scaling, tensor_quant_mx.cu:154-183).  The format is NVIDIA's;
 # what runs here is its fake quantization and calibration (no packed export)
-NVFP4_DEFAULT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": (2, 1), "axis": None,
-                                                         "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}},
-                                   "*input_quantizer": {"num_bits": (2, 1), "axis": None,
-                                                        "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}},
-                                   "*lm_head*": {"enable": False}}, "algorithm": "max"}
+_NVFP4_Q = {"num_bits": (2, 1), "axis": None, "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}}
+NVFP4_DEFAULT_CFG = _preset({"*weight_quantizer": dict(_NVFP4_Q), "*input_quantizer": dict(_NVFP4_Q)}, "max")
 # presets/model/w4a8_awq_beta.yaml quantizer layout (INT4 blocks then FP8 on the weights, FP8 inputs); calibrated with
 # "max" here -- the AWQ search with quantized inputs is outside this path
-W4A8_MAX_CFG = {"quant_cfg": {"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
-                                                    {"num_bits": (4, 3), "axis": None}],
-                              "*input_quantizer": {"num_bits": (4, 3), "axis": None},
-                              "*lm_head*": {"enable": False}}, "algorithm": "max"}
-INT8_SMOOTHQUANT_CFG = {"quant_cfg": {"*weight_quantizer": {"num_bits": 8, "axis": 0},
-                                      "*input_quantizer": {"num_bits": 8, "axis": None},
-                                      "*lm_head*": {"enable": False}},
-                        "algorithm": {"method": "smoothquant", "alpha": 1.0}}
+W4A8_MAX_CFG = _preset({"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                                              {"num_bits": (4, 3), "axis": None}],
+                        "*input_quantizer": {"num_bits": (4, 3), "axis": None}}, "max")
+INT8_SMOOTHQUANT_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
+                                "*input_quantizer": {"num_bits": 8, "axis": None}},
+                               {"method": "smoothquant", "alpha": 1.0})
 
 
 # presets/kv/fp8.yaml (units/kv_fp8.yaml): FP8 E4M3 per-tensor key / value quantizers, merged into a model preset
@@ -93,7 +87,11 @@ def update_quant_cfg_with_kv_cache_quant(quant_cfg: dict, kv_cache_quant_cfg: di
     import copy
 
     out = copy.deepcopy(quant_cfg)
-    out["quant_cfg"] = {**out.get("quant_cfg", {}), **copy.deepcopy(kv_cache_quant_cfg)}
+    base = out.get("quant_cfg", {})
+    if isinstance(base, dict) and isinstance(kv_cache_quant_cfg, dict):
+        out["quant_cfg"] = {**base, **copy.deepcopy(kv_cache_quant_cfg)}
+    else:  # list form: entries are simply appended
+        out["quant_cfg"] = normalize_quant_cfg_list(base) + normalize_quant_cfg_list(copy.deepcopy(kv_cache_quant_cfg))
     if out.get("algorithm") is None:
         out["algorithm"] = "max"
     return out
@@ -118,19 +116,89 @@ def _normalize_fused_experts_quantizer_name(name: str) -> str:
     return _FUSED_EXPERTS_QUANTIZER_LIST_RE.sub(lambda m: m.group(1).removesuffix("s"), name)
 
 
-def set_quantizer_by_cfg(model: nn.Module, quant_cfg: dict):
-    """conversion.py:245 set_quantizer_by_cfg: later wildcard entries override earlier ones.  A LIST of attribute
-    dicts turns the quantizer into a SequentialQuantizer with one member per entry (conversion.py:296-321)."""
-    for name, mod in list(model.named_modules()):
-        if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
-            continue
-        if "." in name and isinstance(model.get_submodule(name.rpartition(".")[0]), SequentialQuantizer):
-            continue  # members are configured through their container
-        normalized = _normalize_fused_experts_quantizer_name(name)
-        for pattern, attrs in quant_cfg.items():
-            if not (fnmatch.fnmatch(name, pattern) or (normalized != name and fnmatch.fnmatch(normalized, pattern))):
+def normalize_quant_cfg_list(v) -> list[dict]:
+    """config.py:1447-1569: the canonical quant_cfg is an ORDERED LIST of entries
+    {"quantizer_name": wildcard, "cfg": attributes | [attributes, ...] | None, "enable": bool, "parent_class": str | None};
+    also accepted: the legacy flat dict {wildcard: attributes} (its "default" key means "*"), single-key dict entries
+    inside a list, and the legacy {"nn.<Class>": {wildcard: attributes}} scoping.  `enable` defaults to True when a cfg
+    is given; an entry needs a cfg, an enable flag, or both."""
+    if isinstance(v, dict):
+        v = [{k: val} for k, val in v.items()]
+    elif not isinstance(v, (list, tuple)):
+        raise ValueError(f"quant_cfg must be a sequence of entries (or a legacy flat mapping), got {type(v).__name__}")
+
+    def from_pair(key, value):
+        if key == "default":
+            key = "*"
+        if isinstance(key, str) and key.startswith("nn."):
+            if not isinstance(value, dict):
+                raise ValueError(f"For 'nn.*' scoped format, value must be a mapping, got {value!r}")
+            out = []
+            for q_path, sub in value.items():
+                sub = dict(sub)
+                enable = sub.pop("enable", None)
+                out.append({"parent_class": key, "quantizer_name": q_path, "cfg": sub or None, "enable": enable})
+            return out
+        if isinstance(value, dict):
+            cfg = {k: val for k, val in value.items() if k != "enable"} or None
+            return [{"quantizer_name": key, "cfg": cfg, "enable": value.get("enable")}]
+        return [{"quantizer_name": key, "cfg": value, "enable": None}]
+
+    out = []
+    for raw in v:
+        if isinstance(raw, dict) and "quantizer_name" in raw:
+            entries = [dict(raw)]
+        elif isinstance(raw, dict) and (len(raw) == 1 or any(str(k).startswith("nn.") for k in raw)):
+            entries = [e for k, val in raw.items() for e in from_pair(k, val)]
+        else:
+            raise ValueError(f"Invalid quant_cfg entry: {raw!r}.")
+        for e in entries:
+            cfg, enable = e.get("cfg"), e.get("enable")
+            if cfg is None and enable is None:
+                raise ValueError(f"quant_cfg entry {e!r} must specify 'cfg', 'enable', or both.")
+            if isinstance(cfg, (list, tuple)):
+                cfg = [dict(c) for c in cfg]
+            elif cfg is not None:
+                cfg = dict(cfg)
+            out.append({"quantizer_name": e["quantizer_name"], "cfg": cfg, "enable": True if enable is None else bool(enable),
+                        "parent_class": e.get("parent_class")})
+    return out
+
+
+def _resolve_parent_class(name: str):
+    """The module class a `parent_class` entry names ("nn.Linear", "nn.BatchNorm2d", ...): matched with isinstance
+    against the quantizer's immediate parent module (conversion.py:284-294 looks the name up in its registry of
+    quantized classes, which are subclasses of the originals)."""
+    if name.startswith("nn.") and hasattr(nn, name[3:]):
+        return getattr(nn, name[3:])
+    raise ValueError(f"parent_class {name!r} not found (expected a torch.nn class name like 'nn.Linear')")
+
+
+def set_quantizer_by_cfg(model: nn.Module, quant_cfg):
+    """conversion.py:245-314 set_quantizer_by_cfg: the entries of `quant_cfg` (normalize_quant_cfg_list) are applied in
+    order, later entries override earlier ones for any quantizer they match.  An entry with a cfg REPLACES the matched
+    quantizer's attributes (unspecified ones go back to their defaults) and enables it unless it says otherwise; an
+    entry without one only toggles `enable`.  A LIST of attribute dicts turns the quantizer into a SequentialQuantizer
+    with one member per entry (conversion.py:296-321)."""
+    for entry in normalize_quant_cfg_list(quant_cfg):
+        pattern, cfg, enable = entry["quantizer_name"], entry["cfg"], entry["enable"]
+        parent_class = _resolve_parent_class(entry["parent_class"]) if entry["parent_class"] else None
+        attrs = {"enable": enable} if cfg is None else cfg
+        for name, mod in list(model.named_modules()):
+            if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
                 continue
             parent = model.get_submodule(name.rpartition(".")[0]) if "." in name else model
+            if isinstance(parent, SequentialQuantizer):
+                continue  # members are configured through their container
+            normalized = _normalize_fused_experts_quantizer_name(name)
+            if not (fnmatch.fnmatch(name, pattern) or (normalized != name and fnmatch.fnmatch(normalized, pattern))):
+                continue
+            if parent_class is not None:
+                owner = parent
+                if isinstance(owner, (nn.ModuleList, nn.ModuleDict)) and name.count(".") >= 2:
+                    owner = model.get_submodule(name.rsplit(".", 2)[0])  # per-expert quantizer lists hang off the experts
+                if not isinstance(owner, parent_class):
+                    continue
             attr = name.rpartition(".")[-1]
             cur = getattr(parent, attr)
             if isinstance(attrs, (list, tuple)):
@@ -138,16 +206,16 @@ def set_quantizer_by_cfg(model: nn.Module, quant_cfg: dict):
                     cur = SequentialQuantizer(*[TensorQuantizer() for _ in attrs])
                     setattr(parent, attr, cur)
                 for q, a in zip(cur, attrs):
-                    _apply_attrs(q, a)
+                    _apply_attrs(q, {**a, "enable": enable})
             else:
                 if isinstance(cur, SequentialQuantizer):
-                    if set(attrs) <= {"enable"}:  # enable / disable broadcasts to the members
+                    if cfg is None:  # enable / disable broadcasts to the members
                         for q in cur:
                             _apply_attrs(q, attrs)
                         continue
                     cur = TensorQuantizer()
                     setattr(parent, attr, cur)
-                _apply_attrs(cur, attrs)
+                _apply_attrs(cur, attrs if cfg is None else {**attrs, "enable": enable})
 
 
 def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:

@@ -410,3 +410,81 @@ def test_export_refuses_formats_it_does_not_pack():
         mnn.replace_quant_module(m3)
         model_quant.set_quantizer_by_cfg(m3, cfg["quant_cfg"])
         assert export.get_quantization_format(m3[0]) == want, want
+
+
+def test_quant_cfg_list_form_default_key_and_parent_class():
+    """set_quantizer_by_cfg takes the reference's canonical ordered-list quant_cfg (config.py:1447-1569,
+    conversion.py:245-314): entries with cfg replace the attributes and enable, enable-only entries toggle, the legacy
+    "default" key means "*", parent_class restricts an entry to quantizers of that module class."""
+    moa = _moa_import.load()
+    mq = moa.model_quant
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(16, 16)
+            self.norm = torch.nn.LayerNorm(16)
+            self.lm_head = torch.nn.Linear(16, 8)
+
+    def build(cfg):
+        net = Net()
+        moa.nn.replace_quant_module(net)
+        mq.set_quantizer_by_cfg(net, cfg)
+        return net
+
+    listed = build([{"quantizer_name": "*", "enable": False},
+                    {"quantizer_name": "*weight_quantizer", "cfg": {"num_bits": 4, "block_sizes": {-1: 8, "type": "static"}}},
+                    {"quantizer_name": "*input_quantizer", "cfg": {"num_bits": (4, 3), "axis": None}},
+                    {"parent_class": "nn.LayerNorm", "quantizer_name": "*", "enable": False},
+                    {"quantizer_name": "*lm_head*", "enable": False}])
+    assert listed.fc.weight_quantizer.is_enabled and listed.fc.weight_quantizer.num_bits == 4
+    assert listed.fc.input_quantizer.is_enabled and tuple(listed.fc.input_quantizer.num_bits) == (4, 3)
+    assert not listed.fc.output_quantizer.is_enabled
+    assert not listed.norm.input_quantizer.is_enabled                      # parent_class entry
+    assert tuple(listed.norm.input_quantizer.num_bits) == (4, 3)           # ... which only toggled `enable`
+    assert not listed.lm_head.weight_quantizer.is_enabled and not listed.lm_head.input_quantizer.is_enabled
+    legacy = build({"default": {"enable": False}, "*weight_quantizer": {"num_bits": 8, "axis": 0},
+                    "nn.LayerNorm": {"*input_quantizer": {"num_bits": 8, "axis": None}}})
+    assert legacy.fc.weight_quantizer.is_enabled and not legacy.fc.input_quantizer.is_enabled  # "default" == "*"
+    assert legacy.norm.input_quantizer.is_enabled and not legacy.lm_head.input_quantizer.is_enabled
+    with pytest.raises(ValueError):
+        mq.normalize_quant_cfg_list([{"quantizer_name": "*"}])              # neither cfg nor enable
+    with pytest.raises(ValueError):
+        build([{"parent_class": "nn.NoSuchLayer", "quantizer_name": "*", "enable": False}])
+    # every preset ends with the reference's default-disabled patterns (units/default_disabled_quantizers.yaml)
+    for preset in (mq.FP8_DEFAULT_CFG, mq.INT4_AWQ_CFG, mq.INT8_SMOOTHQUANT_CFG, mq.MXFP4_DEFAULT_CFG, mq.W4A8_MAX_CFG):
+        tail = list(preset["quant_cfg"].items())[-len(mq.DEFAULT_DISABLED_QUANTIZERS):]
+        assert [k for k, _ in tail] == list(mq.DEFAULT_DISABLED_QUANTIZERS) and all(v == {"enable": False} for _, v in tail)
+
+
+def test_presets_keep_moe_gates_and_routers_in_high_precision():
+    """A Qwen2-MoE style block: `mlp.gate` (the router), `mlp.shared_expert_gate` and `lm_head` are nn.Linear modules the
+    reference's presets leave unquantized (default_disabled_quantizers.yaml)."""
+    moa = _moa_import.load()
+
+    class MLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.gate = torch.nn.Linear(16, 4, bias=False)
+            self.shared_expert_gate = torch.nn.Linear(16, 1, bias=False)
+            self.up_proj = torch.nn.Linear(16, 32, bias=False)
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.mlp = MLP()
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([Layer()])
+            self.router = torch.nn.Linear(16, 4)
+            self.lm_head = torch.nn.Linear(16, 8)
+
+    net = Net()
+    moa.nn.replace_quant_module(net)
+    moa.model_quant.set_quantizer_by_cfg(net, moa.model_quant.FP8_DEFAULT_CFG["quant_cfg"])
+    mlp = net.layers[0].mlp
+    assert mlp.up_proj.weight_quantizer.is_enabled and mlp.up_proj.input_quantizer.is_enabled
+    for lin in (mlp.gate, mlp.shared_expert_gate, net.router, net.lm_head):
+        assert not lin.weight_quantizer.is_enabled and not lin.input_quantizer.is_enabled
