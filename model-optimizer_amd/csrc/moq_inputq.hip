@@ -91,17 +91,23 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   const int64_t n_chunks = (p.n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   constexpr int Q = kIqBlock / kBlock;
   const int quarter = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kBlock));
-  for (int64_t c = (int64_t)blockIdx.x * Q + quarter; c < n_chunks; c += (int64_t)gridDim.x * Q) {
+  // Two chunks in flight per quarter: the loads of the next chunk are issued before the current one is worked on, so
+  // a wave's HBM latency hides under its own LDS / VALU phase (with the 64 KiB table there is one workgroup per CU).
+  const int64_t stride = (int64_t)gridDim.x * Q;
+  auto load_chunk = [&](int64_t c, Pack16 (&in)[P]) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     const bool fast = al && e0 + MOQ_MT_CHUNK <= p.n;
-    int64_t col0 = 0;
-    if constexpr (PQS) col0 = e0 % p.cols;  // wave-uniform; cols % V == 0 (host-checked): a packet stays in one row
-    Pack16 in[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + (u * kBlock + tid) * V;
       in[u] = fast ? ld_packet<DT, true>(p.x, e, p.n) : ld_packet<DT, false>(p.x, e, p.n);
     }
+  };
+  auto work_chunk = [&](int64_t c, const Pack16 (&in)[P]) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    const bool fast = al && e0 + MOQ_MT_CHUNK <= p.n;
+    int64_t col0 = 0;
+    if constexpr (PQS) col0 = e0 % p.cols;  // wave-uniform; cols % V == 0 (host-checked): a packet stays in one row
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + (u * kBlock + tid) * V;
@@ -162,6 +168,21 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
           else st_packet<DT, false>(p.y, e, p.n, pack<DT>(f));
         }
       }
+    }
+  };
+  {
+    Pack16 buf_a[P], buf_b[P];
+    int64_t c = (int64_t)blockIdx.x * Q + quarter;
+    if (c < n_chunks) load_chunk(c, buf_a);
+    while (c < n_chunks) {
+      const int64_t c1 = c + stride;
+      if (c1 < n_chunks) load_chunk(c1, buf_b);
+      work_chunk(c, buf_a);
+      if (c1 >= n_chunks) break;
+      const int64_t c2 = c1 + stride;
+      if (c2 < n_chunks) load_chunk(c2, buf_a);
+      work_chunk(c1, buf_b);
+      c = c2;
     }
   }
   if constexpr (AMAX) {

@@ -60,3 +60,36 @@ def stage_report(q, g, replay):
                 break
         out[name] = first
     return out
+
+
+def pin_host_pow(monkeypatch, replay):
+    """get_scale's pow / divide run in torch's HOST math library (model_calib.get_scale), whose last bit depends on the
+    CPU's vector ISA (Sleef AVX2 vs AVX-512 vs the scalar tail): third-party arithmetic outside the path, like the
+    model's GEMMs.  The fixture was generated on the build container's CPU; on another host a scale vector may come out
+    one fp32 ulp away.  For the byte comparison the replay pins it: a freshly computed scale vector that agrees with one
+    of the reference run's best_scale vectors to within ONE ulp everywhere is replaced by that vector (anything further
+    off is left alone and fails the stage report).  Returns the list of (linear, differing entries) it pinned."""
+    from model_optimizer_amd import model_calib
+
+    refs = {name: from_bits(replay.raw(f"ref/{name}.best_scale"), torch.float32).reshape(-1)
+            for name in replay.cases["linears"]}
+    pinned = []
+    orig = model_calib.get_scale
+
+    def get_scale(x_max, w_max, alpha):
+        out = orig(x_max, w_max, alpha)
+        o = out.detach().float().cpu()
+        for name, ref in refs.items():
+            if ref.numel() != o.numel():
+                continue
+            ulp = torch.maximum(ref.abs(), o.abs()) * 2.0 ** -23
+            if bool(((ref - o).abs() <= ulp).all()):
+                n = int((ref != o).sum())
+                if n:
+                    pinned.append((name, n))
+                    return ref.to(out.device)
+                break
+        return out
+
+    monkeypatch.setattr(model_calib, "get_scale", get_scale)
+    return pinned
