@@ -35,6 +35,15 @@ namespace moq {
 
 constexpr int kIqBlock = 1024;
 constexpr int kLutEntries = 32768;  // |x| patterns of a 16-bit float
+// Same-address LDS atomics serialise (the probe: 1.6 lanes per clock on 4 addresses, 6.5 on 4 bins x 8 copies, 14.6
+// when every lane has its own dword), and activations whose range is set by a few outliers put most elements into
+// the very lowest bins.  The kHotBins lowest bins therefore get one copy PER LANE (conflict-free whatever the data);
+// the other bins share R = 2^rshift interleaved copies.  Slot layout: [hot bins: bin * 64 + lane][bins: bin * R + copy].
+constexpr int kHotBins = 32;
+constexpr int kHotSlots = kHotBins * 64;
+__device__ __forceinline__ uint32_t slot_base(int bin, int rshift) {
+  return bin < kHotBins ? (uint32_t)bin * 64u : (uint32_t)kHotSlots + ((uint32_t)bin << rshift);
+}
 
 struct IqParams {
   const void* x;
@@ -62,18 +71,18 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   const int copy = (int)(threadIdx.x & ((1u << p.rshift) - 1u));
   const SharedDiv sd = make_shared_div(p.max_edge);
   constexpr bool LUT = HIST && DT != MOQ_F32;
-  const int slots = (p.bins + 1) << p.rshift;
+  const int slots = kHotSlots + ((p.bins + 1) << p.rshift);
   // LDS: [histogram: slots x u32][table: 32768 x u16 (16-bit inputs)]
   uint16_t* lut = reinterpret_cast<uint16_t*>(lds_hist + slots);
   if constexpr (HIST) {
     for (int b = threadIdx.x; b < slots; b += kIqBlock) lds_hist[b] = 0;
     if constexpr (LUT) {
-      // lut[|x| pattern] = first slot of the pattern's bin ((bin << rshift); invalid -> the trash bin `bins`)
+      // lut[|x| pattern] = first slot of the pattern's bin (slot_base; invalid -> the trash bin `bins`)
       for (int v = threadIdx.x; v < kLutEntries; v += kIqBlock) {
         float a;
         if constexpr (DT == MOQ_BF16) a = __uint_as_float((uint32_t)v << 16);
         else { uint16_t h = (uint16_t)v; a = (float)*reinterpret_cast<_Float16*>(&h); }
-        lut[v] = (uint16_t)(hist_bin<SHARED>(a, p.bins, p.max_edge, sd, p.skip_zeros) << p.rshift);
+        lut[v] = (uint16_t)slot_base(hist_bin<SHARED>(a, p.bins, p.max_edge, sd, p.skip_zeros), p.rshift);
       }
     }
     __syncthreads();
@@ -147,16 +156,16 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
           }
           if (!fast) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) slot[i] = e + i < p.n ? slot[i] : (uint32_t)(p.bins << p.rshift);
+            for (int i = 0; i < 8; ++i) slot[i] = e + i < p.n ? slot[i] : slot_base(p.bins, p.rshift);
           }
 #pragma unroll
-          for (int i = 0; i < 8; ++i) atomicAdd(&lds_hist[slot[i] + copy], 1u);
+          for (int i = 0; i < 8; ++i) atomicAdd(&lds_hist[slot[i] + (slot[i] < (uint32_t)kHotSlots ? lane : copy)], 1u);
         } else {
 #pragma unroll
           for (int i = 0; i < V; ++i) {
             int b = hist_bin<SHARED>(__builtin_fabsf(f[i]), p.bins, p.max_edge, sd, p.skip_zeros);
             if (!fast) b = e + i < p.n ? b : p.bins;
-            atomicAdd(&lds_hist[(b << p.rshift) + copy], 1u);
+            atomicAdd(&lds_hist[slot_base(b, p.rshift) + (b < kHotBins ? lane : copy)], 1u);
           }
         }
       }
@@ -200,7 +209,9 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   if constexpr (HIST) {
     for (int b = threadIdx.x; b < p.bins; b += kIqBlock) {
       uint32_t cnt = 0;
-      for (int r = 0; r < (1 << p.rshift); ++r) cnt += lds_hist[(b << p.rshift) + r];
+      const int copies = b < kHotBins ? 64 : (1 << p.rshift);
+      const uint32_t base = slot_base(b, p.rshift);
+      for (int r = 0; r < copies; ++r) cnt += lds_hist[base + r];
       if (cnt) atomicAdd(&p.counts[b], (unsigned long long)cnt);
     }
   }
@@ -277,9 +288,9 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
     // interleaved copies of the histogram (hot bins spread over banks) as far as LDS allows; the table of a 16-bit
     // input takes 64 KiB, which leaves room for one workgroup per CU
     const size_t table = dt == MOQ_F32 ? 0 : (size_t)kLutEntries * 2;
-    const size_t room = (table ? kIqLdsBudget : (size_t)64 * 1024 + 32) - table;
+    const size_t room = (table ? kIqLdsBudget : (size_t)72 * 1024 + 32) - table - (size_t)kHotSlots * 4;
     while (p.rshift < 3 && ((size_t)(hist_bins + 1) << (p.rshift + 1)) * 4 <= room) ++p.rshift;
-    lds = ((size_t)(hist_bins + 1) << p.rshift) * 4 + table;
+    lds = ((size_t)kHotSlots + ((size_t)(hist_bins + 1) << p.rshift)) * 4 + table;
     if (lds > kIqLdsBudget) {
       set_error("moq_input_quant: %d bins do not fit the LDS histogram", hist_bins);
       return MOQ_ERR_UNSUPPORTED;

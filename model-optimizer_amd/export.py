@@ -368,7 +368,11 @@ def export_quantized_weight(module, dtype: torch.dtype):
         block = wq.block_sizes.get(-1) or wq.block_sizes.get(module.weight.dim() - 1)
         w = module.weight.detach().to(dtype)
         packed, e8m0 = ops.mxfp4_quantize(w, block)
-        return {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
+        out = {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
+        pqs = getattr(iq, "_pre_quant_scale", None)
+        if pqs is not None:  # SmoothQuant scaling composed with MXFP4: promoted like every other format's (:1121-1138)
+            out["pre_quant_scale"] = pqs.detach().clone()
+        return out
     if fmt == QUANTIZATION_MXFP8:
         # unified_export_hf.py:671-679, export/quant_utils.py:871-872: E8M0 scale bytes [Cout, Cin / 32] from the block
         # abs-max, E4M3 elements from the tile pack kernel

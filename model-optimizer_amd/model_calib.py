@@ -255,9 +255,20 @@ def apply_pre_quant_scale_and_smooth(linear: QuantLinear, pre_quant_scale: torch
 
 
 @torch.no_grad()
-def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
-    """model_calib.py:1273-1359."""
+def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str = "int8"):
+    """model_calib.py:1273-1359.
+
+    formats = "int8" (default): the reference's behaviour -- only linears whose input AND weight quantizers are INT8
+              are smoothed, every other one is skipped with a warning (:1344-1346).
+    formats = "all": the per-channel scale math (:1309-1335) and the fold (:1226-1270) do not depend on the number
+              format, so any linear with an enabled input quantizer is smoothed -- BASELINE configs[4]: SmoothQuant
+              scaling composed with MXFP4 (g = 32, E8M0 block scales).  Per-tensor formats get the reference's
+              post-smoothing input amax max(act_amax * s); dynamic-block (MX) quantizers, which recompute their block
+              scales from every input, keep no amax at all.  The scales and folded weights are bit-identical to the
+              reference's INT8 run on the same model (tests/test_host_flows_cpu.py: sq_mxfp4 fixture)."""
     assert forward_loop is not None, "forward_loop must be provided for smoothquant"
+    if formats not in ("int8", "all"):
+        raise ValueError(f"smoothquant: formats must be 'int8' or 'all', got {formats!r}")
     for m in model.modules():
         if is_quantized_linear(m) and m.input_quantizer.is_enabled and m.input_quantizer.axis is None:
             m.input_quantizer.axis = -1
@@ -270,7 +281,7 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
         if not hasattr(iq, "_amax"):
             warnings.warn(f"{name} is not calibrated, skip smoothing")
             continue
-        if iq.num_bits != 8 or wq.num_bits != 8:
+        if formats == "int8" and (iq.num_bits != 8 or wq.num_bits != 8):
             warnings.warn(f"Only int8 smoothing is supported, skip {name}")
             continue
         if iq.axis != -1:
@@ -281,10 +292,11 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0):
         # model weight_scale^(1 - alpha) is rounded to 16 bits before the fp32 division
         weight_scale = ops.reduce_amax(m.weight, axis=(0,)).reshape(-1)
         scale_a = weight_scale.pow(1 - alpha) / act_amax.pow(alpha)
-        iq._amax_for_smoothing = act_amax.cpu()
         iq.reset_amax()
         iq.axis = None
-        iq.amax = act_amax.amax().to(dtype=m.weight.dtype, device=m.weight.device)
+        if not iq._block_dynamic:
+            iq._amax_for_smoothing = act_amax.cpu()
+            iq.amax = act_amax.amax().to(dtype=m.weight.dtype, device=m.weight.device)
         epsilon = 1.0 / (1 << 31)
         if scale_a.min() <= epsilon:
             scale_a[act_amax <= epsilon] = 1

@@ -76,6 +76,13 @@ INT8_SMOOTHQUANT_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
                                {"method": "smoothquant", "alpha": 1.0})
 
 
+# BASELINE configs[4]: MXFP4 (g = 32, E8M0 block scales) weights and inputs with SmoothQuant's per-channel scaling folded
+# in first (model_calib.smoothquant(formats="all")).  The reference has no such preset -- its smoothquant skips every
+# non-INT8 linear -- the composition is the one SURVEY 9.1 spells out: its INT8 scale math + its MX quantization
+MXFP4_SMOOTHQUANT_CFG = _preset({"*weight_quantizer": dict(_MXFP4_Q), "*input_quantizer": dict(_MXFP4_Q)},
+                                {"method": "smoothquant", "alpha": 0.5, "formats": "all"})
+
+
 # presets/kv/fp8.yaml (units/kv_fp8.yaml): FP8 E4M3 per-tensor key / value quantizers, merged into a model preset
 FP8_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "axis": None, "enable": True}},
               "algorithm": "max"}

@@ -17,6 +17,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   model_flows.npz -- mtq.quantize() end to end on a tiny MLP: max (INT8, FP8), smoothquant, awq_lite
   export_llama.npz -- INT4-AWQ export_hf_checkpoint of a tiny Llama: pre-export state and exported tensors
   export_llama_replay.npz -- the same run: every linear's input per calibration batch + the search's statistics
+  sq_mxfp4.npz  -- configs[4]: MXFP4QTensor.quantize of the INT8-SmoothQuant run's smoothed weights (packed bytes, E8M0)
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
   block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
@@ -1068,6 +1069,27 @@ def gen_export_int8_sq(out):
                                              hf_quant_config=quant_cfg)))
 
 
+def gen_sq_mxfp4(out):
+    """BASELINE configs[4] -- SmoothQuant scaling composed with MXFP4: the reference's smoothquant only acts
+    on INT8 quantizers and its MX fake quantization needs the CUDA extension, so the composition is pinned from its two
+    runnable halves.  (1) The scale math + fold: format independent, taken from the reference's INT8 SmoothQuant run of the
+    tiny Llama (export_llama_int8_sq.npz: pre_quant_scale and smoothed weight of every linear -- what a composed flow
+    must reproduce bit for bit from the ORIGINAL weights and tokens).  (2) The MXFP4 real quantization of THOSE smoothed
+    weights by the reference's MXFP4QTensor.quantize (qtensor/mxfp4_tensor.py:37-81, CPU branch): packed E2M1 nibbles and
+    E8M0 scale bytes, as export_hf_checkpoint stores them for an MXFP4 model.  alpha = 1.0 (the INT8 preset's)."""
+    from modelopt.torch.quantization.qtensor import MXFP4QTensor
+
+    have = np.load(os.path.join(HERE, "export_llama_int8_sq.npz"))
+    cases = json.loads(str(have["cases"]))
+    for n in cases["linears"]:
+        raw = have[f"pre/{n}.weight"]
+        w = torch.from_numpy(raw.view(np.int16).copy()).view(torch.bfloat16)
+        qt, e8m0 = MXFP4QTensor.quantize(w, 32)
+        out[f"mx/{n}.weight"] = qt._quantized_data.view(torch.uint8).numpy().copy()
+        out[f"mx/{n}.weight_scale"] = e8m0.view(torch.uint8).numpy().copy()
+    out["cases"] = np.array(json.dumps(dict(linears=cases["linears"], alpha=1.0, block=32)))
+
+
 def gen_mxfp8(out):
     """MXFP8QTensor (qtensor/mxfp8_tensor.py:26-268) on CPU: E8M0 scale bytes, E4M3 bytes and the dequantised tensor
     for 2-D / 3-D weights, a ragged last dim, all-zero blocks, block maxima ON the 448 * 2^k boundary and tiny /
@@ -1104,11 +1126,11 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

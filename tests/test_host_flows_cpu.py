@@ -383,3 +383,46 @@ def test_tensor_quantizer_fused_input_pass_equals_unfused_chain(hostmem):
         want = moa.ops.scaled_e4m3(v, q.amax) if nb == (4, 3) else moa.ops.fake_tensor_quant(v, q.amax, 8, False, False)
         assert_bits_equal(y_both, want, f"num_bits={nb}")
         assert_bits_equal(q(x1), want, f"quant only, num_bits={nb}")
+
+
+def test_smoothquant_composed_with_mxfp4_equals_reference_halves(golden, hostmem):
+    """BASELINE configs[4]: MXFP4_SMOOTHQUANT_CFG from the ORIGINAL weights and tokens.  The per-channel scales and the
+    folded weights equal the reference's INT8 SmoothQuant run bit for bit (the scale math does not depend on the format);
+    the exported packed E2M1 nibbles / E8M0 scales equal the reference's MXFP4QTensor.quantize of those weights; the MX
+    quantizers keep no amax; the fake-quantized forward equals the oracle's MX QDQ of (x * s) and the folded weight."""
+    from oracle import oracle
+
+    g, mx = golden("export_llama_int8_sq"), golden("sq_mxfp4")
+    cases = g.cases
+    model = _llama(g, cases, torch.bfloat16)
+    batches = [torch.from_numpy(g.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    cfg = copy.deepcopy(moa.model_quant.MXFP4_SMOOTHQUANT_CFG)
+    cfg["algorithm"]["alpha"] = mx.cases["alpha"]
+    with torch.no_grad():
+        moa.quantize(model, cfg, lambda m: [m(b) for b in batches])
+    for name in cases["linears"]:
+        lin = model.get_submodule(name)
+        assert torch.equal(lin.input_quantizer._pre_quant_scale, from_bits(g.raw(f"pre/{name}.pre_quant_scale"), torch.bfloat16)), name
+        assert torch.equal(lin.weight, from_bits(g.raw(f"pre/{name}.weight"), torch.bfloat16)), name
+        assert lin.input_quantizer.amax is None and lin.input_quantizer.axis is None and lin.input_quantizer.is_mx_format
+    state = moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    for name in cases["linears"]:
+        for key in ("weight", "weight_scale"):
+            got = state[f"{name}.{key}"].contiguous().view(torch.uint8).numpy()
+            want = mx.raw(f"mx/{name}.{key}")
+            assert np.array_equal(got.reshape(want.shape), want), f"{name}.{key}"
+        assert torch.equal(state[f"{name}.pre_quant_scale"], from_bits(g.raw(f"pre/{name}.pre_quant_scale"), torch.bfloat16))
+    assert moa.export.hf_quant_config(model)["quantization"]["quant_algo"] == "mxfp4"
+    # one linear's fake-quantized forward: MX QDQ of the scaled input times MX QDQ of the folded weight
+    lin = model.get_submodule(cases["linears"][0])
+    x = (torch.randn(8, lin.weight.shape[1], generator=torch.Generator().manual_seed(0)) * 2).to(torch.bfloat16)
+    xq = oracle.mx_fused_amax_convert(x * lin.input_quantizer._pre_quant_scale, 32, "E2M1")
+    wq = oracle.mx_fused_amax_convert(lin.weight.detach(), 32, "E2M1")
+    assert_bits_equal(lin(x), torch.nn.functional.linear(xq, wq), "MXFP4 forward of a smoothed linear")
+    # the reference's own behaviour stays the default: formats="int8" skips MX linears
+    model2 = _llama(g, cases, torch.bfloat16)
+    cfg2 = copy.deepcopy(moa.model_quant.MXFP4_SMOOTHQUANT_CFG)
+    cfg2["algorithm"] = {"method": "smoothquant", "alpha": 1.0}
+    with torch.no_grad(), pytest.warns(UserWarning, match="Only int8 smoothing"):
+        moa.quantize(model2, cfg2, lambda m: [m(b) for b in batches[:1]])
+    assert model2.get_submodule(cases["linears"][0]).input_quantizer.pre_quant_scale is None
