@@ -9,6 +9,9 @@ One step = one pass of the hot path over ALL linear weights of a synthetic Llama
     int4g128 (BASELINE configs[2] weight side / north-star kernel): fused per-group(128) abs-max + INT4 QDQ,
              one launch, 4 + 4/128 B/element.
     mxfp4, mask24, int8 : the other formats of the path, for the record.
+    mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
+             apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
+             the whole model in one launch; 4 + 4 B/element.  Use with --model llama3-70b --inplace.
 `value` = weight bytes of the WHOLE model (2 B/element) / wall time per step.  Multi-GPU is STRONG scaling: the 224
 per-layer weight tensors are dealt round-robin over the ranks (distributed.shard_list: independent units, no
 data-path collective); the only exchange is one bucketed all-reduce(MAX) that leaves every rank with all 224 amax
@@ -108,6 +111,7 @@ def cpu_baseline(workload, budget_s=12.0):
     oracle.set_threads(threads)
     w = (torch.randn(4096, 4096, generator=torch.Generator().manual_seed(1234)) * 0.02).to(torch.bfloat16)
     n_bytes = w.numel() * 2
+    sq_scale = torch.exp(0.5 * torch.randn(4096, generator=torch.Generator().manual_seed(99)))
 
     def one():
         if workload == "fp8":
@@ -120,6 +124,8 @@ def cpu_baseline(workload, budget_s=12.0):
             oracle.fake_quant_int(w, a.reshape(1), 8, False, True)
         elif workload == "mxfp4":
             oracle.mx_fused_amax_convert(w, 32, "E2M1")
+        elif workload == "mxfp4-sq":
+            oracle.mx_fused_amax_convert(oracle.scale_cols(w, sq_scale), 32, "E2M1")
         else:
             oracle.mask_2to4(w)
 
@@ -151,7 +157,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mask24"])
+    ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mxfp4-sq", "mask24"])
     ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
     ap.add_argument("--layers", type=int, default=0, help="0 = all layers of the model")
     ap.add_argument("--group-mb", type=int, default=0,
@@ -215,6 +221,16 @@ def main():
             cur_b += b
         groups.append(cur)
         groups = [SegmentTable([weights[i] for i in g], outputs=[tab.outputs[i] for i in g]) for g in groups]
+    fold_scales = None
+    if wl == "mxfp4-sq":
+        # per-channel SmoothQuant scales of each tensor (synthetic, log-normal); steps alternate s and 1/s so that the
+        # in-place fold keeps the weights' magnitude over many steps
+        gs = torch.Generator(device=dev).manual_seed(99)
+        fold_scales = []
+        for w in weights:
+            sv = torch.exp(0.5 * torch.randn(w.shape[1], generator=gs, device=dev, dtype=torch.float32))
+            fold_scales.append((sv, 1.0 / sv))
+    step_no = [0]
     masks = None
     if wl == "mask24":
         masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in weights]
@@ -257,6 +273,18 @@ def main():
                 e0, e1 = ev(), ev()
                 e0.record()
             tab.amax_qdq_int_group(4, False, False)
+            if record:
+                e1.record()
+                dom_events.append((e0, e1))
+        elif wl == "mxfp4-sq":
+            k = step_no[0] & 1
+            step_no[0] += 1
+            for w, sv in zip(weights, fold_scales):
+                moa.ops.scale_cols(w, sv[k], out=w)  # the fold: fp32 multiply, one rounding, in place
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+            tab.mx_fused_amax_convert(32, "E2M1")
             if record:
                 e1.record()
                 dom_events.append((e0, e1))
@@ -313,9 +341,10 @@ def main():
     # dominant kernel: average launch duration from the HIP events recorded inside the timed region
     dom_all = [a.elapsed_time(b) for a, b in dom_events]
     dom_ms = sum(dom_all) / len(dom_all)
-    alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mask24": 3.0}[wl]
+    alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mxfp4-sq": 4.0, "mask24": 3.0}[wl]
     dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
                 "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
+                "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>",
                 "mask24": "mt_mask24_kernel<bf16>"}[wl]
     achieved = n_local * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9  # this rank's launch over this rank's tensors
     traffic, traffic_src = pmc_traffic(wl, args.model, n_layers) if world == 1 else (None, None)
