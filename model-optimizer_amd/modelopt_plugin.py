@@ -17,11 +17,21 @@ Nothing here imports modelopt at module import time; `install()` raises ImportEr
 
 from __future__ import annotations
 
+import collections
 import types
 
 import torch
 
 from . import _lib, ops, sparsity
+
+# Calls served per seam entry point, and every call a seam handed BACK to the reference ("<seam>:fallback[:reason]"):
+# coverage holes under the real reference are visible instead of silent (tests assert that no unexpected fallback
+# happened; `STATS.clear()` resets).
+STATS: collections.Counter = collections.Counter()
+
+
+def _count(key: str):
+    STATS[key] += 1
 
 
 class IntExtension:
@@ -29,23 +39,28 @@ class IntExtension:
 
     @staticmethod
     def fake_tensor_quant(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        _count("S1:fake_tensor_quant")
         return ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range)
 
     @staticmethod
     def fake_tensor_quant_(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        _count("S1:fake_tensor_quant_")
         ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range, inplace=True)
 
     @staticmethod
     def fake_tensor_quant_with_axis(inputs, amax, axis, num_bits=8, unsigned=False, narrow_range=True):
+        _count("S1:fake_tensor_quant_with_axis")
         return ops.fake_tensor_quant_with_axis(inputs, amax, axis, num_bits, unsigned, narrow_range)
 
     @staticmethod
     def INT4_quantize(input, scales, block_size):  # noqa: N802
         # the CUDA kernel's rounding (clamp, then roundf(v + 8)) -- tensor_quant_gpu.cu:322-333
+        _count("S1:INT4_quantize")
         return ops.int4_quantize(input.reshape(-1), scales.reshape(-1), block_size, _lib.ROUND_HALF_AWAY)
 
     @staticmethod
     def INT4_dequantize(quantized_data, scales, block_size):  # noqa: N802
+        _count("S1:INT4_dequantize")
         return ops.int4_dequantize(quantized_data, scales.reshape(-1), block_size)
 
     @staticmethod
@@ -60,10 +75,12 @@ class Fp8Extension:
 
     @staticmethod
     def fake_e4m3fy(inputs, amax):
+        _count("S1:fake_e4m3fy")
         return ops.scaled_e4m3(inputs, amax.reshape(-1)[:1])
 
     @staticmethod
     def fake_e4m3fy_with_axis(inputs, amax, axis):
+        _count("S1:fake_e4m3fy_with_axis")
         return ops.fake_e4m3fy_with_axis(inputs, amax, axis)
 
 
@@ -74,16 +91,19 @@ class MxExtension:
 
     @staticmethod
     def fused_amax_convert(inputs, block_size, format, scale_format, global_amax=None):
+        _count("S1:fused_amax_convert")
         return ops.fused_amax_convert(inputs, block_size, int(format), int(scale_format), global_amax)
 
     @staticmethod
     def convert_to_exmy(x, format):
+        _count("S1:convert_to_exmy")
         return ops.convert_to_exmy(x, int(format))
 
 
 def mi355x_backend(inputs: torch.Tensor, tq) -> torch.Tensor:
     """S3 entrypoint(inputs, tensor_quantizer): fused dynamic-amax QDQ for static-block INT quantizers,
     plain kernels otherwise.  `tq` is a *modelopt* TensorQuantizer (duck-typed)."""
+    _count("S3:mi355x_backend")
     nb = tq._num_bits
     amax = getattr(tq, "_amax", None)
     if isinstance(nb, int) and tq.block_sizes and amax is None and inputs.dim() == 2:
@@ -99,13 +119,23 @@ def mi355x_backend(inputs: torch.Tensor, tq) -> torch.Tensor:
     return ops.fake_tensor_quant(inputs, amax, nb, tq._unsigned, tq._narrow_range)
 
 
+def _takes(t: torch.Tensor) -> bool:
+    """The seams serve GPU tensors and leave everything else to the reference's own code."""
+    return t.is_cuda
+
+
 def _reduce_amax_seam(original):
     def reduce_amax(input, axis=None, keepdims=True, squeeze_scalar=True):
-        if not input.is_cuda:
+        if not _takes(input):
             return original(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
         try:
-            return ops.reduce_amax(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
-        except _lib.MoquantUnsupported:
+            out = ops.reduce_amax(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
+            _count("S6:reduce_amax")
+            return out
+        except _lib.MoquantUnsupported as e:
+            # the reference's convention for its own extensions (tensor_quant.py:386-389): an unsupported layout
+            # falls back to eager -- counted, so that coverage holes show up
+            _count(f"S6:reduce_amax:fallback:{type(e).__name__}")
             return original(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
 
     return reduce_amax
@@ -113,8 +143,9 @@ def _reduce_amax_seam(original):
 
 def _asp_mask_seam(original):
     def create_asp_mask(tensor, pattern):
-        if not tensor.is_cuda:
+        if not _takes(tensor):
             return original(tensor, pattern)
+        _count("S5:create_asp_mask")
         return sparsity.create_asp_mask(tensor, pattern)
 
     return create_asp_mask
@@ -122,8 +153,9 @@ def _asp_mask_seam(original):
 
 def _sgpt_mask_seam(original):
     def create_sgpt_mask(tensor, hessian, config):
-        if not tensor.is_cuda:
+        if not _takes(tensor):
             return original(tensor, hessian, config)
+        _count("S5:create_sgpt_mask")
         return sparsity.create_sgpt_mask(tensor, hessian, dict(config))
 
     return create_sgpt_mask
@@ -135,9 +167,10 @@ def _sgpt_hessian_seam(original):
 
     def hook(cls, mod, inp, out):
         x = inp[0] if isinstance(inp, tuple) else inp
-        if not ("Linear" in type(mod).__name__ and x.is_cuda and mod.hessian.is_cuda
+        if not ("Linear" in type(mod).__name__ and _takes(x) and _takes(mod.hessian)
                 and x.dtype in (torch.bfloat16, torch.float16) and x.shape[-1] % 4 == 0):
             return original.__func__(cls, mod, inp, out)
+        _count("S5:sgpt_hessian")
         b = 1 if x.dim() == 2 else x.shape[0]
         decay = mod.samples / (mod.samples + b)
         mod.samples += b
@@ -148,7 +181,10 @@ def _sgpt_hessian_seam(original):
 
 def _library_op_seam(original, ours):
     def op(inputs, *args, **kwargs):
-        return ours(inputs, *args, **kwargs) if inputs.is_cuda else original(inputs, *args, **kwargs)
+        if not _takes(inputs):
+            return original(inputs, *args, **kwargs)
+        _count("S2:" + getattr(ours, "__name__", "library_op"))
+        return ours(inputs, *args, **kwargs)
 
     op._moq_seam = True
     return op

@@ -363,3 +363,88 @@ def test_fp8_per_channel_per_token_calibration_and_forward_equal_the_reference_l
     moa.quantize(model, moa.model_quant.FP8_PER_CHANNEL_PER_TOKEN_CFG, lambda m: m(_batches()[0]))
     with pytest.raises(NotImplementedError, match="fp8_pc_pt"):
         real_export(model, dtype)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The drop-in boundary under the REAL reference with real tensors: modelopt_plugin.install() + the
+# reference's own mtq.quantize().  The reference only hands GPU tensors to its extension modules (`inputs.is_cuda`
+# gates in tensor_quant.py:80, :374 and its device guard), and this tier has no GPU: for the duration of the test every
+# tensor answers is_cuda = True, the reference's CUDA device guard is a no-op, and the C-ABI is served by the host-memory
+# stand-in -- so the reference's UNMODIFIED call sites (tensor_quant.py:83-91, :103-111, :184-191, calib/max.py:63-64)
+# drive our adapters with real data.  Everything must equal the un-installed reference run.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("preset,expected", [
+    ("FP8_DEFAULT_CFG", ["S1:fake_e4m3fy", "S6:reduce_amax"]),
+    ("INT8_DEFAULT_CFG", ["S1:fake_tensor_quant", "S1:fake_tensor_quant_with_axis", "S6:reduce_amax"]),
+    ("INT4_AWQ_CFG", ["S1:fake_tensor_quant_with_axis", "S6:reduce_amax"]),
+    ("MXFP4_DEFAULT_CFG", ["S1:fused_amax_convert"]),
+])
+def test_reference_quantize_through_installed_seams(monkeypatch, preset, expected):
+    import contextlib
+
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    import modelopt.torch.quantization.extensions as ext
+    from modelopt.torch.quantization.nn.modules import tensor_quantizer as ref_tq_mod
+    from modelopt.torch.quantization.utils import core_utils
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from model_optimizer_amd import modelopt_plugin
+
+    def tiny():
+        torch.manual_seed(0)
+        cfg = LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+                          num_key_value_heads=2, vocab_size=64, max_position_embeddings=32,
+                          architectures=["LlamaForCausalLM"])
+        return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+
+    batches = [torch.randint(0, 64, (2, 16), generator=torch.Generator().manual_seed(i)) for i in range(2)]
+
+    def run():
+        m = tiny()
+        with torch.no_grad():
+            q = mtq.quantize(m, copy.deepcopy(getattr(mtq, preset)), lambda mm: [mm(b) for b in batches])
+            logits = q(batches[0]).logits
+        state = {n: t.clone() for n, t in q.state_dict().items()}
+        return state, logits
+
+    if preset == "MXFP4_DEFAULT_CFG":
+        base = None  # the reference has no CPU implementation of the MX kernels: nothing to compare a baseline with
+    else:
+        base = run()
+    # -- install: seams + host-memory backend + "every tensor is a GPU tensor"
+    saved = {fn: getattr(fn, "extension", None) for fn in (ext.get_cuda_ext, ext.get_cuda_ext_fp8, ext.get_cuda_ext_mx)}
+    saved_reduce = (core_utils.reduce_amax, )
+    hostmem_backend.install(monkeypatch, moa)
+    try:
+        installed = modelopt_plugin.install()
+        assert "S1:extensions" in installed and "S6:reduce_amax" in installed
+        monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)
+        monkeypatch.setattr(ref_tq_mod, "same_device_as", lambda t: contextlib.nullcontext())
+        modelopt_plugin.STATS.clear()
+        ours = run()
+        stats = dict(modelopt_plugin.STATS)
+    finally:
+        monkeypatch.undo()
+        for fn, v in saved.items():
+            if v is None and hasattr(fn, "extension"):
+                del fn.extension
+            elif v is not None:
+                fn.extension = v
+    for key in expected:
+        assert stats.get(key, 0) > 0, f"{preset}: the reference never reached {key}: {stats}"
+    assert not [k for k in stats if "fallback" in k], f"{preset}: unexpected fallbacks {stats}"
+    if base is not None:
+        assert set(base[0]) == set(ours[0])
+        for n in base[0]:
+            assert torch.equal(base[0][n], ours[0][n]), f"{preset}: {n} differs from the un-installed reference run"
+        assert torch.equal(base[1], ours[1]), f"{preset}: logits differ"
+    else:
+        # MXFP4 under the reference = its own TensorQuantizer / QuantLinear code calling our MX kernel through S1; this
+        # package's quantize() of the same model calls the same kernel from its own host code: identical logits
+        hostmem_backend.install(monkeypatch, moa)
+        m = tiny()
+        with torch.no_grad():
+            q = moa.quantize(m, copy.deepcopy(moa.model_quant.MXFP4_DEFAULT_CFG), None)
+            mine = q(batches[0]).logits
+        assert torch.equal(mine, ours[1]), "MXFP4 logits: reference through the seams vs this package"
