@@ -13,6 +13,7 @@ contract of the Llama-family models of BASELINE.json.
 from __future__ import annotations
 
 import json
+import warnings
 import os
 
 import torch
@@ -88,6 +89,32 @@ def _load_quantizer_state(layer, state):
 
 
 @torch.no_grad()
+def _atomic_save(obj, path: str):
+    tmp = path + ".tmp"
+    with open(tmp, "wb") as f:
+        torch.save(obj, f)
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, path)
+
+
+def _replay_to_layer(model, layers, start: int, forward_loop):
+    """Inputs of layer `start` when the saved ones cannot be trusted: the forward loop is run up to that layer through
+    the restored (calibrated) layers 0 .. start-1 -- with their quantizers bypassed, as the saved inputs were produced."""
+    qs = [q for lyr in list(layers)[:start] for q in lyr.modules() if isinstance(q, TensorQuantizer)]
+    saved = [(q._disabled, q._if_calib) for q in qs]
+    for q in qs:
+        q._disabled, q._if_calib = True, False
+    try:
+        inputs = _capture_inputs(model, layers[start], forward_loop)
+    finally:
+        for q, (d, c) in zip(qs, saved):
+            q._disabled, q._if_calib = d, c
+    if not inputs:
+        raise RuntimeError(f"forward_loop never reached decoder layer {start}")
+    return inputs
+
+
 def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None, checkpoint_dir: str | None = None,
                         get_qdq_activations_from_prev_layer: bool = False, calib_mutates_weights: bool = True,
                         **calib_kwargs):
@@ -116,9 +143,18 @@ def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None,
                         layers[i].load_state_dict(blob["weights"], strict=False)
                 if 0 < start < n_layers:
                     dev = next(layers[start].parameters()).device
+                    # the checkpoint directory is the user's own (pickled kwargs of the layer calls: weights_only
+                    # cannot apply); what is checked is that the inputs belong to the layer the manifest resumes at
                     nxt = torch.load(os.path.join(checkpoint_dir, "next_inputs.pt"), weights_only=False)
-                    inputs = [(tuple(a.to(dev) if isinstance(a, torch.Tensor) else a for a in args), kwargs)
-                              for args, kwargs in nxt]
+                    if not isinstance(nxt, dict) or nxt.get("for_layer") != start:
+                        found = nxt.get("for_layer") if isinstance(nxt, dict) else "an older format"
+                        warnings.warn(f"layerwise_calibrate: {checkpoint_dir}/next_inputs.pt holds the inputs of layer "
+                                      f"{found}, the manifest resumes at layer {start} (interrupted checkpoint write); "
+                                      "re-capturing the inputs by replaying the finished layers")
+                        inputs = _replay_to_layer(model, layers, start, forward_loop)
+                    else:
+                        inputs = [(tuple(a.to(dev) if isinstance(a, torch.Tensor) else a for a in args), kwargs)
+                                  for args, kwargs in nxt["inputs"]]
     if start >= n_layers:
         return 0
     if inputs is None:
@@ -157,15 +193,25 @@ def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None,
         if not is_last and get_qdq_activations_from_prev_layer:
             next_inputs = outputs_of(layer)  # with quantizers active and any weight updates (GPTQ-style)
         if checkpoint_dir:
+            # Crash-safe: every file is written under a temporary name and moved into place (os.replace is atomic), the
+            # manifest LAST; the saved inputs carry the index of the layer they feed, so a resume that finds inputs of
+            # another layer than the manifest names (a crash between the two moves) refuses them instead of
+            # calibrating a layer on its successor's activations.
             blob = {"quantizers": _quantizer_state(layer),
                     "weights": {k: v.detach().cpu() for k, v in layer.state_dict().items()
                                 if "quantizer" not in k} if calib_mutates_weights else None}
-            torch.save(blob, os.path.join(checkpoint_dir, f"layer_{idx:04d}.pt"))
+            _atomic_save(blob, os.path.join(checkpoint_dir, f"layer_{idx:04d}.pt"))
             if next_inputs is not None:
-                torch.save([(tuple(a.cpu() if isinstance(a, torch.Tensor) else a for a in args), kwargs)
-                            for args, kwargs in next_inputs], os.path.join(checkpoint_dir, "next_inputs.pt"))
-            with open(manifest_path, "w") as f:
+                _atomic_save({"for_layer": idx + 1,
+                              "inputs": [(tuple(a.cpu() if isinstance(a, torch.Tensor) else a for a in args), kwargs)
+                                         for args, kwargs in next_inputs]},
+                             os.path.join(checkpoint_dir, "next_inputs.pt"))
+            tmp = manifest_path + ".tmp"
+            with open(tmp, "w") as f:
                 json.dump({"num_layers": n_layers, "completed": idx + 1}, f)
+                f.flush()
+                os.fsync(f.fileno())
+            os.replace(tmp, manifest_path)
         inputs = next_inputs
         done += 1
     return done

@@ -110,3 +110,42 @@ def test_layerwise_awq_lite_equals_whole_model(search):
             assert torch.equal(a.weight, b.weight), name
             assert torch.equal(a.input_quantizer.pre_quant_scale, b.input_quantizer.pre_quant_scale), name
             assert torch.equal(a.weight_quantizer.amax, b.weight_quantizer.amax), name
+
+
+def test_layerwise_resume_after_an_interrupted_checkpoint_write(tmp_path):
+    """A crash between the write of next_inputs.pt (inputs of layer N + 1) and the manifest leaves the manifest at
+    completed = N: the saved inputs name the layer they feed, a resume that finds another layer's inputs re-captures them
+    instead of calibrating layer N on layer N + 1's activations; files are moved into place atomically."""
+    import json
+    import os
+
+    cfg = model_quant.FP8_DEFAULT_CFG
+    model, batches = _setup(cfg)
+    ref = copy.deepcopy(model)
+    layerwise.layerwise_calibrate(ref, lambda m: [m(b) for b in batches], model_calib.max_calibrate)
+    calls = {"n": 0}
+
+    def flaky(layer, loop, **kw):
+        if calls["n"] == 3:
+            raise KeyboardInterrupt
+        calls["n"] += 1
+        model_calib.max_calibrate(layer, loop, **kw)
+
+    m1 = copy.deepcopy(model)
+    with pytest.raises(KeyboardInterrupt):
+        layerwise.layerwise_calibrate(m1, lambda m: [m(b) for b in batches], flaky, checkpoint_dir=str(tmp_path))
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+    blob = torch.load(os.path.join(tmp_path, "next_inputs.pt"), weights_only=False)
+    assert blob["for_layer"] == 3
+    # the simulated crash: next_inputs.pt already holds layer 3's inputs, the manifest still says 2 layers are done
+    with open(os.path.join(tmp_path, "manifest.json"), "w") as f:
+        json.dump({"num_layers": 4, "completed": 2}, f)
+    m2 = copy.deepcopy(model)
+    with pytest.warns(UserWarning, match="interrupted checkpoint write"):
+        n = layerwise.layerwise_calibrate(m2, lambda m: [m(b) for b in batches], model_calib.max_calibrate,
+                                          checkpoint_dir=str(tmp_path))
+    assert n == 2
+    a, b = _amax(ref), _amax(m2)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"{k}: run resumed from re-captured inputs differs"
