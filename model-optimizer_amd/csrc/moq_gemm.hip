@@ -222,6 +222,96 @@ __device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, in
   }
 }
 
+// The epilogue shared by every loop structure: the wave's NI x NJ accumulator tiles against `ref` / into `out`.
+// C layout of 32x32: col (t) = lane & 31, row (n) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane holds runs of 4
+// consecutive n for one t -> 8-byte accesses of out / out_actual rows.
+template <int DT, int MODE, int NI, int NJ, int WAVES>
+__device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const void* __restrict__ ref,
+                                              const void* __restrict__ bias, void* __restrict__ out,
+                                              float* __restrict__ partial, uint8_t* smem, int T, int N, int n0, int t0,
+                                              int tn, int tt, int wn, int wt, int fr, int fh, int lane, int wave,
+                                              float decay, float scale, int upper_only) {
+  float sq = 0.0f;
+  const bool has_bias = bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + (wn * NI + i) * 32 + 8 * q + 4 * fh;
+      if (n >= N) continue;  // N % 4 == 0 is required by the host, so a run of 4 is all-in or all-out
+      float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (has_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = load1<DT>(bias, n + e);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int t = t0 + (wt * NJ + j) * 32 + fr;
+        if (t >= T) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = round_to_dtype<DT>(acc[i][j][q * 4 + e] + bv[e]);
+        const int64_t off = (int64_t)t * N + n;
+        if constexpr (MODE == 2) {
+          float4* hp = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off);
+          float4 h = *hp;
+          h.x = h.x * decay + scale * acc[i][j][q * 4 + 0];
+          h.y = h.y * decay + scale * acc[i][j][q * 4 + 1];
+          h.z = h.z * decay + scale * acc[i][j][q * 4 + 2];
+          h.w = h.w * decay + scale * acc[i][j][q * 4 + 3];
+          *hp = h;
+          if (tn != tt && !upper_only) {  // mirrored block: out[n + e, t]; lanes run along t -> 128-byte runs
+            float* hm = reinterpret_cast<float*>(out) + (int64_t)n * N + t;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hm[(int64_t)e * N] = hm[(int64_t)e * N] * decay + scale * acc[i][j][q * 4 + e];
+          }
+        } else if constexpr (MODE == 3) {
+          const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ref) + off);
+          sq += acc[i][j][q * 4 + 0] * rv.x;
+          sq += acc[i][j][q * 4 + 1] * rv.y;
+          sq += acc[i][j][q * 4 + 2] * rv.z;
+          sq += acc[i][j][q * 4 + 3] * rv.w;
+        } else if constexpr (MODE == 0) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
+          float rf[4];
+          if constexpr (DT == MOQ_BF16) {
+            rf[0] = __uint_as_float(rv.x << 16); rf[1] = __uint_as_float(rv.x & 0xFFFF0000u);
+            rf[2] = __uint_as_float(rv.y << 16); rf[3] = __uint_as_float(rv.y & 0xFFFF0000u);
+          } else {
+            const f16x2 h0 = *reinterpret_cast<const f16x2*>(&rv.x), h1 = *reinterpret_cast<const f16x2*>(&rv.y);
+            rf[0] = (float)h0.x; rf[1] = (float)h0.y; rf[2] = (float)h1.x; rf[3] = (float)h1.y;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = round_to_dtype<DT>(o[e] - rf[e]);  // (out - out_actual) in the model dtype
+            sq += d * d;                                       // .float().pow(2)
+          }
+        } else {
+          float f4[8] = {o[0], o[1], o[2], o[3], 0, 0, 0, 0};
+          const Pack16 p = pack<DT>(f4);
+          uint2 st;
+          st.x = p.w[0]; st.y = p.w[1];
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + off) = st;
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 0 || MODE == 3) {
+    // deterministic workgroup sum: butterfly inside the wave, fixed order across the waves
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    __syncthreads();  // all LDS tile reads are done; reuse the first words
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = red[0];
+      for (int v = 1; v < WAVES; ++v) s += red[v];
+      partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
+    }
+  }
+}
+
 // MODE 0: accumulate the squared error against `ref` into partial[block]; MODE 1: store out[t, n];
 // MODE 2: out is fp32 [T, N], T == N, x == w: out = out * decay + scale * acc (running Gram / Hessian X^T X of
 //         SparseGPT and of the AWQ Gram search); only tiles with n-tile >= t-tile are contracted.  upper_only = 0:
@@ -411,88 +501,183 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     }
   }
 
-  // epilogue.  C layout of 32x32: col (t) = lane & 31, row (n) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5):
-  // a lane holds runs of 4 consecutive n for one t -> 8-byte accesses of out / out_actual rows.
-  float sq = 0.0f;
-  const bool has_bias = bias != nullptr;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + (wn * NI + i) * 32 + 8 * q + 4 * fh;
-      if (n >= N) continue;  // N % 4 == 0 is required by the host, so a run of 4 is all-in or all-out
-      float bv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (has_bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = load1<DT>(bias, n + e);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int t = t0 + (wt * NJ + j) * 32 + fr;
-        if (t >= T) continue;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = round_to_dtype<DT>(acc[i][j][q * 4 + e] + bv[e]);
-        const int64_t off = (int64_t)t * N + n;
-        if constexpr (MODE == 2) {
-          float4* hp = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off);
-          float4 h = *hp;
-          h.x = h.x * decay + scale * acc[i][j][q * 4 + 0];
-          h.y = h.y * decay + scale * acc[i][j][q * 4 + 1];
-          h.z = h.z * decay + scale * acc[i][j][q * 4 + 2];
-          h.w = h.w * decay + scale * acc[i][j][q * 4 + 3];
-          *hp = h;
-          if (tn != tt && !upper_only) {  // mirrored block: out[n + e, t]; lanes run along t -> 128-byte runs
-            float* hm = reinterpret_cast<float*>(out) + (int64_t)n * N + t;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hm[(int64_t)e * N] = hm[(int64_t)e * N] * decay + scale * acc[i][j][q * 4 + e];
-          }
-        } else if constexpr (MODE == 3) {
-          const float4 rv = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ref) + off);
-          sq += acc[i][j][q * 4 + 0] * rv.x;
-          sq += acc[i][j][q * 4 + 1] * rv.y;
-          sq += acc[i][j][q * 4 + 2] * rv.z;
-          sq += acc[i][j][q * 4 + 3] * rv.w;
-        } else if constexpr (MODE == 0) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
-          float rf[4];
-          if constexpr (DT == MOQ_BF16) {
-            rf[0] = __uint_as_float(rv.x << 16); rf[1] = __uint_as_float(rv.x & 0xFFFF0000u);
-            rf[2] = __uint_as_float(rv.y << 16); rf[3] = __uint_as_float(rv.y & 0xFFFF0000u);
-          } else {
-            const f16x2 h0 = *reinterpret_cast<const f16x2*>(&rv.x), h1 = *reinterpret_cast<const f16x2*>(&rv.y);
-            rf[0] = (float)h0.x; rf[1] = (float)h0.y; rf[2] = (float)h1.x; rf[3] = (float)h1.y;
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float d = round_to_dtype<DT>(o[e] - rf[e]);  // (out - out_actual) in the model dtype
-            sq += d * d;                                       // .float().pow(2)
-          }
-        } else {
-          float f4[8] = {o[0], o[1], o[2], o[3], 0, 0, 0, 0};
-          const Pack16 p = pack<DT>(f4);
-          uint2 st;
-          st.x = p.w[0]; st.y = p.w[1];
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + off) = st;
-        }
-      }
-    }
-  }
-  if constexpr (MODE == 0 || MODE == 3) {
-    // deterministic workgroup sum: butterfly inside the wave, fixed order across the waves
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
-    __syncthreads();  // all LDS tile reads are done; reuse the first words
-    float* red = reinterpret_cast<float*>(smem);
-    if (lane == 0) red[wave] = sq;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float s = red[0];
-      for (int v = 1; v < Geo<GEO>::WAVES; ++v) s += red[v];
-      partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = s;
-    }
-  }
+  gemm_epilogue<DT, MODE, NI, NJ, Geo<GEO>::WAVES>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, wn, wt, fr, fh,
+                                                   lane, wave, decay, scale, upper_only);
 }
+
+// ---- GEO 6: the 256 x 256 x 64 tile as a two-group ping-pong (cdna_hip_programming.md 5, "8-phase" idea restated on
+// this kernel's 32x32x16 tiles and whole-tile double buffer).
+//
+// What limited GEO 4 (PMC, profiles/r01_gemm_table.md): all eight waves meet at ONE barrier per K-tile and then do the
+// same thing at the same time -- wait for the DMA, read fragments, multiply -- so the matrix pipe of every SIMD idles
+// through each "wait, barrier, first reads" stretch (MFMA busy 46 %, waves parked 36 %).  Here the two waves that share
+// a SIMD (wave w and w + 4: one of each GROUP) never do the same thing: a K-tile is four phases of
+//     R: fragment reads + two LDS-DMA pieces      | barrier |      M: one quadrant of the wave's 128 x 64 tile, 8 MFMAs
+// and group 1 runs ONE barrier behind group 0, so in every interval between two barriers one wave of each SIMD
+// multiplies while the other reads and stages.  The DMA never drains: the pieces of tile kt + 1 / kt + 2 are issued two
+// per phase, and the single wait per K-tile (`vmcnt(2)` at the start of the tile's last phase) leaves the newest two in
+// flight; a tile is first read two barriers after every wave waited for its own pieces of it.
+//
+// Per wave and K-tile: R1 reads a0 b0 b1 (16 x ds_read_b128), R2 reads a1 (8); all reads of tile kt are retired before
+// the wave's third phase, so from there on tile kt's stage takes the pieces of tile kt + 2.  Piece order of a wave
+// (8 per tile: A rows of its own group's half, B rows of its eighth of the token tile, alternating):
+//     R3(kt): (kt+2)[0,1]   R4(kt): wait, (kt+2)[2,3]   R1(kt+1): (kt+2)[4,5]   R2(kt+1): (kt+2)[6,7]
+// Hazards.  RAW: wave waits vmcnt at R4(kt) for ALL its pieces of tile kt + 1 (<= 2 newer ones outstanding); group 0
+// reads that tile two barriers later, group 1 three.  WAR: a stage is re-filled only after every reader passed an
+// `s_waitcnt lgkmcnt(0)` (end of each M segment) and a barrier.
+__device__ __forceinline__ void stage_piece(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
+                                            int rbase, int lane) {
+  const int r = rbase + (lane >> 3), pos = lane & 7;
+  const int c = pos ^ ((r >> 1) & 7);
+  const int k = k0 + c * 8;
+  const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
+  const i32x4_t rs = desc.words;
+  uint8_t* dst = lds_tile + rbase * kRowBytes;
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
+}
+
+#define MOQ_BAR()                                   \
+  do {                                              \
+    asm volatile("s_barrier" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+#define MOQ_M_END()                                            \
+  do {                                                         \
+    __builtin_amdgcn_s_setprio(0);                             \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(512, 2)
+void err_gemm6_kernel(const void* __restrict__ x, const void* __restrict__ w, const void* __restrict__ ref,
+                      const void* __restrict__ bias, void* __restrict__ out, float* __restrict__ partial, int T, int N,
+                      int K, int tiles_t, int tiles_n, int64_t x_stride, int64_t w_stride, float decay, float scale,
+                      int upper_only) {
+  constexpr int TILE = 256, NI = 4, NJ = 2;
+  constexpr int TB = TILE * kRowBytes, SB = 2 * TB;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nblk = tiles_t * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tn = bid / tiles_t, tt = bid % tiles_t;
+  const int n0 = tn * TILE, t0 = tt * TILE;
+  if constexpr (MODE == 2) {
+    if (tn < tt) return;
+  }
+  x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
+  w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
+  if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
+  const int rows_w = N - n0 < TILE ? N - n0 : TILE;
+  const int rows_x = T - t0 < TILE ? T - t0 : TILE;
+  const int64_t ld_bytes = (int64_t)K * 2;
+  const TileDesc rs_w = make_tile_desc(reinterpret_cast<const uint8_t*>(w) + (int64_t)n0 * ld_bytes,
+                                       (int)(rows_w * ld_bytes));
+  const TileDesc rs_x = make_tile_desc(reinterpret_cast<const uint8_t*>(x) + (int64_t)t0 * ld_bytes,
+                                       (int)(rows_x * ld_bytes));
+  f32x16_t acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int g = wave >> 2, wq = wave & 3;  // group = the wave's n half (A rows g * 128 ..), wq = its 64 tokens
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  const uint8_t* la0 = smem + (g * NI * 32) * kRowBytes;
+  const uint8_t* lb0 = smem + TB + (wq * NJ * 32) * kRowBytes;
+  Pack16 a[NI][4], b[NJ][4];
+
+  // piece p (0..7) of this wave for K-tile `kt`: even = 8 rows of the group's A half, odd = 8 rows of the B tile
+  auto issue = [&](int kt, int p) {
+    uint8_t* st = smem + (kt & 1) * SB;
+    const int j = p >> 1;
+    if (p & 1) stage_piece(rs_x, st + TB, ld_bytes, kt * kBK, K, (wave * 4 + j) * 8, lane);
+    else stage_piece(rs_w, st, ld_bytes, kt * kBK, K, g * 128 + (wq * 4 + j) * 8, lane);
+  };
+  auto read_a = [&](int so, int i0) {  // row blocks i0, i0 + 1 of the wave's A half, all four k sub-steps
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[i0 + i][ks] = read_frag(la0 + so, (i0 + i) * 32 + fr, ks * 2 + fh);
+  };
+  auto read_b = [&](int so, int j) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) b[j][ks] = read_frag(lb0 + so, j * 32 + fr, ks * 2 + fh);
+  };
+  auto quadrant = [&](int i0, int j) {  // 8 MFMAs: two accumulators, four dependent k sub-steps each
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      acc[i0][j] = mfma32<DT>(a[i0][ks], b[j][ks], acc[i0][j]);
+      acc[i0 + 1][j] = mfma32<DT>(a[i0 + 1][ks], b[j][ks], acc[i0 + 1][j]);
+    }
+  };
+
+  // prologue: tile 0 whole, the first half of tile 1
+#pragma unroll
+  for (int p = 0; p < 8; ++p) issue(0, p);
+  if (nk > 1) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) issue(1, p);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  MOQ_BAR();
+  if (g == 1) MOQ_BAR();  // group 1 runs one barrier behind group 0 from here on
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int so = (kt & 1) * SB;
+    const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+    // ---- phase 1
+    read_b(so, 0);
+    read_b(so, 1);
+    read_a(so, 0);
+    if (has1) { issue(kt + 1, 4); issue(kt + 1, 5); }
+    MOQ_BAR();
+    quadrant(0, 0);
+    MOQ_M_END();
+    MOQ_BAR();
+    // ---- phase 2
+    read_a(so, 2);
+    if (has1) { issue(kt + 1, 6); issue(kt + 1, 7); }
+    MOQ_BAR();
+    quadrant(0, 1);
+    MOQ_M_END();
+    MOQ_BAR();
+    // ---- phase 3: every read of tile kt is retired (M_END above + barrier): its stage takes tile kt + 2
+    if (has2) { issue(kt + 2, 0); issue(kt + 2, 1); }
+    MOQ_BAR();
+    quadrant(2, 1);
+    MOQ_M_END();
+    MOQ_BAR();
+    // ---- phase 4: this wave's pieces of tile kt + 1 have landed (the two just issued may still fly)
+    if (has1) {
+      if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (has2) { issue(kt + 2, 2); issue(kt + 2, 3); }
+    MOQ_BAR();
+    quadrant(2, 0);
+    MOQ_M_END();
+    MOQ_BAR();
+  }
+  if (g == 0) MOQ_BAR();  // same number of barriers for both groups
+  gemm_epilogue<DT, MODE, NI, NJ, 8>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, g, wq, fr, fh, lane, wave,
+                                     decay, scale, upper_only);
+}
+#undef MOQ_BAR
+#undef MOQ_M_END
 
 // loss_acc[0] += (float)(sum(partial) / count): partial sums are added in index order in double
 __global__ void err_finalize_kernel(const float* __restrict__ partial, int n, double inv_count,
@@ -543,11 +728,11 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
 }
 
 static int gemm_geo() {
-  // MOQ_TUNE_GEMM_GEO = 0 | 1 | 2 | 3 | 4 selects the tile geometry / loop structure (A/B knob, read once)
+  // MOQ_TUNE_GEMM_GEO = 0 .. 6 selects the tile geometry / loop structure (A/B knob, read once)
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 4;
-    return g < 0 || g > 5 ? 4 : g;
+    return g < 0 || g > 6 ? 4 : g;
   }();
   return geo;
 }
@@ -587,6 +772,31 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   }
 }
 
+template <int MODE>
+static void launch_geo6(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
+                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
+                        int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
+  constexpr int TILE = 256, LDS = 2 * 2 * TILE * kRowBytes;  // two stages of an A and a B tile: 128 KiB
+  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  static std::atomic<uint64_t> attr_set{0};
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const uint64_t bit = 1ull << (device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)err_gemm6_kernel<MOQ_BF16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)err_gemm6_kernel<MOQ_F16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  const dim3 grid((unsigned)(tiles_t * tiles_n), (unsigned)n_cand), block(512);
+  if (dt == MOQ_BF16) {
+    hipLaunchKernelGGL((err_gemm6_kernel<MOQ_BF16, MODE>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
+                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
+  } else {
+    hipLaunchKernelGGL((err_gemm6_kernel<MOQ_F16, MODE>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
+                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
+  }
+}
+
 // returns the number of per-tile partial sums each candidate produced (MODE 0), or a negative status
 template <int MODE>
 static int64_t launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
@@ -606,6 +816,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 5: launch_geo<MODE, 5>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
   return nblk;
