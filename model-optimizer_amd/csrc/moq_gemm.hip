@@ -222,6 +222,30 @@ __device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, in
   }
 }
 
+// Workgroup -> output tile.  (1) XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a contiguous run of tile ids
+// (bijective for any grid size).  (2) Grouped order inside the run: consecutive ids -- the 32 workgroups an XCD runs at a
+// time -- cover kTileGroup weight tiles x (32 / kTileGroup) token tiles instead of 2 x 16, so a K-step of the XCD touches
+// 8 + 4 operand slices instead of 2 + 16: a third less traffic behind the XCD's L2 (hit rate 72 % -> 81 % by count).
+constexpr int kTileGroup = 8;
+__device__ __forceinline__ void tile_of_block(int bid, int tiles_t, int tiles_n, int group, int& tn, int& tt) {
+  const int nblk = tiles_t * tiles_n;
+  {
+    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  if (group <= 1) {
+    tn = bid / tiles_t;  // consecutive workgroups share the W tile
+    tt = bid % tiles_t;
+    return;
+  }
+  const int per_group = group * tiles_t;
+  const int gid = bid / per_group, first_n = gid * group;
+  const int gsz = tiles_n - first_n < group ? tiles_n - first_n : group;
+  const int in_group = bid - gid * per_group;
+  tn = first_n + in_group % gsz;
+  tt = in_group / gsz;
+}
+
 // The epilogue shared by every loop structure: the wave's NI x NJ accumulator tiles against `ref` / into `out`.
 // C layout of 32x32: col (t) = lane & 31, row (n) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane holds runs of 4
 // consecutive n for one t -> 8-byte accesses of out / out_actual rows.
@@ -332,15 +356,8 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   constexpr int WTC = Geo<GEO>::WAVES / Geo<GEO>::WN;  // waves along t
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles so that
-  // the W tile it is streaming is shared through that XCD's L2 (bijective for any grid size).
-  const int nblk = tiles_t * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = bid / tiles_t, tt = bid % tiles_t;  // consecutive workgroups share the W tile
+  int tn, tt;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
   const int n0 = tn * TILE, t0 = tt * TILE;
   if constexpr (MODE == 2) {
     if (tn < tt) return;  // mirror image of tile (tn, tt)
@@ -561,13 +578,8 @@ void err_gemm6_kernel(const void* __restrict__ x, const void* __restrict__ w, co
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int nblk = tiles_t * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, idx = bid >> 3, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tn = bid / tiles_t, tt = bid % tiles_t;
+  int tn, tt;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
   const int n0 = tn * TILE, t0 = tt * TILE;
   if constexpr (MODE == 2) {
     if (tn < tt) return;
@@ -804,6 +816,16 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
                            int64_t x_stride, int64_t w_stride, void* stream, float decay = 0.0f,
                            float scale = 0.0f, int upper_only = 0) {
   const int geo = gemm_geo();
+  if constexpr (MODE != 2) {
+    // the kernels' last argument is the Gram mode's upper_only flag; the other modes carry the tile-group size of the
+    // workgroup -> tile order in it (tile_of_block).  MOQ_TUNE_GEMM_GROUP = 1 restores the plain row-major order.
+    static const int group = [] {
+      const char* e = getenv("MOQ_TUNE_GEMM_GROUP");
+      const int g = e ? atoi(e) : kTileGroup;
+      return g < 1 || g > 64 ? kTileGroup : g;
+    }();
+    upper_only = group;
+  }
   const int tile = geo >= 2 ? 256 : 128;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
   if (nblk > 0x7FFFFFFF) {
