@@ -86,11 +86,14 @@ def pmc_traffic(workload, model, n_layers):
     profile of this workload / model size is committed."""
     if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
-    path = os.path.join(ROOT, "profiles", f"r01c_{workload}_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r01b_{workload}_pmc.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", f"r01_{workload}_pmc.json")
+    path = None
+    for tag in ("r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
+        cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc.json")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
+        return None, None
     try:
         with open(path) as f:
             prof = json.load(f)
