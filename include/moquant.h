@@ -191,6 +191,12 @@ int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols
 int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
                  float max_edge, int skip_zeros, void* stream);
 
+/* INT8 checkpoint weights: out[r, c] = (int8) clamp(rint(w[r, c] / scale[r]), -128, 127), fp32 quotient, round half to
+ * even -- to_quantized_weight for W8A8_SQ_PER_CHANNEL / INT8 weight-only (export/quant_utils.py:868-869) with the fp32
+ * per-output-channel scaling factor of get_weight_scaling_factor.  Needs cols % (16 / sizeof(elem)) == 0. */
+int moq_int8_pack_rows(const void* w, const float* scale, int8_t* out, int64_t rows, int64_t cols, int dt,
+                       void* stream);
+
 /* ------------------------------------------------------------------ fused input-quantizer pass (8f-3) */
 
 /* TensorQuantizer.forward for a per-tensor input quantizer in ONE read of the activation x[rows, cols]

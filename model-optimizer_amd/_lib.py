@@ -62,6 +62,7 @@ SIGNATURES = {
     "moq_col_abs_mean_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
     "moq_input_quant": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
+    "moq_int8_pack_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "moq_hist_abs": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_float, c_int, c_void_p]),
     "moq_mask_2to4": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "moq_int4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

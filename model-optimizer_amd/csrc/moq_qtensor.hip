@@ -68,10 +68,15 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
       float v[8];
       unpack<DT>(in[u], v);
       uint32_t b[4] = {0, 0, 0, 0};
+      // one denominator per packet: the shared exact division (moq_common.h) -- bit-identical to `/` while the
+      // numerators stay below 2^16 (checked on the packet's abs-max), the IEEE sequence otherwise
+      const SharedDiv sd = make_shared_div(sc[u]);
+      const bool exact_fast = sd.fast && pack_absmax<DT>(in[u]) <= 0x47800000u;
 #pragma unroll
       for (int i = 0; i < V; i += 2) {
-        const float qa = round_to_dtype<DT>(v[i] / sc[u]), qb = round_to_dtype<DT>(v[i + 1] / sc[u]);
-        b[i / 2] = e4m3fn_bytes2(qa, qb);
+        const float da = exact_fast ? shared_div(v[i], sd) : v[i] / sc[u];
+        const float db = exact_fast ? shared_div(v[i + 1], sd) : v[i + 1] / sc[u];
+        b[i / 2] = e4m3fn_bytes2(round_to_dtype<DT>(da), round_to_dtype<DT>(db));
       }
       if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
       else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
@@ -297,9 +302,12 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_tile_kernel(const void* __res
     float v[8];
     unpack<DT>(in, v);
     uint32_t b[4] = {0, 0, 0, 0};
+    const SharedDiv sd = make_shared_div(sc);  // as in fp8_pack_kernel
+    const bool exact_fast = sd.fast && pack_absmax<DT>(in) <= 0x47800000u;
 #pragma unroll
     for (int i = 0; i < V; i += 2) {
-      float qa = v[i] / sc, qb = v[i + 1] / sc;
+      float qa = exact_fast ? shared_div(v[i], sd) : v[i] / sc;
+      float qb = exact_fast ? shared_div(v[i + 1], sd) : v[i + 1] / sc;
       if constexpr (!PROMOTE) {
         qa = round_to_dtype<DT>(qa);
         qb = round_to_dtype<DT>(qb);
@@ -430,6 +438,61 @@ extern "C" int moq_fp8_pack(const void* x, const void* scales, int scale_dt, uin
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   }
   return check_launch("moq_fp8_pack");
+}
+
+// ---------------------------------------------------------------- INT8 weight pack (export)
+// to_quantized_weight for INT8 SmoothQuant / weight-only (export/quant_utils.py:868-869):
+//     (weight / weights_scaling_factor[:, None]).round().clamp(-128, 127).to(int8)
+// with an fp32 scaling factor per output channel: the quotient is fp32 (a dimensioned fp32 operand promotes), rounded
+// half to even, clamped.  One 16-byte packet never leaves its row (cols % V == 0), so the row's scale is one shared
+// exact division per packet.
+namespace moq {
+template <int DT>
+__global__ __launch_bounds__(kBlock) void int8_pack_rows_kernel(const void* __restrict__ w,
+                                                                const float* __restrict__ scale,
+                                                                int8_t* __restrict__ out, int64_t n_packets,
+                                                                int64_t cols) {
+  constexpr int V = Elem<DT>::kVec;
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
+    const int64_t e = p * V;
+    const float sc = scale[e / cols];
+    const Pack16 in = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
+    float v[8];
+    unpack<DT>(in, v);
+    const SharedDiv sd = make_shared_div(sc);
+    const bool exact_fast = sd.fast && pack_absmax<DT>(in) <= 0x47800000u;
+    uint32_t b[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float q = exact_fast ? shared_div(v[i], sd) : v[i] / sc;
+      float t = __builtin_rintf(q);
+      t = __builtin_fminf(__builtin_fmaxf(t, -128.0f), 127.0f);
+      // torch: NaN -> int8 conversion is 0 on the host; clamp keeps NaN, the cast then gives 0
+      const int c = (q != q) ? 0 : (int)t;
+      b[i / 4] |= ((uint32_t)c & 0xFFu) << (8 * (i % 4));
+    }
+    if constexpr (V == 8) q_store8_nt(reinterpret_cast<uint8_t*>(out) + e, b[0], b[1]);
+    else __builtin_nontemporal_store(b[0], reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + e));
+  }
+}
+}  // namespace moq
+
+extern "C" int moq_int8_pack_rows(const void* w, const float* scale, int8_t* out, int64_t rows, int64_t cols, int dt,
+                                  void* stream) {
+  if (rows < 0 || cols <= 0 || (rows > 0 && (w == nullptr || scale == nullptr || out == nullptr))) {
+    set_error("moq_int8_pack_rows: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (rows == 0) return MOQ_OK;
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  if (cols % vec != 0 || (reinterpret_cast<uintptr_t>(w) & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 7u) != 0) {
+    set_error("moq_int8_pack_rows: needs cols %% %d == 0, a 16-byte aligned weight and an 8-byte aligned output", vec);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int64_t n_packets = rows * cols / vec;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int8_pack_rows_kernel<DT>), dim3(stream_grid(kBlock, n_packets)),
+                                            dim3(kBlock), 0, S(stream), w, scale, out, n_packets, cols));
+  return check_launch("moq_int8_pack_rows");
 }
 
 extern "C" int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, int64_t n, int dt, int amax_mode,

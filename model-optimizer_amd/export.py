@@ -230,7 +230,7 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
     if quantization == QUANTIZATION_MXFP4:
         raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
-        return (weight / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)
+        return ops.int8_pack_rows(weight, wsf)
     raise NotImplementedError(f"quantization format {quantization} not supported")
 
 

@@ -539,6 +539,25 @@ def pack_int4_in_uint8(weight: torch.Tensor, weights_scaling_factor: torch.Tenso
 
 # ----------------------------------------------------------------------------------------------- AWQ / smooth
 @torch.no_grad()
+def int8_pack_rows(weight: torch.Tensor, weights_scaling_factor: torch.Tensor) -> torch.Tensor:
+    """(weight / wsf[:, None]).round().clamp(-128, 127).to(int8) with an fp32 scaling factor per output channel
+    (export/quant_utils.py:868-869), one kernel."""
+    _require_gpu(weight, "int8_pack_rows")
+    w = weight.detach().contiguous()
+    rows, cols = w.shape
+    wsf = _f32(weights_scaling_factor, w.device).reshape(-1)
+    if wsf.numel() != rows:
+        raise MoquantError("int8_pack_rows: one scaling factor per output channel expected")
+    vec = 4 if w.dtype == torch.float32 else 8
+    if cols % vec:
+        return (w / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)  # ragged rows: the reference's own ops
+    out = torch.empty(rows, cols, dtype=torch.int8, device=w.device)
+    with _on(w) as stream:
+        check(_lib.lib().moq_int8_pack_rows(_p(w), _p(wsf), _p(out), rows, cols, _dt(w), stream))
+    return out
+
+
+@torch.no_grad()
 def scale_cols(weight: torch.Tensor, scale: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
     """(W * s_fp32[None, :]).to(W.dtype) -- _apply_weight_pre_quant_scale (model_calib.py:1208-1216)."""
     _require_gpu(weight, "scale_cols")

@@ -179,6 +179,18 @@ class HostMemLib:
         a[:] = a + mean
         return OK
 
+    def moq_int8_pack_rows(self, w, scale, out, rows, cols, dt, stream):
+        import torch
+
+        tdt = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[int(dt)]
+        n = int(rows) * int(cols)
+        src = (ctypes.c_char * (n * (4 if int(dt) == 0 else 2))).from_address(_addr(w))
+        wt = torch.frombuffer(bytearray(src), dtype=tdt).reshape(int(rows), int(cols))
+        sc = torch.from_numpy(_f32_view(scale, rows).copy())
+        q = (wt / sc[:, None]).round().clamp(-128, 127).to(torch.int8)  # the reference's own expression
+        ctypes.memmove(_addr(out), q.contiguous().numpy().tobytes(), n)
+        return OK
+
     def moq_input_quant(self, x, pqs, y, rows, cols, dt, amax_running, qdq_amax, fmt, num_bits, unsigned, narrow,
                         hist_counts, hist_bins, hist_max_edge, hist_skip_zeros, stream):
         """The fused pass as the chain of the oracle's single stages (scale -> amax -> histogram -> QDQ)."""
