@@ -389,6 +389,7 @@ class AWQLiteHelper:
         self.gram_bytes = 0  # what this helper holds of the HBM budget for its Gram matrix
         # tie-aware re-evaluation (search="auto"): candidates whose Gram loss lies within the margin of the best one
         # are re-scored by the exact-rounding error-GEMM engine; `gram_loss` keeps the Gram scores for inspection
+        self.scored_here = False  # this rank evaluated the Gram scores (data parallel: one rank per Gram matrix)
         self.gram_loss = None
         self.contenders = None  # indices into `alphas`, ascending; None: the Gram scores decide
         self.exact_buf = None  # fp32 [len(contenders)] accumulated by the error GEMM
@@ -457,7 +458,6 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
             w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
             err = w_hat.float().mul_(r).sub_(wf)
             h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
-    h.num_search_steps = h.num_gram_steps
 
 
 # Relative margin inside which two candidates' Gram scores do not decide the search (search="auto").  The Gram loss
@@ -609,15 +609,60 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 h.gram_stage.flush()
                 h.gram_stage = None
 
-    def gram_losses():  # Gram-matrix linears: all alpha losses from the (local) Gram; the loss is linear in it
+    def shard_gram_scoring():
+        """Data parallel: instead of every rank scoring every linear on its LOCAL Gram matrix (the scores are linear in
+        it and get summed), the distinct Gram matrices are dealt over the ranks -- balanced by the scoring work they
+        carry -- each is SUM-reduced to its rank over RCCL (a real exchange: sum of Cin^2 fp32 over the model, 33 GB for
+        Llama-3-8B, a few hundred ms over xGMI) and only that rank scores the linears that read it; the other ranks
+        contribute zeros to the score bucket.  The scoring (11 quadratic forms per linear, a third of the single-GPU
+        search) then scales with the number of GPUs like the accumulation does.  Returns {owner helper: rank} or None
+        when the ranks do not see the same sharing structure (then every rank scores locally, as before)."""
+        if not _dist_on():
+            return None
+        hs = [helpers[m] for _, m in mods]
+        index = {id(h): i for i, h in enumerate(hs)}
+        sig = [None if (h.gram is None or h.act_scale is None or not h.is_enabled)
+               else (index[id(h.gram_owner or h)], tuple(h.gram.shape), str(h.gram.dtype)) for h in hs]
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, sig)
+        if any(g != sig for g in gathered):
+            return None
+        cost, owners = {}, []
+        for (_, m), h, s_ in zip(mods, hs, sig):
+            if s_ is None:
+                continue
+            o = hs[s_[0]]
+            if id(o) not in cost:
+                cost[id(o)] = 0
+                owners.append(o)
+            cost[id(o)] += m.weight.shape[0] * m.weight.shape[1] * m.weight.shape[1]
+        load = [0] * dist.get_world_size()
+        placement = {}
+        for o in sorted(owners, key=lambda o: -cost[id(o)]):  # largest first onto the least loaded rank
+            r = min(range(len(load)), key=load.__getitem__)
+            placement[id(o)] = r
+            load[r] += cost[id(o)]
+        for o in owners:  # same order on every rank
+            dist.reduce(o.gram, dst=placement[id(o)], op=dist.ReduceOp.SUM)
+        return placement
+
+    def gram_losses():
+        """Gram-matrix linears: all alpha losses from the Gram matrix (the loss is linear in it).  Single process: the
+        local matrix.  Data parallel: the reduced matrix on the rank it was dealt to (shard_gram_scoring), or -- when
+        the ranks disagree on the sharing structure -- every rank's local matrix, summed later in the score bucket."""
+        placement = shard_gram_scoring()
+        me = dist.get_rank() if placement is not None else 0
         for _, m in mods:
             h = helpers[m]
             if h.gram is not None and h.act_scale is not None:
                 own = h.gram_owner or h
-                if m.weight.dtype != torch.float32 and not own.gram_symmetrized:
-                    ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
-                    own.gram_symmetrized = True
-                _gram_losses(h, m)
+                h.num_search_steps = h.num_gram_steps
+                if placement is None or placement.get(id(own)) == me:
+                    if m.weight.dtype != torch.float32 and not own.gram_symmetrized:
+                        ops.symmetrize(h.gram)  # the MFMA accumulation kept the upper tiles only; once per matrix
+                        own.gram_symmetrized = True
+                    _gram_losses(h, m)
+                    h.scored_here = True
                 budget.release(h.gram_bytes)  # an owner's matrix really goes when its last alias has been scored
                 h.gram_bytes = 0
                 h.gram = None  # release Cin^2 floats as soon as the last linear using them is done

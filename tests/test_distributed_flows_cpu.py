@@ -120,7 +120,8 @@ def _job_awq(rank, world, moa, single):
         yield {"alpha": {n: h.best_alpha for n, h in hs.items()}, "act_scale": {n: h.act_scale.clone() for n, h in hs.items()},
                "loss": {n: h.loss_buf.clone() for n, h in hs.items()}, "amax": _amaxes(model),
                "w": {n: p.detach().clone() for n, p in model.named_parameters()},
-               "contenders": {n: h.contenders for n, h in hs.items()}}
+               "contenders": {n: h.contenders for n, h in hs.items()},
+               "scored_here": {n: (h.use_gram, h.scored_here) for n, h in hs.items()}}
 
 
 def _compare(kind, want, got):
@@ -128,6 +129,8 @@ def _compare(kind, want, got):
         for key in a:
             for name in a[key]:
                 x, y = a[key][name], b[key][name]
+                if key == "scored_here":
+                    continue  # which rank scored a linear is checked across ranks in the worker
                 if key in ("alpha", "contenders"):
                     assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
                 elif key in ("act_scale", "loss") or (kind == "awq" and key in ("amax", "w")):
@@ -149,6 +152,17 @@ def _worker(rank, world, port, kind, ret):
             dist.init_process_group("gloo", rank=rank, world_size=world)
             got = list(job(rank, world, moa, single=False))
         _compare(kind, want, got)
+        if kind == "awq":
+            # Gram-scored linears: every Gram matrix was reduced to ONE rank, which alone evaluated the 11 quadratic forms
+            for g in got:
+                mine = g["scored_here"]
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                for name, (use_gram, _) in mine.items():
+                    n_scorers = sum(int(e[name][1]) for e in everyone)
+                    assert n_scorers == (1 if use_gram else 0), f"{name}: scored on {n_scorers} ranks"
+                if any(u for u, _ in mine.values()):
+                    assert any(s for _, s in mine.values()) or any(s for e in everyone for _, s in e.values())
         # and every rank holds the same state (the reference's property)
         for g in got:
             for key in ("amax", "hist"):
