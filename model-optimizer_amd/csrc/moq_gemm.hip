@@ -57,6 +57,9 @@ template <> struct Geo<4> { static constexpr int TILE = 256, WAVES = 8, WN = 2, 
 //   GEO 5 (experiment): the GEO 4 loop with FOUR waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator registers, one
 //          wave per SIMD): 8 fragment reads per 16 MFMAs instead of 6 per 8 -- a third less LDS read traffic
 template <> struct Geo<5> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
+//   GEO 7 (experiment): GEO 4 with the next tile's eight LDS-DMA pieces issued ONE AT A TIME after every second MFMA of
+//          the first two sub-steps (pinned with sched_barrier) instead of as one block of eight between two MFMA groups
+template <> struct Geo<7> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -220,6 +223,20 @@ __device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, in
 #pragma unroll
       for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[ks][i], b[ks][j], acc[i][j]);
   }
+}
+
+// one LDS-DMA piece: rows rbase .. rbase + 7 of an operand tile for the K-step starting at k0 (stage_tile's loop body)
+__device__ __forceinline__ void stage_piece(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
+                                            int rbase, int lane) {
+  const int r = rbase + (lane >> 3), pos = lane & 7;
+  const int c = pos ^ ((r >> 1) & 7);
+  const int k = k0 + c * 8;
+  const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
+  const i32x4_t rs = desc.words;
+  uint8_t* dst = lds_tile + rbase * kRowBytes;
+  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
 }
 
 // Workgroup -> output tile.  (1) XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a contiguous run of tile ids
@@ -388,7 +405,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 4 || GEO == 5) {
+  if constexpr (GEO == 4 || GEO == 5 || GEO == 7) {
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
     Pack16 a[2][NI], b[2][NJ];
@@ -405,6 +422,22 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[buf][i], b[buf][j], acc[i][j]);
     };
+    // GEO 7: piece p (0..7) of this wave for the tile at `nxt`: A rows, then B rows
+    auto piece = [&](uint8_t* nxt, int k0, int p) {
+      const int rb = (wave * 4 + (p & 3)) * 8;
+      if (p < 4) stage_piece(rs_w, nxt, ld_bytes, k0, K, rb, lane);
+      else stage_piece(rs_x, nxt + TB, ld_bytes, k0, K, rb, lane);
+    };
+    auto mma_sub_staged = [&](int buf, uint8_t* nxt, int k0, int p0, bool on) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        acc[i][0] = mfma32<DT>(a[buf][i], b[buf][0], acc[i][0]);
+        acc[i][1] = mfma32<DT>(a[buf][i], b[buf][1], acc[i][1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (on) piece(nxt, k0, p0 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
@@ -415,6 +448,28 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       __syncthreads();
       read_sub(0, so, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      if constexpr (GEO == 7) {
+        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        const bool more = kt + 1 < nk;
+        const int k0 = (kt + 1) * kBK;
+        if (kt > 0) {
+          mma_sub_staged(1, nxt, k0, 0, more);
+        } else if (more) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) piece(nxt, k0, p);
+        }
+        read_sub(1, so, 1);
+        mma_sub_staged(0, nxt, k0, 4, more);
+        read_sub(0, so, 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+        mma_sub(1);
+        __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+        read_sub(1, so, 3);
+        __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+        mma_sub(0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
+        continue;
+      }
       if (kt > 0) {
         mma_sub(1);  // last sub-step of tile kt - 1, under the reads above
         __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
@@ -542,19 +597,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
 // Hazards.  RAW: wave waits vmcnt at R4(kt) for ALL its pieces of tile kt + 1 (<= 2 newer ones outstanding); group 0
 // reads that tile two barriers later, group 1 three.  WAR: a stage is re-filled only after every reader passed an
 // `s_waitcnt lgkmcnt(0)` (end of each M segment) and a barrier.
-__device__ __forceinline__ void stage_piece(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
-                                            int rbase, int lane) {
-  const int r = rbase + (lane >> 3), pos = lane & 7;
-  const int c = pos ^ ((r >> 1) & 7);
-  const int k = k0 + c * 8;
-  const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
-  const i32x4_t rs = desc.words;
-  uint8_t* dst = lds_tile + rbase * kRowBytes;
-  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
-}
-
 #define MOQ_BAR()                                   \
   do {                                              \
     asm volatile("s_barrier" ::: "memory");         \
@@ -744,7 +786,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 4;
-    return g < 0 || g > 6 ? 4 : g;
+    return g < 0 || g > 7 ? 4 : g;
   }();
   return geo;
 }
@@ -838,6 +880,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 5: launch_geo<MODE, 5>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 7: launch_geo<MODE, 7>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }

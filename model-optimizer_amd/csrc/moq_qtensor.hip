@@ -68,15 +68,12 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
       float v[8];
       unpack<DT>(in[u], v);
       uint32_t b[4] = {0, 0, 0, 0};
-      // one denominator per packet: the shared exact division (moq_common.h) -- bit-identical to `/` while the
-      // numerators stay below 2^16 (checked on the packet's abs-max), the IEEE sequence otherwise
-      const SharedDiv sd = make_shared_div(sc[u]);
-      const bool exact_fast = sd.fast && pack_absmax<DT>(in[u]) <= 0x47800000u;
 #pragma unroll
       for (int i = 0; i < V; i += 2) {
-        const float da = exact_fast ? shared_div(v[i], sd) : v[i] / sc[u];
-        const float db = exact_fast ? shared_div(v[i + 1], sd) : v[i + 1] / sc[u];
-        b[i / 2] = e4m3fn_bytes2(round_to_dtype<DT>(da), round_to_dtype<DT>(db));
+        // IEEE division per element: the shared exact division of the QDQ kernels was tried here (round 2) and
+        // changed nothing -- the packers are not bound by it
+        const float qa = round_to_dtype<DT>(v[i] / sc[u]), qb = round_to_dtype<DT>(v[i + 1] / sc[u]);
+        b[i / 2] = e4m3fn_bytes2(qa, qb);
       }
       if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
       else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
@@ -302,12 +299,9 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_tile_kernel(const void* __res
     float v[8];
     unpack<DT>(in, v);
     uint32_t b[4] = {0, 0, 0, 0};
-    const SharedDiv sd = make_shared_div(sc);  // as in fp8_pack_kernel
-    const bool exact_fast = sd.fast && pack_absmax<DT>(in) <= 0x47800000u;
 #pragma unroll
     for (int i = 0; i < V; i += 2) {
-      float qa = exact_fast ? shared_div(v[i], sd) : v[i] / sc;
-      float qb = exact_fast ? shared_div(v[i + 1], sd) : v[i + 1] / sc;
+      float qa = v[i] / sc, qb = v[i + 1] / sc;
       if constexpr (!PROMOTE) {
         qa = round_to_dtype<DT>(qa);
         qb = round_to_dtype<DT>(qb);
