@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batches", type=int, default=4)
-    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "mxfp4"])
+    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "mxfp4", "mxfp4_sq", "int8_sq"])
     ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
                     help="mixtral: 8 experts per layer with fused 3-D expert weights (Mixtral-8x7B layer shapes)")
     args = ap.parse_args()
@@ -51,7 +51,8 @@ def main():
     torch.cuda.synchronize()
     t_plain = time.perf_counter() - t0
     qcfg = {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
-            "int4_awq": mq.INT4_AWQ_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG}[args.qformat]
+            "int4_awq": mq.INT4_AWQ_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
+            "int8_sq": mq.INT8_SMOOTHQUANT_CFG}[args.qformat]
     t0 = time.perf_counter()
     moa.quantize(model, qcfg, loop)
     torch.cuda.synchronize()
@@ -68,12 +69,19 @@ def main():
     torch.cuda.synchronize()
     t_export = time.perf_counter() - t0
     n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
+    awq = [m.awq_lite for m in model.modules() if hasattr(m, "awq_lite")]
+    extra = {}
+    if awq:
+        alphas = [round(float(h.best_alpha), 1) for h in awq if h.best_alpha is not None]
+        extra = {"awq_rescored_linears": sum(1 for h in awq if h.contenders is not None),
+                 "awq_rescored_candidates": sum(len(h.contenders) for h in awq if h.contenders is not None),
+                 "awq_best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}
     print(json.dumps({"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
                       "plain_forward_loop_s": round(t_plain, 3), "quantize_s": round(t_quant, 3),
                       "fake_quant_forward_s": round(t_fq, 3), "export_state_dict_s": round(t_export, 3),
                       "enabled_quantizers": n_q, "exported_tensors": len(state),
                       "logits_finite": bool(torch.isfinite(logits).all()),
-                      "kv_cache_quant_algo": moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"]}))
+                      "kv_cache_quant_algo": moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"], **extra}))
 
 
 if __name__ == "__main__":
