@@ -41,6 +41,25 @@ def main():
                     worst = max(worst, (dd.max() - dd.min()) / e.min())
             print(f"| {m:g} | {cnt} | {tot} | {worst:.2e} |")
         print()
+        print("| score gap of a candidate pair (relative to the best score) | pairs | max spread of d / gap |")
+        print("|---|---|---|")
+        rows, overturned = [], 0.0
+        for l in lin:
+            g, e = np.array(l["gram_loss"]), np.array(l["loss"])
+            dd = e - g
+            for i in range(len(g)):
+                for j in range(i + 1, len(g)):
+                    gap, spread = abs(g[i] - g[j]) / g.min(), abs(dd[i] - dd[j]) / g.min()
+                    if gap > 0:
+                        rows.append((gap, spread / gap))
+                    if spread >= gap:
+                        overturned = max(overturned, gap)
+        rows = np.array(rows)
+        for lo, hi in ((0, 1e-3), (1e-3, 5e-3), (5e-3, 2e-2), (2e-2, 1e-1), (1e-1, 10)):
+            sel = rows[(rows[:, 0] >= lo) & (rows[:, 0] < hi)]
+            if len(sel):
+                print(f"| [{lo:g}, {hi:g}) | {len(sel)} | {sel[:, 1].max():.3f} |")
+        print(f"\nlargest score gap a rounding spread could overturn (spread >= gap): {overturned:.2e}\n")
 
 
 if __name__ == "__main__":
