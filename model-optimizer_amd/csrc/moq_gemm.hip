@@ -21,6 +21,7 @@
 //
 // Roofline: MFMA-bound.  2 * T * Cout * Cin flop per launch against ~2.5 PFLOP/s dense bf16.
 #include <atomic>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "moq_common.h"
@@ -60,6 +61,15 @@ template <> struct Geo<5> { static constexpr int TILE = 256, WAVES = 4, WN = 2, 
 //   GEO 7 (experiment): GEO 4 with the next tile's eight LDS-DMA pieces issued ONE AT A TIME after every second MFMA of
 //          the first two sub-steps (pinned with sched_barrier) instead of as one block of eight between two MFMA groups
 template <> struct Geo<7> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+//   GEO 10 (experiment): the GEO 4 loop as ONE pinned stream in which every MFMA is followed by one memory instruction --
+//          a fragment read of the NEXT sub-step or an LDS-DMA piece of the next tile (32 MFMAs : 24 reads + 8 pieces per
+//          wave and K-tile = 1 : 1, the recipe of the hand-scheduled kernels); the pieces go out in the first two
+//          sub-steps so that they have two sub-steps of lead before the tile-boundary wait
+template <> struct Geo<10> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+//   GEO 8 / 9 (diagnostics, wrong results by construction -- timing only, tools/gemm_bench.py): the GEO 4 loop with ONLY
+//          its LDS-DMA traffic (8: no fragment reads, no MFMAs) or ONLY its compute (9: no DMA after the prologue)
+template <> struct Geo<8> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+template <> struct Geo<9> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -405,11 +415,12 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 4 || GEO == 5 || GEO == 7) {
+  if constexpr (GEO == 4 || GEO == 5 || GEO == 7 || GEO == 8 || GEO == 9 || GEO == 10) {
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
     Pack16 a[2][NI], b[2][NJ];
     auto read_sub = [&](int buf, int stage_off, int ks) {
+      if constexpr (GEO == 8) return;
       const int c = ks * 2 + fh;
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[buf][i] = read_frag(la0 + stage_off, i * 32 + fr, c);
@@ -417,6 +428,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       for (int j = 0; j < NJ; ++j) b[buf][j] = read_frag(lb0 + stage_off, j * 32 + fr, c);
     };
     auto mma_sub = [&](int buf) {
+      if constexpr (GEO == 8) return;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -448,6 +460,41 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       __syncthreads();
       read_sub(0, so, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
+      if constexpr (GEO == 10) {
+        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        const bool more = kt + 1 < nk;
+        const int k0 = (kt + 1) * kBK;
+        // eight MFMAs of register buffer BUF, each followed by one read of sub-step KS into the other buffer (six) and,
+        // when `on`, by one LDS-DMA piece after every second MFMA (pieces p0 .. p0 + 3)
+        auto group = [&](auto BUF, auto KS, bool on, int p0) {
+          constexpr int buf = decltype(BUF)::value, ks = decltype(KS)::value, nb = buf ^ 1;
+          const int c = ks * 2 + fh;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            acc[n >> 1][n & 1] = mfma32<DT>(a[buf][n >> 1], b[buf][n & 1], acc[n >> 1][n & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (n < 4) a[nb][n] = read_frag(la0 + so, n * 32 + fr, c);
+            else if (n < 6) b[nb][n - 4] = read_frag(lb0 + so, (n - 4) * 32 + fr, c);
+            if (on && (n & 1)) piece(nxt, k0, p0 + (n >> 1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        if (kt > 0) {
+          group(I1{}, I0{}, more, 0);  // last sub-step of tile kt - 1 under the first reads of tile kt
+        } else {
+          read_sub(0, so, 0);
+          if (more) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) piece(nxt, k0, p);
+          }
+        }
+        group(I0{}, I1{}, more, 4);
+        group(I1{}, std::integral_constant<int, 2>{}, false, 0);
+        group(I0{}, std::integral_constant<int, 3>{}, false, 0);
+        continue;
+      }
       if constexpr (GEO == 7) {
         uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
         const bool more = kt + 1 < nk;
@@ -474,7 +521,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
         mma_sub(1);  // last sub-step of tile kt - 1, under the reads above
         __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
       }
-      if (kt + 1 < nk) {  // next tile's DMA: its address arithmetic issues in the gaps of the MFMAs above
+      if (GEO != 9 && kt + 1 < nk) {  // next tile's DMA: its address arithmetic issues in the gaps of the MFMAs above
         uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
         stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
         stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
@@ -786,7 +833,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 4;
-    return g < 0 || g > 7 ? 4 : g;
+    return g < 0 || g > 10 ? 4 : g;
   }();
   return geo;
 }
@@ -880,6 +927,9 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 5: launch_geo<MODE, 5>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 10: launch_geo<MODE, 10>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 8: launch_geo<MODE, 8>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 9: launch_geo<MODE, 9>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 7: launch_geo<MODE, 7>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
