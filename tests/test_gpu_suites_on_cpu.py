@@ -29,7 +29,11 @@ SELECTED = {
     "test_gpu_mse": ["test_mse_calibrator_matches_reference", "test_quantize_mse_flow_matches_reference"],
     "test_gpu_export": ["test_export_from_reference_state_is_byte_identical", "test_fp8_export_from_reference_state_is_byte_identical",
                         "test_mxfp4_export_is_byte_identical", "test_int8_smoothquant_export_from_reference_state_is_byte_identical",
-                        "test_quantize_and_export_end_to_end"],
+                        "test_quantize_and_export_end_to_end",
+                        "test_quantize_and_export_with_replayed_inputs_is_byte_identical",
+                        "test_smoothquant_mxfp4_composition_on_gpu"],
+    "test_gpu_input_quant": ["test_tensor_quantizer_takes_the_fused_pass",
+                             "test_histogram_calibrator_later_batches_are_one_pass"],
     "test_gpu_calibrate_weights": ["test_row_hist_equals_numpy_on_reference_weights", "test_calibrate_weights_matches_reference_run"],
     "test_gpu_fp8_2d": ["test_fp8_qtensor_2d_blocks_match_reference_run", "test_fp8_2d_blockwise_export_is_byte_identical",
                         "test_reduce_block_amax_and_padding"],
