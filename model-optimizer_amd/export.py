@@ -30,6 +30,7 @@ QUANTIZATION_FP8 = "fp8"
 QUANTIZATION_INT8_SQ = "int8_sq"
 QUANTIZATION_INT8_WO = "int8_wo"
 QUANTIZATION_INT4_AWQ = "int4_awq"
+QUANTIZATION_W4A8_AWQ = "w4a8_awq"
 QUANTIZATION_MXFP4 = "mxfp4"
 QUANTIZATION_FP8_PB_WO = "fp8_pb_wo"
 QUANTIZATION_MXFP8 = "mxfp8"
@@ -43,9 +44,13 @@ def get_quantization_format(module) -> str | None:
     if not wq.is_enabled:
         return QUANTIZATION_NONE
     if isinstance(wq, SequentialQuantizer):
-        # W4A8 (INT4 blocks -> FP8) needs its own packing and a second scale (QUANTIZATION_W4A8_AWQ,
-        # export/quant_utils.py:519-526); exporting the first stage alone would silently drop the FP8 stage
-        raise NotImplementedError("export of a SequentialQuantizer weight format (W4A8) is outside this path")
+        # export/quant_utils.py:503-516: INT4 blocks chained with FP8 is W4A8_AWQ -- nibbles packed on the block
+        # scale of stage 0, the per-tensor scale of stage 1 travels as weight_scale_2
+        nbs = [q._num_bits for q in wq]
+        if not (len(wq) == 2 and nbs[0] == 4 and isinstance(nbs[1], (tuple, list)) and tuple(nbs[1]) == (4, 3)):
+            raise NotImplementedError(f"export of the SequentialQuantizer weight format {nbs} is outside this path")
+        assert wq[0].is_static_block_quant and wq[1].block_sizes is None, "Invalid block_sizes for SequentialQuantizer"
+        return QUANTIZATION_W4A8_AWQ
     nb = wq._num_bits
     if nb == 4 and wq.is_static_block_quant:
         return QUANTIZATION_INT4_AWQ
@@ -83,7 +88,35 @@ def get_scaling_factor(quantizer) -> torch.Tensor | None:
 
 
 def get_weight_scaling_factor(module) -> torch.Tensor | None:
-    return get_scaling_factor(module.weight_quantizer)
+    wq = module.weight_quantizer
+    return get_scaling_factor(wq[0] if isinstance(wq, SequentialQuantizer) else wq)  # export/quant_utils.py:277-278
+
+
+def get_weight_scaling_factor_2(module) -> torch.Tensor | None:
+    """export/quant_utils.py:338-345: the scale of the LAST stage of a two-stage sequential weight quantizer."""
+    wq = module.weight_quantizer
+    if not isinstance(wq, SequentialQuantizer) or not wq[-1].is_enabled:
+        return None
+    assert len(wq) == 2, "modelopt only supports 2 sequential quantization layers for now"
+    return get_scaling_factor(wq[-1])
+
+
+def _recollect_weight_amax(module):
+    """"Redo weights collection" (export/quant_utils.py:1297-1301) on the weight quantizer alone; every stage of a
+    sequential quantizer sees the unquantized weight (calibration passes the input through)."""
+    wq = module.weight_quantizer
+    stages = list(wq) if isinstance(wq, SequentialQuantizer) else [wq]
+    state = [q._if_quant for q in stages]
+    for q in stages:
+        q.reset_amax()
+        q.disable_quant()
+        q.enable_calib()
+    wq(module.weight)
+    for q, was_quant in zip(stages, state):
+        q.load_calib_amax()
+        q.disable_calib()
+        if was_quant:
+            q.enable_quant()
 
 
 @torch.no_grad()
@@ -93,17 +126,7 @@ def _update_pre_quant_scale(module, new_pre_quant_scale: torch.Tensor):
     old = module.input_quantizer._pre_quant_scale
     ops.rescale_cols(module.weight.data, old, new_pre_quant_scale, out=module.weight.data)
     module.input_quantizer.pre_quant_scale = new_pre_quant_scale
-    # "Redo weights collection" (:1297-1301) on the weight quantizer alone
-    wq = module.weight_quantizer
-    wq.reset_amax()
-    was_quant = wq._if_quant
-    wq.disable_quant()
-    wq.enable_calib()
-    wq(module.weight)
-    wq.load_calib_amax()
-    wq.disable_calib()
-    if was_quant:
-        wq.enable_quant()
+    _recollect_weight_amax(module)
 
 
 @torch.no_grad()
@@ -129,7 +152,13 @@ def preprocess_linear_fusion(modules, resmooth_only: bool = False):
         for m in modules:
             m.input_quantizer.amax = input_amax
     wq0 = modules[0].weight_quantizer
-    if wq0.is_enabled and wq0.amax is not None and wq0.amax.numel() == 1:
+    if isinstance(wq0, SequentialQuantizer):  # :1515-1524: the per-tensor FP8 stage is unified, the blocks are not
+        if wq0[-1].is_enabled:
+            assert len(wq0) == 2
+            weight_amax = torch.max(torch.stack([m.weight_quantizer[-1].amax for m in modules]))
+            for m in modules:
+                m.weight_quantizer[-1].amax = weight_amax
+    elif wq0.is_enabled and wq0.amax is not None and wq0.amax.numel() == 1:
         weight_amax = torch.max(torch.stack([m.weight_quantizer.amax for m in modules]))
         for m in modules:
             m.weight_quantizer.amax = weight_amax
@@ -217,7 +246,7 @@ def requantize_resmooth_fused_llm_layers(model, dummy_forward_fn):
 @torch.no_grad()
 def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
     """export/quant_utils.py:836-938 for the formats of this path."""
-    if quantization == QUANTIZATION_INT4_AWQ:
+    if quantization in (QUANTIZATION_INT4_AWQ, QUANTIZATION_W4A8_AWQ):  # :911-912
         return ops.pack_int4_in_uint8(weight, weights_scaling_factor)
     wsf = weights_scaling_factor.to(weight.device)
     if quantization == QUANTIZATION_FP8:
@@ -406,6 +435,8 @@ def export_quantized_weight(module, dtype: torch.dtype):
         out["input_scale"] = get_scaling_factor(iq).squeeze()
     out["weight"] = to_quantized_weight(module.weight.detach().to(dtype), weight_scale, fmt)
     out["weight_scale"] = weight_scale
+    if fmt == QUANTIZATION_W4A8_AWQ:  # unified_export_hf.py:696-709
+        out["weight_scale_2"] = get_weight_scaling_factor_2(module).squeeze()
     pqs = getattr(iq, "_pre_quant_scale", None)
     if pqs is not None:  # unified_export_hf.py:1121-1138: promoted to <module>.pre_quant_scale
         out["pre_quant_scale"] = pqs.detach().clone()
@@ -509,11 +540,11 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
 def hf_quant_config(model, group_size: int | None = None) -> dict:
     """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
     fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
-    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_MXFP8: "MXFP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
+    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_W4A8_AWQ: "W4A8_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_MXFP8: "MXFP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
             QUANTIZATION_INT8_WO: "W8A16"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
     q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}
-    if fmt == QUANTIZATION_INT4_AWQ:
+    if fmt in (QUANTIZATION_INT4_AWQ, QUANTIZATION_W4A8_AWQ):
         q.update(group_size=group_size or 128, has_zero_point=False, pre_quant_scale=True)
     return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}
 

@@ -372,6 +372,8 @@ class AWQLiteHelper:
         self.best_alpha = None
         self.best_scale = None
         self.is_enabled = True  # False: NaN in a scale on some rank, or no tokens anywhere (:1605-1629)
+        self.is_input_quantized = False  # set by awq_lite's setup (:1432)
+        self.setup_disabled = False  # an input quantizer with a channel axis other than the last one (:1441-1443)
         # search-pass caches (alpha -> tensors); scales depend on alpha only once act_scale is final
         self._inv_scale = None
         self._scale_dt = None
@@ -508,21 +510,31 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         raise ValueError(f"awq_lite: unknown search mode {search!r}")
     mods = [(n, m) for n, m in model.named_modules()
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
-    for n, m in mods:
-        if m.input_quantizer.is_enabled:
-            # the reference max-calibrates such inputs in the cache pass and searches on the quantized activations
-            # (is_input_quantized, :1427, :1527-1531); that branch (W4A8 AWQ) is outside this path
-            raise MoquantUnsupported(f"awq_lite: {n}: the AWQ search with an enabled input quantizer is outside this "
-                                     "path; disable the input quantizers of the searched linears")
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
+    for _, m in mods:
+        # quantized inputs (W4A8 AWQ; setup, :1436-1444): the input quantizer is bypassed for the whole search -- the
+        # losses are taken on UNquantized activations -- and max-calibrated per input channel in the cache pass; the
+        # per-tensor amax it ends up with is that of the smoothed activation, max_c(amax_c * pre_quant_scale_c)
+        h, iq = helpers[m], m.input_quantizer
+        h.is_input_quantized = iq.is_enabled
+        if h.is_input_quantized:
+            iq.disable()
+            if iq.axis not in (None, -1):
+                h.is_enabled = False
+                h.setup_disabled = True
+            else:
+                iq.axis = -1
     state = {"mode": "cache", "do_gemm": True, "do_exact": False}
     if mods:
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
             h = helpers[m]
             cin = m.weight.shape[1]
-            fits = search != "gemm" and cin % 4 == 0 and budget.reserve(4 * cin * cin)
-            if fits or (search == "gram" and cin % 4 == 0):
+            # ragged rows (Cin not a multiple of the block: the reference zero-pads, tensor_quantizer.py:712-745) stay
+            # on the error-GEMM engine, whose QDQ operand kernel pads the same way
+            gram_ok = cin % 4 == 0 and cin % h.block_size == 0
+            fits = search != "gemm" and gram_ok and budget.reserve(4 * cin * cin)
+            if fits or (search == "gram" and gram_ok):
                 h.gram = torch.zeros(cin, cin, dtype=torch.float32, device=m.weight.device)
                 h.gram_bytes = 4 * cin * cin if fits else 0
                 h.use_gram = True
@@ -586,7 +598,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
     def patched_forward(self, input):
         h = helpers[self]
         out_actual = F.linear(input, self.weight, self.bias)
-        if input.numel() == 0:
+        if input.numel() == 0 or h.setup_disabled:
             return out_actual
         x2 = input.reshape(-1, input.shape[-1])
         if state["mode"] == "cache":
@@ -594,6 +606,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             ops.col_abs_mean_accum(x2, h.act_sum)
             h.num_cache_steps += 1
             h.num_tokens += x2.shape[0]
+            if h.is_input_quantized:  # :1534-1538: running per-channel amax of the raw input
+                iq = self.input_quantizer
+                iq.enable()
+                max_calibrate(iq, lambda q: q(input), distributed_sync=False)
+                iq.disable()
         if state["mode"] == state["gram_pass"] and h.gram is not None and h.is_enabled:
             accumulate_gram(h, input, x2)
         if state["mode"] == "cache" or not h.is_enabled:
@@ -729,6 +746,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         if others and dist.is_available() and dist.is_initialized():
             mdist.sync_amax_bucketed([q for q in others if not q._dynamic],
                                      device=mods[0][1].weight.device if mods else None)
+        if dist.is_available() and dist.is_initialized():
+            # the per-channel input amax of W4A8 linears is synchronised like any other amax (:1581-1586, :396-398)
+            chan = [m.input_quantizer for _, m in mods if helpers[m].is_input_quantized]
+            if chan:
+                mdist.sync_amax_bucketed(chan, device=mods[0][1].weight.device)
         if state["gram_pass"] == "cache":
             finish_gram_pass()
         for h in helpers.values():
@@ -800,6 +822,20 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for h in helpers.values():
             h.release()
             h.gram = None
+    def restore_input_quantizer(m, h):
+        """:1642-1653 / :1707-1714: the per-channel amax is kept (on the host) for the smoothing step and collapses to
+        the per-tensor amax the quantizer is exported with; a dynamic input quantizer is just re-enabled."""
+        iq = m.input_quantizer
+        if not h.is_input_quantized:
+            return
+        if iq.amax is not None:
+            act_amax = iq.amax
+            iq._amax_for_smoothing = act_amax.cpu()
+            iq.reset_amax()
+            iq.axis = None
+            iq.amax = act_amax.amax()
+        iq.enable()
+
     for name, m in mods:
         h = helpers[m]
         if h.is_enabled and h.search_steps_all_ranks == 0:
@@ -819,6 +855,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             m.input_quantizer._enable_pre_quant_scale = True
             m.input_quantizer.pre_quant_scale = torch.ones(m.weight.shape[1], dtype=m.weight.dtype,
                                                            device=m.weight.device)
+            restore_input_quantizer(m, h)
             continue
         if h.contenders is not None and h.exact_steps_all_ranks > 0:
             # near-ties: the exact scores replace the Gram scores of the re-scored candidates and decide among them
@@ -844,6 +881,12 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         max_calibrate(m, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
         m.input_quantizer._enable_pre_quant_scale = True
         m.input_quantizer.pre_quant_scale = pre_quant_scale.to(m.weight.dtype)
+        restore_input_quantizer(m, h)
+        iq = m.input_quantizer
+        if h.is_input_quantized and iq.amax is not None:
+            # :1257-1265: amax of the smoothed activation, the product taken in the weight dtype
+            smooth = iq._amax_for_smoothing.to(device=m.weight.device, dtype=m.weight.dtype)
+            iq.amax = (smooth * pre_quant_scale.to(m.weight.device)).amax().to(m.weight.dtype)
     return helpers
 
 

@@ -3,6 +3,7 @@
 
 from __future__ import annotations
 
+import copy
 import fnmatch
 import re
 
@@ -66,11 +67,13 @@ MXINT8_DEFAULT_CFG = _mx_cfg(8)      # presets/model/mxint8.yaml
 # what runs here is its fake quantization and calibration (no packed export)
 _NVFP4_Q = {"num_bits": (2, 1), "axis": None, "block_sizes": {-1: 16, "type": "dynamic", "scale_bits": (4, 3)}}
 NVFP4_DEFAULT_CFG = _preset({"*weight_quantizer": dict(_NVFP4_Q), "*input_quantizer": dict(_NVFP4_Q)}, "max")
-# presets/model/w4a8_awq_beta.yaml quantizer layout (INT4 blocks then FP8 on the weights, FP8 inputs); calibrated with
-# "max" here -- the AWQ search with quantized inputs is outside this path
-W4A8_MAX_CFG = _preset({"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
-                                              {"num_bits": (4, 3), "axis": None}],
-                        "*input_quantizer": {"num_bits": (4, 3), "axis": None}}, "max")
+# presets/model/w4a8_awq_beta.yaml: INT4 blocks then FP8 on the weights, FP8 inputs; AWQ-lite searches on the INT4
+# stage with the input quantizers bypassed and max-calibrated per channel (model_calib.awq_lite)
+_W4A8_Q = {"*weight_quantizer": [{"num_bits": 4, "block_sizes": {-1: 128, "type": "static"}},
+                                 {"num_bits": (4, 3), "axis": None}],
+           "*input_quantizer": {"num_bits": (4, 3), "axis": None}}
+W4A8_AWQ_BETA_CFG = _preset(copy.deepcopy(_W4A8_Q), "awq_lite")
+W4A8_MAX_CFG = _preset(copy.deepcopy(_W4A8_Q), "max")  # the same layout, max calibration only
 INT8_SMOOTHQUANT_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
                                 "*input_quantizer": {"num_bits": 8, "axis": None}},
                                {"method": "smoothquant", "alpha": 1.0})

@@ -664,7 +664,7 @@ def gen_mse(out):
     out["cases"] = np.array(json.dumps(cases))
 
 
-def gen_export(out, capture=None):
+def gen_export(out, capture=None, preset="INT4_AWQ_CFG"):
     """INT4-AWQ checkpoint export of a tiny bf16 Llama by the reference (mtq.quantize(INT4_AWQ_CFG) +
     export_hf_checkpoint, export/unified_export_hf.py:1491): the original weights + calibration tokens (for the
     end-to-end test), the calibrated state right before export (folded weights, pre_quant_scales, per-block amax,
@@ -693,7 +693,9 @@ def gen_export(out, capture=None):
             if isinstance(m, torch.nn.Linear):
                 m.register_forward_pre_hook(lambda mod, args, n=n: calls.setdefault(n, []).append(args[0].detach().clone()))
     import copy as _copy
-    awq_cfg = _copy.deepcopy(mtq.INT4_AWQ_CFG)
+    awq_cfg = _copy.deepcopy(getattr(mtq, preset))
+    if isinstance(awq_cfg["algorithm"], str):
+        awq_cfg["algorithm"] = {"method": awq_cfg["algorithm"]}
     awq_cfg["algorithm"]["debug"] = True  # keeps module.awq_lite (best_alpha) after calibration
     q = mtq.quantize(model, awq_cfg, lambda m: [m(b) for b in batches])
     linears = []
@@ -701,7 +703,12 @@ def gen_export(out, capture=None):
         if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
             linears.append(n)
             out[f"pre/{n}.weight"] = bits(m.weight)
-            out[f"pre/{n}.amax"] = bits(m.weight_quantizer._amax)
+            stages = list(m.weight_quantizer) if preset != "INT4_AWQ_CFG" else [m.weight_quantizer]
+            out[f"pre/{n}.amax"] = bits(stages[0]._amax)
+            if len(stages) > 1:  # W4A8: the FP8 stage's per-tensor amax and the collapsed input amax
+                out[f"pre/{n}.amax2"] = bits(stages[1]._amax.float())
+                out[f"pre/{n}.in_amax"] = bits(m.input_quantizer._amax.float())
+                out[f"pre/{n}.in_amax_channels"] = bits(m.input_quantizer._amax_for_smoothing.float())
             out[f"pre/{n}.pre_quant_scale"] = bits(m.input_quantizer._pre_quant_scale)
             out[f"pre/{n}.best_alpha"] = np.array(float(m.awq_lite.best_alpha) if hasattr(m, "awq_lite") else -1.0)
             if capture is not None:
@@ -729,6 +736,30 @@ def gen_export(out, capture=None):
         quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
     out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), linears=linears, dtypes=dtypes,
                                              hf_quant_config=quant_cfg)))
+
+
+def gen_export_w4a8(out):
+    """W4A8_AWQ_BETA_CFG (INT4 blocks -> FP8 weights, FP8 inputs, awq_lite) on the SAME model, tokens and -- asserted
+    here -- the same per-linear inputs as export_llama.npz / export_llama_replay.npz: the input quantizers are bypassed
+    in both calibration passes (model_calib.py:1436-1444), so the replay data serves this run too.  Stored: what differs
+    from the INT4 run -- the exported tensors, the quantizer state right before export and hf_quant_config."""
+    full, cap = {}, {}
+    gen_export(full, capture=cap, preset="W4A8_AWQ_BETA_CFG")
+    base = np.load(os.path.join(HERE, "export_llama.npz"))
+    replay = np.load(os.path.join(HERE, "export_llama_replay.npz"))
+    rc = json.loads(str(replay["cases"]))
+    for k in base.files:
+        if k.startswith(("orig/", "tokens")):
+            assert np.array_equal(base[k], full[k]), k
+    for n in rc["linears"]:
+        for b in range(rc["n_batches"]):
+            owner = rc["alias"].get(n, n)
+            assert np.array_equal(replay[f"in/{owner}/{b}"], bits(cap[f"in/{n}/{b}"])), (n, b)
+        assert np.array_equal(replay[f"ref/{n}.act_scale"], cap[f"ref/{n}.act_scale"]), n
+        assert float(full[f"pre/{n}.best_alpha"]) == float(base[f"pre/{n}.best_alpha"]), n
+    for k, v in full.items():
+        if k.startswith("exp/") or k == "cases" or k.endswith((".amax2", ".in_amax", ".in_amax_channels")):
+            out[k] = v
 
 
 def gen_export_replay(out):
@@ -1126,11 +1157,11 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

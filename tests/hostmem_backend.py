@@ -244,10 +244,16 @@ class HostMemLib:
         return OK
 
     def moq_awq_scale_qdq(self, w, s, y, rows, cols, g, dt, num_bits, stream):
+        if rows < 0 or cols <= 0 or g <= 0 or cols % g != 0:  # the C-ABI's own argument check (moq_stream.hip)
+            self._err = b"moq_awq_scale_qdq: cols must be a positive multiple of g"
+            return -1
         self.o.orc_awq_scale_qdq(_vp(w), _vp(s), _vp(y), I64(rows), I64(cols), int(g), int(dt), int(num_bits))
         return OK
 
     def moq_awq_weight_scale(self, w, rows, cols, g, dt, out, workspace, stream):
+        if rows < 0 or cols <= 0 or g <= 0 or cols % g != 0:  # moq_reduce.hip: needs cols % g == 0
+            self._err = b"moq_awq_weight_scale: needs cols % g == 0"
+            return -1
         self.o.orc_awq_weight_scale(_vp(w), I64(rows), I64(cols), int(g), int(dt), _vp(out))
         return OK
 

@@ -62,6 +62,18 @@ def stage_report(q, g, replay):
     return out
 
 
+def check_w4a8_state(q, g):
+    """Quantizer state of a W4A8-AWQ run right before export against gen_golden.gen_export_w4a8's record."""
+    for name in g.cases["linears"]:
+        lin = q.get_submodule(name)
+        iq, stages = lin.input_quantizer, list(lin.weight_quantizer)
+        assert iq.is_enabled and iq.axis is None, name
+        for what, got, key in [("per-channel input amax", iq._amax_for_smoothing, "in_amax_channels"),
+                               ("input amax", iq._amax, "in_amax"), ("FP8 stage amax", stages[1]._amax, "amax2")]:
+            want = from_bits(g.raw(f"pre/{name}.{key}"), torch.float32).reshape(-1)
+            assert torch.equal(got.detach().float().cpu().reshape(-1), want), f"{name}: {what} differs"
+
+
 def pin_host_pow(monkeypatch, replay):
     """get_scale's pow / divide run in torch's HOST math library (model_calib.get_scale), whose last bit depends on the
     CPU's vector ISA (Sleef AVX2 vs AVX-512 vs the scalar tail): third-party arithmetic outside the path, like the

@@ -150,6 +150,8 @@ SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
     ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "phi3", None),
     ("INT4_AWQ_CFG", torch.bfloat16, False, "gpt2", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "gemma2", None),
     ("INT4_AWQ_CFG", torch.float16, True, "mistral", None),
+    # W4A8 AWQ: INT4 -> FP8 sequential weight quantizers, per-channel input calibration collapsed after the search
+    ("W4A8_AWQ_BETA_CFG", torch.bfloat16, False, "llama", None), ("W4A8_AWQ_BETA_CFG", torch.float16, True, "qwen2", None),
     ("MXFP8_DEFAULT_CFG", torch.bfloat16, False, "llama", None), ("MXFP8_DEFAULT_CFG", torch.float16, True, "qwen2", None),
     ("MXFP8_DEFAULT_CFG", torch.float32, False, "opt", None),
 ])

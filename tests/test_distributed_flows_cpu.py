@@ -110,9 +110,11 @@ def _job_awq(rank, world, moa, single):
     of the ranks' means, the per-alpha losses are summed, every rank picks the single-rank run's alpha and folds the
     same weights."""
     mq = moa.model_quant
-    for search, dtype in (("auto", torch.bfloat16), ("gemm", torch.bfloat16), ("gram", torch.float32)):
-        cfg = copy.deepcopy(mq.INT4_AWQ_CFG)
-        cfg["algorithm"]["search"] = search
+    for search, dtype, preset in (("auto", torch.bfloat16, "INT4_AWQ_CFG"), ("gemm", torch.bfloat16, "INT4_AWQ_CFG"),
+                                  ("gram", torch.float32, "INT4_AWQ_CFG"), ("auto", torch.bfloat16, "W4A8_AWQ_BETA_CFG")):
+        # W4A8: the per-channel input amax collected in the cache pass is MAX-synchronised before it collapses
+        cfg = copy.deepcopy(getattr(mq, preset))
+        cfg["algorithm"] = {"method": "awq_lite", "search": search}
         batches = _batches(128, dtype)
         mine = batches if single else batches[rank::world]
         model = moa.quantize(MLP(dtype=dtype), cfg, lambda m: [m(b) for b in mine])
@@ -121,6 +123,8 @@ def _job_awq(rank, world, moa, single):
                "loss": {n: h.loss_buf.clone() for n, h in hs.items()}, "amax": _amaxes(model),
                "w": {n: p.detach().clone() for n, p in model.named_parameters()},
                "contenders": {n: h.contenders for n, h in hs.items()},
+               "chan_amax": {n: m.input_quantizer._amax_for_smoothing.clone() for n, m in model.named_modules()
+                             if hasattr(m, "awq_lite") and hasattr(m.input_quantizer, "_amax_for_smoothing")},
                "scored_here": {n: (h.use_gram, h.scored_here) for n, h in hs.items()}}
 
 

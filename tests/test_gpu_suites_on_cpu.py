@@ -31,6 +31,7 @@ SELECTED = {
                         "test_mxfp4_export_is_byte_identical", "test_int8_smoothquant_export_from_reference_state_is_byte_identical",
                         "test_quantize_and_export_end_to_end",
                         "test_quantize_and_export_with_replayed_inputs_is_byte_identical",
+    "test_w4a8_awq_with_replayed_inputs_is_byte_identical",
                         "test_smoothquant_mxfp4_composition_on_gpu"],
     "test_gpu_input_quant": ["test_tensor_quantizer_takes_the_fused_pass",
                              "test_histogram_calibrator_later_batches_are_one_pass"],

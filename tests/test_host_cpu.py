@@ -388,13 +388,15 @@ def test_host_helpers_agree_with_the_reference_functions():
 
 
 def test_export_refuses_formats_it_does_not_pack():
-    """get_quantization_format: a W4A8 SequentialQuantizer weight format raises instead of exporting its first stage
-    only; disabled weight quantizers export the plain weight; NVFP4-layout blocks are refused too."""
+    """get_quantization_format: INT4 -> FP8 sequential weight quantizers are W4A8_AWQ, any other chain raises instead of
+    exporting its first stage only; disabled weight quantizers export the plain weight; NVFP4-layout blocks are refused."""
     from model_optimizer_amd import export, nn as mnn
     m = torch.nn.Sequential(torch.nn.Linear(128, 64, bias=False))
     mnn.replace_quant_module(m)
     model_quant.set_quantizer_by_cfg(m, model_quant.W4A8_MAX_CFG["quant_cfg"])
-    with pytest.raises(NotImplementedError, match="W4A8"):
+    assert export.get_quantization_format(m[0]) == "w4a8_awq"
+    model_quant.set_quantizer_by_cfg(m, {"*weight_quantizer": [{"num_bits": 8, "axis": 0}, {"num_bits": (4, 3), "axis": None}]})
+    with pytest.raises(NotImplementedError, match="SequentialQuantizer"):
         export.get_quantization_format(m[0])
     model_quant.set_quantizer_by_cfg(m, {"*weight_quantizer": {"enable": False}})
     assert export.get_quantization_format(m[0]) is export.QUANTIZATION_NONE

@@ -324,17 +324,44 @@ def test_awq_lite_near_tie_is_rescored_like_the_reference_structure(hostmem, mon
         assert hi.gram_loss is not None and len(hi.gram_loss) == 11
 
 
-def test_awq_lite_refuses_enabled_input_quantizers(hostmem):
-    """The W4A8 AWQ branch (inputs calibrated in the cache pass, search on quantized activations) is outside this path
-    and must say so instead of leaving the input quantizers uncalibrated."""
-    from model_optimizer_amd._lib import MoquantUnsupported
+def test_awq_lite_with_quantized_inputs(hostmem):
+    """W4A8-style AWQ (model_calib.py:1432-1444, :1534-1538, :1642-1653, :1257-1265): the input quantizer is bypassed
+    during the search (same alphas as the weight-only run), max-calibrated per channel in the cache pass, and ends up
+    enabled with the per-tensor amax of the SMOOTHED activation; a channel axis other than the last one switches the
+    search off for that linear (neutral pre_quant_scale)."""
+    shapes = [(64, 128), (96, 256)]
+    b = _flat_batches(shapes, torch.float32, 2, 16, 1, 0.1)
 
-    model = _FlatStack([(64, 128)], torch.float32, 0)
-    cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
-    cfg["quant_cfg"]["*input_quantizer"] = {"num_bits": 8, "axis": None, "enable": True}
-    b = _flat_batches([(64, 128)], torch.float32, 1, 16, 1, 0.1)
-    with pytest.raises(MoquantUnsupported):
+    def run(input_cfg):
+        model = _FlatStack(shapes, torch.float32, 0)
+        cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+        if input_cfg is not None:
+            cfg["quant_cfg"]["*input_quantizer"] = input_cfg
         moa.quantize(model, cfg, lambda m: [m(x) for x in b])
+        return model
+
+    plain = run(None)
+    quant = run({"num_bits": 8, "axis": None, "enable": True})
+    lin_p = [m for m in plain.modules() if hasattr(m, "awq_lite")]
+    lin_q = [m for m in quant.modules() if hasattr(m, "awq_lite")]
+    assert len(lin_q) == len(shapes)
+    for mp, mq_ in zip(lin_p, lin_q):
+        assert mq_.awq_lite.is_input_quantized and not mp.awq_lite.is_input_quantized
+        assert mq_.awq_lite.best_alpha == mp.awq_lite.best_alpha
+        assert torch.equal(mq_.weight, mp.weight) and torch.equal(mq_.weight_quantizer.amax, mp.weight_quantizer.amax)
+        iq = mq_.input_quantizer
+        assert iq.is_enabled and iq.axis is None and iq.amax.numel() == 1
+        per_channel = iq._amax_for_smoothing.reshape(-1)
+        assert per_channel.numel() == mq_.weight.shape[1]
+        assert torch.equal(iq.amax.reshape(()), (per_channel * iq.pre_quant_scale.reshape(-1)).amax())
+    for i, m in enumerate(lin_q):  # per-channel amax = column-wise abs-max over all batches of that linear's input
+        want = torch.stack([xs[i].reshape(-1, xs[i].shape[-1]).abs().amax(0) for xs in b]).amax(0)
+        assert torch.equal(m.input_quantizer._amax_for_smoothing.reshape(-1), want)
+    with pytest.warns(UserWarning, match="Forcing pre_quant_scale=1"):
+        off = run({"num_bits": 8, "axis": 0, "enable": True})
+    for m in (m for m in off.modules() if hasattr(m, "awq_lite")):
+        assert not m.awq_lite.is_enabled and m.awq_lite.best_alpha is None
+        assert torch.all(m.input_quantizer.pre_quant_scale == 1) and m.input_quantizer.is_enabled
 
 
 def test_int4_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, hostmem):
@@ -351,6 +378,35 @@ def test_int4_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, host
     assert not any(report.values()), {k: v for k, v in report.items() if v}
     state = moa.export.export_state_dict(q, torch.bfloat16, lambda: q(torch.ones([1, 2], dtype=torch.long)))
     _compare_state(state, g, g.cases)
+
+
+def test_w4a8_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, hostmem):
+    """W4A8_AWQ_BETA_CFG (INT4 blocks -> FP8 weights, FP8 inputs) end to end with the reference run's per-linear inputs
+    replayed (the input quantizers are bypassed in both passes, so the INT4 run's replay data is this run's too -- asserted
+    by gen_golden.gen_export_w4a8): per-channel input amax, its collapse to the smoothed per-tensor amax, the FP8 stage's
+    amax and every byte of the exported checkpoint (weight_scale_2, input_scale included) equal the reference's."""
+    import replay_common
+
+    base, r, g = golden("export_llama"), golden("export_llama_replay"), golden("export_llama_w4a8")
+    model = _llama(base, base.cases, torch.bfloat16)
+    with torch.no_grad():
+        q = moa.quantize(model, moa.model_quant.W4A8_AWQ_BETA_CFG, replay_common.replay_loop(r, "cpu"))
+    replay_common.check_w4a8_state(q, g)
+    state = moa.export.export_state_dict(q, torch.bfloat16, lambda: q(torch.ones([1, 2], dtype=torch.long)))
+    _compare_state(state, g, g.cases)
+    assert any(k.endswith("weight_scale_2") for k in state) and any(k.endswith("input_scale") for k in state)
+    assert moa.export.hf_quant_config(q)["quantization"]["quant_algo"] == g.cases["hf_quant_config"]["quantization"]["quant_algo"]
+
+
+def test_awq_lite_ragged_input_width_fails_loudly(hostmem):
+    """Cin that is not a multiple of the INT4 block: the kernels have no padded-block layout (the reference zero-pads,
+    tensor_quantizer.py:712-745) -- the C-ABI's argument check surfaces instead of a search on garbage."""
+    from model_optimizer_amd._lib import MoquantError
+
+    model = _FlatStack([(128, 64)], torch.float32, 0)
+    b = _flat_batches([(128, 64)], torch.float32, 1, 16, 1, 0.1)
+    with pytest.raises(MoquantError, match="cols % g"):
+        moa.quantize(model, moa.model_quant.INT4_AWQ_CFG, lambda m: [m(x) for x in b])
 
 
 def test_tensor_quantizer_fused_input_pass_equals_unfused_chain(hostmem):
