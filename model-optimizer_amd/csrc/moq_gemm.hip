@@ -61,7 +61,7 @@ template <> struct Geo<5> { static constexpr int TILE = 256, WAVES = 4, WN = 2, 
 //   GEO 7 (experiment): GEO 4 with the next tile's eight LDS-DMA pieces issued ONE AT A TIME after every second MFMA of
 //          the first two sub-steps (pinned with sched_barrier) instead of as one block of eight between two MFMA groups
 template <> struct Geo<7> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-//   GEO 10 (experiment): the GEO 4 loop as ONE pinned stream in which every MFMA is followed by one memory instruction --
+//   GEO 10 (default): the GEO 4 loop as ONE pinned stream in which every MFMA is followed by one memory instruction --
 //          a fragment read of the NEXT sub-step or an LDS-DMA piece of the next tile (32 MFMAs : 24 reads + 8 pieces per
 //          wave and K-tile = 1 : 1, the recipe of the hand-scheduled kernels); the pieces go out in the first two
 //          sub-steps so that they have two sub-steps of lead before the tile-boundary wait
@@ -87,6 +87,7 @@ __device__ __forceinline__ f32x16_t mfma32(const Pack16& a, const Pack16& b, f32
 }
 
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
+template <int V> using IC = std::integral_constant<int, V>;
 typedef __attribute__((address_space(3))) uint8_t* lds_u8_t;
 
 // One operand tile (TILE rows x 64 k) HBM -> LDS.  `rsrc` covers the tile's valid rows only (base = first row
@@ -434,21 +435,65 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[buf][i], b[buf][j], acc[i][j]);
     };
-    // GEO 7: piece p (0..7) of this wave for the tile at `nxt`: A rows, then B rows
-    auto piece = [&](uint8_t* nxt, int k0, int p) {
-      const int rb = (wave * 4 + (p & 3)) * 8;
-      if (p < 4) stage_piece(rs_w, nxt, ld_bytes, k0, K, rb, lane);
-      else stage_piece(rs_x, nxt + TB, ld_bytes, k0, K, rb, lane);
-    };
-    auto mma_sub_staged = [&](int buf, uint8_t* nxt, int k0, int p0, bool on) {
+    // LDS-DMA piece p (0..7) of this wave for the tile in stage `sn`: 8 rows of W (p < 4) or of x (p >= 4).  Everything
+    // that does not change from tile to tile is computed once: the LDS base of the wave's rows as a 32-bit LDS address
+    // (no generic -> local cast, whose null check costs ~8 instructions per piece) and the lane's byte offset inside the
+    // operand tile for k0 = 0 (W and x have the same row pitch, so one set serves both).  The tile's k offset travels in
+    // the instruction's SCALAR offset, which the descriptor's range check ignores: rows past the matrix edge still read
+    // as zero.  The ragged last tile (K % 64 != 0) swaps in a second offset set whose chunks at or past K point out of
+    // range (one v_cndmask on a wave-uniform condition).  `live` = false (no next tile): the piece still issues --
+    // against an empty descriptor, filling its rows of the idle stage with zeros -- instead of branching around every
+    // piece of the pinned streams.  Three to four instructions per piece, no branch, one VALU.
+    constexpr bool kFourPerOperand = Geo<GEO>::WAVES == 8;
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * 4 * 8 * kRowBytes));
+    const bool k_ragged = (K & (kBK - 1)) != 0;
+    int voff[4], voff_tail[4];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        acc[i][0] = mfma32<DT>(a[buf][i], b[buf][0], acc[i][0]);
-        acc[i][1] = mfma32<DT>(a[buf][i], b[buf][1], acc[i][1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (on) piece(nxt, k0, p0 + i);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int j = 0; j < 4; ++j) {
+      const int r = (wave * 4 + j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      voff[j] = (int)(r * ld_bytes + c * 16);
+      voff_tail[j] = (nk - 1) * kBK + c * 8 < K ? voff[j] : 0x7FFFFFF0;
+    }
+    const i32x4_t rsw = rs_w.words, rsx = rs_x.words;
+    auto piece = [&](int sn, int k0, auto P, bool live = true) {  // P: compile-time piece index (register selection)
+      constexpr int p = decltype(P)::value, j = p & 3;
+      const uint32_t m0v = lds_wave + (uint32_t)(sn * SB + (p < 4 ? 0 : TB) + j * 8 * kRowBytes);
+      const int koff = k0 * 2;
+      // (operands copied to locals first: clang rejects captured variables named directly in an asm statement of a
+      // generic lambda)
+      const int vfull = voff[j], vtail = voff_tail[j];
+      const int vo = (k_ragged && k0 + kBK > K) ? vtail : vfull;
+      i32x4_t rr = p < 4 ? rsw : rsx;
+      rr.z = live ? rr.z : 0;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
+    };
+    // (piece indices must be compile-time constants: they select the lane-offset register)
+    auto mma_sub_staged = [&](int buf, int sn, int k0, auto P0, bool on) {
+      constexpr int p0 = decltype(P0)::value;
+      static_assert(NI == 4, "one piece after every second MFMA");
+      acc[0][0] = mfma32<DT>(a[buf][0], b[buf][0], acc[0][0]);
+      acc[0][1] = mfma32<DT>(a[buf][0], b[buf][1], acc[0][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(sn, k0, IC<p0 + 0>{}, on);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1][0] = mfma32<DT>(a[buf][1], b[buf][0], acc[1][0]);
+      acc[1][1] = mfma32<DT>(a[buf][1], b[buf][1], acc[1][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(sn, k0, IC<p0 + 1>{}, on);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[2][0] = mfma32<DT>(a[buf][2], b[buf][0], acc[2][0]);
+      acc[2][1] = mfma32<DT>(a[buf][2], b[buf][1], acc[2][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(sn, k0, IC<p0 + 2>{}, on);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[3][0] = mfma32<DT>(a[buf][3], b[buf][0], acc[3][0]);
+      acc[3][1] = mfma32<DT>(a[buf][3], b[buf][1], acc[3][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      piece(sn, k0, IC<p0 + 3>{}, on);
+      __builtin_amdgcn_sched_barrier(0);
     };
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
@@ -461,52 +506,56 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       read_sub(0, so, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
       if constexpr (GEO == 10) {
-        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        const int sn = (kt + 1) & 1;
         const bool more = kt + 1 < nk;
         const int k0 = (kt + 1) * kBK;
-        // eight MFMAs of register buffer BUF, each followed by one read of sub-step KS into the other buffer (six) and,
-        // when `on`, by one LDS-DMA piece after every second MFMA (pieces p0 .. p0 + 3)
-        auto group = [&](auto BUF, auto KS, bool on, int p0) {
-          constexpr int buf = decltype(BUF)::value, ks = decltype(KS)::value, nb = buf ^ 1;
-          const int c = ks * 2 + fh;
-#pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            acc[n >> 1][n & 1] = mfma32<DT>(a[buf][n >> 1], b[buf][n & 1], acc[n >> 1][n & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (n < 4) a[nb][n] = read_frag(la0 + so, n * 32 + fr, c);
-            else if (n < 6) b[nb][n - 4] = read_frag(lb0 + so, (n - 4) * 32 + fr, c);
-            if (on && (n & 1)) piece(nxt, k0, p0 + (n >> 1));
-            __builtin_amdgcn_sched_barrier(0);
+        {
+          // eight MFMAs of register buffer BUF, each followed by one read of sub-step KS into the other buffer (six)
+          // and, when `on`, by one LDS-DMA piece after every second MFMA (pieces p0 .. p0 + 3)
+          auto group = [&](auto BUF, auto KS, bool on, auto P0) {
+            constexpr int buf = decltype(BUF)::value, ks = decltype(KS)::value, nb = buf ^ 1, p0 = decltype(P0)::value;
+            const int c = ks * 2 + fh;
+            auto one = [&](auto NC) {
+              constexpr int n = decltype(NC)::value;
+              acc[n >> 1][n & 1] = mfma32<DT>(a[buf][n >> 1], b[buf][n & 1], acc[n >> 1][n & 1]);
+              __builtin_amdgcn_sched_barrier(0);
+              if constexpr (n < 4) a[nb][n] = read_frag(la0 + so, n * 32 + fr, c);
+              else if constexpr (n < 6) b[nb][n - 4] = read_frag(lb0 + so, (n - 4) * 32 + fr, c);
+              if constexpr ((n & 1) != 0 && p0 >= 0) piece(sn, k0, IC<p0 + (n >> 1)>{}, on);
+              __builtin_amdgcn_sched_barrier(0);
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{}); one(std::integral_constant<int, 3>{});
+            one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+          };
+          using I0 = std::integral_constant<int, 0>;
+          using I1 = std::integral_constant<int, 1>;
+          if (kt > 0) {
+            group(I1{}, I0{}, more, I0{});  // last sub-step of tile kt - 1 under the first reads of tile kt
+          } else {
+            read_sub(0, so, 0);
+            if (more) {
+              piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
+            }
           }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        if (kt > 0) {
-          group(I1{}, I0{}, more, 0);  // last sub-step of tile kt - 1 under the first reads of tile kt
-        } else {
-          read_sub(0, so, 0);
-          if (more) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) piece(nxt, k0, p);
-          }
+          group(I0{}, I1{}, more, std::integral_constant<int, 4>{});
+          group(I1{}, std::integral_constant<int, 2>{}, false, std::integral_constant<int, -1>{});
+          group(I0{}, std::integral_constant<int, 3>{}, false, std::integral_constant<int, -1>{});
         }
-        group(I0{}, I1{}, more, 4);
-        group(I1{}, std::integral_constant<int, 2>{}, false, 0);
-        group(I0{}, std::integral_constant<int, 3>{}, false, 0);
         continue;
       }
       if constexpr (GEO == 7) {
-        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
+        const int sn = (kt + 1) & 1;
         const bool more = kt + 1 < nk;
         const int k0 = (kt + 1) * kBK;
         if (kt > 0) {
-          mma_sub_staged(1, nxt, k0, 0, more);
+          mma_sub_staged(1, sn, k0, std::integral_constant<int, 0>{}, more);
         } else if (more) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) piece(nxt, k0, p);
+          piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
         }
         read_sub(1, so, 1);
-        mma_sub_staged(0, nxt, k0, 4, more);
+        mma_sub_staged(0, sn, k0, std::integral_constant<int, 4>{}, more);
         read_sub(0, so, 2);
         __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
         mma_sub(1);
@@ -521,10 +570,17 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
         mma_sub(1);  // last sub-step of tile kt - 1, under the reads above
         __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
       }
-      if (GEO != 9 && kt + 1 < nk) {  // next tile's DMA: its address arithmetic issues in the gaps of the MFMAs above
-        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
-        stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+      if (GEO != 9 && kt + 1 < nk) {  // next tile's DMA, issued in the gaps of the MFMAs above
+        const int sn = (kt + 1) & 1;
+        if constexpr (kFourPerOperand) {
+          const int k0 = (kt + 1) * kBK;
+          piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
+          piece(sn, k0, IC<4>{}); piece(sn, k0, IC<5>{}); piece(sn, k0, IC<6>{}); piece(sn, k0, IC<7>{});
+        } else {
+          uint8_t* nxt = smem + sn * SB;
+          stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+          stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
+        }
       }
       read_sub(1, so, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
@@ -540,6 +596,8 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
     }
     mma_sub(1);  // last sub-step of the last tile
+    // the last tile's "dead" pieces (zero fills of the idle stage) must have landed before the epilogue reuses the LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else if constexpr (GEO == 3) {
     constexpr int BK3 = 32;
     const int nk3 = (K + BK3 - 1) / BK3;
@@ -829,11 +887,13 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
 }
 
 static int gemm_geo() {
-  // MOQ_TUNE_GEMM_GEO = 0 .. 6 selects the tile geometry / loop structure (A/B knob, read once)
+  // MOQ_TUNE_GEMM_GEO selects the tile geometry / loop structure (A/B knob, read once).  Default: GEO 10 -- the 1 : 1
+  // MFMA / memory stream; with the branch-free three-instruction LDS-DMA pieces it runs 3-5 % ahead of GEO 4
+  // (profiles/r02_gemm_table.md)
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
-    const int g = e ? atoi(e) : 4;
-    return g < 0 || g > 10 ? 4 : g;
+    const int g = e ? atoi(e) : 10;
+    return g < 0 || g > 12 ? 10 : g;
   }();
   return geo;
 }
