@@ -886,6 +886,230 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
   return MOQ_OK;
 }
 
+// ---- GEO 12: 256 x 256 x 64 with FOUR waves (one per SIMD), the token operand direct to registers.
+//
+// What bounds the 8-wave loops (profiles/r02_gemm_table.md): two 64 KiB LDS stages are all that fits, so a K-tile's
+// operands are requested ONE tile ahead; every first touch of an operand slice by an XCD misses its L2 (~19 % of the
+// requests), takes longer than a tile and parks the whole workgroup at the tile's barrier.  Here only the WEIGHT tile
+// (256 rows, shared by the waves) goes through the LDS -- 32 KiB stages, FOUR of them -- and each wave owns a 64-token
+// column slab of the tile whose x rows nobody else reads: they go from HBM/L2 straight to the wave's registers in MFMA
+// fragment layout (`buffer_load_dwordx4`, 32 VGPRs per K-tile, three register buffers).  Both operands are then
+// requested THREE tiles ahead (~2.5 us of matrix work); the wait before a tile is a counted `vmcnt(32)` that never
+// drains the queue, and near the end of K "dead" loads against an empty descriptor keep that count uniform.
+//
+// Per wave and K-tile: 64 MFMAs (8 weight blocks x 2 token blocks x 4 sub-steps) : 32 ds_read_b128 + 8 LDS-DMA pieces
+// + 8 register loads.  LDS traffic drops to 32 KiB written + 128 KiB read per tile (8-wave loops: 64 + 192).
+// k order inside a tile: sub-step j multiplies, for the half-wave h = lane >> 5, k = 32 h + 8 j .. + 7 -- a lane's four
+// register loads of a row are then 64 contiguous bytes, issued back to back so that the row's line is fetched once.
+// The same permutation is applied to the weight fragments (chunk 4 h + j); a sum over k does not care.
+//
+// Hazards.  RAW: wave waits `vmcnt(32)` -- everything it requested for tile kt has landed -- then the barrier makes
+// the weight stage everyone's.  WAR (LDS): stage (kt + 3) & 3 = (kt - 1) & 3 is refilled after the barrier that opens
+// tile kt, which every wave passes only after its fragment reads of tile kt - 1 were waited for (lgkmcnt before the
+// MFMAs that consume them).  WAR (registers): buffer kt % 3 is reloaded after the last MFMA that reads it was issued.
+template <int DT>
+__device__ __forceinline__ f32x16_t mfma32v(const i32x4_t& a, const i32x4_t& b, f32x16_t c) {
+  if constexpr (DT == MOQ_BF16) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
+                                                   0, 0, 0);
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0,
+                                                  0, 0);
+  }
+}
+
+// DIAG (timing only, wrong results): 1 = MFMAs alone, 2 = MFMAs + fragment reads, 3 = MFMAs + HBM requests,
+// 4 = HBM requests alone
+template <int DT, int MODE, int DIAG = 0>
+__global__ __launch_bounds__(256, 1)
+void err_gemm12_kernel(const void* __restrict__ x, const void* __restrict__ w, const void* __restrict__ ref,
+                       const void* __restrict__ bias, void* __restrict__ out, float* __restrict__ partial, int T, int N,
+                       int K, int tiles_t, int tiles_n, int64_t x_stride, int64_t w_stride, float decay, float scale,
+                       int upper_only) {
+  constexpr int TILE = 256, NI = 8, NJ = 2;
+  constexpr int TB = TILE * kRowBytes;  // one weight stage: 32 KiB
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int tn, tt;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
+  const int n0 = tn * TILE, t0 = tt * TILE;
+  if constexpr (MODE == 2) {
+    if (tn < tt) return;
+  }
+  x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
+  w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
+  if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
+  const int rows_w = N - n0 < TILE ? N - n0 : TILE;
+  const int rows_x = T - t0 < TILE ? T - t0 : TILE;
+  const int64_t ld_bytes = (int64_t)K * 2;
+  const TileDesc rs_w = make_tile_desc(reinterpret_cast<const uint8_t*>(w) + (int64_t)n0 * ld_bytes,
+                                       (int)(rows_w * ld_bytes));
+  const TileDesc rs_x = make_tile_desc(reinterpret_cast<const uint8_t*>(x) + (int64_t)t0 * ld_bytes,
+                                       (int)(rows_x * ld_bytes));
+  const i32x4_t rsw = rs_w.words, rsx = rs_x.words;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nk = (K + kBK - 1) / kBK;
+  const bool k_ragged = (K & (kBK - 1)) != 0;
+
+  f32x16_t acc[NI][NJ];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // weight pieces: wave w stages rows (8 w + j) * 8 .. + 7, j = 0 .. 7 (lane -> row / chunk as in stage_tile)
+  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+      (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * 8 * 8 * kRowBytes));
+  int voff_a[8], voff_a_tail[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = (wave * 8 + j) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    voff_a[j] = (int)(r * ld_bytes + c * 16);
+    voff_a_tail[j] = (nk - 1) * kBK + c * 8 < K ? voff_a[j] : 0x7FFFFFF0;
+  }
+  auto piece = [&](int kt, auto J) {  // weight piece J of tile kt (dead past the last tile)
+    constexpr int j = decltype(J)::value;
+    if constexpr (DIAG == 1 || DIAG == 2) return;
+    const bool live = kt < nk;
+    const uint32_t m0v = lds_wave + (uint32_t)((kt & 3) * TB + j * 8 * kRowBytes);
+    const int koff = kt * kBK * 2;
+    const int vfull = voff_a[j], vtail = voff_a_tail[j];
+    const int vo = (k_ragged && kt == nk - 1) ? vtail : vfull;
+    i32x4_t rr = rsw;
+    rr.z = live ? rr.z : 0;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
+  };
+  // token rows: lane (fr, fh) of block jb holds row 64 w + 32 jb + fr, bytes [64 fh, 64 fh + 64) of the tile's 128
+  int voff_b[NJ];
+#pragma unroll
+  for (int jb = 0; jb < NJ; ++jb) voff_b[jb] = (int)((wave * 64 + jb * 32 + fr) * ld_bytes + fh * 64);
+  const int kh = fh * 32;
+  i32x4_t bq[3][NJ][4];
+  auto load_b = [&](int kt, auto BUF, auto JB, auto J) {
+    constexpr int buf = decltype(BUF)::value, jb = decltype(JB)::value, j = decltype(J)::value;
+    if constexpr (DIAG == 1 || DIAG == 2) {
+      if (kt < 3) bq[buf][jb][j] = i32x4_t{lane, kt, j, jb};
+      return;
+    }
+    const bool live = kt < nk;
+    const int koff = kt * kBK * 2;
+    const int vb = voff_b[jb];
+    const int vo = kt * kBK + kh + j * 8 < K ? vb : 0x7FFFFFF0;  // k tail: chunks at or past K read as zero
+    i32x4_t rr = rsx;
+    rr.z = live ? rr.z : 0;
+    i32x4_t v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
+                 : "=v"(v) : "v"(vo), "s"(rr), "s"(koff), "n"(j * 16) : "memory");
+    bq[buf][jb][j] = v;
+  };
+  auto request = [&](int kt, auto BUF) {  // prologue form: everything of tile kt at once
+    piece(kt, IC<0>{}); piece(kt, IC<1>{}); piece(kt, IC<2>{}); piece(kt, IC<3>{});
+    piece(kt, IC<4>{}); piece(kt, IC<5>{}); piece(kt, IC<6>{}); piece(kt, IC<7>{});
+    load_b(kt, BUF, IC<0>{}, IC<0>{}); load_b(kt, BUF, IC<0>{}, IC<1>{});
+    load_b(kt, BUF, IC<0>{}, IC<2>{}); load_b(kt, BUF, IC<0>{}, IC<3>{});
+    load_b(kt, BUF, IC<1>{}, IC<0>{}); load_b(kt, BUF, IC<1>{}, IC<1>{});
+    load_b(kt, BUF, IC<1>{}, IC<2>{}); load_b(kt, BUF, IC<1>{}, IC<3>{});
+  };
+
+  // weight fragments: row 32 i + fr, chunk 4 fh + j at position chunk ^ ((fr >> 1) & 7)
+  const int sw = (fr >> 1) & 7;
+  i32x4_t a[2][NI];
+  auto read_a = [&](const uint8_t* la, auto BUF, auto J, auto I) {
+    constexpr int buf = decltype(BUF)::value, j = decltype(J)::value, i = decltype(I)::value;
+    if constexpr (DIAG == 1 || DIAG == 3 || DIAG == 4) {
+      a[buf][i] = i32x4_t{lane + i, j, buf, 1};
+      return;
+    }
+    a[buf][i] = *reinterpret_cast<const i32x4_t*>(la + (i * 32 + fr) * kRowBytes + (((fh * 4 + j) ^ sw) << 4));
+  };
+
+  request(0, IC<0>{});
+  request(1, IC<1>{});
+  request(2, IC<2>{});
+
+  auto tile = [&](int kt, auto BUF) {
+    constexpr int buf = decltype(BUF)::value;
+    if constexpr (DIAG == 0 || DIAG == 3)
+      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // all of tile kt landed; tiles kt + 1, kt + 2 stay in flight
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const uint8_t* la = smem + (kt & 3) * TB;
+    read_a(la, IC<0>{}, IC<0>{}, IC<0>{}); read_a(la, IC<0>{}, IC<0>{}, IC<1>{});
+    read_a(la, IC<0>{}, IC<0>{}, IC<2>{}); read_a(la, IC<0>{}, IC<0>{}, IC<3>{});
+    read_a(la, IC<0>{}, IC<0>{}, IC<4>{}); read_a(la, IC<0>{}, IC<0>{}, IC<5>{});
+    read_a(la, IC<0>{}, IC<0>{}, IC<6>{}); read_a(la, IC<0>{}, IC<0>{}, IC<7>{});
+    __builtin_amdgcn_sched_barrier(0);
+    // sub-step J: 16 MFMAs; after every second one a fragment read of sub-step J + 1, after the 4th and 12th a weight
+    // piece of tile kt + 3
+    auto sub = [&](auto J) {
+      constexpr int j = decltype(J)::value, cur = j & 1, nxt = cur ^ 1;
+      auto pair = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        if constexpr (DIAG != 4) {
+          acc[i][0] = mfma32v<DT>(a[cur][i], bq[buf][0][j], acc[i][0]);
+          acc[i][1] = mfma32v<DT>(a[cur][i], bq[buf][1][j], acc[i][1]);
+        } else if constexpr (i == 0 && j == 0) {  // keep the loaded registers alive: one cheap use per tile
+          acc[0][0][0] += __builtin_bit_cast(float, bq[buf][0][0].x ^ bq[buf][1][3].w ^ bq[buf][0][1].y ^ bq[buf][1][2].z);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j < 3) read_a(la, IC<nxt>{}, IC<(j + 1) & 3>{}, I);
+        if constexpr (i == 1) piece(kt + 3, IC<2 * j>{});
+        if constexpr (i == 5) piece(kt + 3, IC<2 * j + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      pair(IC<0>{}); pair(IC<1>{}); pair(IC<2>{}); pair(IC<3>{});
+      pair(IC<4>{}); pair(IC<5>{}); pair(IC<6>{}); pair(IC<7>{});
+    };
+    sub(IC<0>{}); sub(IC<1>{}); sub(IC<2>{}); sub(IC<3>{});
+    // the buffer is free: its reload for tile kt + 3, a row's four loads back to back
+    load_b(kt + 3, BUF, IC<0>{}, IC<0>{}); load_b(kt + 3, BUF, IC<0>{}, IC<1>{});
+    load_b(kt + 3, BUF, IC<0>{}, IC<2>{}); load_b(kt + 3, BUF, IC<0>{}, IC<3>{});
+    load_b(kt + 3, BUF, IC<1>{}, IC<0>{}); load_b(kt + 3, BUF, IC<1>{}, IC<1>{});
+    load_b(kt + 3, BUF, IC<1>{}, IC<2>{}); load_b(kt + 3, BUF, IC<1>{}, IC<3>{});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt < nk; kt += 3) {
+    tile(kt, IC<0>{});
+    if (kt + 1 < nk) tile(kt + 1, IC<1>{});
+    if (kt + 2 < nk) tile(kt + 2, IC<2>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead loads: registers and LDS are reused by the epilogue
+
+  gemm_epilogue<DT, MODE, NI, NJ, 4>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, 0, wave, fr, fh, lane,
+                                     wave, decay, scale, upper_only);
+}
+
+template <int MODE, int DIAG = 0>
+static void launch_geo12(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
+                         int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
+                         int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
+  constexpr int TILE = 256, LDS = 4 * TILE * kRowBytes;  // four weight stages: 128 KiB
+  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  static std::atomic<uint64_t> attr_set{0};
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const uint64_t bit = 1ull << (device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)err_gemm12_kernel<MOQ_BF16, MODE, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)err_gemm12_kernel<MOQ_F16, MODE, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  const dim3 grid((unsigned)(tiles_t * tiles_n), (unsigned)n_cand), block(256);
+  if (dt == MOQ_BF16) {
+    hipLaunchKernelGGL((err_gemm12_kernel<MOQ_BF16, MODE, DIAG>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
+                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
+  } else {
+    hipLaunchKernelGGL((err_gemm12_kernel<MOQ_F16, MODE, DIAG>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
+                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
+  }
+}
+
 static int gemm_geo() {
   // MOQ_TUNE_GEMM_GEO selects the tile geometry / loop structure (A/B knob, read once).  Default: GEO 10 -- the 1 : 1
   // MFMA / memory stream; with the branch-free three-instruction LDS-DMA pieces it runs 3-5 % ahead of GEO 4
@@ -893,7 +1117,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 10;
-    return g < 0 || g > 12 ? 10 : g;
+    return g < 0 || g > 16 ? 10 : g;
   }();
   return geo;
 }
@@ -991,6 +1215,11 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 8: launch_geo<MODE, 8>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 9: launch_geo<MODE, 9>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 7: launch_geo<MODE, 7>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 12: launch_geo12<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 13: launch_geo12<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 14: launch_geo12<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 16: launch_geo12<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 15: launch_geo12<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
