@@ -406,11 +406,12 @@ int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs,
  * split-precision products in the fp32 accumulators.  a, b: dt = MOQ_BF16 | MOQ_F16, 16-byte aligned, k % 8 == 0,
  * cols % 4 == 0.  partial: moq_awq_err_gemm_workspace(rows, cols) floats. */
 /* One candidate of the Gram search from one read of W [rows, cols]:  e_out = dt(QDQ_g(dt(w * s[c]))) * r[c] - w  (fp32)
- * and a_out = [bf16(e) | bf16(e) | bf16(e - bf16(e))] (bf16 [rows, 3 cols]), the `a` operand of moq_awq_quadform.
+ * and a_out = the `a` operand of moq_awq_quadform, bf16 [rows, planes * cols] with hi = bf16(e), lo = bf16(e - hi):
+ * planes 3: [hi | hi | lo] (against b = [G_hi | G_lo | G_hi]), 2: [hi | lo] (b = [G_hi | G_hi]), 1: [hi] (b = [G_hi]).
  * s: dtype dt [cols] (awq_scale.to(dtype), model_calib.py:1552), r: fp32 [cols] (float of (1/awq_scale).to(dtype),
  * :1551); dynamic per-group amax, signed INT-num_bits, narrow_range False.  cols % g == 0. */
 int moq_awq_err_weight(const void* w, const void* s, const float* r, float* e_out, void* a_out, int64_t rows,
-                       int64_t cols, int g, int dt, int num_bits, void* stream);
+                       int64_t cols, int g, int dt, int num_bits, int planes, void* stream);
 int moq_awq_quadform(const void* a, const void* b, const float* ref, int64_t rows, int64_t cols, int64_t k, int dt,
                      float* partial, float* loss_acc, double inv_count, void* stream);
 

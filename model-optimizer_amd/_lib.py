@@ -99,7 +99,7 @@ SIGNATURES = {
     "moq_sgpt_block_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_void_p]),
     "moq_awq_err_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
-                                   c_void_p]),
+                                   c_int, c_void_p]),
     "moq_awq_quadform": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p,
                                  c_double, c_void_p]),
     "moq_block2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -253,7 +253,8 @@ __global__ __launch_bounds__(kBlock) void awq_err_weight_kernel(const void* __re
                                                                 const float* __restrict__ r,
                                                                 float* __restrict__ e_out,
                                                                 uint16_t* __restrict__ a_out, int64_t n,
-                                                                int64_t cols, int cols_shift, int num_bits) {
+                                                                int64_t cols, int cols_shift, int num_bits,
+                                                                int planes) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
   const IntQ q = make_intq(num_bits, 0, 0);
@@ -311,20 +312,21 @@ __global__ __launch_bounds__(kBlock) void awq_err_weight_kernel(const void* __re
       float* ep = e_out + e;
       *reinterpret_cast<float4*>(ep) = make_float4(err[0], err[1], err[2], err[3]);
       if constexpr (V == 8) *reinterpret_cast<float4*>(ep + 4) = make_float4(err[4], err[5], err[6], err[7]);
-      uint16_t* ap = a_out + row[u] * 3 * cols + col[u];
+      // planes 3: [hi | hi | lo], 2: [hi | lo], 1: [hi]
+      uint16_t* ap = a_out + row[u] * planes * cols + col[u];
       const Pack16 plo = pack<MOQ_BF16>(lo);
       if constexpr (V == 8) {
         Pack16 phi;
 #pragma unroll
         for (int i = 0; i < 4; ++i) phi.w[i] = hi_bits[2 * i] | (hi_bits[2 * i + 1] << 16);
         store16(ap, phi);
-        store16(ap + cols, phi);
-        store16(ap + 2 * cols, plo);
+        if (planes == 3) store16(ap + cols, phi);
+        if (planes >= 2) store16(ap + (planes - 1) * cols, plo);
       } else {
         const uint2 phi = make_uint2(hi_bits[0] | (hi_bits[1] << 16), hi_bits[2] | (hi_bits[3] << 16));
         *reinterpret_cast<uint2*>(ap) = phi;
-        *reinterpret_cast<uint2*>(ap + cols) = phi;
-        *reinterpret_cast<uint2*>(ap + 2 * cols) = make_uint2(plo.w[0], plo.w[1]);
+        if (planes == 3) *reinterpret_cast<uint2*>(ap + cols) = phi;
+        if (planes >= 2) *reinterpret_cast<uint2*>(ap + (planes - 1) * cols) = make_uint2(plo.w[0], plo.w[1]);
       }
     }
   }
@@ -774,9 +776,9 @@ extern "C" int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk
 }
 
 extern "C" int moq_awq_err_weight(const void* w, const void* s, const float* r, float* e_out, void* a_out, int64_t rows,
-                                  int64_t cols, int g, int dt, int num_bits, void* stream) {
+                                  int64_t cols, int g, int dt, int num_bits, int planes, void* stream) {
   if (w == nullptr || s == nullptr || r == nullptr || e_out == nullptr || a_out == nullptr || rows <= 0 || cols <= 0 ||
-      g <= 0 || num_bits < 2 || num_bits > 8) {
+      g <= 0 || num_bits < 2 || num_bits > 8 || planes < 1 || planes > 3) {
     set_error("moq_awq_err_weight: bad arguments");
     return MOQ_ERR_INVALID;
   }
@@ -795,6 +797,6 @@ extern "C" int moq_awq_err_weight(const void* w, const void* s, const float* r, 
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((awq_err_weight_kernel<DT, LPG>), dim3(grid),
                                                                   dim3(kBlock), 0, S(stream), w, s, r, e_out,
                                                                   reinterpret_cast<uint16_t*>(a_out), n, cols, cs,
-                                                                  num_bits)));
+                                                                  num_bits, planes)));
   return check_launch("moq_awq_err_weight");
 }

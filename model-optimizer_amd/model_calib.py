@@ -460,13 +460,14 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     # library's fp32 GEMM (agreement with the reference to ~1e-6 is asserted for them)
     mfma = dt in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0 and w.shape[1] % h.block_size == 0
     wf = None if mfma else w.float()
-    gram_op = ops.gram_operand(h.gram) if mfma else None
+    planes = gram_score_planes(dt)
+    gram_op = ops.gram_operand(h.gram, planes) if mfma else None
     for i, alpha in enumerate(h.alphas):
         s = h.scale(alpha)
         r = h._r_dev[i]  # (1 / s) rounded to the model dtype: input_quantizer.pre_quant_scale as the forward uses it (:1551)
         if mfma:
             # E and its split-precision MFMA operand from ONE read of W, then <E G, E> on the matrix cores
-            err, a_op = ops.awq_err_weight(w, s.to(dt), r, h.block_size, bits)
+            err, a_op = ops.awq_err_weight(w, s.to(dt), r, h.block_size, bits, planes)
             ops.awq_quadform(err, gram_op, h.loss_buf[i:i + 1], 1.0 / n_out, a_operand=a_op)
         else:
             w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
@@ -487,6 +488,21 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
 # at full size, 2e-3 for 200-token test shapes).
 GRAM_TIE_MARGIN = {torch.bfloat16: 1e-3, torch.float16: 2e-4, torch.float32: 2e-5}
 GRAM_TIE_NOISE = 0.5
+# bf16 planes of the Gram scoring contraction <E G, E> (ops.gram_operand): 3 = split precision in both factors.  bf16
+# models screen with ONE plane (E and G rounded to bf16, a third of the contraction and of the operand memory): on the
+# full-size run (profiles/r02_awq_tie_margin.md, "scoring planes") the one-plane scores differ from the three-plane ones
+# by at most 2.9e-4 relative, by at most 2.7e-4 between any two candidates of a linear and 6e-5 between candidates within
+# 5e-3 of the best; GRAM_PLANES_SLACK widens the re-scoring margin by the larger figure.  Same 224 / 224 alphas, same
+# 106 re-scored candidates.  f16 models (margin 2e-4) keep the three planes.
+GRAM_SCORE_PLANES = {torch.bfloat16: 1, torch.float16: 3}
+GRAM_PLANES_SLACK = 3e-4
+
+
+def gram_score_planes(dtype) -> int:
+    import os
+
+    env = os.environ.get("MOQ_TUNE_GRAM_PLANES")  # A/B knob for the precision study (profiles/r02_awq_tie_margin.md)
+    return int(env) if env in ("1", "2", "3") else GRAM_SCORE_PLANES.get(dtype, 3)
 
 
 @torch.no_grad()
@@ -724,6 +740,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             if margin is None:
                 outputs = max(1, getattr(h, "tokens_all_ranks", h.num_tokens) * m.weight.shape[0])
                 margin = GRAM_TIE_MARGIN.get(m.weight.dtype, 5e-3) + GRAM_TIE_NOISE / math.sqrt(outputs)
+                if gram_score_planes(m.weight.dtype) < 3 and m.weight.dtype != torch.float32:
+                    margin += GRAM_PLANES_SLACK
             best = min(row)  # a NaN score never compares smaller: such a linear keeps the plain first-minimum rule
             if not math.isfinite(best):
                 continue

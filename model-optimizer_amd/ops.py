@@ -1099,27 +1099,34 @@ def split_bf16(x: torch.Tensor):
 
 
 @torch.no_grad()
-def gram_operand(gram: torch.Tensor) -> torch.Tensor:
-    """[G_hi | G_lo | G_hi] (bf16 [Cin, 3 Cin]) of a symmetric fp32 Gram matrix -- the `b` operand of awq_quadform."""
+def gram_operand(gram: torch.Tensor, planes: int = 3) -> torch.Tensor:
+    """The `b` operand of awq_quadform for a symmetric fp32 Gram matrix, bf16 [Cin, planes * Cin]: planes 3 =
+    [G_hi | G_lo | G_hi] (against a = [E_hi | E_hi | E_lo]: E_hi G_hi + E_hi G_lo + E_lo G_hi), 2 = [G_hi | G_hi] (against
+    [E_hi | E_lo]: (E_hi + E_lo) G_hi), 1 = [G_hi]."""
+    if planes == 1:
+        return gram.to(torch.bfloat16).contiguous()
+    if planes == 2:
+        hi = gram.to(torch.bfloat16)
+        return torch.cat([hi, hi], dim=1).contiguous()
     hi, lo = split_bf16(gram)
     return torch.cat([hi, lo, hi], dim=1).contiguous()
 
 
 @torch.no_grad()
 def awq_err_weight(weight: torch.Tensor, awq_scale_dt: torch.Tensor, inv_scale_f32: torch.Tensor, group_size: int,
-                   num_bits: int = 4):
-    """(E fp32 [Cout, Cin], A bf16 [Cout, 3 Cin]) of one candidate: E = QDQ((W * s).to(dtype)) * r - W and its
-    split-precision MFMA operand, from one read of W."""
+                   num_bits: int = 4, planes: int = 3):
+    """(E fp32 [Cout, Cin], A bf16 [Cout, planes * Cin]) of one candidate: E = QDQ((W * s).to(dtype)) * r - W and its
+    split-precision MFMA operand (see gram_operand), from one read of W."""
     _require_gpu(weight, "awq_err_weight")
     w = weight.detach().contiguous()
     rows, cols = w.shape
     s = awq_scale_dt.detach().to(device=w.device, dtype=w.dtype).contiguous().reshape(-1)
     r = _f32(inv_scale_f32, w.device).reshape(-1)
     err = torch.empty(rows, cols, dtype=torch.float32, device=w.device)
-    a = torch.empty(rows, 3 * cols, dtype=torch.bfloat16, device=w.device)
+    a = torch.empty(rows, planes * cols, dtype=torch.bfloat16, device=w.device)
     with _on(w) as stream:
         check(_lib.lib().moq_awq_err_weight(_p(w), _p(s), _p(r), _p(err), _p(a), rows, cols, int(group_size), _dt(w),
-                                            int(num_bits), stream))
+                                            int(num_bits), int(planes), stream))
     return err, a
 
 
@@ -1127,22 +1134,26 @@ def awq_err_weight(weight: torch.Tensor, awq_scale_dt: torch.Tensor, inv_scale_f
 def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tensor, inv_count: float,
                  a_operand: torch.Tensor | None = None) -> torch.Tensor:
     """loss_acc[0] += inv_count * trace(E G E^T) = inv_count * <E G, E> for the fp32 error weight E [Cout, Cin] and
-    gram_op = gram_operand(G): one MFMA contraction over K = 3 Cin (split-precision: E_hi G_hi + E_hi G_lo + E_lo G_hi)
-    with the product against E fused into the epilogue."""
+    gram_op = gram_operand(G, planes): one MFMA contraction over K = planes * Cin (planes 3: split precision
+    E_hi G_hi + E_hi G_lo + E_lo G_hi) with the product against E fused into the epilogue."""
     _require_gpu(err, "awq_quadform")
     if err.dtype != torch.float32 or not err.is_contiguous() or gram_op.dtype != torch.bfloat16:
         raise MoquantError("awq_quadform: err must be contiguous fp32, gram_op bf16")
     rows, cols = err.shape
-    if tuple(gram_op.shape) != (cols, 3 * cols) or loss_acc.dtype != torch.float32 or loss_acc.numel() != 1:
+    planes = gram_op.shape[1] // cols if gram_op.dim() == 2 and cols else 0
+    if planes not in (1, 2, 3) or tuple(gram_op.shape) != (cols, planes * cols) or loss_acc.dtype != torch.float32 \
+            or loss_acc.numel() != 1:
         raise MoquantError("awq_quadform: operand shapes do not match")
     if a_operand is None:
         hi, lo = split_bf16(err)
-        a = torch.cat([hi, hi, lo], dim=1).contiguous()
+        a = torch.cat({1: [hi], 2: [hi, lo], 3: [hi, hi, lo]}[planes], dim=1).contiguous()
     else:
         a = a_operand
+        if tuple(a.shape) != (rows, planes * cols):
+            raise MoquantError("awq_quadform: a_operand and gram_op were built for different plane counts")
     ws = torch.empty(int(_lib.lib().moq_awq_err_gemm_workspace(rows, cols)), dtype=torch.float32, device=err.device)
     with _on(err) as stream:
-        check(_lib.lib().moq_awq_quadform(_p(a), _p(gram_op), _p(err), rows, cols, 3 * cols, _lib.BF16, _p(ws),
+        check(_lib.lib().moq_awq_quadform(_p(a), _p(gram_op), _p(err), rows, cols, planes * cols, _lib.BF16, _p(ws),
                                           _p(loss_acc), float(inv_count), stream))
     return loss_acc
 

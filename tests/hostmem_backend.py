@@ -328,7 +328,7 @@ class HostMemLib:
         a[(iu[1], iu[0])] = a[iu]
         return OK
 
-    def moq_awq_err_weight(self, w, s, r, e_out, a_out, rows, cols, g, dt, num_bits, stream):
+    def moq_awq_err_weight(self, w, s, r, e_out, a_out, rows, cols, g, dt, num_bits, planes, stream):
         y = np.empty((int(rows), int(cols)), dtype=np.float32 if dt == 0 else np.uint16)
         self.o.orc_awq_scale_qdq(_vp(w), _vp(s), oracle._p(y), I64(rows), I64(cols), int(g), int(dt), int(num_bits))
         wa = self._as_2d(w, rows, cols, dt)
@@ -338,8 +338,10 @@ class HostMemLib:
         _f32_view(e_out, rows * cols).reshape(int(rows), int(cols))[:] = e
         hi = self._bf16_round(e)
         lo = self._bf16_round(e - self._to_f32(hi, 2))
-        ao = np.ctypeslib.as_array(ctypes.cast(_addr(a_out), ctypes.POINTER(ctypes.c_uint16)), shape=(int(rows), 3 * int(cols)))
-        ao[:, :cols], ao[:, cols:2 * cols], ao[:, 2 * cols:] = hi, hi, lo
+        ao = np.ctypeslib.as_array(ctypes.cast(_addr(a_out), ctypes.POINTER(ctypes.c_uint16)),
+                                   shape=(int(rows), int(planes) * int(cols)))
+        for i, plane in enumerate({1: [hi], 2: [hi, lo], 3: [hi, hi, lo]}[int(planes)]):
+            ao[:, i * cols:(i + 1) * cols] = plane
         return OK
 
     def moq_awq_quadform(self, a, b, ref, rows, cols, k, dt, partial, loss_acc, inv_count, stream):
