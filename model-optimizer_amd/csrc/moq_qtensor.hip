@@ -157,10 +157,18 @@ __device__ __forceinline__ int mxfp4_exponent(float amax) {
 __device__ __forceinline__ float pow2i(int e) {  // 2^e for e in [-127, 127]
   return e >= -126 ? __uint_as_float((uint32_t)(e + 127) << 23) : __uint_as_float(0x00400000u);
 }
+// ord = #{bound < |v|} over the 7 E2M1 rounding bounds 0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5 (strict: ties round down);
+// sign_bit = (2 - sign(v)) // 2: zero gets 1.  Every bound has at most two mantissa bits, so "|v| > bound" is a comparison
+// of the key (bits(|v|) + 2^21 - 1) >> 21 -- exponent field and top two mantissa bits, rounded up -- against the bound's
+// own key: the seven compare / add pairs of the direct form (the kernel was VALU-bound on them, ~27 VALU instructions per
+// element) become add, shift, clamp and a 19-entry table packed in one 64-bit constant.  NaN compares false everywhere.
 __device__ __forceinline__ uint32_t mxfp4_nibble(float v) {
-  const float a = __builtin_fabsf(v);
-  // strict > against the 7 bounds (ties round down); sign_bit = (2 - sign(v)) // 2: zero gets 1
-  const uint32_t ord = (a > 0.25f) + (a > 0.75f) + (a > 1.25f) + (a > 1.75f) + (a > 2.5f) + (a > 3.5f) + (a > 5.0f);
+  const uint32_t u = __float_as_uint(v) & 0x7FFFFFFFu;
+  int idx = (int)((u + 0x1FFFFFu) >> 21) - 500;  // key of 0.25 is 500, of 5.0 is 517
+  idx = idx < 0 ? 0 : (idx > 18 ? 18 : idx);
+  // idx: 0 -> 0 | 1..6 -> 1 | 7..9 -> 2 | 10, 11 -> 3 | 12, 13 -> 4 | 14, 15 -> 5 | 16, 17 -> 6 | 18 -> 7
+  uint32_t ord = (uint32_t)(0x01F6B646D2449248ull >> (3 * idx)) & 7u;
+  ord = u > 0x7F800000u ? 0u : ord;
   return ((v > 0.0f) ? 0u : 8u) + ord;
 }
 // FAST layout (host-checked): n % block == 0, block % kVec == 0, LPG = block / kVec a power of two <= 64.

@@ -115,6 +115,29 @@ def test_mxfp4_power_of_two_edges():
     assert torch.equal(got_e.cpu(), want_e) and torch.equal(got_q.cpu(), want_q)
 
 
+@pytest.mark.parametrize("dn", ["bf16", "f16"])
+def test_mxfp4_pack_every_16_bit_pattern(dn):
+    """Every FINITE 16-bit pattern of the dtype as an element, under block exponents that put it on every side of the seven
+    E2M1 rounding bounds (exact ties included: the bounds are representable): nibbles and scale bytes equal the oracle's.
+    Pins the key-table form of the rounding (moq_qtensor.hip, mxfp4_nibble).  Blocks with a non-finite abs-max are left
+    out: the reference's ceil(log2(inf)) -> uint8 conversion is undefined there."""
+    dt = DT[dn]
+    pats = torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dt)  # every pattern once
+    pats = torch.cat([pats, torch.zeros(29, dtype=dt)])  # 65565 = 31 x 2115
+    pats = torch.where(torch.isfinite(pats.float()), pats, torch.zeros((), dtype=dt))
+    top = torch.finfo(dt).max / 64
+    rows = []
+    for shift in (0, 5, -9):  # the block's first element sets the exponent: 2^shift times the row's own magnitude
+        x = pats.reshape(-1, 31).clone()
+        lead = (x.float().abs().amax(dim=1, keepdim=True).clamp(2.0 ** -20, top) * 2.0 ** shift)
+        rows.append(torch.cat([lead.to(dt), x], dim=1))
+    x = torch.cat(rows)
+    want_q, want_e = oracle.mxfp4_pack(x, 32)
+    got_q, got_e = ops.mxfp4_quantize(x.to(DEV), 32)
+    assert torch.equal(got_e.cpu(), want_e), f"{dn}: scale bytes differ"
+    assert torch.equal(got_q.cpu(), want_q), f"{dn}: {int((got_q.cpu() != want_q).sum())} packed bytes differ"
+
+
 def test_int4_qtensor_round_trip_matches_kernels():
     gen = torch.Generator().manual_seed(3)
     w = (torch.randn(64, 256, generator=gen) * 0.02).to(torch.bfloat16)
