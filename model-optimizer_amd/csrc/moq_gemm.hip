@@ -274,6 +274,24 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_t, int tiles_n,
   tt = in_group / gsz;
 }
 
+// Gram mode (MODE 2): only tiles on and above the diagonal are contracted.  Dealing the n x n tile grid out in runs per XCD
+// left XCD 7 with 13x the live tiles of XCD 0 (rows 49..55 of 56 against rows 0..6) -- the launch took as long as that
+// XCD.  The triangle is folded into a rectangle instead: row r is paired with row n - 1 - r (r + 1 and n - r live tiles:
+// n + 1 together), so the grid is ceil(n / 2) x (n + 1) workgroups, every one of them live (but the second half of an
+// odd side's middle row), and tile_of_block's XCD runs and 8 x 4 groups apply to that rectangle.  Returns false for a
+// dead cell.
+__device__ __forceinline__ bool gram_tile(int r, int c, int n, int& tn, int& tt) {
+  if (c <= r) {
+    tn = r;
+    tt = c;
+    return true;
+  }
+  if (2 * r == n - 1) return false;  // odd side: the middle row has no partner
+  tn = n - 1 - r;
+  tt = c - (r + 1);
+  return true;
+}
+
 // The epilogue shared by every loop structure: the wave's NI x NJ accumulator tiles against `ref` / into `out`.
 // C layout of 32x32: col (t) = lane & 31, row (n) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): a lane holds runs of 4
 // consecutive n for one t -> 8-byte accesses of out / out_actual rows.
@@ -312,7 +330,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
           h.z = h.z * decay + scale * acc[i][j][q * 4 + 2];
           h.w = h.w * decay + scale * acc[i][j][q * 4 + 3];
           *hp = h;
-          if (tn != tt && !upper_only) {  // mirrored block: out[n + e, t]; lanes run along t -> 128-byte runs
+          if (tn != tt && !(upper_only & 1)) {  // mirrored block (MODE 2: bit 0 = upper_only, the rest = tile group): out[n + e, t]; lanes run along t -> 128-byte runs
             float* hm = reinterpret_cast<float*>(out) + (int64_t)n * N + t;
 #pragma unroll
             for (int e = 0; e < 4; ++e) hm[(int64_t)e * N] = hm[(int64_t)e * N] * decay + scale * acc[i][j][q * 4 + e];
@@ -385,11 +403,12 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
-  const int n0 = tn * TILE, t0 = tt * TILE;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
   if constexpr (MODE == 2) {
-    if (tn < tt) return;  // mirror image of tile (tn, tt)
+    // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
+    if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
   }
+  const int n0 = tn * TILE, t0 = tt * TILE;
   // blockIdx.y = candidate index of a batched launch (all alphas of one linear in one grid): every candidate has
   // its own operands x[a] / w[a] and its own partial-sum plane; `ref` / `bias` are shared
   x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
@@ -726,11 +745,12 @@ void err_gemm6_kernel(const void* __restrict__ x, const void* __restrict__ w, co
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
-  const int n0 = tn * TILE, t0 = tt * TILE;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
   if constexpr (MODE == 2) {
-    if (tn < tt) return;
+    // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
+    if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
   }
+  const int n0 = tn * TILE, t0 = tt * TILE;
   x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
   w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
   if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
@@ -932,11 +952,12 @@ void err_gemm12_kernel(const void* __restrict__ x, const void* __restrict__ w, c
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? 1 : upper_only, tn, tt);  // upper_only carries the group size
-  const int n0 = tn * TILE, t0 = tt * TILE;
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
   if constexpr (MODE == 2) {
-    if (tn < tt) return;
+    // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
+    if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
   }
+  const int n0 = tn * TILE, t0 = tt * TILE;
   x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
   w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
   if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
@@ -1090,7 +1111,12 @@ static void launch_geo12(const void* x, const void* w, const void* ref, const vo
                          int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
                          int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
   constexpr int TILE = 256, LDS = 4 * TILE * kRowBytes;  // four weight stages: 128 KiB
-  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
+    const int n = tiles_n;
+    tiles_t = n + 1;
+    tiles_n = (n + 1) / 2;
+  }
   static std::atomic<uint64_t> attr_set{0};
   int device = 0;
   (void)hipGetDevice(&device);
@@ -1130,7 +1156,12 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
                        int64_t w_stride, void* stream, float decay = 0.0f, float scale = 0.0f, int upper_only = 0) {
   constexpr int TILE = Geo<GEO>::TILE;
-  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
+    const int n = tiles_n;
+    tiles_t = n + 1;
+    tiles_n = (n + 1) / 2;
+  }
   const unsigned nblk = (unsigned)(tiles_t * tiles_n);
   // > 64 KiB of dynamic LDS needs the opt-in attribute -- per DEVICE (a process may drive several GPUs), set by
   // whichever thread gets there first (setting it twice is harmless, so a relaxed bit mask is enough)
@@ -1162,7 +1193,12 @@ static void launch_geo6(const void* x, const void* w, const void* ref, const voi
                         int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
                         int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
   constexpr int TILE = 256, LDS = 2 * 2 * TILE * kRowBytes;  // two stages of an A and a B tile: 128 KiB
-  const int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
+  if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
+    const int n = tiles_n;
+    tiles_t = n + 1;
+    tiles_n = (n + 1) / 2;
+  }
   static std::atomic<uint64_t> attr_set{0};
   int device = 0;
   (void)hipGetDevice(&device);
@@ -1198,6 +1234,14 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
       return g < 1 || g > 64 ? kTileGroup : g;
     }();
     upper_only = group;
+  } else {
+    // Gram mode: bit 0 stays the upper_only flag, the tile-group size rides above it
+    static const int group2 = [] {
+      const char* e = getenv("MOQ_TUNE_GEMM_GROUP");
+      const int g = e ? atoi(e) : kTileGroup;
+      return g < 1 || g > 64 ? kTileGroup : g;
+    }();
+    upper_only = (upper_only ? 1 : 0) | (group2 << 1);
   }
   const int tile = geo >= 2 ? 256 : 128;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
