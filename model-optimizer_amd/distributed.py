@@ -153,6 +153,55 @@ def agree_histogram_range(x_max_local: torch.Tensor, group=None, src: int = 0) -
     return x_max_local
 
 
+def _leaf_quantizers(q):
+    """The TensorQuantizers behind a (Sequential / Grouped) quantizer container."""
+    if hasattr(q, "_amax") or not isinstance(q, torch.nn.ModuleList | torch.nn.Sequential):
+        return [q]
+    return [leaf for member in q for leaf in _leaf_quantizers(member)]
+
+
+def sync_amax_tensor_parallel(model, group, column_parallel, row_parallel):
+    """The tensor-parallel amax rules of max_calibrate (model_calib.py:408-485) for a model whose linears are sharded
+    by the caller: "the quantization parameters when TP = 8 then changed to TP = 4 then back to TP = 8 should be the same".
+
+      column parallel (weights split along Cout): input AND weight amax are shared over the group when the quantizer's
+          axis is None or -1 (per-tensor, or per input channel -- every rank sees the whole input);
+      row parallel (weights split along Cin):     input amax shared when axis is None; weight amax when axis is None or 0
+          (per-tensor, or per output channel -- every rank holds a slice of every row);
+      block-quantized quantizers are left alone (INT4 / W4A8 blocks are local; block_sizes type "dynamic" has no amax);
+      scalar KV-cache quantizers (k_bmm / v_bmm) are shared.
+
+    `column_parallel(name, module)` / `row_parallel(name, module)` tell which linears are which (this package wraps plain
+    nn.Linear / HF modules and has no parallel_state of its own).  ONE bucketed MAX for everything."""
+    from .nn import is_quantized_linear
+
+    if not _initialized(group):
+        return []
+    picked = []
+
+    def take(q, axes):
+        for leaf in _leaf_quantizers(q):
+            if getattr(leaf, "block_sizes", None) is not None:
+                continue
+            if getattr(leaf, "_amax", None) is not None and leaf.axis in axes:
+                picked.append(leaf)
+
+    for name, m in model.named_modules():
+        if is_quantized_linear(m):
+            if column_parallel(name, m):
+                take(m.input_quantizer, (None, -1))
+                take(m.weight_quantizer, (None, -1))
+            elif row_parallel(name, m):
+                take(m.input_quantizer, (None,))
+                take(m.weight_quantizer, (None, 0))
+        for attr in ("k_bmm_quantizer", "v_bmm_quantizer"):
+            q = getattr(m, attr, None)
+            if q is not None and getattr(q, "_amax", None) is not None and q._amax.numel() == 1:
+                picked.append(q)
+    sync_amax_bucketed(picked, group=group, on_missing="raise")
+    return picked
+
+
 def shard_list(items, rank: int | None = None, world: int | None = None):
     """Round-robin shard of per-layer weight tensors (or calibration batches) over the ranks: independent
     units, no data-path collective."""

@@ -235,8 +235,8 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     method, kwargs = (algo, {}) if not isinstance(algo, dict) else (algo["method"], {k: v for k, v in algo.items() if k != "method"})
     if method is None:
         return model
-    if method == "max":
-        model_calib.max_calibrate(model, forward_loop)
+    if method == "max":  # MaxCalibConfig.distributed_sync (config.py): off for callers that synchronise by their own rules
+        model_calib.max_calibrate(model, forward_loop, distributed_sync=bool(kwargs.get("distributed_sync", True)))
     elif method == "mse":
         model_calib.mse_calibrate(model, forward_loop, **kwargs)
     elif method == "smoothquant":

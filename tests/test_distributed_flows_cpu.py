@@ -128,6 +128,68 @@ def _job_awq(rank, world, moa, single):
                "scored_here": {n: (h.use_gram, h.scored_here) for n, h in hs.items()}}
 
 
+class _TPShard(torch.nn.Module):
+    """Rank r's shard of the MLP under tensor parallelism: fc1 column parallel (rows r * H/W ..), fc2 row parallel (the
+    matching input columns); the partial outputs are not combined -- only the calibration statistics matter here."""
+
+    def __init__(self, full: MLP, rank, world):
+        super().__init__()
+        h = full.fc1.out_features // world
+        self.fc1 = torch.nn.Linear(full.fc1.in_features, h, bias=False)
+        self.fc2 = torch.nn.Linear(h, full.fc2.out_features, bias=False)
+        with torch.no_grad():
+            self.fc1.weight.copy_(full.fc1.weight[rank * h:(rank + 1) * h])
+            self.fc2.weight.copy_(full.fc2.weight[:, rank * h:(rank + 1) * h])
+
+    def forward(self, x):
+        return self.fc2(torch.relu(self.fc1(x)))
+
+
+class _TPFull(torch.nn.Module):
+    def __init__(self, full: MLP):
+        super().__init__()
+        self.fc1, self.fc2 = full.fc1, torch.nn.Linear(full.fc2.in_features, full.fc2.out_features, bias=False)
+        with torch.no_grad():
+            self.fc2.weight.copy_(full.fc2.weight)
+
+    def forward(self, x):
+        return self.fc2(torch.relu(self.fc1(x)))
+
+
+def _job_tensor_parallel(rank, world, moa, single):
+    """The tensor-parallel amax rules (distributed.sync_amax_tensor_parallel; model_calib.py:408-485): after calibrating
+    the rank's shard and the TP sync, per-tensor amaxes equal the unsharded model's, the row-parallel per-channel weight
+    amax equals the unsharded rows', the column-parallel per-channel weight amax stays the shard's own rows."""
+    mq = moa.model_quant
+    for preset in ("FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG"):
+        cfg = copy.deepcopy(getattr(mq, preset))
+        cfg["algorithm"] = {"method": "max", "distributed_sync": False}  # every rank sees every batch: no DP here
+        batches = _batches(128, torch.float32)
+        full = MLP()
+        if single:
+            model = moa.quantize(_TPFull(full), cfg, lambda m: [m(b) for b in batches])
+            yield {"amax": _amaxes(model)}
+            continue
+        model = moa.quantize(_TPShard(full, rank, world), cfg, lambda m: [m(b) for b in batches])
+        picked = moa.distributed.sync_amax_tensor_parallel(model, None, lambda n, m: n == "fc1", lambda n, m: n == "fc2")
+        yield {"amax": _amaxes(model), "picked": len(picked), "rank": rank, "world": world}
+
+
+def _compare_tp(want, got):
+    for a, b in zip(want, got):
+        r, w = b["rank"], b["world"]
+        for name, full in a["amax"].items():
+            mine = b["amax"][name]
+            if full.numel() == 1:
+                assert torch.equal(mine.reshape(()), full.reshape(())), f"tp {name}: per-tensor amax differs"
+            elif name.startswith("fc1"):  # column parallel, per output channel: the shard's own rows, untouched
+                h = full.shape[0] // w
+                assert torch.equal(mine, full[r * h:(r + 1) * h]), f"tp {name}"
+            else:  # row parallel, per output channel: MAX over the input shards = the unsharded row amax
+                assert torch.equal(mine, full), f"tp {name}"
+        assert b["picked"] == (4 if all(v.numel() == 1 for v in a["amax"].values()) else 3)
+
+
 def _compare(kind, want, got):
     for i, (a, b) in enumerate(zip(want, got)):
         for key in a:
@@ -155,6 +217,10 @@ def _worker(rank, world, port, kind, ret):
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
             dist.init_process_group("gloo", rank=rank, world_size=world)
             got = list(job(rank, world, moa, single=False))
+        if kind == "tensor_parallel":
+            _compare_tp(want, got)
+            ret[rank] = "ok"
+            return
         _compare(kind, want, got)
         if kind == "awq":
             # Gram-scored linears: every Gram matrix was reduced to ONE rank, which alone evaluated the 11 quadratic forms
@@ -184,7 +250,7 @@ def _worker(rank, world, port, kind, ret):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq"])
+@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "tensor_parallel"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
     mgr = mp.Manager()
