@@ -359,7 +359,13 @@ class AWQLiteHelper:
     def __init__(self, module: QuantLinear, alpha_step: float):
         wq = module.weight_quantizer
         self.block_size = wq.block_sizes.get(-1, None) or wq.block_sizes.get(module.weight.dim() - 1)
-        self.weight_scale = ops.awq_weight_scale(module.weight, self.block_size)
+        # Cin that is not a block multiple: the reference zero-pads the last block (get_weight_scale, :1453-1469; the
+        # static block quantizer, tensor_quantizer.py:975-1043).  The kernels take whole blocks, so such a linear works on
+        # a zero-padded copy of its weight and cuts the padding off again: zeros change neither a block's abs-max nor
+        # any quantized value.
+        self.cin = module.weight.shape[1]
+        self.pad = (-self.cin) % self.block_size
+        self.weight_scale = ops.awq_weight_scale(self._padded(module.weight), self.block_size)[:self.cin].contiguous()
         self.act_sum = torch.zeros(module.weight.shape[1], dtype=torch.float32, device=module.weight.device)
         self.act_scale = None
         self.num_cache_steps = 0
@@ -397,6 +403,9 @@ class AWQLiteHelper:
         self.exact_buf = None  # fp32 [len(contenders)] accumulated by the error GEMM
         self.num_exact_steps = 0
 
+    def _padded(self, w: torch.Tensor, value: float = 0.0) -> torch.Tensor:
+        return F.pad(w, (0, self.pad), "constant", value) if self.pad else w
+
     def prepare_scales(self, act_host: torch.Tensor, weight_host: torch.Tensor, dtype: torch.dtype):
         """All candidate scale vectors of this linear at once, on the HOST (get_scale), uploaded in ONE copy: s_alpha
         (fp32) and the input-side 1 / s_alpha as the forward uses it (rounded to the model dtype).  Done for every linear
@@ -430,8 +439,14 @@ class AWQLiteHelper:
         w_hat = self._w_hat
         if w_hat is None:
             w_hat = torch.empty(len(self._scale_dt), *module.weight.shape, dtype=dt, device=module.weight.device)
-            for i, s in enumerate(self._scale_dt):
-                ops.awq_scale_qdq(module.weight, s, self.block_size, module.weight_quantizer.num_bits, out=w_hat[i])
+            if self.pad:  # whole blocks for the kernel (zero weight columns, unit scales), the padding cut off again
+                w_pad = self._padded(module.weight)
+                for i, s in enumerate(self._scale_dt):
+                    y = ops.awq_scale_qdq(w_pad, self._padded(s, 1.0), self.block_size, module.weight_quantizer.num_bits)
+                    w_hat[i].copy_(y[:, :self.cin])
+            else:
+                for i, s in enumerate(self._scale_dt):
+                    ops.awq_scale_qdq(module.weight, s, self.block_size, module.weight_quantizer.num_bits, out=w_hat[i])
             if self._cache_w:
                 self._w_hat = w_hat
         return self._inv_scale, w_hat
@@ -546,8 +561,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for _, m in mods:
             h = helpers[m]
             cin = m.weight.shape[1]
-            # ragged rows (Cin not a multiple of the block: the reference zero-pads, tensor_quantizer.py:712-745) stay
-            # on the error-GEMM engine, whose QDQ operand kernel pads the same way
+            # ragged rows (Cin not a multiple of the block: zero-padded, AWQLiteHelper) stay on the error-GEMM engine
             gram_ok = cin % 4 == 0 and cin % h.block_size == 0
             fits = search != "gemm" and gram_ok and budget.reserve(4 * cin * cin)
             if fits or (search == "gram" and gram_ok):

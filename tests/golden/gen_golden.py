@@ -762,6 +762,46 @@ def gen_export_w4a8(out):
             out[k] = v
 
 
+def gen_awq_ragged(out):
+    """INT4_AWQ_CFG by the reference on ONE bf16 linear whose input width (192) is not a multiple of the INT4 block
+    (128): the last block of every row is zero-padded (get_weight_scale, model_calib.py:1453-1469; static block quantizer,
+    tensor_quantizer.py:975-1043).  The linear is fed directly (no model GEMM upstream), so alpha, pre_quant_scale, the
+    folded weight, the per-block amax and the fake-quantized output are reproducible bit for bit."""
+    import copy as _copy
+
+    import modelopt.torch.quantization as mtq
+
+    class One(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(192, 96, bias=False)
+
+        def forward(self, x):
+            return self.fc(x)
+
+    model = One()
+    with torch.no_grad():
+        model.fc.weight.copy_(weight_like((96, 192), torch.float32, 4242).float())
+    model = model.to(torch.bfloat16)
+    batches = _calib_batches(192, torch.bfloat16, 4243, n=3)
+    out["w"] = bits(model.fc.weight)
+    for i, b in enumerate(batches):
+        out[f"x{i}"] = bits(b)
+    cfg = _copy.deepcopy(mtq.INT4_AWQ_CFG)
+    cfg["algorithm"]["debug"] = True
+    q = mtq.quantize(model, cfg, lambda m: [m(b) for b in batches])
+    h = q.fc.awq_lite
+    out["best_alpha"] = np.array(float(h.best_alpha))
+    out["loss"] = np.array([float(v) for v in h.loss.values()], dtype=np.float64)
+    out["weight_scale"], out["act_scale"] = bits(h.weight_scale), bits(h.act_scale)
+    out["pre_quant_scale"] = bits(q.fc.input_quantizer._pre_quant_scale)
+    out["folded"] = bits(q.fc.weight)
+    out["amax"] = bits(q.fc.weight_quantizer._amax.float())
+    with torch.no_grad():
+        out["y0"] = bits(q(batches[0]))
+    out["cases"] = np.array(json.dumps(dict(n_batches=len(batches), amax_shape=list(q.fc.weight_quantizer._amax.shape))))
+
+
 def gen_export_replay(out):
     """Replay data for the end-to-end INT4-AWQ checkpoint test: the SAME reference run as export_llama.npz (checked
     array by array against that file), plus what every quantized linear received in each calibration batch and the
@@ -1157,11 +1197,11 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

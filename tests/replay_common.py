@@ -7,9 +7,11 @@ received in that batch.  Everything the path computes from there -- activation /
 the fold, the per-group amax, the resmooth + norm fusion + nibble packing of the export -- must then reproduce the
 reference's model.safetensors byte for byte (export/unified_export_hf.py:1491, export/quant_utils.py:792-833)."""
 
+import copy
+
 import torch
 
-from conftest import from_bits
+from conftest import assert_bits_equal, from_bits
 
 
 def replay_loop(replay, device):
@@ -60,6 +62,45 @@ def stage_report(q, g, replay):
                 break
         out[name] = first
     return out
+
+
+def awq_ragged_check(moa, golden, device):
+    """tests/golden/awq_ragged.npz (gen_golden.gen_awq_ragged): INT4-AWQ of one bf16 linear with Cin = 192 (block 128)."""
+    g = golden("awq_ragged")
+
+    class One(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = torch.nn.Linear(192, 96, bias=False)
+
+        def forward(self, x):
+            return self.fc(x)
+
+    model = One().to(torch.bfloat16)
+    with torch.no_grad():
+        model.fc.weight.copy_(from_bits(g.raw("w"), torch.bfloat16).reshape(96, 192))
+    model = model.to(device)
+    batches = [from_bits(g.raw(f"x{i}"), torch.bfloat16).reshape(24, 192).to(device) for i in range(g.cases["n_batches"])]
+    for search in ("auto", "gemm"):
+        m = copy.deepcopy(model)
+        cfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
+        cfg["algorithm"] = {"method": "awq_lite", "search": search}
+        with torch.no_grad():
+            q = moa.quantize(m, cfg, lambda mm: [mm(b) for b in batches])
+            y0 = q(batches[0])
+        h = q.fc.awq_lite
+        assert not h.use_gram, "a ragged input width stays on the error-GEMM engine"
+        assert float(h.best_alpha) == float(g.raw("best_alpha"))
+        assert_bits_equal(h.weight_scale.cpu(), from_bits(g.raw("weight_scale"), torch.float32), "weight_scale")
+        assert_bits_equal(h.act_scale.cpu(), from_bits(g.raw("act_scale"), torch.float32), "act_scale")
+        ref_loss = torch.from_numpy(g.raw("loss")).float()
+        assert ((h.loss_buf.cpu() - ref_loss).abs() <= 1e-2 * ref_loss).all(), "per-alpha losses"
+        assert_bits_equal(q.fc.input_quantizer._pre_quant_scale.cpu().reshape(-1),
+                          from_bits(g.raw("pre_quant_scale"), torch.bfloat16).reshape(-1), "pre_quant_scale")
+        assert_bits_equal(q.fc.weight.detach().cpu().reshape(-1), from_bits(g.raw("folded"), torch.bfloat16).reshape(-1), "folded weight")
+        assert list(q.fc.weight_quantizer._amax.shape) == g.cases["amax_shape"]
+        assert_bits_equal(q.fc.weight_quantizer._amax.float().cpu().reshape(-1), from_bits(g.raw("amax"), torch.float32).reshape(-1), "block amax")
+        assert_bits_equal(y0.cpu().reshape(-1), from_bits(g.raw("y0"), torch.bfloat16).reshape(-1), "fake-quantized output")
 
 
 def check_w4a8_state(q, g):

@@ -293,3 +293,12 @@ def test_col_abs_mean_accum_equals_host_get_act_scale(dtype):
         assert torch.allclose(got, want, rtol=2e-6, atol=0)
     else:
         assert torch.equal(got, want), f"{int((got != want).sum())} of {cols} columns differ"
+
+
+def test_awq_lite_ragged_input_width_equals_the_reference_run(golden):
+    """Cin = 192 with INT4 blocks of 128 on the GPU: the helper works on a zero-padded copy of the weight (whole blocks for
+    the kernels) like the reference pads its last block; alpha, scales, folded weight, per-block amax and the
+    fake-quantized output equal the reference run bit for bit (tests/golden/awq_ragged.npz)."""
+    import replay_common
+
+    replay_common.awq_ragged_check(moa, golden, DEV)

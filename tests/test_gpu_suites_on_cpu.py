@@ -45,7 +45,8 @@ SELECTED = {
     "test_gpu_sparsegpt": ["test_create_sgpt_mask_matches_reference", "test_hessian_matches_reference_hook",
                            "test_sparsify_sparsegpt_flow", "test_sparsegpt_hessian_shared_between_linears_with_the_same_input"],
     # (the Gram-sharing test counts staged launches; the staging buffer is budgeted from free GPU memory and is off here)
-    "test_gpu_awq_search": ["test_gram_search_equals_gemm_search", "test_unexercised_and_nan_linears_fall_back_to_max_calibration"],
+    "test_gpu_awq_search": ["test_gram_search_equals_gemm_search", "test_unexercised_and_nan_linears_fall_back_to_max_calibration",
+                            "test_awq_lite_ragged_input_width_equals_the_reference_run"],
     "test_gpu_layerwise": None,
     "test_gpu_kv_cache": ["test_fp8_kv_cache_calibration_and_export_match_reference"],
     "test_gpu_moe": ["test_mixtral_fp8_calibration_and_export_match_reference"],

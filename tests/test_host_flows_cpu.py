@@ -398,15 +398,14 @@ def test_w4a8_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, host
     assert moa.export.hf_quant_config(q)["quantization"]["quant_algo"] == g.cases["hf_quant_config"]["quantization"]["quant_algo"]
 
 
-def test_awq_lite_ragged_input_width_fails_loudly(hostmem):
-    """Cin that is not a multiple of the INT4 block: the kernels have no padded-block layout (the reference zero-pads,
-    tensor_quantizer.py:712-745) -- the C-ABI's argument check surfaces instead of a search on garbage."""
-    from model_optimizer_amd._lib import MoquantError
 
-    model = _FlatStack([(128, 64)], torch.float32, 0)
-    b = _flat_batches([(128, 64)], torch.float32, 1, 16, 1, 0.1)
-    with pytest.raises(MoquantError, match="cols % g"):
-        moa.quantize(model, moa.model_quant.INT4_AWQ_CFG, lambda m: [m(x) for x in b])
+
+def test_awq_lite_ragged_input_width_equals_the_reference_run(golden, hostmem):
+    """Cin not a multiple of the INT4 block: zero-padded last block like the reference (get_weight_scale,
+    model_calib.py:1453-1469): alpha, scales, folded weight, per-block amax and the fake-quantized output bit for bit."""
+    import replay_common
+
+    replay_common.awq_ragged_check(moa, golden, "cpu")
 
 
 def test_tensor_quantizer_fused_input_pass_equals_unfused_chain(hostmem):
