@@ -110,7 +110,8 @@ def _reference_recipe(x, block_sizes):
 @pytest.mark.parametrize("dn", ["bf16", "f32"])
 @pytest.mark.parametrize("shape,blocks", [((256, 384), {-1: 128, -2: 128}), ((64, 96), {-1: 32, -2: 16}),
                                           ((6, 64, 96), {-1: 32, -2: 16}), ((4, 8, 16, 32), {1: 4, -1: 8}),
-                                          ((12, 40), {0: 3}), ((5, 7, 64), {-1: 64}), ((30, 50), {-1: 10, -2: 15})])
+                                          ((12, 40), {0: 3}), ((5, 7, 64), {-1: 64}), ((30, 50), {-1: 10, -2: 15}),
+                                          ((9, 6, 50), {1: 3}), ((3, 70, 4096), {1: 7}), ((2, 9, 24), {1: 9})])
 def test_reduce_block_amax_and_padding(dn, shape, blocks):
     dt = DT[dn]
     gen = torch.Generator().manual_seed(len(shape) * 100 + shape[-1])
