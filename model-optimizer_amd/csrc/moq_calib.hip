@@ -187,19 +187,41 @@ __global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restr
   const int64_t c0 = blockIdx.x * per, c1 = c0 + per < cols ? c0 + per : cols;
   const int64_t base = row * cols;
   auto edge = [&](int k) { return k == bins ? hi : (float)k * step + lo; };
-  for (int64_t c = c0 + threadIdx.x; c < c1; c += kBlock) {
-    const float v = __builtin_fabsf(load1<DT>(x, base + c));
-    if (!(v >= lo && v <= hi)) continue;  // NaN (numpy raises on non-finite ranges; nothing is counted here)
+  auto count = [&](float xv) {
+    const float v = __builtin_fabsf(xv);
+    if (!(v >= lo && v <= hi)) return;  // NaN (numpy raises on non-finite ranges; nothing is counted here)
     int idx = (int)(((v - lo) / width) * fbins);
     if (idx == bins) idx = bins - 1;
     if (v < edge(idx)) --idx;
     if (idx != bins - 1 && v >= edge(idx + 1)) ++idx;
     atomicAdd(&lds_hist[idx], 1);
+  };
+  constexpr int V = Elem<DT>::kVec;
+  const char* xb = reinterpret_cast<const char*>(x);
+  if (((base + c0) % V) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+    // 16-byte packets per lane (the scalar form moved 2 bytes per lane and load), the row's tail element by element
+    const int64_t n_pk = (c1 - c0) / V;
+    for (int64_t p = threadIdx.x; p < n_pk; p += kBlock) {
+      const Pack16 pk = load16_nt(xb + (base + c0 + p * V) * (16 / V));
+      float f[8];
+      unpack<DT>(pk, f);
+#pragma unroll
+      for (int e = 0; e < V; ++e) count(f[e]);
+    }
+    for (int64_t c = c0 + n_pk * V + threadIdx.x; c < c1; c += kBlock) count(load1<DT>(x, base + c));
+  } else {
+    for (int64_t c = c0 + threadIdx.x; c < c1; c += kBlock) count(load1<DT>(x, base + c));
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < bins; b += kBlock) {
-    const int n = lds_hist[b];
-    if (n) atomicAdd(&counts[row * bins + b], n);
+  if (gridDim.x == 1) {
+    // the row is this workgroup's alone: plain coalesced stores of every bin instead of one global atomic per
+    // non-empty bin (58 M atomics for a 28672 x 8192 weight)
+    for (int b = threadIdx.x; b < bins; b += kBlock) counts[row * bins + b] = lds_hist[b];
+  } else {
+    for (int b = threadIdx.x; b < bins; b += kBlock) {
+      const int n = lds_hist[b];
+      if (n) atomicAdd(&counts[row * bins + b], n);
+    }
   }
 }
 
