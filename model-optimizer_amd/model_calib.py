@@ -204,13 +204,18 @@ def _mse_quant_func(x, amax, quantizer):
 
 @torch.no_grad()
 def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, step_size: float = 0.1,
-                  start_multiplier: float = 0.25, stop_multiplier: float = 4.0):
+                  start_multiplier: float = 0.25, stop_multiplier: float = 4.0, fp8_scale_sweep: bool = False,
+                  shared_states=None):
     """model_calib.py:732-826 (multiplier search, fp8_scale_sweep=False): max calibration first, then every
     eligible weight quantizer's amax is refined by the MSE sweep -- here one fused kernel per weight."""
     from functools import partial
 
     from .calib import MseCalibrator
 
+    if fp8_scale_sweep or shared_states:
+        # the FP8-scale sweep of NVFP4 static block scales and shared quantizer state (model_calib.py:740-741, :770-826)
+        # belong to formats outside this path; the reference's defaults (False / None) are accepted
+        raise MoquantUnsupported("mse_calibrate: fp8_scale_sweep / shared_states are outside this path")
     max_calibrate(model, forward_loop, distributed_sync)
     for m in model.modules():
         if not is_quantized_linear(m):
