@@ -19,7 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batches", type=int, default=4)
-    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "mxfp4", "mxfp4_sq", "int8_sq"])
+    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq"])
     ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
                     help="mixtral: 8 experts per layer with fused 3-D expert weights (Mixtral-8x7B layer shapes)")
     args = ap.parse_args()
@@ -51,7 +51,7 @@ def main():
     torch.cuda.synchronize()
     t_plain = time.perf_counter() - t0
     qcfg = {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
-            "int4_awq": mq.INT4_AWQ_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
+            "int4_awq": mq.INT4_AWQ_CFG, "w4a8_awq": mq.W4A8_AWQ_BETA_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
             "int8_sq": mq.INT8_SMOOTHQUANT_CFG}[args.qformat]
     t0 = time.perf_counter()
     moa.quantize(model, qcfg, loop)
@@ -65,7 +65,7 @@ def main():
     t0 = time.perf_counter()
     state = moa.export.export_state_dict(model, torch.bfloat16,
                                          (lambda: model(torch.ones([1, 2], dtype=torch.long, device=dev)))
-                                         if args.qformat == "int4_awq" else None)
+                                         if args.qformat in ("int4_awq", "w4a8_awq") else None)
     torch.cuda.synchronize()
     t_export = time.perf_counter() - t0
     n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
