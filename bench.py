@@ -87,7 +87,7 @@ def pmc_traffic(workload, model, n_layers):
     if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
     path = None
-    for tag in ("r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
+    for tag in ("r03", "r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
         cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc.json")
         if os.path.exists(cand):
             path = cand
@@ -103,6 +103,37 @@ def pmc_traffic(workload, model, n_layers):
     except (OSError, ValueError):
         pass
     return None, None
+
+
+def node_probe(dev, budget_ms=25.0):
+    """What THIS node's memory system gives plain streams right now (the pool has fast and slow-write nodes,
+    profiles/r01_stream_probe_*.txt): a 1 GiB device-to-device copy (read + write) and a 1 GiB read-only reduction,
+    each repeated for ~budget_ms, HIP-event timed.  Reported beside the roofline so that a line from a slow node says
+    so itself; not part of any timed region."""
+    n = 1 << 29  # bf16 elements = 1 GiB
+    src = torch.empty(n, dtype=torch.bfloat16, device=dev).normal_()
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, nbytes in (("node_copy_GBs", lambda: dst.copy_(src), 4.0 * n),
+                             ("node_read_GBs", lambda: _moa_import.load().ops.reduce_amax(src), 2.0 * n)):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 0
+        t0 = time.perf_counter()
+        a.record()
+        while True:
+            fn()
+            reps += 1
+            if reps % 8 == 0:
+                torch.cuda.synchronize()
+                if (time.perf_counter() - t0) * 1e3 > budget_ms:
+                    break
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = round(nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9, 1)
+    del src, dst
+    return out
 
 
 def cpu_baseline(workload, budget_s=12.0):
@@ -172,6 +203,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other kernels, the "
                                                             "Llama-3-70B in-place pass, the INT4-AWQ wall-clock)")
+    ap.add_argument("--no-hf", action="store_true", help="extra: skip the INT4-AWQ flow on the random-init HF Llama-3-8B")
     ap.add_argument("--awq-layers", type=int, default=32, help="extra: layers of the INT4-AWQ wall-clock run (0 = skip)")
     ap.add_argument("--awq-batches", type=int, default=64, help="extra: calibration batches of 4096 tokens in total")
     args = ap.parse_args()
@@ -350,12 +382,29 @@ def main():
                 "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>",
                 "mask24": "mt_mask24_kernel<bf16>"}[wl]
     achieved = n_local * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9  # this rank's launch over this rank's tensors
-    traffic, traffic_src = pmc_traffic(wl, args.model, n_layers) if world == 1 else (None, None)
+    # PMC traffic comes from the committed single-GPU profile of the same launch over the whole model; a rank that
+    # owns a share of the tensors moves that share of it (the kernel's traffic is proportional to its elements)
+    traffic, traffic_src = pmc_traffic(wl, args.model, n_layers)
+    if traffic is not None and world > 1:
+        traffic = int(traffic * n_local / n_elem)
+        traffic_src = f"{traffic_src}, scaled to rank 0's {n_local / n_elem:.4f} of the elements"
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "alg_bytes_per_launch": int(n_local * alg_bytes_per_elem), "avg_launch_ms": round(dom_ms, 4),
                 "min_launch_ms": round(min(dom_all), 4), "max_launch_ms": round(max(dom_all), 4)}
+    try:
+        roofline.update(node_probe(dev))  # this node's own copy / read ceilings, after the timed region
+    except Exception as e:  # a reported extra, never a reason to lose the main result
+        roofline["node_probe_failed"] = f"{type(e).__name__}: {e}"
+    if world > 1:
+        # every rank's own launch against the roofline (rank order): the line's `roofline` is rank 0's
+        mine = torch.tensor([achieved, dom_ms, roofline.get("node_copy_GBs", 0.0)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        roofline["per_rank"] = [{"achieved": round(t[0].item(), 1), "frac": round(t[0].item() / HBM_PEAK_GBS, 4),
+                                 "avg_launch_ms": round(t[1].item(), 4), "node_copy_GBs": round(t[2].item(), 1)}
+                                for t in every]
 
     out = {
         "metric": f"GB/s weights calibrated+QDQ ({MODEL_NAMES[args.model]})",
@@ -442,14 +491,34 @@ def main():
             line.pop("best_alphas", None)
             extra["awq_wallclock_s"] = line["value"]
             extra["awq"] = {k: line[k] for k in ("config", "search", "rescored_linears", "rescored_candidates",
-                                                 "search_gemm_TFLOPs_equiv", "best_alpha_hist")}
+                                                 "search_gemm_TFLOPs_equiv", "best_alpha_hist", "passes", "stages_s",
+                                                 "tie_check") if k in line}
         except Exception as e:
             extra["awq_wallclock_s"] = None
             extra["awq"] = {"failed": f"{type(e).__name__}: {e}"}
+    if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b" and world == 1 and not args.no_hf:
+        # the other AWQ case: a random-init Hugging Face Llama-3-8B (real decoder topology: attention, norms, the
+        # inputs of q/k/v and gate/up shared), whose activations have no outlier channels -- all 11 candidates of a linear
+        # score within a fraction of a percent, the worst case for the exact re-scoring (tools/hf_flow_check.py)
+        try:
+            torch.cuda.empty_cache()
+            if os.path.join(ROOT, "tools") not in sys.path:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hf_flow_check
+
+            hf = hf_flow_check.run(hf_flow_check.parse_args(["--layers", str(args.awq_layers), "--batches",
+                                                             str(args.awq_batches), "--qformat", "int4_awq"]), moa, dev)
+            extra["awq_hf_random_init"] = {"quantize_s": hf["quantize_s"], "plain_forward_loop_s": hf["plain_forward_loop_s"],
+                                           "rescored_linears": hf.get("awq_rescored_linears"),
+                                           "rescored_candidates": hf.get("awq_rescored_candidates"),
+                                           "stats": hf.get("awq_stats")}
+        except Exception as e:
+            extra["awq_hf_random_init"] = {"failed": f"{type(e).__name__}: {e}"}
     if extra:
         out["extra"] = extra
 
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: rank 0 times it too, after the timed region; the other ranks wait at the group's teardown)
         try:
             out["cpu_baseline"] = cpu_baseline(wl)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result

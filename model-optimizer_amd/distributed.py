@@ -18,6 +18,38 @@ def _initialized(group=None) -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+# ------------------------------------------------------------------------------------------------ replicas
+# Weight-side work (abs-max of the weights, 2:4 masks, SmoothQuant fold, MX QDQ, export packing) is independent per
+# tensor, so it can be dealt over the ranks -- but ONLY when every rank holds the same weights (pure data-parallel
+# replicas).  Under tensor parallelism or FSDP the ranks hold different shards and each must process all of its own
+# tensors.  A process group says nothing about which of the two it is, so sharding is something the caller states:
+# `declare_data_parallel(group)` once (or `shard_weights=True` per call); nothing is sharded otherwise.
+_REPLICAS = {"declared": False, "group": None}
+
+
+def declare_data_parallel(group=None, enabled: bool = True):
+    """State that the ranks of `group` (default: the world) are replicas holding IDENTICAL weights.  From here on the
+    weight-side passes of max_calibrate / smoothquant / sparsify / quantize_weights / export deal their tensors over
+    the ranks (`shard_list`) unless a call says otherwise."""
+    _REPLICAS["declared"], _REPLICAS["group"] = bool(enabled), group if enabled else None
+
+
+def replicas_declared() -> bool:
+    return bool(_REPLICAS["declared"]) and _initialized() and dist.get_world_size(_REPLICAS["group"]) > 1
+
+
+def replica_group():
+    return _REPLICAS["group"]
+
+
+def resolve_shard(shard_weights) -> bool:
+    """shard_weights argument of the weight-side flows: True / False are taken literally (True needs a process group of
+    more than one rank to mean anything), None follows declare_data_parallel."""
+    if shard_weights is None:
+        return replicas_declared()
+    return bool(shard_weights) and _initialized() and dist.get_world_size(_REPLICAS["group"]) > 1
+
+
 def all_reduce_bucket(tensors, op, group=None, average: bool = False):
     """All-reduce a list of tensors as one flat buffer (per dtype), results written back in place."""
     if not tensors or not _initialized(group):
@@ -210,3 +242,85 @@ def shard_list(items, rank: int | None = None, world: int | None = None):
     if world is None:
         world = dist.get_world_size() if _initialized() else 1
     return [it for i, it in enumerate(items) if i % world == rank]
+
+
+# ------------------------------------------------------------------------------------------------ weight-side shards
+# Largest single collective call (bytes).  The payloads here are either KB-sized statistics or whole tensors /
+# Gram matrices of hundreds of MB; the big ones are cut into calls of at most this size so that no call depends on
+# RCCL staging one multi-GB message (first contact with an 8-GPU node should not be a 33 GB reduce).
+MAX_COLLECTIVE_BYTES = 1 << 30
+
+
+def _global_rank(group, group_rank: int) -> int:
+    return group_rank if group is None else dist.get_global_rank(group, group_rank)
+
+
+def _as_bytes(t: torch.Tensor) -> torch.Tensor:
+    """Flat uint8 alias of a contiguous tensor (bool travels as bytes: RCCL has no bool type)."""
+    return t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1)
+
+
+def _chunks(nbytes: int, limit: int):
+    limit = max(int(limit), 1)
+    return [(a, min(a + limit, nbytes)) for a in range(0, nbytes, limit)]
+
+
+def owner_rank(index: int, world: int | None = None) -> int:
+    """Rank that `shard_list` deals unit `index` to."""
+    if world is None:
+        world = dist.get_world_size(replica_group()) if _initialized() else 1
+    return index % world
+
+
+def broadcast_from_owners(tensors, group=None, small_bytes: int = 32 << 20, max_bytes: int | None = None,
+                          owners=None):
+    """tensors[i] was computed on rank `owner_rank(i)` only (shard_list order; or on group rank `owners[i]`); afterwards
+    every rank holds every result, in place.  All ranks pass same-shaped, same-dtype, contiguous tensors (results or
+    empty buffers).
+
+    Large tensors are broadcast in place (no staging copy), in calls of at most `max_bytes`; the small ones of an owner
+    travel in one flat bucket.  This is the exchange step of the weight-side flows (masks, folded weights,
+    fake-quantized weights) -- whether it PAYS is a bandwidth question: an elementwise pass over a
+    replica's own weights runs at HBM speed, a broadcast at xGMI speed."""
+    if not _initialized(group):
+        return
+    limit = MAX_COLLECTIVE_BYTES if max_bytes is None else max_bytes
+    world = dist.get_world_size(group)
+    me = dist.get_rank(group)
+    for r in range(world):
+        src = _global_rank(group, r)
+        mine = [t for i, t in enumerate(tensors) if (i % world if owners is None else owners[i]) == r]
+        small = []
+        for t in mine:
+            if not t.is_contiguous():
+                raise ValueError("broadcast_from_owners: tensors must be contiguous")
+            if t.numel() == 0:
+                continue
+            flat = _as_bytes(t)
+            if flat.numel() >= small_bytes:
+                for a, b in _chunks(flat.numel(), limit):
+                    dist.broadcast(flat[a:b], src=src, group=group)
+            else:
+                small.append(flat)
+        if small:
+            bucket = torch.cat(small) if me == r else torch.empty(sum(f.numel() for f in small), dtype=torch.uint8,
+                                                                  device=small[0].device)
+            for a, b in _chunks(bucket.numel(), limit):
+                dist.broadcast(bucket[a:b], src=src, group=group)
+            if me != r:
+                off = 0
+                for f in small:
+                    f.copy_(bucket[off:off + f.numel()])
+                    off += f.numel()
+
+
+def reduce_chunked(t: torch.Tensor, dst: int, op=None, group=None, max_bytes: int | None = None):
+    """dist.reduce of a (large, contiguous) tensor to group rank `dst`, in calls of at most `max_bytes`."""
+    if not _initialized(group):
+        return
+    op = dist.ReduceOp.SUM if op is None else op
+    limit = MAX_COLLECTIVE_BYTES if max_bytes is None else max_bytes
+    flat = t.reshape(-1)
+    step = max(1, limit // t.element_size())
+    for a in range(0, flat.numel(), step):
+        dist.reduce(flat[a:a + step], dst=_global_rank(group, dst), op=op, group=group)

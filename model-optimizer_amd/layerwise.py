@@ -88,7 +88,6 @@ def _load_quantizer_state(layer, state):
                     q.pre_quant_scale = v.to(dev)
 
 
-@torch.no_grad()
 def _atomic_save(obj, path: str):
     tmp = path + ".tmp"
     with open(tmp, "wb") as f:
@@ -98,13 +97,22 @@ def _atomic_save(obj, path: str):
     os.replace(tmp, path)
 
 
-def _replay_to_layer(model, layers, start: int, forward_loop):
+@torch.no_grad()
+def _replay_to_layer(model, layers, start: int, forward_loop, qdq_from_prev_layer: bool = False):
     """Inputs of layer `start` when the saved ones cannot be trusted: the forward loop is run up to that layer through
-    the restored (calibrated) layers 0 .. start-1 -- with their quantizers bypassed, as the saved inputs were produced."""
+    the restored (calibrated) layers 0 .. start-1 -- with their quantizers bypassed, as the saved inputs were produced,
+    or ACTIVE when the run feeds every layer the quantized output of its predecessor (`qdq_from_prev_layer`).
+
+    The replay is exact for calibrations that leave the weights alone (max / mse / histogram).  After a
+    weight-mutating calibration (AWQ fold, SparseGPT, GPTQ-style updates) the restored layers carry their FINAL weights,
+    whereas the lost inputs came from layer N-1 before / while it was calibrated: the replayed activations then differ
+    from an uninterrupted run's by that layer's update (the caller warns)."""
     qs = [q for lyr in list(layers)[:start] for q in lyr.modules() if isinstance(q, TensorQuantizer)]
     saved = [(q._disabled, q._if_calib) for q in qs]
     for q in qs:
-        q._disabled, q._if_calib = True, False
+        if not qdq_from_prev_layer:
+            q._disabled = True
+        q._if_calib = False
     try:
         inputs = _capture_inputs(model, layers[start], forward_loop)
     finally:
@@ -115,6 +123,7 @@ def _replay_to_layer(model, layers, start: int, forward_loop):
     return inputs
 
 
+@torch.no_grad()
 def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None, checkpoint_dir: str | None = None,
                         get_qdq_activations_from_prev_layer: bool = False, calib_mutates_weights: bool = True,
                         **calib_kwargs):
@@ -150,8 +159,12 @@ def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None,
                         found = nxt.get("for_layer") if isinstance(nxt, dict) else "an older format"
                         warnings.warn(f"layerwise_calibrate: {checkpoint_dir}/next_inputs.pt holds the inputs of layer "
                                       f"{found}, the manifest resumes at layer {start} (interrupted checkpoint write); "
-                                      "re-capturing the inputs by replaying the finished layers")
-                        inputs = _replay_to_layer(model, layers, start, forward_loop)
+                                      "re-capturing the inputs by replaying the finished layers"
+                                      + ("; the calibration mutates weights, so the replayed activations are those of "
+                                         "the FINAL weights of the finished layers -- approximate, not those of an "
+                                         "uninterrupted run" if calib_mutates_weights else ""))
+                        inputs = _replay_to_layer(model, layers, start, forward_loop,
+                                                  get_qdq_activations_from_prev_layer)
                     else:
                         inputs = [(tuple(a.to(dev) if isinstance(a, torch.Tensor) else a for a in args), kwargs)
                                   for args, kwargs in nxt["inputs"]]

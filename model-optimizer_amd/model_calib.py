@@ -11,6 +11,7 @@ Host-side orchestration is the reference's; the passes over tensor data are HIP 
 from __future__ import annotations
 
 import math
+import time
 import warnings
 
 import torch
@@ -117,14 +118,19 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
 
 
 @torch.no_grad()
-def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True):
+def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, shard_weights: bool | None = None):
     """model_calib.py:310-498 (DP part): collect abs-max statistics for weights and activations, load them,
-    then MAX-reduce every amax across the data-parallel group in ONE bucket.  With a process group up, the weight
-    statistics are sharded over the ranks (weight_only_quantize) and each rank's forward_loop sees its own share of
-    the calibration batches."""
+    then MAX-reduce every amax across the data-parallel group in ONE bucket; each rank's forward_loop sees its own
+    share of the calibration batches.
+
+    shard_weights: deal the weight statistics over the ranks (weight_only_quantize(shard=True)); the values reach the
+    other ranks with the MAX bucket.  Only correct when every rank holds the SAME weights (data-parallel replicas):
+    under tensor parallelism / FSDP the ranks hold different shards and each must calibrate all of its own -- so the
+    default (None) shards only after `distributed.declare_data_parallel()`, and never without `distributed_sync`.
+    Tensor-parallel callers pass distributed_sync=False and synchronise by `distributed.sync_amax_tensor_parallel`."""
     sync = distributed_sync and _dist_on()
     enable_stats_collection(model, distributed_sync=sync)
-    weight_only_quantize(model, shard=sync)
+    weight_only_quantize(model, shard=sync and mdist.resolve_shard(shard_weights))
     if forward_loop is not None:
         forward_loop(model)
     finish_stats_collection(model)
@@ -404,9 +410,15 @@ class AWQLiteHelper:
         # are re-scored by the exact-rounding error-GEMM engine; `gram_loss` keeps the Gram scores for inspection
         self.scored_here = False  # this rank evaluated the Gram scores (data parallel: one rank per Gram matrix)
         self.gram_loss = None
-        self.contenders = None  # indices into `alphas`, ascending; None: the Gram scores decide
-        self.exact_buf = None  # fp32 [len(contenders)] accumulated by the error GEMM
+        self.contenders = None  # indices into `alphas`, ascending, of every re-scored candidate; None: the Gram scores decide
+        self.exact_buf = None  # fp32 [len(contenders)]: their exact scores
         self.num_exact_steps = 0
+        self.pending = None  # candidates the NEXT exact pass scores (indices, ascending); exact_pass_buf accumulates them
+        self.exact_pass_buf = None
+        self.exact_scores = {}  # candidate index -> exact score (host floats, summed over the ranks)
+        self.margin_used = None  # relative Gram margin the contender set was cut at (widened by the tie check)
+        self.tie_need = None  # TIE_SPREAD_FACTOR * S + gap_w of the last check, relative (None: not re-scored)
+        self.tie_rounds = 0  # how often the margin of this linear was widened
 
     def _padded(self, w: torch.Tensor, value: float = 0.0) -> torch.Tensor:
         return F.pad(w, (0, self.pad), "constant", value) if self.pad else w
@@ -508,6 +520,9 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
 # at full size, 2e-3 for 200-token test shapes).
 GRAM_TIE_MARGIN = {torch.bfloat16: 1e-3, torch.float16: 2e-4, torch.float32: 2e-5}
 GRAM_TIE_NOISE = 0.5
+# what the last awq_lite call did: wall-clock per stage, passes over the calibration data, re-scoring counts (tools,
+# bench.py `extra`); overwritten by every call
+AWQ_LITE_STATS: dict = {}
 # bf16 planes of the Gram scoring contraction <E G, E> (ops.gram_operand): 3 = split precision in both factors.  bf16
 # models screen with ONE plane (E and G rounded to bf16, a third of the contraction and of the operand memory): on the
 # full-size run (profiles/r02_awq_tie_margin.md, "scoring planes") the one-plane scores differ from the three-plane ones
@@ -516,6 +531,42 @@ GRAM_TIE_NOISE = 0.5
 # 106 re-scored candidates.  f16 models (margin 2e-4) keep the three planes.
 GRAM_SCORE_PLANES = {torch.bfloat16: 1, torch.float16: 3}
 GRAM_PLANES_SLACK = 3e-4
+# The margin checks itself (search="auto", tie_check=True).  For every re-scored candidate i both scores are known, hence
+# d_i = (exact_i - gram_i) / best_gram; S = max d - min d over the re-scored set measures how far the two engines disagree
+# about THIS linear's candidates.  A candidate k left out (Gram gap > margin) could still beat the exact winner w only if
+# d_w - d_k exceeds its Gram distance to w, i.e. margin - gap_w at least.  The unscored d_k is not known; it is taken to
+# lie within TIE_SPREAD_FACTOR x S of the scored ones (d varies smoothly with alpha; the factor covers the extrapolation
+# past the scored set).  So a linear is settled when  margin >= TIE_SPREAD_FACTOR * S + gap_w ; otherwise its margin is
+# widened to twice that requirement, the newly admitted candidates are re-scored in a further pass, and the check repeats
+# (at most TIE_CHECK_MAX_ROUNDS times, then every candidate of the linear is scored).  Full-size measurements
+# (profiles/r03_awq_tie_check.md): the synthetic outlier stack needs S <= 4.6e-5 against a 1.3e-3 margin (ratio 0.07); a
+# random-init HF Llama-3-8B, whose 11 candidates lie within 0.1-0.9 % of each other, shows S up to 8e-4 and a largest
+# overturned gap of 1.1e-4 -- there a few linears widen.
+TIE_SPREAD_FACTOR = 2.0
+TIE_CHECK_MAX_ROUNDS = 3
+
+
+def tie_margin_check(gram, exact_scores: dict, margin: float, rounds: int):
+    """One round of the margin's self-check for one linear (see TIE_SPREAD_FACTOR).  gram: the Gram scores of all
+    candidates; exact_scores: {candidate index: exact score} of the re-scored ones; margin: the relative Gram margin
+    they were admitted with; rounds: how often it was widened already.  Returns (need, new margin, new candidates):
+    need = TIE_SPREAD_FACTOR * S + gap_w (None when it cannot be formed); new candidates = [] when the linear is
+    settled (need <= margin, or every candidate is scored)."""
+    scored = sorted(exact_scores)
+    best = min(gram)
+    if len(scored) >= len(gram) or not math.isfinite(best) or best <= 0.0:
+        return None, margin, []
+    e = [exact_scores[i] for i in scored]
+    if not all(math.isfinite(v) for v in e):  # NaN / inf somewhere: score everything
+        return None, float("inf"), [i for i in range(len(gram)) if i not in exact_scores]
+    d = [(exact_scores[i] - gram[i]) / best for i in scored]
+    spread = max(d) - min(d)
+    w = scored[min(range(len(e)), key=e.__getitem__)]
+    need = TIE_SPREAD_FACTOR * spread + (gram[w] - best) / best
+    if need <= margin:
+        return need, margin, []
+    margin = float("inf") if rounds + 1 >= TIE_CHECK_MAX_ROUNDS else max(2.0 * need, 2.0 * margin)
+    return need, margin, [i for i, v in enumerate(gram) if i not in exact_scores and v <= best * (1.0 + margin)]
 
 
 def gram_score_planes(dtype) -> int:
@@ -527,7 +578,7 @@ def gram_score_planes(dtype) -> int:
 
 @torch.no_grad()
 def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto",
-             tie_margin: float | None = None):
+             tie_margin: float | None = None, tie_check: bool = True):
     """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
     (the INT4_AWQ_CFG preset).
 
@@ -541,9 +592,26 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              error-GEMM engine -- the reference's arithmetic with all its roundings -- and the best alpha is the
              first minimum of THOSE scores, so that the selection equals search="gemm" (model_calib.py:1489-1495,
              :1548-1556, :1637).  Linears with a clear winner cost nothing extra; when no linear has a near-tie the
-             extra pass is skipped."""
+             extra pass is skipped.  tie_check (default on): the margin verifies itself against the measured
+             disagreement of the two engines on the re-scored candidates and widens per linear when it was too
+             small (TIE_SPREAD_FACTOR); AWQ_LITE_STATS["tie_check"] reports the largest requirement / margin ratio."""
     if search not in ("auto", "gram", "gemm"):
         raise ValueError(f"awq_lite: unknown search mode {search!r}")
+    stats = AWQ_LITE_STATS
+    stats.clear()
+    stats.update({"search": search, "passes": 0, "stages_s": {}})
+    clock = {"t": None, "dev": None}
+
+    def stage(name):
+        """Wall-clock of the flow's stages (tools / bench `extra`): the device is drained only here, at points where the
+        host waits for statistics anyway."""
+        if clock["dev"] is not None and clock["dev"].type == "cuda":
+            torch.cuda.synchronize(clock["dev"])
+        now = time.perf_counter()
+        if name is not None and clock["t"] is not None:
+            stats["stages_s"][name] = round(stats["stages_s"].get(name, 0.0) + now - clock["t"], 4)
+        clock["t"] = now
+
     mods = [(n, m) for n, m in model.named_modules()
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
@@ -653,8 +721,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
         if h.use_gram:
             # scores came from the Gram matrix; only near-ties are re-scored with the reference's arithmetic
-            if state["do_exact"] and h.contenders is not None:
-                error_gemms(self, h, x2, out2, h.contenders, h.exact_buf)
+            if state["do_exact"] and h.pending:
+                error_gemms(self, h, x2, out2, h.pending, h.exact_pass_buf)
                 h.num_exact_steps += 1
         elif state["do_gemm"]:
             error_gemms(self, h, x2, out2, None, h.loss_buf)
@@ -708,7 +776,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             placement[id(o)] = r
             load[r] += cost[id(o)]
         for o in owners:  # same order on every rank
-            dist.reduce(o.gram, dst=placement[id(o)], op=dist.ReduceOp.SUM)
+            mdist.reduce_chunked(o.gram, placement[id(o)], dist.ReduceOp.SUM)  # <= 1 GiB per call
         return placement
 
     def gram_losses():
@@ -764,21 +832,78 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             best = min(row)  # a NaN score never compares smaller: such a linear keeps the plain first-minimum rule
             if not math.isfinite(best):
                 continue
+            h.margin_used = margin
             close = [i for i, v in enumerate(row) if v <= best * (1.0 + margin)]
             if len(close) > 1:
-                h.contenders = close
-                h.exact_buf = torch.zeros(len(close), dtype=torch.float32, device=m.weight.device)
-                h._inv_scale = h._scale_dt = h._w_hat = None
-                h._cache_w = budget.reserve(len(close) * m.weight.numel() * m.weight.element_size())
+                queue_exact(m, h, close)
                 any_tie = True
         return any_tie
+
+    def queue_exact(m, h, indices):
+        """The next exact pass scores these candidates of this linear."""
+        h.pending = list(indices)
+        h.exact_pass_buf = torch.zeros(len(indices), dtype=torch.float32, device=m.weight.device)
+        h.num_exact_steps = 0
+        if h._cache_w and h._w_hat is not None:
+            budget.release(h._w_hat.numel() * h._w_hat.element_size())
+        h._inv_scale = h._scale_dt = h._w_hat = None
+        h._cache_w = budget.reserve(len(indices) * m.weight.numel() * m.weight.element_size())
+
+    def collect_exact() -> bool:
+        """After an exact pass: the scores of the pending candidates (summed over the data-parallel group, so every
+        rank takes the same decisions) move to `exact_scores`; with tie_check every re-scored linear's margin is
+        verified against the measured disagreement of the two engines and widened if it was too small.  Returns whether
+        another exact pass is needed."""
+        todo = [(m, helpers[m]) for _, m in mods if helpers[m].pending]
+        if not todo:
+            return False
+        dev = todo[0][0].weight.device
+        steps = torch.tensor([float(h.num_exact_steps) for _, h in todo], device=dev)
+        if dist.is_available() and dist.is_initialized():
+            mdist.all_reduce_bucket([h.exact_pass_buf for _, h in todo] + [steps], dist.ReduceOp.SUM)
+        flat = torch.cat([h.exact_pass_buf for _, h in todo] + [steps]).cpu().tolist()  # one host sync
+        counts = flat[len(flat) - len(todo):]
+        off, again = 0, False
+        for (m, h), n_steps in zip(todo, counts):
+            vals = flat[off:off + len(h.pending)]
+            off += len(h.pending)
+            pend, h.pending, h.exact_pass_buf = h.pending, None, None
+            if h._cache_w and h._w_hat is not None:
+                budget.release(h._w_hat.numel() * h._w_hat.element_size())
+            h._inv_scale = h._scale_dt = h._w_hat = None
+            h._cache_w = False
+            h.exact_steps_all_ranks = int(n_steps)
+            if n_steps <= 0:
+                continue  # the second pass never reached this linear: the Gram scores stand
+            h.exact_scores.update(zip(pend, vals))
+            if not tie_check or tie_margin is not None and not math.isfinite(tie_margin):
+                continue
+            new = check_margin(h)
+            if new:
+                queue_exact(m, h, new)
+                again = True
+        return again
+
+    def check_margin(h):
+        """The self-check of the re-scoring margin (tie_margin_check): candidates to add, or [] when settled."""
+        need, margin, new = tie_margin_check(h.gram_loss, h.exact_scores, h.margin_used, h.tie_rounds)
+        if need is not None:
+            h.tie_need = need
+        if new:
+            h.tie_rounds += 1
+            h.margin_used = margin
+        return new
 
     try:
         # every OTHER enabled quantizer (KV-cache bmm quantizers, linears outside the search, ...) collects its amax
         # during the cache pass and quantizes during the search pass, as in the reference (:1574-1586); dynamic ones
         # are switched to pass-through for the cache pass
         enable_stats_collection(others_holder)
+        clock["dev"] = mods[0][1].weight.device if mods else None
+        stage(None)
         forward_loop(model)  # cache pass
+        stats["passes"] += 1
+        stage("cache_pass")
         finish_stats_collection(others_holder)
         if others and dist.is_available() and dist.is_initialized():
             mdist.sync_amax_bucketed([q for q in others if not q._dynamic],
@@ -815,9 +940,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                     c = h.act_scale.numel()
                     h.prepare_scales(flat[off:off + c], flat[off + c:off + 2 * c], m.weight.dtype)
                     off += 2 * c
+        stage("scales")
         if state["gram_pass"] == "cache":
             gram_losses()
             state["do_exact"] = pick_contenders()
+        stage("gram_scores")
         need_gemm = any(not h.use_gram and h.act_scale is not None for h in helpers.values())
         need_gram = state["gram_pass"] == "search" and any(h.gram is not None for h in helpers.values())
         if need_gemm or need_gram or state["do_exact"]:
@@ -825,34 +952,37 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             # search pass: error GEMMs (all candidates of the linears without a Gram matrix, the near-ties of the
             # others), and the Gram matrices when they had to wait for quantized inputs
             forward_loop(model)
+            stats["passes"] += 1
+            stage("search_pass")
             state["do_gemm"] = False
             if need_gram:
                 finish_gram_pass()
                 gram_losses()
                 state["gram_pass"] = None
                 state["do_exact"] = pick_contenders()
-                if state["do_exact"]:
-                    forward_loop(model)  # the near-ties of linears whose Gram matrix came from this pass
+                stage("gram_scores")
+            elif state["do_exact"]:
+                state["do_exact"] = collect_exact()
+            while state["do_exact"]:
+                # the near-ties of linears whose Gram matrix came from the search pass; candidates admitted by the
+                # margin's self-check (tie_check)
+                forward_loop(model)
+                stats["passes"] += 1
+                stage("search_pass")
+                state["do_exact"] = collect_exact()
         for h in helpers.values():
             if not getattr(h, "loss_synced", False):
                 h.search_steps_all_ranks = h.num_search_steps
-            h.exact_steps_all_ranks = h.num_exact_steps
         if dist.is_available() and dist.is_initialized() and mods:
             # every rank must pick the same alpha -- and take the same "was it searched at all" decision: SUM the
             # per-alpha losses and the search-step counters in one bucket (Gram-scored linears were summed when the
-            # near-ties were picked; their exact scores travel here)
+            # near-ties were picked, their exact scores after every exact pass: collect_exact)
             dev = mods[0][1].weight.device
             late = [h for h in helpers.values() if not getattr(h, "loss_synced", False)]
-            exact = [h for h in helpers.values() if h.contenders is not None]
-            steps = torch.tensor([float(h.num_search_steps) for h in late] + [float(h.num_exact_steps) for h in exact],
-                                 device=dev)
-            mdist.all_reduce_bucket([h.loss_buf for h in late] + [h.exact_buf for h in exact] + [steps],
-                                    dist.ReduceOp.SUM)
-            counts = steps.tolist()
-            for h, n in zip(late, counts[:len(late)]):
+            steps = torch.tensor([float(h.num_search_steps) for h in late], device=dev)
+            mdist.all_reduce_bucket([h.loss_buf for h in late] + [steps], dist.ReduceOp.SUM)
+            for h, n in zip(late, steps.tolist()):
                 h.search_steps_all_ranks = int(n)
-            for h, n in zip(exact, counts[len(late):]):
-                h.exact_steps_all_ranks = int(n)
     finally:
         for m, f in originals.items():
             m.forward = f
@@ -894,11 +1024,13 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                                                            device=m.weight.device)
             restore_input_quantizer(m, h)
             continue
-        if h.contenders is not None and h.exact_steps_all_ranks > 0:
+        if h.exact_scores:
             # near-ties: the exact scores replace the Gram scores of the re-scored candidates and decide among them
             # (ascending alpha, first minimum: the reference's dict order, :1637)
+            h.contenders = sorted(h.exact_scores)
+            exact = [h.exact_scores[i] for i in h.contenders]
+            h.exact_buf = torch.tensor(exact, dtype=torch.float32, device=h.loss_buf.device)
             h.loss_buf[torch.tensor(h.contenders, device=h.loss_buf.device)] = h.exact_buf
-            exact = h.exact_buf.tolist()
             losses = {a: float(v) for a, v in h.loss.items()}
             h.best_alpha = h.alphas[h.contenders[min(range(len(exact)), key=exact.__getitem__)]]
         else:
@@ -924,6 +1056,17 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             # :1257-1265: amax of the smoothed activation, the product taken in the weight dtype
             smooth = iq._amax_for_smoothing.to(device=m.weight.device, dtype=m.weight.dtype)
             iq.amax = (smooth * pre_quant_scale.to(m.weight.device)).amax().to(m.weight.dtype)
+    stage("fold")
+    resc = [h for h in helpers.values() if h.contenders is not None]
+    checked = [h for h in resc if h.tie_need is not None and h.margin_used and math.isfinite(h.margin_used)]
+    stats.update({"linears": len(mods), "rescored_linears": len(resc),
+                  "rescored_candidates": sum(len(h.contenders) for h in resc),
+                  "tie_check": {"enabled": bool(tie_check), "spread_factor": TIE_SPREAD_FACTOR,
+                                "checked_linears": len(checked),
+                                "widened_linears": sum(1 for h in resc if h.tie_rounds),
+                                "max_need_over_margin": round(max((h.tie_need / h.margin_used for h in checked),
+                                                                  default=0.0), 4),
+                                "max_need": max((h.tie_need for h in checked), default=0.0)}})
     return helpers
 
 
@@ -1038,7 +1181,7 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
     out = {}
     with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
         if algorithm in ("awq_full", "awq_lite"):
-            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin")}
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin", "tie_check")}
             out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
         if algorithm in ("awq_full", "awq_clip"):
             clip_kw = {k: v for k, v in kwargs.items()

@@ -236,7 +236,8 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     if method is None:
         return model
     if method == "max":  # MaxCalibConfig.distributed_sync (config.py): off for callers that synchronise by their own rules
-        model_calib.max_calibrate(model, forward_loop, distributed_sync=bool(kwargs.get("distributed_sync", True)))
+        model_calib.max_calibrate(model, forward_loop, distributed_sync=bool(kwargs.get("distributed_sync", True)),
+                                  shard_weights=kwargs.get("shard_weights"))
     elif method == "mse":
         model_calib.mse_calibrate(model, forward_loop, **kwargs)
     elif method == "smoothquant":
@@ -245,4 +246,103 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
         model_calib.awq(model, forward_loop, algorithm=method, **kwargs)
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
+    return model
+
+
+# ------------------------------------------------------------------------------------------------ fold_weight
+def _fold_kind(w, wq):
+    """Which whole-model launch can fold this (weight, quantizer) pair; None: the quantizer's own forward."""
+    import torch
+
+    if (not w.is_cuda or not w.is_contiguous() or w.dtype not in (torch.float32, torch.float16, torch.bfloat16)
+            or wq.pre_quant_scale is not None or w.data_ptr() % 16 or w.numel() == 0):
+        return None
+    nb = wq._num_bits if not isinstance(wq._num_bits, list) else tuple(wq._num_bits)
+    amax = getattr(wq, "_amax", None)
+    if wq._block_sizes is None and wq._axis is None and amax is not None and amax.numel() == 1:
+        if nb == (4, 3):
+            return ("fp8",)
+        if isinstance(nb, int):
+            return ("int", nb, bool(wq._unsigned), bool(wq._narrow_range))
+    if wq.is_mx_format and isinstance(nb, (tuple, int)):
+        g = wq._block_sizes.get(-1, None) or wq._block_sizes.get(w.dim() - 1, None)
+        fmt = {(2, 1): "E2M1", (4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3", 8: "INT8"}.get(nb)
+        if g and fmt and w.shape[-1] % g == 0 and set(wq._block_sizes) <= {-1, w.dim() - 1, "type", "scale_bits"}:
+            return ("mx", int(g), fmt)
+    if (wq.is_static_block_quant and amax is None and isinstance(nb, int) and w.dim() == 2
+            and set(wq._block_sizes) <= {-1, 1, "type"}):
+        g = wq._block_sizes.get(-1, None) or wq._block_sizes.get(1, None)
+        if g and w.shape[-1] % g == 0:
+            return ("group", int(g), nb, bool(wq._unsigned), bool(wq._narrow_range))
+    return None
+
+
+def fold_weight(model: nn.Module, keep_attrs: bool = False, shard_weights: bool | None = None):
+    """mtq.fold_weight (quantization/model_quant.py:728-736 -> QuantModule.fold_weight / _fold_weight_quantizer,
+    nn/modules/quant_module.py:132-186): every fake-quant weight quantizer is baked into its weight in place and
+    disabled; `_amax` / `_pre_quant_scale` are dropped unless `keep_attrs` (a kept pre-quant scale is made inactive).
+    Sequential (W4A8) weight quantizers are left alone, as in the reference.
+
+    The reference folds tensor by tensor through the quantizer's forward; here all weights that share a format are
+    quantize-dequantized by ONE multi-tensor launch (per-tensor FP8 / INT-k with their calibrated amax, dynamic MX
+    blocks, dynamic per-group INT-k), the rest go through their quantizer.
+
+    shard_weights (data-parallel replicas, distributed.declare_data_parallel): the (weight, quantizer) units are dealt
+    over the ranks, each rank folds its share and the folded weights are broadcast from their owners, so every replica
+    ends up with every folded weight."""
+    import torch
+
+    from . import distributed as mdist
+    from .hf_experts import is_quant_fused_experts
+    from .multi_tensor import SegmentTable
+    from .nn import is_quantized_linear
+
+    units = []
+    for m in model.modules():
+        if is_quantized_linear(m) and isinstance(m.weight_quantizer, TensorQuantizer) and m.weight_quantizer.fake_quant:
+            units.append((m.weight.data, m.weight_quantizer))
+        elif is_quant_fused_experts(m):
+            units += [(w.data if hasattr(w, "data") else w, q) for w, q in m.iter_weights_for_calibration()
+                      if isinstance(q, TensorQuantizer) and q.fake_quant]
+    shard = mdist.resolve_shard(shard_weights)
+    mine = mdist.shard_list(units) if shard else units
+    with torch.no_grad():
+        groups, single = {}, []
+        for w, wq in mine:
+            if wq._disabled:
+                continue  # disabled and no pre-quant scale / rotation on this path: the forward is the identity
+            kind = _fold_kind(w, wq)
+            if kind is None:
+                single.append((w, wq))
+            else:
+                groups.setdefault((kind, w.dtype, w.device), []).append((w, wq))
+        for (kind, _, _), pairs in groups.items():
+            ws = [w for w, _ in pairs]
+            if kind[0] in ("fp8", "int"):
+                tab = SegmentTable(ws, outputs=ws)
+                tab.amax_flat.copy_(torch.cat([wq._amax.detach().reshape(1).float() for _, wq in pairs]))
+                if kind[0] == "fp8":
+                    tab.fake_quant_e4m3()
+                else:
+                    tab.fake_quant_int(kind[1], kind[2], kind[3])
+            elif kind[0] == "mx":
+                SegmentTable(ws, outputs=ws).mx_fused_amax_convert(kind[1], kind[2])
+            else:
+                SegmentTable(ws, outputs=ws, group_size=kind[1]).amax_qdq_int_group(kind[2], kind[3], kind[4])
+        for w, wq in single:
+            w.copy_(wq(w.contiguous()).to(w.dtype))
+        if shard:
+            mdist.broadcast_from_owners([w for w, _ in units], group=mdist.replica_group())
+        seen = set()
+        for _, wq in units:
+            if id(wq) in seen:
+                continue
+            seen.add(id(wq))
+            wq.disable()
+            if keep_attrs and hasattr(wq, "_pre_quant_scale"):
+                wq._enable_pre_quant_scale = False
+            elif not keep_attrs:
+                for attr in ("_pre_quant_scale", "_amax"):
+                    if hasattr(wq, attr):
+                        delattr(wq, attr)
     return model

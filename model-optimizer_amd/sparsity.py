@@ -165,6 +165,44 @@ def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, 
     return (weight != 0).view(shape)
 
 
+def _combine_hessians(mods, states, owner_of) -> dict:
+    """Data-parallel SparseGPT: every rank accumulated H_r = (2 / S_r) sum_{its batches} X^T X over S_r samples.  The
+    Hessian over ALL batches is sum_r (S_r / S) H_r: each rank scales its matrices by S_r, the distinct matrices are
+    dealt over the ranks (largest first onto the least loaded one) and SUM-reduced to their owner in calls of at most
+    1 GiB, the owner divides by S.  Returns {Hessian-owning module: group rank, "me": this rank}; every rank must see
+    the same input-sharing structure (same model, same forward)."""
+    import torch.distributed as dist
+
+    from . import distributed as mdist
+
+    group = mdist.replica_group()
+    owners = [m for m in mods if m not in owner_of]
+    sig = [(mods.index(m), tuple(states[m]._h.shape)) for m in owners]
+    gathered = [None] * dist.get_world_size(group)
+    dist.all_gather_object(gathered, sig, group=group)
+    if any(g != sig for g in gathered):
+        raise RuntimeError("sparsegpt (data parallel): the ranks do not agree on which linears share their input")
+    dev = states[owners[0]]._h.device
+    samples = torch.tensor([float(states[m].samples) for m in owners], dtype=torch.float64, device=dev)
+    total = samples.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    load = [0] * dist.get_world_size(group)
+    placed = {"me": dist.get_rank(group)}
+    cost = {m: sum(x.weight.numel() for x in mods if owner_of.get(x, x) is m) * states[m]._h.shape[0] for m in owners}
+    for m in sorted(owners, key=lambda m: -cost[m]):
+        r = min(range(len(load)), key=load.__getitem__)
+        placed[m] = r
+        load[r] += cost[m]
+    for m, s_r, s in zip(owners, samples.tolist(), total.tolist()):  # same order on every rank
+        h = states[m].hessian
+        h.mul_(s_r)
+        mdist.reduce_chunked(h, placed[m], dist.ReduceOp.SUM, group)
+        if placed[m] == placed["me"]:
+            h.div_(max(s, 1.0))
+            states[m].samples = int(s)
+    return placed
+
+
 def check_weight_size_sgpt(weight: torch.Tensor, pattern: str = _PATTERN_2_4, mod_name: str = "") -> bool:
     """SparseGPTSearcher._check_weight_size (sparsegpt.py:152-165)."""
     _, _, m = get_nmprune_info(pattern)
@@ -174,17 +212,50 @@ def check_weight_size_sgpt(weight: torch.Tensor, pattern: str = _PATTERN_2_4, mo
     return True
 
 
+def _magnitude_masks(targets, pattern: str, shard: bool) -> dict:
+    """2:4 magnitude masks of all target linears.  2-D contiguous GPU weights of one dtype are masked by ONE
+    multi-tensor launch (SegmentTable.mask_2to4); anything else goes through create_asp_mask.  shard: this rank computes
+    the masks of its share of the list (distributed.shard_list) and receives the others from their owners."""
+    from . import distributed as mdist
+    from .multi_tensor import SegmentTable
+
+    masks = {m: torch.empty(m.weight.shape, dtype=torch.bool, device=m.weight.device) for _, m in targets}
+    mine = mdist.shard_list(targets) if shard else targets
+    batched: dict = {}
+    for _, m in mine:
+        w = m.weight.detach()
+        if w.is_cuda and w.dim() == 2 and w.is_contiguous() and w.shape[1] % 4 == 0 and pattern == _PATTERN_2_4:
+            batched.setdefault((w.dtype, w.device), []).append(m)
+        else:
+            masks[m].copy_(create_asp_mask(m.weight, pattern))
+    for mods in batched.values():
+        SegmentTable([m.weight.detach() for m in mods], outputs=[masks[m] for m in mods]).mask_2to4()
+    if shard:
+        mdist.broadcast_from_owners([masks[m] for _, m in targets], group=mdist.replica_group())
+    return masks
+
+
 @torch.no_grad()
-def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loop=None, config: dict | None = None):
+def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loop=None, config: dict | None = None,
+             shard_weights: bool | None = None):
     """mts.sparsify for the two modes of the path (sparsification.py:32-97): every eligible nn.Linear gets a bool
     `_weight_mask` buffer and its weight is masked in place (the reference's SparseModule multiplies on access).
-    "sparsegpt": forward hooks accumulate the input Hessians during forward_loop, then create_sgpt_mask."""
+    "sparsegpt": forward hooks accumulate the input Hessians during forward_loop, then create_sgpt_mask.
+
+    shard_weights (data-parallel replicas; None follows distributed.declare_data_parallel): the mask computation is
+    dealt over the ranks and the masks are broadcast from their owners.  SparseGPT: every rank's forward_loop feeds its
+    own share of the calibration batches; the distinct Hessians are dealt over the ranks, combined on their owner
+    (sample-weighted SUM, the running mean of sparsegpt.py:238-276 over ALL batches), and only the owner inverts the
+    Hessian and sweeps the linears that read it."""
+    from . import distributed as mdist
+
     cfg = {"pattern": _PATTERN_2_4, "col_block_size": 128, "row_block_size": -1, "hessian_damp": 0.1, **(config or {})}
+    shard = mdist.resolve_shard(shard_weights)
     # weight_sparsity/config.py:27-45: {"nn.Linear": {"*": {}, "*lm_head*": None}} -- the output head stays dense
     linears = [(n, m) for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and not fnmatch.fnmatch(n, "*lm_head*")]
     if mode == "sparse_magnitude":
         targets = [(n, m) for n, m in linears if check_weight_size(m.weight, n)]
-        masks = {m: create_asp_mask(m.weight, cfg["pattern"]) for _, m in targets}
+        masks = _magnitude_masks(targets, cfg["pattern"], shard)
     elif mode == "sparsegpt":
         assert forward_loop is not None, "Please provide `data_loader` or `forward_loop`!"
         targets = [(n, m) for n, m in linears if check_weight_size_sgpt(m.weight, cfg["pattern"], n)]
@@ -221,8 +292,15 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
             own = owner_of.get(m, m)
             users[own] = users.get(own, 0) + 1
         masks = {}
+        placed = None
+        if shard:
+            placed = _combine_hessians([m for _, m in targets], states, owner_of)
         for _, m in targets:
             own = owner_of.get(m, m)
+            if placed is not None and placed[own] != placed["me"]:
+                masks[m] = torch.empty(m.weight.shape, dtype=torch.bool, device=m.weight.device)
+                states[own]._h = None
+                continue
             if own not in prepared:
                 prepared[own] = prepare_hessian(states[own].hessian, cfg["hessian_damp"])
                 states[own]._h = None  # Cin^2 floats: only the inverse factor is needed from here on
@@ -231,6 +309,10 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
             users[own] -= 1
             if users[own] == 0:
                 del prepared[own]
+        if placed is not None:
+            mdist.broadcast_from_owners([masks[m].contiguous() if masks[m].is_contiguous() else masks[m] for _, m in targets],
+                                        group=mdist.replica_group(),
+                                        owners=[placed[owner_of.get(m, m)] for _, m in targets])
     else:
         raise ValueError(f"sparsity mode {mode!r} is outside this path")
     for _, m in targets:

@@ -1,0 +1,97 @@
+"""The self-check of the AWQ re-scoring margin (model_calib.tie_margin_check), replayed on MEASURED score tables.
+
+tests/golden/awq_hf_tables.json holds, for the 224 linears of a random-init Hugging Face Llama-3-8B (bf16, 64 x 4096
+calibration tokens, one MI355X, round 3), the Gram score and the error-GEMM ("exact": the reference's arithmetic,
+model_calib.py:1489-1495, :1548-1556) score of ALL 11 candidates.  It is the adversarial case for the Gram screen: all
+candidates of a linear lie within 0.1-0.9 % of each other, the two engines disagree by up to 8e-4 between candidates of
+one linear and the plain Gram minimum is not the exact minimum on 30 linears.  The policy under test decides which
+candidates to re-score from the Gram scores alone, sees the exact scores only of those, and must end on the exact
+minimum (first minimum in ascending alpha, :1637)."""
+
+import json
+import os
+
+import pytest
+
+import _moa_import
+
+moa = _moa_import.load()
+from model_optimizer_amd import model_calib  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def tables():
+    with open(os.path.join(HERE, "golden", "awq_hf_tables.json")) as f:
+        return [(lin["gram"], lin["exact"]) for lin in json.load(f)["linears"]]
+
+
+def _first_min(values):
+    return min(range(len(values)), key=values.__getitem__)
+
+
+def _search(gram, exact, margin, check):
+    """awq_lite's selection for one linear: contenders within `margin` of the best Gram score are re-scored; with
+    `check` the margin verifies itself and widens (every widening is one more pass over the calibration data)."""
+    best = min(gram)
+    pending = [i for i, v in enumerate(gram) if v <= best * (1.0 + margin)]
+    if len(pending) < 2:
+        return _first_min(gram), 0, 0
+    scored, rounds, passes = {}, 0, 0
+    while pending:
+        passes += 1
+        scored.update({i: exact[i] for i in pending})
+        if not check:
+            break
+        _, new_margin, pending = model_calib.tie_margin_check(gram, scored, margin, rounds)
+        if pending:
+            rounds += 1
+            margin = new_margin
+    idx = sorted(scored)
+    return idx[_first_min([scored[i] for i in idx])], len(scored), passes
+
+
+def test_plain_gram_minimum_is_not_enough_on_this_model(tables):
+    assert sum(_first_min(g) != _first_min(e) for g, e in tables) >= 20
+
+
+def test_default_margin_with_self_check_finds_every_exact_minimum(tables):
+    margin = model_calib.GRAM_TIE_MARGIN[moa.ops.torch.bfloat16] + model_calib.GRAM_PLANES_SLACK
+    wrong = cands = extra = 0
+    for g, e in tables:
+        w, n, passes = _search(g, e, margin, check=True)
+        wrong += w != _first_min(e)
+        cands += n
+        extra += passes > 1
+    assert wrong == 0
+    assert cands < 0.55 * 11 * len(tables)  # about half of the full search, even on this all-ties model
+    assert 0 < extra <= 10  # a few linears widen: the check has teeth here, and it is not the common case
+
+
+def test_too_small_a_fixed_margin_flips_linears_and_the_self_check_repairs_them(tables):
+    fixed = sum(_search(g, e, 1e-4, check=False)[0] != _first_min(e) for g, e in tables)
+    assert fixed >= 1, "the fixture lost its teeth"
+    checked = sum(_search(g, e, 1e-4, check=True)[0] != _first_min(e) for g, e in tables)
+    # the check repairs what it can measure; a margin an order of magnitude too small is not fully recoverable (a linear
+    # with one candidate inside it re-scores nothing), which is why the default margin stays at 1e-3 and the check is
+    # the safeguard on top of it, not a replacement for it
+    assert checked < fixed
+
+
+def test_tie_margin_check_rounds_and_nan():
+    gram = [1.0, 1.0005, 1.002, 1.01, 1.2]
+    # engines agree -> settled
+    need, margin, new = model_calib.tie_margin_check(gram, {0: 1.0, 1: 1.0005}, 1e-3, 0)
+    assert new == [] and margin == 1e-3 and need == pytest.approx(0.0, abs=1e-12)
+    # they disagree by 1e-3 between the two scored candidates -> need = 2e-3 (+ the winner's gap), margin doubles that
+    need, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, 0)
+    assert need == pytest.approx(2e-3 + 5e-4) and margin == pytest.approx(2 * need) and new == [2]
+    # last round: everything that is left
+    _, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, model_calib.TIE_CHECK_MAX_ROUNDS - 1)
+    assert margin == float("inf") and new == [2, 3, 4]
+    # a NaN exact score: score every candidate
+    _, _, new = model_calib.tie_margin_check(gram, {0: float("nan"), 1: 1.0}, 1e-3, 0)
+    assert new == [2, 3, 4]
+    # all scored: nothing to add
+    assert model_calib.tie_margin_check(gram, dict(enumerate(gram)), 1e-3, 0)[2] == []

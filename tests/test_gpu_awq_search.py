@@ -257,6 +257,83 @@ def test_auto_search_rescoring_near_ties_equals_gemm_search(dtype):
         assert flipped > 0, "no seed where the plain Gram search disagrees: the test lost its teeth"
 
 
+class AdversarialStack(torch.nn.Module):
+    """Heavy-tailed weights (Student-t, 3 degrees of freedom) or plain Gaussian ones."""
+
+    def __init__(self, dims, dtype, seed, student):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.linears = torch.nn.ModuleList()
+        for co, ci in dims:
+            lin = torch.nn.Linear(ci, co, bias=False)
+            with torch.no_grad():
+                w = torch.randn(co, ci, generator=g)
+                if student:
+                    w = w / torch.sqrt((torch.randn(3, co, ci, generator=g) ** 2).sum(0) / 3)
+                lin.weight.copy_(w * 0.02)
+            self.linears.append(lin)
+        self.to(dtype)
+
+    def forward(self, xs):
+        return [lin(x) for lin, x in zip(self.linears, xs)]
+
+
+def _adversarial_batches(dims, dtype, n, tokens, seed, massive):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        xs = []
+        for _, ci in dims:
+            x = torch.randn(tokens, ci, generator=g) * torch.exp(0.02 * torch.randn(ci, generator=g))
+            if massive:  # 1 % of the tokens are 60x larger than the rest
+                x[torch.randint(0, tokens, (max(1, tokens // 100),), generator=g)] *= 60.0
+            xs.append(x.to(dtype).to(DEV))
+        out.append(xs)
+    return out
+
+
+def _run_adversarial(kind, seed, search, **kw):
+    dims, dtype = [(256, 512), (512, 256), (128, 1024)], torch.bfloat16
+    model = AdversarialStack(dims, dtype, seed, student=kind == "student").to(DEV)
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": search, **kw}
+    b = _adversarial_batches(dims, dtype, 2, 200, seed + 100, massive=kind == "massive")
+    q = moa.quantize(model, cfg, lambda m: [m(x) for x in b])
+    from model_optimizer_amd import model_calib
+
+    return [lin.awq_lite for lin in q.linears], dict(model_calib.AWQ_LITE_STATS)
+
+
+@pytest.mark.parametrize("kind", ["student", "massive"])
+def test_self_checking_margin_on_adversarial_distributions(kind, monkeypatch):
+    """Heavy-tailed weights / activations with 1 % massive tokens, flat loss curves: the default search equals
+    search="gemm" on every linear, the margin's self-check reports requirement / margin <= 1; and with the check forced to
+    distrust every margin (an absurd TIE_SPREAD_FACTOR) the widening loop -- more passes over the data, more candidates
+    per pass, the last round scoring everything -- still ends on the same selection with the same exact scores."""
+    from model_optimizer_amd import model_calib
+
+    monkeypatch.setattr(model_calib._WeightCacheBudget, "host_bytes", 1 << 30)  # CPU re-run tier: Gram matrices on the host
+    for seed in range(3):
+        gemm, _ = _run_adversarial(kind, seed, "gemm")
+        auto, st = _run_adversarial(kind, seed, "auto")
+        assert [h.best_alpha for h in auto] == [h.best_alpha for h in gemm], f"{kind} seed {seed}"
+        tc = st["tie_check"]
+        assert tc["enabled"] and tc["max_need_over_margin"] <= 1.0 + 1e-9 or tc["widened_linears"] > 0
+    monkeypatch.setattr(model_calib, "TIE_SPREAD_FACTOR", 1e6)
+    gemm, _ = _run_adversarial(kind, 1, "gemm")
+    forced, st = _run_adversarial(kind, 1, "auto", tie_margin=0.01)  # wide enough for near-ties on most linears
+    assert [h.best_alpha for h in forced] == [h.best_alpha for h in gemm]
+    widened = [h for h in forced if h.tie_rounds]
+    assert widened and st["tie_check"]["widened_linears"] == len(widened) and st["passes"] >= 3
+    for h, hg in zip(forced, gemm):
+        if h.tie_rounds:
+            assert h.contenders == list(range(11))  # widened until every candidate was scored
+            assert torch.equal(h.loss_buf, hg.loss_buf)  # each candidate scored exactly once, by the same kernel
+    off, _ = _run_adversarial(kind, 1, "auto", tie_margin=0.01, tie_check=False)
+    assert all(h.tie_rounds == 0 for h in off) and any(h.contenders is not None for h in off)
+    assert sum(len(h.contenders or []) for h in off) < sum(len(h.contenders or []) for h in forced)
+
+
 def test_auto_search_margins():
     dims, dt = [(256, 512), (128, 1024)], torch.bfloat16
     gemm, _ = _run_flat(dims, dt, 1, 0.02, "gemm")

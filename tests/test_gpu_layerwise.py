@@ -149,3 +149,28 @@ def test_layerwise_resume_after_an_interrupted_checkpoint_write(tmp_path):
     assert set(a) == set(b)
     for k in a:
         assert torch.equal(a[k], b[k]), f"{k}: run resumed from re-captured inputs differs"
+
+
+def test_layerwise_runs_without_autograd(tmp_path):
+    """calib_func, the input capture, the hand-over to the next layer and the replay after an interrupted checkpoint
+    write all run under no_grad (no autograd graph through every decoder-layer forward on the 70B flow)."""
+    model, batches = _setup(model_quant.FP8_DEFAULT_CFG)
+    seen = []
+
+    class Probe(torch.nn.Module):
+        def forward(self, x):
+            seen.append(torch.is_grad_enabled())
+            return x
+
+    for layer in model.layers:
+        layer.fc1 = torch.nn.Sequential(Probe(), layer.fc1)
+
+    def calib(layer, loop, **kw):
+        seen.append(torch.is_grad_enabled())
+        model_calib.max_calibrate(layer, loop, **kw)
+
+    with torch.enable_grad():
+        layerwise.layerwise_calibrate(model, lambda m: [m(b) for b in batches], calib, checkpoint_dir=str(tmp_path))
+        inputs = layerwise._replay_to_layer(model, model.layers, 2, lambda m: [m(b) for b in batches])
+    assert seen and not any(seen), "autograd was enabled inside the layerwise flow"
+    assert all(not a.requires_grad for args, _ in inputs for a in args if isinstance(a, torch.Tensor))

@@ -125,6 +125,8 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
         "rescored_linears": len(rescored), "rescored_candidates": sum(len(h.contenders) for h in rescored),
         "search_gemm_TFLOPs_equiv": round(flops / dt / 1e12, 1),
         "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))},
+        "passes": moa.model_calib.AWQ_LITE_STATS.get("passes"), "stages_s": moa.model_calib.AWQ_LITE_STATS.get("stages_s"),
+        "tie_check": moa.model_calib.AWQ_LITE_STATS.get("tie_check"),
         "best_alphas": alphas}
 
 

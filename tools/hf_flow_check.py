@@ -15,19 +15,27 @@ sys.path.insert(0, ROOT)
 import _moa_import  # noqa: E402
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq"])
     ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
                     help="mixtral: 8 experts per layer with fused 3-D expert weights (Mixtral-8x7B layer shapes)")
-    args = ap.parse_args()
+    ap.add_argument("--search", default=None, choices=["auto", "gram", "gemm"], help="awq_lite search engine")
+    ap.add_argument("--tie-margin", type=float, default=None, help="awq_lite re-scoring margin (inf: every candidate)")
+    ap.add_argument("--dump", default=None, help="write every linear's AWQ score tables to this JSON file")
+    ap.add_argument("--note", default=None)
+    return ap.parse_args(argv)
+
+
+def run(args, moa=None, dev=None) -> dict:
+    """One flow; returns the result line.  `args`: parse_args() namespace (bench.py builds one for its `extra`)."""
     from transformers import LlamaConfig, LlamaForCausalLM, MixtralConfig, MixtralForCausalLM
 
-    moa = _moa_import.load()
+    moa = moa or _moa_import.load()
     mq = moa.model_quant
-    dev = torch.device("cuda:0")
+    dev = dev or torch.device("cuda:0")
     cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=args.layers, num_attention_heads=32,
                       num_key_value_heads=8, vocab_size=128256, max_position_embeddings=8192, architectures=["LlamaForCausalLM"])
     torch.manual_seed(1234)
@@ -53,6 +61,16 @@ def main():
     qcfg = {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
             "int4_awq": mq.INT4_AWQ_CFG, "w4a8_awq": mq.W4A8_AWQ_BETA_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
             "int8_sq": mq.INT8_SMOOTHQUANT_CFG}[args.qformat]
+    if args.search or args.tie_margin is not None:
+        import copy
+
+        qcfg = copy.deepcopy(qcfg)
+        alg = qcfg["algorithm"] if isinstance(qcfg["algorithm"], dict) else {"method": qcfg["algorithm"]}
+        if args.search:
+            alg["search"] = args.search
+        if args.tie_margin is not None:
+            alg["tie_margin"] = args.tie_margin
+        qcfg["algorithm"] = alg
     t0 = time.perf_counter()
     moa.quantize(model, qcfg, loop)
     torch.cuda.synchronize()
@@ -71,17 +89,34 @@ def main():
     n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
     awq = [m.awq_lite for m in model.modules() if hasattr(m, "awq_lite")]
     extra = {}
+    if args.note:
+        extra["note"] = args.note
+    if awq and args.dump:
+        os.makedirs(os.path.dirname(os.path.abspath(args.dump)), exist_ok=True)
+        named = [(n, m) for n, m in model.named_modules() if hasattr(m, "awq_lite")]
+        with open(args.dump, "w") as f:
+            json.dump({"search": args.search, "tie_margin": args.tie_margin, "alphas": awq[0].alphas,
+                       "planes": os.environ.get("MOQ_TUNE_GRAM_PLANES"),
+                       "linears": [{"name": n, "shape": list(m.weight.shape), "best_alpha": float(m.awq_lite.best_alpha),
+                                    "loss": [float(v) for v in m.awq_lite.loss_buf.tolist()],
+                                    "gram_loss": m.awq_lite.gram_loss, "contenders": m.awq_lite.contenders}
+                                   for n, m in named]}, f)
     if awq:
+        extra["awq_stats"] = dict(moa.model_calib.AWQ_LITE_STATS)
         alphas = [round(float(h.best_alpha), 1) for h in awq if h.best_alpha is not None]
-        extra = {"awq_rescored_linears": sum(1 for h in awq if h.contenders is not None),
-                 "awq_rescored_candidates": sum(len(h.contenders) for h in awq if h.contenders is not None),
-                 "awq_best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}}
-    print(json.dumps({"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
+        extra.update({"awq_rescored_linears": sum(1 for h in awq if h.contenders is not None),
+                      "awq_rescored_candidates": sum(len(h.contenders) for h in awq if h.contenders is not None),
+                      "awq_best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))}})
+    return ({"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
                       "plain_forward_loop_s": round(t_plain, 3), "quantize_s": round(t_quant, 3),
                       "fake_quant_forward_s": round(t_fq, 3), "export_state_dict_s": round(t_export, 3),
                       "enabled_quantizers": n_q, "exported_tensors": len(state),
                       "logits_finite": bool(torch.isfinite(logits).all()),
-                      "kv_cache_quant_algo": moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"], **extra}))
+                      "kv_cache_quant_algo": moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"], **extra})
+
+
+def main():
+    print(json.dumps(run(parse_args())), flush=True)
 
 
 if __name__ == "__main__":
