@@ -9,8 +9,19 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function ${MOQ_EXTRA_FLAGS:-}"
 objs=()
 pids=()
-for src in moq_*.hip; do
-  obj="build/${src%.hip}.o"
+# MOQ_EXPERIMENTS=1: exp/moq_gemm_exp.hip (every loop structure that was built and measured, including timing-only
+# diagnostics that return wrong results by construction) is compiled IN PLACE of the release moq_gemm.hip -- a library
+# for tools/gemm_bench.py and tools/exp/, never the one that ships
+SRCS=(moq_*.hip)
+if [ "${MOQ_EXPERIMENTS:-0}" = "1" ]; then
+  SRCS=("${SRCS[@]/moq_gemm.hip/exp/moq_gemm_exp.hip}")
+  FLAGS="$FLAGS -DMOQ_EXPERIMENTS -I."
+  OUT=${1:-libmoquant_exp.so}
+  echo "[moquant] EXPERIMENT build -> $OUT"
+fi
+for src in "${SRCS[@]}"; do
+  base=$(basename "$src")
+  obj="build/${base%.hip}.o"
   mkdir -p build
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ moq_chunk.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
     echo "[moquant] hipcc $src"

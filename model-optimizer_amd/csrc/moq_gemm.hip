@@ -7,19 +7,25 @@
 // exactly where the reference materialises `out`, subtracted from out_actual in the model dtype, squared in
 // fp32 and reduced -- `out` (T x Cout) is never written to HBM.
 //
-// Tiling (gfx950, wave64): 128(n) x 128(t) x 64(k) per 256-thread workgroup, 2 x 2 waves, each wave owns
-// 64 x 64 as 2 x 2 v_mfma_f32_32x32x16 tiles (64 accumulator VGPRs).  Both operands are K-contiguous
-// ([Cout, Cin] weights, [tokens, Cin] activations), so an MFMA fragment is one 16-byte run of k per lane.
+// Tiling (gfx950, wave64): 256(n) x 256(t) x 64(k) per 512-thread workgroup, 2 x 4 waves, each wave owns 128 x 64 as
+// 4 x 2 v_mfma_f32_32x32x16 tiles (128 accumulator VGPRs).  Both operands are K-contiguous ([Cout, Cin] weights,
+// [tokens, Cin] activations), so an MFMA fragment is one 16-byte run of k per lane.
 // HBM -> LDS goes through `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass); the buffer
 // descriptor's bounds check returns zeros for rows past the matrix edge and for the K tail, so ragged
 // shapes need no second kernel.  LDS rows are 128 B (64 k); the 16-byte chunk c of row r is stored at chunk
 // position c ^ ((r >> 1) & 7): a ds_read_b128 fragment read (32 rows x one chunk column) then touches 16
 // distinct 16-byte slots per 16-lane service group = conflict-free (MI355X_MICROARCH.md, LDS table).  The
 // swizzle is applied on the *source* address because the LDS side of the DMA is lane-linear.
-// Two LDS buffers (64 KiB per workgroup -> 2 workgroups per CU); tile k+1 streams in while tile k is in the
-// matrix cores; one barrier per K-step.
+// Two LDS stages of an A and a B tile (128 KiB per workgroup, one workgroup per CU); tile k+1 streams in while tile k is
+// in the matrix cores; one barrier per K-step.
 //
 // Roofline: MFMA-bound.  2 * T * Cout * Cin flop per launch against ~2.5 PFLOP/s dense bf16.
+//
+// This file is the RELEASE contraction: the two loop structures that ship (GEO 10, the default, and GEO 4, its
+// known-good predecessor -- same tile, same k order per accumulator, bit-identical results).  Every other structure that was
+// built and measured on the way (128 x 128 tiles, four-stage K = 32, the ping-pong groups, direct-to-register token
+// operands, and the timing-only diagnostics that return wrong results by construction) lives in exp/moq_gemm_exp.hip and
+// is compiled only by `MOQ_EXPERIMENTS=1 build.sh` (profiles/r01_gemm_table.md, r02_gemm_table.md).
 #include <atomic>
 #include <type_traits>
 #include <stdlib.h>
@@ -36,42 +42,16 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int kBK = 64;            // k per stage
 constexpr int kRowBytes = kBK * 2;  // 128 B LDS rows
 
-// Tile geometries.  Waves form a WN x WT grid; each wave owns NI x NJ MFMA tiles of 32 x 32.
-//   GEO 0: 128 x 128, 4 waves, ONE 32 KiB LDS stage, ~4 workgroups per CU hide each other's DMA waits
-//   GEO 1: 128 x 128, 4 waves, two stages; all fragments of a K-step are read before the next DMA is issued
-//          (hipcc orders an LDS-DMA before every later ds_read with vmcnt(0), so reads must come first)
-//   GEO 2: 256 x 256, 8 waves, two 64 KiB stages, ONE workgroup per CU; the DMA is issued from inline asm right
-//          after the barrier (the compiler then neither sees a pending LDS write nor drains it early) and lands
-//          under the K-step's 32 MFMAs per wave; half the L2->LDS bytes per flop of the 128 x 128 tile
-template <int GEO> struct Geo;
-template <> struct Geo<0> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 1; };
-template <> struct Geo<1> { static constexpr int TILE = 128, WAVES = 4, WN = 2, NI = 2, NJ = 2, STAGES = 2; };
-template <> struct Geo<2> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-//   GEO 3: 256 x 256, 8 waves, K-step 32 with FOUR 32 KiB stages: three tiles (96 KiB) stay in flight and the wait
-//          before a step is a counted vmcnt(8) (never 0 in steady state) -- the GEO 2 loop keeps one 64 KiB tile in
-//          flight and drains the queue every step, which parks its waves ~35 % of the time (SQ_WAIT_ANY)
-template <> struct Geo<3> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 4; };
-//   GEO 4: GEO 2 with the K-loop rotated by one sub-step: the MFMAs of the LAST sub-step of tile k run after the barrier
-//          that opens tile k + 1, underneath that tile's first fragment reads -- the matrix cores no longer idle
-//          through "wait for the DMA, barrier, first ds_reads" at every K-step boundary
-template <> struct Geo<4> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-//   GEO 5 (experiment): the GEO 4 loop with FOUR waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator registers, one
-//          wave per SIMD): 8 fragment reads per 16 MFMAs instead of 6 per 8 -- a third less LDS read traffic
-template <> struct Geo<5> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
-//   GEO 7 (experiment): GEO 4 with the next tile's eight LDS-DMA pieces issued ONE AT A TIME after every second MFMA of
-//          the first two sub-steps (pinned with sched_barrier) instead of as one block of eight between two MFMA groups
-template <> struct Geo<7> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+// Waves form a WN x WT grid; each wave owns NI x NJ MFMA tiles of 32 x 32.
+//   GEO 4:  256 x 256, 8 waves, two 64 KiB stages, ONE workgroup per CU; the next tile's LDS-DMA is issued from inline asm
+//           right after the barrier; the K-loop is rotated by one sub-step: the MFMAs of the LAST sub-step of tile k run
+//           after the barrier that opens tile k + 1, underneath that tile's first fragment reads
 //   GEO 10 (default): the GEO 4 loop as ONE pinned stream in which every MFMA is followed by one memory instruction --
-//          a fragment read of the NEXT sub-step or an LDS-DMA piece of the next tile (32 MFMAs : 24 reads + 8 pieces per
-//          wave and K-tile = 1 : 1, the recipe of the hand-scheduled kernels); the pieces go out in the first two
-//          sub-steps so that they have two sub-steps of lead before the tile-boundary wait
-template <> struct Geo<10> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-//   GEO 8 / 9 (diagnostics, wrong results by construction -- timing only, tools/gemm_bench.py): the GEO 4 loop with ONLY
-//          its LDS-DMA traffic (8: no fragment reads, no MFMAs) or ONLY its compute (9: no DMA after the prologue)
-template <> struct Geo<8> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-template <> struct Geo<9> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
-template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
-template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
+//           a fragment read of the NEXT sub-step or an LDS-DMA piece of the next tile (32 MFMAs : 24 reads + 8 pieces per
+//           wave and K-tile = 1 : 1, the recipe of the hand-scheduled kernels); the pieces go out in the first two
+//           sub-steps so that they have two sub-steps of lead before the tile-boundary wait
+template <int GEO> struct Geo { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * kRowBytes; }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
 template <int GEO> constexpr int lds_bytes() { return Geo<GEO>::STAGES * stage_bytes<GEO>(); }
 
@@ -141,114 +121,6 @@ __device__ __forceinline__ Pack16 read_frag(const uint8_t* lds_tile, int r, int 
   return *reinterpret_cast<const Pack16*>(lds_tile + r * kRowBytes + ((c ^ ((r >> 1) & 7)) << 4));
 }
 
-// one K-step (64 k) of a wave's NI x NJ tiles from the stage at `stage`.  Fragments are double-buffered in
-// registers: the reads of sub-step ks+1 are in flight while the MFMAs of sub-step ks issue.  `after_first`
-// runs once the first sub-step's reads have been issued (GEO 2 issues the next tile's DMA there, so its address
-// arithmetic hides under the LDS latency instead of delaying the first MFMA after the barrier).
-template <int DT, int GEO, class F>
-__device__ __forceinline__ void k_step(const uint8_t* stage, int wn, int wt, int fr, int fh,
-                                       f32x16_t (&acc)[Geo<GEO>::NI][Geo<GEO>::NJ], F&& after_first) {
-  constexpr int NI = Geo<GEO>::NI, NJ = Geo<GEO>::NJ;
-  const uint8_t* la = stage + (wn * NI * 32) * kRowBytes;
-  const uint8_t* lb = stage + tile_bytes<GEO>() + (wt * NJ * 32) * kRowBytes;
-  Pack16 a[2][NI], b[2][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) a[0][i] = read_frag(la, i * 32 + fr, fh);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) b[0][j] = read_frag(lb, j * 32 + fr, fh);
-  after_first();
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int cur = ks & 1, nxt = cur ^ 1;
-    if (ks < 3) {
-      const int c = (ks + 1) * 2 + fh;
-#pragma unroll
-      for (int i = 0; i < NI; ++i) a[nxt][i] = read_frag(la, i * 32 + fr, c);
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) b[nxt][j] = read_frag(lb, j * 32 + fr, c);
-    }
-#ifdef MOQ_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[cur][i], b[cur][j], acc[i][j]);
-#ifdef MOQ_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#ifndef MOQ_GEMM_NOPIN
-    // pin the issue order hipcc would otherwise collapse: the next sub-step's reads go out first, then this
-    // sub-step's MFMAs run while they are in flight (mask 0x100 = DS read, 0x008 = MFMA)
-    if (ks < 3) __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
-#endif
-  }
-}
-
-// ---- GEO 3: 64-byte LDS rows (32 k).  Chunk c (0..3) of row r sits at position c ^ ((r >> 2) & 3): the 16 rows of a
-// ds_read_b128 service group then cover 16 distinct 16-byte slots of the 256-byte bank row (conflict-free).
-// One wave-instruction of the DMA moves 16 rows x 64 B: lane l fills (row l >> 2, position l & 3).
-__device__ __forceinline__ void stage_tile3(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
-                                            int wave, int lane) {
-  constexpr int PER_WAVE = 256 / 16 / 8;  // 2
-  const int r_local = lane >> 2, pos = lane & 3;
-  const i32x4_t rs = desc.words;
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int rbase = (wave * PER_WAVE + j) * 16;
-    const int r = rbase + r_local;
-    const int c = pos ^ ((r >> 2) & 3);
-    const int k = k0 + c * 8;
-    const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
-    uint8_t* dst = lds_tile + rbase * 64;
-    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                 :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
-  }
-}
-__device__ __forceinline__ Pack16 read_frag3(const uint8_t* lds_tile, int r, int c) {
-  return *reinterpret_cast<const Pack16*>(lds_tile + r * 64 + ((c ^ ((r >> 2) & 3)) << 4));
-}
-// one K-step of 32 k (two MFMA sub-steps) from the stage at `stage`
-template <int DT, class F>
-__device__ __forceinline__ void k_step3(const uint8_t* stage, int wn, int wt, int fr, int fh,
-                                        f32x16_t (&acc)[4][2], F&& after_first) {
-  constexpr int NI = 4, NJ = 2;
-  const uint8_t* la = stage + (wn * NI * 32) * 64;
-  const uint8_t* lb = stage + tile_bytes<3>() + (wt * NJ * 32) * 64;
-  Pack16 a[2][NI], b[2][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) a[0][i] = read_frag3(la, i * 32 + fr, fh);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) b[0][j] = read_frag3(lb, j * 32 + fr, fh);
-  after_first();
-#pragma unroll
-  for (int i = 0; i < NI; ++i) a[1][i] = read_frag3(la, i * 32 + fr, 2 + fh);
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) b[1][j] = read_frag3(lb, j * 32 + fr, 2 + fh);
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[ks][i], b[ks][j], acc[i][j]);
-  }
-}
-
-// one LDS-DMA piece: rows rbase .. rbase + 7 of an operand tile for the K-step starting at k0 (stage_tile's loop body)
-__device__ __forceinline__ void stage_piece(const TileDesc& desc, uint8_t* lds_tile, int64_t ld_bytes, int k0, int K,
-                                            int rbase, int lane) {
-  const int r = rbase + (lane >> 3), pos = lane & 7;
-  const int c = pos ^ ((r >> 1) & 7);
-  const int k = k0 + c * 8;
-  const int voff = k < K ? (int)(r * ld_bytes + k * 2) : 0x7FFFFFF0;
-  const i32x4_t rs = desc.words;
-  uint8_t* dst = lds_tile + rbase * kRowBytes;
-  const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)dst);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(m0v), "v"(voff), "s"(rs) : "memory");
-}
 
 // Workgroup -> output tile.  (1) XCD-aware: workgroup b runs on XCD b % 8; each XCD gets a contiguous run of tile ids
 // (bijective for any grid size).  (2) Grouped order inside the run: consecutive ids -- the 32 workgroups an XCD runs at a
@@ -390,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
 //         ONCE when the accumulation is over (moq_symmetrize);
 // MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
-__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 ? 1 : 2))
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, 2)
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ w,     // [N, K]
                      const void* __restrict__ ref,   // [T, N] (MODE 0)
@@ -435,12 +307,11 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 4 || GEO == 5 || GEO == 7 || GEO == 8 || GEO == 9 || GEO == 10) {
+  {
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
     Pack16 a[2][NI], b[2][NJ];
     auto read_sub = [&](int buf, int stage_off, int ks) {
-      if constexpr (GEO == 8) return;
       const int c = ks * 2 + fh;
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[buf][i] = read_frag(la0 + stage_off, i * 32 + fr, c);
@@ -448,7 +319,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       for (int j = 0; j < NJ; ++j) b[buf][j] = read_frag(lb0 + stage_off, j * 32 + fr, c);
     };
     auto mma_sub = [&](int buf) {
-      if constexpr (GEO == 8) return;
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -463,7 +333,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     // range (one v_cndmask on a wave-uniform condition).  `live` = false (no next tile): the piece still issues --
     // against an empty descriptor, filling its rows of the idle stage with zeros -- instead of branching around every
     // piece of the pinned streams.  Three to four instructions per piece, no branch, one VALU.
-    constexpr bool kFourPerOperand = Geo<GEO>::WAVES == 8;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * 4 * 8 * kRowBytes));
     const bool k_ragged = (K & (kBK - 1)) != 0;
@@ -488,31 +357,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       rr.z = live ? rr.z : 0;
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                    :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
-    };
-    // (piece indices must be compile-time constants: they select the lane-offset register)
-    auto mma_sub_staged = [&](int buf, int sn, int k0, auto P0, bool on) {
-      constexpr int p0 = decltype(P0)::value;
-      static_assert(NI == 4, "one piece after every second MFMA");
-      acc[0][0] = mfma32<DT>(a[buf][0], b[buf][0], acc[0][0]);
-      acc[0][1] = mfma32<DT>(a[buf][0], b[buf][1], acc[0][1]);
-      __builtin_amdgcn_sched_barrier(0);
-      piece(sn, k0, IC<p0 + 0>{}, on);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1][0] = mfma32<DT>(a[buf][1], b[buf][0], acc[1][0]);
-      acc[1][1] = mfma32<DT>(a[buf][1], b[buf][1], acc[1][1]);
-      __builtin_amdgcn_sched_barrier(0);
-      piece(sn, k0, IC<p0 + 1>{}, on);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[2][0] = mfma32<DT>(a[buf][2], b[buf][0], acc[2][0]);
-      acc[2][1] = mfma32<DT>(a[buf][2], b[buf][1], acc[2][1]);
-      __builtin_amdgcn_sched_barrier(0);
-      piece(sn, k0, IC<p0 + 2>{}, on);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[3][0] = mfma32<DT>(a[buf][3], b[buf][0], acc[3][0]);
-      acc[3][1] = mfma32<DT>(a[buf][3], b[buf][1], acc[3][1]);
-      __builtin_amdgcn_sched_barrier(0);
-      piece(sn, k0, IC<p0 + 3>{}, on);
-      __builtin_amdgcn_sched_barrier(0);
     };
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
@@ -564,42 +408,14 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
         }
         continue;
       }
-      if constexpr (GEO == 7) {
-        const int sn = (kt + 1) & 1;
-        const bool more = kt + 1 < nk;
-        const int k0 = (kt + 1) * kBK;
-        if (kt > 0) {
-          mma_sub_staged(1, sn, k0, std::integral_constant<int, 0>{}, more);
-        } else if (more) {
-          piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
-        }
-        read_sub(1, so, 1);
-        mma_sub_staged(0, sn, k0, std::integral_constant<int, 4>{}, more);
-        read_sub(0, so, 2);
-        __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
-        mma_sub(1);
-        __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
-        read_sub(1, so, 3);
-        __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
-        mma_sub(0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
-        continue;
-      }
       if (kt > 0) {
         mma_sub(1);  // last sub-step of tile kt - 1, under the reads above
         __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ, 0);
       }
-      if (GEO != 9 && kt + 1 < nk) {  // next tile's DMA, issued in the gaps of the MFMAs above
-        const int sn = (kt + 1) & 1;
-        if constexpr (kFourPerOperand) {
-          const int k0 = (kt + 1) * kBK;
-          piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
-          piece(sn, k0, IC<4>{}); piece(sn, k0, IC<5>{}); piece(sn, k0, IC<6>{}); piece(sn, k0, IC<7>{});
-        } else {
-          uint8_t* nxt = smem + sn * SB;
-          stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-          stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        }
+      if (kt + 1 < nk) {  // next tile's DMA, issued in the gaps of the MFMAs above
+        const int sn = (kt + 1) & 1, k0 = (kt + 1) * kBK;
+        piece(sn, k0, IC<0>{}); piece(sn, k0, IC<1>{}); piece(sn, k0, IC<2>{}); piece(sn, k0, IC<3>{});
+        piece(sn, k0, IC<4>{}); piece(sn, k0, IC<5>{}); piece(sn, k0, IC<6>{}); piece(sn, k0, IC<7>{});
       }
       read_sub(1, so, 1);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
@@ -617,246 +433,11 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     mma_sub(1);  // last sub-step of the last tile
     // the last tile's "dead" pieces (zero fills of the idle stage) must have landed before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else if constexpr (GEO == 3) {
-    constexpr int BK3 = 32;
-    const int nk3 = (K + BK3 - 1) / BK3;
-    // prologue: three tiles in flight
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      if (p < nk3) {
-        stage_tile3(rs_w, smem + p * SB, ld_bytes, p * BK3, K, wave, lane);
-        stage_tile3(rs_x, smem + p * SB + TB, ld_bytes, p * BK3, K, wave, lane);
-      }
-    }
-    for (int kt = 0; kt < nk3; ++kt) {
-      // tile kt has landed once at most the DMA pieces of the (up to two) younger tiles are outstanding:
-      // 4 pieces per tile per wave
-      if (kt + 2 < nk3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (kt + 1 < nk3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // everyone's part of tile kt landed; everyone finished reading stage (kt - 1) % 4
-      k_step3<DT>(smem + (kt & 3) * SB, wn, wt, fr, fh, acc, [&]() {
-        if (kt + 3 < nk3) {
-          uint8_t* nxt = smem + ((kt + 3) & 3) * SB;
-          stage_tile3(rs_w, nxt, ld_bytes, (kt + 3) * BK3, K, wave, lane);
-          stage_tile3(rs_x, nxt + TB, ld_bytes, (kt + 3) * BK3, K, wave, lane);
-        }
-      });
-    }
-  } else if constexpr (GEO == 2) {
-    stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
-    stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's part of tile kt has landed
-      __syncthreads();  // ... everyone's has, and everyone is done reading the other stage (K-step kt-1)
-      k_step<DT, GEO>(smem + (kt & 1) * SB, wn, wt, fr, fh, acc, [&]() {
-        if (kt + 1 < nk) {
-          uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
-          stage_tile<GEO, true>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-          stage_tile<GEO, true>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        }
-      });
-    }
-  } else if constexpr (GEO == 1) {
-    stage_tile<GEO, false>(rs_w, smem, ld_bytes, 0, K, wave, lane);
-    stage_tile<GEO, false>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
-    for (int kt = 0; kt < nk; ++kt) {
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();  // tile kt landed for everyone; everyone finished reading the other stage
-      const uint8_t* cur = smem + (kt & 1) * SB;
-      const uint8_t* la = cur + (wn * 64) * kRowBytes;
-      const uint8_t* lb = cur + TB + (wt * 64) * kRowBytes;
-      Pack16 a0[4], a1[4], b0[4], b1[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks * 2 + fh;
-        a0[ks] = read_frag(la, fr, c); a1[ks] = read_frag(la, 32 + fr, c);
-        b0[ks] = read_frag(lb, fr, c); b1[ks] = read_frag(lb, 32 + fr, c);
-      }
-      if (kt + 1 < nk) {
-        uint8_t* nxt = smem + ((kt + 1) & 1) * SB;
-        stage_tile<GEO, false>(rs_w, nxt, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-        stage_tile<GEO, false>(rs_x, nxt + TB, ld_bytes, (kt + 1) * kBK, K, wave, lane);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        acc[0][0] = mfma32<DT>(a0[ks], b0[ks], acc[0][0]);
-        acc[0][1] = mfma32<DT>(a0[ks], b1[ks], acc[0][1]);
-        acc[1][0] = mfma32<DT>(a1[ks], b0[ks], acc[1][0]);
-        acc[1][1] = mfma32<DT>(a1[ks], b1[ks], acc[1][1]);
-      }
-    }
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      stage_tile<GEO, false>(rs_w, smem, ld_bytes, kt * kBK, K, wave, lane);
-      stage_tile<GEO, false>(rs_x, smem + TB, ld_bytes, kt * kBK, K, wave, lane);
-      __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();
-      k_step<DT, GEO>(smem, wn, wt, fr, fh, acc, []() {});
-      __syncthreads();  // all fragment reads done before the next tile overwrites the stage
-    }
   }
 
   gemm_epilogue<DT, MODE, NI, NJ, Geo<GEO>::WAVES>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, wn, wt, fr, fh,
                                                    lane, wave, decay, scale, upper_only);
 }
-
-// ---- GEO 6: the 256 x 256 x 64 tile as a two-group ping-pong (cdna_hip_programming.md 5, "8-phase" idea restated on
-// this kernel's 32x32x16 tiles and whole-tile double buffer).
-//
-// What limited GEO 4 (PMC, profiles/r01_gemm_table.md): all eight waves meet at ONE barrier per K-tile and then do the
-// same thing at the same time -- wait for the DMA, read fragments, multiply -- so the matrix pipe of every SIMD idles
-// through each "wait, barrier, first reads" stretch (MFMA busy 46 %, waves parked 36 %).  Here the two waves that share
-// a SIMD (wave w and w + 4: one of each GROUP) never do the same thing: a K-tile is four phases of
-//     R: fragment reads + two LDS-DMA pieces      | barrier |      M: one quadrant of the wave's 128 x 64 tile, 8 MFMAs
-// and group 1 runs ONE barrier behind group 0, so in every interval between two barriers one wave of each SIMD
-// multiplies while the other reads and stages.  The DMA never drains: the pieces of tile kt + 1 / kt + 2 are issued two
-// per phase, and the single wait per K-tile (`vmcnt(2)` at the start of the tile's last phase) leaves the newest two in
-// flight; a tile is first read two barriers after every wave waited for its own pieces of it.
-//
-// Per wave and K-tile: R1 reads a0 b0 b1 (16 x ds_read_b128), R2 reads a1 (8); all reads of tile kt are retired before
-// the wave's third phase, so from there on tile kt's stage takes the pieces of tile kt + 2.  Piece order of a wave
-// (8 per tile: A rows of its own group's half, B rows of its eighth of the token tile, alternating):
-//     R3(kt): (kt+2)[0,1]   R4(kt): wait, (kt+2)[2,3]   R1(kt+1): (kt+2)[4,5]   R2(kt+1): (kt+2)[6,7]
-// Hazards.  RAW: wave waits vmcnt at R4(kt) for ALL its pieces of tile kt + 1 (<= 2 newer ones outstanding); group 0
-// reads that tile two barriers later, group 1 three.  WAR: a stage is re-filled only after every reader passed an
-// `s_waitcnt lgkmcnt(0)` (end of each M segment) and a barrier.
-#define MOQ_BAR()                                   \
-  do {                                              \
-    asm volatile("s_barrier" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);              \
-  } while (0)
-#define MOQ_M_END()                                            \
-  do {                                                         \
-    __builtin_amdgcn_s_setprio(0);                             \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
-    __builtin_amdgcn_sched_barrier(0);                         \
-  } while (0)
-
-template <int DT, int MODE>
-__global__ __launch_bounds__(512, 2)
-void err_gemm6_kernel(const void* __restrict__ x, const void* __restrict__ w, const void* __restrict__ ref,
-                      const void* __restrict__ bias, void* __restrict__ out, float* __restrict__ partial, int T, int N,
-                      int K, int tiles_t, int tiles_n, int64_t x_stride, int64_t w_stride, float decay, float scale,
-                      int upper_only) {
-  constexpr int TILE = 256, NI = 4, NJ = 2;
-  constexpr int TB = TILE * kRowBytes, SB = 2 * TB;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
-  if constexpr (MODE == 2) {
-    // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
-    if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
-  }
-  const int n0 = tn * TILE, t0 = tt * TILE;
-  x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
-  w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
-  if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
-  const int rows_w = N - n0 < TILE ? N - n0 : TILE;
-  const int rows_x = T - t0 < TILE ? T - t0 : TILE;
-  const int64_t ld_bytes = (int64_t)K * 2;
-  const TileDesc rs_w = make_tile_desc(reinterpret_cast<const uint8_t*>(w) + (int64_t)n0 * ld_bytes,
-                                       (int)(rows_w * ld_bytes));
-  const TileDesc rs_x = make_tile_desc(reinterpret_cast<const uint8_t*>(x) + (int64_t)t0 * ld_bytes,
-                                       (int)(rows_x * ld_bytes));
-  f32x16_t acc[NI][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  const int g = wave >> 2, wq = wave & 3;  // group = the wave's n half (A rows g * 128 ..), wq = its 64 tokens
-  const int fr = lane & 31, fh = lane >> 5;
-  const int nk = (K + kBK - 1) / kBK;
-  const uint8_t* la0 = smem + (g * NI * 32) * kRowBytes;
-  const uint8_t* lb0 = smem + TB + (wq * NJ * 32) * kRowBytes;
-  Pack16 a[NI][4], b[NJ][4];
-
-  // piece p (0..7) of this wave for K-tile `kt`: even = 8 rows of the group's A half, odd = 8 rows of the B tile
-  auto issue = [&](int kt, int p) {
-    uint8_t* st = smem + (kt & 1) * SB;
-    const int j = p >> 1;
-    if (p & 1) stage_piece(rs_x, st + TB, ld_bytes, kt * kBK, K, (wave * 4 + j) * 8, lane);
-    else stage_piece(rs_w, st, ld_bytes, kt * kBK, K, g * 128 + (wq * 4 + j) * 8, lane);
-  };
-  auto read_a = [&](int so, int i0) {  // row blocks i0, i0 + 1 of the wave's A half, all four k sub-steps
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[i0 + i][ks] = read_frag(la0 + so, (i0 + i) * 32 + fr, ks * 2 + fh);
-  };
-  auto read_b = [&](int so, int j) {
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b[j][ks] = read_frag(lb0 + so, j * 32 + fr, ks * 2 + fh);
-  };
-  auto quadrant = [&](int i0, int j) {  // 8 MFMAs: two accumulators, four dependent k sub-steps each
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      acc[i0][j] = mfma32<DT>(a[i0][ks], b[j][ks], acc[i0][j]);
-      acc[i0 + 1][j] = mfma32<DT>(a[i0 + 1][ks], b[j][ks], acc[i0 + 1][j]);
-    }
-  };
-
-  // prologue: tile 0 whole, the first half of tile 1
-#pragma unroll
-  for (int p = 0; p < 8; ++p) issue(0, p);
-  if (nk > 1) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) issue(1, p);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  MOQ_BAR();
-  if (g == 1) MOQ_BAR();  // group 1 runs one barrier behind group 0 from here on
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int so = (kt & 1) * SB;
-    const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
-    // ---- phase 1
-    read_b(so, 0);
-    read_b(so, 1);
-    read_a(so, 0);
-    if (has1) { issue(kt + 1, 4); issue(kt + 1, 5); }
-    MOQ_BAR();
-    quadrant(0, 0);
-    MOQ_M_END();
-    MOQ_BAR();
-    // ---- phase 2
-    read_a(so, 2);
-    if (has1) { issue(kt + 1, 6); issue(kt + 1, 7); }
-    MOQ_BAR();
-    quadrant(0, 1);
-    MOQ_M_END();
-    MOQ_BAR();
-    // ---- phase 3: every read of tile kt is retired (M_END above + barrier): its stage takes tile kt + 2
-    if (has2) { issue(kt + 2, 0); issue(kt + 2, 1); }
-    MOQ_BAR();
-    quadrant(2, 1);
-    MOQ_M_END();
-    MOQ_BAR();
-    // ---- phase 4: this wave's pieces of tile kt + 1 have landed (the two just issued may still fly)
-    if (has1) {
-      if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    if (has2) { issue(kt + 2, 2); issue(kt + 2, 3); }
-    MOQ_BAR();
-    quadrant(2, 0);
-    MOQ_M_END();
-    MOQ_BAR();
-  }
-  if (g == 0) MOQ_BAR();  // same number of barriers for both groups
-  gemm_epilogue<DT, MODE, NI, NJ, 8>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, g, wq, fr, fh, lane, wave,
-                                     decay, scale, upper_only);
-}
-#undef MOQ_BAR
-#undef MOQ_M_END
 
 // loss_acc[0] += (float)(sum(partial) / count): partial sums are added in index order in double
 __global__ void err_finalize_kernel(const float* __restrict__ partial, int n, double inv_count,
@@ -906,244 +487,13 @@ static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout
   return MOQ_OK;
 }
 
-// ---- GEO 12: 256 x 256 x 64 with FOUR waves (one per SIMD), the token operand direct to registers.
-//
-// What bounds the 8-wave loops (profiles/r02_gemm_table.md): two 64 KiB LDS stages are all that fits, so a K-tile's
-// operands are requested ONE tile ahead; every first touch of an operand slice by an XCD misses its L2 (~19 % of the
-// requests), takes longer than a tile and parks the whole workgroup at the tile's barrier.  Here only the WEIGHT tile
-// (256 rows, shared by the waves) goes through the LDS -- 32 KiB stages, FOUR of them -- and each wave owns a 64-token
-// column slab of the tile whose x rows nobody else reads: they go from HBM/L2 straight to the wave's registers in MFMA
-// fragment layout (`buffer_load_dwordx4`, 32 VGPRs per K-tile, three register buffers).  Both operands are then
-// requested THREE tiles ahead (~2.5 us of matrix work); the wait before a tile is a counted `vmcnt(32)` that never
-// drains the queue, and near the end of K "dead" loads against an empty descriptor keep that count uniform.
-//
-// Per wave and K-tile: 64 MFMAs (8 weight blocks x 2 token blocks x 4 sub-steps) : 32 ds_read_b128 + 8 LDS-DMA pieces
-// + 8 register loads.  LDS traffic drops to 32 KiB written + 128 KiB read per tile (8-wave loops: 64 + 192).
-// k order inside a tile: sub-step j multiplies, for the half-wave h = lane >> 5, k = 32 h + 8 j .. + 7 -- a lane's four
-// register loads of a row are then 64 contiguous bytes, issued back to back so that the row's line is fetched once.
-// The same permutation is applied to the weight fragments (chunk 4 h + j); a sum over k does not care.
-//
-// Hazards.  RAW: wave waits `vmcnt(32)` -- everything it requested for tile kt has landed -- then the barrier makes
-// the weight stage everyone's.  WAR (LDS): stage (kt + 3) & 3 = (kt - 1) & 3 is refilled after the barrier that opens
-// tile kt, which every wave passes only after its fragment reads of tile kt - 1 were waited for (lgkmcnt before the
-// MFMAs that consume them).  WAR (registers): buffer kt % 3 is reloaded after the last MFMA that reads it was issued.
-template <int DT>
-__device__ __forceinline__ f32x16_t mfma32v(const i32x4_t& a, const i32x4_t& b, f32x16_t c) {
-  if constexpr (DT == MOQ_BF16) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c,
-                                                   0, 0, 0);
-  } else {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0,
-                                                  0, 0);
-  }
-}
-
-// DIAG (timing only, wrong results): 1 = MFMAs alone, 2 = MFMAs + fragment reads, 3 = MFMAs + HBM requests,
-// 4 = HBM requests alone
-template <int DT, int MODE, int DIAG = 0>
-__global__ __launch_bounds__(256, 1)
-void err_gemm12_kernel(const void* __restrict__ x, const void* __restrict__ w, const void* __restrict__ ref,
-                       const void* __restrict__ bias, void* __restrict__ out, float* __restrict__ partial, int T, int N,
-                       int K, int tiles_t, int tiles_n, int64_t x_stride, int64_t w_stride, float decay, float scale,
-                       int upper_only) {
-  constexpr int TILE = 256, NI = 8, NJ = 2;
-  constexpr int TB = TILE * kRowBytes;  // one weight stage: 32 KiB
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
-  if constexpr (MODE == 2) {
-    // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
-    if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
-  }
-  const int n0 = tn * TILE, t0 = tt * TILE;
-  x = reinterpret_cast<const uint8_t*>(x) + (int64_t)blockIdx.y * x_stride * 2;
-  w = reinterpret_cast<const uint8_t*>(w) + (int64_t)blockIdx.y * w_stride * 2;
-  if constexpr (MODE == 1) out = reinterpret_cast<uint8_t*>(out) + (int64_t)blockIdx.y * (int64_t)T * N * 2;
-  const int rows_w = N - n0 < TILE ? N - n0 : TILE;
-  const int rows_x = T - t0 < TILE ? T - t0 : TILE;
-  const int64_t ld_bytes = (int64_t)K * 2;
-  const TileDesc rs_w = make_tile_desc(reinterpret_cast<const uint8_t*>(w) + (int64_t)n0 * ld_bytes,
-                                       (int)(rows_w * ld_bytes));
-  const TileDesc rs_x = make_tile_desc(reinterpret_cast<const uint8_t*>(x) + (int64_t)t0 * ld_bytes,
-                                       (int)(rows_x * ld_bytes));
-  const i32x4_t rsw = rs_w.words, rsx = rs_x.words;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int nk = (K + kBK - 1) / kBK;
-  const bool k_ragged = (K & (kBK - 1)) != 0;
-
-  f32x16_t acc[NI][NJ];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-  // weight pieces: wave w stages rows (8 w + j) * 8 .. + 7, j = 0 .. 7 (lane -> row / chunk as in stage_tile)
-  const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
-      (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * 8 * 8 * kRowBytes));
-  int voff_a[8], voff_a_tail[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int r = (wave * 8 + j) * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    voff_a[j] = (int)(r * ld_bytes + c * 16);
-    voff_a_tail[j] = (nk - 1) * kBK + c * 8 < K ? voff_a[j] : 0x7FFFFFF0;
-  }
-  auto piece = [&](int kt, auto J) {  // weight piece J of tile kt (dead past the last tile)
-    constexpr int j = decltype(J)::value;
-    if constexpr (DIAG == 1 || DIAG == 2) return;
-    const bool live = kt < nk;
-    const uint32_t m0v = lds_wave + (uint32_t)((kt & 3) * TB + j * 8 * kRowBytes);
-    const int koff = kt * kBK * 2;
-    const int vfull = voff_a[j], vtail = voff_a_tail[j];
-    const int vo = (k_ragged && kt == nk - 1) ? vtail : vfull;
-    i32x4_t rr = rsw;
-    rr.z = live ? rr.z : 0;
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
-  };
-  // token rows: lane (fr, fh) of block jb holds row 64 w + 32 jb + fr, bytes [64 fh, 64 fh + 64) of the tile's 128
-  int voff_b[NJ];
-#pragma unroll
-  for (int jb = 0; jb < NJ; ++jb) voff_b[jb] = (int)((wave * 64 + jb * 32 + fr) * ld_bytes + fh * 64);
-  const int kh = fh * 32;
-  i32x4_t bq[3][NJ][4];
-  auto load_b = [&](int kt, auto BUF, auto JB, auto J) {
-    constexpr int buf = decltype(BUF)::value, jb = decltype(JB)::value, j = decltype(J)::value;
-    if constexpr (DIAG == 1 || DIAG == 2) {
-      if (kt < 3) bq[buf][jb][j] = i32x4_t{lane, kt, j, jb};
-      return;
-    }
-    const bool live = kt < nk;
-    const int koff = kt * kBK * 2;
-    const int vb = voff_b[jb];
-    const int vo = kt * kBK + kh + j * 8 < K ? vb : 0x7FFFFFF0;  // k tail: chunks at or past K read as zero
-    i32x4_t rr = rsx;
-    rr.z = live ? rr.z : 0;
-    i32x4_t v;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4"
-                 : "=v"(v) : "v"(vo), "s"(rr), "s"(koff), "n"(j * 16) : "memory");
-    bq[buf][jb][j] = v;
-  };
-  auto request = [&](int kt, auto BUF) {  // prologue form: everything of tile kt at once
-    piece(kt, IC<0>{}); piece(kt, IC<1>{}); piece(kt, IC<2>{}); piece(kt, IC<3>{});
-    piece(kt, IC<4>{}); piece(kt, IC<5>{}); piece(kt, IC<6>{}); piece(kt, IC<7>{});
-    load_b(kt, BUF, IC<0>{}, IC<0>{}); load_b(kt, BUF, IC<0>{}, IC<1>{});
-    load_b(kt, BUF, IC<0>{}, IC<2>{}); load_b(kt, BUF, IC<0>{}, IC<3>{});
-    load_b(kt, BUF, IC<1>{}, IC<0>{}); load_b(kt, BUF, IC<1>{}, IC<1>{});
-    load_b(kt, BUF, IC<1>{}, IC<2>{}); load_b(kt, BUF, IC<1>{}, IC<3>{});
-  };
-
-  // weight fragments: row 32 i + fr, chunk 4 fh + j at position chunk ^ ((fr >> 1) & 7)
-  const int sw = (fr >> 1) & 7;
-  i32x4_t a[2][NI];
-  auto read_a = [&](const uint8_t* la, auto BUF, auto J, auto I) {
-    constexpr int buf = decltype(BUF)::value, j = decltype(J)::value, i = decltype(I)::value;
-    if constexpr (DIAG == 1 || DIAG == 3 || DIAG == 4) {
-      a[buf][i] = i32x4_t{lane + i, j, buf, 1};
-      return;
-    }
-    a[buf][i] = *reinterpret_cast<const i32x4_t*>(la + (i * 32 + fr) * kRowBytes + (((fh * 4 + j) ^ sw) << 4));
-  };
-
-  request(0, IC<0>{});
-  request(1, IC<1>{});
-  request(2, IC<2>{});
-
-  auto tile = [&](int kt, auto BUF) {
-    constexpr int buf = decltype(BUF)::value;
-    if constexpr (DIAG == 0 || DIAG == 3)
-      asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // all of tile kt landed; tiles kt + 1, kt + 2 stay in flight
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const uint8_t* la = smem + (kt & 3) * TB;
-    read_a(la, IC<0>{}, IC<0>{}, IC<0>{}); read_a(la, IC<0>{}, IC<0>{}, IC<1>{});
-    read_a(la, IC<0>{}, IC<0>{}, IC<2>{}); read_a(la, IC<0>{}, IC<0>{}, IC<3>{});
-    read_a(la, IC<0>{}, IC<0>{}, IC<4>{}); read_a(la, IC<0>{}, IC<0>{}, IC<5>{});
-    read_a(la, IC<0>{}, IC<0>{}, IC<6>{}); read_a(la, IC<0>{}, IC<0>{}, IC<7>{});
-    __builtin_amdgcn_sched_barrier(0);
-    // sub-step J: 16 MFMAs; after every second one a fragment read of sub-step J + 1, after the 4th and 12th a weight
-    // piece of tile kt + 3
-    auto sub = [&](auto J) {
-      constexpr int j = decltype(J)::value, cur = j & 1, nxt = cur ^ 1;
-      auto pair = [&](auto I) {
-        constexpr int i = decltype(I)::value;
-        if constexpr (DIAG != 4) {
-          acc[i][0] = mfma32v<DT>(a[cur][i], bq[buf][0][j], acc[i][0]);
-          acc[i][1] = mfma32v<DT>(a[cur][i], bq[buf][1][j], acc[i][1]);
-        } else if constexpr (i == 0 && j == 0) {  // keep the loaded registers alive: one cheap use per tile
-          acc[0][0][0] += __builtin_bit_cast(float, bq[buf][0][0].x ^ bq[buf][1][3].w ^ bq[buf][0][1].y ^ bq[buf][1][2].z);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j < 3) read_a(la, IC<nxt>{}, IC<(j + 1) & 3>{}, I);
-        if constexpr (i == 1) piece(kt + 3, IC<2 * j>{});
-        if constexpr (i == 5) piece(kt + 3, IC<2 * j + 1>{});
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      pair(IC<0>{}); pair(IC<1>{}); pair(IC<2>{}); pair(IC<3>{});
-      pair(IC<4>{}); pair(IC<5>{}); pair(IC<6>{}); pair(IC<7>{});
-    };
-    sub(IC<0>{}); sub(IC<1>{}); sub(IC<2>{}); sub(IC<3>{});
-    // the buffer is free: its reload for tile kt + 3, a row's four loads back to back
-    load_b(kt + 3, BUF, IC<0>{}, IC<0>{}); load_b(kt + 3, BUF, IC<0>{}, IC<1>{});
-    load_b(kt + 3, BUF, IC<0>{}, IC<2>{}); load_b(kt + 3, BUF, IC<0>{}, IC<3>{});
-    load_b(kt + 3, BUF, IC<1>{}, IC<0>{}); load_b(kt + 3, BUF, IC<1>{}, IC<1>{});
-    load_b(kt + 3, BUF, IC<1>{}, IC<2>{}); load_b(kt + 3, BUF, IC<1>{}, IC<3>{});
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (int kt = 0; kt < nk; kt += 3) {
-    tile(kt, IC<0>{});
-    if (kt + 1 < nk) tile(kt + 1, IC<1>{});
-    if (kt + 2 < nk) tile(kt + 2, IC<2>{});
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // dead loads: registers and LDS are reused by the epilogue
-
-  gemm_epilogue<DT, MODE, NI, NJ, 4>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, 0, wave, fr, fh, lane,
-                                     wave, decay, scale, upper_only);
-}
-
-template <int MODE, int DIAG = 0>
-static void launch_geo12(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
-                         int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
-                         int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
-  constexpr int TILE = 256, LDS = 4 * TILE * kRowBytes;  // four weight stages: 128 KiB
-  int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
-  if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
-    const int n = tiles_n;
-    tiles_t = n + 1;
-    tiles_n = (n + 1) / 2;
-  }
-  static std::atomic<uint64_t> attr_set{0};
-  int device = 0;
-  (void)hipGetDevice(&device);
-  const uint64_t bit = 1ull << (device & 63);
-  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)err_gemm12_kernel<MOQ_BF16, MODE, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)err_gemm12_kernel<MOQ_F16, MODE, DIAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set.fetch_or(bit, std::memory_order_release);
-  }
-  const dim3 grid((unsigned)(tiles_t * tiles_n), (unsigned)n_cand), block(256);
-  if (dt == MOQ_BF16) {
-    hipLaunchKernelGGL((err_gemm12_kernel<MOQ_BF16, MODE, DIAG>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
-                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
-  } else {
-    hipLaunchKernelGGL((err_gemm12_kernel<MOQ_F16, MODE, DIAG>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
-                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
-  }
-}
-
 static int gemm_geo() {
-  // MOQ_TUNE_GEMM_GEO selects the tile geometry / loop structure (A/B knob, read once).  Default: GEO 10 -- the 1 : 1
-  // MFMA / memory stream; with the branch-free three-instruction LDS-DMA pieces it runs 3-5 % ahead of GEO 4
-  // (profiles/r02_gemm_table.md)
+  // MOQ_TUNE_GEMM_GEO = 4 selects the block-issue loop, anything else the default GEO 10 stream (read once).  Both are
+  // release kernels with bit-identical results (tests/test_gpu_gemm.py); the knob exists for A/B timing
+  // (profiles/r02_gemm_table.md: GEO 10 runs 3-5 % ahead).
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
-    const int g = e ? atoi(e) : 10;
-    return g < 0 || g > 16 ? 10 : g;
+    return e && atoi(e) == 4 ? 4 : 10;
   }();
   return geo;
 }
@@ -1188,36 +538,6 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   }
 }
 
-template <int MODE>
-static void launch_geo6(const void* x, const void* w, const void* ref, const void* bias, void* out, float* partial,
-                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
-                        int64_t w_stride, void* stream, float decay, float scale, int upper_only) {
-  constexpr int TILE = 256, LDS = 2 * 2 * TILE * kRowBytes;  // two stages of an A and a B tile: 128 KiB
-  int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
-  if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
-    const int n = tiles_n;
-    tiles_t = n + 1;
-    tiles_n = (n + 1) / 2;
-  }
-  static std::atomic<uint64_t> attr_set{0};
-  int device = 0;
-  (void)hipGetDevice(&device);
-  const uint64_t bit = 1ull << (device & 63);
-  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)err_gemm6_kernel<MOQ_BF16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    (void)hipFuncSetAttribute((const void*)err_gemm6_kernel<MOQ_F16, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_set.fetch_or(bit, std::memory_order_release);
-  }
-  const dim3 grid((unsigned)(tiles_t * tiles_n), (unsigned)n_cand), block(512);
-  if (dt == MOQ_BF16) {
-    hipLaunchKernelGGL((err_gemm6_kernel<MOQ_BF16, MODE>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
-                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
-  } else {
-    hipLaunchKernelGGL((err_gemm6_kernel<MOQ_F16, MODE>), grid, block, LDS, S(stream), x, w, ref, bias, out, partial,
-                       (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride, decay, scale, upper_only);
-  }
-}
-
 // returns the number of per-tile partial sums each candidate produced (MODE 0), or a negative status
 template <int MODE>
 static int64_t launch_gemm(const void* x, const void* w, const void* ref, const void* bias, void* out,
@@ -1243,30 +563,16 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     }();
     upper_only = (upper_only ? 1 : 0) | (group2 << 1);
   }
-  const int tile = geo >= 2 ? 256 : 128;
+  const int tile = 256;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);
   if (nblk > 0x7FFFFFFF) {
     set_error("gemm: too many tiles");
     return MOQ_ERR_UNSUPPORTED;
   }
-  switch (geo) {
-    case 0: launch_geo<MODE, 0>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 1: launch_geo<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 3: launch_geo<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 5: launch_geo<MODE, 5>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 2: launch_geo<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 10: launch_geo<MODE, 10>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 8: launch_geo<MODE, 8>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 9: launch_geo<MODE, 9>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 7: launch_geo<MODE, 7>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 12: launch_geo12<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 13: launch_geo12<MODE, 1>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 14: launch_geo12<MODE, 2>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 16: launch_geo12<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 15: launch_geo12<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-    default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
-  }
+  if (geo == 4)
+    launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);
+  else
+    launch_geo<MODE, 10>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);
   return nblk;
 }
 

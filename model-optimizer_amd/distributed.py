@@ -18,6 +18,15 @@ def _initialized(group=None) -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def active(group=None) -> bool:
+    """Is there a process group whose collectives matter?  More than one rank -- or MOQ_FORCE_DIST=1, which lets a
+    single rank walk every collective call site (tests/test_gpu_dist_nccl.py: RCCL accepts a world of one, so the first
+    8-GPU run is not the first time these calls meet the nccl backend)."""
+    import os
+
+    return _initialized(group) and (dist.get_world_size(group) > 1 or os.environ.get("MOQ_FORCE_DIST") == "1")
+
+
 # ------------------------------------------------------------------------------------------------ replicas
 # Weight-side work (abs-max of the weights, 2:4 masks, SmoothQuant fold, MX QDQ, export packing) is independent per
 # tensor, so it can be dealt over the ranks -- but ONLY when every rank holds the same weights (pure data-parallel
@@ -35,7 +44,7 @@ def declare_data_parallel(group=None, enabled: bool = True):
 
 
 def replicas_declared() -> bool:
-    return bool(_REPLICAS["declared"]) and _initialized() and dist.get_world_size(_REPLICAS["group"]) > 1
+    return bool(_REPLICAS["declared"]) and active(_REPLICAS["group"])
 
 
 def replica_group():
@@ -47,7 +56,7 @@ def resolve_shard(shard_weights) -> bool:
     more than one rank to mean anything), None follows declare_data_parallel."""
     if shard_weights is None:
         return replicas_declared()
-    return bool(shard_weights) and _initialized() and dist.get_world_size(_REPLICAS["group"]) > 1
+    return bool(shard_weights) and active(_REPLICAS["group"])
 
 
 def all_reduce_bucket(tensors, op, group=None, average: bool = False):
@@ -257,7 +266,8 @@ def _global_rank(group, group_rank: int) -> int:
 
 def _as_bytes(t: torch.Tensor) -> torch.Tensor:
     """Flat uint8 alias of a contiguous tensor (bool travels as bytes: RCCL has no bool type)."""
-    return t.view(torch.uint8).reshape(-1) if t.dtype != torch.uint8 else t.reshape(-1)
+    t = t.reshape(-1)  # (0-dim tensors cannot be re-viewed with another element size)
+    return t.view(torch.uint8) if t.dtype != torch.uint8 else t
 
 
 def _chunks(nbytes: int, limit: int):

@@ -444,30 +444,54 @@ def export_quantized_weight(module, dtype: torch.dtype):
 
 
 @torch.no_grad()
-def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None) -> dict:
+def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None, shard_weights: bool | None = None) -> dict:
     """Checkpoint tensors of a quantized model: resmooth / fuse (when a probe forward is given), then pack every
-    quantized linear; everything else is copied through."""
+    quantized linear; everything else is copied through.
+
+    shard_weights (data-parallel replicas; None follows distributed.declare_data_parallel): the packing -- the pass
+    over every weight that produces the checkpoint bytes -- is dealt over the ranks (quantized linears / expert
+    containers in module order, distributed.shard_list) and NOT gathered: the returned dict holds this rank's packed
+    modules only (rank 0 also everything that is copied through), for `save_checkpoint` to write as this rank's
+    safetensors shard.  The union over the ranks is the single-rank state dict, byte for byte."""
+    from . import distributed as mdist
+
     if dummy_forward_fn is not None:
         requantize_resmooth_fused_llm_layers(model, dummy_forward_fn)
+    shard = mdist.resolve_shard(shard_weights)
+    world, me = 1, 0
+    if shard:
+        import torch.distributed as dist
+
+        world, me = dist.get_world_size(mdist.replica_group()), dist.get_rank(mdist.replica_group())
     state = {}
     handled = set()
+    unit = 0
     for name, m in model.named_modules():
         prefix = name + "." if name else ""
         if is_quantized_linear(m):
-            for k, v in export_quantized_weight(m, dtype).items():
-                state[prefix + k] = v
-            if m.bias is not None:
-                state[prefix + "bias"] = m.bias.detach()
+            # linears whose quantizers are off (lm_head, routers) are copied through: rank 0, like every other
+            # plain tensor (tied-weight aliases are resolved against the tensors of the same shard)
+            packed = get_quantization_format(m) is not QUANTIZATION_NONE
+            if (unit % world if packed else 0) == me:
+                for k, v in export_quantized_weight(m, dtype).items():
+                    state[prefix + k] = v
+                if m.bias is not None:
+                    state[prefix + "bias"] = m.bias.detach()
+            unit += int(packed)
             handled.add(name)
         elif is_quant_fused_experts(m):
-            for k, v in export_fused_experts(m, dtype).items():
-                state[prefix + k] = v
+            if unit % world == me:
+                for k, v in export_fused_experts(m, dtype).items():
+                    state[prefix + k] = v
+            unit += 1
             handled.add(name)
     kv_format = get_kv_cache_format(model)
     for k, v in model.state_dict().items():
         owner = k.rsplit(".", 1)[0] if "." in k else ""
         if any(owner == h or owner.startswith(h + ".") for h in handled):
             continue  # quantizer buffers (_amax, _pre_quant_scale) and raw weights of exported linears
+        if me != 0:
+            continue  # the tensors that are copied through travel in rank 0's shard
         new_key, value = _postprocess_kv_key(k, v, kv_format)
         if new_key is not None:
             state[new_key] = value
@@ -549,11 +573,44 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}
 
 
-def save_checkpoint(state: dict, export_dir: str, quant_config: dict | None = None):
-    """model.safetensors (+ hf_quant_config.json); tensors are written sorted by key like safetensors does."""
+def save_checkpoint(state: dict, export_dir: str, quant_config: dict | None = None, shard_weights: bool | None = None):
+    """model.safetensors (+ hf_quant_config.json); tensors are written sorted by key like safetensors does.
+
+    shard_weights (with export_state_dict(shard_weights=...)): every rank writes the tensors it packed as
+    model-<rank+1>-of-<world>.safetensors -- device -> host copy and file write run on all ranks at once, no tensor
+    crosses xGMI -- and rank 0 adds the Hugging Face shard index (model.safetensors.index.json: key -> file) from one
+    object all-gather of the key lists."""
     from safetensors.torch import save_file
 
+    from . import distributed as mdist
+
     os.makedirs(export_dir, exist_ok=True)
+    if mdist.resolve_shard(shard_weights):
+        import torch.distributed as dist
+
+        group = mdist.replica_group()
+        world, me = dist.get_world_size(group), dist.get_rank(group)
+        fname = f"model-{me + 1:05d}-of-{world:05d}.safetensors"
+        tensors = {k: v.detach().cpu().contiguous() for k, v in state.items()}
+        save_file(tensors, os.path.join(export_dir, fname), metadata={"format": "pt"})
+        mine = (fname, {k: t.numel() * t.element_size() for k, t in tensors.items()})
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        if me == 0:
+            weight_map, total = {}, 0
+            for f, sizes in everyone:
+                for k, n in sizes.items():
+                    if k in weight_map:
+                        raise RuntimeError(f"sharded export: {k} was packed by two ranks")
+                    weight_map[k] = f
+                    total += n
+            with open(os.path.join(export_dir, "model.safetensors.index.json"), "w") as f:
+                json.dump({"metadata": {"total_size": total}, "weight_map": dict(sorted(weight_map.items()))}, f, indent=2)
+            if quant_config is not None:
+                with open(os.path.join(export_dir, "hf_quant_config.json"), "w") as f:
+                    json.dump(quant_config, f, indent=4)
+        dist.barrier(group=group)
+        return
     save_file({k: v.detach().cpu().contiguous() for k, v in state.items()},
               os.path.join(export_dir, "model.safetensors"), metadata={"format": "pt"})
     if quant_config is not None:

@@ -33,7 +33,7 @@ def _quantizers(model):
 
 
 def _dist_on() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return mdist.active()
 
 
 def enable_stats_collection(model: nn.Module, distributed_sync: bool = False):
@@ -265,9 +265,34 @@ def apply_pre_quant_scale_and_smooth(linear: QuantLinear, pre_quant_scale: torch
         linear.input_quantizer.amax = (a * pre_quant_scale.to(dev)).amax().to(dt)
 
 
+def _broadcast_smoothed(linears, group):
+    """Data-parallel SmoothQuant with the fold dealt over the ranks: linear i was smoothed on rank i % world only; the
+    folded weight, the pre-quant scale and the re-calibrated amaxes reach the other ranks from there (whole weights
+    in place, the small vectors in one bucket per owner)."""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    payload, owners = [], []
+    for i, m in enumerate(linears):
+        r = i % world
+        iq, wq = m.input_quantizer, m.weight_quantizer
+        if r != me:  # buffers of the right shape to receive into
+            iq._enable_pre_quant_scale = True
+            iq.pre_quant_scale = torch.empty(m.weight.shape[1], dtype=m.weight.dtype, device=m.weight.device)
+        for t in (m.weight.data, iq._pre_quant_scale, getattr(wq, "_amax", None), getattr(iq, "_amax", None)):
+            if t is not None:
+                payload.append(t)
+                owners.append(r)
+    mdist.broadcast_from_owners(payload, group=group, owners=owners)
+
+
 @torch.no_grad()
-def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str = "int8"):
+def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str = "int8",
+                shard_weights: bool | None = None):
     """model_calib.py:1273-1359.
+
+    shard_weights (data-parallel replicas; None follows distributed.declare_data_parallel): the weight side of the
+    smoothing -- |W| column abs-max, the fold W <- W / s, the re-calibration of the folded weight: three passes over
+    every weight -- is dealt over the ranks and the results are broadcast from their owners.  The per-channel
+    activation amax is MAX-reduced before (max_calibrate), so every rank would compute the same scales.
 
     formats = "int8" (default): the reference's behaviour -- only linears whose input AND weight quantizers are INT8
               are smoothed, every other one is skipped with a warning (:1344-1346).
@@ -283,8 +308,11 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
     for m in model.modules():
         if is_quantized_linear(m) and m.input_quantizer.is_enabled and m.input_quantizer.axis is None:
             m.input_quantizer.axis = -1
-    max_calibrate(model, forward_loop)
+    max_calibrate(model, forward_loop, shard_weights=shard_weights)
+    shard = mdist.resolve_shard(shard_weights)
+    world, me = (dist.get_world_size(mdist.replica_group()), dist.get_rank(mdist.replica_group())) if shard else (1, 0)
     smoothed = 0
+    dealt = []
     for name, m in model.named_modules():
         if not is_quantized_linear(m):
             continue
@@ -299,6 +327,16 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
             warnings.warn(f"Only per-channel smoothing is supported, skip {name}")
             continue
         act_amax = iq.amax.float().reshape(-1)
+        dealt.append(m)
+        if shard and (len(dealt) - 1) % world != me:
+            # another rank smooths this linear; the state every rank sets without touching the weight
+            iq.reset_amax()
+            iq.axis = None
+            if not iq._block_dynamic:
+                iq._amax_for_smoothing = act_amax.cpu()
+                iq.amax = act_amax.amax().to(dtype=m.weight.dtype, device=m.weight.device)
+            smoothed += 1
+            continue
         # |W|.amax(dim=0) stays in the WEIGHT dtype and so does its power (model_calib.py:1311, :1319): for a 16-bit
         # model weight_scale^(1 - alpha) is rounded to 16 bits before the fp32 division
         weight_scale = ops.reduce_amax(m.weight, axis=(0,)).reshape(-1)
@@ -314,6 +352,8 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
         scale_a = scale_a.clamp(min=1e-4, max=1e4)
         apply_pre_quant_scale_and_smooth(m, scale_a)
         smoothed += 1
+    if shard and dealt:
+        _broadcast_smoothed(dealt, mdist.replica_group())
     return smoothed
 
 

@@ -86,6 +86,73 @@ def _job_max_and_smoothquant(rank, world, moa, single):
                "pqs": {n: m._pre_quant_scale.clone() for n, m in model.named_modules() if hasattr(m, "_pre_quant_scale")}}
 
 
+def _job_weight_side(rank, world, moa, single):
+    """The weight-side flows dealt over the replicas (distributed.declare_data_parallel): 2:4 magnitude masks,
+    SparseGPT (Hessians combined on their owner, masks broadcast), fold_weight (FP8, dynamic MXFP4 blocks and static INT4
+    blocks) and the sharded checkpoint export (each rank packs and writes its own linears; the union of the shards is
+    the single-rank checkpoint, byte for byte)."""
+    import tempfile
+
+    from safetensors.torch import load_file
+
+    mq, sp, ex = moa.model_quant, moa.sparsity, moa.export
+    batches = _batches(128, torch.float32)
+    mine = batches if single else batches[rank::world]
+    # 2:4 magnitude masks
+    model = sp.sparsify(MLP(), "sparse_magnitude")
+    yield {"mask": {n: m._weight_mask.clone() for n, m in model.named_modules() if hasattr(m, "_weight_mask")},
+           "w": {n: p.detach().clone() for n, p in model.named_parameters()}}
+    # SparseGPT: the Hessian over ALL batches whichever rank saw them
+    model = sp.sparsify(MLP(), "sparsegpt", forward_loop=lambda m: [m(b) for b in mine])
+    yield {"mask~": {n: m._weight_mask.clone() for n, m in model.named_modules() if hasattr(m, "_weight_mask")}}
+    # fold_weight after calibration
+    for preset in ("FP8_DEFAULT_CFG", "MXFP4_DEFAULT_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "INT8_SMOOTHQUANT_CFG"):
+        model = moa.quantize(MLP(), copy.deepcopy(getattr(mq, preset)), lambda m: [m(b) for b in mine])
+        state = ex.export_state_dict(model, torch.float32)
+        if not single:
+            with tempfile.TemporaryDirectory() as d:
+                box = [d]
+                dist.broadcast_object_list(box, src=0)  # one directory for all ranks: rank 0's
+                sub = os.path.join(box[0], preset)
+                ex.save_checkpoint(state, sub, ex.hf_quant_config(model))
+                dist.barrier()
+                files = sorted(f for f in os.listdir(sub) if f.endswith(".safetensors"))
+                assert files == [f"model-{r + 1:05d}-of-{world:05d}.safetensors" for r in range(world)], files
+                import json
+
+                index = json.load(open(os.path.join(sub, "model.safetensors.index.json")))["weight_map"]
+                merged = {}
+                for f in files:
+                    part = load_file(os.path.join(sub, f))
+                    assert not set(part) & set(merged)
+                    assert all(index[k] == f for k in part)
+                    merged.update(part)
+                assert set(index) == set(merged)
+                dist.barrier()
+            state = merged
+        else:
+            state = {k: v.detach().cpu() for k, v in state.items()}
+        mq.fold_weight(model)
+        yield {"ckpt": state, "w": {n: p.detach().clone() for n, p in model.named_parameters()},
+               "off": {n: torch.tensor(float(q.is_enabled)) for n, q in model.named_modules() if n.endswith("weight_quantizer")}}
+
+
+def _job_undeclared(rank, world, moa, single):
+    """No declare_data_parallel: ranks holding DIFFERENT weights (tensor parallel, FSDP) calibrate all of their own -- the
+    amax of every weight quantizer is the MAX over the ranks' own values, never one rank's shard alone."""
+    mq = moa.model_quant
+    batches = _batches(128, torch.float32)
+    if single:
+        values = []
+        for r in range(world):
+            m = moa.quantize(MLP(seed=r), copy.deepcopy(mq.FP8_DEFAULT_CFG), lambda mm: [mm(b) for b in batches])
+            values.append(_amaxes(m))
+        yield {"amax": {k: torch.stack([v[k] for v in values]).amax(0) for k in values[0]}}
+    else:
+        m = moa.quantize(MLP(seed=rank), copy.deepcopy(mq.FP8_DEFAULT_CFG), lambda mm: [mm(b) for b in batches])
+        yield {"amax": _amaxes(m)}
+
+
 def _job_histogram(rank, world, moa, single):
     """Histogram calibrators on the activations (percentile and entropy): int64 counts, bin edges and the amax equal
     the single-rank run over all batches."""
@@ -197,6 +264,12 @@ def _compare(kind, want, got):
                 x, y = a[key][name], b[key][name]
                 if key == "scored_here":
                     continue  # which rank scored a linear is checked across ranks in the worker
+                if key == "mask~":
+                    # SparseGPT: the combined Hessian is a differently associated fp32 sum than the single-rank running
+                    # mean, which can flip near-ties of the pruning scores (and everything downstream in that row)
+                    assert x.shape == y.shape and (x == y).float().mean() >= 0.97, f"{kind}[{i}] {name}"
+                    assert torch.equal(y.view(-1, 4).sum(1), torch.full((y.numel() // 4,), 2)), f"{kind}[{i}] {name}: not 2:4"
+                    continue
                 if key in ("alpha", "contenders"):
                     assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
                 elif key in ("act_scale", "loss") or (kind == "awq" and key in ("amax", "w")):
@@ -216,6 +289,8 @@ def _worker(rank, world, port, kind, ret):
             want = list(job(rank, world, moa, single=True))  # no process group yet: plain single-rank flow
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            if kind not in ("tensor_parallel", "undeclared"):
+                moa.distributed.declare_data_parallel()  # the ranks are replicas: weight-side work may be dealt out
             got = list(job(rank, world, moa, single=False))
         if kind == "tensor_parallel":
             _compare_tp(want, got)
@@ -235,7 +310,7 @@ def _worker(rank, world, port, kind, ret):
                     assert any(s for _, s in mine.values()) or any(s for e in everyone for _, s in e.values())
         # and every rank holds the same state (the reference's property)
         for g in got:
-            for key in ("amax", "hist"):
+            for key in ("amax", "hist", "mask", "mask~", "w"):
                 for name, t in g.get(key, {}).items():
                     ref = t.clone().float()
                     dist.all_reduce(ref, op=dist.ReduceOp.MAX)
@@ -250,10 +325,27 @@ def _worker(rank, world, port, kind, ret):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "tensor_parallel"])
+@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "tensor_parallel", "weight_side", "undeclared"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
     assert dict(ret) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {v}" for r, v in dict(ret).items())
+
+
+def test_forced_single_rank_walks_every_collective_site():
+    """tests/dist_nccl_world1.py (the GPU suite runs it on RCCL) dry-run on gloo + the host-memory stand-in: with
+    MOQ_FORCE_DIST=1 a world of one executes every collective call site and must reproduce the plain run bit for bit."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, MOQ_TEST_DEVICE="cpu", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("MOQ_FORCE_DIST", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_nccl_world1.py")], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["ok"], line["mismatches"]
+    for name in ("all_reduce", "reduce", "broadcast", "all_gather_object", "broadcast_object_list", "barrier"):
+        assert line["calls"].get(name, 0) > 0, line["calls"]

@@ -1,0 +1,32 @@
+"""First contact with RCCL before the first multi-GPU run: the data-parallel flows under the "nccl"
+backend with a world of ONE rank and MOQ_FORCE_DIST=1, so that every collective call site runs on device tensors through
+RCCL.  The reference's property (tests/unit/torch/quantization/test_dist.py:27-47: after quantize every amax equals its
+all-reduce) degenerates to: the result equals the plain single-process run bit for bit.  Run in a subprocess with a
+timeout: a collective that hangs must fail this test, not the suite."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_every_collective_call_site_under_nccl_with_one_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("MOQ_FORCE_DIST", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "dist_nccl_world1.py")], capture_output=True, text=True,
+                       timeout=420, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["ok"], line["mismatches"]
+    assert line["compared"] > 60
+    calls = line["calls"]
+    # the bucketed statistics, the chunked Gram / Hessian reduce, the owner broadcasts and the control-plane gathers
+    for name in ("all_reduce", "reduce", "broadcast", "all_gather_object", "barrier"):
+        assert calls.get(name, 0) > 0, f"{name} was never called: {calls}"
+    assert calls["reduce"] >= 4 and calls["broadcast"] >= 8  # chunked: several calls per matrix / weight
+    assert line["sharded_files"] == ["model-00001-of-00001.safetensors"]

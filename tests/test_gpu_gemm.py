@@ -152,3 +152,41 @@ def test_err_gemm_multi_equals_single_launches():
         one = torch.zeros(1, dtype=torch.float32, device=DEV)
         ops.awq_err_gemm(x, w_hat[i], ref, None, one)
         assert shared[i].item() == one.item()
+
+
+_GEO_PROBE = r"""
+import hashlib, sys, torch
+sys.path.insert(0, sys.argv[1])
+import _moa_import
+moa = _moa_import.load(); ops = moa.ops
+g = torch.Generator().manual_seed(11)
+h = hashlib.sha256()
+for t, n, k in ((300, 260, 136), (512, 768, 1024), (257, 384, 200)):
+    for dt in (torch.bfloat16, torch.float16):
+        x = torch.randn(t, k, generator=g).to(dt).cuda(); w = (torch.randn(n, k, generator=g) * 0.05).to(dt).cuda()
+        ref = torch.randn(t, n, generator=g).to(dt).cuda()
+        h.update(ops.gemm_nt(x, w).cpu().view(torch.int16).numpy().tobytes())
+        acc = torch.zeros(1, dtype=torch.float32, device="cuda"); ops.awq_err_gemm(x, w, ref, None, acc)
+        h.update(acc.cpu().numpy().tobytes())
+        hs = torch.zeros(k, k, dtype=torch.float32, device="cuda"); ops.hessian_accum(hs, x, 0.0, 1.0 / t)
+        h.update(hs.cpu().numpy().tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_the_two_release_loop_structures_are_bit_identical():
+    """MOQ_TUNE_GEMM_GEO is the one knob the release contraction reads: 4 selects the block-issue loop, anything else the
+    default GEO 10 stream.  Same tile, same k order per accumulator: stored outputs, fused losses and Gram matrices must be
+    the same bits (the variants that are NOT are no longer in the library: csrc/exp/)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for geo in ("4", "10", "9"):  # 9: was a wrong-by-construction diagnostic; now means the default
+        env = dict(os.environ, MOQ_TUNE_GEMM_GEO=geo)
+        p = subprocess.run([sys.executable, "-c", _GEO_PROBE, root], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        digests[geo] = p.stdout.strip().splitlines()[-1]
+    assert digests["4"] == digests["10"] == digests["9"], digests

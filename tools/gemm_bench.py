@@ -1,6 +1,7 @@
 """MFMA error-GEMM throughput on one MI355X at the Llama-3-8B / 70B linear shapes of one calibration batch
 (8 x 512 = 4096 tokens).  2*T*Cout*Cin flop / HIP-event time, against the 2.5 PFLOP/s dense bf16 peak.
-A/B knob: MOQ_TUNE_GEMM_DBUF=1 (read once per process).  Also times torch's library GEMM (F.linear) + the
+A/B knob: MOQ_TUNE_GEMM_GEO=4|10 (read once per process; the other loop structures need the experiment library,
+`MOQ_EXPERIMENTS=1 model-optimizer_amd/csrc/build.sh` and `--lib model-optimizer_amd/csrc/libmoquant_exp.so`).  Also times torch's library GEMM (F.linear) + the
 unfused loss ops the reference would run, for scale.
 Usage (GPU box): python tools/gemm_bench.py [> profiles/rNN_gemm_table.md]"""
 
@@ -12,6 +13,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _moa_import  # noqa: E402
 
+if "--lib" in sys.argv:  # the experiment library instead of the release one (before the first C-ABI call)
+    from model_optimizer_amd import _lib as _moq_lib  # noqa: E402
+
+    _moa_import.load()
+    _moq_lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 moa = _moa_import.load()
 ops = moa.ops
 DEV = "cuda:0"
@@ -35,7 +41,7 @@ def main():
     shapes = [("8b q/o", 4096, 4096, 4096), ("8b k/v", 4096, 1024, 4096), ("8b gate/up", 4096, 14336, 4096),
               ("8b down", 4096, 4096, 14336), ("70b gate/up", 4096, 28672, 8192), ("70b down", 4096, 8192, 28672),
               ("square 8192", 8192, 8192, 8192)]
-    print(f"variant: MOQ_TUNE_GEMM_GEO={os.environ.get('MOQ_TUNE_GEMM_GEO', '2 (default)')}\n")
+    print(f"variant: MOQ_TUNE_GEMM_GEO={os.environ.get('MOQ_TUNE_GEMM_GEO', '10 (default)')}\n")
     print("| shape (T x Cout x Cin) | fused err-GEMM ms | TFLOP/s | frac of 2.5 PF | batched (11 cand.) ms/cand | TFLOP/s | frac | F.linear ms | F.linear TFLOP/s | F.linear + unfused loss ms |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for name, t, n, k in shapes:
