@@ -205,7 +205,7 @@ int moq_int8_pack_rows(const void* w, const float* scale, int8_t* out, int64_t r
  *   amax_running   != NULL  : amax_running[0] = max(amax_running[0], max |v|)   (collect -> MaxCalibrator, calib/max.py:63-85;
  *                             NaN propagates like torch.max)
  *   hist_counts    != NULL  : hist_counts[bin(|v|)] += 1 with moq_hist_abs' binning over [0, hist_max_edge]
- *                             (HistogramCalibrator.collect with a known range, calib/histogram.py:95-130); 8 <= bins < 16384
+ *                             (HistogramCalibrator.collect with a known range, calib/histogram.py:95-130); 1 <= bins < 16384
  *   fmt 1 / 2               : y = INT-k / FP8-E4M3 quantize-dequantize of v with the per-tensor qdq_amax[0]
  *                             (moq_fake_quant_int / moq_fake_quant_e4m3 arithmetic, tensor_quant.py:607-645, :46-59)
  *   fmt 0                   : y = v when y != NULL and a pre_quant_scale is given (the calibration pass hands the scaled
@@ -392,10 +392,17 @@ int moq_symmetrize(float* h, int64_t n, void* stream);
  * w: fp32 [rows, ld] working weights (block overwritten with the pruned weights q), hinv: fp32 [ld, ld] upper
  * Cholesky factor of the damped inverse Hessian, delta: fp32 [rows, bs] receives err_j = (w_j - q_j) / hinv_jj.
  * Every prune_m consecutive columns lose their prune_n smallest w^2 / (hinv_kk^2 + 1e-9).  bs <= 128,
- * prune_m in {2, 4, 8}, bs % prune_m == 0.  The trailing update w[:, i2:] -= delta @ hinv[i1:i2, i2:] is the
- * caller's (library fp32 GEMM). */
+ * prune_m in {2, 4, 8}, bs % prune_m == 0.  The trailing update w[:, i2:] -= delta @ hinv[i1:i2, i2:] is
+ * moq_sgpt_trailing_update. */
 int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
                          int prune_n, int prune_m, void* stream);
+/* The update between two column blocks of create_sgpt_mask, w_rows[:, i2:] -= delta_blk.matmul(hessian_inv[i1:i2, i2:])
+ * (sparsegpt.py:124; i2 = i1 + bs), with a DEFINED summation order instead of the BLAS library's:
+ *     w[r, c] -= chain_{k = 0 .. bs-1, ascending} fmaf(delta[r, k], hinv[i1 + k, c], .)   started at +0,   c >= i2
+ * on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain).  w: fp32 [rows, ld] working weights,
+ * delta: fp32 [rows, bs] from moq_sgpt_block_sweep, hinv: fp32 [ld, ld].  bs <= 128. */
+int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* delta,
+                             const float* hinv, void* stream);
 
 /* ------------------------------------------------------------------ AWQ-lite Gram-matrix search (a12) */
 

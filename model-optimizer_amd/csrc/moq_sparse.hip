@@ -9,7 +9,18 @@
 // row: lane l keeps columns l and l + 64 of the block in registers, the pivot value is broadcast with a lane
 // read, and the whole 128-column sweep is one kernel.  Every arithmetic step is the reference's fp32 step in the
 // reference's order (no FMA contraction), so q, the per-column errors and the pruning decisions are bit-identical
-// to the oracle; the trailing-block update (delta @ Hinv[i1:i2, i2:], an fp32 GEMM) stays on the library.
+// to the oracle.
+//
+// Between two column blocks the reference spreads the block's errors over all columns to the right with an fp32 GEMM,
+// w_rows[:, i2:] -= delta_blk.matmul(hessian_inv[i1:i2, i2:]) (sparsegpt.py:124) -- in the BLAS library's summation
+// order, whatever that is on the machine at hand, and the 2:4 decisions downstream inherit it.  Here that update is the
+// kernel `sgpt_trailing_kernel` with a DEFINED order: every output is the fp32 fused-multiply-add chain over the block's
+// columns k = 0, 1, ... in ascending order, started at +0, subtracted from the weight once.  It runs on the matrix
+// cores: v_mfma_f32_32x32x2_f32 takes fp32 inputs and is bit-for-bit an fmaf chain (MI355X_MICROARCH.md, "F32 (f32 in)":
+// exact f32, 155 TFLOP/s = the fp32 vector rate), so the oracle restates it with fmaf and masks are reproducible bit
+// for bit from a given inverse factor (tests/test_gpu_sparsegpt.py).
+#include <atomic>
+
 #include "moq_common.h"
 
 namespace moq {
@@ -79,6 +90,110 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
   if (in1) { wr[lane + 64] = q1; delta[row * bs + lane + 64] = e1; }
 }
 
+// ---- trailing update: w[r, i2 + c] -= chain_{k < bs} fma(delta[r, k], hinv[i1 + k, i2 + c]), i2 = i1 + bs.
+//
+// One workgroup (4 waves) owns a 128 x 128 output tile; K is the whole column block (<= 128), so the operands are staged
+// ONCE: A = delta tile [128 r][128 k] (row pitch 129 words: the MFMA's A fragment reads 32 consecutive rows at one k --
+// an odd pitch spreads them over the banks), B = hinv tile [128 k][128 c] (lanes run along c).  Rows past `rows`, columns
+// past the matrix and k >= bs are filled with zeros: fma(0, 0, acc) = acc for every acc this chain can hold (it starts at
+// +0 and round-to-nearest never produces -0 from a sum that is not (-0) + (-0)).  Each wave multiplies a 64 x 64 quarter
+// as 2 x 2 tiles of 32 x 32: per k pair two A and two B words per lane from LDS, four MFMAs.  MFMA operand layout
+// (32x32x2): a = A[m = lane & 31][k = lane >> 5], b = B[k = lane >> 5][n = lane & 31]; accumulator register e of a lane
+// holds row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31 -- lanes run along the weight's columns, so the
+// read-modify-write of w is 128-byte runs.
+typedef float f32x16v __attribute__((ext_vector_type(16)));
+constexpr int kTuTile = 128, kTuPitchA = 129;
+constexpr size_t kTuLds = ((size_t)kTuTile * kTuPitchA + (size_t)kTuTile * kTuTile) * sizeof(float);
+
+__global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
+                                                            int bs, const float* __restrict__ delta,
+                                                            const float* __restrict__ hinv) {
+  extern __shared__ __attribute__((aligned(16))) float tu_lds[];
+  float* sa = tu_lds;                        // [128 r][129]
+  float* sb = tu_lds + kTuTile * kTuPitchA;  // [128 k][128 c]
+  const int64_t i2 = i1 + bs, ncols = ld - i2;
+  const int64_t r0 = (int64_t)blockIdx.y * kTuTile, c0 = (int64_t)blockIdx.x * kTuTile;
+  const int tid = threadIdx.x;
+  // A: thread t takes k quad q = t & 31 of rows (t >> 5) + 8 i -- a wave reads two 512-byte delta rows per step
+  {
+    const int q = tid & 31;
+    for (int i = 0; i < kTuTile / 8; ++i) {
+      const int r = (tid >> 5) + 8 * i;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (r0 + r < rows) {
+        const float* src = delta + (r0 + r) * bs + 4 * q;
+        if (4 * q + 3 < bs) v = *reinterpret_cast<const float4*>(src);  // bs % 4 == 0 is not required:
+        else {                                                          // the ragged quad goes word by word
+          if (4 * q + 0 < bs) v.x = src[0];
+          if (4 * q + 1 < bs) v.y = src[1];
+          if (4 * q + 2 < bs) v.z = src[2];
+        }
+      }
+      float* dst = sa + r * kTuPitchA + 4 * q;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  }
+  // B: thread t takes column quad q = t & 31 of k rows (t >> 5) + 8 i (hinv rows are 16-byte aligned when ld % 4 == 0
+  // and i2 + c0 is a multiple of 4; otherwise word by word)
+  {
+    const int q = tid & 31;
+    const bool vec_ok = (ld % 4 == 0) && ((i2 + c0) % 4 == 0);
+    for (int i = 0; i < kTuTile / 8; ++i) {
+      const int k = (tid >> 5) + 8 * i;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (k < bs) {
+        const float* src = hinv + (i1 + k) * ld + i2 + c0 + 4 * q;
+        const int64_t c = c0 + 4 * q;
+        if (vec_ok && c + 3 < ncols) v = *reinterpret_cast<const float4*>(src);
+        else {
+          if (c + 0 < ncols) v.x = src[0];
+          if (c + 1 < ncols) v.y = src[1];
+          if (c + 2 < ncols) v.z = src[2];
+          if (c + 3 < ncols) v.w = src[3];
+        }
+      }
+      *reinterpret_cast<float4*>(sb + k * kTuTile + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;  // the wave's 64 x 64 quarter
+  const int m = lane & 31, h = lane >> 5;
+  f32x16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  const float* pa = sa + (wr * 64 + m) * kTuPitchA + h;
+  const float* pb = sb + h * kTuTile + wc * 64 + m;
+  const int kpairs = (bs + 1) / 2;
+  for (int j = 0; j < kpairs; ++j) {
+    const float a0 = pa[2 * j], a1 = pa[32 * kTuPitchA + 2 * j];
+    const float b0 = pb[2 * j * kTuTile], b1 = pb[2 * j * kTuTile + 32];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t c = c0 + wc * 64 + j * 32 + m;
+      if (c >= ncols) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t r = r0 + wr * 64 + i * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
+        if (r < rows) {
+          float* dst = w + r * ld + i2 + c;
+          *dst = *dst - acc[i][j][e];
+        }
+      }
+    }
+}
+
 // y[c, r] = x[r, c] for 16-bit elements through a 64 x 64 LDS tile (+1 column of padding: conflict-free columns)
 // y_ld: leading dimension of y (>= rows): y may be a column block of a wider [cols, y_ld] staging buffer
 __global__ __launch_bounds__(kBlock) void transpose16_kernel(const uint16_t* __restrict__ x,
@@ -123,6 +238,36 @@ extern "C" int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t 
     default: hipLaunchKernelGGL((sgpt_sweep_kernel<8>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, prune_n); break;
   }
   return check_launch("moq_sgpt_block_sweep");
+}
+
+extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* delta,
+                                        const float* hinv, void* stream) {
+  if (w == nullptr || hinv == nullptr || delta == nullptr || rows < 0 || ld <= 0 || i1 < 0 || bs <= 0 || i1 + bs > ld) {
+    set_error("moq_sgpt_trailing_update: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (bs > kTuTile) {
+    set_error("moq_sgpt_trailing_update: column block of %d > %d", bs, kTuTile);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int64_t ncols = ld - (i1 + bs);
+  if (rows == 0 || ncols == 0) return MOQ_OK;
+  const int64_t gx = (ncols + kTuTile - 1) / kTuTile, gy = (rows + kTuTile - 1) / kTuTile;
+  if (gy > 65535 || gx > 0x7FFFFFFF) {
+    set_error("moq_sgpt_trailing_update: matrix too large");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  static std::atomic<uint64_t> attr_set{0};  // > 64 KiB of dynamic LDS: opt-in attribute, once per device
+  int device = 0;
+  (void)hipGetDevice(&device);
+  const uint64_t bit = 1ull << (device & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    attr_set.fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(sgpt_trailing_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), kTuLds, S(stream), w, rows, ld, i1,
+                     bs, delta, hinv);
+  return check_launch("moq_sgpt_trailing_update");
 }
 
 extern "C" int moq_transpose16_ld(const void* x, void* y, int64_t rows, int64_t cols, int64_t y_ld, void* stream);

@@ -415,6 +415,7 @@ class AWQLiteHelper:
         # a zero-padded copy of its weight and cuts the padding off again: zeros change neither a block's abs-max nor
         # any quantized value.
         self.cin = module.weight.shape[1]
+        self.dtype = module.weight.dtype  # 1 / s is rounded to it where the forward uses it (prepare_scales)
         self.pad = (-self.cin) % self.block_size
         self.weight_scale = ops.awq_weight_scale(self._padded(module.weight), self.block_size)[:self.cin].contiguous()
         self.act_sum = torch.zeros(module.weight.shape[1], dtype=torch.float32, device=module.weight.device)
@@ -478,7 +479,7 @@ class AWQLiteHelper:
         """get_scale(act_scale, weight_scale, alpha) on the statistics' device (computed on the host, see prepare_scales)."""
         if self._s_dev is None:
             self.prepare_scales(self.act_scale.detach().float().cpu(), self.weight_scale.detach().float().cpu(),
-                                torch.float32)
+                                self.dtype)
         return self._s_dev[self.alphas.index(alpha)]
 
     def search_operands(self, module, subset=None):
@@ -578,11 +579,13 @@ GRAM_PLANES_SLACK = 3e-4
 # lie within TIE_SPREAD_FACTOR x S of the scored ones (d varies smoothly with alpha; the factor covers the extrapolation
 # past the scored set).  So a linear is settled when  margin >= TIE_SPREAD_FACTOR * S + gap_w ; otherwise its margin is
 # widened to twice that requirement, the newly admitted candidates are re-scored in a further pass, and the check repeats
-# (at most TIE_CHECK_MAX_ROUNDS times, then every candidate of the linear is scored).  Full-size measurements
-# (profiles/r03_awq_tie_check.md): the synthetic outlier stack needs S <= 4.6e-5 against a 1.3e-3 margin (ratio 0.07); a
-# random-init HF Llama-3-8B, whose 11 candidates lie within 0.1-0.9 % of each other, shows S up to 8e-4 and a largest
-# overturned gap of 1.1e-4 -- there a few linears widen.
-TIE_SPREAD_FACTOR = 2.0
+# (at most TIE_CHECK_MAX_ROUNDS times, then every candidate of the linear is scored).  Every widening costs one more pass
+# over the calibration data, so the factor is a price: full-size measurements (profiles/r03_awq_tie_check.md) -- the
+# synthetic outlier stack shows S <= 4.6e-5 against a 1.3e-3 margin (requirement / margin 0.07 whatever the factor); a
+# random-init HF Llama-3-8B, whose 11 candidates lie within 0.1-0.9 % of each other, shows S up to 8e-4 among its
+# contenders and a largest overturned Gram gap of 1.1e-4: factor 1.5 settles every linear in the one exact pass
+# (requirement / margin <= 0.98), factor 2 sends 5 of 224 linears through a third pass -- same alphas either way.
+TIE_SPREAD_FACTOR = 1.5
 TIE_CHECK_MAX_ROUNDS = 3
 
 

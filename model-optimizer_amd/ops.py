@@ -1091,6 +1091,20 @@ def sgpt_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, prun
 
 
 # ----------------------------------------------------------------------------------------------- AWQ Gram search
+def sgpt_trailing_update(w: torch.Tensor, i1: int, delta: torch.Tensor, hinv: torch.Tensor) -> torch.Tensor:
+    """In place: w[:, i2:] -= delta @ hinv[i1:i2, i2:] (sparsegpt.py:124, i2 = i1 + delta.shape[1]) as the fp32 fma chain
+    over the block's columns in ascending order on the fp32 matrix cores -- a defined summation order where the reference
+    has the BLAS library's."""
+    _require_gpu(w, "sgpt_trailing_update")
+    if not (w.dtype == delta.dtype == hinv.dtype == torch.float32 and w.is_contiguous() and delta.is_contiguous()
+            and hinv.is_contiguous() and w.dim() == 2 and delta.dim() == 2 and delta.shape[0] == w.shape[0]):
+        raise MoquantError("sgpt_trailing_update: contiguous fp32 w [rows, ld], delta [rows, bs], hinv [ld, ld] expected")
+    rows, ld = w.shape
+    with _on(w) as stream:
+        check(_lib.lib().moq_sgpt_trailing_update(_p(w), rows, ld, int(i1), int(delta.shape[1]), _p(delta), _p(hinv), stream))
+    return w
+
+
 def split_bf16(x: torch.Tensor):
     """fp32 -> (hi, lo) bf16 with hi + lo == x to ~2^-17 relative."""
     hi = x.to(torch.bfloat16)

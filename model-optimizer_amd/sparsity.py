@@ -135,7 +135,9 @@ def prepare(tensor: torch.Tensor, hessian: torch.Tensor, hessian_damp: float):
 def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, hessian_inv: torch.Tensor | None = None,
                      dead_columns: torch.Tensor | None = None):
     """sparsegpt.py:72-133.  The per-column Python loop of the reference is one kernel per column block
-    (ops.sgpt_block_sweep); the trailing-block update is an fp32 library GEMM as in the reference.
+    (ops.sgpt_block_sweep); the trailing-block update (an fp32 GEMM in the BLAS library's order there, :124) is
+    ops.sgpt_trailing_update: the fp32 fma chain over the block's columns in ascending order on the fp32 matrix cores,
+    so the mask is reproducible bit for bit from a given inverse factor.
     `hessian_inv` (+ `dead_columns`) short-cuts prepare() with an already prepared factor: tests, and linears that
     share a Hessian."""
     shape = tensor.size()
@@ -148,6 +150,7 @@ def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, 
         weight = tensor.detach().clone().flatten(1) if tensor.dim() == 4 else tensor.detach().clone()
         if dead_columns is not None:
             weight[:, dead_columns] = 0
+    hessian_inv = hessian_inv.float().contiguous()
     rows, cols = weight.size()
     col_bs = config.get("col_block_size", 128)
     row_bs = config.get("row_block_size", -1)
@@ -160,7 +163,7 @@ def create_sgpt_mask(tensor: torch.Tensor, hessian: torch.Tensor, config: dict, 
             i2 = min(i1 + col_bs, cols)
             delta = ops.sgpt_block_sweep(w_rows, i1, i2 - i1, hessian_inv, n, m)
             if i2 < cols:
-                w_rows[:, i2:] -= delta.matmul(hessian_inv[i1:i2, i2:])
+                ops.sgpt_trailing_update(w_rows, i1, delta, hessian_inv)
         weight[r1:r2] = w_rows.to(weight.dtype)
     return (weight != 0).view(shape)
 

@@ -395,15 +395,29 @@ def sgpt_block_sweep(w, i1, bs, hinv, prune_n=2, prune_m=4):
     return torch.from_numpy(delta)
 
 
-def create_sgpt_mask(weight, hinv, prune_n=2, prune_m=4, col_bs=128):
-    """create_sgpt_mask (sparsegpt.py:72-133) given the prepared inverse-Hessian factor: mask = pruned weight != 0."""
+def sgpt_trailing_update(w, i1, delta, hinv):
+    """In place: w[:, i2:] -= delta @ hinv[i1:i2, i2:] (sparsegpt.py:124) as the ascending-k fmaf chain -- the summation
+    order the product path defines where the reference has its BLAS library's."""
+    assert w.dtype == torch.float32 and w.is_contiguous() and delta.dtype == torch.float32 and hinv.dtype == torch.float32
+    rows, ld = w.shape
+    lib().orc_sgpt_trailing_update(_p(w.numpy()), I64(rows), I64(ld), I64(i1), int(delta.shape[1]),
+                                   _p(np.ascontiguousarray(delta.numpy())), _p(np.ascontiguousarray(hinv.numpy())))
+    return w
+
+
+def create_sgpt_mask(weight, hinv, prune_n=2, prune_m=4, col_bs=128, blas_update=False):
+    """create_sgpt_mask (sparsegpt.py:72-133) given the prepared inverse-Hessian factor: mask = pruned weight != 0.
+    blas_update=True: the trailing update as the reference writes it (torch matmul, the CPU BLAS order)."""
     w = weight.detach().float().clone().contiguous()
     cols = w.shape[1]
     for i1 in range(0, cols, col_bs):
         i2 = min(i1 + col_bs, cols)
         delta = sgpt_block_sweep(w, i1, i2 - i1, hinv, prune_n, prune_m)
         if i2 < cols:
-            w[:, i2:] -= delta.matmul(hinv[i1:i2, i2:])
+            if blas_update:
+                w[:, i2:] -= delta.matmul(hinv[i1:i2, i2:])
+            else:
+                sgpt_trailing_update(w, i1, delta, hinv)
     return w.to(weight.dtype) != 0
 
 

@@ -20,6 +20,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# One-line facts a test wants in the suite's tail (printed after the pass/fail summary, so they show up in the committed
+# `pytest ... | tail` of a GPU run): host-pow pins of the byte-identical replay, SparseGPT tie-audit counts, ...
+SUITE_NOTES: list = []
+
+
+def note(line: str):
+    SUITE_NOTES.append(line)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    for line in SUITE_NOTES:
+        terminalreporter.write_line(f"[note] {line}")
+
+
 def from_bits(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
     """Inverse of gen_golden.bits(): uint16 patterns -> bf16/f16 tensors."""
     if dtype in (torch.bfloat16, torch.float16):

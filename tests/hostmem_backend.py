@@ -299,6 +299,10 @@ class HostMemLib:
         return OK
 
     # -- Gram-matrix AWQ search / SparseGPT Hessian: numpy restatements (fp64 accumulation) of the MFMA entries
+    def moq_sgpt_trailing_update(self, w, rows, ld, i1, bs, delta, hinv, stream):
+        self.o.orc_sgpt_trailing_update(_vp(w), I64(rows), I64(ld), I64(i1), int(bs), _vp(delta), _vp(hinv))
+        return OK
+
     @staticmethod
     def _bf16_round(f32):
         u = np.ascontiguousarray(f32, dtype=np.float32).view(np.uint32)

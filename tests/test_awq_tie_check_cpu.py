@@ -66,7 +66,15 @@ def test_default_margin_with_self_check_finds_every_exact_minimum(tables):
         extra += passes > 1
     assert wrong == 0
     assert cands < 0.55 * 11 * len(tables)  # about half of the full search, even on this all-ties model
-    assert 0 < extra <= 10  # a few linears widen: the check has teeth here, and it is not the common case
+    assert extra <= 10  # widening (one more pass over the data per round) is not the common case
+
+
+def test_a_stricter_factor_widens_some_linears_of_this_model_and_changes_nothing(tables, monkeypatch):
+    monkeypatch.setattr(model_calib, "TIE_SPREAD_FACTOR", 2.0)
+    margin = model_calib.GRAM_TIE_MARGIN[moa.ops.torch.bfloat16] + model_calib.GRAM_PLANES_SLACK
+    results = [_search(g, e, margin, check=True) for g, e in tables]
+    assert all(w == _first_min(e) for (w, _, _), (_, e) in zip(results, tables))
+    assert 0 < sum(p > 1 for _, _, p in results) <= 10  # the check has teeth on this data
 
 
 def test_too_small_a_fixed_margin_flips_linears_and_the_self_check_repairs_them(tables):
@@ -84,9 +92,10 @@ def test_tie_margin_check_rounds_and_nan():
     # engines agree -> settled
     need, margin, new = model_calib.tie_margin_check(gram, {0: 1.0, 1: 1.0005}, 1e-3, 0)
     assert new == [] and margin == 1e-3 and need == pytest.approx(0.0, abs=1e-12)
-    # they disagree by 1e-3 between the two scored candidates -> need = 2e-3 (+ the winner's gap), margin doubles that
+    # they disagree by 1e-3 between the two scored candidates -> need = factor * 1e-3 (+ the winner's gap), margin doubles that
     need, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, 0)
-    assert need == pytest.approx(2e-3 + 5e-4) and margin == pytest.approx(2 * need) and new == [2]
+    assert need == pytest.approx(model_calib.TIE_SPREAD_FACTOR * 1e-3 + 5e-4) and margin == pytest.approx(2 * need)
+    assert new == [2]
     # last round: everything that is left
     _, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, model_calib.TIE_CHECK_MAX_ROUNDS - 1)
     assert margin == float("inf") and new == [2, 3, 4]

@@ -184,6 +184,36 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
 
 
+@pytest.mark.parametrize("preset,dtype", [("FP8_DEFAULT_CFG", torch.bfloat16), ("INT8_DEFAULT_CFG", torch.float32),
+                                          ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16),
+                                          ("INT8_SMOOTHQUANT_CFG", torch.float16)])
+def test_fold_weight_equals_the_reference_live(monkeypatch, preset, dtype):
+    """mtq.fold_weight (model_quant.py:728-736, quant_module.py:132-186) against model_quant.fold_weight on the same
+    calibrated model: folded weights bit-identical, weight quantizers disabled and stripped of amax / pre_quant_scale,
+    logits of the folded model equal."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    ref = mtq.quantize(_model(dtype), copy.deepcopy(getattr(mtq, preset)), lambda m: [m(b) for b in batches])
+    mtq.fold_weight(ref)
+    with torch.no_grad():
+        ref_logits = ref(batches[0]).logits
+    ref_w = {n: p.detach().clone() for n, p in ref.named_parameters()}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(dtype)
+    with torch.no_grad():
+        moa.quantize(ours, copy.deepcopy(getattr(moa.model_quant, preset)), lambda m: [m(b) for b in batches])
+        moa.model_quant.fold_weight(ours)
+        logits = ours(batches[0]).logits
+    for n, p in ours.named_parameters():
+        assert torch.equal(p.detach(), ref_w[n]), f"{preset}: folded {n} differs from the reference's"
+    for n, m in ours.named_modules():
+        if n.endswith("weight_quantizer"):
+            assert not m.is_enabled and not hasattr(m, "_amax") and not hasattr(m, "_pre_quant_scale"), n
+    assert torch.equal(logits, ref_logits)
+
+
 def test_magnitude_sparsity_equals_the_reference_live(monkeypatch):
     """mts.sparsify(model, "sparse_magnitude") of the reference against sparsity.sparsify on the same model: masks equal."""
     ref_shim.install()

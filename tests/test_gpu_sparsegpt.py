@@ -75,6 +75,39 @@ def test_block_sweep_bit_exact_vs_oracle(m, n):
         assert ((blk == 0).sum(-1) >= n).all()
 
 
+@pytest.mark.parametrize("rows,ld,i1,bs", [(70, 256, 0, 128), (33, 384, 128, 128), (16, 200, 128, 72), (5, 64, 0, 64),
+                                           (300, 1030, 256, 128), (129, 515, 0, 127), (1, 130, 0, 2), (64, 256, 128, 128)])
+def test_trailing_update_is_the_ascending_fma_chain_bit_for_bit(rows, ld, i1, bs):
+    """moq_sgpt_trailing_update on the fp32 matrix cores against the oracle's fmaf chain (k ascending, from +0): ragged
+    rows / columns, column blocks shorter than 128, leading dimensions that are not multiples of 4, and the no-op at
+    the last block."""
+    gen = torch.Generator().manual_seed(rows * 7 + bs)
+    w = (torch.randn(rows, ld, generator=gen) * 0.05).float()
+    delta = (torch.randn(rows, bs, generator=gen) * torch.exp(2 * torch.randn(rows, bs, generator=gen))).float()
+    delta[torch.rand(rows, bs, generator=gen) < 0.5] = 0.0  # unpruned columns leave exact zeros
+    hinv = torch.randn(ld, ld, generator=gen).float()
+    want = oracle.sgpt_trailing_update(w.clone(), i1, delta, hinv)
+    got = ops.sgpt_trailing_update(w.clone().to(DEV), i1, delta.to(DEV), hinv.to(DEV)).cpu()
+    assert torch.equal(got[:, :i1 + bs], w[:, :i1 + bs]), "columns left of i2 were touched"
+    bad = got.view(torch.int32) != want.view(torch.int32)
+    assert not bad.any(), f"{int(bad.sum())} of {got.numel()} outputs differ from the fma chain; first {bad.nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("shape", [(64, 256), (96, 384), (40, 520), (256, 1024)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_create_sgpt_mask_is_bit_exact_against_the_oracle_given_the_inverse_factor(shape, dtype):
+    """Sweep and trailing update both have a defined arithmetic now: from the same inverse factor the mask equals the
+    oracle's on EVERY element -- an index result, no tolerance."""
+    rows, cols = shape
+    gen = torch.Generator().manual_seed(cols)
+    w = (torch.randn(rows, cols, generator=gen) * 0.02).to(dtype)
+    x = torch.randn(3 * cols, cols, generator=gen) * torch.exp(0.5 * torch.randn(cols, generator=gen))
+    _, hinv = sparsity.prepare_hessian((2.0 / x.shape[0]) * (x.t() @ x), CFG["hessian_damp"])
+    want = oracle.create_sgpt_mask(w, hinv, 2, 4, 128)
+    got = sparsity.create_sgpt_mask(w.to(DEV), None, CFG, hessian_inv=hinv.to(DEV)).cpu()
+    assert torch.equal(got, want), f"{int((got != want).sum())} mask entries differ"
+
+
 @pytest.mark.parametrize("name", ["sgpt_f32", "sgpt_bf16"])
 def test_create_sgpt_mask_matches_reference(golden, name):
     g = golden("sgpt")
@@ -94,6 +127,52 @@ def test_create_sgpt_mask_matches_reference(golden, name):
     for m in (m1, m2):
         assert m.dtype == torch.bool and m.shape == want.shape
         assert (m.view(m.shape[0], -1, 4).sum(-1) <= 2).all() and abs(m.float().mean().item() - 0.5) < 0.01
+    # (3) the percentages above are not the claim: the TIE AUDIT is.  The traced restatement of the reference loop
+    # reproduces the reference's mask exactly, and every row of m1 that differs from it differs FIRST at a 4-group whose
+    # swapped elements' reference scores lie within the fp32 reordering bound of the trailing-update GEMM (sgpt_audit)
+    import sgpt_audit
+
+    hinv = g.t(f"{name}_hinv")
+    wz = w.detach().clone().cpu()
+    ref = sgpt_audit.trace(wz, hinv)
+    assert torch.equal(ref[0], want), "the traced restatement does not reproduce the reference's mask"
+    report = sgpt_audit.audit(m1, ref, hinv)
+    assert not report["unexplained"], f"{name}: mask disagreements that are not ties: {report['unexplained'][:5]}"
+    assert report["explained"] == report["rows_differing"]
+    import conftest
+
+    conftest.note(f"sgpt tie audit {name} on {DEV}: {agree:.5f} equal given Hinv ({agree2:.5f} from the Hessian), rows "
+                  f"differing {report['rows_differing']}, all explained as ties")
+
+
+def test_sgpt_mask_disagreements_are_ties_at_llama_width():
+    """One Llama-sized input width (4096 columns = 32 column blocks, where order noise has room to accumulate): rows of a
+    bf16 weight against a Hessian of correlated activations.  Reference = the traced CPU restatement of the reference loop
+    (pinned to the reference's own masks by the fixture test above); the GPU mask, from the SAME inverse factor, may
+    differ only in rows whose first disagreement is a tie within the reordering bound, and must agree on >= 98 %."""
+    import sgpt_audit
+
+    gen = torch.Generator().manual_seed(7)
+    rows, cols, tokens = 256, 4096, 6144
+    w = (torch.randn(rows, cols, generator=gen) * 0.02).to(torch.bfloat16)
+    mix = torch.randn(cols, 64, generator=gen)
+    x = torch.randn(tokens, cols, generator=gen) * torch.exp(0.5 * torch.randn(cols, generator=gen)) \
+        + torch.randn(tokens, 64, generator=gen) @ mix.t() * 0.3
+    hessian = (2.0 / tokens) * (x.t() @ x)
+    zero, hinv = sparsity.prepare_hessian(hessian, CFG["hessian_damp"])  # CPU Cholesky: one factor for both sides
+    assert not zero.any()
+    got = sparsity.create_sgpt_mask(w.to(DEV), None, CFG, hessian_inv=hinv.to(DEV)).cpu()
+    ref = sgpt_audit.trace(w.float(), hinv)
+    report = sgpt_audit.audit(got, ref, hinv)
+    agree = (got == ref[0]).float().mean().item()
+    import conftest
+
+    conftest.note(f"sgpt tie audit 256x4096 on {DEV}: {agree:.5f} of the mask equal, rows differing "
+                  f"{report['rows_differing']}, explained as ties {report['explained']}, worst gap / bound "
+                  f"{report['worst_gap_over_bound']:.3g}")
+    assert not report["unexplained"], report["unexplained"][:5]
+    assert report["explained"] == report["rows_differing"] and agree >= 0.98
+    assert (got.view(rows, -1, 4).sum(-1) <= 2).all()
 
 
 def test_sparsify_sparsegpt_flow():

@@ -46,8 +46,8 @@ def main():
         print(f"| Cin={cin} | {ms:.3f} | {fl / ms / 1e9:.0f} | {ms2:.3f} | {fl / ms2 / 1e9:.0f} |")
         del h, h2, x
     print()
-    print("| create_sgpt_mask (2:4, col block 128), bf16 weight | total ms | column sweeps ms | trailing fp32 GEMMs ms |")
-    print("|---|---|---|---|")
+    print("| create_sgpt_mask (2:4, col block 128), bf16 weight | total ms | column sweeps ms | trailing updates (fp32 MFMA, fma chain) ms | TFLOP/s | same updates as library fp32 matmul ms |")
+    print("|---|---|---|---|---|---|")
     for co, ci in ((4096, 4096), (14336, 4096), (4096, 14336)):
         w = (torch.randn(co, ci, device=DEV) * 0.02).to(torch.bfloat16)
         a = torch.randn(ci, 2 * ci, device=DEV)
@@ -56,7 +56,16 @@ def main():
         total = timed(lambda: sparsity.create_sgpt_mask(w, None, cfg, hessian_inv=hinv), reps=2)
         wf = w.float().contiguous()
         sweep = timed(lambda: [ops.sgpt_block_sweep(wf, i1, 128, hinv) for i1 in range(0, ci, 128)], reps=2)
-        print(f"| {co}x{ci} | {total:.2f} | {sweep:.2f} | {total - sweep:.2f} |")
+        delta = torch.randn(co, 128, device=DEV)
+        upd = timed(lambda: [ops.sgpt_trailing_update(wf, i1, delta, hinv) for i1 in range(0, ci - 128, 128)], reps=2)
+
+        def lib_updates():
+            for i1 in range(0, ci - 128, 128):
+                wf[:, i1 + 128:] -= delta.matmul(hinv[i1:i1 + 128, i1 + 128:])
+
+        lib = timed(lib_updates, reps=2)
+        fl = sum(2.0 * co * 128 * (ci - i1 - 128) for i1 in range(0, ci - 128, 128))
+        print(f"| {co}x{ci} | {total:.2f} | {sweep:.2f} | {upd:.2f} | {fl / upd / 1e9:.0f} | {lib:.2f} |")
 
 
 if __name__ == "__main__":
