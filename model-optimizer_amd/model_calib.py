@@ -372,6 +372,25 @@ def get_scale(x_max, w_max, alpha):
     return (scales / (scales.max() * scales.min()).sqrt()).view(-1).to(dev)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def host_math_threads(n: int = 1):
+    """The [Cin]-sized host math of the AWQ search (get_scale and friends: ~30 small CPU tensor ops per candidate) on
+    ONE thread.  torch parallelises some of these ops (sqrt, reductions) over its OpenMP pool even for a few thousand
+    elements; on hosts where the visible CPUs exceed what the process may use (the GPU boxes show 256 CPUs under a
+    16-CPU quota) every such fork/join stalls for milliseconds -- measured 1.35 s vs 0.25 s for the 2464 scale vectors
+    of Llama-3-8B in the build container, 1.3-1.6 s of the flow on the GPU box.  Elementwise results do not depend on
+    the thread count."""
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(n)
+        yield
+    finally:
+        torch.set_num_threads(before)
+
+
 def _host_div(t: torch.Tensor, divisor: float) -> torch.Tensor:
     """t / divisor as IEEE fp32 division on the host (see get_scale), back on t's device."""
     return (t.detach().float().cpu() / divisor).to(t.device)
@@ -469,10 +488,18 @@ class AWQLiteHelper:
         (fp32) and the input-side 1 / s_alpha as the forward uses it (rounded to the model dtype).  Done for every linear
         before the first scoring kernel is queued: a device -> host round trip per candidate inside the scoring loop
         would drain the stream 2464 times for Llama-3-8B (measured: +6 s on 18 s)."""
-        self._s_host = torch.stack([get_scale(act_host, weight_host, a) for a in self.alphas])  # [A, Cin] fp32
-        r = (1.0 / self._s_host).to(dtype).float()
-        up = torch.cat([self._s_host, r]).to(self.act_scale.device)
+        self.upload_scales(self.host_scales(act_host, weight_host, dtype))
+
+    def host_scales(self, act_host: torch.Tensor, weight_host: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+        """The host half of prepare_scales: [2 A, Cin] fp32 = all s_alpha, then all (1 / s_alpha) rounded to `dtype`.
+        Pure CPU tensor math on this linear's own vectors."""
+        s = torch.stack([get_scale(act_host, weight_host, a) for a in self.alphas])  # [A, Cin] fp32
+        return torch.cat([s, (1.0 / s).to(dtype).float()])
+
+    def upload_scales(self, both: torch.Tensor):
         n = len(self.alphas)
+        self._s_host = both[:n]
+        up = both.to(self.act_scale.device)
         self._s_dev, self._r_dev = up[:n], up[n:]
 
     def scale(self, alpha):
@@ -958,9 +985,10 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 mdist.sync_amax_bucketed(chan, device=mods[0][1].weight.device)
         if state["gram_pass"] == "cache":
             finish_gram_pass()
-        for h in helpers.values():
-            if h.num_cache_steps:
-                h.act_scale = _host_div(h.act_sum, h.num_cache_steps)  # :1601, IEEE division (see get_scale)
+        with host_math_threads():
+            for h in helpers.values():
+                if h.num_cache_steps:
+                    h.act_scale = _host_div(h.act_sum, h.num_cache_steps)  # :1601, IEEE division (see get_scale)
         if mods:
             # DP: act_scale average + the any-NaN vote for ALL linears in ONE bucket (reference: one all_reduce and
             # one object gather per linear, :1588-1619); ranks whose shard never reached a linear join with zeros
@@ -978,11 +1006,16 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             live = [(m, helpers[m]) for _, m in mods if helpers[m].act_scale is not None]
             if live:
                 flat = torch.cat([t.detach().float().reshape(-1) for _, h in live for t in (h.act_scale, h.weight_scale)]).cpu()
-                off = 0
+                jobs, off = [], 0
                 for m, h in live:
                     c = h.act_scale.numel()
-                    h.prepare_scales(flat[off:off + c], flat[off + c:off + 2 * c], m.weight.dtype)
+                    jobs.append((h, flat[off:off + c], flat[off + c:off + 2 * c], m.weight.dtype))
                     off += 2 * c
+                # 11 pow / divide / normalise chains per linear on [Cin] vectors, one thread (see host_math_threads)
+                with host_math_threads():
+                    tables = [j[0].host_scales(j[1], j[2], j[3]) for j in jobs]
+                for (h, _, _, _), both in zip(jobs, tables):
+                    h.upload_scales(both)
         stage("scales")
         if state["gram_pass"] == "cache":
             gram_losses()
