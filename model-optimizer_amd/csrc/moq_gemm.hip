@@ -358,82 +358,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                    :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
     };
-    if constexpr (GEO == 11 || GEO == 12) {
-      // ---- GEO 11 / 12 (experiment, correct results): the GEO 10 stream with the operands going HBM/L2 -> VGPRs -> LDS
-      // (buffer_load_dwordx4 + ds_write_b128) instead of through the LDS-DMA.  Why: an LDS-DMA piece costs 60-185
-      // cycles of issue among MFMAs (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), eight per wave and K-tile
-      // against the tile's 1024 cycles of MFMA issue per wave; and its landing must be waited for with vmcnt(0) at
-      // the tile boundary, right before the barrier.  Here the loads of tile kt + 2 are issued in the last sub-step of
-      // tile kt into 32 registers and are waited for (by the compiler's own vmcnt bookkeeping) three sub-steps later,
-      // where tile kt + 1's third sub-step stores them into the stage tile kt just left; the tile boundary waits for
-      // LDS traffic only.  Same lane -> row / chunk mapping as the DMA pieces, so the fragment reads are unchanged.
-      typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-      u32x4_t R[8];
-      const __amdgpu_buffer_rsrc_t bw = rs_w.rsrc, bx = rs_x.rsrc;
-      const int k_last = (nk - 1) * kBK;
-      auto gload = [&](int k0, auto P) {
-        constexpr int p = decltype(P)::value, j = p & 3;
-        const int kk = k0 < k_last ? k0 : k_last;  // past the end: the last tile again (stored into an idle stage)
-        const int vfull = voff[j], vtail = voff_tail[j];  // (locals: a select between array elements goes through scratch)
-        const int vo = (k_ragged && kk + kBK > K) ? vtail : vfull;
-        R[p] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(p < 4 ? bw : bx, vo, kk * 2, 0));
-      };
-      uint8_t* const lds_lane = smem + wave * 4 * 8 * kRowBytes + lane * 16;
-      auto lstore = [&](int sn, auto P) {
-        constexpr int p = decltype(P)::value, j = p & 3;
-        *reinterpret_cast<u32x4_t*>(lds_lane + sn * SB + (p < 4 ? 0 : TB) + j * 8 * kRowBytes) = R[p];
-      };
-      // eight MFMAs of register buffer BUF, each followed by one fragment read of sub-step KS into the other buffer
-      // (six) and, after every second one, by two stores (MODE_ 1) or two loads (MODE_ 2) of pieces 2q, 2q + 1
-      auto group = [&](auto BUF, auto KS, auto MODE_, int so, int sn, int k0) {
-        constexpr int buf = decltype(BUF)::value, ks = decltype(KS)::value, nb = buf ^ 1, md = decltype(MODE_)::value;
-        const int c = ks * 2 + fh;
-        auto one = [&](auto NC) {
-          constexpr int n = decltype(NC)::value;
-          acc[n >> 1][n & 1] = mfma32<DT>(a[buf][n >> 1], b[buf][n & 1], acc[n >> 1][n & 1]);
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (ks >= 0 && n < 4) a[nb][n] = read_frag(la0 + so, n * 32 + fr, c);
-          else if constexpr (ks >= 0 && n < 6) b[nb][n - 4] = read_frag(lb0 + so, (n - 4) * 32 + fr, c);
-          if constexpr ((n & 1) != 0 && md == 1) { lstore(sn, IC<n - 1>{}); lstore(sn, IC<n>{}); }
-          if constexpr ((n & 1) != 0 && md == 2) { gload(k0, IC<n - 1>{}); gload(k0, IC<n>{}); }
-          if constexpr ((n & 1) != 0 && md == 3) {  // GEO 12: a piece is stored and its registers reloaded right away
-            lstore(sn, IC<n - 1>{}); lstore(sn, IC<n>{});
-            gload(k0, IC<n - 1>{}); gload(k0, IC<n>{});
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{});
-      };
-      // prologue: tile 0 through the registers into stage 0, tile 1 on its way
-      gload(0, IC<0>{}); gload(0, IC<1>{}); gload(0, IC<2>{}); gload(0, IC<3>{});
-      gload(0, IC<4>{}); gload(0, IC<5>{}); gload(0, IC<6>{}); gload(0, IC<7>{});
-      lstore(0, IC<0>{}); lstore(0, IC<1>{}); lstore(0, IC<2>{}); lstore(0, IC<3>{});
-      lstore(0, IC<4>{}); lstore(0, IC<5>{}); lstore(0, IC<6>{}); lstore(0, IC<7>{});
-      gload(kBK, IC<0>{}); gload(kBK, IC<1>{}); gload(kBK, IC<2>{}); gload(kBK, IC<3>{});
-      gload(kBK, IC<4>{}); gload(kBK, IC<5>{}); gload(kBK, IC<6>{}); gload(kBK, IC<7>{});
-      for (int kt = 0; kt < nk; ++kt) {
-        const int so = (kt & 1) * SB, sn = (kt + 1) & 1;
-        // every LDS store of tile kt and every fragment read of tile kt - 1 of this wave is done; the barrier makes
-        // that true for the workgroup.  Loads of tile kt + 1 stay in flight across it.
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt > 0) group(IC<1>{}, IC<0>{}, IC<0>{}, so, sn, 0);  // last sub-step of tile kt - 1 under the first reads
-        else read_sub(0, so, 0);
-        group(IC<0>{}, IC<1>{}, IC<0>{}, so, sn, 0);
-        if constexpr (GEO == 11) {
-          group(IC<1>{}, IC<2>{}, IC<1>{}, so, sn, 0);                 // tile kt + 1: registers -> stage sn
-          group(IC<0>{}, IC<3>{}, IC<2>{}, so, sn, (kt + 2) * kBK);    // tile kt + 2: HBM / L2 -> registers
-        } else {  // GEO 12: both in the last sub-step -- the loads get a whole K-tile of lead
-          group(IC<1>{}, IC<2>{}, IC<0>{}, so, sn, 0);
-          group(IC<0>{}, IC<3>{}, IC<3>{}, so, sn, (kt + 2) * kBK);
-        }
-      }
-      mma_sub(1);  // last sub-step of the last tile
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the epilogue reuses the LDS
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
     for (int kt = 0; kt < nk; ++kt) {
@@ -509,7 +433,6 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     mma_sub(1);  // last sub-step of the last tile
     // the last tile's "dead" pieces (zero fills of the idle stage) must have landed before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
 
   gemm_epilogue<DT, MODE, NI, NJ, Geo<GEO>::WAVES>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, wn, wt, fr, fh,
@@ -570,8 +493,7 @@ static int gemm_geo() {
   // (profiles/r02_gemm_table.md: GEO 10 runs 3-5 % ahead).
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
-    const int g = e ? atoi(e) : 10;
-    return g == 4 || g == 11 || g == 12 ? g : 10;
+    return e && atoi(e) == 4 ? 4 : 10;
   }();
   return geo;
 }
@@ -647,11 +569,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     set_error("gemm: too many tiles");
     return MOQ_ERR_UNSUPPORTED;
   }
-  if (geo == 12)
-    launch_geo<MODE, 12>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);
-  else if (geo == 11)
-    launch_geo<MODE, 11>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);
-  else if (geo == 4)
+  if (geo == 4)
     launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);
   else
     launch_geo<MODE, 10>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only);

@@ -169,13 +169,20 @@ __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ 
   const float* pa = sa + (wr * 64 + m) * kTuPitchA + h;
   const float* pb = sb + h * kTuTile + wc * 64 + m;
   const int kpairs = (bs + 1) / 2;
+  // the operands of k pair j + 1 are read while the four MFMAs of pair j issue (64 cycles each: an LDS round trip
+  // hides under one pair); the pad rows / columns behind the last pair are zeros, so reading one pair too far is safe
+  float a0 = pa[0], a1 = pa[32 * kTuPitchA], b0 = pb[0], b1 = pb[32];
   for (int j = 0; j < kpairs; ++j) {
-    const float a0 = pa[2 * j], a1 = pa[32 * kTuPitchA + 2 * j];
-    const float b0 = pb[2 * j * kTuTile], b1 = pb[2 * j * kTuTile + 32];
+    const int jn = j + 1 < kTuTile / 2 ? j + 1 : j;
+    const float a0n = pa[2 * jn], a1n = pa[32 * kTuPitchA + 2 * jn];
+    const float b0n = pb[2 * jn * kTuTile], b1n = pb[2 * jn * kTuTile + 32];
+    __builtin_amdgcn_sched_barrier(0);
     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)

@@ -102,6 +102,8 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
             batched.append((w, wq))
         else:
             wq(w)
+            if isinstance(wq, TensorQuantizer) and wq._if_calib:
+                wq.mark_weight_stats_done(w)
     by_key = {}
     for w, wq in batched:
         by_key.setdefault((w.dtype, w.device), []).append((w, wq))
@@ -115,6 +117,7 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
                 cal._shape, cal._dtype = (), w.dtype
             else:
                 torch.maximum(cal._buf, amax[i:i + 1], out=cal._buf)
+            wq.mark_weight_stats_done(w)
 
 
 @torch.no_grad()

@@ -68,6 +68,8 @@ class TensorQuantizer(nn.Module):
             self.amax = amax
 
     # ------------------------------------------------------------------ configuration
+    _weight_stats_done = None  # (data_ptr, version, shape) of the weight whose max statistics this calibration already holds
+
     def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
         """tensor_quantizer.py:228-290: (re)configure in place; calibration state is dropped."""
         for name in ("_amax", "_pre_quant_scale"):
@@ -173,6 +175,7 @@ class TensorQuantizer(nn.Module):
         self._preserve_amax_in_fp32()
 
     def reset_amax(self):
+        self._weight_stats_done = None
         if hasattr(self, "_amax"):
             delattr(self, "_amax")
         self._calibrator.reset()
@@ -199,12 +202,20 @@ class TensorQuantizer(nn.Module):
     def enable(self):
         self._disabled = False
 
+    def mark_weight_stats_done(self, weight):
+        """model_calib.weight_only_quantize collected this quantizer's max statistics from `weight`: calls with the same,
+        unchanged tensor are pass-throughs until the calibration ends (disable_calib / reset_amax).  Only running-max
+        calibrators qualify (a histogram would count the weight once per forward in the reference)."""
+        if type(self._calibrator).__name__ == "MaxCalibrator" and self.pre_quant_scale is None:
+            self._weight_stats_done = (weight.data_ptr(), weight._version, tuple(weight.shape))
+
     def enable_calib(self):
         if self._dynamic:  # dynamic quantization does not need calibration (tensor_quantizer.py:676-684)
             return
         self._if_calib = True
 
     def disable_calib(self):
+        self._weight_stats_done = None
         self._if_calib = False
 
     def enable_quant(self):
@@ -389,6 +400,13 @@ class TensorQuantizer(nn.Module):
     def forward(self, inputs):
         if inputs.numel() == 0:
             return inputs
+        if self._weight_stats_done is not None and self._if_calib and not self._if_quant and not self._disabled:
+            # a weight quantizer inside max_calibrate's forward loop: its statistics were taken by weight_only_quantize
+            # (one multi-tensor launch) from this very tensor; the reference collects them again on every forward
+            # (model_calib.py:351-362), which for a running abs-max of an unchanged weight changes nothing
+            done = self._weight_stats_done
+            if done[0] == inputs.data_ptr() and done[1] == inputs._version and done[2] == tuple(inputs.shape):
+                return inputs
         pqs = self.pre_quant_scale
         fused_pqs = False
         if pqs is not None:

@@ -481,3 +481,42 @@ def test_smoothquant_composed_with_mxfp4_equals_reference_halves(golden, hostmem
     with torch.no_grad(), pytest.warns(UserWarning, match="Only int8 smoothing"):
         moa.quantize(model2, cfg2, lambda m: [m(b) for b in batches[:1]])
     assert model2.get_submodule(cases["linears"][0]).input_quantizer.pre_quant_scale is None
+
+
+def test_weight_statistics_are_collected_once_per_max_calibration(monkeypatch):
+    """The reference re-collects every weight's abs-max on every calibration forward (model_calib.py:351-362: the weight
+    quantizers stay in calibration mode through forward_loop) -- 0.4 GB of reads per decoder layer and batch for
+    Llama-3-8B.  A running abs-max of an unchanged tensor is idempotent, so here weight_only_quantize's one pass is the
+    only one: the forward loop must not reduce a weight again, and the result is what the redundant collection gives."""
+    import copy
+
+    import hostmem_backend
+
+    hostmem_backend.install(monkeypatch, moa)
+    from model_optimizer_amd import model_calib, ops
+
+    def build():
+        torch.manual_seed(0)
+        return torch.nn.Sequential(torch.nn.Linear(64, 128, bias=False), torch.nn.ReLU(), torch.nn.Linear(128, 32))
+
+    batches = [torch.randn(8, 64) for _ in range(4)]
+    reduced = []
+    orig = ops.reduce_amax
+    monkeypatch.setattr(ops, "reduce_amax", lambda x, *a, **k: (reduced.append(tuple(x.shape)), orig(x, *a, **k))[1])
+    for preset in ("FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG"):
+        reduced.clear()
+        model = moa.quantize(build(), copy.deepcopy(getattr(moa.model_quant, preset)), lambda m: [m(b) for b in batches])
+        weight_shapes = {(128, 64), (32, 128)}
+        assert sum(s in weight_shapes for s in reduced) == 2, reduced  # once per weight, not once per weight and batch
+        # the same amax as with the re-collection forced on every forward
+        redo = build()
+        moa.nn.replace_quant_module(redo)
+        moa.model_quant.set_quantizer_by_cfg(redo, getattr(moa.model_quant, preset)["quant_cfg"])
+        monkeypatch.setattr(moa.TensorQuantizer, "mark_weight_stats_done", lambda self, w: None)
+        model_calib.max_calibrate(redo, lambda m: [m(b) for b in batches])
+        monkeypatch.undo()
+        hostmem_backend.install(monkeypatch, moa)
+        monkeypatch.setattr(ops, "reduce_amax", lambda x, *a, **k: (reduced.append(tuple(x.shape)), orig(x, *a, **k))[1])
+        for (n, q), (_, r) in zip(model.named_modules(), redo.named_modules()):
+            if hasattr(q, "_amax"):
+                assert torch.equal(q._amax, r._amax), n
