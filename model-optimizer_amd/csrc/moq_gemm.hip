@@ -461,14 +461,22 @@ __global__ void err_finalize_kernel(const float* __restrict__ partial, int n, do
 using namespace moq;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// fp32 operands: the fp32 matrix-core kernel of moq_gemm_f32.hip (same epilogues, 128 x 128 tiles)
+int64_t moq_f32_launch_err(const void* x, const void* w, const void* ref, const void* bias, float* partial, int64_t tokens,
+                           int64_t cout, int64_t cin, int n_cand, int64_t x_stride, int64_t w_stride, void* stream);
+int64_t moq_f32_launch_store(const void* x, const void* w, const void* bias, void* out, int64_t tokens, int64_t cout,
+                             int64_t cin, void* stream);
+int64_t moq_f32_launch_dot(const void* a, const void* b, const void* ref, float* partial, int64_t rows, int64_t cols,
+                           int64_t k, void* stream);
+
 static int gemm_check(const void* x, const void* w, int64_t tokens, int64_t cout, int64_t cin, int dt,
                       const char* who) {
   if (x == nullptr || w == nullptr || tokens < 0 || cout <= 0 || cin <= 0) {
     set_error("%s: null pointer or bad sizes", who);
     return MOQ_ERR_INVALID;
   }
-  if (dt != MOQ_BF16 && dt != MOQ_F16) {
-    set_error("%s: only bf16 / f16 operands run on the MFMA path (fp32 models use the library GEMM)", who);
+  if (dt != MOQ_BF16 && dt != MOQ_F16 && dt != MOQ_F32) {
+    set_error("%s: operands must be bf16, f16 or f32", who);
     return MOQ_ERR_UNSUPPORTED;
   }
   if (cin % 8 != 0 || cout % 4 != 0) {
@@ -600,8 +608,9 @@ static int err_gemm_common(const void* x, const void* w, const void* out_actual,
     return MOQ_ERR_INVALID;
   }
   if (tokens == 0) return MOQ_OK;
-  const int64_t nblk = launch_gemm<0>(x, w, out_actual, bias, nullptr, partial, tokens, cout, cin, dt, n_cand,
-                                      x_stride, w_stride, stream);
+  const int64_t nblk = dt == MOQ_F32
+      ? moq_f32_launch_err(x, w, out_actual, bias, partial, tokens, cout, cin, n_cand, x_stride, w_stride, stream)
+      : launch_gemm<0>(x, w, out_actual, bias, nullptr, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream);
   if (nblk < 0) return (int)nblk;
   hipLaunchKernelGGL(err_finalize_kernel, dim3((unsigned)n_cand), dim3(256), 0, S(stream), partial, (int)nblk,
                      1.0 / ((double)tokens * (double)cout), loss_acc);
@@ -632,7 +641,8 @@ extern "C" int moq_gemm_nt(const void* x, const void* w, const void* bias, void*
     return MOQ_ERR_INVALID;
   }
   if (tokens == 0) return MOQ_OK;
-  const int64_t nblk = launch_gemm<1>(x, w, nullptr, bias, out, nullptr, tokens, cout, cin, dt, 1, 0, 0, stream);
+  const int64_t nblk = dt == MOQ_F32 ? moq_f32_launch_store(x, w, bias, out, tokens, cout, cin, stream)
+                                     : launch_gemm<1>(x, w, nullptr, bias, out, nullptr, tokens, cout, cin, dt, 1, 0, 0, stream);
   if (nblk < 0) return (int)nblk;
   return check_launch("moq_gemm_nt");
 }
@@ -675,6 +685,10 @@ extern "C" int moq_hessian_accum(const void* xt, int64_t cin, int64_t tokens, in
                                  float scale, int upper_only, void* stream) {
   int rc = gemm_check(xt, xt, cin, cin, tokens, dt, "moq_hessian_accum");
   if (rc != MOQ_OK) return rc;
+  if (dt == MOQ_F32) {
+    set_error("moq_hessian_accum: the Gram / Hessian accumulation takes bf16 / f16 activations");
+    return MOQ_ERR_UNSUPPORTED;
+  }
   if (hessian == nullptr || (reinterpret_cast<uintptr_t>(hessian) & 15u) != 0) {
     set_error("moq_hessian_accum: hessian must be a non-NULL 16-byte aligned pointer");
     return MOQ_ERR_INVALID;
@@ -694,7 +708,8 @@ extern "C" int moq_awq_quadform(const void* a, const void* b, const float* ref, 
     return MOQ_ERR_INVALID;
   }
   if (rows == 0) return MOQ_OK;
-  const int64_t nblk = launch_gemm<3>(a, b, ref, nullptr, nullptr, partial, rows, cols, k, dt, 1, 0, 0, stream);
+  const int64_t nblk = dt == MOQ_F32 ? moq_f32_launch_dot(a, b, ref, partial, rows, cols, k, stream)
+                                     : launch_gemm<3>(a, b, ref, nullptr, nullptr, partial, rows, cols, k, dt, 1, 0, 0, stream);
   if (nblk < 0) return (int)nblk;
   hipLaunchKernelGGL(err_finalize_kernel, dim3(1), dim3(256), 0, S(stream), partial, (int)nblk, inv_count, loss_acc);
   return check_launch("moq_awq_quadform");

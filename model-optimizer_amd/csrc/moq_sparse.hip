@@ -105,6 +105,31 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 constexpr int kTuTile = 128, kTuPitchA = 129;
 constexpr size_t kTuLds = ((size_t)kTuTile * kTuPitchA + (size_t)kTuTile * kTuTile) * sizeof(float);
 
+// one operand quad: a 16-byte load when the layout allows it (VEC), four words otherwise; elements that are not part of
+// the matrix (`n_valid` < 4, counted from the quad's first element) come back as zeros.  No branch: an invalid quad reads
+// a safe address and is masked, so the sixteen loads of a thread can all be in flight together.
+template <bool VEC>
+__device__ __forceinline__ float4 tu_load_quad(const float* __restrict__ base, int64_t off, int n_valid) {
+  const bool any = n_valid > 0;
+  const float* src = base + (any ? off : 0);
+  float4 v;
+  if constexpr (VEC) {
+    v = *reinterpret_cast<const float4*>(src);
+  } else {
+    v.x = src[0];
+    v.y = src[n_valid > 1 ? 1 : 0];
+    v.z = src[n_valid > 2 ? 2 : 0];
+    v.w = src[n_valid > 3 ? 3 : 0];
+  }
+  v.x = n_valid > 0 ? v.x : 0.0f;
+  v.y = n_valid > 1 ? v.y : 0.0f;
+  v.z = n_valid > 2 ? v.z : 0.0f;
+  v.w = n_valid > 3 ? v.w : 0.0f;
+  return v;
+}
+
+// VA: delta quads are 16-byte aligned and whole (bs % 4 == 0); VB: hinv quads are (ld % 4 == 0, i2 % 4 == 0)
+template <bool VA, bool VB>
 __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
                                                             int bs, const float* __restrict__ delta,
                                                             const float* __restrict__ hinv) {
@@ -114,46 +139,34 @@ __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ 
   const int64_t i2 = i1 + bs, ncols = ld - i2;
   const int64_t r0 = (int64_t)blockIdx.y * kTuTile, c0 = (int64_t)blockIdx.x * kTuTile;
   const int tid = threadIdx.x;
-  // A: thread t takes k quad q = t & 31 of rows (t >> 5) + 8 i -- a wave reads two 512-byte delta rows per step
   {
+    // thread t takes quad q = t & 31 of rows / k rows (t >> 5) + 8 i.  All 32 loads of a thread are issued before the
+    // first LDS write (a load per iteration, waited for at once, would put sixteen memory latencies in a row in front
+    // of a tile's 7 us of MFMAs)
     const int q = tid & 31;
+    float4 va[kTuTile / 8], vb[kTuTile / 8];
+#pragma unroll
     for (int i = 0; i < kTuTile / 8; ++i) {
       const int r = (tid >> 5) + 8 * i;
-      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (r0 + r < rows) {
-        const float* src = delta + (r0 + r) * bs + 4 * q;
-        if (4 * q + 3 < bs) v = *reinterpret_cast<const float4*>(src);  // bs % 4 == 0 is not required:
-        else {                                                          // the ragged quad goes word by word
-          if (4 * q + 0 < bs) v.x = src[0];
-          if (4 * q + 1 < bs) v.y = src[1];
-          if (4 * q + 2 < bs) v.z = src[2];
-        }
-      }
-      float* dst = sa + r * kTuPitchA + 4 * q;
-      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      const int nv = r0 + r < rows ? bs - 4 * q : 0;  // valid words of the quad
+      va[i] = tu_load_quad<VA>(delta, (r0 + r) * bs + 4 * q, nv);
     }
-  }
-  // B: thread t takes column quad q = t & 31 of k rows (t >> 5) + 8 i (hinv rows are 16-byte aligned when ld % 4 == 0
-  // and i2 + c0 is a multiple of 4; otherwise word by word)
-  {
-    const int q = tid & 31;
-    const bool vec_ok = (ld % 4 == 0) && ((i2 + c0) % 4 == 0);
+#pragma unroll
     for (int i = 0; i < kTuTile / 8; ++i) {
       const int k = (tid >> 5) + 8 * i;
-      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (k < bs) {
-        const float* src = hinv + (i1 + k) * ld + i2 + c0 + 4 * q;
-        const int64_t c = c0 + 4 * q;
-        if (vec_ok && c + 3 < ncols) v = *reinterpret_cast<const float4*>(src);
-        else {
-          if (c + 0 < ncols) v.x = src[0];
-          if (c + 1 < ncols) v.y = src[1];
-          if (c + 2 < ncols) v.z = src[2];
-          if (c + 3 < ncols) v.w = src[3];
-        }
-      }
-      *reinterpret_cast<float4*>(sb + k * kTuTile + 4 * q) = v;
+      const int64_t left = ncols - (c0 + 4 * q);
+      const int nv = k < bs ? (int)(left > 4 ? 4 : left) : 0;
+      vb[i] = tu_load_quad<VB>(hinv, (i1 + k) * ld + i2 + c0 + 4 * q, nv);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < kTuTile / 8; ++i) {
+      float* dst = sa + ((tid >> 5) + 8 * i) * kTuPitchA + 4 * q;
+      dst[0] = va[i].x; dst[1] = va[i].y; dst[2] = va[i].z; dst[3] = va[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < kTuTile / 8; ++i)
+      *reinterpret_cast<float4*>(sb + ((tid >> 5) + 8 * i) * kTuTile + 4 * q) = vb[i];
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
@@ -166,6 +179,24 @@ __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  // The read half of the weight tile's read-modify-write is requested HERE, before the MFMA loop: 64 loads per lane
+  // that do not depend on the contraction ride under its ~7 us instead of standing behind it.
+  float cur[2][2][16];
+  float* ptr[2][2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t c = c0 + wc * 64 + j * 32 + m;
+      const bool c_ok = c < ncols;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t r = r0 + wr * 64 + i * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
+        ptr[i][j][e] = (c_ok && r < rows) ? w + r * ld + i2 + c : nullptr;
+        cur[i][j][e] = *(ptr[i][j][e] ? ptr[i][j][e] : w);
+      }
+    }
+  __builtin_amdgcn_sched_barrier(0);
   const float* pa = sa + (wr * 64 + m) * kTuPitchA + h;
   const float* pb = sb + h * kTuTile + wc * 64 + m;
   const int kpairs = (bs + 1) / 2;
@@ -184,21 +215,14 @@ __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ 
     __builtin_amdgcn_sched_barrier(0);
     a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
   }
+  // the weight tile comes back: w -= acc (the loads went out before the MFMA loop)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t c = c0 + wc * 64 + j * 32 + m;
-      if (c >= ncols) continue;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t r = r0 + wr * 64 + i * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
-        if (r < rows) {
-          float* dst = w + r * ld + i2 + c;
-          *dst = *dst - acc[i][j][e];
-        }
-      }
-    }
+      for (int e = 0; e < 16; ++e)
+        if (ptr[i][j][e]) *ptr[i][j][e] = cur[i][j][e] - acc[i][j][e];
 }
 
 // y[c, r] = x[r, c] for 16-bit elements through a 64 x 64 LDS tile (+1 column of padding: conflict-free columns)
@@ -269,11 +293,19 @@ extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int6
   (void)hipGetDevice(&device);
   const uint64_t bit = 1ull << (device & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
     attr_set.fetch_or(bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(sgpt_trailing_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), kTuLds, S(stream), w, rows, ld, i1,
-                     bs, delta, hinv);
+  const bool va = bs % 4 == 0 && (reinterpret_cast<uintptr_t>(delta) & 15u) == 0;
+  const bool vb = ld % 4 == 0 && (i1 + bs) % 4 == 0 && (reinterpret_cast<uintptr_t>(hinv) & 15u) == 0;
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  if (va && vb) hipLaunchKernelGGL((sgpt_trailing_kernel<true, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
+  else if (va) hipLaunchKernelGGL((sgpt_trailing_kernel<true, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
+  else if (vb) hipLaunchKernelGGL((sgpt_trailing_kernel<false, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
+  else hipLaunchKernelGGL((sgpt_trailing_kernel<false, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
   return check_launch("moq_sgpt_trailing_update");
 }
 

@@ -559,10 +559,13 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
     n_out = w.shape[0]
     bits = module.weight_quantizer.num_bits
     # 16-bit models: the Cout x Cin x Cin contraction runs on the matrix cores in split precision (three bf16
-    # products summed in the fp32 accumulators, ~1e-5 relative) with the <., E> product fused; fp32 models keep the
-    # library's fp32 GEMM (agreement with the reference to ~1e-6 is asserted for them)
+    # products summed in the fp32 accumulators, ~1e-5 relative) with the <., E> product fused; fp32 models run the same
+    # contraction on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 products; agreement with the reference to
+    # ~1e-6 is asserted for them).  The library GEMM is left for widths the kernels do not take and for CPU tensors.
     mfma = dt in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0 and w.shape[1] % h.block_size == 0
     wf = None if mfma else w.float()
+    f32_mfma = (not mfma and dt == torch.float32 and w.is_cuda and w.shape[1] % 8 == 0 and w.shape[0] % 4 == 0
+                and h.gram.is_contiguous())
     planes = gram_score_planes(dt)
     gram_op = ops.gram_operand(h.gram, planes) if mfma else None
     for i, alpha in enumerate(h.alphas):
@@ -575,7 +578,10 @@ def _gram_losses(h: AWQLiteHelper, module: QuantLinear):
         else:
             w_hat = ops.awq_scale_qdq(w, s.to(dt), h.block_size, bits)  # QDQ((W * s).to(dtype)), one kernel
             err = w_hat.float().mul_(r).sub_(wf)
-            h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
+            if f32_mfma:  # <E G, E> on the fp32 matrix cores (G is symmetric: the NT kernel's G^T is G)
+                ops.awq_quadform(err, h.gram, h.loss_buf[i:i + 1], 1.0 / n_out)
+            else:
+                h.loss_buf[i] += (torch.matmul(err, h.gram) * err).sum() / n_out
 
 
 # Relative margin inside which two candidates' Gram scores do not decide the search (search="auto").  The Gram loss
@@ -766,7 +772,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             # contraction with the (out - out_actual)^2 mean fused -- `out` never reaches HBM
             xs = ops.scale_cols_multi(x2, inv_s)
             ops.awq_err_gemm_multi(xs, w_hat, out2, self.bias, loss_buf)
-        else:  # fp32 models: library GEMM, the reference's own arithmetic
+        else:  # widths the kernels do not take: library GEMM, the reference's own arithmetic
             for j in range(inv_s.shape[0]):
                 out = F.linear(ops.scale_cols(x2, inv_s[j]), w_hat[j], self.bias)
                 loss_buf[j] += (out - out2).float().pow(2).mean()

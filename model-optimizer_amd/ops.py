@@ -689,8 +689,9 @@ def fake_e4m3fy_with_axis(inputs, amax, axis):
 
 # ----------------------------------------------------------------------------------------------- AWQ error GEMM
 def mfma_gemm_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
-    """Shapes / dtypes the MFMA kernel takes (fp32 models go through the library GEMM instead)."""
-    return (x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and w.shape[-1] % 8 == 0
+    """Shapes / dtypes the MFMA kernels take: bf16 / f16 on the 16-bit loop, fp32 on the fp32 matrix cores
+    (moq_gemm_f32.hip).  What is left for the library: odd widths."""
+    return (x.dtype in (torch.bfloat16, torch.float16, torch.float32) and w.dtype == x.dtype and w.shape[-1] % 8 == 0
             and w.shape[0] % 4 == 0)
 
 
@@ -719,7 +720,7 @@ def awq_err_gemm(xs: torch.Tensor, w_hat: torch.Tensor, out_actual: torch.Tensor
 
 @torch.no_grad()
 def gemm_nt(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None) -> torch.Tensor:
-    """F.linear(x, w, bias) for bf16 / f16 on the same MFMA main loop (store epilogue)."""
+    """F.linear(x, w, bias) for bf16 / f16 / fp32 on the MFMA main loops (store epilogue)."""
     _require_gpu(x, "gemm_nt")
     x2 = x.detach().contiguous().view(-1, x.shape[-1])
     wc = w.detach().contiguous()
@@ -1151,8 +1152,19 @@ def awq_quadform(err: torch.Tensor, gram_op: torch.Tensor, loss_acc: torch.Tenso
     gram_op = gram_operand(G, planes): one MFMA contraction over K = planes * Cin (planes 3: split precision
     E_hi G_hi + E_hi G_lo + E_lo G_hi) with the product against E fused into the epilogue."""
     _require_gpu(err, "awq_quadform")
+    if gram_op.dtype == torch.float32:
+        # fp32 models: E and the (symmetric) Gram matrix as they are, on the fp32 matrix cores -- no split planes
+        rows, cols = err.shape
+        if err.dtype != torch.float32 or not err.is_contiguous() or not gram_op.is_contiguous() \
+                or tuple(gram_op.shape) != (cols, cols) or loss_acc.dtype != torch.float32 or loss_acc.numel() != 1:
+            raise MoquantError("awq_quadform (fp32): err fp32 [Cout, Cin], gram fp32 [Cin, Cin] (contiguous) expected")
+        ws = torch.empty(int(_lib.lib().moq_awq_err_gemm_workspace(rows, cols)), dtype=torch.float32, device=err.device)
+        with _on(err) as stream:
+            check(_lib.lib().moq_awq_quadform(_p(err), _p(gram_op), _p(err), rows, cols, cols, _lib.F32, _p(ws),
+                                              _p(loss_acc), float(inv_count), stream))
+        return loss_acc
     if err.dtype != torch.float32 or not err.is_contiguous() or gram_op.dtype != torch.bfloat16:
-        raise MoquantError("awq_quadform: err must be contiguous fp32, gram_op bf16")
+        raise MoquantError("awq_quadform: err must be contiguous fp32, gram_op bf16 (or fp32 for fp32 models)")
     rows, cols = err.shape
     planes = gram_op.shape[1] // cols if gram_op.dim() == 2 and cols else 0
     if planes not in (1, 2, 3) or tuple(gram_op.shape) != (cols, planes * cols) or loss_acc.dtype != torch.float32 \

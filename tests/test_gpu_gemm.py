@@ -100,8 +100,9 @@ def test_err_gemm_rejects_unsupported():
     x = torch.randn(8, 16, device=DEV)
     w = torch.randn(8, 16, device=DEV)
     acc = torch.zeros(1, dtype=torch.float32, device=DEV)
-    with pytest.raises(ValueError):  # fp32 operands: MOQ_ERR_UNSUPPORTED -> ValueError, loud
-        ops.awq_err_gemm(x, w, torch.randn(8, 8, device=DEV), None, acc)
+    ops.awq_err_gemm(x, w, torch.randn(8, 8, device=DEV), None, acc)  # fp32 operands: the fp32 matrix-core kernel (round 3)
+    with pytest.raises(ValueError):  # float64: MOQ_ERR_UNSUPPORTED -> ValueError, loud
+        ops.awq_err_gemm(x.double(), w.double(), torch.randn(8, 8, device=DEV).double(), None, acc)
     xb = x.to(torch.bfloat16)
     with pytest.raises(ValueError):  # cin % 8 != 0
         ops.gemm_nt(xb[:, :12].contiguous(), w.to(torch.bfloat16)[:, :12].contiguous())
@@ -190,3 +191,52 @@ def test_the_two_release_loop_structures_are_bit_identical():
         assert p.returncode == 0, p.stderr[-2000:]
         digests[geo] = p.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+F32_SHAPES = [(1, 4, 8), (5, 12, 24), (130, 132, 72), (257, 384, 200), (64, 256, 1024), (300, 260, 136), (512, 128, 4096)]
+
+
+@pytest.mark.parametrize("shape", F32_SHAPES)
+def test_f32_gemm_on_the_fp32_matrix_cores(shape):
+    """fp32 operands (fp32 models' AWQ search; moq_gemm_f32.hip, v_mfma_f32_32x32x2_f32): exact on integer data (tile /
+    fragment / edge mapping), and on random data within the fp32 reordering bound of a double-precision reference --
+    store epilogue, fused squared-error loss (two accumulating calls, bias) and the <E G, E> dot of the Gram search."""
+    t, n, k = shape
+    x, w, b = _ints((t, k), torch.float32, 1), _ints((n, k), torch.float32, 2), _ints((n,), torch.float32, 3)
+    for bias in (None, b):
+        want = x @ w.t() + (0 if bias is None else bias)
+        got = ops.gemm_nt(x.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV)).cpu()
+        assert torch.equal(got, want), f"{shape}: integer fp32 GEMM not exact (bias={bias is not None})"
+    g = torch.Generator().manual_seed(t * 31 + k)
+    x, w = torch.randn(t, k, generator=g), torch.randn(n, k, generator=g) * 0.05
+    bias, ref = torch.randn(n, generator=g) * 0.1, torch.randn(t, n, generator=g) * 0.1
+    exact = x.double() @ w.double().t()
+    bound = (k + 4) * 2.0 ** -24 * (x.abs().double() @ w.abs().double().t()) + 1e-30
+    got = ops.gemm_nt(x.to(DEV), w.to(DEV)).cpu()
+    assert ((got.double() - exact).abs() <= bound).all(), f"{shape}: fp32 GEMM outside the summation bound"
+    acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(x.to(DEV), w.to(DEV), ref.to(DEV), bias.to(DEV), acc)
+    ops.awq_err_gemm(x.to(DEV), w.to(DEV), ref.to(DEV), bias.to(DEV), acc)
+    want = 2 * ((exact + bias.double() - ref.double()) ** 2).mean().item()
+    assert abs(acc.item() - want) <= 2e-5 * abs(want), f"{shape}: fused loss {acc.item()} vs {want}"
+    # batched candidates: per-candidate operands, shared reference
+    xs = torch.stack([x, x * 0.5, x * 2.0]).to(DEV)
+    ws = torch.stack([w, w * 2.0, w * 0.25]).to(DEV)
+    accs = torch.zeros(3, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm_multi(xs, ws, ref.to(DEV), None, accs)
+    for a in range(3):
+        want = ((xs[a].cpu().double() @ ws[a].cpu().double().t() - ref.double()) ** 2).mean().item()
+        assert abs(accs[a].item() - want) <= 2e-5 * abs(want)
+
+
+@pytest.mark.parametrize("cout,cin", [(64, 128), (132, 264), (256, 1024)])
+def test_f32_quadform_on_the_fp32_matrix_cores(cout, cin):
+    g = torch.Generator().manual_seed(cin)
+    err = torch.randn(cout, cin, generator=g) * 0.01
+    a = torch.randn(cin, 2 * cin, generator=g)
+    gram = (a @ a.t() / cin).contiguous()
+    gram = ((gram + gram.t()) * 0.5).contiguous()
+    acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_quadform(err.to(DEV), gram.to(DEV), acc, 1.0 / cout)
+    want = ((err.double() @ gram.double()) * err.double()).sum().item() / cout
+    assert abs(acc.item() - want) <= 2e-5 * abs(want), f"{acc.item()} vs {want}"

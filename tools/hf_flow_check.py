@@ -53,6 +53,8 @@ def run(args, moa=None, dev=None) -> dict:
             for b in batches:
                 m(b)
 
+    with torch.no_grad():
+        model(batches[0])  # first touch: library GEMM selection, allocator growth (not part of the plain-loop figure)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loop(model)
