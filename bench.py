@@ -225,8 +225,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MOQ_FORCE_DIST=1 with ONE rank: the process group is initialised (backend nccl = RCCL) and every collective of
+    # the N > 1 path runs with a world of one -- the first multi-GPU run is then not this script's first RCCL run
+    # (tests/test_gpu_dist_nccl.py does the same for the library flows)
+    use_dist = world > 1 or os.environ.get("MOQ_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if one_gpu_debug:
             dist.init_process_group("gloo")
         else:
@@ -285,13 +292,13 @@ def main():
             if record:
                 e1.record()
                 dom_events.append((e0, e1))
-            if world > 1:
+            if use_dist:
                 amax_all.zero_()
                 amax_all[owned_idx] = torch.cat([gt.amax_flat for gt in groups])
                 dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
         elif wl == "fp8" or wl == "int8":
             tab.calibrate_amax()
-            if world > 1:
+            if use_dist:
                 # one bucket: the owners' values reach every rank (zeros are the identity of abs-max)
                 amax_all.zero_()
                 amax_all[owned_idx] = tab.amax_flat
@@ -345,17 +352,17 @@ def main():
     # 5.1 ms as the first work after process start and 4.4 ms later in the same session), so the device is kept busy
     # for ~1.5 s before the contractual warm-up + timed region.
     # The ramp is time-based, so ranks may run different numbers of iterations: it must not contain a collective.
-    dist_world, world = world, 1  # step() reads `world` from this scope: no all-reduce inside the ramp
+    dist_on, use_dist = use_dist, False  # step() reads `use_dist` from this scope: no all-reduce inside the ramp
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 1.5:
         step(False)
         torch.cuda.synchronize()
-    world = dist_world
+    use_dist = dist_on
     for _ in range(args.warmup):
         step(False)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -365,7 +372,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -397,7 +404,7 @@ def main():
         roofline.update(node_probe(dev))  # this node's own copy / read ceilings, after the timed region
     except Exception as e:  # a reported extra, never a reason to lose the main result
         roofline["node_probe_failed"] = f"{type(e).__name__}: {e}"
-    if world > 1:
+    if use_dist:
         # every rank's own launch against the roofline (rank order): the line's `roofline` is rank 0's
         mine = torch.tensor([achieved, dom_ms, roofline.get("node_copy_GBs", 0.0)], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -529,7 +536,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

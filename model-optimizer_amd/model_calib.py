@@ -994,10 +994,18 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 mdist.sync_amax_bucketed(chan, device=mods[0][1].weight.device)
         if state["gram_pass"] == "cache":
             finish_gram_pass()
-        with host_math_threads():
-            for h in helpers.values():
-                if h.num_cache_steps:
-                    h.act_scale = _host_div(h.act_sum, h.num_cache_steps)  # :1601, IEEE division (see get_scale)
+        cached = [h for h in helpers.values() if h.num_cache_steps]
+        if cached:
+            # act_scale = act_sum / steps (:1601) as IEEE division on the host (see get_scale) -- for ALL linears in one
+            # device -> host copy and one upload instead of a stream drain per linear
+            flat = torch.cat([h.act_sum.detach().float().reshape(-1) for h in cached]).cpu()
+            with host_math_threads():
+                steps = torch.cat([torch.full((h.act_sum.numel(),), float(h.num_cache_steps)) for h in cached])
+                flat = (flat / steps).to(cached[0].act_sum.device)
+            off = 0
+            for h in cached:
+                h.act_scale = flat[off:off + h.act_sum.numel()]
+                off += h.act_sum.numel()
         if mods:
             # DP: act_scale average + the any-NaN vote for ALL linears in ONE bucket (reference: one all_reduce and
             # one object gather per linear, :1588-1619); ranks whose shard never reached a linear join with zeros
