@@ -234,10 +234,26 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
-        if one_gpu_debug:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner to the C stdout when the communicator comes up; through a pipe it is block
+        # buffered and would surface at exit, AFTER the JSON line.  fd 1 points at stderr until the communicator exists
+        # and the C buffers are flushed, so that the one line on stdout is the result line.
+        import ctypes
+
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if one_gpu_debug:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)  # the first collective (lazy parts of the communicator, its banner)
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     moa = _moa_import.load()
     from model_optimizer_amd.multi_tensor import SegmentTable
@@ -534,10 +550,22 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
+    if use_dist:
+        # tear the communicator down with fd 1 on stderr as well (anything RCCL still has to say), THEN print: the result
+        # line is the last thing on rank 0's stdout
+        import ctypes
+
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.destroy_process_group()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -160,10 +160,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu_debug:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        import ctypes
+
+        sys.stdout.flush()
+        saved_fd = os.dup(1)  # RCCL's banner goes to the C stdout: keep it off the result line's stream (see bench.py)
+        os.dup2(2, 1)
+        try:
+            if one_gpu_debug:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+            ctypes.CDLL(None).fflush(None)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     moa = _moa_import.load()
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     line = run(moa, args.model, args.layers, args.batches, args.tokens, args.search, dev, rank, world,
