@@ -303,8 +303,9 @@ int moq_col_abs_mean_accum(const void* x, int64_t tokens, int64_t cols, int dt, 
  *   loss_acc[0] += (float) mean_{t,n} ( float(dtype(out[t, n] - out_actual[t, n])) ^ 2 )
  * which is update_loss() of the reference (quantization/model_calib.py:1489-1495) applied to the output of
  * the patched forward (:1552-1556); `out` itself is never written.  x = input * (1/awq_scale) [tokens, cin]
- * and w = QDQ(weight * awq_scale) [cout, cin] are row-major and 16-byte aligned; dt is MOQ_BF16 or MOQ_F16
- * (fp32 models: MOQ_ERR_UNSUPPORTED, the host uses the library GEMM).  cin % 8 == 0, cout % 4 == 0.
+ * and w = QDQ(weight * awq_scale) [cout, cin] are row-major and 16-byte aligned; dt is MOQ_BF16 / MOQ_F16 (16-bit
+ * matrix cores) or MOQ_F32 (fp32 models: v_mfma_f32_32x32x2_f32, every step in fp32 -- dtype() above is the identity;
+ * out_actual, bias and the operands are fp32).  cin % 8 == 0, cout % 4 == 0.
  * `partial`: fp32 workspace of moq_awq_err_gemm_workspace(tokens, cout) floats (per-tile sums, reduced in a
  * fixed order: the result is deterministic).  Not bit-identical to the reference's BLAS accumulation order;
  * tolerance stated in tests/test_gpu_parity.py. */
@@ -319,8 +320,8 @@ int moq_awq_err_gemm(const void* x, const void* w, const void* out_actual, const
 int moq_awq_err_gemm_multi(const void* x, const void* w, const void* out_actual, const void* bias,
                            int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
                            int64_t w_stride, float* partial, float* loss_acc, void* stream);
-/* The same MFMA main loop with a store epilogue: out[t, n] = dtype(sum_k x[t,k] * w[n,k] (+ bias[n])) --
- * torch.nn.functional.linear for the model dtype (used to check the contraction on its own). */
+/* The same MFMA main loops with a store epilogue: out[t, n] = dtype(sum_k x[t,k] * w[n,k] (+ bias[n])) --
+ * torch.nn.functional.linear for the model dtype, bf16 / f16 / f32 (used to check the contractions on their own). */
 int moq_gemm_nt(const void* x, const void* w, const void* bias, void* out, int64_t tokens, int64_t cout,
                 int64_t cin, int dt, void* stream);
 
@@ -411,7 +412,8 @@ int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int64_t i1, int
  * Used for trace(E G E^T) = <E G, E> of the AWQ Gram search: a = [E_hi | E_hi | E_lo] (bf16 [Cout, 3 Cin]),
  * b = [G_hi | G_lo | G_hi] (bf16 [Cin, 3 Cin]; G symmetric), ref = E -- the K-concatenation sums the three
  * split-precision products in the fp32 accumulators.  a, b: dt = MOQ_BF16 | MOQ_F16, 16-byte aligned, k % 8 == 0,
- * cols % 4 == 0.  partial: moq_awq_err_gemm_workspace(rows, cols) floats. */
+ * cols % 4 == 0; or dt = MOQ_F32 (fp32 models): a = E fp32 [Cout, Cin], b = G fp32 [Cin, Cin], k = Cin, on the fp32
+ * matrix cores.  partial: moq_awq_err_gemm_workspace(rows, cols) floats. */
 /* One candidate of the Gram search from one read of W [rows, cols]:  e_out = dt(QDQ_g(dt(w * s[c]))) * r[c] - w  (fp32)
  * and a_out = the `a` operand of moq_awq_quadform, bf16 [rows, planes * cols] with hi = bf16(e), lo = bf16(e - hi):
  * planes 3: [hi | hi | lo] (against b = [G_hi | G_lo | G_hi]), 2: [hi | lo] (b = [G_hi | G_hi]), 1: [hi] (b = [G_hi]).
