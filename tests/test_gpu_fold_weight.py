@@ -72,3 +72,43 @@ def test_fold_weight_keep_attrs():
         model_quant.fold_weight(model, keep_attrs=True)
     for lin, a in zip(model.linears, amax):
         assert not lin.weight_quantizer.is_enabled and torch.equal(lin.weight_quantizer._amax, a)
+
+
+@pytest.mark.parametrize("cfg_name", ["FP8_DEFAULT_CFG", "MXFP4_DEFAULT_CFG"])
+def test_fold_weight_is_idempotent_at_llama_layer_size(cfg_name):
+    """One Llama-3-8B decoder layer's seven weights (218 M elements) through the whole-model launches: a fake-quantized
+    weight is a fixed point of its own quantizer (same per-tensor amax / same block scales), so folding a second time with
+    re-enabled quantizers must change nothing -- a size-independent check where per-element oracles are too slow."""
+    h, i, kv = 4096, 14336, 1024
+    torch.manual_seed(2)
+
+    class Layer(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.linears = torch.nn.ModuleList(torch.nn.Linear(ci, co, bias=False, device=DEV, dtype=torch.bfloat16)
+                                               for co, ci in [(h, h), (kv, h), (kv, h), (h, h), (i, h), (i, h), (h, i)])
+
+        def forward(self, x):
+            return [lin(x[..., :lin.in_features]) for lin in self.linears]
+
+    model = Layer()
+    with torch.no_grad():
+        for lin in model.linears:
+            lin.weight.mul_(0.02 / lin.weight.std())
+        moa.quantize(model, copy.deepcopy(getattr(model_quant, cfg_name)),
+                     (lambda m: m(torch.randn(4, i, device=DEV, dtype=torch.bfloat16))) if cfg_name == "FP8_DEFAULT_CFG" else None)
+        amax = [getattr(lin.weight_quantizer, "_amax", None) for lin in model.linears]
+        amax = [a.clone() if a is not None else None for a in amax]
+        model_quant.fold_weight(model, keep_attrs=True)
+        once = [lin.weight.detach().clone() for lin in model.linears]
+        for lin in model.linears:
+            lin.weight_quantizer.enable()
+        model_quant.fold_weight(model, keep_attrs=True)
+    for lin, w, a in zip(model.linears, once, amax):
+        # value equality: the MX conversion maps a -0 it produced itself to +0 on the second pass (sign of an element
+        # that rounds to zero is kept, the sign of a zero INPUT is not: tensor_quant_mx.h's sign * magnitude form)
+        assert torch.equal(lin.weight.float(), w.float())
+        if cfg_name == "FP8_DEFAULT_CFG":
+            assert torch.equal(lin.weight.view(torch.int16), w.view(torch.int16))
+        if a is not None:
+            assert torch.equal(lin.weight_quantizer._amax, a)

@@ -240,3 +240,22 @@ def test_f32_quadform_on_the_fp32_matrix_cores(cout, cin):
     ops.awq_quadform(err.to(DEV), gram.to(DEV), acc, 1.0 / cout)
     want = ((err.double() @ gram.double()) * err.double()).sum().item() / cout
     assert abs(acc.item() - want) <= 2e-5 * abs(want), f"{acc.item()} vs {want}"
+
+
+def test_f32_gemm_full_size_scaling_property():
+    """4096 x 4096 x 4096 in fp32 (one calibration batch of an fp32 Llama-3-8B attention projection): scaling w by 2 and
+    out_actual by 2 scales every difference by exactly 2, so the fused loss must be exactly 4x; the stored product is
+    within the fp32 summation bound of the library's."""
+    torch.manual_seed(9)
+    t = n = k = 4096
+    x = torch.randn(t, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.02
+    ref = ops.gemm_nt(x, w * 1.03)
+    a1 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    a2 = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.awq_err_gemm(x, w, ref, None, a1)
+    ops.awq_err_gemm(x, w * 2.0, ref * 2.0, None, a2)
+    assert a2.item() == 4.0 * a1.item()
+    lib = torch.nn.functional.linear(x, w * 1.03)
+    bound = (k + 4) * 2.0 ** -23 * torch.nn.functional.linear(x.abs(), w.abs() * 1.03)
+    assert ((ref - lib).abs() <= bound).all()

@@ -230,3 +230,25 @@ def test_sparsegpt_hessian_shared_between_linears_with_the_same_input(dtype):
     assert set(results[0]) == {"q", "k", "v", "o"}
     for n in results[0]:
         assert torch.equal(results[0][n], results[1][n]), n
+
+
+def test_trailing_update_full_size_scaling_property():
+    """Llama-3-8B down_proj width at full size (4096 x 14336, first column block: 14208 columns updated) where the oracle's
+    scalar chain is too slow: scaling delta by 2 scales every product and every partial sum of the fma chain by exactly
+    2 (power-of-two scaling commutes with every fp32 rounding), so from w = 0 the result must be exactly twice as large;
+    and the columns left of the block must not be touched."""
+    torch.manual_seed(5)
+    rows, ld, bs = 4096, 14336, 128
+    delta = torch.randn(rows, bs, device=DEV) * 0.01
+    delta[torch.rand(rows, bs, device=DEV) < 0.5] = 0.0
+    hinv = torch.randn(ld, ld, device=DEV) * 0.05
+    w1 = torch.zeros(rows, ld, device=DEV)
+    w2 = torch.zeros(rows, ld, device=DEV)
+    ops.sgpt_trailing_update(w1, 0, delta, hinv)
+    ops.sgpt_trailing_update(w2, 0, delta * 2.0, hinv)
+    assert torch.equal(w2, w1 * 2.0)
+    assert not w1[:, :bs].any() and w1[:, bs:].abs().max() > 0
+    # and against the library's fp32 GEMM within the reordering bound of 128-term sums
+    want = -(delta @ hinv[:bs, bs:])
+    bound = 2 * 127 * 2.0 ** -24 * (delta.abs() @ hinv[:bs, bs:].abs()) + 1e-30
+    assert ((w1[:, bs:] - want).abs() <= bound).all()
