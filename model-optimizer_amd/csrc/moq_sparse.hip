@@ -92,22 +92,26 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
 
 // ---- trailing update: w[r, i2 + c] -= chain_{k < bs} fma(delta[r, k], hinv[i1 + k, i2 + c]), i2 = i1 + bs.
 //
-// One workgroup (4 waves) owns a 128 x 128 output tile; K is the whole column block (<= 128), so the operands are staged
-// ONCE: A = delta tile [128 r][128 k] (row pitch 129 words: the MFMA's A fragment reads 32 consecutive rows at one k --
-// an odd pitch spreads them over the banks), B = hinv tile [128 k][128 c] (lanes run along c).  Rows past `rows`, columns
-// past the matrix and k >= bs are filled with zeros: fma(0, 0, acc) = acc for every acc this chain can hold (it starts at
-// +0 and round-to-nearest never produces -0 from a sum that is not (-0) + (-0)).  Each wave multiplies a 64 x 64 quarter
-// as 2 x 2 tiles of 32 x 32: per k pair two A and two B words per lane from LDS, four MFMAs.  MFMA operand layout
-// (32x32x2): a = A[m = lane & 31][k = lane >> 5], b = B[k = lane >> 5][n = lane & 31]; accumulator register e of a lane
-// holds row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31 -- lanes run along the weight's columns, so the
-// read-modify-write of w is 128-byte runs.
+// One workgroup (4 waves) owns 128 rows and walks a strip of 64-column tiles.  K is the whole column block (<= 128), so
+// the delta tile [128 r][128 k] is staged ONCE per workgroup (row pitch 129 words: the MFMA's A fragment reads 32
+// consecutive rows at one k -- an odd pitch spreads them over the banks); the Hinv tiles [128 k][64 c] stream through two
+// LDS stages: while the 128 MFMAs of a column tile issue, the next tile's Hinv quads AND the next tile's weights (the read
+// half of w -= acc) are already on their way into registers -- requested before the loop, consumed after it.  Rows past
+// `rows`, columns past the matrix and k >= bs are zeros: fma(0, 0, acc) = acc for every acc this chain can hold (it starts
+// at +0 and round-to-nearest never produces -0 from a sum that is not (-0) + (-0)).  Wave v multiplies rows 32 v .. + 31 of
+// the tile against its 64 columns as two 32 x 32 tiles: per k pair one A and two B words per lane from LDS, two MFMAs.
+// MFMA operand layout (32x32x2): a = A[m = lane & 31][k = lane >> 5], b = B[k = lane >> 5][n = lane & 31]; accumulator
+// register e of a lane holds row 8 (e >> 2) + (e & 3) + 4 (lane >> 5), column lane & 31 -- lanes run along the weight's
+// columns, so the read-modify-write of w is 128-byte runs.
+// (First version, round 3: one 128 x 128 tile per workgroup, everything staged and waited for in turn -- 27 TFLOP/s; with
+// the loads batched 48, the library's fp32 matmul on the same updates: 47-50.)
 typedef float f32x16v __attribute__((ext_vector_type(16)));
-constexpr int kTuTile = 128, kTuPitchA = 129;
-constexpr size_t kTuLds = ((size_t)kTuTile * kTuPitchA + (size_t)kTuTile * kTuTile) * sizeof(float);
+constexpr int kTuRows = 128, kTuCols = 64, kTuK = 128, kTuPitchA = 129;
+constexpr size_t kTuLds = ((size_t)kTuRows * kTuPitchA + 2 * (size_t)kTuK * kTuCols) * sizeof(float);
 
 // one operand quad: a 16-byte load when the layout allows it (VEC), four words otherwise; elements that are not part of
 // the matrix (`n_valid` < 4, counted from the quad's first element) come back as zeros.  No branch: an invalid quad reads
-// a safe address and is masked, so the sixteen loads of a thread can all be in flight together.
+// a safe address and is masked, so all loads of a thread can be in flight together.
 template <bool VEC>
 __device__ __forceinline__ float4 tu_load_quad(const float* __restrict__ base, int64_t off, int n_valid) {
   const bool any = n_valid > 0;
@@ -132,97 +136,156 @@ __device__ __forceinline__ float4 tu_load_quad(const float* __restrict__ base, i
 template <bool VA, bool VB>
 __global__ __launch_bounds__(256) void sgpt_trailing_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
                                                             int bs, const float* __restrict__ delta,
-                                                            const float* __restrict__ hinv) {
+                                                            const float* __restrict__ hinv, int tiles_per_wg) {
   extern __shared__ __attribute__((aligned(16))) float tu_lds[];
   float* sa = tu_lds;                        // [128 r][129]
-  float* sb = tu_lds + kTuTile * kTuPitchA;  // [128 k][128 c]
+  float* sb = tu_lds + kTuRows * kTuPitchA;  // 2 x [128 k][64 c]
   const int64_t i2 = i1 + bs, ncols = ld - i2;
-  const int64_t r0 = (int64_t)blockIdx.y * kTuTile, c0 = (int64_t)blockIdx.x * kTuTile;
-  const int tid = threadIdx.x;
-  {
-    // thread t takes quad q = t & 31 of rows / k rows (t >> 5) + 8 i.  All 32 loads of a thread are issued before the
-    // first LDS write (a load per iteration, waited for at once, would put sixteen memory latencies in a row in front
-    // of a tile's 7 us of MFMAs)
-    const int q = tid & 31;
-    float4 va[kTuTile / 8], vb[kTuTile / 8];
+  const int64_t r0 = (int64_t)blockIdx.y * kTuRows;
+  const int64_t n_ctiles = (ncols + kTuCols - 1) / kTuCols;
+  const int64_t ct0 = (int64_t)blockIdx.x * tiles_per_wg;
+  const int steps = (int)(n_ctiles - ct0 < tiles_per_wg ? n_ctiles - ct0 : tiles_per_wg);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+
+  // Hinv tile of column tile `ct` -> registers: thread t takes quad q = t & 15 of k rows (t >> 4) + 16 i
+  float4 breg[kTuK / 16];
+  auto load_b = [&](int64_t ct) {
+    const int q = tid & 15;
+    const int64_t c = ct * kTuCols + 4 * q;
+    const int64_t left = ncols - c;
 #pragma unroll
-    for (int i = 0; i < kTuTile / 8; ++i) {
-      const int r = (tid >> 5) + 8 * i;
-      const int nv = r0 + r < rows ? bs - 4 * q : 0;  // valid words of the quad
-      va[i] = tu_load_quad<VA>(delta, (r0 + r) * bs + 4 * q, nv);
-    }
-#pragma unroll
-    for (int i = 0; i < kTuTile / 8; ++i) {
-      const int k = (tid >> 5) + 8 * i;
-      const int64_t left = ncols - (c0 + 4 * q);
+    for (int i = 0; i < kTuK / 16; ++i) {
+      const int k = (tid >> 4) + 16 * i;
       const int nv = k < bs ? (int)(left > 4 ? 4 : left) : 0;
-      vb[i] = tu_load_quad<VB>(hinv, (i1 + k) * ld + i2 + c0 + 4 * q, nv);
+      breg[i] = tu_load_quad<VB>(hinv, (i1 + k) * ld + i2 + c, nv);
+    }
+  };
+  auto store_b = [&](int stage) {
+    float* dst = sb + stage * (kTuK * kTuCols) + 4 * (tid & 15);
+#pragma unroll
+    for (int i = 0; i < kTuK / 16; ++i)
+      *reinterpret_cast<float4*>(dst + ((tid >> 4) + 16 * i) * kTuCols) = breg[i];
+  };
+  // the weights this lane will update in column tile `ct` (two accumulator tiles of 16).  Interior tiles take the
+  // unpredicated form -- a wave-uniform row base plus one 32-bit lane offset, 32 loads back to back; tiles on the
+  // matrix edge predicate every element.
+  float cur[2][16], nxt[2][16];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int64_t lane_off = (int64_t)(4 * h) * ld + m;
+  const bool rows_full = r0 + kTuRows <= rows;
+  auto load_w = [&](int64_t ct, float (&dst)[2][16]) {
+    const float* base = w + (r0 + wave_u * 32) * ld + i2 + ct * kTuCols;  // wave-uniform
+    if (rows_full && (ct + 1) * kTuCols <= ncols) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dst[j][e] = base[(int64_t)(8 * (e >> 2) + (e & 3)) * ld + j * 32 + lane_off];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int64_t c = ct * kTuCols + j * 32 + m;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t r = r0 + wave_u * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
+          dst[j][e] = (c < ncols && r < rows) ? w[r * ld + i2 + c] : 0.0f;
+        }
+      }
+    }
+  };
+  load_b(ct0);
+  load_w(ct0, cur);
+  {
+    // delta tile: thread t takes k quad q = t & 31 of rows (t >> 5) + 8 i; all sixteen loads before the first LDS write
+    const int q = tid & 31;
+    float4 va[kTuRows / 8];
+#pragma unroll
+    for (int i = 0; i < kTuRows / 8; ++i) {
+      const int r = (tid >> 5) + 8 * i;
+      const int nv = r0 + r < rows ? bs - 4 * q : 0;
+      va[i] = tu_load_quad<VA>(delta, (r0 + r) * bs + 4 * q, nv);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < kTuTile / 8; ++i) {
+    for (int i = 0; i < kTuRows / 8; ++i) {
       float* dst = sa + ((tid >> 5) + 8 * i) * kTuPitchA + 4 * q;
       dst[0] = va[i].x; dst[1] = va[i].y; dst[2] = va[i].z; dst[3] = va[i].w;
     }
-#pragma unroll
-    for (int i = 0; i < kTuTile / 8; ++i)
-      *reinterpret_cast<float4*>(sb + ((tid >> 5) + 8 * i) * kTuTile + 4 * q) = vb[i];
   }
+  store_b(0);
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;  // the wave's 64 x 64 quarter
-  const int m = lane & 31, h = lane >> 5;
-  f32x16v acc[2][2];
+
+  const float* pa = sa + (wave_u * 32 + m) * kTuPitchA + h;
+  const int kpairs = (bs + 1) / 2;
+  for (int s = 0; s < steps; ++s) {
+    const int64_t ct = ct0 + s;
+    const bool more = s + 1 < steps;
+    if (more) {  // (wave-uniform) the next column tile's operands and weights: requested now, used after the MFMAs
+      load_b(ct + 1);
+      load_w(ct + 1, nxt);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16v acc0, acc1;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+    const float* pb = sb + (s & 1) * (kTuK * kTuCols) + h * kTuCols + m;
+    // The operands of k pair j + 2 are requested while the MFMAs of pair j issue: an LDS round trip (~130 cycles) is
+    // longer than one pair's two MFMAs (128), so a distance of one pair still exposed it every iteration.  Four register
+    // slots, the loop body unrolled four times; pairs past the column block read zero rows (the tile is padded to 128 k).
+    float ra[4], rb0[4], rb1[4];
+    auto rd = [&](int slot, int jj) {
+      const int j2 = jj < kTuK / 2 ? jj : kTuK / 2 - 1;
+      ra[slot] = pa[2 * j2];
+      rb0[slot] = pb[2 * j2 * kTuCols];
+      rb1[slot] = pb[2 * j2 * kTuCols + 32];
+    };
+    rd(0, 0);
+    rd(1, 1);
+    for (int j = 0; j < kpairs; j += 4) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  // The read half of the weight tile's read-modify-write is requested HERE, before the MFMA loop: 64 loads per lane
-  // that do not depend on the contraction ride under its ~7 us instead of standing behind it.
-  float cur[2][2][16];
-  float* ptr[2][2][16];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t c = c0 + wc * 64 + j * 32 + m;
-      const bool c_ok = c < ncols;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t r = r0 + wr * 64 + i * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
-        ptr[i][j][e] = (c_ok && r < rows) ? w + r * ld + i2 + c : nullptr;
-        cur[i][j][e] = *(ptr[i][j][e] ? ptr[i][j][e] : w);
+      for (int u = 0; u < 4; ++u) {
+        rd((u + 2) & 3, j + u + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u], rb0[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[u], rb1[u], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-  __builtin_amdgcn_sched_barrier(0);
-  const float* pa = sa + (wr * 64 + m) * kTuPitchA + h;
-  const float* pb = sb + h * kTuTile + wc * 64 + m;
-  const int kpairs = (bs + 1) / 2;
-  // the operands of k pair j + 1 are read while the four MFMAs of pair j issue (64 cycles each: an LDS round trip
-  // hides under one pair); the pad rows / columns behind the last pair are zeros, so reading one pair too far is safe
-  float a0 = pa[0], a1 = pa[32 * kTuPitchA], b0 = pb[0], b1 = pb[32];
-  for (int j = 0; j < kpairs; ++j) {
-    const int jn = j + 1 < kTuTile / 2 ? j + 1 : j;
-    const float a0n = pa[2 * jn], a1n = pa[32 * kTuPitchA + 2 * jn];
-    const float b0n = pb[2 * jn * kTuTile], b1n = pb[2 * jn * kTuTile + 32];
+    // w -= acc for this column tile
+    {
+      float* base = w + (r0 + wave_u * 32) * ld + i2 + ct * kTuCols;
+      if (rows_full && (ct + 1) * kTuCols <= ncols) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          base[(int64_t)(8 * (e >> 2) + (e & 3)) * ld + lane_off] = cur[0][e] - acc0[e];
+          base[(int64_t)(8 * (e >> 2) + (e & 3)) * ld + 32 + lane_off] = cur[1][e] - acc1[e];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int64_t c = ct * kTuCols + j * 32 + m;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t r = r0 + wave_u * 32 + 8 * (e >> 2) + (e & 3) + 4 * h;
+            if (c < ncols && r < rows) w[r * ld + i2 + c] = cur[j][e] - (j == 0 ? acc0[e] : acc1[e]);
+          }
+        }
+      }
+    }
+    if (more) {
+      store_b((s + 1) & 1);  // the stage the tile before this one was read from (everyone passed the last barrier)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cur[j][e] = nxt[j][e];
+    }
+    // workgroup barrier on LDS traffic ONLY: __syncthreads() would also wait (vmcnt(0)) for this tile's 32 weight stores
+    // per lane to reach memory -- microseconds per column tile, with nothing depending on them
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    asm volatile("s_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
   }
-  // the weight tile comes back: w -= acc (the loads went out before the MFMA loop)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e)
-        if (ptr[i][j][e]) *ptr[i][j][e] = cur[i][j][e] - acc[i][j][e];
 }
 
 // y[c, r] = x[r, c] for 16-bit elements through a 64 x 64 LDS tile (+1 column of padding: conflict-free columns)
@@ -277,13 +340,19 @@ extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int6
     set_error("moq_sgpt_trailing_update: bad arguments");
     return MOQ_ERR_INVALID;
   }
-  if (bs > kTuTile) {
-    set_error("moq_sgpt_trailing_update: column block of %d > %d", bs, kTuTile);
+  if (bs > kTuK) {
+    set_error("moq_sgpt_trailing_update: column block of %d > %d", bs, kTuK);
     return MOQ_ERR_UNSUPPORTED;
   }
   const int64_t ncols = ld - (i1 + bs);
   if (rows == 0 || ncols == 0) return MOQ_OK;
-  const int64_t gx = (ncols + kTuTile - 1) / kTuTile, gy = (rows + kTuTile - 1) / kTuTile;
+  const int64_t n_ctiles = (ncols + kTuCols - 1) / kTuCols, gy = (rows + kTuRows - 1) / kTuRows;
+  // column tiles per workgroup: long strips amortise the delta tile and keep the pipeline full, but the grid should
+  // still cover the chip about twice
+  // (rounded UP: 576 workgroups on 256 CUs run as three rounds with the last one a quarter full -- 512 as two)
+  int64_t per_wg = (n_ctiles * gy + 511) / 512;
+  per_wg = per_wg < 1 ? 1 : (per_wg > 32 ? 32 : per_wg);
+  const int64_t gx = (n_ctiles + per_wg - 1) / per_wg;
   if (gy > 65535 || gx > 0x7FFFFFFF) {
     set_error("moq_sgpt_trailing_update: matrix too large");
     return MOQ_ERR_UNSUPPORTED;
@@ -302,10 +371,11 @@ extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int6
   const bool va = bs % 4 == 0 && (reinterpret_cast<uintptr_t>(delta) & 15u) == 0;
   const bool vb = ld % 4 == 0 && (i1 + bs) % 4 == 0 && (reinterpret_cast<uintptr_t>(hinv) & 15u) == 0;
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
-  if (va && vb) hipLaunchKernelGGL((sgpt_trailing_kernel<true, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
-  else if (va) hipLaunchKernelGGL((sgpt_trailing_kernel<true, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
-  else if (vb) hipLaunchKernelGGL((sgpt_trailing_kernel<false, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
-  else hipLaunchKernelGGL((sgpt_trailing_kernel<false, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv);
+  const int pw = (int)per_wg;
+  if (va && vb) hipLaunchKernelGGL((sgpt_trailing_kernel<true, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv, pw);
+  else if (va) hipLaunchKernelGGL((sgpt_trailing_kernel<true, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv, pw);
+  else if (vb) hipLaunchKernelGGL((sgpt_trailing_kernel<false, true>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv, pw);
+  else hipLaunchKernelGGL((sgpt_trailing_kernel<false, false>), grid, block, kTuLds, S(stream), w, rows, ld, i1, bs, delta, hinv, pw);
   return check_launch("moq_sgpt_trailing_update");
 }
 
