@@ -1,5 +1,7 @@
 // moq_formats.hip -- MX dynamic-block QDQ, histogram, 2:4 mask, real INT4 pack/unpack, export packer and
 // the column-scale fold.  All HBM-bound streaming kernels with 16-byte lane accesses.
+#include <type_traits>
+
 #include "moq_common.h"
 #include "moq_chunk.h"
 #include "moq_hist.h"
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(kBlock) void int4_pack_kernel(const void* __restric
     const int64_t e0 = c * MOQ_MT_CHUNK;
     if constexpr (FASTL) {
       gi.seek(e0);
+      // (the branch-free full-chunk body of int4_unpack_kernel measured 4 % SLOWER here: 0.716 -> 0.685 of the roofline)
       Pack16 in[P];
       float sc[P];
 #pragma unroll
@@ -454,20 +457,25 @@ __global__ __launch_bounds__(kBlock) void int4_unpack_kernel(const uint8_t* __re
     for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
       const int64_t e0 = c * MOQ_MT_CHUNK;
       gi.seek(e0);
+      // a chunk inside the tensor runs a copy of the body without per-packet bounds branches (with them hipcc waits
+      // for every load on its own: one packet in flight per lane instead of the chunk's P)
+      auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
       uint32_t wv[P];
       float sc[P];
 #pragma unroll
       for (int u = 0; u < P; ++u) {
         const int64_t e = e0 + packet_off<DT>(u);
-        if (e < n) {
+        if (full || e < n) {
           wv[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q + e / 2));
           sc[u] = load1<DT>(scales, gi.at((uint32_t)packet_off<DT>(u)));
         }
       }
+      if constexpr (full) __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first use
 #pragma unroll
       for (int u = 0; u < P; ++u) {
         const int64_t e = e0 + packet_off<DT>(u);
-        if (e >= n) continue;
+        if (!full && e >= n) continue;
         float v[8];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -478,6 +486,9 @@ __global__ __launch_bounds__(kBlock) void int4_unpack_kernel(const uint8_t* __re
         }
         store16_nt(reinterpret_cast<char*>(out) + e * 2, pack<DT>(v));
       }
+      };
+      if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+      else body(std::false_type{});
     }
   } else {
     const int64_t n_words = (n_bytes + 3) / 4;
@@ -592,34 +603,55 @@ __global__ __launch_bounds__(kBlock) void scale_cols_kernel(const void* __restri
   const int64_t n = rows * cols;
   if constexpr (FASTL) {
     const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+    // column of packet u = (col0 + toff[u]) mod cols with col0 = e0 mod cols (uniform, once per chunk) and
+    // toff[u] = packet_off(u) mod cols (once per thread): both below cols, so one conditional subtraction wraps
+    int64_t toff[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) toff[u] = (int64_t)packet_off<DT>(u) % cols;
     for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
       const int64_t e0 = c * MOQ_MT_CHUNK;
       const int64_t col0 = e0 % cols;  // uniform
-      Pack16 in[P];
+      // a chunk inside the tensor runs a copy of the body without per-packet bounds branches (with them hipcc waits for
+      // every load on its own); the scale vectors of all packets are requested together with the data
+      auto body = [&](auto FULL) {
+        constexpr bool full = decltype(FULL)::value;
+        Pack16 in[P];
+        float4 m[P][V / 4], d[P][V / 4];
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int64_t e = e0 + packet_off<DT>(u);
-        if (e < n) in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
-      }
+        for (int u = 0; u < P; ++u) {
+          const int64_t e = e0 + packet_off<DT>(u);
+          if (full || e < n) {
+            in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
+            int64_t col = col0 + toff[u];
+            col = col >= cols ? col - cols : col;
 #pragma unroll
-      for (int u = 0; u < P; ++u) {
-        const int64_t e = e0 + packet_off<DT>(u);
-        if (e >= n) continue;
-        int64_t col = col0 + packet_off<DT>(u);
-        if (col >= cols) col %= cols;
-        float v[8];
-        unpack<DT>(in[u], v);
-#pragma unroll
-        for (int i = 0; i < V; i += 4) {
-          const float4 m = *reinterpret_cast<const float4*>(mul + col + i);
-          v[i] *= m.x; v[i + 1] *= m.y; v[i + 2] *= m.z; v[i + 3] *= m.w;
-          if constexpr (MODE == 1) {
-            const float4 d = *reinterpret_cast<const float4*>(div + col + i);
-            v[i] /= d.x; v[i + 1] /= d.y; v[i + 2] /= d.z; v[i + 3] /= d.w;
+            for (int i = 0; i < V / 4; ++i) {
+              m[u][i] = *reinterpret_cast<const float4*>(mul + col + 4 * i);
+              if constexpr (MODE == 1) d[u][i] = *reinterpret_cast<const float4*>(div + col + 4 * i);
+            }
           }
         }
-        store16_nt(reinterpret_cast<char*>(y) + e * (16 / V), pack<DT>(v));
-      }
+        if constexpr (full) __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first use
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int64_t e = e0 + packet_off<DT>(u);
+          if (!full && e >= n) continue;
+          float v[8];
+          unpack<DT>(in[u], v);
+#pragma unroll
+          for (int i = 0; i < V; i += 4) {
+            const float4 mm = m[u][i / 4];
+            v[i] *= mm.x; v[i + 1] *= mm.y; v[i + 2] *= mm.z; v[i + 3] *= mm.w;
+            if constexpr (MODE == 1) {
+              const float4 dd = d[u][i / 4];
+              v[i] /= dd.x; v[i + 1] /= dd.y; v[i + 2] /= dd.z; v[i + 3] /= dd.w;
+            }
+          }
+          store16_nt(reinterpret_cast<char*>(y) + e * (16 / V), pack<DT>(v));
+        }
+      };
+      if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+      else body(std::false_type{});
     }
   } else {
     for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += (int64_t)gridDim.x * kBlock) {

@@ -85,10 +85,12 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   auto load_chunk = [&](int64_t c, Pack16 (&in)[P]) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     const bool fast = al && e0 + MOQ_MT_CHUNK <= p.n;
+    if (fast) {  // one branch per chunk, not per packet: the P loads go out back to back
 #pragma unroll
-    for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + (u * kBlock + tid) * V;
-      in[u] = fast ? ld_packet<DT, true>(p.x, e, p.n) : ld_packet<DT, false>(p.x, e, p.n);
+      for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, true>(p.x, e0 + (u * kBlock + tid) * V, p.n);
+    } else {
+#pragma unroll
+      for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, false>(p.x, e0 + (u * kBlock + tid) * V, p.n);
     }
   };
   Pack16 buf_a[P], buf_b[P];

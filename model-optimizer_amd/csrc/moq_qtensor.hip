@@ -4,6 +4,8 @@
 // HBM-bound streaming kernels on the chunk skeleton (moq_chunk.h): 16-byte lane loads, all packets of a chunk in
 // flight, non-temporal loads / stores.  Algorithmic bytes per element (bf16): FP8 pack 2 + 1, unpack 1 + 2;
 // MXFP4 pack 2 + 0.5 + 1/32, unpack 0.5 + 1/32 + 2.
+#include <type_traits>
+
 #include "moq_common.h"
 #include "moq_chunk.h"
 
@@ -46,13 +48,17 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     if (AXIS) gi.seek(e0);
+    // a chunk inside the tensor runs a copy of the body without per-packet bounds branches: with them hipcc waits for
+    // every load on its own (one 16-byte load in flight per lane instead of the chunk's P)
+    auto body = [&](auto FULL) {
+    constexpr bool full = decltype(FULL)::value;
     Pack16 in[P];
     float sc[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
       sc[u] = s0;
-      if (e < n) {
+      if (full || e < n) {
         in[u] = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
         if (AXIS) {
           int64_t row = gi.at((uint32_t)packet_off<DT>(u));
@@ -61,10 +67,11 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
         }
       }
     }
+      if constexpr (full) __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first use
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
-      if (e >= n) continue;
+      if (!full && e >= n) continue;
       float v[8];
       unpack<DT>(in[u], v);
       uint32_t b[4] = {0, 0, 0, 0};
@@ -78,6 +85,9 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
       if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
       else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
     }
+    };
+    if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 template <int DT, bool AXIS>
@@ -95,13 +105,15 @@ __global__ __launch_bounds__(kBlock) void fp8_unpack_kernel(const uint8_t* __res
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
     if (AXIS) gi.seek(e0);
+    auto body = [&](auto FULL) {  // (see fp8_pack_kernel)
+    constexpr bool full = decltype(FULL)::value;
     uint32_t in[P][2];
     float sc[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
       sc[u] = s0;
-      if (e < n) {
+      if (full || e < n) {
         if constexpr (V == 8) {
           typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(q + e));
@@ -118,10 +130,11 @@ __global__ __launch_bounds__(kBlock) void fp8_unpack_kernel(const uint8_t* __res
         }
       }
     }
+      if constexpr (full) __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first use
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
-      if (e >= n) continue;
+      if (!full && e >= n) continue;
       float v[8];
 #pragma unroll
       for (int i = 0; i < V; ++i) {
@@ -137,6 +150,9 @@ __global__ __launch_bounds__(kBlock) void fp8_unpack_kernel(const uint8_t* __res
       }
       store16_nt(reinterpret_cast<char*>(out) + e * (16 / V), pack<DT>(v));
     }
+    };
+    if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
@@ -291,70 +307,111 @@ __global__ __launch_bounds__(kBlock) void mxfp4_unpack_kernel(const uint8_t* __r
 // elementwise.  Here a packet (V elements of one row, inside one tile because bc % V == 0) looks its tile's scale up.
 // PROMOTE: scales are fp32 while the tensor is 16-bit -> torch promotes the quotient to fp32 (dimensioned operand),
 // so it is NOT rounded to the tensor dtype before the e4m3 cast; with scales of the tensor dtype it is.
+// Indexing: blockIdx.y walks groups of kTileRows consecutive rows, blockIdx.x * kBlock + thread = packet column.  A lane
+// keeps kTileRows packets (one per row of the group, same columns) in flight; no division per packet except the
+// 32-bit col / bc (a shift when bc is a power of two), the row tile is workgroup-uniform.  (The first form -- a flat
+// packet index split with three 64-bit divisions per packet -- was VALU-bound: 0.47 of the HBM roofline.)
+constexpr int kTileRows = 4;
 template <int DT, bool PROMOTE>
 __global__ __launch_bounds__(kBlock) void fp8_pack_tile_kernel(const void* __restrict__ x,
                                                                const void* __restrict__ scales,
-                                                               uint8_t* __restrict__ out, int64_t n_packets,
-                                                               int64_t cols, int br, int bc, int64_t tiles_per_row) {
+                                                               uint8_t* __restrict__ out, int64_t rows,
+                                                               int64_t cols, int br, int bc, int bc_shift,
+                                                               int64_t tiles_per_row) {
   constexpr int V = Elem<DT>::kVec;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    const int64_t row = e / cols;
-    const int64_t col = e - row * cols;
-    const int64_t t = (row / br) * tiles_per_row + col / bc;
-    const float sc = PROMOTE ? reinterpret_cast<const float*>(scales)[t] : load1<DT>(scales, t);
-    const Pack16 in = load16_nt(reinterpret_cast<const char*>(x) + e * (16 / V));
-    float v[8];
-    unpack<DT>(in, v);
-    uint32_t b[4] = {0, 0, 0, 0};
+  const uint32_t col = (blockIdx.x * kBlock + threadIdx.x) * V;
+  if (col >= cols) return;
+  const uint32_t tc = bc_shift >= 0 ? col >> bc_shift : col / (uint32_t)bc;
+  auto ld_scale = [&](int64_t t) { return PROMOTE ? reinterpret_cast<const float*>(scales)[t] : load1<DT>(scales, t); };
+  for (int64_t r0 = (int64_t)blockIdx.y * kTileRows; r0 < rows; r0 += (int64_t)gridDim.y * kTileRows) {
+    auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
+      Pack16 in[kTileRows];
+      float sc[kTileRows];
 #pragma unroll
-    for (int i = 0; i < V; i += 2) {
-      float qa = v[i] / sc, qb = v[i + 1] / sc;
-      if constexpr (!PROMOTE) {
-        qa = round_to_dtype<DT>(qa);
-        qb = round_to_dtype<DT>(qb);
+      for (int k = 0; k < kTileRows; ++k) {
+        if (full || r0 + k < rows) {
+          in[k] = load16_nt(reinterpret_cast<const char*>(x) + ((r0 + k) * cols + col) * (16 / V));
+          sc[k] = ld_scale((int64_t)((uint32_t)(r0 + k) / (uint32_t)br) * tiles_per_row + tc);  // rows < 2^31 (host-checked)
+        }
       }
-      b[i / 2] = e4m3fn_bytes2(qa, qb);
-    }
-    if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-    else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
+#pragma unroll
+      for (int k = 0; k < kTileRows; ++k) {
+        if (!full && r0 + k >= rows) continue;
+        float v[8];
+        unpack<DT>(in[k], v);
+        uint32_t b[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < V; i += 2) {
+          float qa = v[i] / sc[k], qb = v[i + 1] / sc[k];
+          if constexpr (!PROMOTE) {
+            qa = round_to_dtype<DT>(qa);
+            qb = round_to_dtype<DT>(qb);
+          }
+          b[i / 2] = e4m3fn_bytes2(qa, qb);
+        }
+        uint8_t* o = out + (r0 + k) * cols + col;
+        if constexpr (V == 8) q_store8_nt(o, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(o));
+      }
+    };
+    if (r0 + kTileRows <= rows) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
 template <int DT>
 __global__ __launch_bounds__(kBlock) void fp8_unpack_tile_kernel(const uint8_t* __restrict__ q,
                                                                  const void* __restrict__ scales,
-                                                                 void* __restrict__ out, int64_t n_packets,
-                                                                 int64_t cols, int br, int bc, int64_t tiles_per_row) {
+                                                                 void* __restrict__ out, int64_t rows,
+                                                                 int64_t cols, int br, int bc, int bc_shift,
+                                                                 int64_t tiles_per_row) {
   constexpr int V = Elem<DT>::kVec;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    const int64_t row = e / cols;
-    const int64_t col = e - row * cols;
-    const float sc = load1<DT>(scales, (row / br) * tiles_per_row + col / bc);
-    uint32_t in[2] = {0, 0};
-    if constexpr (V == 8) {
-      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-      const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(q + e));
-      in[0] = t.x;
-      in[1] = t.y;
-    } else {
-      in[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(q + e));
-    }
-    float v[8];
+  const uint32_t col = (blockIdx.x * kBlock + threadIdx.x) * V;
+  if (col >= cols) return;
+  const uint32_t tc = bc_shift >= 0 ? col >> bc_shift : col / (uint32_t)bc;
+  for (int64_t r0 = (int64_t)blockIdx.y * kTileRows; r0 < rows; r0 += (int64_t)gridDim.y * kTileRows) {
+    auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
+      uint32_t in[kTileRows][2];
+      float sc[kTileRows];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const int word = (int)in[i / 4];
-      float f;
-      switch (i & 3) {
-        case 0: f = __builtin_amdgcn_cvt_f32_fp8(word, 0); break;
-        case 1: f = __builtin_amdgcn_cvt_f32_fp8(word, 1); break;
-        case 2: f = __builtin_amdgcn_cvt_f32_fp8(word, 2); break;
-        default: f = __builtin_amdgcn_cvt_f32_fp8(word, 3); break;
+      for (int k = 0; k < kTileRows; ++k) {
+        if (full || r0 + k < rows) {
+          const uint8_t* src = q + (r0 + k) * cols + col;
+          if constexpr (V == 8) {
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(src));
+            in[k][0] = t.x;
+            in[k][1] = t.y;
+          } else {
+            in[k][0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src));
+            in[k][1] = 0;
+          }
+          sc[k] = load1<DT>(scales, (int64_t)((uint32_t)(r0 + k) / (uint32_t)br) * tiles_per_row + tc);
+        }
       }
-      v[i] = f * sc;
-    }
-    store16_nt(reinterpret_cast<char*>(out) + e * (16 / V), pack<DT>(v));
+#pragma unroll
+      for (int k = 0; k < kTileRows; ++k) {
+        if (!full && r0 + k >= rows) continue;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const int word = (int)in[k][i / 4];
+          float f;
+          switch (i & 3) {
+            case 0: f = __builtin_amdgcn_cvt_f32_fp8(word, 0); break;
+            case 1: f = __builtin_amdgcn_cvt_f32_fp8(word, 1); break;
+            case 2: f = __builtin_amdgcn_cvt_f32_fp8(word, 2); break;
+            default: f = __builtin_amdgcn_cvt_f32_fp8(word, 3); break;
+          }
+          v[i] = f * sc[k];
+        }
+        store16_nt(reinterpret_cast<char*>(out) + ((r0 + k) * cols + col) * (16 / V), pack<DT>(v));
+      }
+    };
+    if (r0 + kTileRows <= rows) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
@@ -572,6 +629,14 @@ extern "C" int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void
   return check_launch("moq_mxfp4_unpack");
 }
 
+// x: packet columns of a row in workgroups of kBlock lanes; y: groups of kTileRows rows (grid-strided past 65535)
+static dim3 tile_grid(int64_t rows, int64_t cols, int vec) {
+  const int64_t gx = (cols / vec + kBlock - 1) / kBlock;
+  int64_t gy = (rows + kTileRows - 1) / kTileRows;
+  if (gy > 65535) gy = 65535;
+  return dim3((unsigned)gx, (unsigned)gy);
+}
+
 static int fp8_tile_args_ok(const char* who, const void* a, const void* b, const void* c, int64_t rows, int64_t cols,
                             int br, int bc, int dt) {
   if (rows < 0 || cols < 0 || br <= 0 || bc <= 0 || (rows * cols > 0 && (a == nullptr || b == nullptr || c == nullptr))) {
@@ -607,14 +672,17 @@ extern "C" int moq_fp8_pack_tile(const void* x, const void* scales, int scale_dt
     }
     return check_launch("moq_fp8_pack_tile");
   }
-  const int64_t n_packets = rows * cols / vec;
-  const int grid = stream_grid(kBlock, n_packets);
+  if (cols / vec > 0x7FFFFFFF / kBlock || rows > 0x7FFFFFFF) {
+    set_error("moq_fp8_pack_tile: more than 2^31 rows or packets per row are not supported");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const dim3 grid = tile_grid(rows, cols, vec);
   if (promote) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
-                                              scales, out, n_packets, cols, br, bc, cols / bc));
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, true>), grid, dim3(kBlock), 0, S(stream), x,
+                                              scales, out, rows, cols, br, bc, log2_or_neg(bc), cols / bc));
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
-                                              scales, out, n_packets, cols, br, bc, cols / bc));
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_tile_kernel<DT, false>), grid, dim3(kBlock), 0, S(stream), x,
+                                              scales, out, rows, cols, br, bc, log2_or_neg(bc), cols / bc));
   }
   return check_launch("moq_fp8_pack_tile");
 }
@@ -630,8 +698,11 @@ extern "C" int moq_fp8_unpack_tile(const uint8_t* q, const void* scales, void* o
                                               S(stream), q, scales, out, n, cols, br, bc, cols / bc));
     return check_launch("moq_fp8_unpack_tile");
   }
-  const int64_t n_packets = rows * cols / vec;
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_tile_kernel<DT>), dim3(stream_grid(kBlock, n_packets)), dim3(kBlock), 0,
-                                            S(stream), q, scales, out, n_packets, cols, br, bc, cols / bc));
+  if (cols / vec > 0x7FFFFFFF / kBlock || rows > 0x7FFFFFFF) {
+    set_error("moq_fp8_unpack_tile: more than 2^31 rows or packets per row are not supported");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_tile_kernel<DT>), tile_grid(rows, cols, vec), dim3(kBlock), 0,
+                                            S(stream), q, scales, out, rows, cols, br, bc, log2_or_neg(bc), cols / bc));
   return check_launch("moq_fp8_unpack_tile");
 }
