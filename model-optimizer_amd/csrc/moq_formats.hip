@@ -45,41 +45,37 @@ __host__ __device__ inline MxFmt mx_fmt(int t) {
   }
 }
 __device__ __forceinline__ float mx_round_abs(float a, const MxFmt f) {
-  // a >= 0 (may be inf / NaN)
-  if (f.kind == 2) {  // convert_int8_saturating (h:74-84)
+  // a >= 0 (may be inf / NaN).  Both segments are evaluated and one is selected: no data-dependent branch (a divergent
+  // branch per element costs more than the dozen VALU instructions of the segment not taken).
+  if (f.kind == 2) {  // convert_int8_saturating (h:74-84); the format is workgroup-uniform
     float r = __builtin_rintf(a);
     return r > 127.0f ? 127.0f : r;
   }
-  if (a != a) return f.kind == 1 ? a : f.maxv;
-  float q;
   const float min_normal = __builtin_ldexpf(1.0f, f.emin);
-  if (a >= min_normal) {
-    const int shift = 23 - f.m;
-    uint32_t u = __float_as_uint(a);
-    if (u >= 0x7F800000u) return f.maxv;  // inf saturates
-    const uint32_t half = 1u << (shift - 1);
-    u += f.half_up ? half : (half - 1u + ((u >> shift) & 1u));
-    u &= ~((1u << shift) - 1u);
-    q = __uint_as_float(u);
-  } else {
-    const float inv_quantum = __builtin_ldexpf(1.0f, f.m - f.emin), quantum = __builtin_ldexpf(1.0f, f.emin - f.m);
-    const float t = a * inv_quantum;  // exact (power of two)
-    q = (f.half_up ? __builtin_floorf(t + 0.5f) : __builtin_rintf(t)) * quantum;
-  }
-  return q > f.maxv ? f.maxv : q;
+  // normal range: mantissa rounded with integer ops.  inf stays inf here (and saturates below); a carry out of the
+  // largest finite exponent gives inf, which saturates too
+  const int shift = 23 - f.m;
+  uint32_t u = __float_as_uint(a);
+  const uint32_t half = 1u << (shift - 1);
+  u += f.half_up ? half : (half - 1u + ((u >> shift) & 1u));
+  u &= ~((1u << shift) - 1u);
+  const float qn = __uint_as_float(u);
+  // below 2^emin: fixed quantum
+  const float inv_quantum = __builtin_ldexpf(1.0f, f.m - f.emin), quantum = __builtin_ldexpf(1.0f, f.emin - f.m);
+  const float t = a * inv_quantum;  // exact (power of two)
+  const float qs = (f.half_up ? __builtin_floorf(t + 0.5f) : __builtin_rintf(t)) * quantum;
+  float q = a >= min_normal ? qn : qs;
+  q = q > f.maxv ? f.maxv : q;
+  return a != a ? (f.kind == 1 ? a : f.maxv) : q;  // NaN: stays NaN for the fp8 kinds, saturates for the table kinds
 }
 // compute_scale_e8m0_NV (tensor_quant_mx.cu:105-137): unscale = 2^ceil(log2(amax / fmt_max))
 __device__ __forceinline__ void mx_scale_e8m0(float amax, float fmt_max, float& scale, float& unscale) {
-  if (amax == 0.0f || amax != amax || __float_as_uint(amax) == 0x7F800000u) {  // cu:143-145
-    scale = 1.0f;
-    unscale = 1.0f;
-    return;
-  }
+  const bool bad = amax == 0.0f || amax != amax || __float_as_uint(amax) == 0x7F800000u;  // cu:143-145: scale 1
   const float ratio = amax / fmt_max;
   const uint32_t u = __float_as_uint(ratio), ef = (u >> 23) & 0xFFu, mf = u & 0x7FFFFFu;
   const int ue = (mf > 0 && ef != 0xFE && !(ef == 0 && mf <= 0x400000u)) ? (int)ef - 126 : (int)ef - 127;
-  scale = __builtin_ldexpf(1.0f, -ue);
-  unscale = __builtin_ldexpf(1.0f, ue);
+  scale = bad ? 1.0f : __builtin_ldexpf(1.0f, -ue);
+  unscale = bad ? 1.0f : __builtin_ldexpf(1.0f, ue);
 }
 __device__ __forceinline__ float mx_qdq(float x, float scale, float unscale, const MxFmt f) {
   // quantize() (cu:36-55); the reference leaves `sign` uninitialised for 0 / NaN inputs -- taken as 0
@@ -92,64 +88,6 @@ __device__ __forceinline__ float mx_abs_clamped(float x) {
   return a > 3.402823466e+38f ? 3.402823466e+38f : a;
 }
 
-// fast path: cols % block == 0, block % kVec == 0 -> an MX block is LPG adjacent lanes of one packet.
-// Chunk skeleton: all packets of a chunk in flight before the first use, non-temporal loads and stores, dense
-// strided grid.  FMT >= 0 fixes the element format at compile time (E2M1 / E4M3: the MXFP4 / MXFP8 presets) so
-// that the rounding constants fold; FMT < 0 reads it from `fmt`.
-template <int DT, int LPG>
-__device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f) {
-  constexpr int V = Elem<DT>::kVec;
-  constexpr int P = Chunk<DT>::kPackets;
-  constexpr int ES = 16 / V;
-  Pack16 in[P];
-  // n is a multiple of the block (= LPG * V elements), so a group is entirely live or entirely past the end
-#pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
-    if (e < n) in[u] = load16_nt(xb + e * ES);
-    else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
-  }
-#pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
-    float v[8];
-    unpack<DT>(in[u], v);
-    float am = 0.0f;
-#pragma unroll
-    for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
-    // non-negative floats order like their bit patterns
-    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
-    float sc, un;
-    mx_scale_e8m0(am, f.maxv, sc, un);
-#pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
-    if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
-  }
-}
-template <int DT, int LPG, int FMT>
-__global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, void* __restrict__ y,
-                                                    int64_t n, int fmt) {
-  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
-  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
-  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
-    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f);
-}
-// the same over a segment table: all weights of a layer / model in ONE launch (every segment 16-byte aligned with
-// n % block == 0, checked when the table is built)
-template <int DT, int LPG, int FMT>
-__global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict__ segs,
-                                                       const int64_t* __restrict__ blk_start, int n_seg,
-                                                       int64_t n_chunks, int fmt) {
-  if ((int64_t)blockIdx.x >= n_chunks) return;
-  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
-  SegCursor cur;
-  cur.init(segs, blk_start, n_seg, blockIdx.x);
-  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    cur.seek(c);
-    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y),
-                      (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f);
-  }
-}
 // compute_scale / compute_scale_with_global (tensor_quant_mx.cu:139-183) for block-scale formats other than E8M0
 // (NVFP4-style: E2M1 elements, E4M3 block scales, optional tensor-wide amax).  The reference mixes float and double
 // steps; they are kept one by one: float divisions, the product and the reciprocal in double, results narrowed to
@@ -177,6 +115,91 @@ __device__ __forceinline__ void mx_scale_general(float amax, float emax, const M
   }
 }
 
+// fast path: cols % block == 0, block % kVec == 0 -> an MX block is LPG adjacent lanes of one packet.
+// Chunk skeleton: all packets of a chunk in flight before the first use, non-temporal loads and stores, dense
+// strided grid.  FMT >= 0 fixes the element format at compile time (E2M1 / E4M3: the MXFP4 / MXFP8 presets) so
+// that the rounding constants fold; FMT < 0 reads it from `fmt`.
+// block scale of the E8M0 formats / of the two-level (NVFP4-style) formats, as a functor of the block's abs-max
+struct MxScaleE8M0 {
+  float fmt_max;
+  __device__ __forceinline__ void operator()(float am, float& sc, float& un) const { mx_scale_e8m0(am, fmt_max, sc, un); }
+};
+struct MxScaleGeneral {
+  float fmt_max;
+  MxFmt sf;
+  const float* global;
+  __device__ __forceinline__ void operator()(float am, float& sc, float& un) const {
+    mx_scale_general(am, fmt_max, sf, global, sc, un);
+  }
+};
+template <int DT, int LPG, class ScaleFn>
+__device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f,
+                                         const ScaleFn& scale_of) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  constexpr int ES = 16 / V;
+  Pack16 in[P];
+  // n is a multiple of the block (= LPG * V elements), so a group is entirely live or entirely past the end
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    if (e < n) in[u] = load16_nt(xb + e * ES);
+    else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float v[8];
+    unpack<DT>(in[u], v);
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+    // non-negative floats order like their bit patterns
+    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
+    float sc, un;
+    scale_of(am, sc, un);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+    if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
+  }
+}
+template <int DT, int LPG, int FMT>
+__global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, void* __restrict__ y,
+                                                    int64_t n, int fmt) {
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  const MxScaleE8M0 scale_of{f.maxv};
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
+    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
+}
+// two-level block scales (an element format as the scale format, optional tensor-wide amax) on the same skeleton; the
+// one-thread-per-block generic kernel moved 2 bytes per lane and load (0.21 of the HBM roofline at g = 16)
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void mx_two_level_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n,
+                                                              int fmt, int scale_fmt, const float* __restrict__ global_amax) {
+  const MxFmt f = mx_fmt(fmt);
+  const MxScaleGeneral scale_of{f.maxv, mx_fmt(scale_fmt), global_amax};
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
+    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
+}
+// the same over a segment table: all weights of a layer / model in ONE launch (every segment 16-byte aligned with
+// n % block == 0, checked when the table is built)
+template <int DT, int LPG, int FMT>
+__global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict__ segs,
+                                                       const int64_t* __restrict__ blk_start, int n_seg,
+                                                       int64_t n_chunks, int fmt) {
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  const MxScaleE8M0 scale_of{f.maxv};
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    cur.seek(c);
+    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y),
+                      (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
+  }
+}
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding), any alignment and
 // every block-scale format (scale_fmt == MOQ_E8M0: the exponent/mantissa test; else the general path above)
 template <int DT>
@@ -289,35 +312,40 @@ __device__ __forceinline__ uint32_t mask4(float a0, float a1, float a2, float a3
   s[3] = ((a0 + z1) + a2) + z3;
   s[4] = ((a0 + z1) + z2) + a3;
   s[5] = ((z0 + z1) + a2) + a3;
-  int best = 0;
+  // mask bytes for elements 0..3 packed little-endian; the winner's word travels with the running maximum as a
+  // select between literals (indexing a table by the winner made it a constant-memory load per group of four)
+  constexpr uint32_t tbl[6] = {0x01000100u, 0x00000101u, 0x00010100u, 0x00010001u, 0x01000001u, 0x01010000u};
+  uint32_t bm = tbl[0];
   float bv = s[0];
 #pragma unroll
   for (int p = 1; p < 6; ++p) {
-    const bool better = (bv == bv) && ((s[p] != s[p]) || s[p] > bv);  // argmax: NaN is max, first wins
-    if (better) { best = p; bv = s[p]; }
+    // argmax: NaN is max, first wins (`&` / `|`: no short-circuit, hence no divergent branch per pattern)
+    const bool better = (bv == bv) & ((s[p] != s[p]) | (s[p] > bv));
+    bm = better ? tbl[p] : bm;
+    bv = better ? s[p] : bv;
   }
-  // mask bytes for elements 0..3 packed little-endian
-  const uint32_t tbl[6] = {0x01000100u, 0x00000101u, 0x00010100u, 0x00010001u, 0x01000001u, 0x01010000u};
-  return tbl[best];
+  return bm;
 }
+// (global address space stated: a pointer read from the segment table would otherwise get flat_store)
 __device__ __forceinline__ void store8_nt(void* p, uint32_t a, uint32_t b) {
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) u32x2* gptr_8;
   u32x2 v = {a, b};
-  __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(p));
+  __builtin_nontemporal_store(v, (gptr_8)(uintptr_t)p);
 }
 __device__ __forceinline__ void store4_nt(void* p, uint32_t a) {
-  __builtin_nontemporal_store(a, reinterpret_cast<uint32_t*>(p));
+  typedef __attribute__((address_space(1))) uint32_t* gptr_4;
+  __builtin_nontemporal_store(a, (gptr_4)(uintptr_t)p);
 }
-template <int DT>
-__device__ __forceinline__ void mask_chunk(const void* w, uint8_t* mask, int64_t e0, int64_t n, bool fast) {
+// FAST is a template parameter and the chunk loop branches on it ONCE per chunk: with `fast ? a : b` per packet hipcc
+// kept two loads in flight per lane instead of the chunk's four
+template <int DT, bool fast>
+__device__ __forceinline__ void mask_chunk(const void* w, uint8_t* mask, int64_t e0, int64_t n) {
   constexpr int V = Elem<DT>::kVec;  // 8 (two groups of 4) or 4 (one group)
   constexpr int P = Chunk<DT>::kPackets;
   Pack16 in[P];
 #pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
-    in[u] = fast ? ld_packet<DT, true>(w, e, n) : ld_packet<DT, false>(w, e, n);
-  }
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, fast>(w, e0 + packet_off<DT>(u), n);
 #pragma unroll
   for (int u = 0; u < P; ++u) {
     const int64_t e = e0 + packet_off<DT>(u);
@@ -328,7 +356,7 @@ __device__ __forceinline__ void mask_chunk(const void* w, uint8_t* mask, int64_t
     const uint32_t m0 = mask4(v[0], v[1], v[2], v[3]);
     uint32_t m1 = 0;
     if constexpr (V == 8) m1 = mask4(v[4], v[5], v[6], v[7]);
-    if (fast) {
+    if constexpr (fast) {
       if constexpr (V == 8) store8_nt(mask + e, m0, m1);
       else store4_nt(mask + e, m0);
     } else {  // n % 4 == 0: groups of four are all-in or all-out
@@ -346,7 +374,8 @@ __global__ __launch_bounds__(kBlock) void mask24_kernel(const void* __restrict__
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
-    mask_chunk<DT>(w, mask, e0, n, al && e0 + MOQ_MT_CHUNK <= n);
+    if (al && e0 + MOQ_MT_CHUNK <= n) mask_chunk<DT, true>(w, mask, e0, n);
+    else mask_chunk<DT, false>(w, mask, e0, n);
   }
 }
 // the same over a segment table (segs[s].y = the uint8 / bool mask of segs[s].x): one launch per layer / model
@@ -361,7 +390,8 @@ __global__ __launch_bounds__(kBlock) void mt_mask24_kernel(const moq_seg* __rest
     cur.seek(c);
     const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
     const bool al = al16(cur.sg.x) && (reinterpret_cast<uintptr_t>(cur.sg.y) & 7u) == 0;
-    mask_chunk<DT>(cur.sg.x, reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n, al && e0 + MOQ_MT_CHUNK <= cur.sg.n);
+    if (al && e0 + MOQ_MT_CHUNK <= cur.sg.n) mask_chunk<DT, true>(cur.sg.x, reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n);
+    else mask_chunk<DT, false>(cur.sg.x, reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n);
   }
 }
 
@@ -752,6 +782,18 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
     }
 #undef MOQ_MX_CASE
 #undef MOQ_MX_LAUNCH
+  } else if (scale_fmt != MOQ_E8M0 && aligned && cols % block == 0 && block % vec == 0 && lpg <= 8 && (lpg & (lpg - 1)) == 0) {
+    const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+#define MOQ_MX2_CASE(L)                                                                                              \
+  case L:                                                                                                            \
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_two_level_kernel<DT, L>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, \
+                                              n, fmt, scale_fmt, global_amax));                                     \
+    break;
+    switch (lpg) {
+      MOQ_MX2_CASE(1) MOQ_MX2_CASE(2) MOQ_MX2_CASE(4) MOQ_MX2_CASE(8)
+      default: set_error("unreachable"); return MOQ_ERR_INVALID;
+    }
+#undef MOQ_MX2_CASE
   } else {
     const int64_t nb = rows * ((cols + block - 1) / block);
     const int grid = stream_grid(kBlock, nb);
