@@ -119,6 +119,11 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
     opf.sc = fp8_scale(p.qdq_amax[0]);
   }
   uint32_t amax_acc = 0;
+  int64_t toff[PQS ? P : 1];  // (packet offset inside a chunk) mod cols, once per thread
+  if constexpr (PQS) {
+#pragma unroll
+    for (int u = 0; u < P; ++u) toff[u] = (int64_t)((u * kBlock + tid) * V) % p.cols;
+  }
   // Two chunks in flight per quarter: the loads of the next chunk are issued before the current one is worked on, so
   // a wave's HBM latency hides under its own LDS / VALU phase (with the 64 KiB table there is one workgroup per CU).
   auto work_chunk = [&](int64_t c, const Pack16 (&in)[P]) {
@@ -126,18 +131,29 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
     const bool fast = al && e0 + MOQ_MT_CHUNK <= p.n;
     int64_t col0 = 0;
     if constexpr (PQS) col0 = e0 % p.cols;  // wave-uniform; cols % V == 0 (host-checked): a packet stays in one row
+    // the pre_quant_scale vectors of all packets are requested before the first is used (column = col0 + toff[u], both
+    // below cols: one conditional subtraction wraps; the first form took a 64-bit modulo per packet in a divergent
+    // branch and loaded the vectors one packet at a time)
+    float4 pq[PQS ? P : 1][V / 4];
+    if constexpr (PQS) {
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        int64_t col = col0 + toff[u];
+        col = col >= p.cols ? col - p.cols : col;
+#pragma unroll
+        for (int i = 0; i < V / 4; ++i) pq[u][i] = *reinterpret_cast<const float4*>(p.pqs + col + 4 * i);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + (u * kBlock + tid) * V;
       float f[8];
       unpack<DT>(in[u], f);
       if constexpr (PQS) {
-        int64_t col = col0 + (u * kBlock + tid) * V;
-        if (col >= p.cols) col %= p.cols;
-        if (e < p.n) {
+        if (fast || e < p.n) {
 #pragma unroll
           for (int i = 0; i < V; i += 4) {
-            const float4 s = *reinterpret_cast<const float4*>(p.pqs + col + i);
+            const float4 s = pq[u][i / 4];
             f[i] = round_to_dtype<DT>(f[i] * s.x);
             f[i + 1] = round_to_dtype<DT>(f[i + 1] * s.y);
             f[i + 2] = round_to_dtype<DT>(f[i + 2] * s.z);
