@@ -478,6 +478,20 @@ def main():
             ms = timed(lambda: tab.calibrate_amax())
             extra["per_tensor_amax"] = {"ms": round(ms, 4), "hbm_GBs": round(n_elem * 2 / ms / 1e6, 1),
                                         "frac_of_8TBs": round(n_elem * 2 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if wl == "fp8":
+            # the other single-launch configurations of BASELINE.json on the same resident weights: configs[3] (2:4
+            # magnitude mask: 2 B read + 1 B mask written per element) and configs[4]'s QDQ (MXFP4 g32: 2 B + 2 B)
+            mk = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in weights]
+            mtab = SegmentTable(weights, outputs=mk)
+            ms = timed(lambda: mtab.mask_2to4())
+            extra["mask_2to4"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
+                                  "hbm_GBs": round(n_elem * 3 / ms / 1e6, 1),
+                                  "frac_of_8TBs": round(n_elem * 3 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del mtab, mk
+            ms = timed(lambda: tab.mx_fused_amax_convert(32, "E2M1"))
+            extra["mxfp4_g32_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
+                                      "hbm_GBs": round(n_elem * 4 / ms / 1e6, 1),
+                                      "frac_of_8TBs": round(n_elem * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
     if not args.no_extra:
         # release the main workload's tensors: the extras below bring their own
         del tab, weights, groups, masks
