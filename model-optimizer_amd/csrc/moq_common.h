@@ -313,6 +313,15 @@ __device__ __forceinline__ SharedDiv make_shared_div(float d) {
   r.y = __builtin_fmaf(y0, e, y0);
   return r;
 }
+// the exact-window form on its own (caller has tested s.fast once for a whole packet)
+__device__ __forceinline__ float shared_div_in_window(float n, const SharedDiv& s) {
+  const float q0 = n * s.y;
+  const float r0 = __builtin_fmaf(-s.d, q0, n);
+  const float q1 = __builtin_fmaf(r0, s.y, q0);
+  const float r1 = __builtin_fmaf(-s.d, q1, n);
+  const float q = __builtin_fmaf(r1, s.y, q1);
+  return q0 == 0.0f ? q0 : q;  // (see shared_div)
+}
 __device__ __forceinline__ float shared_div(float n, const SharedDiv& s) {
   if (!s.fast) return n / s.d;
   const float q0 = n * s.y;

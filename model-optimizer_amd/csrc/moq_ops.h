@@ -18,9 +18,25 @@ struct OpIntQdq {  // a6 with one scalar amax
     sd = make_shared_div(scale);
   }
   __device__ __forceinline__ void operator()(float* f, int n) const {
+    if (scale != 0.0f && sd.fast) {
+      // the ordinary case, tested ONCE per packet (the scale is the tensor's): same arithmetic as qdq_int_shared
+      // without its two uniform branches per element
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < n) f[i] = qdq_int_shared(f[i], scale, sd, q);
+      for (int i = 0; i < 8; ++i) {
+        if (i < n) {
+          const float p = f[i] * scale;
+          float t = __builtin_rintf(p);
+          t = t < q.lo ? q.lo : t;
+          t = __builtin_fminf(t, q.hi);
+          t = (p != p) ? p : t;
+          f[i] = shared_div_in_window(t, sd);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < n) f[i] = qdq_int_shared(f[i], scale, sd, q);
+    }
   }
 };
 struct OpFp8Qdq {  // a7 with one scalar amax
