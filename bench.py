@@ -314,11 +314,14 @@ def main():
                 dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
         elif wl == "fp8" or wl == "int8":
             tab.calibrate_amax()
+            work = None
             if use_dist:
-                # one bucket: the owners' values reach every rank (zeros are the identity of abs-max)
+                # one bucket: the owners' values reach every rank (zeros are the identity of abs-max).  The QDQ of a
+                # rank's own tensors needs only its own statistics, so the exchange runs on RCCL's stream UNDER the QDQ
+                # launch and is waited for at the end of the step (it is part of the step, not of the QDQ's inputs)
                 amax_all.zero_()
                 amax_all[owned_idx] = tab.amax_flat
-                dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
+                work = dist.all_reduce(amax_all, op=dist.ReduceOp.MAX, async_op=True)
             if record:
                 e0, e1 = ev(), ev()
                 e0.record()
@@ -326,6 +329,8 @@ def main():
             if record:
                 e1.record()
                 dom_events.append((e0, e1))
+            if work is not None:
+                work.wait()  # the step's stream continues only after every rank's statistics have arrived
         elif wl == "int4g128":
             if record:
                 e0, e1 = ev(), ev()
@@ -446,7 +451,7 @@ def main():
                                f"{wl} calibrate + quantize-dequantize{' in place' if args.inplace else ''}, inputs resident in HBM",
                    "format": wl, "model": args.model, "layers": n_layers,
                    "parallelism": f"the {n_tensors} per-layer weight tensors dealt round-robin over {world} GPUs "
-                                  f"({len(weights)} on rank 0); one amax bucket all-reduce(MAX)"
+                                  f"({len(weights)} on rank 0); one amax bucket all-reduce(MAX), in flight under the QDQ launch"
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
     }
