@@ -74,6 +74,12 @@ template <> struct Geo<9> { static constexpr int TILE = 256, WAVES = 8, WN = 2, 
 //          with the operands going HBM/L2 -> VGPRs -> LDS (buffer_load_dwordx4 + ds_write_b128) instead of the LDS-DMA
 template <> struct Geo<17> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
 template <> struct Geo<18> { static constexpr int TILE = 256, WAVES = 8, WN = 2, NI = 4, NJ = 2, STAGES = 2; };
+//   GEO 20 (round 3): the GEO 10 stream with FOUR waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator registers, one
+//          wave per SIMD) -- the geometry of the library's MT256x256x64 kernel (WG32_8_1, MIWT8_8 in its name): 16 MFMAs per
+//          sub-step against 8 fragment reads (GEO 10: 8 against 6), 16 LDS-DMA pieces per wave and K-tile in the first two
+//          sub-steps, one after every second MFMA.  GEO 5 was this geometry with the block-issue loop and the branchy
+//          pieces of round 1
+template <> struct Geo<20> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -394,7 +400,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
 //         ONCE when the accumulation is over (moq_symmetrize);
 // MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
-__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 ? 1 : 2))
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 || GEO == 20 ? 1 : 2))
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ w,     // [N, K]
                      const void* __restrict__ ref,   // [T, N] (MODE 0)
@@ -439,6 +445,93 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
+  if constexpr (GEO == 20) {
+    static_assert(NI == 4 && NJ == 4 && Geo<GEO>::WAVES == 4, "GEO 20: four waves of 4 x 4 MFMA tiles");
+    const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
+    const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
+    Pack16 a[2][NI], b[2][NJ];
+    auto read_sub = [&](int buf, int stage_off, int ks) {
+      const int c = ks * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[buf][i] = read_frag(la0 + stage_off, i * 32 + fr, c);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) b[buf][j] = read_frag(lb0 + stage_off, j * 32 + fr, c);
+    };
+    auto mma_sub = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32<DT>(a[buf][i], b[buf][j], acc[i][j]);
+    };
+    // LDS-DMA pieces as in GEO 10 (branch-free, three instructions), EIGHT per operand and wave: piece p (0..15) = 8 rows
+    // of W (p < 8) or of x (p >= 8)
+    constexpr int PP = 8;
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * PP * 8 * kRowBytes));
+    const bool k_ragged = (K & (kBK - 1)) != 0;
+    int voff[PP], voff_tail[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      const int r = (wave * PP + j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      voff[j] = (int)(r * ld_bytes + c * 16);
+      voff_tail[j] = (nk - 1) * kBK + c * 8 < K ? voff[j] : 0x7FFFFFF0;
+    }
+    const i32x4_t rsw = rs_w.words, rsx = rs_x.words;
+    auto piece = [&](int sn, int k0, auto P, bool live = true) {
+      constexpr int p = decltype(P)::value, j = p & (PP - 1);
+      const uint32_t m0v = lds_wave + (uint32_t)(sn * SB + (p < PP ? 0 : TB) + j * 8 * kRowBytes);
+      const int koff = k0 * 2;
+      const int vfull = voff[j], vtail = voff_tail[j];
+      const int vo = (k_ragged && k0 + kBK > K) ? vtail : vfull;
+      i32x4_t rr = p < PP ? rsw : rsx;
+      rr.z = live ? rr.z : 0;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
+    };
+    // sixteen MFMAs of register buffer BUF, each of the first eight followed by one fragment read of sub-step KS into the
+    // other buffer and, when P0 >= 0, every second one by one LDS-DMA piece (pieces p0 .. p0 + 7)
+    auto group = [&](auto BUF, auto KS, bool on, auto P0, int so, int sn, int k0) {
+      constexpr int buf = decltype(BUF)::value, ks = decltype(KS)::value, nb = buf ^ 1, p0 = decltype(P0)::value;
+      const int c = ks * 2 + fh;
+      auto one = [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        acc[n >> 2][n & 3] = mfma32<DT>(a[buf][n >> 2], b[buf][n & 3], acc[n >> 2][n & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n < 4) a[nb][n] = read_frag(la0 + so, n * 32 + fr, c);
+        else if constexpr (n < 8) b[nb][n - 4] = read_frag(lb0 + so, (n - 4) * 32 + fr, c);
+        if constexpr ((n & 1) != 0 && p0 >= 0) piece(sn, k0, IC<(p0 >= 0 ? p0 : 0) + (n >> 1)>{}, on);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{});
+      one(IC<8>{}); one(IC<9>{}); one(IC<10>{}); one(IC<11>{}); one(IC<12>{}); one(IC<13>{}); one(IC<14>{}); one(IC<15>{});
+    };
+    auto pieces8 = [&](int sn, int k0, auto P0) {
+      constexpr int p0 = decltype(P0)::value;
+      piece(sn, k0, IC<p0 + 0>{}); piece(sn, k0, IC<p0 + 1>{}); piece(sn, k0, IC<p0 + 2>{}); piece(sn, k0, IC<p0 + 3>{});
+      piece(sn, k0, IC<p0 + 4>{}); piece(sn, k0, IC<p0 + 5>{}); piece(sn, k0, IC<p0 + 6>{}); piece(sn, k0, IC<p0 + 7>{});
+    };
+    pieces8(0, 0, IC<0>{});
+    pieces8(0, 0, IC<8>{});
+    for (int kt = 0; kt < nk; ++kt) {
+      const int so = (kt & 1) * SB, sn = (kt + 1) & 1, k0 = (kt + 1) * kBK;
+      const bool more = kt + 1 < nk;
+      // tile kt landed (own pieces; the barrier makes it everyone's) and every fragment read of tile kt - 1 has completed
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt > 0) {
+        group(IC<1>{}, IC<0>{}, more, IC<0>{}, so, sn, k0);  // last sub-step of tile kt - 1 under the first reads of tile kt
+      } else {
+        read_sub(0, so, 0);
+        if (more) pieces8(sn, k0, IC<0>{});
+      }
+      group(IC<0>{}, IC<1>{}, more, IC<8>{}, so, sn, k0);
+      group(IC<1>{}, IC<2>{}, false, IC<-1>{}, so, sn, k0);
+      group(IC<0>{}, IC<3>{}, false, IC<-1>{}, so, sn, k0);
+    }
+    mma_sub(1);  // last sub-step of the last tile
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // "dead" pieces of the last tile before the epilogue reuses the LDS
+  } else
   if constexpr (GEO == 4 || GEO == 5 || GEO == 7 || GEO == 8 || GEO == 9 || GEO == 10 || GEO == 17 || GEO == 18) {
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
@@ -1224,7 +1317,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 10;
-    return g < 0 || g > 18 ? 10 : g;
+    return g < 0 || g > 20 ? 10 : g;
   }();
   return geo;
 }
@@ -1347,6 +1440,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 15: launch_geo12<MODE, 3>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 17: launch_geo<MODE, 17>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 18: launch_geo<MODE, 18>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 20: launch_geo<MODE, 20>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
