@@ -75,7 +75,7 @@ def make_weights(model, n_layers, device, seed=1234, rank=0, world=1):
 
 
 PMC_KERNEL = {"fp8": "mt_map_kernel<2, moq::OpFp8Qdq>", "int8": "mt_map_kernel<2, moq::OpIntQdq>",
-              "int4g128": "mt_group_kernel<2, 16>"}
+              "int4g128": "mt_group_kernel<2, 16>", "mask24": "mt_mask24_kernel<2>", "mxfp4": "mt_mx_kernel<2, 4, 6>"}
 
 
 def pmc_traffic(workload, model, n_layers):
