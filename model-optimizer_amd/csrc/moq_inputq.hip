@@ -119,6 +119,10 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
     opf.sc = fp8_scale(p.qdq_amax[0]);
   }
   uint32_t amax_acc = 0;
+  uint32_t amax_seen = 0;
+  if constexpr (AMAX) {
+    if (threadIdx.x == 0) amax_seen = __builtin_nontemporal_load(p.amax_bits);
+  }
   int64_t toff[PQS ? P : 1];  // (packet offset inside a chunk) mod cols, once per thread
   if constexpr (PQS) {
 #pragma unroll
@@ -228,7 +232,9 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
     if (threadIdx.x == 0) {
       uint32_t m = s_max[0];
       for (int w = 1; w < kIqBlock / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
-      atomicMax(p.amax_bits, m);  // non-negative float patterns order like uints; NaN patterns sit above inf
+      // non-negative float patterns order like uints; NaN patterns sit above inf.  Skipped when the running maximum
+      // already covered this workgroup's result at its start (amax_kernel's note)
+      if (m > amax_seen) atomicMax(p.amax_bits, m);
     }
   }
   if constexpr (HIST) {

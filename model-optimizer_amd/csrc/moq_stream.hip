@@ -61,6 +61,13 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void* __restrict__ x
   __shared__ uint32_t smem[kBlock / 64];
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   const bool al = aligned16(x);
+  // The value the running maximum had when this workgroup started: a maximum only grows, so a workgroup whose own
+  // result does not exceed it has nothing to contribute and skips its atomic.  In a calibration loop (one running
+  // abs-max per quantizer over many batches) that is nearly every workgroup of nearly every launch after the first
+  // batches -- and the atomics matter at the sizes the flow presents: they all hit ONE address and retire at ~80 M/s
+  // (MI355X_MICROARCH.md), 512 of them are a 6 us tail behind a 33 MB sweep that takes 6 us to stream.
+  uint32_t seen = 0;
+  if (threadIdx.x == 0) seen = __builtin_nontemporal_load(out_bits);
   uint32_t acc = 0;
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int64_t e0 = c * MOQ_MT_CHUNK;
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void amax_kernel(const void* __restrict__ x
       acc = chunk_absmax<DT, false>(x, e0, n, acc);
   }
   acc = block_max_u32(acc, smem);
-  if (threadIdx.x == 0) atomicMax(out_bits, acc);  // non-negative float patterns order like uints
+  if (threadIdx.x == 0 && acc > seen) atomicMax(out_bits, acc);  // non-negative float patterns order like uints
 }
 
 template <int DT, class Op>
@@ -527,8 +534,9 @@ extern "C" int moq_amax(const void* x, int64_t n, int dt, float* out, int accumu
   }
   if (n == 0) return MOQ_OK;
   const int64_t chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
-  // <= 512 workgroups: one same-address atomic per workgroup at the end (see mt_amax_kernel note)
-  const int grid = (int)(chunks < 512 ? chunks : 512);
+  // <= 1024 workgroups (four per CU: 64 KiB of loads in flight per CU and chunk round); at most one same-address atomic
+  // per workgroup at the end, none when the running maximum already covers the workgroup's result
+  const int grid = (int)(chunks < 1024 ? chunks : 1024);
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((amax_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
                                             x, n, reinterpret_cast<uint32_t*>(out)));
   return check_launch("moq_amax");
