@@ -11,7 +11,7 @@ One step = one pass of the hot path over ALL linear weights of a synthetic Llama
     mxfp4, mask24, int8 : the other formats of the path, for the record.
     mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
              apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
-             the whole model in one launch; 4 + 4 B/element.  Use with --model llama3-70b --inplace.
+             the whole model in one launch; 4 + 4 B/element.  Use with --model llama3-70b.
 `value` = weight bytes of the WHOLE model (2 B/element) / wall time per step.  Multi-GPU is STRONG scaling: the 224
 per-layer weight tensors are dealt round-robin over the ranks (distributed.shard_list: independent units, no
 data-path collective); the only exchange is one bucketed all-reduce(MAX) that leaves every rank with all 224 amax
@@ -197,9 +197,13 @@ def main():
     ap.add_argument("--group-mb", type=int, default=0,
                     help="fp8/int8: calibrate+QDQ in groups of <= this many MB of weights (second read from the "
                          "Infinity Cache) instead of two whole-model passes; 0 = off")
-    ap.add_argument("--inplace", action="store_true",
-                    help="QDQ output overwrites the weights (y == x is part of the C-ABI contract); needed for "
-                         "llama3-70b on one GPU: 137 GB of weights + 137 GB of outputs do not fit in 288 GB")
+    ap.add_argument("--out-of-place", action="store_true",
+                    help="QDQ outputs go to separate tensors (rounds 1-2 measured this).  Default since round 3: IN PLACE, "
+                         "what the product's fold_weight / max_calibrate paths do (every SegmentTable of the package is built "
+                         "with outputs = inputs; y == x is part of the C-ABI contract) -- same 4 B/element of traffic, and "
+                         "the only form in which llama3-70b fits one GPU.  The default line carries the out-of-place time "
+                         "of the same launch in extra.qdq_out_of_place")
+    ap.add_argument("--inplace", action="store_true", help="(accepted for old command lines; in place is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other kernels, the "
                                                             "Llama-3-70B in-place pass, the INT4-AWQ wall-clock)")
@@ -266,6 +270,7 @@ def main():
     owned_idx = torch.tensor(owned, dtype=torch.int64, device=dev)
     amax_all = torch.zeros(n_tensors, dtype=torch.float32, device=dev)  # every rank ends with every tensor's amax
 
+    args.inplace = not args.out_of_place
     tab = SegmentTable(weights, outputs=weights if args.inplace else None, group_size=128 if wl == "int4g128" else None)
     groups = None
     if args.group_mb and wl in ("fp8", "int8"):
@@ -471,18 +476,23 @@ def main():
 
     if not args.no_extra and world == 1:
         # secondary measurements on the same resident weights (not part of `value`)
-        if wl != "int4g128":
-            tabg = SegmentTable(weights, outputs=tab.outputs, group_size=128)
-            ms = timed(lambda: tabg.amax_qdq_int_group(4, False, False))
-            b = n_elem * (4.0 + 4.0 / 128)
-            extra["int4g128_fused_amax_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
-                                                "hbm_GBs": round(b / ms / 1e6, 1),
-                                                "frac_of_8TBs": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
-            del tabg
+        # (order: the passes that leave the weights alone first; the in-place ones -- the product's form -- last, since
+        # each rewrites the resident weights onto its own grid)
         if wl in ("fp8", "int8"):
             ms = timed(lambda: tab.calibrate_amax())
             extra["per_tensor_amax"] = {"ms": round(ms, 4), "hbm_GBs": round(n_elem * 2 / ms / 1e6, 1),
                                         "frac_of_8TBs": round(n_elem * 2 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if wl == "fp8" and args.inplace:
+            # the same QDQ launch with separate output tensors (what rounds 1-2 timed): depends on where the allocator puts
+            # the 14 GB of outputs relative to the inputs -- pools of one process differ by 10 % on the same box
+            # (profiles/r03_output_placement.md) -- which the in-place default does not
+            tab_o = SegmentTable(weights, outputs=None)
+            tab_o.amax_flat.copy_(tab.amax_flat)
+            ms = timed(lambda: tab_o.fake_quant_e4m3())
+            extra["qdq_out_of_place"] = {"ms": round(ms, 4), "hbm_GBs": round(n_elem * 4 / ms / 1e6, 1),
+                                         "frac_of_8TBs": round(n_elem * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del tab_o
+            torch.cuda.empty_cache()
         if wl == "fp8":
             # the other single-launch configurations of BASELINE.json on the same resident weights: configs[3] (2:4
             # magnitude mask: 2 B read + 1 B mask written per element) and configs[4]'s QDQ (MXFP4 g32: 2 B + 2 B)
@@ -497,6 +507,14 @@ def main():
             extra["mxfp4_g32_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
                                       "hbm_GBs": round(n_elem * 4 / ms / 1e6, 1),
                                       "frac_of_8TBs": round(n_elem * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if wl != "int4g128":
+            tabg = SegmentTable(weights, outputs=tab.outputs, group_size=128)
+            ms = timed(lambda: tabg.amax_qdq_int_group(4, False, False))
+            b = n_elem * (4.0 + 4.0 / 128)
+            extra["int4g128_fused_amax_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
+                                                "hbm_GBs": round(b / ms / 1e6, 1),
+                                                "frac_of_8TBs": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del tabg
     if not args.no_extra:
         # release the main workload's tensors: the extras below bring their own
         del tab, weights, groups, masks

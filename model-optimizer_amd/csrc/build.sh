@@ -13,7 +13,9 @@ pids=()
 # diagnostics that return wrong results by construction) is compiled IN PLACE of the release moq_gemm.hip -- a library
 # for tools/gemm_bench.py and tools/exp/, never the one that ships
 SRCS=(moq_*.hip)
+OBJDIR=build
 if [ "${MOQ_EXPERIMENTS:-0}" = "1" ]; then
+  OBJDIR=build/exp  # every source is compiled with -DMOQ_EXPERIMENTS (the tuning knobs of moq_common.h): own objects
   SRCS=("${SRCS[@]/moq_gemm.hip/exp/moq_gemm_exp.hip}")
   FLAGS="$FLAGS -DMOQ_EXPERIMENTS -I."
   OUT=${1:-libmoquant_exp.so}
@@ -21,8 +23,8 @@ if [ "${MOQ_EXPERIMENTS:-0}" = "1" ]; then
 fi
 for src in "${SRCS[@]}"; do
   base=$(basename "$src")
-  obj="build/${base%.hip}.o"
-  mkdir -p build
+  obj="$OBJDIR/${base%.hip}.o"
+  mkdir -p "$OBJDIR"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ moq_chunk.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
     echo "[moquant] hipcc $src"
     $HIPCC $FLAGS -c "$src" -o "$obj" &

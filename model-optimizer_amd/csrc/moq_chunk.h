@@ -164,7 +164,7 @@ static inline int log2_or_neg(int64_t g) {
 
 // copy-shaped passes: ~8 chunks per workgroup, at least a full machine (2048), at most 128 Ki workgroups
 static inline int copy_grid(int64_t n_chunks) {
-  static const int64_t div = [] { const char* e = getenv("MOQ_TUNE_CHUNKS_PER_WG"); return e ? atoll(e) : 8LL; }();
+  const int64_t div = moq_tune("MOQ_TUNE_CHUNKS_PER_WG", 8);  // (experiment build only)
   int64_t g = n_chunks / (div > 0 ? div : 8);
   if (g < 2048) g = 2048;
   if (g > 131072) g = 131072;

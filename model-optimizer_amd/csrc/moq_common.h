@@ -9,10 +9,26 @@
 //     multiply / round / divide, so no FMA contraction may happen behind our back.
 #pragma once
 
+#include <stdlib.h>
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/moquant.h"
+
+// Tuning knobs (A/B switches between CORRECT variants, grid shapes) exist in the experiment build only
+// (MOQ_EXPERIMENTS=1 build.sh -> libmoquant_exp.so, never the library that ships); there they are read on every call so
+// that one process can compare settings on the same allocations.  The release library reads ONE environment variable,
+// MOQ_TUNE_GEMM_GEO (its two error-GEMM loop structures are both release kernels with identical results).
+static inline long long moq_tune(const char* name, long long dflt) {
+#ifdef MOQ_EXPERIMENTS
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 namespace moq {
 

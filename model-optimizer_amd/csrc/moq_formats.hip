@@ -846,9 +846,9 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
   }
   if (n == 0) return MOQ_OK;
   // 16-bit inputs: the histogram stage of the fused input-quantizer kernel (moq_inputq.hip), which tabulates the
-  // binning rule per |x| pattern once per workgroup instead of evaluating it per element.  MOQ_TUNE_HIST=0 selects the
-  // arithmetic kernel below (the fp32 path) for A/B measurements.
-  static const bool lut_hist = [] { const char* e = getenv("MOQ_TUNE_HIST"); return !(e && e[0] == '0'); }();
+  // binning rule per |x| pattern once per workgroup instead of evaluating it per element.  (Experiment build:
+  // MOQ_TUNE_HIST=0 selects the arithmetic kernel below, the fp32 path, for A/B measurements.)
+  const bool lut_hist = moq_tune("MOQ_TUNE_HIST", 1) != 0;
   if (lut_hist && dt != MOQ_F32 && bins < kHistMaxLdsBins)
     return moq_input_quant(x, nullptr, nullptr, 1, n, dt, nullptr, nullptr, 0, 0, 0, 0, counts, bins, max_edge,
                            skip_zeros, stream);

@@ -555,21 +555,11 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
   const int geo = gemm_geo();
   if constexpr (MODE != 2) {
     // the kernels' last argument is the Gram mode's upper_only flag; the other modes carry the tile-group size of the
-    // workgroup -> tile order in it (tile_of_block).  MOQ_TUNE_GEMM_GROUP = 1 restores the plain row-major order.
-    static const int group = [] {
-      const char* e = getenv("MOQ_TUNE_GEMM_GROUP");
-      const int g = e ? atoi(e) : kTileGroup;
-      return g < 1 || g > 64 ? kTileGroup : g;
-    }();
-    upper_only = group;
+    // workgroup -> tile order in it (tile_of_block)
+    upper_only = kTileGroup;
   } else {
     // Gram mode: bit 0 stays the upper_only flag, the tile-group size rides above it
-    static const int group2 = [] {
-      const char* e = getenv("MOQ_TUNE_GEMM_GROUP");
-      const int g = e ? atoi(e) : kTileGroup;
-      return g < 1 || g > 64 ? kTileGroup : g;
-    }();
-    upper_only = (upper_only ? 1 : 0) | (group2 << 1);
+    upper_only = (upper_only ? 1 : 0) | (kTileGroup << 1);
   }
   const int tile = 256;
   const int64_t nblk = n_tiles_for(tokens, cout, tile);

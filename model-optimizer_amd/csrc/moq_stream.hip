@@ -707,9 +707,9 @@ extern "C" int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_
   if (rc != MOQ_OK || n_seg == 0) return rc;
   hipLaunchKernelGGL(mt_zero_amax_kernel, dim3((n_seg + 255) / 256), dim3(256), 0, S(stream), segs, n_seg);
   if (n_chunks > 0) {
-    // MOQ_TUNE_AMAX_KEEP=1: plain (cache-allocating) loads, for a QDQ pass that follows while the tensors are
-    // still in the 256 MB Infinity Cache
-    static const bool keep = [] { const char* e = getenv("MOQ_TUNE_AMAX_KEEP"); return e && atoi(e) != 0; }();
+    // (experiment build) MOQ_TUNE_AMAX_KEEP=1: plain (cache-allocating) loads, for a QDQ pass that follows while the
+    // tensors are still in the 256 MB Infinity Cache
+    const bool keep = moq_tune("MOQ_TUNE_AMAX_KEEP", 0) != 0;
     if (keep) {
       MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_kernel<DT, false>), dim3(mt_grid(n_chunks)), dim3(kBlock),
                                                 0, S(stream), segs, blk_start, n_seg, n_chunks));
