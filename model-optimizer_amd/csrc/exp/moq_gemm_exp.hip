@@ -80,6 +80,13 @@ template <> struct Geo<18> { static constexpr int TILE = 256, WAVES = 8, WN = 2,
 //          sub-steps, one after every second MFMA.  GEO 5 was this geometry with the block-issue loop and the branchy
 //          pieces of round 1
 template <> struct Geo<20> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
+//   GEO 21 (round 3): GEO 20 with ALL FOUR sub-steps' fragments of a K-tile resident in registers (128 VGPRs beside the 256
+//          accumulators): a stage is read out during the first quarter of its tile's MFMAs and handed back to the LDS-DMA
+//          right away, so the pieces of tile i + 2 are issued a quarter into tile i and waited for three quarters into tile
+//          i + 1 -- 1.0-1.5 K-tiles of lead instead of 0.5-1.0 with the same two 64 KiB stages.  Why: PMC of the library
+//          kernel on the same shape shows its waves parked (s_waitcnt / barrier) 6 % of the time, GEO 10's 35 %
+//          (profiles/r03_gemm_geo_regprefetch.md)
+template <> struct Geo<21> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -400,7 +407,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
 //         ONCE when the accumulation is over (moq_symmetrize);
 // MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
-__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 || GEO == 20 ? 1 : 2))
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 || GEO == 20 || GEO == 21 ? 1 : 2))
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ w,     // [N, K]
                      const void* __restrict__ ref,   // [T, N] (MODE 0)
@@ -413,7 +420,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tn, tt;
-  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : upper_only, tn, tt);  // group size travels in upper_only
+  tile_of_block(blockIdx.x, tiles_t, tiles_n, MODE == 2 ? (upper_only >> 1) : (upper_only & 0xFFFF), tn, tt);  // group size travels in upper_only
   if constexpr (MODE == 2) {
     // tiles_t / tiles_n describe the folded triangle here: (n + 1) columns x ceil(n / 2) row pairs (gram_tile)
     if (!gram_tile(tn, tt, tiles_t - 1, tn, tt)) return;
@@ -445,6 +452,113 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
+  if constexpr (GEO == 21) {
+    static_assert(NI == 4 && NJ == 4 && Geo<GEO>::WAVES == 4, "GEO 21: four waves of 4 x 4 MFMA tiles");
+    const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
+    const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
+    Pack16 a[4][NI], b[4][NJ];  // one register buffer per sub-step of a K-tile
+    constexpr int PP = 8;
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(lds_u8_t)smem + (uint32_t)(wave * PP * 8 * kRowBytes));
+    const bool k_ragged = (K & (kBK - 1)) != 0;
+    int voff[PP], voff_tail[PP];
+#pragma unroll
+    for (int j = 0; j < PP; ++j) {
+      const int r = (wave * PP + j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      voff[j] = (int)(r * ld_bytes + c * 16);
+      voff_tail[j] = (nk - 1) * kBK + c * 8 < K ? voff[j] : 0x7FFFFFF0;
+    }
+    const i32x4_t rsw = rs_w.words, rsx = rs_x.words;
+    auto piece = [&](int sn, int k0, auto P, bool live = true) {
+      constexpr int p = decltype(P)::value, j = p & (PP - 1);
+      const uint32_t m0v = lds_wave + (uint32_t)(sn * SB + (p < PP ? 0 : TB) + j * 8 * kRowBytes);
+      const int koff = k0 * 2;
+      const int vfull = voff[j], vtail = voff_tail[j];
+      const int vo = (k_ragged && k0 + kBK > K) ? vtail : vfull;
+      i32x4_t rr = p < PP ? rsw : rsx;
+      rr.z = live ? rr.z : 0;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                   :: "s"(m0v), "v"(vo), "s"(rr), "s"(koff) : "memory");
+    };
+    auto pieces8 = [&](int sn, int k0, auto P0, bool live) {
+      constexpr int p0 = decltype(P0)::value;
+      piece(sn, k0, IC<p0 + 0>{}, live); piece(sn, k0, IC<p0 + 1>{}, live); piece(sn, k0, IC<p0 + 2>{}, live);
+      piece(sn, k0, IC<p0 + 3>{}, live); piece(sn, k0, IC<p0 + 4>{}, live); piece(sn, k0, IC<p0 + 5>{}, live);
+      piece(sn, k0, IC<p0 + 6>{}, live); piece(sn, k0, IC<p0 + 7>{}, live);
+    };
+    // one fragment read: sub-step KS of the tile in stage offset `st`, fragment f (0..3: a[ks][f], 4..7: b[ks][f - 4])
+    auto frag = [&](auto KS, auto F, int st) {
+      constexpr int ks = decltype(KS)::value, f = decltype(F)::value;
+      const int c = ks * 2 + fh;
+      if constexpr (f < 4) a[ks][f] = read_frag(la0 + st, f * 32 + fr, c);
+      else b[ks][f - 4] = read_frag(lb0 + st, (f - 4) * 32 + fr, c);
+    };
+    // sixteen MFMAs of sub-step buffer BUF; after MFMA n the caller's `after(n)` issues that slot's memory instruction
+    auto group = [&](auto BUF, auto after) {
+      constexpr int buf = decltype(BUF)::value;
+      auto one = [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        acc[n >> 2][n & 3] = mfma32<DT>(a[buf][n >> 2], b[buf][n & 3], acc[n >> 2][n & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        after(NC);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{});
+      one(IC<8>{}); one(IC<9>{}); one(IC<10>{}); one(IC<11>{}); one(IC<12>{}); one(IC<13>{}); one(IC<14>{}); one(IC<15>{});
+    };
+    // prologue: tiles 0 and 1 on their way, tile 0 landed, its first two sub-steps in registers
+    pieces8(0, 0, IC<0>{}, true);
+    pieces8(0, 0, IC<8>{}, true);
+    pieces8(1, kBK, IC<0>{}, nk > 1);
+    pieces8(1, kBK, IC<8>{}, nk > 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int c0 = 0 * 2 + fh, c1 = 1 * 2 + fh;
+      if (f < 4) { a[0][f] = read_frag(la0, f * 32 + fr, c0); a[1][f] = read_frag(la0, f * 32 + fr, c1); }
+      else { b[0][f - 4] = read_frag(lb0, (f - 4) * 32 + fr, c0); b[1][f - 4] = read_frag(lb0, (f - 4) * 32 + fr, c1); }
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      const int so = (kt & 1) * SB, sno = ((kt + 1) & 1) * SB;
+      const int k2 = (kt + 2) * kBK;
+      const bool live2 = kt + 2 < nk;
+      // first quarter: sub-step 0's MFMAs; the other two sub-steps of THIS tile come out of its stage
+      group(IC<0>{}, [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        if constexpr (n < 8) frag(IC<2>{}, IC<n>{}, so);
+        else frag(IC<3>{}, IC<n - 8>{}, so);
+      });
+      // the stage of tile kt is read out (own reads done; the barrier makes it everyone's): it goes back to the DMA
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // second and third quarter: the sixteen pieces of tile kt + 2 into that stage, one after every second MFMA
+      group(IC<1>{}, [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<(n >> 1)>{}, live2);
+      });
+      group(IC<2>{}, [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<8 + (n >> 1)>{}, live2);
+      });
+      // tile kt + 1 (issued a K-tile ago) has landed once only the sixteen pieces above are still outstanding
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // last quarter: sub-step 3's MFMAs; the first two sub-steps of the NEXT tile come out of the other stage
+      group(IC<3>{}, [&](auto NC) {
+        constexpr int n = decltype(NC)::value;
+        if constexpr (n < 8) frag(IC<0>{}, IC<n>{}, sno);
+        else frag(IC<1>{}, IC<n - 8>{}, sno);
+      });
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // dead pieces / reads of the tail before the epilogue reuses the LDS
+    __builtin_amdgcn_sched_barrier(0);
+  } else
   if constexpr (GEO == 20) {
     static_assert(NI == 4 && NJ == 4 && Geo<GEO>::WAVES == 4, "GEO 20: four waves of 4 x 4 MFMA tiles");
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
@@ -871,6 +985,24 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     }
   }
 
+  if constexpr (MODE != 2) {
+    // DIAGNOSTIC (timing only, wrong results): MOQ_TUNE_GEMM_NO_EPILOGUE=1 replaces the loss epilogue -- whose `ref` reads
+    // are 8 bytes per lane from 32 different rows per wave instruction: 7 M partial-line L2 requests per 4096 x 14336 launch
+    // beside the 29 M of the operand stream -- by a plain sum of the accumulators
+    if (upper_only & (1 << 30)) {
+      float sq = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) sq += acc[i][j][e];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+      if (lane == 0) atomicAdd(&partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x], sq);
+      return;
+    }
+  }
   gemm_epilogue<DT, MODE, NI, NJ, Geo<GEO>::WAVES>(acc, ref, bias, out, partial, smem, T, N, n0, t0, tn, tt, wn, wt, fr, fh,
                                                    lane, wave, decay, scale, upper_only);
 }
@@ -1317,7 +1449,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 10;
-    return g < 0 || g > 20 ? 10 : g;
+    return g < 0 || g > 21 ? 10 : g;
   }();
   return geo;
 }
@@ -1407,7 +1539,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
       const int g = e ? atoi(e) : kTileGroup;
       return g < 1 || g > 64 ? kTileGroup : g;
     }();
-    upper_only = group;
+    upper_only = group | (moq_tune("MOQ_TUNE_GEMM_NO_EPILOGUE", 0) ? (1 << 30) : 0);
   } else {
     // Gram mode: bit 0 stays the upper_only flag, the tile-group size rides above it
     static const int group2 = [] {
@@ -1441,6 +1573,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 17: launch_geo<MODE, 17>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 18: launch_geo<MODE, 18>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 20: launch_geo<MODE, 20>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 21: launch_geo<MODE, 21>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }

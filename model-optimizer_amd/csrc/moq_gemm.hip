@@ -54,6 +54,10 @@ template <int GEO> struct Geo { static constexpr int TILE = 256, WAVES = 8, WN =
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * kRowBytes; }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
 template <int GEO> constexpr int lds_bytes() { return Geo<GEO>::STAGES * stage_bytes<GEO>(); }
+// dynamic LDS of a launch: the operand stages, or (MODE 0) the staged out_actual tile of the epilogue: 128 pieces x 1040 bytes
+template <int MODE, int GEO> constexpr int launch_lds_bytes() {
+  return MODE == 0 && lds_bytes<GEO>() < 128 * 1040 ? 128 * 1040 : lds_bytes<GEO>();
+}
 
 template <int DT>
 __device__ __forceinline__ f32x16_t mfma32(const Pack16& a, const Pack16& b, f32x16_t c) {
@@ -175,6 +179,37 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
                                               float decay, float scale, int upper_only) {
   float sq = 0.0f;
   const bool has_bias = bias != nullptr;
+  // MODE 0: the workgroup's 256 x 256 tile of out_actual is STAGED through the LDS (free once the K loop is over) with
+  // full-line LDS-DMA requests.  Read straight from memory, the C layout makes a lane fetch 8 bytes of ONE row -- a wave
+  // instruction touches 32 rows, 16 useful bytes of every 128-byte line, and a 4096 x 14336 launch adds 7 M L2 requests
+  // to the 29 M of its operand stream (PMC, profiles/r03_gemm_geo_regprefetch.md): 5-10 % of the launch at Cin = 4096.
+  // Layout: piece p = rows 2p, 2p + 1 of the tile (512 bytes each, lanes 0-31 / 32-63), 1040 bytes apart (16 bytes of
+  // padding: consecutive rows land on different banks).  Rows past T read as zero through the descriptor's range check;
+  // columns past N read the next row's bytes -- both belong to cells the loop below skips.
+  constexpr int kRefPitch = 1040;
+  bool staged = false;
+  if constexpr (MODE == 0) {
+    staged = ((N & 7) == 0) && ((reinterpret_cast<uintptr_t>(ref) & 15u) == 0);  // 16-byte rows (workgroup-uniform)
+    if (staged) {
+      __syncthreads();  // every wave is done with the operand stages
+      const int64_t origin = ((int64_t)t0 * N + n0) * 2, left = (int64_t)T * N * 2 - origin;
+      const TileDesc rd = make_tile_desc(reinterpret_cast<const uint8_t*>(ref) + origin,
+                                         (int)(left < 0x7FFFFFFF ? left : 0x7FFFFFFF));
+      const i32x4_t rr = rd.words;
+      const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u8_t)smem);
+      const int vrow = (lane >> 5) * N * 2 + (lane & 31) * 16;
+#pragma unroll
+      for (int k = 0; k < 128 / WAVES; ++k) {
+        const int p = wave + WAVES * k;
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(p * kRefPitch));  // (p holds the wave index)
+        const int voff = p * 2 * N * 2 + vrow;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                     :: "s"(m0v), "v"(voff), "s"(rr) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
 #pragma unroll
@@ -214,7 +249,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
           sq += acc[i][j][q * 4 + 2] * rv.z;
           sq += acc[i][j][q * 4 + 3] * rv.w;
         } else if constexpr (MODE == 0) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
+          uint2 rv;
+          if (staged) {
+            const int tl = t - t0, nl = n - n0;
+            rv = *reinterpret_cast<const uint2*>(smem + (tl >> 1) * kRefPitch + (tl & 1) * 512 + nl * 2);
+          } else {
+            rv = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(ref) + off);
+          }
           float rf[4];
           if constexpr (DT == MOQ_BF16) {
             rf[0] = __uint_as_float(rv.x << 16); rf[1] = __uint_as_float(rv.x & 0xFFFF0000u);
@@ -514,6 +555,7 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
                        int64_t tokens, int64_t cout, int64_t cin, int dt, int n_cand, int64_t x_stride,
                        int64_t w_stride, void* stream, float decay = 0.0f, float scale = 0.0f, int upper_only = 0) {
   constexpr int TILE = Geo<GEO>::TILE;
+  constexpr int kLds = launch_lds_bytes<MODE, GEO>();
   int tiles_t = (int)((tokens + TILE - 1) / TILE), tiles_n = (int)((cout + TILE - 1) / TILE);
   if (MODE == 2) {  // the folded upper triangle (gram_tile): (n + 1) x ceil(n / 2) workgroups
     const int n = tiles_n;
@@ -529,18 +571,18 @@ static void launch_geo(const void* x, const void* w, const void* ref, const void
   const uint64_t bit = 1ull << (device & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
     (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_BF16, MODE, GEO>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     (void)hipFuncSetAttribute((const void*)err_gemm_kernel<MOQ_F16, MODE, GEO>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<GEO>());
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const dim3 grid(nblk, (unsigned)n_cand), block(Geo<GEO>::WAVES * 64);
   if (dt == MOQ_BF16) {
-    hipLaunchKernelGGL((err_gemm_kernel<MOQ_BF16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
+    hipLaunchKernelGGL((err_gemm_kernel<MOQ_BF16, MODE, GEO>), grid, block, kLds, S(stream), x, w, ref,
                        bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
                        decay, scale, upper_only);
   } else {
-    hipLaunchKernelGGL((err_gemm_kernel<MOQ_F16, MODE, GEO>), grid, block, lds_bytes<GEO>(), S(stream), x, w, ref,
+    hipLaunchKernelGGL((err_gemm_kernel<MOQ_F16, MODE, GEO>), grid, block, kLds, S(stream), x, w, ref,
                        bias, out, partial, (int)tokens, (int)cout, (int)cin, tiles_t, tiles_n, x_stride, w_stride,
                        decay, scale, upper_only);
   }
