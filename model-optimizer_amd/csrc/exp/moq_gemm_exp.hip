@@ -87,6 +87,10 @@ template <> struct Geo<20> { static constexpr int TILE = 256, WAVES = 4, WN = 2,
 //          kernel on the same shape shows its waves parked (s_waitcnt / barrier) 6 % of the time, GEO 10's 35 %
 //          (profiles/r03_gemm_geo_regprefetch.md)
 template <> struct Geo<21> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
+//   GEO 22 (round 3): GEO 21 with the sixteen pieces of a tile spread EVENLY over a whole K-tile of MFMAs (one after every
+//          fourth MFMA, from a quarter into tile i to a quarter into tile i + 1) instead of one after every second MFMA of
+//          two sub-steps: a request stream without bursts
+template <> struct Geo<22> { static constexpr int TILE = 256, WAVES = 4, WN = 2, NI = 4, NJ = 4, STAGES = 2; };
 template <int GEO> constexpr int row_bytes() { return GEO == 3 ? 64 : kRowBytes; }
 template <int GEO> constexpr int tile_bytes() { return Geo<GEO>::TILE * row_bytes<GEO>(); }
 template <int GEO> constexpr int stage_bytes() { return 2 * tile_bytes<GEO>(); }
@@ -407,7 +411,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16_t (&acc)[NI][NJ], const voi
 //         ONCE when the accumulation is over (moq_symmetrize);
 // MODE 3: `ref` is fp32 [T, N]: partial[block] = sum acc * ref (the dot product <x w^T, ref> of the AWQ Gram search).
 template <int DT, int MODE, int GEO>
-__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 || GEO == 20 || GEO == 21 ? 1 : 2))
+__global__ __launch_bounds__(Geo<GEO>::WAVES * 64, GEO == 0 ? 4 : (GEO == 5 || GEO == 20 || GEO == 21 || GEO == 22 ? 1 : 2))
 void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
                      const void* __restrict__ w,     // [N, K]
                      const void* __restrict__ ref,   // [T, N] (MODE 0)
@@ -452,8 +456,8 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
   const int nk = (K + kBK - 1) / kBK;
   constexpr int TB = tile_bytes<GEO>(), SB = stage_bytes<GEO>();
 
-  if constexpr (GEO == 21) {
-    static_assert(NI == 4 && NJ == 4 && Geo<GEO>::WAVES == 4, "GEO 21: four waves of 4 x 4 MFMA tiles");
+  if constexpr (GEO == 21 || GEO == 22) {
+    static_assert(NI == 4 && NJ == 4 && Geo<GEO>::WAVES == 4, "GEO 21 / 22: four waves of 4 x 4 MFMA tiles");
     const uint8_t* la0 = smem + (wn * NI * 32) * kRowBytes;
     const uint8_t* lb0 = smem + TB + (wt * NJ * 32) * kRowBytes;
     Pack16 a[4][NI], b[4][NJ];  // one register buffer per sub-step of a K-tile
@@ -525,27 +529,45 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
       const int k2 = (kt + 2) * kBK;
       const bool live2 = kt + 2 < nk;
       // first quarter: sub-step 0's MFMAs; the other two sub-steps of THIS tile come out of its stage
+      // (GEO 22: the last four pieces of tile kt + 1 -- whose stage was handed over a K-tile ago -- ride along)
       group(IC<0>{}, [&](auto NC) {
         constexpr int n = decltype(NC)::value;
         if constexpr (n < 8) frag(IC<2>{}, IC<n>{}, so);
         else frag(IC<3>{}, IC<n - 8>{}, so);
+        if constexpr (GEO == 22 && (n & 3) == 3) {
+          if (kt > 0) piece((kt + 1) & 1, (kt + 1) * kBK, IC<12 + (n >> 2)>{}, kt + 1 < nk);
+        }
       });
       // the stage of tile kt is read out (own reads done; the barrier makes it everyone's): it goes back to the DMA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      // second and third quarter: the sixteen pieces of tile kt + 2 into that stage, one after every second MFMA
-      group(IC<1>{}, [&](auto NC) {
-        constexpr int n = decltype(NC)::value;
-        if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<(n >> 1)>{}, live2);
-      });
-      group(IC<2>{}, [&](auto NC) {
-        constexpr int n = decltype(NC)::value;
-        if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<8 + (n >> 1)>{}, live2);
-      });
-      // tile kt + 1 (issued a K-tile ago) has landed once only the sixteen pieces above are still outstanding
-      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if constexpr (GEO == 21) {
+        // second and third quarter: the sixteen pieces of tile kt + 2 into that stage, one after every second MFMA
+        group(IC<1>{}, [&](auto NC) {
+          constexpr int n = decltype(NC)::value;
+          if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<(n >> 1)>{}, live2);
+        });
+        group(IC<2>{}, [&](auto NC) {
+          constexpr int n = decltype(NC)::value;
+          if constexpr ((n & 1) != 0) piece(kt & 1, k2, IC<8 + (n >> 1)>{}, live2);
+        });
+        // tile kt + 1 (issued a K-tile ago) has landed once only the sixteen pieces above are still outstanding
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        // one piece of tile kt + 2 after every fourth MFMA: four per quarter, the last four in the next tile's first quarter
+        group(IC<1>{}, [&](auto NC) {
+          constexpr int n = decltype(NC)::value;
+          if constexpr ((n & 3) == 3) piece(kt & 1, k2, IC<(n >> 2)>{}, live2);
+        });
+        group(IC<2>{}, [&](auto NC) {
+          constexpr int n = decltype(NC)::value;
+          if constexpr ((n & 3) == 3) piece(kt & 1, k2, IC<4 + (n >> 2)>{}, live2);
+        });
+        // tile kt + 1: its last four pieces went out in this tile's first quarter; the eight of tile kt + 2 above are newer
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -554,6 +576,7 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
         constexpr int n = decltype(NC)::value;
         if constexpr (n < 8) frag(IC<0>{}, IC<n>{}, sno);
         else frag(IC<1>{}, IC<n - 8>{}, sno);
+        if constexpr (GEO == 22 && (n & 3) == 3) piece(kt & 1, k2, IC<8 + (n >> 2)>{}, live2);
       });
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // dead pieces / reads of the tail before the epilogue reuses the LDS
@@ -1449,7 +1472,7 @@ static int gemm_geo() {
   static const int geo = [] {
     const char* e = getenv("MOQ_TUNE_GEMM_GEO");
     const int g = e ? atoi(e) : 10;
-    return g < 0 || g > 21 ? 10 : g;
+    return g < 0 || g > 22 ? 10 : g;
   }();
   return geo;
 }
@@ -1574,6 +1597,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
     case 18: launch_geo<MODE, 18>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 20: launch_geo<MODE, 20>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 21: launch_geo<MODE, 21>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
+    case 22: launch_geo<MODE, 22>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     case 6: launch_geo6<MODE>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
     default: launch_geo<MODE, 4>(x, w, ref, bias, out, partial, tokens, cout, cin, dt, n_cand, x_stride, w_stride, stream, decay, scale, upper_only); break;
   }
