@@ -826,12 +826,31 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     } else {
     stage_tile<GEO, true>(rs_w, smem, ld_bytes, 0, K, wave, lane);
     stage_tile<GEO, true>(rs_x, smem + TB, ld_bytes, 0, K, wave, lane);
+    // DIAGNOSTIC (MOQ_TUNE_GEMM_STAT = 1 .. 4, GEO 10, timing only: the loss is replaced by the statistic): s_memtime stamps of
+    // wave 0 around the tile-boundary wait -- 1: ticks per K-tile, 2: ticks parked at the boundary (s_waitcnt + barrier) per
+    // K-tile, 3: ticks between the issue of a tile's first LDS-DMA piece and the boundary wait that needs the tile (the lead),
+    // 4: ticks from kernel start to the end of the K loop, 5: the same in s_memrealtime ticks (constant 100 MHz)
+    const int stat_mode = (GEO == 10 && MODE == 0) ? ((upper_only >> 26) & 7) : 0;
+    unsigned long long st_prev = 0, st_issue = 0, st_sum = 0, st_begin = 0;
+    if (stat_mode) st_begin = stat_mode == 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; ++kt) {
       const int so = (kt & 1) * SB;
       // tile kt landed (own part; the barrier makes it everyone's) and every fragment read of tile kt - 1 has
       // completed -- its last sub-step sits in a[1] / b[1], not yet multiplied
+      unsigned long long st_t1 = 0;
+      if (stat_mode) st_t1 = __builtin_amdgcn_s_memtime();
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();
+      if (stat_mode) {
+        const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();
+        if (kt > 0) {
+          if (stat_mode == 1) st_sum += st_t2 - st_prev;
+          if (stat_mode == 2) st_sum += st_t2 - st_t1;
+          if (stat_mode == 3) st_sum += st_t1 - st_issue;
+        }
+        st_prev = st_t2;
+        st_issue = st_t2;  // GEO 10 issues the next tile's first piece within a few MFMAs of the boundary
+      }
       read_sub(0, so, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NI + NJ, 0);
       if constexpr (GEO == 10) {
@@ -927,6 +946,13 @@ void err_gemm_kernel(const void* __restrict__ x,     // [T, K]
     mma_sub(1);  // last sub-step of the last tile
     // the last tile's "dead" pieces (zero fills of the idle stage) must have landed before the epilogue reuses the LDS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (stat_mode) {
+      if (stat_mode == 4) st_sum = __builtin_amdgcn_s_memtime() - st_begin;
+      if (stat_mode == 5) st_sum = __builtin_amdgcn_s_memrealtime() - st_begin;  // constant 100 MHz
+      if (threadIdx.x == 0)
+        partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = stat_mode >= 4 ? (float)st_sum : (float)st_sum / (float)(nk > 1 ? nk - 1 : 1);
+      return;
+    }
     }
   } else if constexpr (GEO == 3) {
     constexpr int BK3 = 32;
@@ -1562,7 +1588,7 @@ static int64_t launch_gemm(const void* x, const void* w, const void* ref, const 
       const int g = e ? atoi(e) : kTileGroup;
       return g < 1 || g > 64 ? kTileGroup : g;
     }();
-    upper_only = group | (moq_tune("MOQ_TUNE_GEMM_NO_EPILOGUE", 0) ? (1 << 30) : 0);
+    upper_only = group | (moq_tune("MOQ_TUNE_GEMM_NO_EPILOGUE", 0) ? (1 << 30) : 0) | (((int)moq_tune("MOQ_TUNE_GEMM_STAT", 0) & 7) << 26);
   } else {
     // Gram mode: bit 0 stays the upper_only flag, the tile-group size rides above it
     static const int group2 = [] {

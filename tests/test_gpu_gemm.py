@@ -22,7 +22,9 @@ from oracle import oracle  # noqa: E402  (the checker)
 
 DEV = "cuda:0"
 SHAPES = [  # (tokens, cout, cin): ragged tokens / cout, K tail (cin % 64 != 0), multi-tile, single tiny tile
-    (1, 4, 8), (5, 12, 24), (128, 128, 64), (130, 132, 72), (257, 384, 200), (64, 256, 1024), (300, 260, 136)]
+    (1, 4, 8), (5, 12, 24), (128, 128, 64), (130, 132, 72), (257, 384, 200), (64, 256, 1024), (300, 260, 136),
+    # cout % 8 == 0 (the loss epilogue stages out_actual's tile through the LDS) with ragged tokens and partial column tiles
+    (300, 264, 136), (513, 520, 72)]
 
 
 def _ints(shape, dtype, seed, lo=-3, hi=4):
@@ -42,6 +44,28 @@ def test_gemm_nt_exact_on_integer_inputs(dtype, shape):
         bad = (got.view(torch.int16) != want.view(torch.int16)) & ~((got == 0) & (want == 0))
         assert not bad.any(), f"{shape} {dtype} bias={bias is not None}: {int(bad.sum())} of {got.numel()} outputs differ; " \
                               f"first at {bad.nonzero()[0].tolist()}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_err_gemm_out_actual_staged_or_direct_is_the_same(dtype):
+    """out_actual 16-byte aligned: its tile goes through the LDS; 8-byte aligned only: read straight from memory.  Same loss,
+    bit for bit (same cells, same order), on shapes with ragged tokens and a partial column tile."""
+    for t, n, k in [(300, 264, 136), (257, 384, 200), (64, 256, 1024)]:
+        x, w = _ints((t, k), dtype, 14), _ints((n, k), dtype, 15)
+        ref = _ints((t, n), dtype, 16, -8, 9)
+        xd, wd = x.to(DEV), w.to(DEV)
+        buf = torch.zeros(t * n + 8, dtype=dtype, device=DEV)
+        losses = []
+        for shift in (0, 4):  # elements: 0 -> 16-byte aligned (staged), 4 -> 8-byte aligned (direct)
+            rv = buf[shift:shift + t * n].view(t, n)
+            rv.copy_(ref)
+            assert rv.data_ptr() % 16 == (8 if shift else 0)
+            acc = torch.zeros(1, dtype=torch.float32, device=DEV)
+            ops.awq_err_gemm(xd, wd, rv, None, acc)
+            losses.append(acc.item())
+        assert losses[0] == losses[1], (t, n, k, losses)
+        want = oracle.awq_err_gemm(x, w, ref)
+        assert abs(losses[0] - want) <= 2e-6 * abs(want) + 1e-30
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
