@@ -105,6 +105,22 @@ def test_histogram_hot_bins_and_tails():
                 acc = torch.ones(bins, dtype=torch.int64, device=DEV)
                 ops.hist_abs(xv.to(DEV), bins, edge, skip, counts=acc)
                 assert np.array_equal(acc.cpu().numpy(), want + 1)
+                if dtype != torch.float32:
+                    # moq_hist_abs sends 16-bit inputs below 12 M elements to the arithmetic kernel (round 3); the pattern-table
+                    # kernel is reached at any size through the fused input-quantizer entry
+                    tab = torch.zeros(bins, dtype=torch.int64, device=DEV)
+                    ops.input_quant(xv.to(DEV), None, hist_counts=tab, hist_max_edge=edge, hist_skip_zeros=skip)
+                    assert np.array_equal(tab.cpu().numpy(), want), f"table kernel: {name} {dtype} bins={bins}"
+
+
+def test_histogram_table_dispatch_at_flow_size():
+    """13 M elements (26 MB, above moq_hist_abs' 12 M threshold): the pattern-table kernel through moq_hist_abs itself."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(13 * (1 << 20) + 8, generator=g) * torch.exp(torch.randn(1, generator=g))).to(torch.bfloat16)
+    x[::100003] = 0.0
+    for bins, edge, skip in [(2048, 2.5, False), (2048, 1.0, True)]:
+        want = oracle.hist_abs(x, bins, edge, skip).astype(np.int64)
+        assert np.array_equal(ops.hist_abs(x.to(DEV), bins, edge, skip).cpu().numpy(), want)
 
 
 def test_tensor_quantizer_takes_the_fused_pass():
