@@ -30,13 +30,17 @@ __global__ __launch_bounds__(256, 1) void mfma_loop(const uint4* __restrict__ sr
     }
     for (int i = 0; i < 16; ++i) for (int e = 0; e < 16; ++e) out += acc[i][e];
   } else {
-    f32x4 acc[32];
-    for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
+    // sixteen accumulators, two MFMAs per accumulator and iteration (independent chains of length 2 are far enough apart: the
+    // second use of an accumulator comes 16 MFMAs = 256+ cycles after the first)
+    f32x4 acc[16];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) acc[i][e] = 0.0f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 7], b[(i + 3) & 7], acc[i], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 7], b[(i + 3) & 7], acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + 1) & 7], b[(i + 5) & 7], acc[i], 0, 0, 0);
     }
-    for (int i = 0; i < 32; ++i) for (int e = 0; e < 4; ++e) out += acc[i][e];
+    for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) out += acc[i][e];
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x == 0) { ticks[blockIdx.x * 2] = t1 - t0; ticks[blockIdx.x * 2 + 1] = r1 - r0; }
