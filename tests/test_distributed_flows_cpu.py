@@ -46,6 +46,11 @@ class MLP(torch.nn.Module):
         return self.fc3(self.fc2(torch.relu(self.fc1(x))))
 
 
+def _n_batches(world):
+    """an EVEN split for every world (the reference averages the ranks' act-scale means: equal to the single-rank mean only then)"""
+    return 4 if world <= 2 else 2 * world
+
+
 def _batches(d, dtype, n=4):
     g = torch.Generator().manual_seed(5)
     ch = torch.exp(torch.randn(d, generator=g))
@@ -77,7 +82,7 @@ def _job_max_and_smoothquant(rank, world, moa, single):
     activations (batches sharded) bit-equal to the single-rank run."""
     mq = moa.model_quant
     for cfg in (mq.FP8_DEFAULT_CFG, mq.INT8_DEFAULT_CFG, mq.INT8_SMOOTHQUANT_CFG):
-        batches = _batches(128, torch.float32)
+        batches = _batches(128, torch.float32, n=_n_batches(world))
         if single:
             model = moa.quantize(MLP(), copy.deepcopy(cfg), lambda m: [m(b) for b in batches])
         else:
@@ -96,7 +101,7 @@ def _job_weight_side(rank, world, moa, single):
     from safetensors.torch import load_file
 
     mq, sp, ex = moa.model_quant, moa.sparsity, moa.export
-    batches = _batches(128, torch.float32)
+    batches = _batches(128, torch.float32, n=_n_batches(world))
     mine = batches if single else batches[rank::world]
     # 2:4 magnitude masks
     model = sp.sparsify(MLP(), "sparse_magnitude")
@@ -182,7 +187,7 @@ def _job_awq(rank, world, moa, single):
         # W4A8: the per-channel input amax collected in the cache pass is MAX-synchronised before it collapses
         cfg = copy.deepcopy(getattr(mq, preset))
         cfg["algorithm"] = {"method": "awq_lite", "search": search}
-        batches = _batches(128, dtype)
+        batches = _batches(128, dtype, n=_n_batches(world))
         mine = batches if single else batches[rank::world]
         model = moa.quantize(MLP(dtype=dtype), cfg, lambda m: [m(b) for b in mine])
         hs = {n: m.awq_lite for n, m in model.named_modules() if hasattr(m, "awq_lite")}
@@ -328,6 +333,17 @@ def _worker(rank, world, port, kind, ret):
 @pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "tensor_parallel", "weight_side", "undeclared"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {v}" for r, v in dict(ret).items())
+
+
+@pytest.mark.parametrize("kind", ["weight_side", "awq", "max_and_smoothquant"])
+def test_three_replicas_uneven_shards(kind):
+    """world = 3 over a model with fewer linears than that: some rank owns no weight of a given pass (empty shard, nothing to
+    broadcast), the calibration batches split unevenly -- results still equal the single-rank run."""
+    world = 3
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), kind, ret), nprocs=world, join=True)
