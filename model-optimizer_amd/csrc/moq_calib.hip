@@ -40,11 +40,20 @@ __device__ __forceinline__ CandQ<FP8> make_cand(float amax, const IntQ& q) {
   return c;
 }
 
-// squared error of one element under one candidate
-template <bool FP8>
+// squared error of one element under one candidate.  WIN (INT only): the caller has checked ONCE per candidate that the
+// scale is an ordinary number inside the shared division's exact window -- qdq_int_shared's two uniform tests per element
+// are then dead weight in a kernel that is bound by its VALU op count
+template <bool FP8, bool WIN = false>
 __device__ __forceinline__ float sq_err(float x, const CandQ<FP8>& c, const IntQ& q) {
   float y;
-  if constexpr (FP8) {
+  if constexpr (!FP8 && WIN) {
+    const float p = x * c.scale;
+    float t = __builtin_rintf(p);
+    t = t < q.lo ? q.lo : t;
+    t = __builtin_fminf(t, q.hi);
+    t = (p != p) ? p : t;
+    y = shared_div_in_window(t, c.sd);
+  } else if constexpr (FP8) {
     const float a = x * c.scale;
     float ca = __builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f);
     ca = (a != a) ? a : ca;
@@ -95,10 +104,18 @@ __global__ __launch_bounds__(kBlock) void mse_rows_kernel(const void* __restrict
     for (int k = 0; k < n_cand; ++k) {
       const CandQ<FP8> c = make_cand<FP8>(crow[(int64_t)k * axis_size], q);
       float a0 = 0.0f, a1 = 0.0f;  // two chains halve the dependent-add latency
+      if (!FP8 && c.scale != 0.0f && c.sd.fast) {
 #pragma unroll
-      for (int i = 0; i < P * V; i += 2) {
-        a0 += sq_err<FP8>(f[i], c, q);
-        a1 += sq_err<FP8>(f[i + 1], c, q);
+        for (int i = 0; i < P * V; i += 2) {
+          a0 += sq_err<FP8, true>(f[i], c, q);
+          a1 += sq_err<FP8, true>(f[i + 1], c, q);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < P * V; i += 2) {
+          a0 += sq_err<FP8>(f[i], c, q);
+          a1 += sq_err<FP8>(f[i + 1], c, q);
+        }
       }
       float acc = a0 + a1;
 #pragma unroll
@@ -134,8 +151,13 @@ __global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restric
     for (int k = 0; k < n_cand; ++k) {
       const CandQ<FP8> c = make_cand<FP8>(cand[(int64_t)k * axis_size + a], q);
       float acc = 0.0f;
+      if (!FP8 && c.scale != 0.0f && c.sd.fast) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) acc += sq_err<FP8>(f[i], c, q);
+        for (int i = 0; i < V; ++i) acc += sq_err<FP8, true>(f[i], c, q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc += sq_err<FP8>(f[i], c, q);
+      }
 #pragma unroll
       for (int off = LPG / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
       if (live && (threadIdx.x & (LPG - 1)) == 0) {
@@ -159,6 +181,30 @@ __global__ void mse_finalize_kernel(const float* __restrict__ partial, int64_t n
   for (int64_t row = a; row < n_rows; row += axis_size)
     for (int64_t seg = 0; seg < segs_per_row; ++seg) s += partial[(row * segs_per_row + seg) * n_cand + k];
   loss[idx] = accumulate ? loss[idx] + s : s;
+}
+// The same for outputs with MANY work items each (per-tensor: one output per candidate, 57 K segments of a 470 MB weight):
+// one workgroup per output -- thread t adds items t, t + 256, ... in order, the 256 partial sums are folded in a fixed
+// tree.  Deterministic like the serial form, which spent 13 of the sweep's 17.6 ms on 39 threads walking 57 K items each.
+__global__ __launch_bounds__(256) void mse_finalize_wide_kernel(const float* __restrict__ partial, int64_t n_rows,
+                                                                int64_t axis_size, int64_t segs_per_row, int n_cand,
+                                                                float* __restrict__ loss, int accumulate) {
+  __shared__ float sm[256];
+  const int64_t idx = blockIdx.x;  // (k, a)
+  const int k = (int)(idx / axis_size);
+  const int64_t a = idx % axis_size;
+  const int64_t rows_a = (n_rows - a + axis_size - 1) / axis_size, n_items = rows_a * segs_per_row;
+  float s = 0.0f;
+  for (int64_t it = threadIdx.x; it < n_items; it += 256) {
+    const int64_t row = a + (it / segs_per_row) * axis_size, seg = it % segs_per_row;
+    s += partial[(row * segs_per_row + seg) * n_cand + k];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[idx] = accumulate ? loss[idx] + sm[0] : sm[0];
 }
 
 
@@ -295,8 +341,14 @@ extern "C" int moq_mse_sweep(const void* x, int64_t outer, int64_t axis_size, in
                                               n_cand, partial, num_bits, is_unsigned, narrow_range));
   }
   const int64_t n_out = (int64_t)n_cand * axis_size;
-  hipLaunchKernelGGL(mse_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S(stream), partial,
-                     n_rows, axis_size, segs, n_cand, loss, accumulate);
+  const int64_t items_per_out = ((n_rows + axis_size - 1) / axis_size) * segs;
+  if (items_per_out >= 1024 && n_out <= 65535) {
+    hipLaunchKernelGGL(mse_finalize_wide_kernel, dim3((unsigned)n_out), dim3(256), 0, S(stream), partial, n_rows,
+                       axis_size, segs, n_cand, loss, accumulate);
+  } else {
+    hipLaunchKernelGGL(mse_finalize_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, S(stream), partial,
+                       n_rows, axis_size, segs, n_cand, loss, accumulate);
+  }
   return check_launch("moq_mse_sweep");
 }
 

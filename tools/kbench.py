@@ -58,6 +58,7 @@ def main():
     counts_big = torch.zeros(2048, dtype=torch.int64, device=DEV)
     run_amax = torch.zeros(1, dtype=torch.float32, device=DEV)
     pqs = (torch.rand(8192, device=DEV) + 0.5).to(torch.bfloat16)
+    cand39 = torch.linspace(0.1, 4.0, 39, device=DEV).reshape(39, 1)
     amax_x = torch.tensor(xo_max * 0.5, device=DEV)
     ybig = torch.empty_like(xbig)
     cases = [
@@ -98,6 +99,12 @@ def main():
         ("moq_row_hist_np 2048 bins per channel (calibrate_weights)", lambda: ops.row_hist_np(w, 2048), 4 * n),
         ("moq_amax_mid (block amax over a middle dim)", lambda: ops.reduce_block_amax(w.view(rows // 64, 64, cols), {1: 64}), 2 * n),
         ("moq_mx_fused_amax_convert E2M1 / E4M3 scales g=16 (two-level)", lambda: ops.fused_amax_convert(w, 16, "E2M1", "E4M3", amax1), 4 * n),
+        # MseCalibrator.collect: 39 candidate amax values in ONE read (VALU-bound by design: the "GB/s" is the one read; the
+        # reference makes ~5 passes per candidate = 195 x these bytes)
+        ("moq_mse_sweep INT8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, 8), 2 * n),
+        ("moq_mse_sweep INT8 per-channel, 39 candidates", lambda: ops.mse_sweep(w, cand39 * am_c.reshape(1, -1), (1,), 8), 2 * n),
+        ("moq_mse_sweep FP8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, (4, 3)), 2 * n),
+        ("moq_mse_sweep INT4 static g=128, 39 candidates", lambda: ops.mse_sweep(w.view(-1, 128), cand39 * am_g.reshape(1, -1), (1,), 4), 2 * n),
     ]
     print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|")
