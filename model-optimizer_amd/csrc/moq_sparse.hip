@@ -307,6 +307,41 @@ __global__ __launch_bounds__(kBlock) void transpose16_kernel(const uint16_t* __r
   }
 }
 
+// The same for whole tiles of 16-byte aligned matrices (rows % 64 == 0, cols % 64 == 0, y_ld % 8 == 0): 16-byte global
+// loads and stores instead of 2-byte ones, no bounds branch.  A thread loads chunk t % 8 (eight elements) of rows t / 8
+// and t / 8 + 32, parks them in the tile as dwords (pitch 66 elements = 33 dwords: a column walk touches 32 different
+// banks), gathers eight consecutive r of one c back from the tile and stores 16 bytes of y's row c.
+__global__ __launch_bounds__(kBlock) void transpose16_tiles_kernel(const uint16_t* __restrict__ x,
+                                                                   uint16_t* __restrict__ y, int64_t cols,
+                                                                   int64_t y_ld) {
+  __shared__ uint32_t tile[64][33];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x, lr = t >> 3, ch = t & 7;
+  Pack16 v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) v[h] = load16_nt(x + (r0 + lr + 32 * h) * cols + c0 + ch * 8);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    uint32_t* d = &tile[lr + 32 * h][ch * 4];
+    d[0] = v[h].w[0]; d[1] = v[h].w[1]; d[2] = v[h].w[2]; d[3] = v[h].w[3];
+  }
+  __syncthreads();
+  const uint16_t* t16 = reinterpret_cast<const uint16_t*>(&tile[0][0]);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = lr + 32 * h;  // column of x = row of y; ch = which eight consecutive r
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t lo = t16[(ch * 8 + 2 * j) * 66 + c], hi = t16[(ch * 8 + 2 * j + 1) * 66 + c];
+      w[j] = lo | (hi << 16);
+    }
+    Pack16 o;
+    o.w[0] = w[0]; o.w[1] = w[1]; o.w[2] = w[2]; o.w[3] = w[3];
+    store16_nt(y + (c0 + c) * y_ld + r0 + ch * 8, o);
+  }
+}
+
 }  // namespace moq
 
 using namespace moq;
@@ -394,7 +429,14 @@ extern "C" int moq_transpose16_ld(const void* x, void* y, int64_t rows, int64_t 
     set_error("moq_transpose16: too many rows");
     return MOQ_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, S(stream),
-                     reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), rows, cols, y_ld);
+  const bool tiles = rows % 64 == 0 && cols % 64 == 0 && y_ld % 8 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0;
+  if (tiles) {
+    hipLaunchKernelGGL(transpose16_tiles_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, S(stream),
+                       reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), cols, y_ld);
+  } else {
+    hipLaunchKernelGGL(transpose16_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kBlock), 0, S(stream),
+                       reinterpret_cast<const uint16_t*>(x), reinterpret_cast<uint16_t*>(y), rows, cols, y_ld);
+  }
   return check_launch("moq_transpose16");
 }

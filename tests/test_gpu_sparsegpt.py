@@ -17,9 +17,15 @@ CFG = {"pattern": "2:4 sparsity", "col_block_size": 128, "row_block_size": -1, "
 
 
 def test_transpose16():
-    for shape in [(64, 64), (100, 264), (4096, 1000), (7, 9)]:
+    # (whole 64 x 64 tiles of aligned matrices take the 16-byte kernel, everything else the element kernel)
+    for shape in [(64, 64), (100, 264), (4096, 1000), (7, 9), (128, 192), (4096, 4096), (256, 14336), (64, 8)]:
         x = torch.randn(*shape).to(torch.bfloat16)
-        assert torch.equal(ops.transpose16(x.to(DEV)).cpu(), x.t().contiguous())
+        assert torch.equal(ops.transpose16(x.to(DEV)).cpu(), x.t().contiguous()), shape
+    x = torch.randn(129, 128).to(torch.bfloat16).to(DEV)
+    assert torch.equal(ops.transpose16(x[1:]).cpu(), x[1:].t().contiguous().cpu())  # unaligned base (row offset of 256 bytes is aligned, so shift by one element too)
+    buf = torch.randn(128 * 128 + 1).to(torch.bfloat16).to(DEV)
+    xu = buf[1:].view(128, 128)
+    assert torch.equal(ops.transpose16(xu).cpu(), xu.t().contiguous().cpu())
 
 
 @pytest.mark.parametrize("name", ["sgpt_f32", "sgpt_bf16"])

@@ -59,6 +59,10 @@ def main():
     run_amax = torch.zeros(1, dtype=torch.float32, device=DEV)
     pqs = (torch.rand(8192, device=DEV) + 0.5).to(torch.bfloat16)
     cand39 = torch.linspace(0.1, 4.0, 39, device=DEV).reshape(39, 1)
+    q8 = ops.fp8_quantize(w, s448).view(torch.uint8)
+    mxq = ops.mxfp4_quantize(w, 32)
+    wsf_row = (am_c / 127.0).float()
+    hsym = torch.randn(8192, 8192, device=DEV)
     amax_x = torch.tensor(xo_max * 0.5, device=DEV)
     ybig = torch.empty_like(xbig)
     cases = [
@@ -99,6 +103,13 @@ def main():
         ("moq_row_hist_np 2048 bins per channel (calibrate_weights)", lambda: ops.row_hist_np(w, 2048), 4 * n),
         ("moq_amax_mid (block amax over a middle dim)", lambda: ops.reduce_block_amax(w.view(rows // 64, 64, cols), {1: 64}), 2 * n),
         ("moq_mx_fused_amax_convert E2M1 / E4M3 scales g=16 (two-level)", lambda: ops.fused_amax_convert(w, 16, "E2M1", "E4M3", amax1), 4 * n),
+        # entries that had no per-kernel timing before round 3
+        ("moq_fp8_unpack per-tensor (qtensor dequantize)", lambda: ops.fp8_dequantize(q8, s448, torch.bfloat16), 3 * n),
+        ("moq_mxfp4_unpack g=32", lambda: ops.mxfp4_dequantize(mxq[0], mxq[1], torch.bfloat16, 32), n // 2 + n // 32 + 2 * n),
+        ("moq_int8_pack_rows (INT8 SmoothQuant export)", lambda: ops.int8_pack_rows(w, wsf_row), 3 * n),
+        ("moq_awq_weight_scale g=128 (awq_lite get_weight_scale)", lambda: ops.awq_weight_scale(w, 128), 2 * n),
+        ("moq_transpose16 (activation transpose feeding the Gram accumulation)", lambda: ops.transpose16(x), 4 * nx),
+        ("moq_symmetrize 8192 x 8192 fp32 (mirror of an upper-triangle Gram / Hessian)", lambda: ops.symmetrize(hsym), 8 * 8192 * 8192 // 2 * 1),
         # MseCalibrator.collect: 39 candidate amax values in ONE read (VALU-bound by design: the "GB/s" is the one read; the
         # reference makes ~5 passes per candidate = 195 x these bytes)
         ("moq_mse_sweep INT8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, 8), 2 * n),
