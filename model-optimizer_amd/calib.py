@@ -354,6 +354,24 @@ class MseCalibrator(_Calibrator):
         self._losses_sum = None
         self._candidates = None
         self._amax = None
+        self._cand_table = None  # fp32 [K, n] on the device: every candidate amax, built once per calibrator
+        self._loss_acc = None    # fp32 [K, n]: the fused path's running losses (rows are the entries of _losses_sum)
+
+    def _candidate_amax_table(self, device):
+        """All K candidate amax values as ONE fp32 [K, n] device tensor.  Values: exactly what _compute_candidate_amax
+        gives per candidate (0-dim fp32 multiplier x amax tensor on the HOST: float product, one rounding to the amax
+        dtype), formed as one broadcast fp32 product on the tensor's device and rounded to that dtype once -- instead of K host products,
+        K device->host reads of the multiplier and K uploads per collect (a static-block weight has ~460 K amax entries:
+        65 ms per quantizer; an input quantizer paid the 39 synchronisations on every batch)."""
+        if self._cand_table is None or self._cand_table.device != device:
+            # the multipliers come from the HOST linspace (torch's CPU and GPU linspace differ in the last ulp); the product
+            # itself is one IEEE fp32 multiply and one round-to-nearest-even conversion per entry -- the same on any device
+            mult = torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps)  # as _generate_candidates
+            a = self._initial_amax.detach().to(device)
+            # dtype of `amax * 0-dim fp32 multiplier`: the amax dtype for a dimensioned amax, fp32 for a 0-dim one
+            out_dt = torch.result_type(a, mult[0])
+            self._cand_table = (a.float().reshape(1, -1) * mult.to(device).reshape(-1, 1)).to(out_dt).float()
+        return self._cand_table
 
     def _generate_candidates(self, device):
         # calib/mse.py:69-73.  The multipliers are generated on the host and copied: torch's CPU and GPU linspace
@@ -385,13 +403,15 @@ class MseCalibrator(_Calibrator):
         if self._fused_format is not None and self._error_func is None and x.is_cuda and len(candidates) <= 64:
             # candidate amax values with the reference's dtype promotion (0-dim multiplier x amax tensor), then
             # one pass over x for all of them; the fp32 upcast of x (mse.py:92) happens in registers
-            cand = torch.stack([self._compute_candidate_amax(c).float().reshape(-1) for c in candidates])
+            cand = self._candidate_amax_table(x.device)
             nb, uns, narrow = self._fused_format
-            losses = ops.mse_sweep(x.detach(), cand, reduce_axis, nb, uns, narrow)
-            shape = () if reduce_axis is None else None
-            for step in range(len(candidates)):
-                loss = losses[step].reshape(shape) if shape is not None else losses[step]
-                self._losses_sum[step] = loss.clone() if self._losses_sum[step] is None else self._losses_sum[step] + loss
+            # the running sums of all K candidates live in ONE [K, n] tensor (mse_sweep accumulates into it); the list the
+            # reference keeps (`_losses_sum`, read by compute_amax) holds views of its rows
+            first = self._loss_acc is None
+            self._loss_acc = ops.mse_sweep(x.detach(), cand, reduce_axis, nb, uns, narrow, loss=self._loss_acc)
+            if first:
+                rows = self._loss_acc.unbind(0)
+                self._losses_sum = [r.reshape(()) for r in rows] if reduce_axis is None else list(rows)
             return
         x = x.detach().to(dtype=torch.float32)
         for step, candidate in enumerate(candidates):
@@ -404,6 +424,8 @@ class MseCalibrator(_Calibrator):
         self._losses_sum = None
         self._candidates = None
         self._amax = None
+        self._cand_table = None
+        self._loss_acc = None
 
     @torch.no_grad()
     def compute_amax(self, verbose=False):

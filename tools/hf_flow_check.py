@@ -19,7 +19,11 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--batches", type=int, default=4)
-    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq"])
+    ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq",
+                                                          "int8_mse", "fp8_mse", "int4_mse", "int4_awq_clip", "int4_awq_full",
+                                                          "sparse_magnitude", "sparsegpt"],
+                    help="the last rows: the other calibration algorithms of the path (MSE amax search, AWQ clip / full) and the "
+                         "two sparsity modes, for wall-clock at real shapes")
     ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
                     help="mixtral: 8 experts per layer with fused 3-D expert weights (Mixtral-8x7B layer shapes)")
     ap.add_argument("--search", default=None, choices=["auto", "gram", "gemm"], help="awq_lite search engine")
@@ -60,7 +64,28 @@ def run(args, moa=None, dev=None) -> dict:
     loop(model)
     torch.cuda.synchronize()
     t_plain = time.perf_counter() - t0
-    qcfg = {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
+    if args.qformat in ("sparse_magnitude", "sparsegpt"):
+        t0 = time.perf_counter()
+        moa.sparsity.sparsify(model, args.qformat, forward_loop=loop if args.qformat == "sparsegpt" else None)
+        torch.cuda.synchronize()
+        t_sp = time.perf_counter() - t0
+        masks = [m._weight_mask for m in model.modules() if hasattr(m, "_weight_mask")]
+        return {"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
+                "plain_forward_loop_s": round(t_plain, 3), "sparsify_s": round(t_sp, 3), "masked_linears": len(masks),
+                "kept_fraction": round(float(sum(int(m.sum()) for m in masks)) / max(1, sum(m.numel() for m in masks)), 4),
+                **({"note": args.note} if args.note else {})}
+    import copy as _copy
+
+    def with_alg(cfg, alg):
+        c = _copy.deepcopy(cfg)
+        c["algorithm"] = alg
+        return c
+
+    qcfg = {"int8_mse": lambda: with_alg(mq.INT8_DEFAULT_CFG, "mse"), "fp8_mse": lambda: with_alg(mq.FP8_DEFAULT_CFG, "mse"),
+            "int4_mse": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, "mse"),
+            "int4_awq_clip": lambda: with_alg(mq.INT4_AWQ_CFG, "awq_clip"),
+            "int4_awq_full": lambda: with_alg(mq.INT4_AWQ_CFG, "awq_full")}.get(args.qformat)
+    qcfg = qcfg() if qcfg else {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
             "int4_awq": mq.INT4_AWQ_CFG, "w4a8_awq": mq.W4A8_AWQ_BETA_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
             "int8_sq": mq.INT8_SMOOTHQUANT_CFG}[args.qformat]
     if args.search or args.tie_margin is not None:
@@ -85,7 +110,7 @@ def run(args, moa=None, dev=None) -> dict:
     t0 = time.perf_counter()
     state = moa.export.export_state_dict(model, torch.bfloat16,
                                          (lambda: model(torch.ones([1, 2], dtype=torch.long, device=dev)))
-                                         if args.qformat in ("int4_awq", "w4a8_awq") else None)
+                                         if args.qformat in ("int4_awq", "w4a8_awq", "int4_awq_clip", "int4_awq_full") else None)
     torch.cuda.synchronize()
     t_export = time.perf_counter() - t0
     n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
