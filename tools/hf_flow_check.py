@@ -21,6 +21,7 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq",
                                                           "int8_mse", "fp8_mse", "int4_mse", "int4_awq_clip", "int4_awq_full",
+                                                          "int8_percentile", "int8_entropy",
                                                           "sparse_magnitude", "sparsegpt"],
                     help="the last rows: the other calibration algorithms of the path (MSE amax search, AWQ clip / full) and the "
                          "two sparsity modes, for wall-clock at real shapes")
@@ -75,6 +76,22 @@ def run(args, moa=None, dev=None) -> dict:
                 "kept_fraction": round(float(sum(int(m.sum()) for m in masks)) / max(1, sum(m.numel() for m in masks)), 4),
                 **({"note": args.note} if args.note else {})}
     import copy as _copy
+
+    if args.qformat in ("int8_percentile", "int8_entropy"):
+        # the classic histogram flow: per-tensor INT8 input quantizers with histogram calibrators (collected on the device,
+        # the threshold search on the host like the reference), weights max-calibrated
+        hcfg = _copy.deepcopy(mq.INT8_DEFAULT_CFG)
+        hcfg["quant_cfg"]["*input_quantizer"] = {"num_bits": 8, "axis": None, "calibrator": "histogram"}
+        hcfg["algorithm"] = None
+        t0 = time.perf_counter()
+        moa.quantize(model, hcfg)
+        moa.model_calib.histogram_calibrate(model, loop, method=args.qformat.split("_")[1])
+        torch.cuda.synchronize()
+        t_quant = time.perf_counter() - t0
+        n_q = sum(1 for m in model.modules() if isinstance(m, moa.TensorQuantizer) and m.is_enabled)
+        return {"arch": args.arch, "qformat": args.qformat, "layers": args.layers, "batches": args.batches, "tokens_per_batch": 4096,
+                "plain_forward_loop_s": round(t_plain, 3), "quantize_s": round(t_quant, 3), "enabled_quantizers": n_q,
+                **({"note": args.note} if args.note else {})}
 
     def with_alg(cfg, alg):
         c = _copy.deepcopy(cfg)
