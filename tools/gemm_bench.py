@@ -13,11 +13,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _moa_import  # noqa: E402
 
-if "--lib" in sys.argv:  # the experiment library instead of the release one (before the first C-ABI call)
-    from model_optimizer_amd import _lib as _moq_lib  # noqa: E402
-
-    _moa_import.load()
-    _moq_lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+if "--lib" in sys.argv:  # the experiment library instead of the release one: _lib reads MOQ_LIB_PATH when it is first imported
+    os.environ["MOQ_LIB_PATH"] = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 moa = _moa_import.load()
 ops = moa.ops
 DEV = "cuda:0"
