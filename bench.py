@@ -453,7 +453,7 @@ def main():
         "dtype": "bf16 storage, f32 arithmetic",
         "data": "synthetic",
         "config": {"workload": f"{args.model} all {n_tensors} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16), "
-                               f"{wl} calibrate + quantize-dequantize{' in place' if args.inplace else ''}, inputs resident in HBM",
+                               f"{'2:4 magnitude mask (1-byte masks written)' if wl == 'mask24' else wl + ' calibrate + quantize-dequantize'}{' in place' if args.inplace and wl != 'mask24' else ''}, inputs resident in HBM",
                    "format": wl, "model": args.model, "layers": n_layers,
                    "parallelism": f"the {n_tensors} per-layer weight tensors dealt round-robin over {world} GPUs "
                                   f"({len(weights)} on rank 0); one amax bucket all-reduce(MAX), in flight under the QDQ launch"
