@@ -51,6 +51,11 @@ def test_argument_validation_without_gpu():
     assert lib.moq_fp8_pack_tile(P, P, _lib.F16, P, 256, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_INVALID  # scale dtype
     assert lib.moq_fp8_pack_tile(P, P, _lib.BF16, P, 200, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_UNSUPPORTED  # ragged tiles
     assert lib.moq_fp8_unpack_tile(None, P, P, 256, 256, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_INVALID
+    # (round 3: the tile packers index rows and packets in 32 bits -- wider tensors are refused, not wrapped)
+    P16 = ctypes.c_void_p(32)
+    assert lib.moq_fp8_pack_tile(P16, P16, _lib.BF16, P16, 1 << 32, 128, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_UNSUPPORTED
+    assert b"2^31" in lib.moq_last_error()
+    assert lib.moq_fp8_unpack_tile(P16, P16, P16, 1 << 32, 128, 128, 128, _lib.BF16, None) == _lib.MOQ_ERR_UNSUPPORTED
     assert lib.moq_amax_mid(P, 4, 0, 8, _lib.BF16, P, None) == _lib.MOQ_ERR_INVALID                      # empty reduced dim
     assert lib.moq_amax_mid(None, 0, 4, 8, _lib.BF16, None, None) == _lib.MOQ_OK
     assert lib.moq_mx_convert(P, P, 8, 99, None) == _lib.MOQ_ERR_INVALID                                  # unknown format
