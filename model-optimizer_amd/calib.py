@@ -210,14 +210,18 @@ def _compute_amax_percentile(calib_hist, calib_bin_edges, percentile):
     return torch.tensor(calib_bin_edges[idx].item())
 
 
-def _kl_divergence(pk, qk):
+def _kl_divergence(pk, qk, pk_total=None, qk_total=None):
     """scipy.stats.entropy(pk, qk) without its argument-policy wrapper (0.3 ms per call, most of the search): the
-    same three statements on the same arrays -- normalise both, special.rel_entr, sum."""
+    same three statements on the same arrays -- normalise both (x / np.sum(x); scipy's leading `1.0 *` is the
+    identity on fp64), special.rel_entr, sum.  The totals may be handed in when the caller already holds
+    np.sum of the very same array."""
     from scipy.special import rel_entr
+    pk_total = np.add.reduce(pk) if pk_total is None else pk_total
+    qk_total = np.add.reduce(qk) if qk_total is None else qk_total
     with np.errstate(invalid="ignore"):
-        pk = 1.0 * pk / np.sum(pk, axis=0, keepdims=True)
-    qk = 1.0 * qk / np.sum(qk, axis=0, keepdims=True)
-    return np.sum(rel_entr(pk, qk), axis=0)
+        pk = pk / pk_total
+    qk = qk / qk_total
+    return np.add.reduce(rel_entr(pk, qk))
 
 
 def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, stride=1, start_bin=128,
@@ -225,11 +229,13 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
     """KL-divergence threshold search -- calib/histogram.py:210-283.
 
     Same arithmetic as the reference's loop, candidate by candidate, with its slow steps replaced by exact
-    equivalents (about 4x faster on the host, identical divergences bit for bit -- tests/test_host_cpu.py):
+    equivalents (about 5x faster on the host, identical divergences bit for bit -- tests/test_host_cpu.py):
       * `np.digitize(range(i), np.linspace(0, i, nbins + 1)) - 1`: nbins is a power of two, so every edge k*i/nbins
         is exact in fp64 and the bucket of source bin j is floor(j * nbins / i);
       * `np.add.at` of the counts: integer-valued fp64 sums below 2^53 are exact in any order (np.bincount);
-      * `Counter(digitized.tolist())`: the number of non-empty source bins per bucket (np.bincount).
+      * `Counter(digitized.tolist())`: the number of non-empty source bins per bucket (np.bincount);
+      * the two totals of the count check are the very sums scipy.stats.entropy normalises by (np.sum of the same
+        array, same pairwise order), so each is formed once.
     The floating-point part (division, the two totals, the entropy formula) is the reference's, on identical arrays."""
     bins = calib_hist.astype(np.int64).copy()
     bins[0] = bins[1]
@@ -239,27 +245,34 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
     bins_f = bins.astype(np.float64)
     tail = np.concatenate([np.cumsum(bins[::-1])[::-1], [0]])  # tail[i] = sum(bins[i:]), exact
     j_scaled = np.arange(len(bins), dtype=np.int64) * nbins
+    all_nonzero = bool(nonzero.all())
     divergences = []
     for i in range(start_bin, len(bins) + 1, stride):
         valid = nonzero[:i]
-        bucket = (j_scaled[:i] // i)[valid]
-        sums = np.bincount(bucket, weights=bins_f[:i][valid], minlength=nbins)
+        bucket = j_scaled[:i] // i
+        weights = bins_f[:i]
+        if not all_nonzero:
+            bucket, weights = bucket[valid], weights[valid]
+        sums = np.bincount(bucket, weights=weights, minlength=nbins)
         members = np.bincount(bucket, minlength=nbins)
         new_density_counts = np.zeros(nbins, dtype=np.float64)
-        hit = members > 0
-        new_density_counts[hit] = sums[hit] / members[hit]
-        new_density = np.zeros(i, dtype=np.float64)
-        new_density[valid] = new_density_counts[bucket]
-        total_counts_new = np.sum(new_density) + tail[i]
+        np.divide(sums, members, out=new_density_counts, where=members > 0)
+        if all_nonzero:
+            new_density = new_density_counts[bucket]
+        else:
+            new_density = np.zeros(i, dtype=np.float64)
+            new_density[valid] = new_density_counts[bucket]
+        new_sum = np.add.reduce(new_density)
         reference_density = bins_f[:i].copy()
         reference_density[-1] += tail[i]
-        total_counts_old = np.sum(reference_density)
+        old_sum = np.add.reduce(reference_density)
+        total_counts_new, total_counts_old = new_sum + tail[i], old_sum
         if round(total_counts_new) != total_data or round(total_counts_old) != total_data:
             raise RuntimeError(f"Count mismatch! total_counts_new={total_counts_new}, "
                                f"total_counts_old={total_counts_old}, total_data={total_data}")
         # NB: the reference's _normalize_distr rebinds a local and normalises nothing (histogram.py:217-220);
         # scipy.stats.entropy normalises both arguments itself, so the result is the same either way.
-        divergences.append(_kl_divergence(reference_density, new_density))
+        divergences.append(_kl_divergence(reference_density, new_density, old_sum, new_sum))
     divergences = np.array(divergences)
     if divergences_out is not None:
         divergences_out.extend(divergences.tolist())

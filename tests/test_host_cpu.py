@@ -57,15 +57,19 @@ def _entropy_divergences_textbook(hist, num_bits, unsigned, stride, start_bin):
     return np.array(out)
 
 
+@pytest.mark.parametrize("dense", [False, True], ids=["with_empty_bins", "no_empty_bins"])
 @pytest.mark.parametrize("num_bits,unsigned,nb,stride,start", [(8, False, 2048, 1, 128), (8, True, 2048, 3, 128),
                                                                  (4, False, 777, 1, 16), (6, False, 1500, 7, 100)])
-def test_entropy_search_is_the_reference_loop_bit_for_bit(num_bits, unsigned, nb, stride, start):
+def test_entropy_search_is_the_reference_loop_bit_for_bit(num_bits, unsigned, nb, stride, start, dense):
     """calib._compute_amax_entropy replaces digitize / add.at / Counter by exact integer equivalents: every
     divergence must equal the textbook loop's bit for bit (zeros, gaps and a heavy tail included)."""
     rng = np.random.default_rng(nb + num_bits)
     hist = (rng.exponential(1.0, nb) * 1e6 * np.exp(-np.arange(nb) / (nb / 6))).astype(np.int64)
-    hist[rng.integers(0, nb, nb // 10)] = 0          # empty bins
-    hist[nb // 2: nb // 2 + 40] = 0                   # a gap wider than a bucket
+    if dense:
+        hist += 1                                     # every bin occupied: the search's gather-free branch
+    else:
+        hist[rng.integers(0, nb, nb // 10)] = 0      # empty bins
+        hist[nb // 2: nb // 2 + 40] = 0               # a gap wider than a bucket
     hist[-1] = 12345
     got = []
     edges = np.linspace(0, 1.0, nb + 1, dtype=np.float32)
