@@ -12,10 +12,13 @@ One step = one pass of the hot path over ALL linear weights of a synthetic Llama
     mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
              apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
              the whole model in one launch; 4 + 4 B/element.  Use with --model llama3-70b.
-`value` = weight bytes of the WHOLE model (2 B/element) / wall time per step.  Multi-GPU is STRONG scaling: the 224
-per-layer weight tensors are dealt round-robin over the ranks (distributed.shard_list: independent units, no
-data-path collective); the only exchange is one bucketed all-reduce(MAX) that leaves every rank with all 224 amax
-values (a rank contributes zeros -- the abs-max identity -- for the tensors it does not own).
+`value` = weight bytes of the WHOLE pool (2 B/element) / wall time per step.  Multi-GPU (default --scaling weak): the
+pool is N x the model's 224 per-layer weight tensors (N = 8: 111.7 GB, the size of the 8-GPU pools BASELINE configs[3] /
+[4] are quoted on), partitioned over the ranks, 224 tensors each (independent units, no data-path collective); the only
+exchange is one bucketed all-reduce(MAX) that leaves every rank with all N x 224 amax values (a rank contributes zeros
+-- the abs-max identity -- for the tensors it does not own).  Every N > 1 line also carries the STRONG-scaling leg of
+the same run in `extra.strong_scaling` (ONE model's 224 tensors dealt round-robin over the ranks, 1.75 GB per rank at
+N = 8: a 0.8 ms step that mostly measures launch + collective latency); `--scaling strong` makes that the headline.
 
 `extra` (rank 0, outside the timed region) carries the other half of BASELINE.json's metric and the north-star
 target: the INT4-AWQ PTQ wall-clock of the full synthetic Llama-3-8B (tools/awq_bench.py, calibration batches sharded
@@ -55,16 +58,22 @@ def layer_shapes(model):
     return [(h, h), (kv, h), (kv, h), (h, h)] + [(i, h), (i, h), (h, i)] * experts  # q k v o, (gate up down) x experts
 
 
-def make_weights(model, n_layers, device, seed=1234, rank=0, world=1):
-    """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU; tensor i of the model's list is
-    seeded by its index and lives on rank i % world (round-robin shard of the per-layer tensors).
-    Returns (tensors of this rank, their indices in the model's list, number of tensors of the whole model)."""
+def make_weights(model, n_layers, device, seed=1234, rank=0, world=1, scaling="strong"):
+    """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU; tensor i of the pool is seeded by its
+    index.  strong: the pool is the model's list, tensor i lives on rank i % world (round-robin shard of the per-layer
+    tensors).  weak: the pool is `world` times the model's list and rank r holds entries [r * len, (r + 1) * len).
+    Returns (tensors of this rank, their indices in the pool, number of tensors of the whole pool)."""
     shapes = [shape for _ in range(n_layers) for shape in layer_shapes(model)]
+    if scaling == "weak" and world > 1:
+        first, n_model = rank * len(shapes), len(shapes)
+        shapes = shapes * world
+        mine = range(first, first + n_model)
+    else:
+        mine = range(rank, len(shapes), world)
     g = torch.Generator(device=device)
     ws, idx = [], []
-    for i, shape in enumerate(shapes):
-        if i % world != rank:
-            continue
+    for i in mine:
+        shape = shapes[i]
         g.manual_seed(seed + i)
         w = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
         m = torch.rand(shape, generator=g, device=device) < 0.001
@@ -194,6 +203,9 @@ def main():
     ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mxfp4-sq", "mask24"])
     ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
     ap.add_argument("--layers", type=int, default=0, help="0 = all layers of the model")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank holds one model's worth of tensors (the pool grows with N); strong = ONE "
+                         "model's tensors dealt over the ranks.  The other leg is measured too and reported in extra")
     ap.add_argument("--group-mb", type=int, default=0,
                     help="fp8/int8: calibrate+QDQ in groups of <= this many MB of weights (second read from the "
                          "Infinity Cache) instead of two whole-model passes; 0 = off")
@@ -263,9 +275,11 @@ def main():
     from model_optimizer_amd.multi_tensor import SegmentTable
 
     n_layers = args.layers or MODELS[args.model][2]
-    weights, owned, n_tensors = make_weights(args.model, n_layers, dev, rank=rank, world=world)
+    weights, owned, n_tensors = make_weights(args.model, n_layers, dev, rank=rank, world=world, scaling=args.scaling)
     n_local = sum(w.numel() for w in weights)
-    n_elem = sum(r * c for _ in range(n_layers) for r, c in layer_shapes(args.model))  # the whole model
+    n_model_elem = sum(r * c for _ in range(n_layers) for r, c in layer_shapes(args.model))  # one model
+    weak = args.scaling == "weak" and world > 1
+    n_elem = n_model_elem * (world if weak else 1)  # the whole pool
     wl = args.workload
     owned_idx = torch.tensor(owned, dtype=torch.int64, device=dev)
     amax_all = torch.zeros(n_tensors, dtype=torch.float32, device=dev)  # every rank ends with every tensor's amax
@@ -404,7 +418,7 @@ def main():
         elapsed = t.item()
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = n_elem * 2 / (elapsed / args.steps) / 1e9  # the whole model's weights, whatever the number of ranks
+    value = n_elem * 2 / (elapsed / args.steps) / 1e9  # the whole pool's weights: what all ranks processed
 
     # dominant kernel: average launch duration from the HIP events recorded inside the timed region
     dom_all = [a.elapsed_time(b) for a, b in dom_events]
@@ -418,9 +432,9 @@ def main():
     # PMC traffic comes from the committed single-GPU profile of the same launch over the whole model; a rank that
     # owns a share of the tensors moves that share of it (the kernel's traffic is proportional to its elements)
     traffic, traffic_src = pmc_traffic(wl, args.model, n_layers)
-    if traffic is not None and world > 1:
-        traffic = int(traffic * n_local / n_elem)
-        traffic_src = f"{traffic_src}, scaled to rank 0's {n_local / n_elem:.4f} of the elements"
+    if traffic is not None and n_local != n_model_elem:
+        traffic = int(traffic * n_local / n_model_elem)
+        traffic_src = f"{traffic_src}, scaled to rank 0's {n_local / n_model_elem:.4f} of the model's elements"
     roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
@@ -448,15 +462,17 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if weak or world == 1 else "strong",
         "vs_baseline": None,
         "dtype": "bf16 storage, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} all {n_tensors} linear weights ({n_elem * 2 / 1e9:.2f} GB bf16), "
+        "config": {"workload": f"{args.model} all {n_tensors // (world if weak else 1)} linear weights"
+                               f"{f' x {world} (one set per GPU)' if weak else ''} ({n_elem * 2 / 1e9:.2f} GB bf16), "
                                f"{'2:4 magnitude mask (1-byte masks written)' if wl == 'mask24' else wl + ' calibrate + quantize-dequantize'}{' in place' if args.inplace and wl != 'mask24' else ''}, inputs resident in HBM",
                    "format": wl, "model": args.model, "layers": n_layers,
-                   "parallelism": f"the {n_tensors} per-layer weight tensors dealt round-robin over {world} GPUs "
-                                  f"({len(weights)} on rank 0); one amax bucket all-reduce(MAX), in flight under the QDQ launch"
+                   "parallelism": (f"a pool of {n_tensors} per-layer weight tensors partitioned over {world} GPUs "
+                                   f"({len(weights)} on rank 0{', round-robin' if not weak else ''}); one amax bucket "
+                                   f"all-reduce(MAX) of {n_tensors} values, in flight under the QDQ launch")
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
     }
@@ -473,6 +489,55 @@ def main():
         b.record()
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
+
+    def strong_leg():
+        """The STRONG-scaling leg of an N > 1 run: ONE model's tensors (list index i % world == rank of this rank's own set:
+        same shapes and distribution as a round-robin deal of one model) through the same step -- abs-max, the 224-value
+        bucket in flight under the QDQ launch -- timed like the headline (barriers, max over ranks)."""
+        pick = [i for i in range(len(weights)) if i % world == rank]
+        sub = [weights[i] for i in pick]
+        sub_idx = torch.tensor(pick, dtype=torch.int64, device=dev)
+        bucket = torch.zeros(len(weights), dtype=torch.float32, device=dev)
+        if wl == "mask24":
+            stab = SegmentTable(sub, outputs=[masks[i] for i in pick])
+        else:
+            stab = SegmentTable(sub, outputs=[tab.outputs[i] for i in pick], group_size=128 if wl == "int4g128" else None)
+
+        def one():
+            if wl in ("fp8", "int8"):
+                stab.calibrate_amax()
+                bucket.zero_()
+                bucket[sub_idx] = stab.amax_flat
+                work = dist.all_reduce(bucket, op=dist.ReduceOp.MAX, async_op=True)
+                stab.fake_quant_e4m3() if wl == "fp8" else stab.fake_quant_int(8, False, True)
+                work.wait()
+            elif wl == "int4g128":
+                stab.amax_qdq_int_group(4, False, False)
+            elif wl == "mxfp4":
+                stab.mx_fused_amax_convert(32, "E2M1")
+            else:
+                stab.mask_2to4()
+
+        for _ in range(max(args.warmup, 3)):
+            one()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_step = t.item() / args.steps
+        return {"value": round(n_model_elem * 2 / per_step / 1e9, 2), "unit": "GB/s", "ms_per_step": round(per_step * 1e3, 4),
+                "steps": args.steps, "scaling": "strong",
+                "workload": f"{args.model} all {len(weights)} linear weights ({n_model_elem * 2 / 1e9:.2f} GB bf16) dealt "
+                            f"round-robin over {world} GPUs ({len(pick)} on rank 0), one amax bucket of {len(weights)} values"}
+
+    if use_dist and (weak or world == 1) and groups is None and wl != "mxfp4-sq":
+        # (every rank runs it: it contains collectives)
+        leg = strong_leg()
+        if not args.no_extra or world > 1:
+            extra["strong_scaling"] = leg
 
     if not args.no_extra and world == 1:
         # secondary measurements on the same resident weights (not part of `value`)
