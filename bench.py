@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--no-hf", action="store_true", help="extra: skip the INT4-AWQ flow on the random-init HF Llama-3-8B")
     ap.add_argument("--awq-layers", type=int, default=32, help="extra: layers of the INT4-AWQ wall-clock run (0 = skip)")
     ap.add_argument("--awq-batches", type=int, default=64, help="extra: calibration batches of 4096 tokens in total")
+    ap.add_argument("--awq-watchdog-s", type=float, default=240.0,
+                    help="N > 1: print the line without the AWQ extra if that flow has not finished after this many seconds")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -604,6 +606,34 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # a reported extra, never a reason to lose the main result
             extra["llama3_70b_int4g128_inplace"] = {"failed": f"{type(e).__name__}: {e}"}
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: rank 0 times it too, after the timed region; the other ranks wait at the next collective)
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
+            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {type(e).__name__}: {e}"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    watchdog = None
+    if world > 1 and not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b":
+        # The AWQ flow below is the first time its collectives (object gathers, GiB-sized Gram reduces) meet more than
+        # one rank on hardware.  A collective that never returns must not take the measured headline with it: if the flow
+        # has not finished in time, rank 0 prints the line without it and every rank leaves.
+        import threading
+
+        def give_up(limit=args.awq_watchdog_s):
+            if rank == 0:
+                o = dict(out)
+                o["extra"] = dict(extra, awq_wallclock_s=None,
+                                  awq={"failed": f"watchdog: the {world}-rank AWQ flow had not finished after {limit} s"})
+                print(json.dumps(o), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(args.awq_watchdog_s, give_up)
+        watchdog.daemon = True
+        watchdog.start()
     if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b":
         # the second half of BASELINE.json's metric: INT4-AWQ PTQ wall-clock (awq_lite g128, alpha_step 0.1, default
         # search) of the synthetic Llama-3-8B linear stack; every rank holds the linears, the calibration batches
@@ -621,6 +651,8 @@ def main():
         except Exception as e:
             extra["awq_wallclock_s"] = None
             extra["awq"] = {"failed": f"{type(e).__name__}: {e}"}
+        if watchdog is not None:
+            watchdog.cancel()
     if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b" and world == 1 and not args.no_hf:
         # the other AWQ case: a random-init Hugging Face Llama-3-8B (real decoder topology: attention, norms, the
         # inputs of q/k/v and gate/up shared), whose activations have no outlier channels -- all 11 candidates of a linear
@@ -641,16 +673,6 @@ def main():
             extra["awq_hf_random_init"] = {"failed": f"{type(e).__name__}: {e}"}
     if extra:
         out["extra"] = extra
-
-    if rank == 0 and not args.no_cpu_baseline:
-        # (N > 1: rank 0 times it too, after the timed region; the other ranks wait at the group's teardown)
-        try:
-            out["cpu_baseline"] = cpu_baseline(wl)
-        except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
-            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"failed: {type(e).__name__}: {e}"}
-    elif rank == 0:
-        out["cpu_baseline"] = None
 
     if use_dist:
         # tear the communicator down with fd 1 on stderr as well (anything RCCL still has to say), THEN print: the result
