@@ -76,3 +76,21 @@ def test_calibrate_weights_matches_reference_run(golden):
         calib.calibrate_weights(lin, percentile=101)
     with pytest.raises(TypeError):
         calib.calibrate_weights(lin, method="entropy")
+
+
+@pytest.mark.parametrize("perchannel", [True, False])
+def test_calibrate_weights_mse_threshold(perchannel):
+    """method="mse" (unpinned: the reference's search returns a constant, see calib._compute_amax_mse): every channel
+    gets the centre of one of its histogram bins, below its abs-max, and equals the per-row search on that row alone."""
+    gen = torch.Generator().manual_seed(5)
+    w = (torch.randn(12, 700, generator=gen) * torch.exp(torch.randn(12, 1, generator=gen))).to(DEV)
+    lin = _Lin(w)
+    calib.calibrate_weights(lin, method="mse", perchannel=perchannel, num_bins=512)
+    got = lin.weight_quantizer.amax.float().cpu()
+    rows = w if perchannel else w.reshape(1, -1)
+    assert got.shape == ((12, 1) if perchannel else ())
+    counts, edges = ops.row_hist_np(rows, 512)
+    for r in range(rows.shape[0]):
+        one = calib._compute_amax_mse(counts[r].to(torch.int64), edges[r], 8, False).cpu()
+        assert torch.equal(got.reshape(-1)[r], one.float())
+        assert 0 < one.item() <= rows[r].abs().max().item()

@@ -78,6 +78,36 @@ def test_histogram_calibrator_matches_reference(golden):
         assert cal.compute_amax("mse", start_bin=64) > 0  # unpinned (reference defect, see calib.py)
 
 
+@pytest.mark.parametrize("num_bits,unsigned,nb,stride,start", [(8, False, 2048, 1, 128), (4, False, 300, 1, 16),
+                                                                 ((4, 3), False, 512, 3, 64), (8, True, 2048, 7, 128)])
+def test_histogram_mse_threshold_is_the_candidate_loop(num_bits, unsigned, nb, stride, start):
+    """calib._compute_amax_mse evaluates every candidate in one per-row QDQ launch: same pick as the loop form it
+    replaces (one QDQ of the bin centres + count-weighted mean per candidate, first strict minimum), whose per-candidate
+    errors must agree to fp32 reduction-order noise."""
+    gen = torch.Generator().manual_seed(nb + start)
+    x = (torch.randn(1 << 18, generator=gen) * torch.exp(0.7 * torch.randn(1 << 18, generator=gen))).abs()
+    counts = torch.histc(x, bins=nb, min=0, max=float(x.max())).to(torch.int64).to(DEV)
+    edges = torch.linspace(0, float(x.max()), nb + 1)
+    got = calib._compute_amax_mse(counts, edges, num_bits, unsigned, stride, start)
+    e = edges.float().to(DEV)
+    centers = ((e[1:] + e[:-1]) / 2).contiguous()
+    c = counts.float()
+    errs = []
+    for i in range(start, nb, stride):
+        amax = centers[i:i + 1]
+        q = ops.fake_tensor_quant(centers, amax, num_bits, unsigned) if isinstance(num_bits, int) else ops.scaled_e4m3(centers, amax)
+        errs.append((((q - centers) ** 2) * c).mean().item())
+    errs = torch.tensor(errs, dtype=torch.float64)
+    picked = ((centers - got).abs().argmin().item() - start) // stride
+    assert errs[picked] <= errs.min() * (1 + 1e-5)           # the pick is a minimum of the loop form's errors ...
+    if (errs <= errs.min() * (1 + 1e-5)).sum() == 1:
+        assert picked == int(errs.argmin())                    # ... and THE minimum when that is unambiguous
+    with pytest.raises(ValueError, match="no candidate"):
+        calib._compute_amax_mse(counts, edges, num_bits, unsigned, stride, nb)
+    with pytest.raises(TypeError, match="Invalid num_bits"):
+        calib._compute_amax_mse(counts, edges, (5, 2), unsigned, stride, start)
+
+
 def test_awq_weight_scale_vs_oracle_and_reference(golden):
     g = golden("awq")
     for k, c in g.cases.items():

@@ -25,7 +25,7 @@ SELECTED = {
                       "test_tensor_quantizer_block_matches_reference", "test_max_calibrator_matches_reference",
                       "test_histogram_calibrator_matches_reference", "test_awq_weight_scale_vs_oracle_and_reference",
                       "test_sequential_quantizer_w4a8_matches_reference", "test_tensor_quantizer_2d_blocks_match_reference",
-                      "test_two_level_block_format_flow_and_dynamic_type"],
+                      "test_two_level_block_format_flow_and_dynamic_type", "test_histogram_mse_threshold_is_the_candidate_loop"],
     "test_gpu_mse": ["test_mse_calibrator_matches_reference", "test_quantize_mse_flow_matches_reference"],
     "test_gpu_export": ["test_export_from_reference_state_is_byte_identical", "test_fp8_export_from_reference_state_is_byte_identical",
                         "test_mxfp4_export_is_byte_identical", "test_int8_smoothquant_export_from_reference_state_is_byte_identical",
@@ -35,7 +35,8 @@ SELECTED = {
                         "test_smoothquant_mxfp4_composition_on_gpu"],
     "test_gpu_input_quant": ["test_tensor_quantizer_takes_the_fused_pass",
                              "test_histogram_calibrator_later_batches_are_one_pass"],
-    "test_gpu_calibrate_weights": ["test_row_hist_equals_numpy_on_reference_weights", "test_calibrate_weights_matches_reference_run"],
+    "test_gpu_calibrate_weights": ["test_row_hist_equals_numpy_on_reference_weights", "test_calibrate_weights_matches_reference_run",
+                                   "test_calibrate_weights_mse_threshold"],
     "test_gpu_fp8_2d": ["test_fp8_qtensor_2d_blocks_match_reference_run", "test_fp8_2d_blockwise_export_is_byte_identical",
                         "test_reduce_block_amax_and_padding"],
     "test_gpu_mxfp8": ["test_mxfp8_qtensor_matches_reference_run", "test_mxfp8_rejects_wrong_scale_dtype_and_block",
