@@ -305,7 +305,9 @@ def fold_weight(model: nn.Module, keep_attrs: bool = False, shard_weights: bool 
             units += [(w.data if hasattr(w, "data") else w, q) for w, q in m.iter_weights_for_calibration()
                       if isinstance(q, TensorQuantizer) and q.fake_quant]
     shard = mdist.resolve_shard(shard_weights)
-    mine = mdist.shard_list(units) if shard else units
+    # only contiguous weights can be received in place from their owner; the (rare) others are folded by every rank
+    dealt = [u for u in units if u[0].is_contiguous()] if shard else []
+    mine = mdist.shard_list(dealt) + [u for u in units if not u[0].is_contiguous()] if shard else units
     with torch.no_grad():
         groups, single = {}, []
         for w, wq in mine:
@@ -332,7 +334,7 @@ def fold_weight(model: nn.Module, keep_attrs: bool = False, shard_weights: bool 
         for w, wq in single:
             w.copy_(wq(w.contiguous()).to(w.dtype))
         if shard:
-            mdist.broadcast_from_owners([w for w, _ in units], group=mdist.replica_group())
+            mdist.broadcast_from_owners([w for w, _ in dealt], group=mdist.replica_group())
         seen = set()
         for _, wq in units:
             if id(wq) in seen:

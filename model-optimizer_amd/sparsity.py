@@ -313,8 +313,8 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
             if users[own] == 0:
                 del prepared[own]
         if placed is not None:
-            mdist.broadcast_from_owners([masks[m].contiguous() if masks[m].is_contiguous() else masks[m] for _, m in targets],
-                                        group=mdist.replica_group(),
+            # (received IN PLACE: the list must hold the mask tensors themselves; they are contiguous by construction)
+            mdist.broadcast_from_owners([masks[m] for _, m in targets], group=mdist.replica_group(),
                                         owners=[placed[owner_of.get(m, m)] for _, m in targets])
     else:
         raise ValueError(f"sparsity mode {mode!r} is outside this path")
