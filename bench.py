@@ -1,9 +1,8 @@
 """bench.py -- GB/s of weights calibrated + quantize-dequantized on MI355X (BASELINE.json metric).
 
-One step = one pass of the hot path over ALL linear weights of a synthetic Llama-3-8B (224 tensors,
-6.98 G elements, 13.96 GB bf16), already resident in HBM:
-    fp8      (default, BASELINE configs[1]): per-tensor abs-max of every weight (one multi-tensor launch),
-             [N>1: ONE bucketed RCCL all-reduce(MAX) of the 224 amax values -- the reference's
+One step = one pass of the hot path over ALL linear weights of a synthetic model, already resident in HBM:
+    fp8      (default): per-tensor abs-max of every weight (one multi-tensor launch),
+             [N>1: ONE bucketed RCCL all-reduce(MAX) of all amax values -- the reference's
              sync_amax_across_distributed_group, model_calib.py:390-407], per-tensor FP8-E4M3 QDQ of every
              weight (one multi-tensor launch).      algorithmic HBM bytes: 2 + 4 = 6 B/element
     int4g128 (BASELINE configs[2] weight side / north-star kernel): fused per-group(128) abs-max + INT4 QDQ,
@@ -11,20 +10,34 @@ One step = one pass of the hot path over ALL linear weights of a synthetic Llama
     mxfp4, mask24, int8 : the other formats of the path, for the record.
     mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
              apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
-             the whole model in one launch; 4 + 4 B/element.  Use with --model llama3-70b.
-`value` = weight bytes of the WHOLE pool (2 B/element) / wall time per step.  Multi-GPU (default --scaling weak): the
-pool is N x the model's 224 per-layer weight tensors (N = 8: 111.7 GB, the size of the 8-GPU pools BASELINE configs[3] /
-[4] are quoted on), partitioned over the ranks, 224 tensors each (independent units, no data-path collective); the only
-exchange is one bucketed all-reduce(MAX) that leaves every rank with all N x 224 amax values (a rank contributes zeros
--- the abs-max identity -- for the tensors it does not own).  Every N > 1 line also carries the STRONG-scaling leg of
-the same run in `extra.strong_scaling` (ONE model's 224 tensors dealt round-robin over the ranks, 1.75 GB per rank at
-N = 8: a 0.8 ms step that mostly measures launch + collective latency); `--scaling strong` makes that the headline.
+             the whole model in one launch; 4 + 4 B/element.
+`value` = weight bytes of the WHOLE pool (2 B/element) / wall time per step.
+
+Which model (when --model is not given):
+    N = 1 : Llama-3-8B (224 tensors, 13.96 GB) -- BASELINE configs[1], the configuration the metric is quoted on.
+    N > 1 : STRONG scaling of the multi-GPU configuration BASELINE.json names for the format -- ONE model's tensors dealt
+            over the ranks (largest first, round-robin: every rank gets the same number of tensors of every shape), no
+            data-path collective, one amax bucket all-reduce(MAX) in flight under the QDQ launch:
+              fp8 / int8 / mask24        -> Mixtral-8x7B (configs[3]; 896 tensors, 92.9 GB: 11.6 GB per rank at N = 8)
+              int4g128 / mxfp4 / mxfp4-sq -> Llama-3-70B (configs[4]; 560 tensors, 136.9 GB: 17.1 GB per rank at N = 8)
+            Both fit ONE MI355X in place, so `--model mixtral-8x7b` / `--model llama3-70b` at N = 1 is the base of that
+            curve; the default N = 1 line carries it as extra.scale_base_n1 (same step, same model, one GPU).
+            `--scaling weak` (every rank holds one model's worth; the pool grows with N) is kept as a switch and the
+            weak leg of the default run is reported in extra.weak_scaling -- it is not a BASELINE configuration.
 
 `extra` (rank 0, outside the timed region) carries the other half of BASELINE.json's metric and the north-star
 target: the INT4-AWQ PTQ wall-clock of the full synthetic Llama-3-8B (tools/awq_bench.py, calibration batches sharded
 over the ranks) and, at N = 1, the fused per-group amax + INT4 QDQ kernel over all Llama-3-70B weights in place.
+The CPU baseline runs LAST and in a process of its own (`--cpu-baseline-only`): its OpenMP runtime never shares a
+process with a timed flow.
 
-Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.
+Contract: python bench.py --gpus N --steps K --warmup W ; one JSON line on rank 0.  `--gpus N` without a launcher
+(no WORLD_SIZE in the environment) re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`; under torchrun (the driver's form) it runs as the rank it is.
+
+RULE: no edit of this file ships without ONE full default run (`python bench.py --gpus 1 --steps 20 --warmup 5`, all
+extras) after it, its line committed under profiles/ -- round 3 shipped an order change that was only ever run with
+shortened extras and the driver's AWQ figure came out 2.4x the claimed one.
 """
 
 from __future__ import annotations
@@ -58,10 +71,19 @@ def layer_shapes(model):
     return [(h, h), (kv, h), (kv, h), (h, h)] + [(i, h), (i, h), (h, i)] * experts  # q k v o, (gate up down) x experts
 
 
+def deal(shapes, rank, world):
+    """Strong-scaling deal of a model's tensors over the ranks: pool indices sorted largest tensor first (ties by index),
+    dealt round-robin -- every rank gets the same number of tensors of every shape whenever the counts divide (they do
+    for the three models at 2 / 4 / 8 ranks), so the ranks' bytes are equal; a plain index round-robin leaves Mixtral's
+    28-tensor layers 1.7 % out of balance at 4 and 8 ranks.  Returns this rank's pool indices, ascending."""
+    order = sorted(range(len(shapes)), key=lambda i: (-shapes[i][0] * shapes[i][1], i))
+    return sorted(order[rank::world])
+
+
 def make_weights(model, n_layers, device, seed=1234, rank=0, world=1, scaling="strong"):
     """bf16 N(0, 0.02^2) with 0.1% x8 outliers, generated on the GPU; tensor i of the pool is seeded by its
-    index.  strong: the pool is the model's list, tensor i lives on rank i % world (round-robin shard of the per-layer
-    tensors).  weak: the pool is `world` times the model's list and rank r holds entries [r * len, (r + 1) * len).
+    index.  strong: the pool is the model's list, dealt by `deal` (size-balanced round-robin of the per-layer tensors).
+    weak: the pool is `world` times the model's list and rank r holds entries [r * len, (r + 1) * len).
     Returns (tensors of this rank, their indices in the pool, number of tensors of the whole pool)."""
     shapes = [shape for _ in range(n_layers) for shape in layer_shapes(model)]
     if scaling == "weak" and world > 1:
@@ -69,7 +91,7 @@ def make_weights(model, n_layers, device, seed=1234, rank=0, world=1, scaling="s
         shapes = shapes * world
         mine = range(first, first + n_model)
     else:
-        mine = range(rank, len(shapes), world)
+        mine = deal(shapes, rank, world)
     g = torch.Generator(device=device)
     ws, idx = [], []
     for i in mine:
@@ -195,17 +217,47 @@ def cpu_baseline(workload, budget_s=12.0):
     return out
 
 
-def main():
+# the multi-GPU configuration BASELINE.json names for each format (configs[3]: Mixtral-8x7B FP8 + 2:4; configs[4]:
+# Llama-3-70B MXFP4 g32 + SmoothQuant; the per-group INT4 pass is the north-star kernel "over Llama-3-70B weight tensors")
+SCALE_MODEL = {"fp8": "mixtral-8x7b", "int8": "mixtral-8x7b", "mask24": "mixtral-8x7b",
+               "int4g128": "llama3-70b", "mxfp4": "llama3-70b", "mxfp4-sq": "llama3-70b"}
+ALG_BYTES_PER_ELEM = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mxfp4-sq": 4.0, "mask24": 3.0}
+DOM_KERNEL = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
+              "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
+              "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>", "mask24": "mt_mask24_kernel<bf16>"}
+
+
+def default_model(workload, world):
+    return "llama3-8b" if world == 1 else SCALE_MODEL[workload]
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when no launcher started it."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mxfp4-sq", "mask24"])
-    ap.add_argument("--model", default="llama3-8b", choices=list(MODELS))
+    ap.add_argument("--model", default=None, choices=list(MODELS),
+                    help="default: llama3-8b at N = 1 (BASELINE configs[1]); at N > 1 the multi-GPU configuration of the "
+                         "format (mixtral-8x7b for fp8 / int8 / mask24, llama3-70b for int4g128 / mxfp4 / mxfp4-sq)")
     ap.add_argument("--layers", type=int, default=0, help="0 = all layers of the model")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every rank holds one model's worth of tensors (the pool grows with N); strong = ONE "
-                         "model's tensors dealt over the ranks.  The other leg is measured too and reported in extra")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong (default) = ONE model's tensors dealt over the ranks; weak = every rank holds one "
+                         "model's worth of tensors (the pool grows with N).  The other leg is reported in extra")
     ap.add_argument("--group-mb", type=int, default=0,
                     help="fp8/int8: calibrate+QDQ in groups of <= this many MB of weights (second read from the "
                          "Infinity Cache) instead of two whole-model passes; 0 = off")
@@ -217,6 +269,11 @@ def main():
                          "of the same launch in extra.qdq_out_of_place")
     ap.add_argument("--inplace", action="store_true", help="(accepted for old command lines; in place is the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="time the CPU baseline of --workload, print its JSON object and exit (no GPU is touched): the "
+                         "process the main run starts for it, last")
+    ap.add_argument("--cpu-baseline-inproc-first", action="store_true",
+                    help="DIAGNOSTIC (round 3's order): time the CPU baseline inside this process BEFORE the AWQ extras")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other kernels, the "
                                                             "Llama-3-70B in-place pass, the INT4-AWQ wall-clock)")
     ap.add_argument("--no-hf", action="store_true", help="extra: skip the INT4-AWQ flow on the random-init HF Llama-3-8B")
@@ -224,14 +281,177 @@ def main():
     ap.add_argument("--awq-batches", type=int, default=64, help="extra: calibration batches of 4096 tokens in total")
     ap.add_argument("--awq-watchdog-s", type=float, default=240.0,
                     help="N > 1: print the line without the AWQ extra if that flow has not finished after this many seconds")
-    args = ap.parse_args()
+    return ap
+
+
+class Pool:
+    """The tensors one rank holds of a pool of per-layer weights, their segment tables, and one step of the workload."""
+
+    def __init__(self, moa, wl, model, n_layers, dev, rank, world, scaling, inplace=True, group_mb=0, use_dist=False):
+        from model_optimizer_amd.multi_tensor import SegmentTable
+
+        self.moa, self.wl, self.dev, self.use_dist = moa, wl, dev, use_dist
+        self.weights, owned, self.n_tensors = make_weights(model, n_layers, dev, rank=rank, world=world, scaling=scaling)
+        self.n_local = sum(w.numel() for w in self.weights)
+        self.n_model_elem = sum(r * c for _ in range(n_layers) for r, c in layer_shapes(model))  # one model
+        self.weak = scaling == "weak" and world > 1
+        self.n_elem = self.n_model_elem * (world if self.weak else 1)  # the whole pool
+        self.owned_idx = torch.tensor(owned, dtype=torch.int64, device=dev)
+        self.amax_all = torch.zeros(self.n_tensors, dtype=torch.float32, device=dev)  # every rank ends with every amax
+        self.tab = SegmentTable(self.weights, outputs=self.weights if inplace else None,
+                                group_size=128 if wl == "int4g128" else None)
+        self.groups = None
+        if group_mb and wl in ("fp8", "int8"):
+            groups, cur, cur_b = [], [], 0
+            for i, w in enumerate(self.weights):
+                b = w.numel() * w.element_size()
+                if cur and cur_b + b > group_mb * 1e6:
+                    groups.append(cur)
+                    cur, cur_b = [], 0
+                cur.append(i)
+                cur_b += b
+            groups.append(cur)
+            self.groups = [SegmentTable([self.weights[i] for i in g], outputs=[self.tab.outputs[i] for i in g])
+                           for g in groups]
+        self.fold_scales = None
+        if wl == "mxfp4-sq":
+            # per-channel SmoothQuant scales of each tensor (synthetic, log-normal); steps alternate s and 1/s so that the
+            # in-place fold keeps the weights' magnitude over many steps
+            gs = torch.Generator(device=dev).manual_seed(99)
+            self.fold_scales = []
+            for w in self.weights:
+                sv = torch.exp(0.5 * torch.randn(w.shape[1], generator=gs, device=dev, dtype=torch.float32))
+                self.fold_scales.append((sv, 1.0 / sv))
+        self.step_no = 0
+        self.masks = self.mask_tab = None
+        if wl == "mask24":
+            self.masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in self.weights]
+            self.mask_tab = SegmentTable(self.weights, outputs=self.masks)
+        self.dom_events = []
+
+    def release(self):
+        self.tab = self.groups = self.weights = self.masks = self.mask_tab = self.fold_scales = None
+        torch.cuda.empty_cache()
+
+    def step(self, record, collective=True):
+        import torch.distributed as dist
+
+        wl, tab = self.wl, self.tab
+        use_dist = self.use_dist and collective
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+        e0 = e1 = None
+
+        def start():
+            nonlocal e0, e1
+            if record:
+                e0, e1 = ev(), ev()
+                e0.record()
+
+        def stop():
+            if record:
+                e1.record()
+                self.dom_events.append((e0, e1))
+
+        if self.groups is not None:
+            start()
+            for gt in self.groups:
+                gt.calibrate_amax()
+                gt.fake_quant_e4m3() if wl == "fp8" else gt.fake_quant_int(8, False, True)
+            stop()
+            if use_dist:
+                self.amax_all.zero_()
+                self.amax_all[self.owned_idx] = torch.cat([gt.amax_flat for gt in self.groups])
+                dist.all_reduce(self.amax_all, op=dist.ReduceOp.MAX)
+        elif wl == "fp8" or wl == "int8":
+            tab.calibrate_amax()
+            work = None
+            if use_dist:
+                # one bucket: the owners' values reach every rank (zeros are the identity of abs-max).  The QDQ of a
+                # rank's own tensors needs only its own statistics, so the exchange runs on RCCL's stream UNDER the QDQ
+                # launch and is waited for at the end of the step (it is part of the step, not of the QDQ's inputs)
+                self.amax_all.zero_()
+                self.amax_all[self.owned_idx] = tab.amax_flat
+                work = dist.all_reduce(self.amax_all, op=dist.ReduceOp.MAX, async_op=True)
+            start()
+            tab.fake_quant_e4m3() if wl == "fp8" else tab.fake_quant_int(8, False, True)
+            stop()
+            if work is not None:
+                work.wait()  # the step's stream continues only after every rank's statistics have arrived
+        elif wl == "int4g128":
+            start()
+            tab.amax_qdq_int_group(4, False, False)
+            stop()
+        elif wl == "mxfp4-sq":
+            k = self.step_no & 1
+            self.step_no += 1
+            for w, sv in zip(self.weights, self.fold_scales):
+                self.moa.ops.scale_cols(w, sv[k], out=w)  # the fold: fp32 multiply, one rounding, in place
+            start()
+            tab.mx_fused_amax_convert(32, "E2M1")
+            stop()
+        elif wl == "mxfp4":
+            start()
+            tab.mx_fused_amax_convert(32, "E2M1")  # every weight of the model in one launch
+            stop()
+        else:
+            start()
+            self.mask_tab.mask_2to4()  # every weight of the model in one launch
+            stop()
+
+    def run(self, steps, warmup, ramp_s=1.5):
+        """Ramp (untimed), `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
+        returns the elapsed seconds, MAX over the ranks."""
+        import torch.distributed as dist
+
+        # Power-state ramp (not a measured step, not part of the W warm-up steps): a GPU that has been idle starts a
+        # bandwidth-bound kernel ~15 % slower than one that has been busy for a second (measured: the same launch takes
+        # 5.1 ms as the first work after process start and 4.4 ms later in the same session), so the device is kept busy
+        # for ~1.5 s before the contractual warm-up + timed region.
+        # The ramp is time-based, so ranks may run different numbers of iterations: it must not contain a collective.
+        t_ramp = time.perf_counter()
+        while time.perf_counter() - t_ramp < ramp_s:
+            self.step(False, collective=False)
+            torch.cuda.synchronize()
+        for _ in range(warmup):
+            self.step(False)
+
+        def barrier():
+            if self.use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        self.dom_events = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if self.use_dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        return elapsed
+
+
+def main():
+    args = build_parser().parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.workload)), flush=True)
+        return
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # the contract command without a launcher: become the launcher (one rank per GPU; MOQ_BENCH_DEBUG_ONE_GPU=1 puts
+        # all ranks on cuda:0 over gloo).  exec: the launcher's exit code and rank 0's stdout are this command's.
+        cmd = launch_command(args.gpus, sys.argv[1:])
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
@@ -276,160 +496,25 @@ def main():
     moa = _moa_import.load()
     from model_optimizer_amd.multi_tensor import SegmentTable
 
+    model_given = args.model is not None
+    args.model = args.model or default_model(args.workload, world)
     n_layers = args.layers or MODELS[args.model][2]
-    weights, owned, n_tensors = make_weights(args.model, n_layers, dev, rank=rank, world=world, scaling=args.scaling)
-    n_local = sum(w.numel() for w in weights)
-    n_model_elem = sum(r * c for _ in range(n_layers) for r, c in layer_shapes(args.model))  # one model
-    weak = args.scaling == "weak" and world > 1
-    n_elem = n_model_elem * (world if weak else 1)  # the whole pool
     wl = args.workload
-    owned_idx = torch.tensor(owned, dtype=torch.int64, device=dev)
-    amax_all = torch.zeros(n_tensors, dtype=torch.float32, device=dev)  # every rank ends with every tensor's amax
-
     args.inplace = not args.out_of_place
-    tab = SegmentTable(weights, outputs=weights if args.inplace else None, group_size=128 if wl == "int4g128" else None)
-    groups = None
-    if args.group_mb and wl in ("fp8", "int8"):
-        groups, cur, cur_b = [], [], 0
-        for i, w in enumerate(weights):
-            b = w.numel() * w.element_size()
-            if cur and cur_b + b > args.group_mb * 1e6:
-                groups.append(cur)
-                cur, cur_b = [], 0
-            cur.append(i)
-            cur_b += b
-        groups.append(cur)
-        groups = [SegmentTable([weights[i] for i in g], outputs=[tab.outputs[i] for i in g]) for g in groups]
-    fold_scales = None
-    if wl == "mxfp4-sq":
-        # per-channel SmoothQuant scales of each tensor (synthetic, log-normal); steps alternate s and 1/s so that the
-        # in-place fold keeps the weights' magnitude over many steps
-        gs = torch.Generator(device=dev).manual_seed(99)
-        fold_scales = []
-        for w in weights:
-            sv = torch.exp(0.5 * torch.randn(w.shape[1], generator=gs, device=dev, dtype=torch.float32))
-            fold_scales.append((sv, 1.0 / sv))
-    step_no = [0]
-    masks = None
-    if wl == "mask24":
-        masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in weights]
-        mask_tab = SegmentTable(weights, outputs=masks)
-
+    pool = Pool(moa, wl, args.model, n_layers, dev, rank, world, args.scaling, args.inplace, args.group_mb, use_dist)
+    weights, tab, masks = pool.weights, pool.tab, pool.masks
+    n_local, n_model_elem, n_elem, n_tensors, weak = pool.n_local, pool.n_model_elem, pool.n_elem, pool.n_tensors, pool.weak
+    elapsed = pool.run(args.steps, args.warmup)
     ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    dom_events = []
-
-    def step(record):
-        if groups is not None:
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            for gt in groups:
-                gt.calibrate_amax()
-                gt.fake_quant_e4m3() if wl == "fp8" else gt.fake_quant_int(8, False, True)
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-            if use_dist:
-                amax_all.zero_()
-                amax_all[owned_idx] = torch.cat([gt.amax_flat for gt in groups])
-                dist.all_reduce(amax_all, op=dist.ReduceOp.MAX)
-        elif wl == "fp8" or wl == "int8":
-            tab.calibrate_amax()
-            work = None
-            if use_dist:
-                # one bucket: the owners' values reach every rank (zeros are the identity of abs-max).  The QDQ of a
-                # rank's own tensors needs only its own statistics, so the exchange runs on RCCL's stream UNDER the QDQ
-                # launch and is waited for at the end of the step (it is part of the step, not of the QDQ's inputs)
-                amax_all.zero_()
-                amax_all[owned_idx] = tab.amax_flat
-                work = dist.all_reduce(amax_all, op=dist.ReduceOp.MAX, async_op=True)
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            tab.fake_quant_e4m3() if wl == "fp8" else tab.fake_quant_int(8, False, True)
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-            if work is not None:
-                work.wait()  # the step's stream continues only after every rank's statistics have arrived
-        elif wl == "int4g128":
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            tab.amax_qdq_int_group(4, False, False)
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-        elif wl == "mxfp4-sq":
-            k = step_no[0] & 1
-            step_no[0] += 1
-            for w, sv in zip(weights, fold_scales):
-                moa.ops.scale_cols(w, sv[k], out=w)  # the fold: fp32 multiply, one rounding, in place
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            tab.mx_fused_amax_convert(32, "E2M1")
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-        elif wl == "mxfp4":
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            tab.mx_fused_amax_convert(32, "E2M1")  # every weight of the model in one launch
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-        else:
-            if record:
-                e0, e1 = ev(), ev()
-                e0.record()
-            mask_tab.mask_2to4()  # every weight of the model in one launch
-            if record:
-                e1.record()
-                dom_events.append((e0, e1))
-
-    # Power-state ramp (not a measured step, not part of the W warm-up steps): a GPU that has been idle starts a
-    # bandwidth-bound kernel ~15 % slower than one that has been busy for a second (measured: the same launch takes
-    # 5.1 ms as the first work after process start and 4.4 ms later in the same session), so the device is kept busy
-    # for ~1.5 s before the contractual warm-up + timed region.
-    # The ramp is time-based, so ranks may run different numbers of iterations: it must not contain a collective.
-    dist_on, use_dist = use_dist, False  # step() reads `use_dist` from this scope: no all-reduce inside the ramp
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 1.5:
-        step(False)
-        torch.cuda.synchronize()
-    use_dist = dist_on
-    for _ in range(args.warmup):
-        step(False)
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_elem * 2 / (elapsed / args.steps) / 1e9  # the whole pool's weights: what all ranks processed
 
     # dominant kernel: average launch duration from the HIP events recorded inside the timed region
-    dom_all = [a.elapsed_time(b) for a, b in dom_events]
+    dom_all = [a.elapsed_time(b) for a, b in pool.dom_events]
     dom_ms = sum(dom_all) / len(dom_all)
-    alg_bytes_per_elem = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mxfp4-sq": 4.0, "mask24": 3.0}[wl]
-    dom_name = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
-                "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
-                "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>",
-                "mask24": "mt_mask24_kernel<bf16>"}[wl]
+    alg_bytes_per_elem = ALG_BYTES_PER_ELEM[wl]
+    dom_name = DOM_KERNEL[wl]
     achieved = n_local * alg_bytes_per_elem / (dom_ms * 1e-3) / 1e9  # this rank's launch over this rank's tensors
     # PMC traffic comes from the committed single-GPU profile of the same launch over the whole model; a rank that
     # owns a share of the tensors moves that share of it (the kernel's traffic is proportional to its elements)
@@ -455,6 +540,13 @@ def main():
                                  "avg_launch_ms": round(t[1].item(), 4), "node_copy_GBs": round(t[2].item(), 1)}
                                 for t in every]
 
+    def describe(p, model):
+        what = ("2:4 magnitude mask (1-byte masks written)" if wl == "mask24"
+                else wl + " calibrate + quantize-dequantize" + (" in place" if args.inplace else ""))
+        return (f"{model} all {p.n_tensors // (world if p.weak else 1)} linear weights"
+                f"{f' x {world} (one set per GPU)' if p.weak else ''} ({p.n_elem * 2 / 1e9:.2f} GB bf16), {what}, "
+                f"inputs resident in HBM")
+
     out = {
         "metric": f"GB/s weights calibrated+QDQ ({MODEL_NAMES[args.model]})",
         "value": round(value, 2),
@@ -464,17 +556,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak" if weak or world == 1 else "strong",
+        "scaling": "weak" if weak else "strong",  # (one GPU: the same thing; the N > 1 default is strong)
         "vs_baseline": None,
         "dtype": "bf16 storage, f32 arithmetic",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} all {n_tensors // (world if weak else 1)} linear weights"
-                               f"{f' x {world} (one set per GPU)' if weak else ''} ({n_elem * 2 / 1e9:.2f} GB bf16), "
-                               f"{'2:4 magnitude mask (1-byte masks written)' if wl == 'mask24' else wl + ' calibrate + quantize-dequantize'}{' in place' if args.inplace and wl != 'mask24' else ''}, inputs resident in HBM",
+        "config": {"workload": describe(pool, args.model),
                    "format": wl, "model": args.model, "layers": n_layers,
+                   "baseline_config": ({"llama3-8b": "configs[1] (Llama-3-8B FP8 per-tensor, 1 GPU)" if wl == "fp8" else
+                                        "configs[2] weight side" if wl == "int4g128" else None,
+                                        "mixtral-8x7b": "configs[3] (Mixtral-8x7B FP8 + 2:4, weights sharded over the GPUs)",
+                                        "llama3-70b": "configs[4] (Llama-3-70B per-group, weights sharded over the GPUs)"}
+                                       [args.model]),
                    "parallelism": (f"a pool of {n_tensors} per-layer weight tensors partitioned over {world} GPUs "
-                                   f"({len(weights)} on rank 0{', round-robin' if not weak else ''}); one amax bucket "
-                                   f"all-reduce(MAX) of {n_tensors} values, in flight under the QDQ launch")
+                                   f"({len(weights)} on rank 0{', largest first round-robin' if not weak else ''}); one amax "
+                                   f"bucket all-reduce(MAX) of {n_tensors} values, in flight under the QDQ launch")
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
     }
@@ -492,54 +587,21 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps
 
-    def strong_leg():
-        """The STRONG-scaling leg of an N > 1 run: ONE model's tensors (list index i % world == rank of this rank's own set:
-        same shapes and distribution as a round-robin deal of one model) through the same step -- abs-max, the 224-value
-        bucket in flight under the QDQ launch -- timed like the headline (barriers, max over ranks)."""
-        pick = [i for i in range(len(weights)) if i % world == rank]
-        sub = [weights[i] for i in pick]
-        sub_idx = torch.tensor(pick, dtype=torch.int64, device=dev)
-        bucket = torch.zeros(len(weights), dtype=torch.float32, device=dev)
-        if wl == "mask24":
-            stab = SegmentTable(sub, outputs=[masks[i] for i in pick])
-        else:
-            stab = SegmentTable(sub, outputs=[tab.outputs[i] for i in pick], group_size=128 if wl == "int4g128" else None)
-
-        def one():
-            if wl in ("fp8", "int8"):
-                stab.calibrate_amax()
-                bucket.zero_()
-                bucket[sub_idx] = stab.amax_flat
-                work = dist.all_reduce(bucket, op=dist.ReduceOp.MAX, async_op=True)
-                stab.fake_quant_e4m3() if wl == "fp8" else stab.fake_quant_int(8, False, True)
-                work.wait()
-            elif wl == "int4g128":
-                stab.amax_qdq_int_group(4, False, False)
-            elif wl == "mxfp4":
-                stab.mx_fused_amax_convert(32, "E2M1")
-            else:
-                stab.mask_2to4()
-
-        for _ in range(max(args.warmup, 3)):
-            one()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            one()
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_step = t.item() / args.steps
-        return {"value": round(n_model_elem * 2 / per_step / 1e9, 2), "unit": "GB/s", "ms_per_step": round(per_step * 1e3, 4),
-                "steps": args.steps, "scaling": "strong",
-                "workload": f"{args.model} all {len(weights)} linear weights ({n_model_elem * 2 / 1e9:.2f} GB bf16) dealt "
-                            f"round-robin over {world} GPUs ({len(pick)} on rank 0), one amax bucket of {len(weights)} values"}
-
-    if use_dist and (weak or world == 1) and groups is None and wl != "mxfp4-sq":
-        # (every rank runs it: it contains collectives)
-        leg = strong_leg()
-        if not args.no_extra or world > 1:
-            extra["strong_scaling"] = leg
+    def other_pool_leg(model, scaling, steps):
+        """The same step on another pool (every rank runs it: it contains the step's collectives): timed like the
+        headline -- ramp, warm-up, barriers, max over ranks."""
+        p = Pool(moa, wl, model, MODELS[model][2] if model != args.model else n_layers, dev, rank, world, scaling,
+                 True, 0, use_dist)
+        dt = p.run(steps, max(args.warmup, 2), ramp_s=0.5)
+        dom = [a.elapsed_time(b) for a, b in p.dom_events]
+        dms = sum(dom) / len(dom)
+        leg = {"value": round(p.n_elem * 2 / (dt / steps) / 1e9, 2), "unit": "GB/s", "ms_per_step": round(dt / steps * 1e3, 4),
+               "steps": steps, "n_gpus": world, "scaling": "weak" if p.weak else "strong",
+               "workload": describe(p, model),
+               "dominant_kernel_frac_of_8TBs": round(p.n_local * alg_bytes_per_elem / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "dominant_kernel_ms": round(dms, 4)}
+        p.release()
+        return leg
 
     if not args.no_extra and world == 1:
         # secondary measurements on the same resident weights (not part of `value`)
@@ -584,10 +646,24 @@ def main():
             del tabg
     if not args.no_extra:
         # release the main workload's tensors: the extras below bring their own
-        del tab, weights, groups, masks
-        if wl == "mask24":
-            del mask_tab
-        torch.cuda.empty_cache()
+        del tab, weights, masks
+        pool.release()
+    if not args.no_extra and use_dist and not weak and wl != "mxfp4-sq":
+        # the WEAK leg of a multi-GPU run (every rank holds the whole model; not a BASELINE configuration)
+        try:
+            extra["weak_scaling"] = other_pool_leg(args.model, "weak", args.steps)
+        except torch.cuda.OutOfMemoryError as e:  # (same sizes on every rank: all of them land here together)
+            extra["weak_scaling"] = {"failed": f"{type(e).__name__}"}
+    if not args.no_extra and world == 1 and not model_given and SCALE_MODEL[wl] != args.model:
+        # N = 1 base of the strong-scaling curve the N > 1 default runs: the same step over the whole named model
+        try:
+            free, _ = torch.cuda.mem_get_info(dev)
+            big = SCALE_MODEL[wl]
+            need = sum(r * c for _ in range(MODELS[big][2]) for r, c in layer_shapes(big)) * 2
+            if free > need * 1.08:
+                extra["scale_base_n1"] = other_pool_leg(big, "strong", min(args.steps, 10))
+        except Exception as e:  # a reported extra, never a reason to lose the main result
+            extra["scale_base_n1"] = {"failed": f"{type(e).__name__}: {e}"}
     if not args.no_extra and world == 1 and args.model == "llama3-8b":
         # north-star target (BASELINE.json): per-group amax + QDQ over ALL Llama-3-70B weight tensors on one GPU, in
         # place (136.9 GB of weights; out of place would need 274 GB)
@@ -606,18 +682,41 @@ def main():
                 torch.cuda.empty_cache()
         except Exception as e:  # a reported extra, never a reason to lose the main result
             extra["llama3_70b_int4g128_inplace"] = {"failed": f"{type(e).__name__}: {e}"}
-    if rank == 0 and not args.no_cpu_baseline:
-        # (N > 1: rank 0 times it too, after the timed region; the other ranks wait at the next collective)
+
+    def cpu_baseline_inproc():
         try:
-            out["cpu_baseline"] = cpu_baseline(wl)
+            return cpu_baseline(wl)
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU result
-            out["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"failed: {type(e).__name__}: {e}"}
-    elif rank == 0:
+            return {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+                    "sample": f"failed: {type(e).__name__}: {e}"}
+
+    def cpu_baseline_subprocess():
+        """The CPU baseline in a process of its own (`--cpu-baseline-only`): the oracle's OpenMP runtime (the system
+        libgomp) and torch's bundled one never meet inside a process that times a flow, and nothing of it is resident
+        while the GPU extras run."""
+        import subprocess
+
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                            "LOCAL_WORLD_SIZE", "OMP_NUM_THREADS", "TORCHELASTIC_RUN_ID")}
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", wl],
+                               capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr.strip()[-300:]}")
+            return json.loads(lines[-1])
+        except Exception as e:
+            return {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port",
+                    "sample": f"failed: {type(e).__name__}: {e}"}
+
+    if rank == 0:
         out["cpu_baseline"] = None
+        if args.cpu_baseline_inproc_first and not args.no_cpu_baseline:
+            out["cpu_baseline"] = dict(cpu_baseline_inproc(), order="in process, before the AWQ extras (diagnostic)")
 
     watchdog = None
-    if world > 1 and not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b":
+    if world > 1 and not args.no_extra and args.awq_layers > 0:
         # The AWQ flow below is the first time its collectives (object gathers, GiB-sized Gram reduces) meet more than
         # one rank on hardware.  A collective that never returns must not take the measured headline with it: if the flow
         # has not finished in time, rank 0 prints the line without it and every rank leaves.
@@ -634,10 +733,10 @@ def main():
         watchdog = threading.Timer(args.awq_watchdog_s, give_up)
         watchdog.daemon = True
         watchdog.start()
-    if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b":
+    if not args.no_extra and args.awq_layers > 0:
         # the second half of BASELINE.json's metric: INT4-AWQ PTQ wall-clock (awq_lite g128, alpha_step 0.1, default
-        # search) of the synthetic Llama-3-8B linear stack; every rank holds the linears, the calibration batches
-        # (4096 tokens each) are dealt over the ranks, statistics travel in bucketed all-reduces
+        # search) of the synthetic Llama-3-8B linear stack (configs[2]); every rank holds the linears, the calibration
+        # batches (4096 tokens each) are dealt over the ranks, statistics travel in bucketed all-reduces
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import awq_bench
@@ -647,13 +746,14 @@ def main():
             extra["awq_wallclock_s"] = line["value"]
             extra["awq"] = {k: line[k] for k in ("config", "search", "rescored_linears", "rescored_candidates",
                                                  "search_gemm_TFLOPs_equiv", "best_alpha_hist", "passes", "stages_s",
+                                                 "quantize_stages_s", "unstaged_s", "awq_unstaged_s",
                                                  "tie_check") if k in line}
         except Exception as e:
             extra["awq_wallclock_s"] = None
             extra["awq"] = {"failed": f"{type(e).__name__}: {e}"}
         if watchdog is not None:
             watchdog.cancel()
-    if not args.no_extra and args.awq_layers > 0 and args.model == "llama3-8b" and world == 1 and not args.no_hf:
+    if not args.no_extra and args.awq_layers > 0 and world == 1 and not args.no_hf:
         # the other AWQ case: a random-init Hugging Face Llama-3-8B (real decoder topology: attention, norms, the
         # inputs of q/k/v and gate/up shared), whose activations have no outlier channels -- all 11 candidates of a linear
         # score within a fraction of a percent, the worst case for the exact re-scoring (tools/hf_flow_check.py)
@@ -668,9 +768,13 @@ def main():
             extra["awq_hf_random_init"] = {"quantize_s": hf["quantize_s"], "plain_forward_loop_s": hf["plain_forward_loop_s"],
                                            "rescored_linears": hf.get("awq_rescored_linears"),
                                            "rescored_candidates": hf.get("awq_rescored_candidates"),
+                                           "quantize_stages_s": hf.get("quantize_stages_s"),
                                            "stats": hf.get("awq_stats")}
         except Exception as e:
             extra["awq_hf_random_init"] = {"failed": f"{type(e).__name__}: {e}"}
+    if rank == 0 and not args.no_cpu_baseline and out.get("cpu_baseline") is None:
+        # LAST, and in a process of its own (N > 1: the other ranks wait at the communicator's teardown meanwhile)
+        out["cpu_baseline"] = cpu_baseline_subprocess()
     if extra:
         out["extra"] = extra
 

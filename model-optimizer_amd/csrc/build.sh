@@ -9,14 +9,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function ${MOQ_EXTRA_FLAGS:-}"
 objs=()
 pids=()
-# MOQ_EXPERIMENTS=1: exp/moq_gemm_exp.hip (every loop structure that was built and measured, including timing-only
-# diagnostics that return wrong results by construction) is compiled IN PLACE of the release moq_gemm.hip -- a library
-# for tools/gemm_bench.py and tools/exp/, never the one that ships
+# MOQ_EXPERIMENTS=1: the same sources compiled with -DMOQ_EXPERIMENTS -- the MOQ_TUNE_* knobs of moq_common.h become
+# live environment reads (a library for A/B studies from tools/, never the one that ships; own object directory)
 SRCS=(moq_*.hip)
 OBJDIR=build
 if [ "${MOQ_EXPERIMENTS:-0}" = "1" ]; then
-  OBJDIR=build/exp  # every source is compiled with -DMOQ_EXPERIMENTS (the tuning knobs of moq_common.h): own objects
-  SRCS=("${SRCS[@]/moq_gemm.hip/exp/moq_gemm_exp.hip}")
+  OBJDIR=build/exp
   FLAGS="$FLAGS -DMOQ_EXPERIMENTS -I."
   OUT=${1:-libmoquant_exp.so}
   echo "[moquant] EXPERIMENT build -> $OUT"

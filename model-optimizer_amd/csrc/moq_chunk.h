@@ -167,7 +167,10 @@ static inline int copy_grid(int64_t n_chunks) {
   const int64_t div = moq_tune("MOQ_TUNE_CHUNKS_PER_WG", 8);  // (experiment build only)
   int64_t g = n_chunks / (div > 0 ? div : 8);
   if (g < 2048) g = 2048;
-  if (g > 131072) g = 131072;
+  if (g > moq_tune("MOQ_TUNE_COPY_GRID_CAP", 131072)) g = moq_tune("MOQ_TUNE_COPY_GRID_CAP", 131072);
+  const int64_t forced = moq_tune("MOQ_TUNE_COPY_GRID", 0);  // (experiment build only) an explicit grid
+  if (forced > 0) g = forced;
+  if (moq_tune("MOQ_TUNE_COPY_GRID_ODD", 0)) g |= 1;
   if (g > n_chunks) g = n_chunks;
   return (int)(g < 1 ? 1 : g);
 }

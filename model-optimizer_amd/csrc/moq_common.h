@@ -39,6 +39,7 @@ constexpr float kAmaxEps = 1.0f / (1 << 24);  // "amax <= 2^-24" rule (tensor_qu
 // ---------------------------------------------------------------- error plumbing (host)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+bool lds_opt_in(const void* kernel, int bytes, const char* kernel_name);  // > 64 KiB of dynamic LDS; refusal -> check_launch
 
 // grid for grid-stride streaming kernels: enough workgroups to fill 256 CUs x 8 blocks, never more than
 // the work available (cdna_hip_programming.md guideline 11).

@@ -157,7 +157,7 @@ static int64_t launch_f32(const void* x, const void* w, const void* ref, const v
   (void)hipGetDevice(&device);
   const uint64_t bit = 1ull << (device & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kF32Lds);
+    lds_opt_in((const void*)gemm_f32_kernel<MODE>, (int)kF32Lds, "gemm_f32_kernel");
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((gemm_f32_kernel<MODE>), dim3((unsigned)nblk, (unsigned)n_cand), dim3(256), kF32Lds,

@@ -262,8 +262,7 @@ static void launch_iq(const IqParams& p, bool amax, bool hist, bool shared, int 
   do {                                                                                                              \
     if (lds > 64 * 1024) {                                                                                          \
       /* > 64 KiB of dynamic LDS needs the opt-in attribute, per device; setting it again is harmless */           \
-      (void)hipFuncSetAttribute((const void*)input_quant_kernel<DT, FMT, PQS, A, H, SH>,                            \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIqLdsBudget);                     \
+      lds_opt_in((const void*)input_quant_kernel<DT, FMT, PQS, A, H, SH>, (int)kIqLdsBudget, "input_quant_kernel");  \
     }                                                                                                               \
     hipLaunchKernelGGL((input_quant_kernel<DT, FMT, PQS, A, H, SH>), dim3(blocks), dim3(kIqBlock), lds, S(stream), p); \
   } while (0)

@@ -397,10 +397,10 @@ extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int6
   (void)hipGetDevice(&device);
   const uint64_t bit = 1ull << (device & 63);
   if (!(attr_set.load(std::memory_order_acquire) & bit)) {
-    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
-    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
-    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
-    (void)hipFuncSetAttribute((const void*)sgpt_trailing_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTuLds);
+    lds_opt_in((const void*)sgpt_trailing_kernel<true, true>, (int)kTuLds, "sgpt_trailing_kernel");
+    lds_opt_in((const void*)sgpt_trailing_kernel<true, false>, (int)kTuLds, "sgpt_trailing_kernel");
+    lds_opt_in((const void*)sgpt_trailing_kernel<false, true>, (int)kTuLds, "sgpt_trailing_kernel");
+    lds_opt_in((const void*)sgpt_trailing_kernel<false, false>, (int)kTuLds, "sgpt_trailing_kernel");
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const bool va = bs % 4 == 0 && (reinterpret_cast<uintptr_t>(delta) & 15u) == 0;

@@ -489,6 +489,75 @@ __global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restric
   }
 }
 
+#ifdef MOQ_EXPERIMENTS
+// EXPERIMENT (round 4, profiles/r04_pool_placement.md): one dense sweep window, a workgroup owns ADJ adjacent chunks and
+// issues ALL their loads before the first store (read phase / write phase per workgroup: ADJ x 16 KiB in flight each way).
+template <int DT, class Op, int ADJ>
+__global__ __launch_bounds__(kBlock) void mt_map_adj_kernel(const moq_seg* __restrict__ segs,
+                                                            const int64_t* __restrict__ blk_start,
+                                                            int n_seg, int64_t n_chunks, int num_bits,
+                                                            int is_unsigned, int narrow) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_runs = (n_chunks + ADJ - 1) / ADJ;
+  if ((int64_t)blockIdx.x >= n_runs) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, (int64_t)blockIdx.x * ADJ);
+  Op op;
+  bool fresh = true;
+  for (int64_t r = blockIdx.x; r < n_runs; r += gridDim.x) {
+    const int64_t c0 = r * ADJ;
+    fresh |= cur.seek(c0);
+    const int64_t e0 = (c0 - cur.c_begin) * MOQ_MT_CHUNK;
+    const bool whole = c0 + ADJ <= cur.c_end && cur.aligned && e0 + (int64_t)ADJ * MOQ_MT_CHUNK <= cur.sg.n;
+    if (whole) {
+      if (fresh) {
+        fresh = false;
+        if constexpr (__is_same(Op, OpIntQdq)) {
+          op.q = make_intq(num_bits, is_unsigned, narrow);
+          op.set(cur.sg.amax[0]);
+        } else {
+          op.sc = fp8_scale(cur.sg.amax[0]);
+        }
+      }
+      Pack16 in[ADJ * P];
+#pragma unroll
+      for (int a = 0; a < ADJ; ++a)
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+          in[a * P + u] = ld_packet<DT, true>(cur.sg.x, e0 + (int64_t)a * MOQ_MT_CHUNK + packet_off<DT>(u), cur.sg.n);
+#pragma unroll
+      for (int a = 0; a < ADJ; ++a)
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          float f[8];
+          unpack<DT>(in[a * P + u], f);
+          op(f, V);
+          st_packet<DT, true>(cur.sg.y, e0 + (int64_t)a * MOQ_MT_CHUNK + packet_off<DT>(u), cur.sg.n, pack<DT>(f));
+        }
+    } else {
+      for (int64_t c = c0; c < c0 + ADJ && c < n_chunks; ++c) {
+        fresh |= cur.seek(c);
+        if (fresh) {
+          fresh = false;
+          if constexpr (__is_same(Op, OpIntQdq)) {
+            op.q = make_intq(num_bits, is_unsigned, narrow);
+            op.set(cur.sg.amax[0]);
+          } else {
+            op.sc = fp8_scale(cur.sg.amax[0]);
+          }
+        }
+        const int64_t e = (c - cur.c_begin) * MOQ_MT_CHUNK;
+        if (cur.aligned && e + MOQ_MT_CHUNK <= cur.sg.n)
+          chunk_apply<DT, true>(cur.sg.x, cur.sg.y, e, cur.sg.n, op);
+        else
+          chunk_apply<DT, false>(cur.sg.x, cur.sg.y, e, cur.sg.n, op);
+      }
+    }
+  }
+}
+#endif
+
 template <int DT, int LPG>
 __global__ __launch_bounds__(kBlock) void mt_group_kernel(const moq_seg* __restrict__ segs,
                                                           const int64_t* __restrict__ blk_start,
@@ -743,6 +812,18 @@ extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_st
                                       int64_t n_chunks, int dt, void* stream) {
   int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_e4m3");
   if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
+#ifdef MOQ_EXPERIMENTS
+  const int adj = (int)moq_tune("MOQ_TUNE_MAP_ADJ", 0);
+  if (adj == 2 || adj == 4 || adj == 8) {
+    const int64_t runs = (n_chunks + adj - 1) / adj;
+    int64_t g = moq_tune("MOQ_TUNE_COPY_GRID", 0);
+    if (g <= 0 || g > runs) g = runs;
+    if (adj == 2) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 2>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
+    else if (adj == 4) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 4>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
+    else { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 8>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
+    return check_launch("moq_mt_fake_quant_e4m3");
+  }
+#endif
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpFp8Qdq>), dim3(copy_grid(n_chunks)),
                                             dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
                                             0, 0, 0));

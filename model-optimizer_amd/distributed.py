@@ -243,13 +243,22 @@ def sync_amax_tensor_parallel(model, group, column_parallel, row_parallel):
     return picked
 
 
-def shard_list(items, rank: int | None = None, world: int | None = None):
-    """Round-robin shard of per-layer weight tensors (or calibration batches) over the ranks: independent
-    units, no data-path collective."""
+_REPLICA_GROUP = object()  # default of `group` below: whatever declare_data_parallel named (None = the world)
+
+
+def shard_list(items, rank: int | None = None, world: int | None = None, group=_REPLICA_GROUP):
+    """Round-robin shard of per-layer weight tensors (or calibration batches) over the ranks of the replica group:
+    independent units, no data-path collective.  Rank and size are those of `group` (default: the group
+    given to declare_data_parallel, else the world) -- the same numbering `owner_rank` / `broadcast_from_owners` use, so
+    that under a DP subgroup of a larger world every unit has exactly one owner INSIDE the group."""
+    if group is _REPLICA_GROUP:
+        group = replica_group()
     if rank is None:
-        rank = dist.get_rank() if _initialized() else 0
+        rank = dist.get_rank(group) if _initialized() else 0
     if world is None:
-        world = dist.get_world_size() if _initialized() else 1
+        world = dist.get_world_size(group) if _initialized() else 1
+    if rank < 0:
+        raise RuntimeError("shard_list: this rank is not a member of the replica group it was asked to shard over")
     return [it for i, it in enumerate(items) if i % world == rank]
 
 

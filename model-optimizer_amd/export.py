@@ -497,7 +497,18 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None, shard_we
             state[new_key] = value
     for alias in _tied_alias_keys(model, state):
         del state[alias]
-    return rename_to_checkpoint_keys(state, model)
+    # the dict remembers HOW it was produced: save_checkpoint writes a per-rank shard exactly when this is one
+    return ExportedState(rename_to_checkpoint_keys(state, model), sharded=bool(shard))
+
+
+class ExportedState(dict):
+    """export_state_dict's result: a plain dict of checkpoint tensors that also knows whether it holds this rank's
+    shard only (`sharded`) -- save_checkpoint must not re-derive that from the process-wide declare_data_parallel state,
+    which may have changed (or been overridden per call) since the dict was made."""
+
+    def __init__(self, *args, sharded: bool = False, **kw):
+        super().__init__(*args, **kw)
+        self.sharded = sharded
 
 
 def _tied_alias_keys(model, state: dict) -> list:
@@ -585,7 +596,16 @@ def save_checkpoint(state: dict, export_dir: str, quant_config: dict | None = No
     from . import distributed as mdist
 
     os.makedirs(export_dir, exist_ok=True)
-    if mdist.resolve_shard(shard_weights):
+    produced = getattr(state, "sharded", None)  # ExportedState: how export_state_dict made it
+    if produced is not None:
+        if shard_weights is not None and bool(shard_weights) != produced:
+            raise ValueError(f"save_checkpoint(shard_weights={shard_weights}) but the state dict was exported with "
+                             f"shard_weights={produced}: a full dict written as shards collides on every key, a shard "
+                             "written as model.safetensors loses the other ranks' tensors")
+        sharded = produced and mdist.active(mdist.replica_group())
+    else:  # a plain dict (hand-made): the caller's word, else the declared replicas
+        sharded = mdist.resolve_shard(shard_weights)
+    if sharded:
         import torch.distributed as dist
 
         group = mdist.replica_group()

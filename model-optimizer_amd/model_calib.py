@@ -139,7 +139,10 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
     finish_stats_collection(model)
     if sync:
         dev = next((p.device for p in model.parameters()), None)
-        mdist.sync_amax_bucketed(_quantizers(model), device=dev)
+        # the data-parallel group when one was declared (the reference reduces over its DP group, :390-407), else the
+        # world; the dealt weight statistics reach the other replicas through this same reduction
+        group = mdist.replica_group() if mdist.replicas_declared() else None
+        mdist.sync_amax_bucketed(_quantizers(model), group=group, device=dev)
     promote_static_block_weight_quantizers(model)
 
 
@@ -482,6 +485,7 @@ class AWQLiteHelper:
         self.margin_used = None  # relative Gram margin the contender set was cut at (widened by the tie check)
         self.tie_need = None  # TIE_SPREAD_FACTOR * S + gap_w of the last check, relative (None: not re-scored)
         self.tie_rounds = 0  # how often the margin of this linear was widened
+        self.stored = []  # store_activations: (input [T, Cin], out_actual [T, Cout]) of every cache-pass batch
 
     def _padded(self, w: torch.Tensor, value: float = 0.0) -> torch.Tensor:
         return F.pad(w, (0, self.pad), "constant", value) if self.pad else w
@@ -649,15 +653,112 @@ def tie_margin_check(gram, exact_scores: dict, margin: float, rounds: int):
 
 
 def gram_score_planes(dtype) -> int:
-    import os
+    """bf16 planes of the screening contraction for this model dtype (GRAM_SCORE_PLANES; a study that wants another
+    precision edits that table from its own script -- the product path reads no environment knob here)."""
+    return GRAM_SCORE_PLANES.get(dtype, 3)
 
-    env = os.environ.get("MOQ_TUNE_GRAM_PLANES")  # A/B knob for the precision study (profiles/r02_awq_tie_margin.md)
-    return int(env) if env in ("1", "2", "3") else GRAM_SCORE_PLANES.get(dtype, 3)
+
+def _layer_local_plan(model: nn.Module, explicit: bool = False):
+    """The decoder layers awq_lite may walk one at a time, or None.  Conditions: a decoder stack exists (layerwise.
+    get_decoder_layers) and -- unless the caller asked for it explicitly -- the model is a Hugging Face PreTrainedModel whose
+    stack is made of *DecoderLayer modules (the contract "layer N+1's first argument is layer N's output" is theirs; any
+    nn.ModuleList of equal children would otherwise qualify); every searched linear lives inside the stack; no OTHER
+    quantizer is enabled (KV-cache / input quantizers outside the search add their noise in the reference's search pass,
+    which a single pass cannot reproduce)."""
+    from . import layerwise
+    from .hf_attention import _is_supported_hf_model
+
+    layers = layerwise.get_decoder_layers(model)
+    if layers is None:
+        return None
+    if not explicit and not (_is_supported_hf_model(model) and type(layers[0]).__name__.endswith("DecoderLayer")):
+        return None
+    mods = [m for m in model.modules()
+            if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    inside = {id(m) for lyr in layers for m in lyr.modules()}
+    if not mods or any(id(m) not in inside for m in mods):
+        return None
+    searched = {id(q) for m in mods for q in (m.weight_quantizer, m.input_quantizer)}
+    if any(q.is_enabled and id(q) not in searched for q in _quantizers(model)):
+        return None
+    return layers
+
+
+@torch.no_grad()
+def _awq_lite_layer_local(model: nn.Module, forward_loop, layers, **kw):
+    """awq_lite one decoder layer at a time (see awq_lite, `layer_local`).  The model's own forward runs up to the first
+    decoder layer once per batch (embeddings, rotary tables: `layerwise._capture_inputs`); from there every layer is
+    called on the previous layer's outputs with the captured arguments.  KV-cache objects among those arguments are
+    dropped (a layer replayed outside its model must not append to a cache another call owns)."""
+    from . import layerwise
+
+    dev = next(model.parameters()).device
+    total = {"search": kw.get("search", "auto"), "passes": 0, "replayed_passes": 0, "layer_local": True, "stages_s": {},
+             "linears": 0, "rescored_linears": 0, "rescored_candidates": 0, "layers": len(layers),
+             "tie_check": {"enabled": bool(kw.get("tie_check", True)), "spread_factor": TIE_SPREAD_FACTOR,
+                           "checked_linears": 0, "widened_linears": 0, "max_need_over_margin": 0.0, "max_need": 0.0}}
+
+    def drained_clock():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return time.perf_counter()
+
+    t0 = drained_clock()
+    inputs = layerwise._capture_inputs(model, layers[0], forward_loop)
+
+    def without_cache(kwargs):
+        kwargs = dict(kwargs)
+        for k in ("past_key_values", "past_key_value"):
+            if kwargs.get(k) is not None:
+                kwargs[k] = None
+        if kwargs.get("use_cache"):
+            kwargs["use_cache"] = False
+        return kwargs
+
+    reached = torch.tensor([float(len(inputs) > 0)], device=dev)
+    if _dist_on():  # data parallel: the same flow on every rank (a rank whose shard is empty walks the layers with no batches)
+        dist.all_reduce(reached, op=dist.ReduceOp.MAX)
+    if reached.item() == 0:
+        return None  # forward_loop does not drive the decoder stack (e.g. it calls the linears directly)
+    inputs = [(args, without_cache(kwargs)) for args, kwargs in inputs]
+    total["stages_s"]["embed"] = round(drained_clock() - t0, 4)
+    helpers = {}
+    most_passes = 0
+    for idx, layer in enumerate(layers):
+        nxt, calls, is_last = [], {"n": 0}, idx + 1 == len(layers)
+
+        def layer_loop(m, _in=inputs, _nxt=nxt, _calls=calls, _last=is_last):
+            first = _calls["n"] == 0  # the cache pass: the layer still has its original weights and the searched linears
+            _calls["n"] += 1          # return out_actual -- its outputs are the un-quantized inputs of the next layer
+            for args, kwargs in _in:
+                out = m(*args, **kwargs)
+                if first and not _last:
+                    _nxt.append(((layerwise._first_tensor(out).detach(), *args[1:]), kwargs))
+
+        helpers.update(awq_lite(layer, layer_loop, layer_local=False, store_activations=True, **kw))
+        inner = AWQ_LITE_STATS
+        for k, v in (inner.get("stages_s") or {}).items():
+            total["stages_s"][k] = round(total["stages_s"].get(k, 0.0) + v, 4)
+        most_passes = max(most_passes, inner.get("passes", 0))
+        total["replayed_passes"] += inner.get("replayed_passes", 0)
+        for k in ("linears", "rescored_linears", "rescored_candidates"):
+            total[k] += inner.get(k, 0)
+        tc, ic = total["tie_check"], inner.get("tie_check") or {}
+        for k in ("checked_linears", "widened_linears"):
+            tc[k] += ic.get(k, 0)
+        for k in ("max_need_over_margin", "max_need"):
+            tc[k] = max(tc[k], ic.get(k, 0.0))
+        inputs = nxt
+    total["passes"] = most_passes  # forwards through every layer: 1 when every layer's exact pass was a replay
+    AWQ_LITE_STATS.clear()
+    AWQ_LITE_STATS.update(total)
+    return helpers
 
 
 @torch.no_grad()
 def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto",
-             tie_margin: float | None = None, tie_check: bool = True):
+             tie_margin: float | None = None, tie_check: bool = True, layer_local: bool | None = None,
+             store_activations: bool = False):
     """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
     (the INT4_AWQ_CFG preset).
 
@@ -673,9 +774,32 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              :1548-1556, :1637).  Linears with a clear winner cost nothing extra; when no linear has a near-tie the
              extra pass is skipped.  tie_check (default on): the margin verifies itself against the measured
              disagreement of the two engines on the re-scored candidates and widens per linear when it was too
-             small (TIE_SPREAD_FACTOR); AWQ_LITE_STATS["tie_check"] reports the largest requirement / margin ratio."""
+             small (TIE_SPREAD_FACTOR); AWQ_LITE_STATS["tie_check"] reports the largest requirement / margin ratio.
+
+    store_activations: the cache pass keeps every searched linear's input and `out_actual` of every batch (references,
+             counted against the HBM budget); the exact pass then REPLAYS them linear by linear instead of running
+             forward_loop again -- no second forward, no second library GEMM for out_actual.  Only a call whose
+             activations fit can do that (one decoder layer: 36 GB for Llama-3-8B at 64 x 4096 tokens); when a
+             reservation fails the stores are dropped and the pass is a real one.
+    layer_local (None = for search="auto" on Hugging Face decoder stacks): the model is walked ONE DECODER LAYER AT A TIME
+             (layerwise.py's contract: layer N+1's input is layer N's output): the layer's batches run through it once --
+             statistics, Gram matrices, stored activations and the inputs of the next layer all come from that one
+             run -- its linears are scored, their near-ties re-scored from the stores, the layer is folded, the next one
+             follows.  One pass over the calibration data in total (`passes == 1`), same statistics as the whole-model
+             flow (every layer sees the un-quantized output of its predecessor, as in the reference's cache pass)."""
     if search not in ("auto", "gram", "gemm"):
         raise ValueError(f"awq_lite: unknown search mode {search!r}")
+    if layer_local is None or layer_local:
+        plan = _layer_local_plan(model, explicit=bool(layer_local)) if search == "auto" or layer_local else None
+        if plan is not None:
+            done = _awq_lite_layer_local(model, forward_loop, plan, alpha_step=alpha_step, search=search,
+                                         tie_margin=tie_margin, tie_check=tie_check)
+            if done is not None:
+                return done
+            plan = None  # the forward loop never called the first decoder layer (it feeds the linears itself): whole-model flow
+        elif layer_local:
+            raise ValueError("awq_lite(layer_local=True): the model has no decoder stack that holds every searched linear, "
+                             "or other quantizers are enabled (their noise belongs to the search pass)")
     stats = AWQ_LITE_STATS
     stats.clear()
     stats.update({"search": search, "passes": 0, "stages_s": {}})
@@ -693,6 +817,10 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
 
     mods = [(n, m) for n, m in model.named_modules()
             if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    # the stages cover the WHOLE call (setup = helpers, weight scales, Gram buffers; teardown = the bookkeeping after the
+    # fold), so that  sum(stages_s) == wall-clock of awq_lite  by construction
+    clock["dev"] = mods[0][1].weight.device if mods else None
+    stage(None)
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
     for _, m in mods:
         # quantized inputs (W4A8 AWQ; setup, :1436-1444): the input quantizer is bypassed for the whole search -- the
@@ -707,7 +835,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 h.setup_disabled = True
             else:
                 iq.axis = -1
-    state = {"mode": "cache", "do_gemm": True, "do_exact": False}
+    state = {"mode": "cache", "do_gemm": True, "do_exact": False, "store": bool(store_activations), "stored_bytes": 0,
+             "store_last": None}
     if mods:
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
@@ -729,6 +858,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
     # With other quantizers active (FP8 KV cache, ...) the reference's search pass sees THEIR quantization noise in
     # the activations; the Gram matrices are then accumulated in a second pass instead of the cache pass.
     state["gram_pass"] = "search" if others else "cache"
+    if others:
+        state["store"] = False  # the search pass must SEE the other quantizers' noise: nothing of the cache pass is reusable
 
     def accumulate_gram(h, input, x2):
         h.num_gram_steps += 1
@@ -795,6 +926,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 iq.disable()
         if state["mode"] == state["gram_pass"] and h.gram is not None and h.is_enabled:
             accumulate_gram(h, input, x2)
+        if state["mode"] == "cache" and state["store"] and h.is_enabled:
+            store_batch(h, input, x2, out_actual)
         if state["mode"] == "cache" or not h.is_enabled:
             return out_actual
         out2 = out_actual.reshape(-1, out_actual.shape[-1])
@@ -807,6 +940,60 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             error_gemms(self, h, x2, out2, None, h.loss_buf)
             h.num_search_steps += 1
         return out_actual
+
+    def store_batch(h, input, x2, out_actual):
+        """store_activations: keep this batch's input and out_actual of this linear for the replayed exact pass.  The
+        tensors exist anyway -- the store only keeps them alive -- and are charged to the HBM budget (an input shared by
+        q / k / v or gate / up once)."""
+        nbytes = out_actual.numel() * out_actual.element_size()
+        if state["store_last"] is not input:
+            nbytes += x2.numel() * x2.element_size()
+        if not budget.reserve(nbytes):
+            drop_stores()  # does not fit: the exact pass will be a real one
+            return
+        state["store_last"] = input
+        state["stored_bytes"] += nbytes
+        h.stored.append((x2, out_actual.reshape(-1, out_actual.shape[-1])))
+
+    def drop_stores():
+        for hh in helpers.values():
+            hh.stored = []
+        budget.release(state["stored_bytes"])
+        state["stored_bytes"], state["store"], state["store_last"] = 0, False, None
+
+    def replay_search_pass():
+        """The search pass from the stored activations, linear by linear: every candidate this pass has to score of a
+        linear (its near-ties, or all of them for a linear without a Gram matrix) over all stored batches, then the
+        next linear -- one linear's search weights are alive at a time."""
+        for _, m in mods:
+            h = helpers[m]
+            if not h.is_enabled or h.act_scale is None or not h.stored:
+                continue
+            if h.use_gram:
+                if not (state["do_exact"] and h.pending):
+                    continue
+                subset, buf = h.pending, h.exact_pass_buf
+            elif state["do_gemm"]:
+                subset, buf = None, h.loss_buf
+            else:
+                continue
+            keep, h._cache_w = h._cache_w, True  # resident for this linear's batches, released right after
+            for x2, out2 in h.stored:
+                error_gemms(m, h, x2, out2, subset, buf)
+                if h.use_gram:
+                    h.num_exact_steps += 1
+                else:
+                    h.num_search_steps += 1
+            h._inv_scale = h._scale_dt = h._w_hat = None
+            h._cache_w = keep
+
+    def search_pass():
+        if state["store"]:
+            replay_search_pass()
+            stats["replayed_passes"] = stats.get("replayed_passes", 0) + 1
+        else:
+            forward_loop(model)
+            stats["passes"] += 1
 
     originals = {}
     for _, m in mods:
@@ -926,7 +1113,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         if h._cache_w and h._w_hat is not None:
             budget.release(h._w_hat.numel() * h._w_hat.element_size())
         h._inv_scale = h._scale_dt = h._w_hat = None
-        h._cache_w = budget.reserve(len(indices) * m.weight.numel() * m.weight.element_size())
+        # (a replayed pass keeps one linear's search weights alive at a time: nothing to reserve per linear)
+        h._cache_w = (not state["store"]) and budget.reserve(len(indices) * m.weight.numel() * m.weight.element_size())
 
     def collect_exact() -> bool:
         """After an exact pass: the scores of the pending candidates (summed over the data-parallel group, so every
@@ -978,8 +1166,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         # during the cache pass and quantizes during the search pass, as in the reference (:1574-1586); dynamic ones
         # are switched to pass-through for the cache pass
         enable_stats_collection(others_holder)
-        clock["dev"] = mods[0][1].weight.device if mods else None
-        stage(None)
+        stage("setup")
         forward_loop(model)  # cache pass
         stats["passes"] += 1
         stage("cache_pass")
@@ -1043,9 +1230,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         if need_gemm or need_gram or state["do_exact"]:
             state["mode"] = "search"
             # search pass: error GEMMs (all candidates of the linears without a Gram matrix, the near-ties of the
-            # others), and the Gram matrices when they had to wait for quantized inputs
-            forward_loop(model)
-            stats["passes"] += 1
+            # others), and the Gram matrices when they had to wait for quantized inputs -- replayed from the stored
+            # activations when the call keeps them (store_activations), a second forward otherwise
+            if need_gram:
+                drop_stores() if state["store"] else None  # (Gram matrices from the search pass need the real forward)
+            search_pass()
             stage("search_pass")
             state["do_gemm"] = False
             if need_gram:
@@ -1059,8 +1248,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             while state["do_exact"]:
                 # the near-ties of linears whose Gram matrix came from the search pass; candidates admitted by the
                 # margin's self-check (tie_check)
-                forward_loop(model)
-                stats["passes"] += 1
+                search_pass()
                 stage("search_pass")
                 state["do_exact"] = collect_exact()
         for h in helpers.values():
@@ -1082,6 +1270,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         for h in helpers.values():
             h.release()
             h.gram = None
+            h.stored = []
+
     def restore_input_quantizer(m, h):
         """:1642-1653 / :1707-1714: the per-channel amax is kept (on the host) for the smoothing step and collapses to
         the per-tensor amax the quantizer is exported with; a dynamic input quantizer is just re-enabled."""
@@ -1160,6 +1350,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                                 "max_need_over_margin": round(max((h.tie_need / h.margin_used for h in checked),
                                                                   default=0.0), 4),
                                 "max_need": max((h.tie_need for h in checked), default=0.0)}})
+    stage("teardown")
     return helpers
 
 
@@ -1274,7 +1465,7 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
     out = {}
     with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
         if algorithm in ("awq_full", "awq_lite"):
-            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin", "tie_check")}
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin", "tie_check", "layer_local")}
             out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
         if algorithm in ("awq_full", "awq_clip"):
             clip_kw = {k: v for k, v in kwargs.items()

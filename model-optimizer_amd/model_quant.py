@@ -228,9 +228,41 @@ def set_quantizer_by_cfg(model: nn.Module, quant_cfg):
                 _apply_attrs(cur, attrs if cfg is None else {**attrs, "enable": enable})
 
 
+# what the last quantize() call spent where (wall-clock seconds; the device is drained at the three stage boundaries,
+# where nothing is in flight that a later stage could have overlapped): convert = nn.Linear -> QuantLinear and the
+# on-the-fly attention / expert wrappers, set_quantizers = the wildcard config walk, calibrate = the algorithm (for
+# awq_lite its own stages are in model_calib.AWQ_LITE_STATS["stages_s"] and sum to this figure)
+QUANTIZE_STATS: dict = {}
+
+
+def _drain(model):
+    import torch
+
+    p = next(model.parameters(), None)
+    if p is not None and p.is_cuda:
+        torch.cuda.synchronize(p.device)
+
+
 def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
+    import time
+
+    QUANTIZE_STATS.clear()
+    stages = QUANTIZE_STATS.setdefault("stages_s", {})
+    _drain(model)
+    t0 = t = time.perf_counter()
+
+    def stage(name):
+        nonlocal t
+        _drain(model)
+        now = time.perf_counter()
+        stages[name] = round(now - t, 4)
+        QUANTIZE_STATS["total_s"] = round(now - t0, 4)
+        t = now
+
     replace_quant_module(model)
+    stage("convert")
     set_quantizer_by_cfg(model, config["quant_cfg"])
+    stage("set_quantizers")
     algo = config.get("algorithm", "max")
     method, kwargs = (algo, {}) if not isinstance(algo, dict) else (algo["method"], {k: v for k, v in algo.items() if k != "method"})
     if method is None:
@@ -246,6 +278,7 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
         model_calib.awq(model, forward_loop, algorithm=method, **kwargs)
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
+    stage("calibrate")
     return model
 
 
@@ -305,14 +338,25 @@ def fold_weight(model: nn.Module, keep_attrs: bool = False, shard_weights: bool 
             units += [(w.data if hasattr(w, "data") else w, q) for w, q in m.iter_weights_for_calibration()
                       if isinstance(q, TensorQuantizer) and q.fake_quant]
     shard = mdist.resolve_shard(shard_weights)
-    # only contiguous weights can be received in place from their owner; the (rare) others are folded by every rank
-    dealt = [u for u in units if u[0].is_contiguous()] if shard else []
-    mine = mdist.shard_list(dealt) + [u for u in units if not u[0].is_contiguous()] if shard else units
+    # only contiguous weights can be received in place from their owner; the (rare) others are folded by every rank --
+    # and so are weights whose storage appears in more than one unit (tied / shared tensors): dealt to different owners,
+    # the second broadcast would overwrite the first fold, where a single rank (and the reference) folds them in sequence
+    ptr_count = {}
+    for w, _ in units:
+        ptr_count[w.data_ptr()] = ptr_count.get(w.data_ptr(), 0) + 1
+
+    def dealable(u):
+        return u[0].is_contiguous() and ptr_count[u[0].data_ptr()] == 1
+
+    dealt = [u for u in units if dealable(u)] if shard else []
+    mine = mdist.shard_list(dealt) + [u for u in units if not dealable(u)] if shard else units
     with torch.no_grad():
         groups, single = {}, []
         for w, wq in mine:
-            if wq._disabled:
-                continue  # disabled and no pre-quant scale / rotation on this path: the forward is the identity
+            if wq._disabled and wq.pre_quant_scale is None:
+                continue  # disabled and no pre-quant scale on this path: the forward is the identity
+            # (a disabled quantizer that still carries an active pre-quant scale IS folded -- its forward multiplies by
+            # the scale before the disabled early return, quant_module.py:144-158 and its docstring :163-165)
             kind = _fold_kind(w, wq)
             if kind is None:
                 single.append((w, wq))
@@ -332,7 +376,7 @@ def fold_weight(model: nn.Module, keep_attrs: bool = False, shard_weights: bool 
             else:
                 SegmentTable(ws, outputs=ws, group_size=kind[1]).amax_qdq_int_group(kind[2], kind[3], kind[4])
         for w, wq in single:
-            w.copy_(wq(w.contiguous()).to(w.dtype))
+            w.copy_(wq(w.float().contiguous()).to(w.dtype))  # quant_module.py:150: the quantizer sees the fp32 weight
         if shard:
             mdist.broadcast_from_owners([w for w, _ in dealt], group=mdist.replica_group())
         seen = set()

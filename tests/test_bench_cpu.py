@@ -26,7 +26,8 @@ def test_model_tables_give_the_survey_sizes():
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_pool_partition(world, scaling, monkeypatch):
     """Every pool tensor lives on exactly one rank; weak: every rank holds one model's worth (same shapes in the same
-    order, different values), strong: one model's list dealt round-robin; a tensor's values depend on its pool index only."""
+    order, different values), strong: one model's list dealt largest-first round-robin; a tensor's values depend on its
+    pool index only."""
     monkeypatch.setitem(bench.MODELS, "tiny", (16, 24, 3, 8))
     per_rank = [bench.make_weights("tiny", 3, "cpu", rank=r, world=world, scaling=scaling) for r in range(world)]
     n_model = 3 * 7
@@ -41,7 +42,7 @@ def test_pool_partition(world, scaling, monkeypatch):
         if scaling == "weak":
             assert idx == list(range(r * n_model, (r + 1) * n_model))
         else:
-            assert idx == list(range(r, n_model, world))
+            assert idx == bench.deal(shapes, r, world) == sorted(idx)
     if world > 1:
         # the same pool index gives the same tensor whoever generates it; different indices differ
         again, idx, _ = bench.make_weights("tiny", 3, "cpu", rank=1, world=world, scaling=scaling)
@@ -52,6 +53,63 @@ def test_pool_partition(world, scaling, monkeypatch):
         single, _, _ = bench.make_weights("tiny", 3, "cpu")
         for ws, idx, _ in per_rank:
             assert all(torch.equal(w, single[i]) for w, i in zip(ws, idx))
+
+
+@pytest.mark.parametrize("model", ["llama3-8b", "llama3-70b", "mixtral-8x7b"])
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_strong_deal_is_balanced(model, world):
+    """The strong-scaling deal gives every rank the same number of tensors of every shape -- the ranks' bytes are equal,
+    so max-over-ranks time is not an imbalance artefact."""
+    shapes = [s for _ in range(bench.MODELS[model][2]) for s in bench.layer_shapes(model)]
+    loads = [sum(shapes[i][0] * shapes[i][1] for i in bench.deal(shapes, r, world)) for r in range(world)]
+    assert len(set(loads)) == 1
+    assert sorted(i for r in range(world) for i in bench.deal(shapes, r, world)) == list(range(len(shapes)))
+
+
+def test_default_model_is_the_baseline_config_of_the_format():
+    """N = 1: configs[1]'s Llama-3-8B; N > 1: the multi-GPU configuration BASELINE.json names for the format."""
+    for wl in bench.SCALE_MODEL:
+        assert bench.default_model(wl, 1) == "llama3-8b"
+    for n in (2, 4, 8):
+        assert bench.default_model("fp8", n) == bench.default_model("mask24", n) == "mixtral-8x7b"
+        assert bench.default_model("int4g128", n) == bench.default_model("mxfp4-sq", n) == "llama3-70b"
+    args = bench.build_parser().parse_args([])
+    assert (args.gpus, args.scaling, args.model, args.workload) == (1, "strong", None, "fp8")
+
+
+def test_bare_contract_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment re-executes itself under torch.distributed.run:
+    here (no GPU) both ranks then stop with the no-GPU message -- which only ranks started by the launcher print twice."""
+    import subprocess
+    import sys
+
+    cmd = bench.launch_command(2, ["--gpus", "2"], port=29999)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-3:] == [os.path.join(ROOT, "bench.py"), "--gpus", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # (a GPU box: the ranks must stop at the same place)
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr[-2000:]
+
+
+def test_cpu_baseline_only_mode_prints_one_object(monkeypatch):
+    """`--cpu-baseline-only` (the process the main run starts LAST for the CPU baseline) touches no GPU and prints the
+    cpu_baseline object."""
+    import json
+    import subprocess
+    import sys
+
+    code = ("import importlib.util, sys, json; spec = importlib.util.spec_from_file_location('b', sys.argv[1]); "
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b); "
+            "b.cpu_baseline.__defaults__ = (0.2,); sys.argv = ['bench.py', '--cpu-baseline-only', '--workload', 'int4g128']; "
+            "b.main()")
+    r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    obj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert obj["kind"] == "port" and obj["unit"] == "GB/s" and obj["value"] > 0 and obj["cores"] >= 1
 
 
 def test_committed_pmc_traffic_matches_the_algorithmic_bytes():

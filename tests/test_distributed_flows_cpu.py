@@ -365,3 +365,58 @@ def test_forced_single_rank_walks_every_collective_site():
     assert line["ok"], line["mismatches"]
     for name in ("all_reduce", "reduce", "broadcast", "all_gather_object", "broadcast_object_list", "barrier"):
         assert line["calls"].get(name, 0) > 0, line["calls"]
+
+
+# ------------------------------------------------------------------------------------------------ DP subgroups
+def _subgroup_worker(rank, world, port, ret):
+    """4 ranks = 2 data-parallel groups {0, 1} and {2, 3} (as the DP groups of a DP x TP layout are): the replicas of a
+    group hold the SAME model (seeded by the group), the two groups different ones.  declare_data_parallel(own group):
+    every weight-side unit must have exactly one owner INSIDE the group (shard_list numbers the ranks by the group, like
+    owner_rank / broadcast_from_owners), statistics stay inside the group, and every rank ends with the single-rank result
+    of ITS group's model."""
+    try:
+        moa = _moa_import.load()
+        _install_backend(moa)
+        mq, sp = moa.model_quant, moa.sparsity
+        gid = rank // 2
+        batches = _batches(128, torch.float32, n=4)
+
+        def flows(mine):
+            out = []
+            m = moa.quantize(MLP(seed=10 + gid), copy.deepcopy(mq.FP8_DEFAULT_CFG), lambda mm: [mm(b) for b in mine])
+            out.append({"amax": _amaxes(m)})
+            mq.fold_weight(m)
+            out.append({"w": {n: p.detach().clone() for n, p in m.named_parameters()}})
+            m = sp.sparsify(MLP(seed=10 + gid), "sparse_magnitude")
+            out.append({"mask": {n: mod._weight_mask.clone() for n, mod in m.named_modules() if hasattr(mod, "_weight_mask")},
+                        "w": {n: p.detach().clone() for n, p in m.named_parameters()}})
+            m = moa.quantize(MLP(seed=10 + gid), copy.deepcopy(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG), None)
+            mq.fold_weight(m)
+            out.append({"w": {n: p.detach().clone() for n, p in m.named_parameters()}})
+            return out
+
+        with torch.no_grad():
+            want = flows(batches)
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            groups = [dist.new_group([0, 1]), dist.new_group([2, 3])]  # (every rank creates every group)
+            moa.distributed.declare_data_parallel(groups[gid])
+            assert moa.distributed.shard_list(list(range(5))) == list(range(5))[rank % 2::2]
+            got = flows(batches[rank % 2::2])
+        _compare("subgroup", want, got)
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        ret[rank] = f"{type(e).__name__}: {e}\n{traceback.format_exc()}"
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_data_parallel_subgroups_of_a_four_rank_world():
+    world = 4
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_subgroup_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {v}" for r, v in dict(ret).items())

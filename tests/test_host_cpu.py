@@ -494,3 +494,25 @@ def test_presets_keep_moe_gates_and_routers_in_high_precision():
     assert mlp.up_proj.weight_quantizer.is_enabled and mlp.up_proj.input_quantizer.is_enabled
     for lin in (mlp.gate, mlp.shared_expert_gate, net.router, net.lm_head):
         assert not lin.weight_quantizer.is_enabled and not lin.input_quantizer.is_enabled
+
+
+def test_quantize_does_not_import_transformers():
+    """quantize() of a plain nn.Module must not import transformers: the cold import pages in for 17-30 s on a fresh box and
+    sat inside the timed INT4-AWQ call of round 3's driver run (profiles/r04_awq_unstaged.md).  Only a process that already
+    imported transformers.modeling_utils can hold a PreTrainedModel, so the check reads sys.modules."""
+    import subprocess
+    import sys
+
+    code = ("import sys, torch; sys.path.insert(0, %r); import _moa_import; moa = _moa_import.load(); "
+            "from model_optimizer_amd import nn as qnn, hf_attention; "
+            "m = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.ReLU(), torch.nn.Linear(8, 4)); "
+            "qnn.replace_quant_module(m); "
+            "assert isinstance(m[0], qnn.QuantLinear) and not hf_attention._is_supported_hf_model(m); "
+            "assert 'transformers' not in sys.modules, 'convert imported transformers'; "
+            "import transformers; "
+            "cfg = transformers.LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, "
+            "num_key_value_heads=2, vocab_size=50); hm = transformers.LlamaForCausalLM(cfg); "
+            "assert hf_attention._is_supported_hf_model(hm) and not hf_attention._is_supported_hf_model(m); print('ok')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

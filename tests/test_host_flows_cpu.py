@@ -520,3 +520,127 @@ def test_weight_statistics_are_collected_once_per_max_calibration(monkeypatch):
         for (n, q), (_, r) in zip(model.named_modules(), redo.named_modules()):
             if hasattr(q, "_amax"):
                 assert torch.equal(q._amax, r._amax), n
+
+
+# ------------------------------------------------------------------------------------------------ layer-local awq_lite
+class _Block(torch.nn.Module):
+    def __init__(self, d, g):
+        super().__init__()
+        self.q = torch.nn.Linear(d, d, bias=False)
+        self.k = torch.nn.Linear(d, d // 2, bias=False)
+        self.up = torch.nn.Linear(d, 2 * d, bias=False)
+        self.down = torch.nn.Linear(2 * d, d, bias=False)
+        with torch.no_grad():
+            for lin in (self.q, self.k, self.up, self.down):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.05)
+
+    def forward(self, h, scale=1.0):
+        a = self.q(h) + torch.nn.functional.pad(self.k(h), (0, h.shape[-1] // 2))  # q and k read the SAME tensor
+        m = h + scale * a
+        return m + self.down(torch.nn.functional.gelu(self.up(m)))
+
+
+class _Stack(torch.nn.Module):
+    def __init__(self, d=128, n=3, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.embed = torch.nn.Linear(d, d, bias=False)
+        self.layers = torch.nn.ModuleList([_Block(d, g) for _ in range(n)])
+
+    def forward(self, x):
+        h = self.embed(x)
+        for layer in self.layers:
+            h = layer(h, scale=0.5)
+        return h
+
+
+def _stack_batches(d=128, n=3):
+    g = torch.Generator().manual_seed(7)
+    ch = torch.exp(torch.randn(d, generator=g))
+    ch[:2] *= 30
+    return [(torch.randn(32, d, generator=g) * ch).to(torch.bfloat16) for _ in range(n)]
+
+
+@pytest.mark.parametrize("tie_margin", [None, float("inf"), 0.05])
+def test_awq_lite_layer_local_equals_the_whole_model_flow(hostmem, monkeypatch, tie_margin):
+    """awq_lite walking the decoder stack one layer at a time -- ONE forward through every layer, the near-ties re-scored from
+    the stored activations (no second pass) -- picks the alphas, folds the weights and leaves the scales of the whole-model
+    two-pass flow, bit for bit; with tie_margin = inf every candidate of every linear goes through the replayed exact pass."""
+    import copy
+
+    from model_optimizer_amd import model_calib, model_quant
+
+    monkeypatch.setattr(model_calib._WeightCacheBudget, "host_bytes", 1 << 30)
+    base = _Stack().to(torch.bfloat16)
+    batches = _stack_batches()
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["quant_cfg"]["*embed*"] = {"enable": False}
+    cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+
+    def run(layer_local):
+        c = copy.deepcopy(cfg)
+        c["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": "auto", "layer_local": layer_local,
+                          **({"tie_margin": tie_margin} if tie_margin is not None else {})}
+        calls = {"n": 0}
+
+        def loop(m):
+            calls["n"] += 1
+            for b in batches:
+                m(b)
+
+        with torch.no_grad():
+            q = moa.quantize(copy.deepcopy(base), c, loop)
+        return q, dict(model_calib.AWQ_LITE_STATS), calls["n"]
+
+    whole, ws, wn = run(False)
+    local, ls, ln = run(True)
+    assert ls.get("layer_local") and ls["passes"] == 1 and ls["layers"] == 3 and ln == 1
+    if tie_margin is not None:
+        assert ls["replayed_passes"] >= 3 and ws["passes"] >= 2 and wn >= 2  # the whole-model flow needed a second forward
+        assert ls["rescored_candidates"] == ws["rescored_candidates"] > 0
+    n = 0
+    for (name, a), (_, b) in zip(whole.named_modules(), local.named_modules()):
+        if hasattr(a, "awq_lite"):
+            n += 1
+            assert a.awq_lite.best_alpha == b.awq_lite.best_alpha, name
+            assert a.awq_lite.contenders == b.awq_lite.contenders, name
+            assert torch.equal(a.awq_lite.loss_buf, b.awq_lite.loss_buf), name
+            assert torch.equal(a.weight, b.weight), name
+            assert torch.equal(a.input_quantizer.pre_quant_scale, b.input_quantizer.pre_quant_scale), name
+            assert torch.equal(a.weight_quantizer.amax, b.weight_quantizer.amax), name
+    assert n == 12
+
+
+def test_awq_lite_layer_local_is_the_default_on_a_hugging_face_stack(golden, hostmem, monkeypatch):
+    """search="auto" on a transformers decoder stack driven by its own forward: the layer-local single pass is chosen by
+    itself (KV-cache objects among the layer arguments are dropped) and equals the whole-model flow; a forward loop that
+    feeds the linears directly (the replay fixtures) never reaches the first decoder layer and falls back."""
+    import copy
+
+    from model_optimizer_amd import model_calib, model_quant
+
+    monkeypatch.setattr(model_calib._WeightCacheBudget, "host_bytes", 1 << 30)
+    g = golden("export_llama")
+    base = _llama(g, g.cases, torch.bfloat16)
+    vocab = base.config.vocab_size
+    toks = [torch.randint(0, vocab, (2, 24), generator=torch.Generator().manual_seed(i)) for i in range(3)]
+
+    def run(layer_local):
+        c = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+        c["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": "auto", "tie_margin": 0.02,
+                          **({} if layer_local is None else {"layer_local": layer_local})}
+        with torch.no_grad():
+            q = moa.quantize(copy.deepcopy(base), c, lambda m: [m(t) for t in toks])
+        return q, dict(model_calib.AWQ_LITE_STATS)
+
+    whole, ws = run(False)
+    auto, st = run(None)
+    assert st.get("layer_local") and st["passes"] == 1 and not ws.get("layer_local")
+    n = 0
+    for (name, a), (_, b) in zip(whole.named_modules(), auto.named_modules()):
+        if hasattr(a, "awq_lite"):
+            n += 1
+            assert a.awq_lite.best_alpha == b.awq_lite.best_alpha, name
+            assert torch.equal(a.weight, b.weight), name
+            assert torch.equal(a.weight_quantizer.amax, b.weight_quantizer.amax), name
+    assert n == 7 * base.config.num_hidden_layers

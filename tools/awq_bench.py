@@ -127,6 +127,12 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
         "best_alpha_hist": {str(a): alphas.count(a) for a in sorted(set(alphas))},
         "passes": moa.model_calib.AWQ_LITE_STATS.get("passes"), "stages_s": moa.model_calib.AWQ_LITE_STATS.get("stages_s"),
         "tie_check": moa.model_calib.AWQ_LITE_STATS.get("tie_check"),
+        # quantize()'s own three stages (convert, set_quantizers, calibrate = sum of stages_s) and what of the measured
+        # wall-clock neither clock saw (this rank; the barriers of an N > 1 run are in it)
+        "quantize_stages_s": moa.model_quant.QUANTIZE_STATS.get("stages_s"),
+        "unstaged_s": round(dt - sum((moa.model_quant.QUANTIZE_STATS.get("stages_s") or {}).values()), 4),
+        "awq_unstaged_s": round((moa.model_quant.QUANTIZE_STATS.get("stages_s") or {}).get("calibrate", 0.0)
+                                - sum((moa.model_calib.AWQ_LITE_STATS.get("stages_s") or {}).values()), 4),
         "best_alphas": alphas}
 
 

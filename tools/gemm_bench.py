@@ -1,7 +1,6 @@
 """MFMA error-GEMM throughput on one MI355X at the Llama-3-8B / 70B linear shapes of one calibration batch
 (8 x 512 = 4096 tokens).  2*T*Cout*Cin flop / HIP-event time, against the 2.5 PFLOP/s dense bf16 peak.
-A/B knob: MOQ_TUNE_GEMM_GEO=4|10 (read once per process; the other loop structures need the experiment library,
-`MOQ_EXPERIMENTS=1 model-optimizer_amd/csrc/build.sh` and `--lib model-optimizer_amd/csrc/libmoquant_exp.so`).  Also times torch's library GEMM (F.linear) + the
+A/B knob: MOQ_TUNE_GEMM_GEO=4|10 (read once per process).  Also times torch's library GEMM (F.linear) + the
 unfused loss ops the reference would run, for scale.
 Usage (GPU box): python tools/gemm_bench.py [> profiles/rNN_gemm_table.md]"""
 

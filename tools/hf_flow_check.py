@@ -140,11 +140,12 @@ def run(args, moa=None, dev=None) -> dict:
         named = [(n, m) for n, m in model.named_modules() if hasattr(m, "awq_lite")]
         with open(args.dump, "w") as f:
             json.dump({"search": args.search, "tie_margin": args.tie_margin, "alphas": awq[0].alphas,
-                       "planes": os.environ.get("MOQ_TUNE_GRAM_PLANES"),
+                       "planes": {str(k): v for k, v in moa.model_calib.GRAM_SCORE_PLANES.items()},
                        "linears": [{"name": n, "shape": list(m.weight.shape), "best_alpha": float(m.awq_lite.best_alpha),
                                     "loss": [float(v) for v in m.awq_lite.loss_buf.tolist()],
                                     "gram_loss": m.awq_lite.gram_loss, "contenders": m.awq_lite.contenders}
                                    for n, m in named]}, f)
+    extra["quantize_stages_s"] = dict(moa.model_quant.QUANTIZE_STATS.get("stages_s") or {})
     if awq:
         extra["awq_stats"] = dict(moa.model_calib.AWQ_LITE_STATS)
         alphas = [round(float(h.best_alpha), 1) for h in awq if h.best_alpha is not None]
