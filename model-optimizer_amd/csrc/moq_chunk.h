@@ -162,17 +162,35 @@ static inline int log2_or_neg(int64_t g) {
   return s;
 }
 
-// copy-shaped passes: ~8 chunks per workgroup, at least a full machine (2048), at most 128 Ki workgroups
-static inline int copy_grid(int64_t n_chunks) {
-  const int64_t div = moq_tune("MOQ_TUNE_CHUNKS_PER_WG", 8);  // (experiment build only)
-  int64_t g = n_chunks / (div > 0 ? div : 8);
+// Copy-shaped passes (read + write): ONE chunk per workgroup, grid = n_chunks -- the machine's resident workgroups form a single
+// dense window that moves through the tensors in dispatch order.  Rounds 1-3 ran ~8 chunks per workgroup (chunk = blockIdx +
+// k * gridDim: eight windows 1.6 GB apart), which is faster on SOME placements of the tensors (0.80 of 8 TB/s) and slower on
+// others (0.68), by box and by allocation; the single window runs at 0.76-0.77 wherever the driver put the data, on every box
+// measured (profiles/r04_pool_placement.md: eight differently placed copies of the Llama-3-8B weights per process, five boxes;
+// more windows are monotonically worse on the boxes of the slow class whatever their distance).  The kernels keep their
+// grid-stride loops (a grid is capped at 2^31 - 1 workgroups); MOQ_TUNE_* exist in the experiment build only.
+static inline int64_t copy_grid64(int64_t n_chunks) {
+  const int64_t div = moq_tune("MOQ_TUNE_CHUNKS_PER_WG", 1);
+  int64_t g = n_chunks / (div > 0 ? div : 1);
+  const int64_t cap = moq_tune("MOQ_TUNE_COPY_GRID_CAP", 0x7FFFFFFF);
   if (g < 2048) g = 2048;
-  if (g > moq_tune("MOQ_TUNE_COPY_GRID_CAP", 131072)) g = moq_tune("MOQ_TUNE_COPY_GRID_CAP", 131072);
-  const int64_t forced = moq_tune("MOQ_TUNE_COPY_GRID", 0);  // (experiment build only) an explicit grid
-  if (forced > 0) g = forced;
-  if (moq_tune("MOQ_TUNE_COPY_GRID_ODD", 0)) g |= 1;
+  if (g > cap) g = cap;
+  if (g > n_chunks) g = n_chunks;
+  return g < 1 ? 1 : g;
+}
+static inline int copy_grid(int64_t n_chunks) { return (int)copy_grid64(n_chunks); }
+// read-only sweeps (whole-model abs-max): one chunk per workgroup as well -- 0.86 of 8 TB/s against 0.83 for the strided order
+// of rounds 1-3 on the same allocations (profiles/r04_pool_placement.md)
+static inline int read_grid(int64_t n_chunks) {
+  const int64_t div = moq_tune("MOQ_TUNE_READ_CHUNKS_PER_WG", 1);
+  int64_t g = n_chunks / (div > 0 ? div : 1);
+  if (g < 2048) g = 2048;
+  if (g > 0x7FFFFFFF) g = 0x7FFFFFFF;
   if (g > n_chunks) g = n_chunks;
   return (int)(g < 1 ? 1 : g);
 }
-
-
+// Dynamic LDS requested by the whole-model read + write launches although their kernels use none: 32 KiB per 256-thread
+// workgroup caps a CU at 5 resident workgroups instead of 8 (a 20 MiB window over the chip instead of 32 MiB).  Measured per
+// kernel on the same allocations (profiles/r04_pool_placement.md, "occupancy"): FP8 / INT-k map 0.758 -> 0.768, fused INT4 g128
+// 0.736 -> 0.772, 2:4 mask 0.777 -> 0.787 at 32 KiB; the MX kernel (more registers per thread) is best at 24 KiB: 0.729 -> 0.739.
+static inline size_t copy_lds(size_t dflt = 32 * 1024) { return (size_t)moq_tune("MOQ_TUNE_COPY_LDS", (long long)dflt); }

@@ -822,7 +822,7 @@ extern "C" int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* 
   if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
   const int grid = copy_grid(n_chunks);
 #define MOQ_MTMX_LAUNCH(L, F) \
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, fmt))
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), copy_lds(24 * 1024), S(stream), segs, blk_start, n_seg, n_chunks, fmt))
 #define MOQ_MTMX_CASE(L)                                     \
   case L:                                                    \
     if (fmt == MOQ_E2M1) { MOQ_MTMX_LAUNCH(L, MOQ_E2M1); }   \
@@ -904,7 +904,7 @@ extern "C" int moq_mt_mask_2to4(const moq_seg* segs, const int64_t* blk_start, i
     return MOQ_ERR_INVALID;
   }
   if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mask24_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), 0,
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mask24_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), copy_lds(),
                                             S(stream), segs, blk_start, n_seg, n_chunks));
   return check_launch("moq_mt_mask_2to4");
 }

@@ -411,8 +411,8 @@ __global__ __launch_bounds__(kBlock) void mt_amax_kernel(const moq_seg* __restri
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<uint32_t*>(cur.sg.amax), acc);
 }
 
-// Two-stage form of the per-tensor abs-max: stage 1 sweeps memory as one dense window (chunk = blockIdx + k * gridDim,
-// large grid -- the order in which a read-only stream reaches 7.0-7.2 TB/s instead of 6.3, tools/exp/stream_probe.hip)
+// Two-stage form of the per-tensor abs-max: stage 1 sweeps memory as one dense window (one workgroup per chunk, read_grid
+// in moq_chunk.h: 0.86 of 8 TB/s; the strided 8-chunks-per-workgroup order of rounds 1-3 reached 0.83 on the same data)
 // and stores ONE value per chunk with a plain store; stage 2 folds the per-chunk values of every tensor (one workgroup
 // per tensor, 3.4 MB in total for Llama-3-8B).  No same-address atomics at all.
 template <int DT>
@@ -456,10 +456,9 @@ __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg)
   if (i < n_seg) segs[i].amax[0] = 0.0f;
 }
 
-// Copy-shaped passes (read + write) run fastest when the workgroups sweep memory as one dense window:
-// chunk = blockIdx + k * gridDim with a large grid (few chunks per workgroup), 6.6 vs 5.4 TB/s for the
-// contiguous-run order on this chip (tools/exp/stream_probe.hip).  Chunks visited by a workgroup grow
-// monotonically, so the segment cursor only ever advances.
+// Copy-shaped passes (read + write) run fastest when the workgroups sweep memory as ONE dense window: the grid is one
+// workgroup per chunk (copy_grid, moq_chunk.h -- why), chunk = blockIdx + k * gridDim covers grids capped below the chunk
+// count.  Chunks visited by a workgroup grow monotonically, so the segment cursor only ever advances.
 template <int DT, class Op>
 __global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restrict__ segs,
                                                         const int64_t* __restrict__ blk_start,
@@ -488,75 +487,6 @@ __global__ __launch_bounds__(kBlock) void mt_map_kernel(const moq_seg* __restric
       chunk_apply<DT, false>(cur.sg.x, cur.sg.y, e0, cur.sg.n, op);
   }
 }
-
-#ifdef MOQ_EXPERIMENTS
-// EXPERIMENT (round 4, profiles/r04_pool_placement.md): one dense sweep window, a workgroup owns ADJ adjacent chunks and
-// issues ALL their loads before the first store (read phase / write phase per workgroup: ADJ x 16 KiB in flight each way).
-template <int DT, class Op, int ADJ>
-__global__ __launch_bounds__(kBlock) void mt_map_adj_kernel(const moq_seg* __restrict__ segs,
-                                                            const int64_t* __restrict__ blk_start,
-                                                            int n_seg, int64_t n_chunks, int num_bits,
-                                                            int is_unsigned, int narrow) {
-  constexpr int V = Elem<DT>::kVec;
-  constexpr int P = Chunk<DT>::kPackets;
-  const int64_t n_runs = (n_chunks + ADJ - 1) / ADJ;
-  if ((int64_t)blockIdx.x >= n_runs) return;
-  SegCursor cur;
-  cur.init(segs, blk_start, n_seg, (int64_t)blockIdx.x * ADJ);
-  Op op;
-  bool fresh = true;
-  for (int64_t r = blockIdx.x; r < n_runs; r += gridDim.x) {
-    const int64_t c0 = r * ADJ;
-    fresh |= cur.seek(c0);
-    const int64_t e0 = (c0 - cur.c_begin) * MOQ_MT_CHUNK;
-    const bool whole = c0 + ADJ <= cur.c_end && cur.aligned && e0 + (int64_t)ADJ * MOQ_MT_CHUNK <= cur.sg.n;
-    if (whole) {
-      if (fresh) {
-        fresh = false;
-        if constexpr (__is_same(Op, OpIntQdq)) {
-          op.q = make_intq(num_bits, is_unsigned, narrow);
-          op.set(cur.sg.amax[0]);
-        } else {
-          op.sc = fp8_scale(cur.sg.amax[0]);
-        }
-      }
-      Pack16 in[ADJ * P];
-#pragma unroll
-      for (int a = 0; a < ADJ; ++a)
-#pragma unroll
-        for (int u = 0; u < P; ++u)
-          in[a * P + u] = ld_packet<DT, true>(cur.sg.x, e0 + (int64_t)a * MOQ_MT_CHUNK + packet_off<DT>(u), cur.sg.n);
-#pragma unroll
-      for (int a = 0; a < ADJ; ++a)
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          float f[8];
-          unpack<DT>(in[a * P + u], f);
-          op(f, V);
-          st_packet<DT, true>(cur.sg.y, e0 + (int64_t)a * MOQ_MT_CHUNK + packet_off<DT>(u), cur.sg.n, pack<DT>(f));
-        }
-    } else {
-      for (int64_t c = c0; c < c0 + ADJ && c < n_chunks; ++c) {
-        fresh |= cur.seek(c);
-        if (fresh) {
-          fresh = false;
-          if constexpr (__is_same(Op, OpIntQdq)) {
-            op.q = make_intq(num_bits, is_unsigned, narrow);
-            op.set(cur.sg.amax[0]);
-          } else {
-            op.sc = fp8_scale(cur.sg.amax[0]);
-          }
-        }
-        const int64_t e = (c - cur.c_begin) * MOQ_MT_CHUNK;
-        if (cur.aligned && e + MOQ_MT_CHUNK <= cur.sg.n)
-          chunk_apply<DT, true>(cur.sg.x, cur.sg.y, e, cur.sg.n, op);
-        else
-          chunk_apply<DT, false>(cur.sg.x, cur.sg.y, e, cur.sg.n, op);
-      }
-    }
-  }
-}
-#endif
 
 template <int DT, int LPG>
 __global__ __launch_bounds__(kBlock) void mt_group_kernel(const moq_seg* __restrict__ segs,
@@ -799,7 +729,7 @@ extern "C" int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int
     return MOQ_ERR_INVALID;
   }
   if (n_chunks > 0) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_chunks_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), 0,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_chunks_kernel<DT>), dim3(read_grid(n_chunks)), dim3(kBlock), 0,
                                               S(stream), segs, blk_start, n_seg, n_chunks,
                                               reinterpret_cast<uint32_t*>(chunk_scratch)));
   }
@@ -812,20 +742,8 @@ extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_st
                                       int64_t n_chunks, int dt, void* stream) {
   int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_e4m3");
   if (rc != MOQ_OK || n_seg == 0 || n_chunks == 0) return rc;
-#ifdef MOQ_EXPERIMENTS
-  const int adj = (int)moq_tune("MOQ_TUNE_MAP_ADJ", 0);
-  if (adj == 2 || adj == 4 || adj == 8) {
-    const int64_t runs = (n_chunks + adj - 1) / adj;
-    int64_t g = moq_tune("MOQ_TUNE_COPY_GRID", 0);
-    if (g <= 0 || g > runs) g = runs;
-    if (adj == 2) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 2>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
-    else if (adj == 4) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 4>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
-    else { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_adj_kernel<DT, OpFp8Qdq, 8>), dim3((unsigned)g), dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks, 0, 0, 0)); }
-    return check_launch("moq_mt_fake_quant_e4m3");
-  }
-#endif
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpFp8Qdq>), dim3(copy_grid(n_chunks)),
-                                            dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
+                                            dim3(kBlock), copy_lds(), S(stream), segs, blk_start, n_seg, n_chunks,
                                             0, 0, 0));
   return check_launch("moq_mt_fake_quant_e4m3");
 }
@@ -840,7 +758,7 @@ extern "C" int moq_mt_fake_quant_int(const moq_seg* segs, const int64_t* blk_sta
     return MOQ_ERR_INVALID;
   }
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_map_kernel<DT, OpIntQdq>), dim3(copy_grid(n_chunks)),
-                                            dim3(kBlock), 0, S(stream), segs, blk_start, n_seg, n_chunks,
+                                            dim3(kBlock), copy_lds(), S(stream), segs, blk_start, n_seg, n_chunks,
                                             num_bits, is_unsigned, narrow_range));
   return check_launch("moq_mt_fake_quant_int");
 }
@@ -858,7 +776,7 @@ extern "C" int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk
   const int lpg = g / vec;
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((mt_group_kernel<DT, LPG>),
                                                                   dim3(copy_grid(n_chunks)), dim3(kBlock),
-                                                                  0, S(stream), segs, blk_start, n_seg,
+                                                                  copy_lds(), S(stream), segs, blk_start, n_seg,
                                                                   n_chunks, num_bits, is_unsigned,
                                                                   narrow_range)));
   return check_launch("moq_mt_amax_qdq_int_group");

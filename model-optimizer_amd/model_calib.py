@@ -619,13 +619,15 @@ GRAM_PLANES_SLACK = 3e-4
 # lie within TIE_SPREAD_FACTOR x S of the scored ones (d varies smoothly with alpha; the factor covers the extrapolation
 # past the scored set).  So a linear is settled when  margin >= TIE_SPREAD_FACTOR * S + gap_w ; otherwise its margin is
 # widened to twice that requirement, the newly admitted candidates are re-scored in a further pass, and the check repeats
-# (at most TIE_CHECK_MAX_ROUNDS times, then every candidate of the linear is scored).  Every widening costs one more pass
-# over the calibration data, so the factor is a price: full-size measurements (profiles/r03_awq_tie_check.md) -- the
-# synthetic outlier stack shows S <= 4.6e-5 against a 1.3e-3 margin (requirement / margin 0.07 whatever the factor); a
-# random-init HF Llama-3-8B, whose 11 candidates lie within 0.1-0.9 % of each other, shows S up to 8e-4 among its
-# contenders and a largest overturned Gram gap of 1.1e-4: factor 1.5 settles every linear in the one exact pass
-# (requirement / margin <= 0.98), factor 2 sends 5 of 224 linears through a third pass -- same alphas either way.
-TIE_SPREAD_FACTOR = 1.5
+# (at most TIE_CHECK_MAX_ROUNDS times, then every candidate of the linear is scored).  Full-size measurements
+# (profiles/r03_awq_tie_check.md): the synthetic outlier stack shows S <= 4.6e-5 against a 1.3e-3 margin (requirement /
+# margin 0.07 whatever the factor); a random-init HF Llama-3-8B, whose 11 candidates lie within 0.1-0.9 % of each other,
+# shows S up to 8e-4 among its contenders and a largest overturned Gram gap of 1.1e-4: factor 1.5 settles every linear
+# at once with requirement / margin up to 0.98 -- at the edge -- factor 2 widens 5 of 224 linears, same alphas.  Round 3
+# shipped 1.5 because a widening cost one more PASS over the calibration data; since round 4 the exact pass of a decoder
+# stack is a replay of stored activations (layer_local), a widening re-scores a handful of candidates of that one linear,
+# and the default is the safer 2.0.
+TIE_SPREAD_FACTOR = 2.0
 TIE_CHECK_MAX_ROUNDS = 3
 
 

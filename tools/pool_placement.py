@@ -119,32 +119,15 @@ def main():
 
     if args.sweep:
         # the experiment library (MOQ_LIB_PATH=.../libmoquant_exp.so) reads the MOQ_TUNE_* knobs on every call: one process
-        # compares grid shapes on the SAME allocations.  The stride between the chunks a workgroup visits is grid x 16 KiB.
-        n_chunks = tabs[0][1].n_chunks
-        settings = [("default n/8", {}),
-                    ("n/8 | 1 (odd)", {"MOQ_TUNE_COPY_GRID_ODD": "1"}),
-                    ("n/1", {"MOQ_TUNE_CHUNKS_PER_WG": "1", "MOQ_TUNE_COPY_GRID_CAP": "100000000"}),
-                    ("n/2", {"MOQ_TUNE_CHUNKS_PER_WG": "2", "MOQ_TUNE_COPY_GRID_CAP": "100000000"}),
-                    ("n/4", {"MOQ_TUNE_CHUNKS_PER_WG": "4", "MOQ_TUNE_COPY_GRID_CAP": "100000000"}),
-                    ("n/16", {"MOQ_TUNE_CHUNKS_PER_WG": "16"}),
-                    ("n/64", {"MOQ_TUNE_CHUNKS_PER_WG": "64"}),
-                    ("65536", {"MOQ_TUNE_COPY_GRID": "65536"}),
-                    ("65537", {"MOQ_TUNE_COPY_GRID": "65537"}),
-                    ("100003", {"MOQ_TUNE_COPY_GRID": "100003"}),
-                    ("106496 + 32", {"MOQ_TUNE_COPY_GRID": str(n_chunks // 8 + 32)}),
-                    ("106496 + 2048", {"MOQ_TUNE_COPY_GRID": str(n_chunks // 8 + 2048)}),
-                    ("8192", {"MOQ_TUNE_COPY_GRID": "8192"}),
-                    ("2048", {"MOQ_TUNE_COPY_GRID": "2048"}),
-                    # one dense window, a workgroup owns ADJ adjacent chunks: all loads, then all stores
-                    ("adj 2, dense", {"MOQ_TUNE_MAP_ADJ": "2"}),
-                    ("adj 4, dense", {"MOQ_TUNE_MAP_ADJ": "4"}),
-                    ("adj 8, dense", {"MOQ_TUNE_MAP_ADJ": "8"}),
-                    ("adj 4, 2 windows", {"MOQ_TUNE_MAP_ADJ": "4", "MOQ_TUNE_COPY_GRID": str(n_chunks // 8)}),
-                    ("adj 2, 4 windows", {"MOQ_TUNE_MAP_ADJ": "2", "MOQ_TUNE_COPY_GRID": str(n_chunks // 8)})]
-        if args.quick:
-            settings = [s_ for s_ in settings if s_[0] in ("default n/8", "n/1", "n/2") or s_[0].startswith("adj")]
-        knobs = ("MOQ_TUNE_COPY_GRID_ODD", "MOQ_TUNE_CHUNKS_PER_WG", "MOQ_TUNE_COPY_GRID_CAP", "MOQ_TUNE_COPY_GRID",
-                 "MOQ_TUNE_MAP_ADJ")
+        # compares grid shapes on the SAME allocations.  chunks per workgroup W: a workgroup visits chunks blockIdx + k * grid,
+        # i.e. the launch sweeps W windows (n_chunks / W) x 16 KiB apart; LDS: dynamic LDS per workgroup (occupancy cap).
+        settings = [("8 chunks / WG (rounds 1-3)", {"MOQ_TUNE_CHUNKS_PER_WG": "8", "MOQ_TUNE_COPY_GRID_CAP": "131072", "MOQ_TUNE_COPY_LDS": "0"}),
+                    ("2 chunks / WG", {"MOQ_TUNE_CHUNKS_PER_WG": "2", "MOQ_TUNE_COPY_LDS": "0"}),
+                    ("1 chunk / WG", {"MOQ_TUNE_CHUNKS_PER_WG": "1", "MOQ_TUNE_COPY_LDS": "0"}),
+                    ("1 chunk / WG, 24 KiB LDS", {"MOQ_TUNE_CHUNKS_PER_WG": "1", "MOQ_TUNE_COPY_LDS": "24576"}),
+                    ("1 chunk / WG, 32 KiB LDS (release)", {"MOQ_TUNE_CHUNKS_PER_WG": "1", "MOQ_TUNE_COPY_LDS": "32768"}),
+                    ("1 chunk / WG, 40 KiB LDS", {"MOQ_TUNE_CHUNKS_PER_WG": "1", "MOQ_TUNE_COPY_LDS": "40960"})]
+        knobs = ("MOQ_TUNE_CHUNKS_PER_WG", "MOQ_TUNE_COPY_GRID_CAP", "MOQ_TUNE_COPY_LDS", "MOQ_TUNE_READ_CHUNKS_PER_WG")
 
         def t_ms(fn):
             for _ in range(2):
@@ -158,15 +141,30 @@ def main():
             torch.cuda.synchronize()
             return a.elapsed_time(b) / args.reps
 
+        masks = {name: [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in t.inputs] for name, t, _ in tabs[:1]}
+        mtab = SegmentTable(tabs[0][1].inputs, outputs=masks[tabs[0][0]])
         rows = []
         for label, env in settings:
             for k in knobs:
                 os.environ.pop(k, None)
             os.environ.update(env)
-            row = {"grid": label}
+            row = {"order": label}
             for name, t, tg in tabs:
-                row[name] = round(n_elem * 4 / t_ms(lambda: t.fake_quant_e4m3()) / 1e9 / 8.0, 4)
-            row["int4g128:" + tabs[2][0]] = round(n_elem * (4 + 4 / 128) / t_ms(lambda: tabs[2][2].amax_qdq_int_group(4, False, False)) / 1e9 / 8.0, 4)
+                row["fp8:" + name] = round(n_elem * 4 / t_ms(lambda: t.fake_quant_e4m3()) / 1e9 / 8.0, 4)
+            for name, t, tg in tabs[:4]:
+                row["int4g128:" + name] = round(n_elem * (4 + 4 / 128) / t_ms(lambda: tg.amax_qdq_int_group(4, False, False)) / 1e9 / 8.0, 4)
+                row["mxfp4:" + name] = round(n_elem * 4 / t_ms(lambda: t.mx_fused_amax_convert(32, "E2M1")) / 1e9 / 8.0, 4)
+            row["mask24:" + tabs[0][0]] = round(n_elem * 3 / t_ms(lambda: mtab.mask_2to4()) / 1e9 / 8.0, 4)
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+        for label, env in (("read-only abs-max, 8 chunks / WG (release)", {"MOQ_TUNE_READ_CHUNKS_PER_WG": "8"}),
+                           ("read-only abs-max, 1 chunk / WG", {"MOQ_TUNE_READ_CHUNKS_PER_WG": "1"})):
+            for k in knobs:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            row = {"order": label}
+            for name, t, tg in tabs:
+                row["amax:" + name] = round(n_elem * 2 / t_ms(lambda: t.calibrate_amax()) / 1e9 / 8.0, 4)
             rows.append(row)
             print(json.dumps(row), flush=True)
         for k in knobs:
