@@ -147,7 +147,8 @@ int moq_fp8_unpack_tile(const uint8_t* q, const void* scales, void* out, int64_t
 int moq_amax_mid(const void* x, int64_t outer, int64_t mid, int64_t inner, int dt, float* out, void* stream);
 /* a4 `calibrate_weights` (calib/histogram.py:346-433): counts[r, b] += number of |x[r, :]| in bin b of
  * np.histogram(|x[r]|, bins, range=(first[r], last[r])) -- numpy's float32 edges and closed last bin, bit for bit.
- * counts is int32 [rows, bins] and is accumulated into (zero it first). */
+ * counts is int32 [rows, bins] and is OVERWRITTEN (it may be uninitialised memory: the call clears what it accumulates
+ * into). */
 int moq_row_hist_np(const void* x, int64_t rows, int64_t cols, int dt, int bins, const float* first,
                     const float* last, int* counts, void* stream);
 /* Per-tensor FP8-E4M3 QDQ of every segment with its own amax (a7 over a tensor list). */
@@ -190,6 +191,21 @@ int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, int64_t cols
  * HistogramCalibrator.collect (calib/histogram.py:77-130), with exact 64-bit integer counts. */
 int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,
                  float max_edge, int skip_zeros, void* stream);
+
+/* The threshold searches over a collected histogram, on the device.
+ * Entropy (_compute_amax_entropy, calib/histogram.py:210-283): divergences[c] = KL divergence of candidate
+ * i = start_bin + c * stride (clip after source bin i - 1; c = 0 .. (n_bins - start_bin) / stride) in fp64, with the
+ * reference's bins[0] = bins[1] substitution; num_quant_bins = 1 << (num_bits - 1 + unsigned), a power of two <= 4096.
+ * The caller takes the LAST minimum and returns calib_bin_edges[i]; candidates within 1e-9 of the minimum are to be
+ * re-scored with the reference's own summation order for a bit-exact choice (the Python host does). */
+int moq_hist_entropy(const int64_t* hist, int64_t n_bins, int num_quant_bins, int start_bin, int stride,
+                     double* divergences, void* stream);
+/* Percentile (_compute_amax_percentile, calib/histogram.py:326-343; per row for calibrate_weights, :400-412):
+ * idx[r] = np.searchsorted(np.cumsum(hist[r] / hist[r].sum()), q), q = percentile / 100, the running sum formed
+ * sequentially in fp64 like np.cumsum -- bit-exact indices.  hist is int32 (elem_bytes 4) or int64 (8) [rows, bins];
+ * idx = bins when the sum never reaches q. */
+int moq_hist_percentile(const void* hist, int elem_bytes, int64_t rows, int64_t bins, double q, int64_t* idx,
+                        void* stream);
 
 /* INT8 checkpoint weights: out[r, c] = (int8) clamp(rint(w[r, c] / scale[r]), -128, 127), fp32 quotient, round half to
  * even -- to_quantized_weight for W8A8_SQ_PER_CHANNEL / INT8 weight-only (export/quant_utils.py:868-869) with the fp32

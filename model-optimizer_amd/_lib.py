@@ -49,6 +49,8 @@ SIGNATURES = {
     "moq_amax_mid": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p]),
     "moq_mx_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "moq_row_hist_np": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "moq_hist_entropy": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "moq_hist_percentile": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_void_p, c_void_p]),
     "moq_mt_amax_ws": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "moq_mt_fake_quant_e4m3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "moq_mt_fake_quant_int": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,

@@ -186,18 +186,51 @@ class HistogramCalibrator(_Calibrator):
         self._calib_hist += other_hist.to(self._calib_hist.device)
 
     def compute_amax(self, method: str, *, stride: int = 1, start_bin: int = 128, percentile: float = 99.99):
+        return self.finish_amax(self.begin_amax(method, stride=stride, start_bin=start_bin, percentile=percentile))
+
+    def begin_amax(self, method: str, *, stride: int = 1, start_bin: int = 128, percentile: float = 99.99):
+        """First half of compute_amax: queue the device work of the threshold search and return a ticket for
+        `finish_amax`.  A caller with many calibrators (finish_stats_collection) begins them all before it finishes the
+        first, so the searches of a model overlap and the host waits once instead of once per quantizer.
+
+        Histograms on the GPU are searched there: percentile = one kernel, the index never leaves the device (the amax is a
+        gather from the device edges); entropy = one kernel for the 1 921 divergences, of which the host only looks at
+        the minimum (and re-scores exact ties with the reference's own arithmetic, `_pick_entropy_candidate`).  Histograms
+        on the host (the CPU test tier) take the numpy restatement of the reference's loops."""
+        if method not in ("entropy", "mse", "percentile"):
+            raise TypeError(f"Unknown calibration method {method}")
         if self._calib_hist is None:
-            return None
-        hist = self._calib_hist.cpu().numpy()
-        edges = self._calib_bin_edges.cpu().numpy()
-        if method == "entropy":
-            return _compute_amax_entropy(hist, edges, self._num_bits, self._unsigned, stride, start_bin)
+            return ("none", None)
+        if method == "percentile" and (percentile < 0 or percentile > 100):
+            raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
+        hist, edges = self._calib_hist, self._calib_bin_edges
         if method == "mse":
-            return _compute_amax_mse(self._calib_hist, self._calib_bin_edges, self._num_bits, self._unsigned,
-                                     stride, start_bin)
+            return ("value", _compute_amax_mse(hist, edges, self._num_bits, self._unsigned, stride, start_bin))
+        nq_bits = self._num_bits - 1 + int(self._unsigned) if isinstance(self._num_bits, int) else None
+        # (the counts live on the device, the bin edges on the host -- a linspace, as in the reference)
         if method == "percentile":
-            return _compute_amax_percentile(hist, edges, percentile)
-        raise TypeError(f"Unknown calibration method {method}")
+            if hist.is_cuda:
+                return ("percentile", (ops.hist_percentile_index(hist.reshape(1, -1), percentile / 100), edges))
+            return ("value", _compute_amax_percentile(hist.cpu().numpy(), edges.cpu().numpy(), percentile))
+        if hist.is_cuda and nq_bits is not None and 0 <= nq_bits <= 12 and hist.numel() >= start_bin:
+            div = ops.hist_entropy_divergences(hist, 1 << nq_bits, start_bin, stride)
+            return ("entropy", (div, hist, edges, stride, start_bin))
+        return ("value", _compute_amax_entropy(hist.cpu().numpy(), edges.cpu().numpy(), self._num_bits, self._unsigned,
+                                               stride, start_bin))
+
+    def finish_amax(self, ticket):
+        """Second half of compute_amax: the one host read of the search (8 bytes for percentile, 15 KB for entropy) and the
+        amax as a 0-dim fp32 host tensor, like the reference's `torch.tensor(calib_bin_edges[idx].item())`."""
+        kind, payload = ticket
+        if kind in ("none", "value"):
+            return payload
+        if kind == "percentile":
+            idx, edges = payload
+            return torch.tensor(edges[int(idx.cpu()[0])].item())
+        div, hist, edges, stride, start_bin = payload
+        pick = _pick_entropy_candidate(div.cpu().numpy(), lambda: hist.cpu().numpy(), self._num_bits, self._unsigned, stride,
+                                       start_bin)
+        return torch.tensor(edges[pick * stride + start_bin].item())
 
 
 def _compute_amax_percentile(calib_hist, calib_bin_edges, percentile):
@@ -208,6 +241,29 @@ def _compute_amax_percentile(calib_hist, calib_bin_edges, percentile):
     cdf = np.cumsum(calib_hist / total)
     idx = np.searchsorted(cdf, percentile / 100)
     return torch.tensor(calib_bin_edges[idx].item())
+
+
+ENTROPY_TIE_RTOL = 1e-9  # device divergences within this of the minimum are re-scored on the host (they agree to ~1e-13)
+
+
+def _pick_entropy_candidate(div, hist_fn, num_bits, unsigned, stride, start_bin) -> int:
+    """Index (into the candidate list) of the reference's choice -- the LAST minimum of the divergences (histogram.py:
+    277-279) -- from the device's fp64 divergences `div`.  The device sums in its own order, so a value can differ from
+    numpy's in the last bits; that only matters between candidates that tie: every candidate within ENTROPY_TIE_RTOL of
+    the minimum is re-scored with the reference's own arithmetic (`_compute_amax_entropy(..., only=...)`) and the last
+    minimum of THOSE values decides.  NaN divergences behave like np.argmin (a NaN is the minimum)."""
+    if np.isnan(div).any():
+        close = np.flatnonzero(np.isnan(div))
+    else:
+        lo = div.min()
+        close = np.flatnonzero(div <= lo + abs(lo) * ENTROPY_TIE_RTOL + 1e-300) if np.isfinite(lo) else np.flatnonzero(div == lo)
+    if close.size == 1:
+        return int(close[0])
+    exact = []
+    _compute_amax_entropy(hist_fn(), None, num_bits, unsigned, stride, start_bin, divergences_out=exact,
+                          only=[int(c) for c in close])
+    exact = np.array(exact)
+    return int(close[len(exact) - 1 - np.argmin(exact[::-1])])
 
 
 def _kl_divergence(pk, qk, pk_total=None, qk_total=None):
@@ -225,7 +281,7 @@ def _kl_divergence(pk, qk, pk_total=None, qk_total=None):
 
 
 def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, stride=1, start_bin=128,
-                          divergences_out=None):
+                          divergences_out=None, only=None):
     """KL-divergence threshold search -- calib/histogram.py:210-283.
 
     Same arithmetic as the reference's loop, candidate by candidate, with its slow steps replaced by exact
@@ -247,7 +303,10 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
     j_scaled = np.arange(len(bins), dtype=np.int64) * nbins
     all_nonzero = bool(nonzero.all())
     divergences = []
-    for i in range(start_bin, len(bins) + 1, stride):
+    candidates = range(start_bin, len(bins) + 1, stride)
+    if only is not None:  # (the exact tie-break of the device search: these candidate indices only)
+        candidates = [candidates[c] for c in only]
+    for i in candidates:
         valid = nonzero[:i]
         bucket = j_scaled[:i] // i
         weights = bins_f[:i]
@@ -276,6 +335,8 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
     divergences = np.array(divergences)
     if divergences_out is not None:
         divergences_out.extend(divergences.tolist())
+    if only is not None:
+        return None
     last_argmin = len(divergences) - 1 - np.argmin(divergences[::-1])
     return torch.tensor(calib_bin_edges[last_argmin * stride + start_bin].item())
 
@@ -321,9 +382,9 @@ def calibrate_weights(model, method="percentile", perchannel=True, percentile=99
     histogram per output channel (axis 0; transposed convolutions are outside this path) or one per tensor.
 
     The reference moves every channel to the host and calls np.histogram on it (Cout numpy calls per weight); here
-    all channel histograms of a weight come from ONE kernel with numpy's float32 edges (ops.row_hist_np), and the
-    per-channel reductions stay numpy on the host, on [Cout, bins] arrays: `percentile` = cumsum / searchsorted in
-    the reference's float64 arithmetic, row by row."""
+    all channel histograms of a weight come from ONE kernel with numpy's float32 edges (ops.row_hist_np) and the
+    `percentile` reduction -- cumsum / searchsorted in the reference's float64 arithmetic, row by row -- from a second
+    one (ops.hist_percentile_index): nothing but the amax leaves the device."""
     for _, module in model.named_modules():
         if not (hasattr(module, "weight") and hasattr(module, "weight_quantizer")):
             continue
@@ -338,11 +399,10 @@ def calibrate_weights(model, method="percentile", perchannel=True, percentile=99
                 raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
             counts, edges = ops.row_hist_np(w if perchannel else w.reshape(1, -1), num_bins)
             if method == "percentile":
-                hist, e = counts.cpu().numpy().astype(np.int64), edges.cpu().numpy()
-                total = hist.sum(axis=1, keepdims=True)
-                cdf = np.cumsum(hist / total, axis=1)  # float64, sequential along the row like the 1-D call
-                idx = [int(np.searchsorted(cdf[r], percentile / 100)) for r in range(hist.shape[0])]
-                vals = torch.tensor([e[r, i].item() for r, i in enumerate(idx)])
+                # cumsum / searchsorted of every row in the reference's float64 arithmetic, on the device: the [Cout, bins]
+                # counts (235 MB for a 28672-row weight) never travel to the host
+                idx = ops.hist_percentile_index(counts, percentile / 100)
+                vals = edges.gather(1, idx.reshape(-1, 1)).reshape(-1)
             else:
                 vals = torch.stack([_compute_amax_mse(counts[r].to(torch.int64), edges[r], wq._num_bits, wq._unsigned)
                                     for r in range(counts.shape[0])]).cpu()  # one device -> host read per weight

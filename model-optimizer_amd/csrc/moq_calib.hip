@@ -271,10 +271,192 @@ __global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Histogram threshold searches on the device (calib/histogram.py:210-283 entropy, :326-343 percentile).
+// ------------------------------------------------------------------------------------------------
+// Entropy: candidate i (one workgroup) folds source bins [0, i) of the histogram into `nq` buckets, spreads every bucket's
+// count evenly over its NON-EMPTY source bins (new_density) and takes KL(reference_density || new_density) where the
+// reference density is bins[:i] with the clipped tail added to its last bin -- the reference's loop body, candidate by
+// candidate, in fp64.  bins[0] is replaced by bins[1] as there.  The divergences go back to the caller, who takes the LAST
+// minimum; sums are formed in this kernel's own order (integer bucket sums exact, the two fp64 reductions as a tree), so
+// a divergence can differ from numpy's in the last bits: the host re-scores candidates that tie with the minimum to 1e-9
+// with the reference's own arithmetic (calib.py) -- the returned amax is the reference's bit for bit.
+constexpr int kEntMaxBuckets = 4096;
+__global__ __launch_bounds__(256) void hist_entropy_kernel(const int64_t* __restrict__ hist, int n_bins, int nq,
+                                                           int start_bin, int stride, double* __restrict__ div_out) {
+  __shared__ unsigned long long sums[kEntMaxBuckets];
+  __shared__ int members[kEntMaxBuckets];
+  __shared__ double red[256];
+  __shared__ long long red_i[256];
+  const int i = start_bin + (int)blockIdx.x * stride;  // candidate: clip after source bin i - 1
+  const int tid = threadIdx.x;
+  auto bin = [&](int j) -> long long { return hist[(j == 0 && n_bins > 1) ? 1 : j]; };
+  for (int b = tid; b < nq; b += 256) {
+    sums[b] = 0ull;
+    members[b] = 0;
+  }
+  // tail = sum(bins[i:]), total = sum(bins): exact integers
+  long long tail = 0, head = 0;
+  for (int j = tid; j < n_bins; j += 256) {
+    const long long v = bin(j);
+    if (j >= i) tail += v; else head += v;
+  }
+  red_i[tid] = tail;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red_i[tid] += red_i[tid + off];
+    __syncthreads();
+  }
+  tail = red_i[0];
+  __syncthreads();
+  red_i[tid] = head;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red_i[tid] += red_i[tid + off];
+    __syncthreads();
+  }
+  const long long total = red_i[0] + tail;
+  __syncthreads();
+  // bucket of source bin j: floor(j * nq / i)  (np.digitize against linspace(0, i, nq + 1), exact for nq a power of two)
+  for (int j = tid; j < i; j += 256) {
+    const long long v = bin(j);
+    if (v != 0) {
+      const int b = (int)(((long long)j * nq) / i);
+      atomicAdd(&sums[b], (unsigned long long)v);
+      atomicAdd(&members[b], 1);
+    }
+  }
+  __syncthreads();
+  // new_sum = sum of new_density over the candidate's bins (the normaliser scipy.stats.entropy applies to qk)
+  double part = 0.0;
+  for (int j = tid; j < i; j += 256) {
+    if (bin(j) != 0) {
+      const int b = (int)(((long long)j * nq) / i);
+      part += (double)sums[b] / (double)members[b];
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  const double new_sum = red[0];
+  __syncthreads();
+  const double old_sum = (double)total;  // sum(reference_density): bins[:i] plus the tail = every count
+  part = 0.0;
+  for (int j = tid; j < i; j += 256) {
+    const long long v = bin(j);
+    const double pj = (double)(v + (j == i - 1 ? tail : 0)) / old_sum;
+    double qj = 0.0;
+    if (v != 0) {
+      const int b = (int)(((long long)j * nq) / i);
+      qj = ((double)sums[b] / (double)members[b]) / new_sum;
+    }
+    // scipy.special.rel_entr: x log(x / y) for x, y > 0; 0 for x == 0, y >= 0; inf otherwise
+    if (pj > 0.0 && qj > 0.0) part += pj * log(pj / qj);
+    else if (!(pj == 0.0 && qj >= 0.0)) part += __builtin_inf();
+  }
+  red[tid] = part;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) div_out[blockIdx.x] = red[0];
+}
+
+// Percentile: idx[r] = np.searchsorted(np.cumsum(hist[r] / hist[r].sum()), q) -- the FIRST bin whose running fraction
+// reaches q, the running sum formed sequentially in fp64 exactly like np.cumsum (one thread walks a row; 64 rows per
+// workgroup, the counts staged through the LDS in 64 x 64 tiles so that the global reads stay coalesced).  idx = bins
+// when the sum never reaches q (the caller's edges have bins + 1 entries).
+template <typename CT>
+__global__ __launch_bounds__(64) void hist_percentile_kernel(const CT* __restrict__ hist, int64_t rows, int bins, double q,
+                                                             int64_t* __restrict__ idx_out) {
+  __shared__ long long tile[64][65];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int t = threadIdx.x;
+  // pass 1: the row totals (exact integers)
+  long long total = 0;
+  for (int c0 = 0; c0 < bins; c0 += 64) {
+    for (int rr = 0; rr < 64; ++rr) {
+      const int64_t r = r0 + rr;
+      tile[rr][t] = (r < rows && c0 + t < bins) ? (long long)hist[r * bins + c0 + t] : 0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) total += tile[t][c];
+    __syncthreads();
+  }
+  // pass 2: sequential fp64 running sum of hist / total
+  const double tot = (double)total;
+  double acc = 0.0;
+  int found = -1;
+  for (int c0 = 0; c0 < bins; c0 += 64) {
+    for (int rr = 0; rr < 64; ++rr) {
+      const int64_t r = r0 + rr;
+      tile[rr][t] = (r < rows && c0 + t < bins) ? (long long)hist[r * bins + c0 + t] : 0;
+    }
+    __syncthreads();
+    if (found < 0) {
+      const int lim = bins - c0 < 64 ? bins - c0 : 64;
+      for (int c = 0; c < lim; ++c) {
+        acc += (double)tile[t][c] / tot;
+        if (acc >= q) {
+          found = c0 + c;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (total == 0) found = 0;  // an empty row: numpy's cdf is all NaN and searchsorted answers 0
+  if (r0 + t < rows) idx_out[r0 + t] = found < 0 ? bins : found;
+}
+
 }  // namespace moq
 
 using namespace moq;
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int moq_hist_entropy(const int64_t* hist, int64_t n_bins, int num_quant_bins, int start_bin, int stride,
+                                double* divergences, void* stream) {
+  if (hist == nullptr || divergences == nullptr || n_bins < 1 || stride < 1 || start_bin < 1) {
+    set_error("moq_hist_entropy: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (num_quant_bins < 1 || num_quant_bins > kEntMaxBuckets || (num_quant_bins & (num_quant_bins - 1)) != 0 ||
+      n_bins > (1 << 24)) {
+    set_error("moq_hist_entropy: needs a power-of-two bucket count <= %d and at most 2^24 bins", kEntMaxBuckets);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (start_bin > n_bins) return MOQ_OK;  // no candidate (range(start_bin, n_bins + 1, stride) is empty)
+  const int64_t n_cand = (n_bins - start_bin) / stride + 1;
+  hipLaunchKernelGGL(hist_entropy_kernel, dim3((unsigned)n_cand), dim3(256), 0, S(stream), hist, (int)n_bins,
+                     num_quant_bins, start_bin, stride, divergences);
+  return check_launch("moq_hist_entropy");
+}
+
+extern "C" int moq_hist_percentile(const void* hist, int elem_bytes, int64_t rows, int64_t bins, double q, int64_t* idx,
+                                   void* stream) {
+  if (rows < 0 || bins < 1 || (rows > 0 && (hist == nullptr || idx == nullptr)) || !(q >= 0.0 && q <= 1.0)) {
+    set_error("moq_hist_percentile: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if ((elem_bytes != 4 && elem_bytes != 8) || bins > (1 << 24) || rows > ((int64_t)1 << 36)) {
+    set_error("moq_hist_percentile: counts must be int32 or int64, bins <= 2^24");
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return MOQ_OK;
+  const unsigned grid = (unsigned)((rows + 63) / 64);
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((hist_percentile_kernel<int>), dim3(grid), dim3(64), 0, S(stream),
+                       reinterpret_cast<const int*>(hist), rows, (int)bins, q, idx);
+  else
+    hipLaunchKernelGGL((hist_percentile_kernel<long long>), dim3(grid), dim3(64), 0, S(stream),
+                       reinterpret_cast<const long long*>(hist), rows, (int)bins, q, idx);
+  return check_launch("moq_hist_percentile");
+}
 
 static void mse_plan(int64_t n_rows, int64_t inner, int64_t* seg_elems, int64_t* segs) {
   (void)n_rows;
@@ -369,6 +551,13 @@ extern "C" int moq_row_hist_np(const void* x, int64_t rows, int64_t cols, int dt
   const int64_t max_splits = (cols + 8 * kBlock - 1) / (8 * kBlock);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  // one workgroup per row writes every bin of its row with plain stores; only rows split over several workgroups (few,
+  // long rows) accumulate with atomics and need their counts cleared first -- the caller hands over UNINITIALISED memory
+  // (a 28672-row weight has 235 MB of counts: zero-filling them cost as much as the histogram)
+  if (splits > 1 && hipMemsetAsync(counts, 0, (size_t)rows * (size_t)bins * sizeof(int), S(stream)) != hipSuccess) {
+    set_error("moq_row_hist_np: clearing the counts failed");
+    return MOQ_ERR_LAUNCH;
+  }
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((row_hist_np_kernel<DT>), dim3((unsigned)splits, (unsigned)rows), dim3(kBlock),
                                             (size_t)bins * 4, reinterpret_cast<hipStream_t>(stream), x, cols, bins,
                                             first, last, counts));

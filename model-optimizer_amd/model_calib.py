@@ -65,9 +65,19 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
     if distributed_sync and _dist_on():
         mdist.sync_calibrators_bucketed([q._calibrator for q in qs if q._calibrator is not None and not q._dynamic
                                          and hasattr(q._calibrator, "share_range_across_ranks")])
+    # histogram calibrators: every threshold search is QUEUED first (device kernels, calib.HistogramCalibrator.begin_amax)
+    # and read afterwards, so a model's searches overlap and the host does not wait once per quantizer
+    tickets = {}
+    if method:
+        for q in qs:
+            if q._calibrator is not None and not q._dynamic and hasattr(q._calibrator, "begin_amax"):
+                tickets[id(q)] = q._calibrator.begin_amax(method, **kwargs)
     for q in qs:
         if q._calibrator is not None and not q._dynamic:
-            amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
+            if id(q) in tickets:
+                amax = q._calibrator.finish_amax(tickets.pop(id(q)))
+            else:
+                amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
             if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
                 if hasattr(q, "_amax") and q._amax.shape != amax.shape:
                     delattr(q, "_amax")

@@ -460,7 +460,7 @@ def row_hist_np(w: torch.Tensor, bins: int):
     zero = mx == 0
     first = torch.where(zero, torch.full_like(mx, -0.5), torch.zeros_like(mx)).contiguous()  # _get_outer_edges
     last = torch.where(zero, torch.full_like(mx, 0.5), mx).contiguous()
-    counts = torch.zeros(rows, bins, dtype=torch.int32, device=x.device)
+    counts = torch.empty(rows, bins, dtype=torch.int32, device=x.device)  # (the call clears what it accumulates into)
     with _on(x) as stream:
         check(_lib.lib().moq_row_hist_np(_p(x), rows, cols, _dt(x), int(bins), _p(first), _p(last), _p(counts), stream))
     # np.linspace in float32: fp32(fp32(k * step) + first), last edge = stop
@@ -469,6 +469,38 @@ def row_hist_np(w: torch.Tensor, bins: int):
     edges = k[None, :] * step[:, None] + first[:, None]
     edges[:, -1] = last
     return counts, edges
+
+
+@torch.no_grad()
+def hist_entropy_divergences(hist: torch.Tensor, num_quant_bins: int, start_bin: int = 128, stride: int = 1) -> torch.Tensor:
+    """KL divergence of every clipping candidate of the entropy threshold search (calib/histogram.py:210-283) over ONE
+    collected histogram (int64 [bins], on the GPU): fp64 [n_candidates], candidate c clips after source bin
+    start_bin + c * stride - 1.  Nothing is read back here."""
+    _require_gpu(hist, "hist_entropy_divergences")
+    h = hist.detach().reshape(-1).to(torch.int64).contiguous()
+    n_cand = max(0, (h.numel() - start_bin) // stride + 1) if h.numel() >= start_bin else 0
+    out = torch.empty(n_cand, dtype=torch.float64, device=h.device)
+    if n_cand:
+        with _on(h) as stream:
+            check(_lib.lib().moq_hist_entropy(_p(h), h.numel(), int(num_quant_bins), int(start_bin), int(stride), _p(out),
+                                              stream))
+    return out
+
+
+@torch.no_grad()
+def hist_percentile_index(hist: torch.Tensor, q: float) -> torch.Tensor:
+    """np.searchsorted(np.cumsum(hist[r] / hist[r].sum()), q) for every row of an int32 / int64 [rows, bins] histogram on
+    the GPU (calib/histogram.py:326-343, :400-412): int64 [rows], bit-exact (sequential fp64 running sums)."""
+    _require_gpu(hist, "hist_percentile_index")
+    h = hist.detach()
+    if h.dtype not in (torch.int32, torch.int64):
+        h = h.to(torch.int64)
+    h = h.reshape(1, -1) if h.dim() < 2 else h.reshape(h.shape[0], -1)
+    h = h.contiguous()
+    idx = torch.empty(h.shape[0], dtype=torch.int64, device=h.device)
+    with _on(h) as stream:
+        check(_lib.lib().moq_hist_percentile(_p(h), h.element_size(), h.shape[0], h.shape[1], float(q), _p(idx), stream))
+    return idx
 
 
 # ----------------------------------------------------------------------------------------------- sparsity

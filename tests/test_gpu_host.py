@@ -331,3 +331,60 @@ def test_library_ops_on_gpu_and_under_fake_tensor_tracing():
         fx = mode.from_tensor(x)
         fy = torch.ops.moquant.quantize_op(fx, mode.from_tensor(amax), 8, 4, False, False)
         assert fy.shape == x.shape and fy.dtype == x.dtype
+
+
+@pytest.mark.parametrize("dense", [False, True], ids=["with_empty_bins", "no_empty_bins"])
+@pytest.mark.parametrize("num_bits,unsigned,nb,stride,start", [(8, False, 2048, 1, 128), (8, True, 2048, 3, 128),
+                                                                 (4, False, 777, 1, 16), (6, False, 1500, 7, 100),
+                                                                 (8, False, 4096, 1, 128), (8, False, 128, 1, 128)])
+def test_entropy_search_on_the_device_equals_the_reference_loop(num_bits, unsigned, nb, stride, start, dense):
+    """ops.hist_entropy_divergences (one workgroup per clipping candidate): every divergence agrees with the numpy
+    restatement of the reference's loop to 1e-11 relative, the chosen amax is that loop's bit for bit -- zeros, gaps wider
+    than a bucket, a heavy tail, grown ranges (4096 bins) and the single-candidate edge included."""
+    rng = np.random.default_rng(nb + num_bits + int(dense))
+    hist = (rng.exponential(1.0, nb) * 1e6 * np.exp(-np.arange(nb) / (nb / 6))).astype(np.int64)
+    if dense:
+        hist += 1
+    else:
+        hist[rng.integers(0, nb, nb // 10)] = 0
+        hist[nb // 2: nb // 2 + 40] = 0
+    hist[-1] = 12345
+    edges = np.linspace(0, 3.0, nb + 1, dtype=np.float32)
+    want_div = []
+    want = calib._compute_amax_entropy(hist, edges, num_bits, unsigned, stride, start, divergences_out=want_div)
+    want_div = np.array(want_div)
+    got_div = ops.hist_entropy_divergences(torch.from_numpy(hist).to(DEV), 1 << (num_bits - 1 + int(unsigned)), start,
+                                           stride).cpu().numpy()
+    assert got_div.shape == want_div.shape
+    fin = np.isfinite(want_div)
+    assert np.array_equal(fin, np.isfinite(got_div))
+    assert np.allclose(got_div[fin], want_div[fin], rtol=1e-11, atol=1e-14)
+    cal = calib.HistogramCalibrator(num_bits, None, unsigned, num_bins=nb)
+    cal._calib_hist = torch.from_numpy(hist).to(DEV)
+    cal._calib_bin_edges = torch.from_numpy(edges)  # (host edges, device counts: what collect() leaves)
+    ticket = cal.begin_amax("entropy", stride=stride, start_bin=start)
+    assert ticket[0] == "entropy", "the search must run on the device"
+    got = cal.finish_amax(ticket)
+    assert got.dtype == torch.float32 and got.dim() == 0 and got.item() == want.item()
+    pct = cal.begin_amax("percentile", percentile=99.9)
+    assert pct[0] == "percentile"
+    assert cal.finish_amax(pct).item() == calib._compute_amax_percentile(hist, edges, 99.9).item()
+
+
+def test_percentile_search_on_the_device_is_numpy_bit_for_bit():
+    """ops.hist_percentile_index = np.searchsorted(np.cumsum(h / h.sum()), q) per row (sequential fp64 running sums):
+    int32 and int64 counts, ragged row counts (not a multiple of the 64-row workgroup), bins that are not a multiple of the
+    tile, the extremes q = 0 and q = 1, an all-zero row."""
+    rng = np.random.default_rng(5)
+    for rows, bins, dtype in [(1, 2048, np.int64), (130, 512, np.int32), (77, 1000, np.int32), (64, 2048, np.int64)]:
+        h = (rng.exponential(1.0, (rows, bins)) * 1e4 * np.exp(-np.arange(bins) / (bins / 5))).astype(dtype)
+        h[:, rng.integers(0, bins, bins // 7)] = 0
+        if rows > 2:
+            h[2] = 0
+        for pct in (99.99, 99.0, 50.0, 0.0, 100.0):
+            q = pct / 100
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cdf = np.cumsum(h.astype(np.int64) / h.astype(np.int64).sum(axis=1, keepdims=True), axis=1)
+            want = np.array([np.searchsorted(cdf[r], q) for r in range(rows)])
+            got = ops.hist_percentile_index(torch.from_numpy(h).to(DEV), q).cpu().numpy()
+            assert np.array_equal(got, want), (rows, bins, dtype, pct, np.flatnonzero(got != want)[:5])

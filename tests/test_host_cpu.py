@@ -516,3 +516,45 @@ def test_quantize_does_not_import_transformers():
             % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_entropy_device_search_breaks_ties_with_the_reference_arithmetic():
+    """calib._pick_entropy_candidate: the device's divergences decide alone when one candidate is the clear minimum; every
+    candidate within 1e-9 of the minimum is re-scored by the numpy restatement of the reference's loop and the LAST minimum
+    of those exact values wins (histogram.py:277-279) -- so a device value that is off in its last bits cannot move the
+    choice."""
+    rng = np.random.default_rng(3)
+    nb, start, stride = 600, 32, 1
+    hist = (rng.exponential(1.0, nb) * 1e5 * np.exp(-np.arange(nb) / 90)).astype(np.int64)
+    exact = []
+    calib._compute_amax_entropy(hist, np.linspace(0, 1, nb + 1, dtype=np.float32), 8, False, stride, start, divergences_out=exact)
+    exact = np.array(exact)
+    want = len(exact) - 1 - int(np.argmin(exact[::-1]))
+    calls = []
+
+    def hist_fn():
+        calls.append(1)
+        return hist
+
+    assert calib._pick_entropy_candidate(exact.copy(), hist_fn, 8, False, stride, start) == want and not calls
+    # the device is off by a few ulp and makes two OTHER candidates look minimal: the exact re-score restores the choice
+    noisy = exact.copy()
+    others = [want - 3, want + 2]
+    noisy[others] = exact[want] * (1 - 1e-12)
+    noisy[want] = exact[want] * (1 + 1e-12)
+    assert calib._pick_entropy_candidate(noisy, hist_fn, 8, False, stride, start) == want and len(calls) == 1
+    # a true tie: the LAST of the tied candidates (two identical divergences cannot be told apart by value)
+    tied = exact.copy()
+    tied[:] = 5.0
+    assert calib._pick_entropy_candidate(tied, lambda: np.full(nb, 7, dtype=np.int64), 8, False, stride, start) == \
+        len(tied) - 1 - int(np.argmin(np.array(_all_divergences(np.full(nb, 7, dtype=np.int64), stride, start))[::-1]))
+    nan = exact.copy()
+    nan[5] = np.nan
+    assert calib._pick_entropy_candidate(nan, hist_fn, 8, False, stride, start) == 5  # np.argmin: a NaN is the minimum
+
+
+def _all_divergences(hist, stride, start):
+    out = []
+    calib._compute_amax_entropy(hist, np.linspace(0, 1, len(hist) + 1, dtype=np.float32), 8, False, stride, start,
+                                divergences_out=out)
+    return out
