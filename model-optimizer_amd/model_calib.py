@@ -72,10 +72,16 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
         for q in qs:
             if q._calibrator is not None and not q._dynamic and hasattr(q._calibrator, "begin_amax"):
                 tickets[id(q)] = q._calibrator.begin_amax(method, **kwargs)
+    from .calib import MaxCalibrator
+
+    plain_max = [q._calibrator for q in qs if type(q._calibrator) is MaxCalibrator and not q._dynamic] if not method else []
+    max_verified = bool(plain_max) and MaxCalibrator.verify_finite(plain_max)  # one host read for the NaN / inf asserts
     for q in qs:
         if q._calibrator is not None and not q._dynamic:
             if id(q) in tickets:
                 amax = q._calibrator.finish_amax(tickets.pop(id(q)))
+            elif max_verified and type(q._calibrator) is MaxCalibrator:
+                amax = q._calibrator.compute_amax(verified=True)
             else:
                 amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
             if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
@@ -142,11 +148,28 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
     default (None) shards only after `distributed.declare_data_parallel()`, and never without `distributed_sync`.
     Tensor-parallel callers pass distributed_sync=False and synchronise by `distributed.sync_amax_tensor_parallel`."""
     sync = distributed_sync and _dist_on()
+    stats = MAX_CALIBRATE_STATS
+    stats.clear()
+    dev0 = next((p.device for p in model.parameters()), None)
+
+    def lap(name, t=[None]):
+        if dev0 is not None and dev0.type == "cuda":
+            torch.cuda.synchronize(dev0)
+        now = time.perf_counter()
+        if t[0] is not None:
+            stats[name] = round(now - t[0], 4)
+        t[0] = now
+
+    lap(None)
     enable_stats_collection(model, distributed_sync=sync)
+    lap("enable_s")
     weight_only_quantize(model, shard=sync and mdist.resolve_shard(shard_weights))
+    lap("weights_s")
     if forward_loop is not None:
         forward_loop(model)
+    lap("forward_loop_s")
     finish_stats_collection(model)
+    lap("finish_s")
     if sync:
         dev = next((p.device for p in model.parameters()), None)
         # the data-parallel group when one was declared (the reference reduces over its DP group, :390-407), else the
@@ -614,6 +637,8 @@ GRAM_TIE_NOISE = 0.5
 # what the last awq_lite call did: wall-clock per stage, passes over the calibration data, re-scoring counts (tools,
 # bench.py `extra`); overwritten by every call
 AWQ_LITE_STATS: dict = {}
+# wall-clock of the last max_calibrate call by phase (the device is drained at the phase boundaries)
+MAX_CALIBRATE_STATS: dict = {}
 # bf16 planes of the Gram scoring contraction <E G, E> (ops.gram_operand): 3 = split precision in both factors.  bf16
 # models screen with ONE plane (E and G rounded to bf16, a third of the contraction and of the operand memory): on the
 # full-size run (profiles/r02_awq_tie_margin.md, "scoring planes") the one-plane scores differ from the three-plane ones

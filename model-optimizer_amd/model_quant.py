@@ -190,26 +190,32 @@ def set_quantizer_by_cfg(model: nn.Module, quant_cfg):
     quantizer's attributes (unspecified ones go back to their defaults) and enables it unless it says otherwise; an
     entry without one only toggles `enable`.  A LIST of attribute dicts turns the quantizer into a SequentialQuantizer
     with one member per entry (conversion.py:296-321)."""
+    # every configurable quantizer once: (name, fused-experts alias, parent module, attribute, owner for parent_class).
+    # The index survives the loop: an entry may REPLACE a quantizer object (setattr on the parent), never move it, so the
+    # current object is fetched from the parent each time.  (Walking named_modules and get_submodule per entry and
+    # quantizer cost 0.11 s for a 32-layer Llama: 22 entries x 1 500 modules.)
+    mods = dict(model.named_modules())
+    index = []
+    for name, mod in mods.items():
+        if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
+            continue
+        parent = mods[name.rpartition(".")[0]] if "." in name else model
+        if isinstance(parent, SequentialQuantizer):
+            continue  # members are configured through their container
+        owner = parent
+        if isinstance(owner, (nn.ModuleList, nn.ModuleDict)) and name.count(".") >= 2:
+            owner = mods[name.rsplit(".", 2)[0]]  # per-expert quantizer lists hang off the experts
+        index.append((name, _normalize_fused_experts_quantizer_name(name), parent, name.rpartition(".")[-1], owner))
     for entry in normalize_quant_cfg_list(quant_cfg):
         pattern, cfg, enable = entry["quantizer_name"], entry["cfg"], entry["enable"]
         parent_class = _resolve_parent_class(entry["parent_class"]) if entry["parent_class"] else None
         attrs = {"enable": enable} if cfg is None else cfg
-        for name, mod in list(model.named_modules()):
-            if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
+        matches = re.compile(fnmatch.translate(pattern)).match  # (fnmatch.fnmatch on POSIX: case-sensitive, same regex)
+        for name, normalized, parent, attr, owner in index:
+            if not (matches(name) or (normalized != name and matches(normalized))):
                 continue
-            parent = model.get_submodule(name.rpartition(".")[0]) if "." in name else model
-            if isinstance(parent, SequentialQuantizer):
-                continue  # members are configured through their container
-            normalized = _normalize_fused_experts_quantizer_name(name)
-            if not (fnmatch.fnmatch(name, pattern) or (normalized != name and fnmatch.fnmatch(normalized, pattern))):
+            if parent_class is not None and not isinstance(owner, parent_class):
                 continue
-            if parent_class is not None:
-                owner = parent
-                if isinstance(owner, (nn.ModuleList, nn.ModuleDict)) and name.count(".") >= 2:
-                    owner = model.get_submodule(name.rsplit(".", 2)[0])  # per-expert quantizer lists hang off the experts
-                if not isinstance(owner, parent_class):
-                    continue
-            attr = name.rpartition(".")[-1]
             cur = getattr(parent, attr)
             if isinstance(attrs, (list, tuple)):
                 if not isinstance(cur, SequentialQuantizer) or len(cur) != len(attrs):

@@ -400,6 +400,12 @@ class TensorQuantizer(nn.Module):
     def forward(self, inputs):
         if inputs.numel() == 0:
             return inputs
+        if (self._if_calib and not self._if_quant and not self._disabled and not self._dynamic and self._block_sizes is None
+                and self._axis is None and self._weight_stats_done is None and "_pre_quant_scale" not in self._buffers
+                and type(self._calibrator) is MaxCalibrator and self._calibrator.collect_per_tensor_fast(inputs)):
+            # a per-tensor max-calibrated activation quantizer inside the calibration loop: statistics only, the input
+            # passes through (the general path below does exactly this, through a dozen more host-side steps)
+            return inputs
         if self._weight_stats_done is not None and self._if_calib and not self._if_quant and not self._disabled:
             # a weight quantizer inside max_calibrate's forward loop: its statistics were taken by weight_only_quantize
             # (one multi-tensor launch) from this very tensor; the reference collects them again on every forward

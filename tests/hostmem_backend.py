@@ -150,6 +150,8 @@ class HostMemLib:
         return OK
 
     def moq_row_hist_np(self, x, rows, cols, dt, bins, first, last, counts, stream):
+        # the C-ABI call OVERWRITES counts (it may be handed uninitialised memory); the oracle accumulates
+        ctypes.memset(_addr(counts), 0, int(rows) * int(bins) * 4)
         self.o.orc_row_hist_np(_vp(x), I64(rows), I64(cols), int(dt), int(bins), _vp(first), _vp(last), _vp(counts))
         return OK
 

@@ -146,6 +146,8 @@ def run(args, moa=None, dev=None) -> dict:
                                     "gram_loss": m.awq_lite.gram_loss, "contenders": m.awq_lite.contenders}
                                    for n, m in named]}, f)
     extra["quantize_stages_s"] = dict(moa.model_quant.QUANTIZE_STATS.get("stages_s") or {})
+    if moa.model_calib.MAX_CALIBRATE_STATS:
+        extra["max_calibrate_s"] = dict(moa.model_calib.MAX_CALIBRATE_STATS)
     if awq:
         extra["awq_stats"] = dict(moa.model_calib.AWQ_LITE_STATS)
         alphas = [round(float(h.best_alpha), 1) for h in awq if h.best_alpha is not None]
