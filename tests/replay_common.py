@@ -137,28 +137,40 @@ def pin_host_pow(monkeypatch, replay):
             if ref.numel() != o.numel():
                 continue
             ulp = torch.maximum(ref.abs(), o.abs()) * 2.0 ** -23
-            if bool(((ref - o).abs() <= 4 * ulp).all()):
+            if bool(((ref - o).abs() <= MAX_PIN_ULP * ulp).all()):
                 n = int((ref != o).sum())
                 if n:
-                    pinned.append((name, n))
+                    worst = float(((ref - o).abs() / ulp).max())
+                    pinned.append((name, n, int(ref.numel()), round(worst, 2)))
                     return ref.to(out.device)
                 break
         return out
 
     monkeypatch.setattr(model_calib, "get_scale", get_scale)
+    pinned_total = sum(int(r.numel()) for r in refs.values())
+    pinned.append(("__total__", 0, pinned_total, 0.0))
     return pinned
 
 
-MAX_PINNED_VECTORS = 2  # of the 14 scale vectors of the fixture model (observed on the GPU boxes: 2; build container: 0)
+# What a pin may be: a last-bits difference of torch's HOST pow / sqrt (a third-party library whose result depends on the
+# CPU's vector ISA).  The bound is on the SIZE of the difference and on HOW MUCH of the model it touches -- not on which or
+# how many vectors happen to differ on the box at hand (round 3 bounded the vector count by what had been observed: 2):
+MAX_PIN_ULP = 4             # per entry, in fp32 ulps (pow of the entry, of the normalising max and min, the square root)
+MAX_PINNED_FRACTION = 0.25  # of all scale-vector entries of the fixture model (observed on the GPU boxes: 309 of 4096 = 7.5 %, build container: 0)
 
 
 def check_pins(pinned, what: str):
-    """"Byte-identical" must not quietly rest on many pins: at most MAX_PINNED_VECTORS of the model's scale vectors may
-    have been pinned, each differing from the reference's in a few last-bit entries only; the count goes to the suite's
-    tail (conftest.note)."""
+    """"Byte-identical" must not quietly rest on pins: every pinned entry lies within MAX_PIN_ULP ulps of the reference's
+    (by construction of the pin), and the pinned entries are at most MAX_PINNED_FRACTION of the model's scale entries;
+    entries / total, vectors and the largest difference go to the suite's tail (conftest.note)."""
     import conftest
 
-    vectors = sorted(set(pinned))
-    conftest.note(f"{what}: host-pow pins = {len({n for n, _ in vectors})} scale vector(s) {vectors}")
-    assert len({n for n, _ in vectors}) <= MAX_PINNED_VECTORS, \
-        f"{what}: {len(vectors)} scale vectors needed pinning to the reference's host pow: {vectors}"
+    total = next((t for n, _, t, _ in pinned if n == "__total__"), 0)
+    real = sorted({p for p in pinned if p[0] != "__total__"})
+    entries = sum(n for _, n, _, _ in real)
+    worst = max((u for _, _, _, u in real), default=0.0)
+    conftest.note(f"{what}: host-pow pins = {entries} of {total} scale entries in {len({n for n, _, _, _ in real})} vector(s), "
+                  f"largest difference {worst} ulp {[(n, k) for n, k, _, _ in real]}")
+    assert worst <= MAX_PIN_ULP, f"{what}: a pinned entry is {worst} ulp from the reference's"
+    assert total and entries <= MAX_PINNED_FRACTION * total, \
+        f"{what}: {entries} of {total} scale entries needed pinning to the reference's host pow: {real}"
