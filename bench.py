@@ -719,6 +719,10 @@ def main():
         out["cpu_baseline"] = None
         if args.cpu_baseline_inproc_first and not args.no_cpu_baseline:
             out["cpu_baseline"] = dict(cpu_baseline_inproc(), order="in process, before the AWQ extras (diagnostic)")
+        elif world > 1 and not args.no_cpu_baseline:
+            # N > 1: BEFORE the AWQ extra (still in a process of its own), so that the line the watchdog prints if that
+            # flow's first multi-rank collectives never return carries it; the other ranks wait at the flow's first collective
+            out["cpu_baseline"] = cpu_baseline_subprocess()
 
     watchdog = None
     if world > 1 and not args.no_extra and args.awq_layers > 0:
@@ -778,7 +782,7 @@ def main():
         except Exception as e:
             extra["awq_hf_random_init"] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_cpu_baseline and out.get("cpu_baseline") is None:
-        # LAST, and in a process of its own (N > 1: the other ranks wait at the communicator's teardown meanwhile)
+        # N = 1: LAST, and in a process of its own
         out["cpu_baseline"] = cpu_baseline_subprocess()
     if extra:
         out["extra"] = extra
