@@ -8,6 +8,8 @@ One step = one pass of the hot path over ALL linear weights of a synthetic model
     int4g128 (BASELINE configs[2] weight side / north-star kernel): fused per-group(128) abs-max + INT4 QDQ,
              one launch, 4 + 4/128 B/element.
     mxfp4, mask24, int8 : the other formats of the path, for the record.
+    fp8-mask24 (BASELINE configs[3] as ONE step): 2:4 magnitude masks + the masked weights in place + their per-tensor abs-max
+             from one pass (5 B/element), [the amax bucket], FP8 QDQ of the sparse weights (4 B/element).
     mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
              apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
              the whole model in one launch; 4 + 4 B/element.
@@ -224,12 +226,14 @@ def cpu_baseline(workload, budget_s=12.0):
 
 # the multi-GPU configuration BASELINE.json names for each format (configs[3]: Mixtral-8x7B FP8 + 2:4; configs[4]:
 # Llama-3-70B MXFP4 g32 + SmoothQuant; the per-group INT4 pass is the north-star kernel "over Llama-3-70B weight tensors")
-SCALE_MODEL = {"fp8": "mixtral-8x7b", "int8": "mixtral-8x7b", "mask24": "mixtral-8x7b",
+SCALE_MODEL = {"fp8": "mixtral-8x7b", "int8": "mixtral-8x7b", "mask24": "mixtral-8x7b", "fp8-mask24": "mixtral-8x7b",
                "int4g128": "llama3-70b", "mxfp4": "llama3-70b", "mxfp4-sq": "llama3-70b"}
-ALG_BYTES_PER_ELEM = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mxfp4-sq": 4.0, "mask24": 3.0}
+ALG_BYTES_PER_ELEM = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxfp4": 4.0, "mxfp4-sq": 4.0, "mask24": 3.0,
+                      "fp8-mask24": 5.0}
 DOM_KERNEL = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
               "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
-              "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>", "mask24": "mt_mask24_kernel<bf16>"}
+              "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>", "mask24": "mt_mask24_kernel<bf16>",
+              "fp8-mask24": "mt_mask24_apply_kernel<bf16>"}
 
 
 def default_model(workload, world):
@@ -255,7 +259,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mxfp4-sq", "mask24"])
+    ap.add_argument("--workload", default="fp8", choices=["fp8", "int4g128", "int8", "mxfp4", "mxfp4-sq", "mask24", "fp8-mask24"])
     ap.add_argument("--model", default=None, choices=list(MODELS),
                     help="default: llama3-8b at N = 1 (BASELINE configs[1]); at N > 1 the multi-GPU configuration of the "
                          "format (mixtral-8x7b for fp8 / int8 / mask24, llama3-70b for int4g128 / mxfp4 / mxfp4-sq)")
@@ -329,7 +333,7 @@ class Pool:
                 self.fold_scales.append((sv, 1.0 / sv))
         self.step_no = 0
         self.masks = self.mask_tab = None
-        if wl == "mask24":
+        if wl in ("mask24", "fp8-mask24"):
             self.masks = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in self.weights]
             self.mask_tab = SegmentTable(self.weights, outputs=self.masks)
         self.dom_events = []
@@ -382,6 +386,21 @@ class Pool:
             stop()
             if work is not None:
                 work.wait()  # the step's stream continues only after every rank's statistics have arrived
+        elif wl == "fp8-mask24":
+            # BASELINE configs[3] as ONE step: 2:4 magnitude masks, the masked weights in place and their per-tensor abs-max
+            # from one pass (5 B/element), [the amax bucket], FP8 QDQ of the sparse weights (4 B/element)
+            start()
+            self.mask_tab.mask_2to4_apply(calibrate=True)
+            stop()
+            work = None
+            if use_dist:
+                self.amax_all.zero_()
+                self.amax_all[self.owned_idx] = self.mask_tab.amax_flat
+                work = dist.all_reduce(self.amax_all, op=dist.ReduceOp.MAX, async_op=True)
+            tab.amax_flat.copy_(self.mask_tab.amax_flat)
+            tab.fake_quant_e4m3()
+            if work is not None:
+                work.wait()
         elif wl == "int4g128":
             start()
             tab.amax_qdq_int_group(4, False, False)
@@ -547,6 +566,7 @@ def main():
 
     def describe(p, model):
         what = ("2:4 magnitude mask (1-byte masks written)" if wl == "mask24"
+                else "2:4 mask + masked weights + their abs-max in one pass, then FP8 quantize-dequantize, in place" if wl == "fp8-mask24"
                 else wl + " calibrate + quantize-dequantize" + (" in place" if args.inplace else ""))
         return (f"{model} all {p.n_tensors // (world if p.weak else 1)} linear weights"
                 f"{f' x {world} (one set per GPU)' if p.weak else ''} ({p.n_elem * 2 / 1e9:.2f} GB bf16), {what}, "
@@ -641,6 +661,22 @@ def main():
             extra["mxfp4_g32_qdq"] = {"ms": round(ms, 4), "weights_GBs": round(n_elem * 2 / ms / 1e6, 1),
                                       "hbm_GBs": round(n_elem * 4 / ms / 1e6, 1),
                                       "frac_of_8TBs": round(n_elem * 4 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if wl == "fp8" and args.inplace:
+            # configs[3] as one step on the same resident weights: mask + apply + abs-max (5 B/element), FP8 QDQ (4 B/element)
+            mk = [torch.empty(w.shape, dtype=torch.bool, device=dev) for w in weights]
+            mtab = SegmentTable(weights, outputs=mk)
+
+            def sparse_fp8_step():
+                mtab.mask_2to4_apply(calibrate=True)
+                tab.amax_flat.copy_(mtab.amax_flat)
+                tab.fake_quant_e4m3()
+
+            ms_step = timed(sparse_fp8_step)
+            ms = timed(lambda: mtab.mask_2to4_apply(calibrate=True))
+            extra["fp8_mask24_step"] = {"ms_per_step": round(ms_step, 4), "weights_GBs": round(n_elem * 2 / ms_step / 1e6, 1),
+                                        "mask_apply_amax_ms": round(ms, 4),
+                                        "mask_apply_amax_frac_of_8TBs": round(n_elem * 5 / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del mtab, mk
         if wl != "int4g128":
             tabg = SegmentTable(weights, outputs=tab.outputs, group_size=128)
             ms = timed(lambda: tabg.amax_qdq_int_group(4, False, False))

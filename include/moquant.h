@@ -166,6 +166,15 @@ int moq_mt_amax_qdq_int_group(const moq_seg* segs, const int64_t* blk_start, int
  * weight segs[s].x (groups of 4 run along the flattened tensor: every row length % 4 == 0). */
 int moq_mt_mask_2to4(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
                      void* stream);
+/* 2:4 magnitude mask of every segment AND its application in one pass: segs[s].y receives the uint8 mask like
+ * moq_mt_mask_2to4, segs[s].x (the weight) is rewritten IN PLACE as dtype(w * mask) -- what mts.sparsify leaves behind
+ * a SparseModule's weight access (sparsity/weight_sparsity/module.py:97-101, weight * mask: a pruned negative weight
+ * becomes -0.0, inf / NaN times 0 is NaN, as the tensor product gives).  chunk_scratch != NULL (uint32 [n_chunks]):
+ * segs[s].amax[0] additionally receives the abs-max of the MASKED weight (the per-tensor statistic a calibration that
+ * follows would read the model again for).  5 bytes per 16-bit element instead of 3 + 6 (mask, then a mask-typed
+ * multiply) + 2. */
+int moq_mt_mask_2to4_apply(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                           void* chunk_scratch, void* stream);
 /* MX dynamic-block QDQ (see moq_mx_fused_amax_convert) of every segment in one launch; block in
  * {kVec, 2 kVec, 4 kVec, 8 kVec} elements (8..64 for 16-bit types), every segment 16-byte aligned with
  * n % block == 0; E8M0 scales.  segs[s].amax is not used. */

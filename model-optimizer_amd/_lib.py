@@ -58,6 +58,7 @@ SIGNATURES = {
     "moq_mt_amax_qdq_int_group": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p]),
     "moq_mt_mask_2to4": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "moq_mt_mask_2to4_apply": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "moq_mt_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
     "moq_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p]),

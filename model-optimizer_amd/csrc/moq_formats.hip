@@ -367,6 +367,84 @@ __device__ __forceinline__ void mask_chunk(const void* w, uint8_t* mask, int64_t
     }
   }
 }
+// mask + APPLY in one pass (sparsify: `weight.mul_(mask)`, and what every later pass over a SparseModule's weight sees --
+// weight * mask, sparsity/weight_sparsity/module.py:97-101): the chunk's mask bytes go to `mask`, the weight is rewritten in
+// place as dtype(w * m) with m in {0, 1} -- an IEEE product, so a pruned negative weight becomes -0.0 and inf / NaN times 0
+// is NaN exactly like the tensor multiply -- and the thread's abs-max pattern of the KEPT values is returned (the per-tensor
+// amax of the masked weight for a calibration that follows: one read of the model instead of three).
+template <int DT, bool fast>
+__device__ __forceinline__ uint32_t mask_apply_chunk(void* w, uint8_t* mask, int64_t e0, int64_t n) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  Pack16 in[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) in[u] = ld_packet<DT, fast>(w, e0 + packet_off<DT>(u), n);
+  uint32_t top = 0;
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float v[8], a[8];
+    unpack<DT>(in[u], v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) a[i] = __builtin_fabsf(v[i]);
+    const uint32_t m0 = mask4(a[0], a[1], a[2], a[3]);
+    uint32_t m1 = 0;
+    if constexpr (V == 8) m1 = mask4(a[4], a[5], a[6], a[7]);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const uint32_t bit = ((i < 4 ? m0 : m1) >> (8 * (i & 3))) & 1u;
+      v[i] = v[i] * (bit ? 1.0f : 0.0f);  // exact in fp32; the storage rounding of pack() is the identity on w and on +-0
+    }
+    const Pack16 outp = pack<DT>(v);
+    if (fast || e + V <= n) {
+      const uint32_t m = pack_absmax<DT>(outp);
+      top = m > top ? m : top;
+    }
+    if constexpr (fast) {
+      if constexpr (V == 8) store8_nt(mask + e, m0, m1);
+      else store4_nt(mask + e, m0);
+      st_packet<DT, true>(w, e, n, outp);
+    } else {  // n % 4 == 0: groups of four are all-in or all-out
+      if (e + 4 <= n)
+        for (int i = 0; i < 4; ++i) mask[e + i] = (m0 >> (8 * i)) & 1;
+      if (V == 8 && e + 8 <= n)
+        for (int i = 0; i < 4; ++i) mask[e + 4 + i] = (m1 >> (8 * i)) & 1;
+      if (!(e + V <= n)) {  // a ragged last packet: its in-range elements one by one (their abs-max too)
+        for (int i = 0; i < V && e + i < n; ++i) {
+          const uint32_t bits = __float_as_uint(round_to_dtype<DT>(v[i])) & 0x7FFFFFFFu;
+          top = bits > top ? bits : top;
+        }
+      }
+      st_packet<DT, false>(w, e, n, outp);
+    }
+  }
+  return top;
+}
+template <int DT>
+__global__ __launch_bounds__(kBlock) void mt_mask24_apply_kernel(const moq_seg* __restrict__ segs,
+                                                                 const int64_t* __restrict__ blk_start, int n_seg,
+                                                                 int64_t n_chunks, uint32_t* __restrict__ chunk_max) {
+  __shared__ uint32_t smem[kBlock / 64];
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    cur.seek(c);
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    const bool al = al16(cur.sg.x) && (reinterpret_cast<uintptr_t>(cur.sg.y) & 7u) == 0;
+    uint32_t top;
+    if (al && e0 + MOQ_MT_CHUNK <= cur.sg.n)
+      top = mask_apply_chunk<DT, true>(const_cast<void*>(cur.sg.x), reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n);
+    else
+      top = mask_apply_chunk<DT, false>(const_cast<void*>(cur.sg.x), reinterpret_cast<uint8_t*>(cur.sg.y), e0, cur.sg.n);
+    if (chunk_max != nullptr) {  // (workgroup-uniform)
+      top = block_max_u32(top, smem);
+      if (threadIdx.x == 0) chunk_max[c] = top;
+      __syncthreads();
+    }
+  }
+}
+
 template <int DT>
 __global__ __launch_bounds__(kBlock) void mask24_kernel(const void* __restrict__ w,
                                                         uint8_t* __restrict__ mask, int64_t n) {
@@ -907,6 +985,23 @@ extern "C" int moq_mt_mask_2to4(const moq_seg* segs, const int64_t* blk_start, i
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mask24_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), copy_lds(),
                                             S(stream), segs, blk_start, n_seg, n_chunks));
   return check_launch("moq_mt_mask_2to4");
+}
+
+// stage 2 of the two-stage per-tensor abs-max (moq_stream.hip): C++ linkage, not part of the C-ABI
+int moq_mt_amax_fold_launch(const moq_seg* segs, const int64_t* blk_start, int n_seg, const void* chunk_scratch, void* stream);
+extern "C" int moq_mt_mask_2to4_apply(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                                      void* chunk_scratch, void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr))) {
+    set_error("moq_mt_mask_2to4_apply: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_mask24_apply_kernel<DT>), dim3(copy_grid(n_chunks)), dim3(kBlock), copy_lds(),
+                                            S(stream), segs, blk_start, n_seg, n_chunks,
+                                            reinterpret_cast<uint32_t*>(chunk_scratch)));
+  int rc = check_launch("moq_mt_mask_2to4_apply");
+  if (rc != MOQ_OK || chunk_scratch == nullptr) return rc;
+  return moq_mt_amax_fold_launch(segs, blk_start, n_seg, chunk_scratch, stream);  // per-chunk maxima -> segs[s].amax[0]
 }
 
 extern "C" int moq_int4_pack(const void* x, const void* scales, uint8_t* out, int64_t n, int g, int dt,

@@ -738,6 +738,14 @@ extern "C" int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int
   return check_launch("moq_mt_amax_ws");
 }
 
+// internal (moq_formats.hip's mask + apply pass): stage 2 of the two-stage abs-max over per-chunk maxima somebody else wrote
+int moq_mt_amax_fold_launch(const moq_seg* segs, const int64_t* blk_start, int n_seg, const void* chunk_scratch,
+                            void* stream) {
+  hipLaunchKernelGGL(mt_amax_fold_kernel, dim3((unsigned)n_seg), dim3(kBlock), 0, S(stream), segs, blk_start,
+                     reinterpret_cast<const uint32_t*>(chunk_scratch));
+  return check_launch("moq_mt_amax_fold");
+}
+
 extern "C" int moq_mt_fake_quant_e4m3(const moq_seg* segs, const int64_t* blk_start, int n_seg,
                                       int64_t n_chunks, int dt, void* stream) {
   int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_fake_quant_e4m3");

@@ -135,3 +135,23 @@ class SegmentTable:
             check(_lib.lib().moq_mt_mask_2to4(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
                                               self.dtype_code, stream))
         return self.outputs
+
+    # -- a14 + the multiply that follows it (+ a1 of the result): mask, masked weight in place, optionally its abs-max
+    def mask_2to4_apply(self, calibrate: bool = False):
+        """2:4 magnitude masks into `outputs` AND `inputs` rewritten in place as dtype(w * mask), one pass over the
+        tensors (sparsify's mask + `weight.mul_(mask)`).  calibrate=True: `amax_flat[i]` additionally becomes the abs-max of
+        the masked tensor i -- the statistic a per-tensor max calibration of the sparsified model starts with."""
+        if self.group_size is not None:
+            raise MoquantError("mask_2to4_apply is a per-tensor pass (table built with group_size)")
+        for x, m in zip(self.inputs, self.outputs):
+            if m.element_size() != 1 or m.numel() != x.numel() or x.shape[-1] % 4 or m.data_ptr() == x.data_ptr():
+                raise MoquantError("mask_2to4_apply: outputs must be 1-byte masks of the inputs' shapes (last dim % 4 == 0)")
+        scratch = None
+        if calibrate:
+            if getattr(self, "_scratch", None) is None:
+                self._scratch = torch.empty(max(self.n_chunks, 1), dtype=torch.float32, device=self.device)
+            scratch = self._scratch
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_mask_2to4_apply(_p(self._segs), _p(self._blk), self.n_seg, self.n_chunks,
+                                                    self.dtype_code, _p(scratch), stream))
+        return self.outputs

@@ -169,3 +169,48 @@ def test_mask_2to4_ties_and_specials(dn, rows, cols):
     SegmentTable(ws, outputs=ms).mask_2to4()
     for m in ms:
         assert torch.equal(m.cpu().view(torch.uint8), want.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dn", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("rows,cols", [(1, 4), (3, 8), (1, CHUNK), (2, CHUNK + 4), (5, 3 * CHUNK + 12), (7, 1000)])
+def test_mask_2to4_apply_is_mask_then_multiply(dn, rows, cols):
+    """moq_mt_mask_2to4_apply (sparsify's fused pass): the mask bytes equal the oracle's, the weight rewritten in place
+    equals `w * mask` of the tensor multiply bit for bit -- a pruned negative weight is -0.0, inf / NaN times 0 is NaN --
+    and, with calibrate=True, the per-tensor amax is the abs-max of that masked weight (NaN when it holds one).  Values
+    from a small pool (ties between patterns in most groups), random magnitudes in a second tensor, an unaligned third."""
+    from model_optimizer_amd.multi_tensor import SegmentTable
+
+    dt = DT[dn]
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    pool = torch.tensor([0.0, -0.0, 0.5, -0.5, 1.0, 1.0, 2.0, -2.0, float("inf"), float("nan")])
+    w0 = pool[torch.randint(0, 8, (rows, cols), generator=g)]
+    sp = torch.rand(rows, cols, generator=g) < 0.02
+    w0 = torch.where(sp, pool[torch.randint(8, 10, (rows, cols), generator=g)], w0).to(dt)
+    w1 = (torch.randn(rows, cols, generator=g) * 0.02).to(dt)
+    w2 = (torch.randn(rows * cols + 4, generator=g) * 3).to(dt)[4:].reshape(rows, cols)  # storage offset: not 16-byte aligned for 16-bit
+    hosts = [w0, w1, w2.clone()]
+    base = torch.empty(rows * cols + 4, dtype=dt, device=DEV)
+    dev = [hosts[0].to(DEV), hosts[1].to(DEV), base[4:].reshape(rows, cols)]
+    dev[2].copy_(hosts[2])
+    masks = [torch.empty(h.shape, dtype=torch.bool, device=DEV) for h in hosts]
+    tab = SegmentTable(dev, outputs=masks)
+    tab.mask_2to4_apply(calibrate=True)
+    for i, h in enumerate(hosts):
+        want_mask = oracle.mask_2to4(h)
+        want_w = h * want_mask.to(h.dtype)
+        assert torch.equal(masks[i].cpu().view(torch.uint8), want_mask.view(torch.uint8)), f"tensor {i}: mask"
+        assert_bits_equal(dev[i], want_w, f"tensor {i}: masked weight")
+        want_amax = want_w.float().abs().max()
+        got_amax = tab.amax_flat[i].cpu()
+        if torch.isnan(want_w.float()).any():
+            assert torch.isnan(got_amax), f"tensor {i}: NaN must reach the amax"
+        else:
+            assert got_amax.item() == want_amax.item(), f"tensor {i}: amax {got_amax.item()} vs {want_amax.item()}"
+    # without the statistic: same tensors, nothing written to amax_flat
+    dev2 = [h.to(DEV) for h in hosts]
+    tab2 = SegmentTable(dev2, outputs=[torch.empty(h.shape, dtype=torch.bool, device=DEV) for h in hosts])
+    tab2.amax_flat.fill_(-1.0)
+    tab2.mask_2to4_apply()
+    assert torch.equal(tab2.amax_flat.cpu(), torch.full((3,), -1.0))
+    for a, b in zip(dev2, dev):
+        assert_bits_equal(a, b.cpu(), "apply without calibrate")
