@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-COMMON="--no-cpu-baseline --no-extra"
+COMMON="--no-cpu-baseline --no-extra --no-node-probe"
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/${TAG}_trace" -o "$TAG" -- python "$ROOT/bench.py" --steps 10 --warmup 2 $COMMON "$@" > "$OUT/${TAG}_trace.log" 2>&1
 echo "[profile] trace rc=$?"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "moq" -f csv -d "$OUT/${TAG}_fetch" -o "$TAG" -- python "$ROOT/bench.py" --steps 3 --warmup 1 $COMMON "$@" > "$OUT/${TAG}_fetch.log" 2>&1
