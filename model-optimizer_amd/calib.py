@@ -74,7 +74,11 @@ class MaxCalibrator(_Calibrator):
         plain forward -- all of it the host getting from `TensorQuantizer.forward` to the launch, 18 432 times
         (profiles/r03_flows_rocprof.md)."""
         fast = self._fast
-        if fast is None or x.dtype is not fast[0] or not x.is_cuda or not x.is_contiguous():
+        if fast is None or x.dtype is not fast[0] or not x.is_cuda:
+            return False
+        if not x.is_contiguous() and not ops._is_dense(x):
+            # (dense = some permutation of the dims is contiguous, e.g. HF key / value states `.view(B, S, H, D)
+            # .transpose(1, 2)`: numel elements from data_ptr on, which an abs-max may walk in any order)
             return False
         dev = x.device.index
         if dev != fast[2] or torch.cuda.current_device() != dev:

@@ -200,6 +200,61 @@ def _job_awq(rank, world, moa, single):
                "scored_here": {n: (h.use_gram, h.scored_here) for n, h in hs.items()}}
 
 
+class _DecoderBlock(torch.nn.Module):
+    def __init__(self, d, g):
+        super().__init__()
+        self.qkv = torch.nn.Linear(d, d, bias=False)
+        self.up = torch.nn.Linear(d, 2 * d, bias=False)
+        self.down = torch.nn.Linear(2 * d, d, bias=False)
+        with torch.no_grad():
+            for lin in (self.qkv, self.up, self.down):
+                lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) * 0.05)
+
+    def forward(self, h):
+        m = h + 0.5 * self.qkv(h)
+        return m + self.down(torch.nn.functional.gelu(self.up(m)))
+
+
+class _DecoderStack(torch.nn.Module):
+    def __init__(self, d=128, n=3, dtype=torch.bfloat16):
+        super().__init__()
+        g = torch.Generator().manual_seed(11)
+        self.embed = torch.nn.Linear(d, d, bias=False)
+        with torch.no_grad():  # (every process must build the SAME replica: nothing from the global generator)
+            self.embed.weight.copy_(torch.randn(d, d, generator=g) * 0.1)
+        self.layers = torch.nn.ModuleList([_DecoderBlock(d, g) for _ in range(n)])
+        self.to(dtype)
+
+    def forward(self, x):
+        h = self.embed(x)
+        for layer in self.layers:
+            h = layer(h)
+        return h
+
+
+def _job_awq_layer_local(rank, world, moa, single):
+    """awq_lite walking a decoder stack one layer at a time (one forward per layer, near-ties re-scored from the stored
+    activations) under data parallelism: every layer's statistics are reduced before the next layer runs, every rank picks
+    the single-rank alphas and folds the same weights."""
+    mq = moa.model_quant
+    cfg = copy.deepcopy(mq.INT4_AWQ_CFG)
+    cfg["quant_cfg"]["*embed*"] = {"enable": False}
+    cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+    cfg["algorithm"] = {"method": "awq_lite", "search": "auto", "layer_local": True, "tie_margin": 0.05}
+    batches = _batches(128, torch.bfloat16, n=_n_batches(world))
+    mine = batches if single else batches[rank::world]
+    model = moa.quantize(_DecoderStack(), cfg, lambda m: [m(b) for b in mine])
+    from model_optimizer_amd import model_calib
+
+    st = dict(model_calib.AWQ_LITE_STATS)
+    assert st.get("layer_local") and st["passes"] == 1 and st["rescored_candidates"] > 0, st
+    hs = {n: m.awq_lite for n, m in model.named_modules() if hasattr(m, "awq_lite")}
+    yield {"alpha": {n: h.best_alpha for n, h in hs.items()}, "act_scale": {n: h.act_scale.clone() for n, h in hs.items()},
+           "loss": {n: h.loss_buf.clone() for n, h in hs.items()}, "amax": _amaxes(model),
+           "w": {n: p.detach().clone() for n, p in model.named_parameters()},
+           "contenders": {n: h.contenders for n, h in hs.items()}}
+
+
 class _TPShard(torch.nn.Module):
     """Rank r's shard of the MLP under tensor parallelism: fc1 column parallel (rows r * H/W ..), fc2 row parallel (the
     matching input columns); the partial outputs are not combined -- only the calibration statistics matter here."""
@@ -277,7 +332,7 @@ def _compare(kind, want, got):
                     continue
                 if key in ("alpha", "contenders"):
                     assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
-                elif key in ("act_scale", "loss") or (kind == "awq" and key in ("amax", "w")):
+                elif key in ("act_scale", "loss") or (kind.startswith("awq") and key in ("amax", "w")):
                     # averages / sums over ranks associate differently from the single-rank order (fp32)
                     tol = 1e-6 if key == "act_scale" else 2e-2
                     assert torch.allclose(x.float(), y.float(), rtol=tol, atol=0), f"{kind}[{i}] {key} {name}"
@@ -330,7 +385,8 @@ def _worker(rank, world, port, kind, ret):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "tensor_parallel", "weight_side", "undeclared"])
+@pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "awq_layer_local", "tensor_parallel", "weight_side",
+                                  "undeclared"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
     mgr = mp.Manager()
