@@ -34,6 +34,7 @@ QUANTIZATION_W4A8_AWQ = "w4a8_awq"
 QUANTIZATION_MXFP4 = "mxfp4"
 QUANTIZATION_FP8_PB_WO = "fp8_pb_wo"
 QUANTIZATION_MXFP8 = "mxfp8"
+QUANTIZATION_FP8_PC_PT = "fp8_pc_pt"
 
 
 def get_quantization_format(module) -> str | None:
@@ -57,8 +58,11 @@ def get_quantization_format(module) -> str | None:
     if nb == 8:
         return QUANTIZATION_INT8_SQ if iq.is_enabled else QUANTIZATION_INT8_WO
     if isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is None:
-        if wq._axis is not None:  # QUANTIZATION_FP8_PC_PT (export/quant_utils.py:545-546): per-channel weight scales
-            raise NotImplementedError("export of per-channel FP8 weights (fp8_pc_pt) is outside this path")
+        axis = wq._axis
+        if axis is not None:  # export/quant_utils.py:545-546: `weight_quantizer.axis == 0` -> per-channel weight scales
+            if axis == 0 or (isinstance(axis, (tuple, list)) and tuple(axis) == (0,)):
+                return QUANTIZATION_FP8_PC_PT
+            raise NotImplementedError(f"export of FP8 weights quantized along axis {axis} is outside this path")
         return QUANTIZATION_FP8
     if (isinstance(nb, (tuple, list)) and tuple(nb) == (4, 3) and wq.block_sizes is not None
             and wq.block_sizes.get("type", "static") == "dynamic"
@@ -260,6 +264,13 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
         return ops.int8_pack_rows(weight, wsf)
+    if quantization == QUANTIZATION_FP8_PC_PT:
+        # (weight / wsf[:, None]).to(float8_e4m3fn) (export/quant_utils.py:879-909, 2-D weights): the fp32 [Cout, 1]
+        # scaling factor is a dimensioned operand, so torch promotes the quotient to fp32 -- no rounding to the weight
+        # dtype before the cast; one scale per row = 1 x Cin tiles of the tile packer
+        if weight.dim() != 2 or wsf.numel() != weight.shape[0]:
+            raise NotImplementedError("fp8_pc_pt export takes 2-D weights with one scale per output channel")
+        return ops.fp8_quantize_tile(weight, wsf.float().reshape(-1, 1), 1, weight.shape[1])
     raise NotImplementedError(f"quantization format {quantization} not supported")
 
 
@@ -427,7 +438,7 @@ def export_quantized_weight(module, dtype: torch.dtype):
                         else (amax.cpu() / wq.maxbound).to(amax.device))
     else:
         weight_scale = get_weight_scaling_factor(module)
-        if fmt in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO) and weight_scale.dim() > 1:
+        if fmt in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO, QUANTIZATION_FP8_PC_PT) and weight_scale.dim() > 1:
             # per-channel amax is kept as [Cout, 1]; the checkpoint stores [Cout] (export_amax squeezes the kept-dims
             # shape, tensor_quantizer.py:1087-1117) and to_quantized_weight divides by wsf[:, None]
             weight_scale = weight_scale.reshape(-1)
@@ -576,7 +587,7 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
     fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
     algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_W4A8_AWQ: "W4A8_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_MXFP8: "MXFP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
-            QUANTIZATION_INT8_WO: "W8A16"}
+            QUANTIZATION_INT8_WO: "W8A16", QUANTIZATION_FP8_PC_PT: "FP8_PER_CHANNEL_PER_TOKEN"}
     fmt = next(iter(fmts)) if len(fmts) == 1 else None
     q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}
     if fmt in (QUANTIZATION_INT4_AWQ, QUANTIZATION_W4A8_AWQ):

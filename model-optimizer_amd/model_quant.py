@@ -54,8 +54,8 @@ def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8
 
 
 # presets/model/fp8_per_channel_per_token.yaml: per-output-channel FP8 weights, FP8 inputs with a dynamic abs-max per
-# token ({-1: None}: the last dim is reduced; becomes `axis` on the first input).  Calibration and fake quantization;
-# the fp8_pc_pt checkpoint format is not exported on this path
+# token ({-1: None}: the last dim is reduced; becomes `axis` on the first input).  Exported as fp8_pc_pt (E4M3 weights
+# with an fp32 scale per output channel, no input scale: export.QUANTIZATION_FP8_PC_PT)
 FP8_PER_CHANNEL_PER_TOKEN_CFG = _preset({"*weight_quantizer": {"num_bits": (4, 3), "axis": 0},
                                          "*input_quantizer": {"num_bits": (4, 3), "axis": None, "type": "dynamic",
                                                               "block_sizes": {-1: None}}}, "max")

@@ -873,6 +873,50 @@ def gen_export_fp8(out):
                                              hf_quant_config=quant_cfg)))
 
 
+def gen_export_fp8_pc_pt(out):
+    """FP8 per-channel weights + per-token dynamic inputs (FP8_PER_CHANNEL_PER_TOKEN_CFG, max calibration) checkpoint
+    export of the tiny bf16 Llama by the reference: original weights + tokens, the per-channel weight amax right before
+    export, every exported tensor of model.safetensors (E4M3 weights, fp32 [Cout] weight_scale, no input_scale) and
+    hf_quant_config.json (quant_algo FP8_PER_CHANNEL_PER_TOKEN)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16)
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+    # same seed, same config: the original weights and tokens ARE export_llama_fp8.npz's (checked, not stored twice)
+    base = np.load(os.path.join(HERE, "export_llama_fp8.npz"), allow_pickle=False)
+    for k, v in model.state_dict().items():
+        assert np.array_equal(base[f"orig/{k}"], bits(v)), k
+    for i, b in enumerate(batches):
+        assert np.array_equal(base[f"tokens{i}"], b.numpy())
+    q = mtq.quantize(model, mtq.FP8_PER_CHANNEL_PER_TOKEN_CFG, lambda m: [m(b) for b in batches])
+    linears = []
+    for n, m in q.named_modules():
+        if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
+            linears.append(n)
+            out[f"pre/{n}.w_amax"] = bits(m.weight_quantizer._amax.float())
+            assert getattr(m.input_quantizer, "_amax", None) is None  # dynamic per token: nothing calibrated
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = t.view(torch.uint8).numpy().copy() if t.dtype == torch.float8_e4m3fn else bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, n_batches=len(batches), linears=linears, dtypes=dtypes,
+                                             hf_quant_config=quant_cfg)))
+
+
 def gen_export_mxfp4(out):
     """MXFP4 (dynamic blocks of 32, E8M0 scales; MXFP4_DEFAULT_CFG, no calibration) export of the tiny bf16 Llama by
     the reference: original weights and every exported tensor (packed nibbles, E8M0 scale bytes)."""
@@ -1197,11 +1241,13 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged}
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+              "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged)]:
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)
         path = os.path.join(HERE, f"{name}.npz")

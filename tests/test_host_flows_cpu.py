@@ -644,3 +644,27 @@ def test_awq_lite_layer_local_is_the_default_on_a_hugging_face_stack(golden, hos
             assert torch.equal(a.weight, b.weight), name
             assert torch.equal(a.weight_quantizer.amax, b.weight_quantizer.amax), name
     assert n == 7 * base.config.num_hidden_layers
+
+
+def test_fp8_per_channel_per_token_flow_and_export_equal_reference(golden, hostmem):
+    """FP8_PER_CHANNEL_PER_TOKEN_CFG (presets/model/fp8_per_channel_per_token.yaml): per-output-channel E4M3 weights, inputs
+    with a dynamic abs-max per token.  From the ORIGINAL weights and tokens (export_llama_fp8's): the per-channel weight amax
+    and every byte of the fp8_pc_pt checkpoint -- E4M3 weights from the fp32-promoted quotient, fp32 [Cout] weight_scale, no
+    input_scale -- equal the reference run (export/quant_utils.py:545-547, :879-909)."""
+    g, base = golden("export_llama_fp8_pc_pt"), golden("export_llama_fp8")
+    cases = g.cases
+    model = _llama(base, cases, torch.bfloat16)
+    batches = [torch.from_numpy(base.raw(f"tokens{i}")) for i in range(cases["n_batches"])]
+    with torch.no_grad():
+        moa.quantize(model, moa.model_quant.FP8_PER_CHANNEL_PER_TOKEN_CFG, lambda m: [m(b) for b in batches])
+    for name in cases["linears"]:
+        lin = model.get_submodule(name)
+        assert torch.equal(lin.weight_quantizer._amax.float().reshape(-1),
+                           from_bits(g.raw(f"pre/{name}.w_amax"), torch.float32).reshape(-1)), name
+        assert getattr(lin.input_quantizer, "_amax", None) is None, name
+        assert moa.export.get_quantization_format(lin) == moa.export.QUANTIZATION_FP8_PC_PT
+    state = moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    _compare_state(state, g, cases)
+    assert not any(k.endswith("input_scale") for k in state)
+    assert moa.export.hf_quant_config(model)["quantization"]["quant_algo"] == cases["hf_quant_config"]["quantization"]["quant_algo"] \
+        == "FP8_PER_CHANNEL_PER_TOKEN"
