@@ -13,7 +13,10 @@ per-group INT4 pass.
 
 `--pmc` : no timing loops -- every set's FP8 QDQ is launched exactly `--launches` times in set order, so that a rocprofv3
 --pmc pass of this script gives per-dispatch counters that map back to the sets (dispatch i of mt_map_kernel belongs to set
-i // launches).  tools/run/r04_call2.sh drives the passes; tools/pool_placement_report.py builds profiles/r04_pool_placement.md.
+i // launches).  tools/run/pool_placement_pmc.sh drives the passes; tools/run/pool_placement_sweep.sh the `--sweep` run
+(grid shape x occupancy per kernel; needs the experiment library, MOQ_EXPERIMENTS=1 build.sh); profiles/r04_pool_placement.md
+is the write-up.  (The round's other sweeps -- windows at a chosen distance, adjacent chunks per workgroup, split chunks --
+used experiment kernels that were not kept; their results are profiles/r04_pool_sweep_box*.json.)
 """
 
 import argparse

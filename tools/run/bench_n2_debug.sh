@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 10: two-rank control flow of the N > 1 defaults on ONE GPU through the gloo debug mode (never a measurement):
+# (gpurun call of round 4) two-rank control flow of the N > 1 defaults on ONE GPU through the gloo debug mode (never a measurement):
 # fp8 -> Mixtral-8x7B, int4g128 -> Llama-3-70B, mxfp4-sq -> Llama-3-70B; bare command (self-launch); reduced layers
 set -u
 O=gpurun_out/r04l; mkdir -p $O

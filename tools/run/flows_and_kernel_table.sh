@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 8: device-side entropy / percentile searches (tests + flow timing) and the per-kernel table on the new grids
+# (gpurun call of round 4) device-side entropy / percentile searches (tests + flow timing) and the per-kernel table on the new grids
 set -u
 O=gpurun_out/r04j; mkdir -p $O
 timeout 900 python3 -m pytest tests/test_gpu_host.py tests/test_gpu_calibrate_weights.py tests/test_gpu_reference_style.py tests/test_gpu_dist_nccl.py -x -q > $O/tests.log 2>&1

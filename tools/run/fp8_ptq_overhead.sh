@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 9: FP8 W + A + KV calibration overhead over the warm plain loop with the lean per-tensor collect
+# (gpurun call of round 4) FP8 W + A + KV calibration overhead over the warm plain loop with the lean per-tensor collect
 set -u
 O=gpurun_out/r04k; mkdir -p $O
 true

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 13: the whole GPU suite at HEAD + smoke + the full default bench line
+# (gpurun call of round 4) the whole GPU suite at HEAD + smoke + the full default bench line
 set -u
 O=gpurun_out/r04n; mkdir -p $O
 timeout 1500 python3 -m pytest tests -m gpu -x -q -n 2 > $O/gpu_suite.log 2>&1

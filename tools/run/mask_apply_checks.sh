@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 11: fused 2:4 mask + apply (+ abs-max): parity, the sparsify flows, the fp8-mask24 step
+# (gpurun call of round 4) fused 2:4 mask + apply (+ abs-max): parity, the sparsify flows, the fp8-mask24 step
 set -u
 O=gpurun_out/r04m; mkdir -p $O
 timeout 900 python3 -m pytest tests/test_gpu_chunk_bodies.py tests/test_gpu_parity.py tests/test_gpu_moe.py tests/test_gpu_sparsegpt.py tests/test_gpu_dist_nccl.py -x -q -k "mask or spars or dist or nccl" > $O/tests.log 2>&1

@@ -1,12 +1,11 @@
 #!/bin/bash
-# round 4, call 3: (a) grid-shape sweep of the whole-model FP8 QDQ over differently placed copies of the weights (experiment
-# library: knobs read per call), (b) PMC passes of the release kernel over the same sets, reduced on the box
+# rocprofv3 PMC passes over tools/pool_placement.py --pmc (every differently placed copy of the weights gets two FP8 QDQ
+# dispatches, in set order), each pass reduced ON THE BOX to a small JSON (tools/pmc_reduce.py: the raw CSVs of a pass are
+# tens of MB; gpurun merges back at most 64 MiB).  profiles/r04_pool_pmc_box3.json came from this.
 set -u
 ROOT=$(pwd)
-O=$ROOT/gpurun_out/r04c; mkdir -p $O
+O=$ROOT/gpurun_out/pool_pmc; mkdir -p $O
 export TMPDIR=/tmp
-MOQ_LIB_PATH=$ROOT/model-optimizer_amd/csrc/libmoquant_exp.so python3 tools/pool_placement.py --sweep --sets 4 --out $O/sweep.json > $O/sweep.log 2> $O/sweep.err
-echo "sweep rc=$?"; cat $O/sweep.log
 cd /tmp
 i=0
 while read -r line; do
@@ -24,5 +23,4 @@ TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum
 TCC_BUBBLE_sum TCC_EA0_WR_UNCACHED_32B_sum TCC_EA0_RDREQ_GMI_CREDIT_STALL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum
 GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
 P
-cd "$ROOT"
-du -sh $O
+cd "$ROOT"; du -sh $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 6: chunks per workgroup x occupancy cap for the four whole-model read+write kernels and the read-only abs-max
+# (gpurun call of round 4) chunks per workgroup x occupancy cap for the four whole-model read+write kernels and the read-only abs-max
 set -u
 ROOT=$(pwd)
 O=$ROOT/gpurun_out/r04h; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4, call 12: rocprofv3 kernel-trace + PMC (FETCH_SIZE / WRITE_SIZE in separate passes) of the bench command per workload,
+# (gpurun call of round 4) rocprofv3 kernel-trace + PMC (FETCH_SIZE / WRITE_SIZE in separate passes) of the bench command per workload,
 # and a bench line of the same box right after (same session)
 set -u
 for wl in fp8 int4g128 mask24 mxfp4; do
