@@ -668,3 +668,54 @@ def test_fp8_per_channel_per_token_flow_and_export_equal_reference(golden, hostm
     assert not any(k.endswith("input_scale") for k in state)
     assert moa.export.hf_quant_config(model)["quantization"]["quant_algo"] == cases["hf_quant_config"]["quantization"]["quant_algo"] \
         == "FP8_PER_CHANNEL_PER_TOKEN"
+
+
+def test_awq_lite_layer_local_falls_back_when_the_stores_do_not_fit_or_the_loop_bypasses_the_stack(hostmem, monkeypatch):
+    """Two ways out of the single-pass flow, both back to the same result: (1) the stored activations do not fit the HBM
+    budget -- the stores are dropped in the middle of the cache pass and the exact pass of that layer is a real second
+    forward through the layer (`passes` == 2, nothing replayed); (2) the forward loop never calls the first decoder layer
+    (it feeds the linears directly, like the replay fixtures) -- the whole-model flow runs."""
+    import copy
+
+    from model_optimizer_amd import model_calib, model_quant
+
+    base = _Stack().to(torch.bfloat16)
+    batches = _stack_batches()
+    cfg = copy.deepcopy(model_quant.INT4_AWQ_CFG)
+    cfg["quant_cfg"]["*embed*"] = {"enable": False}
+    cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+
+    def run(layer_local, budget, loop=None):
+        monkeypatch.setattr(model_calib._WeightCacheBudget, "host_bytes", budget)
+        c = copy.deepcopy(cfg)
+        c["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": "auto", "layer_local": layer_local, "tie_margin": 0.05}
+        with torch.no_grad():
+            q = moa.quantize(copy.deepcopy(base), c, loop or (lambda m: [m(b) for b in batches]))
+        return q, dict(model_calib.AWQ_LITE_STATS)
+
+    def same(a, b):
+        for (name, x), (_, y) in zip(a.named_modules(), b.named_modules()):
+            if hasattr(x, "awq_lite"):
+                assert x.awq_lite.best_alpha == y.awq_lite.best_alpha and torch.equal(x.weight, y.weight), name
+
+    whole, _ = run(False, 1 << 30)
+    roomy, st = run(True, 1 << 30)
+    assert st["passes"] == 1 and st["replayed_passes"] >= 1
+    # room for the Gram matrices (3 x 128^2 + 256^2 floats per layer) and a few batches of stores, not for all of them
+    tight, st = run(True, 600_000)
+    assert st["layer_local"] and st["passes"] == 2 and st["rescored_candidates"] > 0, st
+    same(whole, roomy)
+    same(whole, tight)
+
+    # (2) a loop that drives the linears itself: every linear gets a tensor, the decoder layers are never called
+    def direct(m):
+        for b in batches:
+            h = b
+            for layer in m.layers:
+                layer.q(h), layer.k(h), layer.up(h), layer.down(torch.cat([h, h], dim=-1))
+
+    a, st = run(None, 1 << 30, direct)  # (None = auto: not a Hugging Face model -> whole-model flow anyway)
+    assert not st.get("layer_local")
+    b, st = run(True, 1 << 30, direct)   # asked for explicitly, but the stack is never entered: falls back
+    assert not st.get("layer_local")
+    same(a, b)
