@@ -529,6 +529,9 @@ def main():
     n_layers = args.layers or MODELS[args.model][2]
     wl = args.workload
     args.inplace = not args.out_of_place
+    if n_layers * len(layer_shapes(args.model)) < world:  # (every rank takes this exit together: the count is the same everywhere)
+        raise SystemExit(f"bench.py: {n_layers} layer(s) of {args.model} hold {n_layers * len(layer_shapes(args.model))} weight "
+                         f"tensors, fewer than the {world} ranks they would be dealt over")
     pool = Pool(moa, wl, args.model, n_layers, dev, rank, world, args.scaling, args.inplace, args.group_mb, use_dist)
     weights, tab, masks = pool.weights, pool.tab, pool.masks
     n_local, n_model_elem, n_elem, n_tensors, weak = pool.n_local, pool.n_model_elem, pool.n_elem, pool.n_tensors, pool.weak
