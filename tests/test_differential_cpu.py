@@ -386,24 +386,23 @@ def test_awq_lite_with_kv_cache_quantizers_both_search_modes_live(monkeypatch, s
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fp8_per_channel_per_token_calibration_and_forward_equal_the_reference_live(monkeypatch, dtype):
-    """FP8_PER_CHANNEL_PER_TOKEN_CFG: per-channel weight amax and the logits of the fake-quantized model (FP8 inputs
-    with a dynamic per-token abs-max, block_sizes {-1: None} -> axis) equal the reference; the fp8_pc_pt checkpoint
-    format is outside this path and its export refuses."""
+def test_fp8_per_channel_per_token_calibration_forward_and_export_equal_the_reference_live(monkeypatch, dtype):
+    """FP8_PER_CHANNEL_PER_TOKEN_CFG: per-channel weight amax, the logits of the fake-quantized model (FP8 inputs with a
+    dynamic per-token abs-max, block_sizes {-1: None} -> axis) and, since round 4, every byte of the fp8_pc_pt checkpoint
+    (E4M3 weights from the fp32-promoted quotient, fp32 [Cout] weight_scale, no input_scale) equal the reference run live."""
     ref_amax, ref_state = _reference_run("FP8_PER_CHANNEL_PER_TOKEN_CFG", dtype, False)
     hostmem_backend.install(monkeypatch, moa)
-    exported = {}
-    real_export = moa.export.export_state_dict
-    monkeypatch.setattr(moa.export, "export_state_dict", lambda *a, **k: exported)
     our_amax, our_state = _our_run("FP8_PER_CHANNEL_PER_TOKEN_CFG", dtype, False)
     assert len(ref_amax) == 14 and set(ref_amax) <= set(our_amax)
     for n, a in ref_amax.items():
         assert a.numel() > 1 and torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
-    assert torch.equal(our_state["__logits__"], ref_state["__logits__"])
-    model = _model(dtype)
-    moa.quantize(model, moa.model_quant.FP8_PER_CHANNEL_PER_TOKEN_CFG, lambda m: m(_batches()[0]))
-    with pytest.raises(NotImplementedError, match="fp8_pc_pt"):
-        real_export(model, dtype)
+    assert torch.equal(our_state.pop("__logits__"), ref_state.pop("__logits__"))
+    assert sorted(our_state) == sorted(ref_state)
+    assert not any(k.endswith("input_scale") for k in ref_state)
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), k
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), k
 
 
 # ------------------------------------------------------------------------------------------------------------------
