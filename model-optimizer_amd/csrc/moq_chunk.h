@@ -194,3 +194,9 @@ static inline int read_grid(int64_t n_chunks) {
 // kernel on the same allocations (profiles/r04_pool_placement.md, "occupancy"): FP8 / INT-k map 0.758 -> 0.768, fused INT4 g128
 // 0.736 -> 0.772, 2:4 mask 0.777 -> 0.787 at 32 KiB; the MX kernel (more registers per thread) is best at 24 KiB: 0.729 -> 0.739.
 static inline size_t copy_lds(size_t dflt = 32 * 1024) { return (size_t)moq_tune("MOQ_TUNE_COPY_LDS", (long long)dflt); }
+// The same cap for single-tensor read + write launches, where it measured above the run-to-run noise (tools/kbench.py with the
+// experiment library at 0 / 24 / 32 KiB, profiles/r04t_kernel_ab.md): column scaling 0.68 -> 0.73, per-group INT QDQ and the
+// AWQ scale + QDQ 0.71-0.75 -> 0.75-0.77, 2:4 mask 0.80 -> 0.83, INT8 row packer 0.79 -> 0.82 at 32 KiB; MX at 24 KiB
+// 0.77 -> 0.79.  Launches that lose (INT4 / MXFP4 packers and unpackers: 0.67 -> 0.53 at 32 KiB; read-only per-group abs-max
+// 0.82 -> 0.71) or do not move (FP8 QDQ / packers) pass the default 0.
+static inline size_t copy_lds_1t(size_t dflt = 0) { return (size_t)moq_tune("MOQ_TUNE_COPY_LDS_1T", (long long)dflt); }

@@ -252,6 +252,34 @@ __device__ __forceinline__ uint32_t pack_absmax(const Pack16& p) {
   }
 }
 
+// True when a packet holds an element with 0 < |x| < 2^-100 (numerators for which the residual steps of a shared division
+// could leave the normal range, see SharedDiv).  |x| - 1 as an unsigned pattern wraps a zero to the top, so one packed
+// min over the packet and one compare decide it; f16 has no such values (its smallest subnormal is 2^-24).
+template <int DT>
+__device__ __forceinline__ bool pack_has_tiny_nonzero(const Pack16& p) {
+  if constexpr (DT == MOQ_F16) {
+    return false;
+  } else if constexpr (DT == MOQ_F32) {
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t a = (p.w[i] & 0x7FFFFFFFu) - 1u;
+      m = a < m ? a : m;
+    }
+    return m < 0x0D800000u - 1u;
+  } else {
+    u16x2 m = {0xFFFF, 0xFFFF};
+    const u16x2 one = {1, 1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t a = p.w[i] & 0x7FFF7FFFu;
+      m = __builtin_elementwise_min(m, *reinterpret_cast<const u16x2*>(&a) - one);
+    }
+    const uint16_t lo = m.x < m.y ? m.x : m.y;
+    return lo < (uint16_t)(0x0D80u - 1u);  // bf16 pattern of 2^-100: exponent field 27
+  }
+}
+
 // ---------------------------------------------------------------- cross-lane reductions (wave64)
 // butterfly max over aligned sub-groups of `WIDTH` lanes (WIDTH power of two <= 64): every lane of the
 // group ends with the group's max.  xor-shuffles of 1/2 lower to DPP quad_perm, 4/8 to DPP row ops,

@@ -585,12 +585,22 @@ __global__ __launch_bounds__(kBlock) void int4_unpack_kernel(const uint8_t* __re
         const int64_t e = e0 + packet_off<DT>(u);
         if (!full && e >= n) continue;
         float v[8];
+        // tensor_quant_gpu.cu:275-281: (nibble - 8) / scale in the scale dtype.  The eight integer numerators of a packet
+        // share the scale: one refined reciprocal, five FMAs per quotient (SharedDiv -- exact for integers up to 2^16 and
+        // a scale inside its window; the kernel spent half its issue slots on eight IEEE division sequences per packet)
+        const SharedDiv sd = make_shared_div(sc[u]);
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const uint32_t byte = (wv[u] >> (8 * b)) & 0xFFu;
-          // tensor_quant_gpu.cu:275-281: (nibble - 8) / scale in the scale dtype
-          v[2 * b] = (float)((int)(byte >> 4) - 8) / sc[u];
-          v[2 * b + 1] = (float)((int)(byte & 0xFu) - 8) / sc[u];
+          v[2 * b] = (float)((int)(byte >> 4) - 8);
+          v[2 * b + 1] = (float)((int)(byte & 0xFu) - 8);
+        }
+        if (sd.fast) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = shared_div_in_window(v[i], sd);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = v[i] / sc[u];
         }
         store16_nt(reinterpret_cast<char*>(out) + e * 2, pack<DT>(v));
       }
@@ -847,7 +857,7 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
   if (scale_fmt == MOQ_E8M0 && aligned && cols % block == 0 && block % vec == 0 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
 #define MOQ_MX_LAUNCH(L, F) \
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, n, fmt))
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), copy_lds_1t(24 * 1024), S(stream), x, y, n, fmt))
 #define MOQ_MX_CASE(L)                                                  \
   case L:                                                               \
     if (L <= 8 && fmt == MOQ_E2M1) { MOQ_MX_LAUNCH(L, (L <= 8 ? MOQ_E2M1 : -1)); }       \
@@ -864,7 +874,7 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
 #define MOQ_MX2_CASE(L)                                                                                              \
   case L:                                                                                                            \
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_two_level_kernel<DT, L>), dim3(grid), dim3(kBlock), 0, S(stream), x, y, \
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_two_level_kernel<DT, L>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), x, y, \
                                               n, fmt, scale_fmt, global_amax));                                     \
     break;
     switch (lpg) {
@@ -970,7 +980,7 @@ extern "C" int moq_mask_2to4(const void* w, int64_t rows, int64_t cols, int dt, 
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
   const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream), w,
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mask24_kernel<DT>), dim3(grid), dim3(kBlock), copy_lds_1t(32 * 1024), S(stream), w,
                                             mask, n));
   return check_launch("moq_mask_2to4");
 }
@@ -1025,10 +1035,10 @@ extern "C" int moq_int4_pack(const void* x, const void* scales, uint8_t* out, in
                      (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
   const int gs = log2_or_neg(g);
   if (fastl) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                               x, scales, out, n, g, gs, rounding));
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_pack_kernel<DT, false>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                               x, scales, out, n, g, gs, rounding));
   }
   return check_launch("moq_int4_pack");
@@ -1046,7 +1056,7 @@ extern "C" int moq_int4_unpack(const uint8_t* q, const void* scales, void* out, 
   const int gs = log2_or_neg(g);
   if (fastl) {
     const int grid = copy_grid((2 * n_bytes + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                               q, scales, out, n_bytes, g, gs));
   } else {
     const int grid = stream_grid(kBlock, (n_bytes + 3) / 4);
@@ -1097,7 +1107,7 @@ extern "C" int moq_scale_cols(const void* w, const float* s, void* y, int64_t ro
                      (cols % vec) == 0;
   if (fastl) {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 0, true>), dim3(copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK)),
-                                              dim3(kBlock), 0, S(stream), w, s, (const float*)nullptr, y, rows, cols));
+                                              dim3(kBlock), copy_lds_1t(32 * 1024), S(stream), w, s, (const float*)nullptr, y, rows, cols));
   } else {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 0, false>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
                                               S(stream), w, s, (const float*)nullptr, y, rows, cols));
@@ -1138,7 +1148,7 @@ extern "C" int moq_rescale_cols(const void* w, const float* mul, const float* di
                        reinterpret_cast<uintptr_t>(div)) & 15u) == 0 && (cols % vec) == 0;
   if (fastl) {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 1, true>), dim3(copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK)),
-                                              dim3(kBlock), 0, S(stream), w, mul, div, y, rows, cols));
+                                              dim3(kBlock), copy_lds_1t(), S(stream), w, mul, div, y, rows, cols));
   } else {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_kernel<DT, 1, false>), dim3(stream_grid(kBlock, n)), dim3(kBlock), 0,
                                               S(stream), w, mul, div, y, rows, cols));

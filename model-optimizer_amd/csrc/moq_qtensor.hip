@@ -29,6 +29,90 @@ __device__ __forceinline__ uint32_t e4m3fn_bytes2(float a, float b) {
   return p;
 }
 
+// One packet -> V e4m3fn bytes (two dwords; the second is 0 for fp32 packets).  The quotient element / scale is rounded
+// to the storage dtype first (ROUND) or kept in fp32 (promoted: fp32 scales).  Three levels, decided per packet from its
+// abs-max pattern:
+//   in range : scale > 0 inside SharedDiv's window and |x| <= 441 * scale for every element: every quotient stays below
+//              448 after both roundings (441 * (1 + 2^-8) < 448) and nothing is NaN, so the converter needs neither the
+//              clamp nor the overflow patch, and the one thing the residual steps of the shared division lose -- the sign
+//              of a zero quotient -- comes back with one v_bfi (copysign).  Numerators too small for the residuals to stay
+//              normal (|x| < 2^-100) have quotients below 2^-40: +-0 in e4m3 whatever their last bit.  About 10 VALU
+//              instructions per element instead of 19 (the body was co-critical with the memory stream: 0.645 of 8 TB/s
+//              in round 4).  With scale = amax / 448 only the packet holding the abs-max itself leaves this level.
+//   shared   : the division still shares its reciprocal; clamp and NaN patch per pair
+//   IEEE     : everything else
+template <int DT, bool ROUND>
+__device__ __forceinline__ void fp8_bytes_of_packet(const Pack16& in, float sc, const SharedDiv& sd, uint32_t& w0,
+                                                    uint32_t& w1) {
+  constexpr int V = Elem<DT>::kVec;
+  float v[8];
+  unpack<DT>(in, v);
+  uint32_t b[4] = {0, 0, 0, 0};
+  const uint32_t pmax = pack_absmax<DT>(in);
+  const uint32_t lim = __float_as_uint(sc * 441.0f);
+  if (sd.fast && sc > 0.0f && pmax <= 0x47800000u && pmax <= lim) {
+    // the residual chain without its zero test: the sign is restored below
+    auto quot = [&](float n) {
+      const float q0 = n * sd.y;
+      const float q1 = __builtin_fmaf(__builtin_fmaf(-sd.d, q0, n), sd.y, q0);
+      return __builtin_fmaf(__builtin_fmaf(-sd.d, q1, n), sd.y, q1);
+    };
+    uint32_t w[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < V; i += 4) {
+      float q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = quot(v[i + j]);
+      if constexpr (ROUND && DT == MOQ_BF16) {
+        // two quotients per v_cvt_pk_bf16_f32; both signs come from the packet's own dword with one v_bfi
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          const f32x2 pr = {q[j], q[j + 1]};
+          const bf16x2 rb = __builtin_convertvector(pr, bf16x2);
+          uint32_t r = *reinterpret_cast<const uint32_t*>(&rb);
+          r = (r & 0x7FFF7FFFu) | (in.w[(i + j) / 2] & 0x80008000u);
+          q[j] = __uint_as_float(r << 16);
+          q[j + 1] = __uint_as_float(r & 0xFFFF0000u);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          q[j] = __builtin_copysignf(q[j], v[i + j]);
+          if constexpr (ROUND) q[j] = round_to_dtype<DT>(q[j]);
+        }
+      }
+      int pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], 0, false);
+      pk = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], pk, true);
+      w[i / 4] = (uint32_t)pk;
+    }
+    w0 = w[0];
+    w1 = w[1];
+    return;
+  } else {
+    const bool shared = sd.fast && pmax <= 0x47800000u;
+#pragma unroll
+    for (int i = 0; i < V; i += 2) {
+      float qa = shared ? shared_div_in_window(v[i], sd) : v[i] / sc;
+      float qb = shared ? shared_div_in_window(v[i + 1], sd) : v[i + 1] / sc;
+      if constexpr (ROUND) {
+        qa = round_to_dtype<DT>(qa);
+        qb = round_to_dtype<DT>(qb);
+        if constexpr (DT == MOQ_BF16) {
+          // torch's float -> bfloat16 conversion returns the canonical +NaN (0x7FC0) for every NaN; the hardware converter
+          // keeps the sign, which the e4m3 NaN byte would then carry (0xFF instead of 0x7F).  Half keeps the sign in both.
+          qa = (qa != qa) ? __uint_as_float(0x7FC00000u) : qa;
+          qb = (qb != qb) ? __uint_as_float(0x7FC00000u) : qb;
+        }
+      }
+      b[i / 2] = e4m3fn_bytes2(qa, qb);
+    }
+  }
+  w0 = b[0] | (b[1] << 16);
+  w1 = b[2] | (b[3] << 16);
+}
+
 // ---------------------------------------------------------------- FP8 pack / unpack
 // scales have the storage dtype DT (the reference divides two tensors of the model dtype).  AXIS: one scale per
 // `inner` consecutive elements, index = (e / inner) % axis_size (per-channel rows, 1-D blocks); else one scale.
@@ -73,23 +157,12 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_kernel(const void* __restrict
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
       if (!full && e >= n) continue;
-      float v[8];
-      unpack<DT>(in[u], v);
-      uint32_t b[4] = {0, 0, 0, 0};
-      // the quotients of a packet share their denominator (SharedDiv: five full-rate FMAs per element instead of the IEEE
-      // sequence with its quarter-rate reciprocal; exact for |numerator| <= 2^16 and the scale inside the window -- tested
-      // per packet).  Round 4: the body was 22 VALU instructions per element, half of the launch: 0.586 -> 0.648 of 8 TB/s
-      // (AXIS: the packet's own scale -- one reciprocal per packet instead of one per element)
-      const SharedDiv sdu = AXIS ? make_shared_div(sc[u]) : sd0;
-      const bool shared = sdu.fast && pack_absmax<DT>(in[u]) <= 0x47800000u;
-#pragma unroll
-      for (int i = 0; i < V; i += 2) {
-        const float na = shared ? shared_div_in_window(v[i], sdu) : v[i] / sc[u];
-        const float nb = shared ? shared_div_in_window(v[i + 1], sdu) : v[i + 1] / sc[u];
-        b[i / 2] = e4m3fn_bytes2(round_to_dtype<DT>(na), round_to_dtype<DT>(nb));
-      }
-      if constexpr (V == 8) q_store8_nt(out + e, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-      else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(out + e));
+      // the quotients of a packet share their denominator (AXIS: the packet's own scale -- one reciprocal per packet
+      // instead of one per element); fp8_bytes_of_packet picks the cheapest exact form
+      uint32_t w0, w1;
+      fp8_bytes_of_packet<DT, true>(in[u], sc[u], AXIS ? make_shared_div(sc[u]) : sd0, w0, w1);
+      if constexpr (V == 8) q_store8_nt(out + e, w0, w1);
+      else __builtin_nontemporal_store(w0, reinterpret_cast<uint32_t*>(out + e));
     }
     };
     if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
@@ -344,24 +417,11 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_tile_kernel(const void* __res
 #pragma unroll
       for (int k = 0; k < kTileRows; ++k) {
         if (!full && r0 + k >= rows) continue;
-        float v[8];
-        unpack<DT>(in[k], v);
-        uint32_t b[4] = {0, 0, 0, 0};
-        const SharedDiv sdk = make_shared_div(sc[k]);  // one tile scale per packet (see fp8_pack_kernel)
-        const bool shared = sdk.fast && pack_absmax<DT>(in[k]) <= 0x47800000u;
-#pragma unroll
-        for (int i = 0; i < V; i += 2) {
-          float qa = shared ? shared_div_in_window(v[i], sdk) : v[i] / sc[k];
-          float qb = shared ? shared_div_in_window(v[i + 1], sdk) : v[i + 1] / sc[k];
-          if constexpr (!PROMOTE) {
-            qa = round_to_dtype<DT>(qa);
-            qb = round_to_dtype<DT>(qb);
-          }
-          b[i / 2] = e4m3fn_bytes2(qa, qb);
-        }
+        uint32_t w0, w1;  // one tile scale per packet (fp8_bytes_of_packet)
+        fp8_bytes_of_packet<DT, !PROMOTE>(in[k], sc[k], make_shared_div(sc[k]), w0, w1);
         uint8_t* o = out + (r0 + k) * cols + col;
-        if constexpr (V == 8) q_store8_nt(o, b[0] | (b[1] << 16), b[2] | (b[3] << 16));
-        else __builtin_nontemporal_store(b[0] | (b[1] << 16), reinterpret_cast<uint32_t*>(o));
+        if constexpr (V == 8) q_store8_nt(o, w0, w1);
+        else __builtin_nontemporal_store(w0, reinterpret_cast<uint32_t*>(o));
       }
     };
     if (r0 + kTileRows <= rows) body(std::true_type{});
@@ -436,7 +496,10 @@ __global__ __launch_bounds__(kBlock) void fp8_pack_tile_elem_kernel(const void* 
     const int64_t t = (row / br) * tiles_per_row + col / bc;
     const float sc = PROMOTE ? reinterpret_cast<const float*>(scales)[t] : load1<DT>(scales, t);
     float q = load1<DT>(x, e) / sc;
-    if constexpr (!PROMOTE) q = round_to_dtype<DT>(q);
+    if constexpr (!PROMOTE) {
+      q = round_to_dtype<DT>(q);
+      if constexpr (DT == MOQ_BF16) q = (q != q) ? __uint_as_float(0x7FC00000u) : q;  // (see fp8_bytes_of_packet)
+    }
     out[e] = (uint8_t)(e4m3fn_bytes2(q, 0.0f) & 0xFFu);
   }
 }
@@ -492,17 +555,17 @@ extern "C" int moq_fp8_pack(const void* x, const void* scales, int scale_dt, uin
   if (amax_mode == MOQ_AMAX_AXIS) {
     const int wrap = n > axis_size * inner ? 1 : 0;
     if (sf32) {
-      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                                 x, scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
     } else {
-      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, false>), dim3(grid), dim3(kBlock), 0, S(stream),
+      MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, true, false>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                                 x, scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
     }
   } else if (sf32) {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, true>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), x,
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, false>), dim3(grid), dim3(kBlock), 0, S(stream), x,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_pack_kernel<DT, false, false>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), x,
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   }
   return check_launch("moq_fp8_pack");
@@ -515,32 +578,86 @@ extern "C" int moq_fp8_pack(const void* x, const void* scales, int scale_dt, uin
 // half to even, clamped.  One 16-byte packet never leaves its row (cols % V == 0), so the row's scale is one shared
 // exact division per packet.
 namespace moq {
+// Chunk skeleton (moq_chunk.h): every packet of a chunk in flight, one 64-bit division per chunk for the row of its first
+// element, a shift / 32-bit division per packet.  (The first form -- one packet per lane and grid step, row = e / cols in
+// 64 bits per packet -- ran at 0.62 of 8 TB/s.)  Per packet, from its abs-max pattern:
+//   in window : every element finite and <= 2^16, the scale inside SharedDiv's window: the shared division is exact, no NaN
+//               exists, rint(clamp(q)) == clamp(rint(q)) for integer bounds, and the rounding itself is the fp32 addition
+//               of 1.5 * 2^23 (round-to-nearest-even at integer spacing) whose low mantissa byte IS the two's-complement
+//               int8 -- no float-to-int conversion, no masking; v_perm_b32 gathers the bytes.  A zero quotient's sign is
+//               irrelevant to an integer.
+//   otherwise : IEEE division, rint, clamp, NaN -> 0 (torch's cast)
 template <int DT>
 __global__ __launch_bounds__(kBlock) void int8_pack_rows_kernel(const void* __restrict__ w,
                                                                 const float* __restrict__ scale,
-                                                                int8_t* __restrict__ out, int64_t n_packets,
-                                                                int64_t cols) {
+                                                                int8_t* __restrict__ out, int64_t n, int64_t cols,
+                                                                int cols_shift) {
   constexpr int V = Elem<DT>::kVec;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets; p += (int64_t)gridDim.x * kBlock) {
-    const int64_t e = p * V;
-    const float sc = scale[e / cols];
-    const Pack16 in = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
-    float v[8];
-    unpack<DT>(in, v);
-    const SharedDiv sd = make_shared_div(sc);
-    const bool exact_fast = sd.fast && pack_absmax<DT>(in) <= 0x47800000u;
-    uint32_t b[2] = {0, 0};
+  constexpr int P = Chunk<DT>::kPackets;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  GroupIndex gi;
+  gi.g = (uint32_t)cols;
+  gi.shift = cols_shift;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    gi.seek(e0);
+    auto body = [&](auto FULL) {  // (see fp8_pack_kernel)
+      constexpr bool full = decltype(FULL)::value;
+      Pack16 in[P];
+      float sc[P];
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      const float q = exact_fast ? shared_div(v[i], sd) : v[i] / sc;
-      float t = __builtin_rintf(q);
-      t = __builtin_fminf(__builtin_fmaxf(t, -128.0f), 127.0f);
-      // torch: NaN -> int8 conversion is 0 on the host; clamp keeps NaN, the cast then gives 0
-      const int c = (q != q) ? 0 : (int)t;
-      b[i / 4] |= ((uint32_t)c & 0xFFu) << (8 * (i % 4));
-    }
-    if constexpr (V == 8) q_store8_nt(reinterpret_cast<uint8_t*>(out) + e, b[0], b[1]);
-    else __builtin_nontemporal_store(b[0], reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + e));
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        sc[u] = 1.0f;
+        if (full || e < n) {
+          in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
+          sc[u] = scale[gi.at((uint32_t)packet_off<DT>(u))];
+        }
+      }
+      if constexpr (full) __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first use
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        if (!full && e >= n) continue;
+        float v[8];
+        unpack<DT>(in[u], v);
+        const SharedDiv sd = make_shared_div(sc[u]);
+        uint32_t b[2] = {0, 0};
+        if (sd.fast && pack_absmax<DT>(in[u]) <= 0x47800000u) {
+#pragma unroll
+          for (int i = 0; i < V; i += 4) {
+            uint32_t m[4];
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {  // two quotients per packed fp32 instruction (v_pk_mul / v_pk_fma)
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              const f32x2 n2 = {v[i + j], v[i + j + 1]}, y2 = {sd.y, sd.y}, d2 = {-sd.d, -sd.d};
+              const f32x2 q0 = n2 * y2;
+              const f32x2 q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(d2, q0, n2), y2, q0);
+              const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(d2, q1, n2), y2, q1);
+              m[j] = __float_as_uint(__builtin_amdgcn_fmed3f(q.x, -128.0f, 127.0f) + 12582912.0f);
+              m[j + 1] = __float_as_uint(__builtin_amdgcn_fmed3f(q.y, -128.0f, 127.0f) + 12582912.0f);
+            }
+            const uint32_t lo = __builtin_amdgcn_perm(m[1], m[0], 0x0c0c0400u);  // byte 0 of m0, byte 0 of m1
+            const uint32_t hi = __builtin_amdgcn_perm(m[3], m[2], 0x04000c0cu);  // the same, placed in bytes 2 and 3
+            b[i / 4] = lo | hi;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < V; ++i) {
+            const float q = v[i] / sc[u];
+            float t = __builtin_rintf(q);
+            t = __builtin_fminf(__builtin_fmaxf(t, -128.0f), 127.0f);
+            // torch: NaN -> int8 conversion is 0 on the host; clamp keeps NaN, the cast then gives 0
+            const int ci = (q != q) ? 0 : (int)t;
+            b[i / 4] |= ((uint32_t)ci & 0xFFu) << (8 * (i % 4));
+          }
+        }
+        if constexpr (V == 8) q_store8_nt(reinterpret_cast<uint8_t*>(out) + e, b[0], b[1]);
+        else __builtin_nontemporal_store(b[0], reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(out) + e));
+      }
+    };
+    if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 }  // namespace moq
@@ -557,9 +674,14 @@ extern "C" int moq_int8_pack_rows(const void* w, const float* scale, int8_t* out
     set_error("moq_int8_pack_rows: needs cols %% %d == 0, a 16-byte aligned weight and an 8-byte aligned output", vec);
     return MOQ_ERR_UNSUPPORTED;
   }
-  const int64_t n_packets = rows * cols / vec;
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int8_pack_rows_kernel<DT>), dim3(stream_grid(kBlock, n_packets)),
-                                            dim3(kBlock), 0, S(stream), w, scale, out, n_packets, cols));
+  const int64_t n = rows * cols;
+  if (cols > 0x7FFFFFFFLL - MOQ_MT_CHUNK) {
+    set_error("moq_int8_pack_rows: cols must be below 2^31 - %d", (int)MOQ_MT_CHUNK);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((int8_pack_rows_kernel<DT>), dim3(grid), dim3(kBlock), copy_lds_1t(32 * 1024), S(stream), w, scale,
+                                            out, n, cols, log2_or_neg(cols)));
   return check_launch("moq_int8_pack_rows");
 }
 
@@ -576,10 +698,10 @@ extern "C" int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, i
   const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
   if (amax_mode == MOQ_AMAX_AXIS) {
     const int wrap = n > axis_size * inner ? 1 : 0;
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream), q,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), q,
                                               scales, out, n, axis_size, inner, log2_or_neg(inner), wrap));
   } else {
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, false>), dim3(grid), dim3(kBlock), 0, S(stream), q,
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((fp8_unpack_kernel<DT, false>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), q,
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   }
   return check_launch("moq_fp8_unpack");
@@ -602,7 +724,7 @@ extern "C" int moq_mxfp4_pack(const void* x, uint8_t* packed, uint8_t* e8m0, int
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
     const int bs = log2_or_neg(block);
 #define MOQ_MXP_CASE(L) \
-  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_pack_kernel<DT, L>), dim3(grid), dim3(kBlock), 0, S(stream), x, packed, e8m0, n, bs)); break;
+  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_pack_kernel<DT, L>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), x, packed, e8m0, n, bs)); break;
     switch (lpg) {
       MOQ_MXP_CASE(1) MOQ_MXP_CASE(2) MOQ_MXP_CASE(4) MOQ_MXP_CASE(8) MOQ_MXP_CASE(16) MOQ_MXP_CASE(32) MOQ_MXP_CASE(64)
       default: set_error("unreachable"); return MOQ_ERR_INVALID;
@@ -629,7 +751,7 @@ extern "C" int moq_mxfp4_unpack(const uint8_t* packed, const uint8_t* e8m0, void
                     (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
   if (fast) {
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), 0, S(stream),
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_unpack_kernel<DT, true>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream),
                                               packed, e8m0, out, n, block, bs));
   } else {
     MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mxfp4_unpack_kernel<DT, false>), dim3(stream_grid(kBlock, n)),

@@ -191,8 +191,23 @@ __global__ __launch_bounds__(kBlock) void awq_wscale_kernel(const void* __restri
       const float den = round_to_dtype<DT>(gmax + tiny);
       float f[8];
       unpack<DT>(pk[r], f);
+      // the V quotients of a packet share `den`: one refined reciprocal and five FMAs each (SharedDiv, moq_common.h) instead
+      // of V IEEE divisions -- the sweep was VALU-bound on them (0.26 of 8 TB/s in round 4).  Exact when neither a residual
+      // nor the quotient can leave the normal range: den in [2^-60, 2^20] and every numerator zero or >= 2^-100 (then
+      // |x| / den >= 2^-120); any other packet divides the IEEE way.
+      const SharedDiv sd = make_shared_div(den);
+      if (sd.fast && den <= 0x1p20f && !pack_has_tiny_nonzero<DT>(pk[r])) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) sm[i] += round_to_dtype<DT>(__builtin_fabsf(f[i]) / den);
+        for (int i = 0; i < V; ++i) {
+          const float n0 = __builtin_fabsf(f[i]);
+          const float q0 = n0 * sd.y;
+          const float q1 = __builtin_fmaf(__builtin_fmaf(-sd.d, q0, n0), sd.y, q0);
+          sm[i] += round_to_dtype<DT>(__builtin_fmaf(__builtin_fmaf(-sd.d, q1, n0), sd.y, q1));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) sm[i] += round_to_dtype<DT>(__builtin_fabsf(f[i]) / den);
+      }
     }
   }
   float* dst = partial + (int64_t)blockIdx.y * cols + c0;

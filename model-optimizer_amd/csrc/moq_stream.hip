@@ -562,13 +562,13 @@ static int launch_map(const void* x, void* y, int64_t n, int dt, const float* am
         return MOQ_ERR_INVALID;
       }
       MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpFp8Cast>), dim3(grid),
-                                                dim3(kBlock), 0, S(stream), x, y, n, amax, 0, 0, 0));
+                                                dim3(kBlock), copy_lds_1t(), S(stream), x, y, n, amax, 0, 0, 0));
     } else if (FP8) {
       MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpFp8Qdq>), dim3(grid),
-                                                dim3(kBlock), 0, S(stream), x, y, n, amax, 0, 0, 0));
+                                                dim3(kBlock), copy_lds_1t(), S(stream), x, y, n, amax, 0, 0, 0));
     } else {
       MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((map_scalar_amax_kernel<DT, OpIntQdq>), dim3(grid),
-                                                dim3(kBlock), 0, S(stream), x, y, n, amax, num_bits,
+                                                dim3(kBlock), copy_lds_1t(), S(stream), x, y, n, amax, num_bits,
                                                 is_unsigned, narrow));
     }
   } else if (amax_mode == MOQ_AMAX_AXIS) {
@@ -640,7 +640,8 @@ int launch_group(const void* x, void* y, float* amax_out, int64_t n_groups, int 
   const int grid = copy_grid((n_groups * (int64_t)g + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
 #define MOQ_LAUNCH_GROUP(QDQ, PRE)                                                                   \
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((group_kernel<DT, LPG, QDQ, PRE>),  \
-                                                                  dim3(grid), dim3(kBlock), 0,        \
+                                                                  dim3(grid), dim3(kBlock),                        \
+                                                                  (QDQ) ? copy_lds_1t(32 * 1024) : 0,                \
                                                                   S(stream), x, y, amax_out, n_groups, \
                                                                   num_bits, is_unsigned, narrow, s,   \
                                                                   cols)))
@@ -810,7 +811,7 @@ extern "C" int moq_awq_err_weight(const void* w, const void* s, const float* r, 
   const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
   const int cs = log2_or_neg(cols);
   MOQ_DISPATCH_DTYPE(dt, MOQ_DISPATCH_LPG(lpg, hipLaunchKernelGGL((awq_err_weight_kernel<DT, LPG>), dim3(grid),
-                                                                  dim3(kBlock), 0, S(stream), w, s, r, e_out,
+                                                                  dim3(kBlock), copy_lds_1t(), S(stream), w, s, r, e_out,
                                                                   reinterpret_cast<uint16_t*>(a_out), n, cols, cs,
                                                                   num_bits, planes)));
   return check_launch("moq_awq_err_weight");

@@ -120,6 +120,35 @@ def test_awq_weight_scale_vs_oracle_and_reference(golden):
         assert ((got - oracle.awq_weight_scale(w, c["g"])).abs() <= ulp).all()
 
 
+@pytest.mark.parametrize("dn", ["f32", "bf16", "f16"])
+def test_awq_weight_scale_quotients_are_ieee_divisions(dn):
+    """The |w| / (group amax + tiny) quotients share their denominator inside a packet: one refined reciprocal and a
+    residual-corrected product per element where that is provably exact, an IEEE division elsewhere.  With at most 16 rows
+    the kernel's sum is one row-ordered fp32 chain, so the result can be restated on the host bit for bit: group magnitudes
+    from 1e-36 to 1e18 (denominators below, inside and above the window), numerators down to subnormals, zeros."""
+    dt = DT[dn]
+    g_ = torch.Generator().manual_seed(15)
+    cols, g = 1 << 15, 128
+    lo, hi = (-36.0, 18.0) if dn != "f16" else (-7.0, 4.0)
+    tiny = torch.finfo(dt).tiny
+    for rows in (1, 16):
+        mag = torch.exp(torch.empty(rows, cols // g, 1).uniform_(lo, hi, generator=g_) * 2.302585)
+        rel = torch.exp(torch.empty(rows, cols // g, g).uniform_(-60.0 if dn != "f16" else -8.0, 0.0, generator=g_))
+        w = (torch.randn(rows, cols // g, g, generator=g_) * mag * rel)
+        w[:, :, 0] = mag[:, :, 0]  # the group's abs-max itself
+        w[:, ::7, 3] = 0.0
+        w = w.reshape(rows, cols).to(dt)
+        got = ops.awq_weight_scale(w.to(DEV), g).cpu()
+        gmax = w.abs().reshape(rows, cols // g, g).amax(dim=-1, keepdim=True)
+        den = gmax + tiny                                       # storage dtype, like the reference
+        q = (w.abs().reshape(rows, cols // g, g) / den).reshape(rows, cols).float()
+        acc = torch.zeros(cols, dtype=torch.float32)
+        for r in range(rows):
+            acc = acc + q[r]
+        want = (acc / float(rows)).to(dt).float()
+        assert_bits_equal(got, want, f"awq_weight_scale {dn} rows={rows}")
+
+
 class TinyMLP(torch.nn.Module):
     def __init__(self, w1, w2, b2):
         super().__init__()

@@ -76,6 +76,76 @@ def test_fp8_pack_unpack_vs_oracle(dn):
         assert_bits_equal(got_d, want_d, f"fp8 unpack {dn} {shape}")
 
 
+def _every_16_bit_pattern(dt):
+    return torch.arange(65536, dtype=torch.int32).to(torch.int16).view(dt)
+
+
+@pytest.mark.parametrize("dn", ["f16", "bf16"])
+def test_fp8_pack_every_16_bit_pattern(dn):
+    """Every 16-bit input pattern under scales that put the packer's three per-packet levels next to each other (in range:
+    |x| <= 441 * scale, no clamp / overflow patch; shared reciprocal with the patch; IEEE division): quotients at and around
+    448 and 464 (where torch's cast turns into NaN), scales outside the shared division's window, negative and zero scales,
+    fp32 scales (export) and a scale per row -- byte-exact against the oracle's literal `(x / scale).to(float8_e4m3fn)`."""
+    dt = DT[dn]
+    x = _every_16_bit_pattern(dt).repeat(2)  # 131 072 elements: 16 chunks
+    big = 3.0e4 if dn == "f16" else 2.0**70
+    for sc in (1.0, 0.0123, 2.0**-7, 3.3e-5, 117.0, 2.0**-14, big, -0.5, 0.0):
+        s = torch.tensor([sc], dtype=dt)
+        got = ops.fp8_quantize(x.to(DEV), s.to(DEV)).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack(x, s)), f"fp8 pack {dn} scale {sc}"
+        s32 = torch.tensor([sc * 1.0001], dtype=torch.float32)
+        got = ops.fp8_quantize(x.to(DEV), s32.to(DEV), fp32_scales=True).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack(x, s32, fp32_scales=True)), f"fp8 pack {dn} fp32 scale {sc}"
+    # one scale per row of 512: each row's scale is its own abs-max / 448 (the export's choice: exactly one packet per row
+    # leaves the in-range level) or a random one
+    xr = x[torch.randperm(x.numel(), generator=torch.Generator().manual_seed(3))].reshape(256, 512)
+    fin = torch.where(torch.isfinite(xr.float()), xr.float().abs(), torch.zeros(()))
+    for rows_scale in ((fin.amax(dim=1) / 448.0).clamp_min(1e-6), torch.rand(256, generator=torch.Generator().manual_seed(4)) * 50 + 1e-3):
+        s = rows_scale.to(dt)
+        got = ops.fp8_quantize(xr.to(DEV), s.to(DEV)).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack(xr, s, axis_size=256, inner=512)), f"fp8 pack {dn} per row"
+        # the same through the 2-D tile packer: 1 x 512 tiles, scales of the tensor dtype and fp32 (promoted quotient)
+        got = ops.fp8_quantize_tile(xr.to(DEV), s.to(DEV), 1, 512).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack_tile(xr, s, 1, 512)), f"fp8 pack tile {dn}"
+        got = ops.fp8_quantize_tile(xr.to(DEV), s.float().to(DEV), 1, 512).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack_tile(xr, s.float(), 1, 512)), f"fp8 pack tile {dn} fp32 scales"
+
+
+def test_fp8_pack_f32_boundaries():
+    """fp32 tensors: quotients straddling 441 (the in-range test), 448 and 464, tiny numerators, signed zeros."""
+    g = torch.Generator().manual_seed(9)
+    for sc in (1.0, 0.37, 2.0**-20, 1234.5):
+        base = torch.tensor([440.9, 441.0, 441.1, 447.9, 448.0, 448.1, 463.9, 464.0, 464.1, 1e-30, -1e-30, 0.0, -0.0, 1e-12,
+                             2.0**-10, 2.0**-9, 3 * 2.0**-11, float("inf"), float("nan"), 65536.0, 65537.0])
+        x = torch.cat([base * sc, -base * sc, torch.randn(8192 * 3 - 2 * base.numel(), generator=g) * 200 * sc]).float()
+        x = x[torch.randperm(x.numel(), generator=g)]
+        s = torch.tensor([sc], dtype=torch.float32)
+        got = ops.fp8_quantize(x.to(DEV), s.to(DEV)).view(torch.uint8).cpu()
+        assert torch.equal(got, oracle.fp8_pack(x, s)), f"fp8 pack f32 scale {sc}"
+
+
+@pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
+def test_int8_pack_rows_equals_the_reference_expression(dn):
+    """export/quant_utils.py:868-869 -- (weight / wsf[:, None]).round().clamp(-128, 127).to(int8) with an fp32 factor per
+    output channel, run by torch on the host: ties at .5 (half to even), the clamp edges, NaN -> 0, infinities, scales
+    outside the shared division's window, negative scales, rows that are not a power of two long, ragged last chunk."""
+    dt = DT[dn]
+    g = torch.Generator().manual_seed(21)
+    for rows, cols in ((64, 1024), (37, 1000), (5, 8192 + 8), (3, 24)):
+        wsf = (torch.rand(rows, generator=g) * 0.02 + 1e-3).float()
+        wsf[0] = 0.5  # exact halves below
+        w = (torch.randn(rows, cols, generator=g) * wsf[:, None] * 60).to(dt)
+        w[0, :16] = torch.tensor([0.25, 0.75, 1.25, -0.25, -0.75, 63.25, 63.75, -64.25, 64.0, -64.0, 63.5, -63.5, 1e4, -1e4, 0.0, -0.0]).to(dt)
+        w[1, :4] = torch.tensor([float("nan"), float("inf"), -float("inf"), 1e-30]).to(dt)
+        if rows > 2:
+            wsf[2] = 1e-25 if dn != "f16" else 1e-9  # outside the window / tiny
+        if rows > 4:
+            wsf[3], wsf[4] = -0.01, 1e22
+        want = (w / wsf[:, None]).round().clamp(-128, 127).to(torch.int8)
+        got = ops.int8_pack_rows(w.to(DEV), wsf.to(DEV)).cpu()
+        assert torch.equal(got, want), f"int8 pack {dn} {rows}x{cols}: {(got != want).sum().item()} differ"
+
+
 @pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
 @pytest.mark.parametrize("block", [32, 16, 64, 8])
 def test_mxfp4_pack_unpack_vs_oracle(dn, block):
