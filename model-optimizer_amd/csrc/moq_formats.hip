@@ -526,14 +526,27 @@ __global__ __launch_bounds__(kBlock) void int4_pack_kernel(const void* __restric
         float v[8];
         unpack<DT>(in[u], v);
         uint32_t q[8];
+        if (rounding == MOQ_ROUND_HALF_EVEN) {
+          // round().clamp(-8, 7) + 8 without a float -> int conversion: rint(clamp(t)) == clamp(rint(t)) for integer bounds,
+          // and adding 1.5 * 2^23 + 8 rounds to nearest-even at integer spacing with the biased nibble in the low mantissa
+          // bits (a NaN product leaves v_med3_f32 as -8, the value the fmin / fmax chain gave it: nibble 0).  Only the
+          // low four bits of q[] are meaningful below.
 #pragma unroll
-        for (int i = 0; i < V; ++i) q[i] = int4_nibble<DT>(v[i], sc[u], rounding);
-        if constexpr (V == 8) {
-          const uint32_t wv = ((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8) |
-                              (((q[4] << 4) | q[5]) << 16) | (((q[6] << 4) | q[7]) << 24);
-          store4_nt(out + e / 2, wv);
+          for (int i = 0; i < V; ++i)
+            q[i] = __float_as_uint(__builtin_amdgcn_fmed3f(round_to_dtype<DT>(v[i] * sc[u]), -8.0f, 7.0f) + 12582920.0f);
         } else {
-          *reinterpret_cast<uint16_t*>(out + e / 2) = (uint16_t)(((q[0] << 4) | q[1]) | (((q[2] << 4) | q[3]) << 8));
+#pragma unroll
+          for (int i = 0; i < V; ++i) q[i] = int4_nibble<DT>(v[i], sc[u], rounding);
+        }
+        // byte k = (q[2k] << 4) | q[2k + 1]: one v_and + one v_lshl_or per pair, the four low bytes gathered by v_perm_b32
+        uint32_t by[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < V; i += 2) by[i / 2] = (q[i] << 4) | (q[i + 1] & 0xFu);
+        const uint32_t lo2 = __builtin_amdgcn_perm(by[1], by[0], 0x0c0c0400u);
+        if constexpr (V == 8) {
+          store4_nt(out + e / 2, lo2 | __builtin_amdgcn_perm(by[3], by[2], 0x04000c0cu));
+        } else {
+          *reinterpret_cast<uint16_t*>(out + e / 2) = (uint16_t)lo2;
         }
       }
     } else {
@@ -661,32 +674,46 @@ __global__ __launch_bounds__(kBlock) void int4_export_kernel(const void* __restr
       // quant_utils.py:800-805: (w / wsf).round().clamp(-8, 7) with fp32 division; the 8 quotients of a row share
       // their denominator (exact shared division, moq_common.h)
       const SharedDiv da = make_shared_div(sa[k]), db = make_shared_div(sb[k]);
-      // the shared division is exact for |numerator| <= 2^16; anything larger (or inf / NaN) takes the IEEE divide
-      bool big = false;
-#pragma unroll
-      for (int i = 0; i < V; ++i)
-        big |= !(__builtin_fabsf(a[i]) <= 65536.0f) || !(__builtin_fabsf(b[i]) <= 65536.0f);
+      // the shared division is exact for |numerator| <= 2^16 and a scale inside its window; anything else (inf / NaN among
+      // them) takes the IEEE divide
+      const uint32_t ma = pack_absmax<DT>(pa[k]), mb = pack_absmax<DT>(pb[k]);
       uint32_t byte[8];
+      if (da.fast && db.fast && (ma > mb ? ma : mb) <= 0x47800000u) {
+        // rint + clamp + two's-complement nibble through the low mantissa bits of q + 1.5 * 2^23 (see int4_pack_kernel);
+        // only the low byte of byte[] is meaningful
 #pragma unroll
-      for (int i = 0; i < V; ++i) {
-        float qa, qb;
-        if (big) {
-          qa = __builtin_rintf(a[i] / sa[k]);
-          qb = __builtin_rintf(b[i] / sb[k]);
-        } else {
-          qa = __builtin_rintf(shared_div(a[i], da));
-          qb = __builtin_rintf(shared_div(b[i], db));
+        for (int i = 0; i < V; i += 2) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 na = {a[i], a[i + 1]}, nb = {b[i], b[i + 1]};
+          const f32x2 ya = {da.y, da.y}, yb = {db.y, db.y}, nda = {-da.d, -da.d}, ndb = {-db.d, -db.d};
+          const f32x2 a0 = na * ya, b0 = nb * yb;
+          const f32x2 a1 = __builtin_elementwise_fma(__builtin_elementwise_fma(nda, a0, na), ya, a0);
+          const f32x2 b1 = __builtin_elementwise_fma(__builtin_elementwise_fma(ndb, b0, nb), yb, b0);
+          const f32x2 qa = __builtin_elementwise_fma(__builtin_elementwise_fma(nda, a1, na), ya, a1);
+          const f32x2 qb = __builtin_elementwise_fma(__builtin_elementwise_fma(ndb, b1, nb), yb, b1);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t la = __float_as_uint(__builtin_amdgcn_fmed3f(j ? qa.y : qa.x, -8.0f, 7.0f) + 12582912.0f);
+            const uint32_t lb = __float_as_uint(__builtin_amdgcn_fmed3f(j ? qb.y : qb.x, -8.0f, 7.0f) + 12582912.0f);
+            byte[i + j] = (lb << 4) | (la & 0xFu);
+          }
         }
-        qa = __builtin_fminf(__builtin_fmaxf(qa, -8.0f), 7.0f);
-        qb = __builtin_fminf(__builtin_fmaxf(qb, -8.0f), 7.0f);
-        byte[i] = ((uint32_t)(int)qa & 0xFu) | (((uint32_t)(int)qb & 0xFu) << 4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          float qa = __builtin_rintf(a[i] / sa[k]);
+          float qb = __builtin_rintf(b[i] / sb[k]);
+          qa = __builtin_fminf(__builtin_fmaxf(qa, -8.0f), 7.0f);
+          qb = __builtin_fminf(__builtin_fmaxf(qb, -8.0f), 7.0f);
+          byte[i] = ((uint32_t)(int)qa & 0xFu) | (((uint32_t)(int)qb & 0xFu) << 4);
+        }
       }
+      const uint32_t w0 = __builtin_amdgcn_perm(byte[1], byte[0], 0x0c0c0400u) | __builtin_amdgcn_perm(byte[3], byte[2], 0x04000c0cu);
       uint8_t* dst = out + r2 * cols + c0;
       if constexpr (V == 8) {
-        store8_nt(dst, byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24),
-                  byte[4] | (byte[5] << 8) | (byte[6] << 16) | (byte[7] << 24));
+        store8_nt(dst, w0, __builtin_amdgcn_perm(byte[5], byte[4], 0x0c0c0400u) | __builtin_amdgcn_perm(byte[7], byte[6], 0x04000c0cu));
       } else {
-        store4_nt(dst, byte[0] | (byte[1] << 8) | (byte[2] << 16) | (byte[3] << 24));
+        store4_nt(dst, w0);
       }
     }
   } else {

@@ -257,13 +257,15 @@ __device__ __forceinline__ float pow2i(int e) {  // 2^e for e in [-127, 127]
 // of the key (bits(|v|) + 2^21 - 1) >> 21 -- exponent field and top two mantissa bits, rounded up -- against the bound's
 // own key: the seven compare / add pairs of the direct form (the kernel was VALU-bound on them, ~27 VALU instructions per
 // element) become add, shift, clamp and a 19-entry table packed in one 64-bit constant.  NaN compares false everywhere.
+// NO_NAN: the caller has seen the block's abs-max pattern at or below +inf -- no element is NaN, the test is dropped
+template <bool NO_NAN = false>
 __device__ __forceinline__ uint32_t mxfp4_nibble(float v) {
   const uint32_t u = __float_as_uint(v) & 0x7FFFFFFFu;
   int idx = (int)((u + 0x1FFFFFu) >> 21) - 500;  // key of 0.25 is 500, of 5.0 is 517
   idx = idx < 0 ? 0 : (idx > 18 ? 18 : idx);
   // idx: 0 -> 0 | 1..6 -> 1 | 7..9 -> 2 | 10, 11 -> 3 | 12, 13 -> 4 | 14, 15 -> 5 | 16, 17 -> 6 | 18 -> 7
   uint32_t ord = (uint32_t)(0x01F6B646D2449248ull >> (3 * idx)) & 7u;
-  ord = u > 0x7F800000u ? 0u : ord;
+  if constexpr (!NO_NAN) ord = u > 0x7F800000u ? 0u : ord;
   return ((v > 0.0f) ? 0u : 8u) + ord;
 }
 // FAST layout (host-checked): n % block == 0, block % kVec == 0, LPG = block / kVec a power of two <= 64.
@@ -288,16 +290,25 @@ __global__ __launch_bounds__(kBlock) void mxfp4_pack_kernel(const void* __restri
 #pragma unroll
     for (int u = 0; u < P; ++u) {
       const int64_t e = e0 + packet_off<DT>(u);
-      const float amax = __uint_as_float(group_max_u32<LPG>(pack_absmax<DT>(in[u])));  // amax in fp32 (:70)
+      const uint32_t amax_bits = group_max_u32<LPG>(pack_absmax<DT>(in[u]));
+      const float amax = __uint_as_float(amax_bits);  // amax in fp32 (:70)
       const int ex = mxfp4_exponent(amax);
       const float inv = pow2i(-ex);  // x / 2^e == x * 2^-e exactly (power of two; same rounding when it underflows)
       float v[8];
       unpack<DT>(in[u], v);
       uint32_t word = 0;
+      if (amax_bits <= 0x7F800000u) {  // every NaN pattern sorts above +inf: none in this block
 #pragma unroll
-      for (int i = 0; i < V; i += 2) {
-        const uint32_t lo = mxfp4_nibble(v[i] * inv), hi = mxfp4_nibble(v[i + 1] * inv);
-        word |= ((hi << 4) + lo) << (8 * (i / 2));
+        for (int i = 0; i < V; i += 2) {
+          const uint32_t lo = mxfp4_nibble<true>(v[i] * inv), hi = mxfp4_nibble<true>(v[i + 1] * inv);
+          word |= ((hi << 4) + lo) << (8 * (i / 2));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; i += 2) {
+          const uint32_t lo = mxfp4_nibble(v[i] * inv), hi = mxfp4_nibble(v[i + 1] * inv);
+          word |= ((hi << 4) + lo) << (8 * (i / 2));
+        }
       }
       if (e < n) {
         if constexpr (V == 8) __builtin_nontemporal_store(word, reinterpret_cast<uint32_t*>(packed + e / 2));

@@ -380,6 +380,36 @@ def test_int4_pack_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_int4_packers_ties_edges_and_odd_scales(dtype):
+    """The INT4 packers round through the low mantissa bits of `clamp(t) + 1.5 * 2^23` and divide by a group-shared
+    reciprocal where that is provably exact.  Products and quotients on every .5 tie from -9.5 to 8.5, values far outside
+    [-8, 7], infinities, numerators above 2^16 (IEEE fallback of the export packer), scales that are tiny, huge (outside the
+    shared division's window), negative -- against the oracle's literal restatement, both rounding modes."""
+    g = 32
+    ties = torch.arange(-19, 18, dtype=torch.float32) / 2.0                      # -9.5 ... 8.5
+    extra = torch.tensor([float("inf"), -float("inf"), 1e5, -1e5, 3e4, 7.49, -8.51, 0.0, -0.0, 1e-30])
+    base = torch.cat([ties, extra, torch.zeros(64 - ties.numel() - extra.numel())])  # two groups of 32
+    rows = []
+    scs = [1.0, 0.5, 0.25, 3.0, 1e-3, 2.0 ** -70 if dtype != torch.float16 else 2.0 ** -12, -1.0, 1e3]
+    for sc in scs:
+        rows.append(base / sc)                                                    # x * scale hits the ties exactly (powers of two)
+    x = torch.stack(rows).to(dtype)                                               # [8, 64]
+    scales = torch.tensor(scs).repeat_interleave(64 // g).to(dtype)               # one per group of 32
+    for rounding in (0, 1):
+        got = ops.int4_quantize(x.reshape(-1).to(DEV), scales.to(DEV), g, rounding).cpu()
+        assert torch.equal(got, oracle.int4_pack(x.reshape(-1), scales, g, rounding)), f"int4 pack rounding={rounding}"
+    # export packer: fp32 scaling factors, quotient = w / wsf
+    wsf = (1.0 / torch.tensor(scs)).reshape(8, 1).repeat(1, 64 // g).float().contiguous()
+    got = ops.pack_int4_in_uint8(x.to(DEV), wsf.to(DEV)).cpu()
+    assert torch.equal(got, oracle.int4_pack_export(x, wsf)), "export pack on ties"
+    # unpack: every nibble under the same scales (shared reciprocal inside the window, IEEE outside)
+    q = torch.arange(256, dtype=torch.uint8).repeat(2)                           # 1024 elements = 32 groups of 32
+    sc_u = torch.tensor(scs + [7.0 / 0.0131, 2.0 ** 70 if dtype != torch.float16 else 6e4]).repeat(4)[:32].to(dtype)
+    deq = ops.int4_dequantize(q.to(DEV), sc_u.to(DEV), g).cpu()
+    assert_bits_equal(deq, oracle.int4_unpack(q, sc_u, g), "int4 unpack, every nibble")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_col_stats_and_scale_vs_oracle(dtype):
     g_ = torch.Generator().manual_seed(71)
     x = (torch.randn(300, 4096, generator=g_) * torch.exp(torch.randn(4096, generator=g_))).to(dtype)
