@@ -132,6 +132,48 @@ struct MxScaleGeneral {
     mx_scale_general(am, fmt_max, sf, global, sc, un);
   }
 };
+// The two-level scales with a tensor-wide amax, without the two fp64 divisions per block of mx_scale_general (they, not
+// the memory stream, bounded the NVFP4-style kernel: 0.47 of 8 TB/s in round 4).  The block scale is
+//     q = (double)r / T,   r = round_to_scale_format(arg),   T = (double)sf.maxv * (double)(emax / global)   (one value per tensor)
+// and r is a scale-format value: r = M * 2^k with a 4-bit M in 8..15 whenever the scale format keeps at most three
+// mantissa bits (E4M3, E5M2, ...; k comes from r's fp32 exponent, subnormals of the scale format included).  Rounding
+// commutes with scaling by a power of two while nothing leaves the normal range, so
+//     unscale = (float)q       = (float)fl64(M / T)        * 2^k
+//     scale   = (float)(1 / q) = (float)fl64(1 / fl64(M / T)) * 2^-k
+// with the eight (M) pairs tabulated once per workgroup in LDS by the very fp64 divisions the reference performs.  A result
+// whose exponent would leave [-125, 126] (a block abs-max ~38 decades from the tensor's) takes mx_scale_general; r == 0
+// gives unscale 0 and scale +inf as there.
+struct MxScaleTwoLevelTable {
+  float fmt_max;
+  MxFmt sf;
+  const float* global;
+  double two_level;    // T
+  bool global_bad;
+  const float2* table;  // LDS: [M - 8] -> {(float)fl64(M / T), (float)fl64(1 / fl64(M / T))}
+  __device__ __forceinline__ void operator()(float am, float& sc, float& un) const {
+    sc = 1.0f;
+    un = 1.0f;
+    if (mx_bad_amax(am) || global_bad) return;
+    const float local_unscale = am / fmt_max;
+    const float arg = (float)((double)local_unscale * two_level);
+    const float r = mx_round_abs(arg, sf);
+    if (r == 0.0f) {
+      un = 0.0f;
+      sc = __uint_as_float(0x7F800000u);
+      return;
+    }
+    const uint32_t rb = __float_as_uint(r);
+    const int k = (int)((rb >> 23) & 0xFFu) - 130;  // r = (8 + top three mantissa bits) * 2^k
+    const float2 t = table[(rb >> 20) & 7u];
+    const int eu = (int)((__float_as_uint(t.x) >> 23) & 0xFFu) - 127 + k, es = (int)((__float_as_uint(t.y) >> 23) & 0xFFu) - 127 - k;
+    if (eu < -125 || eu > 126 || es < -125 || es > 126 || k < -126 || k > 126) {
+      mx_scale_general(am, fmt_max, sf, global, sc, un);
+      return;
+    }
+    un = t.x * __uint_as_float((uint32_t)(k + 127) << 23);
+    sc = t.y * __uint_as_float((uint32_t)(127 - k) << 23);
+  }
+};
 template <int DT, int LPG, class ScaleFn>
 __device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f,
                                          const ScaleFn& scale_of) {
@@ -174,12 +216,30 @@ __global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, 
 }
 // two-level block scales (an element format as the scale format, optional tensor-wide amax) on the same skeleton; the
 // one-thread-per-block generic kernel moved 2 bytes per lane and load (0.21 of the HBM roofline at g = 16)
-template <int DT, int LPG>
+// FMT / SFMT >= 0 fix the element / scale format at compile time (E2M1 elements with E4M3 scales, the NVFP4-style preset),
+// < 0 read them from the arguments.
+template <int DT, int LPG, int FMT, int SFMT>
 __global__ __launch_bounds__(kBlock) void mx_two_level_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n,
                                                               int fmt, int scale_fmt, const float* __restrict__ global_amax) {
-  const MxFmt f = mx_fmt(fmt);
-  const MxScaleGeneral scale_of{f.maxv, mx_fmt(scale_fmt), global_amax};
+  __shared__ float2 s_table[8];
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
+  const MxFmt sf = mx_fmt(SFMT >= 0 ? SFMT : scale_fmt);
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  if (global_amax != nullptr && sf.kind != 2 && sf.m <= 3) {  // (workgroup-uniform)
+    const float g = *global_amax;
+    const bool g_bad = mx_bad_amax(g);
+    const double two_level = (double)sf.maxv * (double)(f.maxv / g);
+    if (threadIdx.x < 8 && !g_bad) {
+      const double q = (double)(float)(8 + threadIdx.x) / two_level;
+      s_table[threadIdx.x] = make_float2((float)q, (float)(1.0 / q));
+    }
+    __syncthreads();
+    const MxScaleTwoLevelTable scale_of{f.maxv, sf, global_amax, two_level, g_bad, s_table};
+    for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
+      mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
+    return;
+  }
+  const MxScaleGeneral scale_of{f.maxv, sf, global_amax};
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
     mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
 }
@@ -899,16 +959,20 @@ extern "C" int moq_mx_fused_amax_convert(const void* x, void* y, int64_t rows, i
 #undef MOQ_MX_LAUNCH
   } else if (scale_fmt != MOQ_E8M0 && aligned && cols % block == 0 && block % vec == 0 && lpg <= 8 && (lpg & (lpg - 1)) == 0) {
     const int grid = copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK);
-#define MOQ_MX2_CASE(L)                                                                                              \
-  case L:                                                                                                            \
-    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_two_level_kernel<DT, L>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), x, y, \
-                                              n, fmt, scale_fmt, global_amax));                                     \
+#define MOQ_MX2_LAUNCH(L, F, SF)                                                                                       \
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mx_two_level_kernel<DT, L, F, SF>), dim3(grid), dim3(kBlock), copy_lds_1t(),  \
+                                            S(stream), x, y, n, fmt, scale_fmt, global_amax))
+#define MOQ_MX2_CASE(L)                                                                  \
+  case L:                                                                                \
+    if (fmt == MOQ_E2M1 && scale_fmt == MOQ_E4M3) { MOQ_MX2_LAUNCH(L, MOQ_E2M1, MOQ_E4M3); } \
+    else { MOQ_MX2_LAUNCH(L, -1, -1); }                                                   \
     break;
     switch (lpg) {
       MOQ_MX2_CASE(1) MOQ_MX2_CASE(2) MOQ_MX2_CASE(4) MOQ_MX2_CASE(8)
       default: set_error("unreachable"); return MOQ_ERR_INVALID;
     }
 #undef MOQ_MX2_CASE
+#undef MOQ_MX2_LAUNCH
   } else {
     const int64_t nb = rows * ((cols + block - 1) / block);
     const int grid = stream_grid(kBlock, nb);

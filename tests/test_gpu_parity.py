@@ -651,6 +651,28 @@ _FP4_LITERALS = [([0, 0.5, 1, 1.5, 2, 3, 4, 6], [0, 0.5, 1, 1.5, 2, 3, 4, 6]),
                  ([0.35, 0.85, 1.35, 1.85, 2.6, 3.6, 5.1, 6], [0.5, 1, 1.5, 2, 3, 4, 6, 6])]
 
 
+@pytest.mark.parametrize("dn", ["f32", "bf16", "f16"])
+def test_two_level_scales_from_the_table_equal_the_fp64_steps(dn):
+    """With a tensor-wide amax the aligned kernel takes the block scale from a per-workgroup table of the eight
+    (4-bit mantissa) quotients instead of two fp64 divisions per block.  Block magnitudes from 1e-30 to 1e30 times the
+    tensor-wide value: the rounded scale-format value hits zero, its subnormals, every mantissa, the saturation at the
+    format maximum, and results whose fp32 exponent leaves the normal range (the kernel's fallback) -- E4M3, E5M2 and
+    E3M2 scales (table), INT8 scales (no table), bit for bit against the oracle's literal fp64 restatement."""
+    dt = DT[dn]
+    gen = torch.Generator().manual_seed(23)
+    spread = 30.0 if dn != "f16" else 3.5
+    for glob in (1.0, 3.7e-3, 2.5e4, 1e-30 if dn != "f16" else 1e-4, 1e30 if dn != "f16" else 6e4):
+        rows, cols = 96, 1024
+        mag = torch.exp(torch.empty(rows, cols // 16, 1).uniform_(-spread, spread, generator=gen) * 2.302585) * glob
+        x = (torch.randn(rows, cols // 16, 16, generator=gen) * mag).reshape(rows, cols).to(dt)
+        x[0, :16] = 0
+        g = torch.tensor(glob, dtype=torch.float32)
+        for fmt, sfmt in (("E2M1", "E4M3"), ("E2M1", "E5M2"), ("E4M3", "E4M3"), ("E2M3", "E3M2"), ("E2M1", "INT8")):
+            got = ops.fused_amax_convert(x.to(DEV), 16, fmt, sfmt, g.to(DEV))
+            want = oracle.mx_fused_amax_convert(x, 16, fmt, sfmt, g)
+            assert_bits_equal(got, want, f"{fmt}/{sfmt} tensor-wide amax {glob}")
+
+
 @pytest.mark.parametrize("dn", ["f32", "f16", "bf16"])
 def test_block_scale_formats_other_than_e8m0(dn):
     """fused_amax_convert with element-format block scales (NVFP4-style E2M1 + E4M3 scales, with and without the
