@@ -422,6 +422,19 @@ int moq_symmetrize(float* h, int64_t n, void* stream);
  * moq_sgpt_trailing_update. */
 int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
                          int prune_n, int prune_m, void* stream);
+/* Column sweep of GPTQ's blockwise weight update over one column block [i1, i1 + bs)
+ * (quantization/utils/calib_utils.py:241-276, gptq_blockwise_update), all rows at once, for quantizers whose amax is
+ * calibrated (static), i.e. elementwise: w: fp32 [rows, ld] working weights (block overwritten with the
+ * quantized-dequantized columns q), hinv: fp32 [ld, ld] upper Cholesky factor of the damped inverse Hessian
+ * (compute_hessian_inverse, calib_utils.py:80-113), delta: fp32 [rows, bs] receives err_j = (w_j - q_j) / hinv_jj.
+ * Column j: q_j = QDQ(w_j) -- fmt 1: INT-num_bits (tensor_quant.py:607-645), fmt 2: FP8-E4M3 (:46-59) -- with the fp32 amax
+ * entry amax[r * amax_row_stride + c / g] of element (r, c) (per tensor: stride 0 and g >= ld; per output channel:
+ * stride 1 and g >= ld; static blocks of g columns: stride ld / g); then every column k >= j of the block gets
+ * w_k -= fl(err_j * hinv[j, k]).  bs <= 128.  The update of the columns right of the block,
+ * weight[:, i2:] -= errs @ hinv[i1:i2, i2:] (calib_utils.py:276), is moq_sgpt_trailing_update. */
+int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
+                         const float* amax, int64_t amax_row_stride, int64_t g, int fmt, int num_bits, int is_unsigned,
+                         int narrow, void* stream);
 /* The update between two column blocks of create_sgpt_mask, w_rows[:, i2:] -= delta_blk.matmul(hessian_inv[i1:i2, i2:])
  * (sparsegpt.py:124; i2 = i1 + bs), with a DEFINED summation order instead of the BLAS library's:
  *     w[r, c] -= chain_{k = 0 .. bs-1, ascending} fmaf(delta[r, k], hinv[i1 + k, c], .)   started at +0,   c >= i2

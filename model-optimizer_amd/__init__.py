@@ -9,7 +9,8 @@ libmoquant.so (include/moquant.h).  Mirrors the reference's plugin surface for t
   nn, model_quant, model_calib   QuantLinear, quantize(), max_calibrate / smoothquant / awq_lite
   hf_attention     q / k / v bmm quantizers (FP8 KV cache) on Hugging Face attention modules
   hf_experts       per-expert weight quantizers on fused 3-D MoE expert containers (Mixtral, Qwen-MoE, ...)
-  sparsity         create_asp_mask (2:4 magnitude)
+  sparsity         create_asp_mask (2:4 magnitude), SparseGPT
+  gptq             GPTQ weight update (Hessian on the matrix cores, one kernel per column block)
   qtensor          INT4QTensor / FP8QTensor / MXFP4QTensor real quantisation (pack / unpack kernels)
   layerwise        layer-by-layer calibration with checkpoint / resume
   export           resmooth / layernorm fusion / INT4 nibble packing of the checkpoint export (byte-identical)
@@ -32,6 +33,7 @@ from . import distributed  # noqa: F401
 from . import model_calib  # noqa: F401
 from . import model_quant  # noqa: F401
 from . import sparsity  # noqa: F401
+from . import gptq  # noqa: F401
 from . import export  # noqa: F401
 from . import qtensor  # noqa: F401
 from . import layerwise  # noqa: F401
@@ -41,5 +43,5 @@ from .model_quant import quantize  # noqa: F401
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
 __all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "hf_attention", "hf_experts", "distributed", "model_calib", "model_quant",
-           "sparsity", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
+           "sparsity", "gptq", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
            "MoquantError", "MoquantUnsupported"]

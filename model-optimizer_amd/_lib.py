@@ -108,6 +108,8 @@ SIGNATURES = {
     "moq_block2d": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_void_p]),
     "moq_sgpt_trailing_update": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),
+    "moq_gptq_block_sweep": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                     c_int, c_int, c_int, c_int, c_void_p]),
     "moq_gemm_nt": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
 }
 

@@ -90,6 +90,63 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
   if (in1) { wr[lane + 64] = q1; delta[row * bs + lane + 64] = e1; }
 }
 
+// ---- GPTQ column sweep (quantization/utils/calib_utils.py:241-276, gptq_blockwise_update) --------------------------
+// The reference walks the columns of a block one at a time and fake-quantizes the WHOLE weight matrix for every column
+// (`qdq = quantize_fn(wblk)`, one column of it kept): ~8 torch ops and a full-matrix QDQ per column.  With a calibrated
+// (static) amax the quantizer is elementwise, so only the pivot column's QDQ matters, rows never interact inside a block,
+// and the sweep has the shape of the SparseGPT one: one wave per row, lane l holds columns l and l + 64 of the block,
+// the pivot is broadcast with a lane read.  q_j = QDQ(w_j) with the amax entry of (row, column): the library's own
+// fp32 INT-k / FP8-E4M3 quantize-dequantize (qdq_int, fp8_scale + e4m3 round trip: tensor_quant.py:607-645, :46-59);
+// err_j = (w_j - q_j) / hinv_jj; every column k >= j of the block gets w_k -= fl(err_j * hinv_jk) -- product rounded,
+// then subtracted, the order the oracle restates (orc_gptq_block_sweep).  amax entry of element (r, c):
+// amax[r * amax_row_stride + c / g]  (per tensor: stride 0, g >= ld; per output channel: stride 1, g >= ld; static
+// blocks of g columns: stride ld / g).
+template <int FMT>  // 1: INT-k, 2: FP8-E4M3
+__global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
+                                                            int bs, const float* __restrict__ hinv,
+                                                            float* __restrict__ delta, const float* __restrict__ amax,
+                                                            int64_t amax_row_stride, int64_t g, IntQ iq) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* wr = w + row * ld + i1;
+  const bool in0 = lane < bs, in1 = lane + 64 < bs;
+  float w0 = in0 ? wr[lane] : 0.0f, w1 = in1 ? wr[lane + 64] : 0.0f;
+  const float d0 = in0 ? hinv[(i1 + lane) * ld + i1 + lane] : 1.0f;
+  const float d1 = in1 ? hinv[(i1 + lane + 64) * ld + i1 + lane + 64] : 1.0f;
+  const float a0 = in0 ? amax[row * amax_row_stride + (i1 + lane) / g] : 1.0f;
+  const float a1 = in1 ? amax[row * amax_row_stride + (i1 + lane + 64) / g] : 1.0f;
+  float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
+  for (int j = 0; j < bs; ++j) {
+    const int src = j & 63;
+    const bool hi = j >= 64;
+    const float wj = __shfl(hi ? w1 : w0, src, 64);
+    const float dj = __shfl(hi ? d1 : d0, src, 64);
+    const float aj = __shfl(hi ? a1 : a0, src, 64);
+    float qj;
+    if constexpr (FMT == 1) {
+      qj = qdq_int(wj, int_scale(aj, iq.hi), iq);
+    } else {
+      const Fp8Scale sc = fp8_scale(aj);
+      const float t = wj * sc.s;
+      float c = __builtin_fminf(__builtin_fmaxf(t, -448.0f), 448.0f);
+      c = (t != t) ? t : c;  // torch.clamp keeps NaN
+      float ra, rb;
+      e4m3_roundtrip2(c, 0.0f, ra, rb);
+      qj = ra * sc.inv;
+    }
+    const float err = (wj - qj) / dj;
+    if (lane == src) {
+      if (hi) { q1 = qj; e1 = err; } else { q0 = qj; e0 = err; }
+    }
+    const float* hrow = hinv + (i1 + j) * ld + i1;
+    if (in0 && lane >= j) w0 = w0 - err * hrow[lane];
+    if (in1 && lane + 64 >= j) w1 = w1 - err * hrow[lane + 64];
+  }
+  if (in0) { wr[lane] = q0; delta[row * bs + lane] = e0; }
+  if (in1) { wr[lane + 64] = q1; delta[row * bs + lane + 64] = e1; }
+}
+
 // ---- trailing update: w[r, i2 + c] -= chain_{k < bs} fma(delta[r, k], hinv[i1 + k, i2 + c]), i2 = i1 + bs.
 //
 // One workgroup (4 waves) owns 128 rows and walks a strip of 64-column tiles.  K is the whole column block (<= 128), so
@@ -367,6 +424,30 @@ extern "C" int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t 
     default: hipLaunchKernelGGL((sgpt_sweep_kernel<8>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, prune_n); break;
   }
   return check_launch("moq_sgpt_block_sweep");
+}
+
+extern "C" int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv,
+                                    float* delta, const float* amax, int64_t amax_row_stride, int64_t g, int fmt,
+                                    int num_bits, int is_unsigned, int narrow, void* stream) {
+  if (w == nullptr || hinv == nullptr || delta == nullptr || amax == nullptr || rows < 0 || ld <= 0 || i1 < 0 || bs <= 0 ||
+      i1 + bs > ld || amax_row_stride < 0 || g <= 0) {
+    set_error("moq_gptq_block_sweep: bad arguments");
+    return MOQ_ERR_INVALID;
+  }
+  if (bs > kSgptMaxBlock || (fmt != 1 && fmt != 2) || (fmt == 1 && (num_bits < 2 || num_bits > 16))) {
+    set_error("moq_gptq_block_sweep: needs col block <= %d, fmt 1 (INT-k, 2 <= k <= 16) or 2 (FP8-E4M3)", kSgptMaxBlock);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (rows == 0) return MOQ_OK;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(kBlock);
+  const IntQ iq = make_intq(fmt == 1 ? num_bits : 8, is_unsigned, narrow);
+  if (fmt == 1)
+    hipLaunchKernelGGL((gptq_sweep_kernel<1>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
+                       amax_row_stride, g, iq);
+  else
+    hipLaunchKernelGGL((gptq_sweep_kernel<2>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
+                       amax_row_stride, g, iq);
+  return check_launch("moq_gptq_block_sweep");
 }
 
 extern "C" int moq_sgpt_trailing_update(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* delta,

@@ -1,0 +1,306 @@
+"""GPTQ weight update -- the `gptq` calibration algorithm of the path (quantization/model_calib.py:2192-2271 and
+quantization/utils/calib_utils.py:50-276: update_hessian, compute_hessian_inverse, GPTQHelper, gptq_blockwise_update).
+
+Per quantized linear: the Hessian of its inputs is accumulated during one forward loop (weight quantizers off), the
+damped inverse is factored (upper Cholesky of H^-1), and the columns are quantized one block at a time, each column's
+rounding error pushed onto the columns to its right through that factor.
+
+What is MI355X-native here:
+  * Hessian: 16-bit activations are transposed and contracted on the matrix cores (ops.hessian_accum -- the SYRK of
+    the SparseGPT path, upper tiles only, mirrored once); linears fed by the SAME tensor (q / k / v, gate / up) share
+    one Hessian and, when their dead columns agree, one inverse factor.
+  * Column sweep: the reference fake-quantizes the WHOLE weight matrix once per column and keeps one column of it.
+    With a calibrated amax the quantizer is elementwise, so the sweep over a block is one kernel
+    (ops.gptq_block_sweep: a wave per row, the block's columns in registers); the update of the columns right of the
+    block is ops.sgpt_trailing_update (fp32 matrix cores, defined summation order).  Quantizers whose scale depends on
+    the current weights (dynamic block formats) take the reference's own loop through the quantizer.
+  * Data-parallel replicas (distributed.declare_data_parallel): Hessians are combined sample-weighted on one owner
+    rank each, the owner updates the linears that read them and broadcasts the weights -- every replica ends with the
+    same model (the reference leaves ranks to diverge).
+"""
+
+from __future__ import annotations
+
+import time
+import warnings
+
+import torch
+from torch import nn
+
+from . import ops
+from .nn import is_quantized_linear
+from .sparsity import HessianState
+from .tensor_quantizer import TensorQuantizer
+
+GPTQ_STATS: dict = {}
+
+
+class TokenHessian(HessianState):
+    """update_hessian (calib_utils.py:50-77): the running mean counts TOKENS (rows of the flattened input), where
+    SparseGPT's hook counts batches: H <- H * n / (n + b) + (2 / (n + b)) X^T X.  (The reference scales the inputs by
+    sqrt(2 / n) before the product; the scale is applied to the fp32 accumulators here -- the same sum up to rounding,
+    and a GEMM's summation order is the library's in the reference anyway.)"""
+
+    @torch.no_grad()
+    def update(self, inp: torch.Tensor):
+        x2 = inp.reshape(-1, inp.shape[-1])
+        b = x2.shape[0]
+        if b == 0:  # in MoEs some experts receive no tokens
+            return
+        decay = self.samples / (self.samples + b)
+        self.samples += b
+        scale = 2.0 / self.samples
+        if x2.dtype in (torch.bfloat16, torch.float16) and x2.shape[1] % 4 == 0 and x2.is_cuda:
+            ops.hessian_accum(self._h, x2, decay, scale, upper_only=True)
+            self._upper = True
+        else:
+            xf = x2.float()
+            self.hessian.mul_(decay).addmm_(xf.t(), xf, alpha=scale)
+
+
+def update_hessian(input: torch.Tensor, hessian: torch.Tensor, n_samples: int):
+    """Functional form of calib_utils.update_hessian: returns (hessian, n_samples); `hessian` is updated in place."""
+    st = TokenHessian.__new__(TokenHessian)
+    st._h, st._upper, st.samples = hessian, False, int(n_samples)
+    st.update(input)
+    return st.hessian, st.samples
+
+
+def dead_columns(weight: torch.Tensor) -> torch.Tensor:
+    """Columns of the weight that are zero in every row (calib_utils.py:97): bool [Cin]."""
+    return weight.eq(0).all(dim=0)
+
+
+def compute_hessian_inverse(hessian: torch.Tensor, weight: torch.Tensor | None, perc_damp: float,
+                            zero_cols: torch.Tensor | None = None) -> torch.Tensor:
+    """calib_utils.py:80-113: dead-neuron columns of `weight` are cut out of the Hessian (row and column zeroed, unit
+    diagonal), the diagonal is damped by perc_damp * mean(diag), and the upper Cholesky factor of the inverse is
+    returned; a Hessian that is not positive definite gives the identity (with the reference's warning)."""
+    h = hessian.clone()
+    zero = zero_cols if zero_cols is not None else dead_columns(weight)
+    if bool(zero.any()):
+        h[zero, :] = 0
+        h[:, zero] = 0
+        idx = torch.nonzero(zero).flatten()
+        h[idx, idx] = 1
+    damp = perc_damp * torch.mean(torch.diag(h))
+    diag = torch.arange(h.shape[0], device=h.device)
+    h[diag, diag] += damp
+    try:
+        h = torch.cholesky_inverse(torch.linalg.cholesky(h))
+        return torch.linalg.cholesky(h, upper=True).contiguous()
+    except (RuntimeError, torch.linalg.LinAlgError):
+        warnings.warn("Warning: Hessian is not positive definite, using identity matrix")
+        return torch.eye(h.shape[0], device=h.device, dtype=h.dtype)
+
+
+def _static_layout(q, weight: torch.Tensor):
+    """(fmt, num_bits, unsigned, narrow, amax fp32 flat, amax_row_stride, g) when `q` is a TensorQuantizer whose
+    quantize-dequantize of a 2-D fp32 weight is ELEMENTWISE with a calibrated amax -- what the sweep kernel takes --,
+    else None (the quantizer's own forward is used column by column, like the reference)."""
+    if not isinstance(q, TensorQuantizer) or weight.dim() != 2:
+        return None
+    if q._disabled or not q.fake_quant or q._dynamic or q._block_dynamic or q.pre_quant_scale is not None:
+        return None
+    amax = getattr(q, "_amax", None)
+    if amax is None:
+        return None
+    nb = q._num_bits if not isinstance(q._num_bits, list) else tuple(q._num_bits)
+    if nb == (4, 3):
+        fmt, bits = 2, 8
+    elif isinstance(nb, int) and 2 <= nb <= 16:
+        fmt, bits = 1, nb
+    else:
+        return None
+    rows, cols = weight.shape
+    am = amax.detach().float().reshape(-1)
+    bsz = q._block_sizes
+    if bsz is None:
+        axis = q._axis
+        if axis is None and am.numel() == 1:
+            stride, g = 0, cols
+        elif axis in (0, (0,), [0], -2, (-2,)) and am.numel() == rows:
+            stride, g = 1, cols
+        else:
+            return None
+    else:
+        if not q.is_static_block_quant or set(bsz) - {-1, 1, "type"} or fmt != 1:
+            return None
+        g = bsz.get(-1, None) or bsz.get(1, None)
+        if not g or cols % g or am.numel() != rows * (cols // g):
+            return None
+        stride = cols // g
+    return fmt, bits, bool(q._unsigned), bool(q._narrow_range), am, int(stride), int(g)
+
+
+@torch.no_grad()
+def gptq_blockwise_update(weight: torch.Tensor, h_inv: torch.Tensor, block_size: int, quantize_fn) -> dict:
+    """calib_utils.py:241-276 on the fp32 working copy `weight` [Cout, Cin], in place.  Returns {"kernel": bool}."""
+    num_cols = weight.shape[1]
+    layout = _static_layout(quantize_fn, weight)
+    if layout is not None and block_size <= 128 and weight.dtype == torch.float32 and weight.is_contiguous():
+        fmt, bits, unsigned, narrow, am, stride, g = layout
+        h_inv = h_inv.float().contiguous()
+        for i1 in range(0, num_cols, block_size):
+            bs = min(block_size, num_cols - i1)
+            errs = ops.gptq_block_sweep(weight, i1, bs, h_inv, am, stride, g, fmt, bits, unsigned, narrow)
+            if i1 + bs < num_cols:
+                ops.sgpt_trailing_update(weight, i1, errs, h_inv)
+        return {"kernel": True}
+    # the reference's loop: the quantizer sees the whole working matrix for every column (dynamic block scales move
+    # with the weights)
+    for block_start in range(0, num_cols, block_size):
+        block_end = min(block_start + block_size, num_cols)
+        h_blk = h_inv[block_start:block_end, block_start:block_end]
+        wblk = weight.clone()
+        errs = torch.zeros_like(weight[:, block_start:block_end])
+        for i in range(block_end - block_start):
+            w_ci = wblk[:, block_start + i]
+            d = h_blk[i, i]
+            qdq = quantize_fn(wblk)
+            weight[:, block_start + i] = qdq[:, block_start + i]
+            err = (w_ci - qdq[:, block_start + i]) / d
+            wblk[:, block_start + i:block_end].addr_(err, h_blk[i, i:], alpha=-1)
+            errs[:, i] = err
+        weight[:, block_end:].addmm_(errs, h_inv[block_start:block_end, block_end:], alpha=-1)
+    return {"kernel": False}
+
+
+def relative_mse(weight_new: torch.Tensor, weight_orig: torch.Tensor, hessian: torch.Tensor) -> float:
+    """GPTQHelper._print_mse_error (calib_utils.py:232-238): Hessian-weighted relative error of the update."""
+    delta = weight_new - weight_orig
+    num = delta.mm(hessian).mul(delta).mean()
+    den = weight_orig.mm(hessian).mul(weight_orig).mean() + 1e-6
+    return float(num / den)
+
+
+class GPTQHelper:
+    """Per-module state of calib_utils.GPTQHelper: owns (or shares) the Hessian, hooks the module during the collection
+    pass, runs the blockwise update."""
+
+    def __init__(self, module: nn.Module, name: str):
+        self.module, self.name = module, name
+        self.state: TokenHessian | None = TokenHessian(module.weight.shape[-1], module.weight.device)
+        self.owner: "GPTQHelper" = self  # the helper whose Hessian this linear reads
+        self._handle = None
+
+    # -- collection
+    def setup(self, shared: dict):
+        helper = self
+
+        def pre_hook(mod, args):
+            x = args[0]
+            x = x.to_local() if hasattr(x, "to_local") else x
+            iq = getattr(mod, "input_quantizer", None)
+            if iq is not None and iq.is_enabled:
+                h_in = iq(x)
+                key = None  # a quantized copy: nothing to share by identity
+            else:
+                h_in, key = x, x
+            first = shared.get("input") is key and key is not None
+            if first and shared["owner"].state._h.shape == helper.state._h.shape and helper.owner in (helper, shared["owner"]):
+                helper.owner = shared["owner"]
+                return
+            if helper.owner is not helper:
+                raise RuntimeError("gptq: a linear that shared its input with another one in an earlier batch got a "
+                                   "different tensor now")
+            helper.state.update(h_in)
+            shared["input"], shared["owner"] = key, helper
+
+        self._handle = self.module.register_forward_pre_hook(pre_hook)
+
+    def cleanup(self):
+        if self._handle is not None:
+            self._handle.remove()
+            self._handle = None
+        if self.owner is not self:
+            self.state = None  # never written
+
+    def free(self):
+        self.state = None
+
+
+def _weight_quantizers_off(model):
+    qs = [m.weight_quantizer for m in model.modules() if is_quantized_linear(m) and isinstance(m.weight_quantizer, TensorQuantizer)]
+    saved = [q._disabled for q in qs]
+    for q in qs:
+        q._disabled = True
+    return qs, saved
+
+
+@torch.no_grad()
+def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: int = 128, fused: bool = False,
+         shard_weights: bool | None = None):
+    """model_calib.gptq (model_calib.py:2192-2271).  `model` is the full model, or one decoder layer when called by
+    layerwise.layerwise_calibrate.  Steps: max_calibrate (amax from the current activations / weights); Hessians of
+    every quantized linear's input from ONE forward loop with the weight quantizers off (the input quantizer, when
+    enabled, is applied to what the Hessian sees); blockwise weight update.  `fused` (the reference's Triton kernel for
+    static NVFP4) has no meaning here: the elementwise formats are always one kernel per block."""
+    from . import distributed as mdist
+    from . import model_calib
+    from .sparsity import _combine_hessians
+
+    t0 = time.perf_counter()
+    model_calib.max_calibrate(model, forward_loop)
+    layers = [(n, m) for n, m in model.named_modules()
+              if is_quantized_linear(m) and isinstance(m.weight_quantizer, TensorQuantizer) and m.weight_quantizer.is_enabled]
+    GPTQ_STATS.clear()
+    GPTQ_STATS.update({"linears": len(layers), "kernel_linears": 0, "shared_hessians": 0, "relative_mse": {}})
+    if not layers:
+        return model
+    helpers = {m: GPTQHelper(m, n) for n, m in layers}
+    shared = {"input": None, "owner": None}
+    for h in helpers.values():
+        h.setup(shared)
+    qs, saved = _weight_quantizers_off(model)
+    try:
+        forward_loop(model)
+    finally:
+        for q, d in zip(qs, saved):
+            q._disabled = d
+        for h in helpers.values():
+            h.cleanup()
+        shared["input"] = shared["owner"] = None
+    GPTQ_STATS["shared_hessians"] = sum(1 for h in helpers.values() if h.owner is not h)
+    shard = mdist.resolve_shard(shard_weights)
+    placed = None
+    mods = [m for _, m in layers]
+    if shard:
+        owner_of = {m: helpers[m].owner.module for m in mods if helpers[m].owner is not helpers[m]}
+        placed = _combine_hessians(mods, {m: helpers[m].owner.state for m in mods}, owner_of)
+    inverse_cache: dict = {}
+    users: dict = {}
+    for m in mods:
+        users[helpers[m].owner] = users.get(helpers[m].owner, 0) + 1
+    t_upd = time.perf_counter()
+    for name, m in layers:
+        h = helpers[m]
+        own = h.owner
+        if placed is not None and placed[own.module] != placed["me"]:
+            users[own] -= 1
+            continue
+        hessian = own.state.hessian
+        w_orig = m.weight.data
+        weight = w_orig.float().clone()
+        zero = dead_columns(weight)
+        key = (own, bytes(zero.cpu().numpy().tobytes()) if bool(zero.any()) else b"")
+        if key not in inverse_cache:
+            inverse_cache[key] = compute_hessian_inverse(hessian.to(weight.device), None, perc_damp, zero_cols=zero)
+        info = gptq_blockwise_update(weight, inverse_cache[key], block_size, m.weight_quantizer)
+        GPTQ_STATS["kernel_linears"] += int(info["kernel"])
+        GPTQ_STATS["relative_mse"][name] = relative_mse(weight, w_orig.float(), hessian.to(weight.device))
+        m.weight.data = weight.reshape(m.weight.shape).to(w_orig.dtype)
+        users[own] -= 1
+        if users[own] == 0:
+            own.free()
+            for k in [k for k in inverse_cache if k[0] is own]:
+                del inverse_cache[k]
+    if placed is not None:
+        mdist.broadcast_from_owners([m.weight.data for m in mods], group=mdist.replica_group(),
+                                    owners=[placed[helpers[m].owner.module] for m in mods])
+    for h in helpers.values():
+        h.free()
+    now = time.perf_counter()
+    GPTQ_STATS["update_s"] = round(now - t_upd, 4)
+    GPTQ_STATS["total_s"] = round(now - t0, 4)
+    return model

@@ -1531,3 +1531,11 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
         if is_quantized_linear(m) and isinstance(m.weight_quantizer, SequentialQuantizer):
             max_calibrate(m, lambda linear: linear.weight_quantizer(linear.weight), distributed_sync=False)
     return out
+
+
+def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: int = 128, fused: bool = False, **kwargs):
+    """model_calib.gptq (model_calib.py:2192-2271): the implementation lives in gptq.py."""
+    from . import gptq as _gptq
+
+    return _gptq.gptq(model, forward_loop, perc_damp=perc_damp, block_size=block_size, fused=fused, **kwargs)
+

@@ -282,6 +282,24 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
         model_calib.smoothquant(model, forward_loop, **kwargs)
     elif method in ("awq_lite", "awq_clip", "awq_full"):
         model_calib.awq(model, forward_loop, algorithm=method, **kwargs)
+    elif method == "gptq":
+        # GPTQCalibConfig (config.py:1204-1250): perc_damp, block_size, fused; `layerwise` = LayerwiseConfig, whose
+        # get_qdq_activations_from_prev_layer defaults to True for this algorithm (every layer's Hessian sees the
+        # quantized output of its predecessors)
+        from . import gptq as _gptq
+        from . import layerwise as _layerwise
+
+        lw = kwargs.pop("layerwise", None) or {}
+        lw = {"enable": bool(lw)} if isinstance(lw, bool) else dict(lw)
+        gk = {k: kwargs[k] for k in ("perc_damp", "block_size", "fused", "shard_weights") if kwargs.get(k) is not None}
+        if lw.get("enable", False):
+            if lw.get("calib_mutates_weights", True) is False:
+                raise ValueError("layerwise.calib_mutates_weights=False is rejected for weight-mutating algorithms (gptq)")
+            _layerwise.layerwise_calibrate(model, forward_loop, _gptq.gptq, checkpoint_dir=lw.get("checkpoint_dir"),
+                                           get_qdq_activations_from_prev_layer=lw.get("get_qdq_activations_from_prev_layer", True),
+                                           calib_mutates_weights=True, **gk)
+        else:
+            _gptq.gptq(model, forward_loop, **gk)
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
     stage("calibrate")

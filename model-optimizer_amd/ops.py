@@ -1123,6 +1123,29 @@ def sgpt_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, prun
     return delta
 
 
+@torch.no_grad()
+def gptq_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, amax: torch.Tensor, amax_row_stride: int,
+                     g: int, fmt: int, num_bits: int = 8, unsigned: bool = False, narrow_range: bool = False) -> torch.Tensor:
+    """In-place column sweep of gptq_blockwise_update over block [i1, i1 + bs) (utils/calib_utils.py:241-276) for a
+    quantizer with a calibrated amax: the block's columns become their quantized-dequantized values, the errors
+    err_j = (w_j - q_j) / hinv_jj are returned [rows, bs].  fmt 1: INT-num_bits, 2: FP8-E4M3; amax: fp32, entry
+    amax[r * amax_row_stride + c / g] for element (r, c)."""
+    _require_gpu(w, "gptq_block_sweep")
+    if w.dtype != torch.float32 or hinv.dtype != torch.float32 or not w.is_contiguous() or not hinv.is_contiguous():
+        raise MoquantError("gptq_block_sweep: contiguous fp32 tensors expected")
+    rows, ld = w.shape
+    am = _f32(amax, w.device).reshape(-1)
+    need = (rows - 1) * int(amax_row_stride) + (ld - 1) // int(g) + 1 if rows else 0
+    if am.numel() < need:
+        raise MoquantError(f"gptq_block_sweep: {am.numel()} amax entries, the layout needs {need}")
+    delta = torch.empty(rows, bs, dtype=torch.float32, device=w.device)
+    with _on(w) as stream:
+        check(_lib.lib().moq_gptq_block_sweep(_p(w), rows, ld, int(i1), int(bs), _p(hinv), _p(delta), _p(am),
+                                              int(amax_row_stride), int(g), int(fmt), int(num_bits), int(bool(unsigned)),
+                                              int(bool(narrow_range)), stream))
+    return delta
+
+
 # ----------------------------------------------------------------------------------------------- AWQ Gram search
 def sgpt_trailing_update(w: torch.Tensor, i1: int, delta: torch.Tensor, hinv: torch.Tensor) -> torch.Tensor:
     """In place: w[:, i2:] -= delta @ hinv[i1:i2, i2:] (sparsegpt.py:124, i2 = i1 + delta.shape[1]) as the fp32 fma chain

@@ -395,6 +395,19 @@ def sgpt_block_sweep(w, i1, bs, hinv, prune_n=2, prune_m=4):
     return torch.from_numpy(delta)
 
 
+def gptq_block_sweep(w, i1, bs, hinv, amax, amax_row_stride, g, fmt, num_bits=8, unsigned=False, narrow=False):
+    """In-place column sweep of gptq_blockwise_update over block [i1, i1 + bs) (calib_utils.py:241-276) for a static
+    amax; fmt 1: INT-num_bits, 2: FP8-E4M3; returns the errors [rows, bs]."""
+    assert w.dtype == torch.float32 and w.is_contiguous() and hinv.dtype == torch.float32 and bs <= 1024
+    rows, ld = w.shape
+    delta = np.zeros((rows, bs), dtype=np.float32)
+    am = np.ascontiguousarray(amax.detach().float().reshape(-1).numpy())
+    lib().orc_gptq_block_sweep(_p(w.numpy()), I64(rows), I64(ld), I64(i1), int(bs), _p(np.ascontiguousarray(hinv.numpy())),
+                               _p(delta), _p(am), I64(amax_row_stride), I64(g), int(fmt), int(num_bits), int(bool(unsigned)),
+                               int(bool(narrow)))
+    return torch.from_numpy(delta)
+
+
 def sgpt_trailing_update(w, i1, delta, hinv):
     """In place: w[:, i2:] -= delta @ hinv[i1:i2, i2:] (sparsegpt.py:124) as the ascending-k fmaf chain -- the summation
     order the product path defines where the reference has its BLAS library's."""

@@ -21,6 +21,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   awq_clip.npz  -- mtq.quantize() with awq_clip / awq_full: w_amax, per-shrink block losses, best_clip_val
   block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
+  gptq.npz      -- GPTQ: Hessian, inverse factor and updated weights of one linear per format; mtq.quantize(gptq) on the tiny MLP
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
@@ -533,6 +534,92 @@ def gen_sgpt(out):
         out[f"{name}_mask"] = mask.numpy().astype(np.uint8)
         cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches), samples=int(mod.samples),
                            kept=float(mask.float().mean()))
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_gptq(out):
+    """GPTQ (quantization/model_calib.py:2192-2271, utils/calib_utils.py:50-276), run on CPU.
+    Building blocks on one linear per weight format -- the steps of gptq() made one by one so that the intermediates can
+    be stored: mtq.quantize(max) for the amax, GPTQHelper.setup + a forward loop with the weight quantizers off (the
+    Hessian), update_weights (inverse factor, blockwise update) -- and mtq.quantize(algorithm = gptq) end to end on the
+    tiny MLP."""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.conversion import set_quantizer_by_cfg_context
+    from modelopt.torch.quantization.utils.calib_utils import GPTQHelper
+
+    int4_g32 = copy.deepcopy(mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG)
+    for entry in (int4_g32["quant_cfg"] if isinstance(int4_g32["quant_cfg"], list) else []):
+        if isinstance(entry, dict) and isinstance(entry.get("cfg"), dict) and "block_sizes" in entry["cfg"]:
+            entry["cfg"]["block_sizes"] = {-1: 32}
+    if isinstance(int4_g32["quant_cfg"], dict):
+        for k, v in int4_g32["quant_cfg"].items():
+            if isinstance(v, dict) and "block_sizes" in v:
+                v["block_sizes"] = {-1: 32}
+    cases = {}
+    blocks = [("int4_g128_bf16", mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, torch.bfloat16, 48, 256, 128, 0.01),
+              ("int4_g32_f32", int4_g32, torch.float32, 40, 192, 64, 0.01),
+              ("fp8_bf16", mtq.FP8_DEFAULT_CFG, torch.bfloat16, 64, 256, 128, 0.01),
+              ("int8_pc_f32", mtq.INT8_DEFAULT_CFG, torch.float32, 32, 160, 128, 0.1)]
+    for name, cfg, dt, co, ci, block_size, perc_damp in blocks:
+        lin = torch.nn.Linear(ci, co, bias=False)
+        with torch.no_grad():
+            lin.weight.copy_(weight_like((co, ci), torch.float32, 2300 + co + ci).float() * 4)
+            if name == "int8_pc_f32":
+                lin.weight[:, 5] = 0  # a dead input column (compute_hessian_inverse zeroes it out of the Hessian)
+        lin = lin.to(dt)
+        g = torch.Generator().manual_seed(2301 + ci)
+        ch = torch.exp(torch.randn(ci, generator=g) * 0.7)
+        batches = [(torch.randn(2, 40, ci, generator=g) * ch).to(dt) for _ in range(3)]
+
+        def loop(m):
+            for b in batches:
+                m(b)
+
+        w0 = lin.weight.detach().clone()
+        q = mtq.quantize(lin, copy.deepcopy(cfg), loop)  # (converts in place; algorithm max)
+        q.weight.data = w0.clone()
+        helper = GPTQHelper(q, name, offload_to_cpu=False)
+        helper.setup()
+        with set_quantizer_by_cfg_context(q, [{"quantizer_name": "*weight_quantizer", "enable": False}]):
+            loop(q)
+        helper.cleanup()
+        hessian = helper.hessian.clone()
+        n_samples = int(helper.n_samples)
+        helper.update_weights(block_size, perc_damp)
+        out[f"{name}_w"] = bits(w0)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+        out[f"{name}_hessian"], out[f"{name}_hinv"] = bits(hessian), bits(helper.h_inv)
+        out[f"{name}_wfinal"] = bits(q.weight.data)
+        out[f"{name}_w_amax"] = bits(q.weight_quantizer._amax.float())
+        if q.input_quantizer.is_enabled and hasattr(q.input_quantizer, "_amax"):
+            out[f"{name}_in_amax"] = bits(q.input_quantizer._amax.float())
+        cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches), n_samples=n_samples, block_size=block_size,
+                           perc_damp=perc_damp, w_amax_shape=list(q.weight_quantizer._amax.shape),
+                           input_quantizer=bool(q.input_quantizer.is_enabled))
+    # end to end: mtq.quantize with the gptq algorithm (not layerwise) on the tiny MLP
+    for name, cfg, dt in [("flow_int4_f32", mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, torch.float32),
+                          ("flow_fp8_bf16", mtq.FP8_DEFAULT_CFG, torch.bfloat16)]:
+        model = _TinyMLP(dtype=dt, seed=31)
+        batches = _calib_batches(128, dt, 32)
+        out[f"{name}_w1"], out[f"{name}_w2"], out[f"{name}_b2"] = bits(model.fc1.weight), bits(model.fc2.weight), bits(model.fc2.bias)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+
+        def loop2(m):
+            for b in batches:
+                m(b)
+
+        cfg = copy.deepcopy(cfg)
+        cfg["algorithm"] = {"method": "gptq", "perc_damp": 0.01, "block_size": 128}
+        qm = mtq.quantize(copy.deepcopy(model), cfg, loop2)
+        for lname in ("fc1", "fc2"):
+            out[f"{name}_{lname}_wfinal"] = bits(getattr(qm, lname).weight)
+            out[f"{name}_{lname}_w_amax"] = bits(getattr(qm, lname).weight_quantizer._amax.float())
+        out[f"{name}_y"] = bits(qm(batches[0]))
+        cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches))
     out["cases"] = np.array(json.dumps(cases))
 
 
@@ -1241,12 +1328,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)

@@ -300,6 +300,12 @@ class HostMemLib:
                                     int(prune_m))
         return OK
 
+    def moq_gptq_block_sweep(self, w, rows, ld, i1, bs, hinv, delta, amax, amax_row_stride, g, fmt, num_bits, is_unsigned,
+                             narrow, stream):
+        self.o.orc_gptq_block_sweep(_vp(w), I64(rows), I64(ld), I64(i1), int(bs), _vp(hinv), _vp(delta), _vp(amax),
+                                    I64(amax_row_stride), I64(g), int(fmt), int(num_bits), int(is_unsigned), int(narrow))
+        return OK
+
     # -- Gram-matrix AWQ search / SparseGPT Hessian: numpy restatements (fp64 accumulation) of the MFMA entries
     def moq_sgpt_trailing_update(self, w, rows, ld, i1, bs, delta, hinv, stream):
         self.o.orc_sgpt_trailing_update(_vp(w), I64(rows), I64(ld), I64(i1), int(bs), _vp(delta), _vp(hinv))

@@ -133,7 +133,7 @@ def test_quantize_config_plumbing_without_gpu():
     with pytest.raises(moa.MoquantError, match="must live on the GPU"):
         model(torch.randn(2, 128))
     with pytest.raises(ValueError, match="outside this path"):
-        moa.quantize(torch.nn.Linear(4, 4), {"quant_cfg": {}, "algorithm": "gptq"})
+        moa.quantize(torch.nn.Linear(4, 4), {"quant_cfg": {}, "algorithm": "svdquant"})
 
 
 def test_modelopt_seams_install():
