@@ -65,6 +65,19 @@ def _capture_inputs(model, layer, forward_loop):
     return calls
 
 
+def without_cache(kwargs: dict) -> dict:
+    """Keyword arguments of a decoder-layer call without its KV-cache objects: a layer replayed outside its model must
+    not append to (or attend over) a cache another call filled -- the second replay would see the keys / values of the
+    first, computed from weights a weight-mutating calibration has since changed."""
+    kwargs = dict(kwargs)
+    for k in ("past_key_values", "past_key_value"):
+        if kwargs.get(k) is not None:
+            kwargs[k] = None
+    if kwargs.get("use_cache"):
+        kwargs["use_cache"] = False
+    return kwargs
+
+
 def _first_tensor(out):
     return out[0] if isinstance(out, (tuple, list)) else out
 
@@ -174,6 +187,7 @@ def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None,
         inputs = _capture_inputs(model, layers[start], forward_loop)
         if not inputs:
             raise RuntimeError("forward_loop never reached the first decoder layer")
+    inputs = [(args, without_cache(kwargs)) for args, kwargs in inputs]
     done = 0
     for idx in range(start, n_layers):
         layer = layers[idx]

@@ -744,14 +744,7 @@ def _awq_lite_layer_local(model: nn.Module, forward_loop, layers, **kw):
     t0 = drained_clock()
     inputs = layerwise._capture_inputs(model, layers[0], forward_loop)
 
-    def without_cache(kwargs):
-        kwargs = dict(kwargs)
-        for k in ("past_key_values", "past_key_value"):
-            if kwargs.get(k) is not None:
-                kwargs[k] = None
-        if kwargs.get("use_cache"):
-            kwargs["use_cache"] = False
-        return kwargs
+    without_cache = layerwise.without_cache
 
     reached = torch.tensor([float(len(inputs) > 0)], device=dev)
     if _dist_on():  # data parallel: the same flow on every rank (a rank whose shard is empty walks the layers with no batches)

@@ -22,6 +22,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
   gptq.npz      -- GPTQ: Hessian, inverse factor and updated weights of one linear per format; mtq.quantize(gptq) on the tiny MLP
+  gptq_llama.npz -- mtq.quantize(algorithm = gptq) on a tiny Llama in one pass (updated weights, logits)
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
@@ -620,6 +621,45 @@ def gen_gptq(out):
             out[f"{name}_{lname}_w_amax"] = bits(getattr(qm, lname).weight_quantizer._amax.float())
         out[f"{name}_y"] = bits(qm(batches[0]))
         cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches))
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_gptq_llama(out):
+    """mtq.quantize(tiny Llama, INT4 blockwise weight-only, algorithm = gptq) in one pass over the whole model: original
+    weights, tokens, every updated weight, the logits.
+    (Not stored: the layer-by-layer mode, layerwise.enable.  With the transformers version of this container (5.15,
+    "not tested" by the reference's own warning) the reference's replay of a decoder layer returns an all-zero attention
+    output -- o_proj's Hessian is the zero matrix, "not positive definite, using identity", and the MLP's Hessian is that
+    of the layer input -- so that run is not an oracle for anything.)"""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    cfg = LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)
+    base = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(40 + i)) for i in range(3)]
+    for k, v in base.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    for i, b in enumerate(batches):
+        out[f"tokens{i}"] = b.numpy()
+    cases = {"config": cfgd, "n_batches": len(batches), "runs": {}}
+    for run, layerwise in (("whole", {"enable": False}),):
+        qcfg = copy.deepcopy(mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG)
+        qcfg["algorithm"] = {"method": "gptq", "perc_damp": 0.01, "block_size": 128, "layerwise": layerwise}
+        q = mtq.quantize(copy.deepcopy(base), qcfg, lambda m: [m(b) for b in batches])
+        names = []
+        for n, m in q.named_modules():
+            if hasattr(m, "weight_quantizer") and m.weight_quantizer.is_enabled:
+                names.append(n)
+                out[f"{run}/{n}.weight"] = bits(m.weight)
+                out[f"{run}/{n}.amax"] = bits(m.weight_quantizer._amax.float())
+        with torch.no_grad():
+            out[f"{run}/logits"] = bits(q(batches[0]).logits)
+        cases["runs"][run] = names
     out["cases"] = np.array(json.dumps(cases))
 
 
@@ -1328,12 +1368,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)

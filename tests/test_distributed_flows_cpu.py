@@ -255,6 +255,27 @@ def _job_awq_layer_local(rank, world, moa, single):
            "contenders": {n: h.contenders for n, h in hs.items()}}
 
 
+def _job_gptq(rank, world, moa, single):
+    """GPTQ under data parallelism: every rank accumulates the Hessians of its share of the batches, the distinct Hessians
+    are combined sample-weighted on one owner each, the owner updates the linears that read them and broadcasts the
+    weights.  The combined Hessian is a differently associated sum than the single-rank running mean: single weights may
+    land on the neighbouring level (key "w~": at most 2 % of a tensor), and every rank must hold the same weights."""
+    mq = moa.model_quant
+    for preset in ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG"):
+        cfg = copy.deepcopy(getattr(mq, preset))
+        if "INT4" in preset:
+            cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+        cfg["algorithm"] = {"method": "gptq", "perc_damp": 0.01, "block_size": 64}
+        batches = _batches(128, torch.float32, n=_n_batches(world))
+        mine = batches if single else batches[rank::world]
+        model = moa.quantize(MLP(), cfg, lambda m: [m(b) for b in mine])
+        from model_optimizer_amd import gptq
+
+        st = gptq.GPTQ_STATS
+        assert st["linears"] == 3 and (st["kernel_linears"] == 3 if single else st["kernel_linears"] <= 3), st
+        yield {"w~": {n: p.detach().clone() for n, p in model.named_parameters()}, "amax": _amaxes(model)}
+
+
 class _TPShard(torch.nn.Module):
     """Rank r's shard of the MLP under tensor parallelism: fc1 column parallel (rows r * H/W ..), fc2 row parallel (the
     matching input columns); the partial outputs are not combined -- only the calibration statistics matter here."""
@@ -330,6 +351,9 @@ def _compare(kind, want, got):
                     assert x.shape == y.shape and (x == y).float().mean() >= 0.97, f"{kind}[{i}] {name}"
                     assert torch.equal(y.view(-1, 4).sum(1), torch.full((y.numel() // 4,), 2)), f"{kind}[{i}] {name}: not 2:4"
                     continue
+                if key == "w~":
+                    assert x.shape == y.shape and (x == y).float().mean() >= 0.98, f"{kind}[{i}] {name}: {(x != y).float().mean():.4f} differ"
+                    continue
                 if key in ("alpha", "contenders"):
                     assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
                 elif key in ("act_scale", "loss") or (kind.startswith("awq") and key in ("amax", "w")):
@@ -370,7 +394,7 @@ def _worker(rank, world, port, kind, ret):
                     assert any(s for _, s in mine.values()) or any(s for e in everyone for _, s in e.values())
         # and every rank holds the same state (the reference's property)
         for g in got:
-            for key in ("amax", "hist", "mask", "mask~", "w"):
+            for key in ("amax", "hist", "mask", "mask~", "w", "w~"):
                 for name, t in g.get(key, {}).items():
                     ref = t.clone().float()
                     dist.all_reduce(ref, op=dist.ReduceOp.MAX)
@@ -386,7 +410,7 @@ def _worker(rank, world, port, kind, ret):
 
 
 @pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "awq_layer_local", "tensor_parallel", "weight_side",
-                                  "undeclared"])
+                                  "undeclared", "gptq"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
     mgr = mp.Manager()

@@ -21,8 +21,8 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq",
                                                           "int8_mse", "fp8_mse", "int4_mse", "int4_awq_clip", "int4_awq_full",
-                                                          "int8_percentile", "int8_entropy",
-                                                          "sparse_magnitude", "sparsegpt"],
+                                                          "int8_percentile", "int8_entropy", "int4_gptq", "int4_gptq_layerwise",
+                                                          "fp8_gptq", "sparse_magnitude", "sparsegpt"],
                     help="the last rows: the other calibration algorithms of the path (MSE amax search, AWQ clip / full) and the "
                          "two sparsity modes, for wall-clock at real shapes")
     ap.add_argument("--arch", default="llama", choices=["llama", "mixtral"],
@@ -101,7 +101,10 @@ def run(args, moa=None, dev=None) -> dict:
     qcfg = {"int8_mse": lambda: with_alg(mq.INT8_DEFAULT_CFG, "mse"), "fp8_mse": lambda: with_alg(mq.FP8_DEFAULT_CFG, "mse"),
             "int4_mse": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, "mse"),
             "int4_awq_clip": lambda: with_alg(mq.INT4_AWQ_CFG, "awq_clip"),
-            "int4_awq_full": lambda: with_alg(mq.INT4_AWQ_CFG, "awq_full")}.get(args.qformat)
+            "int4_awq_full": lambda: with_alg(mq.INT4_AWQ_CFG, "awq_full"),
+            "int4_gptq": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, {"method": "gptq"}),
+            "int4_gptq_layerwise": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, {"method": "gptq", "layerwise": {"enable": True}}),
+            "fp8_gptq": lambda: with_alg(mq.FP8_DEFAULT_CFG, {"method": "gptq"})}.get(args.qformat)
     qcfg = qcfg() if qcfg else {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
             "int4_awq": mq.INT4_AWQ_CFG, "w4a8_awq": mq.W4A8_AWQ_BETA_CFG, "mxfp4": mq.MXFP4_DEFAULT_CFG, "mxfp4_sq": mq.MXFP4_SMOOTHQUANT_CFG,
             "int8_sq": mq.INT8_SMOOTHQUANT_CFG}[args.qformat]
@@ -148,6 +151,11 @@ def run(args, moa=None, dev=None) -> dict:
     extra["quantize_stages_s"] = dict(moa.model_quant.QUANTIZE_STATS.get("stages_s") or {})
     if moa.model_calib.MAX_CALIBRATE_STATS:
         extra["max_calibrate_s"] = dict(moa.model_calib.MAX_CALIBRATE_STATS)
+    if "gptq" in args.qformat:
+        st = dict(moa.gptq.GPTQ_STATS)
+        mse = st.pop("relative_mse", {})
+        st["relative_mse_max"] = max(mse.values()) if mse else None
+        extra["gptq_stats"] = st
     if awq:
         extra["awq_stats"] = dict(moa.model_calib.AWQ_LITE_STATS)
         alphas = [round(float(h.best_alpha), 1) for h in awq if h.best_alpha is not None]
