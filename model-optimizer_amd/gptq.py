@@ -230,12 +230,14 @@ def _weight_quantizers_off(model):
 
 @torch.no_grad()
 def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: int = 128, fused: bool = False,
-         shard_weights: bool | None = None):
+         shard_weights: bool | None = None, report_mse: bool = True):
     """model_calib.gptq (model_calib.py:2192-2271).  `model` is the full model, or one decoder layer when called by
     layerwise.layerwise_calibrate.  Steps: max_calibrate (amax from the current activations / weights); Hessians of
     every quantized linear's input from ONE forward loop with the weight quantizers off (the input quantizer, when
     enabled, is applied to what the Hessian sees); blockwise weight update.  `fused` (the reference's Triton kernel for
-    static NVFP4) has no meaning here: the elementwise formats are always one kernel per block."""
+    static NVFP4) has no meaning here: the elementwise formats are always one kernel per block.  `report_mse`: the
+    Hessian-weighted relative error the reference prints per linear (two fp32 GEMMs against the Hessian each -- as much
+    arithmetic as the update itself for wide linears) goes to GPTQ_STATS["relative_mse"]."""
     from . import distributed as mdist
     from . import model_calib
     from .sparsity import _combine_hessians
@@ -288,7 +290,8 @@ def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: in
             inverse_cache[key] = compute_hessian_inverse(hessian.to(weight.device), None, perc_damp, zero_cols=zero)
         info = gptq_blockwise_update(weight, inverse_cache[key], block_size, m.weight_quantizer)
         GPTQ_STATS["kernel_linears"] += int(info["kernel"])
-        GPTQ_STATS["relative_mse"][name] = relative_mse(weight, w_orig.float(), hessian.to(weight.device))
+        if report_mse:
+            GPTQ_STATS["relative_mse"][name] = relative_mse(weight, w_orig.float(), hessian.to(weight.device))
         m.weight.data = weight.reshape(m.weight.shape).to(w_orig.dtype)
         users[own] -= 1
         if users[own] == 0:

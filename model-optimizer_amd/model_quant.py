@@ -291,7 +291,7 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
 
         lw = kwargs.pop("layerwise", None) or {}
         lw = {"enable": bool(lw)} if isinstance(lw, bool) else dict(lw)
-        gk = {k: kwargs[k] for k in ("perc_damp", "block_size", "fused", "shard_weights") if kwargs.get(k) is not None}
+        gk = {k: kwargs[k] for k in ("perc_damp", "block_size", "fused", "shard_weights", "report_mse") if kwargs.get(k) is not None}
         if lw.get("enable", False):
             if lw.get("calib_mutates_weights", True) is False:
                 raise ValueError("layerwise.calib_mutates_weights=False is rejected for weight-mutating algorithms (gptq)")
