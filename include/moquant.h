@@ -430,7 +430,11 @@ int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs,
  * Column j: q_j = QDQ(w_j) -- fmt 1: INT-num_bits (tensor_quant.py:607-645), fmt 2: FP8-E4M3 (:46-59) -- with the fp32 amax
  * entry amax[r * amax_row_stride + c / g] of element (r, c) (per tensor: stride 0 and g >= ld; per output channel:
  * stride 1 and g >= ld; static blocks of g columns: stride ld / g); then every column k >= j of the block gets
- * w_k -= fl(err_j * hinv[j, k]).  bs <= 128.  The update of the columns right of the block,
+ * w_k -= fl(err_j * hinv[j, k]).  bs <= 128.
+ * fmt 3: MX dynamic blocks (fused_amax_convert, tensor_quant_mx.cu:239-294): num_bits is the element format
+ * (moq_mx_type), g the block size (a power of two <= 64 dividing i1 and bs); the E8M0 scale of the pivot's block comes from
+ * the block's CURRENT abs-max at every column (what the reference's full-matrix call computes), amax may be NULL.
+ * The update of the columns right of the block,
  * weight[:, i2:] -= errs @ hinv[i1:i2, i2:] (calib_utils.py:276), is moq_sgpt_trailing_update. */
 int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,
                          const float* amax, int64_t amax_row_stride, int64_t g, int fmt, int num_bits, int is_unsigned,

@@ -23,7 +23,7 @@ for src in "${SRCS[@]}"; do
   base=$(basename "$src")
   obj="$OBJDIR/${base%.hip}.o"
   mkdir -p "$OBJDIR"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ moq_chunk.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ moq_common.h -nt "$obj" ] || [ moq_chunk.h -nt "$obj" ] || [ moq_mx.h -nt "$obj" ] || [ ../../include/moquant.h -nt "$obj" ]; then
     echo "[moquant] hipcc $src"
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)

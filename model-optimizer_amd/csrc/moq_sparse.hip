@@ -22,6 +22,7 @@
 #include <atomic>
 
 #include "moq_common.h"
+#include "moq_mx.h"
 
 namespace moq {
 
@@ -101,7 +102,12 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
 // then subtracted, the order the oracle restates (orc_gptq_block_sweep).  amax entry of element (r, c):
 // amax[r * amax_row_stride + c / g]  (per tensor: stride 0, g >= ld; per output channel: stride 1, g >= ld; static
 // blocks of g columns: stride ld / g).
-template <int FMT>  // 1: INT-k, 2: FP8-E4M3
+// FMT 3: MX dynamic blocks (E8M0 block scale from the block's CURRENT abs-max, fused_amax_convert: tensor_quant_mx.cu:239-294).
+// Here the reference's full-matrix call matters: the scale of the pivot's block moves with the weights, columns already
+// swept included (a swept column holds w_k - err_k * hinv_kk, its quantized value up to rounding).  A block of g <= 64
+// columns is g adjacent lanes of one half of the wave's 128 columns, so the block abs-max is a butterfly over lanes per
+// pivot step; `iq.hi` carries the element format (moq_mx_type), no amax table is read.
+template <int FMT>  // 1: INT-k, 2: FP8-E4M3, 3: MX element format with E8M0 block scales
 __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
                                                             int bs, const float* __restrict__ hinv,
                                                             float* __restrict__ delta, const float* __restrict__ amax,
@@ -114,18 +120,35 @@ __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ 
   float w0 = in0 ? wr[lane] : 0.0f, w1 = in1 ? wr[lane + 64] : 0.0f;
   const float d0 = in0 ? hinv[(i1 + lane) * ld + i1 + lane] : 1.0f;
   const float d1 = in1 ? hinv[(i1 + lane + 64) * ld + i1 + lane + 64] : 1.0f;
-  const float a0 = in0 ? amax[row * amax_row_stride + (i1 + lane) / g] : 1.0f;
-  const float a1 = in1 ? amax[row * amax_row_stride + (i1 + lane + 64) / g] : 1.0f;
+  float a0 = 1.0f, a1 = 1.0f;
+  if constexpr (FMT != 3) {
+    a0 = in0 ? amax[row * amax_row_stride + (i1 + lane) / g] : 1.0f;
+    a1 = in1 ? amax[row * amax_row_stride + (i1 + lane + 64) / g] : 1.0f;
+  }
+  const MxFmt mxf = mx_fmt(FMT == 3 ? (int)iq.hi : MOQ_E2M1);
   float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
   for (int j = 0; j < bs; ++j) {
     const int src = j & 63;
     const bool hi = j >= 64;
     const float wj = __shfl(hi ? w1 : w0, src, 64);
     const float dj = __shfl(hi ? d1 : d0, src, 64);
-    const float aj = __shfl(hi ? a1 : a0, src, 64);
+    float aj;
+    if constexpr (FMT == 3) {
+      // abs-max of every block of g lanes in the pivot's half, from the current weights (|x| clamped to FLT_MAX, NaN dropped:
+      // compute_max_warp / block, cu:185-226); then the pivot's own block
+      float am = mx_abs_clamped(hi ? w1 : w0);
+      for (int o = 1; o < (int)g; o <<= 1) am = __builtin_fmaxf(am, __shfl_xor(am, o, 64));
+      aj = __shfl(am, src, 64);
+    } else {
+      aj = __shfl(hi ? a1 : a0, src, 64);
+    }
     float qj;
     if constexpr (FMT == 1) {
       qj = qdq_int(wj, int_scale(aj, iq.hi), iq);
+    } else if constexpr (FMT == 3) {
+      float sc, un;
+      mx_scale_e8m0(aj, mxf.maxv, sc, un);
+      qj = mx_qdq(wj, sc, un, mxf);
     } else {
       const Fp8Scale sc = fp8_scale(aj);
       const float t = wj * sc.s;
@@ -429,18 +452,28 @@ extern "C" int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t 
 extern "C" int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv,
                                     float* delta, const float* amax, int64_t amax_row_stride, int64_t g, int fmt,
                                     int num_bits, int is_unsigned, int narrow, void* stream) {
-  if (w == nullptr || hinv == nullptr || delta == nullptr || amax == nullptr || rows < 0 || ld <= 0 || i1 < 0 || bs <= 0 ||
-      i1 + bs > ld || amax_row_stride < 0 || g <= 0) {
+  if (w == nullptr || hinv == nullptr || delta == nullptr || (amax == nullptr && fmt != 3) || rows < 0 || ld <= 0 || i1 < 0 ||
+      bs <= 0 || i1 + bs > ld || amax_row_stride < 0 || g <= 0) {
     set_error("moq_gptq_block_sweep: bad arguments");
     return MOQ_ERR_INVALID;
   }
-  if (bs > kSgptMaxBlock || (fmt != 1 && fmt != 2) || (fmt == 1 && (num_bits < 2 || num_bits > 16))) {
-    set_error("moq_gptq_block_sweep: needs col block <= %d, fmt 1 (INT-k, 2 <= k <= 16) or 2 (FP8-E4M3)", kSgptMaxBlock);
+  if (bs > kSgptMaxBlock || fmt < 1 || fmt > 3 || (fmt == 1 && (num_bits < 2 || num_bits > 16))) {
+    set_error("moq_gptq_block_sweep: needs col block <= %d, fmt 1 (INT-k, 2 <= k <= 16), 2 (FP8-E4M3) or 3 (MX)", kSgptMaxBlock);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (fmt == 3 && (g > 64 || (g & (g - 1)) != 0 || i1 % g != 0 || bs % g != 0 || mx_fmt(num_bits).kind < 0)) {
+    set_error("moq_gptq_block_sweep: MX needs a block size that is a power of two <= 64 dividing i1 and bs, and a known element format");
     return MOQ_ERR_UNSUPPORTED;
   }
   if (rows == 0) return MOQ_OK;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(kBlock);
-  const IntQ iq = make_intq(fmt == 1 ? num_bits : 8, is_unsigned, narrow);
+  IntQ iq = make_intq(fmt == 1 ? num_bits : 8, is_unsigned, narrow);
+  if (fmt == 3) {
+    iq.hi = (float)num_bits;  // the element format code rides in the clamp slot (unused by this format)
+    hipLaunchKernelGGL((gptq_sweep_kernel<3>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
+                       amax_row_stride, g, iq);
+    return check_launch("moq_gptq_block_sweep");
+  }
   if (fmt == 1)
     hipLaunchKernelGGL((gptq_sweep_kernel<1>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
                        amax_row_stride, g, iq);

@@ -12,8 +12,11 @@ What is MI355X-native here:
   * Column sweep: the reference fake-quantizes the WHOLE weight matrix once per column and keeps one column of it.
     With a calibrated amax the quantizer is elementwise, so the sweep over a block is one kernel
     (ops.gptq_block_sweep: a wave per row, the block's columns in registers); the update of the columns right of the
-    block is ops.sgpt_trailing_update (fp32 matrix cores, defined summation order).  Quantizers whose scale depends on
-    the current weights (dynamic block formats) take the reference's own loop through the quantizer.
+    block is ops.sgpt_trailing_update (fp32 matrix cores, defined summation order).  MX formats (dynamic blocks with
+    E8M0 scales: MXFP4, MXFP8 -- the 4-bit format MI355X multiplies natively) are NOT elementwise: the scale of a block
+    follows the weights as they are updated, which is what the reference's full-matrix call is for; the same kernel
+    recomputes the pivot block's abs-max from the block's lanes at every column.  Other dynamic block formats (two-level
+    scales) take the reference's own loop through the quantizer.
   * Data-parallel replicas (distributed.declare_data_parallel): Hessians are combined sample-weighted on one owner
     rank each, the owner updates the linears that read them and broadcasts the weights -- every replica ends with the
     same model (the reference leaves ranks to diverge).
@@ -100,7 +103,20 @@ def _static_layout(q, weight: torch.Tensor):
     else None (the quantizer's own forward is used column by column, like the reference)."""
     if not isinstance(q, TensorQuantizer) or weight.dim() != 2:
         return None
-    if q._disabled or not q.fake_quant or q._dynamic or q._block_dynamic or q.pre_quant_scale is not None:
+    if q._disabled or not q.fake_quant or q._dynamic or q.pre_quant_scale is not None:
+        return None
+    if q.is_mx_format:
+        # dynamic blocks with E8M0 scales (MXFP4 / MXFP8 / ...): the block scale follows the CURRENT weights, which the
+        # sweep kernel recomputes per column from the block's lanes (fmt 3); blocks along the last dim only
+        nb = q._num_bits if not isinstance(q._num_bits, list) else tuple(q._num_bits)
+        fmt = {(2, 1): "E2M1", (4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3", 8: "INT8"}.get(nb)
+        bsz = q._block_sizes
+        g = bsz.get(-1, None) or bsz.get(1, None)
+        if (fmt is None or not g or set(bsz) - {-1, 1, "type", "scale_bits"} or g > 64 or g & (g - 1)
+                or weight.shape[1] % g):
+            return None
+        return 3, fmt, False, False, None, 0, int(g)
+    if q._block_dynamic:
         return None
     amax = getattr(q, "_amax", None)
     if amax is None:
@@ -138,7 +154,9 @@ def gptq_blockwise_update(weight: torch.Tensor, h_inv: torch.Tensor, block_size:
     """calib_utils.py:241-276 on the fp32 working copy `weight` [Cout, Cin], in place.  Returns {"kernel": bool}."""
     num_cols = weight.shape[1]
     layout = _static_layout(quantize_fn, weight)
-    if layout is not None and block_size <= 128 and weight.dtype == torch.float32 and weight.is_contiguous():
+    if (layout is not None and layout[0] == 3 and block_size % layout[6]) or (layout is not None and block_size > 128):
+        layout = None  # (an MX block must not straddle two column blocks of the update)
+    if layout is not None and weight.dtype == torch.float32 and weight.is_contiguous():
         fmt, bits, unsigned, narrow, am, stride, g = layout
         h_inv = h_inv.float().contiguous()
         for i1 in range(0, num_cols, block_size):

@@ -1129,15 +1129,21 @@ def gptq_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, amax
     """In-place column sweep of gptq_blockwise_update over block [i1, i1 + bs) (utils/calib_utils.py:241-276) for a
     quantizer with a calibrated amax: the block's columns become their quantized-dequantized values, the errors
     err_j = (w_j - q_j) / hinv_jj are returned [rows, bs].  fmt 1: INT-num_bits, 2: FP8-E4M3; amax: fp32, entry
-    amax[r * amax_row_stride + c / g] for element (r, c)."""
+    amax[r * amax_row_stride + c / g] for element (r, c).  fmt 3: MX blocks of g columns with E8M0 scales taken from the
+    block's current abs-max at every column (dynamic block quantization); num_bits is the element format (name or
+    moq_mx_type code), amax is not used."""
     _require_gpu(w, "gptq_block_sweep")
     if w.dtype != torch.float32 or hinv.dtype != torch.float32 or not w.is_contiguous() or not hinv.is_contiguous():
         raise MoquantError("gptq_block_sweep: contiguous fp32 tensors expected")
     rows, ld = w.shape
-    am = _f32(amax, w.device).reshape(-1)
-    need = (rows - 1) * int(amax_row_stride) + (ld - 1) // int(g) + 1 if rows else 0
-    if am.numel() < need:
-        raise MoquantError(f"gptq_block_sweep: {am.numel()} amax entries, the layout needs {need}")
+    if int(fmt) == 3:
+        am = None
+        num_bits = _lib.MX_TYPES[num_bits] if isinstance(num_bits, str) else int(num_bits)
+    else:
+        am = _f32(amax, w.device).reshape(-1)
+        need = (rows - 1) * int(amax_row_stride) + (ld - 1) // int(g) + 1 if rows else 0
+        if am.numel() < need:
+            raise MoquantError(f"gptq_block_sweep: {am.numel()} amax entries, the layout needs {need}")
     delta = torch.empty(rows, bs, dtype=torch.float32, device=w.device)
     with _on(w) as stream:
         check(_lib.lib().moq_gptq_block_sweep(_p(w), rows, ld, int(i1), int(bs), _p(hinv), _p(delta), _p(am),

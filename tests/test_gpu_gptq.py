@@ -64,6 +64,67 @@ def test_gptq_block_sweep_equals_the_oracle(fmt, bits, layout, rows, cols, bs):
             assert_bits_equal(wg, wo, f"weights after the trailing update of block {i1}")
 
 
+@pytest.mark.parametrize("elem,g", [("E2M1", 32), ("E2M1", 16), ("E4M3", 32), ("E2M3", 64), ("INT8", 8)])
+@pytest.mark.parametrize("rows,cols,bs", [(37, 256, 128), (64, 192, 64), (130, 320, 64)])
+def test_gptq_block_sweep_mx_equals_the_oracle(elem, g, rows, cols, bs):
+    """fmt 3: MX blocks whose E8M0 scale is recomputed from the block's current values at every column -- kernel and oracle
+    from the same state, bit for bit; an all-zero block (scale 1), an inf (abs-max clamps to FLT_MAX) and a NaN among the
+    values."""
+    gen = torch.Generator().manual_seed(rows + cols + g)
+    w = (torch.randn(rows, cols, generator=gen) * torch.exp(torch.randn(rows, 1, generator=gen))).float()
+    w[1, :g] = 0
+    w[2, 5] = float("inf")
+    w[3, 70] = float("nan")
+    hinv = _factor(cols, 11 + cols)
+    wg, wo, hg = w.clone().to(DEV), w.clone(), hinv.to(DEV)
+    for i1 in range(0, cols, bs):
+        b = min(bs, cols - i1)
+        dg = ops.gptq_block_sweep(wg, i1, b, hg, None, 0, g, 3, elem)
+        do = oracle.gptq_block_sweep(wo, i1, b, hinv, None, 0, g, 3, elem)
+        assert_bits_equal(dg, do, f"errors of block {i1}")
+        assert_bits_equal(wg[:, i1:i1 + b], wo[:, i1:i1 + b], f"quantized columns of block {i1}")
+        if i1 + b < cols:
+            ops.sgpt_trailing_update(wg, i1, dg, hg)
+            oracle.sgpt_trailing_update(wo, i1, do, hinv)
+
+
+def test_mxfp4_gptq_flow_and_the_loop_through_the_quantizer_agree():
+    """MXFP4 (E2M1, blocks of 32, E8M0 scales) weights through gptq(): the kernel path against the reference's column loop
+    through the quantizer's own forward on the GPU, and against round-to-nearest on held-out inputs."""
+    import model_optimizer_amd.gptq as G
+
+    torch.manual_seed(9)
+    d = 512
+    lin = torch.nn.Linear(d, 384, bias=False).to(torch.bfloat16).to(DEV)
+    mix = torch.randn(d, d, device=DEV) / d ** 0.5 * torch.linspace(3.0, 0.05, d, device=DEV)[:, None]
+    batches = [(torch.randn(2, 256, d, device=DEV) @ mix).to(torch.bfloat16) for _ in range(4)]
+    held = (torch.randn(512, d, device=DEV) @ mix).to(torch.bfloat16)
+    cfg = copy.deepcopy(moa.model_quant.MXFP4_DEFAULT_CFG)
+    cfg["quant_cfg"]["*input_quantizer"] = {"enable": False}
+    with torch.no_grad():
+        ref = lin(held).float()
+    rtn = moa.quantize(torch.nn.Sequential(copy.deepcopy(lin)), copy.deepcopy(cfg), lambda m: [m(b) for b in batches])
+    holder = torch.nn.Sequential(copy.deepcopy(lin))
+    cfg_g = copy.deepcopy(cfg)
+    cfg_g["algorithm"] = {"method": "gptq"}
+    moa.quantize(holder, cfg_g, lambda m: [m(b) for b in batches])
+    assert G.GPTQ_STATS["kernel_linears"] == 1
+    w_kernel = holder[0].weight.data.float().clone()
+    holder2 = torch.nn.Sequential(copy.deepcopy(lin))
+    orig, G._static_layout = G._static_layout, (lambda q_, w_: None)
+    try:
+        moa.quantize(holder2, copy.deepcopy(cfg_g), lambda m: [m(b) for b in batches])
+        assert G.GPTQ_STATS["kernel_linears"] == 0
+    finally:
+        G._static_layout = orig
+    same = (w_kernel == holder2[0].weight.data.float()).float().mean().item()
+    assert same >= 0.99, f"kernel path vs the loop through the quantizer: {same:.4f} identical"
+    with torch.no_grad():
+        e_rtn = float((rtn(held).float() - ref).pow(2).mean())
+        e_gptq = float((holder(held).float() - ref).pow(2).mean())
+    assert e_gptq < 0.8 * e_rtn, (e_gptq, e_rtn)
+
+
 @pytest.mark.parametrize("name", ["int4_g128_bf16", "int4_g32_f32", "fp8_bf16", "int8_pc_f32"])
 def test_blockwise_update_equals_the_reference_run(golden, name):
     """gptq_blockwise_update on the GPU from the reference's inverse factor: the updated weight is the reference's."""
