@@ -853,6 +853,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
     clock["dev"] = mods[0][1].weight.device if mods else None
     stage(None)
     helpers = {m: AWQLiteHelper(m, alpha_step) for _, m in mods}
+    stage("weight_scales")  # (helper construction: one moq_awq_weight_scale launch and four small buffers per linear)
     for _, m in mods:
         # quantized inputs (W4A8 AWQ; setup, :1436-1444): the input quantizer is bypassed for the whole search -- the
         # losses are taken on UNquantized activations -- and max-calibrated per input channel in the cache pass; the
@@ -883,6 +884,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             else:
                 h._cache_w = budget.reserve(len(h.alphas) * m.weight.numel() * m.weight.element_size())
 
+    stage("gram_buffers")  # (device-memory query of the budget + one zeroed [Cin, Cin] fp32 matrix per Gram-scored linear)
     searched = {id(q) for _, m in mods for q in (m.weight_quantizer, m.input_quantizer)}
     others = [q for q in _quantizers(model) if id(q) not in searched and q.is_enabled]
     others_holder = nn.ModuleList(others)
