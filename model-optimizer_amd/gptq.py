@@ -42,7 +42,29 @@ class TokenHessian(HessianState):
     """update_hessian (calib_utils.py:50-77): the running mean counts TOKENS (rows of the flattened input), where
     SparseGPT's hook counts batches: H <- H * n / (n + b) + (2 / (n + b)) X^T X.  (The reference scales the inputs by
     sqrt(2 / n) before the product; the scale is applied to the fp32 accumulators here -- the same sum up to rounding,
-    and a GEMM's summation order is the library's in the reference anyway.)"""
+    and a GEMM's summation order is the library's in the reference anyway.)
+    The [Cin, Cin] matrix is allocated by the first update: linears that share another one's Hessian never own one
+    (Llama-3-70B: 2.1 GB per layer instead of 4.1)."""
+
+    def __init__(self, cols: int, device):
+        self._cols, self._device = cols, device
+        self._h = None
+        self._upper = False
+        self.samples = 0
+
+    @property
+    def shape(self):
+        return (self._cols, self._cols)
+
+    def _ensure(self):
+        if self._h is None:
+            try:
+                self._h = torch.zeros(self._cols, self._cols, dtype=torch.float32, device=self._device)
+            except torch.cuda.OutOfMemoryError as e:
+                raise torch.cuda.OutOfMemoryError(
+                    f"gptq: no room for a {self._cols} x {self._cols} fp32 Hessian -- the Hessians of ALL linears are alive "
+                    "in a whole-model pass; use algorithm {'method': 'gptq', 'layerwise': {'enable': True}} (one decoder "
+                    "layer's Hessians at a time)") from e
 
     @torch.no_grad()
     def update(self, inp: torch.Tensor):
@@ -50,6 +72,7 @@ class TokenHessian(HessianState):
         b = x2.shape[0]
         if b == 0:  # in MoEs some experts receive no tokens
             return
+        self._ensure()
         decay = self.samples / (self.samples + b)
         self.samples += b
         scale = 2.0 / self.samples
@@ -63,8 +86,8 @@ class TokenHessian(HessianState):
 
 def update_hessian(input: torch.Tensor, hessian: torch.Tensor, n_samples: int):
     """Functional form of calib_utils.update_hessian: returns (hessian, n_samples); `hessian` is updated in place."""
-    st = TokenHessian.__new__(TokenHessian)
-    st._h, st._upper, st.samples = hessian, False, int(n_samples)
+    st = TokenHessian(hessian.shape[0], hessian.device)
+    st._h, st.samples = hessian, int(n_samples)
     st.update(input)
     return st.hessian, st.samples
 
@@ -216,7 +239,7 @@ class GPTQHelper:
             else:
                 h_in, key = x, x
             first = shared.get("input") is key and key is not None
-            if first and shared["owner"].state._h.shape == helper.state._h.shape and helper.owner in (helper, shared["owner"]):
+            if first and shared["owner"].state.shape == helper.state.shape and helper.owner in (helper, shared["owner"]):
                 helper.owner = shared["owner"]
                 return
             if helper.owner is not helper:
@@ -285,6 +308,9 @@ def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: in
     shard = mdist.resolve_shard(shard_weights)
     placed = None
     mods = [m for _, m in layers]
+    for h in helpers.values():
+        if h.owner is h:
+            h.state._ensure()  # (a linear the forward loop never reached -- or a rank without batches -- has a zero Hessian)
     if shard:
         owner_of = {m: helpers[m].owner.module for m in mods if helpers[m].owner is not helpers[m]}
         placed = _combine_hessians(mods, {m: helpers[m].owner.state for m in mods}, owner_of)

@@ -419,7 +419,7 @@ def test_data_parallel_flow_equals_single_rank(kind):
     assert dict(ret) == {r: "ok" for r in range(world)}, "\n".join(f"rank {r}: {v}" for r, v in dict(ret).items())
 
 
-@pytest.mark.parametrize("kind", ["weight_side", "awq", "max_and_smoothquant"])
+@pytest.mark.parametrize("kind", ["weight_side", "awq", "max_and_smoothquant", "gptq"])
 def test_three_replicas_uneven_shards(kind):
     """world = 3 over a model with fewer linears than that: some rank owns no weight of a given pass (empty shard, nothing to
     broadcast), the calibration batches split unevenly -- results still equal the single-rank run."""
