@@ -68,6 +68,12 @@ def flows(moa):
     out["mask.magnitude"] = {n: mod._weight_mask.clone() for n, mod in m.named_modules() if hasattr(mod, "_weight_mask")}
     m = sp.sparsify(MLP(dtype=dt).to(DEV), "sparsegpt", forward_loop=loop)
     out["mask.sparsegpt"] = {n: mod._weight_mask.clone() for n, mod in m.named_modules() if hasattr(mod, "_weight_mask")}
+    # GPTQ: Hessians combined on their owner, updated weights broadcast
+    cfg = copy.deepcopy(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG)
+    cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+    cfg["algorithm"] = {"method": "gptq", "block_size": 64}
+    m = moa.quantize(MLP(dtype=dt).to(DEV), cfg, loop)
+    out["gptq.w"] = {n: p.detach().clone() for n, p in m.named_parameters()}
     return out
 
 
