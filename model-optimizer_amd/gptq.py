@@ -327,7 +327,7 @@ def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: in
             continue
         hessian = own.state.hessian
         w_orig = m.weight.data
-        weight = w_orig.float().clone()
+        weight = w_orig.to(torch.float32, copy=True)
         zero = dead_columns(weight)
         key = (own, bytes(zero.cpu().numpy().tobytes()) if bool(zero.any()) else b"")
         if key not in inverse_cache:
@@ -336,7 +336,7 @@ def gptq(model: nn.Module, forward_loop, perc_damp: float = 0.01, block_size: in
         GPTQ_STATS["kernel_linears"] += int(info["kernel"])
         if report_mse:
             GPTQ_STATS["relative_mse"][name] = relative_mse(weight, w_orig.float(), hessian.to(weight.device))
-        m.weight.data = weight.reshape(m.weight.shape).to(w_orig.dtype)
+        w_orig.copy_(weight.reshape(w_orig.shape))  # in place (the reference rebinds `.data`): views and tables of the weight stay valid
         users[own] -= 1
         if users[own] == 0:
             own.free()
