@@ -253,15 +253,22 @@ def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
                   shared_states=None):
     """model_calib.py:732-826 (multiplier search, fp8_scale_sweep=False): max calibration first, then every
     eligible weight quantizer's amax is refined by the MSE sweep -- here one fused kernel per weight."""
-    from functools import partial
-
-    from .calib import MseCalibrator
-
     if fp8_scale_sweep or shared_states:
         # the FP8-scale sweep of NVFP4 static block scales and shared quantizer state (model_calib.py:740-741, :770-826)
         # belong to formats outside this path; the reference's defaults (False / None) are accepted
         raise MoquantUnsupported("mse_calibrate: fp8_scale_sweep / shared_states are outside this path")
     max_calibrate(model, forward_loop, distributed_sync)
+    _mse_calibrate_weights(model, step_size, start_multiplier, stop_multiplier)
+
+
+def _mse_calibrate_weights(model: nn.Module, step_size: float, start_multiplier: float, stop_multiplier: float,
+                           error_func_for=None):
+    """_mse_calibrate_weights (model_calib.py:780-826): the weight search of mse_calibrate / local_hessian_calibrate.
+    `error_func_for(weight_quantizer)` -> error function or None (plain squared error: the fused one-kernel sweep)."""
+    from functools import partial
+
+    from .calib import MseCalibrator
+
     for m in model.modules():
         if not is_quantized_linear(m):
             continue
@@ -271,9 +278,11 @@ def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
             continue  # _make_weight_mse_calibrator's eligibility test (model_calib.py:681-689)
         nb = wq._num_bits
         fused = (nb, wq._unsigned, wq._narrow_range) if isinstance(nb, int) or tuple(nb) == (4, 3) else None
+        error_func = error_func_for(wq) if error_func_for is not None else None
         cal = MseCalibrator(amax=wq._amax.clone().detach(), axis=wq._calibrator._axis, step_size=step_size,
                             start_multiplier=start_multiplier, stop_multiplier=stop_multiplier,
-                            quant_func=partial(_mse_quant_func, quantizer=wq), fused_format=fused)
+                            quant_func=partial(_mse_quant_func, quantizer=wq), error_func=error_func,
+                            fused_format=fused if error_func is None else None)
         wq._calibrator = cal
         wq.disable_quant()
         wq.enable_calib()
@@ -282,6 +291,138 @@ def mse_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
         wq.enable_quant()
         wq.disable_calib()
         cal.reset()
+
+
+# ------------------------------------------------------------------------------------------------ local Hessian
+class _LocalHessianAccumulator:
+    """Per-block local Hessian H = sum X^T X of one weight's input (model_calib.py:829-899): Cin is cut into blocks of
+    `block_size` columns, every block keeps its own [bs, bs] matrix -- the metric (W - Wq)^T H (W - Wq) of a block of
+    the weight approximates that block's share of the output error.  Linears fed by the same tensor share one."""
+
+    def __init__(self, cout: int, cin: int, block_size: int):
+        self.cout, self.cin, self.block_size = cout, cin, block_size
+        self.num_blocks_per_cin = cin // block_size
+        self.is_enabled = cin % block_size == 0  # not block-divisible: no Hessian, plain MSE
+        self.hessian_per_block = None
+        self._normalized = None
+        self.num_samples = 0
+
+    @torch.no_grad()
+    def accumulate(self, input_tensor: torch.Tensor):
+        if not self.is_enabled:
+            return
+        # (cin, tokens) -> (n_blocks, bs, tokens), fp32 like the reference; one batched GEMM of tiny blocks per call
+        x = input_tensor.reshape(-1, self.cin).to(torch.float32).T
+        x = x.reshape(self.num_blocks_per_cin, self.block_size, -1)
+        batch = x @ x.transpose(-1, -2)
+        self.hessian_per_block = batch if self.hessian_per_block is None else self.hessian_per_block.add_(batch)
+        self.num_samples += input_tensor.numel() // self.cin
+
+    def normalized_hessian(self):
+        if self._normalized is None and self.hessian_per_block is not None and self.num_samples:
+            self._normalized = self.hessian_per_block / self.num_samples
+        return self._normalized
+
+    def build_error_func(self, cout: int, keep_buffer: bool = False):
+        hessian = self.normalized_hessian()
+        if hessian is None:
+            return None
+        bs = self.block_size
+        if not keep_buffer:
+            self.hessian_per_block = None
+
+        def local_hessian_error(x: torch.Tensor, xq: torch.Tensor) -> torch.Tensor:
+            shape = x.shape
+            dw = (x - xq).view(cout, -1, bs)  # dw (cout, n, bs) . H (n, bs, bs) -> (cout, n)
+            block_loss = torch.einsum("cnb,nbd,cnd->cn", dw, hessian, dw).reshape(-1)
+            return block_loss.unsqueeze(-1).expand(-1, bs).reshape(shape)
+
+        return local_hessian_error
+
+
+@torch.no_grad()
+def local_hessian_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, step_size: float = 0.1,
+                            start_multiplier: float = 0.25, stop_multiplier: float = 4.0, fp8_scale_sweep: bool = True,
+                            block_size: int = 16, debug: bool = False, shared_states=None):
+    """model_calib.local_hessian_calibrate (model_calib.py:1005-1127): the amax search of mse_calibrate with the
+    Hessian-weighted error (W - Wq)^T H (W - Wq), H = per-block sum X^T X of the linear's input taken in a forward with
+    the weight quantizers off.  Phases as in the reference: max calibration; Hessians; weight search.
+    `fp8_scale_sweep` (the reference's default True) selects its FP8-scale sweep, which exists for static NVFP4
+    quantizers only -- every other quantizer is then left at its max-calibrated amax, as in the reference
+    (_make_weight_mse_calibrator, :695-718); pass False for the multiplier search over the quantizers of this path.
+    The Hessians are not combined across ranks (the reference warns the same)."""
+    if forward_loop is None:
+        warnings.warn("forward_loop must be provided for local_hessian; skipping local_hessian")
+        return
+    if shared_states:
+        raise MoquantUnsupported("local_hessian_calibrate: shared_states are outside this path")
+    max_calibrate(model, forward_loop, distributed_sync)
+    linears = [(n, m) for n, m in model.named_modules() if is_quantized_linear(m) and isinstance(m.weight_quantizer, TensorQuantizer)
+               and m.weight_quantizer.is_enabled and m.weight.dim() == 2]
+    accumulators: dict = {}
+    followers: set = set()
+    shared = {"input": None, "acc": None}
+    for n, m in linears:
+        cin = m.weight.shape[1]
+        if cin % block_size:
+            warnings.warn(f"local_hessian: {n} input features ({cin}) not divisible by block_size ({block_size}); "
+                          "falling back to plain MSE for these weights.")
+        qb = (m.weight_quantizer.block_sizes or {}).get(-1)
+        if qb is not None and qb != block_size:
+            warnings.warn(f"local_hessian: block_size ({block_size}) != quantizer scale block ({qb}) for {n}; Hessian "
+                          "weighting will not align with the scale blocks.")
+
+    def hook(mod, args):
+        if not args:
+            return
+        x = args[0]
+        x = x.to_local() if hasattr(x, "to_local") else x
+        wq = mod.weight_quantizer
+        acc = accumulators.get(id(wq))
+        if acc is None:
+            # q / k / v and gate / up read one tensor: the per-block Hessian depends on the input and the block size only
+            if shared["input"] is x and shared["acc"].cin == mod.weight.shape[1]:
+                accumulators[id(wq)] = shared["acc"]
+                followers.add(id(wq))
+                return
+            acc = accumulators[id(wq)] = _LocalHessianAccumulator(mod.weight.shape[0], mod.weight.shape[1], block_size)
+        elif id(wq) in followers:
+            if not (shared["input"] is x and shared["acc"] is acc):
+                raise RuntimeError("local_hessian: a linear that shared its input with another one in an earlier batch got "
+                                   "a different tensor now")
+            return  # (this batch is already in the shared accumulator)
+        acc.accumulate(x)
+        shared["input"], shared["acc"] = x, acc
+
+    handles = [m.register_forward_pre_hook(hook) for _, m in linears]
+    qs = [m.weight_quantizer for _, m in linears]
+    saved = [q._disabled for q in qs]
+    for q in qs:
+        q._disabled = True
+    try:
+        forward_loop(model)
+    finally:
+        for q, d in zip(qs, saved):
+            q._disabled = d
+        for h in handles:
+            h.remove()
+        shared["input"] = shared["acc"] = None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        warnings.warn("local_hessian: Hessian is not synced across ranks; refined weight amaxes may diverge under "
+                      "tensor/data parallelism. Treat local_hessian as single-rank for now.")
+    if fp8_scale_sweep:
+        warnings.warn("local_hessian: fp8_scale_sweep=True searches static NVFP4 quantizers only (none on this path): "
+                      "every weight keeps its max-calibrated amax; pass fp8_scale_sweep=False for the multiplier search.")
+        accumulators.clear()
+        return
+    cout_of = {id(m.weight_quantizer): m.weight.shape[0] for _, m in linears}
+    funcs = {qid: acc.build_error_func(cout_of[qid], keep_buffer=debug) for qid, acc in accumulators.items()}
+    _mse_calibrate_weights(model, step_size, start_multiplier, stop_multiplier, error_func_for=lambda q: funcs.get(id(q)))
+    funcs.clear()
+    if debug:
+        model._local_hessian_accumulators = accumulators
+    else:
+        accumulators.clear()
 
 
 # ------------------------------------------------------------------------------------------------ smoothquant

@@ -278,6 +278,8 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
                                   shard_weights=kwargs.get("shard_weights"))
     elif method == "mse":
         model_calib.mse_calibrate(model, forward_loop, **kwargs)
+    elif method == "local_hessian":
+        model_calib.local_hessian_calibrate(model, forward_loop, **kwargs)
     elif method == "smoothquant":
         model_calib.smoothquant(model, forward_loop, **kwargs)
     elif method in ("awq_lite", "awq_clip", "awq_full"):

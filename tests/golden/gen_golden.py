@@ -22,6 +22,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   block2d.npz   -- TensorQuantizer with blocks on both axes (FP8 128x128, INT8 64x32): amax + fake-quant output
   sgpt.npz      -- SparseGPT: hook-accumulated Hessian, prepared inverse factor, create_sgpt_mask result
   gptq.npz      -- GPTQ: Hessian, inverse factor and updated weights of one linear per format; mtq.quantize(gptq) on the tiny MLP
+  local_hessian.npz -- the local-Hessian amax search (INT4 blocks of 16) on the tiny MLP: amax after max / mse / local_hessian
   gptq_llama.npz -- mtq.quantize(algorithm = gptq) on a tiny Llama in one pass (updated weights, logits)
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
@@ -660,6 +661,38 @@ def gen_gptq_llama(out):
         with torch.no_grad():
             out[f"{run}/logits"] = bits(q(batches[0]).logits)
         cases["runs"][run] = names
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_local_hessian(out):
+    """mtq.quantize(tiny MLP, INT4 blocks of 16, algorithm = local_hessian with the multiplier search) -- the refined amax of
+    both linears, next to the max-calibrated one and to what plain `mse` picks (model_calib.py:1005-1127)."""
+    import copy
+
+    import modelopt.torch.quantization as mtq
+
+    cases = {}
+    for name, dt in (("lh_f32", torch.float32), ("lh_bf16", torch.bfloat16)):
+        model = _TinyMLP(dtype=dt, seed=41)
+        batches = _calib_batches(128, dt, 42)
+        out[f"{name}_w1"], out[f"{name}_w2"], out[f"{name}_b2"] = bits(model.fc1.weight), bits(model.fc2.weight), bits(model.fc2.bias)
+        for i, b in enumerate(batches):
+            out[f"{name}_x{i}"] = bits(b)
+        for alg_name, alg in (("max", "max"), ("mse", {"method": "mse"}),
+                              ("local_hessian", {"method": "local_hessian", "fp8_scale_sweep": False, "block_size": 16})):
+            cfg = copy.deepcopy(mtq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG)
+            for entry in (cfg["quant_cfg"] if isinstance(cfg["quant_cfg"], list) else []):
+                if isinstance(entry, dict) and isinstance(entry.get("cfg"), dict) and "block_sizes" in entry["cfg"]:
+                    entry["cfg"]["block_sizes"] = {-1: 16}
+            if isinstance(cfg["quant_cfg"], dict):
+                for v in cfg["quant_cfg"].values():
+                    if isinstance(v, dict) and "block_sizes" in v:
+                        v["block_sizes"] = {-1: 16}
+            cfg["algorithm"] = alg
+            q = mtq.quantize(copy.deepcopy(model), cfg, lambda m: [m(b) for b in batches])
+            for lname in ("fc1", "fc2"):
+                out[f"{name}_{alg_name}_{lname}_amax"] = bits(getattr(q, lname).weight_quantizer._amax.float())
+        cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches))
     out["cases"] = np.array(json.dumps(cases))
 
 
@@ -1368,12 +1401,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)

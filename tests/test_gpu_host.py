@@ -417,3 +417,37 @@ def test_percentile_search_on_the_device_is_numpy_bit_for_bit():
             want = np.array([np.searchsorted(cdf[r], q) for r in range(rows)])
             got = ops.hist_percentile_index(torch.from_numpy(h).to(DEV), q).cpu().numpy()
             assert np.array_equal(got, want), (rows, bins, dtype, pct, np.flatnonzero(got != want)[:5])
+
+
+@pytest.mark.parametrize("name", ["lh_f32", "lh_bf16"])
+def test_local_hessian_calibrate_on_the_gpu_equals_the_reference_run(golden, name):
+    """local_hessian_calibrate (model_calib.py:1005-1127): per-block input Hessians from a forward with the weight quantizers
+    off, then the amax multiplier search with the Hessian-weighted error -- the refined amax against the reference run."""
+    g = golden("local_hessian")
+    dt = {"float32": torch.float32, "bfloat16": torch.bfloat16}[g.cases[name]["dtype"]]
+
+    class TinyMLP(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(128, 128, bias=False)
+            self.fc2 = torch.nn.Linear(128, 128, bias=True)
+
+        def forward(self, x):
+            return self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    model = TinyMLP().to(dt)
+    model.fc1.weight.data.copy_(g.t(f"{name}_w1", dt))
+    model.fc2.weight.data.copy_(g.t(f"{name}_w2", dt))
+    model.fc2.bias.data.copy_(g.t(f"{name}_b2", dt))
+    model = model.to(DEV)
+    batches = [g.t(f"{name}_x{i}", dt).to(DEV) for i in range(g.cases[name]["n_batches"])]
+    cfg = copy.deepcopy(model_quant.INT4_BLOCKWISE_WEIGHT_ONLY_CFG)
+    cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 16, "type": "static"}, "enable": True}
+    cfg["algorithm"] = {"method": "local_hessian", "fp8_scale_sweep": False, "block_size": 16}
+    model_quant.quantize(model, cfg, lambda m: [m(b) for b in batches])
+    for lname in ("fc1", "fc2"):
+        got = getattr(model, lname).weight_quantizer._amax.float().reshape(-1).cpu()
+        want = g.t(f"{name}_local_hessian_{lname}_amax").reshape(-1)
+        same = (got == want).float().mean().item()
+        assert same >= 0.97, f"{lname}: {same:.4f} of the amax entries equal the reference's"
+
