@@ -120,7 +120,7 @@ def pmc_traffic(workload, model, n_layers):
     if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
     path = None
-    for tag in ("r04", "r03", "r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
+    for tag in ("r05", "r04", "r03", "r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
         cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc.json")
         if os.path.exists(cand):
             path = cand
