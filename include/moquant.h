@@ -434,6 +434,9 @@ int moq_sgpt_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs,
  * fmt 3: MX dynamic blocks (fused_amax_convert, tensor_quant_mx.cu:239-294): num_bits is the element format
  * (moq_mx_type), g the block size (a power of two <= 64 dividing i1 and bs); the E8M0 scale of the pivot's block comes from
  * the block's CURRENT abs-max at every column (what the reference's full-matrix call computes), amax may be NULL.
+ * fmt 4: the same with block scales in an element format relative to a calibrated tensor-wide amax (NVFP4-style two-level
+ * scales, compute_scale_with_global: tensor_quant_mx.cu:139-183): num_bits = element format, is_unsigned = SCALE format
+ * (moq_mx_type both), amax[0] = the tensor-wide amax.
  * The update of the columns right of the block,
  * weight[:, i2:] -= errs @ hinv[i1:i2, i2:] (calib_utils.py:276), is moq_sgpt_trailing_update. */
 int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t i1, int bs, const float* hinv, float* delta,

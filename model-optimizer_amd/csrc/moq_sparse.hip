@@ -107,7 +107,10 @@ __global__ __launch_bounds__(kBlock) void sgpt_sweep_kernel(float* __restrict__ 
 // swept included (a swept column holds w_k - err_k * hinv_kk, its quantized value up to rounding).  A block of g <= 64
 // columns is g adjacent lanes of one half of the wave's 128 columns, so the block abs-max is a butterfly over lanes per
 // pivot step; `iq.hi` carries the element format (moq_mx_type), no amax table is read.
-template <int FMT>  // 1: INT-k, 2: FP8-E4M3, 3: MX element format with E8M0 block scales
+// FMT 4: the same with the block scale in an element format (E4M3: the NVFP4-style two-level scale) relative to the calibrated
+// tensor-wide amax amax[0] (compute_scale_with_global, cu:139-183; the fp64 steps of mx_scale_general once per pivot step);
+// `iq.lo` carries the scale format.
+template <int FMT>  // 1: INT-k, 2: FP8-E4M3, 3: MX element format with E8M0 block scales, 4: element-format block scales
 __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ w, int64_t rows, int64_t ld, int64_t i1,
                                                             int bs, const float* __restrict__ hinv,
                                                             float* __restrict__ delta, const float* __restrict__ amax,
@@ -121,11 +124,12 @@ __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ 
   const float d0 = in0 ? hinv[(i1 + lane) * ld + i1 + lane] : 1.0f;
   const float d1 = in1 ? hinv[(i1 + lane + 64) * ld + i1 + lane + 64] : 1.0f;
   float a0 = 1.0f, a1 = 1.0f;
-  if constexpr (FMT != 3) {
+  if constexpr (FMT == 1 || FMT == 2) {
     a0 = in0 ? amax[row * amax_row_stride + (i1 + lane) / g] : 1.0f;
     a1 = in1 ? amax[row * amax_row_stride + (i1 + lane + 64) / g] : 1.0f;
   }
-  const MxFmt mxf = mx_fmt(FMT == 3 ? (int)iq.hi : MOQ_E2M1);
+  const MxFmt mxf = mx_fmt(FMT >= 3 ? (int)iq.hi : MOQ_E2M1);
+  const MxFmt mxsf = mx_fmt(FMT == 4 ? (int)iq.lo : MOQ_E4M3);
   float q0 = 0.0f, q1 = 0.0f, e0 = 0.0f, e1 = 0.0f;
   for (int j = 0; j < bs; ++j) {
     const int src = j & 63;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ 
     const float wj = __shfl(hi ? w1 : w0, src, 64);
     const float dj = __shfl(hi ? d1 : d0, src, 64);
     float aj;
-    if constexpr (FMT == 3) {
+    if constexpr (FMT >= 3) {
       // abs-max of every block of g lanes in the pivot's half, from the current weights (|x| clamped to FLT_MAX, NaN dropped:
       // compute_max_warp / block, cu:185-226); then the pivot's own block
       float am = mx_abs_clamped(hi ? w1 : w0);
@@ -148,6 +152,10 @@ __global__ __launch_bounds__(kBlock) void gptq_sweep_kernel(float* __restrict__ 
     } else if constexpr (FMT == 3) {
       float sc, un;
       mx_scale_e8m0(aj, mxf.maxv, sc, un);
+      qj = mx_qdq(wj, sc, un, mxf);
+    } else if constexpr (FMT == 4) {
+      float sc, un;
+      mx_scale_general(aj, mxf.maxv, mxsf, amax, sc, un);
       qj = mx_qdq(wj, sc, un, mxf);
     } else {
       const Fp8Scale sc = fp8_scale(aj);
@@ -457,21 +465,29 @@ extern "C" int moq_gptq_block_sweep(float* w, int64_t rows, int64_t ld, int64_t 
     set_error("moq_gptq_block_sweep: bad arguments");
     return MOQ_ERR_INVALID;
   }
-  if (bs > kSgptMaxBlock || fmt < 1 || fmt > 3 || (fmt == 1 && (num_bits < 2 || num_bits > 16))) {
-    set_error("moq_gptq_block_sweep: needs col block <= %d, fmt 1 (INT-k, 2 <= k <= 16), 2 (FP8-E4M3) or 3 (MX)", kSgptMaxBlock);
+  if (bs > kSgptMaxBlock || fmt < 1 || fmt > 4 || (fmt == 1 && (num_bits < 2 || num_bits > 16))) {
+    set_error("moq_gptq_block_sweep: needs col block <= %d, fmt 1 (INT-k, 2 <= k <= 16), 2 (FP8-E4M3), 3 (MX) or 4 (two-level)",
+              kSgptMaxBlock);
     return MOQ_ERR_UNSUPPORTED;
   }
-  if (fmt == 3 && (g > 64 || (g & (g - 1)) != 0 || i1 % g != 0 || bs % g != 0 || mx_fmt(num_bits).kind < 0)) {
-    set_error("moq_gptq_block_sweep: MX needs a block size that is a power of two <= 64 dividing i1 and bs, and a known element format");
+  if (fmt >= 3 && (g > 64 || (g & (g - 1)) != 0 || i1 % g != 0 || bs % g != 0 || mx_fmt(num_bits).kind < 0 ||
+                   (fmt == 4 && mx_fmt(is_unsigned).kind < 0))) {
+    set_error("moq_gptq_block_sweep: dynamic blocks need a block size that is a power of two <= 64 dividing i1 and bs, and "
+              "known element / scale formats");
     return MOQ_ERR_UNSUPPORTED;
   }
   if (rows == 0) return MOQ_OK;
   const dim3 grid((unsigned)((rows + 3) / 4)), block(kBlock);
   IntQ iq = make_intq(fmt == 1 ? num_bits : 8, is_unsigned, narrow);
-  if (fmt == 3) {
-    iq.hi = (float)num_bits;  // the element format code rides in the clamp slot (unused by this format)
-    hipLaunchKernelGGL((gptq_sweep_kernel<3>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
-                       amax_row_stride, g, iq);
+  if (fmt >= 3) {
+    iq.hi = (float)num_bits;    // the element format code rides in the clamp slots (unused by these formats),
+    iq.lo = (float)is_unsigned;  // the scale format of fmt 4 in the other one
+    if (fmt == 3)
+      hipLaunchKernelGGL((gptq_sweep_kernel<3>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
+                         amax_row_stride, g, iq);
+    else
+      hipLaunchKernelGGL((gptq_sweep_kernel<4>), grid, block, 0, S(stream), w, rows, ld, i1, bs, hinv, delta, amax,
+                         amax_row_stride, g, iq);
     return check_launch("moq_gptq_block_sweep");
   }
   if (fmt == 1)

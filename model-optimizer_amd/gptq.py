@@ -15,8 +15,9 @@ What is MI355X-native here:
     block is ops.sgpt_trailing_update (fp32 matrix cores, defined summation order).  MX formats (dynamic blocks with
     E8M0 scales: MXFP4, MXFP8 -- the 4-bit format MI355X multiplies natively) are NOT elementwise: the scale of a block
     follows the weights as they are updated, which is what the reference's full-matrix call is for; the same kernel
-    recomputes the pivot block's abs-max from the block's lanes at every column.  Other dynamic block formats (two-level
-    scales) take the reference's own loop through the quantizer.
+    recomputes the pivot block's abs-max from the block's lanes at every column.  Two-level block scales (an element
+    format as the scale format, relative to the calibrated tensor-wide amax: the NVFP4-style formats) ride the same
+    kernel; only a quantizer without such a calibrated amax takes the reference's own loop through the quantizer.
   * Data-parallel replicas (distributed.declare_data_parallel): Hessians are combined sample-weighted on one owner
     rank each, the owner updates the linears that read them and broadcasts the weights -- every replica ends with the
     same model (the reference leaves ranks to diverge).
@@ -140,7 +141,19 @@ def _static_layout(q, weight: torch.Tensor):
             return None
         return 3, fmt, False, False, None, 0, int(g)
     if q._block_dynamic:
-        return None
+        # block scales in an element format relative to the tensor-wide amax (NVFP4-style two-level scales): row-local once
+        # that amax is calibrated (fmt 4); a tensor-wide amax taken from the current weights would couple the rows
+        amax = getattr(q, "_amax", None)
+        nb = q._num_bits if not isinstance(q._num_bits, list) else tuple(q._num_bits)
+        names = {(2, 1): "E2M1", (4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3", 8: "INT8"}
+        sb = q._block_sizes.get("scale_bits", None)
+        fmt, sfmt = names.get(nb), names.get(tuple(sb) if isinstance(sb, (list, tuple)) else sb)
+        bsz = q._block_sizes
+        g = bsz.get(-1, None) or bsz.get(1, None)
+        if (amax is None or amax.numel() != 1 or fmt is None or sfmt is None or not g or g > 64 or g & (g - 1)
+                or set(bsz) - {-1, 1, "type", "scale_bits"} or weight.shape[1] % g):
+            return None
+        return 4, fmt, sfmt, False, amax.detach().float().reshape(1), 0, int(g)
     amax = getattr(q, "_amax", None)
     if amax is None:
         return None
@@ -177,7 +190,7 @@ def gptq_blockwise_update(weight: torch.Tensor, h_inv: torch.Tensor, block_size:
     """calib_utils.py:241-276 on the fp32 working copy `weight` [Cout, Cin], in place.  Returns {"kernel": bool}."""
     num_cols = weight.shape[1]
     layout = _static_layout(quantize_fn, weight)
-    if (layout is not None and layout[0] == 3 and block_size % layout[6]) or (layout is not None and block_size > 128):
+    if (layout is not None and layout[0] in (3, 4) and block_size % layout[6]) or (layout is not None and block_size > 128):
         layout = None  # (an MX block must not straddle two column blocks of the update)
     if layout is not None and weight.dtype == torch.float32 and weight.is_contiguous():
         fmt, bits, unsigned, narrow, am, stride, g = layout

@@ -1131,14 +1131,19 @@ def gptq_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, amax
     err_j = (w_j - q_j) / hinv_jj are returned [rows, bs].  fmt 1: INT-num_bits, 2: FP8-E4M3; amax: fp32, entry
     amax[r * amax_row_stride + c / g] for element (r, c).  fmt 3: MX blocks of g columns with E8M0 scales taken from the
     block's current abs-max at every column (dynamic block quantization); num_bits is the element format (name or
-    moq_mx_type code), amax is not used."""
+    moq_mx_type code), amax is not used.  fmt 4: block scales in the element format `unsigned` (name or code) relative to
+    the calibrated tensor-wide `amax` (NVFP4-style two-level scales)."""
     _require_gpu(w, "gptq_block_sweep")
     if w.dtype != torch.float32 or hinv.dtype != torch.float32 or not w.is_contiguous() or not hinv.is_contiguous():
         raise MoquantError("gptq_block_sweep: contiguous fp32 tensors expected")
     rows, ld = w.shape
-    if int(fmt) == 3:
-        am = None
+    if int(fmt) in (3, 4):
         num_bits = _lib.MX_TYPES[num_bits] if isinstance(num_bits, str) else int(num_bits)
+        if int(fmt) == 4:  # `unsigned` carries the scale format, amax the tensor-wide value
+            unsigned = _lib.MX_TYPES[unsigned] if isinstance(unsigned, str) else int(unsigned)
+            am = _f32(amax, w.device).reshape(-1)[:1].contiguous()
+        else:
+            am = None
     else:
         am = _f32(amax, w.device).reshape(-1)
         need = (rows - 1) * int(amax_row_stride) + (ld - 1) // int(g) + 1 if rows else 0
@@ -1147,7 +1152,8 @@ def gptq_block_sweep(w: torch.Tensor, i1: int, bs: int, hinv: torch.Tensor, amax
     delta = torch.empty(rows, bs, dtype=torch.float32, device=w.device)
     with _on(w) as stream:
         check(_lib.lib().moq_gptq_block_sweep(_p(w), rows, ld, int(i1), int(bs), _p(hinv), _p(delta), _p(am),
-                                              int(amax_row_stride), int(g), int(fmt), int(num_bits), int(bool(unsigned)),
+                                              int(amax_row_stride), int(g), int(fmt), int(num_bits),
+                                              int(unsigned) if int(fmt) == 4 else int(bool(unsigned)),
                                               int(bool(narrow_range)), stream))
     return delta
 

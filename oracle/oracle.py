@@ -402,11 +402,13 @@ def gptq_block_sweep(w, i1, bs, hinv, amax, amax_row_stride, g, fmt, num_bits=8,
     rows, ld = w.shape
     delta = np.zeros((rows, bs), dtype=np.float32)
     am = np.zeros(1, dtype=np.float32) if amax is None else np.ascontiguousarray(amax.detach().float().reshape(-1).numpy())
-    if fmt == 3 and isinstance(num_bits, str):
+    if fmt in (3, 4) and isinstance(num_bits, str):
         num_bits = MX_TYPES[num_bits]
+    if fmt == 4:
+        unsigned = MX_TYPES[unsigned] if isinstance(unsigned, str) else int(unsigned)
     lib().orc_gptq_block_sweep(_p(w.numpy()), I64(rows), I64(ld), I64(i1), int(bs), _p(np.ascontiguousarray(hinv.numpy())),
-                               _p(delta), _p(am), I64(amax_row_stride), I64(g), int(fmt), int(num_bits), int(bool(unsigned)),
-                               int(bool(narrow)))
+                               _p(delta), _p(am), I64(amax_row_stride), I64(g), int(fmt), int(num_bits),
+                               int(unsigned) if fmt == 4 else int(bool(unsigned)), int(bool(narrow)))
     return torch.from_numpy(delta)
 
 

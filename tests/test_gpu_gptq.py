@@ -88,6 +88,28 @@ def test_gptq_block_sweep_mx_equals_the_oracle(elem, g, rows, cols, bs):
             oracle.sgpt_trailing_update(wo, i1, do, hinv)
 
 
+@pytest.mark.parametrize("elem,sfmt,g", [("E2M1", "E4M3", 16), ("E2M1", "E5M2", 32), ("E4M3", "E4M3", 32)])
+def test_gptq_block_sweep_two_level_equals_the_oracle(elem, sfmt, g):
+    """fmt 4: block scales in an element format relative to a tensor-wide amax (NVFP4-style), recomputed per column --
+    kernel and oracle bit for bit, tensor-wide values below, at and far above the data's own maximum."""
+    rows, cols, bs = 50, 256, 64
+    gen = torch.Generator().manual_seed(77 + g)
+    w = (torch.randn(rows, cols, generator=gen) * torch.exp(torch.randn(rows, 1, generator=gen))).float()
+    w[1, :g] = 0
+    hinv = _factor(cols, 5 + cols)
+    for glob in (float(w.abs().max()), 0.5, 1e4):
+        amax = torch.tensor([glob])
+        wg, wo, hg = w.clone().to(DEV), w.clone(), hinv.to(DEV)
+        for i1 in range(0, cols, bs):
+            dg = ops.gptq_block_sweep(wg, i1, bs, hg, amax.to(DEV), 0, g, 4, elem, sfmt)
+            do = oracle.gptq_block_sweep(wo, i1, bs, hinv, amax, 0, g, 4, elem, sfmt)
+            assert_bits_equal(dg, do, f"errors of block {i1} (tensor-wide amax {glob})")
+            assert_bits_equal(wg[:, i1:i1 + bs], wo[:, i1:i1 + bs], f"quantized columns of block {i1}")
+            if i1 + bs < cols:
+                ops.sgpt_trailing_update(wg, i1, dg, hg)
+                oracle.sgpt_trailing_update(wo, i1, do, hinv)
+
+
 def test_mxfp4_gptq_flow_and_the_loop_through_the_quantizer_agree():
     """MXFP4 (E2M1, blocks of 32, E8M0 scales) weights through gptq(): the kernel path against the reference's column loop
     through the quantizer's own forward on the GPU, and against round-to-nearest on held-out inputs."""
