@@ -110,6 +110,29 @@ def test_gptq_block_sweep_two_level_equals_the_oracle(elem, sfmt, g):
                 oracle.sgpt_trailing_update(wo, i1, do, hinv)
 
 
+@pytest.mark.parametrize("ones,expect_change", [(False, True), (True, False)])
+def test_gptq_updates_like_the_reference_test(ones, expect_change):
+    """tests/gpu/torch/quantization/test_gptq.py::test_gptq_updates of the reference, on the NVFP4-style preset it uses:
+    after max calibration the weight is restored and GPTQ'd (perc_damp 0.1, block_size 16) -- a random weight must end
+    away from its plain quantize-dequantize, an all-equal weight (no quantization error, nothing to compensate) on it."""
+    torch.manual_seed(42)
+    dim, block_size = 128, 16
+    model = torch.nn.Sequential(torch.nn.Linear(dim, dim)).to(DEV)
+    w = torch.ones(dim, dim, device=DEV) if ones else torch.randn(dim, dim, device=DEV)
+    model[0].weight.data = w.clone()
+    x = torch.randn(2, 16, dim, device=DEV)
+    moa.quantize(model, copy.deepcopy(moa.model_quant.NVFP4_DEFAULT_CFG), lambda m: m(x))
+    lin = model[0]
+    q_dq = lin.weight_quantizer(lin.weight.data).clone()
+    lin.weight.data = w.clone()
+    gptq.gptq(model, lambda m: m(x), perc_damp=0.1, block_size=block_size)
+    assert gptq.GPTQ_STATS["kernel_linears"] == 1  # two-level dynamic blocks under the calibrated tensor-wide amax: fmt 4
+    if expect_change:
+        assert not torch.allclose(lin.weight.data, q_dq), "Weight should not be equal"
+    else:
+        assert torch.allclose(lin.weight.data, q_dq), "Weight should be equal"
+
+
 def test_mxfp4_gptq_flow_and_the_loop_through_the_quantizer_agree():
     """MXFP4 (E2M1, blocks of 32, E8M0 scales) weights through gptq(): the kernel path against the reference's column loop
     through the quantizer's own forward on the GPU, and against round-to-nearest on held-out inputs."""
