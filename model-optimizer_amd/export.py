@@ -32,6 +32,7 @@ QUANTIZATION_INT8_WO = "int8_wo"
 QUANTIZATION_INT4_AWQ = "int4_awq"
 QUANTIZATION_W4A8_AWQ = "w4a8_awq"
 QUANTIZATION_MXFP4 = "mxfp4"
+QUANTIZATION_W4A8_MXFP4_FP8 = "w4a8_mxfp4_fp8"
 QUANTIZATION_FP8_PB_WO = "fp8_pb_wo"
 QUANTIZATION_MXFP8 = "mxfp8"
 QUANTIZATION_FP8_PC_PT = "fp8_pc_pt"
@@ -73,6 +74,9 @@ def get_quantization_format(module) -> str | None:
         return QUANTIZATION_FP8_PB_WO  # export/quant_utils.py:531-544 (fake-quant static blocks)
     if (isinstance(nb, (tuple, list)) and tuple(nb) == (2, 1) and wq.block_sizes is not None
             and tuple(wq.block_sizes.get("scale_bits", ())) == (8, 0)):
+        inb = iq._num_bits if not isinstance(iq._num_bits, list) else tuple(iq._num_bits)
+        if (wq.block_sizes.get("type", "static") == "dynamic" and iq.is_enabled and inb == (4, 3) and iq.block_sizes is None):
+            return QUANTIZATION_W4A8_MXFP4_FP8  # export/quant_utils.py:567-574: MXFP4 weights under per-tensor FP8 inputs
         return QUANTIZATION_MXFP4  # export/quant_utils.py:585-586
     raise NotImplementedError(f"export of weight format num_bits={nb} block_sizes={wq.block_sizes} is outside this path")
 
@@ -260,7 +264,7 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         if wsf.numel() != 1:
             raise NotImplementedError("FP8 export with a dimensioned weight scale (per-channel FP8) is outside this path")
         return ops.fp8_quantize(weight, wsf, fp32_scales=weight.dtype != torch.float32)
-    if quantization == QUANTIZATION_MXFP4:
+    if quantization in (QUANTIZATION_MXFP4, QUANTIZATION_W4A8_MXFP4_FP8):
         raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")
     if quantization in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO):
         return ops.int8_pack_rows(weight, wsf)
@@ -402,8 +406,8 @@ def export_quantized_weight(module, dtype: torch.dtype):
         return {"weight": module.weight.detach()}
     wq, iq = module.weight_quantizer, module.input_quantizer
     out = {}
-    if fmt == QUANTIZATION_MXFP4:
-        # export/quant_utils.py:304-307, :935-936: MXFP4QTensor.quantize gives the packed nibbles and the E8M0 scale
+    if fmt in (QUANTIZATION_MXFP4, QUANTIZATION_W4A8_MXFP4_FP8):
+        # export/quant_utils.py:304-307, :935-936 (w4a8_mxfp4_fp8 stores the same two tensors: no input scale is written): MXFP4QTensor.quantize gives the packed nibbles and the E8M0 scale
         # bytes in one pass (moq_mxfp4_pack); the scales are stored as [..., Cin / block]
         block = wq.block_sizes.get(-1) or wq.block_sizes.get(module.weight.dim() - 1)
         w = module.weight.detach().to(dtype)
@@ -583,15 +587,103 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
     return None, None
 
 
-def hf_quant_config(model, group_size: int | None = None) -> dict:
-    """hf_quant_config.json content (export/unified_export_hf.py + quant_utils get_quant_config) for this path."""
-    fmts = {get_quantization_format(m) for m in model.modules() if is_quantized_linear(m)} - {None}
-    algo = {QUANTIZATION_INT4_AWQ: "W4A16_AWQ", QUANTIZATION_W4A8_AWQ: "W4A8_AWQ", QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PB_WO: "fp8_pb_wo", QUANTIZATION_MXFP4: "mxfp4", QUANTIZATION_MXFP8: "MXFP8", QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL",
-            QUANTIZATION_INT8_WO: "W8A16", QUANTIZATION_FP8_PC_PT: "FP8_PER_CHANNEL_PER_TOKEN"}
-    fmt = next(iter(fmts)) if len(fmts) == 1 else None
-    q = {"quant_algo": algo.get(fmt), "kv_cache_quant_algo": get_kv_cache_format(model)}
+def _summarize_excluded(unquantized, quantized) -> set:
+    """_prefix_wildcard_summarize_exclude_modules (export/quant_utils.py:607-677): the unquantized module names as the
+    SHORTEST prefix wildcards cut at a dot that match no quantized module -- `name*` first, then the pair {name, name.*}
+    (emitted as `name.*`), finally the full name; a wildcard already emitted covers later layers."""
+    forbidden = set()
+    for q in quantized:
+        forbidden.add(q)
+        forbidden.update(q[:i] + "*" for i in range(len(q) + 1))
+    picked: set = set()
+    for layer in unquantized:
+        options = []
+        for i, ch in enumerate(layer):
+            if ch == ".":
+                options.append([layer[:i] + "*"])
+                options.append([layer[:i], layer[:i] + ".*"])
+        options.append([layer])
+        choice = []
+        for cand in options:
+            if any(c in forbidden for c in cand):
+                continue  # would swallow a quantized layer: be more specific
+            if all(c in picked for c in cand):
+                choice = []  # covered already
+                break
+            choice = cand
+            break
+        if len(choice) == 2:
+            a, b = sorted(choice, key=len)
+            picked.update([b] if b == a + ".*" else choice)
+        else:
+            picked.update(choice)
+    return picked
+
+
+_QUANT_ALGO = {QUANTIZATION_FP8: "FP8", QUANTIZATION_FP8_PC_PT: "FP8_PER_CHANNEL_PER_TOKEN", QUANTIZATION_INT8_WO: "W8A16",
+               QUANTIZATION_INT8_SQ: "W8A8_SQ_PER_CHANNEL"}
+
+
+def _layer_quant_config(fmt: str, block: int) -> dict:
+    """One layer's entry of process_layer_quant_config (export/quant_utils.py:703-768)."""
     if fmt in (QUANTIZATION_INT4_AWQ, QUANTIZATION_W4A8_AWQ):
-        q.update(group_size=group_size or 128, has_zero_point=False, pre_quant_scale=True)
+        return {"quant_algo": "W4A16_AWQ" if fmt == QUANTIZATION_INT4_AWQ else "W4A8_AWQ", "group_size": block,
+                "has_zero_point": False, "pre_quant_scale": True}
+    if fmt == QUANTIZATION_W4A8_MXFP4_FP8:
+        return {"quant_algo": "W4A8_MXFP4_FP8", "group_size": block}
+    if fmt == QUANTIZATION_MXFP8:
+        return {"quant_algo": "MXFP8", "group_size": block}
+    return {"quant_algo": _QUANT_ALGO.get(fmt, fmt)}  # (mxfp4, fp8_pb_wo: the format's own name)
+
+
+def hf_quant_config(model, group_size: int | None = None) -> dict:
+    """hf_quant_config.json content: get_quant_config + process_layer_quant_config (export/quant_utils.py:1583-1702,
+    :680-790) and the renaming of module references to checkpoint names (unified_export_hf.py:1594-1610).  Every module
+    that carries quantizers in the reference is listed -- quantized linears, fused expert containers, embeddings (the
+    reference wraps them, disabled) and MoE routers (:1550-1580) --; one format over the model gives that format's entry
+    plus `exclude_modules` (shortest prefix wildcards of the unquantized modules), several give MIXED_PRECISION with the
+    per-layer table."""
+    from torch import nn as _nn
+
+    layers: dict = {}
+    for name, m in model.named_modules():
+        if is_quantized_linear(m):
+            wq = m.weight_quantizer
+            fmt = get_quantization_format(m)
+            stage = wq[0] if isinstance(wq, SequentialQuantizer) else wq
+            bsz = getattr(stage, "block_sizes", None) or {}
+            block = bsz.get(-1, None) or bsz.get(m.weight.dim() - 1, None) or 0
+            layers[name] = (fmt, int(block) if fmt is not None else 0)
+        elif is_quant_fused_experts(m):
+            from types import SimpleNamespace
+
+            no_iq = SimpleNamespace(is_enabled=False, _num_bits=None, block_sizes=None)
+            fmts = {get_quantization_format(_ExpertProjection(w, q, no_iq)) for w, q in m.iter_weights_for_calibration()} - {None}
+            layers[name] = (next(iter(fmts)) if len(fmts) == 1 else None, 0)
+        elif isinstance(m, _nn.Embedding):
+            layers[name] = (None, 0)
+    for name, m in model.named_modules():  # MoE routers kept in original precision (not nn.Linear under transformers >= 5)
+        if not hasattr(m, "experts"):
+            continue
+        for attr in ("gate", "router", "shared_expert_gate"):
+            r = getattr(m, attr, None)
+            if isinstance(r, _nn.Module) and isinstance(getattr(r, "weight", None), torch.Tensor) and not is_quantized_linear(r):
+                layers.setdefault(f"{name + '.' if name else ''}{attr}", (None, 0))
+    quantized = {n: _layer_quant_config(f, group_size if (group_size and f in (QUANTIZATION_INT4_AWQ, QUANTIZATION_W4A8_AWQ)) else b)
+                 for n, (f, b) in layers.items() if f is not None}
+    excluded = [n for n, (f, _) in layers.items() if f is None]
+    q: dict = {"quant_algo": None, "kv_cache_quant_algo": None}
+    kinds = {json.dumps(v, sort_keys=True) for v in quantized.values()}
+    rename = lambda n: next(iter(rename_to_checkpoint_keys({n + ".weight": None}, model)))[:-len(".weight")]  # noqa: E731
+    if len(kinds) > 1:
+        q["quant_algo"] = "MIXED_PRECISION"
+        q["quantized_layers"] = {rename(n): v for n, v in quantized.items()}
+    elif len(kinds) == 1:
+        q.update(next(iter(quantized.values())))
+        q["exclude_modules"] = sorted(_summarize_excluded([rename(n) for n in excluded], [rename(n) for n in quantized]))
+    else:
+        q["quantized_layers"] = {}
+    q["kv_cache_quant_algo"] = get_kv_cache_format(model)
     return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}
 
 

@@ -48,6 +48,18 @@ _MXFP4_Q = {"num_bits": (2, 1), "block_sizes": {-1: 32, "type": "dynamic", "scal
 MXFP4_DEFAULT_CFG = _preset({"*weight_quantizer": dict(_MXFP4_Q), "*input_quantizer": dict(_MXFP4_Q)}, None)
 
 
+# presets/model/w4a8_mxfp4_fp8.yaml: MXFP4 block weights under per-tensor FP8 inputs (max-calibrated) -- the 4-bit weight
+# format MI355X multiplies natively with an 8-bit activation; exported as w4a8_mxfp4_fp8
+W4A8_MXFP4_FP8_CFG = _preset({"*weight_quantizer": dict(_MXFP4_Q), "*input_quantizer": {"num_bits": (4, 3), "axis": None}}, None)
+# presets/model/mxfp4_mlp_weight_only.yaml: MXFP4 weights on the MLP / MoE projections only (everything else stays off:
+# base_disable_all first, then the two enabling patterns)
+MXFP4_MLP_WEIGHT_ONLY_CFG = {"quant_cfg": {"*": {"enable": False},
+                                           "*mlp*weight_quantizer": dict(_MXFP4_Q),
+                                           "*block_sparse_moe*weight_quantizer": dict(_MXFP4_Q),
+                                           **{pat: {"enable": False} for pat in DEFAULT_DISABLED_QUANTIZERS}},
+                             "algorithm": None}
+
+
 def _mx_cfg(num_bits):  # numerics/mx*.yaml: blocks of 32 along the last dim, E8M0 block scales, weights and inputs
     q = {"num_bits": num_bits, "block_sizes": {-1: 32, "type": "dynamic", "scale_bits": (8, 0)}}
     return _preset({"*weight_quantizer": dict(q), "*input_quantizer": dict(q)}, None)

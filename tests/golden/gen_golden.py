@@ -27,6 +27,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   w4a8.npz      -- SequentialQuantizer (INT4 blocks -> FP8) weights + FP8 inputs, max calibration
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
+  export_llama_w4a8_mxfp4_fp8.npz, export_llama_mxfp4_mlp.npz -- the two other MXFP4 presets' exports (tensors + hf_quant_config)
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
   export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
   moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
@@ -1106,6 +1107,45 @@ def gen_export_mxfp4(out):
     out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg)))
 
 
+def _gen_export_uncalibrated(out, preset):
+    """export_hf_checkpoint of the tiny bf16 Llama under a preset that needs no calibration (dynamic MX weights)."""
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    model = LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)).to(torch.bfloat16)
+    for k, v in model.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    q = mtq.quantize(model, getattr(mtq, preset), None)
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        dtypes = {}
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                t = f.get_tensor(k)
+                out[f"exp/{k}"] = bits(t)
+                dtypes[k] = str(t.dtype)
+        quant_cfg = json.load(open(os.path.join(d, "hf_quant_config.json")))
+    out["cases"] = np.array(json.dumps(dict(config=cfgd, dtypes=dtypes, hf_quant_config=quant_cfg, preset=preset)))
+
+
+def gen_export_w4a8_mxfp4_fp8(out):
+    """W4A8_MXFP4_FP8_CFG (MXFP4 block weights, per-tensor FP8 inputs; presets/model/w4a8_mxfp4_fp8.yaml) export."""
+    _gen_export_uncalibrated(out, "W4A8_MXFP4_FP8_CFG")
+
+
+def gen_export_mxfp4_mlp(out):
+    """MXFP4_MLP_WEIGHT_ONLY_CFG (MXFP4 on the MLP projections only: a partially quantized model, exclude_modules with
+    prefix wildcards; presets/model/mxfp4_mlp_weight_only.yaml) export."""
+    _gen_export_uncalibrated(out, "MXFP4_MLP_WEIGHT_ONLY_CFG")
+
+
 def gen_export_fp8_kv(out):
     """FP8 W + A with the FP8 KV-cache quantizers (FP8_DEFAULT_CFG + FP8_KV_CFG merged as hf_ptq does with
     update_quant_cfg_with_kv_cache_quant, examples/hf_ptq/hf_ptq.py:552-556) on the tiny fp32 Llama: the k / v
@@ -1401,12 +1441,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_w4a8_mxfp4_fp8", gen_export_w4a8_mxfp4_fp8), ("export_llama_mxfp4_mlp", gen_export_mxfp4_mlp), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)

@@ -93,8 +93,7 @@ def test_fp8_2d_blockwise_export_is_byte_identical(golden):
             want = from_bits(g.raw(f"exp/{key}"), td[dts])
             assert got.dtype == want.dtype and got.shape == want.shape, f"{key}: {got.dtype} {tuple(got.shape)}"
             assert torch.equal(got.reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), key
-    assert moa.export.hf_quant_config(model)["quantization"]["quant_algo"] == \
-        cases["hf_quant_config"]["quantization"]["quant_algo"] == "fp8_pb_wo"
+    assert moa.export.hf_quant_config(model)["quantization"] == cases["hf_quant_config"]["quantization"]
 
 
 def _reference_recipe(x, block_sizes):

@@ -69,8 +69,8 @@ def test_fp8_kv_cache_calibration_and_export_match_reference(golden, impl):
         amax = getattr(attn, f"{key[-7]}_bmm_quantizer")._amax.float().cpu()
         assert_bits_equal(got, amax / 448.0, f"{key} == amax / 448")
     assert sorted(state) == cases["exported_keys"]
-    assert moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"] == \
-        cases["hf_quant_config"]["quantization"]["kv_cache_quant_algo"] == "FP8"
+    assert moa.export.hf_quant_config(model)["quantization"] == cases["hf_quant_config"]["quantization"]
+    assert cases["hf_quant_config"]["quantization"]["kv_cache_quant_algo"] == "FP8"
 
 
 def test_per_tensor_entries_walk_permuted_dense_tensors_in_place():

@@ -87,13 +87,32 @@ def test_int8_smoothquant_flow_and_export_equal_reference(golden, hostmem):
 
 
 def test_fp8_2d_blockwise_and_mxfp4_exports_equal_reference(golden, hostmem):
+    """Presets that need no calibration data: FP8 128 x 128 tiles, MXFP4 everywhere, MXFP4 weights under FP8 inputs
+    (w4a8_mxfp4_fp8), MXFP4 on the MLP projections only (a partially quantized model) -- every exported tensor byte for
+    byte and the whole `quantization` table of hf_quant_config.json (algorithm, group size, exclude_modules with their
+    prefix wildcards)."""
     for fixture, cfg in (("export_llama_fp8_2d", moa.model_quant.FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG),
-                         ("export_llama_mxfp4", moa.model_quant.MXFP4_DEFAULT_CFG)):
+                         ("export_llama_mxfp4", moa.model_quant.MXFP4_DEFAULT_CFG),
+                         ("export_llama_w4a8_mxfp4_fp8", moa.model_quant.W4A8_MXFP4_FP8_CFG),
+                         ("export_llama_mxfp4_mlp", moa.model_quant.MXFP4_MLP_WEIGHT_ONLY_CFG)):
         g = golden(fixture)
         cases = g.cases
         model = _llama(g, cases, torch.bfloat16)
         moa.quantize(model, cfg, None)
         _compare_state(moa.export.export_state_dict(model, torch.bfloat16), g, cases)
+        assert moa.export.hf_quant_config(model)["quantization"] == cases["hf_quant_config"]["quantization"], fixture
+
+
+def test_summarized_exclude_modules_are_the_shortest_safe_prefix_wildcards():
+    """_prefix_wildcard_summarize_exclude_modules (export/quant_utils.py:607-677) on hand-made layer lists."""
+    f = moa.export._summarize_excluded
+    assert f(["lm_head", "model.embed_tokens"], ["model.layers.0.mlp.up_proj"]) == {"lm_head", "model.embed_tokens"}
+    quant = [f"model.layers.{i}.mlp.{p}" for i in range(2) for p in ("up_proj", "down_proj")]
+    unq = [f"model.layers.{i}.self_attn.{p}" for i in range(2) for p in ("q_proj", "k_proj")] + ["lm_head"]
+    assert f(unq, quant) == {"lm_head", "model.layers.0.self_attn*", "model.layers.1.self_attn*"}
+    # `a*` would swallow the quantized `ab.c`: the pair {a, a.*} is tried next and emitted as `a.*`
+    assert f(["a.x"], ["ab.c"]) == {"a.*"}
+    assert f(["a.x", "a.y"], []) == {"a*"}
 
 
 @pytest.mark.parametrize("impl", ["sdpa", "eager"])
@@ -395,7 +414,7 @@ def test_w4a8_awq_checkpoint_with_replayed_inputs_is_byte_identical(golden, host
     state = moa.export.export_state_dict(q, torch.bfloat16, lambda: q(torch.ones([1, 2], dtype=torch.long)))
     _compare_state(state, g, g.cases)
     assert any(k.endswith("weight_scale_2") for k in state) and any(k.endswith("input_scale") for k in state)
-    assert moa.export.hf_quant_config(q)["quantization"]["quant_algo"] == g.cases["hf_quant_config"]["quantization"]["quant_algo"]
+    assert moa.export.hf_quant_config(q)["quantization"] == g.cases["hf_quant_config"]["quantization"]
 
 
 
@@ -666,8 +685,8 @@ def test_fp8_per_channel_per_token_flow_and_export_equal_reference(golden, hostm
     state = moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
     _compare_state(state, g, cases)
     assert not any(k.endswith("input_scale") for k in state)
-    assert moa.export.hf_quant_config(model)["quantization"]["quant_algo"] == cases["hf_quant_config"]["quantization"]["quant_algo"] \
-        == "FP8_PER_CHANNEL_PER_TOKEN"
+    assert moa.export.hf_quant_config(model)["quantization"] == cases["hf_quant_config"]["quantization"]
+    assert cases["hf_quant_config"]["quantization"]["quant_algo"] == "FP8_PER_CHANNEL_PER_TOKEN"
 
 
 def test_awq_lite_layer_local_falls_back_when_the_stores_do_not_fit_or_the_loop_bypasses_the_stack(hostmem, monkeypatch):
