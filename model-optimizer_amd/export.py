@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import json
 import os
+import warnings
 from collections import defaultdict
 
 import torch
@@ -685,6 +686,119 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
         q["quantized_layers"] = {}
     q["kv_cache_quant_algo"] = get_kv_cache_format(model)
     return {"producer": {"name": "model_optimizer_amd", "version": "0.1"}, "quantization": q}
+
+
+# weights / input_activations entries of a compressed-tensors style config group, per quant_algo
+# (export/convert_hf_config.py:23-130, _quant_algo_to_group_config): (activation spec or None, weight spec, extras)
+def _group_of(algo: str, group_size: int | None) -> dict:
+    f8 = {"dynamic": False, "num_bits": 8, "type": "float"}
+    table = {
+        "FP8": (dict(f8), dict(f8), None),
+        "FP8_PER_CHANNEL_PER_TOKEN": (dict(f8), dict(f8, strategy="channel"), None),
+        "W4A16_AWQ": (None, {"dynamic": False, "num_bits": 4, "type": "int", "group_size": group_size or 128}, None),
+        "W4A8_AWQ": (dict(f8, group_size=group_size or 128),
+                     {"dynamic": False, "num_bits": 4, "type": "float", "group_size": group_size or 128}, None),
+        "W8A16": (None, {"dynamic": False, "num_bits": 8, "type": "int"}, None),
+        "W8A8_SQ_PER_CHANNEL": ({"dynamic": False, "num_bits": 8, "type": "int"},
+                                {"dynamic": False, "num_bits": 8, "type": "int", "strategy": "channel"}, None),
+        "W4A8_MXFP4_FP8": (dict(f8), {"dynamic": False, "num_bits": 4, "type": "float", "group_size": group_size or 16}, None),
+        "MXFP8": (dict(f8, group_size=group_size or 32), dict(f8, group_size=group_size or 32), None),
+    }
+    if algo not in table:
+        warnings.warn(f"Unsupported quantization algorithm '{algo}' in the config-group table: the group carries the name only")
+        return {"quant_algo": algo}
+    act, w, _ = table[algo]
+    return {**({"input_activations": act} if act is not None else {}), "weights": w}
+
+
+def convert_hf_quant_config_format(input_config: dict) -> dict:
+    """export/convert_hf_config.py:133-278: the `quantization_config` embedded into config.json (the llm-compressor /
+    compressed-tensors layout deployment frameworks read): config groups for FP8 and for MIXED_PRECISION (one group per
+    distinct per-layer entry, targets = its layers), `ignore` = exclude_modules, the kv-cache scheme, the producer, and
+    quant_method "modelopt"."""
+    q = input_config.get("quantization", {})
+    algo = q.get("quant_algo")
+    out: dict = {}
+    if algo == "FP8":
+        out["config_groups"] = {"group_0": {**_group_of("FP8", None), "targets": ["Linear"]}}
+    elif algo == "MIXED_PRECISION":
+        layers = q.get("quantized_layers", {})
+        by_cfg = defaultdict(list)
+        for name, cfg in layers.items():
+            by_cfg[tuple(sorted(cfg.items()))].append(name)
+        groups = {}
+        for idx, (key, names) in enumerate(by_cfg.items()):
+            cfg = dict(key)
+            groups[f"group_{idx}"] = {**_group_of(cfg.get("quant_algo", ""), cfg.get("group_size")), "targets": sorted(names)}
+        out["config_groups"] = groups
+        out["quantized_layers"] = layers
+    excl = q.get("exclude_modules")
+    out["ignore"] = excl if excl is not None else []
+    if algo:
+        out["quant_algo"] = algo
+    kv = q.get("kv_cache_quant_algo")
+    if kv:
+        out["kv_cache_scheme"] = {"dynamic": False, "num_bits": 8, "type": "float"} if kv == "FP8" else kv
+    if input_config.get("producer"):
+        out["producer"] = input_config["producer"]
+    out["quant_method"] = "modelopt"
+    return out
+
+
+def export_hf_checkpoint(model, dtype: torch.dtype | None = None, export_dir: str | None = None, dummy_forward_fn=None,
+                         max_shard_size: int | str = "10GB") -> dict:
+    """export_hf_checkpoint (export/unified_export_hf.py:1491-1650) for this path: the packed state dict under the
+    checkpoint's tensor names, hf_quant_config.json, and -- for a Hugging Face model -- config.json (with the embedded
+    `quantization_config`), generation_config.json and the (possibly sharded) safetensors through the model's own
+    save_pretrained, like the reference.  Other modules get model.safetensors + hf_quant_config.json (save_checkpoint).
+    `dummy_forward_fn`: the probe forward of the resmooth / fusion step (default for a causal LM: two token ids).
+    Returns the hf_quant_config dict."""
+    import tempfile
+
+    export_dir = export_dir or tempfile.gettempdir()
+    os.makedirs(export_dir, exist_ok=True)
+    param = next(model.parameters())
+    dtype = dtype or param.dtype
+    is_hf = hasattr(model, "save_pretrained") and hasattr(model, "config")
+    if dummy_forward_fn is None and is_hf:
+        dummy_forward_fn = lambda: model(torch.ones([1, 2], dtype=torch.long, device=param.device))  # noqa: E731
+    state = export_state_dict(model, dtype, dummy_forward_fn, shard_weights=False)
+    quant = hf_quant_config(model)
+    qd = quant["quantization"]
+    quantized = qd.get("quant_algo") is not None or qd.get("kv_cache_quant_algo") is not None
+    if not is_hf:
+        save_checkpoint(state, export_dir, quant if quantized else None, shard_weights=False)
+        return quant
+    tensors = {k: v.detach().contiguous() for k, v in state.items()}
+    patched = []
+    try:
+        # transformers >= 5 would apply the reverse of its load-time key conversion to the state dict it is given; the keys
+        # are the checkpoint's already (rename_to_checkpoint_keys) and its converter cannot walk 0-dim scale tensors
+        import importlib
+
+        for mod_name in ("transformers.core_model_loading", "transformers.modeling_utils"):
+            try:
+                mod = importlib.import_module(mod_name)
+            except Exception:  # noqa: BLE001
+                continue
+            if hasattr(mod, "revert_weight_conversion"):
+                patched.append((mod, mod.revert_weight_conversion))
+                mod.revert_weight_conversion = lambda model_, state_dict: state_dict
+        model.save_pretrained(export_dir, state_dict=tensors, max_shard_size=max_shard_size)
+    finally:
+        for mod, fn in patched:
+            mod.revert_weight_conversion = fn
+    if quantized:
+        with open(os.path.join(export_dir, "hf_quant_config.json"), "w") as f:
+            json.dump(quant, f, indent=4)
+    cfg_path = os.path.join(export_dir, "config.json")
+    with open(cfg_path) as f:
+        cfg = json.load(f)
+    if quantized:
+        cfg["quantization_config"] = convert_hf_quant_config_format(quant)
+    with open(cfg_path, "w") as f:
+        json.dump(cfg, f, indent=4)
+    return quant
 
 
 def save_checkpoint(state: dict, export_dir: str, quant_config: dict | None = None, shard_weights: bool | None = None):

@@ -28,6 +28,7 @@ What is produced (every array is the reference's own output on seeded inputs tha
   qtensor.npz   -- FP8QTensor / MXFP4QTensor quantize + dequantize (bytes, scales, dequantised values)
   export_llama_mxfp4.npz -- MXFP4 export_hf_checkpoint of the tiny Llama (packed nibbles + E8M0 scales)
   export_llama_w4a8_mxfp4_fp8.npz, export_llama_mxfp4_mlp.npz -- the two other MXFP4 presets' exports (tensors + hf_quant_config)
+  export_configs.npz -- hf_quant_config.json, config.json's quantization_config and the file list of export_hf_checkpoint for twelve presets
   export_llama_fp8.npz -- FP8 export_hf_checkpoint of the tiny Llama (amax state, exported tensors)
   export_llama_fp8_kv.npz -- FP8 + FP8 KV-cache quantizers on the tiny Llama: k / v amax, logits, k_scale / v_scale
   moe_fp8.npz   -- FP8 on a tiny Mixtral with fused 3-D expert weights: per-expert amax, logits, exported tensors
@@ -1146,6 +1147,56 @@ def gen_export_mxfp4_mlp(out):
     _gen_export_uncalibrated(out, "MXFP4_MLP_WEIGHT_ONLY_CFG")
 
 
+def gen_export_configs(out):
+    """What export_hf_checkpoint writes NEXT TO the tensors, per preset, on the tiny Llama: hf_quant_config.json, the
+    `quantization_config` it embeds into config.json (convert_hf_quant_config_format, export/convert_hf_config.py) and the
+    file list.  One run mixes formats (INT8 weight-only on the MLPs, FP8 elsewhere): MIXED_PRECISION."""
+    import copy
+    import tempfile
+
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    cfgd = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                num_key_value_heads=2, vocab_size=128, max_position_embeddings=64)
+    batches = [torch.randint(0, 128, (4, 32), generator=torch.Generator().manual_seed(10 + i)) for i in range(2)]
+    mixed = copy.deepcopy(mtq.FP8_DEFAULT_CFG)
+    qc = mixed["quant_cfg"]
+    int8_w = {"num_bits": 8, "axis": 0}
+    if isinstance(qc, list):
+        qc += [{"quantizer_name": "*mlp*weight_quantizer", "cfg": int8_w}, {"quantizer_name": "*mlp*input_quantizer", "enable": False}]
+    else:
+        qc["*mlp*weight_quantizer"] = int8_w
+        qc["*mlp*input_quantizer"] = {"enable": False}
+    kv = copy.deepcopy(mtq.FP8_DEFAULT_CFG)
+    from modelopt.torch.quantization.utils import update_quant_cfg_with_kv_cache_quant
+    kv = update_quant_cfg_with_kv_cache_quant(kv, mtq.FP8_KV_CFG["quant_cfg"])
+    runs = {"int4_awq": (mtq.INT4_AWQ_CFG, True), "fp8": (mtq.FP8_DEFAULT_CFG, True), "fp8_kv": (kv, True),
+            "int8_sq": (mtq.INT8_SMOOTHQUANT_CFG, True), "int8_wo": (mtq.INT8_WEIGHT_ONLY_CFG, True),
+            "w4a8_awq": (mtq.W4A8_AWQ_BETA_CFG, True), "fp8_pc_pt": (mtq.FP8_PER_CHANNEL_PER_TOKEN_CFG, True),
+            "mxfp4": (mtq.MXFP4_DEFAULT_CFG, False), "w4a8_mxfp4_fp8": (mtq.W4A8_MXFP4_FP8_CFG, False),
+            "mxfp4_mlp": (mtq.MXFP4_MLP_WEIGHT_ONLY_CFG, False), "fp8_2d": (mtq.FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG, False),
+            "mixed_fp8_int8wo": (mixed, True)}
+    cases = {"config": cfgd, "n_batches": len(batches), "runs": {}}
+    for i, b in enumerate(batches):
+        out[f"tokens{i}"] = b.numpy()
+    torch.manual_seed(0)
+    base = LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **cfgd)).to(torch.bfloat16)
+    for k, v in base.state_dict().items():
+        out[f"orig/{k}"] = bits(v)
+    for name, (cfg, calib) in runs.items():
+        q = mtq.quantize(copy.deepcopy(base), copy.deepcopy(cfg), (lambda m: [m(b) for b in batches]) if calib else None)
+        with tempfile.TemporaryDirectory() as d:
+            export_hf_checkpoint(q, export_dir=d)
+            files = sorted(os.listdir(d))
+            hfq = json.load(open(os.path.join(d, "hf_quant_config.json")))
+            cj = json.load(open(os.path.join(d, "config.json")))
+        cases["runs"][name] = dict(files=files, hf_quant_config=hfq, quantization_config=cj.get("quantization_config"),
+                                   config_keys=sorted(cj))
+    out["cases"] = np.array(json.dumps(cases))
+
+
 def gen_export_fp8_kv(out):
     """FP8 W + A with the FP8 KV-cache quantizers (FP8_DEFAULT_CFG + FP8_KV_CFG merged as hf_ptq does with
     update_quant_cfg_with_kv_cache_quant, examples/hf_ptq/hf_ptq.py:552-556) on the tiny fp32 Llama: the k / v
@@ -1441,12 +1492,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_configs": gen_export_configs, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_llama_w4a8_mxfp4_fp8", gen_export_w4a8_mxfp4_fp8), ("export_llama_mxfp4_mlp", gen_export_mxfp4_mlp), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_configs", gen_export_configs), ("export_llama_w4a8_mxfp4_fp8", gen_export_w4a8_mxfp4_fp8), ("export_llama_mxfp4_mlp", gen_export_mxfp4_mlp), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)
