@@ -39,9 +39,11 @@ from . import qtensor  # noqa: F401
 from . import layerwise  # noqa: F401
 from . import library_ops  # noqa: F401
 from . import modelopt_plugin  # noqa: F401
-from .model_quant import quantize  # noqa: F401
+from .model_quant import (calibrate, disable_quantizer, enable_quantizer, fold_weight, postprocess_amax,  # noqa: F401
+                          print_quant_summary, quantize)
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
 __all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "hf_attention", "hf_experts", "distributed", "model_calib", "model_quant",
-           "sparsity", "gptq", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "TensorQuantizer", "QuantizerAttributeConfig",
+           "sparsity", "gptq", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "calibrate", "fold_weight", "postprocess_amax", "disable_quantizer", "enable_quantizer",
+           "print_quant_summary", "TensorQuantizer", "QuantizerAttributeConfig",
            "MoquantError", "MoquantUnsupported"]

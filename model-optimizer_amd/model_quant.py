@@ -281,7 +281,12 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     stage("convert")
     set_quantizer_by_cfg(model, config["quant_cfg"])
     stage("set_quantizers")
-    algo = config.get("algorithm", "max")
+    _run_algorithm(model, config.get("algorithm", "max"), forward_loop)
+    stage("calibrate")
+    return model
+
+
+def _run_algorithm(model: nn.Module, algo, forward_loop):
     method, kwargs = (algo, {}) if not isinstance(algo, dict) else (algo["method"], {k: v for k, v in algo.items() if k != "method"})
     if method is None:
         return model
@@ -316,8 +321,77 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
             _gptq.gptq(model, forward_loop, **gk)
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
-    stage("calibrate")
     return model
+
+
+def calibrate(model: nn.Module, algorithm="max", forward_loop=None) -> nn.Module:
+    """mtq.calibrate (quantization/model_quant.py:64-129): run a calibration algorithm on a model whose quantizers are in
+    place -- "max", "mse", "local_hessian", "smoothquant", "awq_lite" / "awq_clip" / "awq_full", "gptq", or a dict with
+    "method" and the algorithm's keyword arguments; None does nothing.  A forward_loop that takes no argument is accepted
+    with the reference's deprecation warning; the model is calibrated in eval mode and put back."""
+    import inspect
+    import warnings
+
+    if forward_loop is not None and len(inspect.signature(forward_loop).parameters) == 0:
+        warnings.warn("forward_loop should take model as argument, but got forward_loop without any arguments. This usage "
+                      "will be deprecated in future versions.", DeprecationWarning)
+        zero_arg = forward_loop
+        forward_loop = lambda _model: zero_arg()  # noqa: E731
+    training = model.training
+    model.eval()
+    try:
+        _run_algorithm(model, algorithm, forward_loop)
+    finally:
+        model.train(training)
+    return model
+
+
+def postprocess_amax(model: nn.Module, key: str, post_process_fn) -> nn.Module:
+    """mtq.postprocess_amax (:132-144): amax <- post_process_fn(amax) for every calibrated quantizer whose name matches."""
+    import fnmatch
+
+    assert isinstance(key, str), "key should be a string"
+    for name, module in model.named_modules():
+        if isinstance(module, TensorQuantizer) and hasattr(module, "_amax") and fnmatch.fnmatch(name, key):
+            module.amax = post_process_fn(module.amax)
+    return model
+
+
+def _toggle(model: nn.Module, wildcard_or_filter_func, enable: bool):
+    import fnmatch
+
+    for name, module in model.named_modules():
+        if not isinstance(module, TensorQuantizer):
+            continue
+        hit = wildcard_or_filter_func(name) if callable(wildcard_or_filter_func) else fnmatch.fnmatch(name, wildcard_or_filter_func)
+        if hit:
+            module.enable() if enable else module.disable()
+
+
+def disable_quantizer(model: nn.Module, wildcard_or_filter_func):
+    """mtq.disable_quantizer (:698-700): by wildcard or by a filter function of the quantizer's name."""
+    _toggle(model, wildcard_or_filter_func, False)
+
+
+def enable_quantizer(model: nn.Module, wildcard_or_filter_func):
+    """mtq.enable_quantizer (:703-705)."""
+    _toggle(model, wildcard_or_filter_func, True)
+
+
+def print_quant_summary(model: nn.Module, output_dir: str | None = None):
+    """mtq.print_quant_summary (:709-725): one line per TensorQuantizer, printed or written to <output_dir>/.quant_summary.txt."""
+    import os
+
+    lines = [f"{name:80} {mod}" for name, mod in model.named_modules() if isinstance(mod, TensorQuantizer)]
+    lines.append(f"{len(lines)} TensorQuantizers found in model")
+    if output_dir:
+        os.makedirs(output_dir, exist_ok=True)
+        path = os.path.join(output_dir, ".quant_summary.txt")
+        with open(path, "w", encoding="utf-8") as f:
+            f.write("\n".join(lines) + "\n")
+        print(f"Quant summary saved to {path}")
+    else:
+        print("\n".join(lines))
 
 
 # ------------------------------------------------------------------------------------------------ fold_weight

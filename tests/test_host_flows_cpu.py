@@ -738,3 +738,42 @@ def test_awq_lite_layer_local_falls_back_when_the_stores_do_not_fit_or_the_loop_
     b, st = run(True, 1 << 30, direct)   # asked for explicitly, but the stack is never entered: falls back
     assert not st.get("layer_local")
     same(a, b)
+
+
+def test_small_model_quant_api(hostmem, tmp_path, capsys):
+    """mtq.calibrate / postprocess_amax / disable_quantizer / enable_quantizer / print_quant_summary
+    (quantization/model_quant.py:64-144, :698-725): quantizers put in place without an algorithm, then calibrated by the
+    separate call (a forward loop without an argument is accepted with the deprecation warning); amax post-processing by
+    wildcard; toggling by wildcard and by filter function; the summary printed and written."""
+    import warnings
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 32))
+    x = torch.randn(8, 64)
+    cfg = copy.deepcopy(moa.model_quant.INT8_DEFAULT_CFG)
+    cfg["algorithm"] = None
+    moa.quantize(model, cfg, None)
+    assert not hasattr(model[0].weight_quantizer, "_amax")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        moa.calibrate(model, "max", lambda: model(x))
+    assert any(issubclass(m.category, DeprecationWarning) for m in w)
+    a0 = model[0].input_quantizer.amax.clone()
+    assert torch.equal(a0.reshape(()), x.abs().max())
+    moa.postprocess_amax(model, "0.input_quantizer", lambda a: a * 2)
+    assert torch.equal(model[0].input_quantizer.amax, a0 * 2) and torch.equal(model[2].weight_quantizer.amax.reshape(-1),
+                                                                               model[2].weight.abs().amax(dim=1))
+    moa.disable_quantizer(model, "*input_quantizer")
+    assert not model[0].input_quantizer.is_enabled and not model[2].input_quantizer.is_enabled and model[0].weight_quantizer.is_enabled
+    moa.enable_quantizer(model, lambda name: name.startswith("2."))
+    assert model[2].input_quantizer.is_enabled and not model[0].input_quantizer.is_enabled
+    moa.print_quant_summary(model)
+    out = capsys.readouterr().out
+    assert "0.input_quantizer" in out and "TensorQuantizers found in model" in out
+    moa.print_quant_summary(model, str(tmp_path))
+    text = open(tmp_path / ".quant_summary.txt").read()
+    assert text.rstrip().endswith("TensorQuantizers found in model") and "2.weight_quantizer" in text
+    training = model.training
+    moa.calibrate(model, {"method": "mse"}, lambda m: m(x))
+    assert model.training == training
+
