@@ -201,22 +201,24 @@ def gptq_blockwise_update(weight: torch.Tensor, h_inv: torch.Tensor, block_size:
             if i1 + bs < num_cols:
                 ops.sgpt_trailing_update(weight, i1, errs, h_inv)
         return {"kernel": True}
-    # the reference's loop: the quantizer sees the whole working matrix for every column (dynamic block scales move
-    # with the weights)
-    for block_start in range(0, num_cols, block_size):
-        block_end = min(block_start + block_size, num_cols)
-        h_blk = h_inv[block_start:block_end, block_start:block_end]
-        wblk = weight.clone()
-        errs = torch.zeros_like(weight[:, block_start:block_end])
-        for i in range(block_end - block_start):
-            w_ci = wblk[:, block_start + i]
-            d = h_blk[i, i]
-            qdq = quantize_fn(wblk)
-            weight[:, block_start + i] = qdq[:, block_start + i]
-            err = (w_ci - qdq[:, block_start + i]) / d
-            wblk[:, block_start + i:block_end].addr_(err, h_blk[i, i:], alpha=-1)
-            errs[:, i] = err
-        weight[:, block_end:].addmm_(errs, h_inv[block_start:block_end, block_end:], alpha=-1)
+    # No kernel for this quantizer: every column is quantized by running the quantizer over the WHOLE working matrix (its
+    # scales may depend on any of it) and keeping that one column -- the semantics of calib_utils.py:241-276, column by column
+    n_rows = weight.shape[0]
+    for lo in range(0, num_cols, block_size):
+        hi = min(lo + block_size, num_cols)
+        factor = h_inv[lo:hi, lo:hi]
+        work = weight.clone()  # running values of the block's columns (the others stay as they are)
+        block_err = weight.new_zeros(n_rows, hi - lo)
+        for k in range(hi - lo):
+            col = lo + k
+            before = work[:, col].clone()
+            quantized_col = quantize_fn(work)[:, col]
+            weight[:, col] = quantized_col
+            e = (before - quantized_col) / factor[k, k]
+            work[:, col:hi] -= torch.outer(e, factor[k, k:])  # product rounded, then subtracted
+            block_err[:, k] = e
+        if hi < num_cols:
+            weight[:, hi:] -= block_err @ h_inv[lo:hi, hi:]
     return {"kernel": False}
 
 

@@ -295,49 +295,53 @@ def _mse_calibrate_weights(model: nn.Module, step_size: float, start_multiplier:
 
 # ------------------------------------------------------------------------------------------------ local Hessian
 class _LocalHessianAccumulator:
-    """Per-block local Hessian H = sum X^T X of one weight's input (model_calib.py:829-899): Cin is cut into blocks of
-    `block_size` columns, every block keeps its own [bs, bs] matrix -- the metric (W - Wq)^T H (W - Wq) of a block of
-    the weight approximates that block's share of the output error.  Linears fed by the same tensor share one."""
+    """sum X^T X of one linear's input, kept per block of `block_size` input features (model_calib.py:829-899): the
+    metric (W - Wq)^T H (W - Wq) of a block of the weight approximates that block's share of the output error.  One
+    accumulator serves every linear that reads the same tensor; Cin that the block does not divide has none (plain MSE)."""
 
     def __init__(self, cout: int, cin: int, block_size: int):
         self.cout, self.cin, self.block_size = cout, cin, block_size
-        self.num_blocks_per_cin = cin // block_size
-        self.is_enabled = cin % block_size == 0  # not block-divisible: no Hessian, plain MSE
-        self.hessian_per_block = None
-        self._normalized = None
+        self.n_blocks = cin // block_size
+        self.is_enabled = cin % block_size == 0
+        self.hessian_per_block = None  # fp32 [n_blocks, bs, bs], allocated by the first batch
         self.num_samples = 0
+        self._mean = None
 
     @torch.no_grad()
-    def accumulate(self, input_tensor: torch.Tensor):
+    def accumulate(self, activation: torch.Tensor):
         if not self.is_enabled:
             return
-        # (cin, tokens) -> (n_blocks, bs, tokens), fp32 like the reference; one batched GEMM of tiny blocks per call
-        x = input_tensor.reshape(-1, self.cin).to(torch.float32).T
-        x = x.reshape(self.num_blocks_per_cin, self.block_size, -1)
-        batch = x @ x.transpose(-1, -2)
-        self.hessian_per_block = batch if self.hessian_per_block is None else self.hessian_per_block.add_(batch)
-        self.num_samples += input_tensor.numel() // self.cin
+        tokens = activation.reshape(-1, self.cin).float()          # fp32 like the reference (no 16-bit products)
+        blocks = tokens.t().reshape(self.n_blocks, self.block_size, -1)  # [n_blocks, bs, tokens]
+        gram = torch.bmm(blocks, blocks.transpose(1, 2))
+        if self.hessian_per_block is None:
+            self.hessian_per_block = gram
+        else:
+            self.hessian_per_block += gram
+        self.num_samples += tokens.shape[0]
 
     def normalized_hessian(self):
-        if self._normalized is None and self.hessian_per_block is not None and self.num_samples:
-            self._normalized = self.hessian_per_block / self.num_samples
-        return self._normalized
+        """H / samples, cached (the raw sum may be released once the error functions exist)."""
+        if self._mean is None and self.hessian_per_block is not None and self.num_samples > 0:
+            self._mean = self.hessian_per_block / self.num_samples
+        return self._mean
 
     def build_error_func(self, cout: int, keep_buffer: bool = False):
-        hessian = self.normalized_hessian()
-        if hessian is None:
+        """error(x, xq): every element gets its Hessian block's weighted error dw^T H dw, so that a sum over the quantizer's
+        reduce axes ranks the candidates by it; None without samples."""
+        h = self.normalized_hessian()
+        if h is None:
             return None
-        bs = self.block_size
         if not keep_buffer:
             self.hessian_per_block = None
+        bs = self.block_size
 
-        def local_hessian_error(x: torch.Tensor, xq: torch.Tensor) -> torch.Tensor:
-            shape = x.shape
-            dw = (x - xq).view(cout, -1, bs)  # dw (cout, n, bs) . H (n, bs, bs) -> (cout, n)
-            block_loss = torch.einsum("cnb,nbd,cnd->cn", dw, hessian, dw).reshape(-1)
-            return block_loss.unsqueeze(-1).expand(-1, bs).reshape(shape)
+        def weighted_error(x: torch.Tensor, xq: torch.Tensor) -> torch.Tensor:
+            diff = (x - xq).reshape(cout, -1, bs)
+            per_block = torch.einsum("cnb,nbd,cnd->cn", diff, h, diff)
+            return per_block.reshape(-1, 1).expand(-1, bs).reshape(x.shape)
 
-        return local_hessian_error
+        return weighted_error
 
 
 @torch.no_grad()

@@ -379,19 +379,23 @@ def enable_quantizer(model: nn.Module, wildcard_or_filter_func):
 
 
 def print_quant_summary(model: nn.Module, output_dir: str | None = None):
-    """mtq.print_quant_summary (:709-725): one line per TensorQuantizer, printed or written to <output_dir>/.quant_summary.txt."""
+    """mtq.print_quant_summary (:709-725): one line per TensorQuantizer (name padded to 80 columns, then the quantizer's
+    repr) and the count, printed -- or written to <output_dir>/.quant_summary.txt."""
     import os
 
-    lines = [f"{name:80} {mod}" for name, mod in model.named_modules() if isinstance(mod, TensorQuantizer)]
-    lines.append(f"{len(lines)} TensorQuantizers found in model")
-    if output_dir:
-        os.makedirs(output_dir, exist_ok=True)
-        path = os.path.join(output_dir, ".quant_summary.txt")
-        with open(path, "w", encoding="utf-8") as f:
-            f.write("\n".join(lines) + "\n")
-        print(f"Quant summary saved to {path}")
-    else:
-        print("\n".join(lines))
+    rows = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, TensorQuantizer):
+            rows.append(name.ljust(80) + " " + repr(mod))
+    text = "\n".join(rows + [f"{len(rows)} TensorQuantizers found in model"])
+    if not output_dir:
+        print(text)
+        return
+    os.makedirs(output_dir, exist_ok=True)
+    path = os.path.join(output_dir, ".quant_summary.txt")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write(text + "\n")
+    print(f"Quant summary saved to {path}")
 
 
 # ------------------------------------------------------------------------------------------------ fold_weight
