@@ -21,7 +21,7 @@ def parse_args(argv=None):
     ap.add_argument("--batches", type=int, default=4)
     ap.add_argument("--qformat", default="fp8", choices=["fp8", "int4_awq", "w4a8_awq", "mxfp4", "mxfp4_sq", "int8_sq",
                                                           "int8_mse", "fp8_mse", "int4_mse", "int4_awq_clip", "int4_awq_full",
-                                                          "int8_percentile", "int8_entropy", "int4_gptq", "int4_gptq_layerwise", "int4_local_hessian",
+                                                          "int8_percentile", "int8_entropy", "int4_gptq", "int4_gptq_layerwise", "int4_local_hessian", "mxfp4_gptq",
                                                           "fp8_gptq", "sparse_magnitude", "sparsegpt"],
                     help="the last rows: the other calibration algorithms of the path (MSE amax search, AWQ clip / full) and the "
                          "two sparsity modes, for wall-clock at real shapes")
@@ -105,6 +105,7 @@ def run(args, moa=None, dev=None) -> dict:
             "int4_gptq": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, {"method": "gptq"}),
             "int4_gptq_layerwise": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG, {"method": "gptq", "layerwise": {"enable": True}}),
             "fp8_gptq": lambda: with_alg(mq.FP8_DEFAULT_CFG, {"method": "gptq"}),
+            "mxfp4_gptq": lambda: with_alg(mq.MXFP4_MLP_WEIGHT_ONLY_CFG, {"method": "gptq"}),
             "int4_local_hessian": lambda: with_alg(mq.INT4_BLOCKWISE_WEIGHT_ONLY_CFG,
                                                    {"method": "local_hessian", "fp8_scale_sweep": False, "block_size": 128})}.get(args.qformat)
     qcfg = qcfg() if qcfg else {"fp8": mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, mq.FP8_KV_CFG["quant_cfg"]),
