@@ -488,3 +488,42 @@ def test_reference_quantize_through_installed_seams(monkeypatch, preset, expecte
             q = moa.quantize(m, copy.deepcopy(moa.model_quant.MXFP4_DEFAULT_CFG), None)
             mine = q(batches[0]).logits
         assert torch.equal(mine, ours[1]), "MXFP4 logits: reference through the seams vs this package"
+
+
+@pytest.mark.parametrize("rows,cols,cfg,fmt,bits", [
+    (96, 1024, dict(num_bits=4, block_sizes={-1: 128, "type": "static"}), 1, 4),
+    (64, 768, dict(num_bits=(4, 3), axis=None), 2, 8),
+    (80, 640, dict(num_bits=8, axis=0), 1, 8)])
+def test_gptq_blockwise_update_equals_the_reference_live(monkeypatch, rows, cols, cfg, fmt, bits):
+    """The reference's own gptq_blockwise_update (utils/calib_utils.py:241-276) run HERE -- its quantizer fake-quantizing the
+    whole matrix once per column -- against the oracle's column sweep + defined-order trailing update, from the same inverse
+    factor, over several column blocks of a 640-1024 wide weight: the same weights, every one."""
+    ref_shim.install()
+    from modelopt.torch.quantization.config import QuantizerAttributeConfig
+    from modelopt.torch.quantization.model_calib import max_calibrate
+    from modelopt.torch.quantization.nn import TensorQuantizer
+    from modelopt.torch.quantization.utils import calib_utils
+
+    from oracle import oracle
+
+    gen = torch.Generator().manual_seed(rows + cols)
+    w = (torch.randn(rows, cols, generator=gen) * 0.05).float()
+    mix = torch.randn(cols, cols, generator=gen) / cols ** 0.5 * torch.linspace(2, 0.05, cols)[:, None]
+    x = torch.randn(4 * cols, cols, generator=gen) @ mix
+    hinv = calib_utils.compute_hessian_inverse((2.0 / x.shape[0]) * x.t() @ x, w, 0.01).contiguous()
+    q = TensorQuantizer(QuantizerAttributeConfig(**cfg))
+    max_calibrate(q, lambda qq: qq(w), distributed_sync=False)
+    want = w.clone()
+    calib_utils.gptq_blockwise_update(want, hinv, 128, q)
+    amax = q._amax.float().reshape(-1)
+    stride, g = (0, cols) if amax.numel() == 1 else ((1, cols) if amax.numel() == rows else (cols // 128, 128))
+    got = w.clone().contiguous()
+    for i1 in range(0, cols, 128):
+        delta = oracle.gptq_block_sweep(got, i1, 128, hinv, amax, stride, g, fmt, bits)
+        if i1 + 128 < cols:
+            oracle.sgpt_trailing_update(got, i1, delta, hinv)
+    assert torch.equal(got, want), f"{int((got != want).sum())} of {got.numel()} weights differ"
+    # and this package's own functions on the same inputs (host side through the oracle-backed C-ABI)
+    hostmem_backend.install(monkeypatch, moa)
+    ours_hinv = moa.gptq.compute_hessian_inverse((2.0 / x.shape[0]) * x.t() @ x, w, 0.01)
+    assert torch.equal(ours_hinv, hinv)
