@@ -656,13 +656,21 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
             block = bsz.get(-1, None) or bsz.get(m.weight.dim() - 1, None) or 0
             layers[name] = (fmt, int(block) if fmt is not None else 0)
         elif is_quant_fused_experts(m):
-            from types import SimpleNamespace
-
-            no_iq = SimpleNamespace(is_enabled=False, _num_bits=None, block_sizes=None)
-            fmts = {get_quantization_format(_ExpertProjection(w, q, no_iq)) for w, q in m.iter_weights_for_calibration()} - {None}
-            layers[name] = (next(iter(fmts)) if len(fmts) == 1 else None, 0)
-        elif isinstance(m, _nn.Embedding):
-            layers[name] = (None, 0)
+            # get_quantization_format on the container (quant_utils.py:485-601): per weight attribute the FIRST expert's
+            # weight quantizer stands for all of them, next to the projection's shared input quantizer; the first
+            # attribute with a format decides.  Block size: the first attribute whose quantizer has one (:1640-1650).
+            fmt, block = None, 0
+            for wqs_attr, iq_attr in ((m._first_proj_weight_quantizers_attr, m._first_proj_input_quantizer_attr),
+                                      ("down_proj_weight_quantizers", "down_proj_input_quantizer")):
+                wq = getattr(m, wqs_attr)[0]
+                if fmt is None:
+                    fmt = get_quantization_format(_ExpertProjection(None, wq, getattr(m, iq_attr)))
+                stage = wq[0] if isinstance(wq, SequentialQuantizer) else wq
+                bsz = getattr(stage, "block_sizes", None) or {}
+                block = block or int(bsz.get(-1, None) or 0)
+            layers[name] = (fmt, block if fmt is not None else 0)
+        elif type(m) is _nn.Embedding:  # the reference's registry wraps the exact class only (OPT's learned positional
+            layers[name] = (None, 0)  # embedding, a subclass, carries no quantizers there and is not listed)
     for name, m in model.named_modules():  # MoE routers kept in original precision (not nn.Linear under transformers >= 5)
         if not hasattr(m, "experts"):
             continue

@@ -105,6 +105,12 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
         with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
             for k in f.keys():
                 out[k] = f.get_tensor(k)
+        import json
+
+        # the two JSON tables a deployment framework reads next to the tensors
+        hfq = json.load(open(os.path.join(d, "hf_quant_config.json")))["quantization"] if os.path.exists(os.path.join(d, "hf_quant_config.json")) else None
+        qc = json.load(open(os.path.join(d, "config.json"))).get("quantization_config")
+        out["__quant_json__"] = (hfq, qc)
     return amax, out
 
 
@@ -127,10 +133,21 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
         return amax, {"__logits__": logits}
     state = moa.export.export_state_dict(model, dtype, lambda: model(torch.ones([1, 2], dtype=torch.long)))
     state["__logits__"] = logits
+    quant = moa.export.hf_quant_config(model)
+    state["__quant_json__"] = (quant["quantization"], moa.export.convert_hf_quant_config_format(quant))
     return amax, state
 
 
 SQ_HALF = {"method": "smoothquant", "alpha": 0.5}
+
+
+def _assert_same_quant_json(ours, ref, what=""):
+    """hf_quant_config.json's quantization table (algorithm, group size, exclude_modules wildcards, routers, per-layer
+    table, KV cache) and config.json's quantization_config, up to each library's own producer entry."""
+    assert ours[0] == ref[0], f"{what}: hf_quant_config {ours[0]} vs {ref[0]}"
+    ours_qc, ref_qc = dict(ours[1]), dict(ref[1])
+    ours_qc.pop("producer", None), ref_qc.pop("producer", None)
+    assert ours_qc == ref_qc, f"{what}: quantization_config {ours_qc} vs {ref_qc}"
 
 
 @pytest.mark.parametrize("preset,dtype,with_kv,arch,algorithm", [
@@ -170,6 +187,7 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
     for n, a in ref_amax.items():
         assert n in our_amax, f"{preset}: quantizer {n} has no amax here"
         assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"{preset}: amax of {n} differs"
+    ref_json, our_json = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
     ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
     if ref_logits is not None:  # the forward with fake quantization active, after calibration
         assert torch.equal(our_logits, ref_logits), f"{preset}: logits of the fake-quantized model differ"
@@ -178,6 +196,8 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
     if arch == "llama-ragged":
         return  # calibration (alpha search on padded blocks), amax and the fake-quantized forward are compared
     assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
+    if ref_json is not None and ref_json[0] is not None:
+        _assert_same_quant_json(our_json, ref_json, f"{preset} {arch}")
     for k, want in ref_state.items():
         got = our_state[k].detach().cpu()
         assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{preset} {k}: {got.dtype} {tuple(got.shape)} vs {want.dtype} {tuple(want.shape)}"
@@ -379,6 +399,7 @@ def test_awq_lite_with_kv_cache_quantizers_both_search_modes_live(monkeypatch, s
     for n, a in ref_amax.items():
         assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
     ref_state.pop("__logits__"), our_state.pop("__logits__")
+    _assert_same_quant_json(our_state.pop("__quant_json__"), ref_state.pop("__quant_json__"))  # FP8 KV cache entry included
     assert sorted(our_state) == sorted(ref_state)
     for k, want in ref_state.items():
         got = our_state[k].detach().cpu()
@@ -397,6 +418,7 @@ def test_fp8_per_channel_per_token_calibration_forward_and_export_equal_the_refe
     for n, a in ref_amax.items():
         assert a.numel() > 1 and torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
     assert torch.equal(our_state.pop("__logits__"), ref_state.pop("__logits__"))
+    _assert_same_quant_json(our_state.pop("__quant_json__"), ref_state.pop("__quant_json__"))
     assert sorted(our_state) == sorted(ref_state)
     assert not any(k.endswith("input_scale") for k in ref_state)
     for k, want in ref_state.items():
