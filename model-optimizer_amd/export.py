@@ -380,12 +380,34 @@ def _checkpoint_rename_rules(model_type):
     return rules
 
 
+def _keeps_module_names(model) -> bool:
+    """True when the model holds a fused-experts container whose exported scales have 3 or more dims (2-D FP8 blocks):
+    the model-level form of rename_to_checkpoint_keys' guard, for callers without the tensors at hand (the quantization
+    tables; a rank whose shard of the checkpoint happens to hold no expert)."""
+    return any(is_quant_fused_experts(m) and getattr(m, m._first_proj_weight_quantizers_attr)[0].is_enabled
+               and get_quantization_format(_ExpertProjection(None, getattr(m, m._first_proj_weight_quantizers_attr)[0],
+                                                             getattr(m, m._first_proj_input_quantizer_attr)))
+               == QUANTIZATION_FP8_PB_WO for m in model.modules())
+
+
 def rename_to_checkpoint_keys(state: dict, model) -> dict:
     import re
 
     rules = _checkpoint_rename_rules(getattr(getattr(model, "config", None), "model_type", None))
     if not rules:
         return state
+    if any(kind == "expert" for kind, _, _ in rules):
+        # The reference's reversal is all-or-nothing (unified_export_hf.py:1594-1613): its guard against experts that
+        # were not expanded (quant_aware_conversion.py:298-320) takes ANY tensor of 3 or more dims under `.experts.` for a
+        # stacked expert weight -- which the [R/br, 1, C/bc, 1] scales of 2-D FP8 blocks are -- and the whole checkpoint
+        # (and the module names in the quantization tables) then keeps the module tree's names.  Mirrored, so that both
+        # libraries write the same file for the same model.
+        bad = next((k for k, v in state.items() if ".experts." in k and getattr(v, "ndim", 0) >= 3), None)
+        if bad is not None or _keeps_module_names(model):
+            warnings.warn("checkpoint names not restored (a tensor under `.experts.` has 3 or more dims"
+                          + (f": '{bad}'" if bad else "") + ", which the reference's reversal refuses): tensors and "
+                          "quantization tables keep the module tree's names")
+            return state
     out = {}
     for k, v in state.items():
         for kind, a, b in rules:
@@ -408,12 +430,16 @@ def export_quantized_weight(module, dtype: torch.dtype):
     wq, iq = module.weight_quantizer, module.input_quantizer
     out = {}
     if fmt in (QUANTIZATION_MXFP4, QUANTIZATION_W4A8_MXFP4_FP8):
-        # export/quant_utils.py:304-307, :935-936 (w4a8_mxfp4_fp8 stores the same two tensors: no input scale is written): MXFP4QTensor.quantize gives the packed nibbles and the E8M0 scale
-        # bytes in one pass (moq_mxfp4_pack); the scales are stored as [..., Cin / block]
+        # export/quant_utils.py:304-307, :935-936: MXFP4QTensor.quantize gives the packed nibbles and the E8M0 scale bytes
+        # in one pass (moq_mxfp4_pack); the scales are stored as [..., Cin / block].  w4a8_mxfp4_fp8 stores the same two
+        # tensors plus, once its per-tensor FP8 input quantizer is calibrated, `input_scale` (unified_export_hf.py:685-696:
+        # every format's enabled input quantizer with an amax; MX inputs are dynamic and have none)
         block = wq.block_sizes.get(-1) or wq.block_sizes.get(module.weight.dim() - 1)
         w = module.weight.detach().to(dtype)
         packed, e8m0 = ops.mxfp4_quantize(w, block)
         out = {"weight": packed, "weight_scale": e8m0.reshape(*w.shape[:-1], -1)}
+        if iq.is_enabled and iq.amax is not None:
+            out["input_scale"] = get_scaling_factor(iq).squeeze()
         pqs = getattr(iq, "_pre_quant_scale", None)
         if pqs is not None:  # SmoothQuant scaling composed with MXFP4: promoted like every other format's (:1121-1138)
             out["pre_quant_scale"] = pqs.detach().clone()
@@ -683,7 +709,10 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     excluded = [n for n, (f, _) in layers.items() if f is None]
     q: dict = {"quant_algo": None, "kv_cache_quant_algo": None}
     kinds = {json.dumps(v, sort_keys=True) for v in quantized.values()}
-    rename = lambda n: next(iter(rename_to_checkpoint_keys({n + ".weight": None}, model)))[:-len(".weight")]  # noqa: E731
+    if _keeps_module_names(model):
+        rename = lambda n: n  # noqa: E731 -- (the tensors keep the module tree's names too; warned about there)
+    else:
+        rename = lambda n: next(iter(rename_to_checkpoint_keys({n + ".weight": None}, model)))[:-len(".weight")]  # noqa: E731
     if len(kinds) > 1:
         q["quant_algo"] = "MIXED_PRECISION"
         q["quantized_layers"] = {rename(n): v for n, v in quantized.items()}
