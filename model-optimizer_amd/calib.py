@@ -250,15 +250,16 @@ class HistogramCalibrator(_Calibrator):
         gather from the device edges); entropy = one kernel for the 1 921 divergences, of which the host only looks at
         the minimum (and re-scores exact ties with the reference's own arithmetic, `_pick_entropy_candidate`).  Histograms
         on the host (the CPU test tier) take the numpy restatement of the reference's loops."""
-        if method not in ("entropy", "mse", "percentile"):
+        if method not in ("entropy", "mse", "mse_qdq", "percentile"):
             raise TypeError(f"Unknown calibration method {method}")
         if self._calib_hist is None:
             return ("none", None)
         if method == "percentile" and (percentile < 0 or percentile > 100):
             raise ValueError("Invalid percentile. Must be in range 0 <= percentile <= 100.")
         hist, edges = self._calib_hist, self._calib_bin_edges
-        if method == "mse":
-            return ("value", _compute_amax_mse(hist, edges, self._num_bits, self._unsigned, stride, start_bin))
+        if method in ("mse", "mse_qdq"):
+            search = _compute_amax_mse if method == "mse" else _compute_amax_mse_qdq
+            return ("value", search(hist, edges, self._num_bits, self._unsigned, stride, start_bin))
         nq_bits = self._num_bits - 1 + int(self._unsigned) if isinstance(self._num_bits, int) else None
         # (the counts live on the device, the bin edges on the host -- a linspace, as in the reference)
         if method == "percentile":
@@ -395,10 +396,57 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
 
 
 def _compute_amax_mse(counts, edges, num_bits, unsigned, stride=1, start_bin=128):
-    """MSE threshold search over bin centres.  The reference's version (calib/histogram.py:286-323) passes
-    `num_bits` in the `bias` slot of fake_tensor_quant and therefore returns a constant; this implements
-    the documented intent (QDQ of the centres at each candidate amax, count-weighted squared error, first minimum)
-    and is NOT parity-pinned.
+    """calib/histogram.py:286-323 AS IT COMPUTES, for integer formats: the amax the reference returns for
+    `compute_amax("mse")`, bit for bit (pinned by the reference-run `hist` fixture and the live differential test).
+
+    The reference calls `fake_tensor_quant(centers, amax, num_bits, unsigned)`, whose positional slots are
+    (inputs, amax, bias, num_bits, ...) (`tensor_quant.py:349-360`): the bit width lands in `bias` and the signedness in
+    `num_bits`.  What it evaluates per candidate is therefore a quantizer of int(unsigned) bits around a bias:
+      signed   (0 bits): bound = 2^-1 - 1 = -0.5, clamp(., +0.5, -0.5) = -0.5 for every centre, so the "quantized centres"
+                         are the constant -0.5 / (-0.5 / amax) + num_bits and the count-weighted error is smallest where
+                         amax + num_bits meets the count-weighted mean of the centres;
+      unsigned (1 bit):  bound = 0, scale = 0, 0 / 0 = NaN for every centre: all errors are NaN and numpy's argmin takes the
+                         first candidate, centres[start_bin].
+    Neither is a mean-squared-error search (the MSE search of this path is MseCalibrator, calib/mse.py); a user who
+    switches from the reference gets the amax the reference gave.  The documented intent -- QDQ of the centres at each
+    candidate amax -- is `_compute_amax_mse_qdq` (method "mse_qdq"), which also serves (4, 3): the reference's FP8 branch
+    calls scaled_e4m3 one argument short and raises TypeError, so there is no value to match.
+
+    The arithmetic below follows `_tensor_quant` (`tensor_quant.py:607-645`) step by step in fp32 on the host (2 048 bins:
+    microseconds), as the reference's CPU path does; one [candidates, bins] pass instead of its loop."""
+    if not isinstance(num_bits, int):
+        if tuple(num_bits) != (4, 3):
+            raise TypeError("Invalid num_bits. num_bits must be a positive integer or tuple (4,3).")
+        return _compute_amax_mse_qdq(counts, edges, num_bits, unsigned, stride, start_bin)
+    if num_bits < 0:
+        raise TypeError("Invalid num_bits. num_bits must be a positive integer or tuple (4,3).")
+    dev = counts.device if isinstance(counts, torch.Tensor) else torch.device("cpu")
+    c = torch.as_tensor(counts).detach().to("cpu").float()
+    e = torch.as_tensor(edges).detach().to("cpu").float()
+    centers = (e[1:] + e[:-1]) / 2
+    n_bins = centers.numel()
+    idx = torch.arange(start_bin, n_bins, stride)
+    if idx.numel() == 0:
+        raise ValueError(f"mse threshold search: start_bin={start_bin} leaves no candidate among {n_bins} bins")
+    amax = centers[idx]                                      # [candidates]
+    if bool((amax < 0).any()):  # (an all-zero channel under np.histogram's widened (-0.5, 0.5) range)
+        raise ValueError("Negative values in amax")
+    slot_bits = int(bool(unsigned))                          # what arrives in `num_bits`
+    bound = torch.tensor((2.0 ** (slot_bits - 1)) - 1.0)     # max_bound; `unsigned` itself keeps its default False
+    scale = bound / amax
+    tiny = amax <= 1.0 / (1 << 24)
+    x = centers.reshape(1, -1) - num_bits                    # `inputs - bias`
+    y = torch.clamp((x * torch.where(tiny, torch.zeros_like(scale), scale).reshape(-1, 1)).round_(), -bound, bound)
+    q = y / torch.where(tiny, torch.ones_like(scale), scale).reshape(-1, 1) + num_bits
+    mse = ((q - centers.reshape(1, -1)) ** 2 * c.reshape(1, -1)).mean(dim=1)
+    pick = int(np.argmin(mse.numpy()))                       # first minimum; the first NaN when there is one
+    return centers[idx[pick]].clone().to(dev)
+
+
+def _compute_amax_mse_qdq(counts, edges, num_bits, unsigned, stride=1, start_bin=128):
+    """The MSE threshold search calib/histogram.py:286-323 documents: QDQ of the bin centres at each candidate amax,
+    count-weighted squared error, first minimum (`compute_amax("mse_qdq")`; also what "mse" runs for (4, 3), where the
+    reference raises).  NOT what the reference computes for integer formats -- see _compute_amax_mse.
 
     All candidates of a chunk are one [candidates, bins] per-row QDQ launch (amax [candidates, 1]) instead of the
     reference-shaped loop of one QDQ + reduction + device->host read per candidate (1 920 of them for 2 048 bins);
@@ -457,8 +505,10 @@ def calibrate_weights(model, method="percentile", perchannel=True, percentile=99
                 idx = ops.hist_percentile_index(counts, percentile / 100)
                 vals = edges.gather(1, idx.reshape(-1, 1)).reshape(-1)
             else:
+                if isinstance(wq._num_bits, int):  # the search is host arithmetic: ONE device -> host copy per weight
+                    counts, edges = counts.cpu(), edges.cpu()
                 vals = torch.stack([_compute_amax_mse(counts[r].to(torch.int64), edges[r], wq._num_bits, wq._unsigned)
-                                    for r in range(counts.shape[0])]).cpu()  # one device -> host read per weight
+                                    for r in range(counts.shape[0])]).cpu()
             if perchannel:
                 amax = vals.reshape([w.shape[0]] + [1] * (w.dim() - 1))
             else:

@@ -231,6 +231,16 @@ def gen_hist(out):
             cases[f"c{idx}"] = dict(dtype=dn, skip_zeros=skip_zeros, num_bins=256)
             out[f"c{idx}_pct"] = bits(cal.compute_amax("percentile", percentile=99.9).float().reshape(1))
             out[f"c{idx}_ent"] = bits(cal.compute_amax("entropy", start_bin=64).float().reshape(1))
+            # "mse" as the reference COMPUTES it (bit width in the bias slot: see calib._compute_amax_mse here): through the
+            # calibrator, and on the same counts with unsigned / other widths / strides and edges scaled so that the
+            # count-weighted mean of the centres lies above num_bits (the non-degenerate branch)
+            from modelopt.torch.quantization.calib import histogram as ref_hist
+
+            out[f"c{idx}_mse"] = bits(cal.compute_amax("mse", start_bin=64).float().reshape(1))
+            h_np, e_np = cal._calib_hist.cpu().numpy(), cal._calib_bin_edges.cpu().numpy()
+            out[f"c{idx}_mseu"] = bits(ref_hist._compute_amax_mse(h_np, e_np, 8, True, 1, 64).float().reshape(1))
+            out[f"c{idx}_mse100"] = bits(ref_hist._compute_amax_mse(h_np, e_np * 100, 8, False, 1, 16).float().reshape(1))
+            out[f"c{idx}_mse4s3"] = bits(ref_hist._compute_amax_mse(h_np, e_np * 37, 4, False, 3, 16).float().reshape(1))
             for k, b in enumerate((b0, b1, b2)):
                 out[f"c{idx}_b{k}"] = bits(b)
                 out[f"c{idx}_h{k}"] = bits(snaps[k][0])
@@ -1309,7 +1319,8 @@ def gen_calibrate_weights(out):
 
     cases = {}
     gen = torch.Generator().manual_seed(21)
-    for idx, (co, ci, kind) in enumerate([(16, 300, "normal"), (8, 4096, "heavy"), (5, 64, "grid"), (4, 33, "zero_row")]):
+    for idx, (co, ci, kind) in enumerate([(16, 300, "normal"), (8, 4096, "heavy"), (5, 64, "grid"), (4, 33, "zero_row"),
+                                          (6, 512, "large")]):
         lin = qnn.QuantLinear(ci, co, bias=False)
         with torch.no_grad():
             w = torch.randn(co, ci, generator=gen) * 0.05
@@ -1319,6 +1330,8 @@ def gen_calibrate_weights(out):
                 w = torch.randint(-8, 9, (co, ci), generator=gen).float() * 0.125  # values ON bin edges
             if kind == "zero_row":
                 w[2] = 0
+            if kind == "large":  # mean |w| above the bit width: the non-degenerate branch of the "mse" threshold
+                w = w * torch.tensor([300.0, 400.0, 600.0, 1000.0, 150.0, 2000.0]).reshape(-1, 1)
             lin.weight.copy_(w)
         k = f"c{idx}"
         cases[k] = dict(cout=co, cin=ci, kind=kind)
@@ -1327,10 +1340,21 @@ def gen_calibrate_weights(out):
                         ("pc99", dict(method="percentile", perchannel=True, percentile=99.0)),
                         ("pt999", dict(method="percentile", perchannel=False, percentile=99.9)),
                         ("pcmax", dict(method="max", perchannel=True)),
-                        ("pc512", dict(method="percentile", perchannel=True, percentile=99.5, num_bins=512))]:
+                        ("pc512", dict(method="percentile", perchannel=True, percentile=99.5, num_bins=512)),
+                        ("pcmse", dict(method="mse", perchannel=True, num_bins=512)),
+                        ("ptmse", dict(method="mse", perchannel=False, num_bins=512))]:
             if kind == "zero_row" and "max" not in tag and "pt" not in tag:
                 pass  # all-zero channel: numpy widens the range to (-0.5, 0.5); still a defined result
             lin.weight_quantizer.reset_amax()
+            if kind == "zero_row" and tag == "pcmse":
+                # the all-zero channel's histogram spans (-0.5, 0.5): candidate centres below zero, and the reference's
+                # quantizer refuses a negative amax ("Negative values in amax")
+                try:
+                    ref_calib.calibrate_weights(lin, **kw)
+                    raise AssertionError("expected the reference to refuse the negative candidates")
+                except ValueError as e:
+                    assert "Negative values in amax" in str(e)
+                continue
             ref_calib.calibrate_weights(lin, **kw)
             out[f"{k}_{tag}"] = bits(lin.weight_quantizer.amax.float())
         hists = [np.histogram(r.abs().numpy(), bins=2048, range=(0, r.abs().numpy().max()))[0] for r in lin.weight.detach()]
@@ -1492,7 +1516,7 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_configs": gen_export_configs, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"hist": gen_hist, "mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_configs": gen_export_configs, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),

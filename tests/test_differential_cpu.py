@@ -563,3 +563,80 @@ def test_gptq_blockwise_update_equals_the_reference_live(monkeypatch, rows, cols
     hostmem_backend.install(monkeypatch, moa)
     ours_hinv = moa.gptq.compute_hessian_inverse((2.0 / x.shape[0]) * x.t() @ x, w, 0.01)
     assert torch.equal(ours_hinv, hinv)
+
+
+def test_histogram_mse_threshold_equals_the_reference_live():
+    """`HistogramCalibrator.compute_amax("mse")` for integer formats: the reference's call passes the bit width in the
+    `bias` slot of fake_tensor_quant and the signedness in `num_bits` (calib/histogram.py:305-307 against
+    tensor_quant.py:349-360); calib._compute_amax_mse returns the amax THAT computes, bit for bit, over widths,
+    signedness, strides, start bins and value scales (count-weighted mean of the centres below / above the bit width)."""
+    ref_shim.install()
+    from modelopt.torch.quantization.calib import histogram as ref_hist
+
+    checked = 0
+    for seed in range(10):
+        gen = torch.Generator().manual_seed(seed)
+        nb = [2048, 300, 512, 257, 64][seed % 5]
+        scale = [1.0, 300.0, 0.01, 20.0][seed % 4]
+        x = (torch.randn(1 << 14, generator=gen) * torch.exp(0.7 * torch.randn(1 << 14, generator=gen))).abs() * scale
+        hist = torch.histc(x, bins=nb, min=0, max=float(x.max()))
+        edges = torch.linspace(0, float(x.max()), nb + 1)
+        for bits in (8, 4, 0):
+            for unsigned in (False, True):
+                for stride, start in ((1, 128 if nb > 128 else 8), (3, 16), (7, 1)):
+                    want = ref_hist._compute_amax_mse(hist.numpy(), edges.numpy(), bits, unsigned, stride, start)
+                    got = moa.calib._compute_amax_mse(hist.to(torch.int64), edges, bits, unsigned, stride, start)
+                    assert torch.equal(want.float().reshape(()), got.float().reshape(())), (seed, nb, bits, unsigned, stride, start)
+                    checked += 1
+    assert checked == 180
+    # (4, 3): the reference's call is one argument short
+    with pytest.raises(TypeError):
+        ref_hist._compute_amax_mse(hist.numpy(), edges.numpy(), (4, 3), False, 1, 16)
+
+
+@pytest.mark.parametrize("method,kwargs", [("percentile", {"percentile": 99.9}), ("entropy", {}), ("mse", {})])
+def test_histogram_calibrated_inputs_of_a_model_equal_the_reference_live(monkeypatch, method, kwargs):
+    """The manual flow of the histogram calibrators (config `"calibrator": "histogram"` on the input quantizers,
+    enable_stats_collection, forward passes, `load_calib_amax(method, ...)` per quantizer): every amax of the tiny Llama
+    equals the reference's for the three threshold searches."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization import model_calib as ref_calib
+
+    def with_histograms(cfg):
+        cfg = copy.deepcopy(cfg)
+        entries = cfg["quant_cfg"]
+        spec = {"num_bits": 8, "axis": None, "calibrator": "histogram"}
+        if isinstance(entries, list):
+            for e in entries:
+                if e.get("quantizer_name") == "*input_quantizer":
+                    e["cfg"] = spec
+        else:
+            entries["*input_quantizer"] = spec
+        cfg["algorithm"] = None
+        return cfg
+
+    def run(quantize, cfg, calib_mod, is_quantizer):
+        model = _model(torch.bfloat16, "llama")
+        with torch.no_grad():
+            quantize(model, with_histograms(cfg), None)
+            calib_mod.enable_stats_collection(model)
+            for b in _batches():
+                model(b)
+            for _, m in model.named_modules():
+                if is_quantizer(m) and not m._disabled and m._calibrator is not None:
+                    if type(m._calibrator).__name__ == "MaxCalibrator":
+                        m.load_calib_amax()
+                    else:
+                        m.load_calib_amax(method, **kwargs)
+                    m.enable_quant()
+                    m.disable_calib()
+        return {n: m._amax.detach().float().clone() for n, m in model.named_modules()
+                if is_quantizer(m) and m.is_enabled and getattr(m, "_amax", None) is not None}
+
+    ref = run(mtq.quantize, mtq.INT8_DEFAULT_CFG, ref_calib, lambda m: type(m).__name__ == "TensorQuantizer")
+    hostmem_backend.install(monkeypatch, moa)
+    ours = run(moa.quantize, moa.model_quant.INT8_DEFAULT_CFG, moa.model_calib, lambda m: isinstance(m, moa.TensorQuantizer))
+    assert len(ref) == 28 and set(ref) == set(ours)
+    for n, a in ref.items():
+        assert torch.equal(a.reshape(-1), ours[n].reshape(-1)), f"{method}: amax of {n}: {ours[n]} vs {a}"

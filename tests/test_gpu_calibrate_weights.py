@@ -78,10 +78,33 @@ def test_calibrate_weights_matches_reference_run(golden):
         calib.calibrate_weights(lin, method="entropy")
 
 
+def test_calibrate_weights_mse_matches_reference_run(golden):
+    """method="mse": the amax the reference's calibrate_weights returns (its histogram "mse" search computes with the bit
+    width in the bias slot, see calib._compute_amax_mse), per channel and per tensor; the `large` case reaches the branch
+    where the result is not the first candidate."""
+    g = golden("calibrate_weights")
+    for k, c in g.cases.items():
+        lin = _Lin(g.t(f"{k}_w", torch.float32).to(DEV))
+        for tag, kw in [("pcmse", dict(method="mse", perchannel=True, num_bins=512)),
+                        ("ptmse", dict(method="mse", perchannel=False, num_bins=512))]:
+            if c["kind"] == "zero_row" and tag == "pcmse":
+                # an all-zero channel: numpy's histogram spans (-0.5, 0.5), the candidates below zero are refused
+                with pytest.raises(ValueError, match="Negative values in amax"):
+                    calib.calibrate_weights(lin, **kw)
+                continue
+            calib.calibrate_weights(lin, **kw)
+            want = g.t(f"{k}_{tag}", torch.float32)
+            got = lin.weight_quantizer.amax.float().cpu()
+            assert got.shape == want.shape, f"{k} {tag}: {got.shape} vs {want.shape}"
+            assert torch.equal(got, want), f"{k} {tag} ({c['kind']}): {(got != want).sum().item()} channels differ"
+    assert any(c["kind"] == "large" for c in g.cases.values())
+
+
 @pytest.mark.parametrize("perchannel", [True, False])
 def test_calibrate_weights_mse_threshold(perchannel):
-    """method="mse" (unpinned: the reference's search returns a constant, see calib._compute_amax_mse): every channel
-    gets the centre of one of its histogram bins, below its abs-max, and equals the per-row search on that row alone."""
+    """method="mse" (what the reference's call computes, see calib._compute_amax_mse; pinned by the reference-run
+    fixture above): every channel gets the centre of one of its histogram bins, below its abs-max, and equals the
+    per-row search on that row alone."""
     gen = torch.Generator().manual_seed(5)
     w = (torch.randn(12, 700, generator=gen) * torch.exp(torch.randn(12, 1, generator=gen))).to(DEV)
     lin = _Lin(w)

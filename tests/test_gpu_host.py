@@ -75,20 +75,30 @@ def test_histogram_calibrator_matches_reference(golden):
             assert torch.equal(cal._calib_bin_edges.cpu(), g.t(f"{k}_e{b}")), f"edges {k} batch {b}"
         assert torch.equal(cal.compute_amax("percentile", percentile=99.9).reshape(1), g.t(f"{k}_pct"))
         assert torch.equal(cal.compute_amax("entropy", start_bin=64).reshape(1), g.t(f"{k}_ent"))
-        assert cal.compute_amax("mse", start_bin=64) > 0  # unpinned (reference defect, see calib.py)
+        # "mse": what the reference's call computes (bit width in the bias slot, see calib._compute_amax_mse), pinned
+        assert torch.equal(cal.compute_amax("mse", start_bin=64).reshape(1).cpu(), g.t(f"{k}_mse"))
+        hist, edges = cal._calib_hist, cal._calib_bin_edges
+        for tag, args in (("mseu", (hist, edges, 8, True, 1, 64)), ("mse100", (hist, edges * 100, 8, False, 1, 16)),
+                          ("mse4s3", (hist, edges * 37, 4, False, 3, 16))):
+            got = calib._compute_amax_mse(*args)
+            assert got.device == hist.device and torch.equal(got.reshape(1).cpu(), g.t(f"{k}_{tag}")), f"{tag} {k}"
+        assert cal.compute_amax("mse_qdq", start_bin=64) > 0  # the documented-intent search (not the reference's result)
 
 
 @pytest.mark.parametrize("num_bits,unsigned,nb,stride,start", [(8, False, 2048, 1, 128), (4, False, 300, 1, 16),
                                                                  ((4, 3), False, 512, 3, 64), (8, True, 2048, 7, 128)])
 def test_histogram_mse_threshold_is_the_candidate_loop(num_bits, unsigned, nb, stride, start):
-    """calib._compute_amax_mse evaluates every candidate in one per-row QDQ launch: same pick as the loop form it
-    replaces (one QDQ of the bin centres + count-weighted mean per candidate, first strict minimum), whose per-candidate
-    errors must agree to fp32 reduction-order noise."""
+    """calib._compute_amax_mse_qdq (the documented-intent search: "mse_qdq", and "mse" for (4, 3)) evaluates every
+    candidate in one per-row QDQ launch: same pick as the loop form it replaces (one QDQ of the bin centres +
+    count-weighted mean per candidate, first strict minimum), whose per-candidate errors must agree to fp32
+    reduction-order noise."""
     gen = torch.Generator().manual_seed(nb + start)
     x = (torch.randn(1 << 18, generator=gen) * torch.exp(0.7 * torch.randn(1 << 18, generator=gen))).abs()
     counts = torch.histc(x, bins=nb, min=0, max=float(x.max())).to(torch.int64).to(DEV)
     edges = torch.linspace(0, float(x.max()), nb + 1)
-    got = calib._compute_amax_mse(counts, edges, num_bits, unsigned, stride, start)
+    got = calib._compute_amax_mse_qdq(counts, edges, num_bits, unsigned, stride, start)
+    if not isinstance(num_bits, int):
+        assert torch.equal(got, calib._compute_amax_mse(counts, edges, num_bits, unsigned, stride, start))  # (4, 3) routes here
     e = edges.float().to(DEV)
     centers = ((e[1:] + e[:-1]) / 2).contiguous()
     c = counts.float()
@@ -102,10 +112,11 @@ def test_histogram_mse_threshold_is_the_candidate_loop(num_bits, unsigned, nb, s
     assert errs[picked] <= errs.min() * (1 + 1e-5)           # the pick is a minimum of the loop form's errors ...
     if (errs <= errs.min() * (1 + 1e-5)).sum() == 1:
         assert picked == int(errs.argmin())                    # ... and THE minimum when that is unambiguous
-    with pytest.raises(ValueError, match="no candidate"):
-        calib._compute_amax_mse(counts, edges, num_bits, unsigned, stride, nb)
-    with pytest.raises(TypeError, match="Invalid num_bits"):
-        calib._compute_amax_mse(counts, edges, (5, 2), unsigned, stride, start)
+    for search in (calib._compute_amax_mse, calib._compute_amax_mse_qdq):
+        with pytest.raises(ValueError, match="no candidate"):
+            search(counts, edges, num_bits, unsigned, stride, nb)
+        with pytest.raises(TypeError, match="Invalid num_bits"):
+            search(counts, edges, (5, 2), unsigned, stride, start)
 
 
 def test_awq_weight_scale_vs_oracle_and_reference(golden):

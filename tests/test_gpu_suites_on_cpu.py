@@ -37,7 +37,7 @@ SELECTED = {
     "test_gpu_input_quant": ["test_tensor_quantizer_takes_the_fused_pass",
                              "test_histogram_calibrator_later_batches_are_one_pass"],
     "test_gpu_calibrate_weights": ["test_row_hist_equals_numpy_on_reference_weights", "test_calibrate_weights_matches_reference_run",
-                                   "test_calibrate_weights_mse_threshold"],
+                                   "test_calibrate_weights_mse_threshold", "test_calibrate_weights_mse_matches_reference_run"],
     "test_gpu_fp8_2d": ["test_fp8_qtensor_2d_blocks_match_reference_run", "test_fp8_2d_blockwise_export_is_byte_identical",
                         "test_reduce_block_amax_and_padding"],
     "test_gpu_mxfp8": ["test_mxfp8_qtensor_matches_reference_run", "test_mxfp8_rejects_wrong_scale_dtype_and_block",

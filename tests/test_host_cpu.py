@@ -26,6 +26,12 @@ def test_histogram_threshold_searches_match_reference(golden):
         ent = calib._compute_amax_entropy(hist, edges, 8, False, 1, 64)
         assert torch.equal(pct.reshape(1), g.t(f"{k}_pct")), f"percentile {k}"
         assert torch.equal(ent.reshape(1), g.t(f"{k}_ent")), f"entropy {k}"
+        # "mse" as the reference computes it (bit width in the bias slot, calib._compute_amax_mse): signed, unsigned (all
+        # NaN: the first candidate), and scaled edges that reach the non-degenerate branch
+        h_t, e_t = torch.from_numpy(hist), torch.from_numpy(edges)
+        for tag, args in (("mse", (h_t, e_t, 8, False, 1, 64)), ("mseu", (h_t, e_t, 8, True, 1, 64)),
+                          ("mse100", (h_t, e_t * 100, 8, False, 1, 16)), ("mse4s3", (h_t, e_t * 37, 4, False, 3, 16))):
+            assert torch.equal(calib._compute_amax_mse(*args).reshape(1), g.t(f"{k}_{tag}")), f"{tag} {k}"
     with pytest.raises(ValueError):
         calib._compute_amax_percentile(hist, edges, 101)
 
