@@ -286,41 +286,71 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     return model
 
 
+# algorithms that only write TensorQuantizer amax (QuantizeAlgorithmConfig._mutates_weights False, config.py:784-843):
+# the only ones whose layer-by-layer checkpoints may leave the weights out
+_AMAX_ONLY_ALGORITHMS = ("max", "mse", "local_hessian")
+
+
+def _layerwise_options(method, kwargs: dict) -> dict | None:
+    """The `layerwise` entry of an algorithm dict as LayerwiseConfig reads it (config.py:711-843): None / {} = off, a
+    bool = {"enable": bool}, a dict with enable / get_qdq_activations_from_prev_layer / checkpoint_dir / save_every /
+    calib_mutates_weights.  Same refusals: a checkpoint directory without enable, calib_mutates_weights=False for an
+    algorithm that writes weights; GPTQ's next-layer inputs default to the quantized predecessor (:1243-1250)."""
+    lw = kwargs.pop("layerwise", None)
+    lw = {} if lw is None else {"enable": lw} if isinstance(lw, bool) else dict(lw)
+    unknown = set(lw) - {"enable", "get_qdq_activations_from_prev_layer", "checkpoint_dir", "save_every",
+                         "calib_mutates_weights", "capture"}
+    if unknown:
+        raise ValueError(f"unknown layerwise option(s) {sorted(unknown)}")
+    if lw.get("checkpoint_dir") is not None and not lw.get("enable", False):
+        raise ValueError("layerwise.checkpoint_dir requires layerwise.enable=True. "
+                         "Set layerwise.enable=True or remove layerwise.checkpoint_dir.")
+    if lw.get("calib_mutates_weights", True) is False and method not in _AMAX_ONLY_ALGORITHMS:
+        raise ValueError(f"Algorithm '{method}' mutates layer weights in-place; calib_mutates_weights=False would lose "
+                         "those updates on resume. Only max/mse/local_hessian (amax-only) support this flag.")
+    if not lw.get("enable", False):
+        return None
+    return {"checkpoint_dir": lw.get("checkpoint_dir"),
+            "get_qdq_activations_from_prev_layer": bool(lw.get("get_qdq_activations_from_prev_layer", method == "gptq")),
+            "save_every": int(lw.get("save_every", 1)),
+            "calib_mutates_weights": bool(lw.get("calib_mutates_weights", True)),
+            "capture": lw.get("capture", "parent")}
+
+
 def _run_algorithm(model: nn.Module, algo, forward_loop):
+    """One calibration algorithm on the model -- or, with `layerwise.enable`, on one decoder layer at a time
+    (wrapped_calib_func, mode.py:215-277: every algorithm of this path takes the layer-by-layer wrapper)."""
     method, kwargs = (algo, {}) if not isinstance(algo, dict) else (algo["method"], {k: v for k, v in algo.items() if k != "method"})
     if method is None:
         return model
+    lw = _layerwise_options(method, kwargs)
     if method == "max":  # MaxCalibConfig.distributed_sync (config.py): off for callers that synchronise by their own rules
-        model_calib.max_calibrate(model, forward_loop, distributed_sync=bool(kwargs.get("distributed_sync", True)),
-                                  shard_weights=kwargs.get("shard_weights"))
+        func = model_calib.max_calibrate
+        kwargs = {"distributed_sync": bool(kwargs.get("distributed_sync", True)), "shard_weights": kwargs.get("shard_weights")}
     elif method == "mse":
-        model_calib.mse_calibrate(model, forward_loop, **kwargs)
+        func = model_calib.mse_calibrate
     elif method == "local_hessian":
-        model_calib.local_hessian_calibrate(model, forward_loop, **kwargs)
+        func = model_calib.local_hessian_calibrate
     elif method == "smoothquant":
-        model_calib.smoothquant(model, forward_loop, **kwargs)
+        func = model_calib.smoothquant
     elif method in ("awq_lite", "awq_clip", "awq_full"):
-        model_calib.awq(model, forward_loop, algorithm=method, **kwargs)
+        func, kwargs = model_calib.awq, {**kwargs, "algorithm": method}
     elif method == "gptq":
-        # GPTQCalibConfig (config.py:1204-1250): perc_damp, block_size, fused; `layerwise` = LayerwiseConfig, whose
-        # get_qdq_activations_from_prev_layer defaults to True for this algorithm (every layer's Hessian sees the
-        # quantized output of its predecessors)
+        # GPTQCalibConfig (config.py:1204-1250): perc_damp, block_size, fused
         from . import gptq as _gptq
-        from . import layerwise as _layerwise
 
-        lw = kwargs.pop("layerwise", None) or {}
-        lw = {"enable": bool(lw)} if isinstance(lw, bool) else dict(lw)
-        gk = {k: kwargs[k] for k in ("perc_damp", "block_size", "fused", "shard_weights", "report_mse") if kwargs.get(k) is not None}
-        if lw.get("enable", False):
-            if lw.get("calib_mutates_weights", True) is False:
-                raise ValueError("layerwise.calib_mutates_weights=False is rejected for weight-mutating algorithms (gptq)")
-            _layerwise.layerwise_calibrate(model, forward_loop, _gptq.gptq, checkpoint_dir=lw.get("checkpoint_dir"),
-                                           get_qdq_activations_from_prev_layer=lw.get("get_qdq_activations_from_prev_layer", True),
-                                           calib_mutates_weights=True, **gk)
-        else:
-            _gptq.gptq(model, forward_loop, **gk)
+        func = _gptq.gptq
+        kwargs = {k: kwargs[k] for k in ("perc_damp", "block_size", "fused", "shard_weights", "report_mse") if kwargs.get(k) is not None}
     else:
         raise ValueError(f"algorithm {method!r} is outside this path")
+    if lw is None:
+        func(model, forward_loop, **kwargs)
+        return model
+    if forward_loop is None:
+        raise ValueError("forward_loop is required for calibration but got None.")
+    from . import layerwise as _layerwise
+
+    _layerwise.layerwise_calibrate(model, forward_loop, func, **lw, **kwargs)
     return model
 
 

@@ -174,3 +174,31 @@ def test_layerwise_runs_without_autograd(tmp_path):
         inputs = layerwise._replay_to_layer(model, model.layers, 2, lambda m: [m(b) for b in batches])
     assert seen and not any(seen), "autograd was enabled inside the layerwise flow"
     assert all(not a.requires_grad for args, _ in inputs for a in args if isinstance(a, torch.Tensor))
+
+
+def test_parent_walk_hands_every_block_its_own_arguments():
+    """The default capture mode runs the PARENT's forward for every layer (layerwise.DecoderWalk: finished blocks are
+    meta placeholders, the previous block replays its recorded inputs, the target records and stops), so arguments the
+    parent computes per block reach each block; the hand-over of the first call's arguments does not see them."""
+
+    class PerLayer(Stack):
+        def forward(self, x):
+            h = self.embed(x)
+            for i, layer in enumerate(self.layers):
+                h = layer(h, scale=0.25 * (i + 1))
+            return h
+
+    torch.manual_seed(0)
+    model = PerLayer().to(DEV).to(torch.bfloat16)
+    batches = [torch.randn(16, 128, device=DEV).to(torch.bfloat16) for _ in range(3)]
+    moa.nn.replace_quant_module(model)
+    model_quant.set_quantizer_by_cfg(model, {**model_quant.FP8_DEFAULT_CFG["quant_cfg"], "*embed*": {"enable": False}})
+    whole, handed = copy.deepcopy(model), copy.deepcopy(model)
+    model_calib.max_calibrate(whole, lambda m: [m(b) for b in batches])
+    assert layerwise.layerwise_calibrate(model, lambda m: [m(b) for b in batches], model_calib.max_calibrate) == 4
+    a, b = _amax(whole), _amax(model)
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert all("forward" not in m.__dict__ for m in model.modules())
+    layerwise.layerwise_calibrate(handed, lambda m: [m(b) for b in batches], model_calib.max_calibrate, capture="handover")
+    c = _amax(handed)
+    assert any(not torch.equal(a[k], c[k]) for k in a if ".layers.0." not in k)
