@@ -383,6 +383,11 @@ def layerwise_calibrate(model: nn.Module, forward_loop, calib_func, layers=None,
     start, inputs, out_descs = 0, None, [None] * n_layers
     manifest_path = os.path.join(checkpoint_dir, "manifest.json") if checkpoint_dir else None
     if checkpoint_dir:
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # (utils/layerwise_calib.py:574-579) every rank would write the same files; a resumed rank would restore
+            # state its peers do not have
+            raise RuntimeError("Layerwise calibration checkpointing is not supported in multi-process distributed jobs. "
+                               "Use single-process calibration or disable checkpointing.")
         os.makedirs(checkpoint_dir, exist_ok=True)
         start, _ = _read_manifest(checkpoint_dir, n_layers, save_every, bool(calib_mutates_weights))
         for i in range(start):  # restore finished layers

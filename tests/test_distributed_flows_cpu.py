@@ -255,6 +255,35 @@ def _job_awq_layer_local(rank, world, moa, single):
            "contenders": {n: h.contenders for n, h in hs.items()}}
 
 
+def _job_layerwise(rank, world, moa, single):
+    """`algorithm.layerwise` under data parallelism: the walk runs on every rank over its own batches, each layer's
+    calibration function reduces its statistics across the ranks before the next layer is walked -- amax (max: bit for
+    bit) and AWQ alphas / folded weights equal the single-rank layer-by-layer run.  A checkpoint directory is refused in a
+    multi-process job, as in the reference (utils/layerwise_calib.py:574-579)."""
+    mq = moa.model_quant
+    for preset, method in (("FP8_DEFAULT_CFG", "max"), ("INT4_AWQ_CFG", "awq_lite")):
+        cfg = copy.deepcopy(getattr(mq, preset))
+        cfg["quant_cfg"]["*embed*"] = {"enable": False}
+        if method == "awq_lite":
+            cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
+        cfg["algorithm"] = {"method": method, "layerwise": {"enable": True}}
+        batches = _batches(128, torch.bfloat16, n=_n_batches(world))
+        mine = batches if single else batches[rank::world]
+        model = moa.quantize(_DecoderStack(), cfg, lambda m: [m(b) for b in mine])
+        out = {"amax": _amaxes(model)}
+        if method == "awq_lite":
+            out["alpha"] = {n: m.awq_lite.best_alpha for n, m in model.named_modules() if hasattr(m, "awq_lite")}
+            out["w"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        yield out
+    if not single:
+        import tempfile
+
+        cfg = copy.deepcopy(mq.FP8_DEFAULT_CFG)
+        cfg["algorithm"] = {"method": "max", "layerwise": {"enable": True, "checkpoint_dir": tempfile.mkdtemp()}}
+        with pytest.raises(RuntimeError, match="multi-process"):
+            moa.quantize(_DecoderStack(), cfg, lambda m: [m(b) for b in mine])
+
+
 def _job_gptq(rank, world, moa, single):
     """GPTQ under data parallelism: every rank accumulates the Hessians of its share of the batches, the distinct Hessians
     are combined sample-weighted on one owner each, the owner updates the linears that read them and broadcasts the
@@ -356,7 +385,7 @@ def _compare(kind, want, got):
                     continue
                 if key in ("alpha", "contenders"):
                     assert x == y, f"{kind}[{i}] {key} {name}: {x} vs {y}"
-                elif key in ("act_scale", "loss") or (kind.startswith("awq") and key in ("amax", "w")):
+                elif key in ("act_scale", "loss") or ((kind.startswith("awq") or (kind == "layerwise" and i == 1)) and key in ("amax", "w")):
                     # averages / sums over ranks associate differently from the single-rank order (fp32)
                     tol = 1e-6 if key == "act_scale" else 2e-2
                     assert torch.allclose(x.float(), y.float(), rtol=tol, atol=0), f"{kind}[{i}] {key} {name}"
@@ -410,7 +439,7 @@ def _worker(rank, world, port, kind, ret):
 
 
 @pytest.mark.parametrize("kind", ["max_and_smoothquant", "histogram", "awq", "awq_layer_local", "tensor_parallel", "weight_side",
-                                  "undeclared", "gptq"])
+                                  "undeclared", "gptq", "layerwise"])
 def test_data_parallel_flow_equals_single_rank(kind):
     world = 2
     mgr = mp.Manager()
