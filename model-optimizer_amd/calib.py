@@ -163,6 +163,68 @@ class MaxCalibrator(_Calibrator):
         return f"MaxCalibrator(track_amax={self._track_amax})"
 
 
+class BiasCalibrator(_Calibrator):
+    """The offset of affine quantization (calib/bias.py:102-178): the quantizer subtracts it before the QDQ and adds it
+    back afterwards (KV caches whose keys sit off-centre: FP8_AFFINE_KV_CFG).  `axis` lists the dims that are REDUCED
+    (bias.py:41-50 -- the key / value states [batch, heads, tokens, head_dim] with axis (-2, -4) keep one offset per
+    head and channel).  "mean": the mean of every collected tensor, averaged over the calls (fp32 running average,
+    stored in the tensor's dtype); "max_min": the midpoint of the running extremes.
+
+    A host mirror: torch reductions in the reference's order (the offset is a [1, heads, 1, head_dim]-sized statistic
+    of a tensor the abs-max kernel reads anyway; no kernel of its own)."""
+
+    def __init__(self, method: str = "mean", axis=None):
+        super().__init__(axis=axis)
+        self._method = method
+        self.reset()
+
+    def reset(self):
+        self._calib_bias = self._calib_max = self._calib_min = None
+        self._cnt = 0
+
+    def _reduced_dims(self, x):
+        return tuple(i for i in range(x.dim()) if i in self._axis or (i - x.dim()) in self._axis)
+
+    def _extremes(self, x):
+        if self._axis is None:
+            return torch.max(x), torch.min(x)
+        dims = self._reduced_dims(x)
+        return torch.amax(x, dim=dims, keepdim=True), torch.amin(x, dim=dims, keepdim=True)
+
+    def _of(self, x, method):
+        if method != "mean":
+            hi, lo = self._extremes(x)
+            return (hi + lo) / 2
+        return torch.mean(x) if self._axis is None else torch.mean(x, dim=self._reduced_dims(x), keepdim=True)
+
+    def collect(self, x):
+        if self._method == "mean":
+            now = self._of(x, "mean")
+            if self._calib_bias is None:
+                self._calib_bias = now
+            else:
+                self._calib_bias = ((self._calib_bias.float() * self._cnt + now.float()) / (self._cnt + 1)).to(now.dtype)
+            self._cnt += 1
+        elif self._method == "max_min":
+            hi, lo = self._extremes(x)
+            self._calib_max = hi if self._calib_max is None else torch.max(self._calib_max, hi)
+            self._calib_min = lo if self._calib_min is None else torch.min(self._calib_min, lo)
+            self._calib_bias = (self._calib_max + self._calib_min) / 2
+        else:
+            raise ValueError(f"Unsupported method: {self._method}")
+
+    def compute_bias(self):
+        return self._calib_bias
+
+    def compute_dynamic_bias(self, inputs):
+        if self._method not in ("mean", "max_min"):
+            raise ValueError(f"Unknown bias method: {self._method}")
+        return self._of(inputs, self._method)
+
+    def compute_amax(self, *args, **kwargs):  # not an amax calibrator
+        raise NotImplementedError
+
+
 class HistogramCalibrator(_Calibrator):
     """|x| histogram with the reference's growth rule -- calib/histogram.py:36-205."""
 

@@ -88,6 +88,8 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
                 if hasattr(q, "_amax") and q._amax.shape != amax.shape:
                     delattr(q, "_amax")
                 q.amax = amax
+        if q.bias_calibrator is not None and q.bias_type == "static":
+            q.load_calib_bias()  # the affine offset of the KV-cache presets (:1163-1164)
         q.enable_quant()  # dynamic quantizers come back on here (:1166)
         q.disable_calib()
 
@@ -113,7 +115,7 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
     for w, wq in pairs:
         per_tensor_max = (isinstance(wq, TensorQuantizer) and wq._if_calib and wq.axis is None and wq.block_sizes is None
                           and type(wq._calibrator).__name__ == "MaxCalibrator" and w.is_cuda
-                          and w.is_contiguous() and wq.pre_quant_scale is None)
+                          and w.is_contiguous() and wq.pre_quant_scale is None and wq.bias is None)
         if per_tensor_max:
             batched.append((w, wq))
         else:

@@ -103,6 +103,13 @@ FP8_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "axis": 
               "algorithm": "max"}
 
 
+# presets/kv/fp8_affine.yaml (units/kv_fp8_affine.yaml): the same with an offset per head and channel (mean over batch
+# and tokens of the [batch, heads, tokens, head_dim] states), exported as k_proj.k_bias / v_proj.v_bias
+FP8_AFFINE_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "axis": None, "enable": True,
+                                                           "bias": {-2: None, -4: None, "type": "static"}}},
+                     "algorithm": "max"}
+
+
 def update_quant_cfg_with_kv_cache_quant(quant_cfg: dict, kv_cache_quant_cfg: dict) -> dict:
     """utils/core_utils.py:1049-1075: a copy of `quant_cfg` with the KV-cache entries appended (later entries win);
     a config without an algorithm gets "max" so that the KV quantizers are calibrated."""

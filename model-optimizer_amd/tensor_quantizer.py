@@ -8,8 +8,8 @@ allows it (static-block INT with dynamic amax, optionally with a per-column pre_
 search inner loop), and otherwise one kernel per stage.  GPU tensors only: there is no CPU path.
 
 Scope: fake quantization for INT-k (per-tensor / per-channel / static last-axis blocks), FP8-E4M3
-(per-tensor / per-channel) and dynamic MX blocks.  N-D (non-last-axis) block layouts, rotation, bias
-calibration and real-quant QTensors are outside this path and raise.
+(per-tensor / per-channel), dynamic MX blocks, and the affine offset (`bias`) of the KV-cache presets.  N-D
+(non-last-axis) block layouts, rotation and real-quant QTensors are outside this path and raise.
 """
 
 from __future__ import annotations
@@ -25,7 +25,7 @@ from torch import nn
 
 from . import ops
 from ._lib import MoquantUnsupported
-from .calib import HistogramCalibrator, MaxCalibrator, _Calibrator, convert_quantization_axis_to_reduce_axis
+from .calib import BiasCalibrator, HistogramCalibrator, MaxCalibrator, _Calibrator, convert_quantization_axis_to_reduce_axis
 
 
 @dataclass
@@ -42,7 +42,23 @@ class QuantizerAttributeConfig:
     enable: bool = True
     type: str = "static"  # "dynamic": amax recomputed from every input, never calibrated (config.py:478-489)
     learn_amax: bool = False
+    # affine quantization (config.py:523-588): {reduced dim: None, ..., "type": "static" | "dynamic", "method": "mean" | "max_min"}
+    bias: dict | None = None
     extra: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        v = self.bias
+        if v is None:
+            return
+        if "type" in v and v["type"] not in ("static", "dynamic"):
+            raise ValueError(f"Invalid bias type: {v['type']}, expected 'static' or 'dynamic'")
+        if "method" in v and v["method"] not in ("mean", "max_min"):
+            raise ValueError(f"Invalid bias method: {v['method']}, expected 'mean' or 'max_min'")
+        axis = [k for k in v if k not in ("type", "method")]
+        assert len(axis) > 0, "The axis for bias computation is not specified."
+        for x in axis:
+            if not isinstance(x, int):
+                raise ValueError(f"Invalid axis type {type(axis)}, expected int")
 
 
 class TensorQuantizer(nn.Module):
@@ -62,6 +78,8 @@ class TensorQuantizer(nn.Module):
         self._if_calib = if_calib
         self._enable_pre_quant_scale = True
         self._calibrator = self._make_calibrator(cfg.calibrator)
+        self._bias = dict(cfg.bias) if cfg.bias else None
+        self._bias_calibrator = None  # made on first use (tensor_quantizer.py:222-223, :490-503)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
         if amax is not None:
@@ -72,9 +90,11 @@ class TensorQuantizer(nn.Module):
 
     def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
         """tensor_quantizer.py:228-290: (re)configure in place; calibration state is dropped."""
-        for name in ("_amax", "_pre_quant_scale"):
+        for name in ("_amax", "_pre_quant_scale", "_bias_value"):
             if hasattr(self, name):
                 delattr(self, name)
+        self._bias = dict(cfg.bias) if cfg.bias else None
+        self._bias_calibrator = None
         for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export"):
             self.__dict__.pop(name, None)
         if not cfg.fake_quant:
@@ -179,6 +199,78 @@ class TensorQuantizer(nn.Module):
         if hasattr(self, "_amax"):
             delattr(self, "_amax")
         self._calibrator.reset()
+        self.reset_bias()
+
+    # ------------------------------------------------------------------ affine offset (tensor_quantizer.py:389-503, :722-734, :775-786)
+    bias = property(lambda self: self._bias)
+    bias_method = property(lambda self: None if self._bias is None else self._bias.get("method", "mean"))
+
+    @property
+    def bias_type(self):
+        return None if self._bias is None else self._bias.get("type", "static")
+
+    @bias_type.setter
+    def bias_type(self, value):
+        assert value in ("static", "dynamic"), "bias_type must be either 'static' or 'dynamic'."
+        self._bias["type"] = value
+
+    @property
+    def bias_axis(self):
+        return getattr(self, "_bias_axis", None)
+
+    @bias_axis.setter
+    def bias_axis(self, value):
+        assert value is not None, "bias_axis cannot be set to None."
+        assert isinstance(value, (tuple, list)), "bias_axis must be a tuple or a list."
+        self._bias_axis = value
+
+    @property
+    def bias_value(self):
+        return getattr(self, "_bias_value", None)
+
+    @bias_value.setter
+    def bias_value(self, value):
+        assert value is not None, "bias cannot be set to None."
+        if not isinstance(value, torch.Tensor):
+            value = torch.tensor(value)
+        if not hasattr(self, "_bias_value"):
+            self.register_buffer("_bias_value", value.clone().detach())
+        else:
+            if self._bias_value.shape != value.shape:
+                raise RuntimeError("Changing shape when setting bias is not allowed.")
+            self._bias_value.data.copy_(value.clone().detach().to(self._bias_value.device))
+
+    @property
+    def bias_calibrator(self):
+        if self._bias_calibrator is None and self._bias is not None:
+            self.bias_axis = tuple(k for k in self._bias if isinstance(k, int))
+            self._bias_calibrator = BiasCalibrator(method=self.bias_method, axis=self.bias_axis)
+        return self._bias_calibrator
+
+    def reset_bias(self):
+        if hasattr(self, "_bias_value"):
+            delattr(self, "_bias_value")
+        if self._bias_calibrator is not None:
+            self._bias_calibrator.reset()
+
+    def load_calib_bias(self, *args, **kwargs):
+        assert not self._dynamic, "Dynamic quantization does not need calibration."
+        calib_bias = self.bias_calibrator.compute_bias(*args, **kwargs)
+        if calib_bias is None:
+            raise RuntimeError("Calibrator returned None. This usually happens when calibrator hasn't seen any tensor.")
+        if not hasattr(self, "_bias_value"):
+            self.register_buffer("_bias_value", calib_bias.clone().detach())
+        else:
+            self._bias_value.data.copy_(calib_bias.clone().detach())
+
+    def _get_bias(self, inputs):
+        if self.bias_calibrator is None:
+            return None
+        if self.bias_type == "static":
+            return self._bias_value
+        if self.bias_type == "dynamic":
+            return self.bias_calibrator.compute_dynamic_bias(inputs)
+        raise ValueError(f"Unsupported bias type: {self.bias_type}")
 
     @property
     def pre_quant_scale(self):
@@ -206,7 +298,7 @@ class TensorQuantizer(nn.Module):
         """model_calib.weight_only_quantize collected this quantizer's max statistics from `weight`: calls with the same,
         unchanged tensor are pass-throughs until the calibration ends (disable_calib / reset_amax).  Only running-max
         calibrators qualify (a histogram would count the weight once per forward in the reference)."""
-        if type(self._calibrator).__name__ == "MaxCalibrator" and self.pre_quant_scale is None:
+        if type(self._calibrator).__name__ == "MaxCalibrator" and self.pre_quant_scale is None and self._bias is None:
             self._weight_stats_done = (weight.data_ptr(), weight._version, tuple(weight.shape))
 
     def enable_calib(self):
@@ -344,9 +436,22 @@ class TensorQuantizer(nn.Module):
     def collect(self, inputs):
         if not self._if_calib or self._dynamic:
             return
+        if self._bias is not None and self.bias_type == "static":
+            # the offset first, the abs-max of what is left after it (tensor_quantizer.py:1402-1407)
+            self.bias_calibrator.collect(inputs)
+            inputs = inputs - self.bias_calibrator.compute_bias()
         self._calibrator.collect(inputs)
 
     def _fake_quantize(self, inputs):
+        bias = None if self._bias is None or self._block_dynamic else self._get_bias(inputs)
+        if bias is None:  # (dynamic block formats take no offset: tensor_quant.py:539-561)
+            return self._fake_quantize_at(inputs, None)
+        # the amax is the calibrated one, or that of the input as it came (tensor_quantizer.py:899-901); the grid is laid
+        # around the offset: QDQ(x - bias) + bias (tensor_quant.py:364-392, :438-453)
+        amax = self._get_amax(inputs)
+        return self._fake_quantize_at(inputs - bias, amax) + bias
+
+    def _fake_quantize_at(self, inputs, amax):
         if self._block_dynamic:
             g = self._block_sizes.get(-1, None) or self._block_sizes.get(inputs.dim() - 1, None)
             if g is None:
@@ -357,20 +462,20 @@ class TensorQuantizer(nn.Module):
         if isinstance(self._num_bits, tuple):
             if tuple(self._num_bits) != (4, 3):
                 raise MoquantUnsupported(f"float format {self._num_bits} without dynamic blocks")
-            return ops.scaled_e4m3(inputs, self._get_amax(inputs))
-        if self.is_static_block_quant and not hasattr(self, "_amax") and inputs.dim() == 2:
+            return ops.scaled_e4m3(inputs, self._get_amax(inputs) if amax is None else amax)
+        if amax is None and self.is_static_block_quant and not hasattr(self, "_amax") and inputs.dim() == 2:
             # dynamic per-block amax + QDQ in one pass (what _get_amax + fake_tensor_quant do in two)
             y, _ = ops.amax_qdq_int_group(inputs, inputs.shape[-1], self._num_bits, self._unsigned,
                                           self._narrow_range, return_amax=False)
             return y
-        return ops.fake_tensor_quant(inputs, self._get_amax(inputs), self._num_bits, self._unsigned,
-                                     self._narrow_range)
+        return ops.fake_tensor_quant(inputs, self._get_amax(inputs) if amax is None else amax, self._num_bits,
+                                     self._unsigned, self._narrow_range)
 
     def _fused_input_pass(self, inputs, pqs):
         """pre_quant_scale * x -> collect -> fake-quantize of a PER-TENSOR quantizer as ONE kernel pass over the
         activation (ops.input_quant; the reference runs a multiply, an amax + amin pair and ~8 elementwise kernels,
         tensor_quantizer.py:1143-1212).  Returns the output, or None when this call is not of that shape."""
-        if (self._disabled or inputs.dtype not in (torch.float32, torch.float16, torch.bfloat16)
+        if (self._disabled or self._bias is not None or inputs.dtype not in (torch.float32, torch.float16, torch.bfloat16)
                 or self._axis is not None or self._block_sizes is not None or self._dynamic
                 or not (self._if_quant or self._if_calib) or pqs.numel() != inputs.shape[-1] or pqs.numel() < 2
                 or inputs.shape[-1] % (4 if inputs.dtype == torch.float32 else 8)):
@@ -401,7 +506,7 @@ class TensorQuantizer(nn.Module):
         if inputs.numel() == 0:
             return inputs
         if (self._if_calib and not self._if_quant and not self._disabled and not self._dynamic and self._block_sizes is None
-                and self._axis is None and self._weight_stats_done is None and "_pre_quant_scale" not in self._buffers
+                and self._axis is None and self._bias is None and self._weight_stats_done is None and "_pre_quant_scale" not in self._buffers
                 and type(self._calibrator) is MaxCalibrator and self._calibrator.collect_per_tensor_fast(inputs)):
             # a per-tensor max-calibrated activation quantizer inside the calibration loop: statistics only, the input
             # passes through (the general path below does exactly this, through a dozen more host-side steps)
@@ -419,8 +524,8 @@ class TensorQuantizer(nn.Module):
             out = self._fused_input_pass(inputs, pqs)
             if out is not None:
                 return out
-            can_fuse = (not self._disabled and self._if_quant and not self._if_calib and self.is_static_block_quant
-                        and not hasattr(self, "_amax") and isinstance(self._num_bits, int) and not self._unsigned
+            can_fuse = (not self._disabled and self._bias is None and self._if_quant and not self._if_calib
+                        and self.is_static_block_quant and not hasattr(self, "_amax") and isinstance(self._num_bits, int) and not self._unsigned
                         and not self._narrow_range and inputs.dim() == 2 and pqs.numel() == inputs.shape[-1])
             if can_fuse:
                 g = self._block_size_last(inputs)
@@ -455,7 +560,8 @@ class TensorQuantizer(nn.Module):
     def extra_repr(self):
         return (f"{self._num_bits} bit fake axis={self._axis} block_sizes={self._block_sizes} "
                 f"amax={'dynamic' if self.amax is None else tuple(self.amax.shape)} "
-                f"calibrator={type(self._calibrator).__name__} quant={'on' if self._if_quant else 'off'}"
+                f"calibrator={type(self._calibrator).__name__}{f' bias={self._bias}' if self._bias else ''} "
+                f"quant={'on' if self._if_quant else 'off'}"
                 f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")
 
 

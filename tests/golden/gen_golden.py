@@ -36,6 +36,8 @@ What is produced (every array is the reference's own output on seeded inputs tha
   export_llama_fp8_2d.npz -- FP8 2-D blockwise weight-only export of a tiny Llama + FP8QTensor with blocks on both axes
   export_llama_int8_sq.npz -- INT8 SmoothQuant export of the tiny Llama (pre-export state + exported tensors)
   mse.npz       -- MseCalibrator losses / chosen amax (calib/mse.py:83-172) and mtq.quantize(algorithm="mse")
+  affine_bias.npz -- TensorQuantizer with an affine offset (`bias`: static / dynamic, mean / max_min, per tensor / per head and
+                   channel; FP8 and INT8): calibrated offset and amax, outputs
   mx_vectors.json -- the literal MX golden vectors of tests/gpu/torch/quantization/
                    test_quantize_mxformats_cuda.py (extracted from the test source with ast, not run:
                    the MX kernels have no CPU implementation in the reference)
@@ -705,6 +707,48 @@ def gen_local_hessian(out):
             for lname in ("fc1", "fc2"):
                 out[f"{name}_{alg_name}_{lname}_amax"] = bits(getattr(q, lname).weight_quantizer._amax.float())
         cases[name] = dict(dtype=str(dt).split(".")[-1], n_batches=len(batches))
+    out["cases"] = np.array(json.dumps(cases))
+
+
+def gen_affine_bias(out):
+    """TensorQuantizer(bias=...) on key / value-shaped states [batch, heads, tokens, head_dim] (tensor_quantizer.py:389-503,
+    :1397-1407; calib/bias.py): three calibration batches with an off-centre distribution per head and channel, then the
+    fake-quantized first batch.  Static offsets are calibrated before the abs-max (which sees the centred tensor); dynamic
+    ones are recomputed per call and the amax is that of the tensor as it came."""
+    cases = {}
+    specs = [("fp8_static_mean_head", (4, 3), {-2: None, -4: None, "type": "static"}),
+             ("fp8_static_maxmin_head", (4, 3), {-2: None, -4: None, "type": "static", "method": "max_min"}),
+             ("int8_static_mean_tensor", 8, {-1: None, -2: None, -3: None, -4: None, "type": "static"}),
+             ("int8_static_mean_channel", 8, {-2: None, -3: None, -4: None}),
+             ("fp8_dynamic_mean_head", (4, 3), {-2: None, -4: None, "type": "dynamic"}),
+             ("int8_dynamic_maxmin_token", 8, {-1: None, "type": "dynamic", "method": "max_min"})]
+    for dt_name in ("f32", "bf16"):
+        dt = DT[dt_name]
+        g = torch.Generator().manual_seed(77)
+        centre = torch.randn(1, 3, 1, 16, generator=g) * 2.0
+        xs = [((torch.randn(2, 3, 10, 16, generator=g) * (0.5 + i) + centre)).to(dt) for i in range(3)]
+        for i, x in enumerate(xs):
+            out[f"{dt_name}_x{i}"] = bits(x)
+        for name, nb, bias in specs:
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, axis=None, bias=dict(bias)))
+            static = bias.get("type", "static") == "static"
+            q.disable_quant()
+            q.enable_calib()
+            for x in xs:
+                q(x)
+            q.load_calib_amax()
+            if static:
+                q.load_calib_bias()
+            q.enable_quant()
+            q.disable_calib()
+            key = f"{dt_name}_{name}"
+            out[f"{key}_amax"] = bits(q._amax.float())
+            if static:
+                out[f"{key}_bias"] = bits(q._bias_value)
+            out[f"{key}_y0"] = bits(q(xs[0]))
+            cases[key] = dict(dtype=dt_name, num_bits=list(nb) if isinstance(nb, tuple) else nb,
+                              bias={str(k): v for k, v in bias.items()}, static=static,
+                              bias_shape=list(q._bias_value.shape) if static else None)
     out["cases"] = np.array(json.dumps(cases))
 
 
@@ -1516,12 +1560,12 @@ def gen_mxfp8(out):
 def main():
     torch.manual_seed(1234)
     only = sys.argv[1:] or None
-    single = {"hist": gen_hist, "mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_configs": gen_export_configs, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
+    single = {"hist": gen_hist, "mse": gen_mse, "export_llama": gen_export, "awq_clip": gen_awq_clip, "qtensor": gen_qtensor, "w4a8": gen_w4a8, "sgpt": gen_sgpt, "gptq": gen_gptq, "local_hessian": gen_local_hessian, "affine_bias": gen_affine_bias, "gptq_llama": gen_gptq_llama, "block2d": gen_block2d, "export_llama_fp8": gen_export_fp8, "export_llama_mxfp4": gen_export_mxfp4, "export_configs": gen_export_configs, "export_llama_w4a8_mxfp4_fp8": gen_export_w4a8_mxfp4_fp8, "export_llama_mxfp4_mlp": gen_export_mxfp4_mlp, "export_llama_fp8_kv": gen_export_fp8_kv, "moe_fp8": gen_moe_fp8, "calibrate_weights": gen_calibrate_weights, "export_llama_fp8_2d": gen_export_fp8_2d, "export_llama_int8_sq": gen_export_int8_sq, "mxfp8": gen_mxfp8, "export_llama_replay": gen_export_replay, "sq_mxfp4": gen_sq_mxfp4, "export_llama_w4a8": gen_export_w4a8, "awq_ragged": gen_awq_ragged,
               "export_llama_fp8_pc_pt": gen_export_fp8_pc_pt}
     for name, fn in [(only[0], single[only[0]])] if only and only[0] in single else [("int_fq", gen_int_fq), ("fp8_fq", gen_fp8), ("amax", gen_amax),
                      ("tq_block", gen_tq_block), ("hist", gen_hist), ("mask24", gen_mask),
                      ("int4", gen_int4), ("awq", gen_awq), ("model_flows", gen_model_flows), ("mse", gen_mse),
-                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_configs", gen_export_configs), ("export_llama_w4a8_mxfp4_fp8", gen_export_w4a8_mxfp4_fp8), ("export_llama_mxfp4_mlp", gen_export_mxfp4_mlp), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
+                     ("export_llama", gen_export), ("awq_clip", gen_awq_clip), ("qtensor", gen_qtensor), ("w4a8", gen_w4a8), ("sgpt", gen_sgpt), ("gptq", gen_gptq), ("local_hessian", gen_local_hessian), ("affine_bias", gen_affine_bias), ("gptq_llama", gen_gptq_llama), ("block2d", gen_block2d), ("export_llama_fp8", gen_export_fp8), ("export_llama_mxfp4", gen_export_mxfp4), ("export_configs", gen_export_configs), ("export_llama_w4a8_mxfp4_fp8", gen_export_w4a8_mxfp4_fp8), ("export_llama_mxfp4_mlp", gen_export_mxfp4_mlp), ("export_llama_fp8_kv", gen_export_fp8_kv), ("moe_fp8", gen_moe_fp8), ("calibrate_weights", gen_calibrate_weights), ("export_llama_fp8_2d", gen_export_fp8_2d), ("export_llama_int8_sq", gen_export_int8_sq), ("mxfp8", gen_mxfp8), ("export_llama_replay", gen_export_replay), ("sq_mxfp4", gen_sq_mxfp4), ("export_llama_w4a8", gen_export_w4a8), ("awq_ragged", gen_awq_ragged),
                      ("export_llama_fp8_pc_pt", gen_export_fp8_pc_pt)]:
         out = {}
         fn(out)

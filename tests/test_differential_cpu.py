@@ -86,8 +86,9 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     cfg = copy.deepcopy(getattr(mtq, preset))
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
-    if with_kv:
-        cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
+    if with_kv:  # True: FP8 key / value quantizers; "affine": the same with a per-head per-channel offset
+        kv = mtq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mtq.FP8_KV_CFG
+        cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(kv["quant_cfg"]))
     batches = _batches()
     loop = (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None
     q = mtq.quantize(model, cfg, loop)
@@ -121,7 +122,7 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
-        cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, mq.FP8_KV_CFG["quant_cfg"])
+        cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, (mq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mq.FP8_KV_CFG)["quant_cfg"])
     batches = _batches()
     with torch.no_grad():
         moa.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
@@ -192,6 +193,9 @@ def _assert_same_quant_json(ours, ref, what=""):
     ("W4A8_AWQ_BETA_CFG", torch.bfloat16, True, "gemma2", None), ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "qwen3_moe", None),
     ("W4A8_MXFP4_FP8_CFG", torch.bfloat16, True, "phi3", None), ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.float16, False, "opt", None),
     ("MXFP8_DEFAULT_CFG", torch.bfloat16, True, "gpt2", None), ("INT8_DEFAULT_CFG", torch.bfloat16, True, "phi3", None),
+    # affine KV cache (FP8_AFFINE_KV_CFG): offsets calibrated before the abs-max, exported as k_proj.k_bias / v_proj.v_bias
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "llama", None), ("FP8_DEFAULT_CFG", torch.float32, "affine", "llama-eager", None),
+    ("FP8_DEFAULT_CFG", torch.float16, "affine", "qwen2", None), ("INT4_AWQ_CFG", torch.bfloat16, "affine", "mistral", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)

@@ -462,3 +462,52 @@ def test_local_hessian_calibrate_on_the_gpu_equals_the_reference_run(golden, nam
         same = (got == want).float().mean().item()
         assert same >= 0.97, f"{lname}: {same:.4f} of the amax entries equal the reference's"
 
+
+
+def test_affine_offset_of_the_kv_cache_presets_matches_the_reference_run(golden):
+    """TensorQuantizer(bias=...) (tensor_quantizer.py:389-503, calib/bias.py) against tests/golden/affine_bias.npz: static
+    and dynamic offsets, mean / max_min, per tensor / per head and channel, FP8 and INT8.  The offset is a torch reduction
+    (its last bit follows the device's summation order: compared to a few ulps on the GPU, bit for bit on the host tier);
+    FROM the reference's offset and amax the fake-quantized tensor is the reference's bit for bit."""
+    g = golden("affine_bias")
+    exact = not str(DEV).startswith("cuda")
+    for key, c in g.cases.items():
+        dt = DT[c["dtype"]]
+        xs = [g.t(f"{c['dtype']}_x{i}", dt).to(DEV) for i in range(3)]
+        nb = tuple(c["num_bits"]) if isinstance(c["num_bits"], list) else c["num_bits"]
+        bias = {(int(k) if k.lstrip("-").isdigit() else k): v for k, v in c["bias"].items()}
+        q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, axis=None, bias=bias))
+        q.disable_quant(); q.enable_calib()
+        for x in xs:
+            out = q(x)  # statistics only: the tensor passes through
+            assert out is x or torch.equal(out, x)
+        q.load_calib_amax()
+        if c["static"]:
+            q.load_calib_bias()
+            assert list(q._bias_value.shape) == c["bias_shape"] and q._bias_value.dtype == dt, key
+        q.enable_quant(); q.disable_calib()
+        want_amax, want_y = g.t(f"{key}_amax"), g.t(f"{key}_y0", dt)
+        ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -22
+        if c["static"]:
+            want_bias = g.t(f"{key}_bias", dt)
+            if exact:
+                assert_bits_equal(q._bias_value, want_bias, f"{key} offset")
+                assert_bits_equal(q._amax.float().cpu(), want_amax, f"{key} amax")
+            else:
+                scale = float(want_bias.float().abs().max())
+                assert torch.allclose(q._bias_value.float().cpu(), want_bias.float(), rtol=0, atol=4 * ulp * scale), key
+                assert torch.allclose(q._amax.float().cpu(), want_amax, rtol=8 * ulp, atol=0), key
+            q.bias_value = want_bias.to(DEV)  # from the reference's statistics the output is the reference's
+            q.amax = want_amax.to(q._amax.dtype).to(DEV)
+            assert_bits_equal(q(xs[0]), want_y, f"{key} output")
+            assert "_bias_value" in q.state_dict()
+        else:
+            assert_bits_equal(q._amax.float().cpu(), want_amax, f"{key} amax (of the tensor as it came)")
+            got = q(xs[0])
+            if exact:
+                assert_bits_equal(got, want_y, f"{key} output")
+            else:  # the per-call offset carries the device's summation order: within one quantization step
+                step = float(want_amax.max()) / (127.0 if nb == 8 else 8.0)
+                assert float((got.float().cpu() - want_y.float()).abs().max()) <= step, key
+        q.reset_amax()
+        assert q.bias_value is None and q.amax is None and q.bias_calibrator.compute_bias() is None
