@@ -46,6 +46,9 @@ def enable_stats_collection(model: nn.Module, distributed_sync: bool = False):
     for q in _quantizers(model):
         if not q.is_enabled:
             continue
+        if q._use_constant_amax or q._constant_amax is not None:
+            q.disable_quant()  # nothing to calibrate; no quantization error into the other quantizers' statistics (:1132-1136)
+            continue
         if q._calibrator is not None:
             q.disable_quant()
             q.enable_calib()
@@ -62,21 +65,25 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
     amax is computed (the reference leaves every rank with its own histogram, calib/histogram.py:158-163); running
     maxima need nothing here -- their amax is MAX-reduced afterwards (sync_amax_bucketed)."""
     qs = [q for q in _quantizers(model) if q.is_enabled]
+    live = [q for q in qs if not (q._use_constant_amax or q._constant_amax is not None)]  # the others were never calibrating
     if distributed_sync and _dist_on():
-        mdist.sync_calibrators_bucketed([q._calibrator for q in qs if q._calibrator is not None and not q._dynamic
+        mdist.sync_calibrators_bucketed([q._calibrator for q in live if q._calibrator is not None and not q._dynamic
                                          and hasattr(q._calibrator, "share_range_across_ranks")])
     # histogram calibrators: every threshold search is QUEUED first (device kernels, calib.HistogramCalibrator.begin_amax)
     # and read afterwards, so a model's searches overlap and the host does not wait once per quantizer
     tickets = {}
     if method:
-        for q in qs:
+        for q in live:
             if q._calibrator is not None and not q._dynamic and hasattr(q._calibrator, "begin_amax"):
                 tickets[id(q)] = q._calibrator.begin_amax(method, **kwargs)
     from .calib import MaxCalibrator
 
-    plain_max = [q._calibrator for q in qs if type(q._calibrator) is MaxCalibrator and not q._dynamic] if not method else []
+    plain_max = [q._calibrator for q in live if type(q._calibrator) is MaxCalibrator and not q._dynamic] if not method else []
     max_verified = bool(plain_max) and MaxCalibrator.verify_finite(plain_max)  # one host read for the NaN / inf asserts
     for q in qs:
+        if q._use_constant_amax or q._constant_amax is not None:
+            q.enable_quant()  # (:1150-1153)
+            continue
         if q._calibrator is not None and not q._dynamic:
             if id(q) in tickets:
                 amax = q._calibrator.finish_amax(tickets.pop(id(q)))

@@ -110,6 +110,13 @@ FP8_AFFINE_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "
                      "algorithm": "max"}
 
 
+# presets/kv/fp8_cast.yaml (units/kv_fp8_cast.yaml; hf_ptq.py's default `--kv_cache_qformat fp8_cast`): a plain E4M3 cast --
+# amax fixed at the format's range (448: scale 1), nothing calibrated, no k_scale / v_scale in the checkpoint
+FP8_CAST_KV_CFG = {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": (4, 3), "axis": None, "enable": True,
+                                                         "use_constant_amax": True}},
+                   "algorithm": "max"}
+
+
 def update_quant_cfg_with_kv_cache_quant(quant_cfg: dict, kv_cache_quant_cfg: dict) -> dict:
     """utils/core_utils.py:1049-1075: a copy of `quant_cfg` with the KV-cache entries appended (later entries win);
     a config without an algorithm gets "max" so that the KV quantizers are calibrated."""
@@ -289,6 +296,7 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     set_quantizer_by_cfg(model, config["quant_cfg"])
     stage("set_quantizers")
     _run_algorithm(model, config.get("algorithm", "max"), forward_loop)
+    _warn_invalid_quantizer_state(model)
     stage("calibrate")
     return model
 
@@ -361,6 +369,26 @@ def _run_algorithm(model: nn.Module, algo, forward_loop):
     return model
 
 
+def _warn_invalid_quantizer_state(model: nn.Module):
+    """The check mtq.calibrate ends with (quantization/model_quant.py:119-122): a warning for every `_amax` /
+    `_pre_quant_scale` that holds a negative, infinite or NaN entry.  The reference asks every quantizer (three reductions
+    and three host reads per buffer); here all buffers of a device go through ONE flattened test, and only a failing
+    model is walked quantizer by quantizer for the messages."""
+    import torch
+
+    found = [(name, attr, getattr(mod, attr)) for name, mod in model.named_modules() if isinstance(mod, TensorQuantizer)
+             for attr in ("_amax", "_pre_quant_scale") if isinstance(getattr(mod, attr, None), torch.Tensor)]
+    by_device: dict = {}
+    for _, _, t in found:
+        if not t.is_meta and t.numel():
+            by_device.setdefault(t.device, []).append(t.detach().reshape(-1).float())
+    ok = all(bool((torch.isfinite(flat) & (flat >= 0)).all()) for flat in (torch.cat(ts) for ts in by_device.values()))
+    if not ok:
+        owners = dict(model.named_modules())
+        for name, attr, _ in found:
+            owners[name].validate_attr(attr_name=attr, warn_error=True, name=name)
+
+
 def calibrate(model: nn.Module, algorithm="max", forward_loop=None) -> nn.Module:
     """mtq.calibrate (quantization/model_quant.py:64-129): run a calibration algorithm on a model whose quantizers are in
     place -- "max", "mse", "local_hessian", "smoothquant", "awq_lite" / "awq_clip" / "awq_full", "gptq", or a dict with
@@ -378,6 +406,7 @@ def calibrate(model: nn.Module, algorithm="max", forward_loop=None) -> nn.Module
     model.eval()
     try:
         _run_algorithm(model, algorithm, forward_loop)
+        _warn_invalid_quantizer_state(model)
     finally:
         model.train(training)
     return model

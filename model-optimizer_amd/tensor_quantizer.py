@@ -44,9 +44,16 @@ class QuantizerAttributeConfig:
     learn_amax: bool = False
     # affine quantization (config.py:523-588): {reduced dim: None, ..., "type": "static" | "dynamic", "method": "mean" | "max_min"}
     bias: dict | None = None
+    # amax without calibration (config.py:665-709): use_constant_amax = the FP8 E4M3 range (448) in the forward, no
+    # `_amax` buffer (the cast-style KV-cache presets); constant_amax = `_amax` pinned to the value, forward and export
+    use_constant_amax: bool = False
+    constant_amax: float | None = None
     extra: dict = field(default_factory=dict)
 
     def __post_init__(self):
+        assert self.constant_amax is None or self.constant_amax > 0, "constant_amax must be a positive value."
+        assert not (self.use_constant_amax and self.constant_amax is not None), \
+            "use_constant_amax and constant_amax are mutually exclusive; set only one."
         v = self.bias
         if v is None:
             return
@@ -80,6 +87,10 @@ class TensorQuantizer(nn.Module):
         self._calibrator = self._make_calibrator(cfg.calibrator)
         self._bias = dict(cfg.bias) if cfg.bias else None
         self._bias_calibrator = None  # made on first use (tensor_quantizer.py:222-223, :490-503)
+        self._use_constant_amax = bool(cfg.use_constant_amax)
+        self._constant_amax = cfg.constant_amax
+        if cfg.constant_amax is not None:
+            self.amax = float(cfg.constant_amax)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
         if amax is not None:
@@ -95,6 +106,10 @@ class TensorQuantizer(nn.Module):
                 delattr(self, name)
         self._bias = dict(cfg.bias) if cfg.bias else None
         self._bias_calibrator = None
+        self._use_constant_amax = bool(cfg.use_constant_amax)
+        self._constant_amax = cfg.constant_amax
+        if cfg.constant_amax is not None:  # pinned on the buffer: forward and export read it (tensor_quantizer.py:256-261)
+            self.amax = float(cfg.constant_amax)
         for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export"):
             self.__dict__.pop(name, None)
         if not cfg.fake_quant:
@@ -288,6 +303,58 @@ class TensorQuantizer(nn.Module):
         else:
             self._pre_quant_scale = value.clone().detach().to(self._pre_quant_scale.device)
 
+    @property
+    def step_size(self):
+        """amax / maxbound of an integer format (tensor_quantizer.py:396-405)."""
+        if not hasattr(self, "_amax"):
+            warnings.warn("step_size is undefined under dynamic amax mode!")
+            return None
+        assert isinstance(self._num_bits, int), "Step size is not defined for non-integer quantization."
+        return self._amax / (2.0 ** (self._num_bits - 1 + int(self._unsigned)) - 1.0)
+
+    @property
+    def is_fp8(self):
+        """Per-tensor FP8 E4M3: no block scales, no per-channel axis (:553-556)."""
+        return self._num_bits == (4, 3) and self._block_sizes is None and self._axis is None
+
+    def is_mxfp(self, bits):
+        """MXFP4 / MXFP6 / MXFP8: E8M0 scales over blocks of 32 (:583-604)."""
+        elem = {4: (2, 1), 6: (3, 2), 8: (4, 3)}.get(bits)
+        if elem is None:
+            raise NotImplementedError()
+        nb = tuple(self._num_bits) if isinstance(self._num_bits, (list, tuple)) else self._num_bits
+        return bool(self.is_mx_format and nb == elem and self._block_sizes.get(-1, None) == 32)
+
+    def disable_pre_quant_scale(self):
+        """Context manager: the pre-quant scale is not applied inside (:1387-1395)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            was = self._enable_pre_quant_scale
+            self._enable_pre_quant_scale = False
+            try:
+                yield
+            finally:
+                self._enable_pre_quant_scale = was
+
+        return ctx()
+
+    def validate_attr(self, attr_value=None, attr_name="amax", raise_error=False, warn_error=False, name=""):
+        """True when the attribute is absent or holds only finite values >= 0 (:753-773)."""
+        attr_value = attr_value if attr_value is not None else getattr(self, attr_name, None)
+        if attr_value is None or (isinstance(attr_value, torch.Tensor) and attr_value.is_meta):
+            return True
+        if bool(torch.all(attr_value >= 0)) and not bool(torch.any(torch.isinf(attr_value))) \
+                and not bool(torch.any(torch.isnan(attr_value))):
+            return True
+        msg = f"{f'{name}.' if name else ''}{attr_name} contains invalid values: {attr_value}"
+        if warn_error:
+            warnings.warn(msg)
+        if raise_error:
+            raise ValueError(msg)
+        return False
+
     def disable(self):
         self._disabled = True
 
@@ -428,6 +495,8 @@ class TensorQuantizer(nn.Module):
         self._block_sizes = None
 
     def _get_amax(self, inputs):
+        if self._use_constant_amax:  # (tensor_quantizer.py:738-739)
+            return torch.tensor(torch.finfo(torch.float8_e4m3fn).max, device=inputs.device)
         if hasattr(self, "_amax"):
             return self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
         reduce_axis = convert_quantization_axis_to_reduce_axis(inputs, self._axis)
@@ -559,7 +628,7 @@ class TensorQuantizer(nn.Module):
 
     def extra_repr(self):
         return (f"{self._num_bits} bit fake axis={self._axis} block_sizes={self._block_sizes} "
-                f"amax={'dynamic' if self.amax is None else tuple(self.amax.shape)} "
+                f"amax={'448(const)' if self._use_constant_amax else 'dynamic' if self.amax is None else tuple(self.amax.shape)} "
                 f"calibrator={type(self._calibrator).__name__}{f' bias={self._bias}' if self._bias else ''} "
                 f"quant={'on' if self._if_quant else 'off'}"
                 f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")

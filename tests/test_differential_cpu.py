@@ -88,6 +88,8 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
         cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:  # True: FP8 key / value quantizers; "affine": the same with a per-head per-channel offset
         kv = mtq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mtq.FP8_KV_CFG
+        if with_kv == "cast":  # configs/ptq/units/kv_fp8_cast.yaml (hf_ptq.py's default KV format): amax fixed at 448
+            kv = {"quant_cfg": [{"quantizer_name": "*[kv]_bmm_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "use_constant_amax": True}}]}
         cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(kv["quant_cfg"]))
     batches = _batches()
     loop = (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None
@@ -122,7 +124,8 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
-        cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, (mq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mq.FP8_KV_CFG)["quant_cfg"])
+        kv = {"affine": mq.FP8_AFFINE_KV_CFG, "cast": mq.FP8_CAST_KV_CFG}.get(with_kv, mq.FP8_KV_CFG)
+        cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, kv["quant_cfg"])
     batches = _batches()
     with torch.no_grad():
         moa.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
@@ -196,6 +199,9 @@ def _assert_same_quant_json(ours, ref, what=""):
     # affine KV cache (FP8_AFFINE_KV_CFG): offsets calibrated before the abs-max, exported as k_proj.k_bias / v_proj.v_bias
     ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "llama", None), ("FP8_DEFAULT_CFG", torch.float32, "affine", "llama-eager", None),
     ("FP8_DEFAULT_CFG", torch.float16, "affine", "qwen2", None), ("INT4_AWQ_CFG", torch.bfloat16, "affine", "mistral", None),
+    # cast-style KV cache (use_constant_amax: the reference example's default KV format)
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "cast", "llama", None), ("INT4_AWQ_CFG", torch.bfloat16, "cast", "qwen2", None),
+    ("FP8_DEFAULT_CFG", torch.float32, "cast", "mixtral", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -644,3 +650,53 @@ def test_histogram_calibrated_inputs_of_a_model_equal_the_reference_live(monkeyp
     assert len(ref) == 28 and set(ref) == set(ours)
     for n, a in ref.items():
         assert torch.equal(a.reshape(-1), ours[n].reshape(-1)), f"{method}: amax of {n}: {ours[n]} vs {a}"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_constant_amax_quantizers_skip_calibration_like_the_reference_live(monkeypatch, dtype):
+    """`constant_amax` pins `_amax` at configuration time (config.py:674-709, tensor_quantizer.py:256-261): the input
+    quantizers neither calibrate nor disturb the statistics of the others, the forward and the exported input_scale use
+    the pinned value.  Invalid combinations are refused at configuration time on both sides."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+
+    batches = _batches()
+    loop = lambda m: [m(b) for b in batches]  # noqa: E731
+    ref_cfg = copy.deepcopy(mtq.FP8_DEFAULT_CFG)
+    ref_cfg["quant_cfg"] = list(ref_cfg["quant_cfg"]) + [{"quantizer_name": "*mlp*input_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "constant_amax": 96.0}}]
+    ref = mtq.quantize(_model(dtype), ref_cfg, loop)
+    ref_amax = {n: m._amax.detach().float().clone() for n, m in ref.named_modules()
+                if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
+    with torch.no_grad():
+        ref_logits = ref(batches[0]).logits.clone()
+    ref_state = {}
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(ref, export_dir=d)
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            ref_state = {k: f.get_tensor(k) for k in f.keys()}
+    hostmem_backend.install(monkeypatch, moa)
+    mq = moa.model_quant
+    cfg = copy.deepcopy(mq.FP8_DEFAULT_CFG)
+    cfg["quant_cfg"] = mq.normalize_quant_cfg_list(cfg["quant_cfg"]) + [{"quantizer_name": "*mlp*input_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "constant_amax": 96.0}}]
+    ours = _model(dtype)
+    with torch.no_grad():
+        moa.quantize(ours, cfg, loop)
+        logits = ours(batches[0]).logits.clone()
+    our_amax = {n: m._amax.detach().float().clone() for n, m in ours.named_modules()
+                if isinstance(m, moa.TensorQuantizer) and m.is_enabled and getattr(m, "_amax", None) is not None}
+    assert set(our_amax) == set(ref_amax)
+    for n, a in ref_amax.items():
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
+        if ".mlp." in n and n.endswith("input_quantizer"):
+            assert float(a) == 96.0
+    assert torch.equal(logits, ref_logits)
+    state = moa.export.export_state_dict(ours, dtype, lambda: ours(torch.ones([1, 2], dtype=torch.long)))
+    assert sorted(state) == sorted(ref_state)
+    for k, want in ref_state.items():
+        got = state[k].detach().cpu()
+        assert got.dtype == want.dtype and torch.equal(got.reshape(-1).view(torch.uint8), want.reshape(-1).view(torch.uint8)), k
+    for bad in ({"constant_amax": -1.0}, {"constant_amax": 3.0, "use_constant_amax": True}):
+        with pytest.raises(AssertionError):
+            moa.QuantizerAttributeConfig(num_bits=(4, 3), **bad)

@@ -564,3 +564,45 @@ def _all_divergences(hist, stride, start):
     calib._compute_amax_entropy(hist, np.linspace(0, 1, len(hist) + 1, dtype=np.float32), 8, False, stride, start,
                                 divergences_out=out)
     return out
+
+
+def test_small_quantizer_helpers_and_the_post_calibration_warning(monkeypatch):
+    """step_size / is_fp8 / is_mxfp / disable_pre_quant_scale / validate_attr (tensor_quantizer.py:396-405, :553-604,
+    :753-773, :1387-1395) and the check mtq.calibrate ends with (model_quant.py:119-122): a warning per quantizer buffer
+    holding a negative / inf / NaN entry -- same text as the reference's -- found by ONE flattened test per device."""
+    import warnings
+
+    import hostmem_backend
+
+    hostmem_backend.install(monkeypatch, moa)
+    TQ, Cfg = moa.TensorQuantizer, moa.QuantizerAttributeConfig
+    q = TQ(Cfg(num_bits=8, axis=None))
+    with pytest.warns(UserWarning, match="undefined under dynamic amax"):
+        assert q.step_size is None
+    q.amax = torch.tensor(12.7)
+    assert torch.equal(q.step_size, torch.tensor(12.7) / 127.0)
+    assert TQ(Cfg(num_bits=(4, 3), axis=None)).is_fp8 and not TQ(Cfg(num_bits=(4, 3), axis=0)).is_fp8
+    mx = TQ(Cfg(num_bits=(2, 1), block_sizes={-1: 32, "type": "dynamic", "scale_bits": (8, 0)}))
+    assert mx.is_mxfp(4) and not mx.is_mxfp(8) and not q.is_mxfp(4)
+    with pytest.raises(NotImplementedError):
+        mx.is_mxfp(5)
+    q.pre_quant_scale = torch.ones(4) * 2
+    with q.disable_pre_quant_scale():
+        assert q.pre_quant_scale is None
+    assert torch.equal(q.pre_quant_scale, torch.ones(4) * 2)
+    assert q.validate_attr() and q.validate_attr(attr_name="_pre_quant_scale")
+    with pytest.raises(ValueError, match="contains invalid values"):
+        q.validate_attr(attr_value=torch.tensor([1.0, float("inf")]), raise_error=True)
+
+    net = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # a healthy model: no warning
+        moa.quantize(net, moa.model_quant.INT8_DEFAULT_CFG, lambda m: m(torch.randn(4, 16)))
+    net[0].input_quantizer._amax.fill_(float("nan"))
+    net[2].weight_quantizer._amax.view(-1)[0] = -1.0
+    with pytest.warns(UserWarning) as rec:
+        moa.model_quant.calibrate(net, None)
+    texts = [str(w.message) for w in rec]
+    assert any(t.startswith("0.input_quantizer._amax contains invalid values: ") for t in texts), texts
+    assert any(t.startswith("2.weight_quantizer._amax contains invalid values: ") for t in texts), texts
+    assert len([t for t in texts if "contains invalid values" in t]) == 2
