@@ -37,6 +37,7 @@ from . import gptq  # noqa: F401
 from . import export  # noqa: F401
 from . import qtensor  # noqa: F401
 from . import layerwise  # noqa: F401
+from . import forward_loop  # noqa: F401
 from . import library_ops  # noqa: F401
 from . import modelopt_plugin  # noqa: F401
 from .model_quant import (calibrate, disable_quantizer, enable_quantizer, fold_weight, postprocess_amax,  # noqa: F401
