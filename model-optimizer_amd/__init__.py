@@ -29,6 +29,7 @@ from . import tensor_quantizer  # noqa: F401
 from . import nn  # noqa: F401
 from . import hf_attention  # noqa: F401
 from . import hf_experts  # noqa: F401
+from . import hf_moe  # noqa: F401
 from . import distributed  # noqa: F401
 from . import model_calib  # noqa: F401
 from . import model_quant  # noqa: F401

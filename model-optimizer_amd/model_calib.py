@@ -146,7 +146,8 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
 
 
 @torch.no_grad()
-def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, shard_weights: bool | None = None):
+def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, shard_weights: bool | None = None,
+                  sync_expert_weight_amax: bool = False):
     """model_calib.py:310-498 (DP part): collect abs-max statistics for weights and activations, load them,
     then MAX-reduce every amax across the data-parallel group in ONE bucket; each rank's forward_loop sees its own
     share of the calibration batches.
@@ -155,7 +156,10 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
     other ranks with the MAX bucket.  Only correct when every rank holds the SAME weights (data-parallel replicas):
     under tensor parallelism / FSDP the ranks hold different shards and each must calibrate all of its own -- so the
     default (None) shards only after `distributed.declare_data_parallel()`, and never without `distributed_sync`.
-    Tensor-parallel callers pass distributed_sync=False and synchronise by `distributed.sync_amax_tensor_parallel`."""
+    Tensor-parallel callers pass distributed_sync=False and synchronise by `distributed.sync_amax_tensor_parallel`.
+
+    sync_expert_weight_amax: blocks of separate expert modules share one weight amax per projection as well (the input
+    amax is always shared, hf_moe.layer_sync_moe_local_experts_amax; model_calib.py:365-368)."""
     sync = distributed_sync and _dist_on()
     stats = MAX_CALIBRATE_STATS
     stats.clear()
@@ -178,6 +182,11 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
         forward_loop(model)
     lap("forward_loop_s")
     finish_stats_collection(model)
+    from . import hf_moe
+
+    hf_moe.layer_sync_moe_local_experts_amax(
+        model, sync_weight_amax=sync_expert_weight_amax,
+        calibrate_missing=lambda q, w: max_calibrate(q, lambda m: m(w), distributed_sync=False))
     lap("finish_s")
     if sync:
         dev = next((p.device for p in model.parameters()), None)

@@ -339,9 +339,15 @@ def _run_algorithm(model: nn.Module, algo, forward_loop):
     if method is None:
         return model
     lw = _layerwise_options(method, kwargs)
+    ratio = kwargs.pop("moe_calib_experts_ratio", None)  # QuantizeAlgorithmConfig.moe_calib_experts_ratio (config.py:791-806)
+    if ratio is not None:
+        from . import hf_moe
+
+        hf_moe.set_moe_calib_experts_ratio(model, ratio)  # (mode.py:239-247: it stays on the blocks)
     if method == "max":  # MaxCalibConfig.distributed_sync (config.py): off for callers that synchronise by their own rules
         func = model_calib.max_calibrate
-        kwargs = {"distributed_sync": bool(kwargs.get("distributed_sync", True)), "shard_weights": kwargs.get("shard_weights")}
+        kwargs = {"distributed_sync": bool(kwargs.get("distributed_sync", True)), "shard_weights": kwargs.get("shard_weights"),
+                  "sync_expert_weight_amax": bool(kwargs.get("sync_expert_weight_amax", False))}
     elif method == "mse":
         func = model_calib.mse_calibrate
     elif method == "local_hessian":
