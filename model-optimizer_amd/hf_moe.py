@@ -98,9 +98,18 @@ def _top_k_owner(block):
     return gate if gate is not None and hasattr(gate, "top_k") else block
 
 
-def _count_hook(block):
-    def hook(gate, args, output):
-        if not getattr(block, "_count_expert_tokens", False):
+class _CountTokens:
+    """Forward hook of the block's router: tokens per expert while the counter is on (huggingface.py:668-682)."""
+
+    def __init__(self, block):
+        self.block = block
+
+    def __deepcopy__(self, memo):
+        return _CountTokens(memo.get(id(self.block), self.block))
+
+    def __call__(self, gate, args, output):
+        block = self.block
+        if not getattr(block, "_count_expert_tokens", False) or not hasattr(block, "expert_token_count"):
             return
         with torch.no_grad():
             if isinstance(output, tuple) and len(output) >= 3:
@@ -111,11 +120,22 @@ def _count_hook(block):
             counts = torch.bincount(indices.reshape(-1), minlength=block.expert_token_count.shape[0])
             block.expert_token_count += counts.to(block.expert_token_count.device)
 
-    return hook
 
+class _WidenedForward:
+    """The block's `forward` while a calibration ratio is set: an object rather than a closure, so that a deep copy of
+    the model gets a forward bound to the COPIED block (a copied closure would keep running the original's experts), and
+    the block's own forward is looked up on its class at call time."""
 
-def _widened_forward(block, own):
-    def forward(hidden_states, *args, **kwargs):
+    def __init__(self, block):
+        self.block = block
+
+    def __deepcopy__(self, memo):
+        # (copy._reconstruct enters the new block into the memo before it copies the block's attributes)
+        return _WidenedForward(memo.get(id(self.block), self.block))
+
+    def __call__(self, hidden_states, *args, **kwargs):
+        block = self.block
+        own = type(block).forward.__get__(block)
         ratio = getattr(block, "_moe_calib_experts_ratio", None)
         if ratio is None:
             return own(hidden_states, *args, **kwargs)
@@ -127,15 +147,14 @@ def _widened_forward(block, own):
                 if not n:
                     warnings.warn(f"{type(block).__name__}: could not resolve num_experts; expert routing will not be "
                                   "tracked for this layer.")
-                    block._count_expert_tokens = False
                 else:
                     block.register_buffer("expert_token_count", torch.zeros(n, dtype=torch.long, device=next(block.parameters()).device),
                                           persistent=False)
                     if hasattr(block, "gate"):
-                        block._moe_count_handle = block.gate.register_forward_hook(_count_hook(block))
-                    # (huggingface.py:664: setting the counter up also switches it off for the call that did it -- the
-                    # block's first calibration batch is not in the table; kept, the table is the reference's)
-                    block._count_expert_tokens = False
+                        block.gate.register_forward_hook(_CountTokens(block))
+                # (huggingface.py:664: setting the counter up also switches it off for the call that did it -- the
+                # block's first calibration batch is not in the table; kept, the table is the reference's)
+                block._count_expert_tokens = False
             owner = _top_k_owner(block)
             n_experts = _num_experts_of(owner) or _num_experts_of(block) or _num_experts_of(block.experts) or len(block.experts)
             configured = owner.top_k
@@ -149,8 +168,6 @@ def _widened_forward(block, own):
         block._count_expert_tokens = False
         return out
 
-    return forward
-
 
 def set_moe_calib_experts_ratio(model: nn.Module, ratio) -> int:
     """mode.py:239-247: the share of a block's experts every calibration token is sent to (None: routing as configured;
@@ -159,16 +176,16 @@ def set_moe_calib_experts_ratio(model: nn.Module, ratio) -> int:
         assert isinstance(ratio, (int, float)) and 0 < ratio <= 1, f"Invalid moe_calib_experts_ratio {ratio!r}"
     blocks = sparse_moe_blocks(model)
     for _, block in blocks:
-        had = getattr(block, "_moe_forward_shadow", None)
+        shadow = block.__dict__.get("forward")
         if ratio is None:
-            if had is not None:
-                if block.__dict__.get("forward") is had:
-                    del block.forward
-                block._moe_forward_shadow = None
+            if isinstance(shadow, _WidenedForward):
+                del block.forward
             block._moe_calib_experts_ratio = None
             continue
+        if shadow is not None and not isinstance(shadow, _WidenedForward):
+            raise RuntimeError(f"{type(block).__name__}: the block's forward is already replaced on the instance; "
+                               "moe_calib_experts_ratio wraps the class's forward")
         block._moe_calib_experts_ratio = ratio
-        if had is None:
-            block._moe_forward_shadow = _widened_forward(block, block.forward)
-            block.forward = block._moe_forward_shadow
+        if shadow is None:
+            block.forward = _WidenedForward(block)
     return len(blocks)

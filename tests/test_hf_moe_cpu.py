@@ -136,6 +136,14 @@ def test_widened_routing_calibrates_more_experts_and_leaves_the_output_alone(hos
             q.disable()
     with torch.no_grad():
         assert torch.equal(net(batches[0]), want), "outside calibration the block routes as configured"
+    # a deep copy runs on ITS OWN experts (the shadowed forward is rebound to the copied block)
+    twin = copy.deepcopy(net)
+    assert twin.moe.forward.block is twin.moe and twin.moe.gate._forward_hooks and \
+        all(h.block is twin.moe for h in twin.moe.gate._forward_hooks.values())
+    with torch.no_grad():
+        for p in twin.moe.experts.parameters():
+            p.zero_()
+        assert not torch.equal(net(batches[0]), twin(batches[0])) and torch.equal(net(batches[0]), want)
     assert hf_moe.set_moe_calib_experts_ratio(net, None) == 1 and "forward" not in net.moe.__dict__
     with pytest.raises(AssertionError, match="Invalid moe_calib_experts_ratio"):
         hf_moe.set_moe_calib_experts_ratio(net, 1.5)
