@@ -8,8 +8,8 @@ allows it (static-block INT with dynamic amax, optionally with a per-column pre_
 search inner loop), and otherwise one kernel per stage.  GPU tensors only: there is no CPU path.
 
 Scope: fake quantization for INT-k (per-tensor / per-channel / static last-axis blocks), FP8-E4M3
-(per-tensor / per-channel), dynamic MX blocks, and the affine offset (`bias`) of the KV-cache presets.  N-D
-(non-last-axis) block layouts, rotation and real-quant QTensors are outside this path and raise.
+(per-tensor / per-channel), dynamic MX blocks, tiles over the last two axes (any rank), and the affine offset (`bias`) of the KV-cache presets.
+Block layouts on other axes, rotation and real-quant QTensors are outside this path and raise.
 """
 
 from __future__ import annotations
@@ -110,7 +110,7 @@ class TensorQuantizer(nn.Module):
         self._constant_amax = cfg.constant_amax
         if cfg.constant_amax is not None:  # pinned on the buffer: forward and export read it (tensor_quantizer.py:256-261)
             self.amax = float(cfg.constant_amax)
-        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export"):
+        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view"):
             self.__dict__.pop(name, None)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
@@ -395,6 +395,9 @@ class TensorQuantizer(nn.Module):
             warnings.warn(msg)
             warnings.warn("Set amax to NaN!")
             calib_amax = torch.tensor(math.nan)
+        view = getattr(self, "_block_amax_view", None)
+        if view is not None and calib_amax.numel() == math.prod(view):
+            calib_amax = calib_amax.reshape(view)
         self.amax = calib_amax
 
     def export_amax(self):
@@ -436,23 +439,30 @@ class TensorQuantizer(nn.Module):
 
     def _setup_for_blockquant(self, inputs):
         """tensor_quantizer.py:975-1043.  Last-axis blocks: right-pad the last dim with zeros to a block multiple,
-        view as (-1, g), quantization axis (0,).  Blocks on BOTH axes of a 2-D tensor (the FP8 2-D blockwise
-        preset): zero-pad to whole tiles, view as (R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D
-        block kernel; other N-D layouts raise."""
+        view as (-1, g), quantization axis (0,).  Blocks on the LAST TWO axes (the FP8 2-D blockwise preset; any
+        rank): zero-pad to whole tiles, view as (L * R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D
+        block kernel, the amax buffer in the reference's (L..., R/br, 1, C/bc, 1) shape; other layouts raise."""
         if hasattr(self, "_block_reshape_size"):
             return
         bs = self._block_sizes
         axes = {(k if k >= 0 else inputs.dim() + k): v for k, v in bs.items() if isinstance(k, int)}
-        if len(axes) == 2 and inputs.dim() == 2 and set(axes) == {0, 1}:
-            br, bc = axes[0], axes[1]
-            rows, cols = inputs.shape
+        nd = inputs.dim()
+        if len(axes) == 2 and nd >= 2 and set(axes) == {nd - 2, nd - 1}:
+            # tiles over the LAST TWO axes; leading dims (stacked experts, conv output channels ...) fold into the tile
+            # rows once the matrix dims are padded to whole tiles, so the 2-D kernel serves any rank
+            br, bc = axes[nd - 2], axes[nd - 1]
+            lead = tuple(inputs.shape[:-2])
+            rows, cols = inputs.shape[-2:]
             pad_r, pad_c = (-rows) % br, (-cols) % bc
             self._original_shape = inputs.shape
             if pad_r or pad_c:  # right / bottom zero padding to whole tiles, cut off again after the QDQ (:1018-1043)
                 self._padding = (0, pad_c, 0, pad_r)
-                self._slices = (slice(rows), slice(cols))
-                self._original_shape = torch.Size((rows + pad_r, cols + pad_c))
-            self._block_reshape_size = torch.Size(((rows + pad_r) // br, br, (cols + pad_c) // bc, bc))
+                self._slices = (*(slice(None),) * len(lead), slice(rows), slice(cols))
+                self._original_shape = torch.Size((*lead, rows + pad_r, cols + pad_c))
+            a, b = (rows + pad_r) // br, (cols + pad_c) // bc
+            self._block_reshape_size = torch.Size((math.prod(lead) * a, br, b, bc))
+            if lead:  # the amax buffer keeps the reference's shape (one entry per leading index and tile)
+                self._block_amax_view = torch.Size((*lead, a, 1, b, 1))
             self.axis = (0, 2)
             return
         g = self._block_size_last(inputs)
@@ -498,7 +508,11 @@ class TensorQuantizer(nn.Module):
         if self._use_constant_amax:  # (tensor_quantizer.py:738-739)
             return torch.tensor(torch.finfo(torch.float8_e4m3fn).max, device=inputs.device)
         if hasattr(self, "_amax"):
-            return self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
+            amax = self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
+            view = getattr(self, "_block_amax_view", None)
+            if view is not None and amax.shape == view:  # tiles of an N-D tensor: the kernel's folded (rows, 1, cols, 1) view
+                amax = amax.reshape(self._block_reshape_size[0], 1, self._block_reshape_size[2], 1)
+            return amax
         reduce_axis = convert_quantization_axis_to_reduce_axis(inputs, self._axis)
         return ops.reduce_amax(inputs, axis=reduce_axis, keepdims=True)
 

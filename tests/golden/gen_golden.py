@@ -771,6 +771,23 @@ def gen_block2d(out):
             cases[k] = dict(dtype=dn, num_bits=list(nb) if isinstance(nb, tuple) else nb, br=br, bc=bc,
                             amax_shape=list(q._amax.shape), amax_dtype=str(q._amax.dtype).split(".")[-1])
             idx += 1
+    # the same tiles on the last two axes of tensors of rank 3 / 4 (stacked experts, leading batch dims): whole tiles
+    # and ragged matrices, calibrated and dynamic amax (tensor_quantizer.py:1018-1043)
+    nidx = 0
+    for dn, dt in DT.items():
+        for nb, br, bc, shape in [((4, 3), 16, 32, (3, 32, 64)), (8, 8, 16, (2, 3, 20, 40)), ((4, 3), 16, 16, (4, 30, 50))]:
+            w = weight_like(shape, dt, 2100 + nidx)
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes={-1: bc, -2: br}))
+            q.disable_quant(); q.enable_calib()
+            q(w)
+            q.load_calib_amax()
+            q.enable_quant(); q.disable_calib()
+            k = f"n{nidx}"
+            out[f"{k}_x"], out[f"{k}_y"], out[f"{k}_amax"] = bits(w), bits(q(w)), bits(q._amax.float())
+            out[f"{k}_ydyn"] = bits(TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes={-1: bc, -2: br}))(w))
+            cases[k] = dict(dtype=dn, num_bits=list(nb) if isinstance(nb, tuple) else nb, br=br, bc=bc, lead=list(shape[:-2]),
+                            shape=list(shape), amax_shape=list(q._amax.shape), amax_dtype=str(q._amax.dtype).split(".")[-1])
+            nidx += 1
     out["cases"] = np.array(json.dumps(cases))
 
 

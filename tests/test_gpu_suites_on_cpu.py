@@ -27,7 +27,8 @@ SELECTED = {
                       "test_sequential_quantizer_w4a8_matches_reference", "test_tensor_quantizer_2d_blocks_match_reference",
                       "test_two_level_block_format_flow_and_dynamic_type", "test_histogram_mse_threshold_is_the_candidate_loop",
                       "test_local_hessian_calibrate_on_the_gpu_equals_the_reference_run",
-                      "test_affine_offset_of_the_kv_cache_presets_matches_the_reference_run"],
+                      "test_affine_offset_of_the_kv_cache_presets_matches_the_reference_run",
+                      "test_tensor_quantizer_tiles_on_the_last_two_axes_of_any_rank"],
     "test_gpu_mse": ["test_mse_calibrator_matches_reference", "test_quantize_mse_flow_matches_reference"],
     "test_gpu_export": ["test_export_from_reference_state_is_byte_identical", "test_fp8_export_from_reference_state_is_byte_identical",
                         "test_mxfp4_export_is_byte_identical", "test_int8_smoothquant_export_from_reference_state_is_byte_identical",
