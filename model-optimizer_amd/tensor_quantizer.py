@@ -8,8 +8,8 @@ allows it (static-block INT with dynamic amax, optionally with a per-column pre_
 search inner loop), and otherwise one kernel per stage.  GPU tensors only: there is no CPU path.
 
 Scope: fake quantization for INT-k (per-tensor / per-channel / static last-axis blocks), FP8-E4M3
-(per-tensor / per-channel), dynamic MX blocks, tiles over the last two axes (any rank), and the affine offset (`bias`) of the KV-cache presets.
-Block layouts on other axes, rotation and real-quant QTensors are outside this path and raise.
+(per-tensor / per-channel), dynamic MX blocks, static block grids on any axes (last axis and last-two-axes tiles without a copy), and the affine
+offset (`bias`) of the KV-cache presets.  Rotation and real-quant QTensors are outside this path and raise.
 """
 
 from __future__ import annotations
@@ -68,6 +68,15 @@ class QuantizerAttributeConfig:
                 raise ValueError(f"Invalid axis type {type(axis)}, expected int")
 
 
+def _group_kernel_takes(g: int, dtype) -> bool:
+    """The fused per-group abs-max + QDQ kernel walks a group in 16-byte packets, a power of two (<= 64) of them per
+    group (csrc/moq_stream.hip); other sizes -- the block products of N-D grids can be anything -- take the per-row
+    abs-max and the per-row QDQ instead."""
+    vec = 4 if dtype == torch.float32 else 8
+    p = g // vec
+    return g % vec == 0 and 0 < p <= 64 and p & (p - 1) == 0
+
+
 class TensorQuantizer(nn.Module):
     def __init__(self, quant_attribute_cfg: QuantizerAttributeConfig | None = None, if_quant=True,
                  if_calib=False, amax=None):
@@ -110,7 +119,8 @@ class TensorQuantizer(nn.Module):
         self._constant_amax = cfg.constant_amax
         if cfg.constant_amax is not None:  # pinned on the buffer: forward and export read it (tensor_quantizer.py:256-261)
             self.amax = float(cfg.constant_amax)
-        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view"):
+        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
+                     "_nd_split", "_nd_perm", "_nd_inverse"):
             self.__dict__.pop(name, None)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
@@ -441,7 +451,8 @@ class TensorQuantizer(nn.Module):
         """tensor_quantizer.py:975-1043.  Last-axis blocks: right-pad the last dim with zeros to a block multiple,
         view as (-1, g), quantization axis (0,).  Blocks on the LAST TWO axes (the FP8 2-D blockwise preset; any
         rank): zero-pad to whole tiles, view as (L * R/br, br, C/bc, bc), quantization axes (0, 2) -- served by the 2-D
-        block kernel, the amax buffer in the reference's (L..., R/br, 1, C/bc, 1) shape; other layouts raise."""
+        block kernel, the amax buffer in the reference's (L..., R/br, 1, C/bc, 1) shape.  Any other set of blocked axes:
+        one permuted copy brings it to the last-axis layout."""
         if hasattr(self, "_block_reshape_size"):
             return
         bs = self._block_sizes
@@ -465,6 +476,36 @@ class TensorQuantizer(nn.Module):
                 self._block_amax_view = torch.Size((*lead, a, 1, b, 1))
             self.axis = (0, 2)
             return
+        if any(d != nd - 1 for d in axes):
+            # any other set of blocked axes (rows only, a conv weight's input channels, ...; :1018-1043): every blocked
+            # axis is padded to whole blocks and split into (blocks, block); the block parts are gathered behind the
+            # rest by ONE permuted copy, after which the layout is that of last-axis blocks of size prod(blocks) --
+            # the per-row kernels serve it, and the amax buffer keeps the reference's shape (block parts = 1)
+            sizes = [axes.get(d) for d in range(nd)]
+            pads = [(-inputs.shape[d]) % b if b else 0 for d, b in enumerate(sizes)]
+            self._original_shape = inputs.shape
+            if any(pads):
+                first = next(d for d, p in enumerate(pads) if p)
+                self._padding = tuple(v for d in range(nd - 1, first - 1, -1) for v in (0, pads[d]))
+                self._slices = tuple(slice(inputs.shape[d]) if pads[d] else slice(None) for d in range(nd))
+                self._original_shape = torch.Size(inputs.shape[d] + pads[d] for d in range(nd))
+            split, grid_at, tile_at = [], [], []
+            for d, b in enumerate(sizes):
+                n = self._original_shape[d]
+                if b:
+                    grid_at.append(len(split)), tile_at.append(len(split) + 1)
+                    split += [n // b, b]
+                else:
+                    grid_at.append(len(split))
+                    split.append(n)
+            perm = grid_at + tile_at
+            self._nd_split, self._nd_perm = torch.Size(split), tuple(perm)
+            self._nd_inverse = tuple(perm.index(i) for i in range(len(perm)))
+            tile = math.prod(split[i] for i in tile_at)
+            self._block_reshape_size = torch.Size((-1, tile))
+            self._block_amax_view = torch.Size(1 if i in tile_at else n for i, n in enumerate(split))
+            self.axis = (0,)
+            return
         g = self._block_size_last(inputs)
         self._original_shape = inputs.shape
         pad = (-inputs.shape[-1]) % g
@@ -482,9 +523,14 @@ class TensorQuantizer(nn.Module):
         if inputs.shape != self._original_shape:
             raise ValueError(f"Input shape has changed from {self._original_shape} to {inputs.shape}."
                              " Block-quantization requires a fixed input shape.")
+        if hasattr(self, "_nd_perm"):
+            return inputs.reshape(self._nd_split).permute(self._nd_perm).reshape(self._block_reshape_size)
         return inputs.reshape(self._block_reshape_size)
 
     def _reset_to_original_shape(self, outputs):
+        if hasattr(self, "_nd_perm"):
+            gathered = [self._nd_split[i] for i in self._nd_perm]
+            outputs = outputs.reshape(gathered).permute(self._nd_inverse)
         outputs = outputs.reshape(self._original_shape)
         if hasattr(self, "_slices"):
             outputs = outputs[self._slices]
@@ -510,8 +556,9 @@ class TensorQuantizer(nn.Module):
         if hasattr(self, "_amax"):
             amax = self._amax.to(inputs.device) if self._amax.device != inputs.device else self._amax
             view = getattr(self, "_block_amax_view", None)
-            if view is not None and amax.shape == view:  # tiles of an N-D tensor: the kernel's folded (rows, 1, cols, 1) view
-                amax = amax.reshape(self._block_reshape_size[0], 1, self._block_reshape_size[2], 1)
+            if view is not None and amax.shape == view:  # the kernels' folded view of an N-D grid's amax
+                amax = amax.reshape(-1, 1) if hasattr(self, "_nd_perm") else \
+                    amax.reshape(self._block_reshape_size[0], 1, self._block_reshape_size[2], 1)
             return amax
         reduce_axis = convert_quantization_axis_to_reduce_axis(inputs, self._axis)
         return ops.reduce_amax(inputs, axis=reduce_axis, keepdims=True)
@@ -546,7 +593,8 @@ class TensorQuantizer(nn.Module):
             if tuple(self._num_bits) != (4, 3):
                 raise MoquantUnsupported(f"float format {self._num_bits} without dynamic blocks")
             return ops.scaled_e4m3(inputs, self._get_amax(inputs) if amax is None else amax)
-        if amax is None and self.is_static_block_quant and not hasattr(self, "_amax") and inputs.dim() == 2:
+        if (amax is None and self.is_static_block_quant and not hasattr(self, "_amax") and inputs.dim() == 2
+                and _group_kernel_takes(inputs.shape[-1], inputs.dtype)):
             # dynamic per-block amax + QDQ in one pass (what _get_amax + fake_tensor_quant do in two)
             y, _ = ops.amax_qdq_int_group(inputs, inputs.shape[-1], self._num_bits, self._unsigned,
                                           self._narrow_range, return_amax=False)

@@ -788,6 +788,24 @@ def gen_block2d(out):
             cases[k] = dict(dtype=dn, num_bits=list(nb) if isinstance(nb, tuple) else nb, br=br, bc=bc, lead=list(shape[:-2]),
                             shape=list(shape), amax_shape=list(q._amax.shape), amax_dtype=str(q._amax.dtype).split(".")[-1])
             nidx += 1
+    # grids on other axis sets (rows only, a conv weight's input channels, three axes at once; ragged sizes): two
+    # calibration calls (running maximum), then the output; and the dynamic-amax output
+    gidx = 0
+    for dn, dt in DT.items():
+        for nb, grid, shape in [((4, 3), {0: 8}, (32, 24)), (8, {0: 4, -1: 8}, (6, 5, 20)), ((4, 3), {1: 4}, (6, 10, 3, 3)),
+                                (8, {0: 2, 1: 3, 2: 4}, (4, 7, 8)), (4, {-2: 16}, (40, 16))]:
+            w = weight_like(shape, dt, 2300 + gidx)
+            q = TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes=dict(grid)))
+            q.disable_quant(); q.enable_calib()
+            q(w); q(w * 0.5)
+            q.load_calib_amax()
+            q.enable_quant(); q.disable_calib()
+            k = f"g{gidx}"
+            out[f"{k}_x"], out[f"{k}_y"], out[f"{k}_amax"] = bits(w), bits(q(w)), bits(q._amax.float())
+            out[f"{k}_ydyn"] = bits(TensorQuantizer(QuantizerAttributeConfig(num_bits=nb, block_sizes=dict(grid)))(w))
+            cases[k] = dict(dtype=dn, num_bits=list(nb) if isinstance(nb, tuple) else nb, grid={str(a): b for a, b in grid.items()},
+                            lead=[], shape=list(shape), amax_shape=list(q._amax.shape), amax_dtype=str(q._amax.dtype).split(".")[-1])
+            gidx += 1
     out["cases"] = np.array(json.dumps(cases))
 
 

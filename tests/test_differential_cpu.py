@@ -700,3 +700,32 @@ def test_constant_amax_quantizers_skip_calibration_like_the_reference_live(monke
     for bad in ({"constant_amax": -1.0}, {"constant_amax": 3.0, "use_constant_amax": True}):
         with pytest.raises(AssertionError):
             moa.QuantizerAttributeConfig(num_bits=(4, 3), **bad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_grids_on_any_axes_equal_the_reference_live(monkeypatch, dtype):
+    """Static block_sizes on any set of axes of tensors of rank 2-4 (tensor_quantizer.py:975-1043), whole and ragged:
+    amax buffer (shape and values, running maximum over two calls), fake-quantized output and the dynamic-amax output."""
+    ref_shim.install()
+    from modelopt.torch.quantization.config import QuantizerAttributeConfig as RefCfg
+    from modelopt.torch.quantization.nn import TensorQuantizer as RefQuantizer
+
+    hostmem_backend.install(monkeypatch, moa)
+    cases = [((4, 3), {0: 8}, (32, 24)), (8, {0: 8}, (20, 24)), (8, {0: 4, -1: 8}, (6, 5, 20)), ((4, 3), {1: 4}, (6, 10, 3, 3)),
+             (4, {-2: 16}, (40, 16)), (8, {0: 2, 1: 3, 2: 4}, (4, 7, 8)), ((4, 3), {0: 64}, (8, 16)), (8, {0: 8, 1: 8}, (3, 8, 8)),
+             ((4, 3), {-1: 32, -2: 16}, (3, 32, 64)), (8, {-1: 16, -2: 8}, (2, 3, 20, 40)), (8, {-1: 8, -2: 4}, (5, 8, 8)),
+             (8, {-1: 16}, (3, 5, 40))]
+    for nb, grid, shape in cases:
+        x = (torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))) * 0.3).to(dtype)
+        got = []
+        for Q, C in ((RefQuantizer, RefCfg), (moa.TensorQuantizer, moa.QuantizerAttributeConfig)):
+            q = Q(C(num_bits=nb, block_sizes=dict(grid)))
+            q.disable_quant(); q.enable_calib()
+            q(x); q(x * 0.5)
+            q.load_calib_amax()
+            q.enable_quant(); q.disable_calib()
+            got.append((q(x), q._amax, Q(C(num_bits=nb, block_sizes=dict(grid)))(x)))
+        (ry, ra, rd), (y, a, d) = got
+        what = f"{nb} {grid} {shape}"
+        assert a.shape == ra.shape and a.dtype == ra.dtype and torch.equal(a.float(), ra.float()), what
+        assert torch.equal(y, ry) and torch.equal(d, rd), what

@@ -518,8 +518,10 @@ def test_affine_offset_of_the_kv_cache_presets_matches_the_reference_run(golden)
 def test_tensor_quantizer_tiles_on_the_last_two_axes_of_any_rank(golden):
     """block_sizes on the last two axes of a rank-3 / rank-4 tensor (stacked experts [E, Cout, Cin], leading batch dims;
     tensor_quantizer.py:1018-1043): the matrix dims are zero-padded to whole tiles, the leading dims fold into the tile
-    rows of the 2-D kernel, the amax buffer keeps the reference's (L..., R/br, 1, C/bc, 1) shape -- calibrated amax,
-    output and the dynamic-amax output equal the reference's run."""
+    rows of the 2-D kernel, the amax buffer keeps the reference's (L..., R/br, 1, C/bc, 1) shape.  Grids on OTHER axis sets
+    (rows only, a conv weight's input channels, three axes at once) take one permuted copy to the last-axis layout.
+    Calibrated amax (running maximum over two calls for the general grids), output and the dynamic-amax output equal the
+    reference's run."""
     g = golden("block2d")
     seen = 0
     for k, c in g.cases.items():
@@ -529,20 +531,23 @@ def test_tensor_quantizer_tiles_on_the_last_two_axes_of_any_rank(golden):
         dt = DT[c["dtype"]]
         x = g.t(f"{k}_x", dt).reshape(c["shape"]).to(DEV)
         nb = tuple(c["num_bits"]) if isinstance(c["num_bits"], list) else c["num_bits"]
-        cfg = QuantizerAttributeConfig(num_bits=nb, block_sizes={-1: c["bc"], -2: c["br"]})
+        grid = {int(a): b for a, b in c["grid"].items()} if "grid" in c else {-1: c["bc"], -2: c["br"]}
+        cfg = QuantizerAttributeConfig(num_bits=nb, block_sizes=grid)
         q = TensorQuantizer(cfg)
         q.disable_quant(); q.enable_calib()
         q(x)
+        if "grid" in c:
+            q(x * 0.5)
         q.load_calib_amax()
         q.enable_quant(); q.disable_calib()
         assert list(q._amax.shape) == c["amax_shape"] and str(q._amax.dtype).split(".")[-1] == c["amax_dtype"], k
         assert_bits_equal(q._amax.float().cpu(), g.t(f"{k}_amax").reshape(q._amax.shape), f"{k} amax")
         y = q(x)
         assert y.shape == x.shape
-        assert_bits_equal(y.cpu(), g.t(f"{k}_y", dt).reshape(c["shape"]), f"{k} tiles of a rank-{len(c['shape'])} tensor")
+        assert_bits_equal(y.cpu(), g.t(f"{k}_y", dt).reshape(c["shape"]), f"{k} grid {grid} of a rank-{len(c['shape'])} tensor")
         assert_bits_equal(TensorQuantizer(cfg)(x).cpu(), g.t(f"{k}_ydyn", dt).reshape(c["shape"]), f"{k} dynamic amax")
         state = {kk: v.clone() for kk, v in q.state_dict().items()}
         q2 = TensorQuantizer(cfg)
-        q2.amax = state["_amax"]  # a restored buffer in the reference's shape serves the kernel's folded view
+        q2.amax = state["_amax"]  # a restored buffer in the reference's shape serves the kernels' folded view
         assert_bits_equal(q2(x).cpu(), y.cpu(), f"{k} from a restored amax")
-    assert seen == 9
+    assert seen == 9 + 15
