@@ -139,3 +139,50 @@ def test_the_loop_calibrates_a_hugging_face_model(monkeypatch):
     amax = lambda mod: {n: q._amax.clone() for n, q in mod.named_modules() if isinstance(q, moa.TensorQuantizer) and hasattr(q, "_amax")}  # noqa: E731
     x, y = amax(a), amax(b)
     assert set(x) == set(y) and len(x) > 20 and all(torch.equal(x[k], y[k]) for k in x)
+
+
+class _FakeGpu:
+    """torch.cuda's memory queries over a scripted device: every model call of batch b takes b * per_sample bytes (kept
+    as the allocator's peak), calls above `oom_above` samples run out of memory."""
+
+    def __init__(self, total, used, per_sample, oom_above):
+        self.total, self.free, self.per_sample, self.oom_above, self.peak, self.calls = total, total - used, per_sample, oom_above, 0, []
+
+    def install(self, mp):
+        mp.setattr(torch.cuda, "get_device_properties", lambda d=0: types.SimpleNamespace(total_memory=self.total))
+        mp.setattr(torch.cuda, "device_count", lambda: 1)
+        mp.setattr(torch.cuda, "mem_get_info", lambda d=0: (self.free, self.total))
+        mp.setattr(torch.cuda, "max_memory_allocated", lambda d=0: self.peak)
+        mp.setattr(torch.cuda, "empty_cache", lambda: None)
+
+    def model(self):
+        gpu = self
+
+        class M(torch.nn.Module):
+            device = torch.device("cpu")
+
+            def forward(self, x):
+                gpu.calls.append(x.shape[0])
+                if x.shape[0] > gpu.oom_above:
+                    raise torch.cuda.OutOfMemoryError("probe")
+                gpu.peak = max(gpu.peak, x.shape[0] * gpu.per_sample)
+                gpu.free = min(gpu.free, gpu.total - 1000 - x.shape[0] * gpu.per_sample) if x.shape[0] == 1 else gpu.free
+
+        return M()
+
+
+@pytest.mark.parametrize("total,used,per_sample,oom_above,want", [
+    (100_000, 1000, 10_000, 10**9, 8), (100_000, 1000, 30_000, 10**9, 2), (100_000, 1000, 60_000, 10**9, 1),
+    (10**9, 1000, 1000, 100, 60), (10**9, 1000, 100, 10**9, 512)])
+def test_get_max_batch_size_over_a_scripted_device(monkeypatch, total, used, per_sample, oom_above, want):
+    gpu = _FakeGpu(total, used, per_sample, oom_above)
+    gpu.install(monkeypatch)
+    got = fl.get_max_batch_size(gpu.model(), max_sample_length=8)
+    assert got == want, (got, gpu.calls)
+    if ref_shim.reference_available():  # the reference's probe over the same script
+        ref_shim.install()
+        from modelopt.torch.utils import dataset_utils as ref
+
+        twin = _FakeGpu(total, used, per_sample, oom_above)
+        twin.install(monkeypatch)
+        assert ref.get_max_batch_size(twin.model(), max_sample_length=8) == got and twin.calls == gpu.calls
