@@ -582,18 +582,26 @@ _KV_CACHE_REPLACEMENTS = {"k_bmm_quantizer._amax": "k_proj.k_scale", "v_bmm_quan
 
 
 def get_kv_cache_format(model) -> str | None:
-    """export/quant_utils.py:408-470 for this path: "FP8" when the enabled k / v bmm quantizers are E4M3, None when
-    there are none; every attention must agree (unified_export_hf.py:1679-1690)."""
+    """get_kv_cache_dtype / _compute_kv_cache_dtype (export/quant_utils.py:408-461) over the attentions of the model: "FP8"
+    when an enabled k / v bmm quantizer is E4M3, "INT8" for 8 bits, "NVFP4" / "NVFP4_AFFINE" for E2M1 (with offsets),
+    None when there are none; every attention must agree (unified_export_hf.py:1679-1690).  What the checkpoint writer
+    packs is FP8 (incl. the affine and cast-style presets): an INT8 KV cache stops it with the reference's assertion,
+    NVFP4 is outside this path."""
     fmt = None
     for m in model.modules():
         kq, vq = getattr(m, "k_bmm_quantizer", None), getattr(m, "v_bmm_quantizer", None)
         if kq is None or vq is None or not (kq.is_enabled or vq.is_enabled):
             continue
-        bits = {tuple(q._num_bits) if isinstance(q._num_bits, (tuple, list)) else q._num_bits
-                for q in (kq, vq) if q.is_enabled}
-        if bits != {(4, 3)}:
-            raise NotImplementedError(f"KV-cache format num_bits={bits} is outside this path (FP8 E4M3 only)")
-        this = KV_CACHE_FP8
+        live = [q for q in (kq, vq) if q.is_enabled]
+        bits = [tuple(q._num_bits) if isinstance(q._num_bits, (tuple, list)) else q._num_bits for q in live]
+        if (4, 3) in bits:
+            this = KV_CACHE_FP8
+        elif 8 in bits:
+            this = "INT8"
+        elif (2, 1) in bits:
+            this = "NVFP4_AFFINE" if all(hasattr(q, "_bias_value") for q in live) else "NVFP4"
+        else:
+            continue
         assert fmt in (None, this), "Do not support mixed precision kv cache quantization"
         fmt = this
     return fmt
@@ -608,7 +616,9 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
     for old, new in _KV_CACHE_REPLACEMENTS.items():
         if key.endswith(old):
             if "_amax" in key:
-                assert kv_format == KV_CACHE_FP8, "Invalid KV cache quantization format."
+                if kv_format in ("NVFP4", "NVFP4_AFFINE"):
+                    raise NotImplementedError("NVFP4 KV-cache scales are outside this path (FP8 E4M3 only)")
+                assert kv_format == KV_CACHE_FP8, "Invalid KV cache quantization format."  # (quant_utils.py:1038-1040)
                 value = (value.detach().float().cpu() / 448.0).to(value.device)  # IEEE division (see get_scaling_factor)
             return key[: -len(old)] + new, value
     return None, None

@@ -606,3 +606,23 @@ def test_small_quantizer_helpers_and_the_post_calibration_warning(monkeypatch):
     assert any(t.startswith("0.input_quantizer._amax contains invalid values: ") for t in texts), texts
     assert any(t.startswith("2.weight_quantizer._amax contains invalid values: ") for t in texts), texts
     assert len([t for t in texts if "contains invalid values" in t]) == 2
+
+
+def test_kv_cache_format_names_and_the_int8_refusal(monkeypatch):
+    """get_kv_cache_format names what _compute_kv_cache_dtype names (export/quant_utils.py:440-461); an INT8 KV cache stops
+    the checkpoint writer with the reference's assertion (quant_utils.py:1038-1040: only FP8 / NVFP4 amax become scales)."""
+    import hostmem_backend
+    import transformers as tf
+
+    hostmem_backend.install(monkeypatch, moa)
+    cfg = tf.LlamaConfig(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, num_key_value_heads=2,
+                         vocab_size=50, architectures=["LlamaForCausalLM"])
+    torch.manual_seed(0)
+    model = tf.LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    mq = moa.model_quant
+    qcfg = mq.update_quant_cfg_with_kv_cache_quant(mq.FP8_DEFAULT_CFG, {"*[kv]_bmm_quantizer": {"num_bits": 8, "axis": None, "enable": True}})
+    moa.quantize(model, qcfg, lambda m: m(torch.randint(0, 50, (2, 6))))
+    assert moa.export.get_kv_cache_format(model) == "INT8"
+    assert moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"] == "INT8"
+    with pytest.raises(AssertionError, match="Invalid KV cache quantization format"):
+        moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
