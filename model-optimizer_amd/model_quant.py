@@ -263,7 +263,8 @@ def set_quantizer_by_cfg(model: nn.Module, quant_cfg):
 # what the last quantize() call spent where (wall-clock seconds; the device is drained at the three stage boundaries,
 # where nothing is in flight that a later stage could have overlapped): convert = nn.Linear -> QuantLinear and the
 # on-the-fly attention / expert wrappers, set_quantizers = the wildcard config walk, calibrate = the algorithm (for
-# awq_lite its own stages are in model_calib.AWQ_LITE_STATS["stages_s"] and sum to this figure)
+# awq_lite its own stages are in model_calib.AWQ_LITE_STATS["stages_s"] and sum to this figure), validate = the
+# warning for invalid amax / pre-quant scales mtq.calibrate ends with (one flattened test per device)
 QUANTIZE_STATS: dict = {}
 
 
@@ -296,8 +297,9 @@ def quantize(model: nn.Module, config: dict, forward_loop=None) -> nn.Module:
     set_quantizer_by_cfg(model, config["quant_cfg"])
     stage("set_quantizers")
     _run_algorithm(model, config.get("algorithm", "max"), forward_loop)
-    _warn_invalid_quantizer_state(model)
     stage("calibrate")
+    _warn_invalid_quantizer_state(model)
+    stage("validate")
     return model
 
 
