@@ -68,9 +68,7 @@ def sync_moe_expert_amax(experts, sync_weight_amax: bool = False, calibrate_miss
     for expert in experts:
         for name, q in expert.named_modules():
             if isinstance(q, TensorQuantizer) and name in shared:
-                if hasattr(q, "_amax") and q._amax.shape != shared[name].shape:
-                    delattr(q, "_amax")
-                q.amax = shared[name].detach().clone()
+                q.replace_amax(shared[name].detach().clone())
     for expert in experts:
         for name, q in expert.named_modules():
             if name.endswith("weight_quantizer") and isinstance(q, TensorQuantizer) and q.is_enabled and q.amax is None:

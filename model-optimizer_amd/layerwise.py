@@ -266,9 +266,7 @@ def _load_quantizer_state(layer, state):
                 name = k.lstrip("_")
                 dev = next(layer.parameters()).device
                 if name == "amax":
-                    if hasattr(q, "_amax"):
-                        delattr(q, "_amax")
-                    q.amax = v.to(dev)
+                    q.replace_amax(v.to(dev))
                 elif name == "pre_quant_scale":
                     q.pre_quant_scale = v.to(dev)
 

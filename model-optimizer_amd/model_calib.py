@@ -92,9 +92,7 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
             else:
                 amax = q._calibrator.compute_amax(**({"method": method, **kwargs} if method else {}))
             if amax is not None:  # quantizers that saw no data keep whatever amax they had (:1155-1161)
-                if hasattr(q, "_amax") and q._amax.shape != amax.shape:
-                    delattr(q, "_amax")
-                q.amax = amax
+                q.replace_amax(amax)  # (buffer shape of the reference for N-D block grids, like load_calib_amax)
         if q.bias_calibrator is not None and q.bias_type == "static":
             q.load_calib_bias()  # the affine offset of the KV-cache presets (:1163-1164)
         q.enable_quant()  # dynamic quantizers come back on here (:1166)
@@ -952,7 +950,7 @@ def _awq_lite_layer_local(model: nn.Module, forward_loop, layers, **kw):
 @torch.no_grad()
 def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto",
              tie_margin: float | None = None, tie_check: bool = True, layer_local: bool | None = None,
-             store_activations: bool = False):
+             store_activations: bool | str = "auto"):
     """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
     (the INT4_AWQ_CFG preset).
 
@@ -970,11 +968,17 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              disagreement of the two engines on the re-scored candidates and widens per linear when it was too
              small (TIE_SPREAD_FACTOR); AWQ_LITE_STATS["tie_check"] reports the largest requirement / margin ratio.
 
-    store_activations: the cache pass keeps every searched linear's input and `out_actual` of every batch (references,
+    store_activations: True -- the cache pass keeps every searched linear's input and `out_actual` of every batch (references,
              counted against the HBM budget); the exact pass then REPLAYS them linear by linear instead of running
              forward_loop again -- no second forward, no second library GEMM for out_actual.  Only a call whose
              activations fit can do that (one decoder layer: 36 GB for Llama-3-8B at 64 x 4096 tokens); when a
              reservation fails the stores are dropped and the pass is a real one.
+             "inputs" -- only the INPUTS are kept, each distinct tensor object once (q / k / v and gate / up share theirs; a
+             model fed the same tensors layer after layer shares them across layers); the replay recomputes `out_actual`
+             with the linear's own un-folded weight, and only for the linears that have candidates to re-score.  A stored
+             tensor that was written in place afterwards (its version counter moved) sends the pass back to a real forward.
+             "auto" (default) = "inputs" for search="auto" when no other quantizer is enabled (their noise belongs to a real
+             search pass), else off.  False = always a second forward.
     layer_local (None = for search="auto" on Hugging Face decoder stacks): the model is walked ONE DECODER LAYER AT A TIME
              (layerwise.py's contract: layer N+1's input is layer N's output): the layer's batches run through it once --
              statistics, Gram matrices, stored activations and the inputs of the next layer all come from that one
@@ -1030,8 +1034,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 h.setup_disabled = True
             else:
                 iq.axis = -1
-    state = {"mode": "cache", "do_gemm": True, "do_exact": False, "store": bool(store_activations), "stored_bytes": 0,
-             "store_last": None}
+    if store_activations not in (True, False, "auto", "inputs"):
+        raise ValueError(f"awq_lite: store_activations must be True, False, 'inputs' or 'auto', got {store_activations!r}")
+    store_mode = {True: "full", False: False, "inputs": "inputs"}.get(store_activations, "inputs" if search == "auto" else False)
+    state = {"mode": "cache", "do_gemm": True, "do_exact": False, "store": store_mode, "stored_bytes": 0,
+             "store_last": None, "store_seen": {}}
     if mods:
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
@@ -1155,6 +1162,19 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         """store_activations: keep this batch's input and out_actual of this linear for the replayed exact pass.  The
         tensors exist anyway -- the store only keeps them alive -- and are charged to the HBM budget (an input shared by
         q / k / v or gate / up once)."""
+        if state["store"] == "inputs":
+            # the input only, charged once per distinct tensor object (kept alive in `store_seen`, so an id cannot be
+            # reused); out_actual is recomputed by the replay from the linear's own weight
+            nbytes = 0 if state["store_seen"].get(id(input)) is input else x2.numel() * x2.element_size()
+            if x2.data_ptr() != input.data_ptr():  # a strided input: the flattened copy is this linear's own
+                nbytes = x2.numel() * x2.element_size()
+            if not budget.reserve(nbytes):
+                drop_stores()
+                return
+            state["store_seen"][id(input)] = input
+            state["stored_bytes"] += nbytes
+            h.stored.append((x2, None, input, input._version))
+            return
         nbytes = out_actual.numel() * out_actual.element_size()
         if state["store_last"] is not input:
             nbytes += x2.numel() * x2.element_size()
@@ -1163,13 +1183,18 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             return
         state["store_last"] = input
         state["stored_bytes"] += nbytes
-        h.stored.append((x2, out_actual.reshape(-1, out_actual.shape[-1])))
+        h.stored.append((x2, out_actual.reshape(-1, out_actual.shape[-1]), None, None))
 
     def drop_stores():
         for hh in helpers.values():
             hh.stored = []
         budget.release(state["stored_bytes"])
         state["stored_bytes"], state["store"], state["store_last"] = 0, False, None
+        state["store_seen"] = {}
+
+    def stores_intact() -> bool:
+        """"inputs" mode: every kept input still holds what the cache pass read (no in-place write since)."""
+        return all(src is None or src._version == ver for hh in helpers.values() for _, _, src, ver in hh.stored)
 
     def replay_search_pass():
         """The search pass from the stored activations, linear by linear: every candidate this pass has to score of a
@@ -1188,7 +1213,9 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             else:
                 continue
             keep, h._cache_w = h._cache_w, True  # resident for this linear's batches, released right after
-            for x2, out2 in h.stored:
+            for x2, out2, _, _ in h.stored:
+                if out2 is None:  # "inputs": out_actual from the un-folded weight, as the patched forward computes it
+                    out2 = F.linear(x2, m.weight, m.bias)
                 error_gemms(m, h, x2, out2, subset, buf)
                 if h.use_gram:
                     h.num_exact_steps += 1
@@ -1198,6 +1225,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h._cache_w = keep
 
     def search_pass():
+        if state["store"] == "inputs" and not stores_intact():
+            drop_stores()
         if state["store"]:
             replay_search_pass()
             stats["replayed_passes"] = stats.get("replayed_passes", 0) + 1
@@ -1383,6 +1412,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         stats["passes"] += 1
         state.pop("act_input", None)  # (the last batch's input need not stay alive)
         state.pop("act_owner", None)
+        if state["store"] == "inputs":
+            stats["stored_input_bytes"] = state["stored_bytes"]
         stage("cache_pass")
         finish_stats_collection(others_holder)
         if others and dist.is_available() and dist.is_initialized():
@@ -1485,6 +1516,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h.release()
             h.gram = None
             h.stored = []
+        state["store_seen"] = {}
 
     def restore_input_quantizer(m, h):
         """:1642-1653 / :1707-1714: the per-channel amax is kept (on the host) for the smoothing step and collapses to
@@ -1679,7 +1711,7 @@ def awq(model: nn.Module, forward_loop=None, algorithm: str = "awq_lite", **kwar
     out = {}
     with SequentialQuantizer.convert_to_single_quantizer(model):  # search on the first (INT4) stage only (:1378)
         if algorithm in ("awq_full", "awq_lite"):
-            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin", "tie_check", "layer_local")}
+            lite_kw = {k: v for k, v in kwargs.items() if k in ("alpha_step", "search", "tie_margin", "tie_check", "layer_local", "store_activations")}
             out["awq_lite"] = awq_lite(model, forward_loop, **lite_kw)
         if algorithm in ("awq_full", "awq_clip"):
             clip_kw = {k: v for k, v in kwargs.items()

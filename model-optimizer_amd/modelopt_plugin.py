@@ -190,6 +190,31 @@ def _library_op_seam(original, ours):
     return op
 
 
+# what install() replaced, so that uninstall() can put the reference back as it was (A/B runs of the un-installed
+# reference in the same process: tests/test_gpu_reference_live.py)
+_UNSET = object()
+_SAVED: list = []
+
+
+def _swap(obj, name, new):
+    _SAVED.append((obj, name, obj.__dict__.get(name, _UNSET) if hasattr(obj, "__dict__") else getattr(obj, name, _UNSET)))
+    setattr(obj, name, new)
+
+
+def uninstall():
+    """Undo install(): every re-pointed attribute gets its previous value back (or is deleted if it did not exist).  The
+    registered quant backend name stays (the reference has no unregister call); nothing selects it unless configured."""
+    while _SAVED:
+        obj, name, old = _SAVED.pop()
+        if old is _UNSET:
+            try:
+                delattr(obj, name)
+            except AttributeError:
+                pass
+        else:
+            setattr(obj, name, old)
+
+
 def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True,
             library_ops: bool = False):
     """Wire the seams into an importable modelopt.  Returns the list of seams installed.  `library_ops` additionally
@@ -200,9 +225,9 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
 
     installed = []
     if extensions:
-        ext.get_cuda_ext.extension = IntExtension()
-        ext.get_cuda_ext_fp8.extension = Fp8Extension()
-        ext.get_cuda_ext_mx.extension = MxExtension()
+        _swap(ext.get_cuda_ext, "extension", IntExtension())
+        _swap(ext.get_cuda_ext_fp8, "extension", Fp8Extension())
+        _swap(ext.get_cuda_ext_mx, "extension", MxExtension())
         installed.append("S1:extensions")
     if backend:
         from modelopt.torch.quantization.nn.modules import tensor_quantizer as mtq_tq
@@ -216,8 +241,8 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
         if not getattr(core_utils.reduce_amax, "_moq_seam", False):
             seam = _reduce_amax_seam(core_utils.reduce_amax)
             seam._moq_seam = True
-            core_utils.reduce_amax = seam
-            qutils.reduce_amax = seam
+            _swap(core_utils, "reduce_amax", seam)
+            _swap(qutils, "reduce_amax", seam)
         installed.append("S6:reduce_amax")
     if sparsity_seam:
         from modelopt.torch.sparsity.weight_sparsity import magnitude
@@ -225,16 +250,16 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
         if not getattr(magnitude.create_asp_mask, "_moq_seam", False):
             seam = _asp_mask_seam(magnitude.create_asp_mask)
             seam._moq_seam = True
-            magnitude.create_asp_mask = seam
+            _swap(magnitude, "create_asp_mask", seam)
         installed.append("S5:create_asp_mask")
         from modelopt.torch.sparsity.weight_sparsity import sparsegpt
 
         if not getattr(sparsegpt.create_sgpt_mask, "_moq_seam", False):
             seam = _sgpt_mask_seam(sparsegpt.create_sgpt_mask)
             seam._moq_seam = True
-            sparsegpt.create_sgpt_mask = seam
-            sparsegpt.SparseGPTSearcher._hook_compute_hessian = _sgpt_hessian_seam(
-                sparsegpt.SparseGPTSearcher.__dict__["_hook_compute_hessian"])
+            _swap(sparsegpt, "create_sgpt_mask", seam)
+            _swap(sparsegpt.SparseGPTSearcher, "_hook_compute_hessian", _sgpt_hessian_seam(
+                sparsegpt.SparseGPTSearcher.__dict__["_hook_compute_hessian"]))
         installed.append("S5:create_sgpt_mask")
     if library_ops:
         from modelopt.torch.quantization import tensor_quant as ref_tq
@@ -243,8 +268,8 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
 
         if lo.define():
             if not getattr(ref_tq.quantize_op, "_moq_seam", False):
-                ref_tq.quantize_op = _library_op_seam(ref_tq.quantize_op, lo.quantize_op)
-                ref_tq.dynamic_block_quantize_op = _library_op_seam(ref_tq.dynamic_block_quantize_op,
-                                                                    lo.dynamic_block_quantize_op)
+                _swap(ref_tq, "quantize_op", _library_op_seam(ref_tq.quantize_op, lo.quantize_op))
+                _swap(ref_tq, "dynamic_block_quantize_op", _library_op_seam(ref_tq.dynamic_block_quantize_op,
+                                                                           lo.dynamic_block_quantize_op))
             installed.append("S2:library_ops")
     return installed

@@ -405,10 +405,25 @@ class TensorQuantizer(nn.Module):
             warnings.warn(msg)
             warnings.warn("Set amax to NaN!")
             calib_amax = torch.tensor(math.nan)
+        self.replace_amax(calib_amax)
+
+    def in_amax_buffer_shape(self, amax: torch.Tensor) -> torch.Tensor:
+        """A kernel-side (folded) amax in the shape the `_amax` BUFFER keeps -- the reference's: one entry per leading
+        index and tile / one per block with the block parts as 1 (`_block_amax_view`, set by _setup_for_blockquant for tiles
+        on tensors of rank > 2 and for blocks on other than the last axis); every other layout is its own buffer shape."""
         view = getattr(self, "_block_amax_view", None)
-        if view is not None and calib_amax.numel() == math.prod(view):
-            calib_amax = calib_amax.reshape(view)
-        self.amax = calib_amax
+        if view is not None and amax.numel() == math.prod(view):
+            return amax.reshape(view)
+        return amax
+
+    def replace_amax(self, amax: torch.Tensor):
+        """Every place that LOADS a calibrated amax (load_calib_amax, model_calib.finish_stats_collection, the MoE expert
+        sync, layer-by-layer restores) goes through here: buffer shape of the reference, a buffer of another shape dropped
+        first (the setter refuses a shape change)."""
+        amax = self.in_amax_buffer_shape(amax)
+        if hasattr(self, "_amax") and self._amax.shape != amax.shape:
+            delattr(self, "_amax")
+        self.amax = amax
 
     def export_amax(self):
         """tensor_quantizer.py:1087-1117: 0 / NaN entries are replaced by maxbound, values clamped to the dtype's

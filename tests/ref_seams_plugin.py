@@ -1,0 +1,33 @@
+"""pytest plugin for the subprocess that runs the REFERENCE's own GPU test files on top of this library
+(tests/test_gpu_reference_live.py, section C; `-p ref_seams_plugin`).  With MOQ_INSTALL_SEAMS=1 it calls
+modelopt_plugin.install() in pytest_configure -- before collection, because the reference's test modules call
+get_cuda_ext*() at import time (tests/gpu/torch/quantization/test_quantize_mxformats_cuda.py:26) -- and prints the seam
+counters at the end.  Test infrastructure only."""
+
+import os
+import sys
+
+
+def pytest_configure(config):
+    root = os.environ.get("MOQ_REPO_ROOT")
+    if root and root not in sys.path:
+        sys.path.insert(0, root)
+    if os.environ.get("MOQ_INSTALL_SEAMS") != "1":
+        return
+    import _moa_import
+
+    _moa_import.load()
+    from model_optimizer_amd import modelopt_plugin
+
+    config._moq_seams = modelopt_plugin.install()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not getattr(config, "_moq_seams", None):
+        terminalreporter.write_line("[seams] not installed (the reference's own eager / extension-less path)")
+        return
+    from model_optimizer_amd import modelopt_plugin
+
+    terminalreporter.write_line(f"[seams] installed: {config._moq_seams}")
+    for k, v in sorted(modelopt_plugin.STATS.items()):
+        terminalreporter.write_line(f"[seams] {k} = {v}")

@@ -97,7 +97,8 @@ def test_bare_contract_command_launches_its_own_ranks():
 
 def test_cpu_baseline_only_mode_prints_one_object(monkeypatch):
     """`--cpu-baseline-only` (the process the main run starts LAST for the CPU baseline) touches no GPU and prints the
-    cpu_baseline object."""
+    cpu_baseline object: kind "reference" (the reference's own eager path timed on this host, the C port beside it) wherever
+    the reference is present -- /root/reference here, the staged archive on the GPU box -- kind "port" otherwise."""
     import json
     import subprocess
     import sys
@@ -109,7 +110,15 @@ def test_cpu_baseline_only_mode_prints_one_object(monkeypatch):
     r = subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     obj = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert obj["kind"] == "port" and obj["unit"] == "GB/s" and obj["value"] > 0 and obj["cores"] >= 1
+    assert obj["unit"] == "GB/s" and obj["value"] > 0 and obj["cores"] >= 1
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import ref_shim
+
+    if ref_shim.reference_available():
+        assert obj["kind"] == "reference" and obj["reference_source"] in ("checkout", "staged")
+        assert "max_calibrate(TensorQuantizer)" in obj["sample"] and obj["port"]["value"] > 0
+    else:
+        assert obj["kind"] == "port"
 
 
 def test_committed_pmc_traffic_matches_the_algorithmic_bytes():

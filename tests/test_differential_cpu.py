@@ -76,13 +76,17 @@ def _batches():
     return [torch.randint(0, CFG["vocab_size"], (3, 24), generator=torch.Generator().manual_seed(40 + i)) for i in range(3)]
 
 
-def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
+def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
+    """`device`: None = host tensors (this tier); "cuda" = the same run with the model and the batches on the GPU
+    (tests/test_gpu_reference_live.py: the reference's eager path with device tensors, staged or checked out)."""
     ref_shim.install()
     import modelopt.torch.quantization as mtq
     from modelopt.torch.export import export_hf_checkpoint
     from safetensors import safe_open
 
     model = _model(dtype, arch)
+    if device is not None:
+        model = model.to(device)
     cfg = copy.deepcopy(getattr(mtq, preset))
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
@@ -91,15 +95,15 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
         if with_kv == "cast":  # configs/ptq/units/kv_fp8_cast.yaml (hf_ptq.py's default KV format): amax fixed at 448
             kv = {"quant_cfg": [{"quantizer_name": "*[kv]_bmm_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "use_constant_amax": True}}]}
         cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(kv["quant_cfg"]))
-    batches = _batches()
+    batches = [b.to(device) if device is not None else b for b in _batches()]
     loop = (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None
     q = mtq.quantize(model, cfg, loop)
-    amax = {n: m._amax.detach().float().clone() for n, m in q.named_modules()
+    amax = {n: m._amax.detach().float().cpu().clone() for n, m in q.named_modules()
             if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
     logits = None
     if "MXFP" not in preset:  # the reference's MX fake quant has no CPU implementation
         with torch.no_grad():
-            logits = q(batches[0]).logits.clone()
+            logits = q(batches[0]).logits.cpu().clone()
     out = {"__logits__": logits}
     if arch == "llama-ragged":  # the reference's INT4 packer indexes past its scale tensor for a padded last block
         return amax, out
@@ -117,25 +121,27 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None):
     return amax, out
 
 
-def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None):
+def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
     mq = moa.model_quant
     model = _model(dtype, arch)
+    if device is not None:
+        model = model.to(device)
     cfg = copy.deepcopy(getattr(mq, preset))
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
         kv = {"affine": mq.FP8_AFFINE_KV_CFG, "cast": mq.FP8_CAST_KV_CFG}.get(with_kv, mq.FP8_KV_CFG)
         cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, kv["quant_cfg"])
-    batches = _batches()
+    batches = [b.to(device) if device is not None else b for b in _batches()]
     with torch.no_grad():
         moa.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
-    amax = {n: m._amax.detach().float().clone() for n, m in model.named_modules()
+    amax = {n: m._amax.detach().float().cpu().clone() for n, m in model.named_modules()
             if isinstance(m, moa.TensorQuantizer) and m.is_enabled and getattr(m, "_amax", None) is not None}
     with torch.no_grad():
-        logits = model(batches[0]).logits.clone()
+        logits = model(batches[0]).logits.cpu().clone()
     if arch == "llama-ragged":
         return amax, {"__logits__": logits}
-    state = moa.export.export_state_dict(model, dtype, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+    state = moa.export.export_state_dict(model, dtype, lambda: model(torch.ones([1, 2], dtype=torch.long, device=device)))
     state["__logits__"] = logits
     quant = moa.export.hf_quant_config(model)
     state["__quant_json__"] = (quant["quantization"], moa.export.convert_hf_quant_config_format(quant))

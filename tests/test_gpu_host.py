@@ -14,7 +14,7 @@ from conftest import DT, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 moa = _moa_import.load()
-from model_optimizer_amd import QuantizerAttributeConfig, TensorQuantizer, calib, model_quant, ops  # noqa: E402
+from model_optimizer_amd import QuantizerAttributeConfig, TensorQuantizer, calib, model_calib, model_quant, ops  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 DEV = "cuda:0"
@@ -550,4 +550,11 @@ def test_tensor_quantizer_tiles_on_the_last_two_axes_of_any_rank(golden):
         q2 = TensorQuantizer(cfg)
         q2.amax = state["_amax"]  # a restored buffer in the reference's shape serves the kernels' folded view
         assert_bits_equal(q2(x).cpu(), y.cpu(), f"{k} from a restored amax")
+        # the PRODUCT path: max_calibrate -> finish_stats_collection (every quantize() flow) leaves the same buffer shape
+        # and values as load_calib_amax does (advisor, round 4: it kept the kernel's folded shape)
+        q3 = TensorQuantizer(cfg)
+        model_calib.max_calibrate(q3, (lambda qq: (qq(x), qq(x * 0.5))) if "grid" in c else (lambda qq: qq(x)), distributed_sync=False)
+        assert list(q3._amax.shape) == c["amax_shape"], f"{k}: max_calibrate left amax {list(q3._amax.shape)}"
+        assert_bits_equal(q3._amax.float().cpu(), q._amax.float().cpu(), f"{k} amax through max_calibrate")
+        assert_bits_equal(q3(x).cpu(), y.cpu(), f"{k} output after max_calibrate")
     assert seen == 9 + 15

@@ -596,10 +596,10 @@ def test_awq_lite_layer_local_equals_the_whole_model_flow(hostmem, monkeypatch, 
     cfg["quant_cfg"]["*embed*"] = {"enable": False}
     cfg["quant_cfg"]["*weight_quantizer"] = {"num_bits": 4, "block_sizes": {-1: 32, "type": "static"}, "enable": True}
 
-    def run(layer_local):
+    def run(layer_local, store="auto"):
         c = copy.deepcopy(cfg)
         c["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "search": "auto", "layer_local": layer_local,
-                          **({"tie_margin": tie_margin} if tie_margin is not None else {})}
+                          "store_activations": store, **({"tie_margin": tie_margin} if tie_margin is not None else {})}
         calls = {"n": 0}
 
         def loop(m):
@@ -611,12 +611,20 @@ def test_awq_lite_layer_local_equals_the_whole_model_flow(hostmem, monkeypatch, 
             q = moa.quantize(copy.deepcopy(base), c, loop)
         return q, dict(model_calib.AWQ_LITE_STATS), calls["n"]
 
-    whole, ws, wn = run(False)
+    whole, ws, wn = run(False, store=False)  # the two-pass structure: a second forward for the exact pass
     local, ls, ln = run(True)
+    kept, ks, kn = run(False)  # whole model, inputs kept by tensor identity, out_actual recomputed in the replay
     assert ls.get("layer_local") and ls["passes"] == 1 and ls["layers"] == 3 and ln == 1
     if tie_margin is not None:
         assert ls["replayed_passes"] >= 3 and ws["passes"] >= 2 and wn >= 2  # the whole-model flow needed a second forward
         assert ls["rescored_candidates"] == ws["rescored_candidates"] > 0
+        assert ks["passes"] == 1 and kn == 1 and ks["replayed_passes"] >= 1 and ks["stored_input_bytes"] > 0, ks
+        assert ks["rescored_candidates"] == ws["rescored_candidates"]
+    for (name, a), (_, b) in zip(whole.named_modules(), kept.named_modules()):
+        if hasattr(a, "awq_lite"):
+            assert a.awq_lite.best_alpha == b.awq_lite.best_alpha and a.awq_lite.contenders == b.awq_lite.contenders, name
+            assert torch.equal(a.awq_lite.loss_buf, b.awq_lite.loss_buf), name
+            assert torch.equal(a.weight, b.weight), name
     n = 0
     for (name, a), (_, b) in zip(whole.named_modules(), local.named_modules()):
         if hasattr(a, "awq_lite"):
