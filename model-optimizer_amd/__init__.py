@@ -21,6 +21,7 @@ No CPU fallback exists: every op raises if the HIP library is missing or a tenso
 """
 
 from . import _lib  # noqa: F401
+from . import numerics  # noqa: F401
 from ._lib import MoquantError, MoquantUnsupported  # noqa: F401
 from . import ops  # noqa: F401
 from . import multi_tensor  # noqa: F401

@@ -637,6 +637,11 @@ class MseCalibrator(_Calibrator):
         # GPU kernels round that product differently (the GPU casts the 0-dim operand to the 16-bit dtype first).
         # One ulp of amax moves a clipping-dominated loss by >10 %, so the product is formed with the host
         # arithmetic the CPU-run reference fixtures are pinned to -- identical on every device.
+        # (numerics "device": torch's own product on the amax's device -- the reference's run on that device)
+        from . import numerics
+
+        if not numerics.on_host():
+            return self._initial_amax * candidates.to(self._initial_amax.device)
         if self._initial_amax_host is None:
             self._initial_amax_host = self._initial_amax.detach().cpu()
         return (self._initial_amax_host * candidates.detach().cpu()).to(self._initial_amax.device)

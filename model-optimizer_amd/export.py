@@ -21,7 +21,7 @@ from collections import defaultdict
 import torch
 from torch import nn
 
-from . import ops
+from . import numerics, ops
 from .hf_experts import is_quant_fused_experts
 from .nn import is_quantized_linear
 from .tensor_quantizer import SequentialQuantizer
@@ -89,9 +89,10 @@ def get_scaling_factor(quantizer) -> torch.Tensor | None:
     amax = quantizer.export_amax()
     if amax is None:
         return None
-    # IEEE fp32 division on the host: torch's GPU kernel turns `tensor / python_scalar` into a multiplication by
-    # the reciprocal (last-bit differences), the CPU kernel the reference fixtures come from divides
-    scaling_factor = (amax.float().cpu() / quantizer.maxbound).to(amax.device)
+    # numerics "host" (default): IEEE fp32 division on the host -- torch's GPU kernel turns `tensor / python_scalar` into a
+    # multiplication by the reciprocal (last-bit differences), the CPU kernel the reference fixtures come from divides;
+    # "device": torch's own kernel on amax's device, i.e. what the reference's run on that device writes
+    scaling_factor = numerics.div_scalar(amax, quantizer.maxbound)
     assert torch.all(scaling_factor > 0), f"scaling factor {scaling_factor} not positive."
     return scaling_factor
 
@@ -466,7 +467,7 @@ def export_quantized_weight(module, dtype: torch.dtype):
         amax = wq._amax.to(torch.float32)
         # per-tensor: python float division of amax.item() (unified_export_hf.py:643-647)
         weight_scale = (torch.tensor(amax.item() / wq.maxbound) if amax.numel() == 1
-                        else (amax.cpu() / wq.maxbound).to(amax.device))
+                        else numerics.div_scalar(amax, wq.maxbound))
     else:
         weight_scale = get_weight_scaling_factor(module)
         if fmt in (QUANTIZATION_INT8_SQ, QUANTIZATION_INT8_WO, QUANTIZATION_FP8_PC_PT) and weight_scale.dim() > 1:
@@ -619,7 +620,7 @@ def _postprocess_kv_key(key: str, value: torch.Tensor, kv_format: str | None):
                 if kv_format in ("NVFP4", "NVFP4_AFFINE"):
                     raise NotImplementedError("NVFP4 KV-cache scales are outside this path (FP8 E4M3 only)")
                 assert kv_format == KV_CACHE_FP8, "Invalid KV cache quantization format."  # (quant_utils.py:1038-1040)
-                value = (value.detach().float().cpu() / 448.0).to(value.device)  # IEEE division (see get_scaling_factor)
+                value = numerics.div_scalar(value, 448.0)  # (see get_scaling_factor)
             return key[: -len(old)] + new, value
     return None, None
 

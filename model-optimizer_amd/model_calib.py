@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import distributed as mdist
+from . import numerics
 from . import ops
 from .multi_tensor import SegmentTable
 from .hf_experts import is_quant_fused_experts
@@ -561,13 +562,15 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
 def get_scale(x_max, w_max, alpha):
     """model_calib.py:1474-1487 (no tensor parallel group here).
 
-    The [Cin] vector math (pow, divide, clamp, normalise) runs on the HOST in IEEE fp32, whatever device the
-    statistics live on: it is a few microseconds of work per candidate, and the GPU math library's pow / torch's
-    reciprocal-multiply for `tensor / scalar` differ from the host's in the last bit, which would make the folded
-    weights -- and with them every byte of the exported checkpoint -- depend on the device the search ran on.  The
-    result goes back to x_max's device."""
+    The [Cin] vector math (pow, divide, clamp, normalise) runs where numerics.mode() puts it.  "host" (default): IEEE fp32
+    on the host whatever device the statistics live on -- the GPU math library's pow and torch's reciprocal-multiply for
+    `tensor / scalar` differ from the host's in the last bit, which would make the folded weights, and with them every byte
+    of the exported checkpoint, depend on the device the search ran on; the result equals the reference's CPU run.
+    "device": the same expression on the statistics' device -- the reference's run on THAT device bit for bit, no round
+    trip.  The result goes back to x_max's device."""
     dev = x_max.device
-    x, w = x_max.detach().float().cpu(), w_max.detach().float().cpu()
+    x, w = numerics.vec(x_max), numerics.vec(w_max)
+    w = w.to(x.device)
     scales = (x.pow(alpha) / (w.pow(1 - alpha) + torch.finfo(torch.float32).tiny)).clamp(min=1e-4, max=1e4).view(-1)
     return (scales / (scales.max() * scales.min()).sqrt()).view(-1).to(dev)
 
@@ -589,15 +592,6 @@ def host_math_threads(n: int = 1):
         yield
     finally:
         torch.set_num_threads(before)
-
-
-def _host_div(t: torch.Tensor, divisor: float) -> torch.Tensor:
-    """t / divisor as IEEE fp32 division on the host (see get_scale), back on t's device."""
-    return (t.detach().float().cpu() / divisor).to(t.device)
-
-
-def _host_reciprocal(t: torch.Tensor) -> torch.Tensor:
-    return (1.0 / t.detach().float().cpu()).to(t.device)
 
 
 class _WeightCacheBudget:
@@ -707,8 +701,7 @@ class AWQLiteHelper:
     def scale(self, alpha):
         """get_scale(act_scale, weight_scale, alpha) on the statistics' device (computed on the host, see prepare_scales)."""
         if self._s_dev is None:
-            self.prepare_scales(self.act_scale.detach().float().cpu(), self.weight_scale.detach().float().cpu(),
-                                self.dtype)
+            self.prepare_scales(numerics.vec(self.act_scale), numerics.vec(self.weight_scale), self.dtype)
         return self._s_dev[self.alphas.index(alpha)]
 
     def search_operands(self, module, subset=None):
@@ -1427,7 +1420,11 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         if state["gram_pass"] == "cache":
             finish_gram_pass()
         cached = [h for h in helpers.values() if h.num_cache_steps]
-        if cached:
+        if cached and not numerics.on_host():
+            # act_scale = act_sum / steps (:1601) as torch evaluates `tensor / int` on the statistics' device
+            for h in cached:
+                h.act_scale = h.act_sum.detach().float() / h.num_cache_steps
+        elif cached:
             # act_scale = act_sum / steps (:1601) as IEEE division on the host (see get_scale) -- for ALL linears in one
             # device -> host copy and one upload instead of a stream drain per linear
             flat = torch.cat([h.act_sum.detach().float().reshape(-1) for h in cached]).cpu()
@@ -1453,7 +1450,10 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             # every candidate scale vector of every linear: ONE device -> host copy of all statistics, the [Cin]-sized
             # math on the host (get_scale), one upload per linear -- all before the first scoring kernel is queued
             live = [(m, helpers[m]) for _, m in mods if helpers[m].act_scale is not None]
-            if live:
+            if live and not numerics.on_host():
+                for m, h in live:  # the same tables from device tensors (numerics "device": no copy, no host math)
+                    h.prepare_scales(h.act_scale, h.weight_scale, m.weight.dtype)
+            elif live:
                 flat = torch.cat([t.detach().float().reshape(-1) for _, h in live for t in (h.act_scale, h.weight_scale)]).cpu()
                 jobs, off = [], 0
                 for m, h in live:
@@ -1571,7 +1571,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         # postprocess (:1636-1659) -> apply_pre_quant_scale_and_smooth(module, 1 / best_scale) (:1226-1252): the input
         # gets 1/s in the weight dtype; the weight is multiplied (fp32, one rounding) by 1 / (1/s) -- the fp32 double
         # reciprocal, which is not always s itself -- and recalibrated
-        pqs_host = 1.0 / h._s_host[best_idx]  # IEEE fp32 on the host, like every scale vector (get_scale)
+        pqs_host = 1.0 / h._s_host[best_idx]  # where every scale vector was formed (get_scale: host IEEE fp32, or the device)
         both = torch.stack([pqs_host, 1.0 / pqs_host]).to(m.weight.device)
         pre_quant_scale = both[0]
         ops.scale_cols(m.weight.data, both[1], out=m.weight.data)

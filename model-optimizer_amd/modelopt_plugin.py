@@ -34,21 +34,36 @@ def _count(key: str):
     STATS[key] += 1
 
 
+def _int_bits(num_bits, who):
+    """A bit width the INT kernels do not take is the seam's "layout not supported": ValueError, which the reference's
+    callers answer with their eager path (tensor_quant.py:386-389) -- e.g. its own test_overflow_fp16
+    (tests/_test_utils/torch/quantization/tensor_quant_common.py:131-136) passes `8, False` into the (bias, num_bits)
+    slots of FakeTensorQuantFunction, i.e. num_bits = False; the CUDA kernel shifts by -1 there, eager computes something
+    finite, an exception other than ValueError / AttributeError would fail the caller."""
+    if isinstance(num_bits, bool) or not isinstance(num_bits, int) or not 2 <= num_bits <= 16:
+        _count(f"S1:{who}:fallback:num_bits={num_bits!r}")
+        raise ValueError(f"{who}: num_bits={num_bits!r} is outside the INT kernels' range [2, 16]")
+    return num_bits
+
+
 class IntExtension:
     """Stands in for the `modelopt_cuda_ext` pybind module."""
 
     @staticmethod
     def fake_tensor_quant(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        num_bits = _int_bits(num_bits, "fake_tensor_quant")
         _count("S1:fake_tensor_quant")
         return ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range)
 
     @staticmethod
     def fake_tensor_quant_(inputs, amax, num_bits=8, unsigned=False, narrow_range=True):
+        num_bits = _int_bits(num_bits, "fake_tensor_quant_")
         _count("S1:fake_tensor_quant_")
         ops.fake_tensor_quant(inputs, amax.reshape(-1)[:1], num_bits, unsigned, narrow_range, inplace=True)
 
     @staticmethod
     def fake_tensor_quant_with_axis(inputs, amax, axis, num_bits=8, unsigned=False, narrow_range=True):
+        num_bits = _int_bits(num_bits, "fake_tensor_quant_with_axis")
         _count("S1:fake_tensor_quant_with_axis")
         return ops.fake_tensor_quant_with_axis(inputs, amax, axis, num_bits, unsigned, narrow_range)
 
@@ -135,7 +150,7 @@ def _reduce_amax_seam(original):
         except _lib.MoquantUnsupported as e:
             # the reference's convention for its own extensions (tensor_quant.py:386-389): an unsupported layout
             # falls back to eager -- counted, so that coverage holes show up
-            _count(f"S6:reduce_amax:fallback:{type(e).__name__}")
+            _count(f"S6:reduce_amax:fallback:{type(e).__name__}:{str(e)[:60]}")
             return original(input, axis=axis, keepdims=keepdims, squeeze_scalar=squeeze_scalar)
 
     return reduce_amax

@@ -77,6 +77,45 @@ def _group_kernel_takes(g: int, dtype) -> bool:
     return g % vec == 0 and 0 < p <= 64 and p & (p - 1) == 0
 
 
+class _BufferState:
+    """Descriptor for quantizer state kept in a registered buffer `_<name>` (so it travels with state_dict / .to()).
+
+    get: the buffer, or None while it does not exist (or while `shown(q)` is false: a disabled smoothing scale reads None).
+    set: None is refused; numbers become tensors; the FIRST assignment registers a detached clone as the buffer; later ones
+         copy into it on the buffer's device -- `same_shape`: refusing another shape (amax, offset; a quantizer whose layout
+         changed must drop the buffer first), else replacing the buffer's tensor (the smoothing scale); then `after(q)`."""
+
+    def __init__(self, name, label=None, same_shape=True, shown=None, after=None):
+        self.slot, self.label, self.same_shape, self.shown, self.after = "_" + name, label or name, same_shape, shown, after
+
+    def __get__(self, q, owner=None):
+        if q is None:
+            return self
+        if self.shown is not None and not self.shown(q):
+            return None
+        return getattr(q, self.slot, None)
+
+    def __set__(self, q, value):
+        assert value is not None, f"{self.label} cannot be set to None."
+        fresh = (value if isinstance(value, torch.Tensor) else torch.tensor(value)).clone().detach()
+        held = getattr(q, self.slot, None)
+        if held is None:
+            q.register_buffer(self.slot, fresh)
+        elif not self.same_shape:
+            setattr(q, self.slot, fresh.to(held.device))
+        elif held.shape != fresh.shape:
+            raise RuntimeError(f"Changing shape when setting {self.label} is not allowed.")
+        else:
+            held.data.copy_(fresh.to(held.device))
+        if self.after is not None:
+            self.after(q)
+
+    @staticmethod
+    def drop(q, name):
+        if hasattr(q, "_" + name):
+            delattr(q, "_" + name)
+
+
 class TensorQuantizer(nn.Module):
     def __init__(self, quant_attribute_cfg: QuantizerAttributeConfig | None = None, if_quant=True,
                  if_calib=False, amax=None):
@@ -189,23 +228,13 @@ class TensorQuantizer(nn.Module):
         raise MoquantUnsupported(f"maxbound of {self._num_bits}")
 
     # ------------------------------------------------------------------ state
-    @property
-    def amax(self):
-        return getattr(self, "_amax", None)
-
-    @amax.setter
-    def amax(self, value):
-        assert value is not None, "amax cannot be set to None."
-        if not isinstance(value, torch.Tensor):
-            value = torch.tensor(value)
-        if not hasattr(self, "_amax"):
-            self.register_buffer("_amax", value.clone().detach())
-        else:
-            if self._amax.shape != value.shape:
-                raise RuntimeError("Changing shape when setting amax is not allowed.")
-            self._amax.data.copy_(value.clone().detach().to(self._amax.device))
-        if getattr(self, "_is_static_block_scale_quantizer", False):
-            self._preserve_amax_in_fp32()
+    # The three tensors a quantizer carries -- amax, the affine offset, the smoothing scale -- live in registered buffers
+    # (`_amax`, `_bias_value`, `_pre_quant_scale`: the names the reference's state_dicts use) and are reached through ONE
+    # descriptor, _BufferState below: first assignment registers the buffer, later ones copy into it.  Names, error texts
+    # and the None rules are the reference's interface (nn/modules/tensor_quantizer.py:341-376, :472-520).
+    amax = _BufferState("amax", after=lambda q: q._preserve_amax_in_fp32() if getattr(q, "_is_static_block_scale_quantizer", False) else None)
+    bias_value = _BufferState("bias_value", label="bias")
+    pre_quant_scale = _BufferState("pre_quant_scale", same_shape=False, shown=lambda q: q._enable_pre_quant_scale)
 
     def _preserve_amax_in_fp32(self):
         """StaticBlockScaleQuantizer._preserve_amax_in_fp32 (tensor_quantizer.py:1501-1518)."""
@@ -221,27 +250,14 @@ class TensorQuantizer(nn.Module):
 
     def reset_amax(self):
         self._weight_stats_done = None
-        if hasattr(self, "_amax"):
-            delattr(self, "_amax")
+        _BufferState.drop(self, "amax")
         self._calibrator.reset()
         self.reset_bias()
 
     # ------------------------------------------------------------------ affine offset (tensor_quantizer.py:389-503, :722-734, :775-786)
     bias = property(lambda self: self._bias)
-    bias_method = property(lambda self: None if self._bias is None else self._bias.get("method", "mean"))
-
-    @property
-    def bias_type(self):
-        return None if self._bias is None else self._bias.get("type", "static")
-
-    @bias_type.setter
-    def bias_type(self, value):
-        assert value in ("static", "dynamic"), "bias_type must be either 'static' or 'dynamic'."
-        self._bias["type"] = value
-
-    @property
-    def bias_axis(self):
-        return getattr(self, "_bias_axis", None)
+    bias_method = property(lambda self: (self._bias or {}).get("method", "mean") if self._bias is not None else None)
+    bias_axis = property(lambda self: getattr(self, "_bias_axis", None))
 
     @bias_axis.setter
     def bias_axis(self, value):
@@ -250,68 +266,43 @@ class TensorQuantizer(nn.Module):
         self._bias_axis = value
 
     @property
-    def bias_value(self):
-        return getattr(self, "_bias_value", None)
+    def bias_type(self):
+        return (self._bias or {}).get("type", "static") if self._bias is not None else None
 
-    @bias_value.setter
-    def bias_value(self, value):
-        assert value is not None, "bias cannot be set to None."
-        if not isinstance(value, torch.Tensor):
-            value = torch.tensor(value)
-        if not hasattr(self, "_bias_value"):
-            self.register_buffer("_bias_value", value.clone().detach())
-        else:
-            if self._bias_value.shape != value.shape:
-                raise RuntimeError("Changing shape when setting bias is not allowed.")
-            self._bias_value.data.copy_(value.clone().detach().to(self._bias_value.device))
+    @bias_type.setter
+    def bias_type(self, value):
+        assert value in ("static", "dynamic"), "bias_type must be either 'static' or 'dynamic'."
+        self._bias["type"] = value
 
     @property
     def bias_calibrator(self):
-        if self._bias_calibrator is None and self._bias is not None:
+        """Made on first use from the config's offset entry: its integer keys are the axes the offset keeps."""
+        if self._bias is not None and self._bias_calibrator is None:
             self.bias_axis = tuple(k for k in self._bias if isinstance(k, int))
             self._bias_calibrator = BiasCalibrator(method=self.bias_method, axis=self.bias_axis)
         return self._bias_calibrator
 
     def reset_bias(self):
-        if hasattr(self, "_bias_value"):
-            delattr(self, "_bias_value")
+        _BufferState.drop(self, "bias_value")
         if self._bias_calibrator is not None:
             self._bias_calibrator.reset()
 
     def load_calib_bias(self, *args, **kwargs):
         assert not self._dynamic, "Dynamic quantization does not need calibration."
-        calib_bias = self.bias_calibrator.compute_bias(*args, **kwargs)
-        if calib_bias is None:
+        found = self.bias_calibrator.compute_bias(*args, **kwargs)
+        if found is None:
             raise RuntimeError("Calibrator returned None. This usually happens when calibrator hasn't seen any tensor.")
-        if not hasattr(self, "_bias_value"):
-            self.register_buffer("_bias_value", calib_bias.clone().detach())
-        else:
-            self._bias_value.data.copy_(calib_bias.clone().detach())
+        _BufferState.drop(self, "bias_value") if self.bias_value is not None and self.bias_value.shape != found.shape else None
+        self.bias_value = found
 
     def _get_bias(self, inputs):
-        if self.bias_calibrator is None:
+        """The offset of this call: the calibrated buffer, or (type dynamic) the statistic of the input itself."""
+        cal, kind = self.bias_calibrator, self.bias_type
+        if cal is None:
             return None
-        if self.bias_type == "static":
-            return self._bias_value
-        if self.bias_type == "dynamic":
-            return self.bias_calibrator.compute_dynamic_bias(inputs)
-        raise ValueError(f"Unsupported bias type: {self.bias_type}")
-
-    @property
-    def pre_quant_scale(self):
-        if not hasattr(self, "_pre_quant_scale") or not self._enable_pre_quant_scale:
-            return None
-        return self._pre_quant_scale
-
-    @pre_quant_scale.setter
-    def pre_quant_scale(self, value):
-        assert value is not None, "pre_quant_scale cannot be set to None."
-        if not isinstance(value, torch.Tensor):
-            value = torch.tensor(value)
-        if not hasattr(self, "_pre_quant_scale"):
-            self.register_buffer("_pre_quant_scale", value.clone().detach())
-        else:
-            self._pre_quant_scale = value.clone().detach().to(self._pre_quant_scale.device)
+        if kind not in ("static", "dynamic"):
+            raise ValueError(f"Unsupported bias type: {kind}")
+        return self._bias_value if kind == "static" else cal.compute_dynamic_bias(inputs)
 
     @property
     def step_size(self):

@@ -735,3 +735,26 @@ def test_block_grids_on_any_axes_equal_the_reference_live(monkeypatch, dtype):
         what = f"{nb} {grid} {shape}"
         assert a.shape == ra.shape and a.dtype == ra.dtype and torch.equal(a.float(), ra.float()), what
         assert torch.equal(y, ry) and torch.equal(d, rd), what
+
+
+@pytest.mark.parametrize("preset,dtype,with_kv", [("INT4_AWQ_CFG", torch.bfloat16, False), ("FP8_DEFAULT_CFG", torch.float16, True),
+                                                  ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False)])
+def test_scale_math_on_the_tensors_own_device_equals_the_reference_on_that_device_live(monkeypatch, preset, dtype, with_kv):
+    """numerics mode "device": the flows' small-vector scale math (AWQ scale tables, `amax / maxbound`, ...) as torch
+    evaluates the reference's expressions where the statistics live.  In this tier that device is the host, so the result
+    must equal the reference's (CPU) run like the default mode does; on the GPU the same test runs against the reference's
+    GPU run (tests/test_gpu_reference_live.py, section B), which differs from its CPU run in the last bit of the scales."""
+    ref_amax, ref_state = _reference_run(preset, dtype, with_kv)
+    hostmem_backend.install(monkeypatch, moa)
+    with moa.numerics.scale_math("device"):
+        assert moa.numerics.mode() == "device"
+        our_amax, our_state = _our_run(preset, dtype, with_kv)
+    assert moa.numerics.mode() == "host"
+    for n, a in ref_amax.items():
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), n
+    ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert torch.equal(our_state.pop("__logits__"), ref_state.pop("__logits__"))
+    assert sorted(our_state) == sorted(ref_state)
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), k

@@ -217,9 +217,14 @@ DEVICE_DIFF_CASES = [
 def test_this_package_on_the_device_equals_the_reference_eager_run_on_the_device(ref, preset, dtype, with_kv, arch):
     """Same tiny model, same batches, both sides on cuda:0: the reference's eager torch ops vs the HIP library through the
     C-ABI.  The model's own GEMMs are the same library kernels on both sides, every quantize-dequantize in between is
-    bit-exact, so activations -- and with them every activation amax -- must agree exactly, not within a tolerance."""
+    bit-exact, so activations -- and with them every activation amax -- must agree exactly, not within a tolerance.
+    The small-vector scale math runs in numerics mode "device" here: the reference writes a different checkpoint from a GPU
+    run than from a CPU run (torch's GPU `tensor / scalar` multiplies by a reciprocal: every `amax / maxbound` scale can
+    move by an ulp -- first seen as 1 ulp in down_proj.input_scale of this very test), and the default "host" mode equals its
+    CPU run (the committed fixtures); "device" must equal the run on THIS device byte for byte."""
     ref_amax, ref_state = diff._reference_run(preset, dtype, with_kv, arch, None, device=DEV)
-    our_amax, our_state = diff._our_run(preset, dtype, with_kv, arch, None, device=DEV)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run(preset, dtype, with_kv, arch, None, device=DEV)
     for n, a in ref_amax.items():
         assert n in our_amax, f"{preset}: quantizer {n} has no amax here"
         assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"{preset}: amax of {n} differs"
@@ -245,7 +250,8 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     percent).  Stated tolerance: at least 90 % of the linears pick the reference's alpha (their scales, packed weights and
     weight scales are then byte-identical, which is asserted), and the fake-quantized logits agree to 2e-2 of their range."""
     ref_amax, ref_state = diff._reference_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
-    our_amax, our_state = diff._our_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
     ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
     ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
     assert sorted(our_state) == sorted(ref_state)
@@ -325,18 +331,43 @@ def run_reference_tests(files, seams=True, timeout=900, extra_args=()):
     return counts, outcomes, out
 
 
+# Reasons a reference test may fail on this box that have nothing to do with the seams (matched in the test's own failure
+# text); every other failure fails this suite.
+REFERENCE_TEST_FAILURE_REASONS = {
+    "__nv_isnanf": "the reference's Triton NVFP4 kernels (kernels/quantization/gemm/fp4_kernel.py) call CUDA libdevice "
+                   "functions the ROCm Triton backend refuses -- its own code, never reaches a seam",
+    "NF4 is outside the MI355X PTQ path": "NF4 real quantization is outside SURVEY section 8 (the adapter says so)",
+}
+
+
+def _failure_sections(out):
+    """{test id as pytest prints it in a failure header: that failure's text}."""
+    heads = [(m.start(), m.group(1)) for m in re.finditer(r"^_+ (\S.*?) _+$", out, re.M)]
+    return {name: out[pos:(heads[i + 1][0] if i + 1 < len(heads) else len(out))] for i, (pos, name) in enumerate(heads)}
+
+
 def test_the_references_own_gpu_tests_pass_with_the_seams_installed(ref):
+    """tests/gpu/torch/quantization/{test_tensor_quant_cuda, test_quantize_mxformats_cuda, test_qtensor_cuda, test_calib_cuda,
+    test_tensor_quantizer_cuda, test_quantize_cuda, test_real_quantize_cuda}.py as they lie in the reference, collected AFTER
+    modelopt_plugin.install(): `get_cuda_ext*()` hands them our adapters, so their CUDA-extension assertions (extension ==
+    eager with atol = 0, the literal MX vectors, INT4 pack / unpack, calibrators on device tensors) run on this library."""
     counts, outcomes, out = run_reference_tests(REFERENCE_TEST_FILES, seams=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "reference_own_gpu_tests_seams.txt"), "w") as f:
-        f.write(out[-200000:])
-    note(f"the reference's own GPU tests ({len(REFERENCE_TEST_FILES)} files of tests/gpu/torch/quantization) with the seams "
-         f"installed on the MI355X: {counts}")
+        f.write(out)
+    sections = _failure_sections(out)
     failed = sorted(k for k, v in outcomes.items() if v in ("FAILED", "ERROR"))
-    unexpected = [k for k in failed if not any(re.search(pat, k) for pat in KNOWN_REFERENCE_TEST_FAILURES)]
-    assert counts.get("passed", 0) >= 100, out[-3000:]
+    by_reason, unexpected = {}, []
+    for tid in failed:
+        text = sections.get(".".join(tid.split("::")[1:]), "")
+        why = next((r for r in REFERENCE_TEST_FAILURE_REASONS if r in text), None)
+        if why is None:
+            unexpected.append(tid)
+        else:
+            by_reason[why] = by_reason.get(why, 0) + 1
+    seam_lines = [ln for ln in out.splitlines() if ln.startswith("[seams] S")]
+    note(f"the reference's own GPU tests ({len(REFERENCE_TEST_FILES)} files of tests/gpu/torch/quantization, unmodified) with the "
+         f"seams installed on the MI355X: {counts}; failures by reason: {by_reason or 'none'}; seam calls: "
+         f"{'; '.join(ln[8:] for ln in seam_lines)}")
+    assert counts.get("passed", 0) >= 600, out[-3000:]
     assert not unexpected, f"{len(unexpected)} reference tests fail with the seams installed: {unexpected[:20]}\n{out[-3000:]}"
-
-
-# Reference tests that cannot pass on this box for reasons outside the seams (each with its reason); everything else must.
-KNOWN_REFERENCE_TEST_FAILURES: list = []
