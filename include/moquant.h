@@ -130,6 +130,20 @@ int moq_mt_amax(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_
  * as one dense window (read-only stream at ~7 TB/s instead of ~6.3), then one fold per tensor. */
 int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
                    float* chunk_scratch, void* stream);
+/* RUNNING per-tensor abs-max of many tensors for many calibrators in one sweep -- the collect side of a max-calibration
+ * forward loop (MaxCalibrator.collect, calib/max.py:52-86: `self._calib_amax = torch.max(self._calib_amax, local_amax)`,
+ * called from TensorQuantizer.forward, nn/modules/tensor_quantizer.py:1186-1196, once per quantizer per batch).  The
+ * reference launches its reductions per quantizer per call; here the activations one decoder layer hands its quantizers
+ * (q / k / v read ONE tensor, gate / up another: a tensor appears once in `segs` whatever the number of quantizers that
+ * read it) are swept in one dense window (stage 1 of moq_mt_amax_ws), and fold f then merges segment folds[f].seg's
+ * maximum into the calibrator's running value *folds[f].dst (fp32; bit-pattern maximum: NaN sticks, as in moq_amax with
+ * accumulate).  segs[s].y / .amax are not read. */
+typedef struct moq_amax_fold {
+  float* dst;  /* a calibrator's running abs-max (device, fp32 [1]) */
+  int64_t seg; /* index into segs                                   */
+} moq_amax_fold;
+int moq_mt_amax_running(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                        float* chunk_scratch, const moq_amax_fold* folds, int n_folds, void* stream);
 /* cuda_ext_mx.convert_to_exmy (tensor_quant_mx.cu:398 -> convert_to_types, tensor_quant_mx.h:163-186): y[i] = the value
  * of element format `fmt` nearest to x[i] (format's own tie rule, saturating), no scaling.  fp32 in / out. */
 int moq_mx_convert(const float* x, float* y, int64_t n, int fmt, void* stream);

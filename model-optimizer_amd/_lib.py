@@ -52,6 +52,7 @@ SIGNATURES = {
     "moq_hist_entropy": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "moq_hist_percentile": (c_int, [c_void_p, c_int, c_int64, c_int64, c_double, c_void_p, c_void_p]),
     "moq_mt_amax_ws": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
+    "moq_mt_amax_running": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "moq_mt_fake_quant_e4m3": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "moq_mt_fake_quant_int": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
                                       c_void_p]),

@@ -49,6 +49,103 @@ def convert_quantization_axis_to_reduce_axis(input, axis):
     return [i for i in range(input.dim()) if i not in axis and (i - input.dim()) not in axis]
 
 
+class DeferredAmax:
+    """The per-tensor running abs-max requests of ONE decoder layer answered by ONE sweep (moq_mt_amax_running).
+
+    A max-calibration forward loop asks for nine small reductions per decoder layer and batch (the inputs of q / k / v,
+    o_proj, gate / up, down_proj, the key / value states: 33-117 MB each at Llama-3-8B shapes) -- 7-20 us kernels whose
+    fixed ramp / tail is a third of their time, three of them reading a tensor another one has just read.  While an
+    instance is `current`, MaxCalibrator.collect_per_tensor_fast only NOTES (tensor, running-max buffer); `flush()` -- at
+    the end of every decoder layer (a forward hook set by model_calib.max_calibrate), when `limit_bytes` of tensors are
+    held, and before anybody reads a calibrator -- sweeps the distinct tensors in one dense window and folds each maximum
+    into every buffer that asked for it.  Statistics collection leaves the tensors unchanged (quantization is off while a
+    calibrator collects), so the only thing deferral needs is that nobody writes to a noted tensor before the flush:
+    the version counter of every tensor is checked at flush time and a write is an ERROR, not a wrong statistic.
+    The tables of a flush (segment rows, chunk prefix sums, folds) are cached by their content: the allocator hands a
+    decoder stack the same addresses batch after batch."""
+
+    current = None  # the instance statistics collection runs under, or None (every request is its own launch)
+
+    def __init__(self, device, limit_bytes: int = 1 << 30):
+        self.device = torch.device(device)
+        self.limit_bytes = int(limit_bytes)
+        self.entries = {}      # id(tensor) -> [tensor, version, [running-max buffers]]
+        self.bytes = 0
+        self.dt = None
+        self.tables = {}       # content key -> (device int64 table, n_seg, n_chunks, n_folds, scratch)
+        self.stats = {"requests": 0, "flushes": 0, "tensors": 0, "table_builds": 0, "bytes": 0}
+
+    def add(self, x, dt_code, buf) -> bool:
+        if x.device != self.device or (self.dt is not None and dt_code != self.dt):
+            return False
+        ent = self.entries.get(id(x))
+        if ent is None or ent[0] is not x:
+            self.entries[id(x)] = ent = [x, x._version, []]
+            self.bytes += x.numel() * x.element_size()
+            self.dt = dt_code
+        ent[2].append(buf)
+        self.stats["requests"] += 1
+        if self.bytes >= self.limit_bytes:
+            self.flush()
+        return True
+
+    def _tables(self, ents):
+        key = tuple((e[0].data_ptr(), e[0].numel(), tuple(b.data_ptr() for b in e[2])) for e in ents)
+        hit = self.tables.get(key)
+        if hit is not None:
+            return hit
+        import ctypes
+
+        n_seg = len(ents)
+        sizes = [e[0].numel() for e in ents]
+        blk = (ctypes.c_int64 * (n_seg + 1))()
+        total = _lib.lib().moq_mt_plan((ctypes.c_int64 * n_seg)(*sizes), n_seg, blk)
+        if total < 0:
+            _lib.check(int(total))
+        rows = []
+        for e in ents:  # struct moq_seg: x, y, amax (unused by this entry), n
+            rows += [e[0].data_ptr(), 0, 0, e[0].numel()]
+        rows += list(blk)
+        n_folds = 0
+        for i, e in enumerate(ents):  # struct moq_amax_fold: dst, seg
+            for b in e[2]:
+                rows += [b.data_ptr(), i]
+                n_folds += 1
+        table = torch.tensor(rows, dtype=torch.int64).to(self.device)  # ONE upload: [segs | blk_start | folds]
+        scratch = torch.empty(max(int(total), 1), dtype=torch.float32, device=self.device)
+        if len(self.tables) >= 64:
+            self.tables.clear()
+        self.tables[key] = hit = (table, n_seg, int(total), n_folds, scratch)
+        self.stats["table_builds"] += 1
+        return hit
+
+    def _run(self, ents):
+        self._launch(*self._tables(ents))
+
+    def _launch(self, table, n_seg, n_chunks, n_folds, scratch):
+        base = table.data_ptr()
+        rc = _lib.lib().moq_mt_amax_running(base, base + 32 * n_seg, n_seg, n_chunks, self.dt, scratch.data_ptr(),
+                                            base + 32 * n_seg + 8 * (n_seg + 1), n_folds,
+                                            torch._C._cuda_getCurrentRawStream(self.device.index))
+        if rc:
+            _lib.check(rc)
+
+    def flush(self):
+        if not self.entries:
+            return
+        ents, self.entries, self.bytes = list(self.entries.values()), {}, 0
+        for x, version, _ in ents:
+            if x._version != version:
+                raise RuntimeError(
+                    "deferred statistics: a tensor handed to a quantizer was written in place before the end of its decoder "
+                    "layer, so its abs-max can no longer be taken; calibrate with max_calibrate(..., defer_stats=False)")
+        self._run(ents)
+        self.stats["flushes"] += 1
+        self.stats["tensors"] += len(ents)
+        self.stats["bytes"] += sum(e[0].numel() * e[0].element_size() for e in ents)
+        self.dt = None
+
+
 class MaxCalibrator(_Calibrator):
     """Running abs-max, per tensor or per kept axis -- calib/max.py:26-110."""
 
@@ -87,6 +184,9 @@ class MaxCalibrator(_Calibrator):
         if buf is None or buf.data_ptr() != fast[3]:  # (a deep copy of the calibrator has its own buffer)
             self._fast = None
             return False
+        batch = DeferredAmax.current
+        if batch is not None and batch.add(x, fast[1], buf):
+            return True  # answered by the layer's ONE launch (DeferredAmax.flush)
         rc = _lib._lib.moq_amax(x.data_ptr(), x.numel(), fast[1], fast[3], 1, torch._C._cuda_getCurrentRawStream(dev))
         if rc:
             _lib.check(rc)

@@ -451,6 +451,23 @@ __global__ __launch_bounds__(kBlock) void mt_amax_fold_kernel(const moq_seg* __r
   if (threadIdx.x == 0) segs[s].amax[0] = __uint_as_float(acc);
 }
 
+// Stage 2 for RUNNING maxima with several readers per tensor (moq_mt_amax_running): fold f takes the maximum of segment
+// folds[f].seg's chunk values and merges it into *folds[f].dst -- the calibrator's running abs-max, compared as bit
+// patterns like every abs-max of this library (NaN > inf > finite: a NaN sticks).  One wave per fold; a destination may
+// appear in several folds of one launch (an input quantizer called twice in a layer), hence the atomic.
+__global__ __launch_bounds__(64) void mt_amax_fold_running_kernel(const int64_t* __restrict__ blk_start,
+                                                                  const uint32_t* __restrict__ chunk_max,
+                                                                  const moq_amax_fold* __restrict__ folds) {
+  const moq_amax_fold f = folds[blockIdx.x];
+  uint32_t acc = 0;
+  for (int64_t c = blk_start[f.seg] + threadIdx.x; c < blk_start[f.seg + 1]; c += 64) {
+    const uint32_t v = chunk_max[c];
+    acc = v > acc ? v : acc;
+  }
+  acc = group_max_u32<64>(acc);
+  if (threadIdx.x == 0 && acc != 0) atomicMax(reinterpret_cast<uint32_t*>(f.dst), acc);
+}
+
 __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_seg) segs[i].amax[0] = 0.0f;
@@ -737,6 +754,26 @@ extern "C" int moq_mt_amax_ws(const moq_seg* segs, const int64_t* blk_start, int
   hipLaunchKernelGGL(mt_amax_fold_kernel, dim3((unsigned)n_seg), dim3(kBlock), 0, S(stream), segs, blk_start,
                      reinterpret_cast<const uint32_t*>(chunk_scratch));
   return check_launch("moq_mt_amax_ws");
+}
+
+extern "C" int moq_mt_amax_running(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks, int dt,
+                                  float* chunk_scratch, const moq_amax_fold* folds, int n_folds, void* stream) {
+  int rc = mt_check(segs, blk_start, n_seg, n_chunks, "moq_mt_amax_running");
+  if (rc != MOQ_OK || n_seg == 0) return rc;
+  if (chunk_scratch == nullptr || n_folds < 0 || (n_folds > 0 && folds == nullptr)) {
+    set_error("moq_mt_amax_running: chunk_scratch (n_chunks floats) and folds must not be NULL");
+    return MOQ_ERR_INVALID;
+  }
+  if (n_chunks > 0) {
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_amax_chunks_kernel<DT>), dim3(read_grid(n_chunks)), dim3(kBlock), 0,
+                                              S(stream), segs, blk_start, n_seg, n_chunks,
+                                              reinterpret_cast<uint32_t*>(chunk_scratch)));
+  }
+  if (n_folds > 0) {
+    hipLaunchKernelGGL(mt_amax_fold_running_kernel, dim3((unsigned)n_folds), dim3(64), 0, S(stream), blk_start,
+                       reinterpret_cast<const uint32_t*>(chunk_scratch), folds);
+  }
+  return check_launch("moq_mt_amax_running");
 }
 
 // internal (moq_formats.hip's mask + apply pass): stage 2 of the two-stage abs-max over per-chunk maxima somebody else wrote

@@ -465,8 +465,11 @@ def export_quantized_weight(module, dtype: torch.dtype):
         return {"weight": qt._quantized_data, "weight_scale": weight_scale}
     if fmt == QUANTIZATION_FP8:
         amax = wq._amax.to(torch.float32)
-        # per-tensor: python float division of amax.item() (unified_export_hf.py:643-647)
-        weight_scale = (torch.tensor(amax.item() / wq.maxbound) if amax.numel() == 1
+        # unified_export_hf.py:635-643 decides by the amax buffer's RANK, not its size: a [1] buffer takes python float
+        # division of amax.item(), everything else -- a 0-dim per-tensor amax too -- `amax / maxbound` as a tensor op (on a
+        # GPU a multiplication by the reciprocal: the two forms differ there, which only a run beside the reference on the
+        # device shows -- on the host both are IEEE division)
+        weight_scale = (torch.tensor(amax.item() / wq.maxbound) if amax.dim() == 1
                         else numerics.div_scalar(amax, wq.maxbound))
     else:
         weight_scale = get_weight_scaling_factor(module)
@@ -723,7 +726,11 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     if _keeps_module_names(model):
         rename = lambda n: n  # noqa: E731 -- (the tensors keep the module tree's names too; warned about there)
     else:
-        rename = lambda n: next(iter(rename_to_checkpoint_keys({n + ".weight": None}, model)))[:-len(".weight")]  # noqa: E731
+        # ONE pass over all names (per name, rename_to_checkpoint_keys would re-walk the model for its expert rules:
+        # O(layers x modules), seconds on a Mixtral-sized model)
+        renamed = rename_to_checkpoint_keys({n + ".weight": None for n in layers}, model)
+        table = {n: k[:-len(".weight")] for n, k in zip(layers, renamed)}
+        rename = table.__getitem__
     if len(kinds) > 1:
         q["quant_algo"] = "MIXED_PRECISION"
         q["quantized_layers"] = {rename(n): v for n, v in quantized.items()}

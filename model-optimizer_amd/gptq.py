@@ -129,6 +129,8 @@ def _static_layout(q, weight: torch.Tensor):
         return None
     if q._disabled or not q.fake_quant or q._dynamic or q.pre_quant_scale is not None:
         return None
+    if getattr(q, "_bias", None) is not None:
+        return None  # an affine offset: QDQ(w - bias) + bias is the quantizer's own forward, column by column
     if q.is_mx_format:
         # dynamic blocks with E8M0 scales (MXFP4 / MXFP8 / ...): the block scale follows the CURRENT weights, which the
         # sweep kernel recomputes per column from the block's lanes (fmt 3); blocks along the last dim only
@@ -244,8 +246,10 @@ class GPTQHelper:
     def setup(self, shared: dict):
         helper = self
 
-        def pre_hook(mod, args):
-            x = args[0]
+        def pre_hook(mod, args, kwargs):
+            x = args[0] if args else kwargs.get("input")  # (the reference's patched forward takes `input=` too)
+            if x is None:
+                raise RuntimeError(f"gptq: {helper.name} was called without an input tensor")
             x = x.to_local() if hasattr(x, "to_local") else x
             iq = getattr(mod, "input_quantizer", None)
             if iq is not None and iq.is_enabled:
@@ -253,17 +257,22 @@ class GPTQHelper:
                 key = None  # a quantized copy: nothing to share by identity
             else:
                 h_in, key = x, x
-            first = shared.get("input") is key and key is not None
+            # the same tensor OBJECT in the same state (an in-place write in between makes it another input), and only a
+            # helper that has no samples of its own may start following: its accumulated Hessian would be dropped
+            first = shared.get("input") is key and key is not None and shared.get("version") == key._version
             if first and shared["owner"].state.shape == helper.state.shape and helper.owner in (helper, shared["owner"]):
+                if helper.owner is helper and getattr(helper.state, "samples", 0):
+                    raise RuntimeError(f"gptq: {helper.name} accumulated its own Hessian in earlier batches and now reads the "
+                                       "tensor another linear has just read; the sharing structure must not change between batches")
                 helper.owner = shared["owner"]
                 return
             if helper.owner is not helper:
                 raise RuntimeError("gptq: a linear that shared its input with another one in an earlier batch got a "
                                    "different tensor now")
             helper.state.update(h_in)
-            shared["input"], shared["owner"] = key, helper
+            shared["input"], shared["owner"], shared["version"] = key, helper, (key._version if key is not None else None)
 
-        self._handle = self.module.register_forward_pre_hook(pre_hook)
+        self._handle = self.module.register_forward_pre_hook(pre_hook, with_kwargs=True)
 
     def cleanup(self):
         if self._handle is not None:

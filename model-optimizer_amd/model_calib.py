@@ -65,6 +65,10 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
     distributed_sync: the raw histograms of all histogram calibrators are SUM-reduced in one bucket before their
     amax is computed (the reference leaves every rank with its own histogram, calib/histogram.py:158-163); running
     maxima need nothing here -- their amax is MAX-reduced afterwards (sync_amax_bucketed)."""
+    from . import calib as _calib
+
+    if _calib.DeferredAmax.current is not None:
+        _calib.DeferredAmax.current.flush()  # nobody reads a calibrator before the requests noted for it are answered
     qs = [q for q in _quantizers(model) if q.is_enabled]
     live = [q for q in qs if not (q._use_constant_amax or q._constant_amax is not None)]  # the others were never calibrating
     if distributed_sync and _dist_on():
@@ -144,9 +148,34 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
             wq.mark_weight_stats_done(w)
 
 
+_MAX_CALIBRATE_DEPTH = [0]
+
+
+def _deferred_stats_plan(model: nn.Module, forward_loop, defer_stats):
+    """(device, decoder layers) when the per-tensor running maxima of this calibration may be answered layer by layer
+    (calib.DeferredAmax), else None.  Automatic (defer_stats=None) for Hugging Face decoder stacks on a GPU -- the flush
+    points are their decoder layers' ends, and between a linear's forward and the end of its layer such a model leaves the
+    linear's input alone (a write is caught at the flush); defer_stats=True asks for it on any model that has a decoder
+    stack layerwise.get_decoder_layers finds; False never defers."""
+    from . import calib as _calib
+
+    if defer_stats is False or forward_loop is None or _calib.DeferredAmax.current is not None or not isinstance(model, nn.Module):
+        return None
+    dev = next((p.device for p in model.parameters()), None)
+    if dev is None or dev.type != "cuda":
+        return None
+    from . import layerwise
+    from .hf_attention import _is_supported_hf_model
+
+    layers = layerwise.get_decoder_layers(model)
+    if layers is None or (defer_stats is None and not _is_supported_hf_model(model)):
+        return None
+    return dev, list(layers)
+
+
 @torch.no_grad()
 def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = True, shard_weights: bool | None = None,
-                  sync_expert_weight_amax: bool = False):
+                  sync_expert_weight_amax: bool = False, defer_stats: bool | None = None):
     """model_calib.py:310-498 (DP part): collect abs-max statistics for weights and activations, load them,
     then MAX-reduce every amax across the data-parallel group in ONE bucket; each rank's forward_loop sees its own
     share of the calibration batches.
@@ -158,13 +187,23 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
     Tensor-parallel callers pass distributed_sync=False and synchronise by `distributed.sync_amax_tensor_parallel`.
 
     sync_expert_weight_amax: blocks of separate expert modules share one weight amax per projection as well (the input
-    amax is always shared, hf_moe.layer_sync_moe_local_experts_amax; model_calib.py:365-368)."""
+    amax is always shared, hf_moe.layer_sync_moe_local_experts_amax; model_calib.py:365-368).
+
+    defer_stats: ONE statistics launch per decoder layer instead of one per quantizer call (calib.DeferredAmax;
+    _deferred_stats_plan says when).  Same amax, bit for bit: a maximum does not care in which launch it was taken.
+
+    MAX_CALIBRATE_STATS (phase clock, device drained at the phase boundaries) is filled by the OUTERMOST call only: nested
+    calls -- per linear inside awq(), per layer in layerwise / gptq, per starved expert in hf_moe -- neither wipe it nor
+    add host syncs to the product path."""
     sync = distributed_sync and _dist_on()
-    stats = MAX_CALIBRATE_STATS
+    outer = _MAX_CALIBRATE_DEPTH[0] == 0
+    stats = MAX_CALIBRATE_STATS if outer else {}
     stats.clear()
     dev0 = next((p.device for p in model.parameters()), None)
 
     def lap(name, t=[None]):
+        if not outer:
+            return
         if dev0 is not None and dev0.type == "cuda":
             torch.cuda.synchronize(dev0)
         now = time.perf_counter()
@@ -172,21 +211,42 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
             stats[name] = round(now - t[0], 4)
         t[0] = now
 
-    lap(None)
-    enable_stats_collection(model, distributed_sync=sync)
-    lap("enable_s")
-    weight_only_quantize(model, shard=sync and mdist.resolve_shard(shard_weights))
-    lap("weights_s")
-    if forward_loop is not None:
-        forward_loop(model)
-    lap("forward_loop_s")
-    finish_stats_collection(model)
-    from . import hf_moe
+    _MAX_CALIBRATE_DEPTH[0] += 1
+    try:
+        lap(None)
+        enable_stats_collection(model, distributed_sync=sync)
+        lap("enable_s")
+        weight_only_quantize(model, shard=sync and mdist.resolve_shard(shard_weights))
+        lap("weights_s")
+        if forward_loop is not None:
+            plan = _deferred_stats_plan(model, forward_loop, defer_stats)
+            if plan is None:
+                forward_loop(model)
+            else:
+                from . import calib as _calib
 
-    hf_moe.layer_sync_moe_local_experts_amax(
-        model, sync_weight_amax=sync_expert_weight_amax,
-        calibrate_missing=lambda q, w: max_calibrate(q, lambda m: m(w), distributed_sync=False))
-    lap("finish_s")
+                batch = _calib.DeferredAmax(plan[0])
+                hooks = [layer.register_forward_hook(lambda *_a, _b=batch: _b.flush()) for layer in plan[1]]
+                _calib.DeferredAmax.current = batch
+                try:
+                    forward_loop(model)
+                    batch.flush()  # (requests from outside the decoder stack: the head, a vision tower, ...)
+                finally:
+                    _calib.DeferredAmax.current = None
+                    batch.entries.clear()
+                    for h in hooks:
+                        h.remove()
+                stats["deferred_stats"] = dict(batch.stats)
+        lap("forward_loop_s")
+        finish_stats_collection(model)
+        from . import hf_moe
+
+        hf_moe.layer_sync_moe_local_experts_amax(
+            model, sync_weight_amax=sync_expert_weight_amax,
+            calibrate_missing=lambda q, w: max_calibrate(q, lambda m: m(w), distributed_sync=False))
+        lap("finish_s")
+    finally:
+        _MAX_CALIBRATE_DEPTH[0] -= 1
     if sync:
         dev = next((p.device for p in model.parameters()), None)
         # the data-parallel group when one was declared (the reference reduces over its DP group, :390-407), else the

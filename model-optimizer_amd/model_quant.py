@@ -349,7 +349,8 @@ def _run_algorithm(model: nn.Module, algo, forward_loop):
     if method == "max":  # MaxCalibConfig.distributed_sync (config.py): off for callers that synchronise by their own rules
         func = model_calib.max_calibrate
         kwargs = {"distributed_sync": bool(kwargs.get("distributed_sync", True)), "shard_weights": kwargs.get("shard_weights"),
-                  "sync_expert_weight_amax": bool(kwargs.get("sync_expert_weight_amax", False))}
+                  "sync_expert_weight_amax": bool(kwargs.get("sync_expert_weight_amax", False)),
+                  "defer_stats": kwargs.get("defer_stats")}
     elif method == "mse":
         func = model_calib.mse_calibrate
     elif method == "local_hessian":

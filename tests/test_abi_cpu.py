@@ -63,6 +63,9 @@ def test_argument_validation_without_gpu():
     assert lib.moq_transpose16_ld(P, P, 64, 32, 63, None) == _lib.MOQ_ERR_INVALID                         # y_ld < rows
     assert lib.moq_mt_amax_ws(P, P, 3, 10, _lib.BF16, None, None) == _lib.MOQ_ERR_INVALID                 # no scratch
     assert b"chunk_scratch" in lib.moq_last_error()
+    assert lib.moq_mt_amax_running(P, P, 3, 10, _lib.BF16, None, P, 2, None) == _lib.MOQ_ERR_INVALID      # no scratch
+    assert lib.moq_mt_amax_running(P, P, 3, 10, _lib.BF16, P, None, 2, None) == _lib.MOQ_ERR_INVALID      # folds missing
+    assert lib.moq_mt_amax_running(P, P, 0, 0, _lib.BF16, None, None, 0, None) == _lib.MOQ_OK             # nothing to do
     with pytest.raises(ValueError):
         _lib.check(_lib.MOQ_ERR_UNSUPPORTED)
     with pytest.raises(RuntimeError):

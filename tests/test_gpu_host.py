@@ -558,3 +558,60 @@ def test_tensor_quantizer_tiles_on_the_last_two_axes_of_any_rank(golden):
         assert_bits_equal(q3._amax.float().cpu(), q._amax.float().cpu(), f"{k} amax through max_calibrate")
         assert_bits_equal(q3(x).cpu(), y.cpu(), f"{k} output after max_calibrate")
     assert seen == 9 + 15
+
+
+def test_one_statistics_launch_per_decoder_layer_gives_the_per_call_statistics():
+    """max_calibrate(defer_stats=...) on a tiny Hugging Face Llama with FP8 weights, inputs and KV cache: the running maxima
+    taken by ONE moq_mt_amax_running sweep per decoder layer (calib.DeferredAmax: q / k / v and gate / up share their
+    tensor) equal the per-call launches bit for bit; a module that writes to its linear's input before the layer ends is an
+    error, not a wrong amax."""
+    import transformers as tf
+
+    from model_optimizer_amd import calib as calib_mod
+
+    torch.manual_seed(0)
+    cfg = tf.LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                         vocab_size=64, max_position_embeddings=64, architectures=["LlamaForCausalLM"])
+    base = tf.LlamaForCausalLM(cfg).to(torch.bfloat16).eval().to(DEV)
+    batches = [torch.randint(0, 64, (4, 32), generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(3)]
+    qcfg = model_quant.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(model_quant.FP8_DEFAULT_CFG), model_quant.FP8_KV_CFG["quant_cfg"])
+
+    def run(defer):
+        m = copy.deepcopy(base)
+        c = copy.deepcopy(qcfg)
+        c["algorithm"] = {"method": "max", "defer_stats": defer}
+        with torch.no_grad():
+            model_quant.quantize(m, c, lambda mm: [mm(b) for b in batches])
+        amax = {n: q._amax.detach().float().cpu().clone() for n, q in m.named_modules()
+                if isinstance(q, TensorQuantizer) and q.is_enabled and getattr(q, "_amax", None) is not None}
+        return amax, dict(model_calib.MAX_CALIBRATE_STATS)
+
+    per_call, st0 = run(False)
+    per_layer, st1 = run(None)  # automatic for a Hugging Face decoder stack on the GPU
+    assert "deferred_stats" not in st0 and st1["deferred_stats"]["flushes"] >= 3 * len(batches)
+    d = st1["deferred_stats"]
+    # 9 requests per layer-call (7 linear inputs + key / value states; the first call of every calibrator takes the general
+    # path), 6 distinct tensors; far fewer table builds than flushes (the allocator repeats its addresses)
+    assert d["requests"] >= 9 * 3 * (len(batches) - 1) and d["tensors"] * 9 <= d["requests"] * 6 + 6
+    assert len(per_call) == len(per_layer) and len(per_call) >= 3 * 9 + 3 * 7
+    for n, a in per_call.items():
+        assert torch.equal(a, per_layer[n]), n
+    assert calib_mod.DeferredAmax.current is None
+
+    class Scribbler(torch.nn.Module):  # writes to the activation AFTER the linear (and its input quantizer) have read it
+        def __init__(self, inner):
+            super().__init__()
+            self.inner = inner
+
+        def forward(self, x):
+            y = self.inner(x)
+            x.mul_(0.5)
+            return y
+
+    m = copy.deepcopy(base)
+    m.model.layers[1].mlp.down_proj = Scribbler(m.model.layers[1].mlp.down_proj)
+    c = copy.deepcopy(qcfg)
+    c["algorithm"] = {"method": "max", "defer_stats": True}
+    with pytest.raises(RuntimeError, match="written in place"), torch.no_grad():
+        model_quant.quantize(m, c, lambda mm: [mm(b) for b in batches])
+    assert calib_mod.DeferredAmax.current is None

@@ -626,3 +626,44 @@ def test_kv_cache_format_names_and_the_int8_refusal(monkeypatch):
     assert moa.export.hf_quant_config(model)["quantization"]["kv_cache_quant_algo"] == "INT8"
     with pytest.raises(AssertionError, match="Invalid KV cache quantization format"):
         moa.export.export_state_dict(model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long)))
+
+
+def test_deferred_layer_statistics_bookkeeping():
+    """calib.DeferredAmax on host tensors (the sweep itself -- moq_mt_amax_running -- is the GPU tier's): a tensor noted by
+    several calibrators is held once, every buffer that asked gets the maximum, buffers keep their running value, a tensor
+    written in place before the flush is an error, the byte limit flushes by itself."""
+    from model_optimizer_amd import calib
+
+    class OnHost(calib.DeferredAmax):
+        def _run(self, ents):
+            for x, _, bufs in ents:
+                for b in bufs:
+                    b.copy_(torch.maximum(b, x.abs().max().float().reshape(1)))
+
+    d = OnHost("cpu", limit_bytes=1 << 20)
+    a, b = torch.randn(64, 32), torch.randn(16, 8) * 3
+    qkv = [torch.zeros(1) for _ in range(3)]
+    other = torch.full((1,), 100.0)
+    for buf in qkv:
+        assert d.add(a, 0, buf)
+    assert d.add(b, 0, other) and d.add(b, 0, qkv[0])
+    assert len(d.entries) == 2 and d.bytes == a.numel() * 4 + b.numel() * 4 and d.stats["requests"] == 5
+    d.flush()
+    assert not d.entries and d.bytes == 0 and d.stats["flushes"] == 1 and d.stats["tensors"] == 2
+    assert qkv[1].item() == qkv[2].item() == a.abs().max().item()
+    assert qkv[0].item() == max(a.abs().max().item(), b.abs().max().item()) and other.item() == 100.0
+    d.flush()  # nothing noted: no launch
+    assert d.stats["flushes"] == 1
+    # a write between the note and the flush
+    c = torch.randn(8, 8)
+    d.add(c, 0, qkv[0])
+    c.mul_(2.0)
+    with pytest.raises(RuntimeError, match="written in place"):
+        d.flush()
+    assert not d.entries
+    # the byte limit
+    big = torch.randn(1 << 18)  # 1 MiB
+    d.add(big, 0, qkv[1])
+    assert not d.entries and d.stats["flushes"] == 2 and qkv[1].item() >= big.abs().max().item()
+    # another device / dtype is not taken
+    assert not calib.DeferredAmax("cuda:0").add(a, 0, qkv[0])

@@ -31,6 +31,8 @@ def parse_args(argv=None):
     ap.add_argument("--tie-margin", type=float, default=None, help="awq_lite re-scoring margin (inf: every candidate)")
     ap.add_argument("--dump", default=None, help="write every linear's AWQ score tables to this JSON file")
     ap.add_argument("--note", default=None)
+    ap.add_argument("--defer-stats", default="auto", choices=["auto", "on", "off"],
+                    help="max calibration: one statistics launch per decoder layer (calib.DeferredAmax); off = one per quantizer call")
     return ap.parse_args(argv)
 
 
@@ -120,6 +122,13 @@ def run(args, moa=None, dev=None) -> dict:
             alg["search"] = args.search
         if args.tie_margin is not None:
             alg["tie_margin"] = args.tie_margin
+        qcfg["algorithm"] = alg
+    if getattr(args, "defer_stats", "auto") != "auto" and (qcfg.get("algorithm") == "max" or (isinstance(qcfg.get("algorithm"), dict) and qcfg["algorithm"].get("method") == "max")):
+        import copy
+
+        qcfg = copy.deepcopy(qcfg)
+        alg = qcfg["algorithm"] if isinstance(qcfg["algorithm"], dict) else {"method": "max"}
+        alg["defer_stats"] = args.defer_stats == "on"
         qcfg["algorithm"] = alg
     t0 = time.perf_counter()
     moa.quantize(model, qcfg, loop)
