@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_uint8, c_ulonglong, c_void_p  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MOQ_LIB_PATH: A/B a differently built libmoquant.so (tools/exp); the default is the in-tree build
+# MOQ_LIB_PATH: A/B a differently built libmoquant.so (e.g. `MOQ_EXPERIMENTS=1 csrc/build.sh` -> libmoquant_exp.so with the
+# MOQ_TUNE_* knobs live); the default is the in-tree release build
 LIB_PATH = os.environ.get("MOQ_LIB_PATH") or os.path.join(_HERE, "csrc", "libmoquant.so")
 
 MOQ_OK, MOQ_ERR_INVALID, MOQ_ERR_UNSUPPORTED, MOQ_ERR_LAUNCH = 0, -1, -2, -3

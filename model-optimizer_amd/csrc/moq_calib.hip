@@ -40,20 +40,12 @@ __device__ __forceinline__ CandQ<FP8> make_cand(float amax, const IntQ& q) {
   return c;
 }
 
-// squared error of one element under one candidate.  WIN (INT only): the caller has checked ONCE per candidate that the
-// scale is an ordinary number inside the shared division's exact window -- qdq_int_shared's two uniform tests per element
-// are then dead weight in a kernel that is bound by its VALU op count
-template <bool FP8, bool WIN = false>
+// squared error of one element under one candidate: the general form (any scale, NaN / zero-sign patches of the QDQ cores
+// kept) -- used for INT candidates whose scale is 0 or outside the shared division's exact window
+template <bool FP8>
 __device__ __forceinline__ float sq_err(float x, const CandQ<FP8>& c, const IntQ& q) {
   float y;
-  if constexpr (!FP8 && WIN) {
-    const float p = x * c.scale;
-    float t = __builtin_rintf(p);
-    t = t < q.lo ? q.lo : t;
-    t = __builtin_fminf(t, q.hi);
-    t = (p != p) ? p : t;
-    y = shared_div_in_window(t, c.sd);
-  } else if constexpr (FP8) {
+  if constexpr (FP8) {
     const float a = x * c.scale;
     float ca = __builtin_fminf(__builtin_fmaxf(a, -448.0f), 448.0f);
     ca = (a != a) ? a : ca;
@@ -65,6 +57,50 @@ __device__ __forceinline__ float sq_err(float x, const CandQ<FP8>& c, const IntQ
   }
   const float d = x - y;
   return d * d;
+}
+
+// Squared errors of TWO elements under one candidate, the hot form (round 5; the ISA census of round 4's loop showed 13.6
+// (INT) / 11.4 (FP8) VALU instructions per element and candidate, 9 / 11 of them unpacked).  What the error does not need
+// from the QDQ cores is dropped:
+//   * the NaN re-injection (2 ops): a NaN can only come from a NaN x (the caller has checked that the scale is an ordinary
+//     number), and then d = x - y is NaN whatever y is;
+//   * the sign of a zero quotient (2 ops) and torch.clamp's -0-preserving lower bound (cmp + select + canonicalising
+//     min = 4 ops -> one v_med3_f32): x - (+0) == x - (-0);
+//   * FP8: the converter packs two elements per v_cvt_pk_fp8_f32 (was one element and a zero: a v_mov + half a convert).
+// Everything else is the same arithmetic in the same order -- y is the QDQ value bit for bit -- written on float2 so that
+// the multiplies, the Markstein steps of the shared division, the difference, the square and the running sum are
+// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: 6.3 (INT) / 5.5 (FP8) instruction slots per element and candidate.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool FP8>
+__device__ __forceinline__ f32x2_t sq_err2(f32x2_t x, const CandQ<FP8>& c, const IntQ& q) {
+  f32x2_t y;
+  if constexpr (FP8) {
+    const f32x2_t a = x * c.scale;
+    const float c0 = __builtin_amdgcn_fmed3f(a.x, -448.0f, 448.0f), c1 = __builtin_amdgcn_fmed3f(a.y, -448.0f, 448.0f);
+    float r0, r1;
+    e4m3_roundtrip2(c0, c1, r0, r1);
+    const f32x2_t r = {r0, r1};
+    y = r * c.inv;
+  } else {
+    const f32x2_t p = x * c.scale;
+    f32x2_t t;
+    t.x = __builtin_amdgcn_fmed3f(__builtin_rintf(p.x), q.lo, q.hi);
+    t.y = __builtin_amdgcn_fmed3f(__builtin_rintf(p.y), q.lo, q.hi);
+    const f32x2_t yy = {c.sd.y, c.sd.y}, nd = {-c.sd.d, -c.sd.d};
+    const f32x2_t q0 = t * yy;  // shared_div_in_window, two lanes of it
+    const f32x2_t r0 = __builtin_elementwise_fma(nd, q0, t);
+    const f32x2_t q1 = __builtin_elementwise_fma(r0, yy, q0);
+    const f32x2_t r1 = __builtin_elementwise_fma(nd, q1, t);
+    y = __builtin_elementwise_fma(r1, yy, q1);
+  }
+  const f32x2_t d = x - y;
+  return d * d;
+}
+// may the hot form be used for this candidate?  (wave-uniform per row and candidate)
+template <bool FP8>
+__device__ __forceinline__ bool cand_hot(const CandQ<FP8>& c) {
+  if constexpr (FP8) return c.scale == c.scale && c.inv == c.inv;  // a NaN amax takes the patched form
+  else return c.scale != 0.0f && c.sd.fast;
 }
 
 // One wave per (row, segment) work item; a segment is kSeg = 4096 consecutive elements of a row, held as 64
@@ -103,13 +139,16 @@ __global__ __launch_bounds__(kBlock) void mse_rows_kernel(const void* __restrict
     const float* crow = cand + (row % axis_size);
     for (int k = 0; k < n_cand; ++k) {
       const CandQ<FP8> c = make_cand<FP8>(crow[(int64_t)k * axis_size], q);
-      float a0 = 0.0f, a1 = 0.0f;  // two chains halve the dependent-add latency
-      if (!FP8 && c.scale != 0.0f && c.sd.fast) {
+      float a0 = 0.0f, a1 = 0.0f;  // two chains (even / odd elements): one packed accumulator in the hot form
+      if (cand_hot<FP8>(c)) {
+        f32x2_t a2 = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < P * V; i += 2) {
-          a0 += sq_err<FP8, true>(f[i], c, q);
-          a1 += sq_err<FP8, true>(f[i + 1], c, q);
+          const f32x2_t xv = {f[i], f[i + 1]};
+          a2 += sq_err2<FP8>(xv, c, q);
         }
+        a0 = a2.x;
+        a1 = a2.y;
       } else {
 #pragma unroll
         for (int i = 0; i < P * V; i += 2) {
@@ -151,9 +190,14 @@ __global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restric
     for (int k = 0; k < n_cand; ++k) {
       const CandQ<FP8> c = make_cand<FP8>(cand[(int64_t)k * axis_size + a], q);
       float acc = 0.0f;
-      if (!FP8 && c.scale != 0.0f && c.sd.fast) {
+      if (cand_hot<FP8>(c)) {
+        f32x2_t a2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc += sq_err<FP8, true>(f[i], c, q);
+        for (int i = 0; i < V; i += 2) {
+          const f32x2_t xv = {f[i], f[i + 1]};
+          a2 += sq_err2<FP8>(xv, c, q);
+        }
+        acc = a2.x + a2.y;
       } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) acc += sq_err<FP8>(f[i], c, q);

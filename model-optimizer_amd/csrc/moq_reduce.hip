@@ -122,14 +122,21 @@ __global__ __launch_bounds__(kBlock) void col_stats_kernel(const void* __restric
   }
 }
 
-// sum_out[c] (+)= sum over row blocks, in row-block order (deterministic)
-__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64_t n_blk, int64_t cols,
-                                        float* __restrict__ sum_out, int accumulate) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// sum of partial[b * cols + c] over the row blocks b = 0 .. n_blk - 1, added strictly in block order (the results of the
+// column statistics and of the AWQ weight scale are defined by that order).  The chain of adds is serial by definition; what
+// a thread can do is keep MANY loads in flight: 32 per round trip (round 4: 8 -- a 28672-row weight's 1792 partials cost 224
+// dependent L2 round trips per column, more than the sweep that produced them).
+__device__ __forceinline__ float ordered_block_sum(const float* __restrict__ partial, int64_t n_blk, int64_t cols, int64_t c) {
   float s = 0.0f;
   int64_t b = 0;
-  for (; b + 8 <= n_blk; b += 8) {  // 8 independent loads in flight, added in row-block order
+  for (; b + 32 <= n_blk; b += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = partial[(b + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) s += v[u];
+  }
+  for (; b + 8 <= n_blk; b += 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
@@ -137,6 +144,16 @@ __global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64
     for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; b < n_blk; ++b) s += partial[b * cols + c];
+  return s;
+}
+constexpr int kFinBlock = 64;  // threads per finalize workgroup: 8192 columns = 128 workgroups (256-thread ones filled 32 CUs)
+
+// sum_out[c] (+)= sum over row blocks, in row-block order (deterministic)
+__global__ void col_sum_finalize_kernel(const float* __restrict__ partial, int64_t n_blk, int64_t cols,
+                                        float* __restrict__ sum_out, int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  const float s = ordered_block_sum(partial, n_blk, cols, c);
   sum_out[c] = accumulate ? sum_out[c] + s : s;
 }
 
@@ -148,16 +165,7 @@ __global__ void col_mean_accum_kernel(const float* __restrict__ partial, int64_t
                                       float* __restrict__ acc) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.0f;
-  int64_t b = 0;
-  for (; b + 8 <= n_blk; b += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; b < n_blk; ++b) s += partial[b * cols + c];
+  const float s = ordered_block_sum(partial, n_blk, cols, c);
   acc[c] = acc[c] + round_to_dtype<DT>(s / (float)rows);
 }
 
@@ -219,16 +227,7 @@ __global__ void awq_wscale_finalize_kernel(const float* __restrict__ partial, in
                                            int64_t cols, float* __restrict__ out) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.0f;
-  int64_t b = 0;
-  for (; b + 8 <= n_blk; b += 8) {  // 8 independent loads in flight, added in row-block order
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
-  for (; b < n_blk; ++b) s += partial[b * cols + c];
+  const float s = ordered_block_sum(partial, n_blk, cols, c);
   out[c] = round_to_dtype<DT>(s / (float)rows);  // torch.mean: fp32 accumulate, one rounding to dtype
 }
 
@@ -401,7 +400,7 @@ extern "C" int moq_col_abs_stats(const void* x, int64_t tokens, int64_t cols, in
                                                 S(stream), x, tokens, cols, ab, partial));
     }
     if (sum_out != nullptr)
-      hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+      hipLaunchKernelGGL(col_sum_finalize_kernel, dim3((unsigned)((cols + kFinBlock - 1) / kFinBlock)), dim3(kFinBlock), 0,
                          S(stream), partial, n_blk, cols, sum_out, accumulate);
   } else {
     if (sum_out != nullptr && partial == nullptr && fast) {
@@ -437,8 +436,8 @@ extern "C" int moq_col_abs_mean_accum(const void* x, int64_t tokens, int64_t col
   dim3 grid((unsigned)((cols / vec + 63) / 64), (unsigned)n_blk);
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_stats_kernel<DT, true, false>), grid, dim3(kBlock), 0, S(stream), x,
                                             tokens, cols, (uint32_t*)nullptr, partial));
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_mean_accum_kernel<DT>), dim3((unsigned)((cols + 255) / 256)),
-                                            dim3(256), 0, S(stream), partial, n_blk, tokens, cols, acc));
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((col_mean_accum_kernel<DT>), dim3((unsigned)((cols + kFinBlock - 1) / kFinBlock)),
+                                            dim3(kFinBlock), 0, S(stream), partial, n_blk, tokens, cols, acc));
   return check_launch("moq_col_abs_mean_accum");
 }
 
@@ -466,8 +465,8 @@ extern "C" int moq_awq_weight_scale(const void* w, int64_t rows, int64_t cols, i
     default: set_error("unreachable"); return MOQ_ERR_INVALID;
   }
 #undef MOQ_WS_CASE
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((awq_wscale_finalize_kernel<DT>), dim3((unsigned)((cols + 255) / 256)),
-                                            dim3(256), 0, S(stream), partial, n_blk, rows, cols, out));
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((awq_wscale_finalize_kernel<DT>), dim3((unsigned)((cols + kFinBlock - 1) / kFinBlock)),
+                                            dim3(kFinBlock), 0, S(stream), partial, n_blk, rows, cols, out));
   return check_launch("moq_awq_weight_scale");
 }
 

@@ -265,6 +265,12 @@ def to_quantized_weight(weight, weights_scaling_factor, quantization: str):
         # one kernel: divide, round to dtype, cast
         if wsf.numel() != 1:
             raise NotImplementedError("FP8 export with a dimensioned weight scale (per-channel FP8) is outside this path")
+        if not numerics.on_host() and weight.is_cuda and weight.dtype != torch.float32:
+            # numerics "device": torch's GPU division functor runs in the COMMON dtype -- the 0-dim fp32 divisor is cast
+            # to the 16-bit weight dtype before the fp32 quotient is formed (BinaryDivTrueKernel.cu: DivFunctor<scalar_t>),
+            # where the CPU kernel keeps a 0-dim operand at full precision.  11 % of a bf16 weight's quotients differ
+            # between the reference's two runs (tools/torch_cpu_vs_gpu_ops.py); the same kernel, the divisor rounded first
+            wsf = wsf.to(weight.dtype).float()
         return ops.fp8_quantize(weight, wsf, fp32_scales=weight.dtype != torch.float32)
     if quantization in (QUANTIZATION_MXFP4, QUANTIZATION_W4A8_MXFP4_FP8):
         raise AssertionError("MXFP4 weights are packed together with their scales (export_quantized_weight)")

@@ -588,7 +588,8 @@ def test_one_statistics_launch_per_decoder_layer_gives_the_per_call_statistics()
 
     per_call, st0 = run(False)
     per_layer, st1 = run(None)  # automatic for a Hugging Face decoder stack on the GPU
-    assert "deferred_stats" not in st0 and st1["deferred_stats"]["flushes"] >= 3 * len(batches)
+    # (one flush per decoder layer and batch from the second batch on: a calibrator's first collect takes the general path)
+    assert "deferred_stats" not in st0 and st1["deferred_stats"]["flushes"] >= 3 * (len(batches) - 1)
     d = st1["deferred_stats"]
     # 9 requests per layer-call (7 linear inputs + key / value states; the first call of every calibrator takes the general
     # path), 6 distinct tensors; far fewer table builds than flushes (the allocator repeats its addresses)

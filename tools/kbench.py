@@ -14,6 +14,12 @@ moa = _moa_import.load()
 ops = moa.ops
 DEV = "cuda:0"
 PEAK = 8000.0
+# vector issue peak: 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz lane-instructions per second (an fp32 FMA in every slot
+# is the 78.6 TFLOP/s vector figure, packed FMAs the 157 TFLOP/s one)
+VALU_PEAK = 256 * 4 * 16 * 2.4e9
+# hot loop of moq_mse_sweep per (element, candidate), from the ISA (tools/isa_blocks.py, round 5): INT 415 / 64 (64 rndne +
+# 64 med3 + 287 packed), FP8 351 / 64; round 4's loop: 13.6 / 11.4
+MSE_SLOTS_INT, MSE_SLOTS_FP8 = 415 / 64, 351 / 64
 
 
 def timed(fn, reps=10):
@@ -112,20 +118,26 @@ def main():
         ("moq_symmetrize 8192 x 8192 fp32 (mirror of an upper-triangle Gram / Hessian)", lambda: ops.symmetrize(hsym), 8 * 8192 * 8192 // 2 * 1),
         # MseCalibrator.collect: 39 candidate amax values in ONE read (VALU-bound by design: the "GB/s" is the one read; the
         # reference makes ~5 passes per candidate = 195 x these bytes)
-        ("moq_mse_sweep INT8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, 8), 2 * n),
-        ("moq_mse_sweep INT8 per-channel, 39 candidates", lambda: ops.mse_sweep(w, cand39 * am_c.reshape(1, -1), (1,), 8), 2 * n),
-        ("moq_mse_sweep FP8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, (4, 3)), 2 * n),
-        ("moq_mse_sweep INT4 static g=128, 39 candidates", lambda: ops.mse_sweep(w.view(-1, 128), cand39 * am_g.reshape(1, -1), (1,), 4), 2 * n),
+        # fourth entry: VALU instruction slots per (element, candidate) read off the kernel's hot loop (tools/isa_blocks.py;
+        # a packed fp32 instruction is ONE slot for two elements) -> the kernel's own roofline, the vector issue rate
+        ("moq_mse_sweep INT8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, 8), 2 * n, 39 * MSE_SLOTS_INT),
+        ("moq_mse_sweep INT8 per-channel, 39 candidates", lambda: ops.mse_sweep(w, cand39 * am_c.reshape(1, -1), (1,), 8), 2 * n, 39 * MSE_SLOTS_INT),
+        ("moq_mse_sweep FP8 per-tensor, 39 candidates", lambda: ops.mse_sweep(w, cand39 * amax1, None, (4, 3)), 2 * n, 39 * MSE_SLOTS_FP8),
+        ("moq_mse_sweep INT4 static g=128, 39 candidates", lambda: ops.mse_sweep(w.view(-1, 128), cand39 * am_g.reshape(1, -1), (1,), 4), 2 * n, 39 * MSE_SLOTS_INT),
     ]
     print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|")
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    for name, fn, nbytes in cases:
-        if only and only not in name:
+    for name, fn, nbytes, *valu in cases:
+        if only and not any(o in name for o in only.split(",")):  # comma-separated substrings
             continue
         ms = timed(fn)
         gbs = nbytes / ms / 1e6
-        print(f"| {name} | {ms:.3f} | {gbs:.0f} | {gbs / PEAK:.3f} |")
+        note = ""
+        if valu:  # VALU-bound kernel: elements x slots per element against the chip's vector issue rate
+            rate = n * valu[0] / (ms * 1e-3)
+            note = f" -- VALU-bound: {valu[0]:.0f} instruction slots per element = {rate / 1e12:.1f} T lane-slots/s = {rate / VALU_PEAK:.2f} of the vector issue peak ({VALU_PEAK / 1e12:.1f} T/s)"
+        print(f"| {name}{note} | {ms:.3f} | {gbs:.0f} | {gbs / PEAK:.3f} |")
 
 
 if __name__ == "__main__":
