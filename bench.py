@@ -120,7 +120,8 @@ def pmc_traffic(workload, model, n_layers):
     if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
     path = None
-    for tag in ("r05", "r04", "r03", "r02", "r01c", "r01b", "r01"):  # newest committed profile of this workload
+    # newest committed profile of this workload ("r05h": round 5's; the files tagged plain "r05" were written late in round 4)
+    for tag in ("r05h", "r05", "r04", "r03", "r02", "r01c", "r01b", "r01"):
         cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc.json")
         if os.path.exists(cand):
             path = cand

@@ -164,8 +164,13 @@ __global__ __launch_bounds__(kBlock) void mse_rows_kernel(const void* __restrict
   }
 }
 
-// Short power-of-two rows (static blocks, inner = LPG * V <= 64 * V): LPG adjacent lanes own a row, its packet
-// stays in registers across all candidates, the per-candidate sum is an LPG-wide butterfly.
+// Short power-of-two rows (static blocks, inner = LPG * V <= 64 * V; LPG = 16-byte packets per row).  A candidate costs
+// ~25 VALU slots of setup per lane (the IEEE division of int_scale, the refined reciprocal) before any element is touched:
+// with one packet per lane (round 4) that was half of the hot loop's 8 x 6.5 slots of real work -- the g = 128 sweep ran at
+// 0.45 of the vector issue rate where the long-row kernel reaches 0.7-0.8.  A lane therefore owns PPL = min(4, LPG) packets
+// of its row (packets sub, sub + LN, ... : the LN = LPG / PPL lanes of a row still read one contiguous run), the setup is
+// paid once per 8 * PPL elements, the per-candidate sum is an LN-wide butterfly, and lane 0 of every row stores -- 16 rows
+// of a wave write 64 adjacent bytes per candidate instead of 4 x 4.
 template <int DT, int LPG, bool FP8>
 __global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restrict__ x, int64_t n_rows,
                                                            int64_t axis_size,
@@ -173,18 +178,30 @@ __global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restric
                                                            float* __restrict__ loss, int accumulate,
                                                            int num_bits, int is_unsigned, int narrow) {
   constexpr int V = Elem<DT>::kVec;
+  constexpr int PPL = LPG < 4 ? LPG : 4, LN = LPG / PPL;
   const IntQ q = make_intq(num_bits, is_unsigned, narrow);
-  const int64_t n_packets = n_rows * LPG;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < ((n_packets + 63) & ~(int64_t)63);
-       p += (int64_t)gridDim.x * kBlock) {
-    const bool live = p < n_packets;
-    const int64_t row = (live ? p : n_packets - 1) / LPG;
-    float f[8];
+  const int64_t n_items = n_rows * LN;
+  for (int64_t it = (int64_t)blockIdx.x * kBlock + threadIdx.x; it < ((n_items + 63) & ~(int64_t)63);
+       it += (int64_t)gridDim.x * kBlock) {
+    const bool live = it < n_items;
+    const int64_t row = (live ? it : n_items - 1) / LN;
+    const int sub = (int)(it - (it / LN) * LN);
+    float f[PPL * V];
     if (live) {
-      unpack<DT>(load16_nt(reinterpret_cast<const char*>(x) + p * 16), f);
+      Pack16 pk[PPL];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+        pk[j] = load16_nt(reinterpret_cast<const char*>(x) + (row * LPG + j * LN + sub) * 16);
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        float t[8];
+        unpack<DT>(pk[j], t);
+#pragma unroll
+        for (int i = 0; i < V; ++i) f[j * V + i] = t[i];
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) f[i] = 0.0f;
+      for (int i = 0; i < PPL * V; ++i) f[i] = 0.0f;
     }
     const int64_t a = row % axis_size;
     for (int k = 0; k < n_cand; ++k) {
@@ -193,18 +210,18 @@ __global__ __launch_bounds__(kBlock) void mse_group_kernel(const void* __restric
       if (cand_hot<FP8>(c)) {
         f32x2_t a2 = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0; i < V; i += 2) {
+        for (int i = 0; i < PPL * V; i += 2) {
           const f32x2_t xv = {f[i], f[i + 1]};
           a2 += sq_err2<FP8>(xv, c, q);
         }
         acc = a2.x + a2.y;
       } else {
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc += sq_err<FP8>(f[i], c, q);
+        for (int i = 0; i < PPL * V; ++i) acc += sq_err<FP8>(f[i], c, q);
       }
 #pragma unroll
-      for (int off = LPG / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-      if (live && (threadIdx.x & (LPG - 1)) == 0) {
+      for (int off = LN / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (live && sub == 0) {
         float* dst = loss + (int64_t)k * axis_size + a;
         // outer == 1 for block layouts, so every (k, a) has exactly one writer: plain read-modify-write
         *dst = accumulate ? *dst + acc : acc;
@@ -535,7 +552,7 @@ extern "C" int moq_mse_sweep(const void* x, int64_t outer, int64_t axis_size, in
   const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
   const int64_t lpg = inner % vec == 0 ? inner / vec : 0;
   if (outer == 1 && aligned && lpg >= 1 && lpg <= 64 && (lpg & (lpg - 1)) == 0) {
-    const int grid = stream_grid(kBlock, n_rows * lpg);
+    const int grid = stream_grid(kBlock, n_rows * (lpg < 4 ? 1 : lpg / 4));  // work items: rows x lanes per row
 #define MOQ_MSE_G(L)                                                                                            \
   case L:                                                                                                       \
     if (fp8) { MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mse_group_kernel<DT, L, true>), dim3(grid), dim3(kBlock), 0, S(stream), x, n_rows, axis_size, cand_amax, n_cand, loss, accumulate, num_bits, is_unsigned, narrow_range)); } \

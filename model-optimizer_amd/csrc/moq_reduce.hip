@@ -124,25 +124,25 @@ __global__ __launch_bounds__(kBlock) void col_stats_kernel(const void* __restric
 
 // sum of partial[b * cols + c] over the row blocks b = 0 .. n_blk - 1, added strictly in block order (the results of the
 // column statistics and of the AWQ weight scale are defined by that order).  The chain of adds is serial by definition; what
-// a thread can do is keep MANY loads in flight: 32 per round trip (round 4: 8 -- a 28672-row weight's 1792 partials cost 224
-// dependent L2 round trips per column, more than the sweep that produced them).
+// a thread can do is keep MANY loads in flight: 128 per round trip for long chains, then 32, then 8 (round 4: 8 -- a
+// 28672-row weight's 1792 partials cost 224 dependent L2 round trips per column, more than the sweep that produced them).
+template <int D>
+__device__ __forceinline__ void ordered_rounds(const float* __restrict__ partial, int64_t n_blk, int64_t cols, int64_t c,
+                                               int64_t& b, float& s) {
+  for (; b + D <= n_blk; b += D) {
+    float v[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) v[u] = partial[(b + u) * cols + c];
+#pragma unroll
+    for (int u = 0; u < D; ++u) s += v[u];
+  }
+}
 __device__ __forceinline__ float ordered_block_sum(const float* __restrict__ partial, int64_t n_blk, int64_t cols, int64_t c) {
   float s = 0.0f;
   int64_t b = 0;
-  for (; b + 32 <= n_blk; b += 32) {
-    float v[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = partial[(b + u) * cols + c];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) s += v[u];
-  }
-  for (; b + 8 <= n_blk; b += 8) {
-    float v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * cols + c];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
-  }
+  ordered_rounds<128>(partial, n_blk, cols, c, b, s);
+  ordered_rounds<32>(partial, n_blk, cols, c, b, s);
+  ordered_rounds<8>(partial, n_blk, cols, c, b, s);
   for (; b < n_blk; ++b) s += partial[b * cols + c];
   return s;
 }

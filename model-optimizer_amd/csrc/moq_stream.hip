@@ -453,19 +453,36 @@ __global__ __launch_bounds__(kBlock) void mt_amax_fold_kernel(const moq_seg* __r
 
 // Stage 2 for RUNNING maxima with several readers per tensor (moq_mt_amax_running): fold f takes the maximum of segment
 // folds[f].seg's chunk values and merges it into *folds[f].dst -- the calibrator's running abs-max, compared as bit
-// patterns like every abs-max of this library (NaN > inf > finite: a NaN sticks).  One wave per fold; a destination may
-// appear in several folds of one launch (an input quantizer called twice in a layer), hence the atomic.
-__global__ __launch_bounds__(64) void mt_amax_fold_running_kernel(const int64_t* __restrict__ blk_start,
-                                                                  const uint32_t* __restrict__ chunk_max,
-                                                                  const moq_amax_fold* __restrict__ folds) {
+// patterns like every abs-max of this library (NaN > inf > finite: a NaN sticks).  A destination may appear in several
+// folds of one launch (an input quantizer called twice in a layer), hence the atomic.
+// One 1024-thread workgroup per fold, every thread's loads in flight together: a 117 MB down_proj input is 7168 chunk
+// values, which ONE wave walking them 64 at a time (the first form) took 15.9 us over -- 40 % of the 38 us sweep it follows
+// and the reason the per-layer launch saved only 29 of 137 ms on the FP8 calibration loop of Llama-3-8B
+// (profiles/r05g_fp8_flow_kernels.md).
+constexpr int kFoldBlock = 1024;
+__global__ __launch_bounds__(kFoldBlock) void mt_amax_fold_running_kernel(const int64_t* __restrict__ blk_start,
+                                                                          const uint32_t* __restrict__ chunk_max,
+                                                                          const moq_amax_fold* __restrict__ folds) {
+  __shared__ uint32_t s_max[kFoldBlock / 64];
   const moq_amax_fold f = folds[blockIdx.x];
+  const int64_t c0 = blk_start[f.seg], c1 = blk_start[f.seg + 1];
   uint32_t acc = 0;
-  for (int64_t c = blk_start[f.seg] + threadIdx.x; c < blk_start[f.seg + 1]; c += 64) {
-    const uint32_t v = chunk_max[c];
-    acc = v > acc ? v : acc;
+  for (int64_t c = c0 + threadIdx.x; c < c1; c += 8 * kFoldBlock) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c + u * kFoldBlock < c1 ? chunk_max[c + u * kFoldBlock] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = v[u] > acc ? v[u] : acc;
   }
   acc = group_max_u32<64>(acc);
-  if (threadIdx.x == 0 && acc != 0) atomicMax(reinterpret_cast<uint32_t*>(f.dst), acc);
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < kFoldBlock / 64; ++w) m = s_max[w] > m ? s_max[w] : m;
+    if (m != 0) atomicMax(reinterpret_cast<uint32_t*>(f.dst), m);
+  }
 }
 
 __global__ void mt_zero_amax_kernel(const moq_seg* __restrict__ segs, int n_seg) {
@@ -770,7 +787,7 @@ extern "C" int moq_mt_amax_running(const moq_seg* segs, const int64_t* blk_start
                                               reinterpret_cast<uint32_t*>(chunk_scratch)));
   }
   if (n_folds > 0) {
-    hipLaunchKernelGGL(mt_amax_fold_running_kernel, dim3((unsigned)n_folds), dim3(64), 0, S(stream), blk_start,
+    hipLaunchKernelGGL(mt_amax_fold_running_kernel, dim3((unsigned)n_folds), dim3(kFoldBlock), 0, S(stream), blk_start,
                        reinterpret_cast<const uint32_t*>(chunk_scratch), folds);
   }
   return check_launch("moq_mt_amax_running");

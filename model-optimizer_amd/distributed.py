@@ -109,7 +109,9 @@ def _agree_amax_membership(quantizers, group, on_missing: str, device=None):
             if dev is None and isinstance(q, torch.nn.Module):
                 dev = next((b.device for b in q.buffers()), None)
             zeros = torch.zeros(shape, dtype=getattr(torch, dt), device=dev if dev is not None else "cpu")
-            if isinstance(q, torch.nn.Module) and isinstance(getattr(type(q), "amax", None), property):
+            # (a quantizer module takes it through its `amax` data descriptor -- property or buffer-state -- so that the
+            # zeros become a REGISTERED buffer; a bare attribute would not travel with state_dict / .to())
+            if isinstance(q, torch.nn.Module) and hasattr(getattr(type(q), "amax", None), "__set__"):
                 q.amax = zeros
             else:
                 q._amax = zeros

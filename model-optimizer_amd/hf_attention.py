@@ -43,9 +43,14 @@ class _QuantAttentionMixin:
     def _quantized_attention(original_attention_interface, self, query_states, key_states, value_states, *args,
                              **kwargs):
         # huggingface.py:222-236
-        query_states = self.q_bmm_quantizer(query_states)
-        key_states = self.k_bmm_quantizer(key_states)
-        value_states = self.v_bmm_quantizer(value_states)
+        q, k, v = self.q_bmm_quantizer, self.k_bmm_quantizer, self.v_bmm_quantizer
+        plain = TensorQuantizer  # (a chain or a subclass takes the call)
+        if not (type(q) is plain and q.hands_back()):  # the KV-cache presets leave the query quantizer disabled
+            query_states = q(query_states)
+        if not (type(k) is plain and k.hands_back()):
+            key_states = k(key_states)
+        if not (type(v) is plain and v.hands_back()):
+            value_states = v(value_states)
         if self.p_bmm_quantizer.is_enabled:
             raise NotImplementedError("p_bmm_quantizer (softmax QDQ inside flash attention) is outside this path")
         return original_attention_interface(self, query_states, key_states, value_states, *args, **kwargs)

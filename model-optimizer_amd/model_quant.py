@@ -391,7 +391,18 @@ def _warn_invalid_quantizer_state(model: nn.Module):
     for _, _, t in found:
         if not t.is_meta and t.numel():
             by_device.setdefault(t.device, []).append(t.detach().reshape(-1).float())
-    ok = all(bool((torch.isfinite(flat) & (flat >= 0)).all()) for flat in (torch.cat(ts) for ts in by_device.values()))
+
+    def clean(flat) -> bool:
+        # Per-tensor / per-channel state is a few thousand numbers: one concatenation on the device (a kernel the model's own
+        # forward has already loaded), one copy, the test on the host.  The device form costs four elementwise / reduction
+        # code objects their first use in the process -- 46 ms of a 4.2 s FP8 calibration of Llama-3-8B
+        # (profiles/r05g_fp8_flow_overhead.md); it stays for per-group state (hundreds of MB), where the copy would cost more
+        if flat.numel() <= (1 << 22):
+            host = flat.cpu()
+            return bool((torch.isfinite(host) & (host >= 0)).all())
+        return bool((torch.isfinite(flat) & (flat >= 0)).all())
+
+    ok = all(clean(torch.cat(ts)) for ts in by_device.values())
     if not ok:
         owners = dict(model.named_modules())
         for name, attr, _ in found:

@@ -30,8 +30,11 @@ class QuantLinear(nn.Linear):
 
     def forward(self, input):
         x = self.input_quantizer(input)
-        w = self.weight_quantizer(self.weight)
-        return self.output_quantizer(F.linear(x, w, self.bias))
+        wq, oq, w = self.weight_quantizer, self.output_quantizer, self.weight
+        if not (type(wq) is TensorQuantizer and wq.weight_already_counted(w)):
+            w = wq(w)
+        y = F.linear(x, w, self.bias)
+        return y if type(oq) is TensorQuantizer and oq.hands_back() else oq(y)
 
 
 class QuantLayerNorm(nn.LayerNorm):

@@ -128,7 +128,28 @@ def reduce_amax(input: torch.Tensor, axis=None, keepdims=True, squeeze_scalar=Tr
                 return out
             res = buf.to(x.dtype)
             return res if keepdims else res.reshape(x.shape[0], x.shape[2])
-        outer, kept, inner, keep = _reduce_layout(list(x.shape), axis)
+        try:
+            outer, kept, inner, keep = _reduce_layout(list(x.shape), axis)
+        except MoquantUnsupported:
+            # kept dims that are not one adjacent block (the reference's N-D block views keep e.g. dims 0, 1, 2, 4 of a 5-D
+            # tensor): ONE permuted copy brings the kept dims to the front, then it is the per-row reduction.  A maximum
+            # is exact, so the copy changes nothing but the cost (a cold path: no BASELINE configuration reduces this way)
+            red = sorted({a % nd for a in axis})
+            keep = [d for d in range(nd) if d not in red]
+            x = x.permute(keep + red).contiguous()
+            outer, kept, inner = 1, 1, 1
+            for d in range(len(keep)):
+                kept *= x.shape[d]
+            for d in range(len(keep), nd):
+                inner *= x.shape[d]
+            shape_in = list(input.shape)
+            buf = out if out is not None else torch.empty(kept, dtype=torch.float32, device=x.device)
+            check(_lib.lib().moq_amax_axis(_p(x), outer, kept, inner, _dt(x), _p(buf), int(accumulate), stream))
+            if out is not None:
+                return out
+            shape = [shape_in[d] if d in keep else 1 for d in range(nd)] if keepdims else [shape_in[d] for d in keep]
+            res = buf.to(x.dtype).reshape(shape)
+            return res.reshape(()) if squeeze_scalar and res.numel() == 1 else res
         buf = out if out is not None else torch.empty(kept, dtype=torch.float32, device=x.device)
         check(_lib.lib().moq_amax_axis(_p(x), outer, kept, inner, _dt(x), _p(buf), int(accumulate), stream))
         if out is not None:

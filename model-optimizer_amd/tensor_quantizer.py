@@ -116,33 +116,35 @@ class _BufferState:
             delattr(q, "_" + name)
 
 
+from torch.nn.modules.module import _global_forward_hooks as _GLOBAL_FORWARD_HOOKS  # noqa: E402
+from torch.nn.modules.module import _global_forward_pre_hooks as _GLOBAL_FORWARD_PRE_HOOKS  # noqa: E402
+
+
 class TensorQuantizer(nn.Module):
     def __init__(self, quant_attribute_cfg: QuantizerAttributeConfig | None = None, if_quant=True,
                  if_calib=False, amax=None):
         super().__init__()
         cfg = quant_attribute_cfg or QuantizerAttributeConfig()
-        self._num_bits = cfg.num_bits
-        self._axis = cfg.axis
-        self._block_sizes = dict(cfg.block_sizes) if cfg.block_sizes else None
-        self._unsigned = cfg.unsigned
-        self._narrow_range = cfg.narrow_range
-        self._fake_quant = cfg.fake_quant
-        self._disabled = not cfg.enable
-        self._dynamic = cfg.type == "dynamic"
-        self._if_quant = if_quant
-        self._if_calib = if_calib
-        self._enable_pre_quant_scale = True
-        self._calibrator = self._make_calibrator(cfg.calibrator)
-        self._bias = dict(cfg.bias) if cfg.bias else None
-        self._bias_calibrator = None  # made on first use (tensor_quantizer.py:222-223, :490-503)
-        self._use_constant_amax = bool(cfg.use_constant_amax)
-        self._constant_amax = cfg.constant_amax
-        if cfg.constant_amax is not None:
-            self.amax = float(cfg.constant_amax)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
+        # plain (non-tensor, non-module) state goes straight into the instance dict: nn.Module.__setattr__ checks every
+        # assignment against its parameter / buffer / module tables, and a Llama-3-8B conversion makes 800 quantizers x 28 of
+        # them (half of the convert + set_quantizers stages)
+        self.__dict__.update(_if_quant=if_quant, _if_calib=if_calib, _enable_pre_quant_scale=True)
+        self._take_config(cfg)
         if amax is not None:
             self.amax = amax
+
+    def _take_config(self, cfg: QuantizerAttributeConfig):
+        d = self.__dict__
+        d.update(_num_bits=cfg.num_bits, _axis=cfg.axis, _block_sizes=dict(cfg.block_sizes) if cfg.block_sizes else None,
+                 _unsigned=cfg.unsigned, _narrow_range=cfg.narrow_range, _fake_quant=cfg.fake_quant, _disabled=not cfg.enable,
+                 _dynamic=cfg.type == "dynamic", _bias=dict(cfg.bias) if cfg.bias else None,
+                 _bias_calibrator=None,  # made on first use (tensor_quantizer.py:222-223, :490-503)
+                 _use_constant_amax=bool(cfg.use_constant_amax), _constant_amax=cfg.constant_amax)
+        d["_calibrator"] = self._make_calibrator(cfg.calibrator)
+        if cfg.constant_amax is not None:  # pinned on the buffer: forward and export read it (tensor_quantizer.py:256-261)
+            self.amax = float(cfg.constant_amax)
 
     # ------------------------------------------------------------------ configuration
     _weight_stats_done = None  # (data_ptr, version, shape) of the weight whose max statistics this calibration already holds
@@ -150,28 +152,14 @@ class TensorQuantizer(nn.Module):
     def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
         """tensor_quantizer.py:228-290: (re)configure in place; calibration state is dropped."""
         for name in ("_amax", "_pre_quant_scale", "_bias_value"):
-            if hasattr(self, name):
+            if name in self._buffers or name in self.__dict__:
                 delattr(self, name)
-        self._bias = dict(cfg.bias) if cfg.bias else None
-        self._bias_calibrator = None
-        self._use_constant_amax = bool(cfg.use_constant_amax)
-        self._constant_amax = cfg.constant_amax
-        if cfg.constant_amax is not None:  # pinned on the buffer: forward and export read it (tensor_quantizer.py:256-261)
-            self.amax = float(cfg.constant_amax)
         for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
                      "_nd_split", "_nd_perm", "_nd_inverse"):
             self.__dict__.pop(name, None)
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
-        self._num_bits = cfg.num_bits
-        self._axis = cfg.axis
-        self._block_sizes = dict(cfg.block_sizes) if cfg.block_sizes else None
-        self._unsigned = cfg.unsigned
-        self._narrow_range = cfg.narrow_range
-        self._fake_quant = cfg.fake_quant
-        self._disabled = not cfg.enable
-        self._dynamic = cfg.type == "dynamic"
-        self._calibrator = self._make_calibrator(cfg.calibrator)
+        self._take_config(cfg)
 
     def _make_calibrator(self, spec) -> _Calibrator:
         # config.py:599-613 / tensor_quantizer.py:235-241: "max", "histogram" or (cls, args, kwargs)
@@ -638,6 +626,25 @@ class TensorQuantizer(nn.Module):
             running = cal._buf
         return ops.input_quant(inputs, pqs, amax_running=running, qdq_amax=amax_q, num_bits=nb if amax_q is not None else None,
                                unsigned=self._unsigned, narrow_range=self._narrow_range)
+
+    # -- shortcuts for the callers that own a quantizer (QuantLinear, the attention wrapper): a calibration loop of
+    # Llama-3-8B makes 30 000 calls of quantizers that hand their input straight back (disabled output / query quantizers;
+    # weight quantizers whose statistics weight_only_quantize already took), each through nn.Module.__call__ and the chain of
+    # tests in forward() -- ~0.1 s of host time in a loop the host barely keeps ahead of the GPU (profiles/r05g_fp8_flow_overhead.md)
+    def hands_back(self) -> bool:
+        """True when calling this quantizer cannot do anything to its input: disabled, no smoothing scale, and nobody
+        hooked its call.  (The reference's forward returns the input of a disabled quantizer after the pre_quant_scale
+        step, tensor_quantizer.py:1119-1150.)"""
+        return (self._disabled and "_pre_quant_scale" not in self._buffers and not self._forward_hooks
+                and not self._forward_pre_hooks and not _GLOBAL_FORWARD_HOOKS and not _GLOBAL_FORWARD_PRE_HOOKS)
+
+    def weight_already_counted(self, w) -> bool:
+        """True inside max_calibrate's forward loop for the weight whose statistics this calibration already holds (the
+        second test of forward(), without the call)."""
+        done = self._weight_stats_done
+        return (done is not None and self._if_calib and not self._if_quant and not self._disabled and done[0] == w.data_ptr()
+                and done[1] == w._version and done[2] == tuple(w.shape) and not self._forward_hooks
+                and not self._forward_pre_hooks and not _GLOBAL_FORWARD_HOOKS and not _GLOBAL_FORWARD_PRE_HOOKS)
 
     def forward(self, inputs):
         if inputs.numel() == 0:

@@ -41,9 +41,15 @@ def from_bits(a: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
     return torch.from_numpy(a.copy())
 
 
+class _Arrays(dict):
+    """A generator's in-memory output dressed like the NpzFile the committed fixtures load as."""
+
+    files = property(lambda self: list(self))
+
+
 class Golden:
-    def __init__(self, name):
-        self.z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+    def __init__(self, name, arrays=None):
+        self.z = np.load(os.path.join(GOLDEN, f"{name}.npz")) if arrays is None else _Arrays({k: np.asarray(v) for k, v in arrays.items()})
         self.cases = json.loads(str(self.z["cases"]))
 
     def t(self, key, dtype=torch.float32):
@@ -51,6 +57,56 @@ class Golden:
 
     def raw(self, key):
         return self.z[key]
+
+
+# Fixtures whose arrays come out of a bf16 CPU FORWARD of the reference (name -> its generator in tests/golden/gen_golden.py).
+# torch's CPU bf16 GEMM (oneDNN) is not the same function on every host: on a host whose path differs from the fixture
+# host's, the REFERENCE ITSELF does not regenerate the committed arrays (seen when the build container moved to another
+# machine in round 5: `fp8_max_y` 1 of 3072 elements off by one bf16 ulp, and from there the statistics of every later
+# layer of the tiny Llama; every f32 fixture regenerates identically).  pinned_or_live() keeps such a test pinned to the
+# committed bytes wherever they can be met and otherwise pins it to the reference's LIVE run of the same generator.
+HOST_FORWARD_FIXTURES = {"model_flows": "gen_model_flows", "export_llama_int8_sq": "gen_export_int8_sq",
+                         "sq_mxfp4": "gen_sq_mxfp4", "gptq_llama": "gen_gptq_llama"}
+_LIVE: dict = {}
+
+
+def live_golden(name):
+    """The fixture `name` as the reference generates it on THIS host, or None when there is no reference here or its
+    arrays equal the committed ones (then a failing comparison is a real failure)."""
+    if name not in _LIVE:
+        if GOLDEN not in sys.path:
+            sys.path.insert(0, GOLDEN)
+        import ref_shim
+
+        _LIVE[name] = None
+        if ref_shim.reference_available():
+            import gen_golden
+
+            out: dict = {}
+            if name == "sq_mxfp4":  # built on the INT8 SmoothQuant run's smoothed weights: this host's, if they moved
+                base = live_golden("export_llama_int8_sq")
+                gen_golden.gen_sq_mxfp4(out, have=None if base is None else base.z)
+            else:
+                getattr(gen_golden, HOST_FORWARD_FIXTURES[name])(out)
+            committed = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+            moved = [k for k in committed.files if k != "cases" and not (k in out and np.array_equal(np.asarray(out[k]), committed[k]))]
+            if moved:
+                note(f"fixture {name}: the reference regenerates {len(moved)} of {len(committed.files)} arrays differently on this "
+                     f"host (bf16 CPU forward; first: {moved[0]}) -- compared with the reference's live run instead")
+                _LIVE[name] = Golden(name, arrays=out)
+    return _LIVE[name]
+
+
+def pinned_or_live(golden, names, check):
+    """check(get) with get = the committed fixtures; if that fails and the reference does not reproduce one of `names` on
+    this host either, once more with those fixtures replaced by the reference's live output of the same generators."""
+    try:
+        return check(golden)
+    except AssertionError:
+        lives = {n: live_golden(n) for n in names}
+        if all(v is None for v in lives.values()):
+            raise
+        return check(lambda n: lives.get(n) or golden(n))
 
 
 @pytest.fixture(autouse=True)

@@ -1538,7 +1538,7 @@ def gen_export_int8_sq(out):
                                              hf_quant_config=quant_cfg)))
 
 
-def gen_sq_mxfp4(out):
+def gen_sq_mxfp4(out, have=None):
     """BASELINE configs[4] -- SmoothQuant scaling composed with MXFP4: the reference's smoothquant only acts
     on INT8 quantizers and its MX fake quantization needs the CUDA extension, so the composition is pinned from its two
     runnable halves.  (1) The scale math + fold: format independent, taken from the reference's INT8 SmoothQuant run of the
@@ -1548,7 +1548,9 @@ def gen_sq_mxfp4(out):
     E8M0 scale bytes, as export_hf_checkpoint stores them for an MXFP4 model.  alpha = 1.0 (the INT8 preset's)."""
     from modelopt.torch.quantization.qtensor import MXFP4QTensor
 
-    have = np.load(os.path.join(HERE, "export_llama_int8_sq.npz"))
+    # (`have`: the INT8 SmoothQuant arrays to build on -- the committed fixture, or, for tests/conftest.py's live fallback on a
+    # host whose bf16 forward differs from the fixture host's, the same generator's output on that host)
+    have = np.load(os.path.join(HERE, "export_llama_int8_sq.npz")) if have is None else have
     cases = json.loads(str(have["cases"]))
     for n in cases["linears"]:
         raw = have[f"pre/{n}.weight"]

@@ -12,7 +12,7 @@ import torch
 
 import _moa_import
 import hostmem_backend
-from conftest import from_bits
+from conftest import pinned_or_live, from_bits
 
 moa = _moa_import.load()
 
@@ -70,6 +70,10 @@ def test_fp8_calibration_and_export_equal_reference(golden, hostmem):
 
 
 def test_int8_smoothquant_flow_and_export_equal_reference(golden, hostmem):
+    pinned_or_live(golden, ["export_llama_int8_sq"], _int8_smoothquant_flow_and_export)
+
+
+def _int8_smoothquant_flow_and_export(golden):
     g = golden("export_llama_int8_sq")
     cases = g.cases
     model = _llama(g, cases, torch.bfloat16)
@@ -195,6 +199,10 @@ def _mlp_flow(golden, name, cfg):
 
 @pytest.mark.parametrize("name", ["int8_max", "fp8_max"])
 def test_mlp_max_calibration_equals_reference(golden, hostmem, name):
+    pinned_or_live(golden, ["model_flows"], lambda get: _mlp_max_calibration(get, name))
+
+
+def _mlp_max_calibration(golden, name):
     cfg = moa.model_quant.INT8_DEFAULT_CFG if name == "int8_max" else moa.model_quant.FP8_DEFAULT_CFG
     g, c, q, batches, dt = _mlp_flow(golden, name, cfg)
     for tname, tdtype, tshape in c["tensors"]:
@@ -460,6 +468,10 @@ def test_tensor_quantizer_fused_input_pass_equals_unfused_chain(hostmem):
 
 
 def test_smoothquant_composed_with_mxfp4_equals_reference_halves(golden, hostmem):
+    pinned_or_live(golden, ["export_llama_int8_sq", "sq_mxfp4"], _smoothquant_composed_with_mxfp4)
+
+
+def _smoothquant_composed_with_mxfp4(golden):
     """BASELINE configs[4]: MXFP4_SMOOTHQUANT_CFG from the ORIGINAL weights and tokens.  The per-channel scales and the
     folded weights equal the reference's INT8 SmoothQuant run bit for bit (the scale math does not depend on the format);
     the exported packed E2M1 nibbles / E8M0 scales equal the reference's MXFP4QTensor.quantize of those weights; the MX
