@@ -138,10 +138,11 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
     for group in by_key.values():
         tab = SegmentTable([w.detach() for w, _ in group], outputs=[w.detach() for w, _ in group])
         amax = tab.calibrate_amax()
+        held = amax.clone()  # ONE copy; every fresh calibrator keeps a one-element view of it (was a clone launch per weight)
         for i, (w, wq) in enumerate(group):
             cal = wq._calibrator
             if cal._buf is None:
-                cal._buf = amax[i:i + 1].clone()
+                cal._buf = held[i:i + 1]
                 cal._shape, cal._dtype = (), w.dtype
             else:
                 torch.maximum(cal._buf, amax[i:i + 1], out=cal._buf)

@@ -65,8 +65,16 @@ def run(args, moa=None, dev=None) -> dict:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     loop(model)
+    t_plain_host = time.perf_counter() - t0  # the host is done enqueuing here; the GPU usually is not
     torch.cuda.synchronize()
     t_plain = time.perf_counter() - t0
+    host_times = {"plain_loop_host_s": round(t_plain_host, 3)}
+    plain_loop = loop
+
+    def loop(m):  # noqa: F811  (the calibration loop with a clock on its host side)
+        t = time.perf_counter()
+        plain_loop(m)
+        host_times["calibration_loop_host_s"] = round(time.perf_counter() - t, 3)
     if args.qformat in ("sparse_magnitude", "sparsegpt"):
         t0 = time.perf_counter()
         moa.sparsity.sparsify(model, args.qformat, forward_loop=loop if args.qformat == "sparsegpt" else None)
@@ -161,6 +169,7 @@ def run(args, moa=None, dev=None) -> dict:
                                     "gram_loss": m.awq_lite.gram_loss, "contenders": m.awq_lite.contenders}
                                    for n, m in named]}, f)
     extra["quantize_stages_s"] = dict(moa.model_quant.QUANTIZE_STATS.get("stages_s") or {})
+    extra["host_side"] = host_times  # loop wall-clock == host time: the HOST is the bottleneck of that loop
     if moa.model_calib.MAX_CALIBRATE_STATS:
         extra["max_calibrate_s"] = dict(moa.model_calib.MAX_CALIBRATE_STATS)
     if "gptq" in args.qformat:
