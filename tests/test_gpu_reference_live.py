@@ -271,6 +271,85 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
 
 
+def _wide_llama(outliers: bool):
+    """Two decoder layers of Llama-3-8B's width (hidden 4096, MLP 14336, 32 / 8 heads), random init, small vocabulary.
+    outliers: a few embedding channels and norm gains are scaled up, so activations carry massive channels like a trained
+    model's (then AWQ's candidates stand apart); without them every candidate of a linear lies within a fraction of a
+    percent -- the adversarial case for a search that sums the same products in another order."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(11)
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, vocab_size=1024, max_position_embeddings=1024, architectures=["LlamaForCausalLM"])
+    m = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    if outliers:
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(5)
+            hot = torch.randperm(4096, generator=g)[:24]
+            m.model.embed_tokens.weight[:, hot] *= 30.0
+            for layer in m.model.layers:
+                layer.input_layernorm.weight[hot] *= 8.0
+                layer.post_attention_layernorm.weight[hot] *= 8.0
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("outliers", [True, False])
+def test_int4_awq_at_llama_3_8b_width_picks_the_reference_alphas(ref, outliers):
+    """The screen + exact re-score (search="auto") against the REFERENCE's own awq_lite at full layer width, both on the
+    device (until now only this package's exhaustive engine had been the witness at Cin = 4096 /
+    14336).  The reference scores with the library GEMM, so near-ties may fall the other way; with activation outliers every
+    linear must pick the reference's alpha, without them at least 12 of 14."""
+    import modelopt.torch.quantization as mtq
+
+    batches = [torch.randint(0, 1024, (4, 512), generator=torch.Generator().manual_seed(90 + i)).to(DEV) for i in range(8)]
+
+    def loop(m):
+        with torch.no_grad():
+            for b in batches:
+                m(b)
+
+    def scales(model, quantizer_type):
+        return {n: mod.input_quantizer._pre_quant_scale.detach().float().cpu().clone() for n, mod in model.named_modules()
+                if hasattr(mod, "input_quantizer") and getattr(mod.input_quantizer, "_pre_quant_scale", None) is not None}
+
+    rcfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+    rcfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "debug": True}  # debug: the search tables stay on the modules
+    r = mtq.quantize(_wide_llama(outliers), rcfg, loop)
+    want = scales(r, None)
+    ref_alpha = {n: float(mod.awq_lite.best_alpha) for n, mod in r.named_modules() if hasattr(mod, "awq_lite")}
+    ref_loss = {n: {round(float(a), 1): float(v) for a, v in mod.awq_lite.loss.items()} for n, mod in r.named_modules()
+                if hasattr(mod, "awq_lite")}
+    del r
+    torch.cuda.empty_cache()
+    ours = _wide_llama(outliers)
+    with moa.numerics.scale_math("device"), torch.no_grad():
+        moa.quantize(ours, copy.deepcopy(moa.model_quant.INT4_AWQ_CFG), loop)
+    got = scales(ours, None)
+    alphas = {n: float(mod.awq_lite.best_alpha) for n, mod in ours.named_modules() if hasattr(mod, "awq_lite")}
+    assert sorted(got) == sorted(want) and len(want) == 14 and sorted(alphas) == sorted(ref_alpha)
+    same_alpha = [n for n in ref_alpha if round(alphas[n], 1) == round(ref_alpha[n], 1)]
+    same_vec = [n for n in want if torch.equal(got[n], want[n])]
+    # a linear that picked another alpha: how far apart are the two candidates in the REFERENCE's own loss table?
+    gaps = {}
+    for n in ref_alpha:
+        if n not in same_alpha:
+            t = ref_loss[n]
+            gaps[n.replace("model.layers.", "L")] = (round(ref_alpha[n], 1), round(alphas[n], 1),
+                                                      (t[round(alphas[n], 1)] - t[round(ref_alpha[n], 1)]) / t[round(ref_alpha[n], 1)])
+    # same alpha but another bit in the scale vector: the per-channel mean |x| behind it is summed in this library's own
+    # (defined) order, torch's GPU reduction in another -- stated tolerance: one step of the 16-bit scale
+    worst = max([((got[n] - want[n]).abs() / want[n].abs()).max().item() for n in same_alpha if n not in same_vec] or [0.0])
+    assert worst <= 2.0 ** -7, worst
+    st = moa.model_calib.AWQ_LITE_STATS
+    note(f"INT4-AWQ at Llama-3-8B width on the device vs the reference's eager search ({'outlier channels' if outliers else 'plain random init'}): "
+         f"{len(same_alpha)} / 14 linears pick the reference's alpha ({len(same_vec)} scale vectors bit-identical, the others within {worst:.1e} relative: the activation mean's summation order); other picks "
+         f"(reference alpha, ours, relative gap of the two in the reference's loss table): {gaps}; "
+         f"re-scored {st.get('rescored_candidates')} candidates of {st.get('rescored_linears')} linears")
+    # another pick is accepted only where the reference's own table calls the two candidates a tie to its GEMM's rounding
+    assert all(abs(g[2]) < 2e-4 for g in gaps.values()), gaps
+    assert len(same_alpha) >= (14 if outliers else 11), gaps
+
+
 # ------------------------------------------------------------------------------------------------------------- D
 def test_reference_sparsify_on_the_device_through_the_mask_seam(ref):
     import modelopt.torch.sparsity as mts
