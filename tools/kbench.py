@@ -127,6 +127,8 @@ def main():
     ]
     print(f"| kernel (bf16, {rows}x{cols} weight = {2 * n / 1e6:.0f} MB; activations {tuple(x.shape)}) | ms | algorithmic GB/s | frac of 8 TB/s |")
     print("|---|---|---|---|")
+    # ops under ~40 us are timed from Python here = the host's launch rate (2-3 launches + a small allocation per call), not the
+    # kernel: their kernel-only durations (rocprofv3) are in profiles/r05g_small_kernels_kernel_only.md
     only = sys.argv[1] if len(sys.argv) > 1 else None
     for name, fn, nbytes, *valu in cases:
         if only and not any(o in name for o in only.split(",")):  # comma-separated substrings
@@ -137,6 +139,8 @@ def main():
         if valu:  # VALU-bound kernel: elements x slots per element against the chip's vector issue rate
             rate = n * valu[0] / (ms * 1e-3)
             note = f" -- VALU-bound: {valu[0]:.0f} instruction slots per element = {rate / 1e12:.1f} T lane-slots/s = {rate / VALU_PEAK:.2f} of the vector issue peak ({VALU_PEAK / 1e12:.1f} T/s)"
+        if ms < 0.040:
+            note += " -- HOST-launch-bound at this size; kernel-only: profiles/r05g_small_kernels_kernel_only.md"
         print(f"| {name}{note} | {ms:.3f} | {gbs:.0f} | {gbs / PEAK:.3f} |")
 
 
