@@ -851,7 +851,7 @@ def main():
             extra["awq"] = {k: line[k] for k in ("config", "search", "rescored_linears", "rescored_candidates",
                                                  "search_gemm_TFLOPs_equiv", "best_alpha_hist", "passes", "stages_s",
                                                  "quantize_stages_s", "unstaged_s", "awq_unstaged_s",
-                                                 "tie_check", "replayed_passes", "forward_loop_calls", "warm_forward_s",
+                                                 "tie_check", "replayed_passes", "forward_loop_calls", "warm_forward_s", "rehearsal_s", "alloc_probe_8GiB_s",
                                                  "stored_input_bytes") if k in line}
         except Exception as e:
             extra["awq_wallclock_s"] = None
