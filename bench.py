@@ -851,7 +851,7 @@ def main():
             extra["awq"] = {k: line[k] for k in ("config", "search", "rescored_linears", "rescored_candidates",
                                                  "search_gemm_TFLOPs_equiv", "best_alpha_hist", "passes", "stages_s",
                                                  "quantize_stages_s", "unstaged_s", "awq_unstaged_s",
-                                                 "tie_check", "replayed_passes", "forward_loop_calls", "warm_forward_s", "rehearsal_s", "alloc_probe_8GiB_s",
+                                                 "tie_check", "replayed_passes", "forward_loop_calls", "warm_forward_s", "rehearsal_s", "allocator_reserve",
                                                  "stored_input_bytes") if k in line}
         except Exception as e:
             extra["awq_wallclock_s"] = None
@@ -863,7 +863,9 @@ def main():
         # inputs of q/k/v and gate/up shared), whose activations have no outlier channels -- all 11 candidates of a linear
         # score within a fraction of a percent, the worst case for the exact re-scoring (tools/hf_flow_check.py)
         try:
-            torch.cuda.empty_cache()
+            # (no empty_cache here: memory handed back to the driver is wiped in the background at ~25 GB/s, and an allocation
+            # that needs those pages waits for it -- seconds, inside whatever is being timed; the flow below is served from
+            # torch's cache, tools/awq_bench.py has the measurement)
             if os.path.join(ROOT, "tools") not in sys.path:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
             import hf_flow_check

@@ -665,8 +665,12 @@ class _WeightCacheBudget:
     def __init__(self, device):
         self.left = int(self.host_bytes)
         if device.type == "cuda":
+            # what the flow can still get: the driver's free memory PLUS what torch's caching allocator holds without using
+            # (a process that has run anything large before sits on such blocks -- and a harness may park the flow's memory
+            # there on purpose, tools/awq_bench.py: counting the driver's share alone sent that run into a second pass)
             free, _ = torch.cuda.mem_get_info(device)
-            self.left = int(free * 0.6)
+            cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+            self.left = int((free + max(cached, 0)) * 0.6)
 
     def reserve(self, nbytes: int) -> bool:
         if nbytes <= self.left:

