@@ -765,32 +765,68 @@ __global__ __launch_bounds__(kBlock) void scale_cols_kernel(const void* __restri
   }
 }
 
-// y[a, r, c] = dtype(w[r, c] * s[a, c]) for a < n_scales: ONE read of w, n_scales writes (the 11 pre-scaled
-// activation copies of an AWQ search step).  Requires the fast layout (checked by the host entry).
+// y[a, r, c] = dtype(w[r, c] * s[a, c]) for a < n_scales: ONE read of w, n_scales writes (the pre-scaled activation
+// copies of an AWQ search step: x / s_alpha for every contender of a linear, model_calib.py:1489-1495).  Requires the fast
+// layout (checked by the host entry: 16-byte aligned pointers, cols % kVec == 0).
+// Round 5: on the chunk skeleton (round 1's form was a grid-stride loop with one packet and one 64-bit modulo per
+// iteration, ordinary stores: 92.7 us per call in the HF-topology AWQ flow = 2.2 TB/s, 10 240 calls = 3.7 % of its kernel
+// time).  One chunk per workgroup, the chunk's packets requested before the first use, a candidate's scale vectors for
+// all packets requested together, non-temporal stores (every copy is written once and read once by the error GEMM): 4.0 TB/s
+// on 67 MB x (1 + 5 candidates) -- six address windows per launch, one read and five written; prefetching the next
+// candidate's scales under the current one's stores changed nothing (measured), the windows are what is left.
 template <int DT>
 __global__ __launch_bounds__(kBlock) void scale_cols_multi_kernel(const void* __restrict__ w,
                                                                   const float* __restrict__ s,
                                                                   void* __restrict__ y, int64_t rows,
                                                                   int64_t cols, int n_scales) {
   constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
   const int64_t n = rows * cols;
-  const int64_t n_packets = n / V;
-  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n_packets;
-       p += (int64_t)gridDim.x * kBlock) {
-    float v[8];
-    unpack<DT>(load16_nt(reinterpret_cast<const char*>(w) + p * 16), v);
-    const int64_t c = (p * V) % cols;
-    for (int a = 0; a < n_scales; ++a) {
-      const float* sa = s + (int64_t)a * cols + c;
-      float o[8];
-      const float4 s0 = *reinterpret_cast<const float4*>(sa);
-      o[0] = v[0] * s0.x; o[1] = v[1] * s0.y; o[2] = v[2] * s0.z; o[3] = v[3] * s0.w;
-      if constexpr (V == 8) {
-        const float4 s1 = *reinterpret_cast<const float4*>(sa + 4);
-        o[4] = v[4] * s1.x; o[5] = v[5] * s1.y; o[6] = v[6] * s1.z; o[7] = v[7] * s1.w;
+  const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
+  int64_t toff[P];
+#pragma unroll
+  for (int u = 0; u < P; ++u) toff[u] = (int64_t)packet_off<DT>(u) % cols;
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int64_t e0 = c * MOQ_MT_CHUNK;
+    const int64_t col0 = e0 % cols;  // uniform: one 64-bit division per chunk
+    auto body = [&](auto FULL) {
+      constexpr bool full = decltype(FULL)::value;
+      Pack16 in[P];
+      int64_t col[P];
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        const int64_t e = e0 + packet_off<DT>(u);
+        col[u] = col0 + toff[u];
+        col[u] = col[u] >= cols ? col[u] - cols : col[u];
+        if (full || e < n) in[u] = load16_nt(reinterpret_cast<const char*>(w) + e * (16 / V));
       }
-      store16(reinterpret_cast<char*>(y) + ((int64_t)a * n_packets + p) * 16, pack<DT>(o));
-    }
+      float v[P][8];
+#pragma unroll
+      for (int u = 0; u < P; ++u) unpack<DT>(in[u], v[u]);
+      for (int a = 0; a < n_scales; ++a) {
+        const float* sa = s + (int64_t)a * cols;
+        float4 m[P][V / 4];
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+#pragma unroll
+          for (int i = 0; i < V / 4; ++i) m[u][i] = *reinterpret_cast<const float4*>(sa + col[u] + 4 * i);
+        char* ya = reinterpret_cast<char*>(y) + (int64_t)a * n * (16 / V);
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const int64_t e = e0 + packet_off<DT>(u);
+          if (!full && e >= n) continue;
+          float o[8];
+#pragma unroll
+          for (int i = 0; i < V; i += 4) {
+            const float4 mm = m[u][i / 4];
+            o[i] = v[u][i] * mm.x; o[i + 1] = v[u][i + 1] * mm.y; o[i + 2] = v[u][i + 2] * mm.z; o[i + 3] = v[u][i + 3] * mm.w;
+          }
+          store16_nt(ya + e * (16 / V), pack<DT>(o));
+        }
+      }
+    };
+    if (e0 + MOQ_MT_CHUNK <= n) body(std::true_type{});
+    else body(std::false_type{});
   }
 }
 
@@ -1118,9 +1154,8 @@ extern "C" int moq_scale_cols_multi(const void* w, const float* s, void* y, int6
   }
   const int64_t n = rows * cols;
   if (n == 0) return MOQ_OK;
-  const int grid = stream_grid(kBlock, n / vec);
-  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_multi_kernel<DT>), dim3(grid), dim3(kBlock), 0, S(stream),
-                                            w, s, y, rows, cols, n_scales));
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((scale_cols_multi_kernel<DT>), dim3(copy_grid((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK)),
+                                            dim3(kBlock), 0, S(stream), w, s, y, rows, cols, n_scales));
   return check_launch("moq_scale_cols_multi");
 }
 

@@ -179,6 +179,21 @@ def test_err_gemm_multi_equals_single_launches():
         assert shared[i].item() == one.item()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(4096, 4096), (200, 328), (33, 8200), (1, 8), (8, 1024)])
+def test_scale_cols_multi_is_the_rounded_product(dtype, rows, cols):
+    """y[a] = dtype(x * s[a]) (one fp32 multiply, one rounding) for every candidate, on whole chunks, a ragged last chunk
+    and tensors smaller than a chunk -- the pre-scaled activations x / s_alpha of the AWQ search (model_calib.py:1489-1495)."""
+    g = torch.Generator().manual_seed(rows * 31 + cols)
+    x = torch.randn(rows, cols, generator=g).to(dtype)
+    s = torch.exp(torch.randn(7, cols, generator=g) * 0.3)
+    got = ops.scale_cols_multi(x.to(DEV), s.to(DEV)).cpu()
+    want = (x.float().unsqueeze(0) * s.unsqueeze(1)).to(dtype)
+    assert got.shape == want.shape and got.dtype == dtype
+    assert torch.equal(got.view(torch.int16 if dtype != torch.float32 else torch.int32),
+                       want.view(torch.int16 if dtype != torch.float32 else torch.int32))
+
+
 _GEO_PROBE = r"""
 import hashlib, sys, torch
 sys.path.insert(0, sys.argv[1])

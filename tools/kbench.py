@@ -69,6 +69,7 @@ def main():
     mxq = ops.mxfp4_quantize(w, 32)
     wsf_row = (am_c / 127.0).float()
     hsym = torch.randn(8192, 8192, device=DEV)
+    s5 = torch.rand(5, 8192, device=DEV) + 0.5
     amax_x = torch.tensor(xo_max * 0.5, device=DEV)
     ybig = torch.empty_like(xbig)
     cases = [
@@ -114,6 +115,7 @@ def main():
         ("moq_mxfp4_unpack g=32", lambda: ops.mxfp4_dequantize(mxq[0], mxq[1], torch.bfloat16, 32), n // 2 + n // 32 + 2 * n),
         ("moq_int8_pack_rows (INT8 SmoothQuant export)", lambda: ops.int8_pack_rows(w, wsf_row), 3 * n),
         ("moq_awq_weight_scale g=128 (awq_lite get_weight_scale)", lambda: ops.awq_weight_scale(w, 128), 2 * n),
+        ("moq_scale_cols_multi, 5 candidates (x / s_alpha copies of an AWQ search step)", lambda: ops.scale_cols_multi(x, s5), 2 * nx * 6),
         ("moq_transpose16 (activation transpose feeding the Gram accumulation)", lambda: ops.transpose16(x), 4 * nx),
         ("moq_symmetrize 8192 x 8192 fp32 (mirror of an upper-triangle Gram / Hessian)", lambda: ops.symmetrize(hsym), 8 * 8192 * 8192 // 2 * 1),
         # MseCalibrator.collect: 39 candidate amax values in ONE read (VALU-bound by design: the "GB/s" is the one read; the
