@@ -379,3 +379,19 @@ def test_awq_lite_ragged_input_width_equals_the_reference_run(golden):
     import replay_common
 
     replay_common.awq_ragged_check(moa, golden, DEV)
+
+
+def test_the_hbm_budget_counts_what_torchs_allocator_holds_without_using():
+    """A process that has freed something large sits on it in torch's caching allocator: the driver reports that memory as
+    taken, yet the flow gets it on request.  Counting the driver's share alone sent tools/awq_bench.py's run -- which parks the
+    flow's memory there before its clock starts -- into a second pass over the calibration data."""
+    dev = torch.device(DEV)
+    torch.cuda.empty_cache()
+    before = moa.model_calib._WeightCacheBudget(dev).left
+    held = torch.empty(8 << 30, dtype=torch.uint8, device=dev)
+    during = moa.model_calib._WeightCacheBudget(dev).left
+    del held  # back to torch's cache, not to the driver
+    after = moa.model_calib._WeightCacheBudget(dev).left
+    torch.cuda.empty_cache()
+    assert during <= before - int(0.55 * (8 << 30))
+    assert after >= before - (64 << 20), (before, during, after)
