@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restr
                                                              int* __restrict__ counts) {
   extern __shared__ int lds_hist[];
   const int64_t row = blockIdx.y;
-  for (int b = threadIdx.x; b < bins; b += kBlock) lds_hist[b] = 0;
+  for (int b = threadIdx.x; b <= bins; b += kBlock) lds_hist[b] = 0;  // (+ the trash slot)
   __syncthreads();
   const float lo = first[row], hi = last[row];
   const float width = hi - lo;
@@ -293,16 +293,37 @@ __global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restr
   const int64_t per = (cols + gridDim.x - 1) / gridDim.x;
   const int64_t c0 = blockIdx.x * per, c1 = c0 + per < cols ? c0 + per : cols;
   const int64_t base = row * cols;
-  auto edge = [&](int k) { return k == bins ? hi : (float)k * step + lo; };
-  auto count = [&](float xv) {
-    const float v = __builtin_fabsf(xv);
-    if (!(v >= lo && v <= hi)) return;  // NaN (numpy raises on non-finite ranges; nothing is counted here)
-    int idx = (int)(((v - lo) / width) * fbins);
-    if (idx == bins) idx = bins - 1;
-    if (v < edge(idx)) --idx;
-    if (idx != bins - 1 && v >= edge(idx + 1)) ++idx;
-    atomicAdd(&lds_hist[idx], 1);
+  // numpy ESTIMATES the bin -- trunc(((v - first) / (last - first)) * bins) -- and then CORRECTS the estimate against the
+  // edges: one step down if v < e[idx], else one step up if v >= e[idx + 1] (last bin closed).  Whatever estimate lies
+  // within one bin of the edge-defined bin therefore ends in the same place, and numpy's own always does (its error is
+  // ~bins x 1e-7 of a bin).  So the estimate needs no IEEE division per element (10 of round 4's ~35 vector instructions
+  // per element in a kernel that ran at the vector issue rate): one multiply by bins / (last - first); the edges keep
+  // numpy's own two roundings (fp32(k * step) + first; -ffp-contract=off).  Elements outside [first, last] (NaN: numpy
+  // raises on non-finite ranges) go to a trash slot instead of around a branch.  Two elements per instruction where the
+  // ISA has a packed form.
+  const float scale = fbins / width;  // (width > 0: the host maps an all-zero row to [-0.5, 0.5])
+  const f32x2 lo2 = {lo, lo}, sc2 = {scale, scale}, st2 = {step, step};
+  const int last_bin = bins - 1;
+  auto count2 = [&](float xa, float xb) {
+    const f32x2 v = {__builtin_fabsf(xa), __builtin_fabsf(xb)};
+    const f32x2 q = (v - lo2) * sc2;
+    int ia = (int)q.x, ib = (int)q.y;
+    ia = ia < last_bin ? ia : last_bin;
+    ib = ib < last_bin ? ib : last_bin;
+    const f32x2 k0 = {(float)ia, (float)ib}, k1 = {(float)(ia + 1), (float)(ib + 1)};
+    const f32x2 e0 = k0 * st2 + lo2;
+    f32x2 e1 = k1 * st2 + lo2;
+    e1.x = ia == last_bin ? hi : e1.x;  // e[bins] = last, exactly
+    e1.y = ib == last_bin ? hi : e1.y;
+    // (bitwise, not short-circuit: no exec-mask branches)
+    ia += (int)((v.x >= e1.x) & (ia != last_bin)) - (int)(v.x < e0.x);
+    ib += (int)((v.y >= e1.y) & (ib != last_bin)) - (int)(v.y < e0.y);
+    ia = ((v.x >= lo) & (v.x <= hi)) ? ia : bins;
+    ib = ((v.y >= lo) & (v.y <= hi)) ? ib : bins;
+    atomicAdd(&lds_hist[ia], 1);
+    atomicAdd(&lds_hist[ib], 1);
   };
+  auto count = [&](float xv) { count2(xv, __builtin_nanf("")); };  // (tail elements: the partner lands in the trash slot)
   constexpr int V = Elem<DT>::kVec;
   const char* xb = reinterpret_cast<const char*>(x);
   if (((base + c0) % V) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(kBlock) void row_hist_np_kernel(const void* __restr
       float f[8];
       unpack<DT>(pk, f);
 #pragma unroll
-      for (int e = 0; e < V; ++e) count(f[e]);
+      for (int e = 0; e < V; e += 2) count2(f[e], f[e + 1]);
     }
     for (int64_t c = c0 + n_pk * V + threadIdx.x; c < c1; c += kBlock) count(load1<DT>(x, base + c));
   } else {
@@ -620,7 +641,7 @@ extern "C" int moq_row_hist_np(const void* x, int64_t rows, int64_t cols, int dt
     return MOQ_ERR_LAUNCH;
   }
   MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((row_hist_np_kernel<DT>), dim3((unsigned)splits, (unsigned)rows), dim3(kBlock),
-                                            (size_t)bins * 4, reinterpret_cast<hipStream_t>(stream), x, cols, bins,
+                                            (size_t)(bins + 1) * 4, reinterpret_cast<hipStream_t>(stream), x, cols, bins,
                                             first, last, counts));
   return check_launch("moq_row_hist_np");
 }

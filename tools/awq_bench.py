@@ -116,7 +116,7 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
                            "batches": len(my_batches), "first_batch_slowest_calls": slowest if my_batches else None})
 
     warm_s = rehearsal_s = alloc_probe_s = None
-    if warm and my_batches:
+    if warm and batches >= world:  # (every rank holds a batch: the rehearsal's collectives need all of them)
         torch.cuda.synchronize()
         tw = time.perf_counter()
         with torch.no_grad():
