@@ -2,7 +2,7 @@
 # (gpurun call 13 of round 5) HEAD: default bench line as the FIRST command of a fresh lease, whole GPU suite, smoke, the N = 2
 # control flow on one GPU (gloo debug mode, never a measurement), kernel breakdown of the HF-topology INT4-AWQ flow, kernel table
 set -u
-O=gpurun_out/r05c13; mkdir -p $O
+O=gpurun_out/${1:-r05c13}; mkdir -p $O
 ROOT=$(pwd); export TMPDIR=/tmp
 ( time python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench.err ) 2> $O/bench_time.txt
 echo "bench rc=$? $(grep real $O/bench_time.txt)"
@@ -31,4 +31,9 @@ cd $ROOT
 tail -1 $O/flow_awq_hf.json | cut -c1-300
 python3 tools/kstats_all_md.py $O/prof_awq_hf 16 > $O/awq_hf_kernels.md; head -22 $O/awq_hf_kernels.md | cut -c1-200
 python3 tools/kbench.py 2>&1 | grep -v Warning > $O/kernel_table.md; wc -l $O/kernel_table.md
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*agent_info*" -delete
+cd /tmp
+rocprofv3 --kernel-trace --stats -f csv -d $ROOT/$O/prof_small -o small -- python3 $ROOT/tools/kbench.py "67 MB,columns,col_abs,awq_weight_scale,row_hist,scale_cols_multi" > $ROOT/$O/prof_small.log 2>&1
+cd $ROOT
+python3 tools/kstats_md.py $O/prof_small | tee $O/small_kernels_kernel_only.md | grep "row_hist\|scale_cols_multi\|col_stats\|awq_wscale\|finalize\|accum"
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*agent_info*" -delete
