@@ -17,7 +17,6 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .ops import _reduce_layout
 
 
 class _Calibrator:
@@ -206,9 +205,14 @@ class MaxCalibrator(_Calibrator):
             if n == 1:
                 shape = ()  # a single tile: reduce_amax squeezes scalars (core_utils.py:181-182)
         else:
-            _, kept, _, keep = _reduce_layout(list(x.shape), reduce_axis)
+            # (kept axes that lie apart -- axis=(0, 2) of a rank-3 tensor -- are served by ops.reduce_amax through one
+            # permuted copy; the buffer is the kept axes' product either way)
+            red = {a % nd for a in reduce_axis}
+            keep = [d for d in range(nd) if d not in red]
             shape = tuple(x.shape[d] if d in keep else 1 for d in range(nd))
-            n = kept
+            n = 1
+            for d in keep:
+                n *= x.shape[d]
             if n == 1:
                 shape = ()
         if self._buf is None:

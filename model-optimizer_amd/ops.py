@@ -256,6 +256,24 @@ def _amax_mode(inputs: torch.Tensor, amax: torch.Tensor):
     return _lib.AMAX_AXIS, inputs.shape[axis], inner
 
 
+def _gather_kept_axes(inputs: torch.Tensor, amax: torch.Tensor):
+    """An amax that keeps SEVERAL axes which are not a leading prefix of the input (TensorQuantizer(axis=(0, 2)) on a rank-3
+    tensor: amax [A, 1, C]): the reference's CUDA kernel refuses these and its eager path broadcasts (tensor_quant.py:83-91,
+    :386-389, :607-645).  Here: (input permuted so that the kept axes lead, as a contiguous copy; the amax permuted alike
+    = a leading-prefix amax the per-axis kernel takes; the inverse permutation for the result) -- or None when the amax is
+    of a shape the kernels take as it is.  Two copies, a cold path found by tools/quantizer_fuzz.py."""
+    if amax.dim() != inputs.dim() or amax.numel() == 1:
+        return None
+    keep = [d for d in range(amax.dim()) if amax.shape[d] != 1]
+    if len(keep) < 2 or keep == list(range(len(keep))):
+        return None
+    if any(amax.shape[d] != inputs.shape[d] for d in keep):
+        raise MoquantError(f"amax shape {tuple(amax.shape)} does not broadcast over the input {tuple(inputs.shape)}")
+    order = keep + [d for d in range(inputs.dim()) if d not in keep]
+    inverse = [order.index(d) for d in range(inputs.dim())]
+    return inputs.permute(order).contiguous(), amax.permute(order).contiguous(), inverse
+
+
 @torch.no_grad()
 def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 8, unsigned: bool = False,
                       narrow_range: bool = True, inplace: bool = False,
@@ -263,6 +281,10 @@ def fake_tensor_quant(inputs: torch.Tensor, amax: torch.Tensor, num_bits: int = 
     """INT-k quantize-dequantize -- tensor_quant.py:607-645 / tensor_quant_gpu.cu:43-140."""
     _require_gpu(inputs, "fake_tensor_quant")
     am = _f32(amax, inputs.device)
+    apart = None if inplace else _gather_kept_axes(inputs, am)
+    if apart is not None:
+        y = fake_tensor_quant(apart[0], apart[1], num_bits, unsigned, narrow_range, False, check_inputs)
+        return y.permute(apart[2]).contiguous()
     if not inplace and am.numel() == 1 and not inputs.is_contiguous() and _is_dense(inputs) and not check_inputs:
         # per-tensor amax on a permuted dense tensor: elementwise over its memory, output keeps the strides
         y = torch.empty_like(inputs)
@@ -304,6 +326,10 @@ def scaled_e4m3(inputs: torch.Tensor, amax: torch.Tensor | None) -> torch.Tensor
             check(_lib.lib().moq_fake_quant_e4m3(_p(xa), _p(ya), xa.numel(), _dt(xa), _p(am), _lib.AMAX_SCALAR, 1, 1,
                                                  stream))
         return y
+    if amax is not None:
+        apart = _gather_kept_axes(inputs, _f32(amax, inputs.device))
+        if apart is not None:
+            return scaled_e4m3(apart[0], apart[1]).permute(apart[2]).contiguous()
     x = inputs.contiguous()
     y = torch.empty_like(x)
     with _on(x) as stream:

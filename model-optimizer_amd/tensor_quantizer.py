@@ -582,7 +582,11 @@ class TensorQuantizer(nn.Module):
                 raise ValueError("block size for dynamic quantization not found.")
             amax = None if self.is_mx_format else self._get_amax(inputs)
             nb = self._num_bits if not isinstance(self._num_bits, list) else tuple(self._num_bits)
-            return ops.dynamic_block_quant(inputs, g, amax, nb, tuple(self._block_sizes.get("scale_bits", (8, 0))))
+            sb = self._block_sizes.get("scale_bits", None)
+            # dynamic blocks need their scale format spelled out; the reference's forward asserts exactly this
+            # (tensor_quant.py:482) -- found by tools/quantizer_fuzz.py: a missing scale_bits used to mean E8M0 here
+            assert isinstance(sb, (tuple, list)) and len(sb) == 2
+            return ops.dynamic_block_quant(inputs, g, amax, nb, tuple(sb))
         if isinstance(self._num_bits, tuple):
             if tuple(self._num_bits) != (4, 3):
                 raise MoquantUnsupported(f"float format {self._num_bits} without dynamic blocks")

@@ -737,6 +737,35 @@ def test_block_grids_on_any_axes_equal_the_reference_live(monkeypatch, dtype):
         assert torch.equal(y, ry) and torch.equal(d, rd), what
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_quantization_axes_that_lie_apart_equal_the_reference_live(monkeypatch, dtype):
+    """TensorQuantizer(axis=(0, 2)) on a rank-3 tensor, axis=(1, 3) on rank 4, dynamic and calibrated, INT8 / INT4 / FP8: the kept
+    axes are not one adjacent block (found by tools/quantizer_fuzz.py on the device; the reference's eager path broadcasts such
+    an amax, tensor_quant.py:607-645).  Also the assertion both sides raise for dynamic blocks without scale_bits."""
+    ref_shim.install()
+    from modelopt.torch.quantization.config import QuantizerAttributeConfig as RefCfg
+    from modelopt.torch.quantization.nn import TensorQuantizer as RefQuantizer
+
+    hostmem_backend.install(monkeypatch, moa)
+    for nb, axis, shape in [(8, (0, 2), (3, 20, 16)), ((4, 3), (0, 2), (2, 7, 40)), (4, (1, 3), (2, 3, 5, 8)), (8, (0, -1), (4, 9, 24))]:
+        x = (torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))) * 0.4).to(dtype)
+        got = []
+        for Q, C in ((RefQuantizer, RefCfg), (moa.TensorQuantizer, moa.QuantizerAttributeConfig)):
+            q = Q(C(num_bits=nb, axis=axis))
+            q.disable_quant(); q.enable_calib()
+            q(x); q(x * 0.5)
+            q.load_calib_amax()
+            q.enable_quant(); q.disable_calib()
+            got.append((q(x), q._amax, Q(C(num_bits=nb, axis=axis))(x)))
+        (ry, ra, rd), (y, a, d) = got
+        what = f"{nb} axis {axis} {shape}"
+        assert a.shape == ra.shape and a.dtype == ra.dtype and torch.equal(a.float(), ra.float()), what
+        assert torch.equal(y, ry) and torch.equal(d, rd), what
+    for Q, C in ((RefQuantizer, RefCfg), (moa.TensorQuantizer, moa.QuantizerAttributeConfig)):
+        with pytest.raises(AssertionError):
+            Q(C(num_bits=8, block_sizes={-1: 16, "type": "dynamic"}))(torch.randn(4, 32))
+
+
 @pytest.mark.parametrize("preset,dtype,with_kv", [("INT4_AWQ_CFG", torch.bfloat16, False), ("FP8_DEFAULT_CFG", torch.float16, True),
                                                   ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False)])
 def test_scale_math_on_the_tensors_own_device_equals_the_reference_on_that_device_live(monkeypatch, preset, dtype, with_kv):

@@ -350,6 +350,25 @@ def test_int4_awq_at_llama_3_8b_width_picks_the_reference_alphas(ref, outliers):
     assert len(same_alpha) >= (14 if outliers else 11), gaps
 
 
+def test_random_quantizer_configurations_equal_the_references_quantizer_on_the_device(ref):
+    """tools/quantizer_fuzz.py: 200 seeded random TensorQuantizer configurations (INT4 / 6 / 8 and FP8; per tensor, per axis,
+    static last-axis blocks of 16-128 incl. ragged widths, dynamic blocks; signed / unsigned, narrow range; rank 2-3, three
+    dtypes, magnitudes 0.02-30, zeros and outliers planted): two calibration batches, then the fake-quantized output --
+    amax and output equal the REFERENCE's own TensorQuantizer on the same device bit for bit, and whatever the reference
+    refuses this package refuses too."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import quantizer_fuzz
+
+    st = quantizer_fuzz.main(200, 2025, verbose=False)
+    note(f"quantizer fuzz vs the reference on the device: {st['equal']} of {st['cases']} configurations bit-equal (amax + output), "
+         f"{st['both_refused']} refused by both, {st['reference_refused']} refused by the reference only, "
+         f"{len(st['ours_refused'])} by this package only, {len(st['different'])} different")
+    assert not st["different"], st["different"][:3]
+    assert not st["ours_refused"], st["ours_refused"][:3]
+    assert st["reference_refused"] == 0, st.get("reference_refusals")
+    assert st["equal"] >= 150
+
+
 # ------------------------------------------------------------------------------------------------------------- D
 def test_reference_sparsify_on_the_device_through_the_mask_seam(ref):
     import modelopt.torch.sparsity as mts
