@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-from . import _lib, ops
+from . import _lib, numerics, ops
 from ._lib import MoquantUnsupported
 
 
@@ -23,9 +23,13 @@ class BaseQuantizedTensor:
 
 
 def _div448(amax: torch.Tensor) -> torch.Tensor:
-    """amax / 448.0 as a TRUE division.  torch's GPU `tensor / python_float` multiplies by the reciprocal, which is one
-    ulp off the CPU result for some inputs; tensor / tensor divides on both devices."""
-    return amax / torch.full((), 448.0, dtype=amax.dtype, device=amax.device)
+    """amax / 448.0.  torch's GPU `tensor / python_float` multiplies by the reciprocal, which is one ulp off the CPU result
+    for some inputs (tensor / tensor divides on both devices).  numerics "host" (default): the TRUE division = the
+    reference's CPU run, whatever the device; "device": torch's own kernel on the tensor's device = the reference's run
+    there (numerics.py; tools/ops_fuzz.py compares that mode with the reference on the GPU)."""
+    if numerics.on_host() or not amax.is_cuda:
+        return amax / torch.full((), 448.0, dtype=amax.dtype, device=amax.device)
+    return amax / 448.0
 
 
 def _pad_last(x: torch.Tensor, block: int) -> torch.Tensor:

@@ -369,6 +369,25 @@ def test_random_quantizer_configurations_equal_the_references_quantizer_on_the_d
     assert st["equal"] >= 150
 
 
+def test_random_calls_of_the_paths_functions_equal_the_references_eager_functions_on_the_device(ref):
+    """tools/ops_fuzz.py, 100 seeded random calls per family: reduce_amax over any axis subset (keepdims on / off),
+    reduce_block_padding + reduce_block_amax on rank 2-4, fake_tensor_quant / scaled_e4m3 with scalar, per-axis, leading-prefix
+    and apart amax, create_asp_mask on rank 1-4 with planted ties, FP8QTensor (per tensor / axis / block) and MXFP4QTensor
+    quantize + dequantize -- against the reference's eager implementations on the same device tensors, bit for bit (scale
+    math in numerics mode "device": the reference runs on this GPU too)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ops_fuzz
+
+    out = ops_fuzz.main(100, 2025, verbose=False)
+    note("functions fuzz vs the reference's eager functions on the device: " +
+         ", ".join(f"{fam} {st['equal']}/{st['cases']}" for fam, st in out.items()))
+    for fam, st in out.items():
+        assert not st["different"], (fam, st["different"][:3])
+        assert not st["ours_refused"], (fam, st["ours_refused"][:3])
+        assert not st["reference_refused"], (fam, st["reference_refused"])
+        assert st["equal"] >= 90, (fam, st["equal"])
+
+
 # ------------------------------------------------------------------------------------------------------------- D
 def test_reference_sparsify_on_the_device_through_the_mask_seam(ref):
     import modelopt.torch.sparsity as mts
