@@ -16,7 +16,7 @@ import math
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib, numerics, ops
 
 
 class _Calibrator:
@@ -389,7 +389,14 @@ class HistogramCalibrator(_Calibrator):
         """Keep the bin width, extend the range to hold `x_max` (a 0-dim fp32 host tensor) -- calib/histogram.py:121-127."""
         width = self._calib_bin_edges[1] - self._calib_bin_edges[0]
         self._num_bins = int((x_max / width).ceil().item())
-        self._calib_bin_edges = torch.arange(0, x_max + width, width)
+        dev = self._calib_hist.device
+        if numerics.on_host() or dev.type != "cuda":
+            self._calib_bin_edges = torch.arange(0, x_max + width, width)
+        else:
+            # numerics "device": the reference grows its edges with `torch.arange(..., device=x.device)`, and torch's GPU arange
+            # accumulates in fp32 where the CPU one uses double -- edges past the first range differ in the last bit between
+            # the reference's two runs (found by tools/calib_fuzz.py); this is its run on the device
+            self._calib_bin_edges = torch.arange(0, x_max + width, width, device=dev).cpu()
         grown = torch.zeros(self._num_bins, dtype=torch.int64, device=self._calib_hist.device)
         grown[: self._calib_hist.numel()] = self._calib_hist
         self._calib_hist = grown
