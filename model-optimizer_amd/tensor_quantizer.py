@@ -736,7 +736,10 @@ class SequentialQuantizer(nn.Sequential):
         try:
             return super().__getattr__(name)
         except AttributeError:
-            if len(self) and not name.startswith("__"):
+            # public properties come from the first member (the reference delegates `fake_quant`, `is_enabled`, `amax`,
+            # :1740-1769; this package's own callers also read `num_bits`, `block_sizes`, ...).  PRIVATE state is not
+            # delegated: `hasattr(chain, "_amax")` is False as in the reference (found by tools/flow_fuzz.py)
+            if len(self) and not name.startswith("_"):
                 return getattr(self[0], name)  # first member wins
             raise
 
@@ -786,6 +789,6 @@ class GroupedQuantizer(nn.ModuleList):
         try:
             return super().__getattr__(name)
         except AttributeError:
-            if len(self) and not name.startswith("__"):
+            if len(self) and not name.startswith("_"):  # (public properties only, as for SequentialQuantizer)
                 return getattr(self[0], name)
             raise

@@ -21,7 +21,24 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import _moa_import  # noqa: E402
 import ref_shim  # noqa: E402
 
-DEV = "cuda"
+DEV = os.environ.get("MOQ_FUZZ_DEVICE", "cuda")  # "cpu": the host logic through tests/hostmem_backend.py (oracle-served C-ABI)
+
+
+def load_package():
+    """The package; on MOQ_FUZZ_DEVICE=cpu with its C-ABI served by the oracle (the CPU tier's stand-in), so that the same
+    random cases run in the build container against the reference's CPU path."""
+    moa = _moa_import.load()
+    if DEV == "cpu":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostmem_backend
+
+        class _Setter:
+            @staticmethod
+            def setattr(obj, name, value):
+                setattr(obj, name, value)
+
+        hostmem_backend.install(_Setter, moa)
+    return moa
 DT = {"bfloat16": torch.bfloat16, "float16": torch.float16, "float32": torch.float32}
 
 
@@ -54,7 +71,7 @@ def hist_run(Cal, case):
 
 
 def main(n=20, seed=2025, verbose=True):
-    moa = _moa_import.load()
+    moa = load_package()
     ref_shim.install()
     from modelopt.torch.quantization.calib import HistogramCalibrator as RefHist
 
