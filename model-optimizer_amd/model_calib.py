@@ -588,7 +588,7 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
         if iq.axis != -1:
             warnings.warn(f"Only per-channel smoothing is supported, skip {name}")
             continue
-        act_amax = iq.amax.float().reshape(-1)
+        act_amax = iq._amax.float().reshape(-1)  # the buffer: `amax` reads None on MX inputs (formats="all")
         dealt.append(m)
         if shard and (len(dealt) - 1) % world != me:
             # another rank smooths this linear; the state every rank sets without touching the weight

@@ -220,7 +220,16 @@ class TensorQuantizer(nn.Module):
     # (`_amax`, `_bias_value`, `_pre_quant_scale`: the names the reference's state_dicts use) and are reached through ONE
     # descriptor, _BufferState below: first assignment registers the buffer, later ones copy into it.  Names, error texts
     # and the None rules are the reference's interface (nn/modules/tensor_quantizer.py:341-376, :472-520).
-    amax = _BufferState("amax", after=lambda q: q._preserve_amax_in_fp32() if getattr(q, "_is_static_block_scale_quantizer", False) else None)
+    # amax reads None on an MX-format quantizer even when a max calibration left an `_amax` buffer on it (:358-363: E8M0 block
+    # scales come from every input; the export writes no input_scale for such a quantizer)
+    def _amax_shown(q):
+        if q.is_mx_format or getattr(q, "_amax", None) is None:
+            return False
+        assert not q._dynamic, "Dynamic quantization does not have fixed amax"
+        return True
+
+    amax = _BufferState("amax", shown=_amax_shown,
+                        after=lambda q: q._preserve_amax_in_fp32() if getattr(q, "_is_static_block_scale_quantizer", False) else None)
     bias_value = _BufferState("bias_value", label="bias")
     pre_quant_scale = _BufferState("pre_quant_scale", same_shape=False, shown=lambda q: q._enable_pre_quant_scale)
 

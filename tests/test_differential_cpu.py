@@ -76,9 +76,10 @@ def _batches():
     return [torch.randint(0, CFG["vocab_size"], (3, 24), generator=torch.Generator().manual_seed(40 + i)) for i in range(3)]
 
 
-def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
+def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True):
     """`device`: None = host tensors (this tier); "cuda" = the same run with the model and the batches on the GPU
-    (tests/test_gpu_reference_live.py: the reference's eager path with device tensors, staged or checked out)."""
+    (tests/test_gpu_reference_live.py: the reference's eager path with device tensors, staged or checked out).
+    `edit`: a callable applied to the preset's copy before the KV-cache entries are merged (per-layer overrides)."""
     ref_shim.install()
     import modelopt.torch.quantization as mtq
     from modelopt.torch.export import export_hf_checkpoint
@@ -90,6 +91,8 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
     cfg = copy.deepcopy(getattr(mtq, preset))
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
+    if edit is not None:
+        edit(cfg)
     if with_kv:  # True: FP8 key / value quantizers; "affine": the same with a per-head per-channel offset
         kv = mtq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mtq.FP8_KV_CFG
         if with_kv == "cast":  # configs/ptq/units/kv_fp8_cast.yaml (hf_ptq.py's default KV format): amax fixed at 448
@@ -105,7 +108,7 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
         with torch.no_grad():
             logits = q(batches[0]).logits.cpu().clone()
     out = {"__logits__": logits}
-    if arch == "llama-ragged":  # the reference's INT4 packer indexes past its scale tensor for a padded last block
+    if arch == "llama-ragged" or not export:  # the reference's INT4 packer indexes past its scale tensor for a padded last block
         return amax, out
     with tempfile.TemporaryDirectory() as d:
         export_hf_checkpoint(q, export_dir=d)
@@ -121,7 +124,7 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
     return amax, out
 
 
-def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
+def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True):
     mq = moa.model_quant
     model = _model(dtype, arch)
     if device is not None:
@@ -129,6 +132,8 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
     cfg = copy.deepcopy(getattr(mq, preset))
     if algorithm is not None:
         cfg["algorithm"] = copy.deepcopy(algorithm)
+    if edit is not None:
+        edit(cfg)
     if with_kv:
         kv = {"affine": mq.FP8_AFFINE_KV_CFG, "cast": mq.FP8_CAST_KV_CFG}.get(with_kv, mq.FP8_KV_CFG)
         cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, kv["quant_cfg"])
@@ -139,7 +144,7 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None):
             if isinstance(m, moa.TensorQuantizer) and m.is_enabled and getattr(m, "_amax", None) is not None}
     with torch.no_grad():
         logits = model(batches[0]).logits.cpu().clone()
-    if arch == "llama-ragged":
+    if arch == "llama-ragged" or not export:
         return amax, {"__logits__": logits}
     state = moa.export.export_state_dict(model, dtype, lambda: model(torch.ones([1, 2], dtype=torch.long, device=device)))
     state["__logits__"] = logits
@@ -208,6 +213,9 @@ def _assert_same_quant_json(ours, ref, what=""):
     # cast-style KV cache (use_constant_amax: the reference example's default KV format)
     ("FP8_DEFAULT_CFG", torch.bfloat16, "cast", "llama", None), ("INT4_AWQ_CFG", torch.bfloat16, "cast", "qwen2", None),
     ("FP8_DEFAULT_CFG", torch.float32, "cast", "mixtral", None),
+    # MX inputs under a KV-cache config: the max calibration leaves `_amax` buffers on the E8M0 input quantizers, whose `amax`
+    # still reads None (tensor_quantizer.py:358-363), so no `input_scale` is written (found by tools/hf_flow_fuzz.py)
+    ("MXFP4_DEFAULT_CFG", torch.float16, "cast", "llama", None), ("MXFP4_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)

@@ -1,0 +1,143 @@
+"""Seeded random Hugging Face model shapes x architectures x presets x KV-cache variants through BOTH quantize() + checkpoint
+export paths -- the reference's `mtq.quantize` + `export_hf_checkpoint` and this package's -- with the comparison of
+tests/test_differential_cpu.py (every amax, the fake-quantized logits, every checkpoint tensor byte for byte, both JSON tables).
+Build container only (the reference's CPU path against the CPU tier's stand-in).
+
+    python tools/hf_flow_fuzz.py [cases] [seed]"""
+import json
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+os.environ.setdefault("MOQ_FUZZ_DEVICE", "cpu")
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from quantizer_fuzz import load_package  # noqa: E402
+
+ARCHS = ["llama", "llama", "llama-eager", "qwen2", "mistral", "opt", "gpt2", "phi3", "gemma2", "mixtral", "qwen3_moe"]
+PRESETS = ["FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG", "INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG",
+           "INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG", "MXFP4_DEFAULT_CFG", "MXFP8_DEFAULT_CFG", "FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG",
+           "FP8_PER_CHANNEL_PER_TOKEN_CFG", "W4A8_MXFP4_FP8_CFG", "MXFP4_MLP_WEIGHT_ONLY_CFG"]
+
+
+# per-layer overrides appended after the preset's own entries (the last matching entry wins in both libraries): layers left
+# unquantized (-> exclude_modules), a second format on part of the model (-> the per-layer table of a mixed-precision export)
+OVERRIDES = [
+    [("*layers.0.*", {"enable": False})],
+    [("*o_proj*", {"enable": False}), ("*down_proj*", {"enable": False})],
+    [("*mlp*weight_quantizer", {"num_bits": 8, "axis": 0}), ("*mlp*input_quantizer", {"num_bits": 8, "axis": None})],
+    [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "axis": None}), ("*self_attn*input_quantizer", {"num_bits": (4, 3), "axis": None})],
+    [("*mlp*weight_quantizer", {"num_bits": 4, "block_sizes": {-1: 32}}), ("*mlp*input_quantizer", {"enable": False})],
+    [("*input_quantizer", {"enable": False})],
+]
+ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}], "INT8_DEFAULT_CFG": [None, None, {"method": "mse"}],
+              "INT8_SMOOTHQUANT_CFG": [None, {"method": "smoothquant", "alpha": 0.5}, {"method": "smoothquant", "alpha": 0.8}],
+              "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}]}
+
+
+def override(extra):
+    def edit(cfg):
+        qc = cfg["quant_cfg"]
+        for pat, val in extra:
+            if isinstance(qc, dict):
+                qc[pat] = dict(val)
+            else:
+                qc.append({"quantizer_name": pat, "enable": False} if val == {"enable": False} else {"quantizer_name": pat, "cfg": dict(val)})
+    return edit
+
+
+def draw(rng):
+    heads = rng.choice([2, 4])
+    hidden = heads * rng.choice([32, 64])
+    return {"arch": rng.choice(ARCHS), "preset": rng.choice(PRESETS), "dtype": rng.choice(["bfloat16", "float16", "float32"]),
+            "with_kv": rng.choice([False, False, True, "affine", "cast"]),
+            "override": rng.choice([None, None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3]),
+            "cfg": dict(hidden_size=hidden, intermediate_size=rng.choice([128, 256, 384]), num_hidden_layers=rng.choice([1, 2]),
+                        num_attention_heads=heads, num_key_value_heads=rng.choice([1, heads] if heads == 2 else [1, 2, 4]),
+                        vocab_size=96, max_position_embeddings=64)}
+
+
+def main(n=40, seed=2025, verbose=True):
+    moa = load_package()
+    import test_differential_cpu as diff
+
+    rng = random.Random(seed)
+    st = {"cases": 0, "equal": 0, "both_refused": 0, "reference_refused": {}, "ours_refused": [], "different": []}
+    base_cfg = dict(diff.CFG)
+    for _ in range(n):
+        case = draw(rng)
+        st["cases"] += 1
+        diff.CFG.clear()
+        diff.CFG.update(case["cfg"])
+        dt = getattr(torch, case["dtype"])
+        algos = ALGORITHMS.get(case["preset"], [None])
+        case["algorithm"] = algos[case["algorithm"] % len(algos)]
+        edit = override(OVERRIDES[case["override"]]) if case["override"] is not None else None
+        try:
+            want = diff._reference_run(case["preset"], dt, case["with_kv"], case["arch"], case["algorithm"], edit=edit)
+        except Exception as e:
+            want = e
+        try:
+            got = diff._our_run(case["preset"], dt, case["with_kv"], case["arch"], case["algorithm"], edit=edit)
+        except Exception as e:
+            got = e
+        if isinstance(want, Exception):
+            if isinstance(got, Exception):
+                st["both_refused"] += 1
+            else:
+                why = f"{case['preset']} {case['arch']}: {type(want).__name__}: {str(want)[:80]}"
+                st["reference_refused"][why] = st["reference_refused"].get(why, 0) + 1
+            continue
+        if isinstance(got, Exception):
+            st["ours_refused"].append({"case": case, "error": f"{type(got).__name__}: {got}"[:260]})
+            continue
+        (ra, rs), (oa, os_) = want, got
+        bad = [f"amax {k}" for k, a in ra.items() if k not in oa or not torch.equal(oa[k].reshape(-1), a.reshape(-1))]
+        rj, oj = rs.pop("__quant_json__", None), os_.pop("__quant_json__", None)
+        rl, ol = rs.pop("__logits__"), os_.pop("__logits__")
+        if rl is not None and not torch.equal(ol, rl):
+            bad.append("logits")
+        searched = "AWQ" in case["preset"]  # near-tie alphas may fall the other way on random-init models: counted apart
+        if sorted(rs) != sorted(os_):
+            bad.append("checkpoint keys " + str(sorted(set(rs) ^ set(os_))[:4]))
+        else:
+            bad += [f"tensor {k}" for k, w in rs.items()
+                    if not (os_[k].dtype == w.dtype and tuple(os_[k].shape) == tuple(w.shape)
+                            and torch.equal(os_[k].detach().cpu().contiguous().reshape(-1).view(torch.uint8), w.contiguous().reshape(-1).view(torch.uint8)))]
+        if rj is not None and oj is not None and rj[0] is not None and json.dumps(rj, sort_keys=True, default=str) != json.dumps(oj, sort_keys=True, default=str):
+            try:
+                diff._assert_same_quant_json(oj, rj, "fuzz")
+            except AssertionError:
+                bad.append("quant json")
+        if not bad:
+            st["equal"] += 1
+        elif searched:
+            # how far apart.  An fp32 model's act scale is a MEAN OVER TOKENS in fp32: torch's summation order (which differs
+            # between its own CPU and GPU kernels) against this package's defined one gives scales 1-2 ulp apart (DESIGN.md
+            # section 5); anything larger is a searched alpha that fell the other way on a near-tie
+            def rel(a, b):
+                a, b = a.reshape(-1).float(), b.reshape(-1).float()
+                return float(((a - b).abs() / a.abs().clamp_min(1e-30)).max()) if a.numel() == b.numel() and a.numel() else 0.0
+            far = max([rel(a, oa[k]) for k, a in ra.items() if k in oa]
+                      + [rel(w, os_[k].detach().cpu()) for k, w in rs.items() if k in os_ and w.is_floating_point() and w.dim() <= 2
+                         and not k.endswith(".weight")] + [0.0])
+            kind = "fp32_summation_order" if case["dtype"] == "float32" and far <= 1e-6 else "awq_differences"
+            st.setdefault(kind, []).append({"case": case, "first": bad[:3], "n_bad": len(bad), "max_rel_scale_diff": far})
+        else:
+            st["different"].append({"case": case, "first": bad[:4], "n_bad": len(bad)})
+    diff.CFG.clear()
+    diff.CFG.update(base_cfg)
+    if verbose:
+        print("hf flows", json.dumps({k: (v if not isinstance(v, list) else len(v)) for k, v in st.items()})[:700])
+        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_differences", [])[:6] + st.get("fp32_summation_order", [])[:3]:
+            print("   ", json.dumps(d, default=str)[:600])
+    return {"hf_flows": st}
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2025)
