@@ -427,6 +427,15 @@ def rename_to_checkpoint_keys(state: dict, model) -> dict:
     return out
 
 
+def _with_pre_quant_scale(out: dict, iq) -> dict:
+    """unified_export_hf.py:1121-1138: a smoothing scale left on the input quantizer is promoted to <module>.pre_quant_scale,
+    whatever the linear's format (an AWQ search over a model with per-layer format overrides smooths those layers too)."""
+    pqs = getattr(iq, "_pre_quant_scale", None)
+    if pqs is not None:
+        out["pre_quant_scale"] = pqs.detach().clone()
+    return out
+
+
 @torch.no_grad()
 def export_quantized_weight(module, dtype: torch.dtype):
     """unified_export_hf.py:569-810 for one quantized linear: returns the tensors the checkpoint stores for it
@@ -458,7 +467,7 @@ def export_quantized_weight(module, dtype: torch.dtype):
 
         w = module.weight.detach().to(dtype)
         e8m0 = MXFP8QTensor.get_weights_scaling_factor_from_quantizer(w, wq)
-        return {"weight": MXFP8QTensor.quantize_with_scale(w, e8m0), "weight_scale": e8m0}
+        return _with_pre_quant_scale({"weight": MXFP8QTensor.quantize_with_scale(w, e8m0), "weight_scale": e8m0}, iq)
     if fmt == QUANTIZATION_FP8_PB_WO:
         # export/quant_utils.py:874-877: FP8QTensor.quantize(weight, scale.squeeze(), block_sizes on both axes); the
         # scale keeps the quantizer's amax shape [R/br, 1, C/bc, 1]
@@ -468,7 +477,7 @@ def export_quantized_weight(module, dtype: torch.dtype):
         weight_scale = get_weight_scaling_factor(module)
         w = module.weight.detach().to(dtype)
         qt, _ = FP8QTensor.quantize(w, weight_scale.squeeze(), block_sizes=blocks)
-        return {"weight": qt._quantized_data, "weight_scale": weight_scale}
+        return _with_pre_quant_scale({"weight": qt._quantized_data, "weight_scale": weight_scale}, iq)
     if fmt == QUANTIZATION_FP8:
         amax = wq._amax.to(torch.float32)
         # unified_export_hf.py:635-643 decides by the amax buffer's RANK, not its size: a [1] buffer takes python float

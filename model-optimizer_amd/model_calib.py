@@ -347,12 +347,17 @@ def _mse_calibrate_weights(model: nn.Module, step_size: float, start_multiplier:
 
     from .calib import MseCalibrator
 
+    # every QuantModule's (weight, quantizer) pairs (quant_module.py:123-129): the linears, and a fused MoE expert container's
+    # slice per expert and projection (huggingface.py:1084-1100)
+    pairs = []
     for m in model.modules():
-        if not is_quantized_linear(m):
-            continue
-        wq = m.weight_quantizer
-        if (not wq.is_enabled or wq._dynamic or wq._block_dynamic or wq._calibrator is None
-                or getattr(wq, "_amax", None) is None):
+        if is_quantized_linear(m):
+            pairs.append((m.weight, m.weight_quantizer))
+        elif is_quant_fused_experts(m):
+            pairs += list(m.iter_weights_for_calibration())
+    for weight, wq in pairs:
+        if (not isinstance(wq, TensorQuantizer) or not wq.is_enabled or wq._dynamic or wq._block_dynamic
+                or wq._calibrator is None or getattr(wq, "_amax", None) is None):
             continue  # _make_weight_mse_calibrator's eligibility test (model_calib.py:681-689)
         nb = wq._num_bits
         fused = (nb, wq._unsigned, wq._narrow_range) if isinstance(nb, int) or tuple(nb) == (4, 3) else None
@@ -364,7 +369,7 @@ def _mse_calibrate_weights(model: nn.Module, step_size: float, start_multiplier:
         wq._calibrator = cal
         wq.disable_quant()
         wq.enable_calib()
-        wq(m.weight)
+        wq(weight)
         wq.load_calib_amax(strict=False)
         wq.enable_quant()
         wq.disable_calib()
@@ -682,11 +687,56 @@ class _WeightCacheBudget:
         self.left += nbytes
 
 
+def _awq_searched(m) -> bool:
+    """awq_lite's own rule (model_calib.py:1563-1567): EVERY quantized linear whose weight quantizer is enabled -- whatever
+    its format: a per-layer override that puts FP8 or INT8 on part of an INT4-AWQ model is smoothed and searched too."""
+    return is_quantized_linear(m) and m.weight_quantizer.is_enabled
+
+
+def _awq_fused_format(wq, weight) -> bool:
+    """INT-k static blocks along the last axis only: the format the fused search kernels (scale + per-group QDQ, weight scale,
+    Gram scores) are written for.  Everything else takes the GENERIC route: the same search with the scaled weight passed
+    through the quantizer itself (dynamic amax of its own layout) and the error-GEMM engine."""
+    if not (isinstance(wq, TensorQuantizer) and wq.is_static_block_quant and isinstance(wq._num_bits, int)):
+        return False
+    axes = {(k % weight.dim()) for k in wq._block_sizes if isinstance(k, int)}
+    return axes == {weight.dim() - 1}
+
+
+def _awq_block_size(wq, weight):
+    """_get_awq_quantizer_block_size (model_calib.py:1943-1952): None without block sizes (whole rows)."""
+    if wq.block_sizes is None:
+        return None
+    if -1 in wq.block_sizes:
+        return wq.block_sizes[-1]
+    if 1 in wq.block_sizes:
+        return wq.block_sizes[1]
+    raise ValueError("AWQ requires block quantization along -1 axis")
+
+
+def _awq_weight_scale_generic(weight: torch.Tensor, block) -> torch.Tensor:
+    """get_weight_scale (model_calib.py:1453-1469) for the layouts moq_awq_weight_scale does not take (whole rows, blocks that
+    are no power-of-two number of packets): every |w| over the abs-max of its block (+ tiny) in the weight dtype, the mean over
+    the output rows (torch: fp32 accumulation, one rounding to the dtype), widened to fp32."""
+    rows, cin = weight.shape
+    w = weight.detach()
+    if block and cin % block:
+        w = F.pad(w, (0, block - cin % block), "constant", 0)
+    groups = w.contiguous().view(-1, block) if block else w.contiguous()
+    top = ops.reduce_amax(groups, axis=1, keepdims=True).to(w.dtype)
+    share = (groups.abs() / (top + torch.finfo(w.dtype).tiny)).view(rows, -1)[:, :cin]
+    return share.mean(0).to(torch.float32)
+
+
 class AWQLiteHelper:
     """Per-linear state of awq_lite (model_calib.py:1416-1451)."""
 
     def __init__(self, module: QuantLinear, alpha_step: float):
         wq = module.weight_quantizer
+        self.fused = _awq_fused_format(wq, module.weight)
+        if not self.fused:
+            self._init_generic(module, alpha_step)
+            return
         self.block_size = wq.block_sizes.get(-1, None) or wq.block_sizes.get(module.weight.dim() - 1)
         # Cin that is not a block multiple: the reference zero-pads the last block (get_weight_scale, :1453-1469; the
         # static block quantizer, tensor_quantizer.py:975-1043).  The kernels take whole blocks, so such a linear works on
@@ -696,6 +746,17 @@ class AWQLiteHelper:
         self.dtype = module.weight.dtype  # 1 / s is rounded to it where the forward uses it (prepare_scales)
         self.pad = (-self.cin) % self.block_size
         self.weight_scale = ops.awq_weight_scale(self._padded(module.weight), self.block_size)[:self.cin].contiguous()
+        self._init_state(module, alpha_step)
+
+    def _init_generic(self, module, alpha_step):
+        self.block_size = _awq_block_size(module.weight_quantizer, module.weight)
+        self.cin = module.weight.shape[1]
+        self.dtype = module.weight.dtype
+        self.pad = 0
+        self.weight_scale = _awq_weight_scale_generic(module.weight, self.block_size)
+        self._init_state(module, alpha_step)
+
+    def _init_state(self, module, alpha_step):
         self.act_sum = torch.zeros(module.weight.shape[1], dtype=torch.float32, device=module.weight.device)
         self.act_scale = None
         self.num_cache_steps = 0
@@ -784,7 +845,13 @@ class AWQLiteHelper:
         w_hat = self._w_hat
         if w_hat is None:
             w_hat = torch.empty(len(self._scale_dt), *module.weight.shape, dtype=dt, device=module.weight.device)
-            if self.pad:  # whole blocks for the kernel (zero weight columns, unit scales), the padding cut off again
+            if not self.fused:
+                # the scaled weight through the quantizer itself, which holds no amax during the search and takes that of
+                # its input in its own layout (per tensor, per channel, 2-D blocks, ...): the weight quantizer with
+                # pre_quant_scale = s of the patched forward (:1548-1554)
+                for i, s in enumerate(self._scale_dt):
+                    w_hat[i].copy_(module.weight_quantizer(ops.scale_cols(module.weight.detach(), s.float())))
+            elif self.pad:  # whole blocks for the kernel (zero weight columns, unit scales), the padding cut off again
                 w_pad = self._padded(module.weight)
                 for i, s in enumerate(self._scale_dt):
                     y = ops.awq_scale_qdq(w_pad, self._padded(s, 1.0), self.block_size, module.weight_quantizer.num_bits)
@@ -930,11 +997,12 @@ def _layer_local_plan(model: nn.Module, explicit: bool = False):
         return None
     if not explicit and not (_is_supported_hf_model(model) and type(layers[0]).__name__.endswith("DecoderLayer")):
         return None
-    mods = [m for m in model.modules()
-            if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    mods = [m for m in model.modules() if _awq_searched(m)]
     inside = {id(m) for lyr in layers for m in lyr.modules()}
     if not mods or any(id(m) not in inside for m in mods):
         return None
+    if not all(_awq_fused_format(m.weight_quantizer, m.weight) for m in mods):
+        return None  # a linear in another format (generic route of the search): the whole-model flow
     searched = {id(q) for m in mods for q in (m.weight_quantizer, m.input_quantizer)}
     if any(q.is_enabled and id(q) not in searched for q in _quantizers(model)):
         return None
@@ -1009,8 +1077,11 @@ def _awq_lite_layer_local(model: nn.Module, forward_loop, layers, **kw):
 def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: str = "auto",
              tie_margin: float | None = None, tie_check: bool = True, layer_local: bool | None = None,
              store_activations: bool | str = "auto"):
-    """AWQ-lite (model_calib.py:1394-1721) for INT-k static-block weight quantizers with disabled inputs
-    (the INT4_AWQ_CFG preset).
+    """AWQ-lite (model_calib.py:1394-1721) over every quantized linear whose weight quantizer is enabled (:1563-1567).
+    INT-k static blocks along the last axis (INT4_AWQ_CFG, the first stage of W4A8_AWQ_BETA_CFG) take the fused kernels and
+    the engines below; a linear in any other format (a per-layer override: per-tensor FP8, per-channel INT8, 2-D blocks, ...)
+    takes the GENERIC route -- weight scale over its own blocks or whole rows, every candidate's scaled weight through the
+    quantizer itself with the amax of its own layout, scored by the error-GEMM engine (AWQLiteHelper.fused).
 
     search = "gemm": the reference's structure -- two passes of forward_loop (cache: act scales; search: for every
              alpha the patched forward's GEMM, here one batched MFMA error-GEMM launch per linear and batch);
@@ -1071,8 +1142,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             stats["stages_s"][name] = round(stats["stages_s"].get(name, 0.0) + now - clock["t"], 4)
         clock["t"] = now
 
-    mods = [(n, m) for n, m in model.named_modules()
-            if is_quantized_linear(m) and m.weight_quantizer.is_enabled and m.weight_quantizer.is_static_block_quant]
+    mods = [(n, m) for n, m in model.named_modules() if _awq_searched(m)]
     # the stages cover the WHOLE call (setup = helpers, weight scales, Gram buffers; teardown = the bookkeeping after the
     # fold), so that  sum(stages_s) == wall-clock of awq_lite  by construction
     clock["dev"] = mods[0][1].weight.device if mods else None
@@ -1103,7 +1173,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
             h = helpers[m]
             cin = m.weight.shape[1]
             # ragged rows (Cin not a multiple of the block: zero-padded, AWQLiteHelper) stay on the error-GEMM engine
-            gram_ok = cin % 4 == 0 and cin % h.block_size == 0
+            gram_ok = h.fused and cin % 4 == 0 and cin % h.block_size == 0
             fits = search != "gemm" and gram_ok and budget.reserve(4 * cin * cin)
             if fits or (search == "gram" and gram_ok):
                 h.gram = torch.zeros(cin, cin, dtype=torch.float32, device=m.weight.device)

@@ -216,6 +216,9 @@ def _assert_same_quant_json(ours, ref, what=""):
     # MX inputs under a KV-cache config: the max calibration leaves `_amax` buffers on the E8M0 input quantizers, whose `amax`
     # still reads None (tensor_quantizer.py:358-363), so no `input_scale` is written (found by tools/hf_flow_fuzz.py)
     ("MXFP4_DEFAULT_CFG", torch.float16, "cast", "llama", None), ("MXFP4_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None),
+    # the MSE weight search reaches the per-expert quantizers of fused expert containers too (iter_weights_for_calibration,
+    # quant_module.py:123-129 / huggingface.py:1084-1100; found by tools/hf_flow_fuzz.py)
+    ("FP8_DEFAULT_CFG", torch.bfloat16, False, "qwen3_moe", {"method": "mse"}), ("INT8_DEFAULT_CFG", torch.float32, False, "mixtral", {"method": "mse"}),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -233,6 +236,56 @@ def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype
         return  # the reference's exporter leaves FalconLinear weights unpacked; calibration and fake quant are compared
     if arch == "llama-ragged":
         return  # calibration (alpha search on padded blocks), amax and the fake-quantized forward are compared
+    assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
+    if ref_json is not None and ref_json[0] is not None:
+        _assert_same_quant_json(our_json, ref_json, f"{preset} {arch}")
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{preset} {k}: {got.dtype} {tuple(got.shape)} vs {want.dtype} {tuple(want.shape)}"
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
+
+
+def _override(extra):
+    """Per-layer entries appended after a preset's own (the last matching entry wins in both libraries)."""
+    def edit(cfg):
+        qc = cfg["quant_cfg"]
+        for pattern, value in extra:
+            if isinstance(qc, dict):
+                qc[pattern] = dict(value)
+            elif value == {"enable": False}:
+                qc.append({"quantizer_name": pattern, "enable": False})
+            else:
+                qc.append({"quantizer_name": pattern, "cfg": dict(value)})
+    return edit
+
+
+_FP8_ATTENTION = [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "axis": None}), ("*self_attn*input_quantizer", {"num_bits": (4, 3), "axis": None})]
+_INT8_MLP = [("*mlp*weight_quantizer", {"num_bits": 8, "axis": 0}), ("*mlp*input_quantizer", {"num_bits": 8, "axis": None})]
+_FP8_2D_ATTENTION = [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "block_sizes": {-1: 64, -2: 64}}), ("*self_attn*input_quantizer", {"enable": False})]
+_NO_FIRST_LAYER = [("*layers.0.*", {"enable": False})]
+
+
+@pytest.mark.parametrize("preset,dtype,with_kv,arch,extra", [
+    # a second format on part of an AWQ model: awq_lite smooths and searches EVERY linear whose weight quantizer is enabled
+    # (model_calib.py:1563-1567), per-tensor FP8 / per-channel INT8 / 2-D FP8 blocks included -- the scaled weight goes through
+    # the quantizer itself with the amax of its own layout, weight scale over whole rows (found by tools/hf_flow_fuzz.py:
+    # this package searched the INT-k block linears only and max-calibrated the rest)
+    ("W4A8_AWQ_BETA_CFG", torch.float16, True, "llama-eager", _FP8_ATTENTION), ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", _INT8_MLP),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", _FP8_2D_ATTENTION), ("INT4_AWQ_CFG", torch.float16, "cast", "mistral", _FP8_ATTENTION),
+    # layers left out (exclude_modules of the checkpoint's tables), a second format under max calibration (the per-layer table)
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", _NO_FIRST_LAYER), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "qwen2", _INT8_MLP),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", _FP8_ATTENTION),
+])
+def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, extra):
+    ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, None, edit=_override(extra))
+    hostmem_backend.install(monkeypatch, moa)
+    our_amax, our_state = _our_run(preset, dtype, with_kv, arch, None, edit=_override(extra))
+    for n, a in ref_amax.items():
+        assert n in our_amax, f"{preset}: quantizer {n} has no amax here"
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"{preset}: amax of {n} differs"
+    ref_json, our_json = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
+    assert torch.equal(our_logits, ref_logits), f"{preset}: logits of the fake-quantized model differ"
     assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
     if ref_json is not None and ref_json[0] is not None:
         _assert_same_quant_json(our_json, ref_json, f"{preset} {arch}")

@@ -271,6 +271,50 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
 
 
+def test_a_second_format_on_part_of_the_model_on_the_device_equals_the_reference(ref):
+    """Per-layer overrides under max calibration (FP8 preset, INT8 per-channel MLP): both sides on cuda:0, byte for byte -- the
+    per-layer table of the mixed-precision checkpoint included."""
+    edit = diff._override(diff._INT8_MLP)
+    ref_amax, ref_state = diff._reference_run("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", None, device=DEV, edit=edit)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", None, device=DEV, edit=edit)
+    assert sorted(ref_amax) == sorted(n for n in our_amax if n in ref_amax)
+    for n, a in ref_amax.items():
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"amax of {n} differs"
+    ref_json, our_json = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert torch.equal(our_state.pop("__logits__"), ref_state.pop("__logits__"))
+    assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
+    diff._assert_same_quant_json(our_json, ref_json, "FP8 + INT8 MLP")
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), k
+    note(f"FP8 preset with INT8 per-channel MLP linears, both on the device: {len(ref_amax)} amax, logits, {len(ref_state)} "
+         "checkpoint tensors byte-identical")
+
+
+def test_awq_over_a_model_with_a_second_format_on_the_device_against_the_reference(ref):
+    """INT4-AWQ with per-tensor FP8 attention linears: awq_lite smooths and searches those too (the generic route: scaled
+    weight through the quantizer itself, error-GEMM engine).  Same stated tolerance as the plain INT4-AWQ test: the
+    candidates are scored by GEMMs that sum in different orders, so near-ties of a random-init model may swap."""
+    edit = diff._override(diff._FP8_ATTENTION)
+    ref_amax, ref_state = diff._reference_run("INT4_AWQ_CFG", torch.bfloat16, False, "llama", None, device=DEV, edit=edit)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run("INT4_AWQ_CFG", torch.bfloat16, False, "llama", None, device=DEV, edit=edit)
+    ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
+    ref_json, our_json = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert sorted(our_state) == sorted(ref_state), set(our_state) ^ set(ref_state)
+    diff._assert_same_quant_json(our_json, ref_json, "INT4-AWQ + FP8 attention")
+    pqs = [k for k in ref_state if k.endswith("pre_quant_scale")]
+    attn = [k for k in pqs if "self_attn" in k]
+    assert attn, "the FP8 attention linears carry no smoothing scale in the reference's checkpoint?"
+    same = [k for k in pqs if torch.equal(our_state[k].cpu(), ref_state[k])]
+    note(f"INT4-AWQ + FP8 attention on the device vs the reference: {len(same)} / {len(pqs)} pre_quant_scale vectors identical "
+         f"({sum(k in same for k in attn)} / {len(attn)} of the FP8 linears')")
+    assert len(same) >= 0.75 * len(pqs), f"only {len(same)} of {len(pqs)} scale vectors equal the reference's"
+    span = (ref_logits.float().max() - ref_logits.float().min()).item()
+    assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
+
+
 def _wide_llama(outliers: bool):
     """Two decoder layers of Llama-3-8B's width (hidden 4096, MLP 14336, 32 / 8 heads), random init, small vocabulary.
     outliers: a few embedding channels and norm gains are scaled up, so activations carry massive channels like a trained
