@@ -716,7 +716,7 @@ class TensorQuantizer(nn.Module):
 
     def extra_repr(self):
         return (f"{self._num_bits} bit fake axis={self._axis} block_sizes={self._block_sizes} "
-                f"amax={'448(const)' if self._use_constant_amax else 'dynamic' if self.amax is None else tuple(self.amax.shape)} "
+                f"amax={'None' if self.is_mx_format else '448(const)' if self._use_constant_amax else 'dynamic' if getattr(self, '_amax', None) is None else tuple(self._amax.shape)} "
                 f"calibrator={type(self._calibrator).__name__}{f' bias={self._bias}' if self._bias else ''} "
                 f"quant={'on' if self._if_quant else 'off'}"
                 f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")

@@ -310,7 +310,11 @@ def test_awq_over_a_model_with_a_second_format_on_the_device_against_the_referen
     same = [k for k in pqs if torch.equal(our_state[k].cpu(), ref_state[k])]
     note(f"INT4-AWQ + FP8 attention on the device vs the reference: {len(same)} / {len(pqs)} pre_quant_scale vectors identical "
          f"({sum(k in same for k in attn)} / {len(attn)} of the FP8 linears')")
-    assert len(same) >= 0.75 * len(pqs), f"only {len(same)} of {len(pqs)} scale vectors equal the reference's"
+    # the INT4 linears under the plain INT4-AWQ test's bound; the FP8 linears' candidates differ by FP8's small rounding error
+    # only, far inside the two GEMMs' summation-order noise on a random-init model: their count is reported, not bounded (on
+    # the CPU tier, where both sides sum alike, every one of them equals the reference: tests/test_differential_cpu.py)
+    int4 = [k for k in pqs if k not in attn]
+    assert sum(k in same for k in int4) >= 0.9 * len(int4), f"only {sum(k in same for k in int4)} of {len(int4)} INT4 scale vectors equal"
     span = (ref_logits.float().max() - ref_logits.float().min()).item()
     assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
 

@@ -37,7 +37,9 @@ OVERRIDES = [
 ]
 ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}], "INT8_DEFAULT_CFG": [None, None, {"method": "mse"}],
               "INT8_SMOOTHQUANT_CFG": [None, {"method": "smoothquant", "alpha": 0.5}, {"method": "smoothquant", "alpha": 0.8}],
-              "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}]}
+              "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}, {"method": "awq_clip"}, "max"],
+              "W4A8_AWQ_BETA_CFG": [None, None, None, "max"], "INT8_WEIGHT_ONLY_CFG": [None, {"method": "mse"}],
+              "FP8_PER_CHANNEL_PER_TOKEN_CFG": [None, {"method": "mse"}], "INT4_BLOCKWISE_WEIGHT_ONLY_CFG": [None, {"method": "mse"}]}
 
 
 def override(extra):
@@ -56,7 +58,8 @@ def draw(rng):
     hidden = heads * rng.choice([32, 64])
     return {"arch": rng.choice(ARCHS), "preset": rng.choice(PRESETS), "dtype": rng.choice(["bfloat16", "float16", "float32"]),
             "with_kv": rng.choice([False, False, True, "affine", "cast"]),
-            "override": rng.choice([None, None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3]),
+            "override": rng.choice([None, None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3, 4]),
+            "batches": [rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 3]), rng.choice([8, 17, 24, 40])],  # count, rows, tokens
             "cfg": dict(hidden_size=hidden, intermediate_size=rng.choice([128, 256, 384]), num_hidden_layers=rng.choice([1, 2]),
                         num_attention_heads=heads, num_key_value_heads=rng.choice([1, heads] if heads == 2 else [1, 2, 4]),
                         vocab_size=96, max_position_embeddings=64)}
@@ -68,13 +71,16 @@ def main(n=40, seed=2025, verbose=True):
 
     rng = random.Random(seed)
     st = {"cases": 0, "equal": 0, "both_refused": 0, "reference_refused": {}, "ours_refused": [], "different": []}
-    base_cfg = dict(diff.CFG)
+    base_cfg, base_batches = dict(diff.CFG), diff._batches
     for _ in range(n):
         case = draw(rng)
         st["cases"] += 1
         diff.CFG.clear()
         diff.CFG.update(case["cfg"])
         dt = getattr(torch, case["dtype"])
+        n_b, rows, toks = case["batches"]
+        diff._batches = lambda n_b=n_b, rows=rows, toks=toks: [
+            torch.randint(0, 96, (rows, toks), generator=torch.Generator().manual_seed(40 + i)) for i in range(n_b)]
         algos = ALGORITHMS.get(case["preset"], [None])
         case["algorithm"] = algos[case["algorithm"] % len(algos)]
         edit = override(OVERRIDES[case["override"]]) if case["override"] is not None else None
@@ -89,6 +95,8 @@ def main(n=40, seed=2025, verbose=True):
         if isinstance(want, Exception):
             if isinstance(got, Exception):
                 st["both_refused"] += 1
+                pair = f"{type(want).__name__}: {str(want)[:60]} | {type(got).__name__}: {str(got)[:60]}"
+                st.setdefault("both_refused_how", {})[pair] = st.setdefault("both_refused_how", {}).get(pair, 0) + 1
             else:
                 why = f"{case['preset']} {case['arch']}: {type(want).__name__}: {str(want)[:80]}"
                 st["reference_refused"][why] = st["reference_refused"].get(why, 0) + 1
@@ -126,15 +134,24 @@ def main(n=40, seed=2025, verbose=True):
             far = max([rel(a, oa[k]) for k, a in ra.items() if k in oa]
                       + [rel(w, os_[k].detach().cpu()) for k, w in rs.items() if k in os_ and w.is_floating_point() and w.dim() <= 2
                          and not k.endswith(".weight")] + [0.0])
-            kind = "fp32_summation_order" if case["dtype"] == "float32" and far <= 1e-6 else "awq_differences"
-            st.setdefault(kind, []).append({"case": case, "first": bad[:3], "n_bad": len(bad), "max_rel_scale_diff": far})
+            # awq_clip scores every block's clip candidates with GEMMs that sum in another order than the reference's: on
+            # random-init models a few blocks per linear fall to the neighbouring candidate (DESIGN.md section 5 states the
+            # bound the tests assert); filed apart when under 2 % of the block amax entries differ and nothing else does
+            n_el = sum(a.numel() for a in ra.values())
+            n_off = sum(int((oa[k].reshape(-1) != a.reshape(-1)).sum()) for k, a in ra.items() if k in oa and oa[k].numel() == a.numel())
+            clip = isinstance(case["algorithm"], dict) and case["algorithm"].get("method") in ("awq_clip", "awq_full")
+            kind = ("fp32_summation_order" if case["dtype"] == "float32" and far <= 1e-6
+                    else "awq_clip_near_ties" if clip and 0 < n_off <= 0.02 * n_el else "awq_differences")
+            st.setdefault(kind, []).append({"case": case, "first": bad[:3], "n_bad": len(bad), "max_rel_scale_diff": far,
+                                            "amax_entries_off": f"{n_off} / {n_el}"})
         else:
             st["different"].append({"case": case, "first": bad[:4], "n_bad": len(bad)})
     diff.CFG.clear()
     diff.CFG.update(base_cfg)
+    diff._batches = base_batches
     if verbose:
-        print("hf flows", json.dumps({k: (v if not isinstance(v, list) else len(v)) for k, v in st.items()})[:700])
-        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_differences", [])[:6] + st.get("fp32_summation_order", [])[:3]:
+        print("hf flows", json.dumps({k: (v if not isinstance(v, list) else len(v)) for k, v in st.items()})[:2500])
+        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_differences", [])[:6] + st.get("awq_clip_near_ties", [])[:2] + st.get("fp32_summation_order", [])[:2]:
             print("   ", json.dumps(d, default=str)[:600])
     return {"hf_flows": st}
 
