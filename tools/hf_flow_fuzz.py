@@ -34,6 +34,12 @@ OVERRIDES = [
     [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "axis": None}), ("*self_attn*input_quantizer", {"num_bits": (4, 3), "axis": None})],
     [("*mlp*weight_quantizer", {"num_bits": 4, "block_sizes": {-1: 32}}), ("*mlp*input_quantizer", {"enable": False})],
     [("*input_quantizer", {"enable": False})],
+    [("*lm_head*weight_quantizer", {"num_bits": 8, "axis": 0})],  # the head quantized too (the presets leave it out)
+    [("*weight_quantizer", {"num_bits": 8, "axis": None})],  # per-tensor INT8 weights everywhere (lm_head stays off: no match before it)
+    [("*input_quantizer", {"num_bits": 8, "axis": None, "type": "dynamic"})],  # dynamic per-tensor inputs: nothing to calibrate
+    [("*[qk]_proj*weight_quantizer", {"num_bits": 8, "axis": 0})],  # q / k in another format than v: the exporter's q/k/v checks
+    [("*o_proj*output_quantizer", {"num_bits": (4, 3), "axis": None}), ("*down_proj*output_quantizer", {"num_bits": 8, "axis": None})],
+    [("*layers.1.*", {"enable": False}), ("*mlp*weight_quantizer", {"num_bits": (4, 3), "axis": None})],
 ]
 ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}], "INT8_DEFAULT_CFG": [None, None, {"method": "mse"}],
               "INT8_SMOOTHQUANT_CFG": [None, {"method": "smoothquant", "alpha": 0.5}, {"method": "smoothquant", "alpha": 0.8}],
@@ -58,7 +64,7 @@ def draw(rng):
     hidden = heads * rng.choice([32, 64])
     return {"arch": rng.choice(ARCHS), "preset": rng.choice(PRESETS), "dtype": rng.choice(["bfloat16", "float16", "float32"]),
             "with_kv": rng.choice([False, False, True, "affine", "cast"]),
-            "override": rng.choice([None, None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3, 4]),
+            "override": rng.choice([None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3, 4]),
             "batches": [rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 3]), rng.choice([8, 17, 24, 40])],  # count, rows, tokens
             "cfg": dict(hidden_size=hidden, intermediate_size=rng.choice([128, 256, 384]), num_hidden_layers=rng.choice([1, 2]),
                         num_attention_heads=heads, num_key_value_heads=rng.choice([1, heads] if heads == 2 else [1, 2, 4]),
