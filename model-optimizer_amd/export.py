@@ -601,18 +601,19 @@ _KV_CACHE_REPLACEMENTS = {"k_bmm_quantizer._amax": "k_proj.k_scale", "v_bmm_quan
 
 
 def get_kv_cache_format(model) -> str | None:
-    """get_kv_cache_dtype / _compute_kv_cache_dtype (export/quant_utils.py:408-461) over the attentions of the model: "FP8"
-    when an enabled k / v bmm quantizer is E4M3, "INT8" for 8 bits, "NVFP4" / "NVFP4_AFFINE" for E2M1 (with offsets),
-    None when there are none; every attention must agree (unified_export_hf.py:1679-1690).  What the checkpoint writer
-    packs is FP8 (incl. the affine and cast-style presets): an INT8 KV cache stops it with the reference's assertion,
-    NVFP4 is outside this path."""
+    """get_kv_cache_dtype / _compute_kv_cache_dtype (export/quant_utils.py:408-461) over the modules of the model, the way
+    get_quant_config walks them (:1675-1690): a module counts when its k / v bmm quantizer OR ITS OUTPUT QUANTIZER is enabled
+    (the output quantizers of k_proj / v_proj were the KV-cache quantizers of the Megatron export path, and the rule still
+    reads any module's); "FP8" when one of them is E4M3, "INT8" for 8 bits, "NVFP4" / "NVFP4_AFFINE" for E2M1 (all with
+    offsets), None otherwise; every counted module must agree.  What the checkpoint writer packs is FP8 (incl. the affine and
+    cast-style presets): an INT8 KV cache stops it with the reference's assertion, NVFP4 is outside this path."""
     fmt = None
     for m in model.modules():
-        kq, vq = getattr(m, "k_bmm_quantizer", None), getattr(m, "v_bmm_quantizer", None)
-        if kq is None or vq is None or not (kq.is_enabled or vq.is_enabled):
+        live = [q for q in (getattr(m, name, None) for name in ("k_bmm_quantizer", "v_bmm_quantizer", "output_quantizer"))
+                if q is not None and q.is_enabled]
+        if not live:
             continue
-        live = [q for q in (kq, vq) if q.is_enabled]
-        bits = [tuple(q._num_bits) if isinstance(q._num_bits, (tuple, list)) else q._num_bits for q in live]
+        bits = [tuple(q.num_bits) if isinstance(q.num_bits, (tuple, list)) else q.num_bits for q in live]
         if (4, 3) in bits:
             this = KV_CACHE_FP8
         elif 8 in bits:
@@ -620,9 +621,11 @@ def get_kv_cache_format(model) -> str | None:
         elif (2, 1) in bits:
             this = "NVFP4_AFFINE" if all(hasattr(q, "_bias_value") for q in live) else "NVFP4"
         else:
-            continue
-        assert fmt in (None, this), "Do not support mixed precision kv cache quantization"
-        fmt = this
+            this = None
+        if fmt is None:
+            fmt = this
+        else:
+            assert fmt == this, "Do not support mixed precision kv cache quantization"
     return fmt
 
 

@@ -625,6 +625,8 @@ def int8_pack_rows(weight: torch.Tensor, weights_scaling_factor: torch.Tensor) -
     w = weight.detach().contiguous()
     rows, cols = w.shape
     wsf = _f32(weights_scaling_factor, w.device).reshape(-1)
+    if wsf.numel() == 1 and rows != 1:
+        wsf = wsf.expand(rows).contiguous()  # a per-tensor amax: `wsf[:, None]` of a [1] factor broadcasts over the rows
     if wsf.numel() != rows:
         raise MoquantError("int8_pack_rows: one scaling factor per output channel expected")
     vec = 4 if w.dtype == torch.float32 else 8

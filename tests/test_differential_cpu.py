@@ -251,6 +251,7 @@ def _override(extra):
         qc = cfg["quant_cfg"]
         for pattern, value in extra:
             if isinstance(qc, dict):
+                qc.pop(pattern, None)  # (re-inserted at the END: a later entry wins, like the appended entry of the list form)
                 qc[pattern] = dict(value)
             elif value == {"enable": False}:
                 qc.append({"quantizer_name": pattern, "enable": False})
@@ -263,6 +264,11 @@ _FP8_ATTENTION = [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "axis": N
 _INT8_MLP = [("*mlp*weight_quantizer", {"num_bits": 8, "axis": 0}), ("*mlp*input_quantizer", {"num_bits": 8, "axis": None})]
 _FP8_2D_ATTENTION = [("*self_attn*weight_quantizer", {"num_bits": (4, 3), "block_sizes": {-1: 64, -2: 64}}), ("*self_attn*input_quantizer", {"enable": False})]
 _NO_FIRST_LAYER = [("*layers.0.*", {"enable": False})]
+_INT8_PER_TENSOR_WEIGHTS = [("*layers.*weight_quantizer", {"num_bits": 8, "axis": None})]
+_QUANTIZED_HEAD = [("*lm_head*weight_quantizer", {"num_bits": 8, "axis": 0})]
+_DYNAMIC_INPUTS = [("*input_quantizer", {"num_bits": 8, "axis": None, "type": "dynamic"})]  # (re-enables the head's input quantizer too)
+_FP8_OUTPUT = [("*o_proj*output_quantizer", {"num_bits": (4, 3), "axis": None})]
+_MIXED_OUTPUTS = _FP8_OUTPUT + [("*down_proj*output_quantizer", {"num_bits": 8, "axis": None})]
 
 
 @pytest.mark.parametrize("preset,dtype,with_kv,arch,extra", [
@@ -275,6 +281,11 @@ _NO_FIRST_LAYER = [("*layers.0.*", {"enable": False})]
     # layers left out (exclude_modules of the checkpoint's tables), a second format under max calibration (the per-layer table)
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", _NO_FIRST_LAYER), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "qwen2", _INT8_MLP),
     ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", _FP8_ATTENTION),
+    # per-tensor INT8 weights (`wsf[:, None]` of a one-element factor broadcasts over the rows, export/quant_utils.py:868-869), a
+    # quantized head, dynamic per-tensor inputs, and an enabled OUTPUT quantizer -- which the exporter's KV-cache rule counts
+    # (get_kv_cache_dtype reads any module's output quantizer, :426-435: `kv_cache_quant_algo` "FP8" without a KV quantizer)
+    ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", _INT8_PER_TENSOR_WEIGHTS), ("FP8_DEFAULT_CFG", torch.float16, True, "qwen2", _QUANTIZED_HEAD),
+    ("FP8_DEFAULT_CFG", torch.float16, True, "mistral", _DYNAMIC_INPUTS), ("FP8_DEFAULT_CFG", torch.bfloat16, False, "mistral", _FP8_OUTPUT),
 ])
 def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, extra):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, None, edit=_override(extra))
@@ -293,6 +304,17 @@ def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, p
         got = our_state[k].detach().cpu()
         assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{preset} {k}: {got.dtype} {tuple(got.shape)} vs {want.dtype} {tuple(want.shape)}"
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
+
+
+@pytest.mark.parametrize("with_kv", [False, True])
+def test_output_quantizers_of_two_formats_stop_the_export_like_the_reference_live(monkeypatch, with_kv):
+    """unified_export_hf's table (quant_utils.py:1675-1690): every module with an enabled k / v bmm OR output quantizer must
+    name the same KV-cache format."""
+    with pytest.raises(AssertionError, match="mixed precision kv cache"):
+        _reference_run("FP8_DEFAULT_CFG", torch.bfloat16, with_kv, "mistral", None, edit=_override(_MIXED_OUTPUTS))
+    hostmem_backend.install(monkeypatch, moa)
+    with pytest.raises(AssertionError, match="mixed precision kv cache"):
+        _our_run("FP8_DEFAULT_CFG", torch.bfloat16, with_kv, "mistral", None, edit=_override(_MIXED_OUTPUTS))
 
 
 @pytest.mark.parametrize("preset,dtype", [("FP8_DEFAULT_CFG", torch.bfloat16), ("INT8_DEFAULT_CFG", torch.float32),

@@ -35,7 +35,9 @@ OVERRIDES = [
     [("*mlp*weight_quantizer", {"num_bits": 4, "block_sizes": {-1: 32}}), ("*mlp*input_quantizer", {"enable": False})],
     [("*input_quantizer", {"enable": False})],
     [("*lm_head*weight_quantizer", {"num_bits": 8, "axis": 0})],  # the head quantized too (the presets leave it out)
-    [("*weight_quantizer", {"num_bits": 8, "axis": None})],  # per-tensor INT8 weights everywhere (lm_head stays off: no match before it)
+    # per-tensor INT8 weights in every decoder layer.  (Not "*weight_quantizer": appended after the defaults it would also switch
+    # on the weight quantizer of the reference's QuantEmbedding, a module this path does not wrap -- DESIGN.md section 8)
+    [("*layers.*weight_quantizer", {"num_bits": 8, "axis": None}), ("*.h.*weight_quantizer", {"num_bits": 8, "axis": None})],
     [("*input_quantizer", {"num_bits": 8, "axis": None, "type": "dynamic"})],  # dynamic per-tensor inputs: nothing to calibrate
     [("*[qk]_proj*weight_quantizer", {"num_bits": 8, "axis": 0})],  # q / k in another format than v: the exporter's q/k/v checks
     [("*o_proj*output_quantizer", {"num_bits": (4, 3), "axis": None}), ("*down_proj*output_quantizer", {"num_bits": 8, "axis": None})],
@@ -53,6 +55,7 @@ def override(extra):
         qc = cfg["quant_cfg"]
         for pat, val in extra:
             if isinstance(qc, dict):
+                qc.pop(pat, None)  # (re-inserted at the END: a later entry wins, like the appended entry of the list form)
                 qc[pat] = dict(val)
             else:
                 qc.append({"quantizer_name": pat, "enable": False} if val == {"enable": False} else {"quantizer_name": pat, "cfg": dict(val)})
