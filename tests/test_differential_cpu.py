@@ -97,6 +97,8 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
         kv = mtq.FP8_AFFINE_KV_CFG if with_kv == "affine" else mtq.FP8_KV_CFG
         if with_kv == "cast":  # configs/ptq/units/kv_fp8_cast.yaml (hf_ptq.py's default KV format): amax fixed at 448
             kv = {"quant_cfg": [{"quantizer_name": "*[kv]_bmm_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "use_constant_amax": True}}]}
+        if with_kv == "int8":  # an INT8 KV cache: calibrated like any other, named "INT8" in the tables (quant_utils.py:453-456)
+            kv = {"quant_cfg": [{"quantizer_name": "*[kv]_bmm_quantizer", "cfg": {"num_bits": 8, "axis": None}}]}
         cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(kv["quant_cfg"]))
     batches = [b.to(device) if device is not None else b for b in _batches()]
     loop = (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None
@@ -135,7 +137,8 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, 
     if edit is not None:
         edit(cfg)
     if with_kv:
-        kv = {"affine": mq.FP8_AFFINE_KV_CFG, "cast": mq.FP8_CAST_KV_CFG}.get(with_kv, mq.FP8_KV_CFG)
+        kv = {"affine": mq.FP8_AFFINE_KV_CFG, "cast": mq.FP8_CAST_KV_CFG,
+              "int8": {"quant_cfg": {"*[kv]_bmm_quantizer": {"num_bits": 8, "axis": None, "enable": True}}}}.get(with_kv, mq.FP8_KV_CFG)
         cfg = mq.update_quant_cfg_with_kv_cache_quant(cfg, kv["quant_cfg"])
     batches = [b.to(device) if device is not None else b for b in _batches()]
     with torch.no_grad():

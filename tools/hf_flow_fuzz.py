@@ -43,9 +43,12 @@ OVERRIDES = [
     [("*o_proj*output_quantizer", {"num_bits": (4, 3), "axis": None}), ("*down_proj*output_quantizer", {"num_bits": 8, "axis": None})],
     [("*layers.1.*", {"enable": False}), ("*mlp*weight_quantizer", {"num_bits": (4, 3), "axis": None})],
 ]
-ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}], "INT8_DEFAULT_CFG": [None, None, {"method": "mse"}],
-              "INT8_SMOOTHQUANT_CFG": [None, {"method": "smoothquant", "alpha": 0.5}, {"method": "smoothquant", "alpha": 0.8}],
-              "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}, {"method": "awq_clip"}, "max"],
+ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}, {"method": "mse", "step_size": 0.25, "start_multiplier": 0.5, "stop_multiplier": 2.0}],
+              "INT8_DEFAULT_CFG": [None, None, {"method": "mse"}, {"method": "mse", "step_size": 0.05, "stop_multiplier": 1.0}, {"method": "max", "distributed_sync": False}],
+              "INT8_SMOOTHQUANT_CFG": [None, {"method": "smoothquant", "alpha": 0.5}, {"method": "smoothquant", "alpha": 0.8}, {"method": "smoothquant", "alpha": 1.0}, {"method": "smoothquant", "alpha": 0.0}],
+              "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}, {"method": "awq_clip"}, "max",
+                               {"method": "awq_lite", "alpha_step": 0.5}, {"method": "awq_clip", "min_clip_ratio": 0.7, "shrink_step": 0.1},
+                               {"method": "awq_full", "alpha_step": 0.2}],
               "W4A8_AWQ_BETA_CFG": [None, None, None, "max"], "INT8_WEIGHT_ONLY_CFG": [None, {"method": "mse"}],
               "FP8_PER_CHANNEL_PER_TOKEN_CFG": [None, {"method": "mse"}], "INT4_BLOCKWISE_WEIGHT_ONLY_CFG": [None, {"method": "mse"}]}
 
@@ -66,8 +69,8 @@ def draw(rng):
     heads = rng.choice([2, 4])
     hidden = heads * rng.choice([32, 64])
     return {"arch": rng.choice(ARCHS), "preset": rng.choice(PRESETS), "dtype": rng.choice(["bfloat16", "float16", "float32"]),
-            "with_kv": rng.choice([False, False, True, "affine", "cast"]),
-            "override": rng.choice([None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice([0, 1, 2, 3, 4]),
+            "with_kv": rng.choice([False, False, True, "affine", "cast", "int8"]),
+            "override": rng.choice([None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice(list(range(8))),
             "batches": [rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 3]), rng.choice([8, 17, 24, 40])],  # count, rows, tokens
             "cfg": dict(hidden_size=hidden, intermediate_size=rng.choice([128, 256, 384]), num_hidden_layers=rng.choice([1, 2]),
                         num_attention_heads=heads, num_key_value_heads=rng.choice([1, heads] if heads == 2 else [1, 2, 4]),
@@ -107,7 +110,7 @@ def main(n=40, seed=2025, verbose=True):
                 pair = f"{type(want).__name__}: {str(want)[:60]} | {type(got).__name__}: {str(got)[:60]}"
                 st.setdefault("both_refused_how", {})[pair] = st.setdefault("both_refused_how", {}).get(pair, 0) + 1
             else:
-                why = f"{case['preset']} {case['arch']}: {type(want).__name__}: {str(want)[:80]}"
+                why = f"{case['preset']} {case['arch']} override {case['override']} kv {case['with_kv']}: {type(want).__name__}: {str(want)[:80]}"
                 st["reference_refused"][why] = st["reference_refused"].get(why, 0) + 1
             continue
         if isinstance(got, Exception):

@@ -36,6 +36,40 @@ def load_package():
     return moa
 
 
+def draw_extra(rng: random.Random) -> dict:
+    """The corners beside draw()'s grid (opt-in: `extras`, so that the fixed-seed slice of the GPU suite keeps its cases):
+    top-level dynamic quantizers (per tensor / per token), offsets (`bias`: static or dynamic, mean or max-min, over the token
+    and batch axes of a [batch, heads, tokens, dim] tensor), a smoothing scale in front, constant amax, NaN in the input."""
+    kind = rng.choice(["dynamic", "dynamic", "bias", "bias", "pre_quant_scale", "constant", "nan"])
+    fmt = rng.choice(["int8", "fp8", "fp8", "int4"])
+    nb = {"int8": 8, "int4": 4, "fp8": (4, 3)}[fmt]
+    dtype = rng.choice(["bfloat16", "float16", "float32"])
+    cfg = {"num_bits": nb, "axis": None}
+    shape = [rng.randint(1, 40), rng.choice([8, 64, 128, 520])]
+    pqs = False
+    if kind == "dynamic":
+        cfg["type"] = "dynamic"
+        cfg["axis"] = rng.choice([None, None, 0, (0,)])  # axis 0 of [tokens, features]: one scale per token
+        if rng.random() < 0.4:
+            shape = [rng.randint(1, 3)] + shape
+            cfg["axis"] = rng.choice([None, (0, 1)])
+    elif kind == "bias":
+        shape = [rng.randint(1, 3), rng.choice([1, 2, 4]), rng.randint(1, 24), rng.choice([16, 32, 64])]
+        cfg["bias"] = {-2: None, -4: None, "type": rng.choice(["static", "dynamic"]), "method": rng.choice(["mean", "max_min"])}
+        if rng.random() < 0.3:
+            cfg["bias"] = {-2: None, "type": rng.choice(["static", "dynamic"])}
+    elif kind == "pre_quant_scale":
+        pqs = True
+        cfg["axis"] = rng.choice([None, -1])
+    elif kind == "constant":
+        if rng.random() < 0.5:
+            cfg.update(num_bits=(4, 3), use_constant_amax=True)
+        else:
+            cfg["constant_amax"] = rng.choice([0.5, 3.0, 448.0])
+    return {"fmt": fmt, "dtype": dtype, "shape": shape, "gran": "extra_" + kind, "cfg": cfg, "seed": rng.randint(0, 1 << 30),
+            "scale": rng.choice([0.02, 1.0, 30.0]), "specials": rng.random() < 0.2, "pqs": pqs, "nan": kind == "nan"}
+
+
 def draw(rng: random.Random) -> dict:
     """One configuration: format, granularity, tensor shape and dtype, two calibration batches."""
     fmt = rng.choice(["int8", "int4", "int8", "fp8", "fp8", "int6"])
@@ -84,6 +118,8 @@ def tensors(case):
         if case["specials"] and x.numel() > 8:
             flat = x.view(-1)
             flat[0], flat[1], flat[2] = 0.0, -0.0 if not case["cfg"].get("unsigned") else 0.0, flat.abs().max() * 4
+        if case.get("nan") and k == 1 and x.numel() > 3:
+            x.view(-1)[3] = float("nan")  # in the SECOND calibration batch and not in the quantized one
         out.append(x.to(DEV))
     return out
 
@@ -91,8 +127,14 @@ def tensors(case):
 def run_one(make_quantizer, case):
     q = make_quantizer(case["cfg"]).to(DEV)
     xs = tensors(case)
-    dynamic = case["gran"] == "block_dynamic"
-    if not dynamic:
+    if case.get("pqs"):
+        g = torch.Generator().manual_seed(case["seed"] + 7)
+        q.pre_quant_scale = (torch.rand(case["shape"][-1], generator=g) * 2 + 0.25).to(xs[0].dtype).to(DEV)
+    dynamic = case["gran"] == "block_dynamic" or case["cfg"].get("type") == "dynamic"
+    constant = case["cfg"].get("use_constant_amax") or case["cfg"].get("constant_amax") is not None
+    if constant:  # calibration leaves such a quantizer alone (model_calib.py:1132-1136); called directly it just quantizes
+        pass
+    elif not dynamic:
         q.disable_quant()
         q.enable_calib()
         for x in xs:
@@ -102,6 +144,8 @@ def run_one(make_quantizer, case):
         q.disable_calib()
     y = q(xs[0])
     amax = None if getattr(q, "_amax", None) is None else q._amax.detach().float().cpu()
+    if getattr(q, "_bias_value", None) is not None:  # the calibrated offset rides along with the amax
+        amax = torch.cat([amax.reshape(-1) if amax is not None else torch.zeros(0), q._bias_value.detach().float().cpu().reshape(-1)])
     return amax, y.detach().cpu()
 
 
@@ -114,7 +158,7 @@ def same_bits(a, b):
     return bool(((a.contiguous().view(iv) == b.contiguous().view(iv)) | (torch.isnan(a) & torch.isnan(b))).all())
 
 
-def main(n_cases=200, seed=2025, verbose=True):
+def main(n_cases=200, seed=2025, verbose=True, extras=False):
     moa = load_package()
     ref_shim.install()
     from modelopt.torch.quantization.config import QuantizerAttributeConfig as RefCfg
@@ -123,7 +167,7 @@ def main(n_cases=200, seed=2025, verbose=True):
     rng = random.Random(seed)
     stats = {"cases": 0, "equal": 0, "reference_refused": 0, "both_refused": 0, "ours_refused": [], "different": []}
     for i in range(n_cases):
-        case = draw(rng)
+        case = draw_extra(rng) if extras else draw(rng)
         try:
             want = run_one(lambda c: RefTQ(RefCfg(**c)), case)
         except Exception as e:  # the reference's own refusals (e.g. a block size that does not divide) are not cases
@@ -158,4 +202,5 @@ def main(n_cases=200, seed=2025, verbose=True):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 2025)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 2025,
+         extras=len(sys.argv) > 3 and sys.argv[3] == "extras")
