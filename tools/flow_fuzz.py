@@ -35,6 +35,10 @@ def draw(rng):
         alg = {"method": "smoothquant", "alpha": rng.choice([0.5, 0.8, 1.0])}
     if preset == "INT4_AWQ_CFG" and rng.random() < 0.3:
         alg = {"method": "awq_clip"}
+    if alg is None and "AWQ" not in preset and "SMOOTH" not in preset and rng.random() < 0.3:
+        # the AWQ-lite search over a preset in ANOTHER format: every linear takes the generic route of the search (per-tensor
+        # FP8 / per-channel INT8 / 2-D FP8 blocks / per-token inputs), INT4 blocks the fused one
+        alg = {"method": "awq_lite", "alpha_step": rng.choice([0.1, 0.25])}
     return {"preset": preset, "dims": dims, "bias": rng.random() < 0.5, "dtype": rng.choice(["float32", "bfloat16"]),
             "batches": rng.randint(1, 3), "tokens": rng.choice([8, 24, 64]), "seed": rng.randint(0, 1 << 30), "algorithm": alg,
             "outliers": rng.random() < 0.5}
@@ -71,9 +75,9 @@ def run(quantize, presets, quantizer_type, case, debug_awq=False):
     cfg = copy.deepcopy(getattr(presets, case["preset"]))
     if case["algorithm"] is not None:
         cfg["algorithm"] = copy.deepcopy(case["algorithm"])
-    if debug_awq and "AWQ" in case["preset"] and case["algorithm"] is None:
+    alg = cfg["algorithm"] if isinstance(cfg["algorithm"], dict) else {"method": cfg["algorithm"]}
+    if debug_awq and alg.get("method") in ("awq_lite", "awq_full"):
         # the reference drops its search tables unless asked to keep them (model_calib.py:1719-1721)
-        alg = cfg["algorithm"] if isinstance(cfg["algorithm"], dict) else {"method": cfg["algorithm"]}
         cfg["algorithm"] = {**alg, "debug": True}
     with torch.no_grad():
         q = quantize(model, cfg, lambda m: [m(b) for b in batches])
@@ -122,7 +126,7 @@ def main(n=60, seed=2025, verbose=True):
             continue
         (gs, ga), (ws, wa) = got, want
         keys_equal = sorted(gs) == sorted(ws)
-        searched = "AWQ" in case["preset"]
+        searched = "AWQ" in case["preset"] or (isinstance(case["algorithm"], dict) and str(case["algorithm"].get("method", "")).startswith("awq"))
         if searched and keys_equal:
             # AWQ: the search's DECISIONS must be the reference's (alphas bit-equal); the scale vectors behind them come from
             # a per-channel mean |x| that this library sums in its own defined order, torch in another -- stated tolerance:

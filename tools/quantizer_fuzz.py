@@ -140,6 +140,8 @@ def run_one(make_quantizer, case):
         for x in xs:
             q(x)
         q.load_calib_amax()
+        if (case["cfg"].get("bias") or {}).get("type") == "static":
+            q.load_calib_bias()  # (finish_stats_collection's order: model_calib.py:1155-1164)
         q.enable_quant()
         q.disable_calib()
     y = q(xs[0])
