@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from quantizer_fuzz import load_package  # noqa: E402
 
 ARCHS = ["llama", "llama", "llama-eager", "qwen2", "mistral", "opt", "gpt2", "phi3", "gemma2", "mixtral", "qwen3_moe"]
-PRESETS = ["FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG", "INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG",
+PRESETS = ["INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "INT8_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG", "INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG",
            "INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG", "MXFP4_DEFAULT_CFG", "MXFP8_DEFAULT_CFG", "FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG",
            "FP8_PER_CHANNEL_PER_TOKEN_CFG", "W4A8_MXFP4_FP8_CFG", "MXFP4_MLP_WEIGHT_ONLY_CFG"]
 
@@ -49,8 +49,8 @@ ALGORITHMS = {"FP8_DEFAULT_CFG": [None, None, "max", {"method": "mse"}, {"method
               "INT4_AWQ_CFG": [None, None, {"method": "awq_lite", "alpha_step": 0.25}, {"method": "awq_clip"}, "max",
                                {"method": "awq_lite", "alpha_step": 0.5}, {"method": "awq_clip", "min_clip_ratio": 0.7, "shrink_step": 0.1},
                                {"method": "awq_full", "alpha_step": 0.2}],
-              "W4A8_AWQ_BETA_CFG": [None, None, None, "max"], "INT8_WEIGHT_ONLY_CFG": [None, {"method": "mse"}],
-              "FP8_PER_CHANNEL_PER_TOKEN_CFG": [None, {"method": "mse"}], "INT4_BLOCKWISE_WEIGHT_ONLY_CFG": [None, {"method": "mse"}]}
+              "W4A8_AWQ_BETA_CFG": [None, None, None, "max"], "INT8_WEIGHT_ONLY_CFG": [None, {"method": "mse"}, {"method": "gptq"}],
+              "FP8_PER_CHANNEL_PER_TOKEN_CFG": [None, {"method": "mse"}], "INT4_BLOCKWISE_WEIGHT_ONLY_CFG": [None, {"method": "mse"}, {"method": "gptq"}, {"method": "gptq", "perc_damp": 0.05, "block_size": 64}]}
 
 
 def override(extra):
@@ -69,7 +69,7 @@ def draw(rng):
     heads = rng.choice([2, 4])
     hidden = heads * rng.choice([32, 64])
     return {"arch": rng.choice(ARCHS), "preset": rng.choice(PRESETS), "dtype": rng.choice(["bfloat16", "float16", "float32"]),
-            "with_kv": rng.choice([False, False, True, "affine", "cast", "int8"]),
+            "with_kv": rng.choice([False, False, False, True, True, "affine", "cast", "cast", "int8"]),
             "override": rng.choice([None] + list(range(len(OVERRIDES)))), "algorithm": rng.choice(list(range(8))),
             "batches": [rng.choice([1, 2, 3, 4]), rng.choice([1, 2, 3]), rng.choice([8, 17, 24, 40])],  # count, rows, tokens
             "cfg": dict(hidden_size=hidden, intermediate_size=rng.choice([128, 256, 384]), num_hidden_layers=rng.choice([1, 2]),
@@ -134,8 +134,18 @@ def main(n=40, seed=2025, verbose=True):
                 diff._assert_same_quant_json(oj, rj, "fuzz")
             except AssertionError:
                 bad.append("quant json")
+        gptq = isinstance(case["algorithm"], dict) and case["algorithm"].get("method") == "gptq"
         if not bad:
             st["equal"] += 1
+        elif gptq and sorted(rs) == sorted(os_) and not [b for b in bad if not (b == "logits" or b.startswith("tensor "))]:
+            # GPTQ: the Hessian is a sum over tokens of fp32 products, accumulated here in a defined order and by the library
+            # GEMM there; through the inverse factor a few weights per matrix land on the neighbouring code (the update
+            # itself is bit-exact from the same inverse factor: tests/test_differential_cpu.py).  Stated bound: <= 0.5 % of a
+            # tensor's bytes
+            worst = max(float((os_[k].detach().cpu().contiguous().reshape(-1).view(torch.uint8) != w.contiguous().reshape(-1).view(torch.uint8)).float().mean())
+                        for k, w in rs.items() if f"tensor {k}" in bad) if any(b.startswith("tensor ") for b in bad) else 0.0
+            st.setdefault("gptq_hessian_order" if worst <= 5e-3 else "different", []).append(
+                {"case": case, "first": bad[:3], "n_bad": len(bad), "worst_fraction_of_bytes": worst})
         elif searched:
             # how far apart.  An fp32 model's act scale is a MEAN OVER TOKENS in fp32: torch's summation order (which differs
             # between its own CPU and GPU kernels) against this package's defined one gives scales 1-2 ulp apart (DESIGN.md
@@ -163,7 +173,7 @@ def main(n=40, seed=2025, verbose=True):
     diff._batches = base_batches
     if verbose:
         print("hf flows", json.dumps({k: (v if not isinstance(v, list) else len(v)) for k, v in st.items()})[:2500])
-        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_differences", [])[:6] + st.get("awq_clip_near_ties", [])[:2] + st.get("fp32_summation_order", [])[:2]:
+        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_differences", [])[:6] + st.get("awq_clip_near_ties", [])[:2] + st.get("gptq_hessian_order", [])[:2] + st.get("fp32_summation_order", [])[:2]:
             print("   ", json.dumps(d, default=str)[:600])
     return {"hf_flows": st}
 
