@@ -329,3 +329,16 @@ def sparsify(model: torch.nn.Module, mode: str = "sparse_magnitude", forward_loo
         if m not in applied:  # (the fused mask + apply pass has masked these already)
             m.weight.data.mul_(mask.to(m.weight.dtype))
     return model
+
+
+@torch.no_grad()
+def export(model: torch.nn.Module) -> torch.nn.Module:
+    """mts.export (sparsification.py:100-123): the sparse model as a regular one -- the masks are folded into the weights and
+    no longer kept (nor enforced on later weight updates).  sparsify() above stores the masked weights already, so what is
+    left to do is one more application (a weight written since keeps the pattern) and dropping the `_weight_mask` buffers."""
+    for m in model.modules():
+        mask = m._buffers.get("_weight_mask")
+        if mask is not None:
+            m.weight.data.mul_(mask.to(m.weight.dtype))
+            del m._buffers["_weight_mask"]
+    return model

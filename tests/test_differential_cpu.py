@@ -449,6 +449,46 @@ def test_awq_clip_equals_the_reference_live(monkeypatch):
     assert total > 0 and differing <= 0.01 * total, f"awq_clip: {differing} of {total} clipped block amax values differ"
 
 
+@pytest.mark.parametrize("arch,dtype,preset", [("llama", torch.bfloat16, None), ("gemma2", torch.float16, None),
+                                               ("mixtral", torch.float32, "FP8_DEFAULT_CFG"), ("opt", torch.bfloat16, "INT4_BLOCKWISE_WEIGHT_ONLY_CFG")])
+def test_sparse_models_exported_or_quantized_equal_the_reference_live(monkeypatch, arch, dtype, preset):
+    """mts.sparsify + mts.export (masks folded into the weights, no mask buffers left; sparsification.py:100-123) or
+    mts.sparsify + mtq.quantize on top of the sparse weights, against this package's: masks, exported state dict / amax, logits
+    (tools/sparsity_fuzz.py runs the same over random shapes)."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    import modelopt.torch.sparsity as mts
+
+    batches = _batches()
+    ref = mts.sparsify(_model(dtype, arch), "sparse_magnitude")
+    ref_masks = {n[: -len("._weight_mask")]: b.clone() for n, b in ref.named_buffers() if n.endswith("_weight_mask")}
+    if preset:
+        ref = mtq.quantize(ref, copy.deepcopy(getattr(mtq, preset)), lambda m: [m(b) for b in batches])
+        ref_amax = {n: m._amax.detach().float().clone() for n, m in ref.named_modules()
+                    if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
+    with torch.no_grad():
+        ref_logits = ref(batches[0]).logits.clone()
+    if not preset:
+        ref_state = {k: v.detach().clone() for k, v in mts.export(ref).state_dict().items()}
+    hostmem_backend.install(monkeypatch, moa)
+    ours = moa.sparsity.sparsify(_model(dtype, arch), "sparse_magnitude")
+    our_masks = {n[: -len("._weight_mask")]: b.clone() for n, b in ours.named_buffers() if n.endswith("_weight_mask")}
+    assert sorted(our_masks) == sorted(ref_masks) and ref_masks
+    for n, m in ref_masks.items():
+        assert torch.equal(our_masks[n].bool(), m.bool()), n
+    with torch.no_grad():
+        if preset:
+            moa.quantize(ours, copy.deepcopy(getattr(moa.model_quant, preset)), lambda m: [m(b) for b in batches])
+            for n, a in ref_amax.items():
+                assert torch.equal(dict(ours.named_modules())[n]._amax.float().reshape(-1), a.reshape(-1)), n
+        assert torch.equal(ours(batches[0]).logits, ref_logits)
+    if not preset:
+        state = moa.sparsity.export(ours).state_dict()
+        assert sorted(state) == sorted(ref_state) and not any(k.endswith("_weight_mask") for k in state)
+        for k, v in ref_state.items():
+            assert torch.equal(state[k], v), k
+
+
 def test_sparsegpt_equals_the_reference_live(monkeypatch):
     """mts.sparsify(model, "sparsegpt") against sparsity.sparsify on the same model and batches (fp32 model: both sides
     accumulate the Hessian with an fp32 library GEMM): masks agree on at least 99 % of the weights of every linear
