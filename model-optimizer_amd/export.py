@@ -363,21 +363,41 @@ def export_fused_experts(module, dtype: torch.dtype) -> dict:
 # mapping is derived here from transformers' own table: plain renamings (Mixtral: `.mlp.` -> `.block_sparse_moe.`) and
 # the per-expert projections a fused-experts converter was built from (`experts.*.w1 / w3` -> `experts.gate_up_proj`
 # tells that our `experts.N.gate_proj / up_proj` are `w1 / w3`).
-def _checkpoint_rename_rules(model_type):
+def _checkpoint_rename_rules(model):
+    """The reverse of transformers' checkpoint conversion for THIS model (quant_aware_conversion.py:392-470): the mapping is
+    read per model -- a class-specific entry (GPT-NeoX's head: `^embed_out.` -> `lm_head.`) comes before the model type's --
+    without the legacy renames, and every entry is reversed by transformers itself, so anchored patterns come out right.
+    ("regex", pattern, replacement, scope prefixes) for a WeightRenaming; ("expert", ours, theirs) for the per-expert leaf names
+    of a fused-experts converter (the export expands those into per-expert linears already)."""
     import re
 
     try:
         from transformers import conversion_mapping as cm
 
-        mapping = cm.get_checkpoint_conversion_mapping(model_type)
+        mapping = getattr(model, "_weight_conversions", None)
+        if mapping is None:
+            mapping = cm.get_model_conversion_mapping(model, add_legacy=False)
     except Exception:  # noqa: BLE001 -- older transformers: module trees and checkpoints share their names
         mapping = None
     rules = []
     for item in mapping or []:
         src = list(getattr(item, "source_patterns", []) or [])
         tgt = list(getattr(item, "target_patterns", []) or [])
-        if type(item).__name__ == "WeightRenaming" and len(src) == 1 and len(tgt) == 1:
-            rules.append(("rename", tgt[0], src[0]))
+        if type(item).__name__ == "WeightRenaming":
+            try:
+                rev = item.reverse_transform()
+            except Exception:  # noqa: BLE001
+                continue
+            scope = getattr(rev, "scope_prefix", None)
+            prefixes = ()
+            if scope is not None:  # a sub-model's rule applies under its own path only (:323-345)
+                dot = f"{scope}." if scope != "" else ""
+                base = getattr(rev, "base_model_prefix", None) or ""
+                prefixes = tuple(dict.fromkeys(([f"{base}.{dot}"] if base else []) + [dot]))
+            pats, repls = getattr(rev, "source_patterns", []), getattr(rev, "target_patterns", [])
+            pats, repls = ([pats] if isinstance(pats, str) else list(pats or [])), ([repls] if isinstance(repls, str) else list(repls or []))
+            for pattern, repl in zip(pats, repls):
+                rules.append(("regex", re.compile(pattern), repl, prefixes))
         elif type(item).__name__ == "WeightConverter" and len(tgt) == 1 and tgt[0].endswith(("experts.gate_up_proj", "experts.down_proj")):
             ours = ["gate_proj", "up_proj"] if tgt[0].endswith("gate_up_proj") else ["down_proj"]
             for our_name, pat in zip(ours, src):
@@ -400,10 +420,10 @@ def _keeps_module_names(model) -> bool:
 def rename_to_checkpoint_keys(state: dict, model) -> dict:
     import re
 
-    rules = _checkpoint_rename_rules(getattr(getattr(model, "config", None), "model_type", None))
+    rules = _checkpoint_rename_rules(model)
     if not rules:
         return state
-    if any(kind == "expert" for kind, _, _ in rules):
+    if any(rule[0] == "expert" for rule in rules):
         # The reference's reversal is all-or-nothing (unified_export_hf.py:1594-1613): its guard against experts that
         # were not expanded (quant_aware_conversion.py:298-320) takes ANY tensor of 3 or more dims under `.experts.` for a
         # stacked expert weight -- which the [R/br, 1, C/bc, 1] scales of 2-D FP8 blocks are -- and the whole checkpoint
@@ -415,16 +435,47 @@ def rename_to_checkpoint_keys(state: dict, model) -> dict:
                           + (f": '{bad}'" if bad else "") + ", which the reference's reversal refuses): tensors and "
                           "quantization tables keep the module tree's names")
             return state
-    out = {}
-    for k, v in state.items():
-        for kind, a, b in rules:
-            if kind == "expert":
-                k = re.sub(rf"(\.experts\.\d+\.){re.escape(a)}\.", rf"\g<1>{b}.", k)
-        for kind, a, b in rules:
-            if kind == "rename":
-                k = k.replace(a, b)
-        out[k] = v
-    return out
+    return {_rename_key(k, rules): v for k, v in state.items()}
+
+
+def _rename_key(k: str, rules) -> str:
+    import re
+
+    for rule in rules:
+        if rule[0] == "expert":
+            k = re.sub(rf"(\.experts\.\d+\.){re.escape(rule[1])}\.", rf"\g<1>{rule[2]}.", k)
+    for rule in rules:
+        if rule[0] == "regex":  # in order, each under its scope (quant_aware_conversion.py:173-194)
+            _, pattern, repl, prefixes = rule
+            if not prefixes:
+                k = pattern.sub(repl, k)
+            else:
+                hit = next((p for p in prefixes if k.startswith(p)), None)
+                if hit is not None:
+                    k = hit + pattern.sub(repl, k[len(hit):])
+    return k
+
+
+def _module_name_mapper(model):
+    """build_reverse_name_mapper (quant_aware_conversion.py:236-277): the same rules on the module names and wildcard patterns of
+    the quantization tables, which are summarised and sorted under the module tree's names FIRST and mapped entry by entry
+    afterwards (revert_quant_config_names, :280-295) -- a sentinel path segment lets rules that end in a separator match a
+    bare module name, a trailing wildcard is set aside and put back."""
+    rules = [] if _keeps_module_names(model) else _checkpoint_rename_rules(model)
+    if not rules:
+        return lambda name: name
+    sentinel = ".\x00name_sentinel"
+
+    def mapped(name: str) -> str:
+        base, suffix = name, ""
+        if name.endswith(".*"):
+            base, suffix = name[:-2], ".*"
+        elif name.endswith("*"):
+            base, suffix = name[:-1], "*"
+        out = _rename_key(base + sentinel, rules)
+        return (out[:-len(sentinel)] if out.endswith(sentinel) else out) + suffix
+
+    return mapped
 
 
 def _with_pre_quant_scale(out: dict, iq) -> dict:
@@ -741,20 +792,13 @@ def hf_quant_config(model, group_size: int | None = None) -> dict:
     excluded = [n for n, (f, _) in layers.items() if f is None]
     q: dict = {"quant_algo": None, "kv_cache_quant_algo": None}
     kinds = {json.dumps(v, sort_keys=True) for v in quantized.values()}
-    if _keeps_module_names(model):
-        rename = lambda n: n  # noqa: E731 -- (the tensors keep the module tree's names too; warned about there)
-    else:
-        # ONE pass over all names (per name, rename_to_checkpoint_keys would re-walk the model for its expert rules:
-        # O(layers x modules), seconds on a Mixtral-sized model)
-        renamed = rename_to_checkpoint_keys({n + ".weight": None for n in layers}, model)
-        table = {n: k[:-len(".weight")] for n, k in zip(layers, renamed)}
-        rename = table.__getitem__
+    rename = _module_name_mapper(model)  # (identity when the tensors keep the module tree's names too; warned about there)
     if len(kinds) > 1:
         q["quant_algo"] = "MIXED_PRECISION"
         q["quantized_layers"] = {rename(n): v for n, v in quantized.items()}
     elif len(kinds) == 1:
         q.update(next(iter(quantized.values())))
-        q["exclude_modules"] = sorted(_summarize_excluded([rename(n) for n in excluded], [rename(n) for n in quantized]))
+        q["exclude_modules"] = [rename(e) for e in sorted(_summarize_excluded(excluded, list(quantized)))]
     else:
         q["quantized_layers"] = {}
     q["kv_cache_quant_algo"] = get_kv_cache_format(model)

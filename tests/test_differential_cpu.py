@@ -66,10 +66,38 @@ def _model(dtype, arch="llama"):
                                                          architectures=["FalconForCausalLM"])).to(dtype).eval()
         return tf.Qwen3MoeForCausalLM(tf.Qwen3MoeConfig(architectures=["Qwen3MoeForCausalLM"], moe_intermediate_size=64,
                                                         num_experts=4, num_experts_per_tok=2, head_dim=32, **CFG)).to(dtype).eval()
+    if arch in _MORE_ARCHITECTURES:
+        return _MORE_ARCHITECTURES[arch]().to(dtype).eval()
     if arch == "mixtral":
         cfg = MixtralConfig(architectures=["MixtralForCausalLM"], num_local_experts=4, num_experts_per_tok=2, **CFG)
         return MixtralForCausalLM(cfg).to(dtype).eval()
     return LlamaForCausalLM(LlamaConfig(architectures=["LlamaForCausalLM"], **CFG)).to(dtype).eval()
+
+
+def _tf(cls, cfg_cls, **extra):
+    import transformers as tf
+
+    return lambda: getattr(tf, cls)(getattr(tf, cfg_cls)(architectures=[cls], **{**CFG, **extra}))
+
+
+# round 5: ten more decoder families through the same two flows (attention modules patched on the fly for the KV quantizers,
+# q / k norms, parallel attention + MLP blocks, LayerNorm with bias, multi-head latent attention, a head whose checkpoint name
+# differs from its module name)
+_MORE_ARCHITECTURES = {
+    "qwen3": _tf("Qwen3ForCausalLM", "Qwen3Config", head_dim=32), "gemma": _tf("GemmaForCausalLM", "GemmaConfig", head_dim=32),
+    "starcoder2": _tf("Starcoder2ForCausalLM", "Starcoder2Config"), "olmo2": _tf("Olmo2ForCausalLM", "Olmo2Config"),
+    "cohere": _tf("CohereForCausalLM", "CohereConfig"), "phi": _tf("PhiForCausalLM", "PhiConfig"),
+    "granite": _tf("GraniteForCausalLM", "GraniteConfig"), "glm": _tf("GlmForCausalLM", "GlmConfig", head_dim=32, pad_token_id=0),
+    # GPT-NeoX: the head is `lm_head` in the module tree and `embed_out` in the checkpoint (a class-specific renaming)
+    "gpt_neox": lambda: __import__("transformers").GPTNeoXForCausalLM(__import__("transformers").GPTNeoXConfig(
+        architectures=["GPTNeoXForCausalLM"], hidden_size=CFG["hidden_size"], intermediate_size=CFG["intermediate_size"],
+        num_hidden_layers=CFG["num_hidden_layers"], num_attention_heads=CFG["num_attention_heads"], vocab_size=96, max_position_embeddings=64)),
+    "deepseek_v3": lambda: __import__("transformers").DeepseekV3ForCausalLM(__import__("transformers").DeepseekV3Config(
+        architectures=["DeepseekV3ForCausalLM"], hidden_size=CFG["hidden_size"], intermediate_size=CFG["intermediate_size"],
+        moe_intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4, n_routed_experts=4,
+        num_experts_per_tok=2, n_shared_experts=1, first_k_dense_replace=1, vocab_size=96, max_position_embeddings=64, q_lora_rank=32,
+        kv_lora_rank=32, qk_rope_head_dim=16, qk_nope_head_dim=16, v_head_dim=32, n_group=1, topk_group=1)),
+}
 
 
 def _batches():
@@ -222,6 +250,13 @@ def _assert_same_quant_json(ours, ref, what=""):
     # the MSE weight search reaches the per-expert quantizers of fused expert containers too (iter_weights_for_calibration,
     # quant_module.py:123-129 / huggingface.py:1084-1100; found by tools/hf_flow_fuzz.py)
     ("FP8_DEFAULT_CFG", torch.bfloat16, False, "qwen3_moe", {"method": "mse"}), ("INT8_DEFAULT_CFG", torch.float32, False, "mixtral", {"method": "mse"}),
+    # more decoder families (_MORE_ARCHITECTURES)
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen3", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gemma", None),
+    ("FP8_DEFAULT_CFG", torch.float16, True, "starcoder2", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gpt_neox", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "gpt_neox", None), ("FP8_DEFAULT_CFG", torch.bfloat16, "cast", "olmo2", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "cohere", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "phi", None),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "granite", None), ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "glm", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "deepseek_v3", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
