@@ -152,9 +152,22 @@ def force_eager_experts_impl(model: nn.Module) -> None:
             force(getattr(m, "config", None))
 
 
+# Expert containers the reference quantizes with classes of their own (transposed [E, H, 2I] layouts with biases, one
+# quantizer over the stacked 3-D tensor, DBRX's GLU: plugins/huggingface.py:753-774, :776-875, :877-963, :1467-1557), registered
+# there before the generic rule is tried.  The generic per-expert rule below would accept some of them and quantize them
+# DIFFERENTLY (other quantizer granularity, other checkpoint layout), so they are refused by name instead.
+_OWN_CLASS_IN_THE_REFERENCE = ("Llama4TextExperts", "GptOssExperts", "DbrxExperts", "DbrxExpertGLU", "Qwen3VLMoeTextExperts")
+
+
 def register_fused_experts_on_the_fly(model: nn.Module) -> int:
     """Convert every fused-experts container of the model (huggingface.py:1697-1722) and put the model on the eager
     experts forward."""
+    from ._lib import MoquantUnsupported
+
+    special = sorted({type(m).__name__ for m in model.modules() if type(m).__name__ in _OWN_CLASS_IN_THE_REFERENCE})
+    if special:
+        raise MoquantUnsupported(f"expert containers {special}: the reference quantizes these with container classes of its own "
+                                 "(plugins/huggingface.py:753-963, :1467-1557), which are outside this path")
     found = [m for m in model.modules() if not is_quant_fused_experts(m) and _first_proj_attr_of(m) is not None]
     if not found:
         return 0

@@ -80,7 +80,7 @@ def _tf(cls, cfg_cls, **extra):
     return lambda: getattr(tf, cls)(getattr(tf, cfg_cls)(architectures=[cls], **{**CFG, **extra}))
 
 
-# round 5: ten more decoder families through the same two flows (attention modules patched on the fly for the KV quantizers,
+# round 5: twenty more decoder families through the same two flows (attention modules patched on the fly for the KV quantizers,
 # q / k norms, parallel attention + MLP blocks, LayerNorm with bias, multi-head latent attention, a head whose checkpoint name
 # differs from its module name)
 _MORE_ARCHITECTURES = {
@@ -89,6 +89,23 @@ _MORE_ARCHITECTURES = {
     "cohere": _tf("CohereForCausalLM", "CohereConfig"), "phi": _tf("PhiForCausalLM", "PhiConfig"),
     "granite": _tf("GraniteForCausalLM", "GraniteConfig"), "glm": _tf("GlmForCausalLM", "GlmConfig", head_dim=32, pad_token_id=0),
     # GPT-NeoX: the head is `lm_head` in the module tree and `embed_out` in the checkpoint (a class-specific renaming)
+    # attention classes outside the attention interface: the KV quantizers are written into the class's own products
+    "gptj": lambda: __import__("transformers").GPTJForCausalLM(__import__("transformers").GPTJConfig(
+        architectures=["GPTJForCausalLM"], n_embd=128, n_layer=2, n_head=4, vocab_size=96, n_positions=64, rotary_dim=16)),
+    "codegen": lambda: __import__("transformers").CodeGenForCausalLM(__import__("transformers").CodeGenConfig(
+        architectures=["CodeGenForCausalLM"], n_embd=128, n_layer=2, n_head=4, vocab_size=96, n_positions=64, rotary_dim=16)),
+    "mpt": lambda: __import__("transformers").MptForCausalLM(__import__("transformers").MptConfig(
+        architectures=["MptForCausalLM"], d_model=128, n_heads=4, n_layers=2, vocab_size=96, max_seq_len=64)),
+    "stablelm": _tf("StableLmForCausalLM", "StableLmConfig"), "nemotron": _tf("NemotronForCausalLM", "NemotronConfig"),
+    "glm4": _tf("Glm4ForCausalLM", "Glm4Config", head_dim=32, pad_token_id=0), "exaone4": _tf("Exaone4ForCausalLM", "Exaone4Config"),
+    "ernie4_5": _tf("Ernie4_5ForCausalLM", "Ernie4_5Config"),
+    "gpt_bigcode": lambda: __import__("transformers").GPTBigCodeForCausalLM(__import__("transformers").GPTBigCodeConfig(
+        architectures=["GPTBigCodeForCausalLM"], n_embd=128, n_layer=2, n_head=4, vocab_size=96, n_positions=64)),
+    # more mixture-of-experts families on the generic fused-experts rule
+    "qwen2_moe": _tf("Qwen2MoeForCausalLM", "Qwen2MoeConfig", moe_intermediate_size=64, shared_expert_intermediate_size=64, num_experts=4, num_experts_per_tok=2),
+    "olmoe": _tf("OlmoeForCausalLM", "OlmoeConfig", num_experts=4, num_experts_per_tok=2),
+    "granitemoe": _tf("GraniteMoeForCausalLM", "GraniteMoeConfig", num_local_experts=4, num_experts_per_tok=2),
+    "phimoe": _tf("PhimoeForCausalLM", "PhimoeConfig", num_local_experts=4, num_experts_per_tok=2),
     "gpt_neox": lambda: __import__("transformers").GPTNeoXForCausalLM(__import__("transformers").GPTNeoXConfig(
         architectures=["GPTNeoXForCausalLM"], hidden_size=CFG["hidden_size"], intermediate_size=CFG["intermediate_size"],
         num_hidden_layers=CFG["num_hidden_layers"], num_attention_heads=CFG["num_attention_heads"], vocab_size=96, max_position_embeddings=64)),
@@ -257,6 +274,13 @@ def _assert_same_quant_json(ours, ref, what=""):
     ("INT4_AWQ_CFG", torch.bfloat16, False, "cohere", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "phi", None),
     ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "granite", None), ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "glm", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "deepseek_v3", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gptj", None), ("FP8_DEFAULT_CFG", torch.float16, "cast", "codegen", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "mpt", None), ("INT4_AWQ_CFG", torch.bfloat16, True, "gptj", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "stablelm", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "nemotron", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "glm4", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "exaone4", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "ernie4_5", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gpt_bigcode", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen2_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "olmoe", None),
+    ("FP8_DEFAULT_CFG", torch.float16, "cast", "granitemoe", None), ("INT8_DEFAULT_CFG", torch.bfloat16, False, "phimoe", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
@@ -342,6 +366,17 @@ def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, p
         got = our_state[k].detach().cpu()
         assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), f"{preset} {k}: {got.dtype} {tuple(got.shape)} vs {want.dtype} {tuple(want.shape)}"
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
+
+
+def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
+    """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
+    the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
+    import transformers as tf
+
+    hostmem_backend.install(monkeypatch, moa)
+    model = tf.GptOssForCausalLM(tf.GptOssConfig(num_local_experts=4, num_experts_per_tok=2, head_dim=32, **CFG)).to(torch.bfloat16).eval()
+    with pytest.raises(moa.MoquantUnsupported, match="GptOssExperts"):
+        moa.quantize(model, copy.deepcopy(moa.model_quant.FP8_DEFAULT_CFG), lambda m: [m(b) for b in _batches()])
 
 
 @pytest.mark.parametrize("with_kv", [False, True])

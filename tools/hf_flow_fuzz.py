@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from quantizer_fuzz import load_package  # noqa: E402
 
 ARCHS = ["llama", "llama", "llama-eager", "qwen2", "mistral", "opt", "gpt2", "phi3", "gemma2", "mixtral", "qwen3_moe",
-         "qwen3", "gemma", "starcoder2", "olmo2", "cohere", "phi", "granite", "glm", "gpt_neox"]
+         "qwen3", "gemma", "starcoder2", "olmo2", "cohere", "phi", "granite", "glm", "gpt_neox", "gptj", "codegen", "mpt", "stablelm",
+         "nemotron", "glm4", "exaone4", "ernie4_5", "gpt_bigcode", "qwen2_moe", "olmoe", "granitemoe", "phimoe"]
 PRESETS = ["INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "INT8_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG", "INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG",
            "INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG", "MXFP4_DEFAULT_CFG", "MXFP8_DEFAULT_CFG", "FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG",
            "FP8_PER_CHANNEL_PER_TOKEN_CFG", "W4A8_MXFP4_FP8_CFG", "MXFP4_MLP_WEIGHT_ONLY_CFG"]
