@@ -368,6 +368,36 @@ def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, p
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
 
 
+@pytest.mark.parametrize("preset,dtype,arch", [("FP8_DEFAULT_CFG", torch.bfloat16, "llama"), ("INT4_AWQ_CFG", torch.float16, "qwen2"),
+                                               ("FP8_DEFAULT_CFG", torch.bfloat16, "mixtral")])
+def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, preset, dtype, arch):
+    """export_hf_checkpoint's directory against export.save_checkpoint's: `model.safetensors` is the same FILE, byte for byte
+    (header, key order, metadata, every tensor); `hf_quant_config.json` is the same document up to each library's own
+    `producer` entry."""
+    import json
+
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+
+    batches = _batches()
+    cfg = mtq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(getattr(mtq, preset)), copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
+    ref = mtq.quantize(_model(dtype, arch), cfg, lambda m: [m(b) for b in batches])
+    with tempfile.TemporaryDirectory() as there, tempfile.TemporaryDirectory() as here:
+        export_hf_checkpoint(ref, export_dir=there)
+        hostmem_backend.install(monkeypatch, moa)
+        mq = moa.model_quant
+        ours = _model(dtype, arch)
+        cfg = mq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(getattr(mq, preset)), mq.FP8_KV_CFG["quant_cfg"])
+        with torch.no_grad():
+            moa.quantize(ours, cfg, lambda m: [m(b) for b in batches])
+        state = moa.export.export_state_dict(ours, dtype, lambda: ours(torch.ones([1, 2], dtype=torch.long)))
+        moa.export.save_checkpoint(state, here, moa.export.hf_quant_config(ours))
+        assert open(os.path.join(here, "model.safetensors"), "rb").read() == open(os.path.join(there, "model.safetensors"), "rb").read()
+        mine, theirs = (json.load(open(os.path.join(d, "hf_quant_config.json"))) for d in (here, there))
+        assert mine.pop("producer")["name"] != theirs.pop("producer")["name"] and mine == theirs
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
