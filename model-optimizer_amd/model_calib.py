@@ -1114,6 +1114,9 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              run -- its linears are scored, their near-ties re-scored from the stores, the layer is folded, the next one
              follows.  One pass over the calibration data in total (`passes == 1`), same statistics as the whole-model
              flow (every layer sees the un-quantized output of its predecessor, as in the reference's cache pass)."""
+    if forward_loop is None:  # (:1412-1414)
+        warnings.warn("forward_loop must be provided for awq_lite; skipping awq_lite")
+        return None
     if search not in ("auto", "gram", "gemm"):
         raise ValueError(f"awq_lite: unknown search mode {search!r}")
     if layer_local is None or layer_local:

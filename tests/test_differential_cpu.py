@@ -398,6 +398,50 @@ def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, prese
         assert mine.pop("producer")["name"] != theirs.pop("producer")["name"] and mine == theirs
 
 
+@pytest.mark.parametrize("preset", ["INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG",
+                                    "INT4_AWQ_CFG", "FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG"])
+def test_quantize_without_a_forward_loop_behaves_like_the_reference_live(monkeypatch, preset):
+    """forward_loop=None: weight-only calibration for the max presets (inputs stay uncalibrated), awq_lite warns and skips
+    (model_calib.py:1412-1414), smoothquant stops with its assertion (:1298)."""
+    import warnings
+
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    def both(run):
+        try:
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                amax, logits = run()
+            return amax, logits, sorted({str(w.message) for w in seen if "forward_loop" in str(w.message)})
+        except AssertionError as e:
+            return str(e)
+
+    def reference():
+        q = mtq.quantize(_model(torch.bfloat16), copy.deepcopy(getattr(mtq, preset)), None)
+        amax = {n: m._amax.float().clone() for n, m in q.named_modules() if type(m).__name__.endswith("Quantizer") and getattr(m, "_amax", None) is not None}
+        with torch.no_grad():
+            return amax, q(_batches()[0]).logits
+
+    def ours():
+        model = _model(torch.bfloat16)
+        with torch.no_grad():
+            moa.quantize(model, copy.deepcopy(getattr(moa.model_quant, preset)), None)
+            amax = {n: m._amax.float().clone() for n, m in model.named_modules() if isinstance(m, moa.TensorQuantizer) and getattr(m, "_amax", None) is not None}
+            return amax, model(_batches()[0]).logits
+
+    want = both(reference)
+    hostmem_backend.install(monkeypatch, moa)
+    got = both(ours)
+    if isinstance(want, str):
+        assert got == want and "forward_loop must be provided" in want
+        return
+    assert sorted(got[0]) == sorted(want[0])
+    for n, a in want[0].items():
+        assert torch.equal(got[0][n].reshape(-1), a.reshape(-1)), n
+    assert torch.equal(got[1], want[1]) and got[2] == want[2]
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
