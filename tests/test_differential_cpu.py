@@ -442,6 +442,45 @@ def test_quantize_without_a_forward_loop_behaves_like_the_reference_live(monkeyp
     assert torch.equal(got[1], want[1]) and got[2] == want[2]
 
 
+def test_the_functions_used_on_a_quantized_model_equal_the_reference_live(monkeypatch):
+    """disable_quantizer / enable_quantizer by wildcard, calibrate() again on other data, postprocess_amax -- and the
+    state_dict of the quantized model (keys, shapes, dtypes, values) -- step by step beside the reference."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+    more = [torch.randint(0, CFG["vocab_size"], (2, 30), generator=torch.Generator().manual_seed(99 + i)) for i in range(2)]
+
+    def walk(lib, model, ours):
+        seen = []
+        with torch.no_grad():
+            cfg = lib.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(lib.FP8_DEFAULT_CFG), copy.deepcopy(lib.FP8_KV_CFG["quant_cfg"])) \
+                if not ours else moa.model_quant.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(lib.FP8_DEFAULT_CFG), lib.FP8_KV_CFG["quant_cfg"])
+            q = lib.quantize(model, cfg, lambda m: [m(b) for b in batches]) or model
+            seen.append({k: v.detach().clone() for k, v in q.state_dict().items()})
+            lib.disable_quantizer(q, "*mlp*")
+            seen.append(q(batches[0]).logits.clone())
+            lib.enable_quantizer(q, "*mlp*input_quantizer")
+            seen.append(q(batches[0]).logits.clone())
+            lib.calibrate(q, algorithm="max", forward_loop=lambda m: [m(b) for b in more])
+            seen.append({k: v.detach().clone() for k, v in q.state_dict().items() if k.endswith("_amax")})
+            lib.postprocess_amax(q, "*input_quantizer", lambda a: torch.clamp(a, min=0.5))
+            seen.append({k: v.detach().clone() for k, v in q.state_dict().items() if k.endswith("_amax")})
+            seen.append(q(batches[0]).logits.clone())
+        return seen
+
+    want = walk(mtq, _model(torch.bfloat16), False)
+    hostmem_backend.install(monkeypatch, moa)
+    got = walk(moa.model_quant, _model(torch.bfloat16), True)
+    for i, (a, b) in enumerate(zip(want, got)):
+        if isinstance(a, dict):
+            assert sorted(a) == sorted(b), (i, set(a) ^ set(b))
+            for k in a:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (i, k)
+        else:
+            assert torch.equal(a, b), i
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
