@@ -371,9 +371,9 @@ def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, p
 @pytest.mark.parametrize("preset,dtype,arch", [("FP8_DEFAULT_CFG", torch.bfloat16, "llama"), ("INT4_AWQ_CFG", torch.float16, "qwen2"),
                                                ("FP8_DEFAULT_CFG", torch.bfloat16, "mixtral")])
 def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, preset, dtype, arch):
-    """export_hf_checkpoint's directory against export.save_checkpoint's: `model.safetensors` is the same FILE, byte for byte
-    (header, key order, metadata, every tensor); `hf_quant_config.json` is the same document up to each library's own
-    `producer` entry."""
+    """export_hf_checkpoint's directory against this package's export_hf_checkpoint's: the same four files; `model.safetensors`
+    (header, key order, metadata, every tensor) and `generation_config.json` byte for byte; `hf_quant_config.json` and
+    `config.json` (its `quantization_config` included) the same documents up to each library's own `producer` entry."""
     import json
 
     ref_shim.install()
@@ -391,11 +391,14 @@ def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, prese
         cfg = mq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(getattr(mq, preset)), mq.FP8_KV_CFG["quant_cfg"])
         with torch.no_grad():
             moa.quantize(ours, cfg, lambda m: [m(b) for b in batches])
-        state = moa.export.export_state_dict(ours, dtype, lambda: ours(torch.ones([1, 2], dtype=torch.long)))
-        moa.export.save_checkpoint(state, here, moa.export.hf_quant_config(ours))
-        assert open(os.path.join(here, "model.safetensors"), "rb").read() == open(os.path.join(there, "model.safetensors"), "rb").read()
+        moa.export.export_hf_checkpoint(ours, dtype, here)
+        assert sorted(os.listdir(here)) == sorted(os.listdir(there)) == ["config.json", "generation_config.json", "hf_quant_config.json", "model.safetensors"]
+        for name in ("model.safetensors", "generation_config.json"):
+            assert open(os.path.join(here, name), "rb").read() == open(os.path.join(there, name), "rb").read(), name
         mine, theirs = (json.load(open(os.path.join(d, "hf_quant_config.json"))) for d in (here, there))
         assert mine.pop("producer")["name"] != theirs.pop("producer")["name"] and mine == theirs
+        mine, theirs = (json.load(open(os.path.join(d, "config.json"))) for d in (here, there))
+        assert mine["quantization_config"].pop("producer") != theirs["quantization_config"].pop("producer") and mine == theirs
 
 
 @pytest.mark.parametrize("preset", ["INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG",
