@@ -609,8 +609,49 @@ def export_state_dict(model, dtype: torch.dtype, dummy_forward_fn=None, shard_we
             state[new_key] = value
     for alias in _tied_alias_keys(model, state):
         del state[alias]
+    if not shard:
+        state = _in_module_tree_order(state, model)
     # the dict remembers HOW it was produced: save_checkpoint writes a per-rank shard exactly when this is one
     return ExportedState(rename_to_checkpoint_keys(state, model), sharded=bool(shard))
+
+
+_SCALE_RANK = {"weight": 0, "bias": 0, "weight_scale": 1, "input_scale": 2, "weight_scale_2": 3, "pre_quant_scale": 4}
+_EXPERT_PROJ_RANK = {"gate_proj": 0, "up_proj": 1, "down_proj": 2}
+
+
+def _in_module_tree_order(state: dict, model) -> dict:
+    """The reference's checkpoint dict is the model's own state_dict() -- walked module by module, parameters before buffers --
+    with the exporter's buffers registered on the linears (`weight_scale`, then `input_scale`, `weight_scale_2`, and
+    `pre_quant_scale` promoted last: unified_export_hf.py:630-720, :1121-1138), every expert container expanded in place
+    (expert by expert; gate, up, down) and the KV-cache amax renamed where it stood (export/quant_utils.py:1000-1060).  The ORDER
+    of that dict decides which tensor lands in which file once `max_shard_size` splits the checkpoint, so the same order is
+    produced here: a single file holds its tensors sorted either way, a 47 GB Mixtral checkpoint gets the same five files."""
+    import re
+
+    place = {k: i for i, k in enumerate(model.state_dict().keys())}
+    kv_source = {new: old for old, new in _KV_CACHE_REPLACEMENTS.items()}
+
+    def rank(item):
+        i, key = item
+        owner, _, leaf = key.rpartition(".")
+        m = re.match(r"(.*\.experts)\.(\d+)\.([A-Za-z0-9_]+)\.([A-Za-z0-9_]+)$", key)
+        if m and m.group(3) in _EXPERT_PROJ_RANK:  # an expanded container: where its first fused parameter stood
+            anchor = min((p for k, p in place.items() if k.startswith(m.group(1) + ".")), default=None)
+            if anchor is not None:
+                return (anchor, 0, int(m.group(2)), _EXPERT_PROJ_RANK[m.group(3)], _SCALE_RANK.get(m.group(4), 5), i)
+        if key in place:
+            return (place[key], 0, 0, 0, 0, i)
+        if leaf in _SCALE_RANK:  # an exporter buffer: after the parameters of its linear
+            last = max((place[k] for k in (f"{owner}.weight", f"{owner}.bias") if k in place), default=None)
+            if last is not None:
+                return (last, 1, 0, 0, _SCALE_RANK[leaf], i)
+        for new, old in kv_source.items():  # <attn>.k_proj.k_scale stood at <attn>.k_bmm_quantizer._amax
+            if key.endswith("." + new) and key[: -len(new)] + old in place:
+                return (place[key[: -len(new)] + old], 0, 0, 0, 0, i)
+        return (len(place), 0, 0, 0, 0, i)  # anything else keeps its place at the end
+
+    order = sorted(enumerate(state), key=rank)
+    return {k: state[k] for _, k in order}
 
 
 class ExportedState(dict):
@@ -887,6 +928,11 @@ def export_hf_checkpoint(model, dtype: torch.dtype | None = None, export_dir: st
         save_checkpoint(state, export_dir, quant if quantized else None, shard_weights=False)
         return quant
     tensors = {k: v.detach().contiguous() for k, v in state.items()}
+    # the shard index counts the MODEL's parameters (save_pretrained: num_parameters()); the reference's exporter has put the
+    # packed tensors into its modules by then (INT4: half the elements), this one leaves the model as it was.  (Counted now:
+    # save_pretrained empties the dict it is given while it writes the shards.)
+    rules = [] if _keeps_module_names(model) else _checkpoint_rename_rules(model)
+    total = sum((tensors[k] if (k := _rename_key(n, rules)) in tensors else p).numel() for n, p in model.named_parameters())
     patched = []
     try:
         # transformers >= 5 would apply the reverse of its load-time key conversion to the state dict it is given; the keys
@@ -905,6 +951,14 @@ def export_hf_checkpoint(model, dtype: torch.dtype | None = None, export_dir: st
     finally:
         for mod, fn in patched:
             mod.revert_weight_conversion = fn
+    index_path = os.path.join(export_dir, "model.safetensors.index.json")
+    if os.path.exists(index_path):
+        with open(index_path) as f:
+            index = json.load(f)
+        if index.get("metadata", {}).get("total_parameters") != total:
+            index["metadata"]["total_parameters"] = total
+            with open(index_path, "w") as f:
+                f.write(json.dumps(index, indent=2, sort_keys=True) + "\n")
     if quantized:
         with open(os.path.join(export_dir, "hf_quant_config.json"), "w") as f:
             json.dump(quant, f, indent=4)

@@ -368,9 +368,14 @@ def test_per_layer_overrides_of_a_preset_equal_the_reference_live(monkeypatch, p
         assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
 
 
-@pytest.mark.parametrize("preset,dtype,arch", [("FP8_DEFAULT_CFG", torch.bfloat16, "llama"), ("INT4_AWQ_CFG", torch.float16, "qwen2"),
-                                               ("FP8_DEFAULT_CFG", torch.bfloat16, "mixtral")])
-def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, preset, dtype, arch):
+@pytest.mark.parametrize("preset,dtype,arch,shard", [
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "llama", None), ("INT4_AWQ_CFG", torch.float16, "qwen2", None), ("FP8_DEFAULT_CFG", torch.bfloat16, "mixtral", None),
+    # max_shard_size splits the checkpoint: WHICH tensor lands in which file follows the order of the exported dict (the
+    # model's state_dict order with the exporter's buffers in place, expert containers expanded where they stood), and the index
+    # counts the parameters of a model that holds the packed tensors
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "mixtral", "100KB"), ("INT4_AWQ_CFG", torch.float16, "qwen2", "100KB"),
+    ("W4A8_AWQ_BETA_CFG", torch.bfloat16, "gpt2", "100KB")])
+def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, preset, dtype, arch, shard):
     """export_hf_checkpoint's directory against this package's export_hf_checkpoint's: the same four files; `model.safetensors`
     (header, key order, metadata, every tensor) and `generation_config.json` byte for byte; `hf_quant_config.json` and
     `config.json` (its `quantization_config` included) the same documents up to each library's own `producer` entry."""
@@ -384,16 +389,18 @@ def test_the_checkpoint_files_on_disk_are_the_references_live(monkeypatch, prese
     cfg = mtq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(getattr(mtq, preset)), copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
     ref = mtq.quantize(_model(dtype, arch), cfg, lambda m: [m(b) for b in batches])
     with tempfile.TemporaryDirectory() as there, tempfile.TemporaryDirectory() as here:
-        export_hf_checkpoint(ref, export_dir=there)
+        export_hf_checkpoint(ref, export_dir=there, **({"max_shard_size": shard} if shard else {}))
         hostmem_backend.install(monkeypatch, moa)
         mq = moa.model_quant
         ours = _model(dtype, arch)
         cfg = mq.update_quant_cfg_with_kv_cache_quant(copy.deepcopy(getattr(mq, preset)), mq.FP8_KV_CFG["quant_cfg"])
         with torch.no_grad():
             moa.quantize(ours, cfg, lambda m: [m(b) for b in batches])
-        moa.export.export_hf_checkpoint(ours, dtype, here)
-        assert sorted(os.listdir(here)) == sorted(os.listdir(there)) == ["config.json", "generation_config.json", "hf_quant_config.json", "model.safetensors"]
-        for name in ("model.safetensors", "generation_config.json"):
+        moa.export.export_hf_checkpoint(ours, dtype, here, **({"max_shard_size": shard} if shard else {}))
+        assert sorted(os.listdir(here)) == sorted(os.listdir(there))
+        weights = [f for f in os.listdir(there) if f.endswith(".safetensors") or f.endswith(".index.json")]
+        assert (len(weights) > 2) == bool(shard) and ("model.safetensors" in weights) == (not shard)
+        for name in weights + ["generation_config.json"]:
             assert open(os.path.join(here, name), "rb").read() == open(os.path.join(there, name), "rb").read(), name
         mine, theirs = (json.load(open(os.path.join(d, "hf_quant_config.json"))) for d in (here, there))
         assert mine.pop("producer")["name"] != theirs.pop("producer")["name"] and mine == theirs
