@@ -6,6 +6,7 @@ from __future__ import annotations
 import copy
 import fnmatch
 import re
+import warnings
 
 from torch import nn
 
@@ -452,6 +453,112 @@ def _toggle(model: nn.Module, wildcard_or_filter_func, enable: bool):
         hit = wildcard_or_filter_func(name) if callable(wildcard_or_filter_func) else fnmatch.fnmatch(name, wildcard_or_filter_func)
         if hit:
             module.enable() if enable else module.disable()
+
+
+def _matched_quantizers(model: nn.Module, wildcard_or_filter_func, parent_class):
+    """conversion.py:344-370 (_match_quantizer): quantizers and quantizer chains whose name answers to the wildcard (a fused
+    expert container's per-expert quantizers also under their singular name) or the filter function, optionally only those whose
+    immediate parent is a `parent_class`."""
+    mods = dict(model.named_modules())
+    for name, mod in list(mods.items()):
+        if not isinstance(mod, (TensorQuantizer, SequentialQuantizer)):
+            continue
+        if isinstance(wildcard_or_filter_func, str):
+            normalized = _normalize_fused_experts_quantizer_name(name)
+            if not (fnmatch.fnmatch(name, wildcard_or_filter_func)
+                    or (normalized != name and fnmatch.fnmatch(normalized, wildcard_or_filter_func))):
+                continue
+        elif callable(wildcard_or_filter_func):
+            if not wildcard_or_filter_func(name):
+                continue
+        else:
+            raise NotImplementedError(f"Unsupported type {type(wildcard_or_filter_func)}")
+        parent = mods[name.rpartition(".")[0]] if "." in name else model
+        if parent_class is not None and not isinstance(parent, parent_class):
+            continue
+        yield name, mod, parent
+
+
+def set_quantizer_attributes_partial(model: nn.Module, wildcard_or_filter_func, partial_attributes, parent_class=None):
+    """conversion.py:443-512: MERGE a subset of attributes (a dict, or a list of dicts for a quantizer chain) into every matched
+    quantizer; what is not named stays -- the calibrated amax too.  A dict is broadcast over the members of a chain; a list
+    needs a chain."""
+    if not isinstance(partial_attributes, (dict, list)):
+        raise ValueError(f"Invalid type for attributes: {type(partial_attributes)}, expected dictionary or list of dict.")
+    if isinstance(partial_attributes, list) and not all(isinstance(a, dict) for a in partial_attributes):
+        raise ValueError("All elements in attributes list must be of type dict.")
+    for _, mod, _ in list(_matched_quantizers(model, wildcard_or_filter_func, parent_class)):
+        if isinstance(partial_attributes, list):
+            if not isinstance(mod, SequentialQuantizer):
+                raise ValueError(f"Attributes is a list but {mod} is not a SequentialQuantizer.")
+            for q, a in zip(mod, partial_attributes):
+                q.update_attributes(a)
+        elif isinstance(mod, SequentialQuantizer):
+            for q in mod:
+                q.update_attributes(partial_attributes)
+        else:
+            mod.update_attributes(partial_attributes)
+
+
+def set_quantizer_attribute(model: nn.Module, wildcard_or_filter_func, attribute, parent_class=None):
+    """mtq.set_quantizer_attribute (conversion.py:602-620): the deprecated name of set_quantizer_attributes_partial."""
+    warnings.warn("set_quantizer_attribute is deprecated, use set_quantizer_attributes_partial", DeprecationWarning, stacklevel=2)
+    set_quantizer_attributes_partial(model, wildcard_or_filter_func, attribute, parent_class)
+
+
+def set_quantizer_attributes_full(model: nn.Module, wildcard_or_filter_func, attributes, parent_class=None):
+    """conversion.py:373-440: REPLACE the matched quantizers' attributes by a complete QuantizerAttributeConfig (unspecified
+    fields go back to their defaults); a list of them turns the quantizer into a chain with one member per entry, a single
+    config turns a chain back into one quantizer."""
+    if not isinstance(attributes, (QuantizerAttributeConfig, list)):
+        raise ValueError(f"Invalid type for attributes: {type(attributes)}, expected QuantizerAttributeConfig or list of "
+                         "QuantizerAttributeConfig.")
+    if isinstance(attributes, list) and not all(isinstance(a, QuantizerAttributeConfig) for a in attributes):
+        raise ValueError("All elements in attributes list must be of type QuantizerAttributeConfig.")
+    for name, mod, parent in list(_matched_quantizers(model, wildcard_or_filter_func, parent_class)):
+        attr = name.rpartition(".")[-1]
+        if isinstance(attributes, list):
+            if not isinstance(mod, SequentialQuantizer):
+                mod = SequentialQuantizer(*[TensorQuantizer() for _ in attributes])
+                setattr(parent, attr, mod)
+            elif len(attributes) != len(mod):
+                warnings.warn(f"The number of attributes ({len(attributes)}) does not match the number of quantizers of {mod} "
+                              "leading to partial assignment.")
+            for q, a in zip(mod, attributes):
+                q.set_from_attribute_config(a)
+        else:
+            if isinstance(mod, SequentialQuantizer):
+                mod = TensorQuantizer()
+                setattr(parent, attr, mod)
+            mod.set_from_attribute_config(attributes)
+
+
+class set_quantizer_by_cfg_context:
+    """conversion.py:568-599: apply `quant_cfg` for the length of a `with` block and put every quantizer's ATTRIBUTES back
+    afterwards (buffers -- the amax calibrated inside the block included -- are not part of what is saved).  Entries that would
+    turn a quantizer into a chain are refused there, and here."""
+
+    _SAVED = ("_disabled", "_num_bits", "_axis", "_block_sizes", "_dynamic", "_unsigned", "_narrow_range", "_bias",
+              "_use_constant_amax", "_constant_amax", "_if_quant", "_if_calib")
+
+    def __init__(self, quant_model: nn.Module, quant_cfg):
+        self.model, self.cfg = quant_model, quant_cfg
+
+    def __enter__(self):
+        for entry in normalize_quant_cfg_list(self.cfg):
+            assert not isinstance(entry["cfg"], (list, tuple)), "list of config not support."
+        self.saved = [(q, {k: (dict(v) if isinstance(v, dict) else v) for k, v in q.__dict__.items() if k in self._SAVED},
+                       q._calibrator) for q in model_calib._quantizers(self.model)]
+        set_quantizer_by_cfg(self.model, self.cfg)
+        return self
+
+    def __exit__(self, *exc):
+        for q, attrs, calibrator in self.saved:
+            q.__dict__.update(attrs)
+            q.__dict__["_calibrator"] = calibrator
+            if calibrator is not None:
+                calibrator._axis = attrs.get("_axis")
+        return False
 
 
 def disable_quantizer(model: nn.Module, wildcard_or_filter_func):

@@ -161,6 +161,57 @@ class TensorQuantizer(nn.Module):
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
         self._take_config(cfg)
 
+    _PARTIAL_KEYS = ("enable", "num_bits", "axis", "block_sizes", "type", "calibrator", "unsigned", "narrow_range", "fake_quant",
+                     "bias", "use_constant_amax", "constant_amax")
+
+    def update_attributes(self, partial: dict):
+        """set_from_attribute_config with a plain dict (tensor_quantizer.py:228-290, the form set_quantizer_attributes_partial
+        passes): ONLY the named attributes are written, each through the reference's setter -- axis also reaches the calibrator,
+        block sizes clear the axis, a constant amax is pinned on the buffer -- and everything else, calibration state included,
+        stays as it is."""
+        for key in partial:
+            if key in ("rotate", "backend", "backend_extra_args", "learn_amax", "trt_high_precision_dtype", "pass_through_bwd"):
+                raise MoquantUnsupported(f"quantizer attribute {key!r} is outside this path")
+            assert key in self._PARTIAL_KEYS, f"{key} is not a valid `TensorQuantizer` attribute"
+        d = self.__dict__
+        layout = False
+        for key, val in partial.items():
+            if key == "enable":
+                d["_disabled"] = val is False
+            elif key == "type":
+                d["_dynamic"] = val == "dynamic"
+            elif key == "calibrator":
+                d["_calibrator"] = self._make_calibrator(val)
+            elif key == "axis":
+                d["_axis"] = val
+                if self._calibrator is not None:
+                    self._calibrator._axis = val
+                layout = True
+            elif key == "block_sizes":
+                d["_block_sizes"] = dict(val) if val else None
+                if val is not None:
+                    d["_axis"] = None
+                    if self._calibrator is not None:
+                        self._calibrator._axis = None
+                layout = True
+            elif key == "fake_quant":
+                if not val:
+                    raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
+            elif key == "bias":
+                d["_bias"] = dict(val) if val else None
+            elif key == "use_constant_amax":
+                d["_use_constant_amax"] = bool(val)
+            elif key == "constant_amax":
+                d["_constant_amax"] = val
+                if val is not None:
+                    self.amax = float(val)
+            else:  # num_bits, unsigned, narrow_range
+                d["_" + key] = val
+        if layout:  # shapes cached for the previous layout
+            for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
+                         "_nd_split", "_nd_perm", "_nd_inverse"):
+                d.pop(name, None)
+
     def _make_calibrator(self, spec) -> _Calibrator:
         # config.py:599-613 / tensor_quantizer.py:235-241: "max", "histogram" or (cls, args, kwargs)
         nb = self._num_bits if isinstance(self._num_bits, int) else 8

@@ -491,6 +491,55 @@ def test_the_functions_used_on_a_quantized_model_equal_the_reference_live(monkey
             assert torch.equal(a, b), i
 
 
+def test_the_attribute_setters_equal_the_reference_live(monkeypatch):
+    """set_quantizer_attributes_partial (a merge: the calibrated amax stays, also under other num_bits), set_quantizer_by_cfg_context
+    (attributes put back on exit), set_quantizer_attributes_full (one config, or a list -> a quantizer chain) and their refusals,
+    step by step beside the reference (conversion.py:373-512, :568-599)."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.config import QuantizerAttributeConfig as RefConfig
+
+    batches = _batches()
+
+    def states(q, ours):
+        return {n: (m.is_enabled, str(m.num_bits), str(m.axis), str(m.block_sizes)) for n, m in q.named_modules()
+                if (isinstance(m, moa.TensorQuantizer) if ours else type(m).__name__ == "TensorQuantizer") and "embed" not in n}
+
+    def walk(lib, config, ours):
+        seen = []
+
+        def refused(fn):
+            try:
+                fn()
+            except (AssertionError, ValueError) as e:
+                return f"{type(e).__name__}: {str(e)[:40]}"
+
+        with torch.no_grad():
+            model = _model(torch.bfloat16)
+            q = lib.quantize(model, copy.deepcopy(lib.FP8_DEFAULT_CFG), lambda m: [m(b) for b in batches]) or model
+            lib.set_quantizer_attributes_partial(q, "*mlp*input_quantizer", {"enable": False})
+            seen += [states(q, ours), q(batches[0]).logits.clone()]
+            lib.set_quantizer_attributes_partial(q, lambda n: n.endswith("o_proj.weight_quantizer"), {"num_bits": 8})
+            seen += [states(q, ours), q(batches[0]).logits.clone()]
+            entry = {"*self_attn*input_quantizer": {"enable": False}} if ours else [{"quantizer_name": "*self_attn*input_quantizer", "enable": False}]
+            with lib.set_quantizer_by_cfg_context(q, entry):
+                seen += [states(q, ours), q(batches[0]).logits.clone()]
+            seen += [states(q, ours), q(batches[0]).logits.clone()]
+            seen.append(refused(lambda: lib.set_quantizer_attributes_partial(q, "*gate_proj.weight_quantizer", [{"num_bits": 8}])))
+            seen.append(refused(lambda: lib.set_quantizer_attributes_partial(q, "*gate_proj.weight_quantizer", {"no_such": 1})))
+            lib.set_quantizer_attributes_full(q, "*down_proj.weight_quantizer", config(num_bits=8, axis=0))
+            lib.set_quantizer_attributes_full(q, "*up_proj.weight_quantizer", [config(num_bits=4, block_sizes={-1: 128}), config(num_bits=(4, 3), axis=None)])
+            seen += [states(q, ours), {n: type(m).__name__ for n, m in q.named_modules() if n.endswith("up_proj.weight_quantizer")}]
+        return seen
+
+    want = walk(mtq, RefConfig, False)
+    hostmem_backend.install(monkeypatch, moa)
+    got = walk(moa.model_quant, moa.QuantizerAttributeConfig, True)
+    assert len(want) == len(got)
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, (i, a if not isinstance(a, (dict, torch.Tensor)) else "", b if not isinstance(b, (dict, torch.Tensor)) else "")
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
