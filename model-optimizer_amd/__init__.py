@@ -43,10 +43,12 @@ from . import forward_loop  # noqa: F401
 from . import library_ops  # noqa: F401
 from . import modelopt_plugin  # noqa: F401
 from .model_quant import (calibrate, disable_quantizer, enable_quantizer, fold_weight, postprocess_amax,  # noqa: F401
-                          print_quant_summary, quantize)
+                          print_quant_summary, quantize, set_quantizer_attribute, set_quantizer_attributes_full,
+                          set_quantizer_attributes_partial, set_quantizer_by_cfg, set_quantizer_by_cfg_context)
 from .tensor_quantizer import QuantizerAttributeConfig, TensorQuantizer  # noqa: F401
 
 __all__ = ["ops", "multi_tensor", "calib", "tensor_quantizer", "nn", "hf_attention", "hf_experts", "distributed", "model_calib", "model_quant",
            "sparsity", "gptq", "export", "qtensor", "layerwise", "modelopt_plugin", "quantize", "calibrate", "fold_weight", "postprocess_amax", "disable_quantizer", "enable_quantizer",
-           "print_quant_summary", "TensorQuantizer", "QuantizerAttributeConfig",
+           "print_quant_summary", "set_quantizer_by_cfg", "set_quantizer_by_cfg_context", "set_quantizer_attributes_partial",
+           "set_quantizer_attributes_full", "set_quantizer_attribute", "TensorQuantizer", "QuantizerAttributeConfig",
            "MoquantError", "MoquantUnsupported"]
