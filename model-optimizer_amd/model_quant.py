@@ -455,6 +455,31 @@ def _toggle(model: nn.Module, wildcard_or_filter_func, enable: bool):
             module.enable() if enable else module.disable()
 
 
+def need_calibration(config) -> bool:
+    """config.py:1827-1859: does this configuration need calibration DATA?  Yes for every algorithm other than None / "max";
+    otherwise when some entry that is not a weight quantizer's is switched on and not dynamic."""
+    if config["algorithm"] is not None and config["algorithm"] != "max":
+        return True
+
+    def static(cfg):
+        return cfg.get("enable", True) and cfg.get("type", "") != "dynamic"
+
+    for entry in normalize_quant_cfg_list(config.get("quant_cfg") or []):
+        if "weight_quantizer" in entry["quantizer_name"]:
+            continue  # weights are calibrated without data
+        raw = entry.get("cfg")
+        if isinstance(raw, (list, tuple)):
+            if any(static(c) for c in raw):
+                return True
+            continue
+        cfg = dict(raw or {})
+        if entry.get("enable") is not None:
+            cfg["enable"] = entry["enable"]
+        if static(cfg):
+            return True
+    return False
+
+
 def _matched_quantizers(model: nn.Module, wildcard_or_filter_func, parent_class):
     """conversion.py:344-370 (_match_quantizer): quantizers and quantizer chains whose name answers to the wildcard (a fused
     expert container's per-expert quantizers also under their singular name) or the filter function, optionally only those whose

@@ -540,6 +540,16 @@ def test_the_attribute_setters_equal_the_reference_live(monkeypatch):
         assert torch.equal(a, b) if isinstance(a, torch.Tensor) else a == b, (i, a if not isinstance(a, (dict, torch.Tensor)) else "", b if not isinstance(b, (dict, torch.Tensor)) else "")
 
 
+def test_need_calibration_answers_like_the_reference_for_every_preset_live():
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    names = [n for n in dir(moa.model_quant) if n.endswith("_CFG") and hasattr(mtq, n) and "algorithm" in getattr(mtq, n)]
+    assert len(names) >= 15
+    for n in names:
+        assert moa.model_quant.need_calibration(getattr(moa.model_quant, n)) == mtq.need_calibration(getattr(mtq, n)), n
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
