@@ -89,7 +89,7 @@ W4A8_AWQ_BETA_CFG = _preset(copy.deepcopy(_W4A8_Q), "awq_lite")
 W4A8_MAX_CFG = _preset(copy.deepcopy(_W4A8_Q), "max")  # the same layout, max calibration only
 INT8_SMOOTHQUANT_CFG = _preset({"*weight_quantizer": {"num_bits": 8, "axis": 0},
                                 "*input_quantizer": {"num_bits": 8, "axis": None}},
-                               {"method": "smoothquant", "alpha": 1.0})
+                               "smoothquant")  # (the reference's literal; alpha = 1.0 is SmoothQuantCalibConfig's default)
 
 
 # BASELINE configs[4]: MXFP4 (g = 32, E8M0 block scales) weights and inputs with SmoothQuant's per-channel scaling folded

@@ -548,6 +548,31 @@ def test_need_calibration_answers_like_the_reference_for_every_preset_live():
     assert len(names) >= 15
     for n in names:
         assert moa.model_quant.need_calibration(getattr(moa.model_quant, n)) == mtq.need_calibration(getattr(mtq, n)), n
+        assert getattr(moa.model_quant, n)["algorithm"] == getattr(mtq, n)["algorithm"], n  # the presets' algorithm literals
+
+
+@pytest.mark.parametrize("arch", ["llama", "mixtral"])
+def test_every_shared_model_preset_configures_the_quantizers_like_the_reference_live(monkeypatch, arch):
+    """Every model preset both libraries name, applied without calibration: the same quantizers exist under the same names with
+    the same switches, bits, axes, block sizes, dynamic flag, offsets and constant-amax flag.  (The KV presets are compared
+    merged into model presets everywhere else; on their own they leave the reference's never-used q / p bmm quantizers at the
+    class default -- enabled -- where this package creates them switched off.)"""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    def state(q, ours):
+        return {n: (m.is_enabled, str(m.num_bits), str(m.axis), str(m.block_sizes), bool(m._dynamic), str(getattr(m, "_bias", None)),
+                    bool(getattr(m, "_use_constant_amax", False)))
+                for n, m in q.named_modules() if "embed" not in n
+                and (isinstance(m, moa.TensorQuantizer) if ours else type(m).__name__ == "TensorQuantizer")}
+
+    names = [n for n in dir(moa.model_quant) if n.endswith("_CFG") and hasattr(mtq, n) and "algorithm" in getattr(mtq, n) and "_KV_" not in n]
+    want = {n: state(mtq.quantize(_model(torch.bfloat16, arch), {**copy.deepcopy(getattr(mtq, n)), "algorithm": None}, None), False) for n in names}
+    hostmem_backend.install(monkeypatch, moa)
+    for n in names:
+        model = _model(torch.bfloat16, arch)
+        moa.quantize(model, {**copy.deepcopy(getattr(moa.model_quant, n)), "algorithm": None}, None)
+        assert state(model, True) == want[n], n
 
 
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
