@@ -80,7 +80,7 @@ def _tf(cls, cfg_cls, **extra):
     return lambda: getattr(tf, cls)(getattr(tf, cfg_cls)(architectures=[cls], **{**CFG, **extra}))
 
 
-# round 5: twenty more decoder families through the same two flows (attention modules patched on the fly for the KV quantizers,
+# round 5: thirty-four more decoder families through the same two flows (attention modules patched on the fly for the KV quantizers,
 # q / k norms, parallel attention + MLP blocks, LayerNorm with bias, multi-head latent attention, a head whose checkpoint name
 # differs from its module name)
 _MORE_ARCHITECTURES = {
@@ -106,6 +106,16 @@ _MORE_ARCHITECTURES = {
     "olmoe": _tf("OlmoeForCausalLM", "OlmoeConfig", num_experts=4, num_experts_per_tok=2),
     "granitemoe": _tf("GraniteMoeForCausalLM", "GraniteMoeConfig", num_local_experts=4, num_experts_per_tok=2),
     "phimoe": _tf("PhimoeForCausalLM", "PhimoeConfig", num_local_experts=4, num_experts_per_tok=2),
+    "helium": _tf("HeliumForCausalLM", "HeliumConfig", head_dim=32), "arcee": _tf("ArceeForCausalLM", "ArceeConfig"),
+    "apertus": _tf("ApertusForCausalLM", "ApertusConfig"), "seed_oss": _tf("SeedOssForCausalLM", "SeedOssConfig", head_dim=32),
+    "hunyuan": _tf("HunYuanDenseV1ForCausalLM", "HunYuanDenseV1Config", head_dim=32), "gemma3": _tf("Gemma3ForCausalLM", "Gemma3TextConfig", head_dim=32),
+    "bitnet": _tf("BitNetForCausalLM", "BitNetConfig"),
+    "glm4_moe": _tf("Glm4MoeForCausalLM", "Glm4MoeConfig", moe_intermediate_size=64, n_routed_experts=4, num_experts_per_tok=2,
+                    n_shared_experts=1, first_k_dense_replace=1, head_dim=32, n_group=1, topk_group=1),
+    "ernie4_5_moe": _tf("Ernie4_5_MoeForCausalLM", "Ernie4_5_MoeConfig", moe_intermediate_size=64, moe_num_experts=4, moe_k=2),
+    "dots1": _tf("Dots1ForCausalLM", "Dots1Config", moe_intermediate_size=64, n_routed_experts=4, num_experts_per_tok=2, n_shared_experts=1,
+                 first_k_dense_replace=1, n_group=1, topk_group=1),
+    "minimax": _tf("MiniMaxForCausalLM", "MiniMaxConfig", num_local_experts=4, num_experts_per_tok=2, head_dim=32),
     "gpt_neox": lambda: __import__("transformers").GPTNeoXForCausalLM(__import__("transformers").GPTNeoXConfig(
         architectures=["GPTNeoXForCausalLM"], hidden_size=CFG["hidden_size"], intermediate_size=CFG["intermediate_size"],
         num_hidden_layers=CFG["num_hidden_layers"], num_attention_heads=CFG["num_attention_heads"], vocab_size=96, max_position_embeddings=64)),
@@ -281,6 +291,12 @@ def _assert_same_quant_json(ours, ref, what=""):
     ("INT4_AWQ_CFG", torch.bfloat16, False, "ernie4_5", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gpt_bigcode", None),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "qwen2_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "olmoe", None),
     ("FP8_DEFAULT_CFG", torch.float16, "cast", "granitemoe", None), ("INT8_DEFAULT_CFG", torch.bfloat16, False, "phimoe", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "helium", None), ("INT4_AWQ_CFG", torch.bfloat16, False, "arcee", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "apertus", None), ("FP8_DEFAULT_CFG", torch.float16, "cast", "seed_oss", None),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "hunyuan", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "gemma3", None),
+    ("INT4_AWQ_CFG", torch.bfloat16, True, "bitnet", None), ("FP8_DEFAULT_CFG", torch.bfloat16, True, "glm4_moe", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "ernie4_5_moe", None), ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "dots1", None),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "minimax", None),
 ])
 def test_quantize_and_export_equal_the_reference_live(monkeypatch, preset, dtype, with_kv, arch, algorithm):
     ref_amax, ref_state = _reference_run(preset, dtype, with_kv, arch, algorithm)
