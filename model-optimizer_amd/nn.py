@@ -17,9 +17,11 @@ class QuantLinear(nn.Linear):
     default_quant_desc_weight = QuantizerAttributeConfig(num_bits=8, axis=0)
 
     def _setup(self):
+        # (input, output, weight: the reference's registration order -- the order of named_modules(), hence of the lines of
+        # print_quant_summary and of the quantizer buffers in state_dict())
         self.input_quantizer = TensorQuantizer(self.default_quant_desc_input)
-        self.weight_quantizer = TensorQuantizer(self.default_quant_desc_weight)
         self.output_quantizer = TensorQuantizer(QuantizerAttributeConfig(enable=False))
+        self.weight_quantizer = TensorQuantizer(self.default_quant_desc_weight)
 
     @classmethod
     def convert(cls, linear: nn.Linear) -> "QuantLinear":

@@ -765,12 +765,50 @@ class TensorQuantizer(nn.Module):
             outputs = self._reset_to_original_shape(outputs)
         return outputs
 
+    @staticmethod
+    def _short_tensor(tensor: torch.Tensor, fmt=".2e") -> str:
+        if tensor.numel() == 1:
+            return f"{tensor.item():{fmt}}"
+        return f"[{tensor.min().item():{fmt}}, {tensor.max().item():{fmt}}]({tensor.numel()})"
+
+    def _get_name(self):
+        # a quantizer promoted to static block scales prints under the reference's subclass name (tensor_quantizer.py:1483-1500)
+        return "StaticBlockScaleQuantizer" if getattr(self, "_is_static_block_scale_quantizer", False) else super()._get_name()
+
+    def _short_amax(self, fmt=None) -> str:
+        fmt = fmt or (".4f" if getattr(self, "_is_static_block_scale_quantizer", False) else ".2e")  # (:1623)
+        if self.is_mx_format:
+            return "None"
+        if self._use_constant_amax:
+            return f"{torch.finfo(torch.float8_e4m3fn).max:{fmt}}(const)"
+        held = getattr(self, "_amax", None)
+        if not hasattr(self, "_amax"):
+            return "dynamic"
+        return "None" if held is None else "meta" if held.is_meta else self._short_tensor(held, fmt)
+
     def extra_repr(self):
-        return (f"{self._num_bits} bit fake axis={self._axis} block_sizes={self._block_sizes} "
-                f"amax={'None' if self.is_mx_format else '448(const)' if self._use_constant_amax else 'dynamic' if getattr(self, '_amax', None) is None else tuple(self._amax.shape)} "
-                f"calibrator={type(self._calibrator).__name__}{f' bias={self._bias}' if self._bias else ''} "
-                f"quant={'on' if self._if_quant else 'off'}"
-                f"{' calib' if self._if_calib else ''}{' disabled' if self._disabled else ''}")
+        """The line print_quant_summary shows per quantizer, in the reference's words and order (tensor_quantizer.py:1223-1297):
+        `disabled`, or sign / bits / narrow / fake, the block sizes or the axis (`per-tensor`), `amax=` as a value, a
+        `[min, max](count)` range, `dynamic`, `None` (MX) or the constant, the smoothing scale, the calibrator, the offset, and
+        the quant / calib switches."""
+        pqs = self.pre_quant_scale
+        smoothing = f" pre_quant_scale={self._short_tensor(pqs)}" if pqs is not None else ""
+        if self._disabled:
+            return "disabled" + smoothing
+        s = f"{'unsigned ' if self._unsigned else ''}{self._num_bits} bit"
+        s += " narrow" if self._narrow_range else ""
+        s += " fake" if self._fake_quant else ""
+        if self._block_sizes is not None:
+            s += f" block_sizes={self._block_sizes},"
+        else:
+            s += f" axis={self._axis}" if self._axis is not None else " per-tensor"
+        s += f" amax={self._short_amax()}" + smoothing
+        s += f" calibrator={type(self._calibrator).__name__}" if self._calibrator is not None else ""
+        if self._bias:
+            s += f" bias={self._bias}"
+        s += " quant" if self._if_quant else ""
+        s += " calib" if self._if_calib else ""
+        return s
 
 
 class SequentialQuantizer(nn.Sequential):

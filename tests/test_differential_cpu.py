@@ -591,6 +591,52 @@ def test_every_shared_model_preset_configures_the_quantizers_like_the_reference_
         assert state(model, True) == want[n], n
 
 
+@pytest.mark.parametrize("preset,with_kv", [("INT4_AWQ_CFG", "cast"), ("FP8_DEFAULT_CFG", "affine"), ("W4A8_AWQ_BETA_CFG", False),
+                                            ("INT8_SMOOTHQUANT_CFG", True), ("MXFP4_DEFAULT_CFG", True)])
+def test_print_quant_summary_prints_the_references_lines_live(monkeypatch, preset, with_kv):
+    """What a user reads after quantize(): one line per quantizer in the reference's order (input, output, weight per linear),
+    each quantizer in the reference's words -- `disabled`, bits, `per-tensor` / axis / block sizes, amax as value or
+    `[min, max](count)`, `dynamic`, the constant, the smoothing scale, calibrator, offset, switches; a quantizer promoted to
+    static block scales under its subclass name.  Up to the reference's (switched-off) embedding quantizers and the count."""
+    import contextlib
+    import io
+
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    batches = _batches()
+
+    def lines(lib, model):
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            lib.print_quant_summary(model)
+        return [ln for ln in out.getvalue().splitlines() if "embed_tokens" not in ln]
+
+    def config(lib, ours):
+        cfg = copy.deepcopy(getattr(lib, preset))
+        if not with_kv:
+            return cfg
+        if ours:
+            kv = {"affine": lib.FP8_AFFINE_KV_CFG, "cast": lib.FP8_CAST_KV_CFG}.get(with_kv, lib.FP8_KV_CFG)["quant_cfg"]
+        elif with_kv == "cast":
+            kv = [{"quantizer_name": "*[kv]_bmm_quantizer", "cfg": {"num_bits": (4, 3), "axis": None, "use_constant_amax": True}}]
+        else:
+            kv = copy.deepcopy((lib.FP8_AFFINE_KV_CFG if with_kv == "affine" else lib.FP8_KV_CFG)["quant_cfg"])
+        return lib.update_quant_cfg_with_kv_cache_quant(cfg, kv)
+
+    loop = (lambda m: [m(b) for b in batches]) if getattr(mtq, preset).get("algorithm") or with_kv else None
+    ref = mtq.quantize(_model(torch.bfloat16), config(mtq, False), loop)
+    want = lines(mtq, ref)
+    hostmem_backend.install(monkeypatch, moa)
+    ours = _model(torch.bfloat16)
+    with torch.no_grad():
+        moa.quantize(ours, config(moa.model_quant, True), loop)
+    got = lines(moa.model_quant, ours)
+    assert len(got) == len(want) > 20
+    assert got[:-1] == want[:-1]
+    assert got[-1].endswith("TensorQuantizers found in model") and want[-1].endswith("TensorQuantizers found in model")
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
