@@ -21,7 +21,8 @@ from quantizer_fuzz import load_package  # noqa: E402
 
 ARCHS = ["llama", "llama", "llama-eager", "qwen2", "mistral", "opt", "gpt2", "phi3", "gemma2", "mixtral", "qwen3_moe",
          "qwen3", "gemma", "starcoder2", "olmo2", "cohere", "phi", "granite", "glm", "gpt_neox", "gptj", "codegen", "mpt", "stablelm",
-         "nemotron", "glm4", "exaone4", "ernie4_5", "gpt_bigcode", "qwen2_moe", "olmoe", "granitemoe", "phimoe"]
+         "nemotron", "glm4", "exaone4", "ernie4_5", "gpt_bigcode", "qwen2_moe", "olmoe", "granitemoe", "phimoe", "helium", "arcee",
+         "apertus", "seed_oss", "hunyuan", "gemma3", "bitnet", "glm4_moe", "ernie4_5_moe", "dots1", "minimax"]
 PRESETS = ["INT4_BLOCKWISE_WEIGHT_ONLY_CFG", "INT8_WEIGHT_ONLY_CFG", "FP8_DEFAULT_CFG", "INT8_DEFAULT_CFG", "INT8_SMOOTHQUANT_CFG", "INT8_WEIGHT_ONLY_CFG", "INT4_BLOCKWISE_WEIGHT_ONLY_CFG",
            "INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG", "MXFP4_DEFAULT_CFG", "MXFP8_DEFAULT_CFG", "FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG",
            "FP8_PER_CHANNEL_PER_TOKEN_CFG", "W4A8_MXFP4_FP8_CFG", "MXFP4_MLP_WEIGHT_ONLY_CFG"]
