@@ -634,7 +634,7 @@ def _in_module_tree_order(state: dict, model) -> dict:
     def rank(item):
         i, key = item
         owner, _, leaf = key.rpartition(".")
-        m = re.match(r"(.*\.experts)\.(\d+)\.([A-Za-z0-9_]+)\.([A-Za-z0-9_]+)$", key)
+        m = re.match(r"(.*\bexperts)\.(\d+)\.([A-Za-z0-9_]+)\.([A-Za-z0-9_]+)$", key)
         if m and m.group(3) in _EXPERT_PROJ_RANK:  # an expanded container: where its first fused parameter stood
             anchor = min((p for k, p in place.items() if k.startswith(m.group(1) + ".")), default=None)
             if anchor is not None:
