@@ -95,8 +95,9 @@ def _worker(rank, world, port, ret):
             dist.destroy_process_group()
 
 
-def test_data_parallel_max_calibration_equals_the_references_data_parallel_run_gloo():
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_max_calibration_equals_the_references_data_parallel_run_gloo(world):
+    """world 3: the four batches split 2 / 1 / 1 -- ranks with different amounts of data still end on the all-batches amax."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
