@@ -637,6 +637,49 @@ def test_print_quant_summary_prints_the_references_lines_live(monkeypatch, prese
     assert got[-1].endswith("TensorQuantizers found in model") and want[-1].endswith("TensorQuantizers found in model")
 
 
+@pytest.mark.parametrize("case", ["all_off", "kv_only", "other_dtype_fp8", "other_dtype_int4_awq"])
+def test_corner_exports_write_the_references_directory_live(monkeypatch, case):
+    """A model whose quantizers are all off (three plain files, no quantization tables), a model with only the KV cache
+    quantized, and exports in a dtype other than the model's: the directory is the reference's (producer entries aside)."""
+    import json
+
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.export import export_hf_checkpoint
+
+    batches = _batches()
+    model_dtype, export_dtype = {"other_dtype_fp8": (torch.bfloat16, torch.float16), "other_dtype_int4_awq": (torch.float16, torch.bfloat16)}.get(
+        case, (torch.bfloat16, torch.bfloat16))
+
+    def config(lib, ours):
+        off = {"*": {"enable": False}} if ours else [{"quantizer_name": "*", "enable": False}]
+        if case == "all_off":
+            return {"quant_cfg": off, "algorithm": "max"}
+        if case == "kv_only":
+            kv = lib.FP8_KV_CFG["quant_cfg"]
+            return {"quant_cfg": {**off, **kv} if ours else off + copy.deepcopy(kv), "algorithm": "max"}
+        return copy.deepcopy(lib.FP8_DEFAULT_CFG if case == "other_dtype_fp8" else lib.INT4_AWQ_CFG)
+
+    with tempfile.TemporaryDirectory() as there, tempfile.TemporaryDirectory() as here:
+        ref = mtq.quantize(_model(model_dtype), config(mtq, False), lambda m: [m(b) for b in batches])
+        export_hf_checkpoint(ref, dtype=export_dtype, export_dir=there)
+        hostmem_backend.install(monkeypatch, moa)
+        ours = _model(model_dtype)
+        with torch.no_grad():
+            moa.quantize(ours, config(moa.model_quant, True), lambda m: [m(b) for b in batches])
+        moa.export.export_hf_checkpoint(ours, export_dtype, here)
+        assert sorted(os.listdir(here)) == sorted(os.listdir(there))
+        assert ("hf_quant_config.json" in os.listdir(there)) == (case != "all_off")
+        for name in os.listdir(there):
+            mine, theirs = open(os.path.join(here, name), "rb").read(), open(os.path.join(there, name), "rb").read()
+            if name.endswith(".json") and mine != theirs:
+                mine, theirs = json.loads(mine), json.loads(theirs)
+                for doc in (mine, theirs):
+                    doc.pop("producer", None)
+                    (doc.get("quantization_config") or {}).pop("producer", None)
+            assert mine == theirs, name
+
+
 def test_expert_containers_the_reference_has_a_class_of_its_own_for_are_refused(monkeypatch):
     """GPT-OSS' experts ([E, H, 2I] with biases) have `_QuantGptOssExperts` in the reference (plugins/huggingface.py:1467-1557);
     the generic per-expert rule would take them and quantize them differently, so quantize() stops by name."""
