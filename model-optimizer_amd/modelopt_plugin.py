@@ -11,6 +11,9 @@
   S5  sparsity          : magnitude.create_asp_mask, sparsegpt.create_sgpt_mask and the SparseGPT Hessian hook are
                           re-pointed at our kernels.
   S6  utilities         : core_utils.reduce_amax (and its re-export) is re-pointed at our reductions.
+  S7  algorithms        : install(algorithms=True) -- the `_calib_func` hooks of the calibration modes, weight_only_quantize,
+                          fold_weight and the export packers run this package's fused flows on the reference's own model
+                          objects (modelopt_algorithms.py).
 
 Nothing here imports modelopt at module import time; `install()` raises ImportError if it is absent.
 """
@@ -231,11 +234,16 @@ def uninstall():
 
 
 def install(extensions: bool = True, backend: bool = True, utilities: bool = True, sparsity_seam: bool = True,
-            library_ops: bool = False):
+            library_ops: bool = False, algorithms: bool = False):
     """Wire the seams into an importable modelopt.  Returns the list of seams installed.  `library_ops` additionally
     re-points the S2 module globals `tensor_quant.quantize_op / dynamic_block_quantize_op` at the `moquant::`
     torch.library operators for GPU tensors (redundant with S1 for results; it removes the reference's Python
-    dispatch layers from the call and keeps graphs traceable through our fake implementations)."""
+    dispatch layers from the call and keeps graphs traceable through our fake implementations).
+
+    `algorithms` (S7, modelopt_algorithms.py): the reference's calibration-algorithm hooks (`_calib_func` of its mode
+    descriptors, `weight_only_quantize`, `fold_weight`) and export packers are re-pointed at this package's fused
+    implementations, run on the reference's own model objects -- an unmodified `mtq.quantize(model, cfg, loop)` then takes
+    the multi-tensor / deferred-statistics / Gram-screen path instead of one kernel call per quantizer call."""
     import modelopt.torch.quantization.extensions as ext  # ImportError if modelopt is absent
 
     installed = []
@@ -287,4 +295,8 @@ def install(extensions: bool = True, backend: bool = True, utilities: bool = Tru
                 _swap(ref_tq, "dynamic_block_quantize_op", _library_op_seam(ref_tq.dynamic_block_quantize_op,
                                                                            lo.dynamic_block_quantize_op))
             installed.append("S2:library_ops")
+    if algorithms:
+        from . import modelopt_algorithms
+
+        installed += modelopt_algorithms.install_algorithms(_swap)
     return installed

@@ -1,0 +1,236 @@
+"""S7, the algorithm seam, under the LIVE reference on this tier (modelopt_algorithms.py).
+
+`modelopt_plugin.install(algorithms=True)` + the reference's own, unmodified `mtq.quantize(model, <preset>, loop)` and
+`export_hf_checkpoint`: the calibration algorithm that runs is THIS package's (on the reference's model objects, adopted for
+the call), and what the reference then holds and exports must equal its own eager run -- every quantizer's amax, the logits of
+the fake-quantized model, every checkpoint tensor byte for byte, both JSON tables -- and the model must be the reference's
+again afterwards (classes, quantizer objects, calibrator state).
+
+The C-ABI is served by the host-memory stand-in (tests/hostmem_backend.py) and the seams' "is this a GPU tensor" gate is opened
+for the duration; the device tier repeats the comparison with device tensors (tests/test_gpu_reference_live.py, section A').
+"""
+
+import contextlib
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+import _moa_import
+from conftest import GOLDEN
+
+moa = _moa_import.load()
+sys.path.insert(0, GOLDEN)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import hostmem_backend  # noqa: E402
+import ref_shim  # noqa: E402
+import test_differential_cpu as diff  # noqa: E402  (helpers: models, batches, the reference's run + export)
+
+pytestmark = pytest.mark.skipif(not ref_shim.reference_available(), reason="no reference checkout / staged archive")
+
+
+@contextlib.contextmanager
+def algorithm_seam(monkeypatch):
+    from model_optimizer_amd import modelopt_plugin
+
+    ref_shim.install()
+    hostmem_backend.install(monkeypatch, moa)
+    monkeypatch.setattr(modelopt_plugin, "_takes", lambda t: True)
+    got = modelopt_plugin.install(extensions=False, backend=False, utilities=False, sparsity_seam=False, algorithms=True)
+    modelopt_plugin.STATS.clear()
+    try:
+        yield modelopt_plugin, got
+    finally:
+        modelopt_plugin.uninstall()
+
+
+def _same(ref, ours, what, clip_search=False):
+    ref_amax, ref_state = ref
+    our_amax, our_state = ours
+    assert sorted(ref_amax) == sorted(our_amax), f"{what}: quantizers with an amax differ: {set(ref_amax) ^ set(our_amax)}"
+    if clip_search:
+        # awq_clip picks, per weight block, the first of 10 clip ratios with the smallest output error; the reference sums
+        # that error with torch's CPU kernels, this package block by block in a defined order, and blocks whose two best
+        # ratios tie to rounding fall either way -- the stated tolerance of the package's own comparison with the reference
+        # (tests/test_differential_cpu.py::test_awq_clip_equals_the_reference_live): at most 1 % of the block amax values
+        total = sum(a.numel() for a in ref_amax.values())
+        differing = sum(int((our_amax[n].reshape(-1) != a.reshape(-1)).sum()) for n, a in ref_amax.items())
+        assert differing <= 0.01 * total, f"{what}: {differing} of {total} clipped block amax values differ"
+        return len(ref_amax), 0
+    for n, a in ref_amax.items():
+        assert torch.equal(our_amax[n].reshape(-1), a.reshape(-1)), f"{what}: amax of {n} differs"
+    ref_state, our_state = dict(ref_state), dict(our_state)
+    rl, ol = ref_state.pop("__logits__"), our_state.pop("__logits__")
+    if rl is not None:
+        assert torch.equal(rl, ol), f"{what}: logits differ by {(rl.float() - ol.float()).abs().max().item()}"
+    rj, oj = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert rj == oj, f"{what}: quantization tables differ"
+    assert sorted(ref_state) == sorted(our_state), set(ref_state) ^ set(our_state)
+    for k, want in ref_state.items():
+        got = our_state[k]
+        assert got.dtype == want.dtype and got.shape == want.shape, k
+        assert torch.equal(got.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), \
+            f"{what}: checkpoint tensor {k} differs"
+    return len(ref_amax), len(ref_state)
+
+
+CASES = [
+    # preset, dtype, KV cache, architecture, algorithm override, seam entry that must have served the call
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", None, "S7:max_calibrate"),
+    ("FP8_DEFAULT_CFG", torch.float16, "cast", "llama", None, "S7:max_calibrate"),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "llama", None, "S7:max_calibrate"),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "opt", None, "S7:max_calibrate"),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "gpt2", None, "S7:max_calibrate"),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", None, "S7:smoothquant"),
+    ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "opt", diff.SQ_HALF, "S7:smoothquant"),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", None, "S7:awq"),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", None, "S7:awq"),
+    ("INT4_AWQ_CFG", torch.float16, False, "opt", None, "S7:awq"),
+    ("INT4_AWQ_CFG", torch.bfloat16, True, "llama", {"method": "awq_clip"}, "S7:awq"),
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", {"method": "awq_full", "alpha_step": 0.25}, "S7:awq"),
+    ("W4A8_AWQ_BETA_CFG", torch.bfloat16, False, "llama", None, "S7:awq"),
+    ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
+    ("FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
+    ("FP8_PER_CHANNEL_PER_TOKEN_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
+    ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", {"method": "mse"}, "S7:mse_calibrate"),
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None, "S7:max_calibrate"),
+    ("INT8_WEIGHT_ONLY_CFG", torch.bfloat16, False, "qwen3_moe", None, "S7:max_calibrate"),
+]
+
+
+@pytest.mark.parametrize("preset,dtype,with_kv,arch,algorithm,entry", CASES)
+def test_reference_quantize_and_export_through_the_algorithm_seam(monkeypatch, preset, dtype, with_kv, arch, algorithm, entry):
+    ref = diff._reference_run(preset, dtype, with_kv, arch, algorithm)
+    with algorithm_seam(monkeypatch) as (plugin, got):
+        assert any(g.startswith("S7:_calib_func") for g in got), got
+        ours = diff._reference_run(preset, dtype, with_kv, arch, algorithm)
+        stats = dict(plugin.STATS)
+    assert stats.get(entry, 0) >= 1, f"the reference's quantize() never reached {entry}: {stats}"
+    assert not [k for k in stats if "fallback" in k], f"handed back to the reference: {stats}"
+    _same(ref, ours, f"{preset} {arch}", clip_search=bool(algorithm) and algorithm.get("method") in ("awq_clip", "awq_full"))
+
+
+def test_the_model_is_the_references_again_after_the_call(monkeypatch):
+    """Classes, quantizer OBJECTS, flags, calibrator maxima and promotion: the adoption leaves nothing of this package behind."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.nn import TensorQuantizer as RTQ
+
+    def run():
+        m = diff._model(torch.bfloat16, "llama")
+        batches = diff._batches()
+        q = mtq.quantize(m, copy.deepcopy(mtq.INT4_AWQ_CFG), lambda mm: [mm(b) for b in batches])
+        return q
+
+    base = run()
+    with algorithm_seam(monkeypatch):
+        ours = run()
+    for (n1, a), (n2, b) in zip(base.named_modules(), ours.named_modules(), strict=True):
+        assert n1 == n2 and type(a).__name__ == type(b).__name__ and type(a).__module__ == type(b).__module__, (n1, n2, type(a), type(b))
+        assert not type(b).__module__.startswith("model_optimizer_amd"), (n2, type(b))
+        if isinstance(a, RTQ):
+            for k in ("_disabled", "_if_quant", "_if_calib", "_axis", "_num_bits", "_block_sizes", "_dynamic", "_enable_pre_quant_scale",
+                      "_unsigned", "_narrow_range"):
+                assert a.__dict__.get(k) == b.__dict__.get(k), (n1, k, a.__dict__.get(k), b.__dict__.get(k))
+            assert sorted(a._buffers) == sorted(b._buffers), (n1, list(a._buffers), list(b._buffers))
+            for k, v in a._buffers.items():
+                assert v.dtype == b._buffers[k].dtype and torch.equal(v, b._buffers[k]), (n1, k)
+            ca, cb = getattr(a._calibrator, "_calib_amax", None), getattr(b._calibrator, "_calib_amax", None)
+            assert (ca is None) == (cb is None), n1
+            if ca is not None:
+                assert ca.shape == cb.shape and ca.dtype == cb.dtype and torch.equal(ca, cb), (n1, ca, cb)
+            assert ("_amax_for_smoothing" in a.__dict__) == ("_amax_for_smoothing" in b.__dict__), n1
+    assert not any(hasattr(m, "awq_lite") for m in ours.modules())
+
+
+def test_debug_keeps_the_search_tables_on_the_modules(monkeypatch):
+    """awq_lite(debug=True) (model_calib.py:1719-1720): `module.awq_lite.best_alpha` / `.loss` stay readable."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    def run():
+        m = diff._model(torch.bfloat16, "llama")
+        batches = diff._batches()
+        cfg = copy.deepcopy(mtq.INT4_AWQ_CFG)
+        cfg["algorithm"] = {"method": "awq_lite", "alpha_step": 0.1, "debug": True}
+        q = mtq.quantize(m, cfg, lambda mm: [mm(b) for b in batches])
+        return {n: (float(mod.awq_lite.best_alpha), {round(float(k), 2): float(v) for k, v in mod.awq_lite.loss.items()})
+                for n, mod in q.named_modules() if hasattr(mod, "awq_lite")}
+
+    base = run()
+    with algorithm_seam(monkeypatch):
+        ours = run()
+    assert sorted(base) == sorted(ours) and len(base) == 14
+    for n in base:
+        assert round(base[n][0], 2) == round(ours[n][0], 2), (n, base[n][0], ours[n][0])
+        assert sorted(base[n][1]) == sorted(ours[n][1])
+
+
+def test_a_model_outside_the_path_is_handed_back_and_counted(monkeypatch):
+    """A quantized Conv2d with an enabled weight quantizer is not a plain quantized nn.Linear: the reference's own
+    max_calibrate runs, the counter says why, and the result is the reference's."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    def net():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.Flatten(), torch.nn.Linear(8 * 6 * 6, 16)).eval()
+
+    x = torch.randn(4, 3, 8, 8, generator=torch.Generator().manual_seed(1))
+    base = mtq.quantize(net(), copy.deepcopy(mtq.INT8_DEFAULT_CFG), lambda m: m(x))
+    with algorithm_seam(monkeypatch) as (plugin, _):
+        ours = mtq.quantize(net(), copy.deepcopy(mtq.INT8_DEFAULT_CFG), lambda m: m(x))
+        stats = dict(plugin.STATS)
+    fell = [k for k in stats if k.startswith("S7:max_calibrate:fallback")]
+    assert fell and "Conv2d" in fell[0], stats
+    for (n, a), (_, b) in zip(base.state_dict().items(), ours.state_dict().items(), strict=True):
+        assert torch.equal(a, b), n
+
+
+def test_fold_weight_through_the_seam(monkeypatch):
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+
+    def run():
+        m = diff._model(torch.bfloat16, "llama")
+        batches = diff._batches()
+        q = mtq.quantize(m, copy.deepcopy(mtq.FP8_DEFAULT_CFG), lambda mm: [mm(b) for b in batches])
+        mtq.fold_weight(q)
+        with torch.no_grad():
+            return {n: t.clone() for n, t in q.state_dict().items()}, q(batches[0]).logits, q
+
+    base = run()
+    with algorithm_seam(monkeypatch) as (plugin, _):
+        ours = run()
+        assert plugin.STATS.get("S7:fold_weight", 0) == 1, dict(plugin.STATS)
+    assert sorted(base[0]) == sorted(ours[0])
+    for n in base[0]:
+        assert torch.equal(base[0][n], ours[0][n]), n
+    assert torch.equal(base[1], ours[1])
+    for (n, a), (_, b) in zip(base[2].named_modules(), ours[2].named_modules(), strict=True):
+        if n.endswith("weight_quantizer"):
+            assert a._disabled == b._disabled and sorted(a._buffers) == sorted(b._buffers), n
+
+
+def test_uninstall_puts_the_references_hooks_back():
+    ref_shim.install()
+    import modelopt.torch.quantization.mode as rmode
+    import modelopt.torch.quantization.model_calib as rmc
+    import modelopt.torch.quantization.model_quant as rmq
+
+    from model_optimizer_amd import modelopt_plugin
+
+    before = (rmode.MaxCalibrateModeDescriptor._calib_func, rmode.AWQLiteModeDescriptor._calib_func, rmc.max_calibrate,
+              rmc.weight_only_quantize, rmq.fold_weight)
+    modelopt_plugin.install(extensions=False, backend=False, utilities=False, sparsity_seam=False, algorithms=True)
+    try:
+        assert getattr(rmode.MaxCalibrateModeDescriptor._calib_func, "_moq_seam", False)
+        assert getattr(rmode.AWQLiteModeDescriptor._calib_func, "_moq_seam", False)
+        assert rmode.MaxCalibrateModeDescriptor._calib_func.__wrapped__ is before[0]
+    finally:
+        modelopt_plugin.uninstall()
+    after = (rmode.MaxCalibrateModeDescriptor._calib_func, rmode.AWQLiteModeDescriptor._calib_func, rmc.max_calibrate,
+             rmc.weight_only_quantize, rmq.fold_weight)
+    assert all(a is b for a, b in zip(before, after))
