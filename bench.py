@@ -11,8 +11,10 @@ One step = one pass of the hot path over ALL linear weights of a synthetic model
     fp8-mask24 (BASELINE configs[3] as ONE step): 2:4 magnitude masks + the masked weights in place + their per-tensor abs-max
              from one pass (5 B/element), [the amax bucket], FP8 QDQ of the sparse weights (4 B/element).
     mxfp4-sq (BASELINE configs[4]): SmoothQuant fold W <- dtype(W * (1/s)[col]) of every weight (model_calib.
-             apply_pre_quant_scale_and_smooth; one launch per tensor) followed by the MXFP4 g = 32 quantize-dequantize of
-             the whole model in one launch; 4 + 4 B/element.
+             apply_pre_quant_scale_and_smooth) composed with the MXFP4 g = 32 quantize-dequantize, the whole model in ONE
+             launch (multi_tensor.fold_mx_fused = moq_mt_fold_mx_fused: what smoothquant(fold_weights=True) runs): one read
+             + one write, 4 B/element (+ the column scales, 4 B per column, L2-resident).  Rounds 2-5 ran it as 560
+             scale_cols launches + the MX launch: 8 B/element, 96.0 ms/step on Llama-3-70B.
 `value` = weight bytes of the WHOLE pool (2 B/element) / wall time per step.
 
 Which model (when --model is not given):
@@ -283,7 +285,7 @@ ALG_BYTES_PER_ELEM = {"fp8": 4.0, "int8": 4.0, "int4g128": 4.0 + 4.0 / 128, "mxf
                       "fp8-mask24": 5.0}
 DOM_KERNEL = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf16, OpIntQdq>",
               "int4g128": "mt_group_kernel<bf16, 16>", "mxfp4": "mt_mx_kernel<bf16, 4, E2M1>",
-              "mxfp4-sq": "mt_mx_kernel<bf16, 4, E2M1>", "mask24": "mt_mask24_kernel<bf16>",
+              "mxfp4-sq": "mt_fold_mx_kernel<bf16, 4, E2M1>", "mask24": "mt_mask24_kernel<bf16>",
               "fp8-mask24": "mt_mask24_apply_kernel<bf16>"}
 
 
@@ -377,7 +379,7 @@ class Pool:
             groups.append(cur)
             self.groups = [SegmentTable([self.weights[i] for i in g], outputs=[self.tab.outputs[i] for i in g])
                            for g in groups]
-        self.fold_scales = None
+        self.fold_scales = self.fold_sides = None
         if wl == "mxfp4-sq":
             # per-channel SmoothQuant scales of each tensor (synthetic, log-normal); steps alternate s and 1/s so that the
             # in-place fold keeps the weights' magnitude over many steps
@@ -386,6 +388,8 @@ class Pool:
             for w in self.weights:
                 sv = torch.exp(0.5 * torch.randn(w.shape[1], generator=gs, device=dev, dtype=torch.float32))
                 self.fold_scales.append((sv, 1.0 / sv))
+            # the side tables of the two alternating launches, built once (scale pointers + row lengths beside the segments)
+            self.fold_sides = [self.tab.fold_side([sv[k] for sv in self.fold_scales], 32) for k in (0, 1)]
         self.step_no = 0
         self.masks = self.mask_tab = None
         if wl in ("mask24", "fp8-mask24"):
@@ -394,7 +398,7 @@ class Pool:
         self.dom_events = []
 
     def release(self):
-        self.tab = self.groups = self.weights = self.masks = self.mask_tab = self.fold_scales = None
+        self.tab = self.groups = self.weights = self.masks = self.mask_tab = self.fold_scales = self.fold_sides = None
         torch.cuda.empty_cache()
 
     def step(self, record, collective=True):
@@ -463,10 +467,8 @@ class Pool:
         elif wl == "mxfp4-sq":
             k = self.step_no & 1
             self.step_no += 1
-            for w, sv in zip(self.weights, self.fold_scales):
-                self.moa.ops.scale_cols(w, sv[k], out=w)  # the fold: fp32 multiply, one rounding, in place
             start()
-            tab.mx_fused_amax_convert(32, "E2M1")
+            tab.fold_mx_fused(block_size=32, fmt="E2M1", side=self.fold_sides[k])  # fold + MXFP4 QDQ of every weight, in place
             stop()
         elif wl == "mxfp4":
             start()
@@ -778,6 +780,27 @@ def main():
                 extra["llama3_70b_int4g128_inplace"] = {
                     "ms": round(ms, 3), "weights_GB": round(n70 * 2 / 1e9, 2), "weights_GBs": round(n70 * 2 / ms / 1e6, 1),
                     "hbm_GBs": round(b / ms / 1e6, 1), "frac_of_8TBs": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                # BASELINE configs[4] on the same tensors: SmoothQuant's fold composed with MXFP4 g32, ONE launch in place
+                # (4 B/element; the two-pass form of rounds 2-5 moved 8)
+                try:
+                    gs = torch.Generator(device=dev).manual_seed(99)
+                    svs = [torch.exp(0.5 * torch.randn(w.shape[1], generator=gs, device=dev, dtype=torch.float32)) for w in w70]
+                    tmx = SegmentTable(w70, outputs=w70)
+                    sides = [tmx.fold_side(svs, 32), tmx.fold_side([1.0 / v for v in svs], 32)]
+                    flip = [0]
+
+                    def fold_step():
+                        tmx.fold_mx_fused(block_size=32, fmt="E2M1", side=sides[flip[0] & 1])
+                        flip[0] += 1
+
+                    ms = timed(fold_step, reps=4)
+                    extra["llama3_70b_mxfp4_sq"] = {
+                        "ms": round(ms, 3), "weights_GB": round(n70 * 2 / 1e9, 2), "weights_GBs": round(n70 * 2 / ms / 1e6, 1),
+                        "hbm_GBs": round(n70 * 4.0 / ms / 1e6, 1), "frac_of_8TBs": round(n70 * 4.0 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "launches_per_step": 1, "kernel": "mt_fold_mx_kernel<bf16, 4, E2M1>"}
+                    del tmx, sides, svs
+                except Exception as e:
+                    extra["llama3_70b_mxfp4_sq"] = {"failed": f"{type(e).__name__}: {e}"}
                 del t70, w70
                 torch.cuda.empty_cache()
         except Exception as e:  # a reported extra, never a reason to lose the main result

@@ -194,6 +194,26 @@ int moq_mt_mask_2to4_apply(const moq_seg* segs, const int64_t* blk_start, int n_
  * n % block == 0; E8M0 scales.  segs[s].amax is not used. */
 int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* blk_start, int n_seg, int64_t n_chunks,
                                  int block, int dt, int fmt, void* stream);
+/* SmoothQuant's weight fold composed with the dynamic MX block QDQ, every segment in ONE launch, one read and one write
+ * per element:  y_s = MXQDQ_{block, fmt}( dt( x_s * scale_s[col] ) )  -- _apply_weight_pre_quant_scale
+ * (quantization/model_calib.py:1208-1216: `(weight * pre_quant_scale[None, :]).to(weight.dtype)`, fp32 product, one
+ * rounding) followed by the weight quantizer's MX fake quantization (tensor_quant_mx.cu:239-294, E8M0 block scales) -- the
+ * MX twin of moq_awq_scale_qdq, bit-equal to moq_scale_cols followed by moq_mt_mx_fused_amax_convert (BASELINE configs[4]:
+ * Llama-3-70B MXFP4 g32 + SmoothQuant moved 8 B/element that way, 4 here).  side[s] rides beside segs[s]:
+ * scale = the segment's fp32 column vector [cols] (NULL: no fold for this segment), cols = its row length
+ * (cols % block == 0).  Same layout rules as moq_mt_mx_fused_amax_convert; x == y allowed. */
+typedef struct moq_fold_seg {
+  const float* scale; /* fp32 [cols] multiplied into every row before the block QDQ / pack; NULL = none */
+  int64_t cols;       /* row length of the segment's tensor                                              */
+  uint8_t* e8m0;      /* moq_mt_fold_mxfp4_pack: the segment's E8M0 block scales [n / block]; else unused */
+} moq_fold_seg;
+int moq_mt_fold_mx_fused(const moq_seg* segs, const int64_t* blk_start, const moq_fold_seg* side, int n_seg,
+                         int64_t n_chunks, int block, int dt, int fmt, void* stream);
+/* The PTQ-to-checkpoint form of the same pass: MXFP4QTensor.quantize (qtensor/mxfp4_tensor.py:37-81, as moq_mxfp4_pack)
+ * of dt(x_s * scale_s[col]) for every segment in one launch -- segs[s].y = the packed E2M1 nibbles (uint8 [n / 2]),
+ * side[s].e8m0 = the block exponents (uint8 [n / block]).  2 B read, 0.5 + 1/block B written per element. */
+int moq_mt_fold_mxfp4_pack(const moq_seg* segs, const int64_t* blk_start, const moq_fold_seg* side, int n_seg,
+                           int64_t n_chunks, int block, int dt, void* stream);
 
 /* ------------------------------------------------------------------ MX dynamic block QDQ (a8) */
 

@@ -62,6 +62,8 @@ SIGNATURES = {
     "moq_mt_mask_2to4": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "moq_mt_mask_2to4_apply": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p]),
     "moq_mt_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "moq_mt_fold_mx_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p]),
+    "moq_mt_fold_mxfp4_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "moq_mx_fused_amax_convert": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                           c_void_p, c_void_p]),
     "moq_col_abs_mean_accum": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p]),

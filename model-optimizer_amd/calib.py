@@ -65,7 +65,7 @@ class DeferredAmax:
 
     current = None  # the instance statistics collection runs under, or None (every request is its own launch)
 
-    def __init__(self, device, limit_bytes: int = 1 << 30):
+    def __init__(self, device, limit_bytes: int = 1 << 30, probation: bool = False):
         self.device = torch.device(device)
         self.limit_bytes = int(limit_bytes)
         self.entries = {}      # id(tensor) -> [tensor, version, [running-max buffers]]
@@ -73,9 +73,23 @@ class DeferredAmax:
         self.dt = None
         self.tables = {}       # content key -> (device int64 table, n_seg, n_chunks, n_folds, scratch)
         self.stats = {"requests": 0, "flushes": 0, "tensors": 0, "table_builds": 0, "bytes": 0}
+        # probation (the AUTOMATIC choice of max_calibrate, defer_stats=None): nobody promised that the model leaves a noted
+        # tensor alone until the end of its decoder layer, so the FIRST pass through every flush point answers each request with
+        # its own launch (add() returns False) and only WATCHES the tensors' version counters; a write seen there switches
+        # deferral off for the rest of the calibration -- no statistic is lost, nothing raises -- and a clean first pass
+        # (whether a model writes its activations in place is a property of its code, not of the batch) switches it on
+        self.probation = bool(probation)
+        self.watched = []      # probation: (tensor, version when its quantizer saw it)
+        self.flushed_keys = set()
+        self.disabled = False
 
     def add(self, x, dt_code, buf) -> bool:
-        if x.device != self.device or (self.dt is not None and dt_code != self.dt):
+        if self.disabled or x.device != self.device or (self.dt is not None and dt_code != self.dt):
+            return False
+        if x.is_inference():  # (no version counter to watch: `forward_loop` under torch.inference_mode())
+            return False
+        if self.probation:
+            self.watched.append((x, x._version))
             return False
         ent = self.entries.get(id(x))
         if ent is None or ent[0] is not x:
@@ -129,7 +143,18 @@ class DeferredAmax:
         if rc:
             _lib.check(rc)
 
-    def flush(self):
+    def flush(self, key=None):
+        """key: which flush point this is (a decoder layer); the second visit of a point ends the probation."""
+        if self.probation:
+            if any(x._version != v for x, v in self.watched):
+                self.disabled, self.probation = True, False
+                self.stats["disabled_by_inplace_write"] = True
+            self.watched = []
+            if key is not None and not self.disabled:
+                if key in self.flushed_keys:
+                    self.probation = False  # one clean pass through every flush point: deferral is on from here
+                self.flushed_keys.add(key)
+            return
         if not self.entries:
             return
         ents, self.entries, self.bytes = list(self.entries.values()), {}, 0

@@ -158,6 +158,84 @@ __global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict
                       (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
   }
 }
+// SmoothQuant fold + MX QDQ in one pass over a segment table (moq_mt_fold_mx_fused): the element is multiplied by its column's
+// fp32 scale and rounded to the storage dtype -- what the separate fold writes back to memory -- before the block abs-max is
+// taken.  The column of a chunk's first element costs one 64-bit remainder per chunk (workgroup-uniform); a packet's column
+// is that plus its offset, wrapped by compare-and-subtract when a row is at least a chunk long (every Llama weight) and by
+// a 32-bit remainder otherwise.  A packet never straddles a row (cols % block == 0, block % kVec == 0).
+template <int DT>
+__device__ __forceinline__ uint32_t fold_col(uint32_t c0, int off, uint32_t cols) {
+  uint32_t t = c0 + (uint32_t)off;
+  if (cols >= (uint32_t)MOQ_MT_CHUNK) return t >= cols ? t - cols : t;
+  return t % cols;
+}
+template <int DT>
+__device__ __forceinline__ void fold_load(const float* __restrict__ scale, uint32_t col, float (&sf)[8]) {
+  constexpr int V = Elem<DT>::kVec;
+  const float4 a = *reinterpret_cast<const float4*>(scale + col);
+  sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w;
+  if constexpr (V == 8) {
+    const float4 b = *reinterpret_cast<const float4*>(scale + col + 4);
+    sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+  }
+}
+template <int DT, int LPG>
+__device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f,
+                                              const MxScaleE8M0& scale_of, const float* __restrict__ scale, uint32_t cols) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  constexpr int ES = 16 / V;
+  Pack16 in[P];
+  float sf[P][8];
+  const uint32_t c0 = (uint32_t)(e0 % (int64_t)cols);
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    if (e < n) in[u] = load16_nt(xb + e * ES);
+    else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+  }
+#pragma unroll
+  for (int u = 0; u < P; ++u) fold_load<DT>(scale, fold_col<DT>(c0, packet_off<DT>(u), cols), sf[u]);
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const int64_t e = e0 + packet_off<DT>(u);
+    float v[8];
+    unpack<DT>(in[u], v);
+    float am = 0.0f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      v[i] = round_to_dtype<DT>(v[i] * sf[u][i]);
+      am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+    }
+    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
+    float sc, un;
+    scale_of(am, sc, un);
+#pragma unroll
+    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+    if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
+  }
+}
+template <int DT, int LPG, int FMT>
+__global__ __launch_bounds__(kBlock) void mt_fold_mx_kernel(const moq_seg* __restrict__ segs,
+                                                            const int64_t* __restrict__ blk_start,
+                                                            const moq_fold_seg* __restrict__ side, int n_seg,
+                                                            int64_t n_chunks, int fmt) {
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  const MxFmt f = mx_fmt(FMT >= 0 ? FMT : fmt);
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  moq_fold_seg sd = side[cur.s];
+  const MxScaleE8M0 scale_of{f.maxv};
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    if (cur.seek(c)) sd = side[cur.s];
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
+    if (sd.scale != nullptr)
+      mx_fold_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y), e0, cur.sg.n, f,
+                             scale_of, sd.scale, (uint32_t)sd.cols);
+    else
+      mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y), e0, cur.sg.n, f, scale_of);
+  }
+}
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding), any alignment and
 // every block-scale format (scale_fmt == MOQ_E8M0: the exponent/mantissa test; else the general path above)
 template <int DT>
@@ -949,6 +1027,40 @@ extern "C" int moq_mt_mx_fused_amax_convert(const moq_seg* segs, const int64_t* 
 #undef MOQ_MTMX_CASE
 #undef MOQ_MTMX_LAUNCH
   return check_launch("moq_mt_mx_fused_amax_convert");
+}
+
+extern "C" int moq_mt_fold_mx_fused(const moq_seg* segs, const int64_t* blk_start, const moq_fold_seg* side, int n_seg,
+                                    int64_t n_chunks, int block, int dt, int fmt, void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr || side == nullptr))) {
+    set_error("moq_mt_fold_mx_fused: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  if (mx_fmt(fmt).kind < 0) {
+    set_error("moq_mt_fold_mx_fused: unknown element format %d", fmt);
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = block / vec;
+  if (block <= 0 || block % vec != 0 || lpg > 8 || (lpg & (lpg - 1)) != 0) {
+    set_error("moq_mt_fold_mx_fused: block sizes %d..%d (powers of two) are supported, got %d", vec, 8 * vec, block);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
+  const int grid = copy_grid(n_chunks);
+#define MOQ_MTFM_LAUNCH(L, F) \
+  MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_fold_mx_kernel<DT, L, F>), dim3(grid), dim3(kBlock), copy_lds(24 * 1024), S(stream), segs, blk_start, side, n_seg, n_chunks, fmt))
+#define MOQ_MTFM_CASE(L)                                     \
+  case L:                                                    \
+    if (fmt == MOQ_E2M1) { MOQ_MTFM_LAUNCH(L, MOQ_E2M1); }   \
+    else { MOQ_MTFM_LAUNCH(L, -1); }                         \
+    break;
+  switch (lpg) {
+    MOQ_MTFM_CASE(1) MOQ_MTFM_CASE(2) MOQ_MTFM_CASE(4) MOQ_MTFM_CASE(8)
+    default: set_error("unreachable"); return MOQ_ERR_INVALID;
+  }
+#undef MOQ_MTFM_CASE
+#undef MOQ_MTFM_LAUNCH
+  return check_launch("moq_mt_fold_mx_fused");
 }
 
 extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long* counts, int bins,

@@ -318,6 +318,85 @@ __global__ __launch_bounds__(kBlock) void mxfp4_pack_kernel(const void* __restri
     }
   }
 }
+// the same over a segment table, with SmoothQuant's column fold in front (moq_mt_fold_mxfp4_pack): the block exponent and the
+// nibbles are taken from dt(x * scale[col]), the value the separate fold would have written back
+template <int DT, int LPG>
+__global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_seg* __restrict__ segs,
+                                                                    const int64_t* __restrict__ blk_start,
+                                                                    const moq_fold_seg* __restrict__ side, int n_seg,
+                                                                    int64_t n_chunks, int block_shift) {
+  constexpr int V = Elem<DT>::kVec;
+  constexpr int P = Chunk<DT>::kPackets;
+  if ((int64_t)blockIdx.x >= n_chunks) return;
+  const int lane = threadIdx.x & 63;
+  SegCursor cur;
+  cur.init(segs, blk_start, n_seg, blockIdx.x);
+  moq_fold_seg sd = side[cur.s];
+  for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    if (cur.seek(c)) sd = side[cur.s];
+    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK, n = cur.sg.n;
+    const char* x = reinterpret_cast<const char*>(cur.sg.x);
+    uint8_t* packed = reinterpret_cast<uint8_t*>(cur.sg.y);
+    Pack16 in[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      if (e < n) in[u] = load16_nt(x + e * (16 / V));
+      else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+    }
+    const bool fold = sd.scale != nullptr;  // (workgroup-uniform)
+    const uint32_t cols = (uint32_t)sd.cols;
+    const uint32_t c0 = fold ? (uint32_t)(e0 % (int64_t)cols) : 0u;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const int64_t e = e0 + packet_off<DT>(u);
+      float v[8];
+      unpack<DT>(in[u], v);
+      uint32_t m;
+      if (fold) {
+        uint32_t t = c0 + (uint32_t)packet_off<DT>(u);
+        t = cols >= (uint32_t)MOQ_MT_CHUNK ? (t >= cols ? t - cols : t) : t % cols;
+        const float4 a = *reinterpret_cast<const float4*>(sd.scale + t);
+        float sf[8] = {a.x, a.y, a.z, a.w, 1.0f, 1.0f, 1.0f, 1.0f};
+        if constexpr (V == 8) {
+          const float4 b = *reinterpret_cast<const float4*>(sd.scale + t + 4);
+          sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+        }
+        m = 0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          v[i] = round_to_dtype<DT>(v[i] * sf[i]);
+          const uint32_t ab = absbits(v[i]);
+          m = ab > m ? ab : m;
+        }
+      } else {
+        m = pack_absmax<DT>(in[u]);
+      }
+      const uint32_t amax_bits = group_max_u32<LPG>(m);
+      const int ex = mxfp4_exponent(__uint_as_float(amax_bits));
+      const float inv = pow2i(-ex);
+      uint32_t word = 0;
+      if (amax_bits <= 0x7F800000u) {
+#pragma unroll
+        for (int i = 0; i < V; i += 2) {
+          const uint32_t lo = mxfp4_nibble<true>(v[i] * inv), hi = mxfp4_nibble<true>(v[i + 1] * inv);
+          word |= ((hi << 4) + lo) << (8 * (i / 2));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; i += 2) {
+          const uint32_t lo = mxfp4_nibble(v[i] * inv), hi = mxfp4_nibble(v[i + 1] * inv);
+          word |= ((hi << 4) + lo) << (8 * (i / 2));
+        }
+      }
+      if (e < n) {
+        if constexpr (V == 8) __builtin_nontemporal_store(word, reinterpret_cast<uint32_t*>(packed + e / 2));
+        else *reinterpret_cast<uint16_t*>(packed + e / 2) = (uint16_t)word;
+        if ((lane & (LPG - 1)) == 0) sd.e8m0[e >> block_shift] = (uint8_t)(ex + 127);
+      }
+    }
+  }
+}
 template <int DT>
 __global__ __launch_bounds__(kBlock) void mxfp4_generic_pack_kernel(const void* __restrict__ x,
                                                                     uint8_t* __restrict__ packed,
@@ -716,6 +795,31 @@ extern "C" int moq_fp8_unpack(const uint8_t* q, const void* scales, void* out, i
                                               scales, out, n, (int64_t)1, (int64_t)1, 0, 0));
   }
   return check_launch("moq_fp8_unpack");
+}
+
+extern "C" int moq_mt_fold_mxfp4_pack(const moq_seg* segs, const int64_t* blk_start, const moq_fold_seg* side, int n_seg,
+                                      int64_t n_chunks, int block, int dt, void* stream) {
+  if (n_seg < 0 || n_chunks < 0 || (n_seg > 0 && (segs == nullptr || blk_start == nullptr || side == nullptr))) {
+    set_error("moq_mt_fold_mxfp4_pack: null pointer or negative size");
+    return MOQ_ERR_INVALID;
+  }
+  const int vec = dt == MOQ_F32 ? 4 : 8;
+  const int lpg = block / vec;
+  if (block <= 0 || block % vec != 0 || lpg > 64 || (lpg & (lpg - 1)) != 0) {
+    set_error("moq_mt_fold_mxfp4_pack: block sizes %d..%d (powers of two) are supported, got %d", vec, 64 * vec, block);
+    return MOQ_ERR_UNSUPPORTED;
+  }
+  if (n_seg == 0 || n_chunks == 0) return MOQ_OK;
+  const int grid = copy_grid(n_chunks);
+  const int bs = log2_or_neg(block);
+#define MOQ_MTFP_CASE(L) \
+  case L: MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((mt_fold_mxfp4_pack_kernel<DT, L>), dim3(grid), dim3(kBlock), copy_lds_1t(), S(stream), segs, blk_start, side, n_seg, n_chunks, bs)); break;
+  switch (lpg) {
+    MOQ_MTFP_CASE(1) MOQ_MTFP_CASE(2) MOQ_MTFP_CASE(4) MOQ_MTFP_CASE(8) MOQ_MTFP_CASE(16) MOQ_MTFP_CASE(32) MOQ_MTFP_CASE(64)
+    default: set_error("unreachable"); return MOQ_ERR_INVALID;
+  }
+#undef MOQ_MTFP_CASE
+  return check_launch("moq_mt_fold_mxfp4_pack");
 }
 
 extern "C" int moq_mxfp4_pack(const void* x, uint8_t* packed, uint8_t* e8m0, int64_t n_blocks, int block, int dt,

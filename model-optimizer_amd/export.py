@@ -386,8 +386,13 @@ def _checkpoint_rename_rules(model):
         if type(item).__name__ == "WeightRenaming":
             try:
                 rev = item.reverse_transform()
-            except Exception:  # noqa: BLE001
-                continue
+            except Exception as e:  # noqa: BLE001
+                # all or nothing (the reference's _build_reverse_rules, export/quant_aware_conversion.py: a rule it cannot
+                # reverse keeps the module-tree names for tensors AND tables): a checkpoint with only some keys renamed
+                # would mix two namespaces
+                warnings.warn(f"checkpoint names: a renaming rule of {type(model).__name__} cannot be reversed ({e}); the "
+                              "checkpoint keeps the module names")
+                return []
             scope = getattr(rev, "scope_prefix", None)
             prefixes = ()
             if scope is not None:  # a sub-model's rule applies under its own path only (:323-345)
@@ -404,6 +409,12 @@ def _checkpoint_rename_rules(model):
                 m = re.search(r"experts\.\*\.([A-Za-z0-9_]+)\.weight$", pat)
                 if m and m.group(1) != our_name:
                     rules.append(("expert", our_name, m.group(1)))
+        elif type(item).__name__ == "WeightConverter":
+            # a converter other than the two fused-experts shapes (a dense fused tensor the hub stores in pieces, a scoped
+            # converter): un-fusing it is outside this path -- module names for everything, as above
+            warnings.warn(f"checkpoint names: {type(model).__name__} has a weight converter outside this path "
+                          f"({src} -> {tgt}); the checkpoint keeps the module names")
+            return []
     return rules
 
 
@@ -630,13 +641,22 @@ def _in_module_tree_order(state: dict, model) -> dict:
 
     place = {k: i for i, k in enumerate(model.state_dict().keys())}
     kv_source = {new: old for old, new in _KV_CACHE_REPLACEMENTS.items()}
+    # where every `...experts` container's first tensor stood -- one pass over the model's keys (asking per exported key would
+    # be (exported keys) x (state-dict keys) prefix tests: hours for 58 layers x 256 per-expert linears)
+    anchors: dict = {}
+    for k, pos in place.items():
+        head = k
+        while "." in head:
+            head = head.rpartition(".")[0]
+            if head.endswith("experts") and pos < anchors.get(head, len(place) + 1):
+                anchors[head] = pos
 
     def rank(item):
         i, key = item
         owner, _, leaf = key.rpartition(".")
         m = re.match(r"(.*\bexperts)\.(\d+)\.([A-Za-z0-9_]+)\.([A-Za-z0-9_]+)$", key)
         if m and m.group(3) in _EXPERT_PROJ_RANK:  # an expanded container: where its first fused parameter stood
-            anchor = min((p for k, p in place.items() if k.startswith(m.group(1) + ".")), default=None)
+            anchor = anchors.get(m.group(1))
             if anchor is not None:
                 return (anchor, 0, int(m.group(2)), _EXPERT_PROJ_RANK[m.group(3)], _SCALE_RANK.get(m.group(4), 5), i)
         if key in place:

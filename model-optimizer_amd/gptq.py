@@ -256,7 +256,7 @@ class GPTQHelper:
                 h_in = iq(x)
                 key = None  # a quantized copy: nothing to share by identity
             else:
-                h_in, key = x, x
+                h_in, key = x, (None if x.is_inference() else x)  # (inference tensors carry no version counter: no sharing)
             # the same tensor OBJECT in the same state (an in-place write in between makes it another input), and only a
             # helper that has no samples of its own may start following: its accumulated Hessian would be dropped
             first = shared.get("input") is key and key is not None and shared.get("version") == key._version

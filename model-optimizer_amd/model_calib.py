@@ -226,8 +226,10 @@ def max_calibrate(model: nn.Module, forward_loop=None, distributed_sync: bool = 
             else:
                 from . import calib as _calib
 
-                batch = _calib.DeferredAmax(plan[0])
-                hooks = [layer.register_forward_hook(lambda *_a, _b=batch: _b.flush()) for layer in plan[1]]
+                # (defer_stats=None: nobody vouched for the model -- the first pass through the layers only watches, see
+                # DeferredAmax.probation; defer_stats=True: deferred from the first request, a write is an error)
+                batch = _calib.DeferredAmax(plan[0], probation=defer_stats is None)
+                hooks = [layer.register_forward_hook(lambda *_a, _b=batch, _k=id(layer): _b.flush(key=_k)) for layer in plan[1]]
                 _calib.DeferredAmax.current = batch
                 try:
                     forward_loop(model)
@@ -514,22 +516,50 @@ def local_hessian_calibrate(model: nn.Module, forward_loop=None, distributed_syn
 
 # ------------------------------------------------------------------------------------------------ smoothquant
 @torch.no_grad()
-def apply_pre_quant_scale_and_smooth(linear: QuantLinear, pre_quant_scale: torch.Tensor):
+def apply_pre_quant_scale_and_smooth(linear: QuantLinear, pre_quant_scale: torch.Tensor, fold_later: list | None = None):
     """model_calib.py:1226-1270: input quantizer gets s (in W.dtype), W <- (W * (1/s)_fp32).to(dtype),
-    weight amax recalibrated, input amax <- max(amax_for_smoothing * s)."""
+    weight amax recalibrated, input amax <- max(amax_for_smoothing * s).
+
+    fold_later: a list that takes (linear, 1/s) INSTEAD of the weight being folded and re-calibrated here -- the caller folds
+    all of them in one launch that also bakes the weight quantizer in (smoothquant(fold_weights=True))."""
     assert linear.input_quantizer.pre_quant_scale is None, "pre_quant_scale should be None first!"
     assert torch.all(pre_quant_scale > 0), "pre_quant_scale should be positive"
     pre_quant_scale = pre_quant_scale.to(torch.float32)
     linear.input_quantizer._enable_pre_quant_scale = True
     linear.input_quantizer.pre_quant_scale = pre_quant_scale.to(linear.weight.dtype)
     inv_scale = 1.0 / pre_quant_scale
-    ops.scale_cols(linear.weight.data, inv_scale, out=linear.weight.data)  # fp32 multiply, one rounding
-    linear.weight_quantizer.reset_amax()
-    max_calibrate(linear, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
+    if fold_later is not None:
+        fold_later.append((linear, inv_scale))
+    else:
+        ops.scale_cols(linear.weight.data, inv_scale, out=linear.weight.data)  # fp32 multiply, one rounding
+        linear.weight_quantizer.reset_amax()
+        max_calibrate(linear, lambda lin: lin.weight_quantizer(lin.weight), distributed_sync=False)
     if linear.input_quantizer.amax is not None:
         dev, dt = linear.weight.device, linear.weight.dtype
         a = linear.input_quantizer._amax_for_smoothing.to(device=dev, dtype=dt)
         linear.input_quantizer.amax = (a * pre_quant_scale.to(dev)).amax().to(dt)
+
+
+_MX_ELEMENT_FORMATS = {(2, 1): "E2M1", (4, 3): "E4M3", (5, 2): "E5M2", (3, 2): "E3M2", (2, 3): "E2M3", 8: "INT8"}
+
+
+def _fold_rides_in_mx(m) -> tuple | None:
+    """(block, element format) when this linear's fold W <- dt(W / s) can ride inside its MX weight quantizer's fake
+    quantization (ops: moq_mt_fold_mx_fused): a dynamic-block E8M0 quantizer along the last axis of a dense 2-D GPU weight --
+    nothing to re-calibrate after the fold (block scales come from every input), so fold + QDQ is one read and one write."""
+    wq, w = m.weight_quantizer, m.weight
+    if not isinstance(wq, TensorQuantizer) or not wq.is_enabled or not wq.is_mx_format or wq.pre_quant_scale is not None:
+        return None
+    nb = tuple(wq._num_bits) if isinstance(wq._num_bits, (list, tuple)) else wq._num_bits
+    fmt = _MX_ELEMENT_FORMATS.get(nb)
+    if fmt is None or not set(wq._block_sizes) <= {-1, w.dim() - 1, "type", "scale_bits"}:
+        return None
+    g = wq._block_sizes.get(-1, None) or wq._block_sizes.get(w.dim() - 1, None)
+    vec = 4 if w.dtype == torch.float32 else 8
+    if (not g or w.dim() != 2 or not ops._is_gpu(w) or not w.is_contiguous() or w.data_ptr() % 16 or w.shape[-1] % g
+            or w.dtype not in (torch.float32, torch.float16, torch.bfloat16) or g % vec or (g // vec) not in (1, 2, 4, 8)):
+        return None
+    return int(g), fmt
 
 
 def _broadcast_smoothed(linears, group):
@@ -553,7 +583,7 @@ def _broadcast_smoothed(linears, group):
 
 @torch.no_grad()
 def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str = "int8",
-                shard_weights: bool | None = None):
+                shard_weights: bool | None = None, fold_weights: bool = False):
     """model_calib.py:1273-1359.
 
     shard_weights (data-parallel replicas; None follows distributed.declare_data_parallel): the weight side of the
@@ -568,7 +598,14 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
               scaling composed with MXFP4 (g = 32, E8M0 block scales).  Per-tensor formats get the reference's
               post-smoothing input amax max(act_amax * s); dynamic-block (MX) quantizers, which recompute their block
               scales from every input, keep no amax at all.  The scales and folded weights are bit-identical to the
-              reference's INT8 run on the same model (tests/test_host_flows_cpu.py: sq_mxfp4 fixture)."""
+              reference's INT8 run on the same model (tests/test_host_flows_cpu.py: sq_mxfp4 fixture).
+
+    fold_weights = True: the call ends like `smoothquant(...); model_quant.fold_weight(model)` -- every weight quantizer baked
+              into its weight and switched off (mtq.fold_weight, model_quant.py:728-736) -- and the result is that sequence's
+              bit for bit; but a linear whose weight quantizer is a dynamic MX block format (configs[4]: MXFP4 g32) is neither
+              folded nor re-calibrated on the way: its smoothing fold rides INSIDE the MX quantize-dequantize, all such
+              linears in ONE launch at one read + one write per element (multi_tensor.fold_mx_fused) instead of the fold's read
+              + write, the re-calibration's read and the QDQ's read + write."""
     assert forward_loop is not None, "forward_loop must be provided for smoothquant"
     if formats not in ("int8", "all"):
         raise ValueError(f"smoothquant: formats must be 'int8' or 'all', got {formats!r}")
@@ -580,6 +617,7 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
     world, me = (dist.get_world_size(mdist.replica_group()), dist.get_rank(mdist.replica_group())) if shard else (1, 0)
     smoothed = 0
     dealt = []
+    fold_later = []  # (linear, 1 / s) whose fold rides inside the MX QDQ (fold_weights=True)
     for name, m in model.named_modules():
         if not is_quantized_linear(m):
             continue
@@ -617,10 +655,23 @@ def smoothquant(model: nn.Module, forward_loop, alpha: float = 1.0, formats: str
         if scale_a.min() <= epsilon:
             scale_a[act_amax <= epsilon] = 1
         scale_a = scale_a.clamp(min=1e-4, max=1e4)
-        apply_pre_quant_scale_and_smooth(m, scale_a)
+        rides = fold_weights and not shard and _fold_rides_in_mx(m) is not None
+        apply_pre_quant_scale_and_smooth(m, scale_a, fold_later=fold_later if rides else None)
         smoothed += 1
     if shard and dealt:
         _broadcast_smoothed(dealt, mdist.replica_group())
+    if fold_weights:
+        groups = {}
+        for m, inv_scale in fold_later:
+            groups.setdefault((_fold_rides_in_mx(m), m.weight.dtype, m.weight.device), []).append((m, inv_scale))
+        for ((block, fmt), _, _), pairs in groups.items():
+            ws = [m.weight.data for m, _ in pairs]
+            SegmentTable(ws, outputs=ws).fold_mx_fused([s for _, s in pairs], block, fmt)
+        for m, _ in fold_later:
+            m.weight_quantizer.disable()  # baked in; fold_weight below leaves it alone and drops what it holds
+        from .model_quant import fold_weight
+
+        fold_weight(model, shard_weights=shard_weights)
     return smoothed
 
 
@@ -1107,7 +1158,8 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
              with the linear's own un-folded weight, and only for the linears that have candidates to re-score.  A stored
              tensor that was written in place afterwards (its version counter moved) sends the pass back to a real forward.
              "auto" (default) = "inputs" for search="auto" when no other quantizer is enabled (their noise belongs to a real
-             search pass), else off.  False = always a second forward.
+             search pass), else off; an automatic store stops at a quarter of the HBM budget (the forward's own peak is not in
+             that budget) and the pass is then a real one.  False = always a second forward.
     layer_local (None = for search="auto" on Hugging Face decoder stacks): the model is walked ONE DECODER LAYER AT A TIME
              (layerwise.py's contract: layer N+1's input is layer N's output): the layer's batches run through it once --
              statistics, Gram matrices, stored activations and the inputs of the next layer all come from that one
@@ -1169,7 +1221,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         raise ValueError(f"awq_lite: store_activations must be True, False, 'inputs' or 'auto', got {store_activations!r}")
     store_mode = {True: "full", False: False, "inputs": "inputs"}.get(store_activations, "inputs" if search == "auto" else False)
     state = {"mode": "cache", "do_gemm": True, "do_exact": False, "store": store_mode, "stored_bytes": 0,
-             "store_last": None, "store_seen": {}}
+             "store_last": None, "store_seen": {}, "store_cap": None}
     if mods:
         budget = _WeightCacheBudget(mods[0][1].weight.device)
         for _, m in mods:
@@ -1194,6 +1246,12 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
     state["gram_pass"] = "search" if others else "cache"
     if others:
         state["store"] = False  # the search pass must SEE the other quantizers' noise: nothing of the cache pass is reusable
+    if state["store"] and store_activations == "auto" and mods:
+        # nobody asked for the store: in the whole-model flow the kept inputs of EVERY searched linear and batch share the HBM
+        # with the forward's own peak activations, which the budget (a fraction of what was free at setup) does not see --
+        # the automatic store stops at a quarter of that budget and the search pass is then a real forward, where an
+        # explicit store_activations=True / "inputs" may take all of it
+        state["store_cap"] = budget.left // 4
 
     def accumulate_gram(h, input, x2):
         h.num_gram_steps += 1
@@ -1293,6 +1351,14 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
         """store_activations: keep this batch's input and out_actual of this linear for the replayed exact pass.  The
         tensors exist anyway -- the store only keeps them alive -- and are charged to the HBM budget (an input shared by
         q / k / v or gate / up once)."""
+        if state["store"] == "inputs" and input.is_inference():
+            # (forward_loop under torch.inference_mode(): no version counter says whether the tensor is still what the cache
+            # pass read when the replay gets to it -- nothing is stored, the search pass is a real forward)
+            drop_stores()
+            return
+        if state["store_cap"] is not None and state["stored_bytes"] + x2.numel() * x2.element_size() > state["store_cap"]:
+            drop_stores()
+            return
         if state["store"] == "inputs":
             # the input only, charged once per distinct tensor object (kept alive in `store_seen`, so an id cannot be
             # reused); out_actual is recomputed by the replay from the linear's own weight

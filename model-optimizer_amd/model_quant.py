@@ -583,6 +583,7 @@ class set_quantizer_by_cfg_context:
             q.__dict__["_calibrator"] = calibrator
             if calibrator is not None:
                 calibrator._axis = attrs.get("_axis")
+            q.drop_layout_caches()  # (filled inside the block for the temporary layout)
         return False
 
 

@@ -41,6 +41,7 @@ from torch import nn
 
 from . import model_calib as _mc
 from . import model_quant as _mq
+from . import numerics
 from .nn import QuantLinear
 from .tensor_quantizer import QuantizerAttributeConfig, SequentialQuantizer, TensorQuantizer
 
@@ -274,6 +275,12 @@ def _stats():
     return modelopt_plugin.STATS
 
 
+def _reference_numerics():
+    """Under the reference, "the same result" is the reference's run on the SAME device: the flows' small fp32 scale formulas
+    are evaluated as torch evaluates the reference's expressions on the tensors' device (numerics.py), not on the host."""
+    return numerics.scale_math("device")
+
+
 def _device_ok(model) -> str | None:
     from . import modelopt_plugin
 
@@ -311,7 +318,8 @@ def _adapter(name, original, run, rmc=None, precheck=None):
             return original(model, forward_loop, **kwargs)
         _stats()[f"S7:{name}"] += 1
         try:
-            out = run(model, forward_loop, adoption=adoption, **kwargs)
+            with _reference_numerics():
+                out = run(model, forward_loop, adoption=adoption, **kwargs)
         finally:
             adoption.__exit__(None, None, None)
         if rmc is not None:
@@ -352,8 +360,9 @@ def _max_calibrate_adapter(rmc):
                             shared_states=shared_states, skip_forward_without_activation_calib=skip_forward_without_activation_calib)
         _stats()["S7:max_calibrate"] += 1
         try:
-            _mc.max_calibrate(model, forward_loop, distributed_sync=bool(distributed_sync),
-                              sync_expert_weight_amax=bool(sync_expert_weight_amax))
+            with _reference_numerics():
+                _mc.max_calibrate(model, forward_loop, distributed_sync=bool(distributed_sync),
+                                  sync_expert_weight_amax=bool(sync_expert_weight_amax))
         finally:
             adoption.__exit__(None, None, None)
         for _, module in model.named_modules():  # (:366-368)
@@ -411,7 +420,8 @@ def _weight_only_quantize_adapter(rmc):
             return original(model)
         _stats()["S7:weight_only_quantize"] += 1
         try:
-            _mc.weight_only_quantize(model)
+            with _reference_numerics():
+                _mc.weight_only_quantize(model)
         finally:
             adoption.__exit__(None, None, None)
 
@@ -436,7 +446,8 @@ def _fold_weight_adapter(rmq):
             return original(model, keep_attrs)
         _stats()["S7:fold_weight"] += 1
         try:
-            _mq.fold_weight(model, keep_attrs=keep_attrs)
+            with _reference_numerics():
+                _mq.fold_weight(model, keep_attrs=keep_attrs)
         finally:
             adoption.__exit__(None, None, None)
 
@@ -455,7 +466,8 @@ def _pack_int4_adapter(original):
                 and weight.dtype in (torch.float16, torch.bfloat16, torch.float32) and weight.shape[0] % 2 == 0
                 and weights_scaling_factor.dim() == 2 and weight.shape[1] % weights_scaling_factor.shape[1] == 0):
             try:
-                out = ops.pack_int4_in_uint8(weight, weights_scaling_factor.to(weight.device))
+                with _reference_numerics():
+                    out = ops.pack_int4_in_uint8(weight, weights_scaling_factor.to(weight.device))
                 _stats()["S7:pack_int4_in_uint8"] += 1
                 return out
             except Exception as e:  # an unsupported layout: the reference's own code
@@ -483,7 +495,22 @@ def _to_quantized_weight_adapter(rqu):
                 and quantization in _PACKED_FORMATS and weight.dim() == 2 and weight.is_contiguous()
                 and weight.dtype in (torch.float16, torch.bfloat16, torch.float32) and weights_scaling_factor is not None):
             try:
-                out = _export.to_quantized_weight(weight, weights_scaling_factor.to(weight.device), quantization)
+                with _reference_numerics():
+                    out = _export.to_quantized_weight(weight, weights_scaling_factor.to(weight.device), quantization)
+                _stats()[f"S7:to_quantized_weight:{quantization}"] += 1
+                return out
+            except Exception as e:
+                _stats()[f"S7:to_quantized_weight:fallback:{quantization}:{type(e).__name__}"] += 1
+        if (isinstance(weight, torch.Tensor) and type(weight) in (torch.Tensor, nn.Parameter) and modelopt_plugin._takes(weight)
+                and quantization in ("mxfp4", "w4a8_mxfp4_fp8") and weight.dim() == 2 and weight.is_contiguous()
+                and weight.dtype in (torch.float16, torch.bfloat16, torch.float32)
+                and weight.shape[-1] % (block_size or 32) == 0 and weight.shape[-1] % 2 == 0):
+            # MXFP4QTensor.quantize(weight, block_size)[0]._quantized_data (qtensor/mxfp4_tensor.py:37-81): E2M1 nibbles,
+            # two per byte; the E8M0 block scales are written by the caller's own scale query
+            try:
+                from . import ops
+
+                out = ops.mxfp4_quantize(weight, block_size or 32)[0]
                 _stats()[f"S7:to_quantized_weight:{quantization}"] += 1
                 return out
             except Exception as e:

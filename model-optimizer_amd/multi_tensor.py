@@ -126,6 +126,61 @@ class SegmentTable:
                                                           int(block_size), self.dtype_code, _lib.MX_TYPES[fmt], stream))
         return self.outputs
 
+    # -- SmoothQuant's fold composed with a8 / the MXFP4 packer: ONE read of every weight (moq_mt_fold_mx_fused / _pack)
+    def fold_side(self, scales, block_size, e8m0=None):
+        """Device table of moq_fold_seg rows (scale pointer, cols, e8m0 pointer) beside the segment table.  scales[i]: the
+        fp32 column vector of tensor i (its last dim) or None (no fold for that tensor)."""
+        if len(scales) != self.n_seg:
+            raise MoquantError("one scale vector (or None) per tensor")
+        rows, keep = [], []
+        for i, (t, s) in enumerate(zip(self.inputs, scales)):
+            cols = t.shape[-1]
+            if cols % block_size or t.numel() % block_size:
+                raise MoquantError("every tensor's last dim must be a multiple of the MX block size")
+            if t.data_ptr() % 16:
+                raise MoquantError("multi-tensor MX needs 16-byte aligned tensors")
+            ptr = 0
+            if s is not None:
+                s = s.detach().reshape(-1)
+                if s.dtype != torch.float32 or s.device != self.device or not s.is_contiguous():
+                    s = s.to(device=self.device, dtype=torch.float32).contiguous()
+                if s.numel() != cols:
+                    raise MoquantError("scale length must equal the tensor's last dim")
+                if s.data_ptr() % 16:
+                    s = s.clone()
+                keep.append(s)
+                ptr = s.data_ptr()
+            rows.append([ptr, cols, 0 if e8m0 is None else e8m0[i].data_ptr()])
+        side = torch.tensor(rows, dtype=torch.int64).to(self.device)  # layout == struct moq_fold_seg (3 x 8 bytes)
+        return side, keep  # (a caller that repeats the launch keeps this pair and passes it as `side=`)
+
+    def fold_mx_fused(self, scales=None, block_size: int = 32, fmt: str = "E2M1", side=None):
+        """outputs[i] = MXQDQ(dt(inputs[i] * scales[i][None, :])) for every tensor in ONE launch -- _apply_weight_pre_quant_scale
+        (model_calib.py:1208-1216) followed by the MX weight quantizer's forward, one read and one write per element;
+        bit-equal to ops.scale_cols + mx_fused_amax_convert."""
+        if any(t.data_ptr() % 16 for t in self.outputs):
+            raise MoquantError("multi-tensor MX needs 16-byte aligned tensors")
+        table, keep = side if side is not None else self.fold_side(scales, block_size)
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_fold_mx_fused(_p(self._segs), _p(self._blk), _p(table), self.n_seg, self.n_chunks,
+                                                  int(block_size), self.dtype_code, _lib.MX_TYPES[fmt], stream))
+        del keep
+        return self.outputs
+
+    def fold_mxfp4_pack(self, scales, block_size: int = 32):
+        """MXFP4QTensor.quantize(dt(inputs[i] * scales[i][None, :])) for every tensor in ONE launch: `outputs` must be the
+        packed uint8 tensors [..., K / 2]; returns (outputs, [e8m0 uint8 [n / block, 1] per tensor])."""
+        for x, y in zip(self.inputs, self.outputs):
+            if y.dtype != torch.uint8 or y.numel() * 2 != x.numel() or not y.is_contiguous() or y.data_ptr() % 4:
+                raise MoquantError("fold_mxfp4_pack: outputs must be contiguous uint8 tensors of half the inputs' elements")
+        e8 = [torch.empty(x.numel() // block_size, 1, dtype=torch.uint8, device=self.device) for x in self.inputs]
+        side, keep = self.fold_side(scales, block_size, e8m0=e8)
+        with _on(self._segs) as stream:
+            check(_lib.lib().moq_mt_fold_mxfp4_pack(_p(self._segs), _p(self._blk), _p(side), self.n_seg, self.n_chunks,
+                                                    int(block_size), self.dtype_code, stream))
+        del keep
+        return self.outputs, e8
+
     # -- a14 over the table: outputs must be uint8 / bool tensors of the inputs' shapes
     def mask_2to4(self):
         for x, m in zip(self.inputs, self.outputs):

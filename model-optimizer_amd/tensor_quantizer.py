@@ -149,16 +149,23 @@ class TensorQuantizer(nn.Module):
     # ------------------------------------------------------------------ configuration
     _weight_stats_done = None  # (data_ptr, version, shape) of the weight whose max statistics this calibration already holds
 
-    def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
-        """tensor_quantizer.py:228-290: (re)configure in place; calibration state is dropped."""
-        for name in ("_amax", "_pre_quant_scale", "_bias_value"):
-            if name in self._buffers or name in self.__dict__:
-                delattr(self, name)
-        for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
-                     "_nd_split", "_nd_perm", "_nd_inverse"):
+    _LAYOUT_CACHES = ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
+                      "_nd_split", "_nd_perm", "_nd_inverse")
+
+    def drop_layout_caches(self):
+        """Shapes remembered from the last forward under the current block layout; whoever changes the layout drops them."""
+        for name in self._LAYOUT_CACHES:
             self.__dict__.pop(name, None)
+
+    def set_from_attribute_config(self, cfg: QuantizerAttributeConfig):
+        """tensor_quantizer.py:228-290: (re)configure in place.  Attributes only: the buffers (`_amax`, `_pre_quant_scale`,
+        `_bias_value`) stay, as in the reference -- a calibrated model keeps its calibration and smoothing through a
+        temporary configuration (set_quantizer_by_cfg_context) or a full re-assignment; an `_amax` whose shape no longer
+        fits the new layout is refused where it is next written (`Changing shape when setting amax is not allowed`), and a
+        caller that wants a clean slate calls reset_amax()."""
         if not cfg.fake_quant:
             raise MoquantUnsupported("real quantization (fake_quant=False) is outside this path")
+        self.drop_layout_caches()
         self._take_config(cfg)
 
     _PARTIAL_KEYS = ("enable", "num_bits", "axis", "block_sizes", "type", "calibrator", "unsigned", "narrow_range", "fake_quant",
@@ -208,9 +215,7 @@ class TensorQuantizer(nn.Module):
             else:  # num_bits, unsigned, narrow_range
                 d["_" + key] = val
         if layout:  # shapes cached for the previous layout
-            for name in ("_block_reshape_size", "_padding", "_slices", "_original_shape", "_amax_shape_for_export", "_block_amax_view",
-                         "_nd_split", "_nd_perm", "_nd_inverse"):
-                d.pop(name, None)
+            self.drop_layout_caches()
 
     def _make_calibrator(self, spec) -> _Calibrator:
         # config.py:599-613 / tensor_quantizer.py:235-241: "max", "histogram" or (cls, args, kwargs)
@@ -414,7 +419,8 @@ class TensorQuantizer(nn.Module):
         """model_calib.weight_only_quantize collected this quantizer's max statistics from `weight`: calls with the same,
         unchanged tensor are pass-throughs until the calibration ends (disable_calib / reset_amax).  Only running-max
         calibrators qualify (a histogram would count the weight once per forward in the reference)."""
-        if type(self._calibrator).__name__ == "MaxCalibrator" and self.pre_quant_scale is None and self._bias is None:
+        if (type(self._calibrator).__name__ == "MaxCalibrator" and self.pre_quant_scale is None and self._bias is None
+                and not weight.is_inference()):  # (an inference tensor has no version counter to recognise it unchanged by)
             self._weight_stats_done = (weight.data_ptr(), weight._version, tuple(weight.shape))
 
     def enable_calib(self):
@@ -707,7 +713,7 @@ class TensorQuantizer(nn.Module):
         second test of forward(), without the call)."""
         done = self._weight_stats_done
         return (done is not None and self._if_calib and not self._if_quant and not self._disabled and done[0] == w.data_ptr()
-                and done[1] == w._version and done[2] == tuple(w.shape) and not self._forward_hooks
+                and not w.is_inference() and done[1] == w._version and done[2] == tuple(w.shape) and not self._forward_hooks
                 and not self._forward_pre_hooks and not _GLOBAL_FORWARD_HOOKS and not _GLOBAL_FORWARD_PRE_HOOKS)
 
     def forward(self, inputs):
@@ -724,7 +730,8 @@ class TensorQuantizer(nn.Module):
             # (one multi-tensor launch) from this very tensor; the reference collects them again on every forward
             # (model_calib.py:351-362), which for a running abs-max of an unchanged weight changes nothing
             done = self._weight_stats_done
-            if done[0] == inputs.data_ptr() and done[1] == inputs._version and done[2] == tuple(inputs.shape):
+            if (done[0] == inputs.data_ptr() and not inputs.is_inference() and done[1] == inputs._version
+                    and done[2] == tuple(inputs.shape)):
                 return inputs
         pqs = self.pre_quant_scale
         fused_pqs = False

@@ -439,6 +439,35 @@ class HostMemLib:
         self.o.orc_mxfp4_pack(_vp(x), _vp(packed), _vp(e8m0), I64(n_blocks), int(block), int(dt))
         return OK
 
+    # -- segment tables (multi_tensor.SegmentTable): host arrays of moq_seg / moq_fold_seg rows, walked here row by row
+    @staticmethod
+    def _rows(p, n, width):
+        return np.ctypeslib.as_array(ctypes.cast(_addr(p), ctypes.POINTER(ctypes.c_int64)), shape=(int(n), width))
+
+    def moq_mt_fold_mx_fused(self, segs, blk, side, n_seg, n_chunks, block, dt, fmt, stream):
+        elem = 4 if dt == 0 else 2
+        for (x, y, _, n), (scale, cols, _) in zip(self._rows(segs, n_seg, 4), self._rows(side, n_seg, 3)):
+            rows = int(n) // int(cols)
+            src = int(x)
+            if scale:
+                tmp = np.empty(int(n) * elem, dtype=np.uint8)
+                self.o.orc_scale_cols(_vp(int(x)), _vp(int(scale)), oracle._p(tmp), I64(rows), I64(int(cols)), int(dt))
+                src = tmp.ctypes.data
+            self.o.orc_mx_fused_amax_convert2(_vp(src), _vp(int(y)), I64(rows), I64(int(cols)), int(block), int(dt), int(fmt),
+                                              oracle.MX_TYPES["E8M0"], _vp(None))
+        return OK
+
+    def moq_mt_fold_mxfp4_pack(self, segs, blk, side, n_seg, n_chunks, block, dt, stream):
+        elem = 4 if dt == 0 else 2
+        for (x, y, _, n), (scale, cols, e8) in zip(self._rows(segs, n_seg, 4), self._rows(side, n_seg, 3)):
+            src = int(x)
+            if scale:
+                tmp = np.empty(int(n) * elem, dtype=np.uint8)
+                self.o.orc_scale_cols(_vp(int(x)), _vp(int(scale)), oracle._p(tmp), I64(int(n) // int(cols)), I64(int(cols)), int(dt))
+                src = tmp.ctypes.data
+            self.o.orc_mxfp4_pack(_vp(src), _vp(int(y)), _vp(int(e8)), I64(int(n) // int(block)), int(block), int(dt))
+        return OK
+
     def moq_mxfp4_unpack(self, packed, e8m0, out, n_blocks, block, dt, stream):
         self.o.orc_mxfp4_unpack(_vp(packed), _vp(e8m0), _vp(out), I64(n_blocks), int(block), int(dt))
         return OK
@@ -457,4 +486,9 @@ def install(monkeypatch, moa):
         yield None
 
     monkeypatch.setattr(ops, "_on", _on)
+    monkeypatch.setattr(ops, "_is_gpu", lambda t: True)
+    from model_optimizer_amd import multi_tensor
+
+    monkeypatch.setattr(multi_tensor, "_on", _on)  # (bound by name at import)
+    monkeypatch.setattr(multi_tensor, "_require_gpu", lambda t, what: None)
     return fake

@@ -131,8 +131,9 @@ def _batches():
     return [torch.randint(0, CFG["vocab_size"], (3, 24), generator=torch.Generator().manual_seed(40 + i)) for i in range(3)]
 
 
-def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True):
-    """`device`: None = host tensors (this tier); "cuda" = the same run with the model and the batches on the GPU
+def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True, inspect=None):
+    """`inspect`: called with the quantized model before anything is exported (search tables, module state).
+    `device`: None = host tensors (this tier); "cuda" = the same run with the model and the batches on the GPU
     (tests/test_gpu_reference_live.py: the reference's eager path with device tensors, staged or checked out).
     `edit`: a callable applied to the preset's copy before the KV-cache entries are merged (per-layer overrides)."""
     ref_shim.install()
@@ -158,6 +159,8 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
     batches = [b.to(device) if device is not None else b for b in _batches()]
     loop = (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None
     q = mtq.quantize(model, cfg, loop)
+    if inspect is not None:
+        inspect(q)
     amax = {n: m._amax.detach().float().cpu().clone() for n, m in q.named_modules()
             if type(m).__name__ == "TensorQuantizer" and m.is_enabled and getattr(m, "_amax", None) is not None}
     logits = None
@@ -181,7 +184,7 @@ def _reference_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=
     return amax, out
 
 
-def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True):
+def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, edit=None, export=True, inspect=None):
     mq = moa.model_quant
     model = _model(dtype, arch)
     if device is not None:
@@ -198,6 +201,8 @@ def _our_run(preset, dtype, with_kv, arch="llama", algorithm=None, device=None, 
     batches = [b.to(device) if device is not None else b for b in _batches()]
     with torch.no_grad():
         moa.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
+    if inspect is not None:
+        inspect(model)
     amax = {n: m._amax.detach().float().cpu().clone() for n, m in model.named_modules()
             if isinstance(m, moa.TensorQuantizer) and m.is_enabled and getattr(m, "_amax", None) is not None}
     with torch.no_grad():

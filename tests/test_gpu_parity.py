@@ -634,6 +634,47 @@ def test_multi_tensor_mx_equals_per_tensor(dn):
     assert_bits_equal(w1, ops.fused_amax_convert(ws[3], 32, "E2M1"), "in-place single mx")
 
 
+@pytest.mark.parametrize("dn", ["bf16", "f16", "f32"])
+def test_fold_composed_with_mx_in_one_launch_equals_fold_then_qdq(dn):
+    """moq_mt_fold_mx_fused / moq_mt_fold_mxfp4_pack (BASELINE configs[4]: SmoothQuant's column fold composed with MXFP4 g32):
+    one launch over a segment table == the oracle's separate steps -- scale_cols (model_calib.py:1208-1216: fp32 product, one
+    rounding to the weight dtype), then the MX QDQ / MXFP4QTensor.quantize of what the fold wrote -- bit for bit, and == this
+    library's own two-pass form.  Rows shorter and longer than a chunk (the column index wraps by remainder / by
+    compare-and-subtract), a tensor without a fold, a chunk that starts mid-row, scales that over- and underflow the dtype."""
+    dt = DT[dn]
+    gen = torch.Generator().manual_seed(31)
+    shapes = [(64, 256), (5, 8192 + 64), (3, 96), (130, 1024), (2, 28672), (40, 32)]
+    ws = [(torch.randn(*s, generator=gen) * torch.exp(torch.randn(s[0], 1, generator=gen))).to(dt) for s in shapes]
+    scales = [torch.exp(torch.randn(s[1], generator=gen) * 1.5) for s in shapes]
+    scales[2] = None  # no fold for this tensor
+    scales[3][7], scales[3][8] = 1e30, 1e-30
+    ws[0][3, 5], ws[0][9, 64] = float("nan"), float("inf")
+    dws = [w.to(DEV) for w in ws]
+    dsc = [None if s is None else s.to(DEV) for s in scales]
+    folded = [w if s is None else oracle.scale_cols(w, s) for w, s in zip(ws, scales)]
+    for fmt, block in [("E2M1", 32), ("E4M3", 32), ("E2M1", 16)]:
+        outs = moa.multi_tensor.SegmentTable(dws).fold_mx_fused(dsc, block, fmt)
+        for w, f, y, s in zip(dws, folded, outs, dsc):
+            assert_bits_equal(y.cpu(), oracle.mx_fused_amax_convert(f, block, fmt), f"fold+mx {dn} {fmt} b{block} {tuple(w.shape)}")
+            two_pass = ops.fused_amax_convert(w if s is None else ops.scale_cols(w, s), block, fmt)
+            assert_bits_equal(y, two_pass, f"fused vs two passes {dn} {fmt} {tuple(w.shape)}")
+    # in place, with the side table kept across launches (bench.py's step)
+    mine = [w.clone() for w in dws]
+    tab = moa.multi_tensor.SegmentTable(mine, outputs=mine)
+    side = tab.fold_side(dsc, 32)
+    tab.fold_mx_fused(side=side)
+    for y, f in zip(mine, folded):
+        assert_bits_equal(y.cpu(), oracle.mx_fused_amax_convert(f, 32, "E2M1"), "in place")
+    # the checkpoint form: nibbles + E8M0 of the folded weight
+    packed = [torch.empty(*w.shape[:-1], w.shape[-1] // 2, dtype=torch.uint8, device=DEV) for w in dws]
+    outs, e8 = moa.multi_tensor.SegmentTable(dws, outputs=packed).fold_mxfp4_pack(dsc, 32)
+    for w, f, q, e in zip(dws, folded, outs, e8):
+        wq, we = oracle.mxfp4_pack(f, 32)
+        assert torch.equal(q.cpu(), wq) and torch.equal(e.cpu(), we), f"fold+pack {dn} {tuple(w.shape)}"
+        q2, e2 = ops.mxfp4_quantize(f.to(DEV), 32)
+        assert torch.equal(q, q2) and torch.equal(e, e2)
+
+
 def test_multi_tensor_mask_equals_per_tensor():
     gen = torch.Generator().manual_seed(2)
     ws = [torch.randn(*s, generator=gen).to(torch.bfloat16).to(DEV) for s in [(64, 256), (8192 + 8, 16), (3, 96), (100, 1024)]]

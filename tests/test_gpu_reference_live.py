@@ -247,26 +247,55 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     """INT4-AWQ end to end.  The reference scores its 11 candidates per linear with the library's GEMM, this package with its
     Gram screen + own MFMA error GEMM: the two sum the same products in different orders, so candidates closer than the
     GEMMs' rounding can swap (random-init tiny models are the adversarial case: every candidate within a fraction of a
-    percent).  Stated tolerance: at least 90 % of the linears pick the reference's alpha (their scales, packed weights and
-    weight scales are then byte-identical, which is asserted), and the fake-quantized logits agree to 2e-2 of their range."""
-    ref_amax, ref_state = diff._reference_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
+    percent).  Stated tolerance, evaluated on EVERY searched linear (the search tables of both sides are kept: `debug`) -- in
+    OPT the q / k / v and fc1 scales are folded into the LayerNorms at export and leave no `pre_quant_scale` in the checkpoint,
+    so the checkpoint alone says nothing about two thirds of its linears: at least 90 % of the
+    linears pick the reference's alpha; every other pick must be a tie in the REFERENCE's own loss table (relative gap of the
+    two candidates below 2e-3, the summation-order noise of an fp16 / bf16 GEMM at these sizes); and every checkpoint tensor
+    that differs must belong to (or be fused with: LayerNorm, shared-input group) a linear with such a pick -- or, with equal
+    alphas, differ by the activation mean's summation order only (one 16-bit step in the scale).  Nothing is left unexplained:
+    the test fails on a differing tensor it cannot attribute."""
+    algo = {"method": "awq_lite", "alpha_step": 0.1, "debug": True}
+    tables = {}
+
+    def keep(side):
+        def inspect(model):
+            tables[side] = {n: (round(float(m.awq_lite.best_alpha), 2),
+                                {round(float(a), 2): float(v) for a, v in m.awq_lite.loss.items()},
+                                None if m.awq_lite.act_scale is None else m.awq_lite.act_scale.detach().float().cpu().clone())
+                            for n, m in model.named_modules() if hasattr(m, "awq_lite")}
+        return inspect
+
+    ref_amax, ref_state = diff._reference_run("INT4_AWQ_CFG", dtype, False, arch, algo, device=DEV, inspect=keep("ref"))
     with moa.numerics.scale_math("device"):
-        our_amax, our_state = diff._our_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
+        our_amax, our_state = diff._our_run("INT4_AWQ_CFG", dtype, False, arch, algo, device=DEV, inspect=keep("ours"))
     ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
     ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
     assert sorted(our_state) == sorted(ref_state)
-    pqs = [k for k in ref_state if k.endswith("pre_quant_scale")]
-    same = [k for k in pqs if torch.equal(our_state[k].cpu(), ref_state[k])]
-    tensors_same = sum(torch.equal(our_state[k].cpu().reshape(-1).view(torch.uint8), ref_state[k].reshape(-1).view(torch.uint8))
-                       for k in ref_state)
-    note(f"INT4-AWQ on the device vs the reference's eager search ({arch} {str(dtype)[6:]}): {len(same)} / {len(pqs)} "
-         f"pre_quant_scale vectors identical, {tensors_same} / {len(ref_state)} checkpoint tensors byte-identical")
-    assert len(same) >= 0.9 * len(pqs), f"only {len(same)} of {len(pqs)} scale vectors equal the reference's"
-    for k in same:  # an identical scale => that linear's packed weight and group scales are byte-identical
-        base = k[: -len("pre_quant_scale")]
-        for kk in ref_state:
-            if kk.startswith(base) and kk != k and len(same) == len(pqs):
-                assert torch.equal(our_state[kk].cpu().reshape(-1).view(torch.uint8), ref_state[kk].reshape(-1).view(torch.uint8)), kk
+    rt, ot = tables["ref"], tables["ours"]
+    assert sorted(rt) == sorted(ot) and len(rt) > 0, (sorted(rt), sorted(ot))
+    same_alpha = [n for n in rt if rt[n][0] == ot[n][0]]
+    other = {n: (rt[n][0], ot[n][0], (rt[n][1][ot[n][0]] - rt[n][1][rt[n][0]]) / max(rt[n][1][rt[n][0]], 1e-30)) for n in rt if n not in same_alpha}
+    act_same = [n for n in rt if rt[n][2] is not None and ot[n][2] is not None and torch.equal(rt[n][2], ot[n][2])]
+    differing = [k for k in ref_state
+                 if not torch.equal(our_state[k].cpu().reshape(-1).view(torch.uint8), ref_state[k].reshape(-1).view(torch.uint8))]
+    # attribute every differing tensor: to a linear with another pick, to a linear whose activation mean moved a bit, or to a
+    # tensor fused with such a linear (the LayerNorm in front of it / the sibling projections sharing its input)
+    suspects = set(other) | {n for n in rt if n not in act_same}
+    unexplained = []
+    for k in differing:
+        owner = k.rsplit(".", 1)[0]
+        layer = owner.rsplit(".", 2)[0] if "layers." in owner else owner
+        if not any(s == owner or s.startswith(owner + ".") or (layer and s.startswith(layer + ".")) for s in suspects):
+            unexplained.append(k)
+    note(f"INT4-AWQ on the device vs the reference's eager search ({arch} {str(dtype)[6:]}): {len(same_alpha)} / {len(rt)} searched linears "
+         f"pick the reference's alpha; other picks (reference alpha, ours, relative gap of the two in the REFERENCE's loss table): "
+         f"{ {n.replace('model.', ''): (a, b, float(f'{g:.2e}')) for n, (a, b, g) in other.items()} }; activation means bit-identical for "
+         f"{len(act_same)} / {len(rt)} linears; {len(ref_state) - len(differing)} / {len(ref_state)} checkpoint tensors byte-identical, "
+         f"{len(differing)} differing, of which {len(unexplained)} not attributable to a tie or a moved activation mean")
+    assert len(same_alpha) >= 0.9 * len(rt), f"only {len(same_alpha)} of {len(rt)} linears pick the reference's alpha: {other}"
+    assert all(abs(g) < 2e-3 for _, _, g in other.values()), f"a pick that is no tie in the reference's own table: {other}"
+    assert not unexplained, unexplained
     span = (ref_logits.float().max() - ref_logits.float().min()).item()
     assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
 
@@ -434,6 +463,129 @@ def test_random_calls_of_the_paths_functions_equal_the_references_eager_function
         assert not st["ours_refused"], (fam, st["ours_refused"][:3])
         assert not st["reference_refused"], (fam, st["reference_refused"])
         assert st["equal"] >= 90, (fam, st["equal"])
+
+
+# ------------------------------------------------------------------------------------------------------------- A'
+# S7, the algorithm seam (modelopt_algorithms.py): install(algorithms=True) + the reference's own, unmodified mtq.quantize and
+# export_hf_checkpoint on device tensors.  What runs underneath is this package's fused flow (multi-tensor weight pass, one
+# statistics launch per decoder layer, Gram screen + MFMA error GEMM, fused packers) on the REFERENCE's model objects; what
+# the reference holds and exports afterwards must equal its own eager run on the same device, under section B's tolerances.
+def _quantize_then_export(mtq, preset, dtype, with_kv, arch, stats_after_quantize=None):
+    """diff._reference_run on the device, with the seam counters read right after mtq.quantize returns (the logits forward
+    and the export after it go through the kernel seams too, and are not the search)."""
+    import tempfile
+
+    from modelopt.torch.export import export_hf_checkpoint
+    from safetensors import safe_open
+
+    model = diff._model(dtype, arch).to(DEV)
+    cfg = copy.deepcopy(getattr(mtq, preset))
+    if with_kv:
+        cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
+    batches = [b.to(DEV) for b in diff._batches()]
+    with torch.no_grad():
+        q = mtq.quantize(model, cfg, (lambda m: [m(b) for b in batches]) if cfg.get("algorithm") else None)
+        if stats_after_quantize is not None:
+            stats_after_quantize()
+        state = {"state_dict/" + n: t.detach().cpu().clone() for n, t in q.state_dict().items()}
+        logits = None if "MXFP" in preset and stats_after_quantize is None else q(batches[0]).logits.cpu().clone()
+    with tempfile.TemporaryDirectory() as d:
+        export_hf_checkpoint(q, export_dir=d)
+        with safe_open(os.path.join(d, "model.safetensors"), "pt") as f:
+            for k in f.keys():
+                state[k] = f.get_tensor(k)
+        state["__json__"] = open(os.path.join(d, "hf_quant_config.json")).read()
+    return state, logits
+
+
+ALGORITHM_SEAM_CASES = [
+    ("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", "S7:max_calibrate"),
+    ("FP8_DEFAULT_CFG", torch.float16, True, "mixtral", "S7:max_calibrate"),
+    ("INT8_DEFAULT_CFG", torch.float32, False, "opt", "S7:max_calibrate"),
+    ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", "S7:smoothquant"),
+    ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", "S7:max_calibrate"),
+    ("FP8_PER_CHANNEL_PER_TOKEN_CFG", torch.bfloat16, False, "llama", "S7:max_calibrate"),
+]
+
+
+@pytest.mark.parametrize("preset,dtype,with_kv,arch,entry", ALGORITHM_SEAM_CASES)
+def test_reference_quantize_and_export_through_the_algorithm_seam_on_the_device(ref, preset, dtype, with_kv, arch, entry):
+    base_state, base_logits = _quantize_then_export(ref, preset, dtype, with_kv, arch)
+    seen = {}
+    with installed(algorithms=True) as (plugin, got):
+        assert any(g.startswith("S7:_calib_func") for g in got), got
+        our_state, our_logits = _quantize_then_export(ref, preset, dtype, with_kv, arch, lambda: seen.update(plugin.STATS))
+        total = dict(plugin.STATS)
+    assert seen.get(entry, 0) >= 1, f"{preset}: the reference's quantize() never reached {entry}: {seen}"
+    assert not [k for k in total if "fallback" in k], f"{preset}: handed back to the reference: {total}"
+    assert sorted(base_state) == sorted(our_state), set(base_state) ^ set(our_state)
+    for k, want in base_state.items():
+        got_t = our_state[k]
+        if k == "__json__":
+            assert got_t == want, f"{preset}: hf_quant_config.json differs"
+            continue
+        assert got_t.dtype == want.dtype and got_t.shape == want.shape, k
+        assert torch.equal(got_t.contiguous().reshape(-1).view(torch.uint8), want.contiguous().reshape(-1).view(torch.uint8)), f"{preset}: {k} differs"
+    assert torch.equal(base_logits, our_logits), f"{preset}: logits differ"
+    packers = {k: v for k, v in total.items() if k.startswith("S7:to_quantized_weight") or k.startswith("S7:pack_int4")}
+    note(f"reference through the ALGORITHM seam on the device, {preset} {arch} {str(dtype)[6:]}: {len(base_state) - 1} state / checkpoint "
+         f"tensors + logits + hf_quant_config.json == its eager run; calibration served by {entry} with "
+         f"{sum(v for k, v in seen.items() if k.startswith('S1:') or k.startswith('S6:'))} per-tensor kernel-seam calls inside it; "
+         f"export packers {packers}")
+
+
+@pytest.mark.parametrize("preset,arch,dtype", [("INT4_AWQ_CFG", "llama", torch.bfloat16), ("INT4_AWQ_CFG", "qwen2", torch.bfloat16),
+                                               ("W4A8_AWQ_BETA_CFG", "llama", torch.bfloat16)])
+def test_reference_int4_awq_through_the_algorithm_seam_on_the_device(ref, preset, arch, dtype):
+    """The reference's own mtq.quantize(INT4_AWQ_CFG) + export with the search served by this package's awq_lite.  Section
+    B's stated tolerance (the two sides score with GEMMs that sum in different orders): >= 90 % of the linears end with the
+    reference's scale vector -- those linears' packed weights and group scales are then byte-identical -- and the logits agree to
+    2e-2 of their range.  And the point of the seam: NO per-tensor fake_tensor_quant_with_axis call inside the search."""
+    base_state, base_logits = _quantize_then_export(ref, preset, dtype, False, arch)
+    seen = {}
+    with installed(algorithms=True) as (plugin, got):
+        our_state, our_logits = _quantize_then_export(ref, preset, dtype, False, arch, lambda: seen.update(plugin.STATS))
+        total = dict(plugin.STATS)
+    assert seen.get("S7:awq", 0) == 1, seen
+    assert seen.get("S1:fake_tensor_quant_with_axis", 0) == 0 and seen.get("S1:fake_tensor_quant", 0) == 0, \
+        f"per-tensor kernel-seam calls inside the AWQ search: {seen}"
+    assert not [k for k in total if "fallback" in k], total
+    assert total.get("S7:pack_int4_in_uint8", 0) > 0, total
+    assert sorted(base_state) == sorted(our_state), set(base_state) ^ set(our_state)
+    assert base_state["__json__"] == our_state["__json__"]
+    pqs = [k for k in base_state if k.endswith("pre_quant_scale") and not k.startswith("state_dict/")]
+    same = [k for k in pqs if torch.equal(our_state[k], base_state[k])]
+    tensors = [k for k in base_state if k != "__json__" and not k.startswith("state_dict/")]
+    identical = sum(torch.equal(our_state[k].reshape(-1).view(torch.uint8), base_state[k].reshape(-1).view(torch.uint8)) for k in tensors)
+    note(f"reference {preset} through the ALGORITHM seam on the device ({arch}): {len(same)} / {len(pqs)} pre_quant_scale vectors "
+         f"identical to its eager search, {identical} / {len(tensors)} checkpoint tensors byte-identical; kernel-seam calls inside "
+         f"quantize(): {sorted((k, v) for k, v in seen.items() if not k.startswith('S7'))}")
+    assert len(same) >= 0.9 * len(pqs), f"only {len(same)} of {len(pqs)} scale vectors equal the reference's"
+    if len(same) == len(pqs):
+        assert identical == len(tensors), [k for k in tensors if not torch.equal(our_state[k].reshape(-1).view(torch.uint8),
+                                                                                 base_state[k].reshape(-1).view(torch.uint8))][:5]
+    span = (base_logits.float().max() - base_logits.float().min()).item()
+    assert (our_logits.float() - base_logits.float()).abs().max().item() <= 2e-2 * span
+
+
+def test_reference_mxfp4_through_the_algorithm_seam_equals_the_kernel_seams(ref):
+    """The reference has no eager MX implementation: its MXFP4 run exists only through the kernel seams (S1).  MXFP4_DEFAULT_CFG
+    has no calibration algorithm (E8M0 block scales come from every input), so what the algorithm seam adds here is the export
+    packer: the reference's torch expression of MXFP4QTensor.quantize (kernel-seam run) against this package's pack kernel
+    (algorithm-seam run) -- the checkpoint must not change by a byte."""
+    with installed() as (plugin, _):
+        base_state, base_logits = _quantize_then_export(ref, "MXFP4_DEFAULT_CFG", torch.bfloat16, False, "llama", lambda: None)
+    with installed(algorithms=True) as (plugin, _):
+        our_state, our_logits = _quantize_then_export(ref, "MXFP4_DEFAULT_CFG", torch.bfloat16, False, "llama", lambda: None)
+        total = dict(plugin.STATS)
+    assert total.get("S7:to_quantized_weight:mxfp4", 0) == 14 and not [k for k in total if "fallback" in k], total
+    assert sorted(base_state) == sorted(our_state)
+    for k, want in base_state.items():
+        if k == "__json__":
+            assert our_state[k] == want
+        else:
+            assert torch.equal(our_state[k].reshape(-1).view(torch.uint8), want.reshape(-1).view(torch.uint8)), k
+    assert torch.equal(base_logits, our_logits)
 
 
 # ------------------------------------------------------------------------------------------------------------- D
