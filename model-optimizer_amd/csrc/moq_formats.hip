@@ -160,9 +160,16 @@ __global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict
 }
 // SmoothQuant fold + MX QDQ in one pass over a segment table (moq_mt_fold_mx_fused): the element is multiplied by its column's
 // fp32 scale and rounded to the storage dtype -- what the separate fold writes back to memory -- before the block abs-max is
-// taken.  The column of a chunk's first element costs one 64-bit remainder per chunk (workgroup-uniform); a packet's column
-// is that plus its offset, wrapped by compare-and-subtract when a row is at least a chunk long (every Llama weight) and by
-// a 32-bit remainder otherwise.  A packet never straddles a row (cols % block == 0, block % kVec == 0).
+// taken.
+//
+// TILED chunks.  A bf16 packet is 16 B of weights but needs 32 B of fp32 column scales; walked linearly (a chunk = 8192
+// consecutive elements, every packet its own columns) the scale reads are twice the weight reads -- L2 hits, but three load
+// instructions per packet instead of one: 0.68 of the HBM roofline on all Llama-3-70B weights against the plain MX kernel's
+// 0.76.  So a chunk of a foldable tensor is a TILE instead: kPackets ROWS x (kBlock * kVec) COLUMNS (4 x 2048 for 16-bit
+// types, 8 x 1024 for fp32) -- still exactly MOQ_MT_CHUNK elements, so the segment table's chunk plan holds -- in which
+// packet u of thread t is row u, columns t * kVec ...: all of a thread's packets sit in the SAME columns, one scale load (two
+// 16-byte reads) serves the tile, and a wave instruction still moves one contiguous KiB of a row.  Needs cols % (kBlock * kVec)
+// == 0 and rows % kPackets == 0 (every Llama / Mixtral weight); other tensors take the linear walk below.
 template <int DT>
 __device__ __forceinline__ uint32_t fold_col(uint32_t c0, int off, uint32_t cols) {
   uint32_t t = c0 + (uint32_t)off;
@@ -179,32 +186,56 @@ __device__ __forceinline__ void fold_load(const float* __restrict__ scale, uint3
     sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
   }
 }
-template <int DT, int LPG>
-__device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f,
-                                              const MxScaleE8M0& scale_of, const float* __restrict__ scale, uint32_t cols) {
+// where packet u of this thread lives: element offset inside the tensor, and (TILED only) its columns are the thread's own
+template <int DT>
+struct FoldWalk {
+  bool tiled;
+  uint32_t cols, wpb;  // row length; tiles per band of kPackets rows
+  __device__ __forceinline__ void set(int64_t n, int64_t cols_) {
+    constexpr int W = kBlock * Elem<DT>::kVec;
+    cols = (uint32_t)cols_;
+    tiled = cols % W == 0 && (n / cols_) % Chunk<DT>::kPackets == 0;
+    wpb = cols / W;
+  }
+};
+template <int DT, int LPG, bool TILED>
+__device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t j, int64_t n, const MxFmt f,
+                                              const MxScaleE8M0& scale_of, const float* __restrict__ scale,
+                                              const FoldWalk<DT>& wk) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
   constexpr int ES = 16 / V;
   Pack16 in[P];
-  float sf[P][8];
-  const uint32_t c0 = (uint32_t)(e0 % (int64_t)cols);
+  int64_t e[P];
+  float sf[TILED ? 1 : P][8];
+  if constexpr (TILED) {
+    const int64_t band = j / wk.wpb;
+    const uint32_t col = (uint32_t)(j - band * wk.wpb) * (kBlock * V) + threadIdx.x * V;
 #pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
-    if (e < n) in[u] = load16_nt(xb + e * ES);
-    else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+    for (int u = 0; u < P; ++u) e[u] = (band * P + u) * (int64_t)wk.cols + col;
+#pragma unroll
+    for (int u = 0; u < P; ++u) in[u] = load16_nt(xb + e[u] * ES);  // (rows % P == 0: every packet of a tile is live)
+    fold_load<DT>(scale, col, sf[0]);
+  } else {
+    const int64_t e0 = j * MOQ_MT_CHUNK;
+    const uint32_t c0 = (uint32_t)(e0 % (int64_t)wk.cols);
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      e[u] = e0 + packet_off<DT>(u);
+      if (e[u] < n) in[u] = load16_nt(xb + e[u] * ES);
+      else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) fold_load<DT>(scale, fold_col<DT>(c0, packet_off<DT>(u), wk.cols), sf[u]);
   }
 #pragma unroll
-  for (int u = 0; u < P; ++u) fold_load<DT>(scale, fold_col<DT>(c0, packet_off<DT>(u), cols), sf[u]);
-#pragma unroll
   for (int u = 0; u < P; ++u) {
-    const int64_t e = e0 + packet_off<DT>(u);
     float v[8];
     unpack<DT>(in[u], v);
     float am = 0.0f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      v[i] = round_to_dtype<DT>(v[i] * sf[u][i]);
+      v[i] = round_to_dtype<DT>(v[i] * sf[TILED ? 0 : u][i]);
       am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
     }
     am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
@@ -212,7 +243,7 @@ __device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t 
     scale_of(am, sc, un);
 #pragma unroll
     for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
-    if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
+    if (TILED || e[u] < n) store16_nt(yb + e[u] * ES, pack<DT>(v));
   }
 }
 template <int DT, int LPG, int FMT>
@@ -225,15 +256,23 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mx_kernel(const moq_seg* __res
   SegCursor cur;
   cur.init(segs, blk_start, n_seg, blockIdx.x);
   moq_fold_seg sd = side[cur.s];
+  FoldWalk<DT> wk;
+  wk.set(cur.sg.n, sd.cols);
   const MxScaleE8M0 scale_of{f.maxv};
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    if (cur.seek(c)) sd = side[cur.s];
-    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK;
-    if (sd.scale != nullptr)
-      mx_fold_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y), e0, cur.sg.n, f,
-                             scale_of, sd.scale, (uint32_t)sd.cols);
+    if (cur.seek(c)) {
+      sd = side[cur.s];
+      wk.set(cur.sg.n, sd.cols);
+    }
+    const int64_t j = c - cur.c_begin;
+    const char* xb = reinterpret_cast<const char*>(cur.sg.x);
+    char* yb = reinterpret_cast<char*>(cur.sg.y);
+    if (sd.scale == nullptr)
+      mx_chunk<DT, LPG>(xb, yb, j * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
+    else if (wk.tiled)
+      mx_fold_chunk<DT, LPG, true>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
     else
-      mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y), e0, cur.sg.n, f, scale_of);
+      mx_fold_chunk<DT, LPG, false>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
   }
 }
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding), any alignment and

@@ -319,7 +319,9 @@ __global__ __launch_bounds__(kBlock) void mxfp4_pack_kernel(const void* __restri
   }
 }
 // the same over a segment table, with SmoothQuant's column fold in front (moq_mt_fold_mxfp4_pack): the block exponent and the
-// nibbles are taken from dt(x * scale[col]), the value the separate fold would have written back
+// nibbles are taken from dt(x * scale[col]), the value the separate fold would have written back.  Foldable tensors are
+// walked in TILES (kPackets rows x kBlock * kVec columns: one scale read per thread and tile, see mt_fold_mx_kernel in
+// moq_formats.hip); tensors without a fold, or whose shape does not tile, take the linear walk of mxfp4_pack_kernel.
 template <int DT, int LPG>
 __global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_seg* __restrict__ segs,
                                                                     const int64_t* __restrict__ blk_start,
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_se
                                                                     int64_t n_chunks, int block_shift) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
+  constexpr int W = kBlock * V;
   if ((int64_t)blockIdx.x >= n_chunks) return;
   const int lane = threadIdx.x & 63;
   SegCursor cur;
@@ -334,33 +337,53 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_se
   moq_fold_seg sd = side[cur.s];
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     if (cur.seek(c)) sd = side[cur.s];
-    const int64_t e0 = (c - cur.c_begin) * MOQ_MT_CHUNK, n = cur.sg.n;
+    const int64_t j = c - cur.c_begin, n = cur.sg.n;
     const char* x = reinterpret_cast<const char*>(cur.sg.x);
     uint8_t* packed = reinterpret_cast<uint8_t*>(cur.sg.y);
+    const bool fold = sd.scale != nullptr;  // (workgroup-uniform, like everything derived from the segment below)
+    const uint32_t cols = (uint32_t)sd.cols;
+    const bool tiled = fold && cols % W == 0 && (n / (int64_t)cols) % P == 0;
     Pack16 in[P];
+    int64_t e[P];
+    uint32_t col[P];
+    if (tiled) {
+      const uint32_t wpb = cols / W;
+      const int64_t band = j / wpb;
+      const uint32_t cl = (uint32_t)(j - band * wpb) * W + threadIdx.x * V;
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        e[u] = (band * P + u) * (int64_t)cols + cl;
+        col[u] = cl;
+      }
+    } else {
+      const int64_t e0 = j * MOQ_MT_CHUNK;
+      const uint32_t c0 = fold ? (uint32_t)(e0 % (int64_t)cols) : 0u;
+#pragma unroll
+      for (int u = 0; u < P; ++u) {
+        e[u] = e0 + packet_off<DT>(u);
+        uint32_t t = c0 + (uint32_t)packet_off<DT>(u);
+        col[u] = !fold ? 0u : (cols >= (uint32_t)MOQ_MT_CHUNK ? (t >= cols ? t - cols : t) : t % cols);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
-      if (e < n) in[u] = load16_nt(x + e * (16 / V));
+      if (e[u] < n) in[u] = load16_nt(x + e[u] * (16 / V));
       else in[u].w[0] = in[u].w[1] = in[u].w[2] = in[u].w[3] = 0u;
     }
-    const bool fold = sd.scale != nullptr;  // (workgroup-uniform)
-    const uint32_t cols = (uint32_t)sd.cols;
-    const uint32_t c0 = fold ? (uint32_t)(e0 % (int64_t)cols) : 0u;
+    float sf[8] = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-      const int64_t e = e0 + packet_off<DT>(u);
       float v[8];
       unpack<DT>(in[u], v);
       uint32_t m;
       if (fold) {
-        uint32_t t = c0 + (uint32_t)packet_off<DT>(u);
-        t = cols >= (uint32_t)MOQ_MT_CHUNK ? (t >= cols ? t - cols : t) : t % cols;
-        const float4 a = *reinterpret_cast<const float4*>(sd.scale + t);
-        float sf[8] = {a.x, a.y, a.z, a.w, 1.0f, 1.0f, 1.0f, 1.0f};
-        if constexpr (V == 8) {
-          const float4 b = *reinterpret_cast<const float4*>(sd.scale + t + 4);
-          sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+        if (!tiled || u == 0) {
+          const float4 a = *reinterpret_cast<const float4*>(sd.scale + col[u]);
+          sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w;
+          if constexpr (V == 8) {
+            const float4 b = *reinterpret_cast<const float4*>(sd.scale + col[u] + 4);
+            sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+          }
         }
         m = 0;
 #pragma unroll
@@ -389,10 +412,10 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_se
           word |= ((hi << 4) + lo) << (8 * (i / 2));
         }
       }
-      if (e < n) {
-        if constexpr (V == 8) __builtin_nontemporal_store(word, reinterpret_cast<uint32_t*>(packed + e / 2));
-        else *reinterpret_cast<uint16_t*>(packed + e / 2) = (uint16_t)word;
-        if ((lane & (LPG - 1)) == 0) sd.e8m0[e >> block_shift] = (uint8_t)(ex + 127);
+      if (e[u] < n) {
+        if constexpr (V == 8) __builtin_nontemporal_store(word, reinterpret_cast<uint32_t*>(packed + e[u] / 2));
+        else *reinterpret_cast<uint16_t*>(packed + e[u] / 2) = (uint16_t)word;
+        if ((lane & (LPG - 1)) == 0) sd.e8m0[e[u] >> block_shift] = (uint8_t)(ex + 127);
       }
     }
   }

@@ -148,11 +148,15 @@ def preprocess_linear_fusion(modules, resmooth_only: bool = False):
     iq0 = modules[0].input_quantizer
     if iq0.pre_quant_scale is not None:
         dev = modules[0].weight.device
-        # tiny [Cin] vectors: the reference's expression on the host, then back to the device
-        stacked = torch.stack([m.input_quantizer.pre_quant_scale.detach().cpu() for m in modules])
-        avg = torch.mean(stacked, dim=0)
+        # tiny [Cin] vectors, the reference's expression `torch.mean(torch.stack(scales), dim=0)` where numerics.mode() puts
+        # it: on the host (default: the reference's CPU run), or on the scales' own device -- torch's GPU mean multiplies the
+        # fp32 sum by a rounded 1/N where its CPU mean divides, so a 16-bit mean can land one step apart (OPT fp16 on the
+        # MI355X: 13 of 54 INT4-AWQ checkpoint tensors, all of them q / k / v and the LayerNorm their scale is folded
+        # into, until this ran where the reference's does: tools/diag/opt_awq_device_diff.py)
+        place = (lambda t: t.detach().cpu()) if numerics.on_host() else (lambda t: t.detach())
+        avg = torch.mean(torch.stack([place(m.input_quantizer.pre_quant_scale) for m in modules]), dim=0)
         for m in modules:
-            if not torch.equal(m.input_quantizer.pre_quant_scale.detach().cpu(), avg):
+            if not torch.equal(place(m.input_quantizer.pre_quant_scale), avg):
                 _update_pre_quant_scale(m, avg.to(dev))
     if resmooth_only:
         return

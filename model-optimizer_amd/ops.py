@@ -34,13 +34,13 @@ def _require_gpu(t: torch.Tensor, what: str) -> None:
                            "there is no CPU path in model_optimizer_amd")
 
 
-@contextmanager
 def _is_gpu(t: torch.Tensor) -> bool:
     """Does this tensor live where the library runs?  (One place to ask, so that the CPU tier's host-memory stand-in for the
     C-ABI can answer yes for host tensors: tests/hostmem_backend.py.)"""
     return t.is_cuda
 
 
+@contextmanager
 def _on(t: torch.Tensor):
     """Device guard + current stream handle (reference: same_device_as, tensor_quantizer.py:1205)."""
     with torch.cuda.device(t.device):

@@ -277,6 +277,9 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     same_alpha = [n for n in rt if rt[n][0] == ot[n][0]]
     other = {n: (rt[n][0], ot[n][0], (rt[n][1][ot[n][0]] - rt[n][1][rt[n][0]]) / max(rt[n][1][rt[n][0]], 1e-30)) for n in rt if n not in same_alpha}
     act_same = [n for n in rt if rt[n][2] is not None and ot[n][2] is not None and torch.equal(rt[n][2], ot[n][2])]
+    moved = {n.replace("model.", ""): (int((rt[n][2] != ot[n][2]).sum()), float(((rt[n][2] - ot[n][2]).abs() / rt[n][2].abs().clamp_min(1e-30)).max()))
+             for n in rt if n not in act_same and rt[n][2] is not None and ot[n][2] is not None}
+    assert all(rel <= 2.0 ** -7 for _, rel in moved.values()), moved  # one step of the 16-bit mean, summed over the batches
     differing = [k for k in ref_state
                  if not torch.equal(our_state[k].cpu().reshape(-1).view(torch.uint8), ref_state[k].reshape(-1).view(torch.uint8))]
     # attribute every differing tensor: to a linear with another pick, to a linear whose activation mean moved a bit, or to a
@@ -291,13 +294,43 @@ def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dt
     note(f"INT4-AWQ on the device vs the reference's eager search ({arch} {str(dtype)[6:]}): {len(same_alpha)} / {len(rt)} searched linears "
          f"pick the reference's alpha; other picks (reference alpha, ours, relative gap of the two in the REFERENCE's loss table): "
          f"{ {n.replace('model.', ''): (a, b, float(f'{g:.2e}')) for n, (a, b, g) in other.items()} }; activation means bit-identical for "
-         f"{len(act_same)} / {len(rt)} linears; {len(ref_state) - len(differing)} / {len(ref_state)} checkpoint tensors byte-identical, "
+         f"{len(act_same)} / {len(rt)} linears (others: channels moved, largest relative step: {moved}); {len(ref_state) - len(differing)} / {len(ref_state)} checkpoint tensors byte-identical, "
          f"{len(differing)} differing, of which {len(unexplained)} not attributable to a tie or a moved activation mean")
     assert len(same_alpha) >= 0.9 * len(rt), f"only {len(same_alpha)} of {len(rt)} linears pick the reference's alpha: {other}"
     assert all(abs(g) < 2e-3 for _, _, g in other.values()), f"a pick that is no tie in the reference's own table: {other}"
     assert not unexplained, unexplained
     span = (ref_logits.float().max() - ref_logits.float().min()).item()
     assert (our_logits.float() - ref_logits.float()).abs().max().item() <= 2e-2 * span
+
+
+@pytest.mark.parametrize("arch,dtype", [("opt", torch.float16), ("llama", torch.bfloat16)])
+def test_int4_awq_checkpoint_is_the_references_once_the_activation_mean_is_summed_in_torchs_order(ref, arch, dtype, monkeypatch):
+    """What is left of the INT4-AWQ difference on the device when every linear picks the reference's alpha (the test above: 13
+    of OPT fp16's 54 checkpoint tensors): ONE statistic, AWQ's per-channel mean |x| of a calibration batch.  The reference
+    takes it with torch's GPU reduction (`x.abs().contiguous().view(-1, C).mean(0)`, model_calib.py:1471-1472), this library
+    with its own kernel -- both accumulate in fp32 and round the mean to the activation dtype, in different summation orders, so
+    a channel whose mean lies at a 16-bit rounding boundary can land on either side (2 of OPT's 12 linears have such a
+    channel).  Proof that nothing else differs: with THIS package's flow taking that one statistic by torch's own expression
+    -- everything else unchanged: the HIP weight-scale, search, fold, export kernels -- the checkpoint is the reference's,
+    every tensor, byte for byte, and so are the logits.  (The LayerNorm folds of q / k / v and fc1, export/quant_utils.py:
+    1442-1472, are therefore not where OPT's difference came from.)"""
+    def torch_mean(x, acc):
+        return acc.add_(x.detach().abs().contiguous().view(-1, x.shape[-1]).mean(0).to(torch.float32))
+
+    ref_amax, ref_state = diff._reference_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
+    monkeypatch.setattr(moa.ops, "col_abs_mean_accum", torch_mean)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run("INT4_AWQ_CFG", dtype, False, arch, None, device=DEV)
+    ref_logits, our_logits = ref_state.pop("__logits__"), our_state.pop("__logits__")
+    ref_json, our_json = ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert sorted(our_state) == sorted(ref_state)
+    differing = [k for k in ref_state
+                 if not torch.equal(our_state[k].cpu().reshape(-1).view(torch.uint8), ref_state[k].reshape(-1).view(torch.uint8))]
+    note(f"INT4-AWQ on the device, activation mean by torch's reduction ({arch} {str(dtype)[6:]}): {len(ref_state) - len(differing)} / "
+         f"{len(ref_state)} checkpoint tensors byte-identical to the reference's eager run")
+    assert not differing, differing
+    assert torch.equal(our_logits, ref_logits)
+    diff._assert_same_quant_json(our_json, ref_json, f"INT4-AWQ {arch}")
 
 
 def test_a_second_format_on_part_of_the_model_on_the_device_equals_the_reference(ref):

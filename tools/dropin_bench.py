@@ -145,9 +145,11 @@ def mirror_row(moa, fmt, layers, batches, export: bool):
         row = {"quantize_s": round(t_q, 3)}
         state = quantizer_state(model)
         alphas = {n: round(float(mod.awq_lite.best_alpha), 2) for n, mod in model.named_modules() if hasattr(mod, "awq_lite")}
-        if export:
-            t_e, _ = timed(lambda: moa.export.export_state_dict(
-                model, torch.bfloat16, lambda: model(torch.ones([1, 2], dtype=torch.long, device=DEV))))
+        if export:  # the same deliverable as the reference rows: the checkpoint DIRECTORY (tensors packed, files written)
+            with tempfile.TemporaryDirectory() as d:
+                t_e, _ = timed(lambda: moa.export.export_hf_checkpoint(
+                    model, torch.bfloat16, export_dir=d,
+                    dummy_forward_fn=lambda: model(torch.ones([1, 2], dtype=torch.long, device=DEV))))
             row["export_s"] = round(t_e, 3)
     del model
     torch.cuda.empty_cache()
