@@ -289,6 +289,45 @@ DOM_KERNEL = {"fp8": "mt_map_kernel<bf16, OpFp8Qdq>", "int8": "mt_map_kernel<bf1
               "fp8-mask24": "mt_mask24_apply_kernel<bf16>"}
 
 
+def awq_cold_subprocess(args, dev):
+    """tools/awq_bench.py --cold in a process of its own (see the call site); returns its `cold` object plus the wall-clock of
+    the whole child as this process saw it and how long the driver needed to have clean pages again."""
+    import subprocess
+
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    t_w, probes = time.perf_counter(), 0
+    while time.perf_counter() - t_w < 30.0:  # until a 32 GiB hipMalloc is prompt again (bounded)
+        t = time.perf_counter()
+        block = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        took = time.perf_counter() - t
+        del block
+        torch.cuda.empty_cache()
+        probes += 1
+        if took < 0.05:
+            break
+        time.sleep(1.0)
+    wipe_wait = round(time.perf_counter() - t_w, 3)
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    held = {"parent_allocated_GB": round(torch.cuda.memory_allocated(dev) / 1e9, 2), "device_free_GB": round(free_b / 1e9, 1),
+            "device_total_GB": round(total_b / 1e9, 1)}  # (what the child finds: this process keeps its context and whatever it still holds)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
+    t0 = time.perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "awq_bench.py"), "--layers", str(args.awq_layers),
+                        "--batches", str(args.awq_batches), "--cold"], capture_output=True, text=True, timeout=900, env=env)
+    wall = round(time.perf_counter() - t0, 3)
+    if r.returncode != 0:
+        return {"failed": f"rc {r.returncode}: {r.stderr[-300:]}", "child_wall_s": wall}
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    return dict(line["cold"], child_wall_s=wall, wipe_wait_s=wipe_wait, wipe_probes=probes, **held, passes=line.get("passes"),
+                store_dropped=line.get("store_dropped"), stored_input_bytes=line.get("stored_input_bytes"),
+                stages_s=line.get("stages_s"), forward_loop_calls=line.get("forward_loop_calls"),
+                what="a fresh process: import, build the stack and 64 batches, ONE quantize(); no warm forward, no rehearsal, "
+                     "no memory taken ahead of the clock")
+
+
 def default_model(workload, world):
     return "llama3-8b" if world == 1 else SCALE_MODEL[workload]
 
@@ -506,6 +545,10 @@ class Pool:
         t0 = time.perf_counter()
         for _ in range(steps):
             self.step(True)
+        torch.cuda.synchronize()
+        # this rank's own K steps, before it waits for the others at the closing barrier (the step's collectives couple the
+        # ranks inside the steps already; what differs here is a rank that is simply slower or idle)
+        self.local_elapsed = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
         if self.use_dist:
@@ -659,6 +702,26 @@ def main():
                                   if world > 1 else "single GPU"},
         "roofline": roofline,
     }
+
+    if use_dist:
+        # A line that cannot mislead (no multi-GPU node has ever run this; the driver's will be the first): how many ranks the
+        # collective backend REALLY joined (a SUM of ones), over which backend, on how many distinct devices, and every rank's
+        # own time for the K steps.  A launch that silently ran one rank, N ranks on one GPU (the gloo debug mode), or with
+        # an idle rank shows here -- `multi_gpu_valid` is the conjunction a reader would check by hand.
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or dev.index)
+        mine = [None] * world
+        dist.all_gather_object(mine, {"rank": rank, "device_index": dev.index, "device": ident, "name": props.name,
+                                      "ms_per_step": round(pool.local_elapsed / args.steps * 1e3, 4),
+                                      "tensors": len(weights), "elements": n_local})
+        backend = dist.get_backend()
+        distinct = len({m["device"] for m in mine})
+        out["collective"] = {"backend": backend, "is_rccl": backend == "nccl", "world_size": dist.get_world_size(),
+                             "rccl_ranks_seen": int(round(ones.item())), "distinct_devices": distinct, "per_rank": mine,
+                             "multi_gpu_valid": bool(backend == "nccl" and int(round(ones.item())) == world == args.gpus
+                                                     and distinct == world)}
 
     extra = {}
 
@@ -902,6 +965,18 @@ def main():
                                            "stats": hf.get("awq_stats")}
         except Exception as e:
             extra["awq_hf_random_init"] = {"failed": f"{type(e).__name__}: {e}"}
+    if (not args.no_extra and args.awq_layers > 0 and world == 1 and isinstance(extra.get("awq"), dict)
+            and "failed" not in extra["awq"]):
+        # BASELINE's metric is "INT4-AWQ PTQ wall-clock": `awq_wallclock_s` above is the flow with its first-use costs paid
+        # ahead of the clock (a plain forward, a one-layer rehearsal, the flow's memory taken from the driver -- all printed).
+        # This is the OTHER figure: a process of its own that imports, builds the same stack and calls quantize() ONCE, with
+        # none of that -- what a user's first call pays (code-object loads, first touches, the allocator).  This process
+        # hands its memory back first and waits until the driver serves a large allocation promptly again (freed VRAM is
+        # wiped in the background at ~25 GB/s, tools/alloc_wipe_probe.py): the harness's own 230 GB must not be in the figure.
+        try:
+            extra["awq"]["cold_process"] = awq_cold_subprocess(args, dev)
+        except Exception as e:
+            extra["awq"]["cold_process"] = {"failed": f"{type(e).__name__}: {e}"}
     if rank == 0 and not args.no_cpu_baseline and out.get("cpu_baseline") is None:
         # N = 1: LAST, and in a process of its own
         out["cpu_baseline"] = cpu_baseline_subprocess()

@@ -65,7 +65,7 @@ class DeferredAmax:
 
     current = None  # the instance statistics collection runs under, or None (every request is its own launch)
 
-    def __init__(self, device, limit_bytes: int = 1 << 30, probation: bool = False):
+    def __init__(self, device, limit_bytes: int = 1 << 30, probation: bool = False, flush_points: int | None = None):
         self.device = torch.device(device)
         self.limit_bytes = int(limit_bytes)
         self.entries = {}      # id(tensor) -> [tensor, version, [running-max buffers]]
@@ -79,6 +79,7 @@ class DeferredAmax:
         # deferral off for the rest of the calibration -- no statistic is lost, nothing raises -- and a clean first pass
         # (whether a model writes its activations in place is a property of its code, not of the batch) switches it on
         self.probation = bool(probation)
+        self.flush_points = flush_points  # how many distinct flush points one pass goes through (the decoder layers), if known
         self.watched = []      # probation: (tensor, version when its quantizer saw it)
         self.flushed_keys = set()
         self.disabled = False
@@ -151,9 +152,10 @@ class DeferredAmax:
                 self.stats["disabled_by_inplace_write"] = True
             self.watched = []
             if key is not None and not self.disabled:
-                if key in self.flushed_keys:
-                    self.probation = False  # one clean pass through every flush point: deferral is on from here
+                again = key in self.flushed_keys
                 self.flushed_keys.add(key)
+                if again or (self.flush_points is not None and len(self.flushed_keys) >= self.flush_points):
+                    self.probation = False  # one clean pass through every flush point: deferral is on from here
             return
         if not self.entries:
             return

@@ -39,16 +39,17 @@ def _search(gram, exact, margin, check):
     if len(pending) < 2:
         return _first_min(gram), 0, 0
     scored, rounds, passes = {}, 0, 0
+    need = None
     while pending:
         passes += 1
         scored.update({i: exact[i] for i in pending})
         if not check:
             break
-        _, new_margin, pending = model_calib.tie_margin_check(gram, scored, margin, rounds)
+        need, margin, pending = model_calib.tie_margin_check(gram, scored, margin, rounds)
         if pending:
             rounds += 1
-            margin = new_margin
     idx = sorted(scored)
+    _search.last = (need, margin)  # (the requirement and the margin the linear was settled at)
     return idx[_first_min([scored[i] for i in idx])], len(scored), passes
 
 
@@ -65,8 +66,44 @@ def test_default_margin_with_self_check_finds_every_exact_minimum(tables):
         cands += n
         extra += passes > 1
     assert wrong == 0
-    assert cands < 0.55 * 11 * len(tables)  # about half of the full search, even on this all-ties model
-    assert extra <= 10  # widening (one more pass over the data per round) is not the common case
+    assert cands < 0.6 * 11 * len(tables)  # about half of the full search, even on this all-ties model
+    assert extra <= 40  # widening (a handful of candidates re-scored from stored activations) is not the common case: 31 of 224
+
+
+def test_every_linear_is_settled_with_room_to_spare(tables):
+    """rounds 4 and 5 settled this model's tightest linear with requirement / margin 0.984.  With
+    TIE_HEADROOM a linear that passes by less than 30 % is widened like one that fails: every linear of the measured
+    full-size tables ends at requirement / margin <= 0.7 (or with all of its candidates scored), on the exact minimum, and
+    what that costs is counted here."""
+    margin = model_calib.GRAM_TIE_MARGIN[moa.ops.torch.bfloat16] + model_calib.GRAM_PLANES_SLACK
+    worst, widened, cands, tight = 0.0, 0, 0, 0
+    for g, e in tables:
+        w, n, passes = _search(g, e, margin, check=True)
+        assert w == _first_min(e)
+        cands += n
+        widened += passes > 1
+        need, settled_at = _search.last
+        if need is not None and n < len(g) and settled_at != float("inf"):
+            worst = max(worst, need / settled_at)
+            tight += need > model_calib.TIE_HEADROOM * margin  # would have passed the bare rule (need <= margin) or failed it
+    assert worst <= model_calib.TIE_HEADROOM + 1e-12, worst
+    # measured on these tables: bare rule (headroom 1.0) 5 linears widened, 1199 of 2464 candidates re-scored, worst ratio 0.973;
+    # headroom 0.7: 31 widened, 1250 re-scored (+4 %), worst ratio 0.691 -- the same 224 exact minima either way
+    assert widened <= 40 and cands < 0.6 * 11 * len(tables), (widened, cands)
+
+
+def test_a_requirement_above_the_margin_is_widened_until_the_exact_minimum_is_in():
+    """A linear built to break a fixed margin: the Gram screen ranks candidate 4 best by 3e-3 while the exact engine prefers
+    candidate 7, which lies OUTSIDE the 1.3e-3 margin; the two engines disagree by 2e-3 among the candidates that are inside.
+    need > margin on the first check, the margin widens, candidate 7 is admitted and wins -- the exact engine's argmin."""
+    gram = [1.05, 1.04, 1.03, 1.0008, 1.0, 1.0005, 1.001, 1.003, 1.02, 1.04, 1.06]
+    exact = [1.05, 1.04, 1.03, 1.0030, 1.0012, 1.0002, 1.0004, 1.0001, 1.02, 1.04, 1.06]
+    assert _first_min(gram) == 4 and _first_min(exact) == 7
+    assert _search(gram, exact, 1.3e-3, check=False)[0] != 7  # a fixed margin never sees candidate 7
+    w, n, passes = _search(gram, exact, 1.3e-3, check=True)
+    assert w == 7 and passes >= 2 and n < len(gram)
+    need, settled_at = _search.last
+    assert need <= model_calib.TIE_HEADROOM * settled_at
 
 
 def test_a_stricter_factor_widens_some_linears_of_this_model_and_changes_nothing(tables, monkeypatch):
@@ -74,7 +111,7 @@ def test_a_stricter_factor_widens_some_linears_of_this_model_and_changes_nothing
     margin = model_calib.GRAM_TIE_MARGIN[moa.ops.torch.bfloat16] + model_calib.GRAM_PLANES_SLACK
     results = [_search(g, e, margin, check=True) for g, e in tables]
     assert all(w == _first_min(e) for (w, _, _), (_, e) in zip(results, tables))
-    assert 0 < sum(p > 1 for _, _, p in results) <= 10  # the check has teeth on this data
+    assert 0 < sum(p > 1 for _, _, p in results) <= 40  # the check has teeth on this data
 
 
 def test_too_small_a_fixed_margin_flips_linears_and_the_self_check_repairs_them(tables):
@@ -96,6 +133,9 @@ def test_tie_margin_check_rounds_and_nan():
     need, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, 0)
     assert need == pytest.approx(model_calib.TIE_SPREAD_FACTOR * 1e-3 + 5e-4) and margin == pytest.approx(2 * need)
     assert new == [2]
+    # inside the rule but without room (need = 0.9 x margin): widened as well
+    need, margin, new = model_calib.tie_margin_check(gram, {0: 1.0002, 1: 1.0005}, 4.4e-4, 0)
+    assert need == pytest.approx(4e-4) and need > model_calib.TIE_HEADROOM * 4.4e-4 and margin == pytest.approx(8.8e-4) and new == []
     # last round: everything that is left
     _, margin, new = model_calib.tie_margin_check(gram, {0: 1.001, 1: 1.0005}, 1e-3, model_calib.TIE_CHECK_MAX_ROUNDS - 1)
     assert margin == float("inf") and new == [2, 3, 4]

@@ -32,3 +32,25 @@ def test_every_collective_call_site_under_nccl_with_one_rank():
         assert calls.get(name, 0) > 0, f"{name} was never called: {calls}"
     assert calls["reduce"] >= 4 and calls["broadcast"] >= 8  # chunked: several calls per matrix / weight
     assert line["sharded_files"] == ["model-00001-of-00001.safetensors"]
+
+
+def test_the_scaling_tool_runs_the_two_rank_control_flow_on_one_gpu_and_labels_it_as_no_measurement(tmp_path):
+    """tools/scale_n.py at N = 1, 2 with MOQ_BENCH_DEBUG_ONE_GPU=1 (both ranks on cuda:0, gloo): the N > 1 command line, launch,
+    deal, collectives and line fields all run -- and the N = 2 line says what it is: two ranks seen, ONE distinct device, not
+    RCCL, `multi_gpu_valid` false, which the tool lists as a problem.  (No multi-GPU node is available to this suite; on one,
+    the same command without the variable is the driver's scaling run.)"""
+    out = tmp_path / "scale.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MOQ_BENCH_DEBUG_ONE_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "scale_n.py"), "--gpus", "1,2", "--steps", "2",
+                        "--warmup", "1", "--extra-args", "--layers 2 --no-extra --no-cpu-baseline --no-node-probe", "--out", str(out)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:] + p.stdout[-2000:]
+    runs = json.loads(out.read_text())["runs"]
+    assert [r["n_gpus"] for r in runs] == [1, 2] and all(r["rc"] == 0 for r in runs)
+    one, two = runs
+    assert one["problems"] == [] and one["line"].get("collective") is None
+    col = two["collective"]
+    assert col["backend"] == "gloo" and col["rccl_ranks_seen"] == 2 and col["world_size"] == 2 and col["distinct_devices"] == 1
+    assert col["multi_gpu_valid"] is False and any("not a multi-GPU measurement" in x for x in two["problems"])
+    assert [r["rank"] for r in col["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 and r["tensors"] > 0 for r in col["per_rank"])
+    assert two["line"]["scaling"] == "strong" and two["value"] > 0

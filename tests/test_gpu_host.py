@@ -616,3 +616,20 @@ def test_one_statistics_launch_per_decoder_layer_gives_the_per_call_statistics()
     with pytest.raises(RuntimeError, match="written in place"), torch.no_grad():
         model_quant.quantize(m, c, lambda mm: [mm(b) for b in batches])
     assert calib_mod.DeferredAmax.current is None
+    # the AUTOMATIC choice (nobody vouched for the model) sees the write in its first, watch-only pass and backs off: no error,
+    # no deferred launch, and the statistics of the per-call run of the same (scribbling) model
+    def scribbled(defer):
+        m = copy.deepcopy(base)
+        m.model.layers[1].mlp.down_proj = Scribbler(m.model.layers[1].mlp.down_proj)
+        c = copy.deepcopy(qcfg)
+        c["algorithm"] = {"method": "max", "defer_stats": defer}
+        with torch.no_grad():
+            model_quant.quantize(m, c, lambda mm: [mm(b) for b in batches])
+        return ({n: q._amax.detach().float().cpu().clone() for n, q in m.named_modules()
+                 if isinstance(q, TensorQuantizer) and q.is_enabled and getattr(q, "_amax", None) is not None},
+                dict(model_calib.MAX_CALIBRATE_STATS))
+
+    plain, _ = scribbled(False)
+    auto, st = scribbled(None)
+    assert st["deferred_stats"].get("disabled_by_inplace_write") and st["deferred_stats"]["flushes"] == 0
+    assert sorted(plain) == sorted(auto) and all(torch.equal(plain[n], auto[n]) for n in plain)

@@ -179,6 +179,11 @@ def test_the_automatic_deferral_watches_first_and_backs_off_on_an_in_place_write
     clean.add(torch.randn(4, 8), 0, torch.zeros(1))
     clean.flush(key=1)  # layer 1 again: the first batch went through every flush point untouched
     assert not clean.probation and not clean.disabled
+    counted = moa.calib.DeferredAmax("cpu", probation=True, flush_points=2)  # the caller knows how many layers a pass has
+    for key in (1, 2):
+        counted.add(torch.randn(4, 8), 0, torch.zeros(1))
+        counted.flush(key=key)
+    assert not counted.probation and not counted.disabled  # on from the second batch's FIRST layer
     strict = moa.calib.DeferredAmax("cpu")  # defer_stats=True: deferred from the first request, a write is an error
     y = torch.randn(4, 8)
     assert strict.add(y, 0, torch.zeros(1)) is True
@@ -231,7 +236,7 @@ def test_expert_anchors_are_looked_up_not_searched():
 
 # ---------------------------------------------------------------------------------------- ADVICE round 5, #5
 def test_the_automatic_activation_store_stops_at_its_cap_and_the_search_is_a_real_pass(hostmem, monkeypatch):
-    """awq_lite's automatic input store (store_activations="auto") is capped at a quarter of the HBM budget: beyond it the
+    """awq_lite's automatic input store (store_activations="auto") is capped at half of what the HBM budget has left: beyond it the
     stores are dropped and the exact pass runs forward_loop again -- same alphas and scales as with room for everything."""
     def run(budget_bytes):
         monkeypatch.setattr(mc._WeightCacheBudget, "host_bytes", budget_bytes)
@@ -253,7 +258,7 @@ def test_the_automatic_activation_store_stops_at_its_cap_and_the_search_is_a_rea
                             for n, mod in m.named_modules() if hasattr(mod, "awq_lite")}
 
     roomy_passes, roomy = run(1 << 30)
-    tight_passes, tight = run(1 << 21)  # 2 MiB: Gram matrices fit, a quarter of it does not hold the inputs of every linear
+    tight_passes, tight = run(1 << 20)  # 1 MiB: Gram matrices fit, half of the rest does not hold the inputs of every linear
     assert roomy_passes == 1 and tight_passes == 2, (roomy_passes, tight_passes)
     assert sorted(roomy) == sorted(tight)
     for n in roomy:

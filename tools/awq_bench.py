@@ -19,7 +19,9 @@ import os
 import sys
 import time
 
-import torch
+_T_PROCESS = time.perf_counter()  # (first statement after the standard library: everything a cold process pays is after it)
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -198,6 +200,7 @@ def run(moa, model_name, layers, batches, tokens, search, dev, rank=0, world=1, 
         # un-timed: a one-layer / one-batch rehearsal of the timed call; the flow's memory taken from the driver ahead of the clock
         "rehearsal_s": rehearsal_s, "allocator_reserve": alloc_probe_s,
         "stored_input_bytes": moa.model_calib.AWQ_LITE_STATS.get("stored_input_bytes"),
+        "store_dropped": moa.model_calib.AWQ_LITE_STATS.get("store_dropped"),
         "tie_check": moa.model_calib.AWQ_LITE_STATS.get("tie_check"),
         # quantize()'s own three stages (convert, set_quantizers, calibrate = sum of stages_s) and what of the measured
         # wall-clock neither clock saw (this rank; the barriers of an N > 1 run are in it)
@@ -224,6 +227,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--compare", default=None, help="second search mode to run on the same data; reports how many "
                                                     "linears pick the same alpha")
+    ap.add_argument("--cold", action="store_true",
+                    help="what a user's FIRST call pays: no warm forward, no rehearsal, no memory taken ahead of the clock -- "
+                         "the process imports, builds the stack and calls quantize() once; the line adds `cold` = seconds "
+                         "since the process started, up to the library being loaded, up to the stack and the batches being "
+                         "built, and in quantize() (bench.py runs this in a process of its own: extra.awq.cold_process)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -255,9 +263,15 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     moa = _moa_import.load()
+    t_loaded = time.perf_counter()
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[args.dtype]
     line = run(moa, args.model, args.layers, args.batches, args.tokens, args.search, dev, rank, world,
-               args.tie_margin, dtype, args.dump)
+               args.tie_margin, dtype, args.dump, warm=not args.cold)
+    if args.cold:
+        total = time.perf_counter() - _T_PROCESS
+        line["cold"] = {"process_s": round(total, 3), "import_s": round(t_loaded - _T_PROCESS, 3),
+                        "build_stack_and_batches_s": round(total - (t_loaded - _T_PROCESS) - line["value"], 3),
+                        "quantize_s": line["value"]}
     alphas = line.pop("best_alphas")
     if args.compare:
         other = run(moa, args.model, args.layers, args.batches, args.tokens, args.compare, dev, rank, world, None, dtype)
