@@ -82,6 +82,7 @@ class DeferredAmax:
         self.flush_points = flush_points  # how many distinct flush points one pass goes through (the decoder layers), if known
         self.watched = []      # probation: (tensor, version when its quantizer saw it)
         self.flushed_keys = set()
+        self.pass_watched = 0  # requests watched in the current pass
         self.disabled = False
 
     def add(self, x, dt_code, buf) -> bool:
@@ -150,12 +151,24 @@ class DeferredAmax:
             if any(x._version != v for x, v in self.watched):
                 self.disabled, self.probation = True, False
                 self.stats["disabled_by_inplace_write"] = True
-            self.watched = []
-            if key is not None and not self.disabled:
-                again = key in self.flushed_keys
-                self.flushed_keys.add(key)
-                if again or (self.flush_points is not None and len(self.flushed_keys) >= self.flush_points):
-                    self.probation = False  # one clean pass through every flush point: deferral is on from here
+            seen, self.watched = len(self.watched), []
+            if key is None or self.disabled:
+                self.pass_watched += seen
+                return
+            # A pass through every flush point counts only if requests were WATCHED in it (a calibrator's first collect takes
+            # the general path and never asks: the first batch of a calibration shows nothing) -- then deferral is on from
+            # here; else the next pass is watched.
+            if key in self.flushed_keys:  # this point again: the previous pass ended before this flush
+                if self.pass_watched > 0:
+                    self.probation = False
+                self.flushed_keys, self.pass_watched = {key}, seen
+                return
+            self.flushed_keys.add(key)
+            self.pass_watched += seen
+            if self.flush_points is not None and len(self.flushed_keys) >= self.flush_points:  # the pass ends with this flush
+                if self.pass_watched > 0:
+                    self.probation = False
+                self.flushed_keys, self.pass_watched = set(), 0
             return
         if not self.entries:
             return

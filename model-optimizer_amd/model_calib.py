@@ -796,7 +796,14 @@ class AWQLiteHelper:
         self.cin = module.weight.shape[1]
         self.dtype = module.weight.dtype  # 1 / s is rounded to it where the forward uses it (prepare_scales)
         self.pad = (-self.cin) % self.block_size
-        self.weight_scale = ops.awq_weight_scale(self._padded(module.weight), self.block_size)[:self.cin].contiguous()
+        if numerics.on_host():
+            self.weight_scale = ops.awq_weight_scale(self._padded(module.weight), self.block_size)[:self.cin].contiguous()
+        else:
+            # numerics "device" = the reference's run on this device: like the activation mean (patched_forward), this statistic
+            # is a 16-bit-rounded MEAN -- over Cout of |w| / (group amax + tiny) -- whose last bit depends on the summation
+            # order at full width; torch's own expression (get_weight_scale, :1453-1469), a handful of passes over the weight,
+            # once per linear
+            self.weight_scale = _awq_weight_scale_generic(module.weight, self.block_size).contiguous()
         self._init_state(module, alpha_step)
 
     def _init_generic(self, module, alpha_step):

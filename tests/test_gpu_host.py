@@ -587,13 +587,18 @@ def test_one_statistics_launch_per_decoder_layer_gives_the_per_call_statistics()
         return amax, dict(model_calib.MAX_CALIBRATE_STATS)
 
     per_call, st0 = run(False)
-    per_layer, st1 = run(None)  # automatic for a Hugging Face decoder stack on the GPU
+    per_layer, st1 = run(True)  # asked for: deferred from the first request that can be
     # (one flush per decoder layer and batch from the second batch on: a calibrator's first collect takes the general path)
     assert "deferred_stats" not in st0 and st1["deferred_stats"]["flushes"] >= 3 * (len(batches) - 1)
     d = st1["deferred_stats"]
     # 9 requests per layer-call (7 linear inputs + key / value states; the first call of every calibrator takes the general
     # path), 6 distinct tensors; far fewer table builds than flushes (the allocator repeats its addresses)
     assert d["requests"] >= 9 * 3 * (len(batches) - 1) and d["tensors"] * 9 <= d["requests"] * 6 + 6
+    # automatic for a Hugging Face decoder stack on the GPU -- after one WATCHED pass (round 6: the second batch, the first one
+    # in which calibrators ask): deferred from the third batch on, same statistics
+    auto, st2 = run(None)
+    assert st2["deferred_stats"]["flushes"] >= 3 * (len(batches) - 2) and not st2["deferred_stats"].get("disabled_by_inplace_write")
+    assert sorted(auto) == sorted(per_call) and all(torch.equal(per_call[n], auto[n]) for n in per_call)
     assert len(per_call) == len(per_layer) and len(per_call) >= 3 * 9 + 3 * 7
     for n, a in per_call.items():
         assert torch.equal(a, per_layer[n]), n

@@ -172,18 +172,23 @@ def test_the_automatic_deferral_watches_first_and_backs_off_on_an_in_place_write
     assert dirty.disabled and dirty.stats.get("disabled_by_inplace_write")
     assert dirty.add(torch.randn(4, 8), 0, torch.zeros(1)) is False
     clean = moa.calib.DeferredAmax("cpu", probation=True)
-    for key in (1, 2):  # first batch: layers 1 and 2
+    for key in (1, 2):  # a pass in which nobody asked (every calibrator's first collect takes the general path): proves nothing
+        clean.flush(key=key)
+    for key in (1, 2):  # second batch: layers 1 and 2, requests watched
         assert clean.add(torch.randn(4, 8), 0, torch.zeros(1)) is False
         clean.flush(key=key)
         assert clean.probation and not clean.disabled
     clean.add(torch.randn(4, 8), 0, torch.zeros(1))
-    clean.flush(key=1)  # layer 1 again: the first batch went through every flush point untouched
+    clean.flush(key=1)  # layer 1 again: a whole pass went through every flush point with its tensors untouched
     assert not clean.probation and not clean.disabled
     counted = moa.calib.DeferredAmax("cpu", probation=True, flush_points=2)  # the caller knows how many layers a pass has
     for key in (1, 2):
+        counted.flush(key=key)
+    assert counted.probation  # (nothing was watched in that pass)
+    for key in (1, 2):
         counted.add(torch.randn(4, 8), 0, torch.zeros(1))
         counted.flush(key=key)
-    assert not counted.probation and not counted.disabled  # on from the second batch's FIRST layer
+    assert not counted.probation and not counted.disabled  # on from the next batch's FIRST layer
     strict = moa.calib.DeferredAmax("cpu")  # defer_stats=True: deferred from the first request, a write is an error
     y = torch.randn(4, 8)
     assert strict.add(y, 0, torch.zeros(1)) is True
