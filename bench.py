@@ -110,7 +110,8 @@ def make_weights(model, n_layers, device, seed=1234, rank=0, world=1, scaling="s
 
 
 PMC_KERNEL = {"fp8": "mt_map_kernel<2, moq::OpFp8Qdq>", "int8": "mt_map_kernel<2, moq::OpIntQdq>",
-              "int4g128": "mt_group_kernel<2, 16>", "mask24": "mt_mask24_kernel<2>", "mxfp4": "mt_mx_kernel<2, 4, 6>"}
+              "int4g128": "mt_group_kernel<2, 16>", "mask24": "mt_mask24_kernel<2>", "mxfp4": "mt_mx_kernel<2, 4, 6>",
+              "mxfp4-sq": "mt_fold_mx_kernel<2, 4, 6>"}
 
 
 def pmc_traffic(workload, model, n_layers):
@@ -119,12 +120,14 @@ def pmc_traffic(workload, model, n_layers):
     MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE x 1024 B verified against a kernel with known write bytes).
     Counters cannot be read from inside the timed process, so the bench line quotes the profile; null when no
     profile of this workload / model size is committed."""
-    if model != "llama3-8b" or n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
+    if n_layers != MODELS[model][2] or workload not in PMC_KERNEL:
         return None, None
     path = None
-    # newest committed profile of this workload ("r05h": round 5's; the files tagged plain "r05" were written late in round 4)
-    for tag in ("r05h", "r05", "r04", "r03", "r02", "r01c", "r01b", "r01"):
-        cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}_pmc.json")
+    # newest committed profile of this workload ("r05h": round 5's; the files tagged plain "r05" were written late in round 4);
+    # profiles of a model other than the default carry its name (round 6: configs[4] on Llama-3-70B)
+    suffix = "" if model == "llama3-8b" else f"_{model}"
+    for tag in ("r06", "r05h", "r05", "r04", "r03", "r02", "r01c", "r01b", "r01"):
+        cand = os.path.join(ROOT, "profiles", f"{tag}_{workload}{suffix}_pmc.json")
         if os.path.exists(cand):
             path = cand
             break

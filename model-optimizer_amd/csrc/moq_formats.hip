@@ -72,7 +72,24 @@ struct MxScaleTwoLevelTable {
     sc = t.y * __uint_as_float((uint32_t)(127 - k) << 23);
   }
 };
+// the packet's block abs-max -> scale -> element rounding by integer ops: every format, every scale functor
 template <int DT, int LPG, class ScaleFn>
+__device__ __forceinline__ void mx_packet_general(float (&v)[8], const MxFmt f, const ScaleFn& scale_of) {
+  constexpr int V = Elem<DT>::kVec;
+  float am = 0.0f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+  // non-negative floats order like their bit patterns
+  am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
+  float sc, un;
+  scale_of(am, sc, un);
+#pragma unroll
+  for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+}
+// HW4: E2M1 elements with E8M0 scales (MXFP4) -- the chip's scaled FP4 converters (mx_e2m1_hw, moq_mx.h); a block they do
+// not take (a NaN inside, an exponent at the edge of the range) runs the general packet code: the branch is uniform over the
+// block's LPG lanes, so the DPP butterfly inside it sees whole blocks
+template <int DT, int LPG, bool HW4 = false, class ScaleFn>
 __device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, int64_t n, const MxFmt f,
                                          const ScaleFn& scale_of) {
   constexpr int V = Elem<DT>::kVec;
@@ -91,15 +108,11 @@ __device__ __forceinline__ void mx_chunk(const char* xb, char* yb, int64_t e0, i
     const int64_t e = e0 + packet_off<DT>(u);
     float v[8];
     unpack<DT>(in[u], v);
-    float am = 0.0f;
-#pragma unroll
-    for (int i = 0; i < V; ++i) am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
-    // non-negative floats order like their bit patterns
-    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
-    float sc, un;
-    scale_of(am, sc, un);
-#pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
+    if constexpr (HW4) {
+      if (!mx_e2m1_hw<V>(v, group_max_u32<LPG>(pack_absmax<DT>(in[u])))) mx_packet_general<DT, LPG>(v, f, scale_of);
+    } else {
+      mx_packet_general<DT, LPG>(v, f, scale_of);
+    }
     if (e < n) store16_nt(yb + e * ES, pack<DT>(v));
   }
 }
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void mx_kernel(const void* __restrict__ x, 
   const int64_t n_chunks = (n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK;
   const MxScaleE8M0 scale_of{f.maxv};
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x)
-    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
+    mx_chunk<DT, LPG, FMT == MOQ_E2M1>(reinterpret_cast<const char*>(x), reinterpret_cast<char*>(y), c * MOQ_MT_CHUNK, n, f, scale_of);
 }
 // two-level block scales (an element format as the scale format, optional tensor-wide amax) on the same skeleton; the
 // one-thread-per-block generic kernel moved 2 bytes per lane and load (0.21 of the HBM roofline at g = 16)
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(kBlock) void mt_mx_kernel(const moq_seg* __restrict
   const MxScaleE8M0 scale_of{f.maxv};
   for (int64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     cur.seek(c);
-    mx_chunk<DT, LPG>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y),
-                      (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
+    mx_chunk<DT, LPG, FMT == MOQ_E2M1>(reinterpret_cast<const char*>(cur.sg.x), reinterpret_cast<char*>(cur.sg.y),
+                                       (c - cur.c_begin) * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
   }
 }
 // SmoothQuant fold + MX QDQ in one pass over a segment table (moq_mt_fold_mx_fused): the element is multiplied by its column's
@@ -179,11 +192,12 @@ __device__ __forceinline__ uint32_t fold_col(uint32_t c0, int off, uint32_t cols
 template <int DT>
 __device__ __forceinline__ void fold_load(const float* __restrict__ scale, uint32_t col, float (&sf)[8]) {
   constexpr int V = Elem<DT>::kVec;
-  const float4 a = *reinterpret_cast<const float4*>(scale + col);
-  sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w;
+  // (the pointer comes out of a table in memory: without the address-space cast the compiler emits FLAT loads for it)
+  const u32x4_t a = *((gptr_c16)(uintptr_t)(scale + col));
+  sf[0] = __uint_as_float(a.x); sf[1] = __uint_as_float(a.y); sf[2] = __uint_as_float(a.z); sf[3] = __uint_as_float(a.w);
   if constexpr (V == 8) {
-    const float4 b = *reinterpret_cast<const float4*>(scale + col + 4);
-    sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+    const u32x4_t b = *((gptr_c16)(uintptr_t)(scale + col + 4));
+    sf[4] = __uint_as_float(b.x); sf[5] = __uint_as_float(b.y); sf[6] = __uint_as_float(b.z); sf[7] = __uint_as_float(b.w);
   }
 }
 // where packet u of this thread lives: element offset inside the tensor, and (TILED only) its columns are the thread's own
@@ -198,7 +212,7 @@ struct FoldWalk {
     wpb = cols / W;
   }
 };
-template <int DT, int LPG, bool TILED>
+template <int DT, int LPG, bool TILED, bool HW4>
 __device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t j, int64_t n, const MxFmt f,
                                               const MxScaleE8M0& scale_of, const float* __restrict__ scale,
                                               const FoldWalk<DT>& wk) {
@@ -232,17 +246,17 @@ __device__ __forceinline__ void mx_fold_chunk(const char* xb, char* yb, int64_t 
   for (int u = 0; u < P; ++u) {
     float v[8];
     unpack<DT>(in[u], v);
-    float am = 0.0f;
 #pragma unroll
-    for (int i = 0; i < V; ++i) {
-      v[i] = round_to_dtype<DT>(v[i] * sf[TILED ? 0 : u][i]);
-      am = __builtin_fmaxf(am, mx_abs_clamped(v[i]));
+    for (int i = 0; i < V; ++i) v[i] = v[i] * sf[TILED ? 0 : u][i];
+    // the fold's result AS STORED: rounded to the dtype (pack), and read back (unpack) -- the packed form also gives the
+    // block's abs-max pattern with packed 16-bit ops
+    const Pack16 folded = pack<DT>(v);
+    unpack<DT>(folded, v);
+    if constexpr (HW4) {
+      if (!mx_e2m1_hw<V>(v, group_max_u32<LPG>(pack_absmax<DT>(folded)))) mx_packet_general<DT, LPG>(v, f, scale_of);
+    } else {
+      mx_packet_general<DT, LPG>(v, f, scale_of);
     }
-    am = __uint_as_float(group_max_u32<LPG>(__float_as_uint(am)));
-    float sc, un;
-    scale_of(am, sc, un);
-#pragma unroll
-    for (int i = 0; i < V; ++i) v[i] = mx_qdq(v[i], sc, un, f);
     if (TILED || e[u] < n) store16_nt(yb + e[u] * ES, pack<DT>(v));
   }
 }
@@ -268,11 +282,11 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mx_kernel(const moq_seg* __res
     const char* xb = reinterpret_cast<const char*>(cur.sg.x);
     char* yb = reinterpret_cast<char*>(cur.sg.y);
     if (sd.scale == nullptr)
-      mx_chunk<DT, LPG>(xb, yb, j * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
+      mx_chunk<DT, LPG, FMT == MOQ_E2M1>(xb, yb, j * MOQ_MT_CHUNK, cur.sg.n, f, scale_of);
     else if (wk.tiled)
-      mx_fold_chunk<DT, LPG, true>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
+      mx_fold_chunk<DT, LPG, true, FMT == MOQ_E2M1>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
     else
-      mx_fold_chunk<DT, LPG, false>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
+      mx_fold_chunk<DT, LPG, false, FMT == MOQ_E2M1>(xb, yb, j, cur.sg.n, f, scale_of, sd.scale, wk);
   }
 }
 // generic path: one thread per MX block, handles ragged last blocks (virtual zero padding), any alignment and

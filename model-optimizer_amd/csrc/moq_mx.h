@@ -83,6 +83,47 @@ __device__ __forceinline__ float mx_abs_clamped(float x) {
   return a > 3.402823466e+38f ? 3.402823466e+38f : a;
 }
 
+// MXFP4 (E2M1 elements, E8M0 block scales) on the chip's own converters.  gfx950 has scaled FP4 conversions:
+//   v_cvt_scalef32_pk_fp4_f32  : two f32, divided by the scale 2^k, to two E2M1 nibbles (round to nearest even, saturating)
+//   v_cvt_scalef32_pk_f32_fp4  : two nibbles back to f32, multiplied by 2^k
+// Together they ARE the reference's quantize-dequantize of an element, sign(x) * (round_E2M1(|x| * 2^-k) * 2^k): checked for every
+// bf16 pattern x every block exponent k in [-126, 126] (tools/exp/fp4_probe.hip on the MI355X: 0 differences), with two
+// exceptions the caller handles -- a NaN (the reference's uninitialised sign makes it 0; a block that holds one is found by
+// its abs-max pattern and takes the general path) and the input -0.0 (reference: +0, since its sign is "0"; `x + 0.0f` makes
+// it +0 before the conversion and changes nothing else).  The element rounding by integer ops (mx_round_abs) costs ~20 vector
+// instructions per element -- the MX kernels were bound by vector issue, not by HBM (0.755 of 8 TB/s); this path costs ~5.
+// v: the V elements of a packet (already rounded to the storage dtype); amax_bits: abs-max PATTERN of the packet's block.
+// Returns false when the block must take the general path (NaN inside; block exponent at the edge of the fp32 range).
+typedef float mx_f2 __attribute__((ext_vector_type(2)));
+template <int V>
+__device__ __forceinline__ bool mx_e2m1_hw(float (&v)[8], uint32_t amax_bits) {
+  if (amax_bits > 0x7F800000u) return false;  // every NaN pattern sorts above +inf
+  // |x| clamped to FLT_MAX before the block max (compute_max_warp, cu:185-226): an inf counts as FLT_MAX
+  const float am = __uint_as_float(amax_bits < 0x7F7FFFFFu ? amax_bits : 0x7F7FFFFFu);
+  float sc, un;
+  mx_scale_e8m0(am, 6.0f, sc, un);
+  const uint32_t field = __float_as_uint(un) >> 23;  // un = 2^k: k + 127
+  if (field < 1u || field > 253u) return false;
+  uint32_t q = 0u;
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[0] + 0.0f, v[1] + 0.0f, un, 0);
+  q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[2] + 0.0f, v[3] + 0.0f, un, 1);
+  if constexpr (V == 8) {
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[4] + 0.0f, v[5] + 0.0f, un, 2);
+    q = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(q, v[6] + 0.0f, v[7] + 0.0f, un, 3);
+  }
+  mx_f2 r = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, un, 0);
+  v[0] = r.x; v[1] = r.y;
+  r = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, un, 1);
+  v[2] = r.x; v[3] = r.y;
+  if constexpr (V == 8) {
+    r = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, un, 2);
+    v[4] = r.x; v[5] = r.y;
+    r = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(q, un, 3);
+    v[6] = r.x; v[7] = r.y;
+  }
+  return true;
+}
+
 // compute_scale / compute_scale_with_global (tensor_quant_mx.cu:139-183) for block-scale formats other than E8M0
 // (NVFP4-style: E2M1 elements, E4M3 block scales, optional tensor-wide amax).  The reference mixes float and double
 // steps; they are kept one by one: float divisions, the product and the reciprocal in double, results narrowed to

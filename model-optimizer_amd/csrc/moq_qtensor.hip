@@ -378,11 +378,11 @@ __global__ __launch_bounds__(kBlock) void mt_fold_mxfp4_pack_kernel(const moq_se
       uint32_t m;
       if (fold) {
         if (!tiled || u == 0) {
-          const float4 a = *reinterpret_cast<const float4*>(sd.scale + col[u]);
-          sf[0] = a.x; sf[1] = a.y; sf[2] = a.z; sf[3] = a.w;
+          const u32x4_t a = *((gptr_c16)(uintptr_t)(sd.scale + col[u]));  // (global, not FLAT: see fold_load in moq_formats.hip)
+          sf[0] = __uint_as_float(a.x); sf[1] = __uint_as_float(a.y); sf[2] = __uint_as_float(a.z); sf[3] = __uint_as_float(a.w);
           if constexpr (V == 8) {
-            const float4 b = *reinterpret_cast<const float4*>(sd.scale + col[u] + 4);
-            sf[4] = b.x; sf[5] = b.y; sf[6] = b.z; sf[7] = b.w;
+            const u32x4_t b = *((gptr_c16)(uintptr_t)(sd.scale + col[u] + 4));
+            sf[4] = __uint_as_float(b.x); sf[5] = __uint_as_float(b.y); sf[6] = __uint_as_float(b.z); sf[7] = __uint_as_float(b.w);
           }
         }
         m = 0;
