@@ -76,27 +76,26 @@ def _same(ref, ours, what, clip_search=False):
     return len(ref_amax), len(ref_state)
 
 
+# (round 6 ran 26 such cases -- also FP8 cast KV, GPT-2's Conv1D, Qwen2, awq_full, FP8 2-D blocks, Qwen3-MoE, layer-by-layer max:
+# all equal; the set below keeps one of each kind so that the tier stays within minutes)
 CASES = [
     # preset, dtype, KV cache, architecture, algorithm override, seam entry that must have served the call
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "llama", None, "S7:max_calibrate"),
-    ("FP8_DEFAULT_CFG", torch.float16, "cast", "llama", None, "S7:max_calibrate"),
     ("FP8_DEFAULT_CFG", torch.bfloat16, "affine", "llama", None, "S7:max_calibrate"),
     ("INT8_DEFAULT_CFG", torch.float32, False, "opt", None, "S7:max_calibrate"),
-    ("INT8_DEFAULT_CFG", torch.float32, False, "gpt2", None, "S7:max_calibrate"),
     ("INT8_SMOOTHQUANT_CFG", torch.bfloat16, False, "llama", None, "S7:smoothquant"),
     ("INT8_SMOOTHQUANT_CFG", torch.float32, False, "opt", diff.SQ_HALF, "S7:smoothquant"),
     ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", None, "S7:awq"),
-    ("INT4_AWQ_CFG", torch.bfloat16, False, "qwen2", None, "S7:awq"),
     ("INT4_AWQ_CFG", torch.float16, False, "opt", None, "S7:awq"),
     ("INT4_AWQ_CFG", torch.bfloat16, True, "llama", {"method": "awq_clip"}, "S7:awq"),
-    ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", {"method": "awq_full", "alpha_step": 0.25}, "S7:awq"),
     ("W4A8_AWQ_BETA_CFG", torch.bfloat16, False, "llama", None, "S7:awq"),
     ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
-    ("FP8_2D_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
     ("FP8_PER_CHANNEL_PER_TOKEN_CFG", torch.bfloat16, False, "llama", None, "S7:max_calibrate"),
     ("INT8_DEFAULT_CFG", torch.bfloat16, False, "llama", {"method": "mse"}, "S7:mse_calibrate"),
+    # the reference's OWN layer-by-layer wrapper (mode.py:255-277 -> layerwise_calibrate) calls the hook once per decoder layer:
+    # the adapter then adopts one layer at a time
+    ("INT4_AWQ_CFG", torch.bfloat16, False, "llama", {"method": "awq_lite", "layerwise": {"enable": True}}, "S7:awq"),
     ("FP8_DEFAULT_CFG", torch.bfloat16, True, "mixtral", None, "S7:max_calibrate"),
-    ("INT8_WEIGHT_ONLY_CFG", torch.bfloat16, False, "qwen3_moe", None, "S7:max_calibrate"),
 ]
 
 
