@@ -297,8 +297,11 @@ def awq_cold_subprocess(args, dev):
     the whole child as this process saw it and how long the driver needed to have clean pages again."""
     import subprocess
 
+    import gc
+
     torch.cuda.synchronize()
-    torch.cuda.empty_cache()
+    gc.collect()  # (the flows' modules and closures refer to each other: without this their tensors pin the 160 GiB segment the
+    torch.cuda.empty_cache()  # warm run parked in torch's cache, and the child finds 120 GB free instead of 290)
     t_w, probes = time.perf_counter(), 0
     while time.perf_counter() - t_w < 30.0:  # until a 32 GiB hipMalloc is prompt again (bounded)
         t = time.perf_counter()
@@ -313,7 +316,8 @@ def awq_cold_subprocess(args, dev):
         time.sleep(1.0)
     wipe_wait = round(time.perf_counter() - t_w, 3)
     free_b, total_b = torch.cuda.mem_get_info(dev)
-    held = {"parent_allocated_GB": round(torch.cuda.memory_allocated(dev) / 1e9, 2), "device_free_GB": round(free_b / 1e9, 1),
+    held = {"parent_allocated_GB": round(torch.cuda.memory_allocated(dev) / 1e9, 2),
+            "parent_reserved_GB": round(torch.cuda.memory_reserved(dev) / 1e9, 2), "device_free_GB": round(free_b / 1e9, 1),
             "device_total_GB": round(total_b / 1e9, 1)}  # (what the child finds: this process keeps its context and whatever it still holds)
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}

@@ -46,9 +46,10 @@ from .nn import QuantLinear
 from .tensor_quantizer import QuantizerAttributeConfig, SequentialQuantizer, TensorQuantizer
 
 _BUFFERS = ("_amax", "_pre_quant_scale", "_bias_value")
-# plain attributes an algorithm may change on a quantizer; written back on release (same names on both sides)
-_FLAGS = ("_disabled", "_if_quant", "_if_calib", "_dynamic", "_enable_pre_quant_scale", "_num_bits", "_unsigned", "_narrow_range",
-          "_use_constant_amax", "_constant_amax")
+# plain attributes an ALGORITHM changes on a quantizer (enable / calibration switches, the smoothing switch, dynamic-ness); written
+# back on release together with `_axis` and `_block_sizes` (same names on both sides).  The format itself (`_num_bits`,
+# `_unsigned`, `_narrow_range`) is configuration, not calibration: no algorithm touches it, and it is left as the reference holds it.
+_FLAGS = ("_disabled", "_if_quant", "_if_calib", "_dynamic", "_enable_pre_quant_scale")
 # attributes algorithms hang on a quantizer beside its state (model_calib.py:1646)
 _EXTRAS = ("_amax_for_smoothing",)
 
@@ -136,7 +137,7 @@ def _write_back(r, t, R):
     """release: the twin's state onto the reference's quantizer."""
     d, td = r.__dict__, t.__dict__
     for name in _FLAGS:
-        if name in td and d.get(name, None) is not td[name] and d.get(name, None) != td[name]:
+        if name in td:
             d[name] = td[name]
     if d.get("_axis") != td.get("_axis"):
         d["_axis"] = td["_axis"]
@@ -208,6 +209,11 @@ class Adoption:
                 grp = getattr(ps, g, None)
                 if grp is not None and getattr(grp, "is_initialized", lambda: False)():
                     raise CannotAdopt(f"{g} of {name or type(m).__name__}")
+            # this package reduces statistics over the world (or the replicas declared to it); a reference module whose
+            # data-parallel group is a proper SUBGROUP keeps the reference's own per-group reductions
+            dp = getattr(ps, "data_parallel_group", None)
+            if dp is not None and getattr(dp, "group", None) not in (None, -1):
+                raise CannotAdopt(f"a data-parallel subgroup on {name or type(m).__name__}")
         weighted = [k for k, c in m._modules.items() if k.endswith("weight_quantizer") and c is not None]
         if not weighted:
             return
@@ -392,6 +398,15 @@ def _run_smoothquant(model, forward_loop, adoption=None, alpha=1.0):
     return _mc.smoothquant(model, forward_loop, alpha=alpha)
 
 
+_AWQ_OPTIONS = {"algorithm", "alpha_step", "debug", "max_co_batch_size", "max_tokens_per_batch", "min_clip_ratio", "shrink_step"}
+
+
+def _awq_precheck(kwargs):
+    """An option this package's search does not know (a newer reference) must not be dropped silently: hand the call back."""
+    unknown = sorted(k for k, v in kwargs.items() if k not in _AWQ_OPTIONS and v is not None)
+    return f"awq option(s) {unknown}" if unknown else None
+
+
 def _run_awq(model, forward_loop, adoption=None, algorithm="awq_lite", **kwargs):
     debug = bool(kwargs.pop("debug", False))
     out = _mc.awq(model, forward_loop, algorithm=algorithm, **({"debug": debug} if algorithm != "awq_lite" else {}), **kwargs)
@@ -539,7 +554,7 @@ def install_algorithms(swap, export: bool = True) -> list:
         "MseCalibrateModeDescriptor": _adapter("mse_calibrate", rmc.mse_calibrate, _run_mse, rmc=rmc, precheck=_mse_precheck),
         "SmoothQuantModeDescriptor": _adapter("smoothquant", rmc.smoothquant, _run_smoothquant, rmc=rmc),
     }
-    awq_adapter = _adapter("awq", rmc.awq, _run_awq)
+    awq_adapter = _adapter("awq", rmc.awq, _run_awq, precheck=_awq_precheck)
     for cls in ("AWQLiteModeDescriptor", "AWQClipModeDescriptor", "AWQFullModeDescriptor"):
         table[cls] = awq_adapter
     for cls, fn in table.items():

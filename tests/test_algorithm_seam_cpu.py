@@ -233,3 +233,38 @@ def test_uninstall_puts_the_references_hooks_back():
     after = (rmode.MaxCalibrateModeDescriptor._calib_func, rmode.AWQLiteModeDescriptor._calib_func, rmc.max_calibrate,
              rmc.weight_only_quantize, rmq.fold_weight)
     assert all(a is b for a, b in zip(before, after))
+
+
+def test_an_exception_inside_the_calibration_leaves_the_references_model(monkeypatch):
+    """A forward_loop that raises half way: the adoption is released on the way out -- every module has the reference's class
+    again, every quantizer child is the reference's own object -- and the exception reaches the caller."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.nn import TensorQuantizer as RTQ
+
+    m = diff._model(torch.bfloat16, "llama")
+    batches = diff._batches()
+    calls = []
+
+    def loop(mm):
+        mm(batches[0])
+        calls.append(1)
+        raise RuntimeError("calibration data ran out")
+
+    with algorithm_seam(monkeypatch) as (plugin, _):
+        with pytest.raises(RuntimeError, match="ran out"):
+            mtq.quantize(m, copy.deepcopy(mtq.FP8_DEFAULT_CFG), loop)
+        assert plugin.STATS.get("S7:max_calibrate", 0) == 1 and calls == [1]
+    quantizers = [q for q in m.modules() if "Quantizer" in type(q).__name__]
+    assert quantizers and all(isinstance(q, RTQ) for q in quantizers)
+    assert not any(type(x).__module__.startswith("model_optimizer_amd") for x in m.modules())
+
+
+def test_an_option_the_search_does_not_know_hands_the_call_back(monkeypatch):
+    ref_shim.install()
+    from model_optimizer_amd import modelopt_algorithms as ma
+
+    assert ma._awq_precheck({"algorithm": "awq_lite", "alpha_step": 0.1, "debug": False}) is None
+    assert "some_new_knob" in ma._awq_precheck({"algorithm": "awq_lite", "some_new_knob": 3})
+    assert ma._awq_precheck({"algorithm": "awq_lite", "some_new_knob": None}) is None  # (an unset option changes nothing)
+    assert ma._mse_precheck({"fp8_scale_sweep": True}) and ma._mse_precheck({"step_size": 0.1}) is None
