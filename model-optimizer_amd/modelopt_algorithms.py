@@ -307,7 +307,7 @@ def _adapter(name, original, run, rmc=None, precheck=None):
     def algorithm(model, forward_loop=None, **kwargs):
         why = _device_ok(model) if isinstance(model, nn.Module) else "not a module"
         if why is None and precheck is not None:
-            why = precheck(kwargs)
+            why = precheck(kwargs, model)
         adoption = patterns = None
         if why is None:
             try:
@@ -381,7 +381,7 @@ def _max_calibrate_adapter(rmc):
     return max_calibrate
 
 
-def _mse_precheck(kwargs):
+def _mse_precheck(kwargs, model=None):
     if kwargs.get("fp8_scale_sweep") or kwargs.get("shared_states"):
         return "fp8_scale_sweep / shared_states (NVFP4 static block scales)"
     return None
@@ -401,10 +401,27 @@ def _run_smoothquant(model, forward_loop, adoption=None, alpha=1.0):
 _AWQ_OPTIONS = {"algorithm", "alpha_step", "debug", "max_co_batch_size", "max_tokens_per_batch", "min_clip_ratio", "shrink_step"}
 
 
-def _awq_precheck(kwargs):
-    """An option this package's search does not know (a newer reference) must not be dropped silently: hand the call back."""
+def _awq_precheck(kwargs, model=None):
+    """An option this package's search does not know (a newer reference) must not be dropped silently, and a format its clip
+    search does not take must not fail half way: hand the call back."""
     unknown = sorted(k for k, v in kwargs.items() if k not in _AWQ_OPTIONS and v is not None)
-    return f"awq option(s) {unknown}" if unknown else None
+    if unknown:
+        return f"awq option(s) {unknown}"
+    if kwargs.get("algorithm", "awq_lite") in ("awq_clip", "awq_full") and model is not None:
+        # model_calib.awq_clip: signed static-block INT weight quantizers (the per-tensor NVFP4 branch, model_calib.py:1804-1813,
+        # is outside this path)
+        for name, m in model.named_modules():
+            wq = m._modules.get("weight_quantizer") if hasattr(m, "_modules") else None
+            if wq is None or "input_quantizer" not in m._modules:
+                continue
+            first = wq[0] if isinstance(wq, nn.Sequential) and len(wq) else wq
+            d = getattr(first, "__dict__", {})
+            if d.get("_disabled", False) or not d.get("_block_sizes"):
+                continue
+            if (d["_block_sizes"].get("type", "static") != "static" or not isinstance(d.get("_num_bits"), int)
+                    or d.get("_unsigned") or d.get("_narrow_range")):
+                return f"awq_clip over a block format that is not signed static INT ({name})"
+    return None
 
 
 def _run_awq(model, forward_loop, adoption=None, algorithm="awq_lite", **kwargs):

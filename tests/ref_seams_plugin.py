@@ -19,7 +19,9 @@ def pytest_configure(config):
     _moa_import.load()
     from model_optimizer_amd import modelopt_plugin
 
-    config._moq_seams = modelopt_plugin.install()
+    # MOQ_INSTALL_ALGORITHMS=1: the algorithm seam (S7) on top -- the reference's tests then calibrate through this package's
+    # fused flows wherever a model is adoptable, and through their own code (counted fallbacks) wherever it is not
+    config._moq_seams = modelopt_plugin.install(algorithms=os.environ.get("MOQ_INSTALL_ALGORITHMS") == "1")
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):

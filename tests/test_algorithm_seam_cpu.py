@@ -268,3 +268,29 @@ def test_an_option_the_search_does_not_know_hands_the_call_back(monkeypatch):
     assert "some_new_knob" in ma._awq_precheck({"algorithm": "awq_lite", "some_new_knob": 3})
     assert ma._awq_precheck({"algorithm": "awq_lite", "some_new_knob": None}) is None  # (an unset option changes nothing)
     assert ma._mse_precheck({"fp8_scale_sweep": True}) and ma._mse_precheck({"step_size": 0.1}) is None
+
+
+def test_a_clip_search_over_a_format_it_does_not_take_hands_the_call_back():
+    """awq_clip / awq_full over NVFP4 blocks (the reference's per-tensor-scaled branch, model_calib.py:1804-1813) is outside this
+    path: the precheck says so before anything is adopted, so the reference's own search runs; signed static INT blocks pass."""
+    ref_shim.install()
+    import modelopt.torch.quantization as mtq
+    from modelopt.torch.quantization.conversion import replace_quant_module, set_quantizer_by_cfg
+
+    from model_optimizer_amd import modelopt_algorithms as ma
+
+    def converted(preset):
+        m = torch.nn.Sequential(torch.nn.Linear(32, 32), torch.nn.ReLU(), torch.nn.Linear(32, 16))
+        replace_quant_module(m)
+        set_quantizer_by_cfg(m, copy.deepcopy(getattr(mtq, preset))["quant_cfg"])
+        return m
+
+    for preset in ("NVFP4_AWQ_CLIP_CFG", "NVFP4_AWQ_FULL_CFG"):
+        m = converted(preset)
+        assert ma._awq_precheck({"algorithm": "awq_lite"}, m) is None
+        for algorithm in ("awq_clip", "awq_full"):
+            assert "not signed static INT" in ma._awq_precheck({"algorithm": algorithm}, m), (preset, algorithm)
+    for preset in ("INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG"):
+        m = converted(preset)
+        for algorithm in ("awq_lite", "awq_clip", "awq_full"):
+            assert ma._awq_precheck({"algorithm": algorithm}, m) is None, (preset, algorithm)

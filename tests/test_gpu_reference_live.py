@@ -654,7 +654,7 @@ REFERENCE_TEST_FILES = ["test_tensor_quant_cuda.py", "test_quantize_mxformats_cu
                         "test_real_quantize_cuda.py"]
 
 
-def run_reference_tests(files, seams=True, timeout=900, extra_args=()):
+def run_reference_tests(files, seams=True, timeout=900, extra_args=(), algorithms=False):
     """pytest subprocess over the reference's own test files.  Returns (summary dict, per-test outcomes, raw tail)."""
     root = ref_shim.reference_root()
     shim = ref_shim.install()
@@ -664,6 +664,7 @@ def run_reference_tests(files, seams=True, timeout=900, extra_args=()):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, shim, root, os.path.join(root, "tests")])
     env["MOQ_INSTALL_SEAMS"] = "1" if seams else "0"
+    env["MOQ_INSTALL_ALGORITHMS"] = "1" if algorithms else "0"
     env["MOQ_REPO_ROOT"] = ROOT
     report = os.path.join(root, f"report_{'seams' if seams else 'plain'}_{os.getpid()}.txt")
     cmd = [sys.executable, "-m", "pytest", "-p", "ref_seams_plugin", "-q", "-rA", "--no-header",
@@ -723,3 +724,24 @@ def test_the_references_own_gpu_tests_pass_with_the_seams_installed(ref):
          f"{'; '.join(ln[8:] for ln in seam_lines)}")
     assert counts.get("passed", 0) >= 600, out[-3000:]
     assert not unexpected, f"{len(unexpected)} reference tests fail with the seams installed: {unexpected[:20]}\n{out[-3000:]}"
+
+
+def test_the_references_own_quantize_tests_pass_with_the_algorithm_seam_installed(ref):
+    """tests/gpu/torch/quantization/test_quantize_cuda.py -- the reference's high-level `mtq.quantize` tests: 22 configurations
+    (INT8 / FP8 / W4A8 / SmoothQuant / INT4 blockwise / AWQ lite, clip, full / NVFP4 variants / SVDQuant / local Hessian / MX
+    formats / KV rotation / 2-D blocks / MSE with and without the FP8 scale sweep) x linear, conv and conv + linear models, save /
+    restore, ... -- unmodified, collected after install(algorithms=True).  Every test that passes with the kernel seams alone must
+    pass with the algorithm seam on top: adoptable models calibrate through this package's flows, everything else (conv weights,
+    NVFP4 static blocks, rotation, SVDQuant, the FP8 scale sweep) is handed back to the reference's own function, and the
+    counters say which was which."""
+    base_counts, base, _ = run_reference_tests(["test_quantize_cuda.py"], seams=True)
+    counts, outcomes, out = run_reference_tests(["test_quantize_cuda.py"], seams=True, algorithms=True)
+    regressed = sorted(t for t, v in base.items() if v == "PASSED" and outcomes.get(t) != "PASSED")
+    seam_lines = [ln[8:] for ln in out.splitlines() if ln.startswith("[seams] S7")]
+    served = [ln for ln in seam_lines if "fallback" not in ln]
+    handed_back = [ln for ln in seam_lines if "fallback" in ln]
+    note(f"the reference's own test_quantize_cuda.py with the ALGORITHM seam installed: {counts} (kernel seams alone: {base_counts}); "
+         f"served by S7: {'; '.join(served)}; handed back: {len(handed_back)} kinds, e.g. {'; '.join(handed_back[:4])}")
+    assert not regressed, f"{len(regressed)} reference tests pass with the kernel seams and fail with the algorithm seam: {regressed[:10]}\n{out[-3000:]}"
+    assert counts.get("passed", 0) == base_counts.get("passed", 0) and counts.get("passed", 0) >= 30, (counts, base_counts)
+    assert any(ln.startswith("S7:max_calibrate =") for ln in served) and any(ln.startswith("S7:awq =") for ln in served), seam_lines
