@@ -1081,6 +1081,20 @@ def _layer_local_plan(model: nn.Module, explicit: bool = False):
     return layers
 
 
+_NO_INSTANCE_FORWARD = object()
+
+
+def _restore_forward(m, previous):
+    """Undo `m.forward = patched`: put back the INSTANCE attribute the module had before (an accelerate hook, a user's patch) or
+    remove the instance attribute, so that the class's own forward is looked up again -- assigning the bound method read before the
+    patch would pin the module to the class it had during the search (under the algorithm seam that class is handed back to the
+    reference afterwards; the reference's `unpatch_forward_method` does the same: utils/network.py)."""
+    if previous is _NO_INSTANCE_FORWARD:
+        m.__dict__.pop("forward", None)
+    else:
+        m.forward = previous
+
+
 @torch.no_grad()
 def _awq_lite_layer_local(model: nn.Module, forward_loop, layers, **kw):
     """awq_lite one decoder layer at a time (see awq_lite, `layer_local`).  The model's own forward runs up to the first
@@ -1465,7 +1479,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
 
     originals = {}
     for _, m in mods:
-        originals[m] = m.forward
+        originals[m] = m.__dict__.get("forward", _NO_INSTANCE_FORWARD)
         m.forward = patched_forward.__get__(m, type(m))
 
     def finish_gram_pass():
@@ -1747,7 +1761,7 @@ def awq_lite(model: nn.Module, forward_loop, alpha_step: float = 0.1, search: st
                 h.search_steps_all_ranks = int(n)
     finally:
         for m, f in originals.items():
-            m.forward = f
+            _restore_forward(m, f)
         for h in helpers.values():
             h.release()
             h.gram = None
@@ -1914,7 +1928,7 @@ def awq_clip(model: nn.Module, forward_loop, max_co_batch_size: int = 1024, max_
 
     originals = {}
     for _, m in mods:
-        originals[m] = m.forward
+        originals[m] = m.__dict__.get("forward", _NO_INSTANCE_FORWARD)
         m.forward = patched_forward.__get__(m, type(m))
     try:
         enable_stats_collection(model)  # input / KV quantizers collect during the same pass (:1910-1913)
@@ -1927,7 +1941,7 @@ def awq_clip(model: nn.Module, forward_loop, max_co_batch_size: int = 1024, max_
             mdist.sync_amax_bucketed([q for q in _quantizers(model) if q.is_enabled])
     finally:
         for m, f in originals.items():
-            m.forward = f
+            _restore_forward(m, f)
     for _, m in mods:
         h = helpers[m]
         if h.num_tokens > 0:  # postprocess (:1921-1929)

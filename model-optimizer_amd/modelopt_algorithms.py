@@ -166,6 +166,19 @@ def _write_back(r, t, R):
         else:
             out = buf.detach().to(t._calibrator._dtype or buf.dtype)
             cal._calib_amax = out.reshape(t._calibrator._shape) if t._calibrator._shape is not None else out
+    if "_block_reshape_size" in td and "_block_reshape_size" not in d and d.get("_block_sizes"):
+        # The twin met its first tensor during the call and fixed its block layout; the reference's quantizer would have done
+        # the same in the reference's own run (`_setup_for_blockquant`, tensor_quantizer.py:975-1043: `_original_shape`,
+        # `_block_reshape_size`, `_padding`, `_slices`, and `_amax_shape_for_export`, which `export_amax` reads WITHOUT a
+        # forward in between, :1095-1098).  The two sides lay N-D blocks out differently, so the values are not copied: the
+        # reference computes its own from the shape the twin saw (a meta tensor: shapes only).
+        shape = list(td["_original_shape"])
+        for i, sl in enumerate(td.get("_slices") or ()):
+            if isinstance(sl, slice) and sl.stop is not None:
+                shape[i] = sl.stop  # (the unpadded extent)
+        with contextlib.suppress(Exception):
+            if getattr(r, "is_static_block_quant", False):
+                r._setup_for_blockquant(torch.empty(shape, device="meta"))
     if getattr(t, "_is_static_block_scale_quantizer", False) and R["Static"] is not None and not isinstance(r, R["Static"]):
         R["Static"].from_tensor_quantizer(r)
 

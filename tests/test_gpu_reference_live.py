@@ -669,7 +669,7 @@ def run_reference_tests(files, seams=True, timeout=900, extra_args=(), algorithm
     report = os.path.join(root, f"report_{'seams' if seams else 'plain'}_{os.getpid()}.txt")
     cmd = [sys.executable, "-m", "pytest", "-p", "ref_seams_plugin", "-q", "-rA", "--no-header",
            "-p", "no:cacheprovider", "--rootdir", os.path.join(root, "tests"), "-c", os.path.join(shim, "pytest.ini"),
-           *extra_args, *[os.path.join(tdir, f) for f in files]]
+           *extra_args, *[os.path.join(os.path.dirname(tdir), f) if "/" in f else os.path.join(tdir, f) for f in files]]
     with open(os.path.join(shim, "pytest.ini"), "w") as f:
         f.write("[pytest]\n")
     p = subprocess.run(cmd, env=env, cwd=os.path.join(root, "tests"), capture_output=True, text=True, timeout=timeout)
@@ -726,22 +726,40 @@ def test_the_references_own_gpu_tests_pass_with_the_seams_installed(ref):
     assert not unexpected, f"{len(unexpected)} reference tests fail with the seams installed: {unexpected[:20]}\n{out[-3000:]}"
 
 
+# the reference's GPU tests that reach a calibration algorithm, a fold or an export packer -- what S7 re-points
+REFERENCE_ALGORITHM_TEST_FILES = ["test_quantize_cuda.py", "test_calib_cuda.py", "test_real_quantize_cuda.py",
+                                  "test_layerwise_calibrate.py", "export/test_export.py", "export/test_export_weight_gpu.py",
+                                  "export/test_quant_utils.py"]
+
+
 def test_the_references_own_quantize_tests_pass_with_the_algorithm_seam_installed(ref):
-    """tests/gpu/torch/quantization/test_quantize_cuda.py -- the reference's high-level `mtq.quantize` tests: 22 configurations
-    (INT8 / FP8 / W4A8 / SmoothQuant / INT4 blockwise / AWQ lite, clip, full / NVFP4 variants / SVDQuant / local Hessian / MX
-    formats / KV rotation / 2-D blocks / MSE with and without the FP8 scale sweep) x linear, conv and conv + linear models, save /
-    restore, ... -- unmodified, collected after install(algorithms=True).  Every test that passes with the kernel seams alone must
-    pass with the algorithm seam on top: adoptable models calibrate through this package's flows, everything else (conv weights,
-    NVFP4 static blocks, rotation, SVDQuant, the FP8 scale sweep) is handed back to the reference's own function, and the
-    counters say which was which."""
-    base_counts, base, _ = run_reference_tests(["test_quantize_cuda.py"], seams=True)
-    counts, outcomes, out = run_reference_tests(["test_quantize_cuda.py"], seams=True, algorithms=True)
+    """The reference's high-level GPU tests, unmodified, collected after install(algorithms=True):
+    tests/gpu/torch/quantization/test_quantize_cuda.py (`mtq.quantize` over 22 configurations -- INT8 / FP8 / W4A8 / SmoothQuant /
+    INT4 blockwise / AWQ lite, clip, full / NVFP4 variants / SVDQuant / local Hessian / MX formats / KV rotation / 2-D blocks /
+    MSE with and without the FP8 scale sweep -- x linear, conv and conv + linear models, save / restore), test_calib_cuda.py
+    (SmoothQuant / AWQ against its own expectations), test_real_quantize_cuda.py (quantize -> compress), test_layerwise_calibrate.py
+    (its layer-by-layer wrapper around a calibration function) and tests/gpu/torch/export/{test_export, test_export_weight_gpu,
+    test_quant_utils}.py (scaling factors, packers, the checkpoint writer).  Every test that passes with the kernel seams alone
+    must pass with the algorithm seam on top: adoptable models calibrate through this package's flows, everything else (conv
+    weights, NVFP4 static blocks, rotation, SVDQuant, the FP8 scale sweep) is handed back to the reference's own function, and
+    the counters say which was which."""
+    files = [f for f in REFERENCE_ALGORITHM_TEST_FILES
+             if os.path.exists(os.path.join(ref_shim.reference_root(), "tests", "gpu", "torch", *(f.split("/") if "/" in f else ["quantization", f])))]
+    assert "test_quantize_cuda.py" in files
+    base_counts, base, base_out = run_reference_tests(files, seams=True, timeout=1500)
+    counts, outcomes, out = run_reference_tests(files, seams=True, algorithms=True, timeout=1500)
     regressed = sorted(t for t, v in base.items() if v == "PASSED" and outcomes.get(t) != "PASSED")
     seam_lines = [ln[8:] for ln in out.splitlines() if ln.startswith("[seams] S7")]
     served = [ln for ln in seam_lines if "fallback" not in ln]
     handed_back = [ln for ln in seam_lines if "fallback" in ln]
-    note(f"the reference's own test_quantize_cuda.py with the ALGORITHM seam installed: {counts} (kernel seams alone: {base_counts}); "
-         f"served by S7: {'; '.join(served)}; handed back: {len(handed_back)} kinds, e.g. {'; '.join(handed_back[:4])}")
+    note(f"the reference's own {len(files)} algorithm-level GPU test files ({', '.join(files)}) with the ALGORITHM seam installed: "
+         f"{counts} (kernel seams alone: {base_counts}); served by S7: {'; '.join(served)}; handed back: {len(handed_back)} kinds, "
+         f"e.g. {'; '.join(handed_back[:4])}")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "reference_own_gpu_tests_algorithm_seam.txt"), "w") as f:
+        f.write(out)
+    with open(os.path.join(ROOT, "gpurun_out", "reference_own_gpu_tests_algorithm_seam_base.txt"), "w") as f:
+        f.write(base_out)
     assert not regressed, f"{len(regressed)} reference tests pass with the kernel seams and fail with the algorithm seam: {regressed[:10]}\n{out[-3000:]}"
     assert counts.get("passed", 0) == base_counts.get("passed", 0) and counts.get("passed", 0) >= 30, (counts, base_counts)
     assert any(ln.startswith("S7:max_calibrate =") for ln in served) and any(ln.startswith("S7:awq =") for ln in served), seam_lines

@@ -9,7 +9,7 @@
 #
 #     oracle/_ref/reference_modelopt.tgz   <-  /root/reference/{modelopt, modelopt_recipes} and, so that the reference's OWN
 #                                              GPU tests of this path can run unmodified on top of our library,
-#                                              tests/{conftest.py, _test_utils, gpu/conftest.py, gpu/torch/quantization}
+#                                              tests/{conftest.py, _test_utils, gpu/conftest.py, gpu/torch/quantization, gpu/torch/export}
 #
 # Nothing in model-optimizer_amd/, include/ or the timed region of bench.py reads it.  Readers:
 #   * tests/golden/ref_shim.py   -- unpacks it into a temp dir when /root/reference is absent (the GPU box), so that
@@ -31,7 +31,7 @@ mkdir -p "$OUT"
 tar --sort=name --mtime='2020-01-01 00:00:00' --owner=0 --group=0 --numeric-owner \
     --exclude='__pycache__' --exclude='*.pyc' --exclude='*.cu' --exclude='*.cuh' \
     -C "$REF" -czf "$OUT/reference_modelopt.tgz.tmp" modelopt modelopt_recipes \
-    tests/conftest.py tests/_test_utils tests/gpu/conftest.py tests/gpu/torch/quantization
+    tests/conftest.py tests/_test_utils tests/gpu/conftest.py tests/gpu/torch/quantization tests/gpu/torch/export
 mv "$OUT/reference_modelopt.tgz.tmp" "$OUT/reference_modelopt.tgz"
 ( cd "$REF" && git rev-parse HEAD 2>/dev/null || echo unknown ) > "$OUT/reference_revision.txt"
 ls -l "$OUT/reference_modelopt.tgz" | awk '{print "staged", $NF, $5, "bytes"}'
