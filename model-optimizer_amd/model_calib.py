@@ -104,6 +104,18 @@ def finish_stats_collection(model: nn.Module, method: str | None = None, distrib
         q.disable_calib()
 
 
+def _foreign_weight_pairs(m) -> list:
+    """(weight, quantizer) pairs of a quantized module of ANOTHER package that enumerates its own weights -- the reference's
+    `QuantModule.iter_weights_for_calibration` (nn/modules/quant_module.py:123-129; the per-expert slices of its fused MoE
+    containers, plugins/huggingface.py:1085-1101).  Under the algorithm seam such a module keeps its class for the call while
+    its quantizers are this package's (modelopt_algorithms.Adoption); the reference calibrates those weights from the tensors
+    themselves, whatever the routing of the calibration batches did (model_calib.py:348-352), and so does this."""
+    it = getattr(m, "iter_weights_for_calibration", None)
+    if not callable(it) or is_quantized_linear(m) or is_quant_fused_experts(m):
+        return []
+    return [(w, q) for w, q in it() if isinstance(q, (TensorQuantizer, SequentialQuantizer))]
+
+
 def weight_only_quantize(model: nn.Module, shard: bool = False):
     """model_calib.py:187-199: pass every weight through its quantizer (collects weight statistics).
 
@@ -119,6 +131,8 @@ def weight_only_quantize(model: nn.Module, shard: bool = False):
     for m in model.modules():  # fused MoE expert containers: one (slice, quantizer) pair per expert and projection
         if is_quant_fused_experts(m):
             pairs += [(w, q) for w, q in m.iter_weights_for_calibration() if q.is_enabled]
+        else:
+            pairs += [(w, q) for w, q in _foreign_weight_pairs(m) if q.is_enabled]
     if shard and _dist_on():
         pairs = mdist.shard_list(pairs)
     batched = []
@@ -357,6 +371,8 @@ def _mse_calibrate_weights(model: nn.Module, step_size: float, start_multiplier:
             pairs.append((m.weight, m.weight_quantizer))
         elif is_quant_fused_experts(m):
             pairs += list(m.iter_weights_for_calibration())
+        else:
+            pairs += _foreign_weight_pairs(m)
     for weight, wq in pairs:
         if (not isinstance(wq, TensorQuantizer) or not wq.is_enabled or wq._dynamic or wq._block_dynamic
                 or wq._calibrator is None or getattr(wq, "_amax", None) is None):

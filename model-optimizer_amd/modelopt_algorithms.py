@@ -192,6 +192,8 @@ class Adoption:
         self.pairs: dict[int, tuple] = {}  # id(reference leaf quantizer) -> (reference, twin)
         self.swapped: list = []  # (parent, key, reference child)
         self.linears: list = []  # (module, reference class)
+        self.forwards: list = []  # (module, the instance-level forward the reference's own awq_lite left on it)
+        self.foreign_weighted: list = []  # names of modules that keep their class and hold weight quantizers of their own kind
 
     # -- what the model holds ---------------------------------------------------------------------------------------
     def _leaf(self, r):
@@ -229,6 +231,11 @@ class Adoption:
                 raise CannotAdopt(f"a data-parallel subgroup on {name or type(m).__name__}")
         weighted = [k for k, c in m._modules.items() if k.endswith("weight_quantizer") and c is not None]
         if not weighted:
+            # a module that enumerates weights of its own kind (a fused MoE expert container: one quantizer per expert in a
+            # ModuleList, plugins/huggingface.py:1085-1101) keeps its class; max / mse calibrate its weights through
+            # model_calib._foreign_weight_pairs, a fold is the reference's (its per-module `fold_weight` overrides)
+            if any(k.endswith("weight_quantizers") and c is not None and len(c) for k, c in m._modules.items()):
+                self.foreign_weighted.append(name or type(m).__name__)
             return
         enabled = any(getattr(q, "is_enabled", True) for k in weighted
                       for q in (m._modules[k] if isinstance(m._modules[k], R["Seq"]) else [m._modules[k]]))
@@ -240,8 +247,28 @@ class Adoption:
                         and isinstance(m._modules.get("input_quantizer"), R["TQ"])
                         and isinstance(m._parameters.get("weight"), torch.Tensor) and m._parameters["weight"].dim() == 2)
         if plain_linear:
+            # ... and nothing but the reference's two quantized bases between the module's class and that forward: a subclass
+            # with a forward of its own (SVDQuantLinear's low-rank branch, RealQuantLinear's GEMM dispatch) computes something
+            # this package's QuantLinear does not
+            own = [c.__name__ for c in type(m).__mro__[:type(m).__mro__.index(base)]
+                   if "forward" in c.__dict__ and c.__name__ not in ("QuantLinearConvBase", "QuantInputBase")]
+            if own:
+                raise CannotAdopt(f"{own[0]} ({name}) has a forward of its own")
             if m._parameters["weight"].is_meta or hasattr(m, "_hf_hook") and getattr(m._hf_hook, "offload", False):
                 raise CannotAdopt("offloaded weights")
+            if "_forward_pre_dm" in m.__dict__:
+                # a forward the caller patched onto the instance BEFORE the conversion: the reference's quantized forward
+                # calls it in place of the class's (quant_module.py:204-221, opt/dynamic.py:626-631)
+                raise CannotAdopt(f"a forward patched before the conversion on {name or type(m).__name__}")
+            patched = m.__dict__.get("forward")
+            if patched is not None:
+                # An instance-level `forward` shadows the class's -- swapping the class would change nothing.  The one kind
+                # taken along: what the reference's own awq_lite leaves behind (`unpatch_forward_method`, utils/network.py:
+                # 671-675: a bound method of this very module whose function is a forward of its class hierarchy); it is set
+                # aside for the call and put back on release.  Anything else (an accelerate hook, a user's patch) is the caller's.
+                fn = getattr(patched, "__func__", None)
+                if getattr(patched, "__self__", None) is not m or not any(c.__dict__.get("forward") is fn for c in type(m).__mro__):
+                    raise CannotAdopt(f"a patched forward on {name or type(m).__name__}")
             self.linears.append((m, type(m)))
         elif enabled:
             raise CannotAdopt(f"{type(m).__name__} ({name}) has an enabled weight quantizer and is not a plain quantized nn.Linear")
@@ -251,7 +278,7 @@ class Adoption:
         R = self.R
         if isinstance(self.model, (R["TQ"], R["Seq"])):
             raise CannotAdopt("the root is a quantizer")
-        self.linears, self._twins = [], []
+        self.linears, self._twins, self.foreign_weighted = [], [], []
         for name, m in self.model.named_modules():
             self._check_module(name, m)
         for m in list(self.model.modules()):
@@ -271,12 +298,17 @@ class Adoption:
             self.swapped.append((m, key, child))
         for m, _ in self.linears:
             m.__class__ = QuantLinear
+            if "forward" in m.__dict__:
+                self.forwards.append((m, m.__dict__.pop("forward")))
         return self
 
     def _restore_structure(self):
         for m, cls in self.linears:
             if m.__class__ is QuantLinear:
                 m.__class__ = cls
+        for m, f in self.forwards:
+            m.__dict__.setdefault("forward", f)
+        self.forwards = []
         for m, key, child in self.swapped:
             m._modules[key] = child
 
@@ -483,7 +515,10 @@ def _fold_weight_adapter(rmq):
         adoption = None
         if why is None:
             try:
-                adoption = Adoption(model).probe().__enter__()
+                adoption = Adoption(model).probe()
+                if adoption.foreign_weighted:
+                    raise CannotAdopt(f"{adoption.foreign_weighted[0]} folds its own weights")
+                adoption.__enter__()
             except CannotAdopt as e:
                 why, adoption = str(e), None
         if adoption is None:

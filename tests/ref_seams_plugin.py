@@ -12,6 +12,26 @@ def pytest_configure(config):
     root = os.environ.get("MOQ_REPO_ROOT")
     if root and root not in sys.path:
         sys.path.insert(0, root)
+    if os.environ.get("MOQ_S7_HOSTMEM") == "1":
+        # CPU tier: ONLY the algorithm seam, the C-ABI served by the host-memory stand-in (tests/hostmem_backend.py) and the
+        # seams' "is this a GPU tensor" gate opened -- the reference's own UNIT tests then calibrate through this package's
+        # flows on CPU tensors (tests/test_algorithm_seam_cpu.py::test_the_references_own_unit_tests_...)
+        import _moa_import
+
+        moa = _moa_import.load()
+        import hostmem_backend
+        from model_optimizer_amd import modelopt_plugin
+
+        class _Patch:
+            @staticmethod
+            def setattr(obj, name, value):
+                setattr(obj, name, value)
+
+        hostmem_backend.install(_Patch, moa)
+        modelopt_plugin._takes = lambda t: True
+        config._moq_seams = modelopt_plugin.install(extensions=False, backend=False, utilities=False, sparsity_seam=False,
+                                                    algorithms=True)
+        return
     if os.environ.get("MOQ_INSTALL_SEAMS") != "1":
         return
     import _moa_import
