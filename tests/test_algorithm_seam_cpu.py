@@ -310,8 +310,9 @@ def test_an_option_the_search_does_not_know_hands_the_call_back(monkeypatch):
 
 
 def test_a_clip_search_over_a_format_it_does_not_take_hands_the_call_back():
-    """awq_clip / awq_full over NVFP4 blocks (the reference's per-tensor-scaled branch, model_calib.py:1804-1813) is outside this
-    path: the precheck says so before anything is adopted, so the reference's own search runs; signed static INT blocks pass."""
+    """An AWQ search over NVFP4 blocks (two-level scales, dynamic blocks; awq_clip's per-tensor-scaled branch, model_calib.py:
+    1804-1813) is outside this path: the precheck says so before anything is adopted, so the reference's own search runs; signed
+    static INT blocks pass."""
     ref_shim.install()
     import modelopt.torch.quantization as mtq
     from modelopt.torch.quantization.conversion import replace_quant_module, set_quantizer_by_cfg
@@ -324,11 +325,10 @@ def test_a_clip_search_over_a_format_it_does_not_take_hands_the_call_back():
         set_quantizer_by_cfg(m, copy.deepcopy(getattr(mtq, preset))["quant_cfg"])
         return m
 
-    for preset in ("NVFP4_AWQ_CLIP_CFG", "NVFP4_AWQ_FULL_CFG"):
+    for preset in ("NVFP4_AWQ_LITE_CFG", "NVFP4_AWQ_CLIP_CFG", "NVFP4_AWQ_FULL_CFG"):
         m = converted(preset)
-        assert ma._awq_precheck({"algorithm": "awq_lite"}, m) is None
-        for algorithm in ("awq_clip", "awq_full"):
-            assert "not signed static INT" in ma._awq_precheck({"algorithm": algorithm}, m), (preset, algorithm)
+        for algorithm in ("awq_lite", "awq_clip", "awq_full"):
+            assert "two-level / dynamic block format" in ma._awq_precheck({"algorithm": algorithm}, m), (preset, algorithm)
     for preset in ("INT4_AWQ_CFG", "W4A8_AWQ_BETA_CFG"):
         m = converted(preset)
         for algorithm in ("awq_lite", "awq_clip", "awq_full"):

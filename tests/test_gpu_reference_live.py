@@ -728,8 +728,10 @@ def test_the_references_own_gpu_tests_pass_with_the_seams_installed(ref):
 
 # the reference's GPU tests that reach a calibration algorithm, a fold or an export packer -- what S7 re-points
 REFERENCE_ALGORITHM_TEST_FILES = ["test_quantize_cuda.py", "test_calib_cuda.py", "test_real_quantize_cuda.py",
-                                  "test_layerwise_calibrate.py", "export/test_export.py", "export/test_export_weight_gpu.py",
-                                  "export/test_quant_utils.py"]
+                                  "test_layerwise_calibrate.py", "test_gptq.py", "test_nvfp4_static_quantizer_cuda.py",
+                                  "test_tensor_quantizer_cuda.py", "test_qtensor_cuda.py",
+                                  "quantization/plugins/test_accelerate_gpu.py", "quantization/plugins/test_attention_quant.py",
+                                  "export/test_export.py", "export/test_export_weight_gpu.py", "export/test_quant_utils.py"]
 
 
 def test_the_references_own_quantize_tests_pass_with_the_algorithm_seam_installed(ref):
