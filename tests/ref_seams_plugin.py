@@ -12,7 +12,7 @@ def pytest_configure(config):
     root = os.environ.get("MOQ_REPO_ROOT")
     if root and root not in sys.path:
         sys.path.insert(0, root)
-    if os.environ.get("MOQ_S7_HOSTMEM") == "1":
+    if os.environ.get("MOQ_S7_HOSTMEM") in ("1", "all"):
         # CPU tier: ONLY the algorithm seam, the C-ABI served by the host-memory stand-in (tests/hostmem_backend.py) and the
         # seams' "is this a GPU tensor" gate opened -- the reference's own UNIT tests then calibrate through this package's
         # flows on CPU tensors (tests/test_algorithm_seam_cpu.py::test_the_references_own_unit_tests_...)
@@ -28,8 +28,9 @@ def pytest_configure(config):
                 setattr(obj, name, value)
 
         hostmem_backend.install(_Patch, moa)
-        modelopt_plugin._takes = lambda t: True
-        config._moq_seams = modelopt_plugin.install(extensions=False, backend=False, utilities=False, sparsity_seam=False,
+        modelopt_plugin._takes = lambda t: t.device.type == "cpu"  # (stands in for `is_cuda`: meta / offloaded tensors stay out)
+        every = os.environ["MOQ_S7_HOSTMEM"] == "all"  # (also S6 reduce_amax and the S5 mask seams, on host memory)
+        config._moq_seams = modelopt_plugin.install(extensions=False, backend=False, utilities=every, sparsity_seam=every,
                                                     algorithms=True)
         return
     if os.environ.get("MOQ_INSTALL_SEAMS") != "1":

@@ -358,13 +358,16 @@ def test_compress_after_the_seam_ran_the_calibration(monkeypatch, preset):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The reference's OWN unit tests (tests/unit/torch/{quantization,export}: ~1000 tests -- every preset on linear / conv models,
-# save / restore, calibrators, the HF plugins incl. fused and sequential MoE experts, attention, accelerate and peft, forward
-# patching, layer-by-layer calibration, the export helpers ...), unmodified, in a pytest subprocess that installs ONLY the
-# algorithm seam, served by the host-memory stand-in (tests/ref_seams_plugin.py, MOQ_S7_HOSTMEM=1).  Whatever passes without
-# the seam must pass with it.  Round 6 found four defects this way (a leaked instance-level forward, SVDQuantLinear adopted as a
+# The reference's OWN unit tests (tests/unit/torch/{quantization,export,sparsity}: ~1200 tests -- every preset on linear / conv
+# models, save / restore, calibrators, the HF plugins incl. fused and sequential MoE experts, attention, accelerate and peft,
+# forward patching, layer-by-layer calibration, the export helpers, magnitude and SparseGPT sparsification ...), unmodified, in a
+# pytest subprocess that installs the algorithm seam and the seams that take plain tensors (S6 reduce_amax; the S5 mask seams are
+# installed too, the reference's sparsity unit tests use weights below their size gate),
+# served by the host-memory stand-in (tests/ref_seams_plugin.py, MOQ_S7_HOSTMEM=all; S1's extension objects are only asked for
+# by CUDA tensors).  Whatever passes without the seams must pass with them.  Round 6 found four defects this way (a leaked instance-level forward, SVDQuantLinear adopted as a
 # plain linear, a forward patched before the conversion, weights of never-routed fused experts left without statistics).
-def _run_reference_unit_tests(dirs, s7):
+def _run_reference_unit_tests(targets, s7):
+    """pytest subprocess over directories of tests/unit/torch or over test ids; {test id: outcome}, raw output."""
     import re
     import subprocess
 
@@ -372,12 +375,12 @@ def _run_reference_unit_tests(dirs, s7):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([os.path.join(repo, "tests"), repo, shim, root, os.path.join(root, "tests")])
-    env.update(MOQ_REPO_ROOT=repo, MOQ_S7_HOSTMEM="1" if s7 else "0", MOQ_INSTALL_SEAMS="0")
+    env.update(MOQ_REPO_ROOT=repo, MOQ_S7_HOSTMEM="all" if s7 else "0", MOQ_INSTALL_SEAMS="0")
     with open(os.path.join(shim, "pytest.ini"), "w") as f:
         f.write("[pytest]\n")
+    paths = [os.path.join(root, "tests", t) if "::" in t else os.path.join(root, "tests", "unit", "torch", t) for t in targets]
     cmd = [sys.executable, "-m", "pytest", "-p", "ref_seams_plugin", "-q", "-rA", "--no-header", "--continue-on-collection-errors",
-           "-p", "no:cacheprovider", "--rootdir", os.path.join(root, "tests"), "-c", os.path.join(shim, "pytest.ini"),
-           *[os.path.join(root, "tests", "unit", "torch", d) for d in dirs]]
+           "-p", "no:cacheprovider", "--rootdir", os.path.join(root, "tests"), "-c", os.path.join(shim, "pytest.ini"), *paths]
     p = subprocess.run(cmd, env=env, cwd=os.path.join(root, "tests"), capture_output=True, text=True, timeout=1500)
     out = p.stdout + "\n" + p.stderr
     outcomes = {m.group(2): m.group(1)
@@ -388,14 +391,18 @@ def _run_reference_unit_tests(dirs, s7):
 @pytest.mark.skipif(not os.path.isdir(os.path.join(ref_shim.reference_root() or "", "tests", "unit", "torch", "quantization")),
                     reason="the reference's unit tests are only in the checkout (the staged archive holds its GPU tests)")
 def test_the_references_own_unit_tests_pass_with_the_algorithm_seam_installed():
-    base, base_out = _run_reference_unit_tests(["quantization", "export"], s7=False)
-    ours, out = _run_reference_unit_tests(["quantization", "export"], s7=True)
-    passed = [t for t, v in base.items() if v == "PASSED"]
-    assert len(passed) >= 900, (len(passed), base_out[-2000:])
-    regressed = sorted(t for t in passed if ours.get(t) != "PASSED")
+    ours, out = _run_reference_unit_tests(["quantization", "export", "sparsity"], s7=True)
+    passed = [t for t, v in ours.items() if v == "PASSED"]
+    assert len(passed) >= 1100, (len(passed), out[-2000:])
+    # whatever does not pass with the seams is run again WITHOUT them (a missing optional package, a test that needs a GPU ...
+    # fail either way): only a test that passes there is a finding
+    suspects = sorted(t for t, v in ours.items() if v in ("FAILED", "ERROR") and "::" in t)
+    plain = _run_reference_unit_tests(suspects, s7=False)[0] if suspects else {}
+    regressed = [t for t in suspects if plain.get(t) == "PASSED"]
     served = {ln[8:].split(" = ")[0]: int(ln.rsplit(" = ", 1)[1]) for ln in out.splitlines()
-              if ln.startswith("[seams] S7") and "fallback" not in ln}
-    print(f"[note] the reference's own unit tests with the algorithm seam on the host-memory stand-in: {len(passed)} pass without, "
-          f"{sum(v == 'PASSED' for v in ours.values())} with; served by S7: {served}")
-    assert not regressed, f"{len(regressed)} reference unit tests fail only with the algorithm seam: {regressed[:10]}\n{out[-3000:]}"
+              if ln.startswith("[seams] S") and "fallback" not in ln}
+    print(f"[note] the reference's own unit tests with the algorithm seam, S6 and S5 on the host-memory stand-in: {len(passed)} pass, "
+          f"{len(suspects)} do not (without the seams: {sum(v == 'PASSED' for v in plain.values())} of those pass); served: {served}")
+    assert not regressed, f"{len(regressed)} reference unit tests fail only with the seams installed: {regressed[:10]}\n{out[-3000:]}"
     assert served.get("S7:max_calibrate", 0) >= 100 and served.get("S7:awq", 0) >= 10 and served.get("S7:smoothquant", 0) >= 5, served
+    assert served.get("S6:reduce_amax", 0) >= 1000, served
