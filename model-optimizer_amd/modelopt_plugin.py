@@ -81,11 +81,29 @@ class IntExtension:
         _count("S1:INT4_dequantize")
         return ops.int4_dequantize(quantized_data, scales.reshape(-1), block_size)
 
+    # NF4 is outside the MI355X PTQ path -- but an extension object cannot be absent for two of its entries only,
+    # and without an extension the reference has a working branch of its own (qtensor/nf4_tensor.py:103-118, :178-199).  These
+    # two entries therefore run THAT branch, with the reference's own helpers and table, on the tensor's device (counted): what a
+    # ROCm user of the reference gets today stays what they get with the seams installed.
     @staticmethod
-    def NF4_quantize(*a, **k):  # noqa: N802
-        raise NotImplementedError("NF4 is outside the MI355X PTQ path (SURVEY.md 2.3)")
+    def NF4_quantize(input, scales, block_size):  # noqa: N802
+        from modelopt.torch.quantization.qtensor import nf4_tensor as ref_nf4
 
-    NF4_dequantize = NF4_quantize
+        _count("S1:NF4_quantize:reference-eager")
+        blocks = input.view(-1, block_size)
+        scaled = blocks / scales.view(blocks.shape[0], -1)
+        q = ref_nf4._quantize_to_nearest_lut(scaled.flatten(), ref_nf4.nf4_table.to(device=input.device, dtype=input.dtype))
+        q = q.to(torch.uint8)
+        return q[::2] << 4 | q[1::2]
+
+    @staticmethod
+    def NF4_dequantize(quantized_data, scales, block_size):  # noqa: N802
+        from modelopt.torch.quantization.qtensor import nf4_tensor as ref_nf4
+
+        _count("S1:NF4_dequantize:reference-eager")
+        first = ref_nf4._nf4_lookup((quantized_data >> 4).to(torch.long)).view(-1, block_size // 2) * scales.view(-1, 1)
+        second = ref_nf4._nf4_lookup((quantized_data & 0x0F).to(torch.long)).view(-1, block_size // 2) * scales.view(-1, 1)
+        return torch.stack([first.flatten(), second.flatten()], dim=-1).view(-1)
 
 
 class Fp8Extension:
