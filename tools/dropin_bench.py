@@ -113,6 +113,8 @@ def reference_row(mtq, fmt, layers, batches, mode, export: bool):
         row = {"quantize_s": round(t_q, 3), "seam_calls_in_quantize": sum(v for k, v in calls.items() if "fallback" not in k),
                "fallbacks": sorted(k for k in calls if "fallback" in k),
                "s7": {k: v for k, v in calls.items() if k.startswith("S7")}}
+        if mode == "algorithms" and fmt == "int4_awq":
+            row["awq_stats"] = awq_stats()
         state = quantizer_state(q)
         alphas = {n: round(float(mod.awq_lite.best_alpha), 2) for n, mod in q.named_modules() if hasattr(mod, "awq_lite")}
         if export:
@@ -124,6 +126,15 @@ def reference_row(mtq, fmt, layers, batches, mode, export: bool):
     del q, model
     torch.cuda.empty_cache()
     return row, state, alphas
+
+
+def awq_stats():
+    """Where the fused AWQ flow spent the call (model_calib.AWQ_LITE_STATS of the run that just ended)."""
+    from model_optimizer_amd import model_calib
+
+    st = model_calib.AWQ_LITE_STATS
+    return {k: st.get(k) for k in ("passes", "replayed_passes", "layer_local", "stages_s", "store_dropped", "rescored_linears",
+                                   "rescored_candidates") if k in st}
 
 
 def mirror_row(moa, fmt, layers, batches, export: bool):
@@ -143,6 +154,8 @@ def mirror_row(moa, fmt, layers, batches, export: bool):
     with moa.numerics.scale_math("device"), torch.no_grad():
         t_q, _ = timed(lambda: moa.quantize(model, cfg, loop))
         row = {"quantize_s": round(t_q, 3)}
+        if fmt == "int4_awq":
+            row["awq_stats"] = awq_stats()
         state = quantizer_state(model)
         alphas = {n: round(float(mod.awq_lite.best_alpha), 2) for n, mod in model.named_modules() if hasattr(mod, "awq_lite")}
         if export:  # the same deliverable as the reference rows: the checkpoint DIRECTORY (tensors packed, files written)
