@@ -511,8 +511,9 @@ int moq_awq_quadform(const void* a, const void* b, const float* ref, int64_t row
  * fp8 != 0: FP8-E4M3 QDQ (as moq_fake_quant_e4m3), else INT-num_bits (as moq_fake_quant_int).  x == y allowed.
  * Replaces reduce_block_amax (quantization/utils/core_utils.py:43-90) and the eager fake-quant TensorQuantizer falls
  * back to for a two-axis block amax (nn/modules/tensor_quantizer.py:1018-1043, tensor_quant.py:80) -- the FP8 2-D
- * blockwise weight preset.  rows % br == 0, cols % bc == 0 (pad on the host), br * bc <= 32768 elements (16384 for
- * fp32), bc % (16 / elem size) == 0. */
+ * blockwise weight preset.  rows % br == 0, cols % bc == 0 (pad on the host).  Modes 1 and 2: br * bc <= 32768 elements
+ * (16384 for fp32), bc % (16 / elem size) == 0, 16-byte aligned tensors.  Mode 0 takes every tile shape and alignment (tile
+ * rows that are not whole 16-byte packets go through an element-wise tile kernel). */
 int moq_block2d(const void* x, void* y, float* amax, int64_t rows, int64_t cols, int br, int bc, int dt, int mode,
                 int accumulate, int fp8, int num_bits, int is_unsigned, int narrow_range, void* stream);
 

@@ -95,6 +95,35 @@ __global__ __launch_bounds__(kBlock) void block2d_kernel(const void* __restrict_
   }
 }
 
+// Abs-max of tiles the packet kernel does not take (a tile row that is not whole 16-byte packets: the 2 ... 8 wide blocks of
+// small test shapes and of odd layouts, or an unaligned base).  One workgroup per tile, one element per thread and step,
+// 16-bit rows read as single elements; the statistic is the same fp32 pattern (an unsigned max of |x|'s bits, NaN on top).
+template <int DT>
+__global__ __launch_bounds__(kBlock) void block2d_amax_generic_kernel(const void* __restrict__ x, float* __restrict__ amax,
+                                                                      int64_t cols, int br, int bc, int accumulate) {
+  __shared__ uint32_t smem[kBlock / 64];
+  using T = typename Elem<DT>::storage;
+  const T* xe = reinterpret_cast<const T*>(x) + ((int64_t)blockIdx.y * br) * cols + (int64_t)blockIdx.x * bc;
+  uint32_t acc = 0;
+  const int n = br * bc;
+  for (int i = (int)threadIdx.x; i < n; i += kBlock) {
+    const int r = i / bc, c = i - r * bc;
+    uint32_t a;
+    if constexpr (DT == MOQ_F32) a = __float_as_uint(xe[(int64_t)r * cols + c]) & 0x7FFFFFFFu;
+    else a = widen_abs16<DT>((uint32_t)xe[(int64_t)r * cols + c] & 0x7FFFu);
+    acc = a > acc ? a : acc;
+  }
+  acc = block_max_u32(acc, smem);
+  if (threadIdx.x == 0) {
+    const int64_t a_idx = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (accumulate) {
+      const uint32_t old = __float_as_uint(amax[a_idx]);
+      acc = old > acc ? old : acc;
+    }
+    amax[a_idx] = __uint_as_float(acc);
+  }
+}
+
 }  // namespace moq
 
 using namespace moq;
@@ -115,6 +144,14 @@ extern "C" int moq_block2d(const void* x, void* y, float* amax, int64_t rows, in
   if (rows * cols == 0) return MOQ_OK;
   const int vec = dt == MOQ_F32 ? 4 : 8;
   const int64_t packets = (int64_t)br * (bc / vec);
+  if (mode == 0 && rows % br == 0 && cols % bc == 0 && cols / bc <= 0x7FFFFFFF && rows / br <= 65535 &&
+      (int64_t)br * bc <= 0x7FFFFFFF &&
+      (bc % vec != 0 || packets > (int64_t)kB2dMaxPackets * kBlock || (reinterpret_cast<uintptr_t>(x) & 15u) != 0)) {
+    const dim3 ggrid((unsigned)(cols / bc), (unsigned)(rows / br));
+    MOQ_DISPATCH_DTYPE(dt, hipLaunchKernelGGL((block2d_amax_generic_kernel<DT>), ggrid, dim3(kBlock), 0, S(stream), x, amax, cols,
+                                              br, bc, accumulate))
+    return check_launch("moq_block2d");
+  }
   if (rows % br != 0 || cols % bc != 0 || bc % vec != 0 || packets > (int64_t)kB2dMaxPackets * kBlock ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) != 0 || cols / bc > 0x7FFFFFFF ||
       rows / br > 65535) {
