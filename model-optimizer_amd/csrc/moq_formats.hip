@@ -1130,7 +1130,7 @@ extern "C" int moq_hist_abs(const void* x, int64_t n, int dt, unsigned long long
   // Below ~12 M elements the table does not pay: every workgroup tabulates 32 768 patterns before its first element, which
   // is as much arithmetic as binning 32 K elements directly (kernel-only, 2048 bins: 8.4 MB 15.2 us with the table, 10.0 us
   // without; 33.5 MB 21.1 / 21.1 us; 67 MB 26.9 / 31.9 us -- profiles/r03_amax_flow_sizes.md).  Same hist_bin() either way.
-  constexpr int64_t kLutHistMinElems = 12ll << 20;
+  const int64_t kLutHistMinElems = moq_tune("MOQ_TUNE_HIST_MIN_ELEMS", 12ll << 20);
   if (lut_hist && dt != MOQ_F32 && bins < kHistMaxLdsBins && n >= kLutHistMinElems)
     return moq_input_quant(x, nullptr, nullptr, 1, n, dt, nullptr, nullptr, 0, 0, 0, 0, counts, bins, max_edge,
                            skip_zeros, stream);

@@ -20,6 +20,14 @@
 // an element then costs a field extract, one ds_read_u16 and the ds_add_u32: 3 VALU + 2 LDS instructions.  Results are
 // identical by construction.  fp32 inputs keep the arithmetic rule.  Counts are exact integers either way.
 //
+// Round 6, PATTERN COUNTS (PAT): the table read is itself one of the element's two LDS instructions and sits in front of
+// the atomic (a round trip per packet), and the table build is ~5 us per launch.  So when the bins leave room (<= ~7000),
+// the workgroup counts the 2^15 |x| PATTERNS instead -- 128 KiB of u32 counters, one fire-and-forget ds_add_u32 per
+// element, nothing to build -- and applies the binning rule once per pattern THAT OCCURRED when it flushes: hist_bin() of
+// the pattern's value, its count added to the workgroup's bins, the bins to global memory as before.  Patterns spread
+// over the counters by themselves (an octave is 128 / 1024 patterns wide), except |x| == 0 (ReLU outputs, padding): zeros
+// take one counter per lane.  Same hist_bin(), same counts.
+//
 // Layout: 1024-thread workgroups (four 256-thread quarters walking their own 8192-element chunks, moq_chunk.h) so
 // that the one LDS histogram (+ table) of a workgroup is shared by 16 waves; <= 512 workgroups (one per CU with the
 // table: 64 KiB table + <= 64 KiB of interleaved histogram copies).
@@ -39,6 +47,10 @@ constexpr int kLutEntries = 32768;  // |x| patterns of a 16-bit float
 // when every lane has its own dword), and activations whose range is set by a few outliers put most elements into
 // the very lowest bins.  The kHotBins lowest bins therefore get one copy PER LANE (conflict-free whatever the data);
 // the other bins share R = 2^rshift interleaved copies.  Slot layout: [hot bins: bin * 64 + lane][bins: bin * R + copy].
+// PAT layout: [pattern counters: 32768][past-the-end trash: 64][|x| == 0, one per lane: 64][bins + 1]
+constexpr int kPatTrash = kLutEntries;
+constexpr int kPatZero = kLutEntries + 64;
+constexpr int kPatSlots = kLutEntries + 128;
 constexpr int kHotBins = 32;
 constexpr int kHotSlots = kHotBins * 64;
 __device__ __forceinline__ uint32_t slot_base(int bin, int rshift) {
@@ -57,10 +69,16 @@ struct IqParams {
   int bins;
   float max_edge;
   int skip_zeros, rshift;
+  int dbg;  // experiment build only: timing diagnostics that skip parts of the histogram stage (results are wrong)
 };
 
 // FMT: 0 no quantization, 1 INT-k, 2 FP8-E4M3
-template <int DT, int FMT, bool PQS, bool AMAX, bool HIST, bool SHARED>
+#ifdef MOQ_EXPERIMENTS
+#define MOQ_IQ_DBG(bit) ((p.dbg >> (bit)) & 1)
+#else
+#define MOQ_IQ_DBG(bit) 0
+#endif
+template <int DT, int FMT, bool PQS, bool AMAX, bool HIST, bool SHARED, bool PAT>
 __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p) {
   constexpr int V = Elem<DT>::kVec;
   constexpr int P = Chunk<DT>::kPackets;
@@ -70,8 +88,9 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   const int lane = threadIdx.x & 63;
   const int copy = (int)(threadIdx.x & ((1u << p.rshift) - 1u));
   const SharedDiv sd = make_shared_div(p.max_edge);
-  constexpr bool LUT = HIST && DT != MOQ_F32;
-  const int slots = kHotSlots + ((p.bins + 1) << p.rshift);
+  constexpr bool PATM = HIST && PAT && DT != MOQ_F32;
+  constexpr bool LUT = HIST && DT != MOQ_F32 && !PATM;
+  const int slots = PATM ? kPatSlots + p.bins + 1 : kHotSlots + ((p.bins + 1) << p.rshift);
   // LDS: [histogram: slots x u32][table: 32768 x u16 (16-bit inputs)]
   uint16_t* lut = reinterpret_cast<uint16_t*>(lds_hist + slots);
   // The first two chunks of every quarter are requested BEFORE the histogram is zeroed and the table is built: at the
@@ -98,7 +117,12 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
   if (c_first < n_chunks) load_chunk(c_first, buf_a);
   if (c_first + stride < n_chunks) load_chunk(c_first + stride, buf_b);
   if constexpr (HIST) {
-    for (int b = threadIdx.x; b < slots; b += kIqBlock) lds_hist[b] = 0;
+    if constexpr (PATM) {  // (the allocation is rounded up to whole 16-byte packets)
+      const u32x4_t zero = {0u, 0u, 0u, 0u};
+      for (int b = threadIdx.x; b < (slots + 3) / 4; b += kIqBlock) reinterpret_cast<u32x4_t*>(lds_hist)[b] = zero;
+    } else {
+      for (int b = threadIdx.x; b < slots; b += kIqBlock) lds_hist[b] = 0;
+    }
     if constexpr (LUT) {
       // lut[|x| pattern] = first slot of the pattern's bin (slot_base; invalid -> the trash bin `bins`)
       for (int v = threadIdx.x; v < kLutEntries; v += kIqBlock) {
@@ -174,7 +198,26 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
         }
       }
       if constexpr (HIST) {
-        if constexpr (LUT) {
+        if constexpr (PATM) {
+          const Pack16 pv = PQS ? pack<DT>(f) : in[u];
+          const uint32_t zslot = (uint32_t)(kPatZero + lane);
+          if (MOQ_IQ_DBG(3)) {
+          } else if (fast) {  // (uniform; two bodies so that the live one carries no range tests)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t lo = pv.w[i] & 0x7FFFu, hi = (pv.w[i] >> 16) & 0x7FFFu;
+              atomicAdd(&lds_hist[lo ? lo : zslot], 1u);
+              atomicAdd(&lds_hist[hi ? hi : zslot], 1u);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t lo = pv.w[i] & 0x7FFFu, hi = (pv.w[i] >> 16) & 0x7FFFu;
+              atomicAdd(&lds_hist[e + 2 * i < p.n ? (lo ? lo : zslot) : (uint32_t)kPatTrash], 1u);
+              atomicAdd(&lds_hist[e + 2 * i + 1 < p.n ? (hi ? hi : zslot) : (uint32_t)kPatTrash], 1u);
+            }
+          }
+        } else if constexpr (LUT) {
           // the 16-bit patterns of v: straight from the packet, or re-packed when a pre_quant_scale changed them
           const Pack16 pv = PQS ? pack<DT>(f) : in[u];
           uint32_t slot[8];  // all table reads of the packet first, then its atomics: one LDS round trip per packet
@@ -237,7 +280,54 @@ __global__ __launch_bounds__(kIqBlock) void input_quant_kernel(const IqParams p)
       if (m > amax_seen) atomicMax(p.amax_bits, m);
     }
   }
-  if constexpr (HIST) {
+  if constexpr (PATM) {
+    // the binning rule once per pattern that occurred; step i covers patterns [1024 i, 1024 i + 1024): the occupied
+    // octaves are a few steps in which every wave has work, and a wave skips the steps its lanes saw nothing in
+    uint32_t* wg_bins = lds_hist + kPatSlots;
+    auto bin_of = [&](int v) {
+      float a;
+      if constexpr (DT == MOQ_BF16) a = __uint_as_float((uint32_t)v << 16);
+      else { uint16_t h = (uint16_t)v; a = (float)*reinterpret_cast<_Float16*>(&h); }
+      return hist_bin<SHARED>(a, p.bins, p.max_edge, sd, p.skip_zeros);
+    };
+    // Bins grow with the pattern, so the lanes of a wave (consecutive patterns) that share a bin are neighbours -- and whole
+    // waves share ONE where many octaves fall into the lowest bin or outside the range: those add their sum once (64
+    // same-address LDS atomics of one instruction serialise)
+    auto add_counts = [&](int v, uint32_t cnt) {  // (called by whole waves)
+      const unsigned long long live = __builtin_amdgcn_ballot_w64(cnt != 0);
+      if (live == 0) return;
+      const int b = bin_of(v);
+      const int b0 = __builtin_amdgcn_readlane(b, __builtin_ctzll(live));
+      if (__builtin_amdgcn_ballot_w64(cnt != 0 && b != b0) == 0) {
+        uint32_t tot = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) tot += (uint32_t)__shfl_xor((int)tot, off, 64);
+        if (lane == 0) atomicAdd(&wg_bins[b0], tot);
+      } else if (cnt) {
+        atomicAdd(&wg_bins[b], cnt);
+      }
+    };
+    if (!MOQ_IQ_DBG(0)) {
+      constexpr int kSteps = kLutEntries / kIqBlock;
+      uint32_t cnt[kSteps];  // all counters of the thread are requested before the first is looked at
+#pragma unroll
+      for (int i = 0; i < kSteps; ++i) cnt[i] = lds_hist[i * kIqBlock + (int)threadIdx.x];
+#pragma unroll
+      for (int i = 0; i < kSteps; ++i) add_counts(i * kIqBlock + (int)threadIdx.x, cnt[i]);
+      if (threadIdx.x < 64) add_counts(0, lds_hist[kPatZero + threadIdx.x]);
+    }
+    __syncthreads();
+    if (!MOQ_IQ_DBG(1)) {
+      // every workgroup starts its flush at another bin: 256 workgroups arriving at the same addresses in the same order
+      // queue up behind each other at the memory side
+      const int rot = (int)(((int64_t)blockIdx.x * p.bins) / gridDim.x);
+      for (int k = threadIdx.x; k < p.bins; k += kIqBlock) {
+        const int b = k + rot < p.bins ? k + rot : k + rot - p.bins;
+        const uint32_t c = wg_bins[b];
+        if (c) atomicAdd(&p.counts[b], (unsigned long long)c);
+      }
+    }
+  } else if constexpr (HIST) {
     for (int b = threadIdx.x; b < p.bins; b += kIqBlock) {
       uint32_t cnt = 0;
       const int copies = b < kHotBins ? 64 : (1 << p.rshift);
@@ -257,19 +347,26 @@ constexpr int kIqMaxLdsBins = 16384;   // bin counts beyond this go to moq_hist_
 constexpr size_t kIqLdsBudget = 156 * 1024;  // of the CU's 160 KiB (a few words of static LDS come on top)
 
 template <int DT, int FMT, bool PQS>
-static void launch_iq(const IqParams& p, bool amax, bool hist, bool shared, int blocks, size_t lds, void* stream) {
-#define MOQ_IQ_GO(A, H, SH)                                                                                         \
+static void launch_iq(const IqParams& p, bool amax, bool hist, bool shared, bool pat, int blocks, size_t lds, void* stream) {
+#define MOQ_IQ_GO(A, H, SH, PT)                                                                                       \
   do {                                                                                                              \
     if (lds > 64 * 1024) {                                                                                          \
       /* > 64 KiB of dynamic LDS needs the opt-in attribute, per device; setting it again is harmless */           \
-      lds_opt_in((const void*)input_quant_kernel<DT, FMT, PQS, A, H, SH>, (int)kIqLdsBudget, "input_quant_kernel");  \
+      lds_opt_in((const void*)input_quant_kernel<DT, FMT, PQS, A, H, SH, PT>, (int)kIqLdsBudget, "input_quant_kernel");  \
     }                                                                                                               \
-    hipLaunchKernelGGL((input_quant_kernel<DT, FMT, PQS, A, H, SH>), dim3(blocks), dim3(kIqBlock), lds, S(stream), p); \
+    hipLaunchKernelGGL((input_quant_kernel<DT, FMT, PQS, A, H, SH, PT>), dim3(blocks), dim3(kIqBlock), lds, S(stream), p); \
   } while (0)
-  if (amax && hist) { if (shared) MOQ_IQ_GO(true, true, true); else MOQ_IQ_GO(true, true, false); }
-  else if (hist) { if (shared) MOQ_IQ_GO(false, true, true); else MOQ_IQ_GO(false, true, false); }
-  else if (amax) MOQ_IQ_GO(true, false, false);
-  else MOQ_IQ_GO(false, false, false);
+  if constexpr (DT != MOQ_F32) {
+    if (hist && pat) {
+      if (amax) { if (shared) MOQ_IQ_GO(true, true, true, true); else MOQ_IQ_GO(true, true, false, true); }
+      else { if (shared) MOQ_IQ_GO(false, true, true, true); else MOQ_IQ_GO(false, true, false, true); }
+      return;
+    }
+  }
+  if (amax && hist) { if (shared) MOQ_IQ_GO(true, true, true, false); else MOQ_IQ_GO(true, true, false, false); }
+  else if (hist) { if (shared) MOQ_IQ_GO(false, true, true, false); else MOQ_IQ_GO(false, true, false, false); }
+  else if (amax) MOQ_IQ_GO(true, false, false, false);
+  else MOQ_IQ_GO(false, false, false, false);
 #undef MOQ_IQ_GO
 }
 
@@ -310,17 +407,21 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
   p.qdq_amax = qdq_amax; p.num_bits = num_bits; p.is_unsigned = is_unsigned; p.narrow = narrow_range;
   p.counts = hist_counts; p.bins = hist_bins > 0 ? hist_bins : 1; p.max_edge = hist_max_edge;
   p.skip_zeros = hist_skip_zeros; p.rshift = 0;
+  p.dbg = (int)moq_tune("MOQ_TUNE_IQ_DBG", 0);
   size_t lds = 0;
-  bool shared = false;
+  bool shared = false, pat = false;
   int64_t blocks = ((n + MOQ_MT_CHUNK - 1) / MOQ_MT_CHUNK + 3) / 4;
   if (blocks > 512) blocks = 512;
   if (hist_counts != nullptr) {
     // interleaved copies of the histogram (hot bins spread over banks) as far as LDS allows; the table of a 16-bit
     // input takes 64 KiB, which leaves room for one workgroup per CU
+    // 16-bit inputs whose bins fit beside 128 KiB of pattern counters: count patterns, bin them at the flush (PAT)
+    const size_t pat_lds = (((size_t)kPatSlots + (size_t)hist_bins + 1 + 3) / 4) * 16;
+    pat = dt != MOQ_F32 && pat_lds <= kIqLdsBudget && moq_tune("MOQ_TUNE_HIST_PAT", 1) != 0;
     const size_t table = dt == MOQ_F32 ? 0 : (size_t)kLutEntries * 2;
     const size_t room = (table ? kIqLdsBudget : (size_t)72 * 1024 + 32) - table - (size_t)kHotSlots * 4;
     while (p.rshift < 3 && ((size_t)(hist_bins + 1) << (p.rshift + 1)) * 4 <= room) ++p.rshift;
-    lds = ((size_t)kHotSlots + ((size_t)(hist_bins + 1) << p.rshift)) * 4 + table;
+    lds = pat ? pat_lds : ((size_t)kHotSlots + ((size_t)(hist_bins + 1) << p.rshift)) * 4 + table;
     if (lds > kIqLdsBudget) {
       set_error("moq_input_quant: %d bins do not fit the LDS histogram", hist_bins);
       return MOQ_ERR_UNSUPPORTED;
@@ -331,9 +432,9 @@ extern "C" int moq_input_quant(const void* x, const float* pre_quant_scale, void
   const bool amax = amax_running != nullptr, hist = hist_counts != nullptr;
 #define MOQ_IQ_FMT(F)                                                                                         \
   if (pre_quant_scale != nullptr) {                                                                           \
-    MOQ_DISPATCH_DTYPE(dt, (launch_iq<DT, F, true>(p, amax, hist, shared, (int)blocks, lds, stream)));        \
+    MOQ_DISPATCH_DTYPE(dt, (launch_iq<DT, F, true>(p, amax, hist, shared, pat, (int)blocks, lds, stream)));        \
   } else {                                                                                                    \
-    MOQ_DISPATCH_DTYPE(dt, (launch_iq<DT, F, false>(p, amax, hist, shared, (int)blocks, lds, stream)));       \
+    MOQ_DISPATCH_DTYPE(dt, (launch_iq<DT, F, false>(p, amax, hist, shared, pat, (int)blocks, lds, stream)));       \
   }
   if (fmt == 0) { MOQ_IQ_FMT(0) } else if (fmt == 1) { MOQ_IQ_FMT(1) } else { MOQ_IQ_FMT(2) }
 #undef MOQ_IQ_FMT

@@ -113,6 +113,45 @@ def test_histogram_hot_bins_and_tails():
                     assert np.array_equal(tab.cpu().numpy(), want), f"table kernel: {name} {dtype} bins={bins}"
 
 
+def test_histogram_pattern_counters_and_table_give_the_same_counts():
+    """Round 6: 16-bit inputs whose bins fit beside 128 KiB of LDS pattern counters are counted per |x| PATTERN and binned
+    at the flush (bins <= 7039); more bins take the round-2 pattern TABLE.  Both sides of the switch, zero-heavy data (zeros
+    have a counter per lane), a view that starts off a 16-byte boundary, a ragged end, and the pre_quant_scale stage in
+    front (the patterns counted are those of dtype(x * s))."""
+    g = torch.Generator().manual_seed(11)
+    n = 8192 * 24 + 8 * 5 + 3
+    base = torch.randn(n + 8, generator=g) * torch.exp(torch.randn(n + 8, generator=g))
+    relu = torch.relu(base)
+    relu[::7] = -0.0
+    for dtype in (torch.bfloat16, torch.float16):
+        for name, x in (("gauss", base), ("relu", relu)):
+            xv = x.to(dtype)
+            edge = float(xv.float().abs().max())
+            for off in (0, 1, 3):
+                xs = xv[off:off + n]
+                for bins, skip in [(7039, False), (7040, False), (2048, True), (4095, False), (3, True)]:
+                    want = oracle.hist_abs(xs, bins, edge * 0.9, skip).astype(np.int64)
+                    tab = torch.zeros(bins, dtype=torch.int64, device=DEV)
+                    ops.input_quant(xs.to(DEV) if off == 0 else xv.to(DEV)[off:off + n], None, hist_counts=tab,
+                                    hist_max_edge=edge * 0.9, hist_skip_zeros=skip)
+                    assert np.array_equal(tab.cpu().numpy(), want), f"{name} {dtype} off={off} bins={bins} skip={skip}"
+    # pre_quant_scale in front of the histogram and the running abs-max (2-D: one scale per column)
+    rows, cols = 96 * 3 + 1, 1024
+    x = (torch.randn(rows, cols, generator=g) * 0.5).to(torch.bfloat16)
+    s = (torch.rand(cols, generator=g) * 4).to(torch.bfloat16)
+    s[::17] = 0.0
+    v = (x.float() * s.float()).to(torch.bfloat16)
+    edge = float(v.float().abs().max())
+    for bins in (2048, 7040):
+        want = oracle.hist_abs(v.reshape(-1), bins, edge, False).astype(np.int64)
+        tab = torch.zeros(bins, dtype=torch.int64, device=DEV)
+        amax = torch.zeros(1, dtype=torch.float32, device=DEV)
+        out = ops.input_quant(x.to(DEV), s.to(DEV), amax_running=amax, hist_counts=tab, hist_max_edge=edge)
+        assert np.array_equal(tab.cpu().numpy(), want)
+        assert float(amax) == edge
+        assert_bits_equal(out, v, "scaled activation")
+
+
 def test_histogram_table_dispatch_at_flow_size():
     """13 M elements (26 MB, above moq_hist_abs' 12 M threshold): the pattern-table kernel through moq_hist_abs itself."""
     g = torch.Generator().manual_seed(3)
