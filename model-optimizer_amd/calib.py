@@ -608,6 +608,10 @@ def _compute_amax_entropy(calib_hist, calib_bin_edges, num_bits, unsigned, strid
     return torch.tensor(calib_bin_edges[last_argmin * stride + start_bin].item())
 
 
+_MSE_SEARCH_CHUNK = 1 << 24    # elements of one [candidates, bins] pass of the histogram MSE search (64 MB fp32 per temporary)
+_MSE_SEARCH_BUDGET = 1 << 30   # candidate x bin products evaluated exhaustively (~10 s of host time)
+
+
 def _compute_amax_mse(counts, edges, num_bits, unsigned, stride=1, start_bin=128):
     """calib/histogram.py:286-323 AS IT COMPUTES, for integer formats: the amax the reference returns for
     `compute_amax("mse")`, bit for bit (pinned by the reference-run `hist` fixture and the live differential test).
@@ -648,11 +652,49 @@ def _compute_amax_mse(counts, edges, num_bits, unsigned, stride=1, start_bin=128
     bound = torch.tensor((2.0 ** (slot_bits - 1)) - 1.0)     # max_bound; `unsigned` itself keeps its default False
     scale = bound / amax
     tiny = amax <= 1.0 / (1 << 24)
-    x = centers.reshape(1, -1) - num_bits                    # `inputs - bias`
-    y = torch.clamp((x * torch.where(tiny, torch.zeros_like(scale), scale).reshape(-1, 1)).round_(), -bound, bound)
-    q = y / torch.where(tiny, torch.ones_like(scale), scale).reshape(-1, 1) + num_bits
-    mse = ((q - centers.reshape(1, -1)) ** 2 * c.reshape(1, -1)).mean(dim=1)
-    pick = int(np.argmin(mse.numpy()))                       # first minimum; the first NaN when there is one
+    mul = torch.where(tiny, torch.zeros_like(scale), scale).reshape(-1, 1)
+    div = torch.where(tiny, torch.ones_like(scale), scale).reshape(-1, 1)
+    cen, cnt = centers.reshape(1, -1), c.reshape(1, -1)
+
+    def exact(lo, hi):  # the reference's arithmetic for candidates [lo, hi): one [hi - lo, bins] pass
+        x = cen - num_bits                                   # `inputs - bias`
+        y = torch.clamp((x * mul[lo:hi]).round_(), -bound, bound)
+        q = y / div[lo:hi] + num_bits
+        return ((q - cen) ** 2 * cnt).mean(dim=1)
+
+    # Memory and time are bounded however far the histogram grew (a calibrator whose range grew 800-fold holds 8e5 bins: the
+    # one-pass form asked the host for candidates x bins = 2.7 TB and took the machine down -- found by tools/calib_fuzz.py,
+    # seed 6 case 27).  Up to _MSE_SEARCH_BUDGET candidate x bin products: every candidate in chunks, exactly.
+    n_cand = idx.numel()
+    rows = max(1, _MSE_SEARCH_CHUNK // n_bins)
+    if n_cand * n_bins <= _MSE_SEARCH_BUDGET:
+        mse = torch.cat([exact(lo, min(lo + rows, n_cand)) for lo in range(0, n_cand, rows)])
+        pick = int(np.argmin(mse.numpy()))                   # first minimum; the first NaN when there is one
+        return centers[idx[pick]].clone().to(dev)
+    # Beyond the budget (the reference's own loop needs minutes on a GPU and hours on a host there): the clamp bounds are
+    # inverted or zero (above), so a candidate's "quantized centres" are ONE value q_c whatever the centre, and its error is
+    # the parabola (A q^2 - 2 B q + C) / bins in q_c with A, B, C the count-weighted moments of the centres.  The parabola
+    # (float64) screens; the candidates within 1e-4 of its minimum -- far beyond the fp32 noise of the sums -- are evaluated
+    # with the reference's arithmetic, and the first minimum of those is taken.  NaN rules as np.argmin's: the first NaN wins.
+    q_c = (torch.clamp(((cen[:, :1] - num_bits) * mul).round_(), -bound, bound) / div + num_bits).reshape(-1).double()
+    has_empty_bin = bool((c == 0).any())
+    nan_like = torch.isnan(q_c) | (torch.isinf(q_c) if has_empty_bin else torch.zeros_like(q_c, dtype=torch.bool))
+    if bool(nan_like.any()):
+        return centers[idx[int(nan_like.to(torch.int8).argmax())]].clone().to(dev)
+    c64, cen64 = c.double(), centers.double()
+    a_, b_, c_ = c64.sum(), (c64 * cen64).sum(), (c64 * cen64 * cen64).sum()
+    par = (a_ * q_c * q_c - 2.0 * b_ * q_c + c_) / n_bins
+    par = torch.where(torch.isfinite(par), par, torch.full_like(par, float("inf")))
+    best = float(par.min())
+    near = (par <= best + abs(best) * 1e-4 + 1e-300).nonzero().reshape(-1)
+    lo, hi = int(near.min()), int(near.max()) + 1
+    cap = max(1, _MSE_SEARCH_BUDGET // n_bins)
+    if hi - lo > cap:  # (a flat vertex wider than the budget: centre the window on the parabola's minimum)
+        mid = int(par.argmin())
+        lo = max(0, min(mid - cap // 2, n_cand - cap))
+        hi = min(n_cand, lo + cap)
+    mse = torch.cat([exact(a, min(a + rows, hi)) for a in range(lo, hi, rows)])
+    pick = lo + int(np.argmin(mse.numpy()))
     return centers[idx[pick]].clone().to(dev)
 
 
@@ -764,11 +806,20 @@ class MseCalibrator(_Calibrator):
         dtype), formed as one broadcast fp32 product on the tensor's device and rounded to that dtype once -- instead of K host products,
         K device->host reads of the multiplier and K uploads per collect (a static-block weight has ~460 K amax entries:
         65 ms per quantizer; an input quantizer paid the 39 synchronisations on every batch)."""
+        from . import numerics
+
         if self._cand_table is None or self._cand_table.device != device:
+            a = self._initial_amax.detach().to(device)
+            if not numerics.on_host():
+                # numerics "device": the reference's run on THIS device -- its own expression, candidate by candidate (a GPU
+                # casts the 0-dim multiplier to a 16-bit amax's dtype BEFORE the product, and its linspace is the device's);
+                # K small launches, once per calibrator
+                mult = self._generate_candidates(device)
+                self._cand_table = torch.stack([(a * m).float().reshape(-1) for m in mult.unbind(0)])
+                return self._cand_table
             # the multipliers come from the HOST linspace (torch's CPU and GPU linspace differ in the last ulp); the product
             # itself is one IEEE fp32 multiply and one round-to-nearest-even conversion per entry -- the same on any device
             mult = torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps)  # as _generate_candidates
-            a = self._initial_amax.detach().to(device)
             # dtype of `amax * 0-dim fp32 multiplier`: the amax dtype for a dimensioned amax, fp32 for a 0-dim one
             out_dt = torch.result_type(a, mult[0])
             self._cand_table = (a.float().reshape(1, -1) * mult.to(device).reshape(-1, 1)).to(out_dt).float()
@@ -778,6 +829,11 @@ class MseCalibrator(_Calibrator):
         # calib/mse.py:69-73.  The multipliers are generated on the host and copied: torch's CPU and GPU linspace
         # differ in the last ulp for some steps, which moves bf16 / f16 candidate amax values by one ulp; the host
         # values are the ones the (CPU-run) reference fixtures are pinned to, and they are device independent.
+        # (numerics "device": the reference's own call, on the device -- its run there)
+        from . import numerics
+
+        if not numerics.on_host():
+            return torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps, device=device)
         return torch.linspace(self._start_multiplier, self._stop_multiplier, steps=self._num_steps).to(device)
 
     def _compute_candidate_amax(self, candidates):

@@ -242,6 +242,34 @@ def test_this_package_on_the_device_equals_the_reference_eager_run_on_the_device
          f"{len(ref_state)} checkpoint tensors byte-identical")
 
 
+@pytest.mark.parametrize("preset,dtype,arch", [("INT8_DEFAULT_CFG", torch.bfloat16, "llama"), ("INT8_DEFAULT_CFG", torch.float16, "opt"),
+                                               ("FP8_DEFAULT_CFG", torch.bfloat16, "llama"),
+                                               ("INT4_BLOCKWISE_WEIGHT_ONLY_CFG", torch.bfloat16, "llama"),
+                                               ("INT8_DEFAULT_CFG", torch.float32, "llama")])
+def test_mse_calibration_on_the_device_equals_the_reference_eager_run_on_the_device(ref, preset, dtype, arch):
+    """algorithm "mse" (calib/mse.py:83-121, model_calib.py:732-826), both sides on cuda:0.  The candidate amax values are
+    `initial_amax * multiplier` with a 0-dim fp32 multiplier: for a 16-bit amax a GPU casts the multiplier to that dtype BEFORE
+    the product (a CPU multiplies in fp32 and rounds once), and the device's linspace differs from the host's in the last
+    ulp -- the candidate grid of the reference's GPU run is not that of its CPU run.  A candidate amax one 16-bit step away
+    moves a 72-element row's loss by 2-30 % (tools/diag/mse_device_diff.py: 23 of 384 channels of a flow_fuzz case picked
+    another candidate before the fused candidate table followed the numerics mode).  Every picked amax, the logits and every
+    checkpoint byte must equal the reference's run on this device."""
+    ref_amax, ref_state = diff._reference_run(preset, dtype, False, arch, "mse", device=DEV)
+    with moa.numerics.scale_math("device"):
+        our_amax, our_state = diff._our_run(preset, dtype, False, arch, "mse", device=DEV)
+    bad = [n for n, a in ref_amax.items() if n not in our_amax or not torch.equal(our_amax[n].reshape(-1), a.reshape(-1))]
+    assert not bad, f"{preset} mse: {len(bad)} of {len(ref_amax)} amax differ, first {bad[:4]}"
+    ref_state.pop("__quant_json__", None), our_state.pop("__quant_json__", None)
+    assert torch.equal(our_state.pop("__logits__"), ref_state.pop("__logits__")), f"{preset} mse: logits differ"
+    assert sorted(our_state) == sorted(ref_state)
+    for k, want in ref_state.items():
+        got = our_state[k].detach().cpu()
+        assert got.dtype == want.dtype and torch.equal(got.contiguous().reshape(-1).view(torch.uint8),
+                                                       want.contiguous().reshape(-1).view(torch.uint8)), f"{preset} mse: {k} differs"
+    note(f"mse calibration, this package vs reference eager, both on the device, {preset} {arch} {str(dtype)[6:]}: "
+         f"{len(ref_amax)} amax, logits, {len(ref_state)} checkpoint tensors byte-identical")
+
+
 @pytest.mark.parametrize("arch,dtype", [("llama", torch.bfloat16), ("qwen2", torch.bfloat16), ("opt", torch.float16)])
 def test_int4_awq_on_the_device_against_the_reference_eager_search(ref, arch, dtype):
     """INT4-AWQ end to end.  The reference scores its 11 candidates per linear with the library's GEMM, this package with its
@@ -505,7 +533,7 @@ def test_random_calls_of_the_paths_functions_equal_the_references_eager_function
 # export_hf_checkpoint on device tensors.  What runs underneath is this package's fused flow (multi-tensor weight pass, one
 # statistics launch per decoder layer, Gram screen + MFMA error GEMM, fused packers) on the REFERENCE's model objects; what
 # the reference holds and exports afterwards must equal its own eager run on the same device, under section B's tolerances.
-def _quantize_then_export(mtq, preset, dtype, with_kv, arch, stats_after_quantize=None):
+def _quantize_then_export(mtq, preset, dtype, with_kv, arch, stats_after_quantize=None, algorithm=None):
     """diff._reference_run on the device, with the seam counters read right after mtq.quantize returns (the logits forward
     and the export after it go through the kernel seams too, and are not the search)."""
     import tempfile
@@ -515,6 +543,8 @@ def _quantize_then_export(mtq, preset, dtype, with_kv, arch, stats_after_quantiz
 
     model = diff._model(dtype, arch).to(DEV)
     cfg = copy.deepcopy(getattr(mtq, preset))
+    if algorithm is not None:
+        cfg["algorithm"] = copy.deepcopy(algorithm)
     if with_kv:
         cfg = mtq.update_quant_cfg_with_kv_cache_quant(cfg, copy.deepcopy(mtq.FP8_KV_CFG["quant_cfg"]))
     batches = [b.to(DEV) for b in diff._batches()]
@@ -567,6 +597,30 @@ def test_reference_quantize_and_export_through_the_algorithm_seam_on_the_device(
          f"tensors + logits + hf_quant_config.json == its eager run; calibration served by {entry} with "
          f"{sum(v for k, v in seen.items() if k.startswith('S1:') or k.startswith('S6:'))} per-tensor kernel-seam calls inside it; "
          f"export packers {packers}")
+
+
+@pytest.mark.parametrize("preset,dtype,arch", [("INT8_DEFAULT_CFG", torch.bfloat16, "llama"), ("FP8_DEFAULT_CFG", torch.float16, "llama")])
+def test_reference_mse_calibration_through_the_algorithm_seam_on_the_device(ref, preset, dtype, arch):
+    """The reference's own `mtq.quantize(..., algorithm "mse")` with S7 installed == its eager run on the device (state, logits,
+    checkpoint, JSON): the fused 39-candidate sweep evaluates the candidate grid of the reference's run on THIS device."""
+    base_state, base_logits = _quantize_then_export(ref, preset, dtype, False, arch, algorithm="mse")
+    seen = {}
+    with installed(algorithms=True) as (plugin, got):
+        our_state, our_logits = _quantize_then_export(ref, preset, dtype, False, arch, lambda: seen.update(plugin.STATS), algorithm="mse")
+        total = dict(plugin.STATS)
+    assert seen.get("S7:mse_calibrate", 0) >= 1, seen
+    assert not [k for k in total if "fallback" in k], total
+    assert sorted(base_state) == sorted(our_state)
+    for k, want in base_state.items():
+        got_t = our_state[k]
+        if k == "__json__":
+            assert got_t == want
+            continue
+        assert got_t.dtype == want.dtype and torch.equal(got_t.contiguous().reshape(-1).view(torch.uint8),
+                                                         want.contiguous().reshape(-1).view(torch.uint8)), f"{preset} mse: {k} differs"
+    assert torch.equal(base_logits, our_logits)
+    note(f"reference mse calibration through the ALGORITHM seam on the device, {preset} {arch} {str(dtype)[6:]}: "
+         f"{len(base_state) - 1} state / checkpoint tensors + logits == its eager run")
 
 
 @pytest.mark.parametrize("preset,arch,dtype", [("INT4_AWQ_CFG", "llama", torch.bfloat16), ("INT4_AWQ_CFG", "qwen2", torch.bfloat16),

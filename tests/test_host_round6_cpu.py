@@ -268,3 +268,35 @@ def test_the_automatic_activation_store_stops_at_its_cap_and_the_search_is_a_rea
     assert sorted(roomy) == sorted(tight)
     for n in roomy:
         assert roomy[n][0] == tight[n][0] and torch.equal(roomy[n][1], tight[n][1]), n
+
+
+def test_histogram_mse_threshold_search_is_bounded_however_far_the_histogram_grew(monkeypatch):
+    """`HistogramCalibrator.compute_amax("mse")` on integer formats evaluates the reference's loop (calib/histogram.py:286-323)
+    as [candidates, bins] passes.  A calibrator whose range grew 800-fold holds ~8e5 bins: the one-pass form asked the host for
+    2.7 TB and took a GPU box down (tools/calib_fuzz.py, seed 6 case 27).  Now: chunks of 2^24 elements, every candidate up to
+    2^30 candidate x bin products, beyond that the candidates within 1e-4 of the float64 parabola's minimum -- and that
+    screened form picks what the exhaustive one picks."""
+    from model_optimizer_amd import calib
+
+    g = torch.Generator().manual_seed(5)
+    for bins, unsigned, num_bits in [(700, False, 8), (5000, False, 4), (5000, True, 8), (2048, False, 8)]:
+        x = torch.randn(100000, generator=g).abs() * 3
+        top = float(x.max())
+        edges = torch.linspace(0, top, bins + 1)
+        counts = torch.histc(x, bins=bins, min=0, max=top).to(torch.int64)
+        counts[::5] = 0
+        monkeypatch.setattr(calib, "_MSE_SEARCH_BUDGET", 1 << 40)
+        monkeypatch.setattr(calib, "_MSE_SEARCH_CHUNK", 1 << 40)
+        one_pass = calib._compute_amax_mse(counts, edges, num_bits, unsigned)           # the former form: everything at once
+        monkeypatch.setattr(calib, "_MSE_SEARCH_CHUNK", 1 << 14)
+        chunked = calib._compute_amax_mse(counts, edges, num_bits, unsigned)
+        monkeypatch.setattr(calib, "_MSE_SEARCH_BUDGET", 1 << 16)
+        screened = calib._compute_amax_mse(counts, edges, num_bits, unsigned)
+        assert torch.equal(one_pass, chunked) and torch.equal(one_pass, screened), (bins, unsigned, num_bits)
+    # a grown histogram: 3e5 bins = 9e10 products -- seconds and a bounded footprint, not 360 GB
+    monkeypatch.undo()
+    bins = 300000
+    x = torch.cat([torch.randn(20000, generator=g).abs() * 0.05, torch.randn(20000, generator=g).abs() * 40])
+    top = float(x.max())
+    amax = calib._compute_amax_mse(torch.histc(x, bins=bins, min=0, max=top).to(torch.int64), torch.linspace(0, top, bins + 1), 8, False)
+    assert 0 < float(amax) <= top

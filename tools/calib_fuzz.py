@@ -46,6 +46,18 @@ METHODS = ["percentile", "percentile", "percentile", "entropy", "mse"]
 
 
 def hist_case(rng):
+    case = _hist_case(rng)
+    # a later batch 800 x the first grows the histogram to ~8e5 bins: the REFERENCE's threshold searches are loops over every
+    # bin (minutes on a GPU, hours on a host), and round 6's first run of such a case (seed 6, case 27) took a GPU box down
+    # through this package's then-unbounded one-pass form of the same search -- the growth is capped at 10 x here; the bounded
+    # search has its own test (tests/test_host_round6_cpu.py)
+    first = case["batches"][0]["scale"]
+    for b in case["batches"][1:]:
+        b["scale"] = min(b["scale"], first * 10.0)
+    return case
+
+
+def _hist_case(rng):
     return {"dtype": rng.choice(list(DT)), "bins": rng.choice([256, 1024, 2048]), "skip_zeros": rng.random() < 0.3,
             "unsigned": rng.random() < 0.2, "num_bits": rng.choice([8, 4]),
             "batches": [{"shape": [rng.randint(1, 64), rng.choice([64, 256, 1000, 4096])], "scale": rng.choice([0.05, 1.0, 3.0, 40.0]),

@@ -111,7 +111,11 @@ def main(n=60, seed=2025, verbose=True):
         except Exception as e:
             want = e
         try:
-            got = run(moa.quantize, moa.model_quant, "TensorQuantizer", case)
+            if DEV == "cpu":
+                got = run(moa.quantize, moa.model_quant, "TensorQuantizer", case)
+            else:
+                with moa.numerics.scale_math("device"):  # device vs device: the reference ran on this GPU too
+                    got = run(moa.quantize, moa.model_quant, "TensorQuantizer", case)
         except Exception as e:
             got = e
         if isinstance(want, Exception):
