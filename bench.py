@@ -301,11 +301,19 @@ def awq_cold_subprocess(args, dev):
 
     torch.cuda.synchronize()
     gc.collect()  # (the flows' modules and closures refer to each other: without this their tensors pin the 160 GiB segment the
+    reserved_before = torch.cuda.memory_reserved(dev)
     torch.cuda.empty_cache()  # warm run parked in torch's cache, and the child finds 120 GB free instead of 290)
+    handed_back = max(0, reserved_before - torch.cuda.memory_reserved(dev))
     t_w, probes = time.perf_counter(), 0
-    while time.perf_counter() - t_w < 30.0:  # until a 32 GiB hipMalloc is prompt again (bounded)
+    # The driver wipes what was just handed back in the background (~25 GB/s, tools/alloc_wipe_probe.py) and an allocation that
+    # meets unwiped VRAM stalls for seconds.  Rounds 5-6 probed with 32 GiB allocations until one was prompt -- but the child
+    # takes ~80 GB, a prompt 32 GiB only says 32 GiB of clean pages exist, and the probe's own free is wiped again: one lease
+    # in five still put a 4 s stall into the child's first batch (profiles/r06g_*: linear 91, 4.15 s).  So: wait out the wipe of
+    # what this process handed back (at 20 GB/s, bounded), then confirm with ONE small allocation.
+    time.sleep(min(30.0, handed_back / 20e9 + 1.0))
+    while time.perf_counter() - t_w < 45.0:
         t = time.perf_counter()
-        block = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
+        block = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         took = time.perf_counter() - t
         del block
@@ -328,7 +336,7 @@ def awq_cold_subprocess(args, dev):
     if r.returncode != 0:
         return {"failed": f"rc {r.returncode}: {r.stderr[-300:]}", "child_wall_s": wall}
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    return dict(line["cold"], child_wall_s=wall, wipe_wait_s=wipe_wait, wipe_probes=probes, **held, passes=line.get("passes"),
+    return dict(line["cold"], child_wall_s=wall, wipe_wait_s=wipe_wait, wipe_probes=probes, handed_back_GB=round(handed_back / 1e9, 1), **held, passes=line.get("passes"),
                 store_dropped=line.get("store_dropped"), stored_input_bytes=line.get("stored_input_bytes"),
                 stages_s=line.get("stages_s"), forward_loop_calls=line.get("forward_loop_calls"),
                 what="a fresh process: import, build the stack and 64 batches, ONE quantize(); no warm forward, no rehearsal, "
