@@ -138,6 +138,7 @@ def main(n=60, seed=2025, verbose=True):
             clip = isinstance(case["algorithm"], dict) and case["algorithm"].get("method") == "awq_clip"
             tol = 2e-2 if clip else (2e-6 if case["dtype"] == "float32" else 2.0 ** -7)
             bad = [] if (clip or ga == wa) else [f"<alphas differ: {ga} vs {wa}>"]
+            clip_far = []
             for k in ws:
                 a, b = gs[k].float(), ws[k].float()
                 if a.shape != b.shape or gs[k].dtype != ws[k].dtype:
@@ -145,22 +146,29 @@ def main(n=60, seed=2025, verbose=True):
                 elif k == "__output__":
                     continue
                 elif clip:
-                    # a block's clip ratio is picked from a 5 % grid by a loss whose GEMM sums in another order: a block may
-                    # take the neighbouring ratio (tests/test_gpu_clip.py states the bound); most must agree closely
+                    # a block's clip ratio is picked from a 5 % grid by a loss that is mostly the reference's own rounding noise
+                    # (every product and block sum rounded to the model dtype before `cur - org`): a block
+                    # may take another ratio.  Stated bound (tests/test_gpu_clip.py): >= 85 % identical picks; a case inside
+                    # that bound but with a pick more than two grid steps away is counted apart, not as equal
                     rel = (a - b).abs() / b.abs().clamp_min(1e-30)
-                    if float((rel <= 1e-2).float().mean()) < 0.9 or float(rel.max()) > 0.12:
+                    same = float((a == b).float().mean())
+                    if same < 0.85:
                         bad.append(k)
+                    elif float((rel <= 1e-2).float().mean()) < 0.9 or float(rel.max()) > 0.12:
+                        clip_far.append(k)
                 elif not torch.allclose(a, b, rtol=tol, atol=tol * float(b.abs().max())):
                     bad.append(k)
         else:
             bad = [k for k in ws if k not in gs or not same_bits(gs[k], ws[k])] if keys_equal else ["<key sets differ>"] + sorted(set(gs) ^ set(ws))[:6]
-        if not bad:
+        if not bad and searched and keys_equal and clip_far:
+            st.setdefault("awq_clip_within_the_stated_bound", []).append({"case": case, "first": clip_far[:4]})
+        elif not bad:
             st["equal"] += 1
         else:
             st["different"].append({"case": case, "first": bad[:4], "n_bad": len(bad), "n_keys": len(ws)})
     if verbose:
         print("flows", json.dumps({k: (v if not isinstance(v, list) else len(v)) for k, v in st.items()})[:600])
-        for d in st["different"][:10] + st["ours_refused"][:10]:
+        for d in st["different"][:10] + st["ours_refused"][:10] + st.get("awq_clip_within_the_stated_bound", [])[:4]:
             print("   ", json.dumps(d)[:600])
     return {"flows": st}
 
