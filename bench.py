@@ -828,6 +828,27 @@ def main():
         # release the main workload's tensors: the extras below bring their own
         del tab, weights, masks
         pool.release()
+    if not args.no_extra and world == 1:
+        # north_star's "histogram collection": |x| histogram (2048 bins, range = the tensor's abs-max) of a calibration-sized
+        # activation [131072 tokens, 8192] bf16 = 2.1 GB with per-channel spread and four massive channels -- 2 B/element;
+        # round 6: LDS counters per |x| pattern, binned once per pattern at the flush (profiles/r06e_hist_pattern_counters.md
+        # has the kernel-only durations at the 67 MB a forward presents per batch, where a Python event pair times the host)
+        try:
+            gh = torch.Generator(device=dev).manual_seed(7)
+            chan = torch.exp(torch.randn(8192, generator=gh, device=dev))
+            chan[:4] *= 50.0
+            xh = (torch.randn(131072, 8192, generator=gh, device=dev) * chan).to(torch.bfloat16)
+            edge = float(xh.float().abs().max())
+            counts = torch.zeros(2048, dtype=torch.int64, device=dev)
+            ms = timed(lambda: moa.ops.hist_abs(xh, 2048, edge, counts=counts), reps=10)
+            ok = int(counts.sum()) == 11 * xh.numel()
+            extra["hist_abs_2048bins"] = {"ms": round(ms, 4), "activation_GB": round(xh.numel() * 2 / 1e9, 2),
+                                          "hbm_GBs": round(xh.numel() * 2 / ms / 1e6, 1),
+                                          "frac_of_8TBs": round(xh.numel() * 2 / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                          "every_element_counted": ok}
+            del xh, counts, chan
+        except Exception as e:  # a reported extra, never a reason to lose the main result
+            extra["hist_abs_2048bins"] = {"failed": f"{type(e).__name__}: {e}"}
     if not args.no_extra and use_dist and not weak and wl != "mxfp4-sq":
         # the WEAK leg of a multi-GPU run (every rank holds the whole model; not a BASELINE configuration)
         try:
